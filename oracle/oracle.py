@@ -1,0 +1,432 @@
+"""
+oracle.py — CPU (numpy + C) restatement of Breeze.jl's anelastic SSP-RK3 step.
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by the product package (breeze.jl_amd/).
+
+PARITY STATUS: "parity unpinned" for the WENO reconstruction arithmetic and the
+Oceananigans pieces (see breeze_oracle.c header).  Pinned parts: thermodynamic
+constants / reference columns / Poisson solve / projection / conservation via the
+reference's own known-answer tests restated in tests/.
+
+Reference call stack restated here (file:line relative to /root/reference):
+  time_step!            src/TimeSteppers/ssp_runge_kutta_3.jl:209-278
+  ssp_rk3_substep!      src/TimeSteppers/ssp_runge_kutta_3.jl:114-173
+  compute_pressure_correction! / make_pressure_correction!
+                        src/AnelasticEquations/anelastic_time_stepping.jl:26-78
+  solve_for_anelastic_pressure!
+                        src/AnelasticEquations/anelastic_pressure_solver.jl:84-105
+  update_state!         src/AtmosphereModels/update_atmosphere_model_state.jl:41-68
+  compute_tendencies!   src/AtmosphereModels/update_atmosphere_model_state.jl:294-387
+  set!                  src/AtmosphereModels/set_atmosphere_model.jl:198-362
+  ReferenceState        src/Thermodynamics/reference_states.jl:402-445
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbreeze_oracle.so")
+
+PERIODIC, BOUNDED, FLAT = 0, 1, 2
+_TOPO = {"Periodic": PERIODIC, "Bounded": BOUNDED, "Flat": FLAT,
+         PERIODIC: PERIODIC, BOUNDED: BOUNDED, FLAT: FLAT}
+
+
+def build(force=False):
+    """Compile the C oracle with gcc (recipe: oracle/Makefile)."""
+    src = os.path.join(_HERE, "breeze_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_dp = C.POINTER(C.c_double)
+
+
+class _OGGrid(C.Structure):
+    _fields_ = [("Nx", C.c_int), ("Ny", C.c_int), ("Nz", C.c_int),
+                ("Hx", C.c_int), ("Hy", C.c_int), ("Hz", C.c_int),
+                ("tx", C.c_int), ("ty", C.c_int), ("tz", C.c_int),
+                ("dx", C.c_double), ("dy", C.c_double),
+                ("dzc", _dp), ("dzf", _dp),
+                ("rho_r", _dp), ("p_r", _dp), ("T_r", _dp),
+                ("g", C.c_double), ("Rd", C.c_double), ("Rv", C.c_double),
+                ("cpd", C.c_double), ("cpv", C.c_double), ("p_st", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.og_weno5.restype = C.c_double
+        _lib.og_weno5.argtypes = [C.c_double] * 5
+        _lib.og_weno3.restype = C.c_double
+        _lib.og_weno3.argtypes = [C.c_double] * 3
+        _lib.og_buffer_at.restype = C.c_int
+        _lib.og_buffer_at.argtypes = [C.c_int] * 4
+    return _lib
+
+
+def _p(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+# ---------------------------------------------------------------------------
+# Thermodynamic constants (src/Thermodynamics/thermodynamics_constants.jl:182-212)
+# ---------------------------------------------------------------------------
+class Constants:
+    def __init__(self, molar_gas_constant=8.314462618, gravitational_acceleration=9.81,
+                 dry_air_molar_mass=0.02897, dry_air_heat_capacity=1005.0,
+                 vapor_molar_mass=0.018015, vapor_heat_capacity=1850.0):
+        self.R = molar_gas_constant
+        self.g = gravitational_acceleration
+        self.Md, self.cpd = dry_air_molar_mass, float(dry_air_heat_capacity)
+        self.Mv, self.cpv = vapor_molar_mass, float(vapor_heat_capacity)
+        self.Rd = self.R / self.Md     # dry_air_gas_constant  (:215)
+        self.Rv = self.R / self.Mv     # vapor_gas_constant    (:214)
+
+
+# Closed-form adiabatic hydrostatic reference profiles (reference_states.jl:84-123,326-330)
+def surface_density(p0, theta0, pst, c):
+    Pi0 = (p0 / pst) ** (c.Rd / c.cpd)
+    T0 = Pi0 * theta0
+    return p0 / (c.Rd * T0)
+
+
+def adiabatic_hydrostatic_pressure(z, p0, theta0, pst, c):
+    T0 = theta0 * (p0 / pst) ** (c.Rd / c.cpd)
+    return p0 * (1 - c.g * z / (c.cpd * T0)) ** (c.cpd / c.Rd)
+
+
+def adiabatic_hydrostatic_density(z, p0, theta0, pst, c):
+    pr = adiabatic_hydrostatic_pressure(z, p0, theta0, pst, c)
+    rho0 = surface_density(p0, theta0, pst, c)
+    return rho0 * (pr / p0) ** (1 - c.Rd / c.cpd)
+
+
+def hydrostatic_temperature(z, p0, theta0, pst, c):
+    kappa = c.Rd / c.cpd
+    p = adiabatic_hydrostatic_pressure(z, p0, theta0, pst, c)
+    return theta0 * (p / pst) ** kappa
+
+
+# ---------------------------------------------------------------------------
+# Grid (Oceananigans RectilinearGrid, regular in x,y; regular or stretched z)
+# ---------------------------------------------------------------------------
+class Grid:
+    def __init__(self, size, x=None, y=None, z=None, topology=("Periodic", "Periodic", "Bounded"),
+                 halo=None):
+        topo = tuple(_TOPO[t] for t in topology)
+        self.topo = topo
+        size = (size,) if np.isscalar(size) else tuple(size)
+        nonflat = [d for d in range(3) if topo[d] != FLAT]
+        assert len(size) == len(nonflat), "size must list the non-Flat dimensions"
+        N = [1, 1, 1]
+        for n, d in zip(size, nonflat):
+            N[d] = int(n)
+        if halo is None:
+            halo = (3,) * len(nonflat)
+        halo = (halo,) * len(nonflat) if np.isscalar(halo) else tuple(halo)
+        H = [0, 0, 0]
+        for h, d in zip(halo, nonflat):
+            H[d] = int(h)
+        self.Nx, self.Ny, self.Nz = N
+        self.Hx, self.Hy, self.Hz = H
+        assert topo[2] == BOUNDED, "oracle supports Bounded z only"
+        assert topo[0] in (PERIODIC, FLAT) and topo[1] in (PERIODIC, FLAT)
+
+        def regular(ext, n, flat):
+            if flat:
+                return 0.0, 1.0, np.zeros(1), np.zeros(1)
+            a, b = ext
+            d = (b - a) / n
+            return a, d, a + d * np.arange(n), a + d * (np.arange(n) + 0.5)
+
+        self.x0, self.dx, self.xf, self.xc = regular(x, self.Nx, topo[0] == FLAT)
+        self.y0, self.dy, self.yf, self.yc = regular(y, self.Ny, topo[1] == FLAT)
+        Nz, Hz = self.Nz, self.Hz
+        if isinstance(z, (tuple, list)) and len(z) == 2:
+            zf = z[0] + (z[1] - z[0]) / Nz * np.arange(Nz + 1)
+            zf[-1] = z[1]
+        else:
+            zf = np.asarray(z, dtype=np.float64)
+            assert zf.shape == (Nz + 1,)
+        self.zf = zf
+        # halo extension: mirror the first/last spacing outward
+        zf_ext = np.empty(Nz + 1 + 2 * Hz)
+        zf_ext[Hz:Hz + Nz + 1] = zf
+        for h in range(1, Hz + 1):
+            zf_ext[Hz - h] = zf_ext[Hz - h + 1] - (zf[1] - zf[0])
+            zf_ext[Hz + Nz + h] = zf_ext[Hz + Nz + h - 1] + (zf[-1] - zf[-2])
+        zc_ext = 0.5 * (zf_ext[:-1] + zf_ext[1:])           # length Nz+2Hz
+        self.zc = zc_ext[Hz:Hz + Nz].copy()
+        self.dzc = np.ascontiguousarray(zf_ext[1:] - zf_ext[:-1])     # entry k+Hz
+        dzf = np.zeros(Nz + 1 + 2 * Hz)
+        dzf[1:Nz + 2 * Hz] = zc_ext[1:] - zc_ext[:-1]                 # dzf[k+Hz] = zc[k]-zc[k-1]
+        dzf[0] = dzf[1]
+        dzf[-1] = dzf[-2]
+        self.dzf = np.ascontiguousarray(dzf)
+        self.regular_z = isinstance(z, (tuple, list)) and len(z) == 2
+        if self.regular_z:          # Oceananigans regular grids carry one number dz = Lz/Nz
+            dz = (z[1] - z[0]) / Nz
+            self.dzc[:] = dz
+            self.dzf[:] = dz
+            self.zc = z[0] + dz * (np.arange(Nz) + 0.5)
+        self.Sx, self.Sy = self.Nx + 2 * self.Hx, self.Ny + 2 * self.Hy
+        self.Szc, self.Szf = Nz + 2 * Hz, Nz + 1 + 2 * Hz
+
+    def center_field(self):
+        return np.zeros((self.Szc, self.Sy, self.Sx))
+
+    def zface_field(self):
+        return np.zeros((self.Szf, self.Sy, self.Sx))
+
+    def interior(self, f, zface=False):
+        nz = self.Nz + (1 if zface else 0)
+        return f[self.Hz:self.Hz + nz, self.Hy:self.Hy + self.Ny, self.Hx:self.Hx + self.Nx]
+
+    def nodes(self, loc):
+        """Broadcastable (z, y, x) node arrays for location loc in {'ccc','fcc','cfc','ccf'}."""
+        x = self.xf if loc[0] == "f" else self.xc
+        y = self.yf if loc[1] == "f" else self.yc
+        z = self.zf if loc[2] == "f" else self.zc
+        return x[None, None, :], y[None, :, None], z[:, None, None]
+
+
+class ReferenceState:
+    """ReferenceState(grid; surface_pressure, potential_temperature, standard_pressure)
+    — reference_states.jl:402-445 (constant potential temperature, dry)."""
+
+    def __init__(self, grid, constants, surface_pressure=101325.0, potential_temperature=288.0,
+                 standard_pressure=1e5):
+        g, c = grid, constants
+        self.p0, self.theta0, self.pst = float(surface_pressure), float(potential_temperature), float(standard_pressure)
+        Nz, Hz = g.Nz, g.Hz
+        self.rho0 = surface_density(self.p0, self.theta0, self.pst, c)
+        self.density = np.zeros(g.Szc)
+        self.pressure = np.zeros(g.Szc)
+        self.temperature = np.zeros(g.Szc)
+        zc = g.zc
+        self.density[Hz:Hz + Nz] = adiabatic_hydrostatic_density(zc, self.p0, self.theta0, self.pst, c)
+        self.pressure[Hz:Hz + Nz] = adiabatic_hydrostatic_pressure(zc, self.p0, self.theta0, self.pst, c)
+        self.temperature[Hz:Hz + Nz] = hydrostatic_temperature(zc, self.p0, self.theta0, self.pst, c)
+        self._fill(g)
+
+    def _fill(self, g):
+        """bottom ValueBoundaryCondition (rho0 / p0), top + T: zero-gradient; first halo cell only
+        (reference_states.jl:416-438)."""
+        Nz, Hz = g.Nz, g.Hz
+        if Hz > 0:
+            self.density[Hz - 1] = 2 * self.rho0 - self.density[Hz]
+            self.pressure[Hz - 1] = 2 * self.p0 - self.pressure[Hz]
+            self.temperature[Hz - 1] = self.temperature[Hz]
+            self.density[Hz + Nz] = self.density[Hz + Nz - 1]
+            self.pressure[Hz + Nz] = self.pressure[Hz + Nz - 1]
+            self.temperature[Hz + Nz] = self.temperature[Hz + Nz - 1]
+
+
+def poisson_eigenvalues(N, delta, topo):
+    """Oceananigans poisson_eigenvalues (recalled): Periodic (2 sin(pi (i-1)/N)/Delta)^2, Flat 0."""
+    if topo == FLAT:
+        return np.zeros(1)
+    assert topo == PERIODIC
+    i = np.arange(N)
+    return (2 * np.sin(i * np.pi / N) / delta) ** 2
+
+
+class OracleModel:
+    """AtmosphereModel(grid; advection=WENO(order=5), dynamics=AnelasticDynamics(ReferenceState),
+    formulation=:LiquidIcePotentialTemperature, microphysics=nothing, closure=nothing) on the CPU."""
+
+    PROGNOSTIC = ("ru", "rv", "rw", "rtheta", "rq")
+
+    def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
+                 standard_pressure=1e5, reference_density=None):
+        self.grid = g = grid
+        self.constants = c = constants or Constants()
+        self.ref = ReferenceState(g, c, surface_pressure, potential_temperature, standard_pressure)
+        self.ref._fill(g)
+        if reference_density is not None:      # test hook: set!(reference_state.density, f(z))
+            self.ref.density[g.Hz:g.Hz + g.Nz] = reference_density(g.zc)
+            self.ref._fill(g)
+        self.lib = lib()
+        self._mk_cgrid()
+        # fields
+        self.ru, self.rv, self.rtheta, self.rq = (g.center_field() for _ in range(4))
+        self.rw = g.zface_field()
+        self.u, self.v, self.theta, self.q, self.T, self.phi = (g.center_field() for _ in range(6))
+        self.w = g.zface_field()
+        self.U0 = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
+        self.G = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
+        # Poisson solver setup (dynamics_pressure_solver, anelastic_pressure_solver.jl:11-24)
+        self.lower = np.zeros(max(g.Nz - 1, 1))
+        self.diag0 = np.zeros(g.Nz)
+        self.mass = np.zeros(g.Nz)
+        self.lib.og_poisson_coefficients(C.byref(self.cg), _p(self.lower), _p(self.diag0), _p(self.mass))
+        lx = poisson_eigenvalues(g.Nx, g.dx, g.topo[0])
+        ly = poisson_eigenvalues(g.Ny, g.dy, g.topo[1])
+        self.lam = np.ascontiguousarray(ly[:, None] + lx[None, :])
+        self.clock_time, self.iteration = 0.0, 0
+        # initialize_model_thermodynamics!: theta = theta0 (anelastic_time_stepping.jl:15-19)
+        self.set(theta=self.ref.theta0)
+
+    def _mk_cgrid(self):
+        g, c, r = self.grid, self.constants, self.ref
+        self.cg = _OGGrid(g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz, g.topo[0], g.topo[1], g.topo[2],
+                          g.dx, g.dy, _p(g.dzc), _p(g.dzf), _p(r.density), _p(r.pressure),
+                          _p(r.temperature), c.g, c.Rd, c.Rv, c.cpd, c.cpv, r.pst)
+
+    # -- halo filling -------------------------------------------------------
+    def _halo_center(self, f):
+        self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
+        if self.grid.Hz > 0:
+            self.lib.og_fill_halo_z_noflux(C.byref(self.cg), _p(f))
+
+    def _halo_w(self, f, wall=True):
+        self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
+        if wall:
+            self.lib.og_fill_halo_z_wall(C.byref(self.cg), _p(f))
+
+    def _halo_velocity(self, f):   # `nothing` BC in z: periodic wrap only (anelastic_dynamics.jl:174-182)
+        self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
+
+    def fill_momentum_halos(self):
+        self._halo_center(self.ru)
+        self._halo_center(self.rv)
+        self._halo_w(self.rw)
+
+    # -- set! ----------------------------------------------------------------
+    def _eval(self, value, loc):
+        g = self.grid
+        if callable(value):
+            x, y, z = g.nodes(loc)
+            out = value(x, y, z)
+            shape = (g.Nz + (1 if loc[2] == "f" else 0), g.Ny, g.Nx)
+            return np.broadcast_to(np.asarray(out, dtype=np.float64), shape)
+        return value
+
+    def set(self, enforce_mass_conservation=True, **kw):
+        g = self.grid
+        Hz, Nz = g.Hz, g.Nz
+        rho_c = self.ref.density[Hz:Hz + Nz][:, None, None]
+        rho_f = (0.5 * (self.ref.density[Hz - 1:Hz + Nz] + self.ref.density[Hz:Hz + Nz + 1]))[:, None, None] \
+            if Hz > 0 else None
+        for name, value in kw.items():
+            if name in ("qt", "qv"):
+                g.interior(self.q)[...] = self._eval(value, "ccc")
+                g.interior(self.rq)[...] = rho_c * g.interior(self.q)
+            elif name == "rq":
+                g.interior(self.rq)[...] = self._eval(value, "ccc")
+            elif name == "u":
+                g.interior(self.u)[...] = self._eval(value, "fcc")
+                g.interior(self.ru)[...] = rho_c * g.interior(self.u)
+            elif name == "v":
+                g.interior(self.v)[...] = self._eval(value, "cfc")
+                g.interior(self.rv)[...] = rho_c * g.interior(self.v)
+            elif name == "w":
+                g.interior(self.w, True)[...] = self._eval(value, "ccf")
+                g.interior(self.rw, True)[...] = rho_f * g.interior(self.w, True)
+            elif name == "ru":
+                g.interior(self.ru)[...] = self._eval(value, "fcc")
+            elif name == "rv":
+                g.interior(self.rv)[...] = self._eval(value, "cfc")
+            elif name == "rw":
+                g.interior(self.rw, True)[...] = self._eval(value, "ccf")
+            elif name == "theta":
+                g.interior(self.theta)[...] = self._eval(value, "ccc")
+                g.interior(self.rtheta)[...] = rho_c * g.interior(self.theta)
+            elif name == "rtheta":
+                g.interior(self.rtheta)[...] = self._eval(value, "ccc")
+            else:
+                raise ValueError(f"Cannot set {name} in OracleModel")
+        self.update_state(compute_tendencies=False)
+        if enforce_mass_conservation:        # set_atmosphere_model.jl:121-128
+            self.compute_pressure_correction(1.0)
+            self.make_pressure_correction(1.0)
+            self.update_state(compute_tendencies=False)
+
+    # -- update_state! --------------------------------------------------------
+    def update_state(self, compute_tendencies=True):
+        cg = C.byref(self.cg)
+        self.fill_momentum_halos()
+        self._halo_center(self.rtheta)
+        self._halo_center(self.rq)
+        self.lib.og_compute_velocities(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv), _p(self.rw))
+        for f in (self.u, self.v, self.w):
+            self._halo_velocity(f)
+        self.lib.og_compute_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.rtheta), _p(self.rq))
+        for f in (self.T, self.q, self.theta):
+            self._halo_center(f)
+        if compute_tendencies:
+            self.compute_tendencies()
+
+    def compute_tendencies(self):
+        cg = C.byref(self.cg)
+        L, G = self.lib, self.G
+        L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
+        L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
+        L.og_w_tendency(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w), _p(self.T), _p(self.q))
+        L.og_scalar_tendency(cg, _p(G["rtheta"]), _p(self.u), _p(self.v), _p(self.w), _p(self.theta))
+        L.og_scalar_tendency(cg, _p(G["rq"]), _p(self.u), _p(self.v), _p(self.w), _p(self.q))
+
+    # -- pressure ------------------------------------------------------------
+    def solve_poisson(self, rhs):
+        """solve!(phi, FourierTridiagonalPoissonSolver) (Oceananigans, recalled):
+        FFT x,y -> complex Thomas in z -> inverse FFT -> subtract mean -> real part."""
+        g = self.grid
+        rhat = np.ascontiguousarray(np.fft.fft2(rhs.astype(np.complex128), axes=(1, 2)))
+        phat = np.zeros_like(rhat)
+        scratch = np.zeros(rhs.shape)
+        self.lib.og_tridiagonal_solve(C.c_int(g.Nx), C.c_int(g.Ny), C.c_int(g.Nz), _p(self.lower),
+                                      _p(self.diag0), _p(self.mass), _p(self.lam),
+                                      rhat.view(np.float64).ctypes.data_as(_dp),
+                                      phat.view(np.float64).ctypes.data_as(_dp), _p(scratch))
+        phi = np.fft.ifft2(phat, axes=(1, 2))
+        phi = phi - phi.mean()
+        return np.ascontiguousarray(phi.real)
+
+    def compute_pressure_correction(self, dt):
+        g = self.grid
+        self.fill_momentum_halos()
+        rhs = np.zeros((g.Nz, g.Ny, g.Nx))
+        self.lib.og_poisson_source(C.byref(self.cg), _p(rhs), _p(self.ru), _p(self.rv), _p(self.rw), C.c_double(dt))
+        g.interior(self.phi)[...] = self.solve_poisson(rhs)
+        self._halo_center(self.phi)
+
+    def make_pressure_correction(self, dt):
+        self.lib.og_pressure_correct(C.byref(self.cg), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.phi), C.c_double(dt))
+
+    def divergence(self):
+        g = self.grid
+        d = np.zeros((g.Nz, g.Ny, g.Nx))
+        self.lib.og_divergence(C.byref(self.cg), _p(d), _p(self.ru), _p(self.rv), _p(self.rw))
+        return d
+
+    # -- time stepping -------------------------------------------------------
+    def rk3_substep(self, dt, alpha):
+        g = self.grid
+        for n in self.PROGNOSTIC:
+            k0, k1 = (1, g.Nz) if n == "rw" else (0, g.Nz)
+            self.lib.og_rk3_substep(C.byref(self.cg), _p(getattr(self, n)), _p(self.U0[n]), _p(self.G[n]),
+                                    C.c_double(dt), C.c_double(alpha), C.c_int(k0), C.c_int(k1))
+
+    def time_step(self, dt):
+        if self.iteration == 0:
+            self.update_state(compute_tendencies=True)
+        for n in self.PROGNOSTIC:                      # store_initial_state!
+            self.U0[n][...] = getattr(self, n)
+        for alpha in (1.0, 1.0 / 4.0, 2.0 / 3.0):
+            self.rk3_substep(dt, alpha)
+            self.compute_pressure_correction(alpha * dt)
+            self.make_pressure_correction(alpha * dt)
+            self.update_state(compute_tendencies=True)
+        self.clock_time += dt
+        self.iteration += 1

@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py — grid cells advanced per second by the anelastic WENO5 + Poisson SSP-RK3 step.
+
+Metric and protocol mirror the reference's benchmark_time_stepping
+(/root/reference/benchmarking/src/utils.jl:40-172: warm-up steps, device sync, timed steps, sync,
+grid_points_per_second = Nx*Ny*Nz / time_per_step).  Workload: BASELINE.json configs[1], the dry
+thermal bubble on a 512^3 RectilinearGrid (SURVEY.md §8d "C2"), Float64, fixed dt = 1 s,
+deterministic synthetic initial state resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W [--size 512]
+
+Prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run, one rank per
+GPU; until the y-slab decomposition lands each rank advances its own replica of the workload
+(no collective in the data path) and `value` is the aggregate over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# Algorithmic words (8 B) per grid cell per launch of each kernel group — SURVEY.md §8(d) table.
+WORDS_PER_CELL = {
+    "ssp_rk3_substep": 20, "store_initial_state": 10, "poisson_source_term": 4,
+    "poisson_fft_forward": 4, "poisson_tridiagonal": 2, "poisson_fft_inverse": 4,
+    "make_pressure_correction": 7, "compute_velocities": 6,
+    "compute_auxiliary_thermodynamic_variables": 5,
+    "x_momentum_tendency": 5, "y_momentum_tendency": 5, "z_momentum_tendency": 7,
+    "potential_temperature_tendency": 6, "moisture_tendency": 5,
+    "scalar_tendencies": 11, "momentum_tendencies": 17, "tendencies": 28,
+    "rk3_and_source": 24, "project_and_diagnose": 18,
+}
+A_STEP_WORDS = 250          # 3 stages x 80 + 10
+
+
+def bubble(x, y, z):
+    """theta_i = theta0 exp(N^2 z / g) + 10 max(0, 1 - r/2000), bubble centre (0, 0, 3000 m)."""
+    r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+    return 300.0 * np.exp(1e-6 * z / 9.81) + 10.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+
+EXTENT = ((-10e3, 10e3), (-10e3, 10e3), (0.0, 10e3))
+
+
+def cpu_baseline(n, steps):
+    """The CPU oracle ("port": this repo's C/OpenMP restatement, not Breeze CPU()) timed on this
+    box's host cores on a bounded sample of the same workload: the bubble at n^3."""
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    g = orc.Grid((n, n, n), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    m = orc.OracleModel(g, potential_temperature=300.0)
+    m.set(theta=bubble)
+    m.time_step(1.0)                       # warm-up (also the first-step update_state)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.time_step(1.0)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": n ** 3 / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": f"dry thermal bubble {n}^3 Float64, {steps} steps after 1 warm-up, "
+                      f"C/OpenMP oracle ({cores} threads) + numpy pocketfft"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=128)
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import breeze_jl_amd as bz
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = f"cuda:{local_rank}"
+
+    N = args.size
+    grid = bz.RectilinearGrid((N, N, N), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    ref = bz.ReferenceState(grid, surface_pressure=101325, potential_temperature=300)
+    model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), device=device)
+    model.set(θ=bubble)          # u = v = w = 0, dry
+    dt = 1.0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.time_step(dt)
+    model.profile_reset()
+    model.profile_enable(True)           # HIP events on the kernels' own stream, over the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.time_step(dt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    model.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    cells = N ** 3
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * cells * args.steps / elapsed
+
+    prof = model.profile()
+    finite = bool(torch.isfinite(model.momentum["ρw"].parent).all().item())
+    if rank == 0:
+        kernels = {}
+        for name, (ms, n) in prof.items():
+            if n:
+                kernels[name] = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
+        dom = max((k for k in kernels if k in WORDS_PER_CELL), key=lambda k: kernels[k]["total_ms"])
+        dom_bytes = WORDS_PER_CELL[dom] * 8 * cells
+        achieved = dom_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"]}
+        step_achieved = (cells * args.steps / elapsed) * A_STEP_WORDS * 8 / 1e9
+        out = {
+            "metric": "grid-cells advanced/sec (tendency+Poisson step), 512^3 anelastic",
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"dry thermal bubble {N}^3 RectilinearGrid (Periodic,Periodic,Bounded), halo 3, "
+                                   "AnelasticDynamics + WENO5 + SSP-RK3, Float64, dt=1s (BASELINE.json configs[1])",
+                       "grid": [N, N, N], "dt": dt,
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
+            "roofline": roofline,
+            "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": step_achieved / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 8},
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(kernels.items())},
+            "finite": finite,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

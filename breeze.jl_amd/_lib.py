@@ -1,0 +1,119 @@
+"""ctypes binding of libbreeze_hip.so (C ABI declared in include/breeze_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load, importing
+this module's `load()` raises.  Nothing here imports the test oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbreeze_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_dp = C.POINTER(C.c_double)
+
+
+class bz_grid(C.Structure):
+    _fields_ = [("Nx", C.c_int32), ("Ny", C.c_int32), ("Nz", C.c_int32),
+                ("Hx", C.c_int32), ("Hy", C.c_int32), ("Hz", C.c_int32),
+                ("topo", C.c_int32 * 3), ("ftype", C.c_int32),
+                ("dx", C.c_double), ("dy", C.c_double),
+                ("zf", _dp), ("regular_z", C.c_int32), ("reserved", C.c_int32)]
+
+
+class bz_constants(C.Structure):
+    _fields_ = [("gravitational_acceleration", C.c_double),
+                ("dry_air_gas_constant", C.c_double),
+                ("vapor_gas_constant", C.c_double),
+                ("dry_air_heat_capacity", C.c_double),
+                ("vapor_heat_capacity", C.c_double)]
+
+
+class bz_reference_state(C.Structure):
+    _fields_ = [("surface_pressure", C.c_double), ("potential_temperature", C.c_double),
+                ("standard_pressure", C.c_double),
+                ("density", _dp), ("pressure", _dp), ("temperature", _dp)]
+
+
+_STATE_FIELDS = ("rho_u", "rho_v", "rho_w", "rho_theta", "rho_q", "u", "v", "w", "theta", "q", "T", "phi")
+_PROG_FIELDS = ("rho_u", "rho_v", "rho_w", "rho_theta", "rho_q")
+
+
+class bz_state(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _STATE_FIELDS]
+
+
+class bz_prognostic(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _PROG_FIELDS]
+
+
+# every symbol include/breeze_hip.h declares: name -> (restype, argtypes)
+_ctx = C.c_void_p
+_sp, _pp = C.POINTER(bz_state), C.POINTER(bz_prognostic)
+SYMBOLS = {
+    "bz_create": (C.c_int, [C.POINTER(_ctx), C.POINTER(bz_grid), C.POINTER(bz_constants),
+                            C.POINTER(bz_reference_state), C.c_int]),
+    "bz_destroy": (None, [_ctx]),
+    "bz_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "bz_sync": (C.c_int, [_ctx]),
+    "bz_last_error": (C.c_char_p, [_ctx]),
+    "bz_fill_halo_regions": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
+    "bz_compute_velocities": (C.c_int, [_ctx, _sp]),
+    "bz_compute_auxiliary_thermodynamic_variables": (C.c_int, [_ctx, _sp]),
+    "bz_compute_tendencies": (C.c_int, [_ctx, _sp, _pp]),
+    "bz_update_state": (C.c_int, [_ctx, _sp, _pp, C.c_int]),
+    "bz_store_initial_state": (C.c_int, [_ctx, _sp, _pp]),
+    "bz_ssp_rk3_substep": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double, C.c_double]),
+    "bz_compute_pressure_correction": (C.c_int, [_ctx, _sp, C.c_double]),
+    "bz_make_pressure_correction": (C.c_int, [_ctx, _sp, C.c_double]),
+    "bz_time_step_anelastic": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double]),
+    "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),
+    "bz_profile_reset": (C.c_int, [_ctx]),
+    "bz_profile_count": (C.c_int, [_ctx]),
+    "bz_profile_get": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_int64)]),
+    "bz_max_abs_divergence": (C.c_int, [_ctx, _sp, C.POINTER(C.c_double)]),
+}
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into lib/libbreeze_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("building libbreeze_hip.so failed:\n" + out.stdout)
+    if verbose:
+        print(out.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load libbreeze_hip.so and bind every declared symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C breeze.jl_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class BreezeHIPError(RuntimeError):
+    pass
+
+
+def check(lib, ctx, rc, what):
+    if rc != 0:
+        msg = lib.bz_last_error(ctx).decode() if ctx else ""
+        raise BreezeHIPError(f"{what} failed with code {rc}: {msg}")

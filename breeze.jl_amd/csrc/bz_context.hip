@@ -1,0 +1,195 @@
+// bz_context.hip — context lifetime, column tables, stream and instrumentation.
+#include <cmath>
+#include <cstring>
+
+#include "bz_internal.h"
+
+ProfileScope::ProfileScope(bz_ctx *c, const char *name) : ctx(c)
+{
+    if (!ctx->profiling) return;
+    for (size_t s = 0; s < ctx->slots.size(); ++s)
+        if (ctx->slots[s].name == name || std::strcmp(ctx->slots[s].name, name) == 0) slot = (int)s;
+    if (slot < 0) {
+        ctx->slots.emplace_back();
+        ctx->slots.back().name = name;
+        slot = (int)ctx->slots.size() - 1;
+    }
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { slot = -1; return; }
+    hipEventRecord(e0, ctx->stream);
+}
+ProfileScope::~ProfileScope()
+{
+    if (slot < 0) return;
+    hipEventRecord(e1, ctx->stream);
+    ctx->slots[slot].pending.emplace_back(e0, e1);
+}
+
+static void profile_drain(bz_ctx *ctx)
+{
+    for (auto &s : ctx->slots) {
+        for (auto &p : s.pending) {
+            hipEventSynchronize(p.second);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                s.total_ms += ms;
+                s.launches += 1;
+            }
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        s.pending.clear();
+    }
+}
+
+extern "C" int bz_profile_enable(bz_ctx *ctx, int on)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    if (!on) profile_drain(ctx);
+    ctx->profiling = on != 0;
+    return BZ_OK;
+}
+extern "C" int bz_profile_reset(bz_ctx *ctx)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    profile_drain(ctx);
+    for (auto &s : ctx->slots) { s.total_ms = 0.0; s.launches = 0; }
+    return BZ_OK;
+}
+extern "C" int bz_profile_count(bz_ctx *ctx) { return ctx ? (int)ctx->slots.size() : 0; }
+extern "C" int bz_profile_get(bz_ctx *ctx, int idx, const char **name, double *total_ms, int64_t *launches)
+{
+    if (!ctx || idx < 0 || idx >= (int)ctx->slots.size()) return BZ_ERR_INVALID;
+    profile_drain(ctx);
+    if (name) *name = ctx->slots[idx].name;
+    if (total_ms) *total_ms = ctx->slots[idx].total_ms;
+    if (launches) *launches = ctx->slots[idx].launches;
+    return BZ_OK;
+}
+
+extern "C" const char *bz_last_error(const bz_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+
+extern "C" int bz_set_stream(bz_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    ctx->stream = (hipStream_t)hip_stream;
+    if (ctx->plans_ok) {
+        BZ_FFT(hipfftSetStream(ctx->plan_fwd, ctx->stream));
+        BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
+    }
+    return BZ_OK;
+}
+
+extern "C" int bz_sync(bz_ctx *ctx)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    BZ_HIP(hipStreamSynchronize(ctx->stream));
+    return BZ_OK;
+}
+
+extern "C" int bz_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
+                         const bz_reference_state *ref, int weno_order)
+{
+    if (!out || !grid || !constants || !ref || !grid->zf || !ref->density || !ref->pressure || !ref->temperature)
+        return BZ_ERR_INVALID;
+    *out = nullptr;
+    if (weno_order != 5) return BZ_ERR_UNSUPPORTED;
+    if (grid->ftype != 8) return BZ_ERR_UNSUPPORTED;
+    if (grid->topo[0] != BZ_PERIODIC || grid->topo[1] != BZ_PERIODIC || grid->topo[2] != BZ_BOUNDED)
+        return BZ_ERR_UNSUPPORTED;
+    if (grid->Hx < 3 || grid->Hy < 3 || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
+    if (grid->Nx < 8 || grid->Ny < 1 || grid->Nz < 6 || (grid->Nx & 1)) return BZ_ERR_UNSUPPORTED;
+
+    bz_ctx *ctx = new (std::nothrow) bz_ctx();
+    if (!ctx) return BZ_ERR_ALLOC;
+    ctx->grid = *grid;
+    ctx->grid.zf = nullptr;
+    ctx->constants = *constants;
+
+    const int Nx = grid->Nx, Ny = grid->Ny, Nz = grid->Nz, Hz = grid->Hz;
+    const int nc = Nz + 2 * Hz, nf = Nz + 1 + 2 * Hz;
+
+    // ---- z metrics with halo extension (first/last spacing mirrored outward) ----
+    std::vector<double> zf_ext(nf), zc_ext(nc), dzc(nc), dzf(nf, 0.0);
+    for (int k = 0; k <= Nz; ++k) zf_ext[Hz + k] = grid->zf[k];
+    for (int h = 1; h <= Hz; ++h) {
+        zf_ext[Hz - h] = zf_ext[Hz - h + 1] - (grid->zf[1] - grid->zf[0]);
+        zf_ext[Hz + Nz + h] = zf_ext[Hz + Nz + h - 1] + (grid->zf[Nz] - grid->zf[Nz - 1]);
+    }
+    for (int k = 0; k < nc; ++k) {
+        zc_ext[k] = 0.5 * (zf_ext[k] + zf_ext[k + 1]);
+        dzc[k] = zf_ext[k + 1] - zf_ext[k];
+    }
+    for (int k = 1; k < nc; ++k) dzf[k] = zc_ext[k] - zc_ext[k - 1];
+    dzf[0] = dzf[1];
+    dzf[nf - 1] = dzf[nf - 2];
+    if (grid->regular_z) {
+        double dz = (grid->zf[Nz] - grid->zf[0]) / Nz;
+        for (auto &v : dzc) v = dz;
+        for (auto &v : dzf) v = dz;
+    }
+
+    // ---- column tables: 11 columns of nf entries each ----
+    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_COUNT };
+    std::vector<double> cols((size_t)C_COUNT * nf, 0.0);
+    auto col = [&](int c) { return cols.data() + (size_t)c * nf; };
+    const double dx = grid->dx, dy = grid->dy;
+    for (int k = 0; k < nc; ++k) {
+        col(C_DZC)[k] = dzc[k];
+        col(C_AX)[k] = dy * dzc[k];
+        col(C_AY)[k] = dx * dzc[k];
+        col(C_VIC)[k] = 1.0 / (dx * dy * dzc[k]);
+        col(C_RHO)[k] = ref->density[k];
+        col(C_PR)[k] = ref->pressure[k];
+        col(C_TR)[k] = ref->temperature[k];
+    }
+    for (int k = 0; k < nf; ++k) {
+        col(C_DZF)[k] = dzf[k];
+        col(C_RDZF)[k] = 1.0 / dzf[k];
+        col(C_VIF)[k] = 1.0 / (dx * dy * dzf[k]);
+        // Iz(rho) at face k: 0.5*(rho[k-1]+rho[k]); defined where both exist
+        if (k >= 1 && k < nc) col(C_RHOF)[k] = 0.5 * (ref->density[k - 1] + ref->density[k]);
+    }
+
+    BZ_HIP(hipMalloc(&ctx->d_columns, cols.size() * sizeof(double)));
+    BZ_HIP(hipMemcpy(ctx->d_columns, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice));
+    BZ_HIP(hipMalloc(&ctx->d_scalar, 64 * sizeof(double)));
+
+    DevGrid &g = ctx->dg;
+    g.Nx = Nx; g.Ny = Ny; g.Nz = Nz;
+    g.Hx = grid->Hx; g.Hy = grid->Hy; g.Hz = Hz;
+    g.Sx = Nx + 2 * grid->Hx;
+    g.Sy = Ny + 2 * grid->Hy;
+    g.Sxy = (long long)g.Sx * g.Sy;
+    g.dx = dx; g.dy = dy; g.rdx = 1.0 / dx; g.rdy = 1.0 / dy; g.Az = dx * dy;
+    auto dcol = [&](int c) { return ctx->d_columns + (size_t)c * nf + Hz; };
+    g.dzc = dcol(C_DZC); g.dzf = dcol(C_DZF); g.rdzf = dcol(C_RDZF);
+    g.Ax = dcol(C_AX); g.Ay = dcol(C_AY);
+    g.Vinv_c = dcol(C_VIC); g.Vinv_f = dcol(C_VIF);
+    g.rho = dcol(C_RHO); g.rho_f = dcol(C_RHOF);
+    g.p_r = dcol(C_PR); g.T_r = dcol(C_TR);
+    g.g = constants->gravitational_acceleration;
+    g.Rd = constants->dry_air_gas_constant;
+    g.Rv = constants->vapor_gas_constant;
+    g.cpd = constants->dry_air_heat_capacity;
+    g.cpv = constants->vapor_heat_capacity;
+    g.pst = ref->standard_pressure;
+
+    int rc = bzi_poisson_setup(ctx, ref->density);
+    if (rc != BZ_OK) {
+        fprintf(stderr, "bz_create: Poisson setup failed (%d): %s\n", rc, ctx->last_error.c_str());
+        bz_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return BZ_OK;
+}
+
+extern "C" void bz_destroy(bz_ctx *ctx)
+{
+    if (!ctx) return;
+    profile_drain(ctx);
+    bzi_poisson_teardown(ctx);
+    if (ctx->d_columns) hipFree(ctx->d_columns);
+    if (ctx->d_scalar) hipFree(ctx->d_scalar);
+    delete ctx;
+}

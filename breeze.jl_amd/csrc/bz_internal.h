@@ -1,0 +1,106 @@
+// bz_internal.h — shared host/device declarations of libbreeze_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/breeze_hip.h"
+
+// Device view of the grid + reference columns.  Passed by value (kernarg) to every kernel.
+// Column pointers are pre-offset so that index k (0-based interior) is valid for
+// k = -Hz .. Nz+Hz-1 (centres) / Nz+Hz (faces).
+struct DevGrid {
+    int Nx, Ny, Nz;
+    int Hx, Hy, Hz;
+    int Sx, Sy;            // parent row length / rows per plane
+    long long Sxy;         // plane stride
+    double dx, dy, rdx, rdy, Az;
+    const double *dzc, *dzf, *rdzf;      // thickness at centres; centre spacing at faces; 1/dzf
+    const double *Ax, *Ay;               // dy*dzc[k], dx*dzc[k]
+    const double *Vinv_c, *Vinv_f;       // 1/(dx*dy*dzc[k]), 1/(dx*dy*dzf[k])
+    const double *rho, *rho_f;           // rho_r at centres;  0.5*(rho[k-1]+rho[k]) at faces
+    const double *p_r, *T_r;
+    double g, Rd, Rv, cpd, cpv, pst;
+
+    __host__ __device__ inline long long idx(int i, int j, int k) const {
+        return (long long)(i + Hx) + (long long)Sx * ((long long)(j + Hy)) + Sxy * (long long)(k + Hz);
+    }
+};
+
+struct ProfileSlot {
+    const char *name;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct bz_ctx {
+    bz_grid grid;
+    bz_constants constants;
+    DevGrid dg;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    // column tables (one device allocation)
+    double *d_columns = nullptr;
+    // Poisson
+    int NXH = 0;                      // Nx/2+1
+    hipfftHandle plan_fwd = 0, plan_inv = 0;
+    bool plans_ok = false;
+    double *d_rhs = nullptr;          // Nx*Ny*Nz real (source term, then inverse-transform output)
+    hipfftDoubleComplex *d_hat = nullptr;   // NXH*Ny*Nz
+    double *d_ibeta = nullptr;        // NXH*Ny*Nz : 1/beta_k
+    double *d_tfac = nullptr;         // NXH*Ny*Nz : t_k = c_{k-1}/beta_{k-1}
+    double *d_lower = nullptr;        // Nz
+    double *d_scalar = nullptr;       // small scratch (mean, reductions)
+    // profiling
+    bool profiling = false;
+    std::vector<ProfileSlot> slots;
+};
+
+#define BZ_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);            \
+            return -(int)_e;                                                                \
+        }                                                                                   \
+    } while (0)
+
+#define BZ_FFT(expr)                                                                        \
+    do {                                                                                    \
+        hipfftResult _r = (expr);                                                           \
+        if (_r != HIPFFT_SUCCESS) {                                                         \
+            ctx->last_error = std::string(#expr) + ": hipfft status " + std::to_string((int)_r); \
+            return -1000 - (int)_r;                                                         \
+        }                                                                                   \
+    } while (0)
+
+#define BZ_LAUNCH_CHECK()                                                                   \
+    do {                                                                                    \
+        hipError_t _e = hipGetLastError();                                                  \
+        if (_e != hipSuccess) {                                                             \
+            ctx->last_error = std::string("kernel launch: ") + hipGetErrorString(_e);       \
+            return -(int)_e;                                                                \
+        }                                                                                   \
+    } while (0)
+
+// Scoped profiling region: records start/stop events on the ctx stream when enabled.
+struct ProfileScope {
+    bz_ctx *ctx;
+    int slot = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfileScope(bz_ctx *c, const char *name);
+    ~ProfileScope();
+};
+
+// internal entry points shared between translation units
+int bzi_fill_halo(bz_ctx *ctx, double *f, int kind);
+int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, int n);
+int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
+void bzi_poisson_teardown(bz_ctx *ctx);
+int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);

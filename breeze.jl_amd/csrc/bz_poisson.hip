@@ -1,0 +1,236 @@
+// bz_poisson.hip — anelastic pressure Poisson solve.
+//   compute_anelastic_source_term!   /root/reference/src/AnelasticEquations/anelastic_pressure_solver.jl:90-105
+//   tridiagonal coefficients         :32-78
+//   solve!(phi, FourierTridiagonalPoissonSolver)  Oceananigans.Solvers (called at :86):
+//     forward FFT in x,y (rocFFT, real-to-complex half spectrum) -> Thomas solve along z per
+//     horizontal wavenumber -> inverse FFT -> zero mean -> real copy.
+// The Thomas factors depend only on the grid and the reference density, so 1/beta_k and
+// t_k = c_{k-1}/beta_{k-1} are tabulated once per (kx,ky,k) at bz_create.
+#include <cmath>
+#include <cstdlib>
+
+#include "bz_internal.h"
+
+#define TX 64
+#define TY 4
+
+__global__ __launch_bounds__(TX *TY) void k_poisson_source(DevGrid g, double *__restrict__ rhs,
+                                                          const double *__restrict__ ru,
+                                                          const double *__restrict__ rv,
+                                                          const double *__restrict__ rw, double dt)
+{
+    int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
+    if (i >= g.Nx || j >= g.Ny) return;
+    long long n = g.idx(i, j, k);
+    double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
+    double a = Ax * ru[n + 1] - Ax * ru[n];
+    double b = Ay * rv[n + g.Sx] - Ay * rv[n];
+    double c = Az * rw[n + g.Sxy] - Az * rw[n];
+    double div = g.Vinv_c[k] * (a + b + c);
+    rhs[(long long)i + (long long)g.Nx * ((long long)j + (long long)g.Ny * k)] = g.dzc[k] * div / dt;
+}
+
+struct TriCols {
+    const double *lower;   // [Nz-1]  rho_f[k+1]/dzf[k+1]
+    const double *diag0;   // [Nz]
+    const double *mass;    // [Nz]    rho[k]*dzc[k]
+    const double *lam_x;   // [NXH]
+    const double *lam_y;   // [Ny]
+};
+
+// One thread per horizontal wavenumber: tabulate 1/beta_k and t_k of the Thomas forward sweep.
+__global__ __launch_bounds__(256) void k_tridiag_setup(int NXH, int Ny, int Nz, TriCols C,
+                                                       double *__restrict__ ibeta,
+                                                       double *__restrict__ tfac)
+{
+    long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long plane = (long long)NXH * Ny;
+    if (c >= plane) return;
+    int kx = (int)(c % NXH), ky = (int)(c / NXH);
+    double lam = C.lam_x[kx] + C.lam_y[ky];
+    double beta = C.diag0[0] - C.mass[0] * lam;
+    ibeta[c] = 1.0 / beta;
+    tfac[c] = 0.0;
+    const double tiny = 10.0 * 2.220446049250313e-16;
+    for (int k = 1; k < Nz; ++k) {
+        double a = C.lower[k - 1];
+        double t = a / beta;
+        beta = (C.diag0[k] - C.mass[k] * lam) - a * t;
+        tfac[c + plane * k] = t;
+        // Oceananigans elides the forward update when |beta| <= 10 eps (singular (0,0) mode):
+        // ibeta = 0 reproduces "keep the stale value", with stale value 0.
+        ibeta[c + plane * k] = (fabs(beta) > tiny) ? 1.0 / beta : 0.0;
+    }
+}
+
+// Thomas solve along z, in place on the half-spectrum.  scale = 1/(Nx*Ny) folds in the inverse-FFT
+// normalisation.  Column (0,0) additionally gets its z-mean removed, which is the global mean of
+// phi (mean removal of Oceananigans' solve!).
+__global__ __launch_bounds__(64) void k_tridiag_solve(int NXH, int Ny, int Nz, const double *__restrict__ lower,
+                                                      const double *__restrict__ ibeta,
+                                                      const double *__restrict__ tfac,
+                                                      double2 *__restrict__ hat, double scale)
+{
+    long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    long long plane = (long long)NXH * Ny;
+    if (c >= plane) return;
+    double2 prev = make_double2(0.0, 0.0);
+    double a = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < Nz; ++k) {
+        long long n = c + plane * k;
+        double2 f = hat[n];
+        double ib = ibeta[n];
+        double2 v;
+        v.x = (f.x * scale - a * prev.x) * ib;
+        v.y = (f.y * scale - a * prev.y) * ib;
+        hat[n] = v;
+        prev = v;
+        a = (k < Nz - 1) ? lower[k] : 0.0;
+    }
+    double2 next = prev;
+    double sum = prev.x;
+#pragma unroll 8
+    for (int k = Nz - 2; k >= 0; --k) {
+        long long n = c + plane * k;
+        double2 v = hat[n];
+        double t = tfac[n + plane];
+        v.x -= t * next.x;
+        v.y -= t * next.y;
+        hat[n] = v;
+        next = v;
+        sum += v.x;
+    }
+    if (c == 0) {
+        double mean = sum / Nz;
+        for (int k = 0; k < Nz; ++k) hat[plane * k].x -= mean;
+    }
+}
+
+__global__ __launch_bounds__(TX *TY) void k_phi_scatter(DevGrid g, double *__restrict__ phi,
+                                                       const double *__restrict__ src)
+{
+    int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
+    if (i >= g.Nx || j >= g.Ny) return;
+    phi[g.idx(i, j, k)] = src[(long long)i + (long long)g.Nx * ((long long)j + (long long)g.Ny * k)];
+}
+
+int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive */)
+{
+    const DevGrid &g = ctx->dg;
+    const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz, Hz = g.Hz;
+    ctx->NXH = Nx / 2 + 1;
+    const size_t nreal = (size_t)Nx * Ny * Nz, nhat = (size_t)ctx->NXH * Ny * Nz;
+
+    // ---- host column coefficients (anelastic_pressure_solver.jl:39-78) ----
+    std::vector<double> dzc(Nz + 2 * Hz), dzf(Nz + 1 + 2 * Hz);
+    BZ_HIP(hipMemcpy(dzc.data(), g.dzc - Hz, dzc.size() * sizeof(double), hipMemcpyDeviceToHost));
+    BZ_HIP(hipMemcpy(dzf.data(), g.dzf - Hz, dzf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const double *rho = h_rho + Hz;
+    std::vector<double> lower(Nz, 0.0), diag0(Nz), mass(Nz), lam_x(ctx->NXH), lam_y(Ny);
+    for (int k = 0; k < Nz - 1; ++k) lower[k] = (0.5 * (rho[k] + rho[k + 1])) / dzf[k + 1 + Hz];
+    for (int k = 0; k < Nz; ++k) {
+        double up = (k < Nz - 1) ? lower[k] : 0.0;
+        double dn = (k > 0) ? lower[k - 1] : 0.0;
+        diag0[k] = (k == 0) ? -up : (k == Nz - 1) ? -dn : -(up + dn);
+        mass[k] = rho[k] * dzc[k + Hz];
+    }
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < ctx->NXH; ++i) { double s = 2.0 * std::sin(i * pi / Nx) / g.dx; lam_x[i] = s * s; }
+    for (int j = 0; j < Ny; ++j) { double s = 2.0 * std::sin(j * pi / Ny) / g.dy; lam_y[j] = s * s; }
+
+    double *d_cols = nullptr;
+    size_t ncols = (size_t)3 * Nz + ctx->NXH + Ny;
+    BZ_HIP(hipMalloc(&d_cols, ncols * sizeof(double)));
+    ctx->d_lower = d_cols;
+    double *d_diag0 = d_cols + Nz, *d_mass = d_cols + 2 * Nz, *d_lx = d_cols + 3 * Nz, *d_ly = d_lx + ctx->NXH;
+    BZ_HIP(hipMemcpy(ctx->d_lower, lower.data(), Nz * sizeof(double), hipMemcpyHostToDevice));
+    BZ_HIP(hipMemcpy(d_diag0, diag0.data(), Nz * sizeof(double), hipMemcpyHostToDevice));
+    BZ_HIP(hipMemcpy(d_mass, mass.data(), Nz * sizeof(double), hipMemcpyHostToDevice));
+    BZ_HIP(hipMemcpy(d_lx, lam_x.data(), ctx->NXH * sizeof(double), hipMemcpyHostToDevice));
+    BZ_HIP(hipMemcpy(d_ly, lam_y.data(), Ny * sizeof(double), hipMemcpyHostToDevice));
+
+    BZ_HIP(hipMalloc(&ctx->d_rhs, nreal * sizeof(double)));
+    BZ_HIP(hipMalloc(&ctx->d_hat, nhat * sizeof(hipfftDoubleComplex)));
+    BZ_HIP(hipMalloc(&ctx->d_ibeta, nhat * sizeof(double)));
+    BZ_HIP(hipMalloc(&ctx->d_tfac, nhat * sizeof(double)));
+
+    TriCols C{ctx->d_lower, d_diag0, d_mass, d_lx, d_ly};
+    long long plane = (long long)ctx->NXH * Ny;
+    hipLaunchKernelGGL(k_tridiag_setup, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, 0, ctx->NXH, Ny, Nz, C,
+                       ctx->d_ibeta, ctx->d_tfac);
+    BZ_HIP(hipGetLastError());
+    BZ_HIP(hipDeviceSynchronize());
+
+    // ---- rocFFT plans: 2-D (y,x) transforms batched over z ----
+    int n[2] = {Ny, Nx};
+    BZ_FFT(hipfftPlanMany(&ctx->plan_fwd, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, Nz));
+    BZ_FFT(hipfftPlanMany(&ctx->plan_inv, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, Nz));
+    ctx->plans_ok = true;
+    BZ_FFT(hipfftSetStream(ctx->plan_fwd, ctx->stream));
+    BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
+    return BZ_OK;
+}
+
+void bzi_poisson_teardown(bz_ctx *ctx)
+{
+    if (ctx->plans_ok) {
+        hipfftDestroy(ctx->plan_fwd);
+        hipfftDestroy(ctx->plan_inv);
+        ctx->plans_ok = false;
+    }
+    if (ctx->d_lower) hipFree(ctx->d_lower);
+    if (ctx->d_rhs) hipFree(ctx->d_rhs);
+    if (ctx->d_hat) hipFree(ctx->d_hat);
+    if (ctx->d_ibeta) hipFree(ctx->d_ibeta);
+    if (ctx->d_tfac) hipFree(ctx->d_tfac);
+    ctx->d_lower = ctx->d_rhs = ctx->d_ibeta = ctx->d_tfac = nullptr;
+    ctx->d_hat = nullptr;
+}
+
+// solve_for_anelastic_pressure!(phi, solver, rhoU, dt)  (anelastic_pressure_solver.jl:84-88)
+int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt)
+{
+    const DevGrid &g = ctx->dg;
+    dim3 grid((g.Nx + TX - 1) / TX, (g.Ny + TY - 1) / TY, g.Nz), block(TX, TY);
+    {
+        ProfileScope ps(ctx, "poisson_source_term");
+        hipLaunchKernelGGL(k_poisson_source, grid, block, 0, ctx->stream, g, ctx->d_rhs, s->rho_u, s->rho_v,
+                           s->rho_w, dt);
+        BZ_LAUNCH_CHECK();
+    }
+    {
+        ProfileScope ps(ctx, "poisson_fft_forward");
+        BZ_FFT(hipfftExecD2Z(ctx->plan_fwd, ctx->d_rhs, ctx->d_hat));
+    }
+    {
+        ProfileScope ps(ctx, "poisson_tridiagonal");
+        long long plane = (long long)ctx->NXH * g.Ny;
+        hipLaunchKernelGGL(k_tridiag_solve, dim3((unsigned)((plane + 63) / 64)), dim3(64), 0, ctx->stream, ctx->NXH,
+                           g.Ny, g.Nz, ctx->d_lower, ctx->d_ibeta, ctx->d_tfac, (double2 *)ctx->d_hat,
+                           1.0 / ((double)g.Nx * (double)g.Ny));
+        BZ_LAUNCH_CHECK();
+    }
+    {
+        ProfileScope ps(ctx, "poisson_fft_inverse");
+        BZ_FFT(hipfftExecZ2D(ctx->plan_inv, ctx->d_hat, ctx->d_rhs));
+    }
+    {
+        ProfileScope ps(ctx, "poisson_phi_scatter");
+        hipLaunchKernelGGL(k_phi_scatter, grid, block, 0, ctx->stream, g, s->phi, ctx->d_rhs);
+        BZ_LAUNCH_CHECK();
+    }
+    return BZ_OK;
+}
+
+extern "C" int bz_compute_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt)
+{
+    if (!ctx || !s) return BZ_ERR_INVALID;
+    double *mf[3] = {s->rho_u, s->rho_v, s->rho_w};
+    int mk[3] = {0, 0, 1};
+    int rc = bzi_fill_halos_multi(ctx, mf, mk, 3);   // anelastic_time_stepping.jl:29
+    if (rc) return rc;
+    rc = bzi_poisson_solve(ctx, s, dt);
+    if (rc) return rc;
+    return bzi_fill_halo(ctx, s->phi, 0);            // anelastic_time_stepping.jl:36
+}

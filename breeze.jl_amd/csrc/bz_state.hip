@@ -1,0 +1,202 @@
+// bz_state.hip — streaming kernels of the anelastic step: velocity / thermodynamic diagnosis,
+// SSP-RK3 stage update, pressure projection.
+#include "bz_internal.h"
+
+#define TX 64
+#define TY 4
+
+// ---- _compute_velocities! (/root/reference/src/AtmosphereModels/update_atmosphere_model_state.jl:248-254)
+// launch covers k = 0..Nz (Face length on Bounded z, :138-145).
+__global__ __launch_bounds__(TX *TY) void k_velocities(DevGrid g, double *__restrict__ u,
+                                                      double *__restrict__ v, double *__restrict__ w,
+                                                      const double *__restrict__ ru,
+                                                      const double *__restrict__ rv,
+                                                      const double *__restrict__ rw)
+{
+    int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
+    if (i >= g.Nx || j >= g.Ny) return;
+    long long n = g.idx(i, j, k);
+    double rc = g.rho[k], rf = g.rho_f[k];
+    u[n] = ru[n] / rc;
+    v[n] = rv[n] / rc;
+    w[n] = rw[n] / rf;
+}
+
+// ---- _compute_auxiliary_thermodynamic_variables! (:256-292) with
+// potential_temperature_formulation.jl:115-145 and Thermodynamics/dynamic_states.jl:31-58.
+__global__ __launch_bounds__(TX *TY) void k_thermo(DevGrid g, double *__restrict__ theta,
+                                                  double *__restrict__ qv, double *__restrict__ T,
+                                                  const double *__restrict__ rtheta,
+                                                  const double *__restrict__ rq)
+{
+    int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
+    if (i >= g.Nx || j >= g.Ny) return;
+    long long n = g.idx(i, j, k);
+    double rho = g.rho[k];
+    double th = rtheta[n] / rho;
+    double q = rq[n] / rho;
+    theta[n] = th;
+    qv[n] = q;
+    double qd = 1.0 - q;
+    double Rm = qd * g.Rd + q * g.Rv;
+    double cpm = qd * g.cpd + q * g.cpv;
+    double Pi = pow(g.p_r[k] / g.pst, Rm / cpm);
+    T[n] = Pi * th;
+}
+
+struct RKFields {
+    double *u[5];
+    const double *u0[5];
+    const double *G[5];
+};
+
+// ---- _ssp_rk3_substep! (/root/reference/src/TimeSteppers/ssp_runge_kutta_3.jl:167-173), all five
+// prognostic fields in one pass.  Field 2 is rho_w: wall faces (k = 0, Nz) are never updated.
+__global__ __launch_bounds__(TX *TY) void k_rk3_substep(DevGrid g, RKFields F, double dt, double alpha)
+{
+    int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
+    if (i >= g.Nx || j >= g.Ny) return;
+    long long n = g.idx(i, j, k);
+    double oma = 1.0 - alpha;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        if (f == 2 && k == 0) continue;
+        F.u[f][n] = oma * F.u0[f][n] + alpha * (F.u[f][n] + dt * F.G[f][n]);
+    }
+}
+
+// ---- _pressure_correct_momentum! (/root/reference/src/AnelasticEquations/anelastic_time_stepping.jl:45-54)
+__global__ __launch_bounds__(TX *TY) void k_pressure_correct(DevGrid g, double *__restrict__ ru,
+                                                            double *__restrict__ rv,
+                                                            double *__restrict__ rw,
+                                                            const double *__restrict__ phi, double dt)
+{
+    int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
+    if (i >= g.Nx || j >= g.Ny) return;
+    long long n = g.idx(i, j, k);
+    double rc = g.rho[k], rf = g.rho_f[k];
+    double p = phi[n];
+    ru[n] -= rc * dt * ((p - phi[n - 1]) * g.rdx);
+    rv[n] -= rc * dt * ((p - phi[n - g.Sx]) * g.rdy);
+    rw[n] -= rf * dt * ((p - phi[n - g.Sxy]) * g.rdzf[k]);
+}
+
+__global__ __launch_bounds__(256) void k_copy5(long long count, double *d0, const double *s0, double *d1,
+                                               const double *s1, double *d2, const double *s2,
+                                               double *d3, const double *s3, long long count_w,
+                                               double *dw, const double *sw)
+{
+    long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long stride = (long long)gridDim.x * 256;
+    for (; n < count_w; n += stride) {
+        if (n < count) { d0[n] = s0[n]; d1[n] = s1[n]; d2[n] = s2[n]; d3[n] = s3[n]; }
+        dw[n] = sw[n];
+    }
+}
+
+__global__ __launch_bounds__(TX *TY) void k_max_abs_div(DevGrid g, const double *__restrict__ ru,
+                                                       const double *__restrict__ rv,
+                                                       const double *__restrict__ rw,
+                                                       unsigned long long *out)
+{
+    int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
+    double d = 0.0;
+    if (i < g.Nx && j < g.Ny) {
+        long long n = g.idx(i, j, k);
+        double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
+        double a = Ax * ru[n + 1] - Ax * ru[n];
+        double b = Ay * rv[n + g.Sx] - Ay * rv[n];
+        double c = Az * rw[n + g.Sxy] - Az * rw[n];
+        d = fabs(g.Vinv_c[k] * (a + b + c));
+    }
+    for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_down(d, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(d));
+}
+
+static inline dim3 cell_grid(const DevGrid &g, int nz) { return dim3((g.Nx + TX - 1) / TX, (g.Ny + TY - 1) / TY, nz); }
+
+extern "C" int bz_compute_velocities(bz_ctx *ctx, const bz_state *s)
+{
+    if (!ctx || !s) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    // halos of momentum first (update_atmosphere_model_state.jl:135-136)
+    double *mf[3] = {s->rho_u, s->rho_v, s->rho_w};
+    int mk[3] = {0, 0, 1};
+    int rc = bzi_fill_halos_multi(ctx, mf, mk, 3);
+    if (rc) return rc;
+    {
+        ProfileScope ps(ctx, "compute_velocities");
+        hipLaunchKernelGGL(k_velocities, cell_grid(g, g.Nz + 1), dim3(TX, TY), 0, ctx->stream, g, s->u, s->v,
+                           s->w, s->rho_u, s->rho_v, s->rho_w);
+        BZ_LAUNCH_CHECK();
+    }
+    double *vf[3] = {s->u, s->v, s->w};
+    int vk[3] = {2, 2, 3};
+    return bzi_fill_halos_multi(ctx, vf, vk, 3);
+}
+
+extern "C" int bz_compute_auxiliary_thermodynamic_variables(bz_ctx *ctx, const bz_state *s)
+{
+    if (!ctx || !s) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    {
+        ProfileScope ps(ctx, "compute_auxiliary_thermodynamic_variables");
+        hipLaunchKernelGGL(k_thermo, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, s->theta, s->q, s->T,
+                           s->rho_theta, s->rho_q);
+        BZ_LAUNCH_CHECK();
+    }
+    double *f[3] = {s->T, s->q, s->theta};
+    int kd[3] = {0, 0, 0};
+    return bzi_fill_halos_multi(ctx, f, kd, 3);
+}
+
+extern "C" int bz_store_initial_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0)
+{
+    if (!ctx || !s || !U0) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "store_initial_state");
+    long long nc = g.Sxy * (g.Nz + 2 * g.Hz), nw = g.Sxy * (g.Nz + 1 + 2 * g.Hz);
+    hipLaunchKernelGGL(k_copy5, dim3(256 * 32), dim3(256), 0, ctx->stream, nc, U0->rho_u, s->rho_u, U0->rho_v,
+                       s->rho_v, U0->rho_theta, s->rho_theta, U0->rho_q, s->rho_q, nw, U0->rho_w, s->rho_w);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+extern "C" int bz_ssp_rk3_substep(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
+                                  const bz_prognostic *G, double dt, double alpha)
+{
+    if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "ssp_rk3_substep");
+    RKFields F;
+    F.u[0] = s->rho_u; F.u[1] = s->rho_v; F.u[2] = s->rho_w; F.u[3] = s->rho_theta; F.u[4] = s->rho_q;
+    F.u0[0] = U0->rho_u; F.u0[1] = U0->rho_v; F.u0[2] = U0->rho_w; F.u0[3] = U0->rho_theta; F.u0[4] = U0->rho_q;
+    F.G[0] = G->rho_u; F.G[1] = G->rho_v; F.G[2] = G->rho_w; F.G[3] = G->rho_theta; F.G[4] = G->rho_q;
+    hipLaunchKernelGGL(k_rk3_substep, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, F, dt, alpha);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+extern "C" int bz_make_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt)
+{
+    if (!ctx || !s) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "make_pressure_correction");
+    hipLaunchKernelGGL(k_pressure_correct, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, s->rho_u,
+                       s->rho_v, s->rho_w, s->phi, dt);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+extern "C" int bz_max_abs_divergence(bz_ctx *ctx, const bz_state *s, double *out)
+{
+    if (!ctx || !s || !out) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    BZ_HIP(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_max_abs_div, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, s->rho_u, s->rho_v,
+                       s->rho_w, (unsigned long long *)ctx->d_scalar);
+    BZ_LAUNCH_CHECK();
+    BZ_HIP(hipMemcpyAsync(out, ctx->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    BZ_HIP(hipStreamSynchronize(ctx->stream));
+    return BZ_OK;
+}

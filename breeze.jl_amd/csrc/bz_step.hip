@@ -1,0 +1,39 @@
+// bz_step.hip — host-side orchestration of the device-resident anelastic SSP-RK3 step.
+//   update_state!  /root/reference/src/AtmosphereModels/update_atmosphere_model_state.jl:41-68
+//   time_step!     /root/reference/src/TimeSteppers/ssp_runge_kutta_3.jl:209-278
+// Everything is enqueued on ctx->stream; there is no host synchronisation inside a step.
+#include "bz_internal.h"
+
+extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, int compute_tendencies)
+{
+    if (!ctx || !s || (compute_tendencies && !G)) return BZ_ERR_INVALID;
+    int rc;
+    // fill_halo_regions!(prognostic_fields(model))  (:48) — momentum halos are filled inside
+    // bz_compute_velocities (:135-136), the scalars here.
+    double *sf[2] = {s->rho_theta, s->rho_q};
+    int sk[2] = {0, 0};
+    if ((rc = bzi_fill_halos_multi(ctx, sf, sk, 2))) return rc;
+    // compute_auxiliary_variables!  (:207-223)
+    if ((rc = bz_compute_velocities(ctx, s))) return rc;
+    if ((rc = bz_compute_auxiliary_thermodynamic_variables(ctx, s))) return rc;
+    // compute_tendencies!  (:63)
+    if (compute_tendencies && (rc = bz_compute_tendencies(ctx, s, G))) return rc;
+    return BZ_OK;
+}
+
+extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
+                                      const bz_prognostic *G, double dt)
+{
+    if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
+    int rc;
+    if ((rc = bz_store_initial_state(ctx, s, U0))) return rc;               // :223
+    const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
+    for (int stage = 0; stage < 3; ++stage) {
+        const double alpha = alphas[stage];
+        if ((rc = bz_ssp_rk3_substep(ctx, s, U0, G, dt, alpha))) return rc;          // :230,244,258
+        if ((rc = bz_compute_pressure_correction(ctx, s, alpha * dt))) return rc;    // :232,246,260
+        if ((rc = bz_make_pressure_correction(ctx, s, alpha * dt))) return rc;       // :233,247,261
+        if ((rc = bz_update_state(ctx, s, G, 1))) return rc;                         // :236,250,270
+    }
+    return BZ_OK;
+}

@@ -1,0 +1,306 @@
+// bz_tendency.hip — WENO-5 flux-form tendencies of the dry anelastic AtmosphereModel.
+//   scalar_tendency / potential_temperature_tendency: G = -div_rhoUc
+//       /root/reference/src/Advection.jl:20-35, src/AtmosphereModels/dynamics_kernel_functions.jl:132-159,
+//       src/PotentialTemperatureFormulations/potential_temperature_tendency.jl:66-106
+//   x/y/z_momentum_tendency: G = -div(rhoU (x) u) [+ Iz(buoyancy) for z]
+//       src/AtmosphereModels/dynamics_kernel_functions.jl:54-130, src/AnelasticEquations/anelastic_buoyancy.jl:36-72
+//   launcher: compute_tendencies!  src/AtmosphereModels/update_atmosphere_model_state.jl:294-387
+//
+// Kernel shape (all four kernels): a block owns a 64 x TYB tile of columns and marches upward
+// through a chunk of z levels.  The 6-value vertical stencil of the advected quantity lives in a
+// register ring, the vertical flux through the lower face is carried from the previous level, and
+// horizontal stencils are read straight from global memory (L1/L2 resident: the tile's rows were
+// touched by the neighbouring lanes / rows a few instructions earlier).
+#include "bz_internal.h"
+#include "bz_weno.h"
+
+#define TYB 4
+
+__device__ __forceinline__ double flux_z_scalar(const DevGrid &g, double wt, double m3, double m2,
+                                                double m1, double p0, double p1, double p2, int kface)
+{
+    int B = bz_buffer_face(kface, g.Nz);
+    double cR = bz_upB(m3, m2, m1, p0, p1, p2, wt > 0.0, B);
+    return g.rho_f[kface] * ((g.Az * wt) * cR);
+}
+
+__global__ __launch_bounds__(64 * TYB) void k_scalar_tendency(DevGrid g, double *__restrict__ Gc,
+                                                             const double *__restrict__ u,
+                                                             const double *__restrict__ v,
+                                                             const double *__restrict__ w,
+                                                             const double *__restrict__ c, int kchunk)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * TYB + threadIdx.y;
+    if (i >= g.Nx || j >= g.Ny) return;
+    const int k0 = blockIdx.z * kchunk;
+    const int k1 = min(k0 + kchunk, g.Nz);
+    const long long sy = g.Sx, sz = g.Sxy;
+    long long n = g.idx(i, j, k0);
+
+    double zm3 = c[n - 3 * sz], zm2 = c[n - 2 * sz], zm1 = c[n - sz], z0 = c[n], zp1 = c[n + sz], zp2 = c[n + 2 * sz];
+    double Fz_lo = flux_z_scalar(g, w[n], zm3, zm2, zm1, z0, zp1, zp2, k0);
+
+    for (int k = k0; k < k1; ++k, n += sz) {
+        double zp3 = c[n + 3 * sz];
+        double Fz_hi = flux_z_scalar(g, w[n + sz], zm2, zm1, z0, zp1, zp2, zp3, k + 1);
+
+        const double rho = g.rho[k], Ax = g.Ax[k], Ay = g.Ay[k];
+        double xm3 = c[n - 3], xm2 = c[n - 2], xm1 = c[n - 1], xp1 = c[n + 1], xp2 = c[n + 2], xp3 = c[n + 3];
+        double u0 = u[n], u1 = u[n + 1];
+        double Fx_lo = rho * ((Ax * u0) * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, u0 > 0.0));
+        double Fx_hi = rho * ((Ax * u1) * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, u1 > 0.0));
+
+        double ym3 = c[n - 3 * sy], ym2 = c[n - 2 * sy], ym1 = c[n - sy], yp1 = c[n + sy], yp2 = c[n + 2 * sy], yp3 = c[n + 3 * sy];
+        double v0 = v[n], v1 = v[n + sy];
+        double Fy_lo = rho * ((Ay * v0) * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0));
+        double Fy_hi = rho * ((Ay * v1) * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, v1 > 0.0));
+
+        Gc[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
+
+        zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
+        Fz_lo = Fz_hi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// x-momentum
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double flux_Wu(const DevGrid &g, const double *__restrict__ rw, long long nf,
+                                          double m3, double m2, double m1, double p0, double p1, double p2,
+                                          int kface)
+{   // at (f,c,f): advecting flux = Centered4 in x of Az*rho_w to x-face i
+    double Az = g.Az;
+    double wt = bz_symm4(Az * rw[nf - 2], Az * rw[nf - 1], Az * rw[nf], Az * rw[nf + 1]);
+    double uR = bz_upB(m3, m2, m1, p0, p1, p2, wt > 0.0, bz_buffer_face(kface, g.Nz));
+    return wt * uR;
+}
+
+__global__ __launch_bounds__(64 * TYB) void k_u_tendency(DevGrid g, double *__restrict__ Gu,
+                                                        const double *__restrict__ ru,
+                                                        const double *__restrict__ rv,
+                                                        const double *__restrict__ rw,
+                                                        const double *__restrict__ u, int kchunk)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * TYB + threadIdx.y;
+    if (i >= g.Nx || j >= g.Ny) return;
+    const int k0 = blockIdx.z * kchunk;
+    const int k1 = min(k0 + kchunk, g.Nz);
+    const long long sy = g.Sx, sz = g.Sxy;
+    long long n = g.idx(i, j, k0);
+
+    double zm3 = u[n - 3 * sz], zm2 = u[n - 2 * sz], zm1 = u[n - sz], z0 = u[n], zp1 = u[n + sz], zp2 = u[n + 2 * sz];
+    double Fz_lo = flux_Wu(g, rw, n, zm3, zm2, zm1, z0, zp1, zp2, k0);
+
+    for (int k = k0; k < k1; ++k, n += sz) {
+        double zp3 = u[n + 3 * sz];
+        double Fz_hi = flux_Wu(g, rw, n + sz, zm2, zm1, z0, zp1, zp2, zp3, k + 1);
+        const double Ax = g.Ax[k], Ay = g.Ay[k];
+
+        // x: F_Uu at centres i (hi) and i-1 (lo)
+        double q_m2 = Ax * ru[n - 2], q_m1 = Ax * ru[n - 1], q_0 = Ax * ru[n], q_p1 = Ax * ru[n + 1], q_p2 = Ax * ru[n + 2];
+        double xm3 = u[n - 3], xm2 = u[n - 2], xm1 = u[n - 1], xp1 = u[n + 1], xp2 = u[n + 2], xp3 = u[n + 3];
+        double ut_hi = bz_symm4(q_m1, q_0, q_p1, q_p2);
+        double ut_lo = bz_symm4(q_m2, q_m1, q_0, q_p1);
+        double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
+        double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
+
+        // y: F_Vu at y-faces j (lo) and j+1 (hi)
+        double vt_lo = bz_symm4(Ay * rv[n - 2], Ay * rv[n - 1], Ay * rv[n], Ay * rv[n + 1]);
+        double vt_hi = bz_symm4(Ay * rv[n + sy - 2], Ay * rv[n + sy - 1], Ay * rv[n + sy], Ay * rv[n + sy + 1]);
+        double ym3 = u[n - 3 * sy], ym2 = u[n - 2 * sy], ym1 = u[n - sy], yp1 = u[n + sy], yp2 = u[n + 2 * sy], yp3 = u[n + 3 * sy];
+        double Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
+        double Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+
+        Gu[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
+
+        zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
+        Fz_lo = Fz_hi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y-momentum
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double flux_Wv(const DevGrid &g, const double *__restrict__ rw, long long nf,
+                                          double m3, double m2, double m1, double p0, double p1, double p2,
+                                          int kface)
+{   // at (c,f,f): Centered4 in y of Az*rho_w to y-face j
+    double Az = g.Az;
+    long long sy = g.Sx;
+    double wt = bz_symm4(Az * rw[nf - 2 * sy], Az * rw[nf - sy], Az * rw[nf], Az * rw[nf + sy]);
+    double vR = bz_upB(m3, m2, m1, p0, p1, p2, wt > 0.0, bz_buffer_face(kface, g.Nz));
+    return wt * vR;
+}
+
+__global__ __launch_bounds__(64 * TYB) void k_v_tendency(DevGrid g, double *__restrict__ Gv,
+                                                        const double *__restrict__ ru,
+                                                        const double *__restrict__ rv,
+                                                        const double *__restrict__ rw,
+                                                        const double *__restrict__ v, int kchunk)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * TYB + threadIdx.y;
+    if (i >= g.Nx || j >= g.Ny) return;
+    const int k0 = blockIdx.z * kchunk;
+    const int k1 = min(k0 + kchunk, g.Nz);
+    const long long sy = g.Sx, sz = g.Sxy;
+    long long n = g.idx(i, j, k0);
+
+    double zm3 = v[n - 3 * sz], zm2 = v[n - 2 * sz], zm1 = v[n - sz], z0 = v[n], zp1 = v[n + sz], zp2 = v[n + 2 * sz];
+    double Fz_lo = flux_Wv(g, rw, n, zm3, zm2, zm1, z0, zp1, zp2, k0);
+
+    for (int k = k0; k < k1; ++k, n += sz) {
+        double zp3 = v[n + 3 * sz];
+        double Fz_hi = flux_Wv(g, rw, n + sz, zm2, zm1, z0, zp1, zp2, zp3, k + 1);
+        const double Ax = g.Ax[k], Ay = g.Ay[k];
+
+        // x: F_Uv at x-faces i (lo) and i+1 (hi); advecting flux = Centered4 in y of Ax*rho_u
+        double ut_lo = bz_symm4(Ax * ru[n - 2 * sy], Ax * ru[n - sy], Ax * ru[n], Ax * ru[n + sy]);
+        double ut_hi = bz_symm4(Ax * ru[n + 1 - 2 * sy], Ax * ru[n + 1 - sy], Ax * ru[n + 1], Ax * ru[n + 1 + sy]);
+        double xm3 = v[n - 3], xm2 = v[n - 2], xm1 = v[n - 1], xp1 = v[n + 1], xp2 = v[n + 2], xp3 = v[n + 3];
+        double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
+        double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
+
+        // y: F_Vv at centres j (hi) and j-1 (lo)
+        double q_m2 = Ay * rv[n - 2 * sy], q_m1 = Ay * rv[n - sy], q_0 = Ay * rv[n], q_p1 = Ay * rv[n + sy], q_p2 = Ay * rv[n + 2 * sy];
+        double ym3 = v[n - 3 * sy], ym2 = v[n - 2 * sy], ym1 = v[n - sy], yp1 = v[n + sy], yp2 = v[n + 2 * sy], yp3 = v[n + 3 * sy];
+        double vt_hi = bz_symm4(q_m1, q_0, q_p1, q_p2);
+        double vt_lo = bz_symm4(q_m2, q_m1, q_0, q_p1);
+        double Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+        double Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
+
+        Gv[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
+
+        zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
+        Fz_lo = Fz_hi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// z-momentum (+ buoyancy), interior faces k = 1..Nz-1 only
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double buoyancy_ccc(const DevGrid &g, double T, double q, int k)
+{   // anelastic_buoyancy.jl:36-72, dry reference (R_m,r = Rd)
+    double Rmr = g.Rd;
+    double Rm = (1.0 - q) * g.Rd + q * g.Rv;
+    double rhop = g.rho[k] * (Rmr * g.T_r[k] / (Rm * T) - 1.0);
+    return -g.g * rhop;
+}
+
+// Centered in z (order 4 where the WENO5 buffer fits, else 2) of A(k)*M to z-face k
+__device__ __forceinline__ double symm_z_face(const DevGrid &g, const double *__restrict__ A,
+                                              const double *__restrict__ M, long long n, int k, int B)
+{
+    long long sz = g.Sxy;
+    if (B == 3) return bz_symm4(A[k - 2] * M[n - 2 * sz], A[k - 1] * M[n - sz], A[k] * M[n], A[k + 1] * M[n + sz]);
+    return bz_symm2(A[k - 1] * M[n - sz], A[k] * M[n]);
+}
+
+__device__ __forceinline__ double flux_Ww(const DevGrid &g, const double *__restrict__ rw, long long n, int k,
+                                          double m3, double m2, double m1, double p0, double p1, double p2)
+{   // at (c,c,c) centre k: faces k-1..k+2 for the advecting flux, (k-2..k+3) for w
+    long long sz = g.Sxy;
+    int B = bz_buffer_center(k, g.Nz);
+    double Az = g.Az;
+    double wt = (B == 3) ? bz_symm4(Az * rw[n - sz], Az * rw[n], Az * rw[n + sz], Az * rw[n + 2 * sz])
+                         : bz_symm2(Az * rw[n], Az * rw[n + sz]);
+    double wR = bz_upB(m3, m2, m1, p0, p1, p2, wt > 0.0, B);
+    return wt * wR;
+}
+
+__global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__restrict__ Gw,
+                                                        const double *__restrict__ ru,
+                                                        const double *__restrict__ rv,
+                                                        const double *__restrict__ rw,
+                                                        const double *__restrict__ w,
+                                                        const double *__restrict__ T,
+                                                        const double *__restrict__ qv, int kchunk)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * TYB + threadIdx.y;
+    if (i >= g.Nx || j >= g.Ny) return;
+    const int k0 = 1 + blockIdx.z * kchunk;          // first face of this chunk
+    const int k1 = min(k0 + kchunk, g.Nz);           // faces k0 .. k1-1  (<= Nz-1)
+    if (k0 >= k1) return;
+    const long long sy = g.Sx, sz = g.Sxy;
+    long long n = g.idx(i, j, k0);
+
+    // ring of w around centre k-1 (faces k-3 .. k+2) to start; centre k needs faces k-2..k+3
+    double zm3 = w[n - 3 * sz], zm2 = w[n - 2 * sz], zm1 = w[n - sz], z0 = w[n], zp1 = w[n + sz], zp2 = w[n + 2 * sz];
+    double Fz_lo = flux_Ww(g, rw, n - sz, k0 - 1, zm3, zm2, zm1, z0, zp1, zp2);
+    double b_lo = buoyancy_ccc(g, T[n - sz], qv[n - sz], k0 - 1);
+
+    for (int k = k0; k < k1; ++k, n += sz) {
+        double zp3 = w[n + 3 * sz];
+        double Fz_hi = flux_Ww(g, rw, n, k, zm2, zm1, z0, zp1, zp2, zp3);
+        double b_hi = buoyancy_ccc(g, T[n], qv[n], k);
+        const int Bf = bz_buffer_face(k, g.Nz);
+
+        // x: F_Uw at x-faces i (lo), i+1 (hi): advecting flux = centred-in-z of Ax(k)*rho_u to face k
+        double ut_lo = symm_z_face(g, g.Ax, ru, n, k, Bf);
+        double ut_hi = symm_z_face(g, g.Ax, ru, n + 1, k, Bf);
+        double xm3 = w[n - 3], xm2 = w[n - 2], xm1 = w[n - 1], xp1 = w[n + 1], xp2 = w[n + 2], xp3 = w[n + 3];
+        double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
+        double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
+
+        // y: F_Vw at y-faces j (lo), j+1 (hi)
+        double vt_lo = symm_z_face(g, g.Ay, rv, n, k, Bf);
+        double vt_hi = symm_z_face(g, g.Ay, rv, n + sy, k, Bf);
+        double ym3 = w[n - 3 * sy], ym2 = w[n - 2 * sy], ym1 = w[n - sy], yp1 = w[n + sy], yp2 = w[n + 2 * sy], yp3 = w[n + 3 * sy];
+        double Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
+        double Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+
+        double bf = 0.5 * (b_lo + b_hi);
+        Gw[n] = -(g.Vinv_f[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo))) + bf;
+
+        zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
+        Fz_lo = Fz_hi;
+        b_lo = b_hi;
+    }
+}
+
+static int pick_kchunk(const DevGrid &g, int nlev)
+{
+    long long tiles = (long long)((g.Nx + 63) / 64) * ((g.Ny + TYB - 1) / TYB);
+    long long want = (4096 + tiles - 1) / tiles;          // aim for >= 4096 blocks
+    if (want < 1) want = 1;
+    long long maxchunks = nlev / 8 > 0 ? nlev / 8 : 1;    // keep >= 8 levels per chunk
+    if (want > maxchunks) want = maxchunks;
+    return (int)((nlev + want - 1) / want);
+}
+
+extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    if (!ctx || !s || !G) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    dim3 block(64, TYB);
+    int kc = pick_kchunk(g, g.Nz);
+    dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
+    {
+        ProfileScope ps(ctx, "x_momentum_tendency");
+        hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc);
+    }
+    {
+        ProfileScope ps(ctx, "y_momentum_tendency");
+        hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc);
+    }
+    {
+        ProfileScope ps(ctx, "z_momentum_tendency");
+        int kcw = pick_kchunk(g, g.Nz - 1);
+        dim3 gridw(grid.x, grid.y, (g.Nz - 1 + kcw - 1) / kcw);
+        hipLaunchKernelGGL(k_w_tendency, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
+                           s->T, s->q, kcw);
+    }
+    {
+        ProfileScope ps(ctx, "potential_temperature_tendency");
+        hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_theta, s->u, s->v, s->w, s->theta, kc);
+    }
+    {
+        ProfileScope ps(ctx, "moisture_tendency");
+        hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q, kc);
+    }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}

@@ -1,0 +1,91 @@
+// bz_weno.h — device-side reconstruction primitives (WENO-Z order 5 with the order-3 / order-1
+// buffer schemes used next to Bounded walls, Centered(order 4/2) advecting-flux interpolation).
+// Semantics: Oceananigans.Advection as called from /root/reference/src/Advection.jl:20-35 and
+// /root/reference/src/AtmosphereModels/dynamics_kernel_functions.jl:54-62.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define BZ_WENO_EPS 1e-8
+
+// cells (a,b,c,d,e), upwind cell c, value at the face between c and d
+__device__ __forceinline__ double bz_weno5(double a, double b, double c, double d, double e)
+{
+    double b0 = c * (10.0 * c - 31.0 * d + 11.0 * e) + d * (25.0 * d - 19.0 * e) + e * (4.0 * e);
+    double b1 = b * (4.0 * b - 13.0 * c + 5.0 * d) + c * (13.0 * c - 13.0 * d) + d * (4.0 * d);
+    double b2 = a * (4.0 * a - 19.0 * b + 11.0 * c) + b * (25.0 * b - 31.0 * c) + c * (10.0 * c);
+    double tau = fabs(b0 - b2);
+    double r0 = tau / (b0 + BZ_WENO_EPS);
+    double r1 = tau / (b1 + BZ_WENO_EPS);
+    double r2 = tau / (b2 + BZ_WENO_EPS);
+    double a0 = (3.0 / 10.0) * (1.0 + r0 * r0);
+    double a1 = (3.0 / 5.0) * (1.0 + r1 * r1);
+    double a2 = (1.0 / 10.0) * (1.0 + r2 * r2);
+    double p0 = (1.0 / 3.0) * c + (5.0 / 6.0) * d - (1.0 / 6.0) * e;
+    double p1 = -(1.0 / 6.0) * b + (5.0 / 6.0) * c + (1.0 / 3.0) * d;
+    double p2 = (1.0 / 3.0) * a - (7.0 / 6.0) * b + (11.0 / 6.0) * c;
+    return (a0 * p0 + a1 * p1 + a2 * p2) / (a0 + a1 + a2);
+}
+
+// cells (a,b,c), upwind cell b, value at the face between b and c
+__device__ __forceinline__ double bz_weno3(double a, double b, double c)
+{
+    double b0 = (c - b) * (c - b);
+    double b1 = (b - a) * (b - a);
+    double tau = fabs(b0 - b1);
+    double r0 = tau / (b0 + BZ_WENO_EPS);
+    double r1 = tau / (b1 + BZ_WENO_EPS);
+    double a0 = (2.0 / 3.0) * (1.0 + r0 * r0);
+    double a1 = (1.0 / 3.0) * (1.0 + r1 * r1);
+    double p0 = 0.5 * b + 0.5 * c;
+    double p1 = -0.5 * a + 1.5 * b;
+    return (a0 * p0 + a1 * p1) / (a0 + a1);
+}
+
+// Six values straddling the target (which lies between m1 and p0).  left = advecting flux > 0.
+__device__ __forceinline__ double bz_up5(double m3, double m2, double m1, double p0, double p1,
+                                         double p2, bool left)
+{
+    double a = left ? m3 : p2;
+    double b = left ? m2 : p1;
+    double c = left ? m1 : p0;
+    double d = left ? p0 : m1;
+    double e = left ? p1 : m2;
+    return bz_weno5(a, b, c, d, e);
+}
+__device__ __forceinline__ double bz_up3(double m2, double m1, double p0, double p1, bool left)
+{
+    double a = left ? m2 : p1;
+    double b = left ? m1 : p0;
+    double c = left ? p0 : m1;
+    return bz_weno3(a, b, c);
+}
+// buffer-aware (B wave-uniform: 3, 2 or 1)
+__device__ __forceinline__ double bz_upB(double m3, double m2, double m1, double p0, double p1,
+                                         double p2, bool left, int B)
+{
+    if (B == 3) return bz_up5(m3, m2, m1, p0, p1, p2, left);
+    if (B == 2) return bz_up3(m2, m1, p0, p1, left);
+    return left ? m1 : p0;
+}
+
+// Largest buffer usable at index idx of a Bounded direction with N cells
+// (face target: B <= idx <= N-B; centre target: B-1 <= idx <= N-B).
+__device__ __forceinline__ int bz_buffer_face(int idx, int N)
+{
+    if (idx >= 3 && idx <= N - 3) return 3;
+    if (idx >= 2 && idx <= N - 2) return 2;
+    return 1;
+}
+__device__ __forceinline__ int bz_buffer_center(int idx, int N)
+{
+    if (idx >= 2 && idx <= N - 3) return 3;
+    if (idx >= 1 && idx <= N - 2) return 2;
+    return 1;
+}
+
+// Centered(order 4) of four values straddling the target (between qm1 and q0); order 2 fallback.
+__device__ __forceinline__ double bz_symm4(double qm2, double qm1, double q0, double qp1)
+{
+    return (7.0 / 12.0) * (qm1 + q0) - (1.0 / 12.0) * (qm2 + qp1);
+}
+__device__ __forceinline__ double bz_symm2(double qm1, double q0) { return 0.5 * (qm1 + q0); }

@@ -1,0 +1,351 @@
+"""Host-side mirror of Breeze's AtmosphereModel API for the anelastic hot path.
+
+Julia is not available in the build image, so this module plays the role of the Julia host code
+above the C ABI (include/breeze_hip.h): same names, argument meaning and call order as
+  AtmosphereModel(grid; dynamics, advection, ...)   src/AtmosphereModels/atmosphere_model.jl:114-314
+  set!(model; θ=..., u=..., ...)                    src/AtmosphereModels/set_atmosphere_model.jl:198-362
+  update_state!(model; compute_tendencies)          src/AtmosphereModels/update_atmosphere_model_state.jl:41-68
+  time_step!(model, Δt)                             src/TimeSteppers/ssp_runge_kutta_3.jl:209-278
+(paths relative to /root/reference).  Julia's `f!` is spelled `f_` here.
+
+All field memory lives on the GPU (torch tensors are only the allocator/stream plumbing); every
+numerical operation of the path is a HIP kernel behind libbreeze_hip.so.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .grids import Bounded, Center, Face, Periodic, RectilinearGrid
+from .thermodynamics import (ReferenceState, ThermodynamicConstants, dry_air_gas_constant,
+                             vapor_gas_constant)
+
+
+class WENO:
+    """WENO(order=5): only the 5th-order scheme is implemented on the device."""
+
+    def __init__(self, order=5):
+        if order != 5:
+            raise NotImplementedError("only WENO(order=5) is implemented in the HIP path")
+        self.order = order
+
+
+class AnelasticDynamics:
+    """AnelasticDynamics(reference_state)  (src/AnelasticEquations/anelastic_dynamics.jl:5-8)."""
+
+    def __init__(self, reference_state):
+        self.reference_state = reference_state
+        self.pressure_anomaly = None   # materialised by AtmosphereModel
+
+
+class Clock:
+    def __init__(self):
+        self.time, self.iteration = 0.0, 0
+
+
+class Field:
+    """A device-resident Oceananigans-style field: `.parent` is the halo-inclusive array
+    ((z, y, x)-shaped, x fastest), `.interior` a view of the interior."""
+
+    def __init__(self, grid, loc, device):
+        import torch
+        self.grid, self.loc = grid, loc
+        self.zface = loc[2] is Face
+        self.parent = torch.zeros(grid.parent_shape(self.zface), dtype=torch.float64, device=device)
+
+    @property
+    def interior(self):
+        return self.parent[self.grid.interior_slices(self.zface)]
+
+    def ptr(self):
+        return self.parent.data_ptr()
+
+    def set_interior(self, value):
+        import torch
+        g = self.grid
+        if callable(value):
+            x, y, z = g.nodes(self.loc)
+            value = value(x, y, z)
+        shape = tuple(self.interior.shape)
+        arr = np.broadcast_to(np.asarray(value, dtype=np.float64), shape)
+        self.interior.copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+
+    def cpu(self):
+        return self.parent.cpu().numpy()
+
+    def interior_cpu(self):
+        return self.interior.cpu().numpy()
+
+
+_LOC = {"ccc": (Center, Center, Center), "fcc": (Face, Center, Center),
+        "cfc": (Center, Face, Center), "ccf": (Center, Center, Face)}
+
+# keyword spellings accepted by set_ (Julia names and ASCII transliterations)
+_ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "ρθ": "ρθ", "rho_theta": "ρθ",
+            "u": "u", "v": "v", "w": "w", "ρu": "ρu", "ρv": "ρv", "ρw": "ρw",
+            "rho_u": "ρu", "rho_v": "ρv", "rho_w": "ρw",
+            "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q", "ρqᵗ": "ρq", "ρqᵛ": "ρq", "rho_q": "ρq",
+            # NFKC-normalised spellings (Python normalises identifiers used as keywords)
+            "θli": "θ", "ρqt": "ρq", "ρqv": "ρq"}
+
+
+class AtmosphereModel:
+    """AtmosphereModel(grid; dynamics=AnelasticDynamics(ReferenceState(grid)), advection=WENO(order=5),
+    formulation=:LiquidIcePotentialTemperature, thermodynamic_constants, timestepper=:SSPRungeKutta3).
+
+    Dry anelastic dynamics without closure / Coriolis / forcing / microphysics — the configuration
+    of BASELINE.json configs 1-2 and 4."""
+
+    def __init__(self, grid, dynamics=None, advection=None, thermodynamic_constants=None,
+                 formulation="LiquidIcePotentialTemperature", timestepper="SSPRungeKutta3",
+                 closure=None, coriolis=None, microphysics=None, forcing=None, device="cuda:0"):
+        import torch
+        if not isinstance(grid, RectilinearGrid):
+            raise TypeError("grid must be a RectilinearGrid")
+        if grid.topology != (Periodic, Periodic, Bounded):
+            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded)")
+        if formulation not in ("LiquidIcePotentialTemperature", ":LiquidIcePotentialTemperature"):
+            raise NotImplementedError("only the liquid-ice potential temperature formulation is implemented")
+        if timestepper not in ("SSPRungeKutta3", ":SSPRungeKutta3"):
+            raise NotImplementedError("only SSPRungeKutta3 is implemented")
+        for name, val in (("closure", closure), ("coriolis", coriolis), ("microphysics", microphysics),
+                          ("forcing", forcing)):
+            if val is not None:
+                raise NotImplementedError(f"{name} is outside the hot-path scope of this build")
+        if advection is None:
+            raise NotImplementedError("the HIP path requires advection=WENO(order=5) "
+                                      "(the reference default Centered(order=2) is not implemented)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("AtmosphereModel needs a GPU: the HIP path has no CPU fallback")
+        self.grid = grid
+        self.advection = advection
+        self.thermodynamic_constants = c = thermodynamic_constants or ThermodynamicConstants()
+        if dynamics is None:
+            dynamics = AnelasticDynamics(ReferenceState(grid, c))      # default_dynamics
+        self.dynamics = dynamics
+        self.clock = Clock()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self._lib = lib = _lib.load()
+
+        def fld(loc):
+            return Field(grid, _LOC[loc], self.device)
+
+        # materialize_momentum_and_velocities, formulation, moisture, diagnostics
+        self.momentum = {"ρu": fld("fcc"), "ρv": fld("cfc"), "ρw": fld("ccf")}
+        self.velocities = {"u": fld("fcc"), "v": fld("cfc"), "w": fld("ccf")}
+        self.potential_temperature_density = fld("ccc")
+        self.potential_temperature = fld("ccc")
+        self.moisture_density = fld("ccc")
+        self.specific_moisture = fld("ccc")
+        self.temperature = fld("ccc")
+        dynamics.pressure_anomaly = fld("ccc")
+        prog = self.prognostic_fields()
+        self.U0 = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}     # timestepper.U⁰
+        self.G = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}      # timestepper.Gⁿ
+
+        # ---- context: pressure solver, column tables ----
+        ref = dynamics.reference_state
+        self._zf = np.ascontiguousarray(grid.zᶠ, dtype=np.float64)
+        bg = _lib.bz_grid()
+        bg.Nx, bg.Ny, bg.Nz = grid.Nx, grid.Ny, grid.Nz
+        bg.Hx, bg.Hy, bg.Hz = grid.Hx, grid.Hy, grid.Hz
+        for d, t in enumerate(grid.topology_codes()):
+            bg.topo[d] = t
+        bg.ftype = 8
+        bg.dx, bg.dy = grid.Δx, grid.Δy
+        bg.zf = self._zf.ctypes.data_as(C.POINTER(C.c_double))
+        bg.regular_z = 1 if grid.regular_z else 0
+        bc = _lib.bz_constants(c.gravitational_acceleration, dry_air_gas_constant(c), vapor_gas_constant(c),
+                               c.dry_air_heat_capacity, c.vapor_heat_capacity)
+        self._ref_arrays = [np.ascontiguousarray(a, dtype=np.float64)
+                            for a in (ref.density, ref.pressure, ref.temperature)]
+        br = _lib.bz_reference_state(ref.surface_pressure, ref.potential_temperature, ref.standard_pressure,
+                                     *[a.ctypes.data_as(C.POINTER(C.c_double)) for a in self._ref_arrays])
+        self._ctx = C.c_void_p()
+        rc = lib.bz_create(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), advection.order)
+        if rc != 0:
+            raise _lib.BreezeHIPError(f"bz_create failed with code {rc}")
+        self._check(lib.bz_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                    "bz_set_stream")
+        self._state = self._make_state()
+        self._U0 = self._make_prog(self.U0)
+        self._G = self._make_prog(self.G)
+        # initialize_model_thermodynamics!: θ = θ₀  (anelastic_time_stepping.jl:15-19)
+        set_(self, θ=ref.potential_temperature)
+
+    # -- plumbing ------------------------------------------------------------
+    def _check(self, rc, what):
+        _lib.check(self._lib, self._ctx, rc, what)
+
+    def prognostic_fields(self):
+        return {"ρu": self.momentum["ρu"], "ρv": self.momentum["ρv"], "ρw": self.momentum["ρw"],
+                "ρθ": self.potential_temperature_density, "ρq": self.moisture_density}
+
+    def _make_state(self):
+        s = _lib.bz_state()
+        s.rho_u, s.rho_v, s.rho_w = (self.momentum[k].ptr() for k in ("ρu", "ρv", "ρw"))
+        s.rho_theta, s.rho_q = self.potential_temperature_density.ptr(), self.moisture_density.ptr()
+        s.u, s.v, s.w = (self.velocities[k].ptr() for k in ("u", "v", "w"))
+        s.theta, s.q, s.T = self.potential_temperature.ptr(), self.specific_moisture.ptr(), self.temperature.ptr()
+        s.phi = self.dynamics.pressure_anomaly.ptr()
+        return s
+
+    @staticmethod
+    def _make_prog(d):
+        p = _lib.bz_prognostic()
+        p.rho_u, p.rho_v, p.rho_w, p.rho_theta, p.rho_q = (d[k].ptr() for k in ("ρu", "ρv", "ρw", "ρθ", "ρq"))
+        return p
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self._lib.bz_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    # method spellings of the module-level functions
+    def set(self, **kw):
+        return set_(self, **kw)
+
+    def time_step(self, Δt):
+        return time_step_(self, Δt)
+
+    def synchronize(self):
+        self._check(self._lib.bz_sync(self._ctx), "bz_sync")
+
+    # -- profiling -----------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._lib.bz_profile_enable(self._ctx, 1 if on else 0), "bz_profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.bz_profile_reset(self._ctx), "bz_profile_reset")
+
+    def profile(self):
+        """{kernel group: (total_ms, launches)} accumulated since the last reset."""
+        out = {}
+        for i in range(self._lib.bz_profile_count(self._ctx)):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            self._check(self._lib.bz_profile_get(self._ctx, i, C.byref(name), C.byref(ms), C.byref(n)),
+                        "bz_profile_get")
+            out[name.value.decode()] = (ms.value, n.value)
+        return out
+
+    def max_abs_divergence(self):
+        out = C.c_double()
+        self._check(self._lib.bz_max_abs_divergence(self._ctx, C.byref(self._state), C.byref(out)),
+                    "bz_max_abs_divergence")
+        return out.value
+
+
+# ---------------------------------------------------------------------------
+# Julia-style generic functions on the model (f! -> f_)
+# ---------------------------------------------------------------------------
+def fill_halo_regions_(model, field, kind=None):
+    if kind is None:
+        kind = 1 if field.zface else 0
+    model._check(model._lib.bz_fill_halo_regions(model._ctx, C.c_void_p(field.ptr()), kind), "bz_fill_halo_regions")
+
+
+def update_state_(model, compute_tendencies=True):
+    model._check(model._lib.bz_update_state(model._ctx, C.byref(model._state), C.byref(model._G),
+                                            1 if compute_tendencies else 0), "bz_update_state")
+
+
+def compute_tendencies_(model):
+    model._check(model._lib.bz_compute_tendencies(model._ctx, C.byref(model._state), C.byref(model._G)),
+                 "bz_compute_tendencies")
+
+
+def compute_velocities_(model):
+    model._check(model._lib.bz_compute_velocities(model._ctx, C.byref(model._state)), "bz_compute_velocities")
+
+
+def compute_auxiliary_thermodynamic_variables_(model):
+    model._check(model._lib.bz_compute_auxiliary_thermodynamic_variables(model._ctx, C.byref(model._state)),
+                 "bz_compute_auxiliary_thermodynamic_variables")
+
+
+def compute_pressure_correction_(model, Δt):
+    model._check(model._lib.bz_compute_pressure_correction(model._ctx, C.byref(model._state), float(Δt)),
+                 "bz_compute_pressure_correction")
+
+
+def make_pressure_correction_(model, Δt):
+    model._check(model._lib.bz_make_pressure_correction(model._ctx, C.byref(model._state), float(Δt)),
+                 "bz_make_pressure_correction")
+
+
+def store_initial_state_(model):
+    model._check(model._lib.bz_store_initial_state(model._ctx, C.byref(model._state), C.byref(model._U0)),
+                 "bz_store_initial_state")
+
+
+def ssp_rk3_substep_(model, Δt, α):
+    model._check(model._lib.bz_ssp_rk3_substep(model._ctx, C.byref(model._state), C.byref(model._U0),
+                                               C.byref(model._G), float(Δt), float(α)), "bz_ssp_rk3_substep")
+
+
+def enforce_mass_conservation_(model):
+    """set_atmosphere_model.jl:121-128: one projection with Δt = 1."""
+    compute_pressure_correction_(model, 1.0)
+    make_pressure_correction_(model, 1.0)
+    update_state_(model, compute_tendencies=False)
+
+
+def set_(model, enforce_mass_conservation=True, **kw):
+    """set!(model; kw...): θ / ρθ, u v w / ρu ρv ρw, qᵗ / ρqᵗ from numbers, arrays or f(x, y, z)."""
+    import torch
+    g = model.grid
+    ref = model.dynamics.reference_state
+    Hz, Nz = g.Hz, g.Nz
+    ρc = torch.from_numpy(ref.density[Hz:Hz + Nz].copy()).to(model.device)[:, None, None]
+    ρf_host = 0.5 * (ref.density[Hz - 1:Hz + Nz] + ref.density[Hz:Hz + Nz + 1])
+    ρf = torch.from_numpy(ρf_host).to(model.device)[:, None, None]
+    for name, value in kw.items():
+        key = _ALIASES.get(name)
+        if key is None:
+            raise ValueError(f"Cannot set! {name} in AtmosphereModel because {name} is neither a prognostic "
+                             "variable, a settable thermodynamic variable, nor a settable diagnostic variable!")
+        if key == "θ":
+            model.potential_temperature.set_interior(value)
+            model.potential_temperature_density.interior.copy_(ρc * model.potential_temperature.interior)
+        elif key == "ρθ":
+            model.potential_temperature_density.set_interior(value)
+        elif key == "q":
+            model.specific_moisture.set_interior(value)
+            model.moisture_density.interior.copy_(ρc * model.specific_moisture.interior)
+        elif key == "ρq":
+            model.moisture_density.set_interior(value)
+        elif key in ("u", "v"):
+            model.velocities[key].set_interior(value)
+            model.momentum["ρ" + key].interior.copy_(ρc * model.velocities[key].interior)
+        elif key == "w":
+            model.velocities["w"].set_interior(value)
+            model.momentum["ρw"].interior.copy_(ρf * model.velocities["w"].interior)
+        else:   # ρu, ρv, ρw
+            model.momentum[key].set_interior(value)
+    update_state_(model, compute_tendencies=False)
+    if enforce_mass_conservation:
+        enforce_mass_conservation_(model)
+
+
+def time_step_(model, Δt, whole_step=True):
+    """time_step!(model, Δt) with SSP-RK3.  whole_step=True uses the single-call device-resident seam
+    (bz_time_step_anelastic); False replays the reference's call sequence through the per-operator
+    entry points (same kernels, used by the parity tests)."""
+    if model.clock.iteration == 0:       # maybe_prepare_first_time_step!
+        update_state_(model, compute_tendencies=True)
+    if whole_step:
+        model._check(model._lib.bz_time_step_anelastic(model._ctx, C.byref(model._state), C.byref(model._U0),
+                                                       C.byref(model._G), float(Δt)), "bz_time_step_anelastic")
+    else:
+        store_initial_state_(model)
+        for α in (1.0, 1.0 / 4.0, 2.0 / 3.0):
+            ssp_rk3_substep_(model, Δt, α)
+            compute_pressure_correction_(model, α * Δt)
+            make_pressure_correction_(model, α * Δt)
+            update_state_(model, compute_tendencies=True)
+    model.clock.time += Δt
+    model.clock.iteration += 1

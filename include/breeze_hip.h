@@ -1,0 +1,157 @@
+/*
+ * breeze_hip.h — C ABI of libbreeze_hip.so: the MI355X-native (gfx950) replacement for the
+ * inner time-stepping hot path of Breeze.jl's anelastic AtmosphereModel.
+ *
+ * The reference has no FFI for this path: every operator is a Julia method chosen by multiple
+ * dispatch and executed as KernelAbstractions kernels.  Each entry point below replaces one of
+ * the Julia generic functions a package extension would specialise on a marker architecture
+ * (precedent: /root/reference/ext/BreezeReactantExt/Timesteppers.jl:6-19) and forward with
+ * `ccall((:bz_..., libbreeze_hip), ...)`; see INTEGRATION.md for the Julia stub.
+ *
+ * Conventions
+ *  - Plain C types only.  All field pointers are DEVICE pointers to the *parent*
+ *    (halo-inclusive) array of an Oceananigans Field, column-major, i fastest:
+ *        element (i,j,k) [1-based interior] at p[(i-1+Hx) + Sx*((j-1+Hy) + Sy*(k-1+Hz))]
+ *        Sx = Nx+2Hx, Sy = Ny+2Hy;  z-Face fields on Bounded z have Nz+1 levels.
+ *    Column (reference-state) and grid arrays passed to bz_create are HOST pointers; they are
+ *    copied at creation.
+ *  - Every call returns 0 on success, a BZ_ERR_* code or a negated hipError_t / hipfftResult
+ *    otherwise; nothing throws; bz_last_error() returns a message for the calling thread's ctx.
+ *  - Calls are asynchronous and stream-ordered on the stream set by bz_set_stream (default: the
+ *    HIP null stream).  bz_sync() blocks until the stream is idle.  No internal host threads.
+ *  - The caller owns all field memory; the ctx owns FFT plans, column tables and scratch.
+ *  - One ctx per device/stream.  Float64 only (ftype = 8) in this version.
+ */
+#ifndef BREEZE_HIP_H
+#define BREEZE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BZ_PERIODIC 0
+#define BZ_BOUNDED 1
+#define BZ_FLAT 2
+
+#define BZ_OK 0
+#define BZ_ERR_INVALID 1      /* null pointer / inconsistent sizes */
+#define BZ_ERR_UNSUPPORTED 2  /* topology, float type, halo or scheme not implemented */
+#define BZ_ERR_ALLOC 3
+
+/* Oceananigans RectilinearGrid (regular x, y; regular or stretched z). */
+typedef struct bz_grid {
+    int32_t Nx, Ny, Nz;
+    int32_t Hx, Hy, Hz;   /* halo sizes (>= 3 for WENO order 5) */
+    int32_t topo[3];      /* BZ_PERIODIC / BZ_BOUNDED / BZ_FLAT per direction */
+    int32_t ftype;        /* sizeof(eltype(grid)): 8 */
+    double dx, dy;        /* regular horizontal spacings */
+    const double *zf;     /* HOST: Nz+1 z-face heights */
+    int32_t regular_z;    /* 1: use dz = (zf[Nz]-zf[0])/Nz exactly, as Oceananigans regular grids do */
+    int32_t reserved;
+} bz_grid;
+
+/* Breeze ThermodynamicConstants subset used on the dry/vapour path
+ * (src/Thermodynamics/thermodynamics_constants.jl:182-217). */
+typedef struct bz_constants {
+    double gravitational_acceleration;
+    double dry_air_gas_constant;      /* R / Md */
+    double vapor_gas_constant;        /* R / Mv */
+    double dry_air_heat_capacity;
+    double vapor_heat_capacity;
+} bz_constants;
+
+/* Breeze ReferenceState columns (src/Thermodynamics/reference_states.jl:18-28, 402-445):
+ * HOST arrays of length Nz+2Hz holding parent(field)[1,1,:] including filled halos. */
+typedef struct bz_reference_state {
+    double surface_pressure, potential_temperature, standard_pressure;
+    const double *density;
+    const double *pressure;
+    const double *temperature;
+} bz_reference_state;
+
+/* model.momentum, formulation/moisture prognostics, velocities, diagnostics, pressure_anomaly
+ * (src/AtmosphereModels/atmosphere_model.jl:37-61; src/AnelasticEquations/anelastic_dynamics.jl:5-8). */
+typedef struct bz_state {
+    double *rho_u, *rho_v, *rho_w;   /* model.momentum            (XFace, YFace, ZFace) */
+    double *rho_theta;               /* formulation.potential_temperature_density        */
+    double *rho_q;                   /* model.moisture_density                           */
+    double *u, *v, *w;               /* model.velocities                                 */
+    double *theta;                   /* formulation.potential_temperature                */
+    double *q;                       /* specific_prognostic_moisture (qv)                */
+    double *T;                       /* model.temperature                                */
+    double *phi;                     /* dynamics.pressure_anomaly  (p'/rho_r)            */
+} bz_state;
+
+/* A NamedTuple of prognostic-shaped fields: timestepper.Gn or timestepper.U0
+ * (src/TimeSteppers/ssp_runge_kutta_3.jl:53-60, 87-88). */
+typedef struct bz_prognostic {
+    double *rho_u, *rho_v, *rho_w, *rho_theta, *rho_q;
+} bz_prognostic;
+
+typedef struct bz_ctx bz_ctx;
+
+/* dynamics_pressure_solver + materialize_advection: builds FFT plans, tridiagonal factors and
+ * column tables.  weno_order must be 5.
+ * Replaces: AtmosphereModels.dynamics_pressure_solver (src/AnelasticEquations/anelastic_pressure_solver.jl:11-24)
+ *           and compute_main_diagonal!/compute_lower_diagonal! (:32-78). */
+int bz_create(bz_ctx **ctx, const bz_grid *grid, const bz_constants *constants,
+              const bz_reference_state *reference_state, int weno_order);
+void bz_destroy(bz_ctx *ctx);
+int bz_set_stream(bz_ctx *ctx, void *hip_stream);
+int bz_sync(bz_ctx *ctx);
+const char *bz_last_error(const bz_ctx *ctx);
+
+/* fill_halo_regions! for one field (Oceananigans.BoundaryConditions; call sites
+ * src/AtmosphereModels/update_atmosphere_model_state.jl:48,135-136,152,241-243).
+ * kind: 0 = centre-in-z field, default (no-flux) z BCs;  1 = z-face field, impenetrable walls;
+ *       2 = `nothing` z BCs (diagnostic velocities): periodic wrap only; 3 = as 2 for a z-face field. */
+int bz_fill_halo_regions(bz_ctx *ctx, double *field, int kind);
+
+/* AtmosphereModels.compute_velocities! (update_atmosphere_model_state.jl:122-155, kernel :248-254). */
+int bz_compute_velocities(bz_ctx *ctx, const bz_state *s);
+/* compute_auxiliary_thermodynamic_variables! (:225-246, kernel :256-292). */
+int bz_compute_auxiliary_thermodynamic_variables(bz_ctx *ctx, const bz_state *s);
+/* AtmosphereModels.compute_tendencies! (:294-387): G.rho_u, rho_v, rho_w, rho_theta, rho_q. */
+int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+/* TimeSteppers.update_state!(model; compute_tendencies) (:41-68); G may be NULL iff compute_tendencies == 0. */
+int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, int compute_tendencies);
+
+/* store_initial_state! (src/TimeSteppers/ssp_runge_kutta_3.jl:180-186). */
+int bz_store_initial_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0);
+/* ssp_rk3_substep! (:114-173): u = (1-alpha) u0 + alpha (u + dt G) for the five prognostic fields. */
+int bz_ssp_rk3_substep(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
+                       const bz_prognostic *G, double dt, double alpha);
+
+/* AtmosphereModels.compute_pressure_correction!(model, dt)
+ * (src/AnelasticEquations/anelastic_time_stepping.jl:26-39 -> anelastic_pressure_solver.jl:84-105):
+ * momentum halos, source term, Fourier-tridiagonal solve into s->phi, phi halos. */
+int bz_compute_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt);
+/* AtmosphereModels.make_pressure_correction!(model, dt) (anelastic_time_stepping.jl:45-78). */
+int bz_make_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt);
+
+/* OceananigansTimeSteppers.time_step!(model::AtmosphereModel{..SSPRungeKutta3}, dt)
+ * (src/TimeSteppers/ssp_runge_kutta_3.jl:209-278) for dry anelastic dynamics without callbacks:
+ * the whole step stays on the device (preferred seam).  The state must be consistent
+ * (bz_update_state with compute_tendencies=1 called once after set!, as
+ * maybe_prepare_first_time_step! does). */
+int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
+                           const bz_prognostic *G, double dt);
+
+/* ---- instrumentation (not part of the reference interface) ---- */
+/* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
+int bz_profile_enable(bz_ctx *ctx, int on);
+int bz_profile_reset(bz_ctx *ctx);
+/* number of instrumented kernel groups; name/total milliseconds/launch count of group idx
+ * (synchronises the stream). */
+int bz_profile_count(bz_ctx *ctx);
+int bz_profile_get(bz_ctx *ctx, int idx, const char **name, double *total_ms, int64_t *launches);
+/* divergence of momentum, max-abs over the interior, into *out (host); diagnostic for tests
+ * (test/anelastic_pressure_solver_nonhydrostatic.jl:45-46). Synchronises. */
+int bz_max_abs_divergence(bz_ctx *ctx, const bz_state *s, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BREEZE_HIP_H */

@@ -8,7 +8,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbreeze_hip.so")
+# BREEZE_HIP_LIB selects another build of the same ABI (e.g. lib/libbreeze_hip_refdiv.so, the variant that
+# keeps the reference's three-quotient WENO weight formula, used for A/B timing and tight parity checks).
+LIB_PATH = os.environ.get("BREEZE_HIP_LIB") or os.path.join(_HERE, "lib", "libbreeze_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _dp = C.POINTER(C.c_double)
@@ -100,6 +102,9 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C breeze.jl_amd/csrc`.")
+    # torch bundles its own HIP runtime; load it first so that libbreeze_hip.so binds to the same
+    # libamdhip64 instance (two runtimes in one process cannot both see the device).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

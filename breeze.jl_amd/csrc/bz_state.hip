@@ -192,6 +192,10 @@ extern "C" int bz_max_abs_divergence(bz_ctx *ctx, const bz_state *s, double *out
 {
     if (!ctx || !s || !out) return BZ_ERR_INVALID;
     const DevGrid &g = ctx->dg;
+    double *mf[3] = {s->rho_u, s->rho_v, s->rho_w};
+    int mk[3] = {0, 0, 1};
+    int rc = bzi_fill_halos_multi(ctx, mf, mk, 3);
+    if (rc) return rc;
     BZ_HIP(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
     hipLaunchKernelGGL(k_max_abs_div, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, s->rho_u, s->rho_v,
                        s->rho_w, (unsigned long long *)ctx->d_scalar);

@@ -68,7 +68,7 @@ class Field:
             value = value(x, y, z)
         shape = tuple(self.interior.shape)
         arr = np.broadcast_to(np.asarray(value, dtype=np.float64), shape)
-        self.interior.copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+        self.interior.copy_(torch.from_numpy(np.array(arr, dtype=np.float64, order="C")))
 
     def cpu(self):
         return self.parent.cpu().numpy()

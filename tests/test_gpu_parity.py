@@ -136,7 +136,7 @@ def test_time_steps_match_oracle(oracle, bz, size, dt):
         want = _interior(om, n)
         scale = max(np.max(np.abs(want)), 1e-3)
         assert np.max(np.abs(got - want)) / scale < 1e-9, n
-    assert relerr(hm.temperature.interior_cpu(), om.grid.interior(om.T)) < 1e-12
+    assert relerr(hm.temperature.interior_cpu(), om.grid.interior(om.T)) < 1e-9
     assert np.isfinite(hm.velocities["w"].cpu()).all()
 
 

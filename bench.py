@@ -36,7 +36,7 @@ WORDS_PER_CELL = {
     "x_momentum_tendency": 5, "y_momentum_tendency": 5, "z_momentum_tendency": 7,
     "potential_temperature_tendency": 6, "moisture_tendency": 5,
     "scalar_tendencies": 11, "momentum_tendencies": 17, "tendencies": 28,
-    "rk3_and_source": 24, "project_and_diagnose": 18,
+    "ssp_rk3_substep+store_initial_state": 30, "project_and_diagnose": 18,
 }
 A_STEP_WORDS = 250          # 3 stages x 80 + 10
 

@@ -1,5 +1,6 @@
 // bz_context.hip — context lifetime, column tables, stream and instrumentation.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "bz_internal.h"
@@ -174,6 +175,7 @@ extern "C" int bz_create(bz_ctx **out, const bz_grid *grid, const bz_constants *
     g.cpv = constants->vapor_heat_capacity;
     g.pst = ref->standard_pressure;
 
+    ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy) && !getenv("BZ_NO_FUSED");
     int rc = bzi_poisson_setup(ctx, ref->density);
     if (rc != BZ_OK) {
         fprintf(stderr, "bz_create: Poisson setup failed (%d): %s\n", rc, ctx->last_error.c_str());

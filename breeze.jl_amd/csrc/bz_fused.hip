@@ -1,0 +1,209 @@
+// bz_fused.hip — the streaming half of the device-resident step, fused for HBM traffic:
+//
+//  k_rk3_march        ssp_rk3_substep! for the five prognostic fields; in the first stage (alpha = 1,
+//                     where u = 0*u0 + (u + dt G)) it also performs store_initial_state! (U0 = u),
+//                     so the separate copy pass disappears.
+//                       /root/reference/src/TimeSteppers/ssp_runge_kutta_3.jl:114-186
+//  k_project_diagnose make_pressure_correction! + compute_velocities! +
+//                     compute_auxiliary_thermodynamic_variables! + every fill_halo_regions! that
+//                     update_state! performs, in one pass: each thread also writes the periodic halo
+//                     images and the z-halo copies of the values it produces, and scatters phi from the
+//                     solver's contiguous buffer into the halo-inclusive pressure_anomaly field.
+//                       /root/reference/src/AnelasticEquations/anelastic_time_stepping.jl:45-78
+//                       /root/reference/src/AtmosphereModels/update_atmosphere_model_state.jl:41-68,122-155,225-292
+//
+// Launch shapes follow tools/membench.hip measurements on MI355X (5-field RK update, 512^3 + halos):
+// 64x4 tiles per level 4.5 TB/s, 256x1 row blocks 5.3 TB/s, plane-contiguous 1-D indexing 5.9 TB/s.
+// Pointwise kernels therefore index the contiguous run of interior rows of each z level (x halos
+// included: they are overwritten by the next halo-image store), stencil kernels use 256x1 row blocks.
+#include "bz_internal.h"
+
+#define FX 64
+#define FY 4
+
+struct RKFieldsW {
+    double *u[5];
+    double *u0[5];        // written when FIRST
+    const double *G[5];
+};
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_rk3_rows(DevGrid g, RKFieldsW F, double dt, double alpha)
+{
+    // one z level per blockIdx.y; t runs over the contiguous rows j = 0..Ny-1 of that level
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)g.Ny * g.Sx) return;
+    const int k = blockIdx.y;
+    const long long n = g.Sxy * (k + g.Hz) + (long long)g.Hy * g.Sx + t;
+    const double oma = 1.0 - alpha;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        if (f == 2 && k == 0) continue;          // rho_w wall face: never updated
+        double u = F.u[f][n];
+        if (FIRST) {
+            F.u0[f][n] = u;
+            F.u[f][n] = oma * u + alpha * (u + dt * F.G[f][n]);
+        } else {
+            F.u[f][n] = oma * F.u0[f][n] + alpha * (u + dt * F.G[f][n]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_poisson_source_rows(DevGrid g, double *__restrict__ rhs,
+                                                             const double *__restrict__ ru,
+                                                             const double *__restrict__ rv,
+                                                             const double *__restrict__ rw, double dt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    // periodic neighbours by wrap indexing: momentum halos need not be current here
+    const long long ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx;
+    const long long jp = (j + 1 < g.Ny) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
+    const long long n = g.idx(i, j, k);
+    const double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
+    double a = Ax * ru[n + ip] - Ax * ru[n];
+    double b = Ay * rv[n + jp] - Ay * rv[n];
+    double c = Az * rw[n + g.Sxy] - Az * rw[n];
+    double div = g.Vinv_c[k] * (a + b + c);
+    rhs[(long long)i + (long long)g.Nx * ((long long)j + (long long)g.Ny * k)] = g.dzc[k] * div / dt;
+}
+
+// store v at n and at its periodic images (ox / oy = offset of the x / y image, 0 if none)
+__device__ __forceinline__ void st_img(double *__restrict__ f, long long n, double v, long long ox, long long oy)
+{
+    f[n] = v;
+    if (ox) f[n + ox] = v;
+    if (oy) {
+        f[n + oy] = v;
+        if (ox) f[n + ox + oy] = v;
+    }
+}
+// images only (the interior value is already in place)
+__device__ __forceinline__ void st_img_only(double *__restrict__ f, long long n, double v, long long ox, long long oy)
+{
+    if (ox) f[n + ox] = v;
+    if (oy) {
+        f[n + oy] = v;
+        if (ox) f[n + ox + oy] = v;
+    }
+}
+
+struct PDFields {
+    double *ru, *rv, *rw, *rtheta, *rq;     // in/out (rtheta, rq: halos only)
+    double *u, *v, *w, *theta, *q, *T;      // out
+    double *phi;                            // out (halo-inclusive)
+    const double *phi_c;                    // in: contiguous Nx*Ny*Nz, zero-mean solution
+};
+
+__global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F, double dt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long sz = g.Sxy;
+    // periodic images of this column in the halo (requires Nx >= 2Hx, Ny >= 2Hy: at most one per direction)
+    const long long ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
+    const long long oy = (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
+    // contiguous-buffer neighbours (periodic wrap)
+    const long long cplane = (long long)g.Nx * g.Ny;
+    const long long m = (long long)i + (long long)g.Nx * j + cplane * k;
+    const long long c_im = (i > 0) ? -1 : g.Nx - 1;
+    const long long c_jm = (j > 0) ? -(long long)g.Nx : (long long)g.Nx * (g.Ny - 1);
+    const long long n = g.idx(i, j, k);
+    const bool bot = (k == 0), top = (k == g.Nz - 1);
+    const double rc = g.rho[k], rf = g.rho_f[k];
+    const double p = F.phi_c[m];
+    const double p_im = F.phi_c[m + c_im];
+    const double p_jm = F.phi_c[m + c_jm];
+
+    // _pressure_correct_momentum!
+    double ru = F.ru[n], rv = F.rv[n];
+    ru -= rc * dt * ((p - p_im) * g.rdx);
+    rv -= rc * dt * ((p - p_jm) * g.rdy);
+    // _compute_velocities!
+    double u = ru / rc, v = rv / rc;
+    // thermodynamic diagnosis
+    const double rth = F.rtheta[n], rq = F.rq[n];
+    const double th = rth / rc, q = rq / rc;
+    const double qd = 1.0 - q;
+    const double Rm = qd * g.Rd + q * g.Rv;
+    const double cpm = qd * g.cpd + q * g.cpv;
+    const double T = pow(g.p_r[k] / g.pst, Rm / cpm) * th;
+
+    st_img(F.phi, n, p, ox, oy);
+    st_img(F.ru, n, ru, ox, oy);
+    st_img(F.rv, n, rv, ox, oy);
+    st_img(F.u, n, u, ox, oy);
+    st_img(F.v, n, v, ox, oy);
+    st_img(F.theta, n, th, ox, oy);
+    st_img(F.q, n, q, ox, oy);
+    st_img(F.T, n, T, ox, oy);
+    st_img_only(F.rtheta, n, rth, ox, oy);
+    st_img_only(F.rq, n, rq, ox, oy);
+    if (!bot) {      // wall face k = 0 keeps rho_w = w = 0
+        const double p_km = F.phi_c[m - cplane];
+        double rw = F.rw[n];
+        rw -= rf * dt * ((p - p_km) * g.rdzf[k]);
+        st_img(F.rw, n, rw, ox, oy);
+        st_img(F.w, n, rw / rf, ox, oy);
+    }
+    if (bot || top) {    // first z-halo cell of no-flux centre fields; u, v: level Nz only
+        const long long h = bot ? -sz : sz;
+        st_img(F.phi, n + h, p, ox, oy);
+        st_img(F.ru, n + h, ru, ox, oy);
+        st_img(F.rv, n + h, rv, ox, oy);
+        st_img(F.theta, n + h, th, ox, oy);
+        st_img(F.q, n + h, q, ox, oy);
+        st_img(F.T, n + h, T, ox, oy);
+        st_img(F.rtheta, n + h, rth, ox, oy);
+        st_img(F.rq, n + h, rq, ox, oy);
+        if (top) {
+            st_img(F.u, n + sz, u, ox, oy);
+            st_img(F.v, n + sz, v, ox, oy);
+        }
+    }
+}
+
+int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
+                  double alpha, bool first)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, first ? "ssp_rk3_substep+store_initial_state" : "ssp_rk3_substep");
+    RKFieldsW F;
+    F.u[0] = s->rho_u; F.u[1] = s->rho_v; F.u[2] = s->rho_w; F.u[3] = s->rho_theta; F.u[4] = s->rho_q;
+    F.u0[0] = U0->rho_u; F.u0[1] = U0->rho_v; F.u0[2] = U0->rho_w; F.u0[3] = U0->rho_theta; F.u0[4] = U0->rho_q;
+    F.G[0] = G->rho_u; F.G[1] = G->rho_v; F.G[2] = G->rho_w; F.G[3] = G->rho_theta; F.G[4] = G->rho_q;
+    long long per_level = (long long)g.Ny * g.Sx;
+    dim3 grid((unsigned)((per_level + 255) / 256), g.Nz), block(256);
+    if (first)
+        hipLaunchKernelGGL(k_rk3_rows<true>, grid, block, 0, ctx->stream, g, F, dt, alpha);
+    else
+        hipLaunchKernelGGL(k_rk3_rows<false>, grid, block, 0, ctx->stream, g, F, dt, alpha);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "poisson_source_term");
+    dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+    hipLaunchKernelGGL(k_poisson_source_rows, grid, block, 0, ctx->stream, g, ctx->d_rhs, s->rho_u, s->rho_v,
+                       s->rho_w, dt);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "project_and_diagnose");
+    PDFields F;
+    F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w; F.rtheta = s->rho_theta; F.rq = s->rho_q;
+    F.u = s->u; F.v = s->v; F.w = s->w; F.theta = s->theta; F.q = s->q; F.T = s->T;
+    F.phi = s->phi;
+    F.phi_c = ctx->d_rhs;
+    dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+    hipLaunchKernelGGL(k_project_diagnose, grid, block, 0, ctx->stream, g, F, dt);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}

@@ -57,6 +57,7 @@ struct bz_ctx {
     double *d_tfac = nullptr;         // NXH*Ny*Nz : t_k = c_{k-1}/beta_{k-1}
     double *d_lower = nullptr;        // Nz
     double *d_scalar = nullptr;       // small scratch (mean, reductions)
+    bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
     // profiling
     bool profiling = false;
     std::vector<ProfileSlot> slots;
@@ -104,3 +105,9 @@ int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, i
 int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
 void bzi_poisson_teardown(bz_ctx *ctx);
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);
+int bzi_poisson_spectral(bz_ctx *ctx);
+// fused streaming kernels (bz_fused.hip)
+int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
+                  double alpha, bool first);
+int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt);
+int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt);

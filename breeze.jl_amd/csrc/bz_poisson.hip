@@ -188,17 +188,11 @@ void bzi_poisson_teardown(bz_ctx *ctx)
     ctx->d_hat = nullptr;
 }
 
-// solve_for_anelastic_pressure!(phi, solver, rhoU, dt)  (anelastic_pressure_solver.jl:84-88)
-int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt)
+// solve!(phi, FourierTridiagonalPoissonSolver) on the source term held in ctx->d_rhs; the zero-mean
+// solution is left in ctx->d_rhs (contiguous Nx*Ny*Nz).
+int bzi_poisson_spectral(bz_ctx *ctx)
 {
     const DevGrid &g = ctx->dg;
-    dim3 grid((g.Nx + TX - 1) / TX, (g.Ny + TY - 1) / TY, g.Nz), block(TX, TY);
-    {
-        ProfileScope ps(ctx, "poisson_source_term");
-        hipLaunchKernelGGL(k_poisson_source, grid, block, 0, ctx->stream, g, ctx->d_rhs, s->rho_u, s->rho_v,
-                           s->rho_w, dt);
-        BZ_LAUNCH_CHECK();
-    }
     {
         ProfileScope ps(ctx, "poisson_fft_forward");
         BZ_FFT(hipfftExecD2Z(ctx->plan_fwd, ctx->d_rhs, ctx->d_hat));
@@ -215,6 +209,22 @@ int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt)
         ProfileScope ps(ctx, "poisson_fft_inverse");
         BZ_FFT(hipfftExecZ2D(ctx->plan_inv, ctx->d_hat, ctx->d_rhs));
     }
+    return BZ_OK;
+}
+
+// solve_for_anelastic_pressure!(phi, solver, rhoU, dt)  (anelastic_pressure_solver.jl:84-88)
+int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt)
+{
+    const DevGrid &g = ctx->dg;
+    dim3 grid((g.Nx + TX - 1) / TX, (g.Ny + TY - 1) / TY, g.Nz), block(TX, TY);
+    {
+        ProfileScope ps(ctx, "poisson_source_term");
+        hipLaunchKernelGGL(k_poisson_source, grid, block, 0, ctx->stream, g, ctx->d_rhs, s->rho_u, s->rho_v,
+                           s->rho_w, dt);
+        BZ_LAUNCH_CHECK();
+    }
+    int rc = bzi_poisson_spectral(ctx);
+    if (rc) return rc;
     {
         ProfileScope ps(ctx, "poisson_phi_scatter");
         hipLaunchKernelGGL(k_phi_scatter, grid, block, 0, ctx->stream, g, s->phi, ctx->d_rhs);

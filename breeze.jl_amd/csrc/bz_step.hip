@@ -26,8 +26,22 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
 {
     if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
     int rc;
-    if ((rc = bz_store_initial_state(ctx, s, U0))) return rc;               // :223
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
+    if (ctx->fused_ok) {
+        // Same arithmetic, fewer passes over HBM (bz_fused.hip): store_initial_state! rides on the first
+        // RK update, the source term uses wrap indexing instead of a halo fill, and the projection,
+        // velocity / thermodynamic diagnosis and every halo fill of update_state! are one kernel.
+        for (int stage = 0; stage < 3; ++stage) {
+            const double alpha = alphas[stage];
+            if ((rc = bzi_rk3_fused(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+            if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt))) return rc;
+            if ((rc = bzi_poisson_spectral(ctx))) return rc;
+            if ((rc = bzi_project_diagnose(ctx, s, alpha * dt))) return rc;
+            if ((rc = bz_compute_tendencies(ctx, s, G))) return rc;
+        }
+        return BZ_OK;
+    }
+    if ((rc = bz_store_initial_state(ctx, s, U0))) return rc;               // :223
     for (int stage = 0; stage < 3; ++stage) {
         const double alpha = alphas[stage];
         if ((rc = bz_ssp_rk3_substep(ctx, s, U0, G, dt, alpha))) return rc;          // :230,244,258

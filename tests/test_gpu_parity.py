@@ -153,8 +153,13 @@ def test_whole_step_equals_operator_sequence(bz):
         m.synchronize()
         models.append(m)
     a, b = models
+    # same arithmetic, but the fused kernels are separate compilations (FMA contraction may differ)
     for k in a.prognostic_fields():
-        assert np.array_equal(a.prognostic_fields()[k].cpu(), b.prognostic_fields()[k].cpu()), k
+        assert relerr(a.prognostic_fields()[k].cpu(), b.prognostic_fields()[k].cpu()) < 1e-13, k
+    for fa, fb in ((a.temperature, b.temperature), (a.velocities["u"], b.velocities["u"]),
+                   (a.velocities["w"], b.velocities["w"]), (a.dynamics.pressure_anomaly, b.dynamics.pressure_anomaly),
+                   (a.potential_temperature, b.potential_temperature)):
+        assert relerr(fa.cpu(), fb.cpu()) < 1e-12      # whole parent arrays: halos included
 
 
 def test_momentum_conservation_on_device(bz):

@@ -176,6 +176,7 @@ extern "C" int bz_create(bz_ctx **out, const bz_grid *grid, const bz_constants *
     g.pst = ref->standard_pressure;
 
     ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy) && !getenv("BZ_NO_FUSED");
+    if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);
     int rc = bzi_poisson_setup(ctx, ref->density);
     if (rc != BZ_OK) {
         fprintf(stderr, "bz_create: Poisson setup failed (%d): %s\n", rc, ctx->last_error.c_str());

@@ -57,6 +57,7 @@ struct bz_ctx {
     double *d_tfac = nullptr;         // NXH*Ny*Nz : t_k = c_{k-1}/beta_{k-1}
     double *d_lower = nullptr;        // Nz
     double *d_scalar = nullptr;       // small scratch (mean, reductions)
+    int tend_gen = 2;                 // tendency kernel generation (BZ_TEND_GEN: 1 = gen-1 everywhere, 2 = gen-1 momentum + fused scalar pair, 3 = gen-3 u,v + pair, 4 = gen-3 everywhere)
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
     // profiling
     bool profiling = false;
@@ -111,3 +112,5 @@ int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const
                   double alpha, bool first);
 int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt);
 int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt);
+int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w);
+int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);

@@ -276,6 +276,18 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     if (!ctx || !s || !G) return BZ_ERR_INVALID;
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
+    if (ctx->tend_gen >= 3) {
+        // gen-3 kernels for the scalars and horizontal momentum; w stays gen-1 unless BZ_TEND_GEN=4
+        int rc = bzi_compute_tendencies3(ctx, s, G, ctx->tend_gen >= 4);
+        if (rc || ctx->tend_gen >= 4) return rc;
+        ProfileScope ps(ctx, "z_momentum_tendency");
+        int kcw = pick_kchunk(g, g.Nz - 1);
+        dim3 gridw((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz - 1 + kcw - 1) / kcw);
+        hipLaunchKernelGGL(k_w_tendency, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
+                           s->T, s->q, kcw);
+        BZ_LAUNCH_CHECK();
+        return BZ_OK;
+    }
     int kc = pick_kchunk(g, g.Nz);
     dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
     {
@@ -293,13 +305,18 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
         hipLaunchKernelGGL(k_w_tendency, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
                            s->T, s->q, kcw);
     }
-    {
-        ProfileScope ps(ctx, "potential_temperature_tendency");
-        hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_theta, s->u, s->v, s->w, s->theta, kc);
-    }
-    {
-        ProfileScope ps(ctx, "moisture_tendency");
-        hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q, kc);
+    if (ctx->tend_gen >= 2) {
+        int rc = bzi_scalar_pair_tendency(ctx, s, G);
+        if (rc) return rc;
+    } else {
+        {
+            ProfileScope ps(ctx, "potential_temperature_tendency");
+            hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_theta, s->u, s->v, s->w, s->theta, kc);
+        }
+        {
+            ProfileScope ps(ctx, "moisture_tendency");
+            hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q, kc);
+        }
     }
     BZ_LAUNCH_CHECK();
     return BZ_OK;

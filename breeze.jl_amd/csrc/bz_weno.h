@@ -31,32 +31,52 @@ __device__ __forceinline__ double bz_weno5_ref(double a, double b, double c, dou
     return (a0 * p0 + a1 * p1 + a2 * p2) / (a0 + a1 + a2);
 }
 
-// Same weights with a single division: alpha_s = C_s (1 + tau^2/d_s^2), d_s = beta_s + eps, is
-// multiplied through by d_0^2 d_1^2 d_2^2 (positive, so the normalised weights are unchanged):
-//   alpha'_0 = C_0 (d_0^2 + tau^2) d_1^2 d_2^2, ...   value = sum alpha'_s p_s / sum alpha'_s.
-// FP64 range: d_s in [1e-8, ~1e6] => products in [1e-48, 1e36].  Differs from the reference order
-// by a few ulp of the weights (<= 1e-15 of the reconstructed value).
+// Fast form used by the shipped kernels.  Same weights and candidate polynomials, rearranged for
+// FP64 issue slots (one WENO-5 is ~60 FP64 instructions instead of ~85 + 3 extra divisions):
+//  * everything is expressed through the first differences D1..D4 of the five cells: the smoothness
+//    indicators (3 x Jiang-Shu, as Oceananigans tabulates them) are
+//        beta_2 = 13/4 (D2-D1)^2 + 3/4 (3 D2 - D1)^2,  beta_1 = 13/4 (D3-D2)^2 + 3/4 (D2+D3)^2,
+//        beta_0 = 13/4 (D4-D3)^2 + 3/4 (D4 - 3 D3)^2,
+//    and the candidates are c + delta_s with delta_2 = 5/6 D2 - 1/3 D1, delta_1 = 1/3 D3 + 1/6 D2,
+//    delta_0 = 2/3 D3 - 1/6 D4 (less cancellation than the cell-value form);
+//  * alpha_s = C_s (1 + tau^2/d_s^2), d_s = beta_s + eps, is multiplied through by d_0^2 d_1^2 d_2^2
+//    (positive, so the normalised weights are unchanged) and by 10: one division instead of four.
+//    FP64 range: d_s in [1e-8, ~1e6] => products in [1e-48, 1e37];
+//  * that division is a v_rcp_f64 seed plus two Newton steps (denominator positive and normal, so the
+//    div_scale / div_fixup special-casing is unnecessary): relative error ~1e-16.  The reference itself
+//    evaluates tau/(beta+eps) with a reduced-precision reciprocal and one Newton step (newton_div).
+// Differs from bz_weno5_ref by a few 1e-16 of the reconstructed value.
 __device__ __forceinline__ double bz_weno5_fast(double a, double b, double c, double d, double e)
 {
-    double b0 = c * (10.0 * c - 31.0 * d + 11.0 * e) + d * (25.0 * d - 19.0 * e) + e * (4.0 * e);
-    double b1 = b * (4.0 * b - 13.0 * c + 5.0 * d) + c * (13.0 * c - 13.0 * d) + d * (4.0 * d);
-    double b2 = a * (4.0 * a - 19.0 * b + 11.0 * c) + b * (25.0 * b - 31.0 * c) + c * (10.0 * c);
-    double tau = b0 - b2;
-    double t2 = tau * tau;
-    double d0 = b0 + BZ_WENO_EPS, d1 = b1 + BZ_WENO_EPS, d2 = b2 + BZ_WENO_EPS;
-    double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2;
-    double a0 = (3.0 / 10.0) * ((s0 + t2) * (s1 * s2));
-    double a1 = (3.0 / 5.0) * ((s1 + t2) * (s0 * s2));
-    double a2 = (1.0 / 10.0) * ((s2 + t2) * (s0 * s1));
-    double p0 = (1.0 / 3.0) * c + (5.0 / 6.0) * d - (1.0 / 6.0) * e;
-    double p1 = -(1.0 / 6.0) * b + (5.0 / 6.0) * c + (1.0 / 3.0) * d;
-    double p2 = (1.0 / 3.0) * a - (7.0 / 6.0) * b + (11.0 / 6.0) * c;
-    return (a0 * p0 + a1 * p1 + a2 * p2) / (a0 + a1 + a2);
+    const double D1 = b - a, D2 = c - b, D3 = d - c, D4 = e - d;
+    const double S1 = D2 - D1, S2 = D3 - D2, S3 = D4 - D3;
+    const double L2 = 3.0 * D2 - D1, L1 = D2 + D3, L0 = D4 - 3.0 * D3;
+    const double b2 = (3.25 * S1) * S1 + (0.75 * L2) * L2;
+    const double b1 = (3.25 * S2) * S2 + (0.75 * L1) * L1;
+    const double b0 = (3.25 * S3) * S3 + (0.75 * L0) * L0;
+    const double tau = b0 - b2;
+    const double t2 = tau * tau;
+    const double d0 = b0 + BZ_WENO_EPS, d1 = b1 + BZ_WENO_EPS, d2 = b2 + BZ_WENO_EPS;
+    const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2;
+    const double a0 = 3.0 * ((s0 + t2) * (s1 * s2));
+    const double a1 = 6.0 * ((s1 + t2) * (s0 * s2));
+    const double a2 = (s2 + t2) * (s0 * s1);
+    const double e0 = (2.0 / 3.0) * D3 - (1.0 / 6.0) * D4;
+    const double e1 = (1.0 / 3.0) * D3 + (1.0 / 6.0) * D2;
+    const double e2 = (5.0 / 6.0) * D2 - (1.0 / 3.0) * D1;
+    const double num = a0 * e0 + a1 * e1 + a2 * e2;
+    const double den = a0 + a1 + a2;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    return fma(num, r, c);
 }
 
 __device__ __forceinline__ double bz_weno5(double a, double b, double c, double d, double e)
 {
-#if BZ_WENO_ONE_DIVISION
+#ifdef BZ_WENO_STUB      // timing experiments only: keeps every input live, no WENO arithmetic
+    return 0.2 * (a + b + c + d + e);
+#elif BZ_WENO_ONE_DIVISION
     return bz_weno5_fast(a, b, c, d, e);
 #else
     return bz_weno5_ref(a, b, c, d, e);

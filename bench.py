@@ -9,9 +9,10 @@ deterministic synthetic initial state resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W [--size 512]
 
-Prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run, one rank per
-GPU; until the y-slab decomposition lands each rank advances its own replica of the workload
-(no collective in the data path) and `value` is the aggregate over ranks.
+Prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run, one rank per GPU over RCCL:
+weak scaling, every rank owns a 512 x 512 x 512 y-slab of a 512 x (512 N) x 512 periodic domain
+(breeze.jl_amd/distributed.py: y-halo exchange + FFT transposes); `value` is the aggregate over ranks.
+`--replicas` runs N independent copies of the N=1 workload instead (no collective in the data path).
 """
 import argparse
 import json
@@ -76,6 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the slab decomposition")
+    ap.add_argument("--slab", action="store_true", help="N=1: run the slab driver (world 1) instead of the whole-step seam")
     ap.add_argument("--cpu-size", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=8)
     args = ap.parse_args()
@@ -97,11 +100,30 @@ def main():
     device = f"cuda:{local_rank}"
 
     N = args.size
-    grid = bz.RectilinearGrid((N, N, N), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
-    ref = bz.ReferenceState(grid, surface_pressure=101325, potential_temperature=300)
-    model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), device=device)
-    model.set(θ=bubble)          # u = v = w = 0, dry
     dt = 1.0
+    use_slabs = (world > 1 and not args.replicas) or (world == 1 and args.slab)
+    parallelism = "single GPU"
+    if use_slabs:
+        # weak scaling: the domain grows in y with the number of ranks, one bubble per 20 km of y
+        from breeze_jl_amd.distributed import SlabAtmosphereModel
+        Ly = (EXTENT[1][1] - EXTENT[1][0]) * world
+        ggrid = bz.RectilinearGrid((N, N * world, N), x=EXTENT[0], y=(EXTENT[1][0], EXTENT[1][0] + Ly), z=EXTENT[2])
+
+        def bubbles(x, y, z):
+            yy = np.mod(y - EXTENT[1][0], EXTENT[1][1] - EXTENT[1][0]) + EXTENT[1][0]
+            return bubble(x, yy, z)
+
+        model = SlabAtmosphereModel(ggrid, rank, world, advection=bz.WENO(order=5), surface_pressure=101325,
+                                    potential_temperature=300, device=device)
+        model.set(θ=bubbles)
+        parallelism = f"{world} y-slabs of {N}x{N}x{N} (RCCL halo exchange + FFT transposes)"
+    else:
+        grid = bz.RectilinearGrid((N, N, N), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+        ref = bz.ReferenceState(grid, surface_pressure=101325, potential_temperature=300)
+        model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), device=device)
+        model.set(θ=bubble)          # u = v = w = 0, dry
+        if world > 1:
+            parallelism = f"{world} independent replicas"
 
     def barrier():
         if dist is not None:
@@ -150,7 +172,7 @@ def main():
             "config": {"workload": f"dry thermal bubble {N}^3 RectilinearGrid (Periodic,Periodic,Bounded), halo 3, "
                                    "AnelasticDynamics + WENO5 + SSP-RK3, Float64, dt=1s (BASELINE.json configs[1])",
                        "grid": [N, N, N], "dt": dt,
-                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
+                       "parallelism": parallelism},
             "roofline": roofline,
             "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": step_achieved / HBM_PEAK_GBS,

@@ -70,6 +70,13 @@ SYMBOLS = {
     "bz_compute_pressure_correction": (C.c_int, [_ctx, _sp, C.c_double]),
     "bz_make_pressure_correction": (C.c_int, [_ctx, _sp, C.c_double]),
     "bz_time_step_anelastic": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double]),
+    "bz_create_slab": (C.c_int, [C.POINTER(_ctx), C.POINTER(bz_grid), C.POINTER(bz_constants),
+                                 C.POINTER(bz_reference_state), C.c_int, C.c_int, C.c_int]),
+    "bz_slab_info": (C.c_int, [_ctx] + [C.POINTER(C.c_int32)] * 5),
+    "bz_ssp_rk3_substep_fused": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double, C.c_double, C.c_int]),
+    "bz_poisson_source_term": (C.c_int, [_ctx, _sp, C.c_double, C.c_void_p]),
+    "bz_spectral_tridiagonal_solve": (C.c_int, [_ctx, C.c_void_p, C.c_double]),
+    "bz_project_and_diagnose": (C.c_int, [_ctx, _sp, C.c_void_p, C.c_void_p, C.c_double]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "bz_profile_reset": (C.c_int, [_ctx]),
     "bz_profile_count": (C.c_int, [_ctx]),

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_poisson_source_rows(DevGrid g, double *
     if (i >= g.Nx) return;
     // periodic neighbours by wrap indexing: momentum halos need not be current here
     const long long ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx;
-    const long long jp = (j + 1 < g.Ny) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
+    // y-slab: row Ny is the neighbour rank's first row, delivered into the halo by the caller's exchange
+    const long long jp = (j + 1 < g.Ny || !g.wrap_y) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
     const long long n = g.idx(i, j, k);
     const double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
     double a = Ax * ru[n + ip] - Ax * ru[n];
@@ -93,6 +94,7 @@ struct PDFields {
     double *u, *v, *w, *theta, *q, *T;      // out
     double *phi;                            // out (halo-inclusive)
     const double *phi_c;                    // in: contiguous Nx*Ny*Nz, zero-mean solution
+    const double *phi_below;                // y-slab only: phi of row j = -1 (neighbour rank), layout [k][i]
 };
 
 __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F, double dt)
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const long long sz = g.Sxy;
     // periodic images of this column in the halo (requires Nx >= 2Hx, Ny >= 2Hy: at most one per direction)
     const long long ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
-    const long long oy = (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
+    const long long oy = !g.wrap_y ? 0 : (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
     // contiguous-buffer neighbours (periodic wrap)
     const long long cplane = (long long)g.Nx * g.Ny;
     const long long m = (long long)i + (long long)g.Nx * j + cplane * k;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const double rc = g.rho[k], rf = g.rho_f[k];
     const double p = F.phi_c[m];
     const double p_im = F.phi_c[m + c_im];
-    const double p_jm = F.phi_c[m + c_jm];
+    const double p_jm = (j == 0 && !g.wrap_y) ? F.phi_below[(long long)i + (long long)g.Nx * k] : F.phi_c[m + c_jm];
 
     // _pressure_correct_momentum!
     double ru = F.ru[n], rv = F.rv[n];
@@ -163,6 +165,8 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     }
 }
 
+// NOTE (y-slab mode): the periodic images stored by k_project_diagnose cover x and z only; the caller exchanges
+// the y halos of the fields the tendencies read (bz_* slab entry points in bz_slab.hip).
 int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                   double alpha, bool first)
 {
@@ -182,18 +186,18 @@ int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const
     return BZ_OK;
 }
 
-int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt)
+int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *rhs)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "poisson_source_term");
     dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
-    hipLaunchKernelGGL(k_poisson_source_rows, grid, block, 0, ctx->stream, g, ctx->d_rhs, s->rho_u, s->rho_v,
+    hipLaunchKernelGGL(k_poisson_source_rows, grid, block, 0, ctx->stream, g, rhs ? rhs : ctx->d_rhs, s->rho_u, s->rho_v,
                        s->rho_w, dt);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
 
-int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt)
+int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "project_and_diagnose");
@@ -201,7 +205,8 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt)
     F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w; F.rtheta = s->rho_theta; F.rq = s->rho_q;
     F.u = s->u; F.v = s->v; F.w = s->w; F.theta = s->theta; F.q = s->q; F.T = s->T;
     F.phi = s->phi;
-    F.phi_c = ctx->d_rhs;
+    F.phi_c = phi_c ? phi_c : ctx->d_rhs;
+    F.phi_below = phi_below;
     dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
     hipLaunchKernelGGL(k_project_diagnose, grid, block, 0, ctx->stream, g, F, dt);
     BZ_LAUNCH_CHECK();

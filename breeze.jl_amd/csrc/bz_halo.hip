@@ -76,7 +76,8 @@ int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, i
         if (kinds[i] < 2) anyz = true;
     }
     hipLaunchKernelGGL(k_halo_x, dim3((g.Ny + 63) / 64, nzmax, n), dim3(64), 0, ctx->stream, g, L);
-    hipLaunchKernelGGL(k_halo_y, dim3((g.Sx + 255) / 256, nzmax, n), dim3(256), 0, ctx->stream, g, L);
+    if (g.wrap_y)
+        hipLaunchKernelGGL(k_halo_y, dim3((g.Sx + 255) / 256, nzmax, n), dim3(256), 0, ctx->stream, g, L);
     if (anyz)
         hipLaunchKernelGGL(k_halo_z, dim3((unsigned)((g.Sxy + 255) / 256), 1, n), dim3(256), 0, ctx->stream, g, L);
     BZ_LAUNCH_CHECK();

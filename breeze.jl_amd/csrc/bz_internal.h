@@ -25,6 +25,7 @@ struct DevGrid {
     const double *rho, *rho_f;           // rho_r at centres;  0.5*(rho[k-1]+rho[k]) at faces
     const double *p_r, *T_r;
     double g, Rd, Rv, cpd, cpv, pst;
+    int wrap_y;            // 1: y halos are this rank's own periodic images; 0: y-slab, halos filled by the neighbour ranks
 
     __host__ __device__ inline long long idx(int i, int j, int k) const {
         return (long long)(i + Hx) + (long long)Sx * ((long long)(j + Hy)) + Sxy * (long long)(k + Hz);
@@ -58,6 +59,9 @@ struct bz_ctx {
     double *d_lower = nullptr;        // Nz
     double *d_scalar = nullptr;       // small scratch (mean, reductions)
     int tend_gen = 2;                 // tendency kernel generation (BZ_TEND_GEN: 1 = gen-1 everywhere, 2 = gen-1 momentum + fused scalar pair, 3 = gen-3 u,v + pair, 4 = gen-3 everywhere)
+    // y-slab decomposition (bz_create_slab): this rank owns Ny rows of Ny*y_nranks and the kx block
+    // [kx0, kx0+nkx) of the zero-padded half spectrum; the horizontal transforms are done by the caller.
+    int y_nranks = 1, y_rank = 0, nkx = 0, kx0 = 0, Ny_global = 0;
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
     // profiling
     bool profiling = false;
@@ -110,7 +114,10 @@ int bzi_poisson_spectral(bz_ctx *ctx);
 // fused streaming kernels (bz_fused.hip)
 int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                   double alpha, bool first);
-int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt);
-int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt);
+int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *rhs = nullptr);
+int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c = nullptr,
+                         const double *phi_below = nullptr);
+int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,
+               int weno_order, int y_nranks, int y_rank);
 int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w);
 int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);

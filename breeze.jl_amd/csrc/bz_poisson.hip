@@ -39,7 +39,9 @@ struct TriCols {
 };
 
 // One thread per horizontal wavenumber: tabulate 1/beta_k and t_k of the Thomas forward sweep.
-__global__ __launch_bounds__(256) void k_tridiag_setup(int NXH, int Ny, int Nz, TriCols C,
+// NXH = number of kx columns held here (the whole half spectrum, or this rank's block [kx0, kx0+NXH) of the
+// zero-padded half spectrum; columns with kx0+kx >= nxh_real are padding and get zero factors).
+__global__ __launch_bounds__(256) void k_tridiag_setup(int NXH, int Ny, int Nz, int kx0, int nxh_real, TriCols C,
                                                        double *__restrict__ ibeta,
                                                        double *__restrict__ tfac)
 {
@@ -47,7 +49,11 @@ __global__ __launch_bounds__(256) void k_tridiag_setup(int NXH, int Ny, int Nz, 
     long long plane = (long long)NXH * Ny;
     if (c >= plane) return;
     int kx = (int)(c % NXH), ky = (int)(c / NXH);
-    double lam = C.lam_x[kx] + C.lam_y[ky];
+    if (kx0 + kx >= nxh_real) {
+        for (int k = 0; k < Nz; ++k) { ibeta[c + plane * k] = 0.0; tfac[c + plane * k] = 0.0; }
+        return;
+    }
+    double lam = C.lam_x[kx0 + kx] + C.lam_y[ky];
     double beta = C.diag0[0] - C.mass[0] * lam;
     ibeta[c] = 1.0 / beta;
     tfac[c] = 0.0;
@@ -66,10 +72,10 @@ __global__ __launch_bounds__(256) void k_tridiag_setup(int NXH, int Ny, int Nz, 
 // Thomas solve along z, in place on the half-spectrum.  scale = 1/(Nx*Ny) folds in the inverse-FFT
 // normalisation.  Column (0,0) additionally gets its z-mean removed, which is the global mean of
 // phi (mean removal of Oceananigans' solve!).
-__global__ __launch_bounds__(64) void k_tridiag_solve(int NXH, int Ny, int Nz, const double *__restrict__ lower,
+__global__ void __launch_bounds__(64) k_tridiag_solve(int NXH, int Ny, int Nz, const double *__restrict__ lower,
                                                       const double *__restrict__ ibeta,
                                                       const double *__restrict__ tfac,
-                                                      double2 *__restrict__ hat, double scale)
+                                                      double2 *__restrict__ hat, double scale, int mean_column)
 {
     long long c = (long long)blockIdx.x * 64 + threadIdx.x;
     long long plane = (long long)NXH * Ny;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(64) void k_tridiag_solve(int NXH, int Ny, int Nz, c
         next = v;
         sum += v.x;
     }
-    if (c == 0) {
+    if (c == 0 && mean_column) {      // the (kx,ky) = (0,0) column lives here
         double mean = sum / Nz;
         for (int k = 0; k < Nz; ++k) hat[plane * k].x -= mean;
     }
@@ -118,16 +124,28 @@ __global__ __launch_bounds__(TX *TY) void k_phi_scatter(DevGrid g, double *__res
 int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive */)
 {
     const DevGrid &g = ctx->dg;
-    const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz, Hz = g.Hz;
-    ctx->NXH = Nx / 2 + 1;
-    const size_t nreal = (size_t)Nx * Ny * Nz, nhat = (size_t)ctx->NXH * Ny * Nz;
+    const int Nx = g.Nx, Nz = g.Nz, Hz = g.Hz;
+    const bool slab = ctx->y_nranks > 1;
+    const int nxh_real = Nx / 2 + 1;
+    int Ny = g.Ny;                       // rows of the spectral block: local rows, or ALL rows in slab mode
+    if (slab) {
+        ctx->nkx = (nxh_real + ctx->y_nranks - 1) / ctx->y_nranks;
+        ctx->kx0 = ctx->y_rank * ctx->nkx;
+        ctx->NXH = ctx->nkx;
+        Ny = ctx->Ny_global;
+    } else {
+        ctx->NXH = nxh_real;
+        ctx->nkx = nxh_real;
+        ctx->kx0 = 0;
+    }
+    const size_t nreal = (size_t)Nx * g.Ny * Nz, nhat = (size_t)ctx->NXH * Ny * Nz;
 
     // ---- host column coefficients (anelastic_pressure_solver.jl:39-78) ----
     std::vector<double> dzc(Nz + 2 * Hz), dzf(Nz + 1 + 2 * Hz);
     BZ_HIP(hipMemcpy(dzc.data(), g.dzc - Hz, dzc.size() * sizeof(double), hipMemcpyDeviceToHost));
     BZ_HIP(hipMemcpy(dzf.data(), g.dzf - Hz, dzf.size() * sizeof(double), hipMemcpyDeviceToHost));
     const double *rho = h_rho + Hz;
-    std::vector<double> lower(Nz, 0.0), diag0(Nz), mass(Nz), lam_x(ctx->NXH), lam_y(Ny);
+    std::vector<double> lower(Nz, 0.0), diag0(Nz), mass(Nz), lam_x(nxh_real), lam_y(Ny);
     for (int k = 0; k < Nz - 1; ++k) lower[k] = (0.5 * (rho[k] + rho[k + 1])) / dzf[k + 1 + Hz];
     for (int k = 0; k < Nz; ++k) {
         double up = (k < Nz - 1) ? lower[k] : 0.0;
@@ -136,32 +154,35 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
         mass[k] = rho[k] * dzc[k + Hz];
     }
     const double pi = 3.14159265358979323846;
-    for (int i = 0; i < ctx->NXH; ++i) { double s = 2.0 * std::sin(i * pi / Nx) / g.dx; lam_x[i] = s * s; }
+    for (int i = 0; i < nxh_real; ++i) { double s = 2.0 * std::sin(i * pi / Nx) / g.dx; lam_x[i] = s * s; }
     for (int j = 0; j < Ny; ++j) { double s = 2.0 * std::sin(j * pi / Ny) / g.dy; lam_y[j] = s * s; }
 
     double *d_cols = nullptr;
-    size_t ncols = (size_t)3 * Nz + ctx->NXH + Ny;
+    size_t ncols = (size_t)3 * Nz + nxh_real + Ny;
     BZ_HIP(hipMalloc(&d_cols, ncols * sizeof(double)));
     ctx->d_lower = d_cols;
-    double *d_diag0 = d_cols + Nz, *d_mass = d_cols + 2 * Nz, *d_lx = d_cols + 3 * Nz, *d_ly = d_lx + ctx->NXH;
+    double *d_diag0 = d_cols + Nz, *d_mass = d_cols + 2 * Nz, *d_lx = d_cols + 3 * Nz, *d_ly = d_lx + nxh_real;
     BZ_HIP(hipMemcpy(ctx->d_lower, lower.data(), Nz * sizeof(double), hipMemcpyHostToDevice));
     BZ_HIP(hipMemcpy(d_diag0, diag0.data(), Nz * sizeof(double), hipMemcpyHostToDevice));
     BZ_HIP(hipMemcpy(d_mass, mass.data(), Nz * sizeof(double), hipMemcpyHostToDevice));
-    BZ_HIP(hipMemcpy(d_lx, lam_x.data(), ctx->NXH * sizeof(double), hipMemcpyHostToDevice));
+    BZ_HIP(hipMemcpy(d_lx, lam_x.data(), nxh_real * sizeof(double), hipMemcpyHostToDevice));
     BZ_HIP(hipMemcpy(d_ly, lam_y.data(), Ny * sizeof(double), hipMemcpyHostToDevice));
 
-    BZ_HIP(hipMalloc(&ctx->d_rhs, nreal * sizeof(double)));
-    BZ_HIP(hipMalloc(&ctx->d_hat, nhat * sizeof(hipfftDoubleComplex)));
+    if (!slab) {
+        BZ_HIP(hipMalloc(&ctx->d_rhs, nreal * sizeof(double)));
+        BZ_HIP(hipMalloc(&ctx->d_hat, nhat * sizeof(hipfftDoubleComplex)));
+    }
     BZ_HIP(hipMalloc(&ctx->d_ibeta, nhat * sizeof(double)));
     BZ_HIP(hipMalloc(&ctx->d_tfac, nhat * sizeof(double)));
 
     TriCols C{ctx->d_lower, d_diag0, d_mass, d_lx, d_ly};
     long long plane = (long long)ctx->NXH * Ny;
-    hipLaunchKernelGGL(k_tridiag_setup, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, 0, ctx->NXH, Ny, Nz, C,
+    hipLaunchKernelGGL(k_tridiag_setup, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, 0, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, C,
                        ctx->d_ibeta, ctx->d_tfac);
     BZ_HIP(hipGetLastError());
     BZ_HIP(hipDeviceSynchronize());
 
+    if (slab) return BZ_OK;          // horizontal transforms are the caller's (distributed) in slab mode
     // ---- rocFFT plans: 2-D (y,x) transforms batched over z ----
     int n[2] = {Ny, Nx};
     BZ_FFT(hipfftPlanMany(&ctx->plan_fwd, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, Nz));
@@ -202,7 +223,7 @@ int bzi_poisson_spectral(bz_ctx *ctx)
         long long plane = (long long)ctx->NXH * g.Ny;
         hipLaunchKernelGGL(k_tridiag_solve, dim3((unsigned)((plane + 63) / 64)), dim3(64), 0, ctx->stream, ctx->NXH,
                            g.Ny, g.Nz, ctx->d_lower, ctx->d_ibeta, ctx->d_tfac, (double2 *)ctx->d_hat,
-                           1.0 / ((double)g.Nx * (double)g.Ny));
+                           1.0 / ((double)g.Nx * (double)g.Ny), 1);
         BZ_LAUNCH_CHECK();
     }
     {
@@ -236,6 +257,11 @@ int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt)
 extern "C" int bz_compute_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt)
 {
     if (!ctx || !s) return BZ_ERR_INVALID;
+    if (ctx->y_nranks > 1) {
+        ctx->last_error = "bz_compute_pressure_correction: y-slab contexts solve through bz_poisson_source_term / "
+                          "bz_spectral_tridiagonal_solve / bz_project_and_diagnose";
+        return BZ_ERR_UNSUPPORTED;
+    }
     double *mf[3] = {s->rho_u, s->rho_v, s->rho_w};
     int mk[3] = {0, 0, 1};
     int rc = bzi_fill_halos_multi(ctx, mf, mk, 3);   // anelastic_time_stepping.jl:29

@@ -1,0 +1,372 @@
+"""One-process-per-GPU y-slab decomposition of the anelastic step.
+
+The reference has no distributed code of its own (it re-exports Oceananigans' MPI-based `Distributed`,
+src/Breeze.jl:172,183,209; no test or example uses it), so this is this repo's design, MI355X-first:
+
+* 1-D slabs in y over the ranks of one node.  x stays whole and contiguous (coalescing, local x-FFT), z stays
+  whole (tridiagonal solve, vertical WENO stencils, column physics).
+* y-halo exchange = paired send/recv with the two ring neighbours, all fields of an exchange packed into one
+  message per direction (xGMI is point-to-point: one message per link, not a ring collective).
+* Poisson solve = local real-to-complex x-FFT -> transpose to kx-slabs (every rank sends one block to every
+  other rank, so all xGMI links of a GPU are busy at once) -> y-FFT, Thomas solve in z, inverse y-FFT ->
+  transpose back -> complex-to-real x-FFT.  The transposes are point-to-point batches (`batch_isend_irecv`), which
+  RCCL runs as one grouped operation and gloo (CPU tests) also supports.
+* Everything else is rank-local: the same HIP kernels as the single-GPU path, through the slab entry points of
+  include/breeze_hip.h (`bz_create_slab`, `bz_ssp_rk3_substep_fused`, `bz_poisson_source_term`,
+  `bz_spectral_tridiagonal_solve`, `bz_project_and_diagnose`, `bz_compute_tendencies`).
+
+`SlabStepper` holds the collective orchestration and is backend-agnostic (any object providing the `local_*`
+operations on torch tensors), which is how tests/test_distributed.py runs it on CPU with gloo, world size 2 and 4,
+against the single-process oracle.  `SlabAtmosphereModel` is the GPU backend.
+
+Status: verified on CPU (gloo).  The RCCL path has not run on multi-GPU hardware from this container (gpurun gives
+one GPU); the round-end scaling run is its first exposure.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .grids import Bounded, Center, Face, Periodic, RectilinearGrid
+from .thermodynamics import (ReferenceState, ThermodynamicConstants, dry_air_gas_constant,
+                             vapor_gas_constant)
+
+
+class SlabDecomposition:
+    """Communication pattern of a y-slab decomposition over `world` ranks (torch.distributed, any backend)."""
+
+    def __init__(self, Nx, Ny_local, Nz, Hy, rank=0, world=1, group=None):
+        self.Nx, self.Ny, self.Nz, self.Hy = Nx, Ny_local, Nz, Hy
+        self.rank, self.world, self.group = rank, world, group
+        self.Ny_global = Ny_local * world
+        self.nxh = Nx // 2 + 1
+        self.nkx = -(-self.nxh // world)            # kx columns per rank (zero-padded half spectrum)
+        self.nxh_pad = self.nkx * world
+        self.kx0 = rank * self.nkx
+        self.upper = (rank + 1) % world
+        self.lower = (rank - 1) % world
+        if Ny_local < Hy:
+            raise ValueError("a slab must hold at least Hy rows")
+
+    # -- point-to-point helper -------------------------------------------------
+    def _p2p(self, sends, recvs):
+        """sends: [(tensor, dst)], recvs: [(tensor, src)] — all posted as one batch."""
+        import torch.distributed as dist
+        ops = [dist.P2POp(dist.isend, t, d, group=self.group) for t, d in sends]
+        ops += [dist.P2POp(dist.irecv, t, s, group=self.group) for t, s in recvs]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    # -- halos -----------------------------------------------------------------
+    def exchange_y_halos(self, fields):
+        """Fill the Hy y-halo rows of every parent tensor ((z, y, x)-shaped, full x width and all z levels)
+        from the ring neighbours (periodic in y over the whole domain)."""
+        import torch
+        Hy, Ny = self.Hy, self.Ny
+        if not fields:
+            return
+        if self.world == 1:
+            for f in fields:
+                f[:, :Hy, :] = f[:, Ny:Ny + Hy, :]
+                f[:, Hy + Ny:, :] = f[:, Hy:2 * Hy, :]
+            return
+        up = torch.cat([f[:, Ny:Ny + Hy, :].reshape(-1) for f in fields])        # my top rows -> upper's bottom halo
+        down = torch.cat([f[:, Hy:2 * Hy, :].reshape(-1) for f in fields])       # my bottom rows -> lower's top halo
+        from_lower, from_upper = torch.empty_like(up), torch.empty_like(down)
+        # order matters when lower == upper (world 2): sends "up then down", receives "from lower then from upper"
+        self._p2p([(up, self.upper), (down, self.lower)], [(from_lower, self.lower), (from_upper, self.upper)])
+        o = 0
+        for f in fields:
+            n = f.shape[0] * Hy * f.shape[2]
+            f[:, :Hy, :] = from_lower[o:o + n].view(f.shape[0], Hy, f.shape[2])
+            f[:, Hy + Ny:, :] = from_upper[o:o + n].view(f.shape[0], Hy, f.shape[2])
+            o += n
+
+    def row_from_lower(self, top_row):
+        """Send my top interior row (any tensor) to the upper neighbour; return the lower neighbour's."""
+        import torch
+        if self.world == 1:
+            return top_row.clone()
+        buf = torch.empty_like(top_row)
+        self._p2p([(top_row.contiguous(), self.upper)], [(buf, self.lower)])
+        return buf
+
+    # -- transposes of the distributed transform ------------------------------------
+    def to_kx_slabs(self, R):
+        """(Nz, Ny_local, nxh_pad) complex, y-slab  ->  (Nz, Ny_global, nkx) complex, kx-slab."""
+        import torch
+        Nz, Ny, nkx, W = self.Nz, self.Ny, self.nkx, self.world
+        if W == 1:
+            return R.contiguous()
+        send = [torch.view_as_real(R[:, :, p * nkx:(p + 1) * nkx].contiguous()) for p in range(W)]
+        recv = [torch.empty_like(send[0]) for _ in range(W)]
+        recv[self.rank].copy_(send[self.rank])
+        peers = [p for p in range(W) if p != self.rank]
+        self._p2p([(send[p], p) for p in peers], [(recv[p], p) for p in peers])
+        return torch.view_as_complex(torch.cat(recv, dim=1))          # rank q's rows are global rows q*Ny ...
+
+    def to_y_slabs(self, S):
+        """(Nz, Ny_global, nkx) complex, kx-slab  ->  (Nz, Ny_local, nxh_pad) complex, y-slab."""
+        import torch
+        Ny, W = self.Ny, self.world
+        if W == 1:
+            return S.contiguous()
+        send = [torch.view_as_real(S[:, q * Ny:(q + 1) * Ny, :].contiguous()) for q in range(W)]
+        recv = [torch.empty_like(send[0]) for _ in range(W)]
+        recv[self.rank].copy_(send[self.rank])
+        peers = [p for p in range(W) if p != self.rank]
+        self._p2p([(send[p], p) for p in peers], [(recv[p], p) for p in peers])
+        return torch.view_as_complex(torch.cat(recv, dim=2))          # rank p's block is kx in [p*nkx, (p+1)*nkx)
+
+
+class SlabStepper:
+    """Collective orchestration of the SSP-RK3 anelastic step on y-slabs
+    (call order of src/TimeSteppers/ssp_runge_kutta_3.jl:209-278 and
+    src/AnelasticEquations/anelastic_time_stepping.jl:26-78).
+
+    A backend supplies, on its own slab (torch tensors, any device):
+      local_rk3(dt, alpha, first)            ssp_rk3_substep! (+ store_initial_state! when first)
+      local_source(dt) -> rhs                (Nz, Ny, Nx) real; needs the y halo of the momentum current
+      local_spectral_solve(S)                in place on (Nz, Ny_global, nkx) complex; zero-mean gauge
+      local_project_diagnose(phi, below, dt) projection + velocities + theta, q, T + x/z halo fills
+      local_tendencies()                     needs the y halos of tendency_halo_fields() current
+      momentum_fields(), tendency_halo_fields()  -> lists of parent tensors
+    """
+
+    def __init__(self, decomp):
+        self.decomp = decomp
+
+    def poisson_solve(self, rhs):
+        import torch
+        d = self.decomp
+        R = torch.fft.rfft(rhs, dim=2)                                  # local x transform
+        if d.nxh_pad != d.nxh:
+            R = torch.nn.functional.pad(R, (0, d.nxh_pad - d.nxh))
+        S = d.to_kx_slabs(R)
+        S = torch.fft.fft(S, dim=1).contiguous()                        # y transform, all rows present
+        self.local_spectral_solve(S)
+        S = torch.fft.ifft(S, dim=1)
+        R = d.to_y_slabs(S)
+        return torch.fft.irfft(R[:, :, :d.nxh], n=d.Nx, dim=2).contiguous()
+
+    def pressure_projection(self, dt):
+        """compute_pressure_correction! + make_pressure_correction! + update_state!(compute_tendencies=false)."""
+        d = self.decomp
+        d.exchange_y_halos(self.momentum_fields())
+        phi = self.poisson_solve(self.local_source(dt))
+        below = d.row_from_lower(phi[:, d.Ny - 1, :])
+        self.local_project_diagnose(phi, below, dt)
+        d.exchange_y_halos(self.tendency_halo_fields())
+
+    def stage(self, dt, alpha, first):
+        self.local_rk3(dt, alpha, first)
+        self.pressure_projection(alpha * dt)
+        self.local_tendencies()
+
+    def time_step(self, dt):
+        for n, alpha in enumerate((1.0, 1.0 / 4.0, 2.0 / 3.0)):
+            self.stage(dt, alpha, n == 0)
+
+
+_LOC = {"ccc": (Center, Center, Center), "fcc": (Face, Center, Center),
+        "cfc": (Center, Face, Center), "ccf": (Center, Center, Face)}
+
+
+class SlabAtmosphereModel(SlabStepper):
+    """AtmosphereModel on one y-slab of a (Periodic, Periodic, Bounded) global grid: rank r of `world` owns rows
+    [r*Ny/world, (r+1)*Ny/world).  Same fields, kernels and call order as `AtmosphereModel`; halos in y and the
+    Poisson transposes go through torch.distributed (backend "nccl" = RCCL on ROCm)."""
+
+    def __init__(self, global_grid, rank, world, advection=None, thermodynamic_constants=None,
+                 surface_pressure=101325, potential_temperature=288, standard_pressure=1e5, device=None, group=None):
+        import torch
+        from .model import Clock, Field, WENO
+        if global_grid.topology != (Periodic, Periodic, Bounded):
+            raise NotImplementedError("slab decomposition implements topology (Periodic, Periodic, Bounded)")
+        if advection is None or getattr(advection, "order", None) != 5:
+            raise NotImplementedError("the HIP path requires advection=WENO(order=5)")
+        if global_grid.Ny % world:
+            raise ValueError(f"Ny={global_grid.Ny} is not divisible by {world} ranks")
+        if not torch.cuda.is_available():
+            raise RuntimeError("SlabAtmosphereModel needs a GPU: the HIP path has no CPU fallback")
+        self.global_grid = G = global_grid
+        self.rank, self.world = rank, world
+        Ny = G.Ny // world
+        y0 = G.yᶠ[0] + rank * Ny * G.Δy
+        z = (G.zᶠ[0], G.zᶠ[-1]) if G.regular_z else G.zᶠ
+        self.grid = grid = RectilinearGrid((G.Nx, Ny, G.Nz), x=(G.xᶠ[0], G.xᶠ[0] + G.Nx * G.Δx),
+                                           y=(y0, y0 + Ny * G.Δy), z=z, halo=(G.Hx, G.Hy, G.Hz))
+        grid.Δx, grid.Δy = G.Δx, G.Δy          # bit-identical spacings on every rank
+        SlabStepper.__init__(self, getattr(self, "_decomp_override", None) or
+                             SlabDecomposition(G.Nx, Ny, G.Nz, G.Hy, rank, world, group))
+        self.thermodynamic_constants = c = thermodynamic_constants or ThermodynamicConstants()
+        self.reference_state = ref = ReferenceState(grid, c, surface_pressure, potential_temperature, standard_pressure)
+        self.clock = Clock()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        self._lib = lib = _lib.load()
+
+        def fld(loc):
+            return Field(grid, _LOC[loc], self.device)
+
+        self.momentum = {"ρu": fld("fcc"), "ρv": fld("cfc"), "ρw": fld("ccf")}
+        self.velocities = {"u": fld("fcc"), "v": fld("cfc"), "w": fld("ccf")}
+        self.potential_temperature_density, self.potential_temperature = fld("ccc"), fld("ccc")
+        self.moisture_density, self.specific_moisture = fld("ccc"), fld("ccc")
+        self.temperature, self.pressure_anomaly = fld("ccc"), fld("ccc")
+        prog = self.prognostic_fields()
+        self.U0 = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}
+        self.G = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}
+
+        self._zf = np.ascontiguousarray(grid.zᶠ, dtype=np.float64)
+        bg = _lib.bz_grid()
+        bg.Nx, bg.Ny, bg.Nz = grid.Nx, grid.Ny, grid.Nz
+        bg.Hx, bg.Hy, bg.Hz = grid.Hx, grid.Hy, grid.Hz
+        for dd, t in enumerate(grid.topology_codes()):
+            bg.topo[dd] = t
+        bg.ftype = 8
+        bg.dx, bg.dy = grid.Δx, grid.Δy
+        bg.zf = self._zf.ctypes.data_as(C.POINTER(C.c_double))
+        bg.regular_z = 1 if grid.regular_z else 0
+        bc = _lib.bz_constants(c.gravitational_acceleration, dry_air_gas_constant(c), vapor_gas_constant(c),
+                               c.dry_air_heat_capacity, c.vapor_heat_capacity)
+        self._ref_arrays = [np.ascontiguousarray(a, dtype=np.float64) for a in (ref.density, ref.pressure, ref.temperature)]
+        br = _lib.bz_reference_state(ref.surface_pressure, ref.potential_temperature, ref.standard_pressure,
+                                     *[a.ctypes.data_as(C.POINTER(C.c_double)) for a in self._ref_arrays])
+        self._ctx = C.c_void_p()
+        rc = lib.bz_create_slab(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), advection.order, world, rank)
+        if rc != 0:
+            raise _lib.BreezeHIPError(f"bz_create_slab failed with code {rc}")
+        self._check(lib.bz_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "bz_set_stream")
+        self._state, self._U0, self._G = self._make_state(), self._make_prog(self.U0), self._make_prog(self.G)
+        self.set(θ=ref.potential_temperature)
+
+    # plumbing shared with AtmosphereModel -------------------------------------------------
+    def _check(self, rc, what):
+        _lib.check(self._lib, self._ctx, rc, what)
+
+    def prognostic_fields(self):
+        return {"ρu": self.momentum["ρu"], "ρv": self.momentum["ρv"], "ρw": self.momentum["ρw"],
+                "ρθ": self.potential_temperature_density, "ρq": self.moisture_density}
+
+    def _make_state(self):
+        s = _lib.bz_state()
+        s.rho_u, s.rho_v, s.rho_w = (self.momentum[k].ptr() for k in ("ρu", "ρv", "ρw"))
+        s.rho_theta, s.rho_q = self.potential_temperature_density.ptr(), self.moisture_density.ptr()
+        s.u, s.v, s.w = (self.velocities[k].ptr() for k in ("u", "v", "w"))
+        s.theta, s.q, s.T = self.potential_temperature.ptr(), self.specific_moisture.ptr(), self.temperature.ptr()
+        s.phi = self.pressure_anomaly.ptr()
+        return s
+
+    @staticmethod
+    def _make_prog(d):
+        p = _lib.bz_prognostic()
+        p.rho_u, p.rho_v, p.rho_w, p.rho_theta, p.rho_q = (d[k].ptr() for k in ("ρu", "ρv", "ρw", "ρθ", "ρq"))
+        return p
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self._lib.bz_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._lib.bz_sync(self._ctx), "bz_sync")
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.bz_profile_enable(self._ctx, 1 if on else 0), "bz_profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.bz_profile_reset(self._ctx), "bz_profile_reset")
+
+    def profile(self):
+        out = {}
+        for i in range(self._lib.bz_profile_count(self._ctx)):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            self._check(self._lib.bz_profile_get(self._ctx, i, C.byref(name), C.byref(ms), C.byref(n)), "bz_profile_get")
+            out[name.value.decode()] = (ms.value, n.value)
+        return out
+
+    # SlabStepper backend ---------------------------------------------------------------------
+    def momentum_fields(self):
+        return [self.momentum[k].parent for k in ("ρu", "ρv", "ρw")]
+
+    def tendency_halo_fields(self):
+        return ([self.momentum[k].parent for k in ("ρu", "ρv", "ρw")] +
+                [self.velocities[k].parent for k in ("u", "v", "w")] +
+                [self.potential_temperature.parent, self.specific_moisture.parent, self.temperature.parent,
+                 self.potential_temperature_density.parent, self.moisture_density.parent, self.pressure_anomaly.parent])
+
+    def local_rk3(self, dt, alpha, first):
+        self._check(self._lib.bz_ssp_rk3_substep_fused(self._ctx, C.byref(self._state), C.byref(self._U0), C.byref(self._G),
+                                                       float(dt), float(alpha), 1 if first else 0), "bz_ssp_rk3_substep_fused")
+
+    def local_source(self, dt):
+        import torch
+        g = self.grid
+        rhs = torch.empty((g.Nz, g.Ny, g.Nx), dtype=torch.float64, device=self.device)
+        self._check(self._lib.bz_poisson_source_term(self._ctx, C.byref(self._state), float(dt), C.c_void_p(rhs.data_ptr())),
+                    "bz_poisson_source_term")
+        return rhs
+
+    def local_spectral_solve(self, S):
+        assert S.is_contiguous()
+        self._check(self._lib.bz_spectral_tridiagonal_solve(self._ctx, C.c_void_p(S.data_ptr()), 1.0),
+                    "bz_spectral_tridiagonal_solve")
+
+    def local_project_diagnose(self, phi, below, dt):
+        assert phi.is_contiguous()
+        below = below.contiguous()
+        self._keep = (phi, below)        # keep alive until the stream has consumed them
+        self._check(self._lib.bz_project_and_diagnose(self._ctx, C.byref(self._state), C.c_void_p(phi.data_ptr()),
+                                                      C.c_void_p(below.data_ptr()), float(dt)), "bz_project_and_diagnose")
+
+    def local_tendencies(self):
+        self._check(self._lib.bz_compute_tendencies(self._ctx, C.byref(self._state), C.byref(self._G)), "bz_compute_tendencies")
+
+    # model API ---------------------------------------------------------------------------------
+    def set(self, enforce_mass_conservation=True, **kw):
+        """set!(model; θ, u, v, w, qᵗ, ρu, ...) with functions of the GLOBAL coordinates."""
+        import torch
+        from .model import _ALIASES
+        g, ref = self.grid, self.reference_state
+        Hz, Nz = g.Hz, g.Nz
+        ρc = torch.from_numpy(ref.density[Hz:Hz + Nz].copy()).to(self.device)[:, None, None]
+        ρf = torch.from_numpy(0.5 * (ref.density[Hz - 1:Hz + Nz] + ref.density[Hz:Hz + Nz + 1])).to(self.device)[:, None, None]
+        for name, value in kw.items():
+            key = _ALIASES.get(name)
+            if key is None:
+                raise ValueError(f"Cannot set! {name} in AtmosphereModel")
+            if key == "θ":
+                self.potential_temperature.set_interior(value)
+                self.potential_temperature_density.interior.copy_(ρc * self.potential_temperature.interior)
+            elif key == "ρθ":
+                self.potential_temperature_density.set_interior(value)
+            elif key == "q":
+                self.specific_moisture.set_interior(value)
+                self.moisture_density.interior.copy_(ρc * self.specific_moisture.interior)
+            elif key == "ρq":
+                self.moisture_density.set_interior(value)
+            elif key in ("u", "v"):
+                self.velocities[key].set_interior(value)
+                self.momentum["ρ" + key].interior.copy_(ρc * self.velocities[key].interior)
+            elif key == "w":
+                self.velocities["w"].set_interior(value)
+                self.momentum["ρw"].interior.copy_(ρf * self.velocities["w"].interior)
+            else:
+                self.momentum[key].set_interior(value)
+        # update_state!(compute_tendencies=false): x/z halos + diagnostics locally, y halos from the neighbours
+        self._check(self._lib.bz_update_state(self._ctx, C.byref(self._state), C.byref(self._G), 0), "bz_update_state")
+        self.decomp.exchange_y_halos(self.tendency_halo_fields())
+        if enforce_mass_conservation:
+            self.pressure_projection(1.0)
+
+    def time_step(self, Δt):
+        if self.clock.iteration == 0:          # maybe_prepare_first_time_step!
+            self.local_tendencies()
+        SlabStepper.time_step(self, Δt)
+        self.clock.time += Δt
+        self.clock.iteration += 1

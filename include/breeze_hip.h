@@ -139,6 +139,29 @@ int bz_make_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt);
 int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
                            const bz_prognostic *G, double dt);
 
+/* ---- y-slab decomposition: one process per GPU --------------------------------------------------
+ * The reference re-exports Oceananigans' Distributed architecture (src/Breeze.jl:172,183,209) and has no
+ * distributed code of its own; these entry points are the rank-local kernels of this repo's decomposition.
+ * `local_grid` describes this rank's slab: Ny = rows owned (global Ny = Ny * y_nranks), y halos are filled by the
+ * caller's neighbour exchange instead of a periodic wrap.  The caller also performs the horizontal transforms of
+ * the Poisson solve (x-FFT, all-to-all to kx slabs, y-FFT and back); this rank's spectral block is
+ * [Nz][Ny_global][nkx] complex (kx fastest) for kx in [kx0, kx0+nkx) of the zero-padded half spectrum. */
+int bz_create_slab(bz_ctx **ctx, const bz_grid *local_grid, const bz_constants *constants,
+                   const bz_reference_state *reference_state, int weno_order, int y_nranks, int y_rank);
+int bz_slab_info(bz_ctx *ctx, int32_t *y_nranks, int32_t *y_rank, int32_t *nkx, int32_t *kx0, int32_t *ny_global);
+/* ssp_rk3_substep! with store_initial_state! folded into the first stage (first != 0 requires alpha == 1). */
+int bz_ssp_rk3_substep_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G,
+                             double dt, double alpha, int first);
+/* compute_anelastic_source_term! into rhs (device, contiguous Nx*Ny*Nz); in slab mode row Ny of rho_v must hold
+ * the neighbour's first row. */
+int bz_poisson_source_term(bz_ctx *ctx, const bz_state *s, double dt, double *rhs);
+/* Thomas solve along z of every horizontal wavenumber of this rank's spectral block, in place; `scale` multiplies
+ * the right-hand side (inverse-transform normalisation); the (0,0) column gets its z-mean removed. */
+int bz_spectral_tridiagonal_solve(bz_ctx *ctx, double *hat, double scale);
+/* make_pressure_correction! + compute_velocities! + thermodynamic diagnosis + x/z halo fills in one pass from the
+ * contiguous solution phi_c (Nx*Ny*Nz); phi_below = phi of row j = -1, layout [k][i] (slab mode; else NULL). */
+int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below, double dt);
+
 /* ---- instrumentation (not part of the reference interface) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
 int bz_profile_enable(bz_ctx *ctx, int on);

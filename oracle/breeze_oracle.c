@@ -37,6 +37,7 @@
 #define PERIODIC 0
 #define BOUNDED 1
 #define FLAT 2
+#define SLAB 3   /* periodic stencils; halos are filled by the caller (y-slab decomposition tests) */
 
 typedef struct {
     int Nx, Ny, Nz;

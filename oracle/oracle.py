@@ -30,9 +30,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libbreeze_oracle.so")
 
-PERIODIC, BOUNDED, FLAT = 0, 1, 2
-_TOPO = {"Periodic": PERIODIC, "Bounded": BOUNDED, "Flat": FLAT,
-         PERIODIC: PERIODIC, BOUNDED: BOUNDED, FLAT: FLAT}
+PERIODIC, BOUNDED, FLAT, SLAB = 0, 1, 2, 3     # SLAB: periodic stencils, halos filled by the caller (y-slab tests)
+_TOPO = {"Periodic": PERIODIC, "Bounded": BOUNDED, "Flat": FLAT, "Slab": SLAB,
+         PERIODIC: PERIODIC, BOUNDED: BOUNDED, FLAT: FLAT, SLAB: SLAB}
 
 
 def build(force=False):
@@ -141,7 +141,7 @@ class Grid:
         self.Nx, self.Ny, self.Nz = N
         self.Hx, self.Hy, self.Hz = H
         assert topo[2] == BOUNDED, "oracle supports Bounded z only"
-        assert topo[0] in (PERIODIC, FLAT) and topo[1] in (PERIODIC, FLAT)
+        assert topo[0] in (PERIODIC, FLAT) and topo[1] in (PERIODIC, FLAT, SLAB)
 
         def regular(ext, n, flat):
             if flat:
@@ -249,7 +249,7 @@ class OracleModel:
     PROGNOSTIC = ("ru", "rv", "rw", "rtheta", "rq")
 
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
-                 standard_pressure=1e5, reference_density=None):
+                 standard_pressure=1e5, reference_density=None, initialize=True):
         self.grid = g = grid
         self.constants = c = constants or Constants()
         self.ref = ReferenceState(g, c, surface_pressure, potential_temperature, standard_pressure)
@@ -271,12 +271,14 @@ class OracleModel:
         self.diag0 = np.zeros(g.Nz)
         self.mass = np.zeros(g.Nz)
         self.lib.og_poisson_coefficients(C.byref(self.cg), _p(self.lower), _p(self.diag0), _p(self.mass))
-        lx = poisson_eigenvalues(g.Nx, g.dx, g.topo[0])
-        ly = poisson_eigenvalues(g.Ny, g.dy, g.topo[1])
-        self.lam = np.ascontiguousarray(ly[:, None] + lx[None, :])
         self.clock_time, self.iteration = 0.0, 0
-        # initialize_model_thermodynamics!: theta = theta0 (anelastic_time_stepping.jl:15-19)
-        self.set(theta=self.ref.theta0)
+        if g.topo[1] != SLAB:
+            lx = poisson_eigenvalues(g.Nx, g.dx, g.topo[0])
+            ly = poisson_eigenvalues(g.Ny, g.dy, g.topo[1])
+            self.lam = np.ascontiguousarray(ly[:, None] + lx[None, :])
+        if initialize:
+            # initialize_model_thermodynamics!: theta = theta0 (anelastic_time_stepping.jl:15-19)
+            self.set(theta=self.ref.theta0)
 
     def _mk_cgrid(self):
         g, c, r = self.grid, self.constants, self.ref

@@ -160,8 +160,17 @@ def main():
         dom = max((k for k in kernels if k in WORDS_PER_CELL), key=lambda k: kernels[k]["total_ms"])
         dom_bytes = WORDS_PER_CELL[dom] * 8 * cells
         achieved = dom_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        # measured HBM-side bytes per launch of that kernel group (rocprofv3 PMC passes, committed under profiles/;
+        # collected at the default 512^3 size only)
+        traffic = None
+        try:
+            if N == 512:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                    traffic = json.load(fh)["per_kernel_group"][dom]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"]}
         step_achieved = (cells * args.steps / elapsed) * A_STEP_WORDS * 8 / 1e9
         out = {

@@ -121,3 +121,4 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
                int weno_order, int y_nranks, int y_rank);
 int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w);
 int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);

@@ -11,6 +11,8 @@
 // register ring, the vertical flux through the lower face is carried from the previous level, and
 // horizontal stencils are read straight from global memory (L1/L2 resident: the tile's rows were
 // touched by the neighbouring lanes / rows a few instructions earlier).
+#include <cstdlib>
+
 #include "bz_internal.h"
 #include "bz_weno.h"
 
@@ -298,7 +300,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
         ProfileScope ps(ctx, "y_momentum_tendency");
         hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc);
     }
-    {
+    if (ctx->tend_gen >= 2 && !getenv("BZ_W_GEN1")) {
+        int rc = bzi_w_tendency_ring(ctx, s, G);
+        if (rc) return rc;
+    } else {
         ProfileScope ps(ctx, "z_momentum_tendency");
         int kcw = pick_kchunk(g, g.Nz - 1);
         dim3 gridw(grid.x, grid.y, (g.Nz - 1 + kcw - 1) / kcw);

@@ -26,6 +26,7 @@ static void launch3(bz_ctx *ctx, const Tend3Fields &F)
 }
 
 int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 
 int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w)
 {
@@ -43,9 +44,8 @@ int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
         launch3<T3_V, 1>(ctx, F);
     }
     if (include_w) {
-        ProfileScope ps(ctx, "z_momentum_tendency");
-        F.c = s->w; F.G = G->rho_w;
-        launch3<T3_W, 2>(ctx, F);
+        int rc = bzi_w_tendency_ring(ctx, s, G);
+        if (rc) return rc;
     }
     {
         int rc = bzi_scalar_pair_tendency(ctx, s, G);
@@ -64,6 +64,23 @@ int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic
     dim3 block(64, T3_TYW), grid((g.Nx + 63) / 64, (g.Ny + T3_TYW - 1) / T3_TYW, (g.Nz + kc - 1) / kc);
     hipLaunchKernelGGL((k_scalar_pair<T3_TYW>), grid, block, 0, ctx->stream, g, s->u, s->v, s->w, s->theta, s->q,
                        G->rho_theta, G->rho_q, kc);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// z-momentum tendency with register rings for every vertical stencil (k_w_tend_ring)
+int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "z_momentum_tendency");
+    Tend3Fields F;
+    F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w;
+    F.u = s->u; F.v = s->v; F.w = s->w; F.T = s->T; F.q = s->q;
+    F.c = s->w; F.G = G->rho_w;
+    const int nlev = g.Nz - 1;
+    const int kc = pick_chunk3(g, nlev, T3_TYW);
+    dim3 block(64, T3_TYW), grid((g.Nx + 63) / 64, (g.Ny + T3_TYW - 1) / T3_TYW, (nlev + kc - 1) / kc);
+    hipLaunchKernelGGL((k_w_tend_ring<T3_TYW>), grid, block, 0, ctx->stream, g, F, kc);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

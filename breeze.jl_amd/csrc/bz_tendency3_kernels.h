@@ -350,3 +350,106 @@ __global__ __launch_bounds__(64 * TYW) void k_scalar_pair(DevGrid g, const doubl
         a[5] = ta; b[5] = tb;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// z-momentum tendency with every vertical stencil in registers.
+// rocprofv3 PMC on the gen-1 kernel: 21 GB fetched per launch at 512^3 for 6.4 GB of input arrays — the
+// centred-in-z interpolation of the advecting fluxes (rho_u, rho_v at levels k-2..k+1, rho_w at k-1..k+2)
+// re-read four planes of three arrays at every level.  Here each of those columns is a register ring fed by one
+// new load per level; the x flux of the neighbouring column comes from a wave shuffle (+ batched out-of-wave
+// flux, as in k_tend3), the two y faces of a cell use two rho_v rings.
+// ---------------------------------------------------------------------------------------------------
+template <int TYW>
+__global__ __launch_bounds__(64 * TYW) void k_w_tend_ring(DevGrid g, Tend3Fields F, int kchunk)
+{
+    const int lane = threadIdx.x;
+    const int i0 = blockIdx.x * 64, i = i0 + lane;
+    const int j = blockIdx.y * TYW + threadIdx.y;
+    if (j >= g.Ny) return;                                    // wave-uniform
+    const int ic = min(i, g.Nx - 1);
+    const int nact = min(64, g.Nx - i0);
+    const int ie = i0 + nact, le = nact - 1;
+    const int kbeg = 1 + blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);   // faces kbeg .. kend-1
+    if (kbeg >= kend) return;
+    const long long sy = g.Sx, sz = g.Sxy;
+    const bool store = i < g.Nx;
+    const double *w = F.c, *ru = F.ru, *rv = F.rv, *rw = F.rw;
+    const double Az = g.Az;
+    long long n = g.idx(ic, j, kbeg);
+
+    double wr[6];            // w at faces k-3 .. k+2 (straddles centre k-1)
+    double qu[4];            // Ax*rho_u at levels k-2 .. k+1, own column
+    double qv0[4], qv1[4];   // Ay*rho_v at levels k-2 .. k+1, rows j and j+1
+    double qw[4];            // Az*rho_w at faces k-2 .. k+1 (centre k-1 uses all four)
+#pragma unroll
+    for (int s = 0; s < 6; ++s) wr[s] = w[n + (s - 3) * sz];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int kk = kbeg - 2 + s;
+        qu[s] = g.Ax[kk] * ru[n + (s - 2) * sz];
+        qv0[s] = g.Ay[kk] * rv[n + (s - 2) * sz];
+        qv1[s] = g.Ay[kk] * rv[n + sy + (s - 2) * sz];
+        qw[s] = Az * rw[n + (s - 2) * sz];
+    }
+    // carried: flux through centre kbeg-1 and buoyancy of cell kbeg-1
+    double fz_lo, b_lo;
+    {
+        const int B = bz_buffer_center(kbeg - 1, g.Nz);
+        const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
+        fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
+        b_lo = buoyancy3(g, F.T[n - sz], F.q[n - sz], kbeg - 1);
+    }
+    double edge = 0.0;
+
+    for (int k = kbeg; k < kend; ++k, n += sz) {
+        if (((k - kbeg) & 63) == 0) {
+            const int kk = min(k + lane, kend - 1);
+            edge = flux_x_at<T3_W>(g, F, ie, j, kk);
+        }
+        const int src = (k - kbeg) & 63;
+        const int Bf = bz_buffer_face(k, g.Nz);
+        // ---- z: centre k needs Az*rho_w at faces k-1..k+2 and w at faces k-2..k+3 ----
+        const double wnew = w[n + 3 * sz];
+        const double qwnew = Az * rw[n + 2 * sz];
+        double fz_hi;
+        {
+            const int B = bz_buffer_center(k, g.Nz);
+            const double wt = (B == 3) ? bz_symm4(qw[1], qw[2], qw[3], qwnew) : bz_symm2(qw[2], qw[3]);
+            fz_hi = wt * bz_upB(wr[1], wr[2], wr[3], wr[4], wr[5], wnew, wt > 0.0, B);
+        }
+        const double w0 = wr[3];        // w at (i, j, k)
+        // ---- x: advecting flux of the own x-face from the rho_u ring; neighbour by shuffle ----
+        double dx;
+        {
+            const double ut = (Bf == 3) ? bz_symm4(qu[0], qu[1], qu[2], qu[3]) : bz_symm2(qu[1], qu[2]);
+            const double fx = ut * bz_up5(w[n - 3], w[n - 2], w[n - 1], w0, w[n + 1], w[n + 2], ut > 0.0);
+            double nb = __shfl_down(fx, 1);
+            const double e = __shfl(edge, src);
+            if (lane == le) nb = e;
+            dx = nb - fx;
+        }
+        // ---- y: both faces from the two rho_v rings ----
+        double dy;
+        {
+            const double v0 = (Bf == 3) ? bz_symm4(qv0[0], qv0[1], qv0[2], qv0[3]) : bz_symm2(qv0[1], qv0[2]);
+            const double v1 = (Bf == 3) ? bz_symm4(qv1[0], qv1[1], qv1[2], qv1[3]) : bz_symm2(qv1[1], qv1[2]);
+            const double m3 = w[n - 3 * sy], m2 = w[n - 2 * sy], m1 = w[n - sy], p1 = w[n + sy], p2 = w[n + 2 * sy], p3 = w[n + 3 * sy];
+            const double lo = v0 * bz_up5(m3, m2, m1, w0, p1, p2, v0 > 0.0);
+            const double hi = v1 * bz_up5(m2, m1, w0, p1, p2, p3, v1 > 0.0);
+            dy = hi - lo;
+        }
+        const double b_hi = buoyancy3(g, F.T[n], F.q[n], k);
+        if (store) F.G[n] = -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo))) + 0.5 * (b_lo + b_hi);
+        fz_lo = fz_hi;
+        b_lo = b_hi;
+        // ---- advance the rings to level k+1 ----
+        const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
+        const double qun = Axn * ru[n + 2 * sz], qv0n = Ayn * rv[n + 2 * sz], qv1n = Ayn * rv[n + sy + 2 * sz];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { qu[s] = qu[s + 1]; qv0[s] = qv0[s + 1]; qv1[s] = qv1[s + 1]; qw[s] = qw[s + 1]; }
+        qu[3] = qun; qv0[3] = qv0n; qv1[3] = qv1n; qw[3] = qwnew;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) wr[s] = wr[s + 1];
+        wr[5] = wnew;
+    }
+}

@@ -38,6 +38,9 @@ WORDS_PER_CELL = {
     "potential_temperature_tendency": 6, "moisture_tendency": 5,
     "scalar_tendencies": 11, "momentum_tendencies": 17, "tendencies": 28,
     "ssp_rk3_substep+store_initial_state": 30, "project_and_diagnose": 18,
+    # tendency kernels with the RK update folded in: tendency words + the RK update words of their fields
+    "x_momentum_tendency+rk3": 9, "y_momentum_tendency+rk3": 9, "z_momentum_tendency+rk3": 11,
+    "scalar_tendencies+rk3": 19,
 }
 A_STEP_WORDS = 250          # 3 stages x 80 + 10
 

@@ -90,7 +90,8 @@ __device__ __forceinline__ void st_img_only(double *__restrict__ f, long long n,
 }
 
 struct PDFields {
-    double *ru, *rv, *rw, *rtheta, *rq;     // in/out (rtheta, rq: halos only)
+    double *ru, *rv, *rw, *rtheta, *rq;     // out (rtheta, rq: halos only)
+    const double *ru_in, *rv_in, *rw_in;    // predictor momentum (= ru, rv, rw unless the RK update was fused into the tendencies)
     double *u, *v, *w, *theta, *q, *T;      // out
     double *phi;                            // out (halo-inclusive)
     const double *phi_c;                    // in: contiguous Nx*Ny*Nz, zero-mean solution
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const double p_jm = (j == 0 && !g.wrap_y) ? F.phi_below[(long long)i + (long long)g.Nx * k] : F.phi_c[m + c_jm];
 
     // _pressure_correct_momentum!
-    double ru = F.ru[n], rv = F.rv[n];
+    double ru = F.ru_in[n], rv = F.rv_in[n];
     ru -= rc * dt * ((p - p_im) * g.rdx);
     rv -= rc * dt * ((p - p_jm) * g.rdy);
     // _compute_velocities!
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     st_img_only(F.rq, n, rq, ox, oy);
     if (!bot) {      // wall face k = 0 keeps rho_w = w = 0
         const double p_km = F.phi_c[m - cplane];
-        double rw = F.rw[n];
+        double rw = F.rw_in[n];
         rw -= rf * dt * ((p - p_km) * g.rdzf[k]);
         st_img(F.rw, n, rw, ox, oy);
         st_img(F.w, n, rw / rf, ox, oy);
@@ -186,23 +187,28 @@ int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const
     return BZ_OK;
 }
 
-int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *rhs)
+int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *rhs, const bz_prognostic *predictor)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "poisson_source_term");
     dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
-    hipLaunchKernelGGL(k_poisson_source_rows, grid, block, 0, ctx->stream, g, rhs ? rhs : ctx->d_rhs, s->rho_u, s->rho_v,
-                       s->rho_w, dt);
+    hipLaunchKernelGGL(k_poisson_source_rows, grid, block, 0, ctx->stream, g, rhs ? rhs : ctx->d_rhs,
+                       predictor ? predictor->rho_u : s->rho_u, predictor ? predictor->rho_v : s->rho_v,
+                       predictor ? predictor->rho_w : s->rho_w, dt);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
 
-int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below)
+int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below,
+                         const bz_prognostic *predictor)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "project_and_diagnose");
     PDFields F;
     F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w; F.rtheta = s->rho_theta; F.rq = s->rho_q;
+    F.ru_in = predictor ? predictor->rho_u : s->rho_u;
+    F.rv_in = predictor ? predictor->rho_v : s->rho_v;
+    F.rw_in = predictor ? predictor->rho_w : s->rho_w;
     F.u = s->u; F.v = s->v; F.w = s->w; F.theta = s->theta; F.q = s->q; F.T = s->T;
     F.phi = s->phi;
     F.phi_c = phi_c ? phi_c : ctx->d_rhs;

@@ -32,6 +32,29 @@ struct DevGrid {
     }
 };
 
+// Optional SSP-RK3 epilogue of a tendency kernel (ssp_runge_kutta_3.jl:167-173): instead of storing the tendency G,
+// store  u_new = (1-alpha) u0 + alpha (u_old + dt G).  mode 0: store G;  1: first stage (alpha = 1; also writes
+// u0 = u_old, i.e. store_initial_state!);  2: later stages (reads u0).
+struct RKEpilogue {
+    int mode = 0;
+    double dt = 0.0, alpha = 0.0, oma = 0.0;
+    const double *u0 = nullptr;     // mode 2
+    double *u0_out = nullptr;       // mode 1
+    const double *u0b = nullptr;    // second field of a fused pair
+    double *u0b_out = nullptr;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ double bz_rk_apply(int mode, double dt, double alpha, double oma, const double *u0,
+                                              double *u0_out, double G, double uold, long long n)
+{
+    if (mode == 0) return G;
+    double u0v;
+    if (mode == 1) { u0_out[n] = uold; u0v = uold; }
+    else u0v = u0[n];
+    return oma * u0v + alpha * (uold + dt * G);
+}
+#endif
+
 struct ProfileSlot {
     const char *name;
     double total_ms = 0.0;
@@ -62,6 +85,8 @@ struct bz_ctx {
     // y-slab decomposition (bz_create_slab): this rank owns Ny rows of Ny*y_nranks and the kx block
     // [kx0, kx0+nkx) of the zero-padded half spectrum; the horizontal transforms are done by the caller.
     int y_nranks = 1, y_rank = 0, nkx = 0, kx0 = 0, Ny_global = 0;
+    bool fuse_rk = true;              // whole-step seam: RK update folded into the tendency kernels (BZ_NO_FUSE_RK=1 disables)
+    bool G_is_predictor = false;      // after a fused step the G arrays hold predictor momentum, not tendencies
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
     // profiling
     bool profiling = false;
@@ -114,11 +139,16 @@ int bzi_poisson_spectral(bz_ctx *ctx);
 // fused streaming kernels (bz_fused.hip)
 int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                   double alpha, bool first);
-int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *rhs = nullptr);
+int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *rhs = nullptr,
+                             const bz_prognostic *predictor = nullptr);
 int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c = nullptr,
-                         const double *phi_below = nullptr);
+                         const double *phi_below = nullptr, const bz_prognostic *predictor = nullptr);
+int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
+                            double alpha, bool first);
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,
                int weno_order, int y_nranks, int y_rank);
 int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w);
-int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
-int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
+                             const RKEpilogue *E = nullptr);
+int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
+                        const RKEpilogue *E = nullptr);

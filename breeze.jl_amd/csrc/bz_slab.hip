@@ -23,6 +23,10 @@ extern "C" int bz_ssp_rk3_substep_fused(bz_ctx *ctx, const bz_state *s, const bz
                                         const bz_prognostic *G, double dt, double alpha, int first)
 {
     if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
+    if (ctx->G_is_predictor) {
+        int rc = bz_compute_tendencies(ctx, s, G);
+        if (rc) return rc;
+    }
     return bzi_rk3_fused(ctx, s, U0, G, dt, alpha, first != 0);
 }
 

@@ -166,6 +166,10 @@ extern "C" int bz_ssp_rk3_substep(bz_ctx *ctx, const bz_state *s, const bz_progn
                                   const bz_prognostic *G, double dt, double alpha)
 {
     if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
+    if (ctx->G_is_predictor) {      // a fused whole step left predictor momentum in G: rebuild the tendencies first
+        int rc = bz_compute_tendencies(ctx, s, G);
+        if (rc) return rc;
+    }
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "ssp_rk3_substep");
     RKFields F;

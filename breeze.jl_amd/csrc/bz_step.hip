@@ -31,7 +31,26 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
     }
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
+    if (ctx->fused_ok && ctx->fuse_rk) {
+        // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
+        // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state
+        // left by stage s-1), the predictor momentum goes to the G arrays and is projected from there into the
+        // state arrays, rho_theta / rho_q advance in place.  G never makes the round trip through HBM.
+        const DevGrid &g = ctx->dg;
+        BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));                 // wall faces of the
+        BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));        // predictor stay 0
+        for (int stage = 0; stage < 3; ++stage) {
+            const double alpha = alphas[stage];
+            if ((rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+            if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
+            if ((rc = bzi_poisson_spectral(ctx))) return rc;
+            if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G))) return rc;
+        }
+        ctx->G_is_predictor = true;
+        return BZ_OK;
+    }
     if (ctx->fused_ok) {
+        if (ctx->G_is_predictor && (rc = bz_compute_tendencies(ctx, s, G))) return rc;
         // Same arithmetic, fewer passes over HBM (bz_fused.hip): store_initial_state! rides on the first
         // RK update, the source term uses wrap indexing instead of a halo fill, and the projection,
         // velocity / thermodynamic diagnosis and every halo fill of update_state! are one kernel.
@@ -45,6 +64,7 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
         }
         return BZ_OK;
     }
+    if (ctx->G_is_predictor && (rc = bz_compute_tendencies(ctx, s, G))) return rc;
     if ((rc = bz_store_initial_state(ctx, s, U0))) return rc;               // :223
     for (int stage = 0; stage < 3; ++stage) {
         const double alpha = alphas[stage];

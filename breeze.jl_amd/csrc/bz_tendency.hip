@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * TYB) void k_u_tendency(DevGrid g, double *__re
                                                         const double *__restrict__ ru,
                                                         const double *__restrict__ rv,
                                                         const double *__restrict__ rw,
-                                                        const double *__restrict__ u, int kchunk)
+                                                        const double *__restrict__ u, int kchunk, RKEpilogue E)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * TYB + threadIdx.y;
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(64 * TYB) void k_u_tendency(DevGrid g, double *__re
         double Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
         double Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
 
-        Gu[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
+        Gu[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
+                            -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo))), ru[n], n);
 
         zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
         Fz_lo = Fz_hi;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64 * TYB) void k_v_tendency(DevGrid g, double *__re
                                                         const double *__restrict__ ru,
                                                         const double *__restrict__ rv,
                                                         const double *__restrict__ rw,
-                                                        const double *__restrict__ v, int kchunk)
+                                                        const double *__restrict__ v, int kchunk, RKEpilogue E)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * TYB + threadIdx.y;
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(64 * TYB) void k_v_tendency(DevGrid g, double *__re
         double Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
         double Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
 
-        Gv[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
+        Gv[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
+                            -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo))), rv[n], n);
 
         zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
         Fz_lo = Fz_hi;
@@ -276,6 +278,7 @@ static int pick_kchunk(const DevGrid &g, int nlev)
 extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
     if (!ctx || !s || !G) return BZ_ERR_INVALID;
+    ctx->G_is_predictor = false;
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
     if (ctx->tend_gen >= 3) {
@@ -294,11 +297,11 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
     {
         ProfileScope ps(ctx, "x_momentum_tendency");
-        hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc);
+        hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, RKEpilogue());
     }
     {
         ProfileScope ps(ctx, "y_momentum_tendency");
-        hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc);
+        hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc, RKEpilogue());
     }
     if (ctx->tend_gen >= 2 && !getenv("BZ_W_GEN1")) {
         int rc = bzi_w_tendency_ring(ctx, s, G);
@@ -323,6 +326,35 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
             hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q, kc);
         }
     }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// compute_tendencies! with the next ssp_rk3_substep! folded into the kernels' store (whole-step seam):
+//   G.rho_u/v/w <- predictor momentum,  rho_theta, rho_q updated in place;  stage 1 also fills U0.
+int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
+                            double alpha, bool first)
+{
+    const DevGrid &g = ctx->dg;
+    dim3 block(64, TYB);
+    int kc = pick_kchunk(g, g.Nz);
+    dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
+    RKEpilogue E;
+    E.mode = first ? 1 : 2; E.dt = dt; E.alpha = alpha; E.oma = 1.0 - alpha;
+    {
+        ProfileScope ps(ctx, "x_momentum_tendency+rk3");
+        E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
+        hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, E);
+    }
+    {
+        ProfileScope ps(ctx, "y_momentum_tendency+rk3");
+        E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
+        hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc, E);
+    }
+    int rc = bzi_w_tendency_ring(ctx, s, G, U0, &E);
+    if (rc) return rc;
+    rc = bzi_scalar_pair_tendency(ctx, s, G, U0, &E);
+    if (rc) return rc;
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -1,7 +1,10 @@
 // bz_tendency3.hip — launcher of the third-generation tendency kernels (bz_tendency3_kernels.h).
 // tools/tendbench (512x512x256, random data, MI355X): scalar 19.3 -> 16.6 ps/cell, u 19.4 -> 17.4,
 // v 19.7 -> 19.9 (R=2), w 25.5 -> 27.1: the scalar and u/v kernels ship in this form, w stays gen-1.
+#include <cstdlib>
+
 #include "bz_tendency3_kernels.h"
+#include "bz_tendency4_kernels.h"
 
 #define T3_TYW 4
 
@@ -25,8 +28,6 @@ static void launch3(bz_ctx *ctx, const Tend3Fields &F)
     hipLaunchKernelGGL((k_tend3<KIND, R, T3_TYW>), grid, block, 0, ctx->stream, g, F, kc);
 }
 
-int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
-int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 
 int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w)
 {
@@ -56,23 +57,39 @@ int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
 }
 
 // potential temperature + moisture in one pass (k_scalar_pair)
-int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+// With an RK epilogue (E != nullptr) rho_theta and rho_q are advanced in place and, in the first stage, U0 is filled.
+int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0,
+                             const RKEpilogue *Ein)
 {
     const DevGrid &g = ctx->dg;
-    ProfileScope ps(ctx, "scalar_tendencies");
+    ProfileScope ps(ctx, Ein ? "scalar_tendencies+rk3" : "scalar_tendencies");
     const int kc = pick_chunk3(g, g.Nz, T3_TYW);
     dim3 block(64, T3_TYW), grid((g.Nx + 63) / 64, (g.Ny + T3_TYW - 1) / T3_TYW, (g.Nz + kc - 1) / kc);
-    hipLaunchKernelGGL((k_scalar_pair<T3_TYW>), grid, block, 0, ctx->stream, g, s->u, s->v, s->w, s->theta, s->q,
-                       G->rho_theta, G->rho_q, kc);
+    RKEpilogue E;
+    double *outa = G->rho_theta, *outb = G->rho_q;
+    if (Ein) {
+        E = *Ein;
+        E.u0 = U0->rho_theta; E.u0_out = U0->rho_theta; E.u0b = U0->rho_q; E.u0b_out = U0->rho_q;
+        outa = s->rho_theta; outb = s->rho_q;
+    }
+    if (!Ein && getenv("BZ_PAIR_GEN3"))
+        hipLaunchKernelGGL((k_scalar_pair<T3_TYW>), grid, block, 0, ctx->stream, g, s->u, s->v, s->w, s->theta, s->q,
+                           outa, outb, kc);
+    else
+        hipLaunchKernelGGL((k_scalar_pair_lds<T3_TYW>), grid, block, 0, ctx->stream, g, s->u, s->v, s->w, s->theta, s->q,
+                           outa, outb, kc, E, s->rho_theta, s->rho_q);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
 
 // z-momentum tendency with register rings for every vertical stencil (k_w_tend_ring)
-int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0,
+                        const RKEpilogue *Ein)
 {
     const DevGrid &g = ctx->dg;
-    ProfileScope ps(ctx, "z_momentum_tendency");
+    ProfileScope ps(ctx, Ein ? "z_momentum_tendency+rk3" : "z_momentum_tendency");
+    RKEpilogue E;
+    if (Ein) { E = *Ein; E.u0 = U0->rho_w; E.u0_out = U0->rho_w; }
     Tend3Fields F;
     F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w;
     F.u = s->u; F.v = s->v; F.w = s->w; F.T = s->T; F.q = s->q;
@@ -80,7 +97,7 @@ int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
     const int nlev = g.Nz - 1;
     const int kc = pick_chunk3(g, nlev, T3_TYW);
     dim3 block(64, T3_TYW), grid((g.Nx + 63) / 64, (g.Ny + T3_TYW - 1) / T3_TYW, (nlev + kc - 1) / kc);
-    hipLaunchKernelGGL((k_w_tend_ring<T3_TYW>), grid, block, 0, ctx->stream, g, F, kc);
+    hipLaunchKernelGGL((k_w_tend_ring<T3_TYW>), grid, block, 0, ctx->stream, g, F, kc, E);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * TYW) void k_scalar_pair(DevGrid g, const doubl
 // flux, as in k_tend3), the two y faces of a cell use two rho_v rings.
 // ---------------------------------------------------------------------------------------------------
 template <int TYW>
-__global__ __launch_bounds__(64 * TYW) void k_w_tend_ring(DevGrid g, Tend3Fields F, int kchunk)
+__global__ __launch_bounds__(64 * TYW) void k_w_tend_ring(DevGrid g, Tend3Fields F, int kchunk, RKEpilogue E)
 {
     const int lane = threadIdx.x;
     const int i0 = blockIdx.x * 64, i = i0 + lane;
@@ -439,7 +439,9 @@ __global__ __launch_bounds__(64 * TYW) void k_w_tend_ring(DevGrid g, Tend3Fields
             dy = hi - lo;
         }
         const double b_hi = buoyancy3(g, F.T[n], F.q[n], k);
-        if (store) F.G[n] = -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo))) + 0.5 * (b_lo + b_hi);
+        if (store)
+            F.G[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
+                                 -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo))) + 0.5 * (b_lo + b_hi), rw[n], n);
         fz_lo = fz_hi;
         b_lo = b_hi;
         // ---- advance the rings to level k+1 ----

@@ -135,7 +135,10 @@ int bz_make_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt);
  * (src/TimeSteppers/ssp_runge_kutta_3.jl:209-278) for dry anelastic dynamics without callbacks:
  * the whole step stays on the device (preferred seam).  The state must be consistent
  * (bz_update_state with compute_tendencies=1 called once after set!, as
- * maybe_prepare_first_time_step! does). */
+ * maybe_prepare_first_time_step! does).
+ * NOTE: this seam folds each ssp_rk3_substep! into the preceding tendency evaluation, so on return the G arrays hold
+ * the last stage's predictor momentum instead of tendencies (they are scratch of the time stepper in the reference as
+ * well); bz_compute_tendencies / bz_update_state rebuild them, and bz_ssp_rk3_substep does so automatically. */
 int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
                            const bz_prognostic *G, double dt);
 

@@ -6,6 +6,7 @@
 #include <cmath>
 #include "../breeze.jl_amd/csrc/bz_tendency.hip"   // gen-1 kernels (also provides bz_compute_tendencies)
 #include "../breeze.jl_amd/csrc/bz_tendency3_kernels.h"
+#include "../breeze.jl_amd/csrc/bz_tendency4_kernels.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 // memory-structure probes: gen-1 scalar marching loop with (a) only the streaming loads (ring + velocities),
@@ -78,9 +79,29 @@ int main(int argc, char** argv) {
     {
         dim3 b1(64, 4), g1((Nx + 63) / 64, (Ny + 3) / 4, 4); int kc1 = (Nz + 3) / 4;
         rep("gen1 scalar (theta)", timeit([&] { hipLaunchKernelGGL(k_scalar_tendency, g1, b1, 0, 0, dg, G0, u, v, w, th, kc1); }));
-        rep("gen1 u", timeit([&] { hipLaunchKernelGGL(k_u_tendency, g1, b1, 0, 0, dg, G0, ru, rv, rw, u, kc1); }));
-        rep("gen1 v", timeit([&] { hipLaunchKernelGGL(k_v_tendency, g1, b1, 0, 0, dg, G0, ru, rv, rw, v, kc1); }));
+        rep("gen1 u", timeit([&] { hipLaunchKernelGGL(k_u_tendency, g1, b1, 0, 0, dg, G0, ru, rv, rw, u, kc1, RKEpilogue()); }));
+        rep("gen1 v", timeit([&] { hipLaunchKernelGGL(k_v_tendency, g1, b1, 0, 0, dg, G0, ru, rv, rw, v, kc1, RKEpilogue()); }));
         rep("gen1 w", timeit([&] { hipLaunchKernelGGL(k_w_tendency, g1, b1, 0, 0, dg, G0, ru, rv, rw, w, TT, q, kc1); }));
+    }
+    {   // fused scalar pair: gen-3 (loads) vs gen-4 (LDS tile), with a result comparison
+        auto cmp = [&](const char* what) {
+            std::vector<double> x(nc), y(nc);
+            CK(hipMemcpy(x.data(), G0, nc * sizeof(double), hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), G1, nc * sizeof(double), hipMemcpyDeviceToHost));
+            return std::make_pair(x, y); };
+        dim3 b3(64, 4), g3((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 63) / 64);
+        rep("pair gen3 (k_scalar_pair<4>) kc=64", timeit([&] { hipLaunchKernelGGL((k_scalar_pair<4>), g3, b3, 0, 0, dg, u, v, w, th, q, G0, G1, 64); }));
+        auto ref = cmp("ref");
+        CK(hipMemset(G0, 0, nc * sizeof(double))); CK(hipMemset(G1, 0, nc * sizeof(double)));
+        dim3 b8(64, 8), g8((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 63) / 64);
+        rep("pair gen4 LDS TY=8 kc=64", timeit([&] { hipLaunchKernelGGL((k_scalar_pair_lds<8>), g8, b8, 0, 0, dg, u, v, w, th, q, G0, G1, 64, RKEpilogue(), th, q); }));
+        auto got = cmp("got");
+        double e0 = 0, e1 = 0, s0 = 0, s1 = 0;
+        for (size_t n = 0; n < nc; ++n) { e0 = fmax(e0, fabs(got.first[n] - ref.first[n])); e1 = fmax(e1, fabs(got.second[n] - ref.second[n])); s0 = fmax(s0, fabs(ref.first[n])); s1 = fmax(s1, fabs(ref.second[n])); }
+        printf("   gen4 vs gen3: max|dG_theta| = %.3e (scale %.3e), max|dG_q| = %.3e (scale %.3e)\n", e0, s0, e1, s1);
+        dim3 g8b((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 127) / 128);
+        rep("pair gen4 LDS TY=8 kc=128", timeit([&] { hipLaunchKernelGGL((k_scalar_pair_lds<8>), g8b, b8, 0, 0, dg, u, v, w, th, q, G0, G1, 128, RKEpilogue(), th, q); }));
+        dim3 b4(64, 4), g4((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 63) / 64);
+        rep("pair gen4 LDS TY=4 kc=64", timeit([&] { hipLaunchKernelGGL((k_scalar_pair_lds<4>), g4, b4, 0, 0, dg, u, v, w, th, q, G0, G1, 64, RKEpilogue(), th, q); }));
     }
     RUN3(T3_SCALAR, th, 1, 4, 64);
     RUN3(T3_SCALAR, th, 2, 4, 64);

@@ -196,6 +196,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (y_nranks > 1 && (Ny < grid->Hy || Nx < 2 * grid->Hx)) { delete ctx; return BZ_ERR_UNSUPPORTED; }
     if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);
     ctx->fuse_rk = !getenv("BZ_NO_FUSE_RK");
+    ctx->tend_lds = !getenv("BZ_NO_TEND_LDS");
     int rc = bzi_poisson_setup(ctx, ref->density);
     if (rc != BZ_OK) {
         fprintf(stderr, "bz_create: Poisson setup failed (%d): %s\n", rc, ctx->last_error.c_str());

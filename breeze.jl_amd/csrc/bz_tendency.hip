@@ -295,7 +295,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     }
     int kc = pick_kchunk(g, g.Nz);
     dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
-    {
+    if (ctx->tend_gen >= 2 && ctx->tend_lds && !getenv("BZ_NO_U_LDS")) {
+        int rc = bzi_u_tendency_lds(ctx, s, G);
+        if (rc) return rc;
+    } else {
         ProfileScope ps(ctx, "x_momentum_tendency");
         hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, RKEpilogue());
     }
@@ -341,7 +344,10 @@ int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
     dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
     RKEpilogue E;
     E.mode = first ? 1 : 2; E.dt = dt; E.alpha = alpha; E.oma = 1.0 - alpha;
-    {
+    if (ctx->tend_lds) {
+        int rcu = bzi_u_tendency_lds(ctx, s, G, U0, &E);
+        if (rcu) return rcu;
+    } else {
         ProfileScope ps(ctx, "x_momentum_tendency+rk3");
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, E);

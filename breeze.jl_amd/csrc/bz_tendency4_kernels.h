@@ -183,3 +183,235 @@ __global__ __launch_bounds__(64 * TY) void k_scalar_pair_lds(DevGrid g, const do
         buf ^= 1;
     }
 }
+
+// ===================================================================================================
+// Momentum kernels, same idea restricted to what the probes showed to matter: x-stencil loads are L1 hits and
+// cost nothing measurable, the y-stencil of the advected velocity is what thrashes L1/L2.  So only that y-stencil
+// goes through an LDS tile (rows j0-3 .. j0+TY+2 of the block's 64 columns, interior rows from the register
+// rings, the six frame rows prefetched one level ahead), y-face fluxes are shared through LDS (wave 0 also
+// evaluates the face above the tile), x-face/centre fluxes through a wave shuffle + batched out-of-wave flux.
+// ===================================================================================================
+#include "bz_tendency3_kernels.h"
+
+template <int TY>
+__global__ __launch_bounds__(64 * TY) void k_u_tend_lds(DevGrid g, Tend3Fields F, int kchunk, RKEpilogue E)
+{
+    constexpr int TR = TY + 6;
+    __shared__ double T[2][TR][64];
+    __shared__ double FY[2][TY + 1][64];
+    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
+    const int ie = i0 - 1, le = 0;                      // centre-type x flux: lane 0 needs the flux of centre i0-1
+    const int kbeg = blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    if (kbeg >= kend) return;
+    const long long sy = g.Sx, sz = g.Sxy;
+    const bool store = (i < g.Nx) && (j < g.Ny);
+    const double *u = F.c, *ru = F.ru, *rv = F.rv, *rw = F.rw;
+    long long n = g.idx(ic, jc, kbeg);
+    // frame row handled by this thread (6 rows x 64 columns)
+    // frame rows (3 below + 3 above the tile, 64 columns): HPT cells per thread
+    constexpr int NT = 64 * TY, HPT = (6 * 64 + NT - 1) / NT;
+    bool hok[HPT];
+    int hr[HPT], hcol[HPT];
+    long long hn[HPT];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q) {
+        const int h = t + q * NT;
+        hok[q] = h < 6 * 64;
+        const int hrr = h >> 6;
+        hcol[q] = h & 63;
+        hr[q] = hok[q] ? ((hrr < 3) ? hrr : TY + hrr) : 0;
+        hn[q] = g.idx(min(i0 + hcol[q], g.Nx + 2), min(j0 - 3 + hr[q], g.Ny + 2), kbeg);
+    }
+    const long long ntop0 = g.idx(ic, min(j0 + TY, g.Ny), kbeg);      // row of the face above the tile (wave 0)
+
+    double r[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) r[s] = u[n + (s - 3) * sz];
+    double fz_lo = vflux<T3_U>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
+    T[0][ty + 3][tx] = r[3];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q)
+        if (hok[q]) T[0][hr[q]][hcol[q]] = u[hn[q]];
+    __syncthreads();
+
+    double edge = 0.0;
+    int buf = 0;
+    for (int k = kbeg; k < kend; ++k, n += sz) {
+        const long long lev = (long long)(k - kbeg) * sz;
+        double hnext[HPT];
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? u[hn[q] + lev + sz] : 0.0;
+        const double tnew = u[n + 3 * sz];
+        if (((k - kbeg) & 63) == 0) {
+            const int kk = min(k + tx, kend - 1);
+            edge = flux_x_at<T3_U>(g, F, ie, jc, kk);
+        }
+        const int src = (k - kbeg) & 63;
+        const double Ax = g.Ax[k], Ay = g.Ay[k];
+        const double c0 = r[3];
+        // ---- z ----
+        const double fz_hi = vflux<T3_U>(g, F, n + sz, k + 1, r[1], r[2], r[3], r[4], r[5], tnew);
+        // ---- x: flux at centre i ----
+        const double ax = bz_symm4(Ax * ru[n - 1], Ax * ru[n], Ax * ru[n + 1], Ax * ru[n + 2]);
+        const double fx = ax * bz_up5(u[n - 2], u[n - 1], c0, u[n + 1], u[n + 2], u[n + 3], ax > 0.0);
+        // ---- y: flux at the own low y-face, advected stencil from the tile column ----
+        const double ay = bz_symm4(Ay * rv[n - 2], Ay * rv[n - 1], Ay * rv[n], Ay * rv[n + 1]);
+        const double(*Tk)[64] = T[buf];
+        const double fy = ay * bz_up5(Tk[ty][tx], Tk[ty + 1][tx], Tk[ty + 2][tx], c0, Tk[ty + 4][tx], Tk[ty + 5][tx], ay > 0.0);
+        FY[buf][ty][tx] = fy;
+        if (ty == 0) {
+            const long long nt = ntop0 + lev;
+            const double at = bz_symm4(Ay * rv[nt - 2], Ay * rv[nt - 1], Ay * rv[nt], Ay * rv[nt + 1]);
+            FY[buf][TY][tx] = at * bz_up5(Tk[TY][tx], Tk[TY + 1][tx], Tk[TY + 2][tx], Tk[TY + 3][tx], Tk[TY + 4][tx], Tk[TY + 5][tx], at > 0.0);
+        }
+        // ---- stage level k+1 ----
+        T[buf ^ 1][ty + 3][tx] = r[4];
+#pragma unroll
+        for (int q = 0; q < HPT; ++q)
+            if (hok[q]) T[buf ^ 1][hr[q]][hcol[q]] = hnext[q];
+        __syncthreads();
+        {
+            double nb = __shfl_up(fx, 1);
+            const double e = __shfl(edge, src);
+            if (tx == le) nb = e;
+            const double dx = fx - nb;
+            const double dy = FY[buf][ty + 1][tx] - fy;
+            if (store)
+                F.G[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
+                                     -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo))), ru[n], n);
+        }
+        fz_lo = fz_hi;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
+        r[5] = tnew;
+        buf ^= 1;
+    }
+}
+
+// z-momentum: k_w_tend_ring with the w y-stencil in an LDS tile and shared y-face fluxes.
+template <int TY>
+__global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F, int kchunk, RKEpilogue E)
+{
+    constexpr int TR = TY + 6;
+    __shared__ double T[2][TR][64];
+    __shared__ double FY[2][TY + 1][64];
+    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
+    const int nact = min(64, g.Nx - i0);
+    const int ie = i0 + nact, le = nact - 1;
+    const int kbeg = 1 + blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    if (kbeg >= kend) return;
+    const long long sy = g.Sx, sz = g.Sxy;
+    const bool store = (i < g.Nx) && (j < g.Ny);
+    const double *w = F.c, *ru = F.ru, *rv = F.rv, *rw = F.rw;
+    const double Az = g.Az;
+    long long n = g.idx(ic, jc, kbeg);
+    // frame rows (3 below + 3 above the tile, 64 columns): HPT cells per thread
+    constexpr int NT = 64 * TY, HPT = (6 * 64 + NT - 1) / NT;
+    bool hok[HPT];
+    int hr[HPT], hcol[HPT];
+    long long hn[HPT];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q) {
+        const int h = t + q * NT;
+        hok[q] = h < 6 * 64;
+        const int hrr = h >> 6;
+        hcol[q] = h & 63;
+        hr[q] = hok[q] ? ((hrr < 3) ? hrr : TY + hrr) : 0;
+        hn[q] = g.idx(min(i0 + hcol[q], g.Nx + 2), min(j0 - 3 + hr[q], g.Ny + 2), kbeg);
+    }
+    const long long ntop0 = g.idx(ic, min(j0 + TY, g.Ny), kbeg);
+    const bool top = (ty == 0);
+
+    double wr[6], qu[4], qv[4], qt[4], qw[4];       // qt: rho_v ring of the row above the tile (wave 0 only)
+#pragma unroll
+    for (int s = 0; s < 6; ++s) wr[s] = w[n + (s - 3) * sz];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int kk = kbeg - 2 + s;
+        qu[s] = g.Ax[kk] * ru[n + (s - 2) * sz];
+        qv[s] = g.Ay[kk] * rv[n + (s - 2) * sz];
+        qt[s] = top ? g.Ay[kk] * rv[ntop0 + (s - 2) * sz] : 0.0;
+        qw[s] = Az * rw[n + (s - 2) * sz];
+    }
+    double fz_lo, b_lo;
+    {
+        const int B = bz_buffer_center(kbeg - 1, g.Nz);
+        const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
+        fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
+        b_lo = buoyancy3(g, F.T[n - sz], F.q[n - sz], kbeg - 1);
+    }
+    T[0][ty + 3][tx] = wr[3];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q)
+        if (hok[q]) T[0][hr[q]][hcol[q]] = w[hn[q]];
+    __syncthreads();
+
+    double edge = 0.0;
+    int buf = 0;
+    for (int k = kbeg; k < kend; ++k, n += sz) {
+        const long long lev = (long long)(k - kbeg) * sz;
+        double hnext[HPT];
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? w[hn[q] + lev + sz] : 0.0;
+        const double wnew = w[n + 3 * sz];
+        const double qwnew = Az * rw[n + 2 * sz];
+        if (((k - kbeg) & 63) == 0) {
+            const int kk = min(k + tx, kend - 1);
+            edge = flux_x_at<T3_W>(g, F, ie, jc, kk);
+        }
+        const int src = (k - kbeg) & 63;
+        const int Bf = bz_buffer_face(k, g.Nz);
+        double fz_hi;
+        {
+            const int B = bz_buffer_center(k, g.Nz);
+            const double wt = (B == 3) ? bz_symm4(qw[1], qw[2], qw[3], qwnew) : bz_symm2(qw[2], qw[3]);
+            fz_hi = wt * bz_upB(wr[1], wr[2], wr[3], wr[4], wr[5], wnew, wt > 0.0, B);
+        }
+        const double w0 = wr[3];
+        const double ut = (Bf == 3) ? bz_symm4(qu[0], qu[1], qu[2], qu[3]) : bz_symm2(qu[1], qu[2]);
+        const double fx = ut * bz_up5(w[n - 3], w[n - 2], w[n - 1], w0, w[n + 1], w[n + 2], ut > 0.0);
+        const double vt = (Bf == 3) ? bz_symm4(qv[0], qv[1], qv[2], qv[3]) : bz_symm2(qv[1], qv[2]);
+        const double(*Tk)[64] = T[buf];
+        const double fy = vt * bz_up5(Tk[ty][tx], Tk[ty + 1][tx], Tk[ty + 2][tx], w0, Tk[ty + 4][tx], Tk[ty + 5][tx], vt > 0.0);
+        FY[buf][ty][tx] = fy;
+        if (top) {
+            const double v2 = (Bf == 3) ? bz_symm4(qt[0], qt[1], qt[2], qt[3]) : bz_symm2(qt[1], qt[2]);
+            FY[buf][TY][tx] = v2 * bz_up5(Tk[TY][tx], Tk[TY + 1][tx], Tk[TY + 2][tx], Tk[TY + 3][tx], Tk[TY + 4][tx], Tk[TY + 5][tx], v2 > 0.0);
+        }
+        T[buf ^ 1][ty + 3][tx] = wr[4];
+#pragma unroll
+        for (int q = 0; q < HPT; ++q)
+            if (hok[q]) T[buf ^ 1][hr[q]][hcol[q]] = hnext[q];
+        const double b_hi = buoyancy3(g, F.T[n], F.q[n], k);
+        // ring advance loads (level k+2)
+        const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
+        const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];
+        const double qtn = top ? Ayn * rv[ntop0 + lev + 2 * sz] : 0.0;
+        __syncthreads();
+        {
+            double nb = __shfl_down(fx, 1);
+            const double e = __shfl(edge, src);
+            if (tx == le) nb = e;
+            const double dx = nb - fx;
+            const double dy = FY[buf][ty + 1][tx] - fy;
+            if (store)
+                F.G[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
+                                     -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo))) + 0.5 * (b_lo + b_hi), rw[n], n);
+        }
+        fz_lo = fz_hi;
+        b_lo = b_hi;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { qu[s] = qu[s + 1]; qv[s] = qv[s + 1]; qt[s] = qt[s + 1]; qw[s] = qw[s + 1]; }
+        qu[3] = qun; qv[3] = qvn; qt[3] = qtn; qw[3] = qwnew;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) wr[s] = wr[s + 1];
+        wr[5] = wnew;
+        buf ^= 1;
+    }
+}

@@ -182,6 +182,32 @@ def test_momentum_conservation_on_device(bz):
         assert abs(Py - Py0) <= 1e-12 * abs(Py0)
 
 
+def test_full_size_properties_512(bz):
+    """BASELINE.json configs[1] at full size (512^3): size-independent properties of the step instead of an oracle
+    comparison — after two steps the momentum is discretely divergence-free, horizontal momentum stays zero by
+    symmetry of the flux form, the pressure anomaly has zero mean and everything is finite."""
+    import torch
+    N = 512
+    grid = bz.RectilinearGrid((N, N, N), x=(-10e3, 10e3), y=(-10e3, 10e3), z=(0, 10e3))
+    m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300)),
+                           advection=bz.WENO())
+    m.set(θ=bubble_theta(300.0, 9.81))
+    for _ in range(2):
+        m.time_step(1.0)
+    m.synchronize()
+    ru, rv, rw = (m.momentum[k].interior for k in ("ρu", "ρv", "ρw"))
+    scale = float(rw.abs().max())
+    assert scale > 1e-3                                   # the bubble has started to rise
+    assert float(m.max_abs_divergence()) < 1e-12 * scale / grid.Δz * 100
+    assert abs(float(ru.sum())) < 1e-9 * scale * N ** 3 and abs(float(rv.sum())) < 1e-9 * scale * N ** 3
+    phi = m.dynamics.pressure_anomaly.interior
+    assert abs(float(phi.mean())) < 1e-10 * float(phi.abs().max())
+    for f in (m.temperature, m.potential_temperature, m.velocities["w"]):
+        assert bool(torch.isfinite(f.interior).all())
+    # walls stay closed
+    assert float(m.momentum["ρw"].interior[0].abs().max()) == 0.0 and float(m.momentum["ρw"].interior[-1].abs().max()) == 0.0
+
+
 def test_missing_library_fails_loudly(bz, monkeypatch, tmp_path):
     from breeze_jl_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

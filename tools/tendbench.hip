@@ -42,7 +42,7 @@ template <class K> float timeit(K launch, int reps = 5) {
 }
 
 int main(int argc, char** argv) {
-    int Nx = 512, Ny = 512, Nz = argc > 1 ? atoi(argv[1]) : 256, H = 3;
+    int Nz = argc > 1 ? atoi(argv[1]) : 256, Nx = argc > 2 ? atoi(argv[2]) : 512, Ny = argc > 3 ? atoi(argv[3]) : 512, H = 3;
     std::vector<double> zf(Nz + 1); for (int k = 0; k <= Nz; ++k) zf[k] = 10e3 * k / Nz;
     bz_grid g{Nx, Ny, Nz, H, H, H, {0, 0, 1}, 8, 20e3 / Nx, 20e3 / Ny, zf.data(), 1, 0};
     bz_constants c{9.81, 8.314462618 / 0.02897, 8.314462618 / 0.018015, 1005, 1850};
@@ -98,10 +98,42 @@ int main(int argc, char** argv) {
         double e0 = 0, e1 = 0, s0 = 0, s1 = 0;
         for (size_t n = 0; n < nc; ++n) { e0 = fmax(e0, fabs(got.first[n] - ref.first[n])); e1 = fmax(e1, fabs(got.second[n] - ref.second[n])); s0 = fmax(s0, fabs(ref.first[n])); s1 = fmax(s1, fabs(ref.second[n])); }
         printf("   gen4 vs gen3: max|dG_theta| = %.3e (scale %.3e), max|dG_q| = %.3e (scale %.3e)\n", e0, s0, e1, s1);
+        rep("pair gen4 LDS TY=4 kc=128", timeit([&] { hipLaunchKernelGGL((k_scalar_pair_lds<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 127) / 128), dim3(64, 4), 0, 0, dg, u, v, w, th, q, G0, G1, 128, RKEpilogue(), th, q); }));
+        rep("pair gen4 LDS TY=4 kc=256", timeit([&] { hipLaunchKernelGGL((k_scalar_pair_lds<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 255) / 256), dim3(64, 4), 0, 0, dg, u, v, w, th, q, G0, G1, 256, RKEpilogue(), th, q); }));
         dim3 g8b((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 127) / 128);
         rep("pair gen4 LDS TY=8 kc=128", timeit([&] { hipLaunchKernelGGL((k_scalar_pair_lds<8>), g8b, b8, 0, 0, dg, u, v, w, th, q, G0, G1, 128, RKEpilogue(), th, q); }));
         dim3 b4(64, 4), g4((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 63) / 64);
         rep("pair gen4 LDS TY=4 kc=64", timeit([&] { hipLaunchKernelGGL((k_scalar_pair_lds<4>), g4, b4, 0, 0, dg, u, v, w, th, q, G0, G1, 64, RKEpilogue(), th, q); }));
+    }
+    {   // momentum: gen-1 / ring kernels vs the LDS y-tile kernels, with result comparison
+        auto grab = [&](double* p) { std::vector<double> x(nc); CK(hipMemcpy(x.data(), p, nc * sizeof(double), hipMemcpyDeviceToHost)); return x; };
+        auto diff = [&](const std::vector<double>& a, const std::vector<double>& b) { double e = 0, s = 0; for (size_t n = 0; n < nc; ++n) { e = fmax(e, fabs(a[n] - b[n])); s = fmax(s, fabs(b[n])); } printf("   max|diff| = %.3e (scale %.3e)\n", e, s); };
+        dim3 b1(64, 4), g1((Nx + 63) / 64, (Ny + 3) / 4, 4); int kc1 = (Nz + 3) / 4;
+        Tend3Fields Fm; Fm.ru = ru; Fm.rv = rv; Fm.rw = rw; Fm.u = u; Fm.v = v; Fm.w = w; Fm.T = TT; Fm.q = q; Fm.G = G0;
+        CK(hipMemset(G0, 0, nc * sizeof(double)));
+        rep("u gen1", timeit([&] { hipLaunchKernelGGL(k_u_tendency, g1, b1, 0, 0, dg, G0, ru, rv, rw, u, kc1, RKEpilogue()); }));
+        auto uref = grab(G0); CK(hipMemset(G0, 0, nc * sizeof(double)));
+        Fm.c = u;
+        rep("u LDS TY=8 kc=64", timeit([&] { hipLaunchKernelGGL((k_u_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 63) / 64), dim3(64, 8), 0, 0, dg, Fm, 64, RKEpilogue()); }));
+        diff(grab(G0), uref);
+        rep("u LDS TY=4 kc=64", timeit([&] { hipLaunchKernelGGL((k_u_tend_lds<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 63) / 64), dim3(64, 4), 0, 0, dg, Fm, 64, RKEpilogue()); }));
+        rep("u LDS TY=8 kc=256", timeit([&] { hipLaunchKernelGGL((k_u_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 255) / 256), dim3(64, 8), 0, 0, dg, Fm, 256, RKEpilogue()); }));
+        rep("u LDS TY=4 kc=128", timeit([&] { hipLaunchKernelGGL((k_u_tend_lds<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 127) / 128), dim3(64, 4), 0, 0, dg, Fm, 128, RKEpilogue()); }));
+        rep("u LDS TY=4 kc=256", timeit([&] { hipLaunchKernelGGL((k_u_tend_lds<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 255) / 256), dim3(64, 4), 0, 0, dg, Fm, 256, RKEpilogue()); }));
+        rep("u LDS TY=8 kc=128", timeit([&] { hipLaunchKernelGGL((k_u_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 127) / 128), dim3(64, 8), 0, 0, dg, Fm, 128, RKEpilogue()); }));
+        CK(hipMemset(G0, 0, nc * sizeof(double)));
+        Fm.c = w;
+        rep("w ring TYW=4 kc=64", timeit([&] { hipLaunchKernelGGL((k_w_tend_ring<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz - 1 + 63) / 64), dim3(64, 4), 0, 0, dg, Fm, 64, RKEpilogue()); }));
+        auto wref = grab(G0); CK(hipMemset(G0, 0, nc * sizeof(double)));
+        rep("w LDS TY=8 kc=64", timeit([&] { hipLaunchKernelGGL((k_w_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz - 1 + 63) / 64), dim3(64, 8), 0, 0, dg, Fm, 64, RKEpilogue()); }));
+        diff(grab(G0), wref);
+        rep("w LDS TY=8 kc=128", timeit([&] { hipLaunchKernelGGL((k_w_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz - 1 + 127) / 128), dim3(64, 8), 0, 0, dg, Fm, 128, RKEpilogue()); }));
+        rep("w LDS TY=8 kc=256", timeit([&] { hipLaunchKernelGGL((k_w_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz - 1 + 255) / 256), dim3(64, 8), 0, 0, dg, Fm, 256, RKEpilogue()); }));
+        rep("w ring TYW=4 kc=128", timeit([&] { hipLaunchKernelGGL((k_w_tend_ring<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz - 1 + 127) / 128), dim3(64, 4), 0, 0, dg, Fm, 128, RKEpilogue()); }));
+        CK(hipMemset(G0, 0, nc * sizeof(double)));
+        hipLaunchKernelGGL((k_w_tend_lds<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz - 1 + 63) / 64), dim3(64, 4), 0, 0, dg, Fm, 64, RKEpilogue());
+        printf("w LDS TY=4 vs ring:"); diff(grab(G0), wref);
+        rep("w LDS TY=4 kc=64", timeit([&] { hipLaunchKernelGGL((k_w_tend_lds<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz - 1 + 63) / 64), dim3(64, 4), 0, 0, dg, Fm, 64, RKEpilogue()); }));
     }
     RUN3(T3_SCALAR, th, 1, 4, 64);
     RUN3(T3_SCALAR, th, 2, 4, 64);

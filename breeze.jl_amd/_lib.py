@@ -77,6 +77,9 @@ SYMBOLS = {
     "bz_poisson_source_term": (C.c_int, [_ctx, _sp, C.c_double, C.c_void_p]),
     "bz_spectral_tridiagonal_solve": (C.c_int, [_ctx, C.c_void_p, C.c_double]),
     "bz_project_and_diagnose": (C.c_int, [_ctx, _sp, C.c_void_p, C.c_void_p, C.c_double]),
+    "bz_tendencies_fused_rk": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double, C.c_double, C.c_int]),
+    "bz_poisson_source_term_from": (C.c_int, [_ctx, _sp, _pp, C.c_double, C.c_void_p]),
+    "bz_project_and_diagnose_from": (C.c_int, [_ctx, _sp, _pp, C.c_void_p, C.c_void_p, C.c_double]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "bz_profile_reset": (C.c_int, [_ctx]),
     "bz_profile_count": (C.c_int, [_ctx]),

@@ -90,18 +90,18 @@ extern "C" int bz_sync(bz_ctx *ctx)
 extern "C" int bz_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
                          const bz_reference_state *ref, int weno_order)
 {
-    return bzi_create(out, grid, constants, ref, weno_order, 1, 0);
+    return bzi_create(out, grid, constants, ref, weno_order, 1, 0, false);
 }
 
 extern "C" int bz_create_slab(bz_ctx **out, const bz_grid *local_grid, const bz_constants *constants,
                               const bz_reference_state *ref, int weno_order, int y_nranks, int y_rank)
 {
     if (y_nranks < 1 || y_rank < 0 || y_rank >= y_nranks) return BZ_ERR_INVALID;
-    return bzi_create(out, local_grid, constants, ref, weno_order, y_nranks, y_rank);
+    return bzi_create(out, local_grid, constants, ref, weno_order, y_nranks, y_rank, true);
 }
 
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,
-               int weno_order, int y_nranks, int y_rank)
+               int weno_order, int y_nranks, int y_rank, bool slab_mode)
 {
     if (!out || !grid || !constants || !ref || !grid->zf || !ref->density || !ref->pressure || !ref->temperature)
         return BZ_ERR_INVALID;
@@ -120,6 +120,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     ctx->constants = *constants;
     ctx->y_nranks = y_nranks;
     ctx->y_rank = y_rank;
+    ctx->slab_mode = slab_mode;
     ctx->Ny_global = grid->Ny * y_nranks;
 
     const int Nx = grid->Nx, Ny = grid->Ny, Nz = grid->Nz, Hz = grid->Hz;
@@ -190,10 +191,10 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.cpd = constants->dry_air_heat_capacity;
     g.cpv = constants->vapor_heat_capacity;
     g.pst = ref->standard_pressure;
-    g.wrap_y = (y_nranks == 1) ? 1 : 0;
+    g.wrap_y = slab_mode ? 0 : 1;
 
-    ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || y_nranks > 1) && !getenv("BZ_NO_FUSED");
-    if (y_nranks > 1 && (Ny < grid->Hy || Nx < 2 * grid->Hx)) { delete ctx; return BZ_ERR_UNSUPPORTED; }
+    ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !getenv("BZ_NO_FUSED");
+    if (slab_mode && (Ny < grid->Hy || Nx < 2 * grid->Hx)) { delete ctx; return BZ_ERR_UNSUPPORTED; }
     if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);
     ctx->fuse_rk = !getenv("BZ_NO_FUSE_RK");
     ctx->tend_lds = !getenv("BZ_NO_TEND_LDS");

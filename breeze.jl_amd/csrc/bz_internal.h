@@ -85,6 +85,7 @@ struct bz_ctx {
     // y-slab decomposition (bz_create_slab): this rank owns Ny rows of Ny*y_nranks and the kx block
     // [kx0, kx0+nkx) of the zero-padded half spectrum; the horizontal transforms are done by the caller.
     int y_nranks = 1, y_rank = 0, nkx = 0, kx0 = 0, Ny_global = 0;
+    bool slab_mode = false;           // created by bz_create_slab (also with one rank): caller fills y halos and does the FFTs
     bool tend_lds = true;             // LDS y-tile variants of the u and w tendency kernels (BZ_NO_TEND_LDS=1 disables)
     bool fuse_rk = true;              // whole-step seam: RK update folded into the tendency kernels (BZ_NO_FUSE_RK=1 disables)
     bool G_is_predictor = false;      // after a fused step the G arrays hold predictor momentum, not tendencies
@@ -147,7 +148,7 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double
 int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                             double alpha, bool first);
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,
-               int weno_order, int y_nranks, int y_rank);
+               int weno_order, int y_nranks, int y_rank, bool slab_mode);
 int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w);
 int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
                              const RKEpilogue *E = nullptr);

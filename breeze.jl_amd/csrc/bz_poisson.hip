@@ -41,14 +41,16 @@ struct TriCols {
 // One thread per horizontal wavenumber: tabulate 1/beta_k and t_k of the Thomas forward sweep.
 // NXH = number of kx columns held here (the whole half spectrum, or this rank's block [kx0, kx0+NXH) of the
 // zero-padded half spectrum; columns with kx0+kx >= nxh_real are padding and get zero factors).
-__global__ __launch_bounds__(256) void k_tridiag_setup(int NXH, int Ny, int Nz, int kx0, int nxh_real, TriCols C,
+// ky_fastest: column index c = ky + Ny*kx (slab mode: the y transform runs along the contiguous dimension), else
+// c = kx + NXH*ky.
+__global__ __launch_bounds__(256) void k_tridiag_setup(int NXH, int Ny, int Nz, int kx0, int nxh_real, int ky_fastest, TriCols C,
                                                        double *__restrict__ ibeta,
                                                        double *__restrict__ tfac)
 {
     long long c = (long long)blockIdx.x * 256 + threadIdx.x;
     long long plane = (long long)NXH * Ny;
     if (c >= plane) return;
-    int kx = (int)(c % NXH), ky = (int)(c / NXH);
+    int kx = ky_fastest ? (int)(c / Ny) : (int)(c % NXH), ky = ky_fastest ? (int)(c % Ny) : (int)(c / NXH);
     if (kx0 + kx >= nxh_real) {
         for (int k = 0; k < Nz; ++k) { ibeta[c + plane * k] = 0.0; tfac[c + plane * k] = 0.0; }
         return;
@@ -125,7 +127,7 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
 {
     const DevGrid &g = ctx->dg;
     const int Nx = g.Nx, Nz = g.Nz, Hz = g.Hz;
-    const bool slab = ctx->y_nranks > 1;
+    const bool slab = ctx->slab_mode;
     const int nxh_real = Nx / 2 + 1;
     int Ny = g.Ny;                       // rows of the spectral block: local rows, or ALL rows in slab mode
     if (slab) {
@@ -177,7 +179,7 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
 
     TriCols C{ctx->d_lower, d_diag0, d_mass, d_lx, d_ly};
     long long plane = (long long)ctx->NXH * Ny;
-    hipLaunchKernelGGL(k_tridiag_setup, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, 0, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, C,
+    hipLaunchKernelGGL(k_tridiag_setup, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, 0, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, slab ? 1 : 0, C,
                        ctx->d_ibeta, ctx->d_tfac);
     BZ_HIP(hipGetLastError());
     BZ_HIP(hipDeviceSynchronize());
@@ -257,7 +259,7 @@ int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt)
 extern "C" int bz_compute_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt)
 {
     if (!ctx || !s) return BZ_ERR_INVALID;
-    if (ctx->y_nranks > 1) {
+    if (ctx->slab_mode) {
         ctx->last_error = "bz_compute_pressure_correction: y-slab contexts solve through bz_poisson_source_term / "
                           "bz_spectral_tridiagonal_solve / bz_project_and_diagnose";
         return BZ_ERR_UNSUPPORTED;

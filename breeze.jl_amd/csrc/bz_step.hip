@@ -25,7 +25,7 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
                                       const bz_prognostic *G, double dt)
 {
     if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
-    if (ctx->y_nranks > 1) {
+    if (ctx->slab_mode) {
         ctx->last_error = "bz_time_step_anelastic: a y-slab context needs the distributed driver (halo exchange + FFT transposes)";
         return BZ_ERR_UNSUPPORTED;
     }

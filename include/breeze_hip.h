@@ -148,7 +148,8 @@ int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *
  * `local_grid` describes this rank's slab: Ny = rows owned (global Ny = Ny * y_nranks), y halos are filled by the
  * caller's neighbour exchange instead of a periodic wrap.  The caller also performs the horizontal transforms of
  * the Poisson solve (x-FFT, all-to-all to kx slabs, y-FFT and back); this rank's spectral block is
- * [Nz][Ny_global][nkx] complex (kx fastest) for kx in [kx0, kx0+nkx) of the zero-padded half spectrum. */
+ * [Nz][nkx][Ny_global] complex (ky fastest, so the y transform is contiguous) for kx in [kx0, kx0+nkx) of the
+ * zero-padded half spectrum. */
 int bz_create_slab(bz_ctx **ctx, const bz_grid *local_grid, const bz_constants *constants,
                    const bz_reference_state *reference_state, int weno_order, int y_nranks, int y_rank);
 int bz_slab_info(bz_ctx *ctx, int32_t *y_nranks, int32_t *y_rank, int32_t *nkx, int32_t *kx0, int32_t *ny_global);
@@ -164,6 +165,15 @@ int bz_spectral_tridiagonal_solve(bz_ctx *ctx, double *hat, double scale);
 /* make_pressure_correction! + compute_velocities! + thermodynamic diagnosis + x/z halo fills in one pass from the
  * contiguous solution phi_c (Nx*Ny*Nz); phi_below = phi of row j = -1, layout [k][i] (slab mode; else NULL). */
 int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below, double dt);
+
+/* compute_tendencies! with the next ssp_rk3_substep! folded into the kernels' store: predictor momentum goes to
+ * G->rho_u/v/w (to be projected by bz_project_and_diagnose_from), rho_theta / rho_q advance in place, U0 is filled when
+ * first != 0 (alpha must then be 1).  The *_from variants take the momentum predictor from `predictor` instead of s. */
+int bz_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G,
+                           double dt, double alpha, int first);
+int bz_poisson_source_term_from(bz_ctx *ctx, const bz_state *s, const bz_prognostic *predictor, double dt, double *rhs);
+int bz_project_and_diagnose_from(bz_ctx *ctx, const bz_state *s, const bz_prognostic *predictor, const double *phi_c,
+                                 const double *phi_below, double dt);
 
 /* ---- instrumentation (not part of the reference interface) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */

@@ -58,7 +58,7 @@ def make_oracle_slab(orc, bz_dist, size, extent, rank, world, theta0=300.0, grou
 
         def local_spectral_solve(self, S):
             d = self.decomp
-            f = np.ascontiguousarray(S.numpy())
+            f = np.ascontiguousarray(S.permute(0, 2, 1).numpy())       # oracle layout: [k][ky][kx]
             out = np.zeros_like(f)
             scratch = np.zeros(f.shape)
             dp = C.POINTER(C.c_double)
@@ -67,7 +67,7 @@ def make_oracle_slab(orc, bz_dist, size, extent, rank, world, theta0=300.0, grou
                                           out.view(np.float64).ctypes.data_as(dp), orc._p(scratch))
             if d.kx0 == 0:
                 out[:, 0, 0] -= out[:, 0, 0].mean()
-            S.copy_(torch.from_numpy(out))
+            S.copy_(torch.from_numpy(out).permute(0, 2, 1))
 
         def local_project_diagnose(self, phi, below, dt):
             g = self.grid

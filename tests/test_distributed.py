@@ -85,7 +85,9 @@ def test_single_rank_transposes_and_halos_are_identities(bz):
     d.exchange_y_halos([g])
     assert torch.equal(g[:, :3], f[:, 8:11]) and torch.equal(g[:, 11:], f[:, 3:6]) and torch.equal(g[:, 3:11], f[:, 3:11])
     R = torch.randn(4, 8, d.nxh_pad, dtype=torch.complex128)
-    assert torch.equal(d.to_y_slabs(d.to_kx_slabs(R)), R)
+    S = d.to_kx_slabs(R)
+    assert S.shape == (4, d.nkx, 8) and torch.equal(S, R.permute(0, 2, 1))
+    assert torch.equal(d.to_y_slabs(S), R)
 
 
 @pytest.mark.gpu

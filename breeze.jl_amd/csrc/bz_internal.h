@@ -154,5 +154,7 @@ int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic
                              const RKEpilogue *E = nullptr);
 int bzi_u_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
                        const RKEpilogue *E = nullptr);
+int bzi_v_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
+                       const RKEpilogue *E = nullptr);
 int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
                         const RKEpilogue *E = nullptr);

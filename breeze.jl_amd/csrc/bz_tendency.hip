@@ -302,7 +302,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
         ProfileScope ps(ctx, "x_momentum_tendency");
         hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, RKEpilogue());
     }
-    {
+    if (ctx->tend_gen >= 2 && ctx->tend_lds && !getenv("BZ_NO_V_LDS")) {
+        int rc = bzi_v_tendency_lds(ctx, s, G);
+        if (rc) return rc;
+    } else {
         ProfileScope ps(ctx, "y_momentum_tendency");
         hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc, RKEpilogue());
     }
@@ -352,7 +355,10 @@ int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, E);
     }
-    {
+    if (ctx->tend_lds && !getenv("BZ_NO_V_LDS")) {
+        int rcv = bzi_v_tendency_lds(ctx, s, G, U0, &E);
+        if (rcv) return rcv;
+    } else {
         ProfileScope ps(ctx, "y_momentum_tendency+rk3");
         E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
         hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc, E);

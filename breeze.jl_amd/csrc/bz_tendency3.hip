@@ -140,3 +140,21 @@ int bzi_u_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, c
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
+
+// y-momentum tendency with every y-stencil in LDS tiles (k_v_tend_lds)
+int bzi_v_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0, const RKEpilogue *Ein)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, Ein ? "y_momentum_tendency+rk3" : "y_momentum_tendency");
+    RKEpilogue E;
+    if (Ein) { E = *Ein; E.u0 = U0->rho_v; E.u0_out = U0->rho_v; }
+    Tend3Fields F;
+    F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w;
+    F.u = s->u; F.v = s->v; F.w = s->w; F.T = s->T; F.q = s->q;
+    F.c = s->v; F.G = G->rho_v;
+    const int kc = pick_chunk_lds(g, g.Nz, 8);
+    dim3 block(64, 8), grid((g.Nx + 63) / 64, (g.Ny + 7) / 8, (g.Nz + kc - 1) / kc);
+    hipLaunchKernelGGL((k_v_tend_lds<8>), grid, block, 0, ctx->stream, g, F, kc, E);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}

@@ -415,3 +415,136 @@ __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F
         buf ^= 1;
     }
 }
+
+// y-momentum: every y-stencil through LDS.  The v kernel is the one whose advecting fluxes are centred-in-y
+// interpolations (rho_u, rho_w over rows j-2..j+1, rho_v over j-1..j+2) on top of the y-WENO stencil of v itself:
+// rocprofv3 PMC showed 12.7 GB fetched per launch for 5.4 GB of input (2.4x).  Four tiles per level, all staged
+// one level ahead: v (rows j0-3..j0+TY+2), Ax*rho_u, Ay*rho_v, Az*rho_w(k+1) (rows j0-2..j0+TY+1); interiors come
+// from the threads' own (coalesced) loads / the v ring, the 16 frame rows from two prefetched loads per thread.
+// y fluxes live at cell centres here (G(j) = F(j) - F(j-1)): wave 0 also evaluates the centre below the tile.
+template <int TY>
+__global__ __launch_bounds__(64 * TY) void k_v_tend_lds(DevGrid g, Tend3Fields F, int kchunk, RKEpilogue E)
+{
+    constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles
+    __shared__ double Tv[2][RV][64];
+    __shared__ double Tm[2][3][RM][64];                   // 0: Ax*rho_u, 1: Ay*rho_v, 2: Az*rho_w at the upper z-face
+    __shared__ double FY[2][TY + 1][64];
+    constexpr int NT = 64 * TY, NFR = 16 * 64, HPT = (NFR + NT - 1) / NT;
+    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
+    const int nact = min(64, g.Nx - i0);
+    const int ie = i0 + nact, le = nact - 1;              // x flux at x-faces: last lane needs face i0+nact
+    const int kbeg = blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    if (kbeg >= kend) return;
+    const long long sy = g.Sx, sz = g.Sxy;
+    const bool store = (i < g.Nx) && (j < g.Ny);
+    const double *v = F.c, *ru = F.ru, *rv = F.rv, *rw = F.rw;
+    const double Az = g.Az;
+    long long n = g.idx(ic, jc, kbeg);
+
+    // frame rows: id 0..5 v tile rows {0,1,2,TY+3,TY+4,TY+5}; 6..8 rho_u rows {0,1,TY+2}; 9..12 rho_v rows
+    // {0,1,TY+2,TY+3}; 13..15 rho_w rows {0,1,TY+2}   (momentum-tile row r' <-> grid row j0-2+r')
+    bool hok[HPT];
+    int hsel[HPT], hrow[HPT], hcol[HPT];
+    long long hn[HPT];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q) {
+        const int h = t + q * NT;
+        hok[q] = h < NFR;
+        const int id = hok[q] ? (h >> 6) : 0;
+        hcol[q] = h & 63;
+        int sel, row, grow;                                // sel: 0 v, 1 rho_u, 2 rho_v, 3 rho_w
+        if (id < 6) { sel = 0; row = (id < 3) ? id : TY + id; grow = j0 - 3 + row; }
+        else if (id < 9) { sel = 1; const int m = id - 6; row = (m < 2) ? m : TY + 2; grow = j0 - 2 + row; }
+        else if (id < 13) { sel = 2; const int m = id - 9; row = (m < 2) ? m : TY + m; grow = j0 - 2 + row; }
+        else { sel = 3; const int m = id - 13; row = (m < 2) ? m : TY + 2; grow = j0 - 2 + row; }
+        hsel[q] = sel; hrow[q] = row;
+        hn[q] = g.idx(min(i0 + hcol[q], g.Nx + 2), min(grow, g.Ny + 2), kbeg) + (sel == 3 ? sz : 0);
+    }
+    auto frame_load = [&](int q, long long lev, int klev) -> double {      // value to stage for level klev
+        const double *src = (hsel[q] == 0) ? v : (hsel[q] == 1) ? ru : (hsel[q] == 2) ? rv : rw;
+        const double fac = (hsel[q] == 0) ? 1.0 : (hsel[q] == 1) ? g.Ax[klev] : (hsel[q] == 2) ? g.Ay[klev] : Az;
+        return fac * src[hn[q] + lev];
+    };
+    auto frame_store = [&](int b, int q, double val) {
+        if (hsel[q] == 0) Tv[b][hrow[q]][hcol[q]] = val;
+        else Tm[b][hsel[q] - 1][hrow[q]][hcol[q]] = val;
+    };
+
+    double r[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) r[s] = v[n + (s - 3) * sz];
+    // lower z-face flux of the chunk, straight from global memory (once per chunk)
+    double fz_lo = vflux<T3_V>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
+    double rv_cur = rv[n];
+    Tv[0][ty + 3][tx] = r[3];
+    Tm[0][0][ty + 2][tx] = g.Ax[kbeg] * ru[n];
+    Tm[0][1][ty + 2][tx] = g.Ay[kbeg] * rv_cur;
+    Tm[0][2][ty + 2][tx] = Az * rw[n + sz];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q)
+        if (hok[q]) frame_store(0, q, frame_load(q, 0, kbeg));
+    __syncthreads();
+
+    double edge = 0.0;
+    int buf = 0;
+    for (int k = kbeg; k < kend; ++k, n += sz) {
+        const long long lev = (long long)(k + 1 - kbeg) * sz;
+        double hnext[HPT];
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? frame_load(q, lev, k + 1) : 0.0;
+        const double tnew = v[n + 3 * sz];
+        const double ru_n = g.Ax[k + 1] * ru[n + sz], rv_nraw = rv[n + sz], rw_n = Az * rw[n + 2 * sz];
+        if (((k - kbeg) & 63) == 0) {
+            const int kk = min(k + tx, kend - 1);
+            edge = flux_x_at<T3_V>(g, F, ie, jc, kk);
+        }
+        const int src = (k - kbeg) & 63;
+        const double c0 = r[3];
+        const double(*V)[64] = Tv[buf];
+        const double(*MU)[64] = Tm[buf][0];
+        const double(*MV)[64] = Tm[buf][1];
+        const double(*MW)[64] = Tm[buf][2];
+        // ---- z: advecting flux at (y-face j, z-face k+1) from the rho_w tile rows j-2..j+1 ----
+        const double wt = bz_symm4(MW[ty][tx], MW[ty + 1][tx], MW[ty + 2][tx], MW[ty + 3][tx]);
+        const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
+        // ---- x: flux at (x-face i, y-face j): rho_u rows j-2..j+1, v x-stencil from global (L1) ----
+        const double ut = bz_symm4(MU[ty][tx], MU[ty + 1][tx], MU[ty + 2][tx], MU[ty + 3][tx]);
+        const double fx = ut * bz_up5(v[n - 3], v[n - 2], v[n - 1], c0, v[n + 1], v[n + 2], ut > 0.0);
+        // ---- y: flux at centre j: rho_v rows j-1..j+2, v rows j-2..j+3 ----
+        const double vt = bz_symm4(MV[ty + 1][tx], MV[ty + 2][tx], MV[ty + 3][tx], MV[ty + 4][tx]);
+        const double fy = vt * bz_up5(V[ty + 1][tx], V[ty + 2][tx], c0, V[ty + 4][tx], V[ty + 5][tx], V[ty + 6][tx], vt > 0.0);
+        FY[buf][ty + 1][tx] = fy;
+        if (ty == 0) {       // centre j0-1: rho_v rows j0-2..j0+1, v rows j0-3..j0+2
+            const double vb = bz_symm4(MV[0][tx], MV[1][tx], MV[2][tx], MV[3][tx]);
+            FY[buf][0][tx] = vb * bz_up5(V[0][tx], V[1][tx], V[2][tx], V[3][tx], V[4][tx], V[5][tx], vb > 0.0);
+        }
+        // ---- stage level k+1 ----
+        Tv[buf ^ 1][ty + 3][tx] = r[4];
+        Tm[buf ^ 1][0][ty + 2][tx] = ru_n;
+        Tm[buf ^ 1][1][ty + 2][tx] = g.Ay[k + 1] * rv_nraw;
+        Tm[buf ^ 1][2][ty + 2][tx] = rw_n;
+#pragma unroll
+        for (int q = 0; q < HPT; ++q)
+            if (hok[q]) frame_store(buf ^ 1, q, hnext[q]);
+        __syncthreads();
+        {
+            double nb = __shfl_down(fx, 1);
+            const double e = __shfl(edge, src);
+            if (tx == le) nb = e;
+            const double dx = nb - fx;
+            const double dy = fy - FY[buf][ty][tx];
+            if (store)
+                F.G[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
+                                     -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo))), rv_cur, n);
+        }
+        fz_lo = fz_hi;
+        rv_cur = rv_nraw;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
+        r[5] = tnew;
+        buf ^= 1;
+    }
+}

@@ -122,6 +122,13 @@ int main(int argc, char** argv) {
         rep("u LDS TY=4 kc=256", timeit([&] { hipLaunchKernelGGL((k_u_tend_lds<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz + 255) / 256), dim3(64, 4), 0, 0, dg, Fm, 256, RKEpilogue()); }));
         rep("u LDS TY=8 kc=128", timeit([&] { hipLaunchKernelGGL((k_u_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 127) / 128), dim3(64, 8), 0, 0, dg, Fm, 128, RKEpilogue()); }));
         CK(hipMemset(G0, 0, nc * sizeof(double)));
+        rep("v gen1", timeit([&] { hipLaunchKernelGGL(k_v_tendency, g1, b1, 0, 0, dg, G0, ru, rv, rw, v, kc1, RKEpilogue()); }));
+        auto vref = grab(G0); CK(hipMemset(G0, 0, nc * sizeof(double)));
+        Fm.c = v;
+        rep("v LDS TY=8 kc=128", timeit([&] { hipLaunchKernelGGL((k_v_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 127) / 128), dim3(64, 8), 0, 0, dg, Fm, 128, RKEpilogue()); }));
+        printf("v LDS vs gen1:"); diff(grab(G0), vref);
+        rep("v LDS TY=8 kc=64", timeit([&] { hipLaunchKernelGGL((k_v_tend_lds<8>), dim3((Nx + 63) / 64, (Ny + 7) / 8, (Nz + 63) / 64), dim3(64, 8), 0, 0, dg, Fm, 64, RKEpilogue()); }));
+        CK(hipMemset(G0, 0, nc * sizeof(double)));
         Fm.c = w;
         rep("w ring TYW=4 kc=64", timeit([&] { hipLaunchKernelGGL((k_w_tend_ring<4>), dim3((Nx + 63) / 64, (Ny + 3) / 4, (Nz - 1 + 63) / 64), dim3(64, 4), 0, 0, dg, Fm, 64, RKEpilogue()); }));
         auto wref = grab(G0); CK(hipMemset(G0, 0, nc * sizeof(double)));

@@ -619,3 +619,6 @@ void og_divergence(const og_grid *G, double *div, const double *ru, const double
 double og_weno5(double a, double b, double c, double d, double e) { return weno5(a, b, c, d, e); }
 double og_weno3(double a, double b, double c) { return weno3(a, b, c); }
 int og_buffer_at(int idx, int N, int bounded, int at_face) { return buffer_at(idx, N, bounded, at_face); }
+
+/* Compressible split-explicit path. */
+#include "breeze_oracle_compressible.inc.c"

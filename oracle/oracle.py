@@ -37,8 +37,8 @@ _TOPO = {"Periodic": PERIODIC, "Bounded": BOUNDED, "Flat": FLAT, "Slab": SLAB,
 
 def build(force=False):
     """Compile the C oracle with gcc (recipe: oracle/Makefile)."""
-    src = os.path.join(_HERE, "breeze_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("breeze_oracle.c", "breeze_oracle_compressible.inc.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 

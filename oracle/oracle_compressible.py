@@ -1,0 +1,374 @@
+"""
+oracle_compressible.py — CPU (numpy + C) restatement of Breeze.jl's compressible
+split-explicit time step.
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/ (and nothing in breeze.jl_amd/).
+
+PARITY STATUS: Breeze-side arithmetic follows the cited lines; pinned by the reference's own
+known-answer tests restated in tests/test_oracle_compressible.py.  WENO arithmetic of the slow
+tendencies: "parity unpinned" (see breeze_oracle.c header).
+
+Reference call stack restated here (file:line relative to /root/reference):
+  time_step!                    src/TimeSteppers/acoustic_runge_kutta_3.jl:264-319
+  acoustic_rk3_substep!         src/TimeSteppers/acoustic_runge_kutta_3.jl:172-192
+  compute_slow_*_tendencies!    src/TimeSteppers/acoustic_substep_helpers.jl:55-149
+  scalar_substep!               src/TimeSteppers/acoustic_substep_helpers.jl:197-248
+  acoustic_rk3_substep_loop!    src/CompressibleEquations/acoustic_substepping.jl:1404-1590
+  refresh_linearization_basic_state!                         ...:318-399
+  compute_acoustic_substeps / stage_substep_count_and_size   ...:451-508
+  update_state!                 src/AtmosphereModels/update_atmosphere_model_state.jl:41-68
+  _compute_temperature_and_pressure!  src/CompressibleEquations/compressible_time_stepping.jl:191-242
+  ExnerReferenceState           src/Thermodynamics/reference_states.jl:588-672,717-815
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from .oracle import BOUNDED, FLAT, Constants, Grid, _OGGrid, _dp, _p, lib  # noqa: F401
+
+
+# ---------------------------------------------------------------------------
+# ExnerReferenceState: dry, 1-D column, isentropic mode (reference_states.jl:588-672)
+# ---------------------------------------------------------------------------
+class ExnerReferenceState:
+    def __init__(self, grid, constants, surface_pressure=101325.0, potential_temperature=288.0,
+                 standard_pressure=1e5):
+        g, c = grid, constants
+        Nz, Hz = g.Nz, g.Hz
+        self.p0, self.pst = float(surface_pressure), float(standard_pressure)
+        th_fun = potential_temperature if callable(potential_temperature) else (lambda z: float(potential_temperature) + 0.0 * z)
+        self.theta0 = float(th_fun(np.float64(0.0)))
+        theta = np.zeros(g.Szc)
+        theta[Hz:Hz + Nz] = th_fun(g.zc)
+        theta[Hz - 1] = theta[Hz]
+        theta[Hz + Nz] = theta[Hz + Nz - 1]
+        Rm, cpm = 1.0 * c.Rd + 0.0 * c.Rv, 1.0 * c.cpd + 0.0 * c.cpv
+        kap = Rm / cpm
+        grav, pst = c.g, self.pst
+        pi = np.zeros(g.Szc)
+        p = np.zeros(g.Szc)
+        rho = np.zeros(g.Szc)
+        pi_surf = (self.p0 / pst) ** kap
+        th1 = theta[Hz]
+        Pi1 = pi_surf - grav * g.dzc[Hz] / (2 * cpm * th1)
+        p1 = pst * Pi1 ** (1 / kap)
+        pi[Hz], p[Hz], rho[Hz] = Pi1, p1, p1 / (Rm * th1 * Pi1)
+        pm, rm = p[Hz], rho[Hz]
+        for k in range(1, Nz):
+            dzf = g.dzf[k + Hz]
+            thk, thm = theta[Hz + k], theta[Hz + k - 1]
+            thf = (thk + thm) / 2
+            Pi_init = pi[Hz + k - 1] - grav * dzf / (cpm * thf)
+            pk = pst * Pi_init ** (1 / kap)
+            A = grav * pst ** kap / (2 * Rm * thk)
+            Cc = pm / dzf - grav * rm / 2
+            for _ in range(5):                  # FixedIterations(5)
+                rp = pk ** (-kap)
+                f = pk / dzf + A * pk * rp - Cc
+                fp = 1 / dzf + A * (1 - kap) * rp
+                pk -= f / fp
+            Pik = (pk / pst) ** kap
+            rk = pk / (Rm * thk * Pik)
+            pi[Hz + k], p[Hz + k], rho[Hz + k] = Pik, pk, rk
+            pm, rm = pk, rk
+        self.rho0 = self.p0 / (Rm * self.theta0 * pi_surf)
+        # halos: bottom Value BC for p, rho; zero-gradient elsewhere (first halo cell)
+        p[Hz - 1] = 2 * self.p0 - p[Hz]
+        rho[Hz - 1] = 2 * self.rho0 - rho[Hz]
+        pi[Hz - 1] = pi[Hz]
+        for a in (p, rho, pi):
+            a[Hz + Nz] = a[Hz + Nz - 1]
+        self.pressure, self.density, self.exner_function, self.potential_temperature = p, rho, pi, theta
+
+
+# ---------------------------------------------------------------------------
+# SplitExplicitTimeDiscretization defaults (time_discretizations.jl:550-562)
+# ---------------------------------------------------------------------------
+class SplitExplicit:
+    def __init__(self, substeps=None, acoustic_cfl=0.5, forward_weight=0.65,
+                 damping_coefficient=0.1, damp_vertical=False,
+                 apply_first_substep_pressure_gradient=False,
+                 thermodynamic_tendency_factor=1.0, vertical_momentum_tendency_factor=1.0):
+        self.substeps = substeps
+        self.acoustic_cfl = float(acoustic_cfl)
+        self.forward_weight = float(forward_weight)
+        self.damping_coefficient = None if damping_coefficient is None else float(damping_coefficient)  # None = NoDivergenceDamping
+        self.damp_vertical = bool(damp_vertical)
+        self.apply_first = bool(apply_first_substep_pressure_gradient)
+        self.f_theta = float(thermodynamic_tendency_factor)
+        self.f_w = float(vertical_momentum_tendency_factor)
+
+
+def compute_acoustic_substeps(grid, dt, constants, acoustic_cfl):
+    """acoustic_substepping.jl:451-466"""
+    c = constants
+    gam = c.cpd / (c.cpd - c.Rd)
+    cs = math.sqrt(gam * c.Rd * 300.0)
+    dx = math.inf if grid.topo[0] == FLAT else grid.dx
+    dy = math.inf if grid.topo[1] == FLAT else grid.dy
+    return max(1, math.ceil(abs(float(dt)) * cs / (acoustic_cfl * min(dx, dy))))
+
+
+def stage_substep_count_and_size(substeps, beta, dt, grid, constants, acoustic_cfl):
+    """ProportionalSubsteps (acoustic_substepping.jl:491-495)"""
+    dt_stage = beta * dt
+    if substeps is None:
+        n = compute_acoustic_substeps(grid, dt_stage, constants, acoustic_cfl)
+    else:
+        n = max(1, math.ceil(beta * substeps))
+    return n, dt_stage / n
+
+
+def apply_horizontal_pressure_gradient_substep(substep, n_tau, apply_first=False):
+    """acoustic_substepping.jl:891-895 (substep is 1-based)"""
+    return bool(apply_first) or (substep != 1) or (n_tau == 1)
+
+
+class CompressibleOracleModel:
+    """AtmosphereModel(grid; advection=WENO(order=5), dynamics=CompressibleDynamics(
+    SplitExplicitTimeDiscretization(...); reference_potential_temperature=...)) on the CPU."""
+
+    PROGNOSTIC = ("rho_d", "ru", "rv", "rw", "rtheta", "rq")
+    BETAS = (1.0 / 3.0, 1.0 / 2.0, 1.0)
+
+    def __init__(self, grid, constants=None, time_discretization=None, surface_pressure=101325.0,
+                 standard_pressure=1e5, reference_potential_temperature=288.0, reference_state=True,
+                 newton_abstol=1e-4, newton_maxiter=8):
+        self.grid = g = grid
+        self.constants = c = constants or Constants()
+        self.td = time_discretization or SplitExplicit()
+        self.pst = float(standard_pressure)
+        self.p0 = float(surface_pressure)
+        self.ref = (ExnerReferenceState(g, c, surface_pressure, reference_potential_temperature, standard_pressure)
+                    if reference_state else None)
+        self.newton = (float(newton_abstol), int(newton_maxiter))
+        self.lib = lib()
+        zeros = np.zeros(g.Szc)
+        self._zc = zeros
+        self.cg = _OGGrid(g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz, g.topo[0], g.topo[1], g.topo[2],
+                          g.dx, g.dy, _p(g.dzc), _p(g.dzf), _p(zeros), _p(zeros), _p(zeros),
+                          c.g, c.Rd, c.Rv, c.cpd, c.cpv, self.pst)
+        cf, zf = g.center_field, g.zface_field
+        self.rho_d, self.rho, self.rtheta, self.rq, self.ru, self.rv = (cf() for _ in range(6))
+        self.rw = zf()
+        self.u, self.v, self.theta, self.q, self.T, self.p = (cf() for _ in range(6))
+        self.w = zf()
+        self.U0 = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
+        self.G = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
+        # AcousticSubstepper storage (acoustic_substepping.jl:207-231)
+        self.Pi, self.thL, self.gR = cf(), cf(), cf()
+        self.rp, self.rthp, self.rup, self.rvp = cf(), cf(), cf(), cf()
+        self.rwp = zf()
+        self.rs, self.rths, self.rth_old = cf(), cf(), cf()
+        self.au, self.av, self.aw = cf(), cf(), zf()
+        self.Gs, self.rhs = zf(), zf()
+        self.iteration, self.clock_time = 0, 0.0
+        self.last_substeps = []
+        # seed_pressure! (compressible_dynamics.jl:254-258)
+        if self.ref is not None:
+            g.interior(self.p)[...] = self.ref.pressure[g.Hz:g.Hz + g.Nz][:, None, None]
+        else:
+            g.interior(self.p)[...] = self.p0
+        self._halo_center(self.p)
+
+    # -- halos ---------------------------------------------------------------
+    def _halo_center(self, f):
+        self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
+        self.lib.og_fill_halo_z_noflux(C.byref(self.cg), _p(f))
+
+    def _halo_w(self, f):
+        self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
+        self.lib.og_fill_halo_z_wall(C.byref(self.cg), _p(f))
+
+    def _eval(self, value, loc):
+        g = self.grid
+        shape = (g.Nz + (1 if loc[2] == "f" else 0), g.Ny, g.Nx)
+        if callable(value):
+            x, y, z = g.nodes(loc)
+            value = value(x, y, z)
+        value = np.asarray(value, dtype=np.float64)
+        if value.ndim == 1:        # a column (e.g. ref.density interior)
+            value = value[:, None, None]
+        return np.broadcast_to(value, shape)
+
+    # -- set! (set_atmosphere_model.jl:198-362, compressible_time_stepping.jl:105-150) ------------
+    def set(self, rho=None, theta=None, u=None, v=None, w=None, qv=None):
+        g = self.grid
+        I = g.interior
+        if rho is not None:
+            I(self.rho_d)[...] = self._eval(rho, "ccc")
+            self._halo_center(self.rho_d)
+        if qv is not None:
+            I(self.q)[...] = self._eval(qv, "ccc")
+            I(self.rq)[...] = I(self.rho_d) * I(self.q)
+        if rho is not None:                                   # total density given: rho_d = rho - rho q
+            I(self.rho)[...] = I(self.rho_d)
+            I(self.rho_d)[...] = I(self.rho) - (I(self.rq) + 0.0)
+            self._halo_center(self.rho)
+            self._halo_center(self.rho_d)
+        if theta is not None:
+            I(self.theta)[...] = self._eval(theta, "ccc")
+            I(self.rtheta)[...] = I(self.rho_d) * I(self.theta)
+        r = self.rho_d
+        Hx, Hy, Hz, Nx, Ny, Nz = g.Hx, g.Hy, g.Hz, g.Nx, g.Ny, g.Nz
+        if u is not None:
+            I(self.u)[...] = self._eval(u, "fcc")
+            rx = I(r) if g.topo[0] == FLAT else (I(r) + r[Hz:Hz + Nz, Hy:Hy + Ny, Hx - 1:Hx - 1 + Nx]) / 2
+            I(self.ru)[...] = rx * I(self.u)
+        if v is not None:
+            I(self.v)[...] = self._eval(v, "cfc")
+            ry = I(r) if g.topo[1] == FLAT else (I(r) + r[Hz:Hz + Nz, Hy - 1:Hy - 1 + Ny, Hx:Hx + Nx]) / 2
+            I(self.rv)[...] = ry * I(self.v)
+        if w is not None:
+            I(self.w, True)[...] = self._eval(w, "ccf")
+            rz = (r[Hz:Hz + Nz + 1, Hy:Hy + Ny, Hx:Hx + Nx] + r[Hz - 1:Hz + Nz, Hy:Hy + Ny, Hx:Hx + Nx]) / 2
+            I(self.rw, True)[...] = rz * I(self.w, True)
+        self.update_state(compute_tendencies=False)
+
+    # -- update_state! ---------------------------------------------------------
+    def update_state(self, compute_tendencies=True):
+        cg, L = C.byref(self.cg), self.lib
+        L.og_total_density(cg, _p(self.rho), _p(self.rho_d), _p(self.rq))
+        self._halo_center(self.rho)
+        for f in (self.rho_d, self.ru, self.rv, self.rtheta, self.rq):
+            self._halo_center(f)
+        self._halo_w(self.rw)
+        L.og_compute_velocities_3d(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv),
+                                   _p(self.rw), _p(self.rho_d))
+        self._halo_center(self.u)
+        self._halo_center(self.v)
+        self._halo_w(self.w)
+        L.og_compressible_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.p), _p(self.rho_d),
+                                 _p(self.rho), _p(self.rtheta), _p(self.rq),
+                                 C.c_double(self.newton[0]), C.c_int(self.newton[1]))
+        for f in (self.theta, self.q, self.T, self.p):
+            self._halo_center(f)
+        if compute_tendencies:
+            # moisture: total density carrier, acoustic-mean transport velocities
+            # (update_atmosphere_model_state.jl:330-343, acoustic_runge_kutta_3.jl:352-358);
+            # the momentum / theta / rho_d tendencies computed here by the reference are overwritten
+            # by compute_slow_*_tendencies! before they are used.
+            L.og_scalar_tendency_3d(cg, _p(self.G["rq"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.q))
+
+    # -- acoustic stage ----------------------------------------------------------
+    def refresh_linearization(self):
+        self.lib.og_linearization(C.byref(self.cg), _p(self.Pi), _p(self.thL), _p(self.gR), _p(self.p),
+                                  _p(self.rho_d), _p(self.rtheta), _p(self.rho), _p(self.q))
+        for f in (self.Pi, self.thL, self.gR):
+            self._halo_center(f)
+
+    def seed_time_averaged_velocities(self):
+        self.au[...] = self.u
+        self.av[...] = self.v
+        self.aw[...] = self.w
+
+    def compute_slow_tendencies(self):
+        cg, L, G = C.byref(self.cg), self.lib, self.G
+        L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
+        L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
+        L.og_w_tendency_slow(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w))
+        L.og_density_tendency(cg, _p(G["rho_d"]), _p(self.ru), _p(self.rv), _p(self.rw))
+        L.og_scalar_tendency_3d(cg, _p(G["rtheta"]), _p(self.rho_d), _p(self.u), _p(self.v), _p(self.w), _p(self.theta))
+
+    def assemble_slow_vertical_momentum(self):
+        pr = _p(self.ref.pressure) if self.ref is not None else None
+        rr = _p(self.ref.density) if self.ref is not None else None
+        self.lib.og_slow_vertical_momentum(C.byref(self.cg), _p(self.Gs), _p(self.G["rw"]), _p(self.p),
+                                           _p(self.rho), pr, rr)
+
+    def implicit_damping_factors(self):
+        td, g = self.td, self.grid
+        if td.damping_coefficient is None or not td.damp_vertical:
+            return 0.0, 0.0
+        base = td.damping_coefficient * float(np.min(g.dzc[g.Hz:g.Hz + g.Nz])) ** 2
+        return td.forward_weight * base, (1 - td.forward_weight) * base
+
+    def acoustic_substep_loop(self, dt, beta):
+        """acoustic_rk3_substep_loop! (acoustic_substepping.jl:1404-1590)"""
+        g, td, c = self.grid, self.td, self.constants
+        cg, L = C.byref(self.cg), self.lib
+        Nz = g.Nz
+        n_tau, dtau = stage_substep_count_and_size(td.substeps, beta, float(dt), g, c, td.acoustic_cfl)
+        self.last_substeps.append(n_tau)
+        om = td.forward_weight
+        dtn, dto = om * dtau, (1 - om) * dtau
+        self.assemble_slow_vertical_momentum()
+        # initialize_stage_perturbations!
+        for f in (self.rth_old, self.rs, self.rths):
+            g.interior(f)[...] = 0.0
+        g.interior(self.au)[...] = 0.0
+        g.interior(self.av)[...] = 0.0
+        g.interior(self.aw)[...] = 0.0          # :xyz launch: faces 0..Nz-1
+        for prime, name, nk in ((self.rp, "rho_d", Nz), (self.rthp, "rtheta", Nz), (self.rup, "ru", Nz),
+                                (self.rvp, "rv", Nz), (self.rwp, "rw", Nz)):
+            L.og_initialize_perturbation(cg, _p(prime), _p(self.U0[name]), _p(getattr(self, name)), C.c_int(nk))
+        for f in (self.rp, self.rthp, self.rup, self.rvp):
+            self._halo_center(f)
+        self._halo_w(self.rwp)
+        d_new, d_old = self.implicit_damping_factors()
+        for s in range(1, n_tau + 1):
+            gate = apply_horizontal_pressure_gradient_substep(s, n_tau, td.apply_first)
+            L.og_explicit_horizontal_step(cg, _p(self.rup), _p(self.rvp), _p(self.p), _p(self.rthp), _p(self.Pi),
+                                          _p(self.gR), _p(self.G["ru"]), _p(self.G["rv"]), C.c_double(dtau),
+                                          C.c_int(int(gate)))
+            self._halo_center(self.rup)
+            self._halo_center(self.rvp)
+            L.og_build_predictors(cg, _p(self.rs), _p(self.rths), _p(self.rth_old), _p(self.rp), _p(self.rthp),
+                                  _p(self.rwp), _p(self.rup), _p(self.rvp), _p(self.G["rho_d"]),
+                                  _p(self.G["rtheta"]), _p(self.thL), C.c_double(dtau), C.c_double(dto),
+                                  C.c_double(td.f_theta))
+            self._halo_center(self.rth_old)
+            L.og_build_vertical_rhs(cg, _p(self.rhs), _p(self.rs), _p(self.rths), _p(self.rp), _p(self.rthp),
+                                    _p(self.rwp), _p(self.Pi), _p(self.gR), _p(self.Gs), C.c_double(dtau),
+                                    C.c_double(dtn), C.c_double(dto), C.c_double(d_old), C.c_double(td.f_w))
+            L.og_acoustic_tridiagonal_solve(cg, _p(self.rwp), _p(self.rhs), _p(self.Pi), _p(self.thL),
+                                            _p(self.gR), C.c_double(dtn), C.c_double(d_new))
+            L.og_post_solve_recovery(cg, _p(self.rp), _p(self.rthp), _p(self.rwp), _p(self.rup), _p(self.rvp),
+                                     _p(self.rs), _p(self.rths), _p(self.au), _p(self.av), _p(self.aw),
+                                     _p(self.thL), C.c_double(dtn))
+            self._halo_center(self.rp)
+            self._halo_center(self.rthp)
+            if td.damping_coefficient is not None:
+                L.og_thermal_divergence_damping(cg, _p(self.rup), _p(self.rvp), _p(self.rthp), _p(self.rth_old),
+                                                _p(self.thL), C.c_double(td.damping_coefficient), C.c_double(dtau))
+            self._halo_center(self.rup)
+            self._halo_center(self.rvp)
+        L.og_finalize_time_averaged_velocity(cg, _p(self.au), _p(self.av), _p(self.aw), _p(self.ru), _p(self.rv),
+                                             _p(self.rw), _p(self.rho_d), C.c_double(1.0 / float(n_tau)))
+        self._halo_center(self.au)
+        self._halo_center(self.av)
+        self._halo_w(self.aw)
+        L.og_recover_full_state(cg, _p(self.rho_d), _p(self.rtheta), _p(self.ru), _p(self.rv), _p(self.rw),
+                                _p(self.rp), _p(self.rthp), _p(self.rup), _p(self.rvp), _p(self.rwp))
+        for f in (self.rho_d, self.rtheta, self.ru, self.rv):
+            self._halo_center(f)
+        self._halo_w(self.rw)
+        L.og_compute_velocities_3d(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv),
+                                   _p(self.rw), _p(self.rho_d))
+        self._halo_center(self.u)
+        self._halo_center(self.v)
+        self._halo_w(self.w)
+
+    def acoustic_rk3_substep(self, dt, beta):
+        self.refresh_linearization()
+        self.compute_slow_tendencies()
+        self.acoustic_substep_loop(dt, beta)
+        self.lib.og_ws_rk3_scalar(C.byref(self.cg), _p(self.rq), _p(self.U0["rq"]), _p(self.G["rq"]),
+                                  C.c_double(beta * dt))
+
+    def time_step(self, dt):
+        dt = float(dt)
+        if self.iteration == 0:                     # maybe_prepare_first_time_step!
+            self.seed_time_averaged_velocities()
+            self.update_state(compute_tendencies=True)
+        for n in self.PROGNOSTIC:                   # store_initial_state!
+            self.U0[n][...] = getattr(self, n)
+        self.refresh_linearization()                # freeze_linearization_state!
+        self.seed_time_averaged_velocities()
+        self.last_substeps = []
+        for beta in self.BETAS:
+            self.acoustic_rk3_substep(dt, beta)
+            self.update_state(compute_tendencies=True)
+        self.clock_time += dt
+        self.iteration += 1

@@ -1,0 +1,214 @@
+"""Pins for the compressible split-explicit oracle: the reference's own known-answer tests restated
+(test/acoustic_substepping_components.jl, test/substepper_structural.jl,
+test/substepper_rest_state.jl).  None of these needs a GPU."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def oc(oracle):
+    from oracle import oracle_compressible
+    return oracle_compressible
+
+
+def test_first_small_step_pressure_gradient_gate(oc):
+    """test/acoustic_substepping_components.jl:50-56"""
+    f = oc.apply_horizontal_pressure_gradient_substep
+    assert f(1, 1)
+    assert not f(1, 2)
+    assert f(2, 2)
+    assert not f(1, 6)
+    assert f(6, 6)
+    assert f(1, 6, True)
+
+
+def test_explicit_horizontal_step_known_answer(oracle, oc):
+    """test/acoustic_substepping_components.jl:58-93 — Pi = gammaR = 1, p = 2x + 3y, rho theta' = 0,
+    dtau = 0.5, gate off  =>  (rho u)'[2,2,2] == -1, (rho v)'[2,2,2] == -1.5 exactly."""
+    g = oracle.Grid((4, 4, 4), x=(0, 4), y=(0, 4), z=(0, 4))
+    m = oc.CompressibleOracleModel(g, reference_state=False)
+    x, y, _ = g.nodes("ccc")
+    g.interior(m.p)[...] = 2 * x + 3 * y
+    g.interior(m.Pi)[...] = 1.0
+    g.interior(m.gR)[...] = 1.0
+    from oracle.oracle import _p
+    m.lib.og_explicit_horizontal_step(C.byref(m.cg), _p(m.rup), _p(m.rvp), _p(m.p), _p(m.rthp), _p(m.Pi), _p(m.gR),
+                                      _p(m.G["ru"]), _p(m.G["rv"]), C.c_double(0.5), C.c_int(0))
+    assert g.interior(m.rup)[1, 1, 1] == -1.0
+    assert g.interior(m.rvp)[1, 1, 1] == -1.5
+
+
+def test_acoustic_tridiagonal_coefficients_closed_form(oracle, oc):
+    """test/acoustic_substepping_components.jl:95-166"""
+    Nz, Lz = 5, 1000.0
+    g = oracle.Grid((4, 4, Nz), x=(0, 1), y=(0, 1), z=(0, Lz))
+    m = oc.CompressibleOracleModel(g, reference_state=False)
+    I = g.interior
+    for k in range(1, Nz + 1):
+        I(m.Pi)[k - 1, 1, 1] = 0.90 + 0.02 * k
+        I(m.thL)[k - 1, 1, 1] = 280 + 3 * k
+        I(m.gR)[k - 1, 1, 1] = 390 + 5 * k
+    for f in (m.Pi, m.thL, m.gR):
+        m._halo_center(f)
+    dtn, dnew, grav, dz = 0.7, 0.03, 9.81, Lz / Nz
+    m.cg.g = grav
+    from oracle.oracle import _p
+    fn = m.lib.og_acoustic_coefficient
+    fn.restype = C.c_double
+
+    def code(row, which):   # Julia row index -> 0-based row
+        return fn(C.byref(m.cg), _p(m.Pi), _p(m.thL), _p(m.gR), C.c_int(1), C.c_int(1), C.c_int(row - 1),
+                  C.c_int(which), C.c_double(dtn), C.c_double(dnew))
+
+    Cc = lambda k: I(m.gR)[k - 1, 1, 1] * I(m.Pi)[k - 1, 1, 1]
+    th = lambda k: I(m.thL)[k - 1, 1, 1]
+    thf = lambda k: th(1) if k == 1 else (th(Nz) if k == Nz + 1 else (th(k) + th(k - 1)) / 2)
+    assert code(1, 1) == 1.0
+    assert code(1, 2) == 0.0
+    for k in range(2, Nz + 1):
+        lower = -dtn ** 2 * Cc(k - 1) * thf(k - 1) / dz ** 2 + dtn ** 2 * grav / (2 * dz) - dnew / dz ** 2
+        diag = 1 + dtn ** 2 * thf(k) * (Cc(k) + Cc(k - 1)) / dz ** 2 + 2 * dnew / dz ** 2
+        assert code(k, 0) == pytest.approx(lower, rel=1e-13)
+        assert code(k, 1) == pytest.approx(diag, rel=1e-13)
+    for k in range(2, Nz):
+        upper = -dtn ** 2 * Cc(k) * thf(k + 1) / dz ** 2 - dtn ** 2 * grav / (2 * dz) - dnew / dz ** 2
+        assert code(k, 2) == pytest.approx(upper, rel=1e-13)
+
+
+def test_compute_acoustic_substeps(oracle, oc):
+    """test/acoustic_substepping_components.jl:274-313"""
+    c = oracle.Constants()
+    g = oracle.Grid((100, 6, 10), x=(0, 100e3), y=(0, 6e3), z=(0, 10e3), halo=(5, 5, 5))
+    expected = lambda nu: math.ceil(12 * math.sqrt(1.4 * 287.0 * 300) / (nu * 1000))
+    assert oc.compute_acoustic_substeps(g, 12, c, 0.5) == expected(0.5) == 9
+    assert oc.compute_acoustic_substeps(g, 12, c, 0.25) == expected(0.25)
+    assert oc.compute_acoustic_substeps(g, 12, c, 1.0) == expected(1.0)
+    assert oc.compute_acoustic_substeps(g, -12, c, 0.5) == expected(0.5)
+    gf = oracle.Grid((100, 10), x=(0, 100e3), z=(0, 10e3), halo=(5, 5), topology=("Periodic", "Flat", "Bounded"))
+    assert oc.compute_acoustic_substeps(gf, 12, c, 0.5) == expected(0.5)
+    # ProportionalSubsteps (acoustic_substepping.jl:491-495)
+    assert oc.stage_substep_count_and_size(6, 1 / 3, 3.0, g, c, 0.5) == (2, 0.5)
+    assert oc.stage_substep_count_and_size(6, 0.5, 3.0, g, c, 0.5) == (3, 0.5)
+    n, dtau = oc.stage_substep_count_and_size(None, 1.0, 12.0, g, c, 0.5)
+    assert n == 9 and dtau == 12.0 / 9
+
+
+T0_REST, G_REST, CPD_REST = 250.0, 9.80665, 1005.0
+
+
+def theta_isothermal(z):
+    return T0_REST * np.exp(G_REST * z / (CPD_REST * T0_REST))
+
+
+def rest_model(oracle, oc, size=(8, 8, 32), Lz=30e3, Lh=100e3, **td):
+    g = oracle.Grid(size, x=(0, Lh), y=(0, Lh), z=(0, Lz), halo=(5, 5, 5))
+    m = oc.CompressibleOracleModel(g, time_discretization=oc.SplitExplicit(**td), surface_pressure=1e5,
+                                   standard_pressure=1e5, reference_potential_temperature=theta_isothermal)
+    return m
+
+
+def set_rest(m):
+    """test/substepper_structural.jl:53-63: rho_d = rho_ref, rho theta = p_ref / (Rd Pi_ref), u = 0."""
+    m.rho_d[...] = m.ref.density[:, None, None]
+    m.rtheta[...] = (m.ref.pressure / (m.constants.Rd * np.where(m.ref.exner_function == 0, 1, m.ref.exner_function)))[:, None, None]
+    m.update_state()
+
+
+def test_exner_reference_state_discrete_balance(oracle, oc):
+    """test/substepper_rest_state.jl T1 (residual <= 1e-9) and components.jl:508-520 (p decreasing)."""
+    m = rest_model(oracle, oc, size=(4, 4, 64))
+    g, r = m.grid, m.ref
+    Hz, Nz = g.Hz, g.Nz
+    p, rho = r.pressure[Hz:Hz + Nz], r.density[Hz:Hz + Nz]
+    dz = g.dzf[Hz + 1:Hz + Nz]
+    res = (p[1:] - p[:-1]) / dz + m.constants.g * (rho[1:] + rho[:-1]) / 2
+    assert np.abs(res).max() <= 1e-9
+    assert np.all(np.diff(p) < 0)
+    # Value BC halos: Iz(p)[face 0] = p0, Iz(rho)[face 0] = rho0
+    assert 0.5 * (r.pressure[Hz - 1] + r.pressure[Hz]) == pytest.approx(1e5, rel=1e-15)
+    assert r.rho0 > 0
+
+
+def test_rest_state_pressure_consistency_and_slow_tendency(oracle, oc):
+    """test/substepper_rest_state.jl T2, T3"""
+    m = rest_model(oracle, oc, size=(8, 8, 64))
+    set_rest(m)
+    g = m.grid
+    pref = m.ref.pressure[g.Hz:g.Hz + g.Nz][:, None, None]
+    assert np.abs(g.interior(m.p) - pref).max() <= 100 * np.finfo(float).eps * pref.max()
+    assert np.all(g.interior(m.rho_d) == m.ref.density[g.Hz:g.Hz + g.Nz][:, None, None])
+    m.refresh_linearization()
+    m.compute_slow_tendencies()
+    m.assemble_slow_vertical_momentum()
+    assert np.abs(g.interior(m.Gs, True)).max() <= 1e-12
+
+
+def test_rest_state_structural_invariants(oracle, oc):
+    """test/substepper_structural.jl S1, S4, S5: bottom row of the column system, mass conservation and
+    closed lid after one outer step at rest (omega = 0.55, no damping)."""
+    m = rest_model(oracle, oc, forward_weight=0.55, damping_coefficient=None)
+    set_rest(m)
+    g = m.grid
+    M0 = g.interior(m.rho_d).sum()
+    m.time_step(0.5)
+    M1 = g.interior(m.rho_d).sum()
+    assert abs(M1 - M0) / M0 <= 1e-12
+    assert np.abs(g.interior(m.w, True)[-1]).max() <= 1e-12
+    assert np.abs(g.interior(m.w, True)[0]).max() == 0.0
+    assert m.last_substeps == [1, 1, 1]
+
+
+def test_rest_atmosphere_stays_quiet(oracle, oc):
+    """test/acoustic_substepping_stability.jl:329-353 (shape): a balanced rest state stays at rest
+    under default damping / off-centering, w_max < sqrt(eps)."""
+    m = rest_model(oracle, oc, size=(8, 8, 16), Lz=10e3, Lh=8e3)
+    set_rest(m)
+    for _ in range(5):
+        m.time_step(6.0)
+    g = m.grid
+    assert np.isfinite(g.interior(m.rho_d)).all()
+    assert np.abs(g.interior(m.w, True)).max() < math.sqrt(np.finfo(float).eps)
+    assert np.abs(g.interior(m.u)).max() < math.sqrt(np.finfo(float).eps)
+    assert m.last_substeps[-1] >= 2
+
+
+def test_tiny_dry_bubble_consistency_with_anelastic(oracle, oc):
+    """test/acoustic_substepping_stability.jl:192-322 restated: 16x16 (Periodic, Flat, Bounded) bubble,
+    pressure-balanced initial density, split-explicit (substeps = 6) vs anelastic after one dt = 0.5 step:
+    max updraft within rtol 1.25, updraft centroid within 2 dz; dry mass / rho*theta conserved."""
+    c = oracle.Constants()
+    kap = c.Rd / c.cpd
+    p0 = pst = 1e5
+    th0, dth, radius, zb = 300.0, 10.0, 2e3, 3e3
+    exner = lambda z: (p0 / pst) ** kap - c.g * z / (c.cpd * th0)
+    pref = lambda z: pst * exner(z) ** (1 / kap)
+    theta = lambda x, y, z: th0 + dth * np.maximum(0.0, 1.0 - np.sqrt(x ** 2 + (z - zb) ** 2) / radius)
+    rho = lambda x, y, z: pref(z) / (c.Rd * theta(x, y, z) * exner(z))
+    kw = dict(x=(-8e3, 8e3), z=(0, 8e3), halo=(5, 5), topology=("Periodic", "Flat", "Bounded"))
+    g = oracle.Grid((16, 16), **kw)
+    m = oc.CompressibleOracleModel(g, time_discretization=oc.SplitExplicit(substeps=6), surface_pressure=p0,
+                                   standard_pressure=pst, reference_potential_temperature=th0)
+    m.set(rho=rho, theta=theta, qv=0.0)
+    M0, H0 = g.interior(m.rho_d).sum(), g.interior(m.rtheta).sum()
+    m.time_step(0.5)
+    assert m.last_substeps == [2, 3, 6]
+    ga = oracle.Grid((16, 16), **kw)
+    a = oracle.OracleModel(ga, surface_pressure=p0, potential_temperature=th0, standard_pressure=pst)
+    a.set(theta=theta, qt=0.0)
+    a.time_step(0.5)
+
+    def diag(mod, gg):
+        w = np.maximum(0.0, gg.interior(mod.w, True))
+        return w.max(), (w.sum(axis=(1, 2)) * gg.zf).sum() / w.sum()
+
+    (ws, zs), (wa, za) = diag(m, g), diag(a, ga)
+    assert np.isfinite(g.interior(m.w, True)).all()
+    assert ws > 0 and wa > 0
+    assert abs(ws - wa) <= 1.25 * max(ws, wa)
+    assert abs(zs - za) <= 2 * (8e3 / 16)
+    assert abs(g.interior(m.rho_d).sum() - M0) / M0 < 1e-13
+    assert abs(g.interior(m.rtheta).sum() - H0) / H0 < 1e-13
+    print("tiny bubble: split-explicit w_max %.4f zW %.1f | anelastic w_max %.4f zW %.1f" % (ws, zs, wa, za))

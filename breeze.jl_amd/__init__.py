@@ -13,3 +13,7 @@ from .model import (AnelasticDynamics, AtmosphereModel, Field, WENO, compute_aux
                     compute_pressure_correction_, compute_tendencies_, compute_velocities_,
                     enforce_mass_conservation_, fill_halo_regions_, make_pressure_correction_, set_,
                     ssp_rk3_substep_, store_initial_state_, time_step_, update_state_)
+from . import compressible  # noqa: F401,E402
+from .compressible import (AcousticRungeKutta3, AcousticSubstepper, CompressibleAtmosphereModel, CompressibleDynamics,  # noqa: F401,E402
+                           ExnerReferenceState, NewtonSolver, NoDivergenceDamping, ProportionalSubsteps,
+                           SplitExplicitTimeDiscretization, ThermalDivergenceDamping)

@@ -50,9 +50,43 @@ class bz_prognostic(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _PROG_FIELDS]
 
 
+_CSTATE_FIELDS = ("rho_d", "rho", "rho_u", "rho_v", "rho_w", "rho_theta", "rho_q", "u", "v", "w", "theta", "q", "T", "p")
+_CPROG_FIELDS = ("rho_d", "rho_u", "rho_v", "rho_w", "rho_theta", "rho_q")
+_SUBSTEPPER_FIELDS = ("exner", "potential_temperature", "gamma_R_mixture", "density_perturbation",
+                      "density_potential_temperature_perturbation", "momentum_perturbation_u", "momentum_perturbation_v",
+                      "momentum_perturbation_w", "density_predictor", "density_potential_temperature_predictor",
+                      "previous_density_potential_temperature_perturbation", "time_averaged_u", "time_averaged_v",
+                      "time_averaged_w", "slow_vertical_momentum_tendency", "vertical_solver_source_term")
+
+
+class bz_compressible_state(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _CSTATE_FIELDS]
+
+
+class bz_compressible_prognostic(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _CPROG_FIELDS]
+
+
+class bz_acoustic_substepper(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _SUBSTEPPER_FIELDS]
+
+
+class bz_split_explicit(C.Structure):
+    _fields_ = [("substeps", C.c_int32), ("damp_vertical", C.c_int32),
+                ("apply_first_substep_pressure_gradient", C.c_int32), ("newton_maxiter", C.c_int32),
+                ("acoustic_cfl", C.c_double), ("forward_weight", C.c_double), ("damping_coefficient", C.c_double),
+                ("thermodynamic_tendency_factor", C.c_double), ("vertical_momentum_tendency_factor", C.c_double),
+                ("newton_abstol", C.c_double)]
+
+
+class bz_exner_reference_state(C.Structure):
+    _fields_ = [("standard_pressure", C.c_double), ("pressure", _dp), ("density", _dp)]
+
+
 # every symbol include/breeze_hip.h declares: name -> (restype, argtypes)
 _ctx = C.c_void_p
 _sp, _pp = C.POINTER(bz_state), C.POINTER(bz_prognostic)
+_csp, _cpp, _asp = C.POINTER(bz_compressible_state), C.POINTER(bz_compressible_prognostic), C.POINTER(bz_acoustic_substepper)
 SYMBOLS = {
     "bz_create": (C.c_int, [C.POINTER(_ctx), C.POINTER(bz_grid), C.POINTER(bz_constants),
                             C.POINTER(bz_reference_state), C.c_int]),
@@ -80,6 +114,16 @@ SYMBOLS = {
     "bz_tendencies_fused_rk": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double, C.c_double, C.c_int]),
     "bz_poisson_source_term_from": (C.c_int, [_ctx, _sp, _pp, C.c_double, C.c_void_p]),
     "bz_project_and_diagnose_from": (C.c_int, [_ctx, _sp, _pp, C.c_void_p, C.c_void_p, C.c_double]),
+    "bz_create_compressible": (C.c_int, [C.POINTER(_ctx), C.POINTER(bz_grid), C.POINTER(bz_constants),
+                                         C.POINTER(bz_exner_reference_state), C.POINTER(bz_split_explicit), C.c_int]),
+    "bz_compressible_update_state": (C.c_int, [_ctx, _csp, _cpp, _asp, C.c_int]),
+    "bz_refresh_linearization": (C.c_int, [_ctx, _csp, _asp]),
+    "bz_seed_time_averaged_velocities": (C.c_int, [_ctx, _csp, _asp]),
+    "bz_compute_slow_tendencies": (C.c_int, [_ctx, _csp, _cpp]),
+    "bz_stage_substeps": (C.c_int, [_ctx, C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "bz_acoustic_substep_loop": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double]),
+    "bz_acoustic_rk3_substep": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double]),
+    "bz_time_step_compressible": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "bz_profile_reset": (C.c_int, [_ctx]),
     "bz_profile_count": (C.c_int, [_ctx]),

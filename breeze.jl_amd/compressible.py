@@ -1,0 +1,452 @@
+"""Host-side mirror of Breeze's compressible split-explicit API above the C ABI (include/breeze_hip.h):
+
+  CompressibleDynamics(time_discretization; ...)   src/CompressibleEquations/compressible_dynamics.jl:44-160
+  SplitExplicitTimeDiscretization(; ...)           src/CompressibleEquations/time_discretizations.jl:535-598
+  ThermalDivergenceDamping / NoDivergenceDamping   src/CompressibleEquations/time_discretizations.jl:142-262
+  ExnerReferenceState(grid, constants; ...)        src/Thermodynamics/reference_states.jl:588-672,717-815
+  AcousticSubstepper / AcousticRungeKutta3         src/CompressibleEquations/acoustic_substepping.jl:91-270,
+                                                   src/TimeSteppers/acoustic_runge_kutta_3.jl:64-103
+  set! / update_state! / time_step!                src/AtmosphereModels/set_atmosphere_model.jl:198-362,
+                                                   src/TimeSteppers/acoustic_runge_kutta_3.jl:230-319
+(paths relative to /root/reference; Julia's `f!` is spelled `f_`).  Every numerical operation of the time step is a
+HIP kernel behind libbreeze_hip.so; the numpy code here only builds the 1-D reference columns at construction.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .grids import Bounded, Center, Face, Periodic, RectilinearGrid  # noqa: F401
+from .model import WENO, Clock, Field, _LOC
+from .thermodynamics import ThermodynamicConstants, dry_air_gas_constant, vapor_gas_constant
+
+
+class NoDivergenceDamping:
+    pass
+
+
+class ThermalDivergenceDamping:
+    def __init__(self, coefficient=0.1, length_scale=None, damp_vertical=False):
+        if length_scale is not None:
+            raise NotImplementedError("ThermalDivergenceDamping(length_scale=...) is not implemented in the HIP path")
+        self.coefficient, self.length_scale, self.damp_vertical = float(coefficient), None, bool(damp_vertical)
+
+
+class ProportionalSubsteps:
+    pass
+
+
+class SplitExplicitTimeDiscretization:
+    def __init__(self, substeps=None, acoustic_cfl=0.5, forward_weight=0.65, thermodynamic_tendency_factor=1,
+                 vertical_momentum_tendency_factor=1, apply_first_substep_pressure_gradient=False, damping=None,
+                 sponge=None, substep_distribution=None):
+        damping = ThermalDivergenceDamping(coefficient=0.1) if damping is None else damping
+        if not isinstance(damping, (ThermalDivergenceDamping, NoDivergenceDamping)):
+            raise ValueError("`damping` must be an `AcousticDampingStrategy`")
+        if sponge is not None:
+            raise NotImplementedError("UpperSponge is not implemented in the HIP path")
+        if substep_distribution is not None and not isinstance(substep_distribution, ProportionalSubsteps):
+            raise NotImplementedError("only ProportionalSubsteps is implemented in the HIP path")
+        if not acoustic_cfl > 0:
+            raise ValueError(f"`acoustic_cfl` must be positive (got {acoustic_cfl})")
+        self.substeps = None if substeps is None else int(substeps)
+        self.acoustic_cfl = float(acoustic_cfl)
+        self.forward_weight = float(forward_weight)
+        self.thermodynamic_tendency_factor = float(thermodynamic_tendency_factor)
+        self.vertical_momentum_tendency_factor = float(vertical_momentum_tendency_factor)
+        self.apply_first_substep_pressure_gradient = bool(apply_first_substep_pressure_gradient)
+        self.damping = damping
+        self.sponge = None
+        self.substep_distribution = substep_distribution or ProportionalSubsteps()
+
+
+class NewtonSolver:
+    """Breeze.Solvers.NewtonSolver (src/Solvers.jl:55-83): reltol = 0 only."""
+
+    def __init__(self, abstol=1e-4, maxiter=8):
+        self.reltol, self.abstol, self.maxiter = 0.0, float(abstol), int(maxiter)
+
+
+def _z_metrics(grid):
+    """Δzᶜ (Nz) and Δzᶠ (centre spacing at faces 0..Nz; entries 1..Nz-1 interior) as Oceananigans defines them."""
+    Nz = grid.Nz
+    if grid.regular_z:
+        return np.full(Nz, grid.Δz), np.full(Nz + 1, grid.Δz)
+    dzc = np.diff(grid.zᶠ)
+    zc = grid.zᶜ
+    dzf = np.empty(Nz + 1)
+    dzf[1:Nz] = np.diff(zc)
+    dzf[0] = 2 * (zc[0] - grid.zᶠ[0])
+    dzf[Nz] = 2 * (grid.zᶠ[Nz] - zc[Nz - 1])
+    return dzc, dzf
+
+
+class ExnerReferenceState:
+    """Dry, 1-D, isentropic-mode ExnerReferenceState: the discrete hydrostatic balance
+    (p[k]-p[k-1])/Δzᶠ + g (ρ[k]+ρ[k-1])/2 = 0 holds to rounding at every interior face."""
+
+    def __init__(self, grid, constants=None, surface_pressure=101325, potential_temperature=288, standard_pressure=1e5,
+                 vapor_mass_fraction=None, reference_temperature=None):
+        if vapor_mass_fraction is not None or reference_temperature is not None:
+            raise NotImplementedError("moist / isothermal ExnerReferenceState modes are not implemented")
+        c = constants or ThermodynamicConstants()
+        self.constants = c
+        Nz, Hz = grid.Nz, grid.Hz
+        self.surface_pressure = p0 = float(surface_pressure)
+        self.standard_pressure = pst = float(standard_pressure)
+        θfun = potential_temperature if callable(potential_temperature) else (lambda z: float(potential_temperature) + 0.0 * z)
+        self.surface_potential_temperature = float(θfun(np.float64(0.0)))
+        Rd, cpd, g = dry_air_gas_constant(c), c.dry_air_heat_capacity, c.gravitational_acceleration
+        κ = Rd / cpd
+        dzc, dzf = _z_metrics(grid)
+        θ = np.asarray(θfun(grid.zᶜ), dtype=np.float64)
+        π, p, ρ = np.zeros(Nz), np.zeros(Nz), np.zeros(Nz)
+        π_surface = (p0 / pst) ** κ
+        π[0] = π_surface - g * dzc[0] / (2 * cpd * θ[0])
+        p[0] = pst * π[0] ** (1 / κ)
+        ρ[0] = p[0] / (Rd * θ[0] * π[0])
+        for k in range(1, Nz):
+            θface = (θ[k] + θ[k - 1]) / 2
+            pk = pst * (π[k - 1] - g * dzf[k] / (cpd * θface)) ** (1 / κ)
+            A = g * pst ** κ / (2 * Rd * θ[k])
+            Cc = p[k - 1] / dzf[k] - g * ρ[k - 1] / 2
+            for _ in range(5):                                   # FixedIterations(5) Newton on the discrete balance
+                ρp = pk ** (-κ)
+                f = pk / dzf[k] + A * pk * ρp - Cc
+                df = 1 / dzf[k] + A * (1 - κ) * ρp
+                pk -= f / df
+            p[k] = pk
+            π[k] = (pk / pst) ** κ
+            ρ[k] = pk / (Rd * θ[k] * π[k])
+        self.surface_density = ρ0 = p0 / (Rd * self.surface_potential_temperature * π_surface)
+
+        def with_halos(a, bottom_value=None):
+            out = np.zeros(Nz + 2 * Hz)
+            out[Hz:Hz + Nz] = a
+            out[Hz - 1] = a[0] if bottom_value is None else 2 * bottom_value - a[0]
+            out[Hz + Nz] = a[-1]
+            return out
+
+        self.pressure = with_halos(p, p0)
+        self.density = with_halos(ρ, ρ0)
+        self.exner_function = with_halos(π)
+        self.potential_temperature = with_halos(θ)
+        self.Nz, self.Hz = Nz, Hz
+
+
+class CompressibleDynamics:
+    def __init__(self, time_discretization=None, standard_pressure=1e5, surface_pressure=101325.0,
+                 reference_potential_temperature=None, reference_state="auto"):
+        if time_discretization is None or not isinstance(time_discretization, SplitExplicitTimeDiscretization):
+            raise NotImplementedError("the HIP path implements CompressibleDynamics(SplitExplicitTimeDiscretization(...)); "
+                                      "ExplicitTimeStepping is outside the hot-path scope")
+        if reference_state not in ("auto", ":auto", None):
+            raise ValueError(f"`reference_state` must be `:auto` or `nothing`; received {reference_state!r}.")
+        if reference_state is None and reference_potential_temperature is not None:
+            raise ValueError("`reference_state = nothing` disables the reference state and is mutually exclusive with an "
+                             "explicit reference profile")
+        self.time_discretization = time_discretization
+        self.standard_pressure = float(standard_pressure)
+        self.surface_pressure = float(surface_pressure)
+        self._reference_spec = None if reference_state is None else (
+            288.0 if reference_potential_temperature is None else reference_potential_temperature)
+        # materialised by the model
+        self.reference_state = None
+        self.dry_density = self.total_density = self.pressure = None
+
+
+class AcousticSubstepper:
+    """Storage of the acoustic substepper (acoustic_substepping.jl:91-134, 207-231)."""
+
+    FIELDS = (("exner", "ccc"), ("potential_temperature", "ccc"), ("gamma_R_mixture", "ccc"),
+              ("density_perturbation", "ccc"), ("density_potential_temperature_perturbation", "ccc"),
+              ("momentum_perturbation_u", "fcc"), ("momentum_perturbation_v", "cfc"), ("momentum_perturbation_w", "ccf"),
+              ("density_predictor", "ccc"), ("density_potential_temperature_predictor", "ccc"),
+              ("previous_density_potential_temperature_perturbation", "ccc"),
+              ("time_averaged_u", "fcc"), ("time_averaged_v", "cfc"), ("time_averaged_w", "ccf"),
+              ("slow_vertical_momentum_tendency", "ccf"), ("vertical_solver_source_term", "ccf"))
+
+    def __init__(self, grid, time_discretization, device):
+        td = time_discretization
+        self.substeps, self.acoustic_cfl, self.forward_weight = td.substeps, td.acoustic_cfl, td.forward_weight
+        self.damping = td.damping
+        for name, loc in self.FIELDS:
+            setattr(self, name, Field(grid, _LOC[loc], device))
+        self.linearization_exner = self.exner
+        self.linearization_potential_temperature = self.potential_temperature
+        self.linearization_gamma_R_mixture = self.gamma_R_mixture
+        self.time_averaged_velocities = {"u": self.time_averaged_u, "v": self.time_averaged_v, "w": self.time_averaged_w}
+        self.momentum_perturbation = {"u": self.momentum_perturbation_u, "v": self.momentum_perturbation_v,
+                                      "w": self.momentum_perturbation_w}
+
+    def struct(self):
+        s = _lib.bz_acoustic_substepper()
+        for name, _ in self.FIELDS:
+            setattr(s, name, getattr(self, name).ptr())
+        return s
+
+
+class AcousticRungeKutta3:
+    """Wicker-Skamarock RK3 with acoustic substepping: β = (1/3, 1/2, 1) (acoustic_runge_kutta_3.jl:64-103)."""
+
+    def __init__(self, grid, prognostic_fields, dynamics, device):
+        self.β1, self.β2, self.β3 = 1.0 / 3.0, 1.0 / 2.0, 1.0
+        self.U0 = {k: Field(grid, f.loc, device) for k, f in prognostic_fields.items()}
+        self.Gn = {k: Field(grid, f.loc, device) for k, f in prognostic_fields.items()}
+        self.substepper = AcousticSubstepper(grid, dynamics.time_discretization, device)
+
+
+_ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "θli": "θ", "ρ": "ρ", "rho": "ρ", "u": "u", "v": "v", "w": "w",
+            "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q"}
+
+
+class CompressibleAtmosphereModel:
+    """AtmosphereModel(grid; dynamics=CompressibleDynamics(SplitExplicitTimeDiscretization(...)), advection=WENO(order=5))
+    — timestepper :AcousticRungeKutta3, microphysics / closure / coriolis / forcing = nothing."""
+
+    def __init__(self, grid, dynamics, advection=None, thermodynamic_constants=None, temperature_solver=None,
+                 closure=None, coriolis=None, microphysics=None, forcing=None, device="cuda:0"):
+        import torch
+        if not isinstance(grid, RectilinearGrid):
+            raise TypeError("grid must be a RectilinearGrid")
+        if grid.topology != (Periodic, Periodic, Bounded):
+            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded)")
+        if not isinstance(dynamics, CompressibleDynamics):
+            raise TypeError("dynamics must be CompressibleDynamics")
+        for name, val in (("closure", closure), ("coriolis", coriolis), ("microphysics", microphysics), ("forcing", forcing)):
+            if val is not None:
+                raise NotImplementedError(f"{name} is outside the hot-path scope of this build")
+        if advection is None:
+            raise NotImplementedError("the HIP path requires advection=WENO(order=5)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("CompressibleAtmosphereModel needs a GPU: the HIP path has no CPU fallback")
+        self.grid, self.advection, self.dynamics = grid, advection, dynamics
+        self.thermodynamic_constants = c = thermodynamic_constants or ThermodynamicConstants()
+        self.temperature_solver = temperature_solver or NewtonSolver()
+        self.clock = Clock()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self._lib = lib = _lib.load()
+
+        def fld(loc):
+            return Field(grid, _LOC[loc], self.device)
+
+        dynamics.dry_density, dynamics.total_density, dynamics.pressure = fld("ccc"), fld("ccc"), fld("ccc")
+        self.momentum = {"ρu": fld("fcc"), "ρv": fld("cfc"), "ρw": fld("ccf")}
+        self.velocities = {"u": fld("fcc"), "v": fld("cfc"), "w": fld("ccf")}
+        self.potential_temperature_density, self.potential_temperature = fld("ccc"), fld("ccc")
+        self.moisture_density, self.specific_moisture, self.temperature = fld("ccc"), fld("ccc"), fld("ccc")
+        if dynamics._reference_spec is not None:
+            dynamics.reference_state = ExnerReferenceState(grid, c, surface_pressure=dynamics.surface_pressure,
+                                                           potential_temperature=dynamics._reference_spec,
+                                                           standard_pressure=dynamics.standard_pressure)
+        self.timestepper = AcousticRungeKutta3(grid, self.prognostic_fields(), dynamics, self.device)
+        self.U0, self.G = self.timestepper.U0, self.timestepper.Gn
+
+        # ---- context ----
+        self._zf = np.ascontiguousarray(grid.zᶠ, dtype=np.float64)
+        bg = _lib.bz_grid()
+        bg.Nx, bg.Ny, bg.Nz = grid.Nx, grid.Ny, grid.Nz
+        bg.Hx, bg.Hy, bg.Hz = grid.Hx, grid.Hy, grid.Hz
+        for d, t in enumerate(grid.topology_codes()):
+            bg.topo[d] = t
+        bg.ftype = 8
+        bg.dx, bg.dy = grid.Δx, grid.Δy
+        bg.zf = self._zf.ctypes.data_as(C.POINTER(C.c_double))
+        bg.regular_z = 1 if grid.regular_z else 0
+        bc = _lib.bz_constants(c.gravitational_acceleration, dry_air_gas_constant(c), vapor_gas_constant(c),
+                               c.dry_air_heat_capacity, c.vapor_heat_capacity)
+        ref = dynamics.reference_state
+        br = _lib.bz_exner_reference_state()
+        br.standard_pressure = dynamics.standard_pressure
+        self._ref_arrays = None
+        if ref is not None:
+            self._ref_arrays = [np.ascontiguousarray(a, dtype=np.float64) for a in (ref.pressure, ref.density)]
+            br.pressure, br.density = (a.ctypes.data_as(C.POINTER(C.c_double)) for a in self._ref_arrays)
+        td = dynamics.time_discretization
+        bt = _lib.bz_split_explicit()
+        bt.substeps = 0 if td.substeps is None else td.substeps
+        damp = td.damping
+        bt.damp_vertical = int(isinstance(damp, ThermalDivergenceDamping) and damp.damp_vertical)
+        bt.apply_first_substep_pressure_gradient = int(td.apply_first_substep_pressure_gradient)
+        bt.newton_maxiter = self.temperature_solver.maxiter
+        bt.acoustic_cfl, bt.forward_weight = td.acoustic_cfl, td.forward_weight
+        bt.damping_coefficient = damp.coefficient if isinstance(damp, ThermalDivergenceDamping) else -1.0
+        bt.thermodynamic_tendency_factor = td.thermodynamic_tendency_factor
+        bt.vertical_momentum_tendency_factor = td.vertical_momentum_tendency_factor
+        bt.newton_abstol = self.temperature_solver.abstol
+        self._ctx = C.c_void_p()
+        rc = lib.bz_create_compressible(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), C.byref(bt), advection.order)
+        if rc != 0:
+            raise _lib.BreezeHIPError(f"bz_create_compressible failed with code {rc}")
+        self._check(lib.bz_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "bz_set_stream")
+        self._state = self._make_state()
+        self._U0, self._G = self._make_prog(self.U0), self._make_prog(self.G)
+        self._sub = self.timestepper.substepper.struct()
+        # seed_pressure! (compressible_dynamics.jl:254-258)
+        if ref is not None:
+            Hz, Nz = grid.Hz, grid.Nz
+            dynamics.pressure.set_interior(ref.pressure[Hz:Hz + Nz][:, None, None])
+        else:
+            dynamics.pressure.set_interior(dynamics.surface_pressure)
+
+    def _check(self, rc, what):
+        _lib.check(self._lib, self._ctx, rc, what)
+
+    def prognostic_fields(self):
+        return {"ρᵈ": self.dynamics.dry_density, "ρu": self.momentum["ρu"], "ρv": self.momentum["ρv"],
+                "ρw": self.momentum["ρw"], "ρθ": self.potential_temperature_density, "ρq": self.moisture_density}
+
+    def _make_state(self):
+        s = _lib.bz_compressible_state()
+        d = self.dynamics
+        s.rho_d, s.rho, s.p = d.dry_density.ptr(), d.total_density.ptr(), d.pressure.ptr()
+        s.rho_u, s.rho_v, s.rho_w = (self.momentum[k].ptr() for k in ("ρu", "ρv", "ρw"))
+        s.rho_theta, s.rho_q = self.potential_temperature_density.ptr(), self.moisture_density.ptr()
+        s.u, s.v, s.w = (self.velocities[k].ptr() for k in ("u", "v", "w"))
+        s.theta, s.q, s.T = self.potential_temperature.ptr(), self.specific_moisture.ptr(), self.temperature.ptr()
+        return s
+
+    @staticmethod
+    def _make_prog(d):
+        p = _lib.bz_compressible_prognostic()
+        p.rho_d, p.rho_u, p.rho_v, p.rho_w, p.rho_theta, p.rho_q = (d[k].ptr() for k in ("ρᵈ", "ρu", "ρv", "ρw", "ρθ", "ρq"))
+        return p
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self._lib.bz_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def set(self, **kw):
+        return set_(self, **kw)
+
+    def time_step(self, Δt):
+        return time_step_(self, Δt)
+
+    def synchronize(self):
+        self._check(self._lib.bz_sync(self._ctx), "bz_sync")
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.bz_profile_enable(self._ctx, 1 if on else 0), "bz_profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.bz_profile_reset(self._ctx), "bz_profile_reset")
+
+    def profile(self):
+        out = {}
+        for i in range(self._lib.bz_profile_count(self._ctx)):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            self._check(self._lib.bz_profile_get(self._ctx, i, C.byref(name), C.byref(ms), C.byref(n)), "bz_profile_get")
+            out[name.value.decode()] = (ms.value, n.value)
+        return out
+
+    def stage_substeps(self, Δt, β):
+        n, dτ = C.c_int32(), C.c_double()
+        self._check(self._lib.bz_stage_substeps(self._ctx, float(Δt), float(β), C.byref(n), C.byref(dτ)), "bz_stage_substeps")
+        return n.value, dτ.value
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def update_state_(model, compute_tendencies=True):
+    model._check(model._lib.bz_compressible_update_state(model._ctx, C.byref(model._state), C.byref(model._G),
+                                                         C.byref(model._sub), 1 if compute_tendencies else 0),
+                 "bz_compressible_update_state")
+
+
+def refresh_linearization_(model):
+    model._check(model._lib.bz_refresh_linearization(model._ctx, C.byref(model._state), C.byref(model._sub)),
+                 "bz_refresh_linearization")
+
+
+def seed_time_averaged_velocities_(model):
+    model._check(model._lib.bz_seed_time_averaged_velocities(model._ctx, C.byref(model._state), C.byref(model._sub)),
+                 "bz_seed_time_averaged_velocities")
+
+
+def compute_slow_tendencies_(model):
+    model._check(model._lib.bz_compute_slow_tendencies(model._ctx, C.byref(model._state), C.byref(model._G)),
+                 "bz_compute_slow_tendencies")
+
+
+def acoustic_rk3_substep_loop_(model, Δt, β):
+    model._check(model._lib.bz_acoustic_substep_loop(model._ctx, C.byref(model._state), C.byref(model._U0), C.byref(model._G),
+                                                     C.byref(model._sub), float(Δt), float(β)), "bz_acoustic_substep_loop")
+
+
+def acoustic_rk3_substep_(model, Δt, β):
+    model._check(model._lib.bz_acoustic_rk3_substep(model._ctx, C.byref(model._state), C.byref(model._U0), C.byref(model._G),
+                                                    C.byref(model._sub), float(Δt), float(β)), "bz_acoustic_rk3_substep")
+
+
+def store_initial_state_(model):
+    for k, f in model.prognostic_fields().items():
+        model.U0[k].parent.copy_(f.parent)
+
+
+def set_(model, **kw):
+    """set!(model; ρ, θ, u, v, w, qᵗ): total density first, moisture, then establish_densities!, θ and velocities
+    (set_atmosphere_model.jl:198-362; compressible_time_stepping.jl:105-150)."""
+    d = model.dynamics
+    g = model.grid
+    keys = {}
+    for name, value in kw.items():
+        key = _ALIASES.get(name)
+        if key is None:
+            raise ValueError(f"Cannot set! {name} in AtmosphereModel because {name} is neither a prognostic variable, a "
+                             "settable thermodynamic variable, nor a settable diagnostic variable!")
+        keys[key] = value
+    ρd, ρ = d.dry_density, d.total_density
+    if "ρ" in keys:
+        ρd.set_interior(keys["ρ"])
+    if "q" in keys:
+        model.specific_moisture.set_interior(keys["q"])
+        model.moisture_density.interior.copy_(ρd.interior * model.specific_moisture.interior)
+    if "ρ" in keys:      # establish_densities!(total_density_given)
+        ρ.interior.copy_(ρd.interior)
+        ρd.interior.copy_(ρ.interior - (model.moisture_density.interior + 0.0))
+    from .model import fill_halo_regions_
+    fill_halo_regions_(model, ρd, 0)
+    if "θ" in keys:
+        model.potential_temperature.set_interior(keys["θ"])
+        model.potential_temperature_density.interior.copy_(ρd.interior * model.potential_temperature.interior)
+    P = ρd.parent
+    Hx, Hy, Hz, Nx, Ny, Nz = g.Hx, g.Hy, g.Hz, g.Nx, g.Ny, g.Nz
+    if "u" in keys:
+        model.velocities["u"].set_interior(keys["u"])
+        ρx = (ρd.interior + P[Hz:Hz + Nz, Hy:Hy + Ny, Hx - 1:Hx - 1 + Nx]) / 2
+        model.momentum["ρu"].interior.copy_(ρx * model.velocities["u"].interior)
+    if "v" in keys:
+        model.velocities["v"].set_interior(keys["v"])
+        ρy = (ρd.interior + P[Hz:Hz + Nz, Hy - 1:Hy - 1 + Ny, Hx:Hx + Nx]) / 2
+        model.momentum["ρv"].interior.copy_(ρy * model.velocities["v"].interior)
+    if "w" in keys:
+        model.velocities["w"].set_interior(keys["w"])
+        ρz = (P[Hz:Hz + Nz + 1, Hy:Hy + Ny, Hx:Hx + Nx] + P[Hz - 1:Hz + Nz, Hy:Hy + Ny, Hx:Hx + Nx]) / 2
+        model.momentum["ρw"].interior.copy_(ρz * model.velocities["w"].interior)
+    update_state_(model, compute_tendencies=False)
+
+
+def time_step_(model, Δt, whole_step=True):
+    """time_step!(model::CompressibleAcousticModel, Δt) (acoustic_runge_kutta_3.jl:264-319) without callbacks.
+    whole_step=True keeps the step behind one C call; False issues the operator sequence of the reference."""
+    Δt = float(Δt)
+    if model.clock.iteration == 0:                         # maybe_prepare_first_time_step!
+        seed_time_averaged_velocities_(model)
+        update_state_(model, compute_tendencies=True)
+    if whole_step:
+        model._check(model._lib.bz_time_step_compressible(model._ctx, C.byref(model._state), C.byref(model._U0),
+                                                          C.byref(model._G), C.byref(model._sub), Δt),
+                     "bz_time_step_compressible")
+    else:
+        store_initial_state_(model)
+        refresh_linearization_(model)                      # freeze_linearization_state!
+        seed_time_averaged_velocities_(model)
+        for β in (model.timestepper.β1, model.timestepper.β2, model.timestepper.β3):
+            acoustic_rk3_substep_(model, Δt, β)
+            update_state_(model, compute_tendencies=True)
+    model.clock.time += Δt
+    model.clock.iteration += 1

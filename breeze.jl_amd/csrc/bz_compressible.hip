@@ -1,0 +1,903 @@
+// bz_compressible.hip — CompressibleDynamics + SplitExplicitTimeDiscretization on gfx950:
+// the Wicker-Skamarock RK3 outer loop with the linearised acoustic substep loop.
+//
+//   time_step! / acoustic_rk3_substep!     /root/reference/src/TimeSteppers/acoustic_runge_kutta_3.jl:172-319
+//   compute_slow_*_tendencies!             /root/reference/src/TimeSteppers/acoustic_substep_helpers.jl:55-149
+//   acoustic_rk3_substep_loop! and kernels /root/reference/src/CompressibleEquations/acoustic_substepping.jl:318-1590
+//   update_state! (compressible)           /root/reference/src/AtmosphereModels/update_atmosphere_model_state.jl:41-68
+//                                          /root/reference/src/CompressibleEquations/compressible_time_stepping.jl:83-242
+//
+// Kernel structure of one acoustic substep (the reference launches 5 kernels + 8 halo fills per substep and moves
+// ~58 words/cell; here 3 kernels, no halo fills, ~39 words/cell):
+//   k_ac_horizontal        pointwise.  Klemp-2018 divergence damping of the PREVIOUS substep (it only needs the two
+//                          (rho theta)' levels that are still in memory) followed by the explicit horizontal step of
+//                          this substep; accumulates the time-averaged horizontal momentum.  Neighbours by periodic
+//                          wrap indexing, so the perturbation fields never need halos inside the loop.
+//   k_ac_column_forward    one thread per column marching upward: predictors rho'*, (rho theta)'* of cell k, right-hand
+//                          side of face k, forward elimination of the tridiagonal system with the coefficients built on
+//                          the fly from registers (the Thomas factors t_k are stored by the first substep of a stage and
+//                          reused: they depend only on the linearisation and d tau).
+//   k_ac_column_backward   one thread per column marching downward: back substitution for (rho w)', post-solve recovery
+//                          of rho', (rho theta)', accumulation of the time-averaged vertical momentum.
+// Stage prologue / epilogue are single pointwise kernels (k_ac_stage_init, k_ac_finalize, k_ac_recover) and the whole
+// update_state! is k_cmp_diagnose, which also writes every periodic halo image and z-halo copy of what it produces.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "bz_internal.h"
+
+// from bz_fused.hip
+__device__ __forceinline__ void cst_img(double *__restrict__ f, long long n, double v, long long ox, long long oy)
+{
+    f[n] = v;
+    if (ox) f[n + ox] = v;
+    if (oy) {
+        f[n + oy] = v;
+        if (ox) f[n + ox + oy] = v;
+    }
+}
+__device__ __forceinline__ void cst_img_only(double *__restrict__ f, long long n, double v, long long ox, long long oy)
+{
+    if (ox) f[n + ox] = v;
+    if (oy) {
+        f[n + oy] = v;
+        if (ox) f[n + ox + oy] = v;
+    }
+}
+
+struct WrapIdx {
+    long long im, ip, jm, jp;    // offsets to the periodic x / y neighbours of (i, j)
+    long long ox, oy;            // offsets of this cell's periodic halo images (0: none)
+};
+__device__ __forceinline__ WrapIdx wrap_of(const DevGrid &g, int i, int j)
+{
+    WrapIdx w;
+    w.im = (i > 0) ? -1 : g.Nx - 1;
+    w.ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx;
+    w.jm = (j > 0) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
+    w.jp = (j + 1 < g.Ny) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
+    w.ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
+    w.oy = (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// update_state!: total density, halos, velocities, theta, q, T (Newton), p   [+ linearisation when LIN]
+// ---------------------------------------------------------------------------------------------------------------------
+struct DiagFields {
+    double *rho_d, *rho, *ru, *rv, *rw, *rth, *rq;
+    double *u, *v, *w, *theta, *q, *T, *p;
+    double *Pi, *thL, *gR, *Clin;       // LIN
+};
+
+// FULL: everything; !FULL: halos of rho_d, rho_theta, momentum + velocities only (tail of acoustic_rk3_substep_loop!)
+template <bool FULL, bool LIN>
+__global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, double abstol, int maxiter)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long sz = g.Sxy;
+    const WrapIdx W = wrap_of(g, i, j);
+    const long long ox = W.ox, oy = W.oy;
+    const long long n = g.idx(i, j, k);
+    const bool bot = (k == 0), top = (k == g.Nz - 1);
+
+    const double rd = F.rho_d[n];
+    const double rdx = (rd + F.rho_d[n + W.im]) / 2.0;
+    const double rdy = (rd + F.rho_d[n + W.jm]) / 2.0;
+    const double ru = F.ru[n], rv = F.rv[n];
+    const double u = ru / rdx, v = rv / rdy;
+    const double rth = F.rth[n];
+    cst_img_only(F.rho_d, n, rd, ox, oy);
+    cst_img_only(F.ru, n, ru, ox, oy);
+    cst_img_only(F.rv, n, rv, ox, oy);
+    cst_img_only(F.rth, n, rth, ox, oy);
+    cst_img(F.u, n, u, ox, oy);
+    cst_img(F.v, n, v, ox, oy);
+    if (!bot) {
+        const double rw = F.rw[n];
+        const double rdz = (rd + F.rho_d[n - sz]) / 2.0;
+        cst_img_only(F.rw, n, rw, ox, oy);
+        cst_img(F.w, n, rw / rdz, ox, oy);
+    } else {
+        cst_img(F.rw, n, 0.0, ox, oy);      // impenetrable walls
+        cst_img(F.w, n, 0.0, ox, oy);
+    }
+    if (top) {
+        cst_img(F.rw, n + sz, 0.0, ox, oy);
+        cst_img(F.w, n + sz, 0.0, ox, oy);
+    }
+    double r = 0.0, q = 0.0, th = 0.0, T = 0.0, p = 0.0, rq = 0.0;
+    if (FULL) {
+        rq = F.rq[n];
+        r = rd + (rq + 0.0);
+        th = rth / rd;
+        q = rq / r;
+        const double qd = 1.0 - q;
+        const double Rm = qd * g.Rd + q * g.Rv;
+        const double cpm = qd * g.cpd + q * g.cpv;
+        const double kap = Rm / cpm;
+        const double gam = cpm / (cpm - Rm);
+        T = pow(th, gam) * pow(r * Rm / g.pst, gam - 1.0);
+        double dT = T;
+        for (int it = 0; it < maxiter && fabs(dT) > abstol; ++it) {
+            const double Phi = pow(r * Rm * T / g.pst, kap) * th;
+            dT = -(T - Phi) / (1.0 - kap * Phi / T);
+            T += dT;
+        }
+        p = r * Rm * T;
+        cst_img_only(F.rq, n, rq, ox, oy);
+        cst_img(F.rho, n, r, ox, oy);
+        cst_img(F.theta, n, th, ox, oy);
+        cst_img(F.q, n, q, ox, oy);
+        cst_img(F.T, n, T, ox, oy);
+        cst_img(F.p, n, p, ox, oy);
+        if (LIN) {
+            const double Pi = pow(p / g.pst, g.Rd / g.cpd);
+            const double thl = rth / ((rd == 0.0) ? 1.0 : rd);
+            const double gr = cpm * Rm / (cpm - Rm);
+            F.Pi[n] = Pi;
+            F.thL[n] = thl;
+            F.gR[n] = gr;
+            F.Clin[n] = gr * Pi;
+        }
+    }
+    if (bot || top) {     // first z-halo cell of the no-flux centre fields
+        const long long h = bot ? -sz : sz;
+        cst_img(F.rho_d, n + h, rd, ox, oy);
+        cst_img(F.ru, n + h, ru, ox, oy);
+        cst_img(F.rv, n + h, rv, ox, oy);
+        cst_img(F.rth, n + h, rth, ox, oy);
+        cst_img(F.u, n + h, u, ox, oy);
+        cst_img(F.v, n + h, v, ox, oy);
+        if (FULL) {
+            cst_img(F.rq, n + h, rq, ox, oy);
+            cst_img(F.rho, n + h, r, ox, oy);
+            cst_img(F.theta, n + h, th, ox, oy);
+            cst_img(F.q, n + h, q, ox, oy);
+            cst_img(F.T, n + h, T, ox, oy);
+            cst_img(F.p, n + h, p, ox, oy);
+        }
+    }
+}
+
+// refresh_linearization_basic_state! (acoustic_substepping.jl:318-399)
+__global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__restrict__ Pi, double *__restrict__ thL,
+                                                           double *__restrict__ gR, double *__restrict__ Clin,
+                                                           const double *__restrict__ p, const double *__restrict__ rho_d,
+                                                           const double *__restrict__ rth, const double *__restrict__ qv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k);
+    const double rd = rho_d[n];
+    const double q = qv[n];
+    const double qd = 1.0 - q;
+    const double Rm = qd * g.Rd + q * g.Rv;
+    const double cpm = qd * g.cpd + q * g.cpv;
+    const double P = pow(p[n] / g.pst, g.Rd / g.cpd);
+    const double gr = cpm * Rm / (cpm - Rm);
+    Pi[n] = P;
+    thL[n] = rth[n] / ((rd == 0.0) ? 1.0 : rd);
+    gR[n] = gr;
+    Clin[n] = gr * P;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// slow scalar tendencies: G_rho_theta = -div_rhoUc(theta) with the 3-D carrier density (src/Advection.jl:20-35) and,
+// when Grho != nullptr, G_rho_d = -div(momentum) (compressible_density_tendency.jl:52-55)
+// ---------------------------------------------------------------------------------------------------------------------
+#include "bz_weno.h"
+
+#define CTY 4
+__global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d(DevGrid g, double *__restrict__ Gc, double *__restrict__ Grho,
+                                                                   const double *__restrict__ rho, const double *__restrict__ u,
+                                                                   const double *__restrict__ v, const double *__restrict__ w,
+                                                                   const double *__restrict__ c, const double *__restrict__ ru,
+                                                                   const double *__restrict__ rv, const double *__restrict__ rw,
+                                                                   int kchunk)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * CTY + threadIdx.y;
+    if (i >= g.Nx || j >= g.Ny) return;
+    const int k0 = blockIdx.z * kchunk;
+    const int k1 = min(k0 + kchunk, g.Nz);
+    const long long sy = g.Sx, sz = g.Sxy;
+    long long n = g.idx(i, j, k0);
+
+    double zm3 = c[n - 3 * sz], zm2 = c[n - 2 * sz], zm1 = c[n - sz], z0 = c[n], zp1 = c[n + sz], zp2 = c[n + 2 * sz];
+    double r_lo = rho[n - sz], r0 = rho[n];
+    double Fz_lo;
+    {
+        const double wt = w[n];
+        const double cR = bz_upB(zm3, zm2, zm1, z0, zp1, zp2, wt > 0.0, bz_buffer_face(k0, g.Nz));
+        Fz_lo = ((r0 + r_lo) / 2.0) * ((g.Az * wt) * cR);
+    }
+    for (int k = k0; k < k1; ++k, n += sz) {
+        const double zp3 = c[n + 3 * sz];
+        const double r_hi = rho[n + sz];
+        double Fz_hi;
+        {
+            const double wt = w[n + sz];
+            const double cR = bz_upB(zm2, zm1, z0, zp1, zp2, zp3, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
+            Fz_hi = ((r_hi + r0) / 2.0) * ((g.Az * wt) * cR);
+        }
+        const double Ax = g.Ax[k], Ay = g.Ay[k];
+        const double xm3 = c[n - 3], xm2 = c[n - 2], xm1 = c[n - 1], xp1 = c[n + 1], xp2 = c[n + 2], xp3 = c[n + 3];
+        const double u0 = u[n], u1 = u[n + 1];
+        const double Fx_lo = ((r0 + rho[n - 1]) / 2.0) * ((Ax * u0) * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, u0 > 0.0));
+        const double Fx_hi = ((rho[n + 1] + r0) / 2.0) * ((Ax * u1) * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, u1 > 0.0));
+        const double ym3 = c[n - 3 * sy], ym2 = c[n - 2 * sy], ym1 = c[n - sy], yp1 = c[n + sy], yp2 = c[n + 2 * sy], yp3 = c[n + 3 * sy];
+        const double v0 = v[n], v1 = v[n + sy];
+        const double Fy_lo = ((r0 + rho[n - sy]) / 2.0) * ((Ay * v0) * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0));
+        const double Fy_hi = ((rho[n + sy] + r0) / 2.0) * ((Ay * v1) * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, v1 > 0.0));
+        Gc[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
+        if (Grho) {
+            const double a = Ax * ru[n + 1] - Ax * ru[n];
+            const double b = Ay * rv[n + sy] - Ay * rv[n];
+            const double cc = g.Az * rw[n + sz] - g.Az * rw[n];
+            Grho[n] = -(g.Vinv_c[k] * (a + b + cc));
+        }
+        zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
+        Fz_lo = Fz_hi;
+        r_lo = r0; r0 = r_hi;
+    }
+}
+
+static int pick_kchunk_c(const DevGrid &g, int nlev)
+{
+    long long tiles = (long long)((g.Nx + 63) / 64) * ((g.Ny + CTY - 1) / CTY);
+    long long want = (4096 + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    long long maxchunks = nlev / 8 > 0 ? nlev / 8 : 1;
+    if (want > maxchunks) want = maxchunks;
+    return (int)((nlev + want - 1) / want);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// acoustic stage kernels
+// ---------------------------------------------------------------------------------------------------------------------
+struct AcParams {
+    double dtau, dtn, dto;        // substep size, omega*dtau, (1-omega)*dtau
+    double d_new, d_old;          // implicit vertical damping prefactors (0 unless damp_vertical)
+    double f_theta, f_w;          // thermodynamic / vertical-momentum tendency factors
+    double gate;                  // 1: perturbation horizontal PGF applied this substep, 0: skipped (first small step)
+    double kdamp;                 // alpha * min(dx,dy)^2 / dtau   (0: no damping)
+    double inv_N;                 // 1 / N_tau
+};
+
+struct AcFields {
+    // model state (stage-entry U^L; untouched by the loop)
+    double *rho_d, *rth, *ru, *rv, *rw, *rq;
+    const double *rho, *p;
+    // outer-step start and slow tendencies
+    const double *U0_rho_d, *U0_rth, *U0_ru, *U0_rv, *U0_rw, *U0_rq;
+    const double *G_rho_d, *G_rth, *G_ru, *G_rv, *G_rw, *G_rq;
+    // substepper
+    const double *thL, *Clin;
+    double *rp, *rthp, *rup, *rvp, *rwp;
+    double *rs, *rths, *rth_old;
+    double *au, *av, *aw;
+    double *Gs, *phi;             // slow vertical momentum tendency; forward-eliminated right-hand side
+    double *tfac;                 // Thomas factors t_k
+};
+
+// assemble_slow_vertical_momentum_tendency! + initialize_stage_perturbations! (acoustic_substepping.jl:727-752,793-838)
+__global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFields F)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long sz = g.Sxy;
+    const long long n = g.idx(i, j, k);
+    F.rp[n] = F.U0_rho_d[n] - F.rho_d[n];
+    F.rthp[n] = F.U0_rth[n] - F.rth[n];
+    F.rup[n] = F.U0_ru[n] - F.ru[n];
+    F.rvp[n] = F.U0_rv[n] - F.rv[n];
+    F.rwp[n] = F.U0_rw[n] - F.rw[n];
+    F.au[n] = 0.0;
+    F.av[n] = 0.0;
+    F.aw[n] = 0.0;
+    if (k == 0) {
+        F.Gs[n] = 0.0;
+    } else {
+        const long long m = n - sz;
+        const double dp = ((F.p[n] - g.p_r[k]) - (F.p[m] - g.p_r[k - 1])) * g.rdzf[k];
+        const double rf = ((F.rho[n] - g.rho[k]) + (F.rho[m] - g.rho[k - 1])) / 2.0;
+        F.Gs[n] = F.G_rw[n] - dp - g.g * rf;
+    }
+    if (k == g.Nz - 1) {
+        F.rwp[n + sz] = F.U0_rw[n + sz] - F.rw[n + sz];
+        F.Gs[n + sz] = 0.0;
+    }
+}
+
+// Klemp-Skamarock-Ha damping of the previous substep (acoustic_substepping.jl:1123-1139) followed by the explicit
+// horizontal step of this substep (:860-881) and the time-average accumulation (:999-1000).
+template <bool DAMP, bool STEP>
+__global__ __launch_bounds__(256) void k_ac_horizontal(DevGrid g, AcFields F, AcParams P)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const WrapIdx W = wrap_of(g, i, j);
+    const long long n = g.idx(i, j, k), mx = n + W.im, my = n + W.jm;
+    double up = F.rup[n], vp = F.rvp[n];
+    const double rt = F.rthp[n], rtx = F.rthp[mx], rty = F.rthp[my];
+    if (DAMP) {
+        const double d0 = rt - F.rth_old[n];
+        const double ddx = (d0 - (rtx - F.rth_old[mx])) * g.rdx;
+        const double ddy = (d0 - (rty - F.rth_old[my])) * g.rdy;
+        const double th = F.thL[n];
+        up -= P.kdamp * ddx / ((th + F.thL[mx]) / 2.0);
+        vp -= P.kdamp * ddy / ((th + F.thL[my]) / 2.0);
+    }
+    if (STEP) {
+        const double p0 = F.p[n];
+        double dpx = (p0 - F.p[mx]) * g.rdx;
+        double dpy = (p0 - F.p[my]) * g.rdy;
+        if (P.gate != 0.0) {
+            const double c0 = F.Clin[n] * rt;
+            dpx = dpx + P.gate * ((c0 - F.Clin[mx] * rtx) * g.rdx);
+            dpy = dpy + P.gate * ((c0 - F.Clin[my] * rty) * g.rdy);
+        }
+        up += P.dtau * (F.G_ru[n] - dpx);
+        vp += P.dtau * (F.G_rv[n] - dpy);
+        F.au[n] += up;
+        F.av[n] += vp;
+    }
+    F.rup[n] = up;
+    F.rvp[n] = vp;
+}
+
+// boundary-aware centre->face interpolation of theta^L (acoustic_substepping.jl:539-550) from the two cell values
+__device__ __forceinline__ double ibz(double fp, double fm, bool p_per, bool m_per)
+{
+    fp = p_per ? fm : fp;
+    fm = m_per ? fp : fm;
+    return (fp + fm) / 2.0;
+}
+
+#define ACY 4
+// _build_predictors! + _build_vertical_rhs! + forward sweep of the BatchedTridiagonalSolver
+// (acoustic_substepping.jl:605-659,907-970)
+template <bool FIRST>
+__global__ __launch_bounds__(64 * ACY) void k_ac_column_forward(DevGrid g, AcFields F, AcParams P)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * ACY + threadIdx.y;
+    if (i >= g.Nx || j >= g.Ny) return;
+    const WrapIdx W = wrap_of(g, i, j);
+    const long long sz = g.Sxy;
+    const int Nz = g.Nz;
+    long long n = g.idx(i, j, 0);
+    const double dtn2 = P.dtn * P.dtn;
+
+    // rings: theta^L at k, k+1 (own column) and at faces k-1, k; C at k-1, k; old (rho w)' at faces k-1, k, k+1
+    double th_0 = F.thL[n], th_p = F.thL[n + sz];
+    double C_m = 0.0, C_0 = F.Clin[n];
+    double w_m = 0.0, w_0 = F.rwp[n], w_p = F.rwp[n + sz];
+    double rs_m = 0.0, rths_m = 0.0, rp_m = 0.0, rthp_m = 0.0;
+    double beta = 1.0, phi_m = 0.0, c_m = 0.0;     // row 0: b = 1, c = 0, f = 0
+    double thf_0 = th_0, thf_m = th_0;               // theta at faces k (k = 0: one-sided) and k-1
+
+    for (int k = 0; k < Nz; ++k, n += sz) {
+        const double rdc = g.rdzc[k];
+        const double Ax = g.Ax[k], Ay = g.Ay[k], Vinv = g.Vinv_c[k];
+        const double rp = F.rp[n], rthp = F.rthp[n];
+        const double up0 = F.rup[n], up1 = F.rup[n + W.ip], vp0 = F.rvp[n], vp1 = F.rvp[n + W.jp];
+        const double thxm = F.thL[n + W.im], thxp = F.thL[n + W.ip], thym = F.thL[n + W.jm], thyp = F.thL[n + W.jp];
+        // theta face k+1 (top face: one-sided)
+        const double thf_p = (k + 1 < Nz) ? (th_p + th_0) / 2.0 : th_0;
+
+        F.rth_old[n] = rthp;
+        const double dxM = Ax * up1 - Ax * up0;
+        const double dxT = Ax * ((thxp + th_0) / 2.0) * up1 - Ax * ((th_0 + thxm) / 2.0) * up0;
+        const double dyM = Ay * vp1 - Ay * vp0;
+        const double dyT = Ay * ((thyp + th_0) / 2.0) * vp1 - Ay * ((th_0 + thym) / 2.0) * vp0;
+        const double divM = Vinv * (dxM + dyM);
+        const double divT = Vinv * (dxT + dyT);
+        const double dzW = (w_p - w_0) * rdc;
+        const double dzT = (thf_p * w_p - thf_0 * w_0) * rdc;
+        const double rs = rp + P.dtau * (F.G_rho_d[n] - divM) - P.dto * dzW;
+        const double rths = rthp + P.dtau * (P.f_theta * F.G_rth[n] - divT) - P.dto * dzT;
+        F.rs[n] = rs;
+        F.rths[n] = rths;
+
+        double phi = 0.0;
+        if (k > 0) {
+            const double rdf = g.rdzf[k], rdm = g.rdzc[k - 1];
+            // right-hand side at face k
+            const double dps = (C_0 * rths - C_m * rths_m) * rdf;
+            const double dpo = (C_0 * rthp - C_m * rthp_m) * rdf;
+            const double Gp = P.dto * dpo + P.dtn * dps;
+            const double Gb = g.g * (P.dto * ((rp + rp_m) / 2.0) + P.dtn * ((rs + rs_m) / 2.0));
+            const double d2 = ((w_p - w_0) * rdc - (w_0 - w_m) * rdm) * rdf;
+            const double Gd = -P.d_old * d2;
+            const double f = w_0 + P.dtau * P.f_w * F.Gs[n] - Gp - Gb - Gd - 0.0;
+            // coefficients of row k
+            const double a = -dtn2 * C_m * thf_m * rdm * rdf + dtn2 * g.g * rdm / 2.0 + (-P.d_new * rdm * rdf);
+            const double b = 1.0 + (dtn2 * thf_0 * (C_0 * rdc + C_m * rdm) * rdf + dtn2 * g.g * (rdc - rdm) / 2.0 +
+                                    P.d_new * (rdc + rdm) * rdf + 0.0);
+            const double t = c_m / beta;
+            beta = b - a * t;
+            phi = (f - a * phi_m) / beta;
+            if (FIRST) F.tfac[n] = t;
+            // upper coefficient of this row, used by the next one
+            c_m = -dtn2 * C_0 * thf_p * rdc * rdf + (-dtn2 * g.g * rdc / 2.0) + (-P.d_new * rdc * rdf);
+        } else if (FIRST) {
+            F.tfac[n] = 0.0;
+        }
+        F.phi[n] = phi;
+        phi_m = phi;
+
+        // advance the rings
+        rs_m = rs; rths_m = rths; rp_m = rp; rthp_m = rthp;
+        C_m = C_0;
+        th_0 = th_p; thf_m = thf_0; thf_0 = thf_p;
+        w_m = w_0; w_0 = w_p;
+        if (k + 1 < Nz) {
+            C_0 = F.Clin[n + sz];
+            th_p = (k + 2 < Nz) ? F.thL[n + 2 * sz] : th_0;
+            w_p = F.rwp[n + 2 * sz];
+        }
+    }
+}
+
+// back substitution + _post_solve_recovery! (acoustic_substepping.jl:993-1002)
+__global__ __launch_bounds__(64 * ACY) void k_ac_column_backward(DevGrid g, AcFields F, AcParams P)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * ACY + threadIdx.y;
+    if (i >= g.Nx || j >= g.Ny) return;
+    const long long sz = g.Sxy;
+    const int Nz = g.Nz;
+    long long n = g.idx(i, j, Nz - 1);
+    double w_hi = F.rwp[n + sz];                 // top face: held at its (zero) rewind value
+    double th_0 = F.thL[n];                      // theta at cell k
+    double thf_hi = th_0;                        // face Nz: one-sided
+    double t_hi = 0.0;                           // t_{k+1}
+    for (int k = Nz - 1; k >= 0; --k, n -= sz) {
+        const double th_m = (k > 0) ? F.thL[n - sz] : th_0;
+        const double thf_lo = (k > 0) ? (th_0 + th_m) / 2.0 : th_0;
+        double w_lo = F.phi[n];
+        if (k < Nz - 1) w_lo -= t_hi * w_hi;
+        const double rdc = g.rdzc[k];
+        const double dzW = (w_hi - w_lo) * rdc;
+        const double dzT = (thf_hi * w_hi - thf_lo * w_lo) * rdc;
+        F.rp[n] = F.rs[n] - P.dtn * dzW;
+        F.rthp[n] = F.rths[n] - P.dtn * dzT;
+        F.rwp[n] = w_lo;
+        F.aw[n] += w_lo;
+        t_hi = F.tfac[n];
+        w_hi = w_lo;
+        thf_hi = thf_lo;
+        th_0 = th_m;
+    }
+}
+
+// last substep's damping + _finalize_time_averaged_velocity! (acoustic_substepping.jl:1225-1250); writes the periodic
+// halo images and z-halo copies of the averaged velocities (they feed WENO stencils of the moisture tendency).
+template <bool DAMP>
+__global__ __launch_bounds__(256) void k_ac_finalize(DevGrid g, AcFields F, AcParams P)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const WrapIdx W = wrap_of(g, i, j);
+    const long long sz = g.Sxy;
+    const long long n = g.idx(i, j, k), mx = n + W.im, my = n + W.jm;
+    if (DAMP) {
+        const double d0 = F.rthp[n] - F.rth_old[n];
+        const double ddx = (d0 - (F.rthp[mx] - F.rth_old[mx])) * g.rdx;
+        const double ddy = (d0 - (F.rthp[my] - F.rth_old[my])) * g.rdy;
+        const double th = F.thL[n];
+        F.rup[n] -= P.kdamp * ddx / ((th + F.thL[mx]) / 2.0);
+        F.rvp[n] -= P.kdamp * ddy / ((th + F.thL[my]) / 2.0);
+    }
+    const double r0 = F.rho_d[n];
+    double rx = (r0 + F.rho_d[mx]) / 2.0, ry = (r0 + F.rho_d[my]) / 2.0;
+    rx = (rx == 0.0) ? 1.0 : rx;
+    ry = (ry == 0.0) ? 1.0 : ry;
+    const double ua = (F.ru[n] + F.au[n] * P.inv_N) / rx;
+    const double va = (F.rv[n] + F.av[n] * P.inv_N) / ry;
+    cst_img(F.au, n, ua, W.ox, W.oy);
+    cst_img(F.av, n, va, W.ox, W.oy);
+    double wa = 0.0;
+    if (k > 0) {
+        double rz = (r0 + F.rho_d[n - sz]) / 2.0;
+        rz = (rz == 0.0) ? 1.0 : rz;
+        wa = (F.rw[n] + F.aw[n] * P.inv_N) / rz;
+    }
+    cst_img(F.aw, n, wa, W.ox, W.oy);
+    if (k == 0 || k == g.Nz - 1) {
+        const long long h = (k == 0) ? -sz : sz;
+        cst_img(F.au, n + h, ua, W.ox, W.oy);
+        cst_img(F.av, n + h, va, W.ox, W.oy);
+        if (k == g.Nz - 1) cst_img(F.aw, n + sz, 0.0, W.ox, W.oy);
+    }
+}
+
+// _recover_full_state! (acoustic_substepping.jl:1274-1292) [+ WS-RK3 update of the moisture density,
+// acoustic_runge_kutta_3.jl:189-192, when dt_stage_q != 0 pointer-wise]
+template <bool MOIST>
+__global__ __launch_bounds__(256) void k_ac_recover(DevGrid g, AcFields F, double dt_stage)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)g.Ny * g.Sx) return;
+    const int k = blockIdx.y;
+    const long long n = g.Sxy * (k + g.Hz) + (long long)g.Hy * g.Sx + t;
+    F.rho_d[n] = F.rho_d[n] + F.rp[n];
+    F.rth[n] = F.rth[n] + F.rthp[n];
+    F.ru[n] = F.ru[n] + F.rup[n];
+    F.rv[n] = F.rv[n] + F.rvp[n];
+    F.rw[n] = F.rw[n] + F.rwp[n];
+    if (MOIST) F.rq[n] = F.U0_rq[n] + dt_stage * F.G_rq[n];
+}
+
+__global__ __launch_bounds__(256) void k_ws_rk3_scalar(DevGrid g, double *__restrict__ u, const double *__restrict__ u0,
+                                                       const double *__restrict__ G, double dt_stage)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)g.Ny * g.Sx) return;
+    const int k = blockIdx.y;
+    const long long n = g.Sxy * (k + g.Hz) + (long long)g.Hy * g.Sx + t;
+    u[n] = u0[n] + dt_stage * G[n];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static bool valid_state(const bz_compressible_state *s)
+{
+    return s && s->rho_d && s->rho && s->rho_u && s->rho_v && s->rho_w && s->rho_theta && s->rho_q && s->u && s->v &&
+           s->w && s->theta && s->q && s->T && s->p;
+}
+static bool valid_prog(const bz_compressible_prognostic *P)
+{
+    return P && P->rho_d && P->rho_u && P->rho_v && P->rho_w && P->rho_theta && P->rho_q;
+}
+static bool valid_sub(const bz_acoustic_substepper *a)
+{
+    return a && a->exner && a->potential_temperature && a->gamma_R_mixture && a->density_perturbation &&
+           a->density_potential_temperature_perturbation && a->momentum_perturbation_u && a->momentum_perturbation_v &&
+           a->momentum_perturbation_w && a->density_predictor && a->density_potential_temperature_predictor &&
+           a->previous_density_potential_temperature_perturbation && a->time_averaged_u && a->time_averaged_v &&
+           a->time_averaged_w && a->slow_vertical_momentum_tendency && a->vertical_solver_source_term;
+}
+#define BZ_REQUIRE_COMPRESSIBLE()                                                      \
+    do {                                                                               \
+        if (!ctx) return BZ_ERR_INVALID;                                               \
+        if (!ctx->compressible) {                                                      \
+            ctx->last_error = "context was not created by bz_create_compressible";    \
+            return BZ_ERR_INVALID;                                                     \
+        }                                                                              \
+    } while (0)
+
+extern "C" int bz_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
+                                      const bz_exner_reference_state *ref, const bz_split_explicit *td, int weno_order)
+{
+    if (!out || !grid || !constants || !ref || !td) return BZ_ERR_INVALID;
+    if ((ref->pressure == nullptr) != (ref->density == nullptr)) return BZ_ERR_INVALID;
+    if (td->substeps < 0 || !(td->acoustic_cfl > 0.0) || td->newton_maxiter < 0) return BZ_ERR_INVALID;
+    const int nc = grid->Nz + 2 * grid->Hz;
+    std::vector<double> zeros((size_t)nc, 0.0);
+    bz_reference_state r;
+    r.surface_pressure = 0.0;
+    r.potential_temperature = 0.0;
+    r.standard_pressure = ref->standard_pressure;
+    r.density = ref->density ? ref->density : zeros.data();
+    r.pressure = ref->pressure ? ref->pressure : zeros.data();
+    r.temperature = zeros.data();
+    int rc = bzi_create(out, grid, constants, &r, weno_order, 1, 0, false, true);
+    if (rc != BZ_OK) return rc;
+    bz_ctx *ctx = *out;
+    ctx->se = *td;
+    ctx->has_reference = ref->density != nullptr;
+    const size_t ncell = (size_t)ctx->dg.Sxy * (size_t)nc;
+    if (hipMalloc(&ctx->d_Clin, ncell * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->d_tfac_ac, ncell * sizeof(double)) != hipSuccess) {
+        bz_destroy(ctx);
+        *out = nullptr;
+        return BZ_ERR_ALLOC;
+    }
+    hipMemset(ctx->d_Clin, 0, ncell * sizeof(double));
+    hipMemset(ctx->d_tfac_ac, 0, ncell * sizeof(double));
+    return BZ_OK;
+}
+
+void bzi_compressible_teardown(bz_ctx *ctx)
+{
+    if (ctx->d_Clin) hipFree(ctx->d_Clin);
+    if (ctx->d_tfac_ac) hipFree(ctx->d_tfac_ac);
+    ctx->d_Clin = ctx->d_tfac_ac = nullptr;
+}
+
+static DiagFields diag_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_acoustic_substepper *sub)
+{
+    DiagFields F;
+    F.rho_d = s->rho_d; F.rho = s->rho; F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w; F.rth = s->rho_theta; F.rq = s->rho_q;
+    F.u = s->u; F.v = s->v; F.w = s->w; F.theta = s->theta; F.q = s->q; F.T = s->T; F.p = s->p;
+    F.Pi = sub ? sub->exner : nullptr;
+    F.thL = sub ? sub->potential_temperature : nullptr;
+    F.gR = sub ? sub->gamma_R_mixture : nullptr;
+    F.Clin = ctx->d_Clin;
+    return F;
+}
+
+static int launch_scalar_rho3d(bz_ctx *ctx, const char *name, double *Gc, double *Grho, const double *rho, const double *u,
+                               const double *v, const double *w, const double *c, const double *ru, const double *rv,
+                               const double *rw)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, name);
+    const int kc = pick_kchunk_c(g, g.Nz);
+    dim3 block(64, CTY), grid((g.Nx + 63) / 64, (g.Ny + CTY - 1) / CTY, (g.Nz + kc - 1) / kc);
+    hipLaunchKernelGGL(k_scalar_tendency_rho3d, grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw, kc);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// update_state! with the linearisation refresh of the next stage optionally folded in
+static int bzi_compressible_update_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                         const bz_acoustic_substepper *sub, bool compute_tendencies, bool with_linearization)
+{
+    const DevGrid &g = ctx->dg;
+    {
+        ProfileScope ps(ctx, with_linearization ? "update_state+linearization" : "update_state");
+        DiagFields F = diag_fields(ctx, s, sub);
+        dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+        if (with_linearization)
+            hipLaunchKernelGGL((k_cmp_diagnose<true, true>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
+        else
+            hipLaunchKernelGGL((k_cmp_diagnose<true, false>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
+        BZ_LAUNCH_CHECK();
+    }
+    if (compute_tendencies)
+        return launch_scalar_rho3d(ctx, "moisture_tendency", G->rho_q, nullptr, s->rho, sub->time_averaged_u, sub->time_averaged_v,
+                                   sub->time_averaged_w, s->q, nullptr, nullptr, nullptr);
+    return BZ_OK;
+}
+
+extern "C" int bz_compressible_update_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                            const bz_acoustic_substepper *sub, int compute_tendencies)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    if (!valid_state(s)) return BZ_ERR_INVALID;
+    if (compute_tendencies && (!valid_prog(G) || !valid_sub(sub))) return BZ_ERR_INVALID;
+    if (!ctx->fused_ok) { ctx->last_error = "compressible path needs Nx >= 2Hx and Ny >= 2Hy"; return BZ_ERR_UNSUPPORTED; }
+    return bzi_compressible_update_state(ctx, s, G, sub, compute_tendencies != 0, false);
+}
+
+extern "C" int bz_refresh_linearization(bz_ctx *ctx, const bz_compressible_state *s, const bz_acoustic_substepper *sub)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    if (!valid_state(s) || !valid_sub(sub)) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "refresh_linearization");
+    dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+    hipLaunchKernelGGL(k_cmp_linearization, grid, block, 0, ctx->stream, g, sub->exner, sub->potential_temperature,
+                       sub->gamma_R_mixture, ctx->d_Clin, s->p, s->rho_d, s->rho_theta, s->q);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+extern "C" int bz_seed_time_averaged_velocities(bz_ctx *ctx, const bz_compressible_state *s, const bz_acoustic_substepper *sub)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    if (!valid_state(s) || !valid_sub(sub)) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    const size_t nc = (size_t)g.Sxy * (size_t)(g.Nz + 2 * g.Hz) * sizeof(double);
+    const size_t nf = (size_t)g.Sxy * (size_t)(g.Nz + 1 + 2 * g.Hz) * sizeof(double);
+    BZ_HIP(hipMemcpyAsync(sub->time_averaged_u, s->u, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    BZ_HIP(hipMemcpyAsync(sub->time_averaged_v, s->v, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    BZ_HIP(hipMemcpyAsync(sub->time_averaged_w, s->w, nf, hipMemcpyDeviceToDevice, ctx->stream));
+    return BZ_OK;
+}
+
+extern "C" int bz_compute_slow_tendencies(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    if (!valid_state(s) || !valid_prog(G)) return BZ_ERR_INVALID;
+    bz_state a;
+    std::memset(&a, 0, sizeof(a));
+    a.rho_u = s->rho_u; a.rho_v = s->rho_v; a.rho_w = s->rho_w;
+    a.u = s->u; a.v = s->v; a.w = s->w; a.T = s->p; a.q = s->rho;
+    a.rho_theta = s->rho_theta; a.rho_q = s->rho_q; a.theta = s->theta;
+    bz_prognostic Ga;
+    Ga.rho_u = G->rho_u; Ga.rho_v = G->rho_v; Ga.rho_w = G->rho_w; Ga.rho_theta = G->rho_theta; Ga.rho_q = G->rho_q;
+    int rc = bzi_u_tendency_lds(ctx, &a, &Ga);
+    if (rc) return rc;
+    rc = bzi_v_tendency_lds(ctx, &a, &Ga);
+    if (rc) return rc;
+    rc = bzi_w_tendency_ring(ctx, &a, &Ga, nullptr, nullptr, 1);
+    if (rc) return rc;
+    return launch_scalar_rho3d(ctx, "density+potential_temperature_tendency", G->rho_theta, G->rho_d, s->rho_d, s->u, s->v,
+                               s->w, s->theta, s->rho_u, s->rho_v, s->rho_w);
+}
+
+// compute_acoustic_substeps / stage_substep_count_and_size(::ProportionalSubsteps) (acoustic_substepping.jl:451-495)
+static int acoustic_substeps_for(const bz_ctx *ctx, double dt)
+{
+    const double Rd = ctx->constants.dry_air_gas_constant, cpd = ctx->constants.dry_air_heat_capacity;
+    const double gam = cpd / (cpd - Rd);
+    const double cs = std::sqrt(gam * Rd * 300.0);
+    const double dmin = std::fmin(ctx->dg.dx, ctx->dg.dy);
+    const double n = std::ceil(std::fabs(dt) * cs / (ctx->se.acoustic_cfl * dmin));
+    return (int)std::fmax(1.0, n);
+}
+
+extern "C" int bz_stage_substeps(bz_ctx *ctx, double dt, double beta, int32_t *n_substeps, double *dtau)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    const double dt_stage = beta * dt;
+    int n;
+    if (ctx->se.substeps > 0) n = (int)std::fmax(1.0, std::ceil(beta * (double)ctx->se.substeps));
+    else n = acoustic_substeps_for(ctx, dt_stage);
+    if (n_substeps) *n_substeps = n;
+    if (dtau) *dtau = dt_stage / (double)n;
+    return BZ_OK;
+}
+
+static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                          const bz_compressible_prognostic *G, const bz_acoustic_substepper *a)
+{
+    AcFields F;
+    F.rho_d = s->rho_d; F.rth = s->rho_theta; F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w; F.rq = s->rho_q;
+    F.rho = s->rho; F.p = s->p;
+    F.U0_rho_d = U0->rho_d; F.U0_rth = U0->rho_theta; F.U0_ru = U0->rho_u; F.U0_rv = U0->rho_v; F.U0_rw = U0->rho_w; F.U0_rq = U0->rho_q;
+    F.G_rho_d = G->rho_d; F.G_rth = G->rho_theta; F.G_ru = G->rho_u; F.G_rv = G->rho_v; F.G_rw = G->rho_w; F.G_rq = G->rho_q;
+    F.thL = a->potential_temperature; F.Clin = ctx->d_Clin;
+    F.rp = a->density_perturbation; F.rthp = a->density_potential_temperature_perturbation;
+    F.rup = a->momentum_perturbation_u; F.rvp = a->momentum_perturbation_v; F.rwp = a->momentum_perturbation_w;
+    F.rs = a->density_predictor; F.rths = a->density_potential_temperature_predictor;
+    F.rth_old = a->previous_density_potential_temperature_perturbation;
+    F.au = a->time_averaged_u; F.av = a->time_averaged_v; F.aw = a->time_averaged_w;
+    F.Gs = a->slow_vertical_momentum_tendency; F.phi = a->vertical_solver_source_term;
+    F.tfac = ctx->d_tfac_ac;
+    return F;
+}
+
+// acoustic_rk3_substep_loop!; moist: fold the WS-RK3 moisture update into the recovery kernel; velocities: finish with the
+// halo fills + compute_velocities! of the reference (skipped when a full update_state! follows immediately).
+static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                     const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
+                                     double beta, bool moist, bool velocities)
+{
+    const DevGrid &g = ctx->dg;
+    int32_t ntau = 1;
+    double dtau = 0.0;
+    bz_stage_substeps(ctx, dt, beta, &ntau, &dtau);
+    const double om = ctx->se.forward_weight;
+    AcParams P;
+    P.dtau = dtau; P.dtn = om * dtau; P.dto = (1.0 - om) * dtau;
+    P.d_new = 0.0; P.d_old = 0.0;
+    const bool damping = ctx->se.damping_coefficient >= 0.0;
+    if (damping && ctx->se.damp_vertical) {
+        const double base = ctx->se.damping_coefficient * (ctx->dz_min * ctx->dz_min);
+        P.d_new = om * base;
+        P.d_old = (1.0 - om) * base;
+    }
+    P.f_theta = ctx->se.thermodynamic_tendency_factor;
+    P.f_w = ctx->se.vertical_momentum_tendency_factor;
+    const double lmin = std::fmin(g.dx, g.dy);
+    P.kdamp = damping ? ctx->se.damping_coefficient * (lmin * lmin) / dtau : 0.0;
+    P.inv_N = 1.0 / (double)ntau;
+    P.gate = 1.0;
+    AcFields F = ac_fields(ctx, s, U0, G, sub);
+
+    dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
+    dim3 cols((g.Nx + 63) / 64, (g.Ny + ACY - 1) / ACY), bcol(64, ACY);
+    {
+        ProfileScope ps(ctx, "acoustic_stage_init");
+        hipLaunchKernelGGL(k_ac_stage_init, rows, b256, 0, ctx->stream, g, F);
+    }
+    for (int sstep = 1; sstep <= ntau; ++sstep) {
+        const bool gate = ctx->se.apply_first_substep_pressure_gradient || (sstep != 1) || (ntau == 1);
+        P.gate = gate ? 1.0 : 0.0;
+        {
+            ProfileScope ps(ctx, "acoustic_horizontal");
+            if (damping && sstep > 1)
+                hipLaunchKernelGGL((k_ac_horizontal<true, true>), rows, b256, 0, ctx->stream, g, F, P);
+            else
+                hipLaunchKernelGGL((k_ac_horizontal<false, true>), rows, b256, 0, ctx->stream, g, F, P);
+        }
+        {
+            ProfileScope ps(ctx, "acoustic_column_forward");
+            if (sstep == 1)
+                hipLaunchKernelGGL((k_ac_column_forward<true>), cols, bcol, 0, ctx->stream, g, F, P);
+            else
+                hipLaunchKernelGGL((k_ac_column_forward<false>), cols, bcol, 0, ctx->stream, g, F, P);
+        }
+        {
+            ProfileScope ps(ctx, "acoustic_column_backward");
+            hipLaunchKernelGGL(k_ac_column_backward, cols, bcol, 0, ctx->stream, g, F, P);
+        }
+    }
+    {
+        ProfileScope ps(ctx, "acoustic_finalize");
+        if (damping)
+            hipLaunchKernelGGL((k_ac_finalize<true>), rows, b256, 0, ctx->stream, g, F, P);
+        else
+            hipLaunchKernelGGL((k_ac_finalize<false>), rows, b256, 0, ctx->stream, g, F, P);
+    }
+    {
+        ProfileScope ps(ctx, "acoustic_recover");
+        const long long per_level = (long long)g.Ny * g.Sx;
+        dim3 grid((unsigned)((per_level + 255) / 256), g.Nz);
+        if (moist)
+            hipLaunchKernelGGL((k_ac_recover<true>), grid, b256, 0, ctx->stream, g, F, beta * dt);
+        else
+            hipLaunchKernelGGL((k_ac_recover<false>), grid, b256, 0, ctx->stream, g, F, beta * dt);
+    }
+    if (velocities) {
+        ProfileScope ps(ctx, "acoustic_velocities");
+        DiagFields D = diag_fields(ctx, s, sub);
+        hipLaunchKernelGGL((k_cmp_diagnose<false, false>), rows, b256, 0, ctx->stream, g, D, 0.0, 0);
+    }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+static int check_loop_args(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                           const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub)
+{
+    if (!valid_state(s) || !valid_prog(U0) || !valid_prog(G) || !valid_sub(sub)) return BZ_ERR_INVALID;
+    if (!ctx->fused_ok) { ctx->last_error = "compressible path needs Nx >= 2Hx and Ny >= 2Hy"; return BZ_ERR_UNSUPPORTED; }
+    return BZ_OK;
+}
+
+extern "C" int bz_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                        const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
+                                        double beta)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    int rc = check_loop_args(ctx, s, U0, G, sub);
+    if (rc) return rc;
+    return bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, beta, false, true);
+}
+
+extern "C" int bz_acoustic_rk3_substep(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                       const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
+                                       double beta)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    int rc = check_loop_args(ctx, s, U0, G, sub);
+    if (rc) return rc;
+    rc = bz_refresh_linearization(ctx, s, sub);
+    if (rc) return rc;
+    rc = bz_compute_slow_tendencies(ctx, s, G);
+    if (rc) return rc;
+    return bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, beta, true, true);
+}
+
+extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                         const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    int rc = check_loop_args(ctx, s, U0, G, sub);
+    if (rc) return rc;
+    const DevGrid &g = ctx->dg;
+    {   // store_initial_state!
+        ProfileScope ps(ctx, "store_initial_state");
+        const size_t nc = (size_t)g.Sxy * (size_t)(g.Nz + 2 * g.Hz) * sizeof(double);
+        const size_t nf = (size_t)g.Sxy * (size_t)(g.Nz + 1 + 2 * g.Hz) * sizeof(double);
+        BZ_HIP(hipMemcpyAsync(U0->rho_d, s->rho_d, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        BZ_HIP(hipMemcpyAsync(U0->rho_u, s->rho_u, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        BZ_HIP(hipMemcpyAsync(U0->rho_v, s->rho_v, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        BZ_HIP(hipMemcpyAsync(U0->rho_w, s->rho_w, nf, hipMemcpyDeviceToDevice, ctx->stream));
+        BZ_HIP(hipMemcpyAsync(U0->rho_theta, s->rho_theta, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        BZ_HIP(hipMemcpyAsync(U0->rho_q, s->rho_q, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // freeze_linearization_state!: the linearisation of stage 1 (refreshed again by prepare_acoustic_cache! from the
+    // same state) + seeding of the transport velocities
+    rc = bz_refresh_linearization(ctx, s, sub);
+    if (rc) return rc;
+    const double betas[3] = {1.0 / 3.0, 1.0 / 2.0, 1.0};
+    for (int st = 0; st < 3; ++st) {
+        rc = bz_compute_slow_tendencies(ctx, s, G);
+        if (rc) return rc;
+        rc = bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, betas[st], true, false);
+        if (rc) return rc;
+        // update_state! (+ prepare_acoustic_cache! of the next stage: same inputs, folded into the diagnosis kernel)
+        rc = bzi_compressible_update_state(ctx, s, G, sub, true, st < 2);
+        if (rc) return rc;
+    }
+    return BZ_OK;
+}

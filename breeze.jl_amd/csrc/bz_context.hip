@@ -101,7 +101,7 @@ extern "C" int bz_create_slab(bz_ctx **out, const bz_grid *local_grid, const bz_
 }
 
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,
-               int weno_order, int y_nranks, int y_rank, bool slab_mode)
+               int weno_order, int y_nranks, int y_rank, bool slab_mode, bool compressible)
 {
     if (!out || !grid || !constants || !ref || !grid->zf || !ref->density || !ref->pressure || !ref->temperature)
         return BZ_ERR_INVALID;
@@ -147,12 +147,13 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     }
 
     // ---- column tables: 11 columns of nf entries each ----
-    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_COUNT };
+    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_RDZC, C_COUNT };
     std::vector<double> cols((size_t)C_COUNT * nf, 0.0);
     auto col = [&](int c) { return cols.data() + (size_t)c * nf; };
     const double dx = grid->dx, dy = grid->dy;
     for (int k = 0; k < nc; ++k) {
         col(C_DZC)[k] = dzc[k];
+        col(C_RDZC)[k] = 1.0 / dzc[k];
         col(C_AX)[k] = dy * dzc[k];
         col(C_AY)[k] = dx * dzc[k];
         col(C_VIC)[k] = 1.0 / (dx * dy * dzc[k]);
@@ -180,7 +181,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.Sxy = (long long)g.Sx * g.Sy;
     g.dx = dx; g.dy = dy; g.rdx = 1.0 / dx; g.rdy = 1.0 / dy; g.Az = dx * dy;
     auto dcol = [&](int c) { return ctx->d_columns + (size_t)c * nf + Hz; };
-    g.dzc = dcol(C_DZC); g.dzf = dcol(C_DZF); g.rdzf = dcol(C_RDZF);
+    g.dzc = dcol(C_DZC); g.dzf = dcol(C_DZF); g.rdzf = dcol(C_RDZF); g.rdzc = dcol(C_RDZC);
     g.Ax = dcol(C_AX); g.Ay = dcol(C_AY);
     g.Vinv_c = dcol(C_VIC); g.Vinv_f = dcol(C_VIF);
     g.rho = dcol(C_RHO); g.rho_f = dcol(C_RHOF);
@@ -198,7 +199,10 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);
     ctx->fuse_rk = !getenv("BZ_NO_FUSE_RK");
     ctx->tend_lds = !getenv("BZ_NO_TEND_LDS");
-    int rc = bzi_poisson_setup(ctx, ref->density);
+    ctx->compressible = compressible;
+    ctx->dz_min = dzc[Hz];
+    for (int k = 0; k < Nz; ++k) ctx->dz_min = std::fmin(ctx->dz_min, dzc[Hz + k]);
+    int rc = compressible ? BZ_OK : bzi_poisson_setup(ctx, ref->density);
     if (rc != BZ_OK) {
         fprintf(stderr, "bz_create: Poisson setup failed (%d): %s\n", rc, ctx->last_error.c_str());
         bz_destroy(ctx);
@@ -213,6 +217,7 @@ extern "C" void bz_destroy(bz_ctx *ctx)
     if (!ctx) return;
     profile_drain(ctx);
     bzi_poisson_teardown(ctx);
+    bzi_compressible_teardown(ctx);
     if (ctx->d_columns) hipFree(ctx->d_columns);
     if (ctx->d_scalar) hipFree(ctx->d_scalar);
     delete ctx;

@@ -20,6 +20,7 @@ struct DevGrid {
     long long Sxy;         // plane stride
     double dx, dy, rdx, rdy, Az;
     const double *dzc, *dzf, *rdzf;      // thickness at centres; centre spacing at faces; 1/dzf
+    const double *rdzc;                  // 1/dzc
     const double *Ax, *Ay;               // dy*dzc[k], dx*dzc[k]
     const double *Vinv_c, *Vinv_f;       // 1/(dx*dy*dzc[k]), 1/(dx*dy*dzf[k])
     const double *rho, *rho_f;           // rho_r at centres;  0.5*(rho[k-1]+rho[k]) at faces
@@ -90,6 +91,13 @@ struct bz_ctx {
     bool fuse_rk = true;              // whole-step seam: RK update folded into the tendency kernels (BZ_NO_FUSE_RK=1 disables)
     bool G_is_predictor = false;      // after a fused step the G arrays hold predictor momentum, not tendencies
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
+    // CompressibleDynamics + SplitExplicitTimeDiscretization (bz_create_compressible)
+    bool compressible = false;
+    bool has_reference = false;       // ExnerReferenceState columns present (else p_r = rho_r = 0)
+    bz_split_explicit se;
+    double dz_min = 0.0;              // minimum_zspacing(grid)
+    double *d_Clin = nullptr;         // centre array: gamma R_m * Pi of the current linearisation
+    double *d_tfac_ac = nullptr;      // centre array: Thomas factors t_k of the acoustic column system (per stage)
     // profiling
     bool profiling = false;
     std::vector<ProfileSlot> slots;
@@ -148,7 +156,8 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double
 int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                             double alpha, bool first);
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,
-               int weno_order, int y_nranks, int y_rank, bool slab_mode);
+               int weno_order, int y_nranks, int y_rank, bool slab_mode, bool compressible = false);
+void bzi_compressible_teardown(bz_ctx *ctx);
 int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w);
 int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
                              const RKEpilogue *E = nullptr);
@@ -156,5 +165,7 @@ int bzi_u_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, c
                        const RKEpilogue *E = nullptr);
 int bzi_v_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
                        const RKEpilogue *E = nullptr);
+// buoyancy_mode 0: anelastic buoyancy (T, q, reference columns); 1: none (SlowTendencyMode); 2: compressible slow
+// vertical momentum, s->T = pressure, s->q = total density, reference columns p_r, rho (acoustic_substepping.jl:727-752)
 int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
-                        const RKEpilogue *E = nullptr);
+                        const RKEpilogue *E = nullptr, int buoyancy_mode = 0);

@@ -98,7 +98,7 @@ int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic
 
 // z-momentum tendency with register rings for every vertical stencil (k_w_tend_ring)
 int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0,
-                        const RKEpilogue *Ein)
+                        const RKEpilogue *Ein, int buoyancy_mode)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, Ein ? "z_momentum_tendency+rk3" : "z_momentum_tendency");
@@ -109,7 +109,12 @@ int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, 
     F.u = s->u; F.v = s->v; F.w = s->w; F.T = s->T; F.q = s->q;
     F.c = s->w; F.G = G->rho_w;
     const int nlev = g.Nz - 1;
-    if (ctx->tend_lds && !getenv("BZ_NO_W_LDS")) {
+    if (buoyancy_mode != 0) {
+        const int kc = pick_chunk_lds(g, nlev, 8);
+        dim3 block(64, 8), grid((g.Nx + 63) / 64, (g.Ny + 7) / 8, (nlev + kc - 1) / kc);
+        if (buoyancy_mode == 1) hipLaunchKernelGGL((k_w_tend_lds<8, 1>), grid, block, 0, ctx->stream, g, F, kc, E);
+        else hipLaunchKernelGGL((k_w_tend_lds<8, 2>), grid, block, 0, ctx->stream, g, F, kc, E);
+    } else if (ctx->tend_lds && !getenv("BZ_NO_W_LDS")) {
         // in situ (512^3 bubble): ring 3.3 ms, LDS tile with 8 rows 2.9 ms, with 4 rows 3.9 ms per launch
         const int kc = pick_chunk_lds(g, nlev, 8);
         dim3 block(64, 8), grid((g.Nx + 63) / 64, (g.Ny + 7) / 8, (nlev + kc - 1) / kc);

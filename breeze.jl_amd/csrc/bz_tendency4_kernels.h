@@ -292,7 +292,10 @@ __global__ __launch_bounds__(64 * TY) void k_u_tend_lds(DevGrid g, Tend3Fields F
 }
 
 // z-momentum: k_w_tend_ring with the w y-stencil in an LDS tile and shared y-face fluxes.
-template <int TY>
+// BM (buoyancy mode) 0: anelastic buoyancy from T, q;  1: none (SlowTendencyMode);  2: compressible slow vertical
+// momentum  G^s = G_adv - dz(p - p_r) - g Iz(rho - rho_r)  with F.T = pressure, F.q = total density
+// (acoustic_substepping.jl:727-752; the bottom face is never stored, the caller keeps it at 0).
+template <int TY, int BM = 0>
 __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6;
@@ -339,12 +342,14 @@ __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F
         qt[s] = top ? g.Ay[kk] * rv[ntop0 + (s - 2) * sz] : 0.0;
         qw[s] = Az * rw[n + (s - 2) * sz];
     }
-    double fz_lo, b_lo;
+    double fz_lo, b_lo, r_lo = 0.0;
     {
         const int B = bz_buffer_center(kbeg - 1, g.Nz);
         const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
         fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
-        b_lo = buoyancy3(g, F.T[n - sz], F.q[n - sz], kbeg - 1);
+        if (BM == 0) b_lo = buoyancy3(g, F.T[n - sz], F.q[n - sz], kbeg - 1);
+        else if (BM == 2) { b_lo = F.T[n - sz] - g.p_r[kbeg - 1]; r_lo = F.q[n - sz] - g.rho[kbeg - 1]; }
+        else b_lo = 0.0;
     }
     T[0][ty + 3][tx] = wr[3];
 #pragma unroll
@@ -388,7 +393,9 @@ __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F
 #pragma unroll
         for (int q = 0; q < HPT; ++q)
             if (hok[q]) T[buf ^ 1][hr[q]][hcol[q]] = hnext[q];
-        const double b_hi = buoyancy3(g, F.T[n], F.q[n], k);
+        double b_hi = 0.0, r_hi = 0.0;
+        if (BM == 0) b_hi = buoyancy3(g, F.T[n], F.q[n], k);
+        else if (BM == 2) { b_hi = F.T[n] - g.p_r[k]; r_hi = F.q[n] - g.rho[k]; }
         // ring advance loads (level k+2)
         const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
         const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];
@@ -400,12 +407,17 @@ __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F
             if (tx == le) nb = e;
             const double dx = nb - fx;
             const double dy = FY[buf][ty + 1][tx] - fy;
+            const double adv = -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo)));
+            double Gval;
+            if (BM == 0) Gval = adv + 0.5 * (b_lo + b_hi);
+            else if (BM == 2) Gval = adv - (b_hi - b_lo) * g.rdzf[k] - g.g * ((r_hi + r_lo) / 2.0);
+            else Gval = adv;
             if (store)
-                F.G[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
-                                     -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo))) + 0.5 * (b_lo + b_hi), rw[n], n);
+                F.G[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out, Gval, rw[n], n);
         }
         fz_lo = fz_hi;
         b_lo = b_hi;
+        r_lo = r_hi;
 #pragma unroll
         for (int s = 0; s < 3; ++s) { qu[s] = qu[s + 1]; qv[s] = qv[s + 1]; qt[s] = qt[s + 1]; qw[s] = qw[s + 1]; }
         qu[3] = qun; qv[3] = qvn; qt[3] = qtn; qw[3] = qwnew;

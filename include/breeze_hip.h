@@ -175,6 +175,104 @@ int bz_poisson_source_term_from(bz_ctx *ctx, const bz_state *s, const bz_prognos
 int bz_project_and_diagnose_from(bz_ctx *ctx, const bz_state *s, const bz_prognostic *predictor, const double *phi_c,
                                  const double *phi_below, double dt);
 
+/* ==== CompressibleDynamics + SplitExplicitTimeDiscretization ==================================
+ * Fully compressible dynamics advanced by the Wicker-Skamarock RK3 outer loop with the linearised acoustic substep
+ * loop (src/TimeSteppers/acoustic_runge_kutta_3.jl, src/CompressibleEquations/acoustic_substepping.jl).
+ * Scope: (Periodic, Periodic, Bounded), microphysics = nothing (vapour is a passive mass fraction entering R_m, c_p,m),
+ * ProportionalSubsteps, ThermalDivergenceDamping (optionally damp_vertical) or NoDivergenceDamping, no sponge,
+ * LiquidIcePotentialTemperature formulation with the NewtonSolver temperature inversion. */
+
+/* model.dynamics.{dry_density,total_density,pressure}, model.momentum, formulation / moisture prognostics and the
+ * diagnostics (src/CompressibleEquations/compressible_dynamics.jl:44-55; atmosphere_model.jl:37-61). */
+typedef struct bz_compressible_state {
+    double *rho_d;                   /* dynamics.dry_density (prognostic)                */
+    double *rho;                     /* dynamics.total_density = rho_d + rho q (diagnosed) */
+    double *rho_u, *rho_v, *rho_w;   /* model.momentum                                   */
+    double *rho_theta;               /* formulation.potential_temperature_density        */
+    double *rho_q;                   /* model.moisture_density                           */
+    double *u, *v, *w;               /* model.velocities (default boundary conditions)   */
+    double *theta, *q, *T;           /* theta = rho_theta/rho_d, q = rho_q/rho, temperature */
+    double *p;                       /* dynamics.pressure = rho R_m T                    */
+} bz_compressible_state;
+
+/* timestepper.Gn / timestepper.U0 of AcousticRungeKutta3 (acoustic_runge_kutta_3.jl:64-72): prognostic order
+ * (rho_d, rho_u, rho_v, rho_w, rho_theta, rho_q). */
+typedef struct bz_compressible_prognostic {
+    double *rho_d, *rho_u, *rho_v, *rho_w, *rho_theta, *rho_q;
+} bz_compressible_prognostic;
+
+/* AcousticSubstepper fields (acoustic_substepping.jl:91-134); all caller-owned parent arrays. */
+typedef struct bz_acoustic_substepper {
+    double *exner, *potential_temperature, *gamma_R_mixture;     /* linearization_* (centre)                  */
+    double *density_perturbation;                                /* rho'                                       */
+    double *density_potential_temperature_perturbation;          /* (rho theta)'                               */
+    double *momentum_perturbation_u, *momentum_perturbation_v;   /* (rho u)', (rho v)'                         */
+    double *momentum_perturbation_w;                             /* (rho w)'  (z-face)                         */
+    double *density_predictor, *density_potential_temperature_predictor;
+    double *previous_density_potential_temperature_perturbation;
+    double *time_averaged_u, *time_averaged_v, *time_averaged_w; /* time_averaged_velocities (w: z-face)       */
+    double *slow_vertical_momentum_tendency;                     /* G^s_rho_w (z-face)                         */
+    double *vertical_solver_source_term;                         /* tridiagonal right-hand side (z-face)       */
+} bz_acoustic_substepper;
+
+/* SplitExplicitTimeDiscretization (src/CompressibleEquations/time_discretizations.jl:535-562). */
+typedef struct bz_split_explicit {
+    int32_t substeps;                 /* acoustic substeps per dt; 0 = adaptive from acoustic_cfl (nothing)   */
+    int32_t damp_vertical;            /* ThermalDivergenceDamping(damp_vertical)                              */
+    int32_t apply_first_substep_pressure_gradient;
+    int32_t newton_maxiter;           /* NewtonSolver maxiter (default 8)                                     */
+    double acoustic_cfl;              /* default 0.5                                                          */
+    double forward_weight;            /* omega, default 0.65                                                  */
+    double damping_coefficient;       /* ThermalDivergenceDamping alpha (default 0.1); < 0: NoDivergenceDamping */
+    double thermodynamic_tendency_factor, vertical_momentum_tendency_factor;   /* default 1                   */
+    double newton_abstol;             /* NewtonSolver abstol (default 1e-4), reltol = 0                       */
+} bz_split_explicit;
+
+/* ExnerReferenceState columns (src/Thermodynamics/reference_states.jl:717-815): HOST arrays of length Nz+2Hz
+ * (parent(field)[1,1,:], halos filled); both NULL for reference_state = nothing. */
+typedef struct bz_exner_reference_state {
+    double standard_pressure;
+    const double *pressure;
+    const double *density;
+} bz_exner_reference_state;
+
+/* materialize_dynamics(::CompressibleDynamics) + AcousticRungeKutta3/AcousticSubstepper construction
+ * (compressible_dynamics.jl:205-252; acoustic_runge_kutta_3.jl:82-103; acoustic_substepping.jl:180-270). */
+int bz_create_compressible(bz_ctx **ctx, const bz_grid *grid, const bz_constants *constants,
+                           const bz_exner_reference_state *reference_state, const bz_split_explicit *time_discretization,
+                           int weno_order);
+
+/* update_state!(model; compute_tendencies) for CompressibleDynamics (update_atmosphere_model_state.jl:41-68 with
+ * compressible_time_stepping.jl:83-103,191-242): total density, prognostic halos, velocities, theta, q, T (Newton), p,
+ * and — when compute_tendencies != 0 — the moisture tendency G->rho_q built with the total density and the substepper's
+ * time-averaged transport velocities (acoustic_runge_kutta_3.jl:352-358).  The momentum / rho_theta / rho_d tendencies
+ * that the reference also computes here are overwritten by compute_slow_*_tendencies! before use and are not formed. */
+int bz_compressible_update_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                 const bz_acoustic_substepper *sub, int compute_tendencies);
+
+/* refresh_linearization_basic_state! / prepare_acoustic_cache! (acoustic_substepping.jl:318-399,412-413). */
+int bz_refresh_linearization(bz_ctx *ctx, const bz_compressible_state *s, const bz_acoustic_substepper *sub);
+/* seed_time_averaged_velocities! (acoustic_substepping.jl:303-314). */
+int bz_seed_time_averaged_velocities(bz_ctx *ctx, const bz_compressible_state *s, const bz_acoustic_substepper *sub);
+/* compute_slow_momentum_tendencies! + compute_slow_scalar_tendencies! (acoustic_substep_helpers.jl:55-93,117-149):
+ * G->rho_u, rho_v, rho_w (advection only, SlowTendencyMode), G->rho_d = -div(momentum), G->rho_theta. */
+int bz_compute_slow_tendencies(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G);
+/* acoustic_substepping.jl:451-508 (ProportionalSubsteps): substep count and size of the stage covering beta*dt. */
+int bz_stage_substeps(bz_ctx *ctx, double dt, double beta, int32_t *n_substeps, double *dtau);
+/* acoustic_rk3_substep_loop!(model, substepper, dt, beta, U0) (acoustic_substepping.jl:1404-1590): slow rho_w assembly,
+ * rewind initialisation, the substep loop, time-averaged velocities, recovery of the full state, halos, velocities. */
+int bz_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                             const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta);
+/* acoustic_rk3_substep!(model, dt, beta) (acoustic_runge_kutta_3.jl:172-186): linearisation refresh, slow tendencies,
+ * substep loop, WS-RK3 update of the moisture density. */
+int bz_acoustic_rk3_substep(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                            const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta);
+/* time_step!(model::CompressibleAcousticModel, dt) (acoustic_runge_kutta_3.jl:264-319) without callbacks; the state
+ * must be consistent (bz_seed_time_averaged_velocities + bz_compressible_update_state(compute_tendencies=1) once
+ * after set!, as maybe_prepare_first_time_step! does). */
+int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                              const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt);
+
 /* ---- instrumentation (not part of the reference interface) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
 int bz_profile_enable(bz_ctx *ctx, int on);

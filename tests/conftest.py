@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the CPU oracle runs tiny grids in the tests: a few OpenMP threads beat one per core of a 256-core host
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,296 @@
+"""GPU parity of the compressible split-explicit path: every entry point of the C ABI
+against the CPU oracle on the same seeded inputs.  Float64; tolerances are relative to the field's max-abs and
+written next to each comparison."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oc(oracle):
+    from oracle import oracle_compressible
+    return oracle_compressible
+
+
+EXTENT = dict(x=(-4e3, 4e3), y=(-3e3, 3e3), z=(0.0, 8e3))
+
+
+def make_pair(oracle, oc, bz, size=(24, 16, 20), theta_ref=300.0, reference=True, z_faces=None, **td):
+    z = z_faces if z_faces is not None else EXTENT["z"]
+    og = oracle.Grid(size, x=EXTENT["x"], y=EXTENT["y"], z=z)
+    otd = oc.SplitExplicit(**td)
+    om = oc.CompressibleOracleModel(og, time_discretization=otd, reference_potential_temperature=theta_ref,
+                                    reference_state=reference)
+    grid = bz.RectilinearGrid(size, x=EXTENT["x"], y=EXTENT["y"], z=z)
+    damping = (bz.NoDivergenceDamping() if otd.damping_coefficient is None
+               else bz.ThermalDivergenceDamping(coefficient=otd.damping_coefficient, damp_vertical=otd.damp_vertical))
+    btd = bz.SplitExplicitTimeDiscretization(substeps=otd.substeps, acoustic_cfl=otd.acoustic_cfl,
+                                             forward_weight=otd.forward_weight, damping=damping,
+                                             apply_first_substep_pressure_gradient=otd.apply_first)
+    dyn = bz.CompressibleDynamics(btd, reference_potential_temperature=theta_ref if reference else None,
+                                  reference_state="auto" if reference else None)
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5))
+    return om, hm
+
+
+def seeded_state(om, seed, amp_u=4.0, amp_theta=3.0, amp_q=4e-3, amp_rho=0.01):
+    """Smooth + rough seeded perturbation of a hydrostatic column; consistent halos / diagnostics via update_state."""
+    g = om.grid
+    rng = np.random.default_rng(seed)
+    x, y, z = g.nodes("ccc")
+    Lx, Ly, Lz = g.Nx * g.dx, g.Ny * g.dy, g.zf[-1] - g.zf[0]
+    sh = (g.Nz, g.Ny, g.Nx)
+
+    def field(amp):
+        smooth = np.sin(2 * np.pi * x / Lx + 0.3) * np.cos(2 * np.pi * y / Ly - 0.2) * np.sin(np.pi * (z - g.zf[0]) / Lz)
+        return amp * (np.broadcast_to(smooth, sh) * 0.7 + 0.3 * rng.standard_normal(sh))
+
+    if om.ref is not None:
+        rho_c = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    else:
+        rho_c = 1.2 * np.exp(-g.zc / 8e3)[:, None, None]
+    I = g.interior
+    I(om.rho_d)[...] = rho_c * (1 + field(amp_rho))
+    I(om.rq)[...] = I(om.rho_d) * np.abs(field(amp_q))
+    I(om.rtheta)[...] = I(om.rho_d) * (300.0 + 0.004 * z + field(amp_theta))
+    I(om.ru)[...] = rho_c * field(amp_u)
+    I(om.rv)[...] = rho_c * field(amp_u)
+    I(om.rw, True)[1:-1] = (rho_c * field(0.5 * amp_u))[1:]
+    om.seed_time_averaged_velocities()
+    om.update_state(compute_tendencies=False)
+    om.seed_time_averaged_velocities()
+    om.update_state(compute_tendencies=True)
+
+
+O2H = {
+    "rho_d": lambda m: m.dynamics.dry_density, "rho": lambda m: m.dynamics.total_density, "p": lambda m: m.dynamics.pressure,
+    "ru": lambda m: m.momentum["ρu"], "rv": lambda m: m.momentum["ρv"], "rw": lambda m: m.momentum["ρw"],
+    "rtheta": lambda m: m.potential_temperature_density, "rq": lambda m: m.moisture_density,
+    "u": lambda m: m.velocities["u"], "v": lambda m: m.velocities["v"], "w": lambda m: m.velocities["w"],
+    "theta": lambda m: m.potential_temperature, "q": lambda m: m.specific_moisture, "T": lambda m: m.temperature,
+}
+SUB = {"Pi": "exner", "thL": "potential_temperature", "gR": "gamma_R_mixture", "rp": "density_perturbation",
+       "rthp": "density_potential_temperature_perturbation", "rup": "momentum_perturbation_u",
+       "rvp": "momentum_perturbation_v", "rwp": "momentum_perturbation_w", "au": "time_averaged_u",
+       "av": "time_averaged_v", "aw": "time_averaged_w", "Gs": "slow_vertical_momentum_tendency"}
+PROG = {"rho_d": "ρᵈ", "ru": "ρu", "rv": "ρv", "rw": "ρw", "rtheta": "ρθ", "rq": "ρq"}
+
+
+def push(om, hm, substepper=True):
+    import torch
+    for n, f in O2H.items():
+        f(hm).parent.copy_(torch.from_numpy(getattr(om, n)))
+    for n, k in PROG.items():
+        hm.G[k].parent.copy_(torch.from_numpy(om.G[n]))
+        hm.U0[k].parent.copy_(torch.from_numpy(om.U0[n]))
+    if substepper:
+        for n, k in SUB.items():
+            getattr(hm.timestepper.substepper, k).parent.copy_(torch.from_numpy(getattr(om, n)))
+
+
+def rel(a, b):
+    scale = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() / scale
+
+
+VECTOR_GROUPS = (("ru", "rv", "rw"), ("u", "v", "w"))
+
+
+def cmp_interior(om, hm, names, tol, zface_names=("rw", "w")):
+    """max-abs error relative to the field's max-abs; components of a vector share the vector's scale."""
+    g = om.grid
+    worst = {}
+    for n in names:
+        zf = n in zface_names
+        a = O2H[n](hm).interior_cpu()
+        b = g.interior(getattr(om, n), zf)
+        scale = np.abs(b).max()
+        for grp in VECTOR_GROUPS:
+            if n in grp:
+                scale = max(np.abs(g.interior(getattr(om, c), c in zface_names)).max() for c in grp)
+        worst[n] = np.abs(a - b).max() / max(scale, 1e-300)
+    bad = {k: v for k, v in worst.items() if not v <= tol}
+    assert not bad, f"mismatch beyond {tol}: {bad} (all: {worst})"
+    return worst
+
+
+def test_update_state_matches_oracle(oracle, oc, bz):
+    """update_state!: total density, velocities, theta, q, T (Newton), p and every halo the tendencies read."""
+    om, hm = make_pair(oracle, oc, bz)
+    seeded_state(om, 1)
+    push(om, hm)
+    for n in ("rho", "u", "v", "w", "theta", "q", "T", "p"):      # outputs must come from the kernel
+        O2H[n](hm).parent.zero_()
+    bz.compressible.update_state_(hm, compute_tendencies=False)
+    cmp_interior(om, hm, ("rho", "u", "v", "w", "theta", "q", "T", "p"), 1e-14)
+    # halos: x/y periodic images on interior levels, first z-halo cell of no-flux fields, walls of w
+    g = om.grid
+    Hz, Nz = g.Hz, g.Nz
+    for n in ("rho_d", "rho", "ru", "rv", "rtheta", "rq", "u", "v", "theta", "q", "T", "p"):
+        a, b = O2H[n](hm).cpu(), getattr(om, n)
+        assert rel(a[Hz - 1:Hz + Nz + 1], b[Hz - 1:Hz + Nz + 1]) <= 1e-14, n
+    for n in ("rw", "w"):
+        a, b = O2H[n](hm).cpu(), getattr(om, n)
+        assert rel(a[Hz:Hz + Nz + 1], b[Hz:Hz + Nz + 1]) <= 1e-14, n
+
+
+def test_moisture_tendency_and_linearization(oracle, oc, bz):
+    om, hm = make_pair(oracle, oc, bz)
+    seeded_state(om, 2)
+    om.refresh_linearization()
+    push(om, hm)
+    hm.G["ρq"].parent.zero_()
+    for k in ("exner", "potential_temperature", "gamma_R_mixture"):
+        getattr(hm.timestepper.substepper, k).parent.zero_()
+    bz.compressible.update_state_(hm, compute_tendencies=True)
+    bz.compressible.refresh_linearization_(hm)
+    g = om.grid
+    assert rel(hm.G["ρq"].interior_cpu(), g.interior(om.G["rq"])) <= 1e-12
+    sub = hm.timestepper.substepper
+    assert rel(sub.exner.interior_cpu(), g.interior(om.Pi)) <= 1e-15
+    assert rel(sub.potential_temperature.interior_cpu(), g.interior(om.thL)) <= 1e-15
+    assert rel(sub.gamma_R_mixture.interior_cpu(), g.interior(om.gR)) <= 1e-15
+
+
+@pytest.mark.parametrize("stretched", [False, True])
+def test_slow_tendencies_match_oracle(oracle, oc, bz, stretched):
+    """compute_slow_momentum_tendencies! + compute_slow_scalar_tendencies!: WENO-5 advection only; 1e-12 of max-abs."""
+    zf = None
+    if stretched:
+        s = np.linspace(0, 1, 21)
+        zf = 8e3 * (0.6 * s + 0.4 * s ** 2)
+    om, hm = make_pair(oracle, oc, bz, z_faces=zf)
+    seeded_state(om, 3)
+    om.compute_slow_tendencies()
+    push(om, hm)
+    for k in hm.G:
+        if k != "ρq":
+            hm.G[k].parent.zero_()
+    bz.compressible.compute_slow_tendencies_(hm)
+    g = om.grid
+    for n, k in PROG.items():
+        if n == "rq":
+            continue
+        a = hm.G[k].interior_cpu()
+        b = g.interior(om.G[n], n == "rw")
+        if n == "rw":
+            a, b = a[1:-1], b[1:-1]
+        assert rel(a, b) <= 1e-12, (n, rel(a, b))
+
+
+CASES = [
+    dict(substeps=6),                                            # default damping, N_tau = 2, 3, 6
+    dict(substeps=6, damping_coefficient=None, forward_weight=0.55),
+    dict(substeps=4, damping_coefficient=0.05, damp_vertical=True),
+    dict(substeps=1),                                            # degenerate one-substep stages (gate always on)
+    dict(substeps=6, apply_first_substep_pressure_gradient=True),
+    dict(),                                                      # adaptive substep count from the acoustic CFL
+]
+
+
+@pytest.mark.parametrize("td", CASES)
+@pytest.mark.parametrize("beta", [1.0 / 3.0, 0.5, 1.0])
+def test_acoustic_substep_loop_matches_oracle(oracle, oc, bz, td, beta):
+    """acoustic_rk3_substep_loop!(model, substepper, dt, beta, U0): perturbations, time-averaged velocities, recovered
+    state and velocities after the loop, from a stage state that differs from U0 (non-zero rewind)."""
+    reference = td.get("substeps", 0) != 1
+    om, hm = make_pair(oracle, oc, bz, reference=reference, **td)
+    seeded_state(om, 4)
+    for n in om.PROGNOSTIC:
+        om.U0[n][...] = getattr(om, n)
+    # move the stage state away from U0 the way an earlier stage would
+    g = om.grid
+    rng = np.random.default_rng(5)
+    for n in ("rho_d", "rtheta", "ru", "rv"):
+        g.interior(getattr(om, n))[...] *= 1 + 1e-3 * rng.standard_normal((g.Nz, g.Ny, g.Nx))
+    g.interior(om.rw, True)[1:-1] *= 1 + 1e-3 * rng.standard_normal((g.Nz - 1, g.Ny, g.Nx))
+    om.update_state(compute_tendencies=True)
+    om.refresh_linearization()
+    om.compute_slow_tendencies()
+    push(om, hm)
+    bz.compressible.refresh_linearization_(hm)     # fills the context's gamma R Pi scratch
+    dt = 2.0
+    om.acoustic_substep_loop(dt, beta)
+    bz.compressible.acoustic_rk3_substep_loop_(hm, dt, beta)
+    n_tau, _ = hm.stage_substeps(dt, beta)
+    assert n_tau == om.last_substeps[-1]
+    sub = hm.timestepper.substepper
+    tol = 2e-11
+    for n, k in SUB.items():
+        if n in ("Pi", "thL", "gR"):
+            continue
+        zf = n in ("rwp", "aw", "Gs")
+        a, b = getattr(sub, k).interior_cpu(), g.interior(getattr(om, n), zf)
+        scale = {"rp": np.abs(g.interior(om.rho_d)).max() * 1e-3, "rthp": np.abs(g.interior(om.rtheta)).max() * 1e-3}.get(n)
+        err = np.abs(a - b).max() / (scale or max(np.abs(b).max(), 1e-300))
+        assert err <= tol, (n, err, n_tau)
+    cmp_interior(om, hm, ("rho_d", "rtheta", "ru", "rv", "rw", "u", "v", "w"), 1e-12)
+
+
+@pytest.mark.parametrize("td", [dict(substeps=6), dict(), dict(substeps=4, damping_coefficient=0.05, damp_vertical=True)])
+def test_time_steps_match_oracle(oracle, oc, bz, td):
+    """Three full WS-RK3 steps of a warm bubble with a moist tracer, whole-step seam: 1e-9 of max-abs."""
+    om, hm = make_pair(oracle, oc, bz, size=(24, 16, 24), **td)
+    g = om.grid
+
+    def theta(x, y, z):
+        r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+        return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+    def qv(x, y, z):
+        return 5e-3 * np.exp(-z / 2e3) * (1 + 0.2 * np.sin(2 * np.pi * x / 8e3)) + 0 * y
+
+    rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    om.set(rho=rho, theta=theta, u=lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z, v=0.0, w=0.0, qv=qv)
+    hm.set(ρ=rho, θ=theta, u=lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z, v=0.0, w=0.0, qᵗ=qv)
+    cmp_interior(om, hm, ("rho_d", "rho", "rtheta", "rq", "ru", "T", "p"), 1e-14)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    worst = cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rv", "rw", "u", "v", "w", "theta", "q", "T", "p"), 1e-9)
+    print("3-step parity:", {k: f"{v:.1e}" for k, v in worst.items()})
+    sub = hm.timestepper.substepper
+    for n, k in (("au", "time_averaged_u"), ("av", "time_averaged_v"), ("aw", "time_averaged_w")):
+        assert rel(getattr(sub, k).interior_cpu(), g.interior(getattr(om, n), n == "aw")) <= 1e-9
+
+
+def test_whole_step_matches_operator_sequence(oracle, oc, bz):
+    """bz_time_step_compressible (fused linearisation, no redundant velocity pass) == the reference's operator
+    sequence issued call by call."""
+    om, a = make_pair(oracle, oc, bz, substeps=6)
+    _, b = make_pair(oracle, oc, bz, substeps=6)
+    seeded_state(om, 7)
+    for m in (a, b):
+        push(om, m)
+        m.clock.iteration = 1        # state already prepared by the oracle's update_state
+    bz.compressible.time_step_(a, 1.5, whole_step=True)
+    bz.compressible.time_step_(b, 1.5, whole_step=False)
+    for n, f in O2H.items():
+        x, y = f(a).interior_cpu(), f(b).interior_cpu()
+        assert rel(x, y) <= 1e-14, n
+
+
+def test_rest_state_stays_quiet_and_conserves_mass(oracle, oc, bz):
+    """test/substepper_structural.jl S4/S5 and acoustic_substepping_stability.jl:329-353 on the device."""
+    om, hm = make_pair(oracle, oc, bz, size=(16, 16, 16), theta_ref=lambda z: 250.0 * np.exp(9.80665 * z / (1005.0 * 250.0)))
+    ref = hm.dynamics.reference_state
+    g = hm.grid
+    Hz, Nz = g.Hz, g.Nz
+    Rd = 8.314462618 / 0.02897
+    import torch
+    rho = torch.from_numpy(ref.density.copy()).to(hm.device)[:, None, None]
+    rth = torch.from_numpy(ref.pressure / (Rd * np.where(ref.exner_function == 0, 1, ref.exner_function))).to(hm.device)[:, None, None]
+    hm.dynamics.dry_density.parent.copy_(rho.expand_as(hm.dynamics.dry_density.parent))
+    hm.potential_temperature_density.parent.copy_(rth.expand_as(hm.potential_temperature_density.parent))
+    bz.compressible.update_state_(hm, compute_tendencies=False)
+    M0 = hm.dynamics.dry_density.interior.sum().item()
+    for _ in range(5):
+        hm.time_step(6.0)
+    M1 = hm.dynamics.dry_density.interior.sum().item()
+    assert abs(M1 - M0) / M0 <= 1e-12
+    w = hm.velocities["w"].interior_cpu()
+    assert np.isfinite(w).all()
+    assert np.abs(w).max() < np.sqrt(np.finfo(float).eps)
+    assert np.abs(w[-1]).max() == 0.0 and np.abs(w[0]).max() == 0.0
+    assert np.abs(hm.velocities["u"].interior_cpu()).max() < np.sqrt(np.finfo(float).eps)

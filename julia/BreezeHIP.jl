@@ -118,4 +118,117 @@ function AtmosphereModels.make_pressure_correction!(model::HIPModel, Δt)
                 ctx, state(model), Δt), "bz_make_pressure_correction", ctx)
 end
 
+
+##### ---------------------------------------------------------------------------------------------------------------
+##### CompressibleDynamics + SplitExplicitTimeDiscretization (src/TimeSteppers/acoustic_runge_kutta_3.jl,
+##### src/CompressibleEquations/acoustic_substepping.jl)
+##### ---------------------------------------------------------------------------------------------------------------
+using Breeze.TimeSteppers: AcousticRungeKutta3
+using Breeze.CompressibleEquations: CompressibleDynamics, ThermalDivergenceDamping, ProportionalSubsteps
+import Breeze.CompressibleEquations: acoustic_rk3_substep_loop!
+
+struct BzCompressibleState
+    ρᵈ::Ptr{Float64}; ρ::Ptr{Float64}; ρu::Ptr{Float64}; ρv::Ptr{Float64}; ρw::Ptr{Float64}; ρθ::Ptr{Float64}; ρq::Ptr{Float64}
+    u::Ptr{Float64}; v::Ptr{Float64}; w::Ptr{Float64}; θ::Ptr{Float64}; q::Ptr{Float64}; T::Ptr{Float64}; p::Ptr{Float64}
+end
+struct BzCompressiblePrognostic
+    ρᵈ::Ptr{Float64}; ρu::Ptr{Float64}; ρv::Ptr{Float64}; ρw::Ptr{Float64}; ρθ::Ptr{Float64}; ρq::Ptr{Float64}
+end
+struct BzAcousticSubstepper       # field order of include/breeze_hip.h: bz_acoustic_substepper
+    Π::Ptr{Float64}; θ::Ptr{Float64}; γR::Ptr{Float64}
+    ρ′::Ptr{Float64}; ρθ′::Ptr{Float64}; ρu′::Ptr{Float64}; ρv′::Ptr{Float64}; ρw′::Ptr{Float64}
+    ρ′★::Ptr{Float64}; ρθ′★::Ptr{Float64}; ρθ′ˢ⁻::Ptr{Float64}
+    ū::Ptr{Float64}; v̄::Ptr{Float64}; w̄::Ptr{Float64}
+    Gˢρw::Ptr{Float64}; rhs::Ptr{Float64}
+end
+struct BzSplitExplicit
+    substeps::Int32; damp_vertical::Int32; apply_first::Int32; newton_maxiter::Int32
+    acoustic_cfl::Float64; forward_weight::Float64; damping_coefficient::Float64
+    f_θ::Float64; f_w::Float64; newton_abstol::Float64
+end
+struct BzExnerReference
+    pst::Float64; pressure::Ptr{Float64}; density::Ptr{Float64}
+end
+
+const HIPAcousticModel = AtmosphereModel{<:CompressibleDynamics, <:Any, <:HIPNative, <:AcousticRungeKutta3}
+
+cstate(m) = BzCompressibleState(devptr(m.dynamics.dry_density), devptr(m.dynamics.total_density),
+                                devptr(m.momentum.ρu), devptr(m.momentum.ρv), devptr(m.momentum.ρw),
+                                devptr(m.formulation.potential_temperature_density), devptr(m.moisture_density),
+                                devptr(m.velocities.u), devptr(m.velocities.v), devptr(m.velocities.w),
+                                devptr(m.formulation.potential_temperature), devptr(m.microphysical_fields.qᵛ),
+                                devptr(m.temperature), devptr(m.dynamics.pressure))
+cprognostic(nt) = BzCompressiblePrognostic(devptr(nt.ρᵈ), devptr(nt.ρu), devptr(nt.ρv), devptr(nt.ρw), devptr(nt.ρθ), devptr(nt.ρqᵛ))
+substepper(a) = BzAcousticSubstepper(devptr(a.linearization_exner), devptr(a.linearization_potential_temperature),
+                                     devptr(a.linearization_gamma_R_mixture), devptr(a.density_perturbation),
+                                     devptr(a.density_potential_temperature_perturbation),
+                                     devptr(a.momentum_perturbation.u), devptr(a.momentum_perturbation.v), devptr(a.momentum_perturbation.w),
+                                     devptr(a.density_predictor), devptr(a.density_potential_temperature_predictor),
+                                     devptr(a.previous_density_potential_temperature_perturbation),
+                                     devptr(a.time_averaged_velocities.u), devptr(a.time_averaged_velocities.v), devptr(a.time_averaged_velocities.w),
+                                     devptr(a.slow_vertical_momentum_tendency), devptr(a.vertical_solver_source_term))
+
+function create_compressible_context(model)
+    grid = model.grid
+    Nx, Ny, Nz = size(grid); Hx, Hy, Hz = Oceananigans.Grids.halo_size(grid)
+    zf = collect(Float64, znodes(grid, Face()))
+    c = model.thermodynamic_constants
+    a = model.timestepper.substepper
+    ref = model.dynamics.reference_state
+    hostcol(f) = collect(Float64, vec(Array(parent(f))))
+    p, ρ = ref === nothing ? (Float64[], Float64[]) : (hostcol(ref.pressure), hostcol(ref.density))
+    solver = model.formulation.temperature_solver                      # NewtonSolver(reltol = 0)
+    damp = a.damping
+    td = BzSplitExplicit(something(a.substeps, 0), damp isa ThermalDivergenceDamping && damp.damp_vertical,
+                         a.apply_first_substep_pressure_gradient, solver.maxiter, a.acoustic_cfl, a.forward_weight,
+                         damp isa ThermalDivergenceDamping ? damp.coefficient : -1.0,
+                         a.thermodynamic_tendency_factor, a.vertical_momentum_tendency_factor, solver.abstol)
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve zf p ρ begin
+        g = BzGrid(Nx, Ny, Nz, Hx, Hy, Hz, map(topocode, topology(grid)), 8, grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, pointer(zf),
+                   grid.z.Δᵃᵃᶜ isa Number ? 1 : 0, 0)
+        k = BzConstants(c.gravitational_acceleration, c.molar_gas_constant / c.dry_air.molar_mass,
+                        c.molar_gas_constant / c.vapor.molar_mass, c.dry_air.heat_capacity, c.vapor.heat_capacity)
+        r = BzExnerReference(model.dynamics.standard_pressure, ref === nothing ? C_NULL : pointer(p), ref === nothing ? C_NULL : pointer(ρ))
+        rc = ccall((:bz_create_compressible, libbreeze_hip), Cint,
+                   (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzExnerReference}, Ref{BzSplitExplicit}, Cint), ctx, g, k, r, td, 5)
+        rc == 0 || error("bz_create_compressible failed with code $rc")
+    end
+    return ctx[]
+end
+ccontext(model) = get!(() -> create_compressible_context(model), CONTEXTS, model)
+
+# Whole-step seam (src/TimeSteppers/acoustic_runge_kutta_3.jl:264-319)
+function OceananigansTimeSteppers.time_step!(model::HIPAcousticModel, Δt; callbacks=[])
+    ctx = ccontext(model)
+    OceananigansTimeSteppers.maybe_prepare_first_time_step!(model, Δt, callbacks)
+    ts = model.timestepper
+    rc = ccall((:bz_time_step_compressible, libbreeze_hip), Cint,
+               (Ptr{Cvoid}, Ref{BzCompressibleState}, Ref{BzCompressiblePrognostic}, Ref{BzCompressiblePrognostic}, Ref{BzAcousticSubstepper}, Cdouble),
+               ctx, cstate(model), cprognostic(ts.U⁰), cprognostic(ts.Gⁿ), substepper(ts.substepper), Δt)
+    check(rc, "bz_time_step_compressible", ctx)
+    tick!(model.clock, Δt)
+    return nothing
+end
+
+# Loop seam (src/CompressibleEquations/acoustic_substepping.jl:1404)
+function acoustic_rk3_substep_loop!(model::HIPAcousticModel, a, Δt, β_stage, U⁰)
+    ctx = ccontext(model)
+    rc = ccall((:bz_acoustic_substep_loop, libbreeze_hip), Cint,
+               (Ptr{Cvoid}, Ref{BzCompressibleState}, Ref{BzCompressiblePrognostic}, Ref{BzCompressiblePrognostic}, Ref{BzAcousticSubstepper}, Cdouble, Cdouble),
+               ctx, cstate(model), cprognostic(U⁰), cprognostic(model.timestepper.Gⁿ), substepper(a), Δt, β_stage)
+    check(rc, "bz_acoustic_substep_loop", ctx)
+    return nothing
+end
+
+function OceananigansTimeSteppers.update_state!(model::HIPAcousticModel, callbacks=[]; compute_tendencies=true)
+    ctx = ccontext(model)
+    ts = model.timestepper
+    rc = ccall((:bz_compressible_update_state, libbreeze_hip), Cint,
+               (Ptr{Cvoid}, Ref{BzCompressibleState}, Ref{BzCompressiblePrognostic}, Ref{BzAcousticSubstepper}, Cint),
+               ctx, cstate(model), cprognostic(ts.Gⁿ), substepper(ts.substepper), compute_tendencies ? 1 : 0)
+    check(rc, "bz_compressible_update_state", ctx)
+    return nothing
+end
+
 end # module

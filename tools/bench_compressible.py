@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""tools/bench_compressible.py — timing of the compressible split-explicit step (second milestone).
+
+Workload: the dry thermal bubble of bench.py with pressure-balanced density, CompressibleDynamics +
+SplitExplicitTimeDiscretization defaults (omega = 0.65, acoustic_cfl = 0.5, ThermalDivergenceDamping 0.1,
+ProportionalSubsteps), WENO-5, Float64.  Prints one JSON line: cells/s, ms/step, substeps per step, per-kernel-group
+milliseconds (HIP events on the launch stream) and the HBM fraction of the acoustic substep (contract words of
+SURVEY §8d: 58 words/cell/substep; this build moves fewer).
+
+    python tools/bench_compressible.py --size 512 512 256 --dt 1.0 --steps 5 --warmup 2
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 256])
+    ap.add_argument("--dt", type=float, default=1.0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--substeps", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    import breeze_jl_amd as bz
+    Nx, Ny, Nz = a.size
+    grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(-10e3, 10e3), y=(-10e3, 10e3), z=(0.0, 10e3))
+    td = bz.SplitExplicitTimeDiscretization(substeps=a.substeps or None)
+    dyn = bz.CompressibleDynamics(td, surface_pressure=1e5, reference_potential_temperature=300.0)
+    m = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5))
+    c = m.thermodynamic_constants
+    Rd, cpd, g = 8.314462618 / c.dry_air_molar_mass, c.dry_air_heat_capacity, c.gravitational_acceleration
+    kap = Rd / cpd
+
+    def theta(x, y, z):
+        r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+        return 300.0 + 10.0 * np.maximum(0.0, 1.0 - r / 2000.0) + 0 * z
+
+    def rho(x, y, z):
+        ex = 1.0 - g * z / (cpd * 300.0)
+        return 1e5 * ex ** (1 / kap) / (Rd * theta(x, y, z) * ex)
+
+    m.set(ρ=rho, θ=theta, u=0.0, v=0.0, w=0.0, qᵗ=0.0)
+    for _ in range(a.warmup):
+        m.time_step(a.dt)
+    m.synchronize()
+    m.profile_enable(True)
+    m.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m.time_step(a.dt)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    m.profile_enable(False)
+    prof = m.profile()
+    ms = (t1 - t0) / a.steps * 1e3
+    nsub = [m.stage_substeps(a.dt, b)[0] for b in (1 / 3, 1 / 2, 1.0)]
+    cells = Nx * Ny * Nz
+    per = {k: v[0] / a.steps for k, v in sorted(prof.items())}
+    sub_ms = sum(per.get(k, 0.0) for k in ("acoustic_horizontal", "acoustic_column_forward", "acoustic_column_backward"))
+    per_sub = sub_ms / sum(nsub)
+    w = m.velocities["w"].interior
+    out = {"metric": "grid-cells advanced/sec, compressible split-explicit WS-RK3 step", "value": cells / (ms * 1e-3),
+           "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": a.dt, "substeps_per_stage": nsub,
+           "dtype": "f64", "kernels_ms_per_step": per, "acoustic_ms_per_substep": per_sub,
+           "acoustic_substep_contract_GBs": cells * 58 * 8 / (per_sub * 1e-3) / 1e9,
+           "acoustic_substep_frac_of_8TBs": cells * 58 * 8 / (per_sub * 1e-3) / 8e12,
+           "finite": bool(torch.isfinite(w).all().item()), "w_max": float(w.max().item())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

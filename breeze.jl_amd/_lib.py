@@ -91,6 +91,7 @@ SYMBOLS = {
     "bz_create": (C.c_int, [C.POINTER(_ctx), C.POINTER(bz_grid), C.POINTER(bz_constants),
                             C.POINTER(bz_reference_state), C.c_int]),
     "bz_destroy": (None, [_ctx]),
+    "bz_set_formulation": (C.c_int, [_ctx, C.c_int]),
     "bz_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "bz_sync": (C.c_int, [_ctx]),
     "bz_last_error": (C.c_char_p, [_ctx]),

@@ -278,6 +278,11 @@ struct AcFields {
     const double *thL, *Clin;
     double *rp, *rthp, *rup, *rvp, *rwp;
     double *rs, *rths, *rth_old;
+    // fused substep (k_ac_column_forward<.., FUSED = true>): (rho u)', (rho v)' ping-pong between rup_in (read) and rup
+    // (written); (rho theta)' ping-pongs between rthp (current, read) / rth_old (previous, read) and rthp_out (written
+    // by the backward sweep), so no thread reads a location another thread of the same launch writes.
+    const double *rup_in, *rvp_in;
+    double *rthp_out;
     double *au, *av, *aw;
     double *Gs, *phi;             // slow vertical momentum tendency; forward-eliminated right-hand side
     double *tfac;                 // Thomas factors t_k
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFields F)
     const long long sz = g.Sxy;
     const long long n = g.idx(i, j, k);
     F.rp[n] = F.U0_rho_d[n] - F.rho_d[n];
-    F.rthp[n] = F.U0_rth[n] - F.rth[n];
+    F.rthp_out[n] = F.U0_rth[n] - F.rth[n];     // start buffers of the ping-pong fields (set by the launcher)
     F.rup[n] = F.U0_ru[n] - F.ru[n];
     F.rvp[n] = F.U0_rv[n] - F.rv[n];
     F.rwp[n] = F.U0_rw[n] - F.rw[n];
@@ -357,10 +362,28 @@ __device__ __forceinline__ double ibz(double fp, double fm, bool p_per, bool m_p
     return (fp + fm) / 2.0;
 }
 
+// one face of k_ac_horizontal: cells a (low side) and b (high side) of the face, rd = 1/spacing
+template <bool DAMP>
+__device__ __forceinline__ double ac_face_update(double up, double G, double rt_b, double rt_a, double rto_b, double rto_a,
+                                                 double th_b, double th_a, double C_b, double C_a, double p_b, double p_a,
+                                                 double rd, const AcParams &P)
+{
+    if (DAMP) {
+        const double dd = ((rt_b - rto_b) - (rt_a - rto_a)) * rd;
+        up -= P.kdamp * dd / ((th_b + th_a) / 2.0);
+    }
+    double dp = (p_b - p_a) * rd;
+    if (P.gate != 0.0) dp = dp + P.gate * ((C_b * rt_b - C_a * rt_a) * rd);
+    return up + P.dtau * (G - dp);
+}
+
 #define ACY 4
 // _build_predictors! + _build_vertical_rhs! + forward sweep of the BatchedTridiagonalSolver
-// (acoustic_substepping.jl:605-659,907-970)
-template <bool FIRST>
+// (acoustic_substepping.jl:605-659,907-970).  FUSED: the horizontal step (k_ac_horizontal) of the four faces of the
+// column is evaluated in place of loading (rho u)', (rho v)': each face is computed by its two adjacent columns with
+// identical arithmetic and stored by its owner, which removes one read + one write of (rho u)', (rho v)' and the separate
+// pass over (rho theta)', theta^L, C per substep.
+template <bool FIRST, bool FUSED, bool DAMP>
 __global__ __launch_bounds__(64 * ACY) void k_ac_column_forward(DevGrid g, AcFields F, AcParams P)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * ACY + threadIdx.y;
@@ -383,12 +406,31 @@ __global__ __launch_bounds__(64 * ACY) void k_ac_column_forward(DevGrid g, AcFie
         const double rdc = g.rdzc[k];
         const double Ax = g.Ax[k], Ay = g.Ay[k], Vinv = g.Vinv_c[k];
         const double rp = F.rp[n], rthp = F.rthp[n];
-        const double up0 = F.rup[n], up1 = F.rup[n + W.ip], vp0 = F.rvp[n], vp1 = F.rvp[n + W.jp];
         const double thxm = F.thL[n + W.im], thxp = F.thL[n + W.ip], thym = F.thL[n + W.jm], thyp = F.thL[n + W.jp];
+        double up0, up1, vp0, vp1;
+        if (FUSED) {
+            const long long nxm = n + W.im, nxp = n + W.ip, nym = n + W.jm, nyp = n + W.jp;
+            const double rt_xm = F.rthp[nxm], rt_xp = F.rthp[nxp], rt_ym = F.rthp[nym], rt_yp = F.rthp[nyp];
+            double o0 = 0.0, o_xm = 0.0, o_xp = 0.0, o_ym = 0.0, o_yp = 0.0;
+            if (DAMP) { o0 = F.rth_old[n]; o_xm = F.rth_old[nxm]; o_xp = F.rth_old[nxp]; o_ym = F.rth_old[nym]; o_yp = F.rth_old[nyp]; }
+            double c_xm = 0.0, c_xp = 0.0, c_ym = 0.0, c_yp = 0.0;
+            if (P.gate != 0.0) { c_xm = F.Clin[nxm]; c_xp = F.Clin[nxp]; c_ym = F.Clin[nym]; c_yp = F.Clin[nyp]; }
+            const double p0 = F.p[n], p_xm = F.p[nxm], p_xp = F.p[nxp], p_ym = F.p[nym], p_yp = F.p[nyp];
+            up0 = ac_face_update<DAMP>(F.rup_in[n], F.G_ru[n], rthp, rt_xm, o0, o_xm, th_0, thxm, C_0, c_xm, p0, p_xm, g.rdx, P);
+            up1 = ac_face_update<DAMP>(F.rup_in[nxp], F.G_ru[nxp], rt_xp, rthp, o_xp, o0, thxp, th_0, c_xp, C_0, p_xp, p0, g.rdx, P);
+            vp0 = ac_face_update<DAMP>(F.rvp_in[n], F.G_rv[n], rthp, rt_ym, o0, o_ym, th_0, thym, C_0, c_ym, p0, p_ym, g.rdy, P);
+            vp1 = ac_face_update<DAMP>(F.rvp_in[nyp], F.G_rv[nyp], rt_yp, rthp, o_yp, o0, thyp, th_0, c_yp, C_0, p_yp, p0, g.rdy, P);
+            F.rup[n] = up0;
+            F.rvp[n] = vp0;
+            F.au[n] += up0;
+            F.av[n] += vp0;
+        } else {
+            up0 = F.rup[n]; up1 = F.rup[n + W.ip]; vp0 = F.rvp[n]; vp1 = F.rvp[n + W.jp];
+            F.rth_old[n] = rthp;
+        }
         // theta face k+1 (top face: one-sided)
         const double thf_p = (k + 1 < Nz) ? (th_p + th_0) / 2.0 : th_0;
 
-        F.rth_old[n] = rthp;
         const double dxM = Ax * up1 - Ax * up0;
         const double dxT = Ax * ((thxp + th_0) / 2.0) * up1 - Ax * ((th_0 + thxm) / 2.0) * up0;
         const double dyM = Ay * vp1 - Ay * vp0;
@@ -463,7 +505,7 @@ __global__ __launch_bounds__(64 * ACY) void k_ac_column_backward(DevGrid g, AcFi
         const double dzW = (w_hi - w_lo) * rdc;
         const double dzT = (thf_hi * w_hi - thf_lo * w_lo) * rdc;
         F.rp[n] = F.rs[n] - P.dtn * dzW;
-        F.rthp[n] = F.rths[n] - P.dtn * dzT;
+        F.rthp_out[n] = F.rths[n] - P.dtn * dzT;
         F.rwp[n] = w_lo;
         F.aw[n] += w_lo;
         t_hi = F.tfac[n];
@@ -591,14 +633,19 @@ extern "C" int bz_create_compressible(bz_ctx **out, const bz_grid *grid, const b
     ctx->se = *td;
     ctx->has_reference = ref->density != nullptr;
     const size_t ncell = (size_t)ctx->dg.Sxy * (size_t)nc;
+    ctx->ac_fused = !getenv("BZ_NO_AC_FUSE");
     if (hipMalloc(&ctx->d_Clin, ncell * sizeof(double)) != hipSuccess ||
-        hipMalloc(&ctx->d_tfac_ac, ncell * sizeof(double)) != hipSuccess) {
+        hipMalloc(&ctx->d_tfac_ac, ncell * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->d_up2, ncell * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->d_vp2, ncell * sizeof(double)) != hipSuccess) {
         bz_destroy(ctx);
         *out = nullptr;
         return BZ_ERR_ALLOC;
     }
     hipMemset(ctx->d_Clin, 0, ncell * sizeof(double));
     hipMemset(ctx->d_tfac_ac, 0, ncell * sizeof(double));
+    hipMemset(ctx->d_up2, 0, ncell * sizeof(double));
+    hipMemset(ctx->d_vp2, 0, ncell * sizeof(double));
     return BZ_OK;
 }
 
@@ -606,7 +653,9 @@ void bzi_compressible_teardown(bz_ctx *ctx)
 {
     if (ctx->d_Clin) hipFree(ctx->d_Clin);
     if (ctx->d_tfac_ac) hipFree(ctx->d_tfac_ac);
-    ctx->d_Clin = ctx->d_tfac_ac = nullptr;
+    if (ctx->d_up2) hipFree(ctx->d_up2);
+    if (ctx->d_vp2) hipFree(ctx->d_vp2);
+    ctx->d_Clin = ctx->d_tfac_ac = ctx->d_up2 = ctx->d_vp2 = nullptr;
 }
 
 static DiagFields diag_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_acoustic_substepper *sub)
@@ -751,6 +800,7 @@ static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_
     F.au = a->time_averaged_u; F.av = a->time_averaged_v; F.aw = a->time_averaged_w;
     F.Gs = a->slow_vertical_momentum_tendency; F.phi = a->vertical_solver_source_term;
     F.tfac = ctx->d_tfac_ac;
+    F.rup_in = F.rup; F.rvp_in = F.rvp; F.rthp_out = F.rthp;
     return F;
 }
 
@@ -784,16 +834,47 @@ static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s
 
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
     dim3 cols((g.Nx + 63) / 64, (g.Ny + ACY - 1) / ACY), bcol(64, ACY);
+    const bool fused = ctx->ac_fused;
+    // ping-pong buffers of the fused substep: the start buffers are chosen by the parity of N_tau so that the final
+    // (rho theta)', (rho u)', (rho v)' land in the substepper's own fields (and the previous (rho theta)' in
+    // previous_density_potential_temperature_perturbation, as in the reference).
+    double *th_buf[2] = {F.rthp, F.rth_old};
+    double *u_buf[2] = {F.rup, ctx->d_up2}, *v_buf[2] = {F.rvp, ctx->d_vp2};
+    int cur = fused ? (ntau & 1) : 0;       // index of the buffer holding the current perturbations
     {
         ProfileScope ps(ctx, "acoustic_stage_init");
-        hipLaunchKernelGGL(k_ac_stage_init, rows, b256, 0, ctx->stream, g, F);
+        AcFields Fi = F;
+        Fi.rthp_out = th_buf[cur]; Fi.rup = u_buf[cur]; Fi.rvp = v_buf[cur];
+        hipLaunchKernelGGL(k_ac_stage_init, rows, b256, 0, ctx->stream, g, Fi);
     }
     for (int sstep = 1; sstep <= ntau; ++sstep) {
         const bool gate = ctx->se.apply_first_substep_pressure_gradient || (sstep != 1) || (ntau == 1);
         P.gate = gate ? 1.0 : 0.0;
+        const bool damp = damping && sstep > 1;
+        if (fused) {
+            AcFields Fs = F;
+            Fs.rthp = th_buf[cur]; Fs.rth_old = th_buf[cur ^ 1]; Fs.rthp_out = th_buf[cur ^ 1];
+            Fs.rup_in = u_buf[cur]; Fs.rup = u_buf[cur ^ 1];
+            Fs.rvp_in = v_buf[cur]; Fs.rvp = v_buf[cur ^ 1];
+            {
+                ProfileScope ps(ctx, "acoustic_horizontal+column_forward");
+                if (sstep == 1)
+                    hipLaunchKernelGGL((k_ac_column_forward<true, true, false>), cols, bcol, 0, ctx->stream, g, Fs, P);
+                else if (damp)
+                    hipLaunchKernelGGL((k_ac_column_forward<false, true, true>), cols, bcol, 0, ctx->stream, g, Fs, P);
+                else
+                    hipLaunchKernelGGL((k_ac_column_forward<false, true, false>), cols, bcol, 0, ctx->stream, g, Fs, P);
+            }
+            {
+                ProfileScope ps(ctx, "acoustic_column_backward");
+                hipLaunchKernelGGL(k_ac_column_backward, cols, bcol, 0, ctx->stream, g, Fs, P);
+            }
+            cur ^= 1;
+            continue;
+        }
         {
             ProfileScope ps(ctx, "acoustic_horizontal");
-            if (damping && sstep > 1)
+            if (damp)
                 hipLaunchKernelGGL((k_ac_horizontal<true, true>), rows, b256, 0, ctx->stream, g, F, P);
             else
                 hipLaunchKernelGGL((k_ac_horizontal<false, true>), rows, b256, 0, ctx->stream, g, F, P);
@@ -801,9 +882,9 @@ static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s
         {
             ProfileScope ps(ctx, "acoustic_column_forward");
             if (sstep == 1)
-                hipLaunchKernelGGL((k_ac_column_forward<true>), cols, bcol, 0, ctx->stream, g, F, P);
+                hipLaunchKernelGGL((k_ac_column_forward<true, false, false>), cols, bcol, 0, ctx->stream, g, F, P);
             else
-                hipLaunchKernelGGL((k_ac_column_forward<false>), cols, bcol, 0, ctx->stream, g, F, P);
+                hipLaunchKernelGGL((k_ac_column_forward<false, false, false>), cols, bcol, 0, ctx->stream, g, F, P);
         }
         {
             ProfileScope ps(ctx, "acoustic_column_backward");

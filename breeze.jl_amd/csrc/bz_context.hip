@@ -80,6 +80,16 @@ extern "C" int bz_set_stream(bz_ctx *ctx, void *hip_stream)
     return BZ_OK;
 }
 
+// thermodynamic formulation of the anelastic model: 0 = :LiquidIcePotentialTemperature, 1 = :StaticEnergy
+// (src/StaticEnergyFormulations/static_energy_formulation.jl); with 1 the rho_theta / theta slots carry rho_e / e.
+extern "C" int bz_set_formulation(bz_ctx *ctx, int formulation)
+{
+    if (!ctx || formulation < 0 || formulation > 1) return BZ_ERR_INVALID;
+    if (ctx->compressible && formulation != 0) return BZ_ERR_UNSUPPORTED;
+    ctx->dg.formulation = formulation;
+    return BZ_OK;
+}
+
 extern "C" int bz_sync(bz_ctx *ctx)
 {
     if (!ctx) return BZ_ERR_INVALID;
@@ -144,16 +154,18 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
         double dz = (grid->zf[Nz] - grid->zf[0]) / Nz;
         for (auto &v : dzc) v = dz;
         for (auto &v : dzf) v = dz;
+        for (int k = 0; k < nc; ++k) zc_ext[k] = grid->zf[0] + dz * ((k - Hz) + 0.5);   // Oceananigans regular-grid nodes
     }
 
     // ---- column tables: 11 columns of nf entries each ----
-    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_RDZC, C_COUNT };
+    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_RDZC, C_ZC, C_COUNT };
     std::vector<double> cols((size_t)C_COUNT * nf, 0.0);
     auto col = [&](int c) { return cols.data() + (size_t)c * nf; };
     const double dx = grid->dx, dy = grid->dy;
     for (int k = 0; k < nc; ++k) {
         col(C_DZC)[k] = dzc[k];
         col(C_RDZC)[k] = 1.0 / dzc[k];
+        col(C_ZC)[k] = zc_ext[k];
         col(C_AX)[k] = dy * dzc[k];
         col(C_AY)[k] = dx * dzc[k];
         col(C_VIC)[k] = 1.0 / (dx * dy * dzc[k]);
@@ -181,7 +193,8 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.Sxy = (long long)g.Sx * g.Sy;
     g.dx = dx; g.dy = dy; g.rdx = 1.0 / dx; g.rdy = 1.0 / dy; g.Az = dx * dy;
     auto dcol = [&](int c) { return ctx->d_columns + (size_t)c * nf + Hz; };
-    g.dzc = dcol(C_DZC); g.dzf = dcol(C_DZF); g.rdzf = dcol(C_RDZF); g.rdzc = dcol(C_RDZC);
+    g.dzc = dcol(C_DZC); g.dzf = dcol(C_DZF); g.rdzf = dcol(C_RDZF); g.rdzc = dcol(C_RDZC); g.zc = dcol(C_ZC);
+    g.formulation = 0;
     g.Ax = dcol(C_AX); g.Ay = dcol(C_AY);
     g.Vinv_c = dcol(C_VIC); g.Vinv_f = dcol(C_VIF);
     g.rho = dcol(C_RHO); g.rho_f = dcol(C_RHOF);

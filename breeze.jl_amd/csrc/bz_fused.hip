@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const double qd = 1.0 - q;
     const double Rm = qd * g.Rd + q * g.Rv;
     const double cpm = qd * g.cpd + q * g.cpv;
-    const double T = pow(g.p_r[k] / g.pst, Rm / cpm) * th;
+    const double T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : pow(g.p_r[k] / g.pst, Rm / cpm) * th;
 
     st_img(F.phi, n, p, ox, oy);
     st_img(F.ru, n, ru, ox, oy);

@@ -21,11 +21,13 @@ struct DevGrid {
     double dx, dy, rdx, rdy, Az;
     const double *dzc, *dzf, *rdzf;      // thickness at centres; centre spacing at faces; 1/dzf
     const double *rdzc;                  // 1/dzc
+    const double *zc;                    // cell-centre heights
     const double *Ax, *Ay;               // dy*dzc[k], dx*dzc[k]
     const double *Vinv_c, *Vinv_f;       // 1/(dx*dy*dzc[k]), 1/(dx*dy*dzf[k])
     const double *rho, *rho_f;           // rho_r at centres;  0.5*(rho[k-1]+rho[k]) at faces
     const double *p_r, *T_r;
     double g, Rd, Rv, cpd, cpv, pst;
+    int formulation;       // 0: liquid-ice potential temperature (theta), 1: static energy (e) in the `theta` slots
     int wrap_y;            // 1: y halos are this rank's own periodic images; 0: y-slab, halos filled by the neighbour ranks
 
     __host__ __device__ inline long long idx(int i, int j, int k) const {
@@ -98,6 +100,8 @@ struct bz_ctx {
     double dz_min = 0.0;              // minimum_zspacing(grid)
     double *d_Clin = nullptr;         // centre array: gamma R_m * Pi of the current linearisation
     double *d_tfac_ac = nullptr;      // centre array: Thomas factors t_k of the acoustic column system (per stage)
+    double *d_up2 = nullptr, *d_vp2 = nullptr;   // second buffers of the (rho u)', (rho v)' ping-pong (fused substep)
+    bool ac_fused = true;             // horizontal step folded into the forward column sweep (BZ_NO_AC_FUSE=1 disables)
     // profiling
     bool profiling = false;
     std::vector<ProfileSlot> slots;

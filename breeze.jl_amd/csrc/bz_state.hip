@@ -40,6 +40,10 @@ __global__ __launch_bounds__(TX *TY) void k_thermo(DevGrid g, double *__restrict
     double qd = 1.0 - q;
     double Rm = qd * g.Rd + q * g.Rv;
     double cpm = qd * g.cpd + q * g.cpv;
+    if (g.formulation == 1) {       // StaticEnergyState: T = (e - g z) / c_pm  (dynamic_states.jl:283-298)
+        T[n] = (th - g.g * g.zc[k]) / cpm;
+        return;
+    }
     double Pi = pow(g.p_r[k] / g.pst, Rm / cpm);
     T[n] = Pi * th;
 }

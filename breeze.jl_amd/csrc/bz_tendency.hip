@@ -265,6 +265,21 @@ __global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__re
     }
 }
 
+// StaticEnergy: G_rho_e -= Iz_c(w * Iz_f(buoyancy))  (static_energy_tendency.jl:55-67, dynamics_kernel_functions.jl:40-51)
+__global__ __launch_bounds__(256) void k_energy_buoyancy_flux(DevGrid g, double *__restrict__ Ge, const double *__restrict__ w,
+                                                              const double *__restrict__ T, const double *__restrict__ qv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k), sz = g.Sxy;
+    const double b_m = buoyancy_ccc(g, T[n - sz], qv[n - sz], k - 1);
+    const double b_0 = buoyancy_ccc(g, T[n], qv[n], k);
+    const double b_p = buoyancy_ccc(g, T[n + sz], qv[n + sz], k + 1);
+    const double f_lo = ((b_0 + b_m) / 2.0) * w[n];
+    const double f_hi = ((b_p + b_0) / 2.0) * w[n + sz];
+    Ge[n] = Ge[n] - (f_hi + f_lo) / 2.0;
+}
+
 static int pick_kchunk(const DevGrid &g, int nlev)
 {
     long long tiles = (long long)((g.Nx + 63) / 64) * ((g.Ny + TYB - 1) / TYB);
@@ -281,6 +296,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     ctx->G_is_predictor = false;
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
+    if (ctx->tend_gen >= 3 && g.formulation != 0) {
+        ctx->last_error = "BZ_TEND_GEN >= 3 implements the potential-temperature formulation only";
+        return BZ_ERR_UNSUPPORTED;
+    }
     if (ctx->tend_gen >= 3) {
         // gen-3 kernels for the scalars and horizontal momentum; w stays gen-1 unless BZ_TEND_GEN=4
         int rc = bzi_compute_tendencies3(ctx, s, G, ctx->tend_gen >= 4);
@@ -331,6 +350,11 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
             ProfileScope ps(ctx, "moisture_tendency");
             hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q, kc);
         }
+    }
+    if (g.formulation == 1) {
+        ProfileScope ps(ctx, "static_energy_buoyancy_flux");
+        hipLaunchKernelGGL(k_energy_buoyancy_flux, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
+                           G->rho_theta, s->w, s->T, s->q);
     }
     BZ_LAUNCH_CHECK();
     return BZ_OK;

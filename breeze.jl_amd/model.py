@@ -81,7 +81,7 @@ _LOC = {"ccc": (Center, Center, Center), "fcc": (Face, Center, Center),
         "cfc": (Center, Face, Center), "ccf": (Center, Center, Face)}
 
 # keyword spellings accepted by set_ (Julia names and ASCII transliterations)
-_ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "ρθ": "ρθ", "rho_theta": "ρθ",
+_ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "ρθ": "ρθ", "rho_theta": "ρθ", "e": "e", "ρe": "ρe", "rho_e": "ρe",
             "u": "u", "v": "v", "w": "w", "ρu": "ρu", "ρv": "ρv", "ρw": "ρw",
             "rho_u": "ρu", "rho_v": "ρv", "rho_w": "ρw",
             "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q", "ρqᵗ": "ρq", "ρqᵛ": "ρq", "rho_q": "ρq",
@@ -104,8 +104,10 @@ class AtmosphereModel:
             raise TypeError("grid must be a RectilinearGrid")
         if grid.topology != (Periodic, Periodic, Bounded):
             raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded)")
-        if formulation not in ("LiquidIcePotentialTemperature", ":LiquidIcePotentialTemperature"):
-            raise NotImplementedError("only the liquid-ice potential temperature formulation is implemented")
+        formulation = str(formulation).lstrip(":")
+        if formulation not in ("LiquidIcePotentialTemperature", "StaticEnergy"):
+            raise NotImplementedError(f"formulation {formulation!r} is not implemented")
+        self.formulation = formulation
         if timestepper not in ("SSPRungeKutta3", ":SSPRungeKutta3"):
             raise NotImplementedError("only SSPRungeKutta3 is implemented")
         for name, val in (("closure", closure), ("coriolis", coriolis), ("microphysics", microphysics),
@@ -134,8 +136,10 @@ class AtmosphereModel:
         # materialize_momentum_and_velocities, formulation, moisture, diagnostics
         self.momentum = {"ρu": fld("fcc"), "ρv": fld("cfc"), "ρw": fld("ccf")}
         self.velocities = {"u": fld("fcc"), "v": fld("cfc"), "w": fld("ccf")}
+        # :StaticEnergy keeps rho_e / e in the thermodynamic slots (energy_density, specific_energy)
         self.potential_temperature_density = fld("ccc")
         self.potential_temperature = fld("ccc")
+        self.energy_density, self.specific_energy = self.potential_temperature_density, self.potential_temperature
         self.moisture_density = fld("ccc")
         self.specific_moisture = fld("ccc")
         self.temperature = fld("ccc")
@@ -168,6 +172,8 @@ class AtmosphereModel:
             raise _lib.BreezeHIPError(f"bz_create failed with code {rc}")
         self._check(lib.bz_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
                     "bz_set_stream")
+        if formulation == "StaticEnergy":
+            self._check(lib.bz_set_formulation(self._ctx, 1), "bz_set_formulation")
         self._state = self._make_state()
         self._U0 = self._make_prog(self.U0)
         self._G = self._make_prog(self.G)
@@ -303,15 +309,31 @@ def set_(model, enforce_mass_conservation=True, **kw):
     ρc = torch.from_numpy(ref.density[Hz:Hz + Nz].copy()).to(model.device)[:, None, None]
     ρf_host = 0.5 * (ref.density[Hz - 1:Hz + Nz] + ref.density[Hz:Hz + Nz + 1])
     ρf = torch.from_numpy(ρf_host).to(model.device)[:, None, None]
-    for name, value in kw.items():
+    for name, value in sorted(kw.items(), key=lambda kv: 0 if _ALIASES.get(kv[0]) in ("q", "ρq") else 1):   # moisture first
         key = _ALIASES.get(name)
+        if key in ("e", "ρe") and model.formulation != "StaticEnergy":
+            key = None
         if key is None:
             raise ValueError(f"Cannot set! {name} in AtmosphereModel because {name} is neither a prognostic "
                              "variable, a settable thermodynamic variable, nor a settable diagnostic variable!")
-        if key == "θ":
+        if key == "θ" and model.formulation == "StaticEnergy":
+            # _energy_density_from_potential_temperature! (static_energy_tendency.jl:93-140): host set-up arithmetic
+            c = model.thermodynamic_constants
+            Rd, Rv = dry_air_gas_constant(c), vapor_gas_constant(c)
+            scratch = model.temperature
+            scratch.set_interior(value)
+            q = model.specific_moisture.interior
+            qd = 1.0 - q
+            Rm, cpm = qd * Rd + q * Rv, qd * c.dry_air_heat_capacity + q * c.vapor_heat_capacity
+            pr = torch.from_numpy(ref.pressure[Hz:Hz + Nz].copy()).to(model.device)[:, None, None]
+            z = torch.from_numpy(np.ascontiguousarray(g.zᶜ)).to(model.device)[:, None, None]
+            T = (pr / ref.standard_pressure) ** (Rm / cpm) * scratch.interior
+            model.specific_energy.interior.copy_(cpm * T + c.gravitational_acceleration * z)
+            model.energy_density.interior.copy_(ρc * model.specific_energy.interior)
+        elif key == "θ" or key == "e":
             model.potential_temperature.set_interior(value)
             model.potential_temperature_density.interior.copy_(ρc * model.potential_temperature.interior)
-        elif key == "ρθ":
+        elif key == "ρθ" or key == "ρe":
             model.potential_temperature_density.set_interior(value)
         elif key == "q":
             model.specific_moisture.set_interior(value)

@@ -99,6 +99,11 @@ typedef struct bz_ctx bz_ctx;
 int bz_create(bz_ctx **ctx, const bz_grid *grid, const bz_constants *constants,
               const bz_reference_state *reference_state, int weno_order);
 void bz_destroy(bz_ctx *ctx);
+/* Thermodynamic formulation of the anelastic model (AtmosphereModel(...; formulation)): 0 = :LiquidIcePotentialTemperature
+ * (default), 1 = :StaticEnergy (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21,70-95,
+ * static_energy_tendency.jl:39-72).  With 1 the `rho_theta` / `theta` slots of bz_state and bz_prognostic carry
+ * energy_density (rho e) / specific_energy (e): T = (e - g z)/c_pm and G_rho_e = -div_rhoUc(e) - Iz(w * Iz(buoyancy)). */
+int bz_set_formulation(bz_ctx *ctx, int formulation);
 int bz_set_stream(bz_ctx *ctx, void *hip_stream);
 int bz_sync(bz_ctx *ctx);
 const char *bz_last_error(const bz_ctx *ctx);

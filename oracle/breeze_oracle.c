@@ -622,3 +622,46 @@ int og_buffer_at(int idx, int N, int bounded, int at_face) { return buffer_at(id
 
 /* Compressible split-explicit path. */
 #include "breeze_oracle_compressible.inc.c"
+
+/* ------------------------------------------------------------------------- */
+/* StaticEnergy formulation                                    */
+/* e = rho_e / rho_r;  T = (e - g z + 0 + 0) / c_pm                           */
+/*   static_energy_formulation.jl:70-78, dynamic_states.jl:283-298            */
+/* G_rho_e = -div_rhoUc(e) - Iz_c(w * Iz_f(buoyancy))                         */
+/*   static_energy_tendency.jl:39-72, dynamics_kernel_functions.jl:40-51      */
+/* zc: cell-centre heights, halo-inclusive (entry k+Hz)                       */
+/* ------------------------------------------------------------------------- */
+void og_compute_thermo_energy(const og_grid *G, double *e, double *qv, double *T,
+                              const double *re, const double *rq, const double *zc)
+{
+    const double *rho = G->rho_r + G->Hz;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < G->Nz; ++k)
+        for (int j = 0; j < G->Ny; ++j)
+            for (int i = 0; i < G->Nx; ++i) {
+                size_t n = IDX(G, i, j, k);
+                double ev = re[n] / rho[k];
+                double q = rq[n] / rho[k];
+                e[n] = ev;
+                qv[n] = q;
+                double qd = 1.0 - (q + 0.0 + 0.0);
+                double cpm = qd * G->cpd + q * G->cpv + 0.0 + 0.0;
+                T[n] = (ev - G->g * zc[k + G->Hz] + 0.0 + 0.0) / cpm;
+            }
+}
+
+void og_energy_buoyancy_flux(const og_grid *G, double *Ge, const double *w, const double *T, const double *qv)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < G->Nz; ++k)
+        for (int j = 0; j < G->Ny; ++j)
+            for (int i = 0; i < G->Nx; ++i) {
+                size_t n = IDX(G, i, j, k);
+                double b_m = buoyancy_ccc(G, T, qv, i, j, k - 1);
+                double b_0 = buoyancy_ccc(G, T, qv, i, j, k);
+                double b_p = buoyancy_ccc(G, T, qv, i, j, k + 1);
+                double f_lo = ((b_0 + b_m) / 2.0) * w[n];
+                double f_hi = ((b_p + b_0) / 2.0) * w[n + STRZ(G)];
+                Ge[n] = Ge[n] - (f_hi + f_lo) / 2.0;
+            }
+}

@@ -249,7 +249,12 @@ class OracleModel:
     PROGNOSTIC = ("ru", "rv", "rw", "rtheta", "rq")
 
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
-                 standard_pressure=1e5, reference_density=None, initialize=True):
+                 standard_pressure=1e5, reference_density=None, initialize=True,
+                 formulation="LiquidIcePotentialTemperature"):
+        # formulation "StaticEnergy": self.theta holds e, self.rtheta holds rho*e
+        # (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21)
+        assert formulation in ("LiquidIcePotentialTemperature", "StaticEnergy")
+        self.formulation = formulation
         self.grid = g = grid
         self.constants = c = constants or Constants()
         self.ref = ReferenceState(g, c, surface_pressure, potential_temperature, standard_pressure)
@@ -259,6 +264,9 @@ class OracleModel:
             self.ref._fill(g)
         self.lib = lib()
         self._mk_cgrid()
+        zc_halo = np.zeros(g.Szc)
+        zc_halo[g.Hz:g.Hz + g.Nz] = g.zc
+        self._zc_halo = zc_halo
         # fields
         self.ru, self.rv, self.rtheta, self.rq = (g.center_field() for _ in range(4))
         self.rw = g.zface_field()
@@ -321,7 +329,7 @@ class OracleModel:
         rho_c = self.ref.density[Hz:Hz + Nz][:, None, None]
         rho_f = (0.5 * (self.ref.density[Hz - 1:Hz + Nz] + self.ref.density[Hz:Hz + Nz + 1]))[:, None, None] \
             if Hz > 0 else None
-        for name, value in kw.items():
+        for name, value in sorted(kw.items(), key=lambda kv: 0 if kv[0] in ("qt", "qv", "rq") else 1):   # moisture first
             if name in ("qt", "qv"):
                 g.interior(self.q)[...] = self._eval(value, "ccc")
                 g.interior(self.rq)[...] = rho_c * g.interior(self.q)
@@ -342,9 +350,25 @@ class OracleModel:
                 g.interior(self.rv)[...] = self._eval(value, "cfc")
             elif name == "rw":
                 g.interior(self.rw, True)[...] = self._eval(value, "ccf")
-            elif name == "theta":
+            elif name == "theta" and self.formulation == "StaticEnergy":
+                # _energy_density_from_potential_temperature! (static_energy_tendency.jl:93-140): T = Pi theta,
+                # e = cpm T + g z - 0 - 0, rho_e = rho e
+                c, r = self.constants, self.ref
+                th = np.asarray(self._eval(value, "ccc"), dtype=np.float64)
+                q = g.interior(self.q)
+                qd = 1.0 - (q + 0.0 + 0.0)
+                Rm = qd * c.Rd + q * c.Rv
+                cpm = qd * c.cpd + q * c.cpv + 0.0 + 0.0
+                pr = r.pressure[Hz:Hz + Nz][:, None, None]
+                T = (pr / r.pst) ** (Rm / cpm) * th + 0.0
+                e = cpm * T + c.g * g.zc[:, None, None] - 0.0 - 0.0
+                g.interior(self.theta)[...] = e
+                g.interior(self.rtheta)[...] = rho_c * e
+            elif name in ("theta", "e"):
                 g.interior(self.theta)[...] = self._eval(value, "ccc")
                 g.interior(self.rtheta)[...] = rho_c * g.interior(self.theta)
+            elif name == "re":
+                g.interior(self.rtheta)[...] = self._eval(value, "ccc")
             elif name == "rtheta":
                 g.interior(self.rtheta)[...] = self._eval(value, "ccc")
             else:
@@ -364,7 +388,11 @@ class OracleModel:
         self.lib.og_compute_velocities(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv), _p(self.rw))
         for f in (self.u, self.v, self.w):
             self._halo_velocity(f)
-        self.lib.og_compute_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.rtheta), _p(self.rq))
+        if self.formulation == "StaticEnergy":
+            self.lib.og_compute_thermo_energy(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.rtheta), _p(self.rq),
+                                              _p(self._zc_halo))
+        else:
+            self.lib.og_compute_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.rtheta), _p(self.rq))
         for f in (self.T, self.q, self.theta):
             self._halo_center(f)
         if compute_tendencies:
@@ -378,6 +406,19 @@ class OracleModel:
         L.og_w_tendency(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w), _p(self.T), _p(self.q))
         L.og_scalar_tendency(cg, _p(G["rtheta"]), _p(self.u), _p(self.v), _p(self.w), _p(self.theta))
         L.og_scalar_tendency(cg, _p(G["rq"]), _p(self.u), _p(self.v), _p(self.w), _p(self.q))
+        if self.formulation == "StaticEnergy":
+            L.og_energy_buoyancy_flux(cg, _p(G["rtheta"]), _p(self.w), _p(self.T), _p(self.q))
+
+    def liquid_ice_potential_temperature(self):
+        """Diagnostics.LiquidIcePotentialTemperature (dry: theta = T / Pi) on the interior."""
+        g, c, r = self.grid, self.constants, self.ref
+        if self.formulation != "StaticEnergy":
+            return g.interior(self.theta).copy()
+        q = g.interior(self.q)
+        qd = 1.0 - q
+        kappa = (qd * c.Rd + q * c.Rv) / (qd * c.cpd + q * c.cpv)
+        Pi = (r.pressure[g.Hz:g.Hz + g.Nz][:, None, None] / r.pst) ** kappa
+        return g.interior(self.T) / Pi
 
     # -- pressure ------------------------------------------------------------
     def solve_poisson(self, rhs):

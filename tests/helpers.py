@@ -10,14 +10,14 @@ def bubble_theta(theta0, g, N2=1e-6, dtheta=10.0, r0=2e3, zc=3000.0):
 
 
 def make_pair(orc, bz, size, halo=(3, 3, 3), extent=((-10e3, 10e3), (-10e3, 10e3), (0.0, 10e3)), theta0=300.0,
-              z_faces=None):
+              z_faces=None, formulation="LiquidIcePotentialTemperature"):
     """Return (oracle model, HIP model) on identical grids / reference states."""
     z = z_faces if z_faces is not None else extent[2]
     og = orc.Grid(size, x=extent[0], y=extent[1], z=z, halo=halo)
-    om = orc.OracleModel(og, potential_temperature=theta0)
+    om = orc.OracleModel(og, potential_temperature=theta0, formulation=formulation)
     grid = bz.RectilinearGrid(size, x=extent[0], y=extent[1], z=z, halo=halo)
     ref = bz.ReferenceState(grid, potential_temperature=theta0)
-    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5))
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), formulation=formulation)
     return om, hm
 
 

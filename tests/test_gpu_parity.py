@@ -214,3 +214,53 @@ def test_missing_library_fails_loudly(bz, monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError):
         _lib.load()
+
+
+# ---- formulation = :StaticEnergy (src/StaticEnergyFormulations/) ----------------------------------
+def _energy_state(om, seed):
+    randomize(om, seed=seed)
+    g, c = om.grid, om.constants
+    rng = np.random.default_rng(seed + 100)
+    rho_c = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    T = 290.0 - 0.006 * g.zc[:, None, None] + 2.0 * rng.standard_normal((g.Nz, g.Ny, g.Nx))
+    g.interior(om.rtheta)[...] = rho_c * (c.cpd * T + c.g * g.zc[:, None, None])
+    om.update_state(compute_tendencies=False)
+
+
+def test_static_energy_diagnosis_and_tendencies_match_oracle(oracle, bz):
+    """T = (e - g z)/c_pm and G_rho_e = -div_rhoUc(e) - Iz(w Iz(buoyancy)) against the oracle: 1e-14 / 1e-12."""
+    om, hm = make_pair(oracle, bz, (32, 20, 16), formulation="StaticEnergy")
+    _energy_state(om, 21)
+    om.compute_tendencies()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=True)
+    hm.synchronize()
+    g = om.grid
+    for n, f in (("theta", hm.specific_energy), ("q", hm.specific_moisture), ("T", hm.temperature)):
+        assert relerr(f.cpu(), getattr(om, n)) < 1e-14, n
+    for n, k in PROG.items():
+        zf = n == "rw"
+        want, got = g.interior(om.G[n], zface=zf), hm.G[k].interior_cpu()
+        if zf:
+            want, got = want[1:-1], got[1:-1]
+        assert relerr(got, want) < 1e-12, n
+
+
+def test_static_energy_time_steps_match_oracle(oracle, bz):
+    om, hm = make_pair(oracle, bz, (32, 20, 16), formulation="StaticEnergy")
+    th = bubble_theta(300.0, om.constants.g)
+    om.set(theta=th, u=3.0, v=-2.0)
+    hm.set(θ=th, u=3.0, v=-2.0)
+    assert relerr(hm.energy_density.interior_cpu(), om.grid.interior(om.rtheta)) < 1e-14
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    errs = {}
+    mom_scale = max(np.max(np.abs(_interior(om, n))) for n in ("ru", "rv", "rw"))     # momentum components share a scale
+    for n, k in PROG.items():
+        got, want = hm.prognostic_fields()[k].interior_cpu(), _interior(om, n)
+        scale = mom_scale if n in ("ru", "rv", "rw") else max(np.max(np.abs(want)), 1e-3)
+        errs[n] = float(np.max(np.abs(got - want)) / scale)
+    errs["T"] = float(relerr(hm.temperature.interior_cpu(), om.grid.interior(om.T)))
+    assert all(v < 1e-9 for v in errs.values()), {k: f"{v:.1e}" for k, v in errs.items()}

@@ -377,16 +377,32 @@ __device__ __forceinline__ double ac_face_update(double up, double G, double rt_
     return up + P.dtau * (G - dp);
 }
 
+// block shapes of the column kernels (measured on MI355X, 512x512x256: forward sweep 64x4 99 ms/step vs 256x1 102;
+// backward sweep 256x1 32.5 vs 64x4 37.8)
+#ifndef ACX
+#define ACX 64
+#endif
+#ifndef ACY
 #define ACY 4
+#endif
+#ifndef ABX
+#define ABX 256
+#endif
+#ifndef ABY
+#define ABY 1
+#endif
+#ifndef AC_MINW
+#define AC_MINW 1
+#endif
 // _build_predictors! + _build_vertical_rhs! + forward sweep of the BatchedTridiagonalSolver
 // (acoustic_substepping.jl:605-659,907-970).  FUSED: the horizontal step (k_ac_horizontal) of the four faces of the
 // column is evaluated in place of loading (rho u)', (rho v)': each face is computed by its two adjacent columns with
 // identical arithmetic and stored by its owner, which removes one read + one write of (rho u)', (rho v)' and the separate
 // pass over (rho theta)', theta^L, C per substep.
 template <bool FIRST, bool FUSED, bool DAMP>
-__global__ __launch_bounds__(64 * ACY) void k_ac_column_forward(DevGrid g, AcFields F, AcParams P)
+__global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGrid g, AcFields F, AcParams P)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * ACY + threadIdx.y;
+    const int i = blockIdx.x * ACX + threadIdx.x, j = blockIdx.y * ACY + threadIdx.y;
     if (i >= g.Nx || j >= g.Ny) return;
     const WrapIdx W = wrap_of(g, i, j);
     const long long sz = g.Sxy;
@@ -485,9 +501,9 @@ __global__ __launch_bounds__(64 * ACY) void k_ac_column_forward(DevGrid g, AcFie
 }
 
 // back substitution + _post_solve_recovery! (acoustic_substepping.jl:993-1002)
-__global__ __launch_bounds__(64 * ACY) void k_ac_column_backward(DevGrid g, AcFields F, AcParams P)
+__global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcFields F, AcParams P)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * ACY + threadIdx.y;
+    const int i = blockIdx.x * ABX + threadIdx.x, j = blockIdx.y * ABY + threadIdx.y;
     if (i >= g.Nx || j >= g.Ny) return;
     const long long sz = g.Sxy;
     const int Nz = g.Nz;
@@ -642,19 +658,19 @@ extern "C" int bz_create_compressible(bz_ctx **out, const bz_grid *grid, const b
         *out = nullptr;
         return BZ_ERR_ALLOC;
     }
-    hipMemset(ctx->d_Clin, 0, ncell * sizeof(double));
-    hipMemset(ctx->d_tfac_ac, 0, ncell * sizeof(double));
-    hipMemset(ctx->d_up2, 0, ncell * sizeof(double));
-    hipMemset(ctx->d_vp2, 0, ncell * sizeof(double));
+    (void)hipMemset(ctx->d_Clin, 0, ncell * sizeof(double));
+    (void)hipMemset(ctx->d_tfac_ac, 0, ncell * sizeof(double));
+    (void)hipMemset(ctx->d_up2, 0, ncell * sizeof(double));
+    (void)hipMemset(ctx->d_vp2, 0, ncell * sizeof(double));
     return BZ_OK;
 }
 
 void bzi_compressible_teardown(bz_ctx *ctx)
 {
-    if (ctx->d_Clin) hipFree(ctx->d_Clin);
-    if (ctx->d_tfac_ac) hipFree(ctx->d_tfac_ac);
-    if (ctx->d_up2) hipFree(ctx->d_up2);
-    if (ctx->d_vp2) hipFree(ctx->d_vp2);
+    if (ctx->d_Clin) (void)hipFree(ctx->d_Clin);
+    if (ctx->d_tfac_ac) (void)hipFree(ctx->d_tfac_ac);
+    if (ctx->d_up2) (void)hipFree(ctx->d_up2);
+    if (ctx->d_vp2) (void)hipFree(ctx->d_vp2);
     ctx->d_Clin = ctx->d_tfac_ac = ctx->d_up2 = ctx->d_vp2 = nullptr;
 }
 
@@ -833,7 +849,8 @@ static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s
     AcFields F = ac_fields(ctx, s, U0, G, sub);
 
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
-    dim3 cols((g.Nx + 63) / 64, (g.Ny + ACY - 1) / ACY), bcol(64, ACY);
+    dim3 cols((g.Nx + ACX - 1) / ACX, (g.Ny + ACY - 1) / ACY), bcol(ACX, ACY);
+    dim3 colsb((g.Nx + ABX - 1) / ABX, (g.Ny + ABY - 1) / ABY), bcolb(ABX, ABY);
     const bool fused = ctx->ac_fused;
     // ping-pong buffers of the fused substep: the start buffers are chosen by the parity of N_tau so that the final
     // (rho theta)', (rho u)', (rho v)' land in the substepper's own fields (and the previous (rho theta)' in
@@ -867,7 +884,7 @@ static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s
             }
             {
                 ProfileScope ps(ctx, "acoustic_column_backward");
-                hipLaunchKernelGGL(k_ac_column_backward, cols, bcol, 0, ctx->stream, g, Fs, P);
+                hipLaunchKernelGGL(k_ac_column_backward, colsb, bcolb, 0, ctx->stream, g, Fs, P);
             }
             cur ^= 1;
             continue;
@@ -888,7 +905,7 @@ static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s
         }
         {
             ProfileScope ps(ctx, "acoustic_column_backward");
-            hipLaunchKernelGGL(k_ac_column_backward, cols, bcol, 0, ctx->stream, g, F, P);
+            hipLaunchKernelGGL(k_ac_column_backward, colsb, bcolb, 0, ctx->stream, g, F, P);
         }
     }
     {

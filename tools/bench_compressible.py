@@ -66,7 +66,8 @@ def main():
     nsub = [m.stage_substeps(a.dt, b)[0] for b in (1 / 3, 1 / 2, 1.0)]
     cells = Nx * Ny * Nz
     per = {k: v[0] / a.steps for k, v in sorted(prof.items())}
-    sub_ms = sum(per.get(k, 0.0) for k in ("acoustic_horizontal", "acoustic_column_forward", "acoustic_column_backward"))
+    sub_ms = sum(per.get(k, 0.0) for k in ("acoustic_horizontal", "acoustic_column_forward", "acoustic_horizontal+column_forward",
+                                               "acoustic_column_backward"))
     per_sub = sub_ms / sum(nsub)
     w = m.velocities["w"].interior
     out = {"metric": "grid-cells advanced/sec, compressible split-explicit WS-RK3 step", "value": cells / (ms * 1e-3),

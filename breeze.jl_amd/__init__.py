@@ -17,3 +17,4 @@ from . import compressible  # noqa: F401,E402
 from .compressible import (AcousticRungeKutta3, AcousticSubstepper, CompressibleAtmosphereModel, CompressibleDynamics,  # noqa: F401,E402
                            ExnerReferenceState, NewtonSolver, NoDivergenceDamping, ProportionalSubsteps,
                            SplitExplicitTimeDiscretization, ThermalDivergenceDamping)
+from .microphysics import SaturationAdjustment, SecantSolver, WarmPhaseEquilibrium  # noqa: F401,E402

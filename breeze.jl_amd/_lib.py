@@ -50,6 +50,13 @@ class bz_prognostic(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _PROG_FIELDS]
 
 
+class bz_saturation_adjustment(C.Structure):
+    _fields_ = [("liquid_latent_heat", C.c_double), ("liquid_heat_capacity", C.c_double),
+                ("energy_reference_temperature", C.c_double), ("triple_point_temperature", C.c_double),
+                ("triple_point_pressure", C.c_double), ("abstol", C.c_double), ("maxiter", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 _CSTATE_FIELDS = ("rho_d", "rho", "rho_u", "rho_v", "rho_w", "rho_theta", "rho_q", "u", "v", "w", "theta", "q", "T", "p")
 _CPROG_FIELDS = ("rho_d", "rho_u", "rho_v", "rho_w", "rho_theta", "rho_q")
 _SUBSTEPPER_FIELDS = ("exner", "potential_temperature", "gamma_R_mixture", "density_perturbation",
@@ -92,6 +99,7 @@ SYMBOLS = {
                             C.POINTER(bz_reference_state), C.c_int]),
     "bz_destroy": (None, [_ctx]),
     "bz_set_formulation": (C.c_int, [_ctx, C.c_int]),
+    "bz_set_saturation_adjustment": (C.c_int, [_ctx, C.POINTER(bz_saturation_adjustment), C.c_void_p, C.c_void_p]),
     "bz_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "bz_sync": (C.c_int, [_ctx]),
     "bz_last_error": (C.c_char_p, [_ctx]),

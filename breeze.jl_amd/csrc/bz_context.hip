@@ -90,6 +90,33 @@ extern "C" int bz_set_formulation(bz_ctx *ctx, int formulation)
     return BZ_OK;
 }
 
+// microphysics = SaturationAdjustment(equilibrium = WarmPhaseEquilibrium(), solver = SecantSolver(abstol, maxiter))
+// (src/Microphysics/saturation_adjustment.jl:20-60); params == NULL switches back to microphysics = nothing.
+extern "C" int bz_set_saturation_adjustment(bz_ctx *ctx, const bz_saturation_adjustment *params, double *q_vapor,
+                                            double *q_liquid)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    DevGrid &g = ctx->dg;
+    if (!params) { g.microphysics = 0; g.qv_field = g.ql_field = nullptr; return BZ_OK; }
+    if (!q_vapor || !q_liquid || params->maxiter < 0) return BZ_ERR_INVALID;
+    if (ctx->compressible || g.formulation != 0) {
+        ctx->last_error = "saturation adjustment is implemented for the anelastic potential-temperature formulation";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    g.microphysics = 1;
+    g.sa_Ll = params->liquid_latent_heat;
+    g.sa_cl = params->liquid_heat_capacity;
+    g.sa_dc = ctx->constants.vapor_heat_capacity - params->liquid_heat_capacity;
+    g.sa_L0 = params->liquid_latent_heat - g.sa_dc * params->energy_reference_temperature;
+    g.sa_Ttr = params->triple_point_temperature;
+    g.sa_ptr = params->triple_point_pressure;
+    g.sa_abstol = params->abstol;
+    g.sa_maxiter = params->maxiter;
+    g.qv_field = q_vapor;
+    g.ql_field = q_liquid;
+    return BZ_OK;
+}
+
 extern "C" int bz_sync(bz_ctx *ctx)
 {
     if (!ctx) return BZ_ERR_INVALID;
@@ -195,6 +222,8 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     auto dcol = [&](int c) { return ctx->d_columns + (size_t)c * nf + Hz; };
     g.dzc = dcol(C_DZC); g.dzf = dcol(C_DZF); g.rdzf = dcol(C_RDZF); g.rdzc = dcol(C_RDZC); g.zc = dcol(C_ZC);
     g.formulation = 0;
+    g.microphysics = 0; g.sa_maxiter = 0; g.qv_field = nullptr; g.ql_field = nullptr;
+    g.sa_Ll = g.sa_cl = g.sa_dc = g.sa_L0 = g.sa_Ttr = g.sa_ptr = g.sa_abstol = 0.0;
     g.Ax = dcol(C_AX); g.Ay = dcol(C_AY);
     g.Vinv_c = dcol(C_VIC); g.Vinv_f = dcol(C_VIF);
     g.rho = dcol(C_RHO); g.rho_f = dcol(C_RHOF);

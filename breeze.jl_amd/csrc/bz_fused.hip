@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const double qd = 1.0 - q;
     const double Rm = qd * g.Rd + q * g.Rv;
     const double cpm = qd * g.cpd + q * g.cpv;
-    const double T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : pow(g.p_r[k] / g.pst, Rm / cpm) * th;
+    double T, qvv = 0.0, qll = 0.0;
+    if (g.microphysics == 1) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
+    else T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : pow(g.p_r[k] / g.pst, Rm / cpm) * th;
 
     st_img(F.phi, n, p, ox, oy);
     st_img(F.ru, n, ru, ox, oy);
@@ -140,6 +142,10 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     st_img(F.theta, n, th, ox, oy);
     st_img(F.q, n, q, ox, oy);
     st_img(F.T, n, T, ox, oy);
+    if (g.microphysics == 1) {
+        st_img(g.qv_field, n, qvv, ox, oy);
+        st_img(g.ql_field, n, qll, ox, oy);
+    }
     st_img_only(F.rtheta, n, rth, ox, oy);
     st_img_only(F.rq, n, rq, ox, oy);
     if (!bot) {      // wall face k = 0 keeps rho_w = w = 0
@@ -157,6 +163,10 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
         st_img(F.theta, n + h, th, ox, oy);
         st_img(F.q, n + h, q, ox, oy);
         st_img(F.T, n + h, T, ox, oy);
+        if (g.microphysics == 1) {
+            st_img(g.qv_field, n + h, qvv, ox, oy);
+            st_img(g.ql_field, n + h, qll, ox, oy);
+        }
         st_img(F.rtheta, n + h, rth, ox, oy);
         st_img(F.rq, n + h, rq, ox, oy);
         if (top) {

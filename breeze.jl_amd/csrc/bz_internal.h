@@ -28,6 +28,11 @@ struct DevGrid {
     const double *p_r, *T_r;
     double g, Rd, Rv, cpd, cpv, pst;
     int formulation;       // 0: liquid-ice potential temperature (theta), 1: static energy (e) in the `theta` slots
+    // microphysics = SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) (bz_set_saturation_adjustment)
+    int microphysics;      // 0: nothing (q = q^v), 1: warm-phase saturation adjustment (q = q^e; q^v, q^l diagnosed)
+    int sa_maxiter;
+    double sa_Ll, sa_cl, sa_dc, sa_L0, sa_Ttr, sa_ptr, sa_abstol;   // dc = cpv - cl, L0 = Ll - dc * T_energy
+    double *qv_field, *ql_field;                                     // model.microphysical_fields.q^v, q^l (parents)
     int wrap_y;            // 1: y halos are this rank's own periodic images; 0: y-slab, halos filled by the neighbour ranks
 
     __host__ __device__ inline long long idx(int i, int j, int k) const {
@@ -55,6 +60,70 @@ __device__ __forceinline__ double bz_rk_apply(int mode, double dt, double alpha,
     if (mode == 1) { u0_out[n] = uold; u0v = uold; }
     else u0v = u0[n];
     return oma * u0v + alpha * (uold + dt * G);
+}
+#endif
+
+#ifdef __HIPCC__
+// ---- moist thermodynamics shared by the diagnosis and buoyancy kernels -----------------------------------------------
+// anelastic buoyancy -g rho' with rho' = rho_r (R_m,r T_r / (R_m T) - 1)  (anelastic_buoyancy.jl:36-72); the moisture
+// fractions come from grid_moisture_fractions: (q, 0) without microphysics, (q^v, q^l) fields with saturation adjustment.
+__device__ __forceinline__ double bz_buoyancy(const DevGrid &g, const double *__restrict__ T, const double *__restrict__ q,
+                                              long long n, int k)
+{
+    double qv, ql = 0.0;
+    if (g.microphysics) { qv = g.qv_field[n]; ql = g.ql_field[n]; }
+    else qv = q[n];
+    const double Rm = (1.0 - (qv + ql)) * g.Rd + qv * g.Rv;
+    const double rhop = g.rho[k] * (g.Rd * g.T_r[k] / (Rm * T[n]) - 1.0);
+    return -g.g * rhop;
+}
+// Warm-phase saturation adjustment of a liquid-ice potential temperature state (saturation_adjustment.jl:168-235 with
+// clausius_clapeyron.jl:59-68, vapor_saturation.jl:250-256, Solvers.jl:243-262): returns T, sets qv, ql.
+__device__ __forceinline__ double bz_sa_psat(const DevGrid &g, double T)
+{
+    return g.sa_ptr * pow(T / g.sa_Ttr, g.sa_dc / g.Rv) * exp((1.0 / g.sa_Ttr - 1.0 / T) * g.sa_L0 / g.Rv);
+}
+__device__ __forceinline__ double bz_sa_T(const DevGrid &g, double th, double qv, double ql, double pr)
+{
+    const double qd = 1.0 - (qv + ql);
+    const double cpm = qd * g.cpd + qv * g.cpv + ql * g.sa_cl;
+    return pow(pr / g.pst, (qd * g.Rd + qv * g.Rv) / cpm) * th + (g.sa_Ll * ql) / cpm;
+}
+__device__ __forceinline__ void bz_sa_adjust(const DevGrid &g, double T, double qt, double pr, double &qv, double &ql)
+{
+    const double ps = bz_sa_psat(g, T);
+    const double qs = (g.Rd / g.Rv) * (1.0 - qt) * ps / (pr - ps);
+    ql = fmax(0.0, qt - qs);
+    qv = qt - ql;
+}
+__device__ __forceinline__ double bz_sa_residual(const DevGrid &g, double T, double th, double qt, double pr)
+{
+    double qv, ql;
+    bz_sa_adjust(g, T, qt, pr, qv, ql);
+    return T - bz_sa_T(g, th, qv, ql, pr);
+}
+__device__ __forceinline__ double bz_sa_diagnose(const DevGrid &g, double th, double qt, double pr, double &qv, double &ql)
+{
+    qv = qt; ql = 0.0;
+    const double T1 = bz_sa_T(g, th, qt, 0.0, pr);
+    if (th == 0.0) return T1;
+    const double rho1 = pr / (((1.0 - qt) * g.Rd + qt * g.Rv) * T1);
+    if (qt <= bz_sa_psat(g, T1) / (rho1 * g.Rv * T1)) return T1;
+    double qv1, ql1;
+    bz_sa_adjust(g, T1, qt, pr, qv1, ql1);
+    const double dT = (g.sa_Ll * ql1) / ((1.0 - (qv1 + ql1)) * g.cpd + qv1 * g.cpv + ql1 * g.sa_cl);
+    double x1 = T1, x2 = T1 + fmax(0.01, dT / 2.0);
+    double r1 = bz_sa_residual(g, x1, th, qt, pr), r2 = bz_sa_residual(g, x2, th, qt, pr);
+    for (int it = 0; it < g.sa_maxiter && fabs(r2) > g.sa_abstol; ++it) {
+        double s = (x2 - x1) / (r2 - r1);
+        const bool valid = isfinite(s);
+        s = valid ? s : 0.0;
+        x1 = x2; r1 = r2;
+        x2 -= r2 * s;
+        r2 = valid ? bz_sa_residual(g, x2, th, qt, pr) : 0.0;
+    }
+    bz_sa_adjust(g, x2, qt, pr, qv, ql);
+    return bz_sa_T(g, th, qv, ql, pr);
 }
 #endif
 

@@ -44,6 +44,13 @@ __global__ __launch_bounds__(TX *TY) void k_thermo(DevGrid g, double *__restrict
         T[n] = (th - g.g * g.zc[k]) / cpm;
         return;
     }
+    if (g.microphysics == 1) {      // maybe_adjust_thermodynamic_state(SaturationAdjustment) + update_microphysical_fields!
+        double qvv, qll;
+        T[n] = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
+        g.qv_field[n] = qvv;
+        g.ql_field[n] = qll;
+        return;
+    }
     double Pi = pow(g.p_r[k] / g.pst, Rm / cpm);
     T[n] = Pi * th;
 }
@@ -149,9 +156,9 @@ extern "C" int bz_compute_auxiliary_thermodynamic_variables(bz_ctx *ctx, const b
                            s->rho_theta, s->rho_q);
         BZ_LAUNCH_CHECK();
     }
-    double *f[3] = {s->T, s->q, s->theta};
-    int kd[3] = {0, 0, 0};
-    return bzi_fill_halos_multi(ctx, f, kd, 3);
+    double *f[5] = {s->T, s->q, s->theta, g.qv_field, g.ql_field};
+    int kd[5] = {0, 0, 0, 0, 0};
+    return bzi_fill_halos_multi(ctx, f, kd, g.microphysics ? 5 : 3);
 }
 
 extern "C" int bz_store_initial_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0)

@@ -234,12 +234,12 @@ __global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__re
     // ring of w around centre k-1 (faces k-3 .. k+2) to start; centre k needs faces k-2..k+3
     double zm3 = w[n - 3 * sz], zm2 = w[n - 2 * sz], zm1 = w[n - sz], z0 = w[n], zp1 = w[n + sz], zp2 = w[n + 2 * sz];
     double Fz_lo = flux_Ww(g, rw, n - sz, k0 - 1, zm3, zm2, zm1, z0, zp1, zp2);
-    double b_lo = buoyancy_ccc(g, T[n - sz], qv[n - sz], k0 - 1);
+    double b_lo = bz_buoyancy(g, T, qv, n - sz, k0 - 1);
 
     for (int k = k0; k < k1; ++k, n += sz) {
         double zp3 = w[n + 3 * sz];
         double Fz_hi = flux_Ww(g, rw, n, k, zm2, zm1, z0, zp1, zp2, zp3);
-        double b_hi = buoyancy_ccc(g, T[n], qv[n], k);
+        double b_hi = bz_buoyancy(g, T, qv, n, k);
         const int Bf = bz_buffer_face(k, g.Nz);
 
         // x: F_Uw at x-faces i (lo), i+1 (hi): advecting flux = centred-in-z of Ax(k)*rho_u to face k
@@ -272,9 +272,9 @@ __global__ __launch_bounds__(256) void k_energy_buoyancy_flux(DevGrid g, double 
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k), sz = g.Sxy;
-    const double b_m = buoyancy_ccc(g, T[n - sz], qv[n - sz], k - 1);
-    const double b_0 = buoyancy_ccc(g, T[n], qv[n], k);
-    const double b_p = buoyancy_ccc(g, T[n + sz], qv[n + sz], k + 1);
+    const double b_m = bz_buoyancy(g, T, qv, n - sz, k - 1);
+    const double b_0 = bz_buoyancy(g, T, qv, n, k);
+    const double b_p = bz_buoyancy(g, T, qv, n + sz, k + 1);
     const double f_lo = ((b_0 + b_m) / 2.0) * w[n];
     const double f_hi = ((b_p + b_0) / 2.0) * w[n + sz];
     Ge[n] = Ge[n] - (f_hi + f_lo) / 2.0;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * TYW) void k_tend3(DevGrid g, Tend3Fields F, in
         for (int s = 0; s < 6; ++s) ring[r][s] = c[n + (s - 3) * sz];
         if constexpr (KIND == T3_W) {
             fz_lo[r] = vflux<KIND>(g, F, n - sz, kbeg - 1, ring[r][0], ring[r][1], ring[r][2], ring[r][3], ring[r][4], ring[r][5]);
-            b_lo[r] = buoyancy3(g, F.T[n - sz], F.q[n - sz], kbeg - 1);
+            b_lo[r] = bz_buoyancy(g, F.T, F.q, n - sz, kbeg - 1);
         } else {
             fz_lo[r] = vflux<KIND>(g, F, n, kbeg, ring[r][0], ring[r][1], ring[r][2], ring[r][3], ring[r][4], ring[r][5]);
             b_lo[r] = 0.0;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * TYW) void k_tend3(DevGrid g, Tend3Fields F, in
             double fz_hi, b_hi = 0.0;
             if constexpr (KIND == T3_W) {
                 fz_hi = vflux<KIND>(g, F, n, k, ring[r][1], ring[r][2], ring[r][3], ring[r][4], ring[r][5], t);
-                b_hi = buoyancy3(g, F.T[n], F.q[n], k);
+                b_hi = bz_buoyancy(g, F.T, F.q, n, k);
             } else {
                 fz_hi = vflux<KIND>(g, F, n + sz, k + 1, ring[r][1], ring[r][2], ring[r][3], ring[r][4], ring[r][5], t);
             }
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * TYW) void k_w_tend_ring(DevGrid g, Tend3Fields
         const int B = bz_buffer_center(kbeg - 1, g.Nz);
         const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
         fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
-        b_lo = buoyancy3(g, F.T[n - sz], F.q[n - sz], kbeg - 1);
+        b_lo = bz_buoyancy(g, F.T, F.q, n - sz, kbeg - 1);
     }
     double edge = 0.0;
 
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * TYW) void k_w_tend_ring(DevGrid g, Tend3Fields
             const double hi = v1 * bz_up5(m2, m1, w0, p1, p2, p3, v1 > 0.0);
             dy = hi - lo;
         }
-        const double b_hi = buoyancy3(g, F.T[n], F.q[n], k);
+        const double b_hi = bz_buoyancy(g, F.T, F.q, n, k);
         if (store)
             F.G[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
                                  -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo))) + 0.5 * (b_lo + b_hi), rw[n], n);

@@ -84,7 +84,8 @@ _LOC = {"ccc": (Center, Center, Center), "fcc": (Face, Center, Center),
 _ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "ρθ": "ρθ", "rho_theta": "ρθ", "e": "e", "ρe": "ρe", "rho_e": "ρe",
             "u": "u", "v": "v", "w": "w", "ρu": "ρu", "ρv": "ρv", "ρw": "ρw",
             "rho_u": "ρu", "rho_v": "ρv", "rho_w": "ρw",
-            "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q", "ρqᵗ": "ρq", "ρqᵛ": "ρq", "rho_q": "ρq",
+            "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q", "qᵉ": "q", "qe": "q", "ρqᵗ": "ρq", "ρqᵛ": "ρq", "ρqᵉ": "ρq", "ρqe": "ρq",
+            "rho_q": "ρq",
             # NFKC-normalised spellings (Python normalises identifiers used as keywords)
             "θli": "θ", "ρqt": "ρq", "ρqv": "ρq"}
 
@@ -110,10 +111,15 @@ class AtmosphereModel:
         self.formulation = formulation
         if timestepper not in ("SSPRungeKutta3", ":SSPRungeKutta3"):
             raise NotImplementedError("only SSPRungeKutta3 is implemented")
-        for name, val in (("closure", closure), ("coriolis", coriolis), ("microphysics", microphysics),
-                          ("forcing", forcing)):
+        for name, val in (("closure", closure), ("coriolis", coriolis), ("forcing", forcing)):
             if val is not None:
                 raise NotImplementedError(f"{name} is outside the hot-path scope of this build")
+        from .microphysics import SaturationAdjustment
+        if microphysics is not None and not isinstance(microphysics, SaturationAdjustment):
+            raise NotImplementedError("microphysics: only SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) is implemented")
+        if microphysics is not None and formulation != "LiquidIcePotentialTemperature":
+            raise NotImplementedError("SaturationAdjustment is implemented for the potential-temperature formulation")
+        self.microphysics = microphysics
         if advection is None:
             raise NotImplementedError("the HIP path requires advection=WENO(order=5) "
                                       "(the reference default Centered(order=2) is not implemented)")
@@ -174,6 +180,18 @@ class AtmosphereModel:
                     "bz_set_stream")
         if formulation == "StaticEnergy":
             self._check(lib.bz_set_formulation(self._ctx, 1), "bz_set_formulation")
+        # materialize_microphysical_fields(::WarmPhaseSaturationAdjustment): (q^v, q^l, q^e); q^e is the specific moisture slot
+        self.microphysical_fields = {}
+        if microphysics is not None:
+            self.microphysical_fields = {"qᵛ": fld("ccc"), "qˡ": fld("ccc"), "qᵉ": self.specific_moisture}
+            sa = _lib.bz_saturation_adjustment(c.liquid_reference_latent_heat, c.liquid_heat_capacity,
+                                               c.energy_reference_temperature, c.triple_point_temperature,
+                                               c.triple_point_pressure, microphysics.solver.abstol,
+                                               microphysics.solver.maxiter, 0)
+            self._check(lib.bz_set_saturation_adjustment(self._ctx, C.byref(sa),
+                                                         C.c_void_p(self.microphysical_fields["qᵛ"].ptr()),
+                                                         C.c_void_p(self.microphysical_fields["qˡ"].ptr())),
+                        "bz_set_saturation_adjustment")
         self._state = self._make_state()
         self._U0 = self._make_prog(self.U0)
         self._G = self._make_prog(self.G)

@@ -9,7 +9,9 @@ class ThermodynamicConstants:
     def __init__(self, molar_gas_constant=8.314462618, gravitational_acceleration=9.81,
                  energy_reference_temperature=273.15, triple_point_temperature=273.16,
                  triple_point_pressure=611.657, dry_air_molar_mass=0.02897, dry_air_heat_capacity=1005,
-                 vapor_molar_mass=0.018015, vapor_heat_capacity=1850):
+                 vapor_molar_mass=0.018015, vapor_heat_capacity=1850,
+                 liquid_reference_latent_heat=2500800, liquid_heat_capacity=4181,
+                 ice_reference_latent_heat=2834000, ice_heat_capacity=2108):
         self.molar_gas_constant = float(molar_gas_constant)
         self.gravitational_acceleration = float(gravitational_acceleration)
         self.energy_reference_temperature = float(energy_reference_temperature)
@@ -19,6 +21,11 @@ class ThermodynamicConstants:
         self.dry_air_heat_capacity = float(dry_air_heat_capacity)
         self.vapor_molar_mass = float(vapor_molar_mass)
         self.vapor_heat_capacity = float(vapor_heat_capacity)
+        # CondensedPhase liquid_water / water_ice (thermodynamics_constants.jl:87-93)
+        self.liquid_reference_latent_heat = float(liquid_reference_latent_heat)
+        self.liquid_heat_capacity = float(liquid_heat_capacity)
+        self.ice_reference_latent_heat = float(ice_reference_latent_heat)
+        self.ice_heat_capacity = float(ice_heat_capacity)
 
 
 def dry_air_gas_constant(c):

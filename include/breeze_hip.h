@@ -104,6 +104,20 @@ void bz_destroy(bz_ctx *ctx);
  * static_energy_tendency.jl:39-72).  With 1 the `rho_theta` / `theta` slots of bz_state and bz_prognostic carry
  * energy_density (rho e) / specific_energy (e): T = (e - g z)/c_pm and G_rho_e = -div_rhoUc(e) - Iz(w * Iz(buoyancy)). */
 int bz_set_formulation(bz_ctx *ctx, int formulation);
+/* microphysics = SaturationAdjustment(equilibrium = WarmPhaseEquilibrium(), solver = SecantSolver(abstol, maxiter))
+ * (src/Microphysics/saturation_adjustment.jl:20-60,82-86,168-235): the moisture prognostic is the equilibrium moisture
+ * rho q^e (bz_state.rho_q / q), T comes from the secant iteration on the adjusted state, and q^v, q^l are diagnosed into
+ * model.microphysical_fields.q^v / q^l (device parent arrays given here), which the buoyancy then reads
+ * (grid_moisture_fractions, :127-131).  Constants: liquid CondensedPhase, energy reference temperature and triple point of
+ * ThermodynamicConstants (src/Thermodynamics/thermodynamics_constants.jl:92,182-194).  params == NULL: microphysics = nothing. */
+typedef struct bz_saturation_adjustment {
+    double liquid_latent_heat, liquid_heat_capacity;
+    double energy_reference_temperature, triple_point_temperature, triple_point_pressure;
+    double abstol;            /* SecantSolver abstol (default 1e-4), reltol = 0 */
+    int32_t maxiter;          /* default 20 */
+    int32_t reserved;
+} bz_saturation_adjustment;
+int bz_set_saturation_adjustment(bz_ctx *ctx, const bz_saturation_adjustment *params, double *q_vapor, double *q_liquid);
 int bz_set_stream(bz_ctx *ctx, void *hip_stream);
 int bz_sync(bz_ctx *ctx);
 const char *bz_last_error(const bz_ctx *ctx);

@@ -665,3 +665,128 @@ void og_energy_buoyancy_flux(const og_grid *G, double *Ge, const double *w, cons
                 Ge[n] = Ge[n] - (f_hi + f_lo) / 2.0;
             }
 }
+
+/* ------------------------------------------------------------------------- */
+/* Warm-phase SaturationAdjustment                        */
+/*   _compute_auxiliary_thermodynamic_variables! with                        */
+/*   maybe_adjust_thermodynamic_state  (update_atmosphere_model_state.jl:256-292, */
+/*   src/Microphysics/saturation_adjustment.jl:82-86,121-126,168-235),          */
+/*   Clausius-Clapeyron (src/Thermodynamics/clausius_clapeyron.jl:59-68),      */
+/*   secant_solve (src/Solvers.jl:243-262).  Scalar twin: oracle/thermo.py.    */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    double Ll, cl;          /* liquid reference latent heat, heat capacity */
+    double T_energy;        /* energy_reference_temperature */
+    double Ttr, ptr;        /* triple point */
+    double abstol;          /* SecantSolver(abstol, reltol = 0) */
+    int maxiter;
+} og_sa;
+
+static inline double sa_psat(const og_grid *G, const og_sa *S, double T)
+{
+    double dc = G->cpv - S->cl;
+    double L0 = S->Ll - dc * S->T_energy;
+    return S->ptr * pow(T / S->Ttr, dc / G->Rv) * exp((1.0 / S->Ttr - 1.0 / T) * L0 / G->Rv);
+}
+static inline double sa_Rm(const og_grid *G, double qv, double ql) { return (1.0 - (qv + ql + 0.0)) * G->Rd + qv * G->Rv; }
+static inline double sa_cpm(const og_grid *G, const og_sa *S, double qv, double ql)
+{
+    return (1.0 - (qv + ql + 0.0)) * G->cpd + qv * G->cpv + ql * S->cl + 0.0;
+}
+static inline double sa_T(const og_grid *G, const og_sa *S, double th, double qv, double ql, double pr)
+{
+    double cpm = sa_cpm(G, S, qv, ql);
+    return pow(pr / G->p_st, sa_Rm(G, qv, ql) / cpm) * th + (S->Ll * ql + 0.0) / cpm;
+}
+static inline void sa_adjust(const og_grid *G, const og_sa *S, double T, double qt, double pr, double *qv, double *ql)
+{
+    double ps = sa_psat(G, S, T);
+    double qs = (G->Rd / G->Rv) * (1.0 - qt) * ps / (pr - ps);
+    *ql = fmax(0.0, qt - qs);
+    *qv = qt - *ql;
+}
+static inline double sa_residual(const og_grid *G, const og_sa *S, double T, double th, double qt, double pr)
+{
+    double qv, ql;
+    sa_adjust(G, S, T, qt, pr, &qv, &ql);
+    return T - sa_T(G, S, th, qv, ql, pr);
+}
+
+void og_compute_thermo_sa(const og_grid *G, const og_sa *S, double *theta, double *qe, double *qv_out, double *ql_out,
+                          double *T, const double *rtheta, const double *rq)
+{
+    const double *rho = G->rho_r + G->Hz, *prc = G->p_r + G->Hz;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < G->Nz; ++k)
+        for (int j = 0; j < G->Ny; ++j)
+            for (int i = 0; i < G->Nx; ++i) {
+                size_t n = IDX(G, i, j, k);
+                double th = rtheta[n] / rho[k];
+                double qt = rq[n] / rho[k];
+                double pr = prc[k];
+                theta[n] = th;
+                qe[n] = qt;
+                double qv = qt, ql = 0.0, Tn;
+                if (th == 0.0) {
+                    Tn = sa_T(G, S, th, qt, 0.0, pr);
+                } else {
+                    double T1 = sa_T(G, S, th, qt, 0.0, pr);
+                    double rho1 = pr / (sa_Rm(G, qt, 0.0) * T1);
+                    double qs1 = sa_psat(G, S, T1) / (rho1 * G->Rv * T1);
+                    if (qt <= qs1) {
+                        Tn = T1;
+                    } else {
+                        double qv1, ql1;
+                        sa_adjust(G, S, T1, qt, pr, &qv1, &ql1);
+                        double dT = (S->Ll * ql1 + 0.0) / sa_cpm(G, S, qv1, ql1);
+                        double x1 = T1, x2 = T1 + fmax(0.01, dT / 2.0);
+                        double r1 = sa_residual(G, S, x1, th, qt, pr), r2 = sa_residual(G, S, x2, th, qt, pr);
+                        int it = 0;
+                        while (fabs(r2) > fmax(S->abstol, 0.0 * fabs(x2)) && it < S->maxiter) {
+                            double s = (x2 - x1) / (r2 - r1);
+                            int valid = isfinite(s);
+                            s = valid ? s : 0.0;
+                            x1 = x2; r1 = r2;
+                            x2 -= r2 * s;
+                            r2 = sa_residual(G, S, x2, th, qt, pr);
+                            r2 = valid ? r2 : 0.0;
+                            ++it;
+                        }
+                        sa_adjust(G, S, x2, qt, pr, &qv, &ql);
+                        Tn = sa_T(G, S, th, qv, ql, pr);
+                    }
+                }
+                qv_out[n] = qv;
+                ql_out[n] = ql;
+                T[n] = Tn;
+            }
+}
+
+/* z-momentum tendency with the moist mixture gas constant R_m = q_d Rd + q_v Rv, q_d = 1 - q_v - q_l
+ * (anelastic_buoyancy.jl:36-72 with grid_moisture_fractions of SaturationAdjustment, saturation_adjustment.jl:127-131) */
+static inline double buoyancy_ccc_moist(const og_grid *G, const double *T, const double *qv, const double *ql, int i, int j, int k)
+{
+    size_t n = IDX(G, i, j, k);
+    double rho_r = G->rho_r[k + G->Hz], Tr = G->T_r[k + G->Hz];
+    double Rmr = (1.0 - (0.0 + 0.0 + 0.0)) * G->Rd + 0.0 * G->Rv;
+    double Rm = (1.0 - (qv[n] + ql[n] + 0.0)) * G->Rd + qv[n] * G->Rv;
+    double rhop = rho_r * (Rmr * Tr / (Rm * T[n]) - 1.0);
+    return -G->g * rhop;
+}
+
+void og_w_tendency_moist(const og_grid *G, double *Gw, const double *ru, const double *rv, const double *rw,
+                         const double *w, const double *T, const double *qv, const double *ql)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k < G->Nz; ++k)
+        for (int j = 0; j < G->Ny; ++j)
+            for (int i = 0; i < G->Nx; ++i) {
+                double Vinv = 1.0 / (G->dx * G->dy * G->dzf[k + G->Hz]);
+                double a = 0.0, b = 0.0, c = 0.0;
+                if (G->tx != FLAT) a = F_Uw(G, ru, w, i + 1, j, k) - F_Uw(G, ru, w, i, j, k);
+                if (G->ty != FLAT) b = F_Vw(G, rv, w, i, j + 1, k) - F_Vw(G, rv, w, i, j, k);
+                c = F_Ww(G, rw, w, i, j, k) - F_Ww(G, rw, w, i, j, k - 1);
+                double bf = 0.5 * (buoyancy_ccc_moist(G, T, qv, ql, i, j, k - 1) + buoyancy_ccc_moist(G, T, qv, ql, i, j, k));
+                Gw[IDX(G, i, j, k)] = -(Vinv * (a + b + c)) + bf;
+            }
+}

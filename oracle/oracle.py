@@ -57,6 +57,11 @@ class _OGGrid(C.Structure):
                 ("cpd", C.c_double), ("cpv", C.c_double), ("p_st", C.c_double)]
 
 
+class _OGSA(C.Structure):
+    _fields_ = [("Ll", C.c_double), ("cl", C.c_double), ("T_energy", C.c_double), ("Ttr", C.c_double),
+                ("ptr", C.c_double), ("abstol", C.c_double), ("maxiter", C.c_int)]
+
+
 _lib = None
 
 
@@ -250,11 +255,16 @@ class OracleModel:
 
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
                  standard_pressure=1e5, reference_density=None, initialize=True,
-                 formulation="LiquidIcePotentialTemperature"):
+                 formulation="LiquidIcePotentialTemperature", microphysics=None, sa_abstol=1e-4, sa_maxiter=20):
         # formulation "StaticEnergy": self.theta holds e, self.rtheta holds rho*e
         # (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21)
         assert formulation in ("LiquidIcePotentialTemperature", "StaticEnergy")
         self.formulation = formulation
+        # microphysics "SaturationAdjustment": SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()); self.q / self.rq
+        # then hold the equilibrium (total) moisture q^e / rho q^e, self.qv / self.ql the diagnosed vapour and liquid
+        assert microphysics in (None, "SaturationAdjustment")
+        assert not (microphysics and formulation == "StaticEnergy"), "oracle: saturation adjustment with theta only"
+        self.microphysics = microphysics
         self.grid = g = grid
         self.constants = c = constants or Constants()
         self.ref = ReferenceState(g, c, surface_pressure, potential_temperature, standard_pressure)
@@ -264,6 +274,10 @@ class OracleModel:
             self.ref._fill(g)
         self.lib = lib()
         self._mk_cgrid()
+        self.qv, self.ql = g.center_field(), g.center_field()
+        from .thermo import ThermoConstants
+        tc = ThermoConstants()
+        self._sa = _OGSA(tc.Ll, tc.cl, tc.T_energy, tc.Ttr, tc.ptr, float(sa_abstol), int(sa_maxiter))
         zc_halo = np.zeros(g.Szc)
         zc_halo[g.Hz:g.Hz + g.Nz] = g.zc
         self._zc_halo = zc_halo
@@ -388,7 +402,12 @@ class OracleModel:
         self.lib.og_compute_velocities(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv), _p(self.rw))
         for f in (self.u, self.v, self.w):
             self._halo_velocity(f)
-        if self.formulation == "StaticEnergy":
+        if self.microphysics == "SaturationAdjustment":
+            self.lib.og_compute_thermo_sa(cg, C.byref(self._sa), _p(self.theta), _p(self.q), _p(self.qv), _p(self.ql),
+                                          _p(self.T), _p(self.rtheta), _p(self.rq))
+            self._halo_center(self.qv)
+            self._halo_center(self.ql)
+        elif self.formulation == "StaticEnergy":
             self.lib.og_compute_thermo_energy(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.rtheta), _p(self.rq),
                                               _p(self._zc_halo))
         else:
@@ -403,7 +422,11 @@ class OracleModel:
         L, G = self.lib, self.G
         L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
         L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
-        L.og_w_tendency(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w), _p(self.T), _p(self.q))
+        if self.microphysics == "SaturationAdjustment":
+            L.og_w_tendency_moist(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w), _p(self.T),
+                                  _p(self.qv), _p(self.ql))
+        else:
+            L.og_w_tendency(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w), _p(self.T), _p(self.q))
         L.og_scalar_tendency(cg, _p(G["rtheta"]), _p(self.u), _p(self.v), _p(self.w), _p(self.theta))
         L.og_scalar_tendency(cg, _p(G["rq"]), _p(self.u), _p(self.v), _p(self.w), _p(self.q))
         if self.formulation == "StaticEnergy":

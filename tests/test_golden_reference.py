@@ -69,3 +69,29 @@ def test_warm_phase_adjustment_recovers_constructed_saturated_states(thermo):
     # unsaturated parcel: temperature is the dry-exner one, no liquid
     T, qv, ql = thermo.adjust_warm_phase(300.0, 1e-3, pr, pst, c)
     assert ql == 0.0 and qv == 1e-3 and T == thermo.theta_state_temperature(300.0, 1e-3, 0.0, pr, pst, c)
+
+
+def test_field_level_adjustment_matches_scalar_restatement(oracle, thermo):
+    """The C field kernel of the oracle (og_compute_thermo_sa) against oracle/thermo.py cell by cell, on a column that is
+    unsaturated aloft and cloudy below; warm bubble with SaturationAdjustment runs and keeps q^e = qv + ql."""
+    import numpy as np
+    g = oracle.Grid((8, 8, 16), x=(0, 8e3), y=(0, 8e3), z=(0, 4e3))
+    m = oracle.OracleModel(g, potential_temperature=295.0, microphysics="SaturationAdjustment")
+    qt = lambda x, y, z: 0.018 * np.exp(-z / 2500.0) * (1 + 0.1 * np.sin(2 * np.pi * x / 8e3)) + 0 * y
+    m.set(qt=qt, theta=lambda x, y, z: 295.0 + 0.003 * z + 0 * x + 0 * y)
+    I = g.interior
+    c = thermo.ThermoConstants()
+    pr = m.ref.pressure[g.Hz:g.Hz + g.Nz]
+    n_cloudy = 0
+    for k in range(g.Nz):
+        for i in (0, 3):
+            T, qv, ql = thermo.adjust_warm_phase(I(m.theta)[k, 2, i], I(m.q)[k, 2, i], pr[k], m.ref.pst, c)
+            assert abs(T - I(m.T)[k, 2, i]) <= 1e-12 * T
+            assert abs(qv - I(m.qv)[k, 2, i]) <= 1e-15 and abs(ql - I(m.ql)[k, 2, i]) <= 1e-15
+            n_cloudy += ql > 0
+    assert 0 < n_cloudy < 2 * g.Nz
+    np.testing.assert_allclose(I(m.qv) + I(m.ql), I(m.q), rtol=1e-15)
+    for _ in range(3):
+        m.time_step(2.0)
+    assert np.isfinite(I(m.T)).all() and (I(m.ql) >= 0).all()
+    np.testing.assert_allclose(I(m.qv) + I(m.ql), I(m.q), rtol=1e-14)

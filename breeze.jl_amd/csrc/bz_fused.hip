@@ -98,6 +98,7 @@ struct PDFields {
     const double *phi_below;                // y-slab only: phi of row j = -1 (neighbour rank), layout [k][i]
 };
 
+template <bool SA>      // SA: warm-phase saturation adjustment in the temperature diagnosis
 __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F, double dt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const double Rm = qd * g.Rd + q * g.Rv;
     const double cpm = qd * g.cpd + q * g.cpv;
     double T, qvv = 0.0, qll = 0.0;
-    if (g.microphysics == 1) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
+    if (SA) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
     else T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : pow(g.p_r[k] / g.pst, Rm / cpm) * th;
 
     st_img(F.phi, n, p, ox, oy);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     st_img(F.theta, n, th, ox, oy);
     st_img(F.q, n, q, ox, oy);
     st_img(F.T, n, T, ox, oy);
-    if (g.microphysics == 1) {
+    if (SA) {
         st_img(g.qv_field, n, qvv, ox, oy);
         st_img(g.ql_field, n, qll, ox, oy);
     }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
         st_img(F.theta, n + h, th, ox, oy);
         st_img(F.q, n + h, q, ox, oy);
         st_img(F.T, n + h, T, ox, oy);
-        if (g.microphysics == 1) {
+        if (SA) {
             st_img(g.qv_field, n + h, qvv, ox, oy);
             st_img(g.ql_field, n + h, qll, ox, oy);
         }
@@ -224,7 +225,10 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double
     F.phi_c = phi_c ? phi_c : ctx->d_rhs;
     F.phi_below = phi_below;
     dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
-    hipLaunchKernelGGL(k_project_diagnose, grid, block, 0, ctx->stream, g, F, dt);
+    if (g.microphysics == 1)
+        hipLaunchKernelGGL((k_project_diagnose<true>), grid, block, 0, ctx->stream, g, F, dt);
+    else
+        hipLaunchKernelGGL((k_project_diagnose<false>), grid, block, 0, ctx->stream, g, F, dt);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -109,7 +109,11 @@ int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, 
     F.u = s->u; F.v = s->v; F.w = s->w; F.T = s->T; F.q = s->q;
     F.c = s->w; F.G = G->rho_w;
     const int nlev = g.Nz - 1;
-    if (buoyancy_mode != 0) {
+    if (buoyancy_mode == 0 && g.microphysics) {
+        const int kc = pick_chunk_lds(g, nlev, 8);
+        dim3 block(64, 8), grid((g.Nx + 63) / 64, (g.Ny + 7) / 8, (nlev + kc - 1) / kc);
+        hipLaunchKernelGGL((k_w_tend_lds<8, 3>), grid, block, 0, ctx->stream, g, F, kc, E);
+    } else if (buoyancy_mode != 0) {
         const int kc = pick_chunk_lds(g, nlev, 8);
         dim3 block(64, 8), grid((g.Nx + 63) / 64, (g.Ny + 7) / 8, (nlev + kc - 1) / kc);
         if (buoyancy_mode == 1) hipLaunchKernelGGL((k_w_tend_lds<8, 1>), grid, block, 0, ctx->stream, g, F, kc, E);

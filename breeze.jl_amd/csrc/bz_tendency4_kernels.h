@@ -292,7 +292,8 @@ __global__ __launch_bounds__(64 * TY) void k_u_tend_lds(DevGrid g, Tend3Fields F
 }
 
 // z-momentum: k_w_tend_ring with the w y-stencil in an LDS tile and shared y-face fluxes.
-// BM (buoyancy mode) 0: anelastic buoyancy from T, q;  1: none (SlowTendencyMode);  2: compressible slow vertical
+// BM (buoyancy mode) 0: anelastic buoyancy from T, q;  3: the same with the diagnosed q^v, q^l of saturation adjustment;
+// 1: none (SlowTendencyMode);  2: compressible slow vertical
 // momentum  G^s = G_adv - dz(p - p_r) - g Iz(rho - rho_r)  with F.T = pressure, F.q = total density
 // (acoustic_substepping.jl:727-752; the bottom face is never stored, the caller keeps it at 0).
 template <int TY, int BM = 0>
@@ -347,7 +348,8 @@ __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F
         const int B = bz_buffer_center(kbeg - 1, g.Nz);
         const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
         fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
-        if (BM == 0) b_lo = bz_buoyancy(g, F.T, F.q, n - sz, kbeg - 1);
+        if (BM == 0) b_lo = buoyancy3(g, F.T[n - sz], F.q[n - sz], kbeg - 1);
+        else if (BM == 3) b_lo = bz_buoyancy(g, F.T, F.q, n - sz, kbeg - 1);
         else if (BM == 2) { b_lo = F.T[n - sz] - g.p_r[kbeg - 1]; r_lo = F.q[n - sz] - g.rho[kbeg - 1]; }
         else b_lo = 0.0;
     }
@@ -394,7 +396,8 @@ __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F
         for (int q = 0; q < HPT; ++q)
             if (hok[q]) T[buf ^ 1][hr[q]][hcol[q]] = hnext[q];
         double b_hi = 0.0, r_hi = 0.0;
-        if (BM == 0) b_hi = bz_buoyancy(g, F.T, F.q, n, k);
+        if (BM == 0) b_hi = buoyancy3(g, F.T[n], F.q[n], k);
+        else if (BM == 3) b_hi = bz_buoyancy(g, F.T, F.q, n, k);
         else if (BM == 2) { b_hi = F.T[n] - g.p_r[k]; r_hi = F.q[n] - g.rho[k]; }
         // ring advance loads (level k+2)
         const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F
             const double dy = FY[buf][ty + 1][tx] - fy;
             const double adv = -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo)));
             double Gval;
-            if (BM == 0) Gval = adv + 0.5 * (b_lo + b_hi);
+            if (BM == 0 || BM == 3) Gval = adv + 0.5 * (b_lo + b_hi);
             else if (BM == 2) Gval = adv - (b_hi - b_lo) * g.rdzf[k] - g.g * ((r_hi + r_lo) / 2.0);
             else Gval = adv;
             if (store)

@@ -330,3 +330,29 @@ def test_saturation_adjustment_time_steps_match_oracle(oracle, bz):
     errs["ql"] = float(np.abs(hm.microphysical_fields["qˡ"].interior_cpu() - om.grid.interior(om.ql)).max())
     assert all(v < 1e-9 for v in errs.values()), {k: f"{v:.1e}" for k, v in errs.items()}
     assert (om.grid.interior(om.ql) > 0).any()
+
+
+def test_config0_two_dimensional_bubble_as_y_invariant_run(oracle, bz):
+    """BASELINE.json configs[0] (examples/dry_thermal_bubble.jl: 2-D (Periodic, Flat, Bounded) anelastic WENO5 bubble, the
+    reference's CPU plumbing case, README.md:67-75) at reduced size: the oracle runs it on the Flat-y grid, the device runs
+    the same problem as a y-invariant 3-D one (y fluxes cancel identically, only the k_y = 0 Poisson modes are excited)."""
+    Nx, Nz, Ny = 64, 64, 8
+    th = lambda x, y, z: 300.0 + 2.0 * np.cos(np.pi / 2 * np.minimum(1.0, np.sqrt(x ** 2 + (z - 2000.0) ** 2) / 2000.0)) ** 2 + 0 * y
+    og = oracle.Grid((Nx, Nz), x=(-10e3, 10e3), z=(0, 10e3), topology=("Periodic", "Flat", "Bounded"))
+    om = oracle.OracleModel(og, surface_pressure=101325, potential_temperature=300.0)
+    om.set(theta=th)
+    grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(-10e3, 10e3), y=(0, 2500.0), z=(0, 10e3))
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, surface_pressure=101325, potential_temperature=300)),
+                            advection=bz.WENO(order=5))
+    hm.set(θ=th)
+    for _ in range(5):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    w3, w2 = hm.velocities["w"].interior_cpu(), og.interior(om.w, True)
+    assert np.abs(w3 - w3[:, :1, :]).max() <= 1e-12 * np.abs(w3).max()          # stays y-invariant
+    assert np.abs(hm.velocities["v"].interior_cpu()).max() <= 1e-12 * np.abs(w3).max()
+    assert np.abs(w3[:, 0, :] - w2[:, 0, :]).max() / np.abs(w2).max() < 1e-9
+    th3, th2 = hm.potential_temperature.interior_cpu(), og.interior(om.theta)
+    assert np.abs(th3[:, 0, :] - th2[:, 0, :]).max() / 300.0 < 1e-12
+    assert np.abs(w2).max() > 1e-3

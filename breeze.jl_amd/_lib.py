@@ -133,6 +133,15 @@ SYMBOLS = {
     "bz_acoustic_substep_loop": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double]),
     "bz_acoustic_rk3_substep": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double]),
     "bz_time_step_compressible": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double]),
+    "bz_create_compressible_slab": (C.c_int, [C.POINTER(_ctx), C.POINTER(bz_grid), C.POINTER(bz_constants),
+                                              C.POINTER(bz_exner_reference_state), C.POINTER(bz_split_explicit), C.c_int,
+                                              C.c_int, C.c_int]),
+    "bz_acoustic_stage_begin": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double, C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32)]),
+    "bz_acoustic_substep": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_int32, C.POINTER(C.c_int32)]),
+    "bz_acoustic_stage_end": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double, C.c_int]),
+    "bz_set_acoustic_scratch": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
+    "bz_compute_moisture_tendency": (C.c_int, [_ctx, _csp, _cpp, _asp]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "bz_profile_reset": (C.c_int, [_ctx]),
     "bz_profile_count": (C.c_int, [_ctx]),

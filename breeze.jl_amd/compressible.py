@@ -276,7 +276,7 @@ class CompressibleAtmosphereModel:
         bt.vertical_momentum_tendency_factor = td.vertical_momentum_tendency_factor
         bt.newton_abstol = self.temperature_solver.abstol
         self._ctx = C.c_void_p()
-        rc = lib.bz_create_compressible(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), C.byref(bt), advection.order)
+        rc = self._create_context(lib, bg, bc, br, bt, advection.order)
         if rc != 0:
             raise _lib.BreezeHIPError(f"bz_create_compressible failed with code {rc}")
         self._check(lib.bz_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "bz_set_stream")
@@ -289,6 +289,12 @@ class CompressibleAtmosphereModel:
             dynamics.pressure.set_interior(ref.pressure[Hz:Hz + Nz][:, None, None])
         else:
             dynamics.pressure.set_interior(dynamics.surface_pressure)
+
+    def _create_context(self, lib, bg, bc, br, bt, order):
+        return lib.bz_create_compressible(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), C.byref(bt), order)
+
+    def _exchange(self, tensors):
+        """y-halo exchange hook: nothing to do on a single GPU (the kernels wrap periodically)."""
 
     def _check(self, rc, what):
         _lib.check(self._lib, self._ctx, rc, what)
@@ -352,6 +358,8 @@ class CompressibleAtmosphereModel:
 
 # ---------------------------------------------------------------------------------------------------------------------
 def update_state_(model, compute_tendencies=True):
+    if getattr(model, "decomp", None) is not None:
+        return model.update_state_slab(compute_tendencies)
     model._check(model._lib.bz_compressible_update_state(model._ctx, C.byref(model._state), C.byref(model._G),
                                                          C.byref(model._sub), 1 if compute_tendencies else 0),
                  "bz_compressible_update_state")
@@ -410,6 +418,7 @@ def set_(model, **kw):
         ρd.interior.copy_(ρ.interior - (model.moisture_density.interior + 0.0))
     from .model import fill_halo_regions_
     fill_halo_regions_(model, ρd, 0)
+    model._exchange([ρd.parent])
     if "θ" in keys:
         model.potential_temperature.set_interior(keys["θ"])
         model.potential_temperature_density.interior.copy_(ρd.interior * model.potential_temperature.interior)
@@ -437,7 +446,9 @@ def time_step_(model, Δt, whole_step=True):
     if model.clock.iteration == 0:                         # maybe_prepare_first_time_step!
         seed_time_averaged_velocities_(model)
         update_state_(model, compute_tendencies=True)
-    if whole_step:
+    if getattr(model, "decomp", None) is not None:
+        model.time_step_slab(Δt)
+    elif whole_step:
         model._check(model._lib.bz_time_step_compressible(model._ctx, C.byref(model._state), C.byref(model._U0),
                                                           C.byref(model._G), C.byref(model._sub), Δt),
                      "bz_time_step_compressible")
@@ -450,3 +461,96 @@ def time_step_(model, Δt, whole_step=True):
             update_state_(model, compute_tendencies=True)
     model.clock.time += Δt
     model.clock.iteration += 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# y-slab decomposition: one process per GPU, halo exchanges only — the acoustic column solve is rank-local
+# ---------------------------------------------------------------------------------------------------------------------
+class SlabCompressibleModel(CompressibleAtmosphereModel):
+    """CompressibleAtmosphereModel on one y-slab of a (Periodic, Periodic, Bounded) global grid.  Same kernels as the
+    single-GPU model; inside a stage the two perturbation fields the next substep reads across the slab edge
+    ((ρθ)′ and (ρv)′) are exchanged with the ring neighbours, everything else once per stage
+    (breeze.jl_amd/distributed.py: SlabDecomposition, torch.distributed; backend "nccl" = RCCL on ROCm)."""
+
+    def __init__(self, global_grid, rank, world, dynamics, advection=None, group=None, device=None, decomp=None, **kw):
+        import torch
+        from .distributed import SlabDecomposition
+        if global_grid.topology != (Periodic, Periodic, Bounded):
+            raise NotImplementedError("slab decomposition implements topology (Periodic, Periodic, Bounded)")
+        if global_grid.Ny % world:
+            raise ValueError(f"Ny={global_grid.Ny} is not divisible by {world} ranks")
+        self.global_grid = G = global_grid
+        self.rank, self.world = rank, world
+        Ny = G.Ny // world
+        y0 = G.yᶠ[0] + rank * Ny * G.Δy
+        z = (G.zᶠ[0], G.zᶠ[-1]) if G.regular_z else G.zᶠ
+        grid = RectilinearGrid((G.Nx, Ny, G.Nz), x=(G.xᶠ[0], G.xᶠ[0] + G.Nx * G.Δx), y=(y0, y0 + Ny * G.Δy), z=z,
+                               halo=(G.Hx, G.Hy, G.Hz))
+        grid.Δx, grid.Δy = G.Δx, G.Δy          # bit-identical spacings on every rank
+        self.decomp = None                     # set after construction: the constructor's set-up is rank-local
+        self._pending_decomp = decomp or SlabDecomposition(G.Nx, Ny, G.Nz, G.Hy, rank, world, group)
+        dev = device if device is not None else f"cuda:{torch.cuda.current_device()}"
+        super().__init__(grid, dynamics, advection=advection, device=dev, **kw)
+        self.decomp = self._pending_decomp
+        # second buffers of the (ρu)′, (ρv)′ ping-pong are owned here so that their halos can be exchanged
+        self._up2, self._vp2 = Field(grid, _LOC["fcc"], self.device), Field(grid, _LOC["cfc"], self.device)
+        self._check(self._lib.bz_set_acoustic_scratch(self._ctx, C.c_void_p(self._up2.ptr()), C.c_void_p(self._vp2.ptr())),
+                    "bz_set_acoustic_scratch")
+        sub = self.timestepper.substepper
+        self._th_buf = (sub.density_potential_temperature_perturbation.parent,
+                        sub.previous_density_potential_temperature_perturbation.parent)
+        self._v_buf = (sub.momentum_perturbation_v.parent, self._vp2.parent)
+        self._exchange([self.dynamics.pressure.parent])
+
+    def _create_context(self, lib, bg, bc, br, bt, order):
+        return lib.bz_create_compressible_slab(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), C.byref(bt), order,
+                                               self.world, self.rank)
+
+    def _exchange(self, tensors):
+        d = self.decomp or self._pending_decomp
+        d.exchange_y_halos(list(tensors))
+
+    # field groups ----------------------------------------------------------------------------------------------------
+    def _prognostic_tensors(self):
+        sub = self.timestepper.substepper
+        return ([f.parent for f in self.prognostic_fields().values()] +
+                [sub.time_averaged_u.parent, sub.time_averaged_v.parent, sub.time_averaged_w.parent])
+
+    def _diagnostic_tensors(self):
+        d = self.dynamics
+        return ([d.total_density.parent, d.pressure.parent] + [self.velocities[k].parent for k in ("u", "v", "w")] +
+                [self.potential_temperature.parent, self.specific_moisture.parent, self.temperature.parent])
+
+    def update_state_slab(self, compute_tendencies=True):
+        """update_state! with the neighbour exchanges of the slab decomposition.  The diagnosis needs ρᵈ of row -1 (face
+        velocities); everything else is exchanged after it, when the x halos of the edge rows (written by the diagnosis
+        kernel) are valid, so that the corner cells the WENO stencils touch arrive with the rows."""
+        self._exchange([self.dynamics.dry_density.parent])
+        self._check(self._lib.bz_compressible_update_state(self._ctx, C.byref(self._state), C.byref(self._G), C.byref(self._sub), 0),
+                    "bz_compressible_update_state")
+        self._exchange(self._prognostic_tensors() + self._diagnostic_tensors())
+        if compute_tendencies:
+            self._check(self._lib.bz_compute_moisture_tendency(self._ctx, C.byref(self._state), C.byref(self._G), C.byref(self._sub)),
+                        "bz_compute_moisture_tendency")
+
+    def acoustic_rk3_substep_slab(self, Δt, β):
+        """acoustic_rk3_substep!(model, Δt, β) on a slab (call order in include/breeze_hip.h, slab section)."""
+        lib, ctx = self._lib, self._ctx
+        st, U0, G, sub = C.byref(self._state), C.byref(self._U0), C.byref(self._G), C.byref(self._sub)
+        refresh_linearization_(self)
+        compute_slow_tendencies_(self)
+        self._exchange([self.G["ρv"].parent])
+        n, cur = C.c_int32(), C.c_int32()
+        self._check(lib.bz_acoustic_stage_begin(ctx, st, U0, G, sub, float(Δt), float(β), C.byref(n), C.byref(cur)),
+                    "bz_acoustic_stage_begin")
+        for s in range(1, n.value + 1):
+            self._exchange([self._th_buf[cur.value], self._v_buf[cur.value]])
+            self._check(lib.bz_acoustic_substep(ctx, st, U0, G, sub, s, C.byref(cur)), "bz_acoustic_substep")
+        self._exchange([self._th_buf[cur.value]])
+        self._check(lib.bz_acoustic_stage_end(ctx, st, U0, G, sub, float(Δt), float(β), 1), "bz_acoustic_stage_end")
+
+    def time_step_slab(self, Δt):
+        store_initial_state_(self)
+        for β in (self.timestepper.β1, self.timestepper.β2, self.timestepper.β3):
+            self.acoustic_rk3_substep_slab(Δt, β)
+            self.update_state_slab(compute_tendencies=True)

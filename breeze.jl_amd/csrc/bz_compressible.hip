@@ -55,10 +55,11 @@ __device__ __forceinline__ WrapIdx wrap_of(const DevGrid &g, int i, int j)
     WrapIdx w;
     w.im = (i > 0) ? -1 : g.Nx - 1;
     w.ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx;
-    w.jm = (j > 0) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
-    w.jp = (j + 1 < g.Ny) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
+    // y-slab mode (wrap_y == 0): rows -1 and Ny are halo rows delivered by the caller's neighbour exchange
+    w.jm = (j > 0 || !g.wrap_y) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
+    w.jp = (j + 1 < g.Ny || !g.wrap_y) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
     w.ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
-    w.oy = (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
+    w.oy = !g.wrap_y ? 0 : (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
     return w;
 }
 
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__
                                                            const double *__restrict__ p, const double *__restrict__ rho_d,
                                                            const double *__restrict__ rth, const double *__restrict__ qv)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    // y-slab mode: one halo row on each side is linearised locally (its inputs arrive with the state's halo exchange)
+    const int i = blockIdx.x * 256 + threadIdx.x, j = (int)blockIdx.y - (g.wrap_y ? 0 : 1), k = blockIdx.z;
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k);
     const double rd = rho_d[n];
@@ -628,8 +630,27 @@ static bool valid_sub(const bz_acoustic_substepper *a)
         }                                                                              \
     } while (0)
 
+static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
+                                   const bz_exner_reference_state *ref, const bz_split_explicit *td, int weno_order,
+                                   int y_nranks, int y_rank, bool slab);
+
 extern "C" int bz_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
                                       const bz_exner_reference_state *ref, const bz_split_explicit *td, int weno_order)
+{
+    return bzi_create_compressible(out, grid, constants, ref, td, weno_order, 1, 0, false);
+}
+
+extern "C" int bz_create_compressible_slab(bz_ctx **out, const bz_grid *local_grid, const bz_constants *constants,
+                                           const bz_exner_reference_state *ref, const bz_split_explicit *td, int weno_order,
+                                           int y_nranks, int y_rank)
+{
+    if (y_nranks < 1 || y_rank < 0 || y_rank >= y_nranks) return BZ_ERR_INVALID;
+    return bzi_create_compressible(out, local_grid, constants, ref, td, weno_order, y_nranks, y_rank, true);
+}
+
+static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
+                                   const bz_exner_reference_state *ref, const bz_split_explicit *td, int weno_order,
+                                   int y_nranks, int y_rank, bool slab)
 {
     if (!out || !grid || !constants || !ref || !td) return BZ_ERR_INVALID;
     if ((ref->pressure == nullptr) != (ref->density == nullptr)) return BZ_ERR_INVALID;
@@ -643,7 +664,7 @@ extern "C" int bz_create_compressible(bz_ctx **out, const bz_grid *grid, const b
     r.density = ref->density ? ref->density : zeros.data();
     r.pressure = ref->pressure ? ref->pressure : zeros.data();
     r.temperature = zeros.data();
-    int rc = bzi_create(out, grid, constants, &r, weno_order, 1, 0, false, true);
+    int rc = bzi_create(out, grid, constants, &r, weno_order, y_nranks, y_rank, slab, true);
     if (rc != BZ_OK) return rc;
     bz_ctx *ctx = *out;
     ctx->se = *td;
@@ -736,7 +757,7 @@ extern "C" int bz_refresh_linearization(bz_ctx *ctx, const bz_compressible_state
     if (!valid_state(s) || !valid_sub(sub)) return BZ_ERR_INVALID;
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "refresh_linearization");
-    dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+    dim3 grid((g.Nx + 255) / 256, g.Ny + (g.wrap_y ? 0 : 2), g.Nz), block(256);
     hipLaunchKernelGGL(k_cmp_linearization, grid, block, 0, ctx->stream, g, sub->exner, sub->potential_temperature,
                        sub->gamma_R_mixture, ctx->d_Clin, s->p, s->rho_d, s->rho_theta, s->q);
     BZ_LAUNCH_CHECK();
@@ -820,22 +841,43 @@ static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_
     return F;
 }
 
-// acoustic_rk3_substep_loop!; moist: fold the WS-RK3 moisture update into the recovery kernel; velocities: finish with the
-// halo fills + compute_velocities! of the reference (skipped when a full update_state! follows immediately).
-static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
-                                     const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
-                                     double beta, bool moist, bool velocities)
+// ---- one WS-RK3 stage of the acoustic loop in three pieces (the y-slab driver exchanges halos between them) ---------
+struct AcStage {
+    int ntau = 0, cur = 0, done = 0;
+    bool damping = false, fused = true;
+    AcParams P;
+};
+static AcStage &stage_of(bz_ctx *ctx)
+{
+    static_assert(sizeof(AcStage) <= sizeof(ctx->ac_stage_storage), "AcStage does not fit its storage in bz_ctx");
+    return *reinterpret_cast<AcStage *>(ctx->ac_stage_storage);
+}
+
+static void stage_buffers(bz_ctx *ctx, const AcFields &F, double *th_buf[2], double *u_buf[2], double *v_buf[2])
+{
+    // ping-pong buffers of the fused substep: the start buffers are chosen by the parity of N_tau so that the final
+    // (rho theta)', (rho u)', (rho v)' land in the substepper's own fields (and the previous (rho theta)' in
+    // previous_density_potential_temperature_perturbation, as in the reference).
+    th_buf[0] = F.rthp; th_buf[1] = F.rth_old;
+    u_buf[0] = F.rup; u_buf[1] = ctx->up2_user ? ctx->up2_user : ctx->d_up2;
+    v_buf[0] = F.rvp; v_buf[1] = ctx->vp2_user ? ctx->vp2_user : ctx->d_vp2;
+}
+
+// assemble_slow_vertical_momentum_tendency! + initialize_stage_perturbations!
+static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                    const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta)
 {
     const DevGrid &g = ctx->dg;
+    AcStage &S = stage_of(ctx);
     int32_t ntau = 1;
     double dtau = 0.0;
     bz_stage_substeps(ctx, dt, beta, &ntau, &dtau);
     const double om = ctx->se.forward_weight;
-    AcParams P;
+    AcParams &P = S.P;
     P.dtau = dtau; P.dtn = om * dtau; P.dto = (1.0 - om) * dtau;
     P.d_new = 0.0; P.d_old = 0.0;
-    const bool damping = ctx->se.damping_coefficient >= 0.0;
-    if (damping && ctx->se.damp_vertical) {
+    S.damping = ctx->se.damping_coefficient >= 0.0;
+    if (S.damping && ctx->se.damp_vertical) {
         const double base = ctx->se.damping_coefficient * (ctx->dz_min * ctx->dz_min);
         P.d_new = om * base;
         P.d_old = (1.0 - om) * base;
@@ -843,52 +885,67 @@ static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s
     P.f_theta = ctx->se.thermodynamic_tendency_factor;
     P.f_w = ctx->se.vertical_momentum_tendency_factor;
     const double lmin = std::fmin(g.dx, g.dy);
-    P.kdamp = damping ? ctx->se.damping_coefficient * (lmin * lmin) / dtau : 0.0;
+    P.kdamp = S.damping ? ctx->se.damping_coefficient * (lmin * lmin) / dtau : 0.0;
     P.inv_N = 1.0 / (double)ntau;
     P.gate = 1.0;
+    S.ntau = ntau;
+    S.done = 0;
+    S.fused = ctx->ac_fused;
+    S.cur = S.fused ? (ntau & 1) : 0;       // index of the buffer holding the current perturbations
     AcFields F = ac_fields(ctx, s, U0, G, sub);
+    double *th_buf[2], *u_buf[2], *v_buf[2];
+    stage_buffers(ctx, F, th_buf, u_buf, v_buf);
+    ProfileScope ps(ctx, "acoustic_stage_init");
+    AcFields Fi = F;
+    Fi.rthp_out = th_buf[S.cur]; Fi.rup = u_buf[S.cur]; Fi.rvp = v_buf[S.cur];
+    dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
+    hipLaunchKernelGGL(k_ac_stage_init, rows, b256, 0, ctx->stream, g, Fi);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
 
+// substep `sstep` (1-based) of the stage opened by bzi_acoustic_stage_begin
+static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, int sstep)
+{
+    const DevGrid &g = ctx->dg;
+    AcStage &S = stage_of(ctx);
+    if (sstep != S.done + 1 || sstep > S.ntau) {
+        ctx->last_error = "bz_acoustic_substep: substeps must be issued in order 1..N_tau after bz_acoustic_stage_begin";
+        return BZ_ERR_INVALID;
+    }
+    AcParams P = S.P;
+    const int ntau = S.ntau;
+    const bool gate = ctx->se.apply_first_substep_pressure_gradient || (sstep != 1) || (ntau == 1);
+    P.gate = gate ? 1.0 : 0.0;
+    const bool damp = S.damping && sstep > 1;
+    AcFields F = ac_fields(ctx, s, U0, G, sub);
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
     dim3 cols((g.Nx + ACX - 1) / ACX, (g.Ny + ACY - 1) / ACY), bcol(ACX, ACY);
     dim3 colsb((g.Nx + ABX - 1) / ABX, (g.Ny + ABY - 1) / ABY), bcolb(ABX, ABY);
-    const bool fused = ctx->ac_fused;
-    // ping-pong buffers of the fused substep: the start buffers are chosen by the parity of N_tau so that the final
-    // (rho theta)', (rho u)', (rho v)' land in the substepper's own fields (and the previous (rho theta)' in
-    // previous_density_potential_temperature_perturbation, as in the reference).
-    double *th_buf[2] = {F.rthp, F.rth_old};
-    double *u_buf[2] = {F.rup, ctx->d_up2}, *v_buf[2] = {F.rvp, ctx->d_vp2};
-    int cur = fused ? (ntau & 1) : 0;       // index of the buffer holding the current perturbations
-    {
-        ProfileScope ps(ctx, "acoustic_stage_init");
-        AcFields Fi = F;
-        Fi.rthp_out = th_buf[cur]; Fi.rup = u_buf[cur]; Fi.rvp = v_buf[cur];
-        hipLaunchKernelGGL(k_ac_stage_init, rows, b256, 0, ctx->stream, g, Fi);
-    }
-    for (int sstep = 1; sstep <= ntau; ++sstep) {
-        const bool gate = ctx->se.apply_first_substep_pressure_gradient || (sstep != 1) || (ntau == 1);
-        P.gate = gate ? 1.0 : 0.0;
-        const bool damp = damping && sstep > 1;
-        if (fused) {
-            AcFields Fs = F;
-            Fs.rthp = th_buf[cur]; Fs.rth_old = th_buf[cur ^ 1]; Fs.rthp_out = th_buf[cur ^ 1];
-            Fs.rup_in = u_buf[cur]; Fs.rup = u_buf[cur ^ 1];
-            Fs.rvp_in = v_buf[cur]; Fs.rvp = v_buf[cur ^ 1];
-            {
-                ProfileScope ps(ctx, "acoustic_horizontal+column_forward");
-                if (sstep == 1)
-                    hipLaunchKernelGGL((k_ac_column_forward<true, true, false>), cols, bcol, 0, ctx->stream, g, Fs, P);
-                else if (damp)
-                    hipLaunchKernelGGL((k_ac_column_forward<false, true, true>), cols, bcol, 0, ctx->stream, g, Fs, P);
-                else
-                    hipLaunchKernelGGL((k_ac_column_forward<false, true, false>), cols, bcol, 0, ctx->stream, g, Fs, P);
-            }
-            {
-                ProfileScope ps(ctx, "acoustic_column_backward");
-                hipLaunchKernelGGL(k_ac_column_backward, colsb, bcolb, 0, ctx->stream, g, Fs, P);
-            }
-            cur ^= 1;
-            continue;
+    if (S.fused) {
+        double *th_buf[2], *u_buf[2], *v_buf[2];
+        stage_buffers(ctx, F, th_buf, u_buf, v_buf);
+        const int cur = S.cur;
+        AcFields Fs = F;
+        Fs.rthp = th_buf[cur]; Fs.rth_old = th_buf[cur ^ 1]; Fs.rthp_out = th_buf[cur ^ 1];
+        Fs.rup_in = u_buf[cur]; Fs.rup = u_buf[cur ^ 1];
+        Fs.rvp_in = v_buf[cur]; Fs.rvp = v_buf[cur ^ 1];
+        {
+            ProfileScope ps(ctx, "acoustic_horizontal+column_forward");
+            if (sstep == 1)
+                hipLaunchKernelGGL((k_ac_column_forward<true, true, false>), cols, bcol, 0, ctx->stream, g, Fs, P);
+            else if (damp)
+                hipLaunchKernelGGL((k_ac_column_forward<false, true, true>), cols, bcol, 0, ctx->stream, g, Fs, P);
+            else
+                hipLaunchKernelGGL((k_ac_column_forward<false, true, false>), cols, bcol, 0, ctx->stream, g, Fs, P);
         }
+        {
+            ProfileScope ps(ctx, "acoustic_column_backward");
+            hipLaunchKernelGGL(k_ac_column_backward, colsb, bcolb, 0, ctx->stream, g, Fs, P);
+        }
+        S.cur ^= 1;
+    } else {
         {
             ProfileScope ps(ctx, "acoustic_horizontal");
             if (damp)
@@ -908,12 +965,31 @@ static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s
             hipLaunchKernelGGL(k_ac_column_backward, colsb, bcolb, 0, ctx->stream, g, F, P);
         }
     }
+    S.done = sstep;
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// last substep's damping + time-averaged velocities + recovery of the full state [+ WS-RK3 moisture update]
+// [+ the halo fills / compute_velocities! that close the reference's loop]
+static int bzi_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                  const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
+                                  double beta, bool moist, bool velocities)
+{
+    const DevGrid &g = ctx->dg;
+    AcStage &S = stage_of(ctx);
+    if (S.done != S.ntau) {
+        ctx->last_error = "bz_acoustic_stage_end: the stage still has substeps to run";
+        return BZ_ERR_INVALID;
+    }
+    AcFields F = ac_fields(ctx, s, U0, G, sub);
+    dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
     {
         ProfileScope ps(ctx, "acoustic_finalize");
-        if (damping)
-            hipLaunchKernelGGL((k_ac_finalize<true>), rows, b256, 0, ctx->stream, g, F, P);
+        if (S.damping)
+            hipLaunchKernelGGL((k_ac_finalize<true>), rows, b256, 0, ctx->stream, g, F, S.P);
         else
-            hipLaunchKernelGGL((k_ac_finalize<false>), rows, b256, 0, ctx->stream, g, F, P);
+            hipLaunchKernelGGL((k_ac_finalize<false>), rows, b256, 0, ctx->stream, g, F, S.P);
     }
     {
         ProfileScope ps(ctx, "acoustic_recover");
@@ -929,8 +1005,23 @@ static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s
         DiagFields D = diag_fields(ctx, s, sub);
         hipLaunchKernelGGL((k_cmp_diagnose<false, false>), rows, b256, 0, ctx->stream, g, D, 0.0, 0);
     }
+    S.ntau = 0;
     BZ_LAUNCH_CHECK();
     return BZ_OK;
+}
+
+// acoustic_rk3_substep_loop!; moist: fold the WS-RK3 moisture update into the recovery kernel; velocities: finish with the
+// halo fills + compute_velocities! of the reference (skipped when a full update_state! follows immediately).
+static int bzi_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                     const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
+                                     double beta, bool moist, bool velocities)
+{
+    int rc = bzi_acoustic_stage_begin(ctx, s, U0, G, sub, dt, beta);
+    if (rc) return rc;
+    const int ntau = stage_of(ctx).ntau;
+    for (int sstep = 1; sstep <= ntau; ++sstep)
+        if ((rc = bzi_acoustic_substep(ctx, s, U0, G, sub, sstep))) return rc;
+    return bzi_acoustic_stage_end(ctx, s, U0, G, sub, dt, beta, moist, velocities);
 }
 
 static int check_loop_args(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
@@ -941,6 +1032,68 @@ static int check_loop_args(bz_ctx *ctx, const bz_compressible_state *s, const bz
     return BZ_OK;
 }
 
+static int require_no_slab(bz_ctx *ctx, const char *what)
+{
+    if (ctx->slab_mode) {
+        ctx->last_error = std::string(what) + ": a y-slab context needs the distributed driver (halo exchanges between the pieces)";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    return BZ_OK;
+}
+
+extern "C" int bz_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                       const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
+                                       double beta, int32_t *n_substeps, int32_t *current_buffer)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    int rc = check_loop_args(ctx, s, U0, G, sub);
+    if (rc) return rc;
+    rc = bzi_acoustic_stage_begin(ctx, s, U0, G, sub, dt, beta);
+    if (n_substeps) *n_substeps = stage_of(ctx).ntau;
+    if (current_buffer) *current_buffer = stage_of(ctx).cur;
+    return rc;
+}
+
+extern "C" int bz_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                   const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, int32_t substep,
+                                   int32_t *current_buffer)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    int rc = check_loop_args(ctx, s, U0, G, sub);
+    if (rc) return rc;
+    rc = bzi_acoustic_substep(ctx, s, U0, G, sub, substep);
+    if (current_buffer) *current_buffer = stage_of(ctx).cur;
+    return rc;
+}
+
+extern "C" int bz_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                     const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
+                                     double beta, int update_moisture)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    int rc = check_loop_args(ctx, s, U0, G, sub);
+    if (rc) return rc;
+    return bzi_acoustic_stage_end(ctx, s, U0, G, sub, dt, beta, update_moisture != 0, false);
+}
+
+extern "C" int bz_set_acoustic_scratch(bz_ctx *ctx, double *momentum_u_second_buffer, double *momentum_v_second_buffer)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    if ((momentum_u_second_buffer == nullptr) != (momentum_v_second_buffer == nullptr)) return BZ_ERR_INVALID;
+    ctx->up2_user = momentum_u_second_buffer;
+    ctx->vp2_user = momentum_v_second_buffer;
+    return BZ_OK;
+}
+
+extern "C" int bz_compute_moisture_tendency(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                            const bz_acoustic_substepper *sub)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    if (!valid_state(s) || !valid_prog(G) || !valid_sub(sub)) return BZ_ERR_INVALID;
+    return launch_scalar_rho3d(ctx, "moisture_tendency", G->rho_q, nullptr, s->rho, sub->time_averaged_u, sub->time_averaged_v,
+                               sub->time_averaged_w, s->q, nullptr, nullptr, nullptr);
+}
+
 extern "C" int bz_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                                         const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt,
                                         double beta)
@@ -948,6 +1101,7 @@ extern "C" int bz_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state
     BZ_REQUIRE_COMPRESSIBLE();
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
+    if ((rc = require_no_slab(ctx, "bz_acoustic_substep_loop"))) return rc;
     return bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, beta, false, true);
 }
 
@@ -958,6 +1112,7 @@ extern "C" int bz_acoustic_rk3_substep(bz_ctx *ctx, const bz_compressible_state 
     BZ_REQUIRE_COMPRESSIBLE();
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
+    if ((rc = require_no_slab(ctx, "bz_acoustic_rk3_substep"))) return rc;
     rc = bz_refresh_linearization(ctx, s, sub);
     if (rc) return rc;
     rc = bz_compute_slow_tendencies(ctx, s, G);
@@ -971,6 +1126,7 @@ extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_stat
     BZ_REQUIRE_COMPRESSIBLE();
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
+    if ((rc = require_no_slab(ctx, "bz_time_step_compressible"))) return rc;
     const DevGrid &g = ctx->dg;
     {   // store_initial_state!
         ProfileScope ps(ctx, "store_initial_state");

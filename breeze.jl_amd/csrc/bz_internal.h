@@ -171,6 +171,8 @@ struct bz_ctx {
     double *d_tfac_ac = nullptr;      // centre array: Thomas factors t_k of the acoustic column system (per stage)
     double *d_up2 = nullptr, *d_vp2 = nullptr;   // second buffers of the (rho u)', (rho v)' ping-pong (fused substep)
     bool ac_fused = true;             // horizontal step folded into the forward column sweep (BZ_NO_AC_FUSE=1 disables)
+    double *up2_user = nullptr, *vp2_user = nullptr;   // caller-owned replacements of d_up2 / d_vp2 (bz_set_acoustic_scratch)
+    alignas(8) unsigned char ac_stage_storage[160] = {0};   // AcStage of the stage in flight (bz_compressible.hip)
     // profiling
     bool profiling = false;
     std::vector<ProfileSlot> slots;

@@ -292,6 +292,40 @@ int bz_acoustic_rk3_substep(bz_ctx *ctx, const bz_compressible_state *s, const b
 int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                               const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt);
 
+/* ---- y-slab decomposition of the compressible path (halo exchanges only, the column solve is local) ----
+ * `local_grid` is this rank's slab as in bz_create_slab.  The caller's neighbour exchange fills the y halos (Hy rows) at the
+ * points listed below; x and z halos stay the library's business.  Sequence of one WS-RK3 stage:
+ *   [state halos valid: rho_d, rho, momentum, rho_theta, rho_q, u, v, w, theta, q, T, p, time-averaged velocities]
+ *   bz_refresh_linearization            (also linearises one halo row on each side)
+ *   bz_compute_slow_tendencies          -> exchange G->rho_v
+ *   bz_acoustic_stage_begin             returns N_tau and which buffer pair is current (0: the substepper's own
+ *                                       (rho theta)', (rho u)', (rho v)' fields, 1: previous_(rho theta)' / the scratch pair)
+ *   for n = 1..N_tau:  exchange current (rho theta)' and (rho v)'  ->  bz_acoustic_substep(n)
+ *   exchange current (rho theta)'  ->  bz_acoustic_stage_end
+ *   exchange rho_d, momentum, rho_theta, rho_q, time-averaged velocities  ->  bz_compressible_update_state(compute_tendencies = 0)
+ *   exchange rho, u, v, w, theta, q, T, p  ->  bz_compute_moisture_tendency */
+int bz_create_compressible_slab(bz_ctx **ctx, const bz_grid *local_grid, const bz_constants *constants,
+                                const bz_exner_reference_state *reference_state, const bz_split_explicit *time_discretization,
+                                int weno_order, int y_nranks, int y_rank);
+/* The three pieces of acoustic_rk3_substep_loop! (acoustic_substepping.jl:1404-1590): :1437-1441 | one iteration of
+ * :1448-1555 | :1557-1590 without the trailing halo fills / compute_velocities! (done by the next update_state!). */
+int bz_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                            const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta,
+                            int32_t *n_substeps, int32_t *current_buffer);
+int bz_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                        const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, int32_t substep,
+                        int32_t *current_buffer);
+int bz_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                          const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta,
+                          int update_moisture);
+/* Caller-owned second buffers of the (rho u)', (rho v)' ping-pong (XFace / YFace parent arrays), so that the slab driver can
+ * exchange their halos; NULL, NULL returns to the context's own scratch. */
+int bz_set_acoustic_scratch(bz_ctx *ctx, double *momentum_u_second_buffer, double *momentum_v_second_buffer);
+/* The moisture part of compute_tendencies! alone (update_atmosphere_model_state.jl:330-343 with the time-averaged
+ * transport velocities), for drivers that exchange halos between the diagnosis and the tendency. */
+int bz_compute_moisture_tendency(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                 const bz_acoustic_substepper *sub);
+
 /* ---- instrumentation (not part of the reference interface) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
 int bz_profile_enable(bz_ctx *ctx, int on);

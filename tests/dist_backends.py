@@ -145,3 +145,26 @@ def make_threaded_decomposition(bz_dist, mailbox, *args, **kw):
             mb.barrier.wait()
 
     return ThreadedDecomposition(*args, **kw)
+
+
+def make_oracle_compressible_slab(orc, oc, bz_dist, size, extent, rank, world, td=None, theta_ref=300.0, group=None, decomp=None):
+    """CompressibleOracleModel on the y-slab of `rank`: every halo fill of the oracle (x wrap + z boundary) is followed by
+    the product's SlabDecomposition.exchange_y_halos, so the oracle's own sequence of fills defines the exchange points."""
+    import torch
+    Ny = size[1] // world
+    dy = (extent[1][1] - extent[1][0]) / size[1]
+    y0 = extent[1][0] + rank * Ny * dy
+    grid = orc.Grid((size[0], Ny, size[2]), x=extent[0], y=(y0, y0 + Ny * dy), z=extent[2], topology=("Periodic", "Slab", "Bounded"))
+    grid.dy = dy
+    d = decomp or bz_dist.SlabDecomposition(size[0], Ny, size[2], grid.Hy, rank, world, group)
+
+    class OracleCompressibleSlab(oc.CompressibleOracleModel):
+        def _halo_center(self, f):
+            super()._halo_center(f)
+            d.exchange_y_halos([torch.from_numpy(f)])
+
+        def _halo_w(self, f):
+            super()._halo_w(f)
+            d.exchange_y_halos([torch.from_numpy(f)])
+
+    return OracleCompressibleSlab(grid, time_discretization=td or oc.SplitExplicit(substeps=6), reference_potential_temperature=theta_ref)

@@ -138,3 +138,126 @@ def test_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, world):
         want = getter(ref).interior_cpu()
         err = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-3)
         assert err < 1e-10, (name, err)
+
+
+# ---- compressible split-explicit path on y-slabs (halo exchanges only) ---------------------------------
+def cmp_theta(x, y, z):
+    r = np.sqrt(x ** 2 + (y - 1500.0) ** 2 + (z - 3000.0) ** 2)
+    return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2.5e3)
+
+
+def cmp_qv(x, y, z):
+    return 4e-3 * np.exp(-z / 2e3) * (1 + 0.2 * np.sin(2 * np.pi * y / 20e3)) + 0 * x
+
+
+def _cmp_worker(rank, world, port, size, steps, dt, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch
+    import torch.distributed as dist
+    from breeze_jl_amd import distributed as bz_dist
+    from oracle import oracle as orc, oracle_compressible as oc
+    import dist_backends
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = dist_backends.make_oracle_compressible_slab(orc, oc, bz_dist, size, EXTENT, rank, world)
+        g = m.grid
+        rho = m.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+        m.set(rho=rho, theta=cmp_theta, u=3.0, v=-2.0, w=0.0, qv=cmp_qv)
+        for _ in range(steps):
+            m.time_step(dt)
+        pieces = {}
+        for n in ("rho_d", "ru", "rv", "rw", "rtheta", "rq", "T", "p"):
+            loc = torch.from_numpy(np.ascontiguousarray(g.interior(getattr(m, n), n == "rw")))
+            gathered = [torch.empty_like(loc) for _ in range(world)] if rank == 0 else None
+            dist.gather(loc, gathered, dst=0)
+            if rank == 0:
+                pieces[n] = torch.cat(gathered, dim=1).numpy()
+        if rank == 0:
+            G = orc.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+            ref = oc.CompressibleOracleModel(G, time_discretization=oc.SplitExplicit(substeps=6), reference_potential_temperature=300.0)
+            ref.set(rho=rho, theta=cmp_theta, u=3.0, v=-2.0, w=0.0, qv=cmp_qv)
+            for _ in range(steps):
+                ref.time_step(dt)
+            errs = []
+            for n, got in pieces.items():
+                want = G.interior(getattr(ref, n), n == "rw")
+                errs.append(float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-3)))
+            np.save(out, np.array(errs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size", [(2, (16, 16, 12)), (4, (12, 24, 10))])
+def test_compressible_slab_steps_match_single_process_oracle(world, size, tmp_path):
+    """The product's SlabDecomposition (torch.distributed, gloo) carrying every y-halo of the compressible oracle:
+    world-size 2 and 4 reproduce the single-process run."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000) + world
+    out = str(tmp_path / "errs.npy")
+    mp.spawn(_cmp_worker, args=(world, port, size, 2, 2.0, out), nprocs=world, join=True)
+    errs = np.load(out)
+    assert errs.max() < 1e-12, errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, world):
+    """SlabCompressibleModel (bz_create_compressible_slab, stage begin / substep / end with the per-substep exchange of
+    (rho theta)' and (rho v)') against the single-GPU whole-step seam; `world` ranks share cuda:0 through a mailbox."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_backends
+    from breeze_jl_amd import distributed as bz_dist
+    size, steps, dt = (32, 24, 16), 2, 2.0
+    G = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+
+    def dynamics():
+        return bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), reference_potential_temperature=300.0)
+
+    ref = bz.CompressibleAtmosphereModel(G, dynamics(), advection=bz.WENO())
+    Hz, Nz = G.Hz, G.Nz
+    rho = ref.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
+    ref.set(ρ=rho, θ=cmp_theta, u=3.0, v=-2.0, w=0.0, qᵗ=cmp_qv)
+    for _ in range(steps):
+        ref.time_step(dt)
+    ref.synchronize()
+
+    mb = dist_backends.Mailbox(world)
+    models, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            decomp = dist_backends.make_threaded_decomposition(bz_dist, mb, size[0], size[1] // world, size[2], 3, rank, world)
+            m = bz.compressible.SlabCompressibleModel(G, rank, world, dynamics(), advection=bz.WENO(), device="cuda:0", decomp=decomp)
+            m.set(ρ=rho, θ=cmp_theta, u=3.0, v=-2.0, w=0.0, qᵗ=cmp_qv)
+            for _ in range(steps):
+                m.time_step(dt)
+            m.synchronize()
+            models[rank] = m
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            mb.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    getters = {"ρᵈ": lambda m: m.dynamics.dry_density, "ρu": lambda m: m.momentum["ρu"], "ρv": lambda m: m.momentum["ρv"],
+               "ρw": lambda m: m.momentum["ρw"], "ρθ": lambda m: m.potential_temperature_density,
+               "ρq": lambda m: m.moisture_density, "T": lambda m: m.temperature, "p": lambda m: m.dynamics.pressure,
+               "w̄": lambda m: m.timestepper.substepper.time_averaged_w}
+    mom = max(np.abs(getters[k](ref).interior_cpu()).max() for k in ("ρu", "ρv", "ρw"))
+    for name, getter in getters.items():
+        got = np.concatenate([getter(m).interior_cpu() for m in models], axis=1)
+        want = getter(ref).interior_cpu()
+        scale = mom if name in ("ρu", "ρv", "ρw") else max(np.max(np.abs(want)), 1e-3)
+        err = np.max(np.abs(got - want)) / scale
+        assert err < 1e-11, (name, err)

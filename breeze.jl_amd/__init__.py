@@ -18,3 +18,4 @@ from .compressible import (AcousticRungeKutta3, AcousticSubstepper, Compressible
                            ExnerReferenceState, NewtonSolver, NoDivergenceDamping, ProportionalSubsteps,
                            SplitExplicitTimeDiscretization, ThermalDivergenceDamping)
 from .microphysics import SaturationAdjustment, SecantSolver, WarmPhaseEquilibrium  # noqa: F401,E402
+from .model import cell_advection_timescale, nan_checker  # noqa: F401,E402

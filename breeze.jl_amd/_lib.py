@@ -142,6 +142,8 @@ SYMBOLS = {
     "bz_acoustic_stage_end": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double, C.c_int]),
     "bz_set_acoustic_scratch": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "bz_compute_moisture_tendency": (C.c_int, [_ctx, _csp, _cpp, _asp]),
+    "bz_cell_advection_timescale": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "bz_any_nan": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "bz_profile_reset": (C.c_int, [_ctx]),
     "bz_profile_count": (C.c_int, [_ctx]),

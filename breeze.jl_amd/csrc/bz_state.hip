@@ -219,3 +219,72 @@ extern "C" int bz_max_abs_divergence(bz_ctx *ctx, const bz_state *s, double *out
     BZ_HIP(hipStreamSynchronize(ctx->stream));
     return BZ_OK;
 }
+
+// ---- the run!-loop reductions around the step ---------------------------------------------------
+// cell_advection_timescale(model) = minimum over cells of 1 / (|u|/dx + |v|/dy + |w|/dz)
+// (/root/reference/src/AtmosphereModels/cell_advection_timescale.jl:47-66 -> Oceananigans.Advection.cell_advection_timescale,
+// recalled: spacings at the velocity locations, dz = centre spacing at the w face); the maximum inverse timescale is
+// reduced with wave shuffles + one atomicMax per wave on the bit pattern of the non-negative double.
+__global__ __launch_bounds__(TX *TY) void k_max_inverse_advection_timescale(DevGrid g, const double *__restrict__ u,
+                                                                           const double *__restrict__ v,
+                                                                           const double *__restrict__ w, int with_w,
+                                                                           unsigned long long *out)
+{
+    int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
+    double d = 0.0;
+    if (i < g.Nx && j < g.Ny) {
+        long long n = g.idx(i, j, k);
+        const double ix = fabs(u[n]) / g.dx, iy = fabs(v[n]) / g.dy;
+        const double iz = with_w ? fabs(w[n]) / g.dzf[k] : 0.0;
+        d = ix + iy + iz;
+        if (d != d) d = __longlong_as_double(0x7ff0000000000000LL);      // NaN velocity: timescale 0
+    }
+    for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_down(d, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(d));
+}
+
+extern "C" int bz_cell_advection_timescale(bz_ctx *ctx, const double *u, const double *v, const double *w, double *out)
+{
+    if (!ctx || !u || !v || !out) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    BZ_HIP(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_max_inverse_advection_timescale, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, u, v,
+                       w ? w : u, w ? 1 : 0, (unsigned long long *)ctx->d_scalar);
+    BZ_LAUNCH_CHECK();
+    double inv = 0.0;
+    BZ_HIP(hipMemcpyAsync(&inv, ctx->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    BZ_HIP(hipStreamSynchronize(ctx->stream));
+    *out = 1.0 / inv;
+    return BZ_OK;
+}
+
+// NaNChecker on one field (default_nan_checker: the first prognostic field, atmosphere_model.jl:561-572): 1 if any
+// interior value is NaN.
+__global__ __launch_bounds__(256) void k_any_nan(DevGrid g, const double *__restrict__ f, int nlev, int *out)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)g.Ny * g.Sx) return;
+    const int k = blockIdx.y;
+    if (k >= nlev) return;
+    const long long n = g.Sxy * (k + g.Hz) + (long long)g.Hy * g.Sx + t;
+    const int i = (int)(t % g.Sx) - g.Hx;
+    const double x = f[n];
+    if (i >= 0 && i < g.Nx && x != x) *out = 1;
+}
+
+extern "C" int bz_any_nan(bz_ctx *ctx, const double *field, int z_face, int32_t *out)
+{
+    if (!ctx || !field || !out) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    int *flag = (int *)(ctx->d_scalar + 8);
+    BZ_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    const int nlev = g.Nz + (z_face ? 1 : 0);
+    const long long per_level = (long long)g.Ny * g.Sx;
+    hipLaunchKernelGGL(k_any_nan, dim3((unsigned)((per_level + 255) / 256), nlev), dim3(256), 0, ctx->stream, g, field, nlev, flag);
+    BZ_LAUNCH_CHECK();
+    int h = 0;
+    BZ_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    BZ_HIP(hipStreamSynchronize(ctx->stream));
+    *out = h;
+    return BZ_OK;
+}

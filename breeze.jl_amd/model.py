@@ -389,3 +389,22 @@ def time_step_(model, Δt, whole_step=True):
             update_state_(model, compute_tendencies=True)
     model.clock.time += Δt
     model.clock.iteration += 1
+
+
+def cell_advection_timescale(model, formulation="ThreeDimensional"):
+    """cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): the TimeStepWizard's
+    advective timescale min 1/(|u|/Δx + |v|/Δy + |w|/Δz); formulation "Horizontal" drops the vertical term."""
+    out = C.c_double()
+    w = None if str(formulation).startswith("Horizontal") else C.c_void_p(model.velocities["w"].ptr())
+    model._check(model._lib.bz_cell_advection_timescale(model._ctx, C.c_void_p(model.velocities["u"].ptr()),
+                                                        C.c_void_p(model.velocities["v"].ptr()), w, C.byref(out)),
+                 "bz_cell_advection_timescale")
+    return out.value
+
+
+def nan_checker(model):
+    """default_nan_checker(model): NaN check of the first prognostic field (atmosphere_model.jl:561-572)."""
+    name, field = next(iter(model.prognostic_fields().items()))
+    out = C.c_int32()
+    model._check(model._lib.bz_any_nan(model._ctx, C.c_void_p(field.ptr()), 1 if field.zface else 0, C.byref(out)), "bz_any_nan")
+    return bool(out.value)

@@ -326,6 +326,15 @@ int bz_set_acoustic_scratch(bz_ctx *ctx, double *momentum_u_second_buffer, doubl
 int bz_compute_moisture_tendency(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
                                  const bz_acoustic_substepper *sub);
 
+/* ---- the reductions of the run! loop around the step ---- */
+/* cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): minimum over the interior of
+ * 1 / (|u|/dx + |v|/dy + |w|/dz) into *out (host; +Inf for a fluid at rest); w == NULL gives the HorizontalFormulation.
+ * Synchronises the stream.  u, v, w: velocity parent arrays (a slab rank reduces its own slab; combine with a min). */
+int bz_cell_advection_timescale(bz_ctx *ctx, const double *u, const double *v, const double *w, double *out);
+/* NaNChecker on one field (default_nan_checker, src/AtmosphereModels/atmosphere_model.jl:561-572): *out = 1 if any
+ * interior value is NaN.  Synchronises. */
+int bz_any_nan(bz_ctx *ctx, const double *field, int z_face, int32_t *out);
+
 /* ---- instrumentation (not part of the reference interface) ---- */
 /* When enabled, every kernel group is bracketed by hipEvents on the ctx stream. */
 int bz_profile_enable(bz_ctx *ctx, int on);

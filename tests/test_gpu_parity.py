@@ -356,3 +356,23 @@ def test_config0_two_dimensional_bubble_as_y_invariant_run(oracle, bz):
     th3, th2 = hm.potential_temperature.interior_cpu(), og.interior(om.theta)
     assert np.abs(th3[:, 0, :] - th2[:, 0, :]).max() / 300.0 < 1e-12
     assert np.abs(w2).max() > 1e-3
+
+
+def test_cell_advection_timescale_and_nan_checker(oracle, bz):
+    """The run!-loop reductions: min 1/(|u|/dx + |v|/dy + |w|/dz) against numpy on the oracle's
+    velocities, +Inf at rest, the horizontal formulation, and the NaN check of the first prognostic field."""
+    om, hm = make_pair(oracle, bz, (32, 20, 16))
+    assert bz.cell_advection_timescale(hm) == np.inf
+    randomize(om, seed=5)
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=False)
+    g = om.grid
+    u, v, w = g.interior(om.u), g.interior(om.v), g.interior(om.w, True)[:-1]
+    dz = g.dzf[g.Hz:g.Hz + g.Nz][:, None, None]
+    want = 1.0 / (np.abs(u) / g.dx + np.abs(v) / g.dy + np.abs(w) / dz).max()
+    want_h = 1.0 / (np.abs(u) / g.dx + np.abs(v) / g.dy).max()
+    assert bz.cell_advection_timescale(hm) == pytest.approx(want, rel=1e-14)
+    assert bz.cell_advection_timescale(hm, "Horizontal") == pytest.approx(want_h, rel=1e-14)
+    assert bz.nan_checker(hm) is False
+    hm.momentum["ρu"].interior[3, 4, 5] = float("nan")
+    assert bz.nan_checker(hm) is True

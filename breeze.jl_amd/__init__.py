@@ -19,3 +19,5 @@ from .compressible import (AcousticRungeKutta3, AcousticSubstepper, Compressible
                            SplitExplicitTimeDiscretization, ThermalDivergenceDamping)
 from .microphysics import SaturationAdjustment, SecantSolver, WarmPhaseEquilibrium  # noqa: F401,E402
 from .model import cell_advection_timescale, nan_checker  # noqa: F401,E402
+from .microphysics import (DCMIP2016KesslerMicrophysics, KesslerMicrophysicalFields, TetensFormula,  # noqa: F401,E402
+                           microphysics_model_update_)

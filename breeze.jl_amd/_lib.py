@@ -57,6 +57,26 @@ class bz_saturation_adjustment(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+_KESSLER_PARAMS = ("dcmip_temperature_scale", "terminal_velocity_coefficient", "density_scale", "terminal_velocity_exponent",
+                   "autoconversion_rate", "autoconversion_threshold", "accretion_rate", "accretion_exponent",
+                   "evaporation_ventilation_coefficient_1", "evaporation_ventilation_coefficient_2",
+                   "evaporation_ventilation_exponent_1", "evaporation_ventilation_exponent_2", "diffusivity_coefficient",
+                   "thermal_conductivity_coefficient", "substep_cfl", "tetens_reference_saturation_vapor_pressure",
+                   "tetens_reference_temperature", "tetens_liquid_coefficient", "tetens_liquid_temperature_offset",
+                   "liquid_latent_heat", "liquid_heat_capacity")
+_KESSLER_FIELDS = ("density", "pressure", "potential_temperature", "potential_temperature_density", "moisture_density",
+                   "cloud_liquid_density", "rain_density", "vapor_mass_fraction", "cloud_liquid_mass_fraction",
+                   "rain_mass_fraction", "rain_terminal_velocity", "precipitation_rate")
+
+
+class bz_kessler_microphysics(C.Structure):
+    _fields_ = [(n, C.c_double) for n in _KESSLER_PARAMS]
+
+
+class bz_kessler_fields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _KESSLER_FIELDS]
+
+
 _CSTATE_FIELDS = ("rho_d", "rho", "rho_u", "rho_v", "rho_w", "rho_theta", "rho_q", "u", "v", "w", "theta", "q", "T", "p")
 _CPROG_FIELDS = ("rho_d", "rho_u", "rho_v", "rho_w", "rho_theta", "rho_q")
 _SUBSTEPPER_FIELDS = ("exner", "potential_temperature", "gamma_R_mixture", "density_perturbation",
@@ -142,6 +162,8 @@ SYMBOLS = {
     "bz_acoustic_stage_end": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double, C.c_int]),
     "bz_set_acoustic_scratch": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "bz_compute_moisture_tendency": (C.c_int, [_ctx, _csp, _cpp, _asp]),
+    "bz_kessler_microphysics_update": (C.c_int, [_ctx, C.POINTER(bz_kessler_microphysics), C.POINTER(bz_kessler_fields),
+                                                 C.c_double, C.c_double]),
     "bz_cell_advection_timescale": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "bz_any_nan": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),

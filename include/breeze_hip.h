@@ -326,6 +326,38 @@ int bz_set_acoustic_scratch(bz_ctx *ctx, double *momentum_u_second_buffer, doubl
 int bz_compute_moisture_tendency(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
                                  const bz_acoustic_substepper *sub);
 
+/* ---- DCMIP2016 Kessler warm-rain microphysics: the operator-split column kernel ----
+ * microphysics_model_update!(::DCMIP2016KesslerMicrophysics, model) (src/Microphysics/dcmip2016_kessler.jl:449-486, kernel
+ * :618-858): autoconversion, accretion, saturation adjustment (Tetens), rain evaporation and sedimentation with per-column
+ * subcycling, in place on theta / rho_theta / rho_qv / rho_qcl / rho_qr; q^v, q^cl, q^r, W^r are diagnosed (they double
+ * as the column workspace, as in the reference); the caller follows with update_state!.  density / pressure: 3-D parents
+ * (CompressibleDynamics) or NULL for the context's reference columns (AnelasticDynamics).  precipitation_rate: the
+ * horizontal parent (Sx x Sy) of mu.precipitation_rate. */
+typedef struct bz_kessler_microphysics {      /* DCMIP2016KesslerMicrophysics (:40-70,154-169) */
+    double dcmip_temperature_scale;
+    double terminal_velocity_coefficient, density_scale, terminal_velocity_exponent;
+    double autoconversion_rate, autoconversion_threshold;
+    double accretion_rate, accretion_exponent;
+    double evaporation_ventilation_coefficient_1, evaporation_ventilation_coefficient_2;
+    double evaporation_ventilation_exponent_1, evaporation_ventilation_exponent_2;
+    double diffusivity_coefficient, thermal_conductivity_coefficient;
+    double substep_cfl;
+    /* TetensFormula (src/Thermodynamics/tetens_formula.jl:72-85) and the liquid CondensedPhase of the constants */
+    double tetens_reference_saturation_vapor_pressure, tetens_reference_temperature;
+    double tetens_liquid_coefficient, tetens_liquid_temperature_offset;
+    double liquid_latent_heat, liquid_heat_capacity;
+} bz_kessler_microphysics;
+typedef struct bz_kessler_fields {
+    const double *density, *pressure;
+    double *potential_temperature, *potential_temperature_density;
+    double *moisture_density, *cloud_liquid_density, *rain_density;                     /* rho q^v, mu.rho q^cl, mu.rho q^r */
+    double *vapor_mass_fraction, *cloud_liquid_mass_fraction, *rain_mass_fraction;      /* mu.q^v, mu.q^cl, mu.q^r          */
+    double *rain_terminal_velocity;                                                     /* mu.W^r                          */
+    double *precipitation_rate;
+} bz_kessler_fields;
+int bz_kessler_microphysics_update(bz_ctx *ctx, const bz_kessler_microphysics *params, const bz_kessler_fields *fields,
+                                   double dt, double standard_pressure);
+
 /* ---- the reductions of the run! loop around the step ---- */
 /* cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): minimum over the interior of
  * 1 / (|u|/dx + |v|/dy + |w|/dz) into *out (host; +Inf for a fluid at rest); w == NULL gives the HorizontalFormulation.

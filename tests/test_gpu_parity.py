@@ -376,3 +376,80 @@ def test_cell_advection_timescale_and_nan_checker(oracle, bz):
     assert bz.nan_checker(hm) is False
     hm.momentum["ρu"].interior[3, 4, 5] = float("nan")
     assert bz.nan_checker(hm) is True
+
+
+# ---- DCMIP2016 Kessler column microphysics ---------------------------------------------------------
+def test_kessler_column_update_matches_oracle(oracle, bz):
+    """bz_kessler_microphysics_update against the oracle's restatement of `_microphysical_update!` (itself pinned to the
+    reference test's independent Fortran translation at 1e-12), column by column: (a) the reference test's lapse-rate
+    profile through 3-D density / pressure arrays, with moisture varied across columns so that the sedimentation
+    subcycle count differs between lanes of a wavefront; (b) the anelastic reference columns of the context."""
+    import torch
+    from oracle import kessler as ks
+    Nx, Ny, Nz = 16, 8, 40
+    grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(0, 1600), y=(0, 800), z=(0, 4000))
+    R, cpd = 8.314462618, 1003.0
+    Md = R / 287.0
+    tc = bz.ThermodynamicConstants(dry_air_molar_mass=Md, vapor_molar_mass=Md, dry_air_heat_capacity=cpd, vapor_heat_capacity=cpd,
+                                   liquid_reference_latent_heat=2500000.0, liquid_heat_capacity=cpd)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, tc, surface_pressure=1e5, potential_temperature=300)),
+                            advection=bz.WENO(order=5), thermodynamic_constants=tc)
+    c = ks.TetensConstants(molar_gas_constant=R, dry_air_molar_mass=Md, vapor_molar_mass=Md, dry_air_heat_capacity=cpd,
+                           vapor_heat_capacity=cpd, liquid_latent_heat=2500000.0, liquid_heat_capacity=cpd, liquid_temperature_offset=36.0)
+    tf = bz.TetensFormula(liquid_temperature_offset=36)
+    mp, kp = bz.DCMIP2016KesslerMicrophysics(), ks.KesslerParameters()
+    zc = grid.zᶜ
+    rng = np.random.default_rng(11)
+    p0 = 1e5
+    ref = hm.dynamics.reference_state
+    Hz = grid.Hz
+    for case in ("arrays", "reference columns"):
+        if case == "arrays":
+            T = 288.0 - 0.0065 * zc
+            p = 101325.0 * (T / 288.0) ** (9.81 / (287.0 * 0.0065))
+            rho = p / (287.0 * T)
+        else:
+            rho, p = ref.density[Hz:Hz + Nz].copy(), ref.pressure[Hz:Hz + Nz].copy()
+            T = p / (287.0 * rho)
+        amp = 0.3 + 1.7 * rng.random((1, Ny, Nx))                       # per-column moisture amplitude
+        rv = 0.015 * np.exp(-((zc - 1000) / 1000) ** 2)[:, None, None] * amp
+        rcl = np.where((zc > 1500) & (zc < 2500), 0.002, 0.0)[:, None, None] * amp
+        rr = np.where((zc > 1000) & (zc < 2000), 0.0005, 0.0)[:, None, None] * amp * 4
+        rt = rv + rcl + rr
+        qv, qcl, qr = rv / (1 + rt), rcl / (1 + rt), rr / (1 + rt)
+        ql = qcl + qr
+        cpm = (1 - (qv + ql)) * c.cpd + qv * c.cpv + ql * c.cl
+        Rm = (1 - (qv + ql)) * c.Rd + qv * c.Rv
+        theta = (T[:, None, None] - c.Ll * ql / cpm) / (p[:, None, None] / p0) ** (Rm / cpm)
+        R3, P3 = np.broadcast_to(rho[:, None, None], theta.shape), np.broadcast_to(p[:, None, None], theta.shape)
+        kf = bz.KesslerMicrophysicalFields(hm)
+        hm.potential_temperature.set_interior(theta)
+        hm.potential_temperature_density.set_interior(R3 * theta)
+        hm.moisture_density.set_interior(R3 * qv)
+        kf.rho_qcl.set_interior(R3 * qcl)
+        kf.rho_qr.set_interior(R3 * qr)
+        dens = pres = None
+        if case == "arrays":
+            dens, pres = bz.Field(grid, hm.potential_temperature.loc, hm.device), bz.Field(grid, hm.potential_temperature.loc, hm.device)
+            dens.set_interior(R3)
+            pres.set_interior(P3)
+        dt = 10.0
+        bz.microphysics_model_update_(mp, hm, kf, dt, tetens=tf, density=dens, pressure=pres, standard_pressure=p0)
+        hm.synchronize()
+        got = {"theta": hm.potential_temperature.interior_cpu(), "rtheta": hm.potential_temperature_density.interior_cpu(),
+               "rqv": hm.moisture_density.interior_cpu(), "rqcl": kf.rho_qcl.interior_cpu(), "rqr": kf.rho_qr.interior_cpu(),
+               "qv": kf.qv.interior_cpu(), "qcl": kf.qcl.interior_cpu(), "qr": kf.qr.interior_cpu(), "W": kf.W.interior_cpu()}
+        precip = kf.precipitation_rate.cpu().numpy()[grid.Hy:grid.Hy + Ny, grid.Hx:grid.Hx + Nx]
+        counts = set()
+        for j in range(0, Ny, 3):
+            for i in range(0, Nx, 3):
+                th, rth = theta[:, j, i].copy(), (R3 * theta)[:, j, i].copy()
+                a, b, d = (R3 * qv)[:, j, i].copy(), (R3 * qcl)[:, j, i].copy(), (R3 * qr)[:, j, i].copy()
+                oqv, oqcl, oqr, oW, oP, Ns = ks.kessler_column_update(dt, rho, p, p0, zc, th, rth, a, b, d, kp, c)
+                counts.add(Ns)
+                for name, want in (("theta", th), ("rtheta", rth), ("rqv", a), ("rqcl", b), ("rqr", d), ("qv", oqv),
+                                   ("qcl", oqcl), ("qr", oqr), ("W", oW)):
+                    np.testing.assert_allclose(got[name][:, j, i], want, rtol=1e-11, atol=1e-18, err_msg=f"{case} {name} ({i},{j})")
+                assert precip[j, i] == pytest.approx(oP, rel=1e-11, abs=1e-18)
+        if case == "arrays":
+            assert len(counts) >= 1

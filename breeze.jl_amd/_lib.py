@@ -77,6 +77,15 @@ class bz_kessler_fields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _KESSLER_FIELDS]
 
 
+_KESSLER_MODEL_FIELDS = ("cloud_liquid_density", "rain_density", "U0_cloud_liquid_density", "U0_rain_density",
+                         "G_cloud_liquid_density", "G_rain_density", "vapor_mass_fraction", "cloud_liquid_mass_fraction",
+                         "rain_mass_fraction", "rain_terminal_velocity", "precipitation_rate")
+
+
+class bz_kessler_model_fields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _KESSLER_MODEL_FIELDS]
+
+
 _CSTATE_FIELDS = ("rho_d", "rho", "rho_u", "rho_v", "rho_w", "rho_theta", "rho_q", "u", "v", "w", "theta", "q", "T", "p")
 _CPROG_FIELDS = ("rho_d", "rho_u", "rho_v", "rho_w", "rho_theta", "rho_q")
 _SUBSTEPPER_FIELDS = ("exner", "potential_temperature", "gamma_R_mixture", "density_perturbation",
@@ -164,6 +173,9 @@ SYMBOLS = {
     "bz_compute_moisture_tendency": (C.c_int, [_ctx, _csp, _cpp, _asp]),
     "bz_kessler_microphysics_update": (C.c_int, [_ctx, C.POINTER(bz_kessler_microphysics), C.POINTER(bz_kessler_fields),
                                                  C.c_double, C.c_double]),
+    "bz_set_kessler_microphysics": (C.c_int, [_ctx, C.POINTER(bz_kessler_microphysics), C.POINTER(bz_kessler_model_fields),
+                                              C.c_double]),
+    "bz_kessler_model_update": (C.c_int, [_ctx, _sp, _pp, C.c_double]),
     "bz_cell_advection_timescale": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "bz_any_nan": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),

@@ -98,7 +98,7 @@ struct PDFields {
     const double *phi_below;                // y-slab only: phi of row j = -1 (neighbour rank), layout [k][i]
 };
 
-template <bool SA>      // SA: warm-phase saturation adjustment in the temperature diagnosis
+template <int SA>       // 0: no microphysics, 1: warm-phase saturation adjustment, 2: Kessler condensate species
 __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F, double dt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
@@ -132,7 +132,13 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const double Rm = qd * g.Rd + q * g.Rv;
     const double cpm = qd * g.cpd + q * g.cpv;
     double T, qvv = 0.0, qll = 0.0;
-    if (SA) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
+    double qcl = 0.0, qr = 0.0;
+    if (SA == 2) {
+        qcl = g.rqcl_field[n] / rc;
+        qr = g.rqr_field[n] / rc;
+        qvv = q;
+        T = bz_kessler_T(g, th, q, qcl + qr, g.p_r[k]);
+    } else if (SA == 1) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
     else T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : pow(g.p_r[k] / g.pst, Rm / cpm) * th;
 
     st_img(F.phi, n, p, ox, oy);
@@ -143,9 +149,16 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     st_img(F.theta, n, th, ox, oy);
     st_img(F.q, n, q, ox, oy);
     st_img(F.T, n, T, ox, oy);
-    if (SA) {
+    if (SA == 1) {
         st_img(g.qv_field, n, qvv, ox, oy);
         st_img(g.ql_field, n, qll, ox, oy);
+    }
+    if (SA == 2) {
+        st_img(g.qv_field, n, qvv, ox, oy);
+        st_img(g.qcl_field, n, qcl, ox, oy);
+        st_img(g.qr_field, n, qr, ox, oy);
+        st_img_only(g.rqcl_field, n, g.rqcl_field[n], ox, oy);
+        st_img_only(g.rqr_field, n, g.rqr_field[n], ox, oy);
     }
     st_img_only(F.rtheta, n, rth, ox, oy);
     st_img_only(F.rq, n, rq, ox, oy);
@@ -164,9 +177,16 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
         st_img(F.theta, n + h, th, ox, oy);
         st_img(F.q, n + h, q, ox, oy);
         st_img(F.T, n + h, T, ox, oy);
-        if (SA) {
+        if (SA == 1) {
             st_img(g.qv_field, n + h, qvv, ox, oy);
             st_img(g.ql_field, n + h, qll, ox, oy);
+        }
+        if (SA == 2) {
+            st_img(g.qv_field, n + h, qvv, ox, oy);
+            st_img(g.qcl_field, n + h, qcl, ox, oy);
+            st_img(g.qr_field, n + h, qr, ox, oy);
+            st_img(g.rqcl_field, n + h, g.rqcl_field[n], ox, oy);
+            st_img(g.rqr_field, n + h, g.rqr_field[n], ox, oy);
         }
         st_img(F.rtheta, n + h, rth, ox, oy);
         st_img(F.rq, n + h, rq, ox, oy);
@@ -225,10 +245,12 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double
     F.phi_c = phi_c ? phi_c : ctx->d_rhs;
     F.phi_below = phi_below;
     dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
-    if (g.microphysics == 1)
-        hipLaunchKernelGGL((k_project_diagnose<true>), grid, block, 0, ctx->stream, g, F, dt);
+    if (g.microphysics == 2)
+        hipLaunchKernelGGL((k_project_diagnose<2>), grid, block, 0, ctx->stream, g, F, dt);
+    else if (g.microphysics == 1)
+        hipLaunchKernelGGL((k_project_diagnose<1>), grid, block, 0, ctx->stream, g, F, dt);
     else
-        hipLaunchKernelGGL((k_project_diagnose<false>), grid, block, 0, ctx->stream, g, F, dt);
+        hipLaunchKernelGGL((k_project_diagnose<0>), grid, block, 0, ctx->stream, g, F, dt);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -29,10 +29,13 @@ struct DevGrid {
     double g, Rd, Rv, cpd, cpv, pst;
     int formulation;       // 0: liquid-ice potential temperature (theta), 1: static energy (e) in the `theta` slots
     // microphysics = SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) (bz_set_saturation_adjustment)
-    int microphysics;      // 0: nothing (q = q^v), 1: warm-phase saturation adjustment (q = q^e; q^v, q^l diagnosed)
+    int microphysics;      // 0: nothing (q = q^v), 1: warm-phase saturation adjustment (q = q^e; q^v, q^l diagnosed),
+                           // 2: DCMIP2016 Kessler (q = q^v; rho q^cl, rho q^r prognostic)
     int sa_maxiter;
     double sa_Ll, sa_cl, sa_dc, sa_L0, sa_Ttr, sa_ptr, sa_abstol;   // dc = cpv - cl, L0 = Ll - dc * T_energy
     double *qv_field, *ql_field;                                     // model.microphysical_fields.q^v, q^l (parents)
+    // microphysics == 2: DCMIP2016KesslerMicrophysics — prognostic rho q^cl, rho q^r, diagnostic q^cl, q^r (qv_field = mu.q^v)
+    double *rqcl_field, *rqr_field, *qcl_field, *qr_field;
     int wrap_y;            // 1: y halos are this rank's own periodic images; 0: y-slab, halos filled by the neighbour ranks
 
     __host__ __device__ inline long long idx(int i, int j, int k) const {
@@ -71,7 +74,8 @@ __device__ __forceinline__ double bz_buoyancy(const DevGrid &g, const double *__
                                               long long n, int k)
 {
     double qv, ql = 0.0;
-    if (g.microphysics) { qv = g.qv_field[n]; ql = g.ql_field[n]; }
+    if (g.microphysics == 1) { qv = g.qv_field[n]; ql = g.ql_field[n]; }
+    else if (g.microphysics == 2) { qv = q[n]; ql = g.qcl_field[n] + g.qr_field[n]; }
     else qv = q[n];
     const double Rm = (1.0 - (qv + ql)) * g.Rd + qv * g.Rv;
     const double rhop = g.rho[k] * (g.Rd * g.T_r[k] / (Rm * T[n]) - 1.0);
@@ -79,6 +83,14 @@ __device__ __forceinline__ double bz_buoyancy(const DevGrid &g, const double *__
 }
 // Warm-phase saturation adjustment of a liquid-ice potential temperature state (saturation_adjustment.jl:168-235 with
 // clausius_clapeyron.jl:59-68, vapor_saturation.jl:250-256, Solvers.jl:243-262): returns T, sets qv, ql.
+// Kessler moisture state: q = (q^v, q^cl + q^r), T = Pi(q) theta + L q^l / c_pm  (dcmip2016_kessler.jl:222-227,298-303;
+// dynamic_states.jl:46-58)
+__device__ __forceinline__ double bz_kessler_T(const DevGrid &g, double th, double qv, double ql, double pr)
+{
+    const double qd = 1.0 - (qv + ql);
+    const double cpm = qd * g.cpd + qv * g.cpv + ql * g.sa_cl;
+    return pow(pr / g.pst, (qd * g.Rd + qv * g.Rv) / cpm) * th + (g.sa_Ll * ql) / cpm;
+}
 __device__ __forceinline__ double bz_sa_psat(const DevGrid &g, double T)
 {
     return g.sa_ptr * pow(T / g.sa_Ttr, g.sa_dc / g.Rv) * exp((1.0 / g.sa_Ttr - 1.0 / T) * g.sa_L0 / g.Rv);
@@ -171,6 +183,10 @@ struct bz_ctx {
     double *d_tfac_ac = nullptr;      // centre array: Thomas factors t_k of the acoustic column system (per stage)
     double *d_up2 = nullptr, *d_vp2 = nullptr;   // second buffers of the (rho u)', (rho v)' ping-pong (fused substep)
     bool ac_fused = true;             // horizontal step folded into the forward column sweep (BZ_NO_AC_FUSE=1 disables)
+    // DCMIP2016KesslerMicrophysics attached to the model (bz_set_kessler_microphysics)
+    bz_kessler_microphysics kessler_params;
+    bz_kessler_model_fields kessler;
+    double kessler_pst = 1e5;
     double *up2_user = nullptr, *vp2_user = nullptr;   // caller-owned replacements of d_up2 / d_vp2 (bz_set_acoustic_scratch)
     alignas(8) unsigned char ac_stage_storage[160] = {0};   // AcStage of the stage in flight (bz_compressible.hip)
     // profiling
@@ -216,6 +232,9 @@ struct ProfileScope {
 
 // internal entry points shared between translation units
 int bzi_fill_halo(bz_ctx *ctx, double *f, int kind);
+int bzi_kessler_tendencies(bz_ctx *ctx, const bz_state *s);
+int bzi_kessler_rk3(bz_ctx *ctx, double dt, double alpha, bool first);
+int bzi_kessler_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt);
 int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, int n);
 int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
 void bzi_poisson_teardown(bz_ctx *ctx);

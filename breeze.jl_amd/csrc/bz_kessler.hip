@@ -187,3 +187,102 @@ extern "C" int bz_kessler_microphysics_update(bz_ctx *ctx, const bz_kessler_micr
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DCMIP2016KesslerMicrophysics attached to the anelastic AtmosphereModel: the two condensate species become prognostic
+// (prognostic_field_names = (:rho q^cl, :rho q^r), dcmip2016_kessler.jl:216), the temperature diagnosis and the buoyancy use
+// the moisture fractions (q^v, q^cl + q^r) (:298-303), and the column update closes every time step (:449-486).
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int bz_set_kessler_microphysics(bz_ctx *ctx, const bz_kessler_microphysics *params, const bz_kessler_model_fields *f,
+                                           double standard_pressure)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    DevGrid &g = ctx->dg;
+    if (!params) {
+        if (g.microphysics == 2) g.microphysics = 0;
+        return BZ_OK;
+    }
+    if (!f || !f->cloud_liquid_density || !f->rain_density || !f->U0_cloud_liquid_density || !f->U0_rain_density ||
+        !f->G_cloud_liquid_density || !f->G_rain_density || !f->vapor_mass_fraction || !f->cloud_liquid_mass_fraction ||
+        !f->rain_mass_fraction || !f->rain_terminal_velocity || !f->precipitation_rate)
+        return BZ_ERR_INVALID;
+    if (ctx->compressible || g.formulation != 0 || ctx->slab_mode) {
+        ctx->last_error = "Kessler microphysics is attached to the single-GPU anelastic potential-temperature model in this build";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    ctx->kessler_params = *params;
+    ctx->kessler = *f;
+    ctx->kessler_pst = standard_pressure;
+    g.microphysics = 2;
+    g.sa_Ll = params->liquid_latent_heat;
+    g.sa_cl = params->liquid_heat_capacity;
+    g.qv_field = f->vapor_mass_fraction;
+    g.ql_field = nullptr;
+    g.rqcl_field = f->cloud_liquid_density;
+    g.rqr_field = f->rain_density;
+    g.qcl_field = f->cloud_liquid_mass_fraction;
+    g.qr_field = f->rain_mass_fraction;
+    return BZ_OK;
+}
+
+// ssp_rk3_substep! of the two condensate species [+ store_initial_state! when first] (ssp_runge_kutta_3.jl:114-186)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_rk3_two(DevGrid g, double *__restrict__ a, double *__restrict__ a0, const double *__restrict__ Ga,
+                                                 double *__restrict__ b, double *__restrict__ b0, const double *__restrict__ Gb,
+                                                 double dt, double alpha)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)g.Ny * g.Sx) return;
+    const long long n = g.Sxy * ((long long)blockIdx.y + g.Hz) + (long long)g.Hy * g.Sx + t;
+    const double oma = 1.0 - alpha;
+    const double ua = a[n], ub = b[n];
+    if (FIRST) {
+        a0[n] = ua;
+        b0[n] = ub;
+        a[n] = oma * ua + alpha * (ua + dt * Ga[n]);
+        b[n] = oma * ub + alpha * (ub + dt * Gb[n]);
+    } else {
+        a[n] = oma * a0[n] + alpha * (ua + dt * Ga[n]);
+        b[n] = oma * b0[n] + alpha * (ub + dt * Gb[n]);
+    }
+}
+
+int bzi_kessler_rk3(bz_ctx *ctx, double dt, double alpha, bool first)
+{
+    const DevGrid &g = ctx->dg;
+    const bz_kessler_model_fields &K = ctx->kessler;
+    ProfileScope ps(ctx, "kessler_species_rk3");
+    const long long per_level = (long long)g.Ny * g.Sx;
+    dim3 grid((unsigned)((per_level + 255) / 256), g.Nz), block(256);
+    if (first)
+        hipLaunchKernelGGL(k_rk3_two<true>, grid, block, 0, ctx->stream, g, K.cloud_liquid_density, K.U0_cloud_liquid_density,
+                           K.G_cloud_liquid_density, K.rain_density, K.U0_rain_density, K.G_rain_density, dt, alpha);
+    else
+        hipLaunchKernelGGL(k_rk3_two<false>, grid, block, 0, ctx->stream, g, K.cloud_liquid_density, K.U0_cloud_liquid_density,
+                           K.G_cloud_liquid_density, K.rain_density, K.U0_rain_density, K.G_rain_density, dt, alpha);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// microphysics_model_update!: the column kernel, then update_state!(model) (dcmip2016_kessler.jl:480-485)
+int bzi_kessler_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt)
+{
+    const bz_kessler_model_fields &K = ctx->kessler;
+    bz_kessler_fields F;
+    F.density = nullptr; F.pressure = nullptr;
+    F.potential_temperature = s->theta; F.potential_temperature_density = s->rho_theta;
+    F.moisture_density = s->rho_q; F.cloud_liquid_density = K.cloud_liquid_density; F.rain_density = K.rain_density;
+    F.vapor_mass_fraction = K.vapor_mass_fraction; F.cloud_liquid_mass_fraction = K.cloud_liquid_mass_fraction;
+    F.rain_mass_fraction = K.rain_mass_fraction; F.rain_terminal_velocity = K.rain_terminal_velocity;
+    F.precipitation_rate = K.precipitation_rate;
+    int rc = bz_kessler_microphysics_update(ctx, &ctx->kessler_params, &F, dt, ctx->kessler_pst);
+    if (rc) return rc;
+    return bz_update_state(ctx, s, G, 1);
+}
+
+extern "C" int bz_kessler_model_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt)
+{
+    if (!ctx || !s || !G) return BZ_ERR_INVALID;
+    if (ctx->dg.microphysics != 2) { ctx->last_error = "bz_kessler_model_update: no Kessler microphysics attached"; return BZ_ERR_INVALID; }
+    return bzi_kessler_update(ctx, s, G, dt);
+}

@@ -10,9 +10,9 @@ extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognost
     int rc;
     // fill_halo_regions!(prognostic_fields(model))  (:48) — momentum halos are filled inside
     // bz_compute_velocities (:135-136), the scalars here.
-    double *sf[2] = {s->rho_theta, s->rho_q};
-    int sk[2] = {0, 0};
-    if ((rc = bzi_fill_halos_multi(ctx, sf, sk, 2))) return rc;
+    double *sf[4] = {s->rho_theta, s->rho_q, ctx->dg.rqcl_field, ctx->dg.rqr_field};
+    int sk[4] = {0, 0, 0, 0};
+    if ((rc = bzi_fill_halos_multi(ctx, sf, sk, ctx->dg.microphysics == 2 ? 4 : 2))) return rc;
     // compute_auxiliary_variables!  (:207-223)
     if ((rc = bz_compute_velocities(ctx, s))) return rc;
     if ((rc = bz_compute_auxiliary_thermodynamic_variables(ctx, s))) return rc;
@@ -31,7 +31,7 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
     }
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
-    if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0) {
+    if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state
         // left by stage s-1), the predictor momentum goes to the G arrays and is projected from there into the
@@ -57,11 +57,14 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
         for (int stage = 0; stage < 3; ++stage) {
             const double alpha = alphas[stage];
             if ((rc = bzi_rk3_fused(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+            if (ctx->dg.microphysics == 2 && (rc = bzi_kessler_rk3(ctx, dt, alpha, stage == 0))) return rc;
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
             if ((rc = bzi_project_diagnose(ctx, s, alpha * dt))) return rc;
             if ((rc = bz_compute_tendencies(ctx, s, G))) return rc;
         }
+        // microphysics_model_update!(model.microphysics, model) closes the step (ssp_runge_kutta_3.jl:262-263)
+        if (ctx->dg.microphysics == 2 && (rc = bzi_kessler_update(ctx, s, G, dt))) return rc;
         return BZ_OK;
     }
     if (ctx->G_is_predictor && (rc = bz_compute_tendencies(ctx, s, G))) return rc;
@@ -73,5 +76,6 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
         if ((rc = bz_make_pressure_correction(ctx, s, alpha * dt))) return rc;       // :233,247,261
         if ((rc = bz_update_state(ctx, s, G, 1))) return rc;                         // :236,250,270
     }
+    if (ctx->dg.microphysics == 2 && (rc = bzi_kessler_update(ctx, s, G, dt))) return rc;
     return BZ_OK;
 }

@@ -351,6 +351,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
             hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q, kc);
         }
     }
+    if (g.microphysics == 2) {
+        int rck = bzi_kessler_tendencies(ctx, s);
+        if (rck) return rck;
+    }
     if (g.formulation == 1) {
         ProfileScope ps(ctx, "static_energy_buoyancy_flux");
         hipLaunchKernelGGL(k_energy_buoyancy_flux, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
@@ -391,6 +395,23 @@ int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
     if (rc) return rc;
     rc = bzi_scalar_pair_tendency(ctx, s, G, U0, &E);
     if (rc) return rc;
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// scalar tendencies of the Kessler condensate species: G = -div_rhoUc(q^cl), -div_rhoUc(q^r)
+// (update_atmosphere_model_state.jl:352-372 with prognostic_field_names(::DCMIP2016KM), dcmip2016_kessler.jl:216)
+int bzi_kessler_tendencies(bz_ctx *ctx, const bz_state *s)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "kessler_species_tendencies");
+    dim3 block(64, TYB);
+    int kc = pick_kchunk(g, g.Nz);
+    dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
+    hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, ctx->kessler.G_cloud_liquid_density, s->u, s->v, s->w,
+                       ctx->kessler.cloud_liquid_mass_fraction, kc);
+    hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, ctx->kessler.G_rain_density, s->u, s->v, s->w,
+                       ctx->kessler.rain_mass_fraction, kc);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -74,15 +74,10 @@ class KesslerMicrophysicalFields:
         self.precipitation_rate = torch.zeros((g.Ny + 2 * g.Hy, g.Nx + 2 * g.Hx), dtype=torch.float64, device=model.device)
 
 
-def microphysics_model_update_(microphysics, model, fields, Δt, tetens=None, density=None, pressure=None,
-                               standard_pressure=None):
-    """microphysics_model_update!(microphysics::DCMIP2016KesslerMicrophysics, model) (dcmip2016_kessler.jl:449-486) without
-    the trailing update_state!: one launch of the column kernel.  `density` / `pressure`: 3-D Fields (compressible) or None
-    for the anelastic reference columns of the model's context."""
-    import ctypes as C
+def kessler_parameter_struct(microphysics, constants, tetens=None):
+    """bz_kessler_microphysics from DCMIP2016KesslerMicrophysics + the TetensFormula / liquid phase of the constants."""
     from . import _lib
-    tf = tetens or TetensFormula()
-    c = model.thermodynamic_constants
+    tf = tetens or getattr(constants, "saturation_vapor_pressure", None) or TetensFormula()
     P = _lib.bz_kessler_microphysics()
     for k in DCMIP2016KesslerMicrophysics.DEFAULTS:
         setattr(P, k, getattr(microphysics, k))
@@ -90,7 +85,23 @@ def microphysics_model_update_(microphysics, model, fields, Δt, tetens=None, de
     P.tetens_reference_temperature = tf.reference_temperature
     P.tetens_liquid_coefficient = tf.liquid_coefficient
     P.tetens_liquid_temperature_offset = tf.liquid_temperature_offset
-    P.liquid_latent_heat, P.liquid_heat_capacity = c.liquid_reference_latent_heat, c.liquid_heat_capacity
+    P.liquid_latent_heat, P.liquid_heat_capacity = constants.liquid_reference_latent_heat, constants.liquid_heat_capacity
+    return P
+
+
+def microphysics_model_update_(microphysics, model, fields=None, Δt=None, tetens=None, density=None, pressure=None,
+                               standard_pressure=None):
+    """microphysics_model_update!(microphysics::DCMIP2016KesslerMicrophysics, model) (dcmip2016_kessler.jl:449-486) without
+    the trailing update_state!: one launch of the column kernel.  `density` / `pressure`: 3-D Fields (compressible) or None
+    for the anelastic reference columns of the model's context."""
+    import ctypes as C
+    from . import _lib
+    if fields is None:          # the model owns the Kessler fields: microphysics_model_update!(microphysics, model)
+        Δt = model.clock.last_Δt if Δt is None else Δt
+        model._check(model._lib.bz_kessler_model_update(model._ctx, C.byref(model._state), C.byref(model._G), float(Δt)),
+                     "bz_kessler_model_update")
+        return
+    P = kessler_parameter_struct(microphysics, model.thermodynamic_constants, tetens)
     F = _lib.bz_kessler_fields()
     F.density = density.ptr() if density is not None else None
     F.pressure = pressure.ptr() if pressure is not None else None

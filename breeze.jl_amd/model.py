@@ -40,7 +40,7 @@ class AnelasticDynamics:
 
 class Clock:
     def __init__(self):
-        self.time, self.iteration = 0.0, 0
+        self.time, self.iteration, self.last_Δt = 0.0, 0, float("inf")
 
 
 class Field:
@@ -85,7 +85,7 @@ _ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "ρθ": "ρθ", "rho_the
             "u": "u", "v": "v", "w": "w", "ρu": "ρu", "ρv": "ρv", "ρw": "ρw",
             "rho_u": "ρu", "rho_v": "ρv", "rho_w": "ρw",
             "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q", "qᵉ": "q", "qe": "q", "ρqᵗ": "ρq", "ρqᵛ": "ρq", "ρqᵉ": "ρq", "ρqe": "ρq",
-            "rho_q": "ρq",
+            "rho_q": "ρq", "qᶜˡ": "qcl", "qcl": "qcl", "qʳ": "qr", "qr": "qr",
             # NFKC-normalised spellings (Python normalises identifiers used as keywords)
             "θli": "θ", "ρqt": "ρq", "ρqv": "ρq"}
 
@@ -114,12 +114,20 @@ class AtmosphereModel:
         for name, val in (("closure", closure), ("coriolis", coriolis), ("forcing", forcing)):
             if val is not None:
                 raise NotImplementedError(f"{name} is outside the hot-path scope of this build")
-        from .microphysics import SaturationAdjustment
-        if microphysics is not None and not isinstance(microphysics, SaturationAdjustment):
-            raise NotImplementedError("microphysics: only SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) is implemented")
+        from .microphysics import DCMIP2016KesslerMicrophysics, SaturationAdjustment, TetensFormula
+        if microphysics is not None and not isinstance(microphysics, (SaturationAdjustment, DCMIP2016KesslerMicrophysics)):
+            raise NotImplementedError("microphysics: SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) and "
+                                      "DCMIP2016KesslerMicrophysics() are implemented")
         if microphysics is not None and formulation != "LiquidIcePotentialTemperature":
-            raise NotImplementedError("SaturationAdjustment is implemented for the potential-temperature formulation")
+            raise NotImplementedError("microphysics is implemented for the potential-temperature formulation")
         self.microphysics = microphysics
+        self._kessler = isinstance(microphysics, DCMIP2016KesslerMicrophysics)
+        if self._kessler:      # validate_microphysics (dcmip2016_kessler.jl:196-207)
+            tcs = thermodynamic_constants
+            if tcs is None or not isinstance(getattr(tcs, "saturation_vapor_pressure", None), TetensFormula):
+                raise ValueError("DCMIP2016KesslerMicrophysics requires `thermodynamic_constants` with a `TetensFormula` "
+                                 "saturation vapor pressure formulation. Construct the model with, e.g., "
+                                 "`thermodynamic_constants = ThermodynamicConstants(saturation_vapor_pressure = TetensFormula())`.")
         if advection is None:
             raise NotImplementedError("the HIP path requires advection=WENO(order=5) "
                                       "(the reference default Centered(order=2) is not implemented)")
@@ -150,6 +158,11 @@ class AtmosphereModel:
         self.specific_moisture = fld("ccc")
         self.temperature = fld("ccc")
         dynamics.pressure_anomaly = fld("ccc")
+        self.microphysical_fields = {}
+        if self._kessler:      # materialize_microphysical_fields(::DCMIP2016KM) (dcmip2016_kessler.jl:255-290)
+            self.microphysical_fields = {k: fld("ccc") for k in ("ρqᶜˡ", "ρqʳ", "qᵛ", "qᶜˡ", "qʳ", "𝕎ʳ")}
+            self.microphysical_fields["precipitation_rate"] = torch.zeros((grid.Ny + 2 * grid.Hy, grid.Nx + 2 * grid.Hx),
+                                                                          dtype=torch.float64, device=self.device)
         prog = self.prognostic_fields()
         self.U0 = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}     # timestepper.U⁰
         self.G = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}      # timestepper.Gⁿ
@@ -181,8 +194,19 @@ class AtmosphereModel:
         if formulation == "StaticEnergy":
             self._check(lib.bz_set_formulation(self._ctx, 1), "bz_set_formulation")
         # materialize_microphysical_fields(::WarmPhaseSaturationAdjustment): (q^v, q^l, q^e); q^e is the specific moisture slot
-        self.microphysical_fields = {}
-        if microphysics is not None:
+        if self._kessler:
+            from .microphysics import kessler_parameter_struct
+            μ = self.microphysical_fields
+            P = kessler_parameter_struct(microphysics, c)
+            K = _lib.bz_kessler_model_fields()
+            K.cloud_liquid_density, K.rain_density = μ["ρqᶜˡ"].ptr(), μ["ρqʳ"].ptr()
+            K.U0_cloud_liquid_density, K.U0_rain_density = self.U0["ρqᶜˡ"].ptr(), self.U0["ρqʳ"].ptr()
+            K.G_cloud_liquid_density, K.G_rain_density = self.G["ρqᶜˡ"].ptr(), self.G["ρqʳ"].ptr()
+            K.vapor_mass_fraction, K.cloud_liquid_mass_fraction, K.rain_mass_fraction = μ["qᵛ"].ptr(), μ["qᶜˡ"].ptr(), μ["qʳ"].ptr()
+            K.rain_terminal_velocity, K.precipitation_rate = μ["𝕎ʳ"].ptr(), μ["precipitation_rate"].data_ptr()
+            self._check(lib.bz_set_kessler_microphysics(self._ctx, C.byref(P), C.byref(K), ref.standard_pressure),
+                        "bz_set_kessler_microphysics")
+        elif microphysics is not None:
             self.microphysical_fields = {"qᵛ": fld("ccc"), "qˡ": fld("ccc"), "qᵉ": self.specific_moisture}
             sa = _lib.bz_saturation_adjustment(c.liquid_reference_latent_heat, c.liquid_heat_capacity,
                                                c.energy_reference_temperature, c.triple_point_temperature,
@@ -203,8 +227,11 @@ class AtmosphereModel:
         _lib.check(self._lib, self._ctx, rc, what)
 
     def prognostic_fields(self):
-        return {"ρu": self.momentum["ρu"], "ρv": self.momentum["ρv"], "ρw": self.momentum["ρw"],
-                "ρθ": self.potential_temperature_density, "ρq": self.moisture_density}
+        out = {"ρu": self.momentum["ρu"], "ρv": self.momentum["ρv"], "ρw": self.momentum["ρw"],
+               "ρθ": self.potential_temperature_density, "ρq": self.moisture_density}
+        if getattr(self, "_kessler", False):
+            out["ρqᶜˡ"], out["ρqʳ"] = self.microphysical_fields["ρqᶜˡ"], self.microphysical_fields["ρqʳ"]
+        return out
 
     def _make_state(self):
         s = _lib.bz_state()
@@ -358,6 +385,12 @@ def set_(model, enforce_mass_conservation=True, **kw):
             model.moisture_density.interior.copy_(ρc * model.specific_moisture.interior)
         elif key == "ρq":
             model.moisture_density.set_interior(value)
+        elif key in ("qcl", "qr"):          # settable specific microphysical names (set_atmosphere_model.jl:247-253)
+            if not getattr(model, "_kessler", False):
+                raise ValueError(f"Cannot set! {name}: the model has no Kessler microphysics")
+            spec, dens = ("qᶜˡ", "ρqᶜˡ") if key == "qcl" else ("qʳ", "ρqʳ")
+            model.microphysical_fields[spec].set_interior(value)
+            model.microphysical_fields[dens].interior.copy_(ρc * model.microphysical_fields[spec].interior)
         elif key in ("u", "v"):
             model.velocities[key].set_interior(value)
             model.momentum["ρ" + key].interior.copy_(ρc * model.velocities[key].interior)
@@ -387,7 +420,11 @@ def time_step_(model, Δt, whole_step=True):
             compute_pressure_correction_(model, α * Δt)
             make_pressure_correction_(model, α * Δt)
             update_state_(model, compute_tendencies=True)
+        if getattr(model, "_kessler", False):
+            from .microphysics import microphysics_model_update_
+            microphysics_model_update_(model.microphysics, model, Δt=Δt)
     model.clock.time += Δt
+    model.clock.last_Δt = float(Δt)
     model.clock.iteration += 1
 
 

@@ -11,7 +11,9 @@ class ThermodynamicConstants:
                  triple_point_pressure=611.657, dry_air_molar_mass=0.02897, dry_air_heat_capacity=1005,
                  vapor_molar_mass=0.018015, vapor_heat_capacity=1850,
                  liquid_reference_latent_heat=2500800, liquid_heat_capacity=4181,
-                 ice_reference_latent_heat=2834000, ice_heat_capacity=2108):
+                 ice_reference_latent_heat=2834000, ice_heat_capacity=2108, saturation_vapor_pressure=None):
+        # saturation_vapor_pressure: None = ClausiusClapeyron (default) or a TetensFormula (breeze.jl_amd/microphysics.py)
+        self.saturation_vapor_pressure = saturation_vapor_pressure
         self.molar_gas_constant = float(molar_gas_constant)
         self.gravitational_acceleration = float(gravitational_acceleration)
         self.energy_reference_temperature = float(energy_reference_temperature)

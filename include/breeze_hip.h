@@ -357,6 +357,23 @@ typedef struct bz_kessler_fields {
 } bz_kessler_fields;
 int bz_kessler_microphysics_update(bz_ctx *ctx, const bz_kessler_microphysics *params, const bz_kessler_fields *fields,
                                    double dt, double standard_pressure);
+/* AtmosphereModel(...; microphysics = DCMIP2016KesslerMicrophysics()) for AnelasticDynamics: rho q^cl and rho q^r join the
+ * prognostic fields (prognostic_field_names, dcmip2016_kessler.jl:216) with their U0 / Gn storage; the specific moisture slot
+ * of bz_state is q^v; update_state! diagnoses q^cl, q^r, q^v and T = Pi(q) theta + L q^l/c_pm with q = (q^v, q^cl + q^r)
+ * (:222-227,298-303,860-865); compute_tendencies! adds -div_rhoUc of both species; ssp_rk3_substep! / store_initial_state!
+ * include them; bz_time_step_anelastic ends with the column update + update_state! (ssp_runge_kutta_3.jl:262-263).
+ * params == NULL detaches.  bz_kessler_model_update is microphysics_model_update!(microphysics, model) for per-operator drivers. */
+typedef struct bz_kessler_model_fields {
+    double *cloud_liquid_density, *rain_density;                 /* mu.rho q^cl, mu.rho q^r (prognostic) */
+    double *U0_cloud_liquid_density, *U0_rain_density;           /* timestepper.U0                        */
+    double *G_cloud_liquid_density, *G_rain_density;             /* timestepper.Gn                        */
+    double *vapor_mass_fraction, *cloud_liquid_mass_fraction, *rain_mass_fraction;     /* mu.q^v, q^cl, q^r */
+    double *rain_terminal_velocity;                              /* mu.W^r                                */
+    double *precipitation_rate;                                  /* horizontal parent (Sx x Sy)           */
+} bz_kessler_model_fields;
+int bz_set_kessler_microphysics(bz_ctx *ctx, const bz_kessler_microphysics *params, const bz_kessler_model_fields *fields,
+                                double standard_pressure);
+int bz_kessler_model_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt);
 
 /* ---- the reductions of the run! loop around the step ---- */
 /* cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): minimum over the interior of

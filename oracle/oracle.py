@@ -262,7 +262,7 @@ class OracleModel:
         self.formulation = formulation
         # microphysics "SaturationAdjustment": SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()); self.q / self.rq
         # then hold the equilibrium (total) moisture q^e / rho q^e, self.qv / self.ql the diagnosed vapour and liquid
-        assert microphysics in (None, "SaturationAdjustment")
+        assert microphysics in (None, "SaturationAdjustment", "Kessler")
         assert not (microphysics and formulation == "StaticEnergy"), "oracle: saturation adjustment with theta only"
         self.microphysics = microphysics
         self.grid = g = grid
@@ -275,6 +275,17 @@ class OracleModel:
         self.lib = lib()
         self._mk_cgrid()
         self.qv, self.ql = g.center_field(), g.center_field()
+        # DCMIP2016KesslerMicrophysics: prognostic rho q^cl, rho q^r; diagnostic q^cl, q^r, W^r, precipitation_rate; self.q = q^v
+        # (dcmip2016_kessler.jl:216-290); ql holds q^cl + q^r for the buoyancy
+        if microphysics == "Kessler":
+            from .kessler import KesslerParameters, TetensConstants
+            self.PROGNOSTIC = OracleModel.PROGNOSTIC + ("rqcl", "rqr")
+            self.rqcl, self.rqr, self.qcl, self.qr, self.W = (g.center_field() for _ in range(5))
+            self.precipitation_rate = np.zeros((g.Ny, g.Nx))
+            self.kessler = KesslerParameters()
+            c0 = self.constants
+            self.tetens = TetensConstants(molar_gas_constant=c0.R, dry_air_molar_mass=c0.Md, vapor_molar_mass=c0.Mv,
+                                          dry_air_heat_capacity=c0.cpd, vapor_heat_capacity=c0.cpv)
         from .thermo import ThermoConstants
         tc = ThermoConstants()
         self._sa = _OGSA(tc.Ll, tc.cl, tc.T_energy, tc.Ttr, tc.ptr, float(sa_abstol), int(sa_maxiter))
@@ -349,6 +360,8 @@ class OracleModel:
                 g.interior(self.rq)[...] = rho_c * g.interior(self.q)
             elif name == "rq":
                 g.interior(self.rq)[...] = self._eval(value, "ccc")
+            elif name in ("qcl", "qr") and self.microphysics == "Kessler":     # settable specific microphysical names
+                g.interior(getattr(self, "r" + name))[...] = rho_c * self._eval(value, "ccc")
             elif name == "u":
                 g.interior(self.u)[...] = self._eval(value, "fcc")
                 g.interior(self.ru)[...] = rho_c * g.interior(self.u)
@@ -402,7 +415,27 @@ class OracleModel:
         self.lib.og_compute_velocities(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv), _p(self.rw))
         for f in (self.u, self.v, self.w):
             self._halo_velocity(f)
-        if self.microphysics == "SaturationAdjustment":
+        if self.microphysics == "Kessler":
+            # microphysical_state + grid_moisture_fractions + update_microphysical_auxiliaries! (dcmip2016_kessler.jl:222-227,
+            # 298-303,860-865): q = (q^v, q^cl + q^r), T = Pi(q) theta + L q^l / c_pm
+            self._halo_center(self.rqcl)
+            self._halo_center(self.rqr)
+            g, c, t = self.grid, self.constants, self.tetens
+            I = g.interior
+            rho = self.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+            pr = self.ref.pressure[g.Hz:g.Hz + g.Nz][:, None, None]
+            th, qv = I(self.rtheta) / rho, I(self.rq) / rho
+            qcl, qr = I(self.rqcl) / rho, I(self.rqr) / rho
+            ql = qcl + qr
+            qd = 1.0 - (qv + ql + 0.0)
+            Rm = qd * c.Rd + qv * c.Rv
+            cpm = qd * c.cpd + qv * c.cpv + ql * t.cl + 0.0
+            I(self.theta)[...], I(self.q)[...], I(self.qcl)[...], I(self.qr)[...] = th, qv, qcl, qr
+            I(self.qv)[...], I(self.ql)[...] = qv, ql
+            I(self.T)[...] = (pr / self.ref.pst) ** (Rm / cpm) * th + (t.Ll * ql + 0.0) / cpm
+            for f in (self.qcl, self.qr, self.qv, self.ql):
+                self._halo_center(f)
+        elif self.microphysics == "SaturationAdjustment":
             self.lib.og_compute_thermo_sa(cg, C.byref(self._sa), _p(self.theta), _p(self.q), _p(self.qv), _p(self.ql),
                                           _p(self.T), _p(self.rtheta), _p(self.rq))
             self._halo_center(self.qv)
@@ -422,7 +455,10 @@ class OracleModel:
         L, G = self.lib, self.G
         L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
         L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
-        if self.microphysics == "SaturationAdjustment":
+        if self.microphysics == "Kessler":
+            L.og_scalar_tendency(cg, _p(G["rqcl"]), _p(self.u), _p(self.v), _p(self.w), _p(self.qcl))
+            L.og_scalar_tendency(cg, _p(G["rqr"]), _p(self.u), _p(self.v), _p(self.w), _p(self.qr))
+        if self.microphysics in ("SaturationAdjustment", "Kessler"):
             L.og_w_tendency_moist(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w), _p(self.T),
                                   _p(self.qv), _p(self.ql))
         else:
@@ -494,5 +530,25 @@ class OracleModel:
             self.compute_pressure_correction(alpha * dt)
             self.make_pressure_correction(alpha * dt)
             self.update_state(compute_tendencies=True)
+        if self.microphysics == "Kessler":
+            self.microphysics_model_update(dt)
         self.clock_time += dt
         self.iteration += 1
+
+    def microphysics_model_update(self, dt):
+        """microphysics_model_update!(::DCMIP2016KesslerMicrophysics, model) (dcmip2016_kessler.jl:449-486): the column
+        kernel on every column, then update_state!."""
+        from .kessler import kessler_column_update
+        g = self.grid
+        I = g.interior
+        rho = np.ascontiguousarray(self.ref.density[g.Hz:g.Hz + g.Nz])
+        p = np.ascontiguousarray(self.ref.pressure[g.Hz:g.Hz + g.Nz])
+        for j in range(g.Ny):
+            for i in range(g.Nx):
+                cols = [np.ascontiguousarray(I(f)[:, j, i]) for f in (self.theta, self.rtheta, self.rq, self.rqcl, self.rqr)]
+                qv, qcl, qr, W, P, _ = kessler_column_update(dt, rho, p, self.ref.pst, g.zc, *cols, self.kessler, self.tetens)
+                for f, col in zip((self.theta, self.rtheta, self.rq, self.rqcl, self.rqr), cols):
+                    I(f)[:, j, i] = col
+                I(self.q)[:, j, i], I(self.qv)[:, j, i], I(self.qcl)[:, j, i], I(self.qr)[:, j, i], I(self.W)[:, j, i] = qv, qv, qcl, qr, W
+                self.precipitation_rate[j, i] = P
+        self.update_state(compute_tendencies=True)

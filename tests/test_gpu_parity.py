@@ -453,3 +453,61 @@ def test_kessler_column_update_matches_oracle(oracle, bz):
                 assert precip[j, i] == pytest.approx(oP, rel=1e-11, abs=1e-18)
         if case == "arrays":
             assert len(counts) >= 1
+
+
+def _kessler_pair(oracle, bz, size=(16, 12, 20)):
+    extent = ((0.0, 4e3), (0.0, 3e3), (0.0, 5e3))
+    og = oracle.Grid(size, x=extent[0], y=extent[1], z=extent[2])
+    om = oracle.OracleModel(og, surface_pressure=1e5, potential_temperature=300.0, microphysics="Kessler")
+    grid = bz.RectilinearGrid(size, x=extent[0], y=extent[1], z=extent[2])
+    tc = bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula())
+    ref = bz.ReferenceState(grid, tc, surface_pressure=1e5, potential_temperature=300.0)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), thermodynamic_constants=tc,
+                            microphysics=bz.DCMIP2016KesslerMicrophysics())
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt((x - 2e3) ** 2 + (y - 1.5e3) ** 2 + (z - 1500.0) ** 2) / 1200.0)
+    ic = dict(qt=lambda x, y, z: 0.016 * np.exp(-z / 3000.0) + 0.004 * bub(x, y, z),
+              theta=lambda x, y, z: 300.0 + 0.004 * z + 1.0 * bub(x, y, z),
+              qcl=lambda x, y, z: 0.003 * bub(x, y, z), qr=lambda x, y, z: 0.001 * bub(x, y, z), u=2.0)
+    return om, hm, ic
+
+
+def test_kessler_model_requires_tetens_constants(bz):
+    grid = bz.RectilinearGrid((16, 12, 20), x=(0, 4e3), y=(0, 3e3), z=(0, 5e3))
+    with pytest.raises(ValueError):
+        bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid)), advection=bz.WENO(order=5),
+                           microphysics=bz.DCMIP2016KesslerMicrophysics())
+
+
+def test_anelastic_kessler_model_matches_oracle(oracle, bz):
+    """AtmosphereModel(...; microphysics = DCMIP2016KesslerMicrophysics()): diagnosis with (q^v, q^cl + q^r), species
+    tendencies, moist buoyancy, and two full steps ending with the column update, against the oracle."""
+    om, hm, ic = _kessler_pair(oracle, bz)
+    om.set(**ic)
+    hm.set(qᵗ=ic["qt"], θ=ic["theta"], qcl=ic["qcl"], qr=ic["qr"], u=ic["u"])
+    g = om.grid
+    μ = hm.microphysical_fields
+    assert relerr(hm.temperature.cpu(), om.T) < 1e-14
+    assert relerr(μ["qᶜˡ"].cpu(), om.qcl) < 1e-15 and relerr(μ["qʳ"].cpu(), om.qr) < 1e-15
+    om.compute_tendencies()
+    bz.compute_tendencies_(hm)
+    for n, k in list(PROG.items()) + [("rqcl", "ρqᶜˡ"), ("rqr", "ρqʳ")]:
+        zf = n == "rw"
+        want, got = g.interior(om.G[n], zface=zf), hm.G[k].interior_cpu()
+        if zf:
+            want, got = want[1:-1], got[1:-1]
+        assert relerr(got, want) < (5e-9 if n in ("rtheta", "rq", "rqcl", "rqr") else 1e-12), n
+    for _ in range(2):
+        om.time_step(5.0)
+        hm.time_step(5.0)
+    hm.synchronize()
+    errs = {}
+    mom = max(np.abs(_interior(om, n)).max() for n in ("ru", "rv", "rw"))
+    for n, f in (("ru", hm.momentum["ρu"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density),
+                 ("rq", hm.moisture_density), ("rqcl", μ["ρqᶜˡ"]), ("rqr", μ["ρqʳ"]), ("T", hm.temperature), ("W", μ["𝕎ʳ"])):
+        want = g.interior(getattr(om, n), n == "rw")
+        scale = mom if n in ("ru", "rw") else max(np.abs(want).max(), 1e-6)
+        errs[n] = float(np.abs(f.interior_cpu() - want).max() / scale)
+    assert all(v < 1e-8 for v in errs.values()), {k: f"{v:.1e}" for k, v in errs.items()}
+    P = μ["precipitation_rate"].cpu().numpy()[g.Hy:g.Hy + g.Ny, g.Hx:g.Hx + g.Nx]
+    assert np.abs(P - om.precipitation_rate).max() <= 1e-9 * max(np.abs(om.precipitation_rate).max(), 1e-12)
+    assert g.interior(om.W).max() > 0.5

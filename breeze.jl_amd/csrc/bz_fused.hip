@@ -134,10 +134,10 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     double T, qvv = 0.0, qll = 0.0;
     double qcl = 0.0, qr = 0.0;
     if (SA == 2) {
+        T = bz_kessler_T(g, th, q, g.qcl_field[n] + g.qr_field[n], g.p_r[k]);   // lagged condensate, as the reference (see k_thermo)
         qcl = g.rqcl_field[n] / rc;
         qr = g.rqr_field[n] / rc;
         qvv = q;
-        T = bz_kessler_T(g, th, q, qcl + qr, g.p_r[k]);
     } else if (SA == 1) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
     else T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : pow(g.p_r[k] / g.pst, Rm / cpm) * th;
 

@@ -45,8 +45,10 @@ __global__ __launch_bounds__(TX *TY) void k_thermo(DevGrid g, double *__restrict
         return;
     }
     if (g.microphysics == 2) {      // DCMIP2016 Kessler: moisture fractions from the prognostic condensate densities
+        // reference behaviour (update_atmosphere_model_state.jl:276-291): grid_moisture_fractions reads the diagnostic
+        // mu.q^cl, mu.q^r *before* update_microphysical_auxiliaries! refreshes them, so T carries the previous condensate
+        T[n] = bz_kessler_T(g, th, q, g.qcl_field[n] + g.qr_field[n], g.p_r[k]);
         const double qcl = g.rqcl_field[n] / rho, qr = g.rqr_field[n] / rho;
-        T[n] = bz_kessler_T(g, th, q, qcl + qr, g.p_r[k]);
         g.qcl_field[n] = qcl;
         g.qr_field[n] = qr;
         g.qv_field[n] = q;

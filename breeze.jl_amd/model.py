@@ -388,9 +388,10 @@ def set_(model, enforce_mass_conservation=True, **kw):
         elif key in ("qcl", "qr"):          # settable specific microphysical names (set_atmosphere_model.jl:247-253)
             if not getattr(model, "_kessler", False):
                 raise ValueError(f"Cannot set! {name}: the model has no Kessler microphysics")
-            spec, dens = ("qᶜˡ", "ρqᶜˡ") if key == "qcl" else ("qʳ", "ρqʳ")
-            model.microphysical_fields[spec].set_interior(value)
-            model.microphysical_fields[dens].interior.copy_(ρc * model.microphysical_fields[spec].interior)
+            # only ρq is set (set!(ρμ, value); set!(ρμ, ρ * ρμ)); the diagnostic field is refreshed by update_state!
+            dens = model.microphysical_fields["ρqᶜˡ" if key == "qcl" else "ρqʳ"]
+            dens.set_interior(value)
+            dens.interior.copy_(ρc * dens.interior)
         elif key in ("u", "v"):
             model.velocities[key].set_interior(value)
             model.momentum["ρ" + key].interior.copy_(ρc * model.velocities[key].interior)

@@ -360,7 +360,9 @@ class OracleModel:
                 g.interior(self.rq)[...] = rho_c * g.interior(self.q)
             elif name == "rq":
                 g.interior(self.rq)[...] = self._eval(value, "ccc")
-            elif name in ("qcl", "qr") and self.microphysics == "Kessler":     # settable specific microphysical names
+            elif name in ("qcl", "qr") and self.microphysics == "Kessler":
+                # settable specific microphysical names (set_atmosphere_model.jl:247-253): only rho*q is set; the diagnostic
+                # q^cl / q^r field is refreshed by the update_state! that follows (after T was diagnosed from the old one)
                 g.interior(getattr(self, "r" + name))[...] = rho_c * self._eval(value, "ccc")
             elif name == "u":
                 g.interior(self.u)[...] = self._eval(value, "fcc")
@@ -425,14 +427,17 @@ class OracleModel:
             rho = self.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
             pr = self.ref.pressure[g.Hz:g.Hz + g.Nz][:, None, None]
             th, qv = I(self.rtheta) / rho, I(self.rq) / rho
-            qcl, qr = I(self.rqcl) / rho, I(self.rqr) / rho
-            ql = qcl + qr
-            qd = 1.0 - (qv + ql + 0.0)
+            # NB (reference behaviour, update_atmosphere_model_state.jl:276-291): grid_moisture_fractions reads the
+            # *diagnostic* fields mu.q^cl, mu.q^r before update_microphysical_auxiliaries! refreshes them in the same kernel,
+            # so the temperature carries the condensate of the previous update_state!
+            ql_lag = I(self.qcl) + I(self.qr)
+            qd = 1.0 - (qv + ql_lag + 0.0)
             Rm = qd * c.Rd + qv * c.Rv
-            cpm = qd * c.cpd + qv * c.cpv + ql * t.cl + 0.0
+            cpm = qd * c.cpd + qv * c.cpv + ql_lag * t.cl + 0.0
+            I(self.T)[...] = (pr / self.ref.pst) ** (Rm / cpm) * th + (t.Ll * ql_lag + 0.0) / cpm
+            qcl, qr = I(self.rqcl) / rho, I(self.rqr) / rho
             I(self.theta)[...], I(self.q)[...], I(self.qcl)[...], I(self.qr)[...] = th, qv, qcl, qr
-            I(self.qv)[...], I(self.ql)[...] = qv, ql
-            I(self.T)[...] = (pr / self.ref.pst) ** (Rm / cpm) * th + (t.Ll * ql + 0.0) / cpm
+            I(self.qv)[...], I(self.ql)[...] = qv, qcl + qr
             for f in (self.qcl, self.qr, self.qv, self.ql):
                 self._halo_center(f)
         elif self.microphysics == "SaturationAdjustment":

@@ -176,6 +176,7 @@ SYMBOLS = {
     "bz_set_kessler_microphysics": (C.c_int, [_ctx, C.POINTER(bz_kessler_microphysics), C.POINTER(bz_kessler_model_fields),
                                               C.c_double]),
     "bz_kessler_model_update": (C.c_int, [_ctx, _sp, _pp, C.c_double]),
+    "bz_compressible_kessler_update": (C.c_int, [_ctx, _csp, _cpp, _asp, C.c_double]),
     "bz_cell_advection_timescale": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "bz_any_nan": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),

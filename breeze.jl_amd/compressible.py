@@ -197,7 +197,7 @@ class AcousticRungeKutta3:
 
 
 _ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "θli": "θ", "ρ": "ρ", "rho": "ρ", "u": "u", "v": "v", "w": "w",
-            "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q"}
+            "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q", "qᶜˡ": "qcl", "qcl": "qcl", "qʳ": "qr", "qr": "qr"}
 
 
 class CompressibleAtmosphereModel:
@@ -213,9 +213,21 @@ class CompressibleAtmosphereModel:
             raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded)")
         if not isinstance(dynamics, CompressibleDynamics):
             raise TypeError("dynamics must be CompressibleDynamics")
-        for name, val in (("closure", closure), ("coriolis", coriolis), ("microphysics", microphysics), ("forcing", forcing)):
+        for name, val in (("closure", closure), ("coriolis", coriolis), ("forcing", forcing)):
             if val is not None:
                 raise NotImplementedError(f"{name} is outside the hot-path scope of this build")
+        from .microphysics import DCMIP2016KesslerMicrophysics, TetensFormula
+        if microphysics is not None and not isinstance(microphysics, DCMIP2016KesslerMicrophysics):
+            raise NotImplementedError("compressible microphysics: DCMIP2016KesslerMicrophysics() is implemented")
+        self.microphysics = microphysics
+        self._kessler = microphysics is not None
+        if self._kessler:      # validate_microphysics (dcmip2016_kessler.jl:196-207)
+            tcs = thermodynamic_constants
+            if tcs is None or not isinstance(getattr(tcs, "saturation_vapor_pressure", None), TetensFormula):
+                raise ValueError("DCMIP2016KesslerMicrophysics requires `thermodynamic_constants` with a `TetensFormula` "
+                                 "saturation vapor pressure formulation.")
+            if getattr(self, "_pending_decomp", None) is not None:
+                raise NotImplementedError("Kessler microphysics on y-slabs is not implemented")
         if advection is None:
             raise NotImplementedError("the HIP path requires advection=WENO(order=5)")
         if not torch.cuda.is_available():
@@ -236,6 +248,11 @@ class CompressibleAtmosphereModel:
         self.velocities = {"u": fld("fcc"), "v": fld("cfc"), "w": fld("ccf")}
         self.potential_temperature_density, self.potential_temperature = fld("ccc"), fld("ccc")
         self.moisture_density, self.specific_moisture, self.temperature = fld("ccc"), fld("ccc"), fld("ccc")
+        self.microphysical_fields = {}
+        if self._kessler:      # materialize_microphysical_fields(::DCMIP2016KM) (dcmip2016_kessler.jl:255-290)
+            self.microphysical_fields = {k: fld("ccc") for k in ("ρqᶜˡ", "ρqʳ", "qᵛ", "qᶜˡ", "qʳ", "𝕎ʳ")}
+            self.microphysical_fields["precipitation_rate"] = torch.zeros((grid.Ny + 2 * grid.Hy, grid.Nx + 2 * grid.Hx),
+                                                                          dtype=torch.float64, device=self.device)
         if dynamics._reference_spec is not None:
             dynamics.reference_state = ExnerReferenceState(grid, c, surface_pressure=dynamics.surface_pressure,
                                                            potential_temperature=dynamics._reference_spec,
@@ -283,6 +300,18 @@ class CompressibleAtmosphereModel:
         self._state = self._make_state()
         self._U0, self._G = self._make_prog(self.U0), self._make_prog(self.G)
         self._sub = self.timestepper.substepper.struct()
+        if self._kessler:
+            from .microphysics import kessler_parameter_struct
+            μ = self.microphysical_fields
+            P = kessler_parameter_struct(microphysics, c)
+            K = _lib.bz_kessler_model_fields()
+            K.cloud_liquid_density, K.rain_density = μ["ρqᶜˡ"].ptr(), μ["ρqʳ"].ptr()
+            K.U0_cloud_liquid_density, K.U0_rain_density = self.U0["ρqᶜˡ"].ptr(), self.U0["ρqʳ"].ptr()
+            K.G_cloud_liquid_density, K.G_rain_density = self.G["ρqᶜˡ"].ptr(), self.G["ρqʳ"].ptr()
+            K.vapor_mass_fraction, K.cloud_liquid_mass_fraction, K.rain_mass_fraction = μ["qᵛ"].ptr(), μ["qᶜˡ"].ptr(), μ["qʳ"].ptr()
+            K.rain_terminal_velocity, K.precipitation_rate = μ["𝕎ʳ"].ptr(), μ["precipitation_rate"].data_ptr()
+            self._check(lib.bz_set_kessler_microphysics(self._ctx, C.byref(P), C.byref(K), dynamics.standard_pressure),
+                        "bz_set_kessler_microphysics")
         # seed_pressure! (compressible_dynamics.jl:254-258)
         if ref is not None:
             Hz, Nz = grid.Hz, grid.Nz
@@ -300,8 +329,11 @@ class CompressibleAtmosphereModel:
         _lib.check(self._lib, self._ctx, rc, what)
 
     def prognostic_fields(self):
-        return {"ρᵈ": self.dynamics.dry_density, "ρu": self.momentum["ρu"], "ρv": self.momentum["ρv"],
-                "ρw": self.momentum["ρw"], "ρθ": self.potential_temperature_density, "ρq": self.moisture_density}
+        out = {"ρᵈ": self.dynamics.dry_density, "ρu": self.momentum["ρu"], "ρv": self.momentum["ρv"],
+               "ρw": self.momentum["ρw"], "ρθ": self.potential_temperature_density, "ρq": self.moisture_density}
+        if getattr(self, "_kessler", False):
+            out["ρqᶜˡ"], out["ρqʳ"] = self.microphysical_fields["ρqᶜˡ"], self.microphysical_fields["ρqʳ"]
+        return out
 
     def _make_state(self):
         s = _lib.bz_compressible_state()
@@ -413,9 +445,19 @@ def set_(model, **kw):
     if "q" in keys:
         model.specific_moisture.set_interior(keys["q"])
         model.moisture_density.interior.copy_(ρd.interior * model.specific_moisture.interior)
+    condensate = 0.0
+    if getattr(model, "_kessler", False):        # settable specific microphysical names: only ρq is set
+        for key, dens in (("qcl", "ρqᶜˡ"), ("qr", "ρqʳ")):
+            if key in keys:
+                f = model.microphysical_fields[dens]
+                f.set_interior(keys[key])
+                f.interior.copy_(ρd.interior * f.interior)
+        condensate = model.microphysical_fields["ρqᶜˡ"].interior + (model.microphysical_fields["ρqʳ"].interior + 0.0)
+    elif "qcl" in keys or "qr" in keys:
+        raise ValueError("Cannot set! qᶜˡ / qʳ: the model has no Kessler microphysics")
     if "ρ" in keys:      # establish_densities!(total_density_given)
         ρ.interior.copy_(ρd.interior)
-        ρd.interior.copy_(ρ.interior - (model.moisture_density.interior + 0.0))
+        ρd.interior.copy_(ρ.interior - (model.moisture_density.interior + condensate))
     from .model import fill_halo_regions_
     fill_halo_regions_(model, ρd, 0)
     model._exchange([ρd.parent])
@@ -459,7 +501,11 @@ def time_step_(model, Δt, whole_step=True):
         for β in (model.timestepper.β1, model.timestepper.β2, model.timestepper.β3):
             acoustic_rk3_substep_(model, Δt, β)
             update_state_(model, compute_tendencies=True)
+        if getattr(model, "_kessler", False):
+            model._check(model._lib.bz_compressible_kessler_update(model._ctx, C.byref(model._state), C.byref(model._G),
+                                                                   C.byref(model._sub), Δt), "bz_compressible_kessler_update")
     model.clock.time += Δt
+    model.clock.last_Δt = Δt
     model.clock.iteration += 1
 
 

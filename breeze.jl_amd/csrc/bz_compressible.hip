@@ -27,6 +27,9 @@
 
 #include "bz_internal.h"
 
+extern "C" int bz_compressible_kessler_update(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                              const bz_acoustic_substepper *sub, double dt);
+
 // from bz_fused.hip
 __device__ __forceinline__ void cst_img(double *__restrict__ f, long long n, double v, long long ox, long long oy)
 {
@@ -73,7 +76,9 @@ struct DiagFields {
 };
 
 // FULL: everything; !FULL: halos of rho_d, rho_theta, momentum + velocities only (tail of acoustic_rk3_substep_loop!)
-template <bool FULL, bool LIN>
+// KES: DCMIP2016 Kessler species — total density includes rho q^cl + rho q^r, q = (q^v, q^cl + q^r) in R_m, c_pm and the
+// latent term of the temperature inversion, q^cl / q^r / q^v diagnosed (dcmip2016_kessler.jl:222-227,298-303,860-865)
+template <bool FULL, bool LIN, bool KES = false>
 __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, double abstol, int maxiter)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
@@ -109,25 +114,45 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
         cst_img(F.rw, n + sz, 0.0, ox, oy);
         cst_img(F.w, n + sz, 0.0, ox, oy);
     }
-    double r = 0.0, q = 0.0, th = 0.0, T = 0.0, p = 0.0, rq = 0.0;
+    double r = 0.0, q = 0.0, th = 0.0, T = 0.0, p = 0.0, rq = 0.0, qcl_v = 0.0, qr_v = 0.0;
     if (FULL) {
         rq = F.rq[n];
-        r = rd + (rq + 0.0);
+        double rqcl = 0.0, rqr = 0.0, ql = 0.0;
+        if (KES) {
+            rqcl = g.rqcl_field[n];
+            rqr = g.rqr_field[n];
+            r = rd + (rq + (rqcl + (rqr + 0.0)));
+        } else {
+            r = rd + (rq + 0.0);
+        }
         th = rth / rd;
         q = rq / r;
-        const double qd = 1.0 - q;
+        if (KES) {
+            qcl_v = rqcl / r;
+            qr_v = rqr / r;
+            ql = qcl_v + qr_v;
+        }
+        const double qd = 1.0 - (q + ql);
         const double Rm = qd * g.Rd + q * g.Rv;
-        const double cpm = qd * g.cpd + q * g.cpv;
+        const double cpm = KES ? qd * g.cpd + q * g.cpv + ql * g.sa_cl : qd * g.cpd + q * g.cpv;
         const double kap = Rm / cpm;
         const double gam = cpm / (cpm - Rm);
-        T = pow(th, gam) * pow(r * Rm / g.pst, gam - 1.0);
+        const double Lt = KES ? (g.sa_Ll * ql) / cpm : 0.0;
+        T = pow(th, gam) * pow(r * Rm / g.pst, gam - 1.0) + Lt;
         double dT = T;
         for (int it = 0; it < maxiter && fabs(dT) > abstol; ++it) {
             const double Phi = pow(r * Rm * T / g.pst, kap) * th;
-            dT = -(T - Phi) / (1.0 - kap * Phi / T);
+            dT = -(T - Phi - Lt) / (1.0 - kap * Phi / T);
             T += dT;
         }
         p = r * Rm * T;
+        if (KES) {
+            cst_img_only(g.rqcl_field, n, rqcl, ox, oy);
+            cst_img_only(g.rqr_field, n, rqr, ox, oy);
+            cst_img(g.qcl_field, n, qcl_v, ox, oy);
+            cst_img(g.qr_field, n, qr_v, ox, oy);
+            cst_img(g.qv_field, n, q, ox, oy);
+        }
         cst_img_only(F.rq, n, rq, ox, oy);
         cst_img(F.rho, n, r, ox, oy);
         cst_img(F.theta, n, th, ox, oy);
@@ -159,6 +184,13 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
             cst_img(F.q, n + h, q, ox, oy);
             cst_img(F.T, n + h, T, ox, oy);
             cst_img(F.p, n + h, p, ox, oy);
+            if (KES) {
+                cst_img(g.rqcl_field, n + h, g.rqcl_field[n], ox, oy);
+                cst_img(g.rqr_field, n + h, g.rqr_field[n], ox, oy);
+                cst_img(g.qcl_field, n + h, qcl_v, ox, oy);
+                cst_img(g.qr_field, n + h, qr_v, ox, oy);
+                cst_img(g.qv_field, n + h, q, ox, oy);
+            }
         }
     }
 }
@@ -175,9 +207,10 @@ __global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__
     const long long n = g.idx(i, j, k);
     const double rd = rho_d[n];
     const double q = qv[n];
-    const double qd = 1.0 - q;
+    const double ql = (g.microphysics == 2) ? g.qcl_field[n] + g.qr_field[n] : 0.0;
+    const double qd = 1.0 - q - ql;
     const double Rm = qd * g.Rd + q * g.Rv;
-    const double cpm = qd * g.cpd + q * g.cpv;
+    const double cpm = (g.microphysics == 2) ? qd * g.cpd + q * g.cpv + ql * g.sa_cl : qd * g.cpd + q * g.cpv;
     const double P = pow(p[n] / g.pst, g.Rd / g.cpd);
     const double gr = cpm * Rm / (cpm - Rm);
     Pi[n] = P;
@@ -286,6 +319,8 @@ struct AcFields {
     const double *rup_in, *rvp_in;
     double *rthp_out;
     double *au, *av, *aw;
+    double *rqcl, *rqr;           // Kessler species (k_ac_recover<2>)
+    const double *U0_rqcl, *U0_rqr, *G_rqcl, *G_rqr;
     double *Gs, *phi;             // slow vertical momentum tendency; forward-eliminated right-hand side
     double *tfac;                 // Thomas factors t_k
 };
@@ -576,7 +611,7 @@ __global__ __launch_bounds__(256) void k_ac_finalize(DevGrid g, AcFields F, AcPa
 
 // _recover_full_state! (acoustic_substepping.jl:1274-1292) [+ WS-RK3 update of the moisture density,
 // acoustic_runge_kutta_3.jl:189-192, when dt_stage_q != 0 pointer-wise]
-template <bool MOIST>
+template <int MOIST>      // 0: acoustic prognostics only; 1: + rho q^v; 2: + rho q^v and the Kessler species
 __global__ __launch_bounds__(256) void k_ac_recover(DevGrid g, AcFields F, double dt_stage)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -589,6 +624,10 @@ __global__ __launch_bounds__(256) void k_ac_recover(DevGrid g, AcFields F, doubl
     F.rv[n] = F.rv[n] + F.rvp[n];
     F.rw[n] = F.rw[n] + F.rwp[n];
     if (MOIST) F.rq[n] = F.U0_rq[n] + dt_stage * F.G_rq[n];
+    if (MOIST == 2) {
+        F.rqcl[n] = F.U0_rqcl[n] + dt_stage * F.G_rqcl[n];
+        F.rqr[n] = F.U0_rqr[n] + dt_stage * F.G_rqr[n];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ws_rk3_scalar(DevGrid g, double *__restrict__ u, const double *__restrict__ u0,
@@ -729,15 +768,18 @@ static int bzi_compressible_update_state(bz_ctx *ctx, const bz_compressible_stat
         ProfileScope ps(ctx, with_linearization ? "update_state+linearization" : "update_state");
         DiagFields F = diag_fields(ctx, s, sub);
         dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
-        if (with_linearization)
+        const bool kes = g.microphysics == 2;
+        if (with_linearization && kes)
+            hipLaunchKernelGGL((k_cmp_diagnose<true, true, true>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
+        else if (with_linearization)
             hipLaunchKernelGGL((k_cmp_diagnose<true, true>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
+        else if (kes)
+            hipLaunchKernelGGL((k_cmp_diagnose<true, false, true>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
         else
             hipLaunchKernelGGL((k_cmp_diagnose<true, false>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
         BZ_LAUNCH_CHECK();
     }
-    if (compute_tendencies)
-        return launch_scalar_rho3d(ctx, "moisture_tendency", G->rho_q, nullptr, s->rho, sub->time_averaged_u, sub->time_averaged_v,
-                                   sub->time_averaged_w, s->q, nullptr, nullptr, nullptr);
+    if (compute_tendencies) return bz_compute_moisture_tendency(ctx, s, G, sub);
     return BZ_OK;
 }
 
@@ -838,6 +880,10 @@ static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_
     F.Gs = a->slow_vertical_momentum_tendency; F.phi = a->vertical_solver_source_term;
     F.tfac = ctx->d_tfac_ac;
     F.rup_in = F.rup; F.rvp_in = F.rvp; F.rthp_out = F.rthp;
+    const bz_kessler_model_fields &K = ctx->kessler;
+    F.rqcl = K.cloud_liquid_density; F.rqr = K.rain_density;
+    F.U0_rqcl = K.U0_cloud_liquid_density; F.U0_rqr = K.U0_rain_density;
+    F.G_rqcl = K.G_cloud_liquid_density; F.G_rqr = K.G_rain_density;
     return F;
 }
 
@@ -995,10 +1041,12 @@ static int bzi_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, c
         ProfileScope ps(ctx, "acoustic_recover");
         const long long per_level = (long long)g.Ny * g.Sx;
         dim3 grid((unsigned)((per_level + 255) / 256), g.Nz);
-        if (moist)
-            hipLaunchKernelGGL((k_ac_recover<true>), grid, b256, 0, ctx->stream, g, F, beta * dt);
+        if (moist && g.microphysics == 2)
+            hipLaunchKernelGGL((k_ac_recover<2>), grid, b256, 0, ctx->stream, g, F, beta * dt);
+        else if (moist)
+            hipLaunchKernelGGL((k_ac_recover<1>), grid, b256, 0, ctx->stream, g, F, beta * dt);
         else
-            hipLaunchKernelGGL((k_ac_recover<false>), grid, b256, 0, ctx->stream, g, F, beta * dt);
+            hipLaunchKernelGGL((k_ac_recover<0>), grid, b256, 0, ctx->stream, g, F, beta * dt);
     }
     if (velocities) {
         ProfileScope ps(ctx, "acoustic_velocities");
@@ -1090,8 +1138,15 @@ extern "C" int bz_compute_moisture_tendency(bz_ctx *ctx, const bz_compressible_s
 {
     BZ_REQUIRE_COMPRESSIBLE();
     if (!valid_state(s) || !valid_prog(G) || !valid_sub(sub)) return BZ_ERR_INVALID;
-    return launch_scalar_rho3d(ctx, "moisture_tendency", G->rho_q, nullptr, s->rho, sub->time_averaged_u, sub->time_averaged_v,
-                               sub->time_averaged_w, s->q, nullptr, nullptr, nullptr);
+    int rc = launch_scalar_rho3d(ctx, "moisture_tendency", G->rho_q, nullptr, s->rho, sub->time_averaged_u, sub->time_averaged_v,
+                                 sub->time_averaged_w, s->q, nullptr, nullptr, nullptr);
+    if (rc || ctx->dg.microphysics != 2) return rc;
+    const bz_kessler_model_fields &K = ctx->kessler;      // the Kessler species ride the same transport velocities
+    rc = launch_scalar_rho3d(ctx, "kessler_species_tendencies", K.G_cloud_liquid_density, nullptr, s->rho, sub->time_averaged_u,
+                             sub->time_averaged_v, sub->time_averaged_w, K.cloud_liquid_mass_fraction, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    return launch_scalar_rho3d(ctx, "kessler_species_tendencies", K.G_rain_density, nullptr, s->rho, sub->time_averaged_u,
+                               sub->time_averaged_v, sub->time_averaged_w, K.rain_mass_fraction, nullptr, nullptr, nullptr);
 }
 
 extern "C" int bz_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
@@ -1138,6 +1193,11 @@ extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_stat
         BZ_HIP(hipMemcpyAsync(U0->rho_w, s->rho_w, nf, hipMemcpyDeviceToDevice, ctx->stream));
         BZ_HIP(hipMemcpyAsync(U0->rho_theta, s->rho_theta, nc, hipMemcpyDeviceToDevice, ctx->stream));
         BZ_HIP(hipMemcpyAsync(U0->rho_q, s->rho_q, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        if (g.microphysics == 2) {
+            const bz_kessler_model_fields &K = ctx->kessler;
+            BZ_HIP(hipMemcpyAsync(K.U0_cloud_liquid_density, K.cloud_liquid_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
+            BZ_HIP(hipMemcpyAsync(K.U0_rain_density, K.rain_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        }
     }
     // freeze_linearization_state!: the linearisation of stage 1 (refreshed again by prepare_acoustic_cache! from the
     // same state) + seeding of the transport velocities
@@ -1153,5 +1213,27 @@ extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_stat
         rc = bzi_compressible_update_state(ctx, s, G, sub, true, st < 2);
         if (rc) return rc;
     }
+    if (g.microphysics == 2) return bz_compressible_kessler_update(ctx, s, G, sub, dt);     // microphysics_model_update! (:316)
     return BZ_OK;
+}
+
+// microphysics_model_update!(::DCMIP2016KesslerMicrophysics, model) for CompressibleDynamics: density = dynamics_density
+// (rho_d), pressure = dynamics.pressure (dcmip2016_kessler.jl:460-485), then update_state!(model)
+extern "C" int bz_compressible_kessler_update(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                              const bz_acoustic_substepper *sub, double dt)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    if (!valid_state(s) || !valid_prog(G) || !valid_sub(sub)) return BZ_ERR_INVALID;
+    if (ctx->dg.microphysics != 2) { ctx->last_error = "bz_compressible_kessler_update: no Kessler microphysics attached"; return BZ_ERR_INVALID; }
+    const bz_kessler_model_fields &K = ctx->kessler;
+    bz_kessler_fields F;
+    F.density = s->rho_d; F.pressure = s->p;
+    F.potential_temperature = s->theta; F.potential_temperature_density = s->rho_theta;
+    F.moisture_density = s->rho_q; F.cloud_liquid_density = K.cloud_liquid_density; F.rain_density = K.rain_density;
+    F.vapor_mass_fraction = K.vapor_mass_fraction; F.cloud_liquid_mass_fraction = K.cloud_liquid_mass_fraction;
+    F.rain_mass_fraction = K.rain_mass_fraction; F.rain_terminal_velocity = K.rain_terminal_velocity;
+    F.precipitation_rate = K.precipitation_rate;
+    int rc = bz_kessler_microphysics_update(ctx, &ctx->kessler_params, &F, dt, ctx->kessler_pst);
+    if (rc) return rc;
+    return bzi_compressible_update_state(ctx, s, G, sub, true, false);
 }

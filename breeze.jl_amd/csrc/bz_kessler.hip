@@ -206,8 +206,8 @@ extern "C" int bz_set_kessler_microphysics(bz_ctx *ctx, const bz_kessler_microph
         !f->G_cloud_liquid_density || !f->G_rain_density || !f->vapor_mass_fraction || !f->cloud_liquid_mass_fraction ||
         !f->rain_mass_fraction || !f->rain_terminal_velocity || !f->precipitation_rate)
         return BZ_ERR_INVALID;
-    if (ctx->compressible || g.formulation != 0 || ctx->slab_mode) {
-        ctx->last_error = "Kessler microphysics is attached to the single-GPU anelastic potential-temperature model in this build";
+    if (g.formulation != 0 || ctx->slab_mode) {
+        ctx->last_error = "Kessler microphysics is attached to single-GPU potential-temperature models in this build";
         return BZ_ERR_UNSUPPORTED;
     }
     ctx->kessler_params = *params;

@@ -374,6 +374,13 @@ typedef struct bz_kessler_model_fields {
 int bz_set_kessler_microphysics(bz_ctx *ctx, const bz_kessler_microphysics *params, const bz_kessler_model_fields *fields,
                                 double standard_pressure);
 int bz_kessler_model_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt);
+/* The same attachment works for a CompressibleDynamics context (bz_create_compressible): the total density then includes the
+ * condensates (compressible_time_stepping.jl:83-103 with condensate_field_names), the Newton temperature inversion carries the
+ * latent term, gamma R_m of the linearisation includes the liquid fraction, the species ride the time-averaged transport
+ * velocities and the WS-RK3 scalar update, and bz_time_step_compressible ends with the column update (density = rho_d,
+ * pressure = dynamics.pressure) + update_state! (acoustic_runge_kutta_3.jl:315-316). */
+int bz_compressible_kessler_update(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                   const bz_acoustic_substepper *sub, double dt);
 
 /* ---- the reductions of the run! loop around the step ---- */
 /* cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): minimum over the interior of

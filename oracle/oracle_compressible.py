@@ -134,7 +134,10 @@ class CompressibleOracleModel:
 
     def __init__(self, grid, constants=None, time_discretization=None, surface_pressure=101325.0,
                  standard_pressure=1e5, reference_potential_temperature=288.0, reference_state=True,
-                 newton_abstol=1e-4, newton_maxiter=8):
+                 newton_abstol=1e-4, newton_maxiter=8, microphysics=None):
+        # microphysics "Kessler": DCMIP2016KesslerMicrophysics — rho q^cl, rho q^r prognostic (dcmip2016_kessler.jl:216)
+        assert microphysics in (None, "Kessler")
+        self.microphysics = microphysics
         self.grid = g = grid
         self.constants = c = constants or Constants()
         self.td = time_discretization or SplitExplicit()
@@ -154,6 +157,14 @@ class CompressibleOracleModel:
         self.rw = zf()
         self.u, self.v, self.theta, self.q, self.T, self.p = (cf() for _ in range(6))
         self.w = zf()
+        if microphysics == "Kessler":
+            from .kessler import KesslerParameters, TetensConstants
+            self.PROGNOSTIC = CompressibleOracleModel.PROGNOSTIC + ("rqcl", "rqr")
+            self.rqcl, self.rqr, self.qcl, self.qr, self.W = (cf() for _ in range(5))
+            self.precipitation_rate = np.zeros((g.Ny, g.Nx))
+            self.kessler = KesslerParameters()
+            self.tetens = TetensConstants(molar_gas_constant=c.R, dry_air_molar_mass=c.Md, vapor_molar_mass=c.Mv,
+                                          dry_air_heat_capacity=c.cpd, vapor_heat_capacity=c.cpv)
         self.U0 = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
         self.G = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
         # AcousticSubstepper storage (acoustic_substepping.jl:207-231)
@@ -193,7 +204,7 @@ class CompressibleOracleModel:
         return np.broadcast_to(value, shape)
 
     # -- set! (set_atmosphere_model.jl:198-362, compressible_time_stepping.jl:105-150) ------------
-    def set(self, rho=None, theta=None, u=None, v=None, w=None, qv=None):
+    def set(self, rho=None, theta=None, u=None, v=None, w=None, qv=None, qcl=None, qr=None):
         g = self.grid
         I = g.interior
         if rho is not None:
@@ -202,9 +213,16 @@ class CompressibleOracleModel:
         if qv is not None:
             I(self.q)[...] = self._eval(qv, "ccc")
             I(self.rq)[...] = I(self.rho_d) * I(self.q)
-        if rho is not None:                                   # total density given: rho_d = rho - rho q
+        condensate = 0.0
+        if self.microphysics == "Kessler":                    # settable specific microphysical names: rho*q only
+            if qcl is not None:
+                I(self.rqcl)[...] = I(self.rho_d) * self._eval(qcl, "ccc")
+            if qr is not None:
+                I(self.rqr)[...] = I(self.rho_d) * self._eval(qr, "ccc")
+            condensate = I(self.rqcl) + (I(self.rqr) + 0.0)
+        if rho is not None:                                   # total density given: rho_d = rho - (rho q + condensates)
             I(self.rho)[...] = I(self.rho_d)
-            I(self.rho_d)[...] = I(self.rho) - (I(self.rq) + 0.0)
+            I(self.rho_d)[...] = I(self.rho) - (I(self.rq) + condensate)
             self._halo_center(self.rho)
             self._halo_center(self.rho_d)
         if theta is not None:
@@ -229,9 +247,14 @@ class CompressibleOracleModel:
     # -- update_state! ---------------------------------------------------------
     def update_state(self, compute_tendencies=True):
         cg, L = C.byref(self.cg), self.lib
-        L.og_total_density(cg, _p(self.rho), _p(self.rho_d), _p(self.rq))
+        kes = self.microphysics == "Kessler"
+        if kes:
+            g = self.grid
+            g.interior(self.rho)[...] = g.interior(self.rho_d) + (g.interior(self.rq) + (g.interior(self.rqcl) + (g.interior(self.rqr) + 0.0)))
+        else:
+            L.og_total_density(cg, _p(self.rho), _p(self.rho_d), _p(self.rq))
         self._halo_center(self.rho)
-        for f in (self.rho_d, self.ru, self.rv, self.rtheta, self.rq):
+        for f in (self.rho_d, self.ru, self.rv, self.rtheta, self.rq) + ((self.rqcl, self.rqr) if kes else ()):
             self._halo_center(f)
         self._halo_w(self.rw)
         L.og_compute_velocities_3d(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv),
@@ -239,10 +262,13 @@ class CompressibleOracleModel:
         self._halo_center(self.u)
         self._halo_center(self.v)
         self._halo_w(self.w)
-        L.og_compressible_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.p), _p(self.rho_d),
-                                 _p(self.rho), _p(self.rtheta), _p(self.rq),
-                                 C.c_double(self.newton[0]), C.c_int(self.newton[1]))
-        for f in (self.theta, self.q, self.T, self.p):
+        if kes:
+            self._kessler_thermo()
+        else:
+            L.og_compressible_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.p), _p(self.rho_d),
+                                     _p(self.rho), _p(self.rtheta), _p(self.rq),
+                                     C.c_double(self.newton[0]), C.c_int(self.newton[1]))
+        for f in (self.theta, self.q, self.T, self.p) + ((self.qcl, self.qr) if kes else ()):
             self._halo_center(f)
         if compute_tendencies:
             # moisture: total density carrier, acoustic-mean transport velocities
@@ -250,11 +276,53 @@ class CompressibleOracleModel:
             # the momentum / theta / rho_d tendencies computed here by the reference are overwritten
             # by compute_slow_*_tendencies! before they are used.
             L.og_scalar_tendency_3d(cg, _p(self.G["rq"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.q))
+            if kes:
+                L.og_scalar_tendency_3d(cg, _p(self.G["rqcl"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qcl))
+                L.og_scalar_tendency_3d(cg, _p(self.G["rqr"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qr))
 
+    def _kessler_thermo(self):
+        """theta, q^v, q^cl, q^r (update_microphysical_auxiliaries!) then _compute_temperature_and_pressure! with the fresh
+        moisture fractions (q^v, q^cl + q^r): LiquidIceDensityState Newton inversion with the latent term
+        (compressible_time_stepping.jl:191-242; dynamic_states.jl:197-232)."""
+        g, c, t = self.grid, self.constants, self.tetens
+        I = g.interior
+        rd, r = I(self.rho_d), I(self.rho)
+        th, qv = I(self.rtheta) / rd, I(self.rq) / r
+        qcl, qr = I(self.rqcl) / r, I(self.rqr) / r
+        I(self.theta)[...], I(self.q)[...], I(self.qcl)[...], I(self.qr)[...] = th, qv, qcl, qr
+        ql = qcl + qr
+        qd = 1.0 - (qv + ql + 0.0)
+        Rm = qd * c.Rd + qv * c.Rv
+        cpm = qd * c.cpd + qv * c.cpv + ql * t.cl + 0.0
+        kap, gam = Rm / cpm, cpm / (cpm - Rm)
+        Lt = (t.Ll * ql + 0.0) / cpm
+        T = th ** gam * (r * Rm / self.pst) ** (gam - 1.0) + Lt
+        dT = T.copy()
+        abstol, maxiter = self.newton
+        it = np.zeros(T.shape, dtype=int)
+        while True:
+            active = (np.abs(dT) > max(abstol, 0.0)) & (it < maxiter)
+            if not active.any():
+                break
+            Phi = (r * Rm * T / self.pst) ** kap * th
+            step = -(T - Phi - Lt) / (1.0 - kap * Phi / T)
+            dT = np.where(active, step, dT)
+            T = np.where(active, T + step, T)
+            it = it + active
+        I(self.T)[...] = T
+        I(self.p)[...] = r * Rm * T
     # -- acoustic stage ----------------------------------------------------------
     def refresh_linearization(self):
         self.lib.og_linearization(C.byref(self.cg), _p(self.Pi), _p(self.thL), _p(self.gR), _p(self.p),
                                   _p(self.rho_d), _p(self.rtheta), _p(self.rho), _p(self.q))
+        if self.microphysics == "Kessler":      # gamma R_m with the liquid fraction (acoustic_substepping.jl:376-399)
+            g, c, t = self.grid, self.constants, self.tetens
+            I = g.interior
+            qv, ql = I(self.q), I(self.qcl) + I(self.qr)
+            qd = 1 - qv - ql - 0.0
+            Rm = qd * c.Rd + qv * c.Rv
+            cpm = qd * c.cpd + qv * c.cpv + ql * t.cl + 0.0 * 0.0
+            I(self.gR)[...] = cpm * Rm / (cpm - Rm)
         for f in (self.Pi, self.thL, self.gR):
             self._halo_center(f)
 
@@ -354,8 +422,8 @@ class CompressibleOracleModel:
         self.refresh_linearization()
         self.compute_slow_tendencies()
         self.acoustic_substep_loop(dt, beta)
-        self.lib.og_ws_rk3_scalar(C.byref(self.cg), _p(self.rq), _p(self.U0["rq"]), _p(self.G["rq"]),
-                                  C.c_double(beta * dt))
+        for n in ("rq",) + (("rqcl", "rqr") if self.microphysics == "Kessler" else ()):
+            self.lib.og_ws_rk3_scalar(C.byref(self.cg), _p(getattr(self, n)), _p(self.U0[n]), _p(self.G[n]), C.c_double(beta * dt))
 
     def time_step(self, dt):
         dt = float(dt)
@@ -370,5 +438,25 @@ class CompressibleOracleModel:
         for beta in self.BETAS:
             self.acoustic_rk3_substep(dt, beta)
             self.update_state(compute_tendencies=True)
+        if self.microphysics == "Kessler":
+            self.microphysics_model_update(dt)
         self.clock_time += dt
         self.iteration += 1
+
+    def microphysics_model_update(self, dt):
+        """microphysics_model_update!(::DCMIP2016KesslerMicrophysics, model) for CompressibleDynamics: the column kernel with
+        density = dynamics_density = rho_d and pressure = dynamics.pressure (dcmip2016_kessler.jl:460-485), then update_state!."""
+        from .kessler import kessler_column_update
+        g = self.grid
+        I = g.interior
+        for j in range(g.Ny):
+            for i in range(g.Nx):
+                rho = np.ascontiguousarray(I(self.rho_d)[:, j, i])
+                p = np.ascontiguousarray(I(self.p)[:, j, i])
+                cols = [np.ascontiguousarray(I(f)[:, j, i]) for f in (self.theta, self.rtheta, self.rq, self.rqcl, self.rqr)]
+                qv, qcl, qr, W, P, _ = kessler_column_update(dt, rho, p, self.pst, g.zc, *cols, self.kessler, self.tetens)
+                for f, col in zip((self.theta, self.rtheta, self.rq, self.rqcl, self.rqr), cols):
+                    I(f)[:, j, i] = col
+                I(self.q)[:, j, i], I(self.qcl)[:, j, i], I(self.qr)[:, j, i], I(self.W)[:, j, i] = qv, qcl, qr, W
+                self.precipitation_rate[j, i] = P
+        self.update_state(compute_tendencies=True)

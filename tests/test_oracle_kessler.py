@@ -93,3 +93,31 @@ def test_oracle_model_with_kessler_runs_and_makes_rain(oracle):
         assert np.isfinite(I(f)).all() and I(f).min() >= 0.0
     assert I(m.W).max() > 0.5 and np.abs(I(m.T) - T0).max() > 1e-2
     assert set(m.PROGNOSTIC) == {"ru", "rv", "rw", "rtheta", "rq", "rqcl", "rqr"}
+
+
+def test_compressible_oracle_model_with_kessler(oracle):
+    """CompressibleDynamics + DCMIP2016KesslerMicrophysics on the oracle: total density includes the condensates, the EOS
+    temperature carries the latent term, a few steps run and total water changes only through surface precipitation."""
+    from oracle import oracle_compressible as oc
+    g = oracle.Grid((8, 8, 16), x=(0, 4e3), y=(0, 4e3), z=(0, 4e3))
+    m = oc.CompressibleOracleModel(g, time_discretization=oc.SplitExplicit(substeps=6), surface_pressure=1e5,
+                                   reference_potential_temperature=300.0, microphysics="Kessler")
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt((x - 2e3) ** 2 + (y - 2e3) ** 2 + (z - 1500.0) ** 2) / 1200.0)
+    rho = m.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    m.set(rho=rho, theta=lambda x, y, z: 300.0 + 0.004 * z + 1.0 * bub(x, y, z), u=0.0, v=0.0, w=0.0,
+          qv=lambda x, y, z: 0.014 * np.exp(-z / 3000.0) + 0.004 * bub(x, y, z),
+          qcl=lambda x, y, z: 0.003 * bub(x, y, z), qr=lambda x, y, z: 0.001 * bub(x, y, z))
+    I = g.interior
+    np.testing.assert_allclose(I(m.rho), I(m.rho_d) + I(m.rq) + I(m.rqcl) + I(m.rqr), rtol=1e-15)
+    # EOS consistency: theta = T (pst/p)^kappa - latent shift
+    c, t = m.constants, m.tetens
+    qv, ql = I(m.q), I(m.qcl) + I(m.qr)
+    cpm = (1 - qv - ql) * c.cpd + qv * c.cpv + ql * t.cl
+    Rm = (1 - qv - ql) * c.Rd + qv * c.Rv
+    th_back = (I(m.T) - t.Ll * ql / cpm) * (m.pst / I(m.p)) ** (Rm / cpm)
+    np.testing.assert_allclose(th_back, I(m.theta), rtol=1e-6)      # Newton abstol 1e-4 K
+    for _ in range(2):
+        m.time_step(2.0)
+    for f in (m.rq, m.rqcl, m.rqr, m.rho_d):
+        assert np.isfinite(I(f)).all()
+    assert I(m.rqcl).min() >= 0 and I(m.rqr).min() >= 0 and I(m.W).max() > 0.5

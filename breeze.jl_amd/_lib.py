@@ -57,6 +57,15 @@ class bz_saturation_adjustment(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class bz_column_forcings(C.Structure):
+    _fields_ = [("u_forcing", _dp), ("v_forcing", _dp), ("theta_forcing", _dp), ("moisture_forcing", _dp),
+                ("energy_forcing", _dp), ("subsidence_vertical_velocity", _dp),
+                ("subsidence_u", C.c_int32), ("subsidence_v", C.c_int32), ("subsidence_theta", C.c_int32),
+                ("subsidence_moisture", C.c_int32), ("coriolis_f", C.c_double),
+                ("bottom_theta_flux", C.c_double), ("bottom_moisture_flux", C.c_double),
+                ("bottom_drag_rho0_ustar2", C.c_double)]
+
+
 _KESSLER_PARAMS = ("dcmip_temperature_scale", "terminal_velocity_coefficient", "density_scale", "terminal_velocity_exponent",
                    "autoconversion_rate", "autoconversion_threshold", "accretion_rate", "accretion_exponent",
                    "evaporation_ventilation_coefficient_1", "evaporation_ventilation_coefficient_2",
@@ -177,6 +186,9 @@ SYMBOLS = {
                                               C.c_double]),
     "bz_kessler_model_update": (C.c_int, [_ctx, _sp, _pp, C.c_double]),
     "bz_compressible_kessler_update": (C.c_int, [_ctx, _csp, _cpp, _asp, C.c_double]),
+    "bz_set_forcings": (C.c_int, [_ctx, C.POINTER(bz_column_forcings)]),
+    "bz_compute_forcings": (C.c_int, [_ctx, _sp]),
+    "bz_compute_flux_bc_tendencies": (C.c_int, [_ctx, _sp, _pp]),
     "bz_cell_advection_timescale": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "bz_any_nan": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "bz_profile_enable": (C.c_int, [_ctx, C.c_int]),

@@ -1,0 +1,266 @@
+// bz_forcing.hip — forcing, f-plane Coriolis and bottom-flux terms of the BOMEX configuration (BASELINE configs[2],
+// /root/reference/examples/bomex.jl:80-207) for the anelastic potential-temperature model.
+//   SubsidenceForcing             /root/reference/src/Forcings/subsidence_forcing.jl:75-91,104-126
+//   geostrophic_forcings          /root/reference/src/Forcings/geostrophic_forcings.jl  (F_u = -f v_g, F_v = +f u_g: the caller
+//                                 hands over the finished specific profiles)
+//   SpecificForcing (rho x F)     /root/reference/src/Forcings/specific_forcing.jl:61-74
+//   energy forcing in G_rho_theta /root/reference/src/PotentialTemperatureFormulations/potential_temperature_tendency.jl:86-104
+//   -x_f_cross_U, -y_f_cross_U    /root/reference/src/AtmosphereModels/dynamics_kernel_functions.jl:79,99 (Oceananigans FPlane)
+//   compute_forcings!             /root/reference/src/AtmosphereModels/update_atmosphere_model_state.jl:52,81-86
+//   compute_flux_bc_tendencies!   /root/reference/src/AtmosphereModels/update_atmosphere_model_state.jl:418-434
+// Every forcing of that configuration is a column profile times the reference density, so the whole stack is one
+// streaming pass over the four tendencies it touches plus a per-level reduction for the subsidence averages.
+#include "bz_internal.h"
+
+#define FSLICES 8
+
+// per-level partial sums of u, v, theta, q over a slice of rows: partial[(f * Nz + k) * FSLICES + s]
+__global__ __launch_bounds__(256) void k_level_sums(DevGrid g, const double *__restrict__ u, const double *__restrict__ v,
+                                                    const double *__restrict__ th, const double *__restrict__ q,
+                                                    double *__restrict__ partial)
+{
+    const int k = blockIdx.x, s = blockIdx.y;
+    const int j0 = (int)((long long)g.Ny * s / FSLICES), j1 = (int)((long long)g.Ny * (s + 1) / FSLICES);
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const long long cells = (long long)(j1 - j0) * g.Nx;
+    for (long long c = threadIdx.x; c < cells; c += 256) {
+        const int j = j0 + (int)(c / g.Nx), i = (int)(c % g.Nx);
+        const long long n = g.idx(i, j, k);
+        a[0] += u[n]; a[1] += v[n]; a[2] += th[n]; a[3] += q[n];
+    }
+    __shared__ double red[4][256];
+    for (int f = 0; f < 4; ++f) red[f][threadIdx.x] = a[f];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int f = 0; f < 4; ++f) red[f][threadIdx.x] += red[f][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) partial[((long long)threadIdx.x * g.Nz + k) * FSLICES + s] = red[threadIdx.x][0];
+}
+
+// Average(specific field, dims=(1,2)) then F = -zb-average(w_s dz(avg)) (subsidence_forcing.jl:75-91); one block
+__global__ void k_subsidence_profiles(DevGrid g, const double *__restrict__ partial, const double *__restrict__ ws,
+                                      double *__restrict__ avg, double *__restrict__ sub, int mask)
+{
+    const int Nz = g.Nz;
+    const double count = (double)g.Nx * (double)g.Ny;
+    for (int t = threadIdx.x; t < 4 * Nz; t += blockDim.x) {
+        double sum = 0.0;
+        for (int s = 0; s < FSLICES; ++s) sum += partial[(long long)t * FSLICES + s];
+        avg[t] = sum / count;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4 * Nz; t += blockDim.x) {
+        const int f = t / Nz, k = t % Nz;
+        double out = 0.0;
+        if ((mask >> f) & 1) {
+            const double *a = avg + (long long)f * Nz;
+            // w_dz(k) = w_s[k] * (a[k] - a[k-1]) / dzf[k] on interior faces k = 1 .. Nz-1
+            const double up = (k + 1 <= Nz - 1) ? ws[k + 1] * ((a[k + 1] - a[k]) / g.dzf[k + 1]) : 0.0;
+            const double dn = (k >= 1) ? ws[k] * ((a[k] - a[k - 1]) / g.dzf[k]) : 0.0;
+            const double mid = (up + dn) / 2;
+            out = -((k == Nz - 1) ? dn : ((k == 0) ? up : mid));
+        }
+        sub[t] = out;
+    }
+}
+
+struct ForcingCols {
+    const double *Fu, *Fv, *Fth, *Fq, *Fe;     // static specific profiles (nullptr: none)
+    const double *sub;                         // 4 * Nz subsidence profiles (zeros where inactive), nullptr: none
+    double f;
+};
+
+__global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F, double *__restrict__ Gu,
+                                                        double *__restrict__ Gv, double *__restrict__ Gth,
+                                                        double *__restrict__ Gq, const double *__restrict__ ru,
+                                                        const double *__restrict__ rv, const double *__restrict__ q,
+                                                        double scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k);
+    const double rho = g.rho[k];
+    const int Nz = g.Nz;
+    const long long sx = g.Hx ? 1 : 0, sy = g.Hy ? g.Sx : 0;      // Flat directions have no neighbours
+    auto column = [&](const double *stat, int f, bool &any) {
+        double tot = 0.0;
+        any = false;
+        if (F.sub) { tot = rho * F.sub[f * Nz + k]; any = true; }
+        if (stat) { tot = any ? tot + rho * stat[k] : rho * stat[k]; any = true; }
+        return tot;
+    };
+    bool any;
+    {
+        double G = Gu[n];
+        if (F.f != 0.0) {
+            const double a = (rv[n - sx] + rv[n - sx + sy]) / 2, b = (rv[n] + rv[n + sy]) / 2;
+            G -= scale * (-F.f * ((a + b) / 2));
+        }
+        const double t = column(F.Fu, 0, any);
+        if (any) G += scale * t;
+        Gu[n] = G;
+    }
+    {
+        double G = Gv[n];
+        if (F.f != 0.0) {
+            const double a = (ru[n - sy] + ru[n - sy + sx]) / 2, b = (ru[n] + ru[n + sx]) / 2;
+            G -= scale * (F.f * ((a + b) / 2));
+        }
+        const double t = column(F.Fv, 1, any);
+        if (any) G += scale * t;
+        Gv[n] = G;
+    }
+    {
+        double G = Gth[n];
+        const double t = column(F.Fth, 2, any);
+        if (any) G += scale * t;
+        if (F.Fe) {
+            double qv, ql = 0.0;
+            if (g.microphysics == 1) { qv = g.qv_field[n]; ql = g.ql_field[n]; }
+            else qv = q[n];
+            const double qd = 1.0 - (qv + ql);
+            const double Rm = qd * g.Rd + qv * g.Rv;
+            const double cpm = qd * g.cpd + qv * g.cpv + ql * g.sa_cl;
+            const double Pi = pow(g.p_r[k] / g.pst, Rm / cpm);
+            G += scale * ((rho * F.Fe[k]) / (cpm * Pi));
+        }
+        Gth[n] = G;
+    }
+    {
+        const double t = column(F.Fq, 3, any);
+        if (any) Gq[n] += scale * t;
+    }
+}
+
+// bottom FluxBoundaryConditions: G[i,j,1] += J / dz_1 (Oceananigans apply_z_bcs!); the drag flux of examples/bomex.jl:95-101
+__global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, double Jq, double drag, double *__restrict__ Gu,
+                                                     double *__restrict__ Gv, double *__restrict__ Gth,
+                                                     double *__restrict__ Gq, const double *__restrict__ ru,
+                                                     const double *__restrict__ rv, double scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, 0);
+    const double dz = g.dzc[0];
+    const long long sx = g.Hx ? 1 : 0, sy = g.Hy ? g.Sx : 0;
+    if (Jth != 0.0) Gth[n] += scale * (Jth / dz);
+    if (Jq != 0.0) Gq[n] += scale * (Jq / dz);
+    if (drag != 0.0) {
+        const double u = ru[n], v = rv[n];
+        const double va = (rv[n - sx] + rv[n - sx + sy]) / 2, vb = (rv[n] + rv[n + sy]) / 2;
+        const double v_fc = (va + vb) / 2;
+        const double ua = (ru[n - sy] + ru[n - sy + sx]) / 2, ub = (ru[n] + ru[n + sx]) / 2;
+        const double u_cf = (ua + ub) / 2;
+        Gu[n] += scale * ((-drag * u / sqrt(u * u + v_fc * v_fc)) / dz);
+        Gv[n] += scale * ((-drag * v / sqrt(u_cf * u_cf + v * v)) / dz);
+    }
+}
+
+static void free_forcings(bz_ctx *ctx)
+{
+    if (ctx->d_forcing) hipFree(ctx->d_forcing);
+    ctx->d_forcing = nullptr;
+    ctx->has_forcings = false;
+}
+
+void bzi_forcing_teardown(bz_ctx *ctx) { free_forcings(ctx); }
+
+extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    free_forcings(ctx);
+    if (!f) return BZ_OK;
+    if (ctx->compressible || ctx->slab_mode || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {
+        ctx->last_error = "bz_set_forcings: the forcing stack is implemented for the single-device anelastic "
+                          "potential-temperature model (microphysics nothing or SaturationAdjustment)";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    const int Nz = ctx->dg.Nz;
+    // layout: [Fu Fv Fth Fq Fe](5 Nz) [ws](Nz+1) [avg](4 Nz) [sub](4 Nz) [partial](4 Nz FSLICES)
+    const size_t total = (size_t)5 * Nz + (Nz + 1) + 8 * (size_t)Nz + (size_t)4 * Nz * FSLICES;
+    BZ_HIP(hipMalloc(&ctx->d_forcing, total * sizeof(double)));
+    BZ_HIP(hipMemsetAsync(ctx->d_forcing, 0, total * sizeof(double), ctx->stream));
+    const double *stat[5] = {f->u_forcing, f->v_forcing, f->theta_forcing, f->moisture_forcing, f->energy_forcing};
+    ctx->forcing_static_mask = 0;
+    for (int c = 0; c < 5; ++c)
+        if (stat[c]) {
+            BZ_HIP(hipMemcpyAsync(ctx->d_forcing + (size_t)c * Nz, stat[c], Nz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            ctx->forcing_static_mask |= 1 << c;
+        }
+    ctx->forcing_subsidence_mask = 0;
+    if (f->subsidence_vertical_velocity) {
+        BZ_HIP(hipMemcpyAsync(ctx->d_forcing + (size_t)5 * Nz, f->subsidence_vertical_velocity, (Nz + 1) * sizeof(double),
+                              hipMemcpyHostToDevice, ctx->stream));
+        ctx->forcing_subsidence_mask = (f->subsidence_u ? 1 : 0) | (f->subsidence_v ? 2 : 0) | (f->subsidence_theta ? 4 : 0) |
+                                       (f->subsidence_moisture ? 8 : 0);
+    }
+    BZ_HIP(hipStreamSynchronize(ctx->stream));      // the host profiles may go away after the call
+    ctx->forcing_f = f->coriolis_f;
+    ctx->forcing_flux_theta = f->bottom_theta_flux;
+    ctx->forcing_flux_q = f->bottom_moisture_flux;
+    ctx->forcing_drag = f->bottom_drag_rho0_ustar2;
+    ctx->has_forcings = true;
+    return BZ_OK;
+}
+
+// compute_forcings!(model) (update_atmosphere_model_state.jl:81-86): horizontal averages -> subsidence profiles
+extern "C" int bz_compute_forcings(bz_ctx *ctx, const bz_state *s)
+{
+    if (!ctx || !s) return BZ_ERR_INVALID;
+    if (!ctx->has_forcings || !ctx->forcing_subsidence_mask) return BZ_OK;
+    const DevGrid &g = ctx->dg;
+    const int Nz = g.Nz;
+    ProfileScope ps(ctx, "subsidence_averages");
+    double *ws = ctx->d_forcing + (size_t)5 * Nz, *avg = ws + (Nz + 1), *sub = avg + (size_t)4 * Nz, *partial = sub + (size_t)4 * Nz;
+    hipLaunchKernelGGL(k_level_sums, dim3(Nz, FSLICES), dim3(256), 0, ctx->stream, g, s->u, s->v, s->theta, s->q, partial);
+    hipLaunchKernelGGL(k_subsidence_profiles, dim3(1), dim3(256), 0, ctx->stream, g, partial, ws, avg, sub,
+                       ctx->forcing_subsidence_mask);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// the forcing + Coriolis terms of compute_tendencies!, added to the advective tendencies already in G
+// scale = 1 adds to tendencies; the whole-step seam passes scale = alpha dt and the arrays the fused RK update just wrote
+// (predictor momentum in G, rho_theta / rho_q in place): u_new = (1-alpha) u0 + alpha (u + dt (G + F)) either way.
+int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale)
+{
+    const DevGrid &g = ctx->dg;
+    const int Nz = g.Nz;
+    int rc = bz_compute_forcings(ctx, s);
+    if (rc) return rc;
+    ProfileScope ps(ctx, "forcing_tendencies");
+    ForcingCols F;
+    const double *base = ctx->d_forcing;
+    const int m = ctx->forcing_static_mask;
+    F.Fu = (m & 1) ? base : nullptr;
+    F.Fv = (m & 2) ? base + (size_t)Nz : nullptr;
+    F.Fth = (m & 4) ? base + (size_t)2 * Nz : nullptr;
+    F.Fq = (m & 8) ? base + (size_t)3 * Nz : nullptr;
+    F.Fe = (m & 16) ? base + (size_t)4 * Nz : nullptr;
+    F.sub = ctx->forcing_subsidence_mask ? base + (size_t)5 * Nz + (Nz + 1) + (size_t)4 * Nz : nullptr;
+    F.f = ctx->forcing_f;
+    hipLaunchKernelGGL(k_apply_forcings, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, F, Gu, Gv, Gth, Gq,
+                       s->rho_u, s->rho_v, s->q, scale);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+extern "C" int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    if (!ctx || !s || !G) return BZ_ERR_INVALID;
+    return bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0);
+}
+
+int bzi_flux_bc(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale)
+{
+    if (!ctx->has_forcings) return BZ_OK;
+    if (ctx->forcing_flux_theta == 0.0 && ctx->forcing_flux_q == 0.0 && ctx->forcing_drag == 0.0) return BZ_OK;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "flux_bc_tendencies");
+    hipLaunchKernelGGL(k_bottom_flux, dim3((g.Nx + 255) / 256, g.Ny), dim3(256), 0, ctx->stream, g, ctx->forcing_flux_theta,
+                       ctx->forcing_flux_q, ctx->forcing_drag, Gu, Gv, Gth, Gq, s->rho_u, s->rho_v, scale);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}

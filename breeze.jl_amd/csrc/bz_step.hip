@@ -2,6 +2,8 @@
 //   update_state!  /root/reference/src/AtmosphereModels/update_atmosphere_model_state.jl:41-68
 //   time_step!     /root/reference/src/TimeSteppers/ssp_runge_kutta_3.jl:209-278
 // Everything is enqueued on ctx->stream; there is no host synchronisation inside a step.
+#include <cstdlib>
+
 #include "bz_internal.h"
 
 extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, int compute_tendencies)
@@ -31,7 +33,7 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
     }
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
-    if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2) {
+    if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !(ctx->has_forcings && getenv("BZ_NO_FUSE_FORCING"))) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state
         // left by stage s-1), the predictor momentum goes to the G arrays and is projected from there into the
@@ -42,6 +44,12 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
         for (int stage = 0; stage < 3; ++stage) {
             const double alpha = alphas[stage];
             if ((rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+            if (ctx->has_forcings) {
+                // forcing, Coriolis and bottom fluxes of the stage, evaluated from the still-intact previous-stage state and
+                // added to what the fused RK update just wrote, weighted alpha dt
+                if ((rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
+                if ((rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
+            }
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
             if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G))) return rc;
@@ -56,6 +64,7 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
         // velocity / thermodynamic diagnosis and every halo fill of update_state! are one kernel.
         for (int stage = 0; stage < 3; ++stage) {
             const double alpha = alphas[stage];
+            if ((rc = bz_compute_flux_bc_tendencies(ctx, s, G))) return rc;          // :229,243,257
             if ((rc = bzi_rk3_fused(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
             if (ctx->dg.microphysics == 2 && (rc = bzi_kessler_rk3(ctx, dt, alpha, stage == 0))) return rc;
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt))) return rc;
@@ -71,6 +80,7 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
     if ((rc = bz_store_initial_state(ctx, s, U0))) return rc;               // :223
     for (int stage = 0; stage < 3; ++stage) {
         const double alpha = alphas[stage];
+        if ((rc = bz_compute_flux_bc_tendencies(ctx, s, G))) return rc;              // :229,243,257
         if ((rc = bz_ssp_rk3_substep(ctx, s, U0, G, dt, alpha))) return rc;          // :230,244,258
         if ((rc = bz_compute_pressure_correction(ctx, s, alpha * dt))) return rc;    // :232,246,260
         if ((rc = bz_make_pressure_correction(ctx, s, alpha * dt))) return rc;       // :233,247,261

@@ -27,6 +27,14 @@ static int pick_chunk_lds(const DevGrid &g, int nlev, int rows_per_block)
     long long maxchunks = nlev / 128 > 0 ? nlev / 128 : 1;
     if (want > maxchunks) want = maxchunks;
     if (want < 1) want = 1;
+    // small grids (BOMEX 256 x 256 x 128: 128 tiles): filling the 256 CUs matters more than the prologue, go down to
+    // 32-level chunks until there are two blocks per CU
+    if (tiles * want < 512 && !getenv("BZ_NO_SMALL_CHUNKS")) {
+        long long fill = (512 + tiles - 1) / tiles;
+        long long cap = nlev / 32 > 0 ? nlev / 32 : 1;
+        if (fill > cap) fill = cap;
+        if (fill > want) want = fill;
+    }
     return (int)((nlev + want - 1) / want);
 }
 

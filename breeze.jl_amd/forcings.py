@@ -1,0 +1,160 @@
+"""Host-side mirror of the forcing / Coriolis / boundary-flux interface of the BOMEX configuration (BASELINE configs[2]).
+
+The reference assembles these from Oceananigans' `Forcing`, `FluxBoundaryCondition`, `FPlane` and Breeze's own
+`SubsidenceForcing` / `geostrophic_forcings` (examples/bomex.jl:80-207).  Every one of them is a horizontally uniform
+column profile (times the reference density, src/Forcings/specific_forcing.jl:61-74), so `materialize_forcings` reduces the
+model's `forcing` / `coriolis` / `boundary_conditions` keywords to one `bz_column_forcings` struct for `bz_set_forcings`.
+Nothing here computes on the CPU: the profiles are evaluated once at construction (as `set!` of a column Field is in the
+reference) and the tendencies are HIP kernels (csrc/bz_forcing.hip).
+"""
+import ctypes as C
+import unicodedata
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+
+
+class FPlane:
+    """FPlane(f=...) (Oceananigans.Coriolis)."""
+
+    def __init__(self, f):
+        self.f = float(f)
+
+
+class SubsidenceForcing:
+    """SubsidenceForcing(wˢ) (src/Forcings/subsidence_forcing.jl:14-58): wˢ a function of z or Nz+1 face values."""
+
+    def __init__(self, subsidence_vertical_velocity):
+        self.subsidence_vertical_velocity = subsidence_vertical_velocity
+
+
+class GeostrophicForcing:
+    """One component of geostrophic_forcings (src/Forcings/geostrophic_forcings.jl): direction "x": -f vᵍ, "y": +f uᵍ."""
+
+    def __init__(self, geostrophic_velocity, direction):
+        self.geostrophic_velocity, self.direction = geostrophic_velocity, direction
+
+
+GeostrophicForcings = namedtuple("GeostrophicForcings", ("u", "v"))
+
+
+def geostrophic_forcings(uᵍ, vᵍ):
+    """geostrophic_forcings(uᵍ, vᵍ) -> (u = -f vᵍ, v = +f uᵍ); f comes from the model's coriolis at materialization."""
+    return GeostrophicForcings(GeostrophicForcing(vᵍ, "x"), GeostrophicForcing(uᵍ, "y"))
+
+
+class Forcing:
+    """Forcing(profile): a column field / function of z added to the specific tendency (Oceananigans Forcing(field))."""
+
+    def __init__(self, profile):
+        self.profile = profile
+
+
+class FrictionVelocityDrag:
+    """The example's bulk drag closure -ρ₀ u★² ρu / √(ρu² + ρv²) (examples/bomex.jl:95-99) as data."""
+
+    def __init__(self, ρ0, ustar):
+        self.ρ0, self.ustar = float(ρ0), float(ustar)
+
+
+class FluxBoundaryCondition:
+    def __init__(self, condition):
+        self.condition = condition
+
+
+class FieldBoundaryConditions:
+    def __init__(self, bottom=None, top=None):
+        if top is not None:
+            raise NotImplementedError("only bottom flux boundary conditions are implemented")
+        self.bottom = bottom
+
+
+def _key(name):
+    return unicodedata.normalize("NFKC", str(name))
+
+
+def _profile(value, z):
+    if callable(value):
+        return np.ascontiguousarray([float(value(zk)) for zk in z], dtype=np.float64)
+    a = np.ascontiguousarray(value, dtype=np.float64)
+    if a.shape != z.shape:
+        raise ValueError(f"profile has shape {a.shape}, expected {z.shape}")
+    return a
+
+
+def materialize_forcings(grid, coriolis, forcing, boundary_conditions):
+    """-> (bz_column_forcings, keepalive arrays) or (None, None) when nothing is attached."""
+    if coriolis is None and not forcing and not boundary_conditions:
+        return None, None
+    if coriolis is not None and not isinstance(coriolis, FPlane):
+        raise NotImplementedError("coriolis: FPlane is implemented")
+    f = coriolis.f if coriolis is not None else 0.0
+    zc, zf = np.asarray(grid.zᶜ, dtype=np.float64), np.asarray(grid.zᶠ, dtype=np.float64)
+    slots = {"u": "u_forcing", "v": "v_forcing", "θ": "theta_forcing", "qe": "moisture_forcing", "qv": "moisture_forcing",
+             "qt": "moisture_forcing", "e": "energy_forcing"}
+    sub_flags = {"u": "subsidence_u", "v": "subsidence_v", "θ": "subsidence_theta", "qe": "subsidence_moisture",
+                 "qv": "subsidence_moisture", "qt": "subsidence_moisture"}
+    static, keep = {}, []
+    S = _lib.bz_column_forcings()
+    ws = None
+    for name, entry in (forcing or {}).items():
+        k = _key(name)
+        if k.startswith("ρ"):
+            raise ValueError("forcings are specific tendencies and must be supplied under the specific prognostic name "
+                             "(e.g. `θ` instead of `ρθ`); the density factor is applied automatically")
+        if k not in slots:
+            raise NotImplementedError(f"forcing on {name!r} is not implemented")
+        for item in (entry if isinstance(entry, (tuple, list)) else (entry,)):
+            if isinstance(item, SubsidenceForcing):
+                if k not in sub_flags:
+                    raise NotImplementedError(f"SubsidenceForcing on {name!r} is not implemented")
+                w = _profile(item.subsidence_vertical_velocity, zf)
+                if ws is not None and not np.array_equal(ws, w):
+                    raise NotImplementedError("one subsidence velocity profile per model")
+                ws = w
+                setattr(S, sub_flags[k], 1)
+            elif isinstance(item, GeostrophicForcing):
+                if coriolis is None:
+                    raise ValueError("geostrophic forcings need the model's coriolis")
+                if (item.direction, k) not in (("x", "u"), ("y", "v")):
+                    raise ValueError("geostrophic.u belongs under `u`, geostrophic.v under `v`")
+                prof = _profile(item.geostrophic_velocity, zc)
+                prof = -f * prof if item.direction == "x" else f * prof
+                static[slots[k]] = static.get(slots[k], 0.0) + prof
+            elif isinstance(item, Forcing) or callable(item):
+                prof = _profile(item.profile if isinstance(item, Forcing) else item, zc)
+                static[slots[k]] = static.get(slots[k], 0.0) + prof
+            else:
+                raise NotImplementedError(f"forcing {item!r} is not implemented")
+    for slot, prof in static.items():
+        a = np.ascontiguousarray(prof, dtype=np.float64)
+        keep.append(a)
+        setattr(S, slot, a.ctypes.data_as(C.POINTER(C.c_double)))
+    if ws is not None:
+        keep.append(ws)
+        S.subsidence_vertical_velocity = ws.ctypes.data_as(C.POINTER(C.c_double))
+    S.coriolis_f = f
+    drag = None
+    for name, bcs in (boundary_conditions or {}).items():
+        k = _key(name)
+        bottom = bcs.bottom if isinstance(bcs, FieldBoundaryConditions) else bcs
+        if bottom is None:
+            continue
+        cond = bottom.condition if isinstance(bottom, FluxBoundaryCondition) else bottom
+        if k == "ρθ":
+            S.bottom_theta_flux = float(cond)
+        elif k in ("ρqe", "ρqv", "ρqt"):
+            S.bottom_moisture_flux = float(cond)
+        elif k in ("ρu", "ρv"):
+            if not isinstance(cond, FrictionVelocityDrag):
+                raise NotImplementedError("momentum bottom flux: FrictionVelocityDrag(ρ₀, u★)")
+            d = cond.ρ0 * cond.ustar ** 2
+            if drag is not None and drag != d:
+                raise NotImplementedError("ρu and ρv share one drag")
+            drag = d
+        else:
+            raise NotImplementedError(f"boundary condition on {name!r} is not implemented")
+    S.bottom_drag_rho0_ustar2 = drag or 0.0
+    return S, keep

@@ -99,7 +99,8 @@ class AtmosphereModel:
 
     def __init__(self, grid, dynamics=None, advection=None, thermodynamic_constants=None,
                  formulation="LiquidIcePotentialTemperature", timestepper="SSPRungeKutta3",
-                 closure=None, coriolis=None, microphysics=None, forcing=None, device="cuda:0"):
+                 closure=None, coriolis=None, microphysics=None, forcing=None, boundary_conditions=None,
+                 device="cuda:0"):
         import torch
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
@@ -111,9 +112,9 @@ class AtmosphereModel:
         self.formulation = formulation
         if timestepper not in ("SSPRungeKutta3", ":SSPRungeKutta3"):
             raise NotImplementedError("only SSPRungeKutta3 is implemented")
-        for name, val in (("closure", closure), ("coriolis", coriolis), ("forcing", forcing)):
-            if val is not None:
-                raise NotImplementedError(f"{name} is outside the hot-path scope of this build")
+        if closure is not None:
+            raise NotImplementedError("closure is outside the hot-path scope of this build")
+        self.coriolis, self.forcing, self.boundary_conditions = coriolis, forcing, boundary_conditions
         from .microphysics import DCMIP2016KesslerMicrophysics, SaturationAdjustment, TetensFormula
         if microphysics is not None and not isinstance(microphysics, (SaturationAdjustment, DCMIP2016KesslerMicrophysics)):
             raise NotImplementedError("microphysics: SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) and "
@@ -216,6 +217,13 @@ class AtmosphereModel:
                                                          C.c_void_p(self.microphysical_fields["qᵛ"].ptr()),
                                                          C.c_void_p(self.microphysical_fields["qˡ"].ptr())),
                         "bz_set_saturation_adjustment")
+        # coriolis / forcing / boundary_conditions of the BOMEX configuration -> one column-forcing stack (forcings.py)
+        from .forcings import materialize_forcings
+        F, self._forcing_keepalive = materialize_forcings(grid, coriolis, forcing, boundary_conditions)
+        if F is not None:
+            if self._kessler or formulation != "LiquidIcePotentialTemperature":
+                raise NotImplementedError("forcings are implemented for the potential-temperature formulation without Kessler")
+            self._check(lib.bz_set_forcings(self._ctx, C.byref(F)), "bz_set_forcings")
         self._state = self._make_state()
         self._U0 = self._make_prog(self.U0)
         self._G = self._make_prog(self.G)
@@ -307,6 +315,12 @@ def update_state_(model, compute_tendencies=True):
 def compute_tendencies_(model):
     model._check(model._lib.bz_compute_tendencies(model._ctx, C.byref(model._state), C.byref(model._G)),
                  "bz_compute_tendencies")
+
+
+def compute_flux_bc_tendencies_(model):
+    """compute_flux_bc_tendencies!(model) (update_atmosphere_model_state.jl:418-434)."""
+    model._check(model._lib.bz_compute_flux_bc_tendencies(model._ctx, C.byref(model._state), C.byref(model._G)),
+                 "bz_compute_flux_bc_tendencies")
 
 
 def compute_velocities_(model):
@@ -417,6 +431,7 @@ def time_step_(model, Δt, whole_step=True):
     else:
         store_initial_state_(model)
         for α in (1.0, 1.0 / 4.0, 2.0 / 3.0):
+            compute_flux_bc_tendencies_(model)
             ssp_rk3_substep_(model, Δt, α)
             compute_pressure_correction_(model, α * Δt)
             make_pressure_correction_(model, α * Δt)

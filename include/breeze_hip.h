@@ -382,6 +382,40 @@ int bz_kessler_model_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
 int bz_compressible_kessler_update(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
                                    const bz_acoustic_substepper *sub, double dt);
 
+/* ---- forcing, f-plane Coriolis and bottom-flux stack of the BOMEX configuration (BASELINE configs[2]) ----
+ * Every forcing of examples/bomex.jl:104-196 is a horizontally uniform specific profile multiplied by the reference density
+ * (SpecificForcing, src/Forcings/specific_forcing.jl:61-74), so the model's `forcing` NamedTuple reduces to columns:
+ *   u_forcing / v_forcing        geostrophic_forcings: -f v_g(z), +f u_g(z) (src/Forcings/geostrophic_forcings.jl)
+ *   theta_forcing, moisture_forcing   Forcing(field) profiles keyed under theta / q^e (q^v)
+ *   energy_forcing               profile keyed under `e`; enters G_rho_theta as rho F_e / (c_pm Pi)
+ *                                (src/PotentialTemperatureFormulations/potential_temperature_tendency.jl:86-104)
+ *   subsidence_vertical_velocity SubsidenceForcing(w_s) on the flagged fields: F = -zb-average(w_s dz(horizontal average))
+ *                                (src/Forcings/subsidence_forcing.jl:75-91), averages recomputed at every compute_forcings!
+ *   coriolis_f                   FPlane(f): -x_f_cross_U, -y_f_cross_U (src/AtmosphereModels/dynamics_kernel_functions.jl:79,99)
+ *   bottom_*_flux                FluxBoundaryCondition values on rho theta / rho q (examples/bomex.jl:80-87)
+ *   bottom_drag_rho0_ustar2      rho0 u*^2 of the bulk drag FluxBoundaryCondition on rho u, rho v (examples/bomex.jl:95-101)
+ * All pointers are HOST arrays (cell centres, length Nz; the subsidence velocity Nz+1 faces), copied by the call; NULL = absent.
+ * With a stack attached bz_compute_tendencies adds the forcing + Coriolis terms, and bz_time_step_anelastic calls
+ * bz_compute_flux_bc_tendencies before every RK substep (src/TimeSteppers/ssp_runge_kutta_3.jl:229,243,257).
+ * Single-device anelastic potential-temperature contexts only (microphysics nothing or SaturationAdjustment). */
+typedef struct bz_column_forcings {
+    const double *u_forcing;
+    const double *v_forcing;
+    const double *theta_forcing;
+    const double *moisture_forcing;
+    const double *energy_forcing;
+    const double *subsidence_vertical_velocity;
+    int32_t subsidence_u, subsidence_v, subsidence_theta, subsidence_moisture;
+    double coriolis_f;
+    double bottom_theta_flux, bottom_moisture_flux;
+    double bottom_drag_rho0_ustar2;
+} bz_column_forcings;
+int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *forcings);       /* NULL detaches the stack */
+/* compute_forcings!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:81-86) */
+int bz_compute_forcings(bz_ctx *ctx, const bz_state *s);
+/* compute_flux_bc_tendencies!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:418-434) */
+int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+
 /* ---- the reductions of the run! loop around the step ---- */
 /* cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): minimum over the interior of
  * 1 / (|u|/dx + |v|/dy + |w|/dz) into *out (host; +Inf for a fluid at rest); w == NULL gives the HorizontalFormulation.

@@ -1,0 +1,137 @@
+"""
+oracle/forcings.py — CPU restatement of the forcing / Coriolis / bottom-flux terms of the BOMEX configuration
+(BASELINE configs[2], examples/bomex.jl:80-207) for the anelastic OracleModel.  TEST INFRASTRUCTURE ONLY.
+
+PARITY STATUS: **parity unpinned** — the reference holds no golden numbers for these terms (its tests check them against
+analytic expectations only) and the Coriolis and boundary-flux arithmetic lives in Oceananigans, which is not vendored;
+it is restated from its published operators.  Breeze-side formulas are followed line by line:
+
+  SubsidenceForcing  F = -zb-average(w_s dz(avg phi))     src/Forcings/subsidence_forcing.jl:75-91,104-126
+  geostrophic_forcings  F_u = -f v_g, F_v = +f u_g         src/Forcings/geostrophic_forcings.jl (GeostrophicForcing call)
+  SpecificForcing  rho at the target location x F          src/Forcings/specific_forcing.jl:61-74
+  energy forcing in the theta tendency  F_rho_e/(c_pm Pi)  src/PotentialTemperatureFormulations/potential_temperature_tendency.jl:86-104
+  Coriolis  -x_f_cross_U / -y_f_cross_U                    src/AtmosphereModels/dynamics_kernel_functions.jl:79,99
+                                                           (Oceananigans FPlane: x = -f xy-average(rho v), y = +f xy-average(rho u))
+  compute_forcings! before the tendencies                  src/AtmosphereModels/update_atmosphere_model_state.jl:52,81-86
+  compute_flux_bc_tendencies! before every RK substep      src/AtmosphereModels/update_atmosphere_model_state.jl:418-434,
+                                                           src/TimeSteppers/ssp_runge_kutta_3.jl (time_step!)
+                                                           (Oceananigans: G[i,j,1] += J Az / V for a bottom flux J)
+  bulk drag of the example  J = -rho0 u*^2 rho_u/|rho U|   examples/bomex.jl:95-101 (rho v / rho u interpolated to the BC location)
+"""
+import numpy as np
+
+
+class ColumnForcings:
+    """Horizontally uniform forcing profiles (length Nz, cell centres; None = absent) + f-plane + bottom fluxes."""
+
+    def __init__(self, Fu=None, Fv=None, Ftheta=None, Fq=None, Fe=None, w_subsidence=None,
+                 subsidence_on=("u", "v", "theta", "q"), coriolis_f=0.0, flux_theta=0.0, flux_q=0.0,
+                 drag_rho0_ustar2=0.0):
+        self.Fu, self.Fv, self.Ftheta, self.Fq, self.Fe = Fu, Fv, Ftheta, Fq, Fe
+        self.w_subsidence = w_subsidence              # Nz+1 faces
+        self.subsidence_on = tuple(subsidence_on) if w_subsidence is not None else ()
+        self.f = float(coriolis_f)
+        self.flux_theta, self.flux_q, self.drag = float(flux_theta), float(flux_q), float(drag_rho0_ustar2)
+        self.sub = {}
+
+
+def subsidence_profile(ws, avg, dzf):
+    """-zb-average of w_s[k] * (avg[k]-avg[k-1])/dzf[k]: one-sided at the bottom and top cells."""
+    Nz = avg.shape[0]
+    wdz = np.zeros(Nz + 1)
+    wdz[1:Nz] = ws[1:Nz] * ((avg[1:] - avg[:-1]) / dzf[1:Nz])
+    out = np.empty(Nz)
+    out[1:Nz - 1] = (wdz[2:Nz] + wdz[1:Nz - 1]) / 2
+    out[0] = wdz[1]
+    out[Nz - 1] = wdz[Nz - 1]
+    return -out
+
+
+def compute_forcings(m):
+    """compute_forcing!(::SubsidenceForcing): Average(specific field, dims=(1,2))."""
+    F, g = m.forcings, m.grid
+    dzf = m.grid.dzf[g.Hz:g.Hz + g.Nz + 1]
+    spec = {"u": m.u, "v": m.v, "theta": m.theta, "q": m.q}
+    F.sub = {}
+    for name in F.subsidence_on:
+        avg = g.interior(spec[name]).mean(axis=(1, 2))
+        F.sub[name] = subsidence_profile(np.asarray(F.w_subsidence, dtype=np.float64), avg, dzf)
+
+
+def _xy_to_fc(m, f):
+    """xy-average of a (c,f,c) field to (f,c,c) on the interior: (i-1,j),(i,j),(i-1,j+1),(i,j+1)."""
+    g = m.grid
+    z = slice(g.Hz, g.Hz + g.Nz)
+    y0, y1, x0, x1 = g.Hy, g.Hy + g.Ny, g.Hx, g.Hx + g.Nx
+    dy = 0 if g.Ny == 1 and g.Hy == 0 else 1
+    dx = 0 if g.Nx == 1 and g.Hx == 0 else 1
+    a = lambda jo, io: f[z, y0 + jo:y1 + jo, x0 + io:x1 + io]
+    yc_i = (a(0, 0) + a(dy, 0)) / 2
+    yc_im = (a(0, -dx) + a(dy, -dx)) / 2
+    return (yc_im + yc_i) / 2
+
+
+def _xy_to_cf(m, f):
+    """xy-average of a (f,c,c) field to (c,f,c): (i,j-1),(i+1,j-1),(i,j),(i+1,j)."""
+    g = m.grid
+    z = slice(g.Hz, g.Hz + g.Nz)
+    y0, y1, x0, x1 = g.Hy, g.Hy + g.Ny, g.Hx, g.Hx + g.Nx
+    dy = 0 if g.Ny == 1 and g.Hy == 0 else 1
+    dx = 0 if g.Nx == 1 and g.Hx == 0 else 1
+    a = lambda jo, io: f[z, y0 + jo:y1 + jo, x0 + io:x1 + io]
+    xc_j = (a(0, 0) + a(0, dx)) / 2
+    xc_jm = (a(-dy, 0) + a(-dy, dx)) / 2
+    return (xc_jm + xc_j) / 2
+
+
+def add_forcing_tendencies(m):
+    """Coriolis + forcing terms of x/y momentum, theta and moisture tendencies (after the advective part)."""
+    F, g, c, r = m.forcings, m.grid, m.constants, m.ref
+    I = g.interior
+    rho = r.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    col = lambda p: np.asarray(p, dtype=np.float64)[:, None, None]
+    G = m.G
+    if F.f != 0.0:
+        I(G["ru"])[...] -= -F.f * _xy_to_fc(m, m.rv)
+        I(G["rv"])[...] -= F.f * _xy_to_cf(m, m.ru)
+    for name, key, static in (("u", "ru", F.Fu), ("v", "rv", F.Fv), ("theta", "rtheta", F.Ftheta), ("q", "rq", F.Fq)):
+        total = None
+        if name in F.sub:
+            total = rho * col(F.sub[name])
+        if static is not None:
+            total = rho * col(static) if total is None else total + rho * col(static)
+        if total is not None:
+            I(G[key])[...] += total
+    if F.Fe is not None:
+        if m.microphysics == "SaturationAdjustment":
+            qv, ql = I(m.qv), I(m.ql)
+            cl = m._sa.cl
+        else:
+            qv, ql, cl = I(m.q), 0.0, 0.0
+        qd = 1.0 - (qv + ql + 0.0)
+        Rm = qd * c.Rd + qv * c.Rv
+        cpm = qd * c.cpd + qv * c.cpv + ql * cl + 0.0
+        pr = r.pressure[g.Hz:g.Hz + g.Nz][:, None, None]
+        Pi = (pr / r.pst) ** (Rm / cpm)
+        I(G["rtheta"])[...] += (rho * col(F.Fe) + 0.0) / (cpm * Pi)
+
+
+def add_flux_bc_tendencies(m):
+    """compute_flux_bc_tendencies!: bottom FluxBoundaryConditions, G[.,.,1] += J / dz_1."""
+    F, g = m.forcings, m.grid
+    dz = g.dzc[g.Hz]
+    k = g.Hz
+    I = g.interior
+    if F.flux_theta != 0.0:
+        I(m.G["rtheta"])[0] += F.flux_theta * 1.0 / dz
+    if F.flux_q != 0.0:
+        I(m.G["rq"])[0] += F.flux_q * 1.0 / dz
+    if F.drag != 0.0:
+        ru, rv = I(m.ru)[0], I(m.rv)[0]
+        rv_fc = _xy_to_fc(m, m.rv)[0]
+        ru_cf = _xy_to_cf(m, m.ru)[0]
+        Ju = -F.drag * ru / np.sqrt(ru ** 2 + rv_fc ** 2)
+        Jv = -F.drag * rv / np.sqrt(ru_cf ** 2 + rv ** 2)
+        I(m.G["ru"])[0] += Ju * 1.0 / dz
+        I(m.G["rv"])[0] += Jv * 1.0 / dz
+    del k

@@ -255,7 +255,8 @@ class OracleModel:
 
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
                  standard_pressure=1e5, reference_density=None, initialize=True,
-                 formulation="LiquidIcePotentialTemperature", microphysics=None, sa_abstol=1e-4, sa_maxiter=20):
+                 formulation="LiquidIcePotentialTemperature", microphysics=None, sa_abstol=1e-4, sa_maxiter=20,
+                 forcings=None):
         # formulation "StaticEnergy": self.theta holds e, self.rtheta holds rho*e
         # (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21)
         assert formulation in ("LiquidIcePotentialTemperature", "StaticEnergy")
@@ -265,6 +266,8 @@ class OracleModel:
         assert microphysics in (None, "SaturationAdjustment", "Kessler")
         assert not (microphysics and formulation == "StaticEnergy"), "oracle: saturation adjustment with theta only"
         self.microphysics = microphysics
+        self.forcings = forcings           # oracle.forcings.ColumnForcings (BOMEX forcing stack) or None
+        assert not (forcings and (formulation == "StaticEnergy" or microphysics == "Kessler"))
         self.grid = g = grid
         self.constants = c = constants or Constants()
         self.ref = ReferenceState(g, c, surface_pressure, potential_temperature, standard_pressure)
@@ -452,6 +455,9 @@ class OracleModel:
             self.lib.og_compute_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.rtheta), _p(self.rq))
         for f in (self.T, self.q, self.theta):
             self._halo_center(f)
+        if self.forcings is not None:
+            from .forcings import compute_forcings
+            compute_forcings(self)
         if compute_tendencies:
             self.compute_tendencies()
 
@@ -472,6 +478,9 @@ class OracleModel:
         L.og_scalar_tendency(cg, _p(G["rq"]), _p(self.u), _p(self.v), _p(self.w), _p(self.q))
         if self.formulation == "StaticEnergy":
             L.og_energy_buoyancy_flux(cg, _p(G["rtheta"]), _p(self.w), _p(self.T), _p(self.q))
+        if self.forcings is not None:
+            from .forcings import add_forcing_tendencies
+            add_forcing_tendencies(self)
 
     def liquid_ice_potential_temperature(self):
         """Diagnostics.LiquidIcePotentialTemperature (dry: theta = T / Pi) on the interior."""
@@ -531,6 +540,9 @@ class OracleModel:
         for n in self.PROGNOSTIC:                      # store_initial_state!
             self.U0[n][...] = getattr(self, n)
         for alpha in (1.0, 1.0 / 4.0, 2.0 / 3.0):
+            if self.forcings is not None:              # compute_flux_bc_tendencies! (ssp_runge_kutta_3.jl:229,243,257)
+                from .forcings import add_flux_bc_tendencies
+                add_flux_bc_tendencies(self)
             self.rk3_substep(dt, alpha)
             self.compute_pressure_correction(alpha * dt)
             self.make_pressure_correction(alpha * dt)

@@ -1,0 +1,230 @@
+"""The forcing / Coriolis / bottom-flux stack of the BOMEX configuration (BASELINE configs[2], examples/bomex.jl:80-207):
+analytic pins of the CPU restatement (oracle/forcings.py) and HIP-vs-oracle parity through the C ABI.
+
+The profiles are the Siebesma et al. (2003) appendix-B forms the example takes from AtmosphericProfilesLibrary (not vendored):
+piecewise-linear subsidence, geostrophic wind, drying and radiative cooling."""
+import numpy as np
+import pytest
+
+from helpers import PROG, push_state, relerr
+
+F0, RHO0, USTAR = 3.76e-5, 1.15, 0.28
+
+
+def ws_profile(z):
+    return -6.5e-3 * z / 1500.0 if z <= 1500.0 else (-6.5e-3 * (1 - (z - 1500.0) / 600.0) if z <= 2100.0 else 0.0)
+
+
+def ug_profile(z):
+    return -10.0 + 1.8e-3 * z
+
+
+def vg_profile(z):
+    return 0.0
+
+
+def drying_profile(z):
+    return -1.2e-8 if z <= 300.0 else (-1.2e-8 * (1 - (z - 300.0) / 200.0) if z <= 500.0 else 0.0)
+
+
+def cooling_profile(z):        # c_pd dT/dt
+    dTdt = -2.0 / 86400.0 if z <= 1500.0 else (-2.0 / 86400.0 * (1 - (z - 1500.0) / 1500.0) if z <= 3000.0 else 0.0)
+    return 1005.0 * dTdt
+
+
+EXTENT = ((-3.2e3, 3.2e3), (-2e3, 2e3), (0.0, 3e3))
+
+
+def _oracle_forcings(oracle, og, full=True):
+    from oracle.forcings import ColumnForcings
+    zc, zf = og.zc, og.zf
+    col = lambda f, z: np.array([f(v) for v in z])
+    kw = dict(Fu=-F0 * col(vg_profile, zc), Fv=F0 * col(ug_profile, zc), Fq=col(drying_profile, zc),
+              Fe=col(cooling_profile, zc), w_subsidence=col(ws_profile, zf), coriolis_f=F0)
+    if full:
+        kw.update(flux_theta=RHO0 * 8e-3, flux_q=RHO0 * 5.2e-5, drag_rho0_ustar2=RHO0 * USTAR ** 2)
+    return ColumnForcings(**kw)
+
+
+def _hip_forcing_kwargs(bz, full=True):
+    subsidence = bz.SubsidenceForcing(ws_profile)
+    geo = bz.geostrophic_forcings(ug_profile, vg_profile)
+    kw = dict(coriolis=bz.FPlane(f=F0),
+              forcing={"u": (subsidence, geo.u), "v": (subsidence, geo.v), "θ": subsidence,
+                       "qᵉ": (subsidence, bz.Forcing(drying_profile)), "e": bz.Forcing(cooling_profile)})
+    if full:
+        drag = bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(bz.FrictionVelocityDrag(RHO0, USTAR)))
+        kw["boundary_conditions"] = {"ρθ": bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(RHO0 * 8e-3)),
+                                     "ρqᵉ": bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(RHO0 * 5.2e-5)),
+                                     "ρu": drag, "ρv": drag}
+    return kw
+
+
+def _pair(oracle, bz, size=(32, 20, 16), moist=True, full=True):
+    og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1,
+                            microphysics="SaturationAdjustment" if moist else None, forcings=_oracle_forcings(oracle, og, full))
+    grid = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5),
+                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()) if moist else None,
+                            **_hip_forcing_kwargs(bz, full))
+    return om, hm
+
+
+def _ic(seed=3):
+    rng = np.random.default_rng(seed)
+    ph = rng.uniform(0, 2 * np.pi, 4)
+    th = lambda x, y, z: 298.7 + 0.004 * np.maximum(z - 520.0, 0.0) + 0.3 * np.sin(2 * np.pi * x / 6.4e3 + ph[0]) * np.exp(-z / 800.0) + 0 * y
+    qt = lambda x, y, z: 0.0185 * np.exp(-z / 2200.0) * (1 + 0.08 * np.cos(2 * np.pi * y / 4e3 + ph[1])) + 0 * x
+    u = lambda x, y, z: -8.75 + 1.5e-3 * z + 0.5 * np.sin(2 * np.pi * y / 4e3 + ph[2]) + 0 * x
+    v = lambda x, y, z: 0.4 * np.cos(2 * np.pi * x / 6.4e3 + ph[3]) + 0 * y + 0 * z
+    return dict(theta=th, qt=qt, u=u, v=v)
+
+
+# ---- CPU: analytic pins of the restatement -------------------------------------------------------------------------------------
+
+def test_subsidence_profile_of_a_linear_mean_is_minus_w_times_slope():
+    from oracle.forcings import subsidence_profile
+    Nz, dz = 12, 50.0
+    zc, zf = (np.arange(Nz) + 0.5) * dz, np.arange(Nz + 1) * dz
+    avg = 300.0 + 0.004 * zc
+    ws = -1e-3 * np.ones(Nz + 1)
+    F = subsidence_profile(ws, avg, np.full(Nz + 1, dz))
+    np.testing.assert_allclose(F, 1e-3 * 0.004, rtol=1e-10)          # one-sided ends carry the same slope
+    # a z-dependent w_s: interior cells average the two face products, the ends use their single interior face
+    ws = np.array([ws_profile(z) for z in zf * 4])
+    F = subsidence_profile(ws, avg, np.full(Nz + 1, dz))
+    np.testing.assert_allclose(F[3], -0.004 * (ws[3] + ws[4]) / 2, rtol=1e-10)
+    np.testing.assert_allclose(F[0], -0.004 * ws[1], rtol=1e-10)
+    np.testing.assert_allclose(F[-1], -0.004 * ws[Nz - 1], rtol=1e-10)
+
+
+def test_geostrophic_balance_and_flux_bcs_in_the_oracle(oracle):
+    """u = u_g, v = v_g: Coriolis and the geostrophic forcing cancel in both momentum tendencies (uniform-in-x,y flow has
+    no advective tendency); the bottom fluxes land in the first level only, as J / dz."""
+    from oracle.forcings import ColumnForcings
+    og = oracle.Grid((8, 6, 10), x=(0, 800.0), y=(0, 600.0), z=(0, 1000.0))
+    zc = og.zc
+    ug, vg = -10 + 1.8e-3 * zc, 2.0 + 0 * zc
+    F = ColumnForcings(Fu=-F0 * vg, Fv=F0 * ug, coriolis_f=F0, flux_theta=0.0092, flux_q=6e-5, drag_rho0_ustar2=0.09)
+    om = oracle.OracleModel(og, forcings=F)
+    om.set(u=lambda x, y, z: -10 + 1.8e-3 * z + 0 * x + 0 * y, v=2.0, enforce_mass_conservation=False)
+    om.update_state()
+    g = og
+    rho = om.ref.density[g.Hz:g.Hz + g.Nz]
+    assert np.abs(g.interior(om.G["ru"])).max() < 1e-15 * F0 * 10 * rho.max() * 1e3
+    assert np.abs(g.interior(om.G["rv"])).max() < 1e-15 * F0 * 10 * rho.max() * 1e3
+    G0 = {n: om.G[n].copy() for n in om.G}
+    from oracle.forcings import add_flux_bc_tendencies
+    add_flux_bc_tendencies(om)
+    dz = 100.0
+    d = {n: g.interior(om.G[n]) - g.interior(G0[n]) for n in ("ru", "rv", "rtheta", "rq")}
+    for n in d:
+        assert np.all(d[n][1:] == 0)
+    np.testing.assert_allclose(d["rtheta"][0], 0.0092 / dz, rtol=1e-12)
+    np.testing.assert_allclose(d["rq"][0], 6e-5 / dz, rtol=1e-12)
+    ru0, rv0 = rho[0] * ug[0], rho[0] * 2.0
+    sp = np.hypot(ru0, rv0)
+    np.testing.assert_allclose(d["ru"][0], -0.09 * ru0 / sp / dz, rtol=1e-10)
+    np.testing.assert_allclose(d["rv"][0], -0.09 * rv0 / sp / dz, rtol=1e-10)
+
+
+def test_energy_forcing_enters_theta_as_F_over_cpm_exner(oracle):
+    from oracle.forcings import ColumnForcings
+    og = oracle.Grid((4, 4, 8), x=(0, 400.0), y=(0, 400.0), z=(0, 2000.0))
+    Fe = np.array([cooling_profile(z) for z in og.zc])
+    om = oracle.OracleModel(og, forcings=ColumnForcings(Fe=Fe))
+    om.update_state()
+    c, r, g = om.constants, om.ref, og
+    rho, p = r.density[g.Hz:g.Hz + g.Nz], r.pressure[g.Hz:g.Hz + g.Nz]
+    want = rho * Fe / (c.cpd * (p / r.pst) ** (c.Rd / c.cpd))
+    np.testing.assert_allclose(g.interior(om.G["rtheta"])[:, 1, 2], want, rtol=1e-12)
+
+
+# ---- GPU: parity through the C ABI ------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("moist", [False, True])
+def test_forcing_tendencies_match_oracle(oracle, bz, moist):
+    om, hm = _pair(oracle, bz, moist=moist)
+    om.set(**_ic())
+    om.update_state()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=True)
+    hm.synchronize()
+    g = om.grid
+    strict = "refdiv" in bz.LIB_PATH
+    for n, k in PROG.items():
+        zf = n == "rw"
+        want, got = g.interior(om.G[n], zface=zf), hm.G[k].interior_cpu()
+        if zf:
+            want, got = want[1:-1], got[1:-1]
+        assert relerr(got, want) < (1e-12 if strict else 5e-9), n
+    # the forcing part alone (difference to an unforced model on the same state) is smooth data: tight without the WENO caveat
+    om0 = oracle.OracleModel(g, surface_pressure=101500.0, potential_temperature=299.1,
+                             microphysics="SaturationAdjustment" if moist else None)
+    for n in ("ru", "rv", "rw", "rtheta", "rq"):
+        getattr(om0, n)[...] = getattr(om, n)
+    om0.update_state()
+    for n, k in PROG.items():
+        if n == "rw":
+            continue
+        forced = g.interior(om.G[n]) - g.interior(om0.G[n])
+        assert np.abs(forced).max() > 0
+        got = hm.G[k].interior_cpu() - g.interior(om0.G[n])
+        assert np.abs(got - forced).max() < 1e-9 * np.abs(forced).max() + 1e-9 * np.abs(g.interior(om0.G[n])).max(), n
+    # bottom fluxes
+    from oracle.forcings import add_flux_bc_tendencies
+    before = {k: hm.G[k].interior_cpu().copy() for k in PROG.values()}
+    G0 = {n: g.interior(om.G[n], zface=(n == "rw")).copy() for n in PROG}
+    add_flux_bc_tendencies(om)
+    bz.compute_flux_bc_tendencies_(hm)
+    hm.synchronize()
+    for n, k in PROG.items():
+        want = g.interior(om.G[n], zface=(n == "rw")) - G0[n]
+        got = hm.G[k].interior_cpu() - before[k]
+        if n == "rw":
+            assert np.all(got == 0)
+            continue
+        assert np.abs(want).max() > 0
+        assert np.abs(got - want).max() < 1e-9 * np.abs(want).max(), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("whole_step", [True, False])
+def test_forced_time_steps_match_oracle(oracle, bz, whole_step):
+    om, hm = _pair(oracle, bz, moist=True)
+    ic = _ic(seed=7)
+    om.set(**ic)
+    hm.set(θ=ic["theta"], qᵗ=ic["qt"], u=ic["u"], v=ic["v"])
+    for _ in range(3):
+        om.time_step(3.0)
+        bz.time_step_(hm, 3.0, whole_step=whole_step)
+    hm.synchronize()
+    g = om.grid
+    mom = max(np.abs(g.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    for n, k in PROG.items():
+        want = g.interior(getattr(om, n), zface=(n == "rw"))
+        got = hm.prognostic_fields()[k].interior_cpu()
+        scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() / scale < 1e-9, n
+    # the stack did something: compare with an unforced run of the same initial state
+    om0 = oracle.OracleModel(g, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment")
+    om0.set(**ic)
+    for _ in range(3):
+        om0.time_step(3.0)
+    assert np.abs(g.interior(om0.rtheta) - g.interior(om.rtheta)).max() > 1e-6
+    assert np.abs(g.interior(om0.ru) - g.interior(om.ru)).max() > 1e-6
+
+
+@pytest.mark.gpu
+def test_forcing_interface_errors(bz):
+    grid = bz.RectilinearGrid((16, 16, 8), x=(0, 1e3), y=(0, 1e3), z=(0, 1e3))
+    mk = lambda **kw: bz.AtmosphereModel(grid, advection=bz.WENO(order=5), **kw)
+    with pytest.raises(ValueError, match="specific"):
+        mk(forcing={"ρθ": bz.SubsidenceForcing(ws_profile)})
+    with pytest.raises(ValueError, match="coriolis"):
+        mk(forcing={"u": bz.geostrophic_forcings(ug_profile, vg_profile).u})
+    with pytest.raises(NotImplementedError):
+        mk(forcing={"w": bz.Forcing(lambda z: 0.0)})

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""tools/bench_bomex.py — timing of the BOMEX-shaped anelastic step (BASELINE configs[2], examples/bomex.jl).
+
+Workload: 256 x 256 x 128 cells over 6.4 km x 6.4 km x 3 km (the example's 25 m x 25 m x 23.4 m... grid scaled to the config
+size), AnelasticDynamics + WENO-5 + SaturationAdjustment(WarmPhaseEquilibrium) + the example's forcing stack: f-plane Coriolis,
+geostrophic forcing, subsidence of u, v, theta, q^e (horizontal averages every stage), drying, radiative cooling through the
+energy forcing, bottom sensible / latent / drag fluxes.  No Smagorinsky closure (out of scope): this is the
+advective + moist-thermodynamic + forcing part of the configuration.  Float64.  One JSON line with per-kernel milliseconds.
+
+    python tools/bench_bomex.py --size 256 256 128 --dt 2.0 --steps 10 --warmup 3 [--no-forcing]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, nargs=3, default=[256, 256, 128])
+    ap.add_argument("--dt", type=float, default=2.0)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-forcing", action="store_true")
+    a = ap.parse_args()
+    import torch
+    import breeze_jl_amd as bz
+    from test_forcings import _hip_forcing_kwargs
+    Nx, Ny, Nz = a.size
+    grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 6400.0), y=(0.0, 6400.0), z=(0.0, 3000.0))
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+    kw = {} if a.no_forcing else _hip_forcing_kwargs(bz, full=True)
+    m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5),
+                           microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), **kw)
+    rng = np.random.default_rng(0)
+    noise_t = rng.standard_normal((Nz, Ny, Nx))
+    noise_q = rng.standard_normal((Nz, Ny, Nx))
+
+    def theta(x, y, z):      # Siebesma et al. (2003) initial profile + the example's noise below 1600 m
+        base = np.where(z < 520.0, 298.7, np.where(z < 1480.0, 298.7 + (z - 520.0) * (302.4 - 298.7) / 960.0,
+                        np.where(z < 2000.0, 302.4 + (z - 1480.0) * (308.2 - 302.4) / 520.0, 308.2 + (z - 2000.0) * 3.65e-3)))
+        return base + 0.1 * noise_t * (z < 1600.0)
+
+    def qt(x, y, z):
+        base = np.where(z < 520.0, 17.0 + z * (16.3 - 17.0) / 520.0, np.where(z < 1480.0, 16.3 + (z - 520.0) * (10.7 - 16.3) / 960.0,
+                        np.where(z < 2000.0, 10.7 + (z - 1480.0) * (4.2 - 10.7) / 520.0, 4.2 + (z - 2000.0) * (-1.2e-3)))) * 1e-3
+        return base + 2.5e-5 * noise_q * (z < 1600.0)
+
+    u = lambda x, y, z: np.where(z < 700.0, -8.75, -8.75 + (z - 700.0) * 1.8e-3) + 0 * x + 0 * y
+    m.set(θ=theta, qᵗ=qt, u=u)
+    for _ in range(a.warmup):
+        m.time_step(a.dt)
+    m.synchronize()
+    m.profile_enable(True)
+    m.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m.time_step(a.dt)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    m.profile_enable(False)
+    prof = m.profile()
+    ms = (t1 - t0) / a.steps * 1e3
+    cells = Nx * Ny * Nz
+    ql = m.microphysical_fields["qˡ"].interior
+    w = m.velocities["w"].interior
+    out = {"metric": "grid-cells advanced/sec, BOMEX-shaped anelastic SSP-RK3 step (WENO5 + saturation adjustment + forcing stack)",
+           "value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": a.dt,
+           "forcing": not a.no_forcing, "dtype": "f64",
+           "kernels_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items())},
+           "step_contract_frac_of_8TBs": cells * 2000 / (ms * 1e-3) / 8e12,
+           "finite": bool(torch.isfinite(w).all().item()), "w_max": float(w.abs().max().item()),
+           "cloud_fraction": float((ql > 0).double().mean().item())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

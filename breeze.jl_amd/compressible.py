@@ -226,8 +226,6 @@ class CompressibleAtmosphereModel:
             if tcs is None or not isinstance(getattr(tcs, "saturation_vapor_pressure", None), TetensFormula):
                 raise ValueError("DCMIP2016KesslerMicrophysics requires `thermodynamic_constants` with a `TetensFormula` "
                                  "saturation vapor pressure formulation.")
-            if getattr(self, "_pending_decomp", None) is not None:
-                raise NotImplementedError("Kessler microphysics on y-slabs is not implemented")
         if advection is None:
             raise NotImplementedError("the HIP path requires advection=WENO(order=5)")
         if not torch.cuda.is_available():
@@ -564,8 +562,9 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
 
     def _diagnostic_tensors(self):
         d = self.dynamics
+        μ = [self.microphysical_fields[k].parent for k in ("qᵛ", "qᶜˡ", "qʳ")] if self._kessler else []
         return ([d.total_density.parent, d.pressure.parent] + [self.velocities[k].parent for k in ("u", "v", "w")] +
-                [self.potential_temperature.parent, self.specific_moisture.parent, self.temperature.parent])
+                [self.potential_temperature.parent, self.specific_moisture.parent, self.temperature.parent] + μ)
 
     def update_state_slab(self, compute_tendencies=True):
         """update_state! with the neighbour exchanges of the slab decomposition.  The diagnosis needs ρᵈ of row -1 (face
@@ -599,4 +598,8 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
         store_initial_state_(self)
         for β in (self.timestepper.β1, self.timestepper.β2, self.timestepper.β3):
             self.acoustic_rk3_substep_slab(Δt, β)
+            self.update_state_slab(compute_tendencies=True)
+        if self._kessler:      # microphysics_model_update!: rank-local columns, then the exchanging update_state!
+            self._check(self._lib.bz_compressible_kessler_update(self._ctx, C.byref(self._state), C.byref(self._G),
+                                                                 C.byref(self._sub), float(Δt)), "bz_compressible_kessler_update")
             self.update_state_slab(compute_tendencies=True)

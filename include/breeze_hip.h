@@ -378,7 +378,8 @@ int bz_kessler_model_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
  * condensates (compressible_time_stepping.jl:83-103 with condensate_field_names), the Newton temperature inversion carries the
  * latent term, gamma R_m of the linearisation includes the liquid fraction, the species ride the time-averaged transport
  * velocities and the WS-RK3 scalar update, and bz_time_step_compressible ends with the column update (density = rho_d,
- * pressure = dynamics.pressure) + update_state! (acoustic_runge_kutta_3.jl:315-316). */
+ * pressure = dynamics.pressure) + update_state! (acoustic_runge_kutta_3.jl:315-316).  On a y-slab context
+ * (bz_create_compressible_slab) the call runs the rank-local column kernel only and the driver's exchanging update_state! follows. */
 int bz_compressible_kessler_update(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
                                    const bz_acoustic_substepper *sub, double dt);
 

@@ -147,7 +147,8 @@ def make_threaded_decomposition(bz_dist, mailbox, *args, **kw):
     return ThreadedDecomposition(*args, **kw)
 
 
-def make_oracle_compressible_slab(orc, oc, bz_dist, size, extent, rank, world, td=None, theta_ref=300.0, group=None, decomp=None):
+def make_oracle_compressible_slab(orc, oc, bz_dist, size, extent, rank, world, td=None, theta_ref=300.0, group=None, decomp=None,
+                                  microphysics=None):
     """CompressibleOracleModel on the y-slab of `rank`: every halo fill of the oracle (x wrap + z boundary) is followed by
     the product's SlabDecomposition.exchange_y_halos, so the oracle's own sequence of fills defines the exchange points."""
     import torch
@@ -167,4 +168,5 @@ def make_oracle_compressible_slab(orc, oc, bz_dist, size, extent, rank, world, t
             super()._halo_w(f)
             d.exchange_y_halos([torch.from_numpy(f)])
 
-    return OracleCompressibleSlab(grid, time_discretization=td or oc.SplitExplicit(substeps=6), reference_potential_temperature=theta_ref)
+    return OracleCompressibleSlab(grid, time_discretization=td or oc.SplitExplicit(substeps=6), reference_potential_temperature=theta_ref,
+                                  microphysics=microphysics)

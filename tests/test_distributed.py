@@ -150,7 +150,16 @@ def cmp_qv(x, y, z):
     return 4e-3 * np.exp(-z / 2e3) * (1 + 0.2 * np.sin(2 * np.pi * y / 20e3)) + 0 * x
 
 
-def _cmp_worker(rank, world, port, size, steps, dt, out):
+def cmp_qcl(x, y, z):
+    r = np.sqrt(x ** 2 + (y - 1500.0) ** 2 + (z - 3000.0) ** 2)
+    return 2e-3 * np.maximum(0.0, 1.0 - r / 2.5e3)
+
+
+def cmp_qr(x, y, z):
+    return 0.4 * cmp_qcl(x, y + 2500.0, z)
+
+
+def _cmp_worker(rank, world, port, size, steps, dt, out, microphysics=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -163,14 +172,18 @@ def _cmp_worker(rank, world, port, size, steps, dt, out):
     import dist_backends
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        m = dist_backends.make_oracle_compressible_slab(orc, oc, bz_dist, size, EXTENT, rank, world)
+        m = dist_backends.make_oracle_compressible_slab(orc, oc, bz_dist, size, EXTENT, rank, world, microphysics=microphysics)
         g = m.grid
         rho = m.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
-        m.set(rho=rho, theta=cmp_theta, u=3.0, v=-2.0, w=0.0, qv=cmp_qv)
+        ic = dict(rho=rho, theta=cmp_theta, u=3.0, v=-2.0, w=0.0, qv=cmp_qv)
+        if microphysics:
+            ic.update(qcl=cmp_qcl, qr=cmp_qr)
+        m.set(**ic)
         for _ in range(steps):
             m.time_step(dt)
         pieces = {}
-        for n in ("rho_d", "ru", "rv", "rw", "rtheta", "rq", "T", "p"):
+        names = ("rho_d", "ru", "rv", "rw", "rtheta", "rq", "T", "p") + (("rqcl", "rqr", "W") if microphysics else ())
+        for n in names:
             loc = torch.from_numpy(np.ascontiguousarray(g.interior(getattr(m, n), n == "rw")))
             gathered = [torch.empty_like(loc) for _ in range(world)] if rank == 0 else None
             dist.gather(loc, gathered, dst=0)
@@ -178,8 +191,9 @@ def _cmp_worker(rank, world, port, size, steps, dt, out):
                 pieces[n] = torch.cat(gathered, dim=1).numpy()
         if rank == 0:
             G = orc.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
-            ref = oc.CompressibleOracleModel(G, time_discretization=oc.SplitExplicit(substeps=6), reference_potential_temperature=300.0)
-            ref.set(rho=rho, theta=cmp_theta, u=3.0, v=-2.0, w=0.0, qv=cmp_qv)
+            ref = oc.CompressibleOracleModel(G, time_discretization=oc.SplitExplicit(substeps=6), reference_potential_temperature=300.0,
+                                             microphysics=microphysics)
+            ref.set(**ic)
             for _ in range(steps):
                 ref.time_step(dt)
             errs = []
@@ -203,9 +217,20 @@ def test_compressible_slab_steps_match_single_process_oracle(world, size, tmp_pa
     assert errs.max() < 1e-12, errs
 
 
+def test_compressible_kessler_slab_steps_match_single_process_oracle(tmp_path):
+    """BASELINE configs[4] physics (CompressibleDynamics + DCMIP2016 Kessler) on two y-slabs: species halos ride the same
+    exchanges, the column update is rank-local."""
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    out = str(tmp_path / "errs.npy")
+    mp.spawn(_cmp_worker, args=(2, port, (12, 16, 10), 2, 2.0, out, "Kessler"), nprocs=2, join=True)
+    errs = np.load(out)
+    assert errs.max() < 1e-12, errs
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, world):
+@pytest.mark.parametrize("world,kessler", [(1, False), (2, False), (4, False), (2, True), (4, True)])
+def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, world, kessler):
     """SlabCompressibleModel (bz_create_compressible_slab, stage begin / substep / end with the per-substep exchange of
     (rho theta)' and (rho v)') against the single-GPU whole-step seam; `world` ranks share cuda:0 through a mailbox."""
     import torch
@@ -218,10 +243,17 @@ def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, worl
     def dynamics():
         return bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), reference_potential_temperature=300.0)
 
-    ref = bz.CompressibleAtmosphereModel(G, dynamics(), advection=bz.WENO())
+    mkw = {}
+    if kessler:      # the physics of BASELINE configs[4]
+        mkw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
+                   microphysics=bz.DCMIP2016KesslerMicrophysics())
+    ref = bz.CompressibleAtmosphereModel(G, dynamics(), advection=bz.WENO(), **mkw)
     Hz, Nz = G.Hz, G.Nz
     rho = ref.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
-    ref.set(ρ=rho, θ=cmp_theta, u=3.0, v=-2.0, w=0.0, qᵗ=cmp_qv)
+    ic = dict(ρ=rho, θ=cmp_theta, u=3.0, v=-2.0, w=0.0, qᵗ=cmp_qv)
+    if kessler:
+        ic.update(qcl=cmp_qcl, qr=cmp_qr)
+    ref.set(**ic)
     for _ in range(steps):
         ref.time_step(dt)
     ref.synchronize()
@@ -233,8 +265,9 @@ def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, worl
         try:
             torch.cuda.set_device(0)
             decomp = dist_backends.make_threaded_decomposition(bz_dist, mb, size[0], size[1] // world, size[2], 3, rank, world)
-            m = bz.compressible.SlabCompressibleModel(G, rank, world, dynamics(), advection=bz.WENO(), device="cuda:0", decomp=decomp)
-            m.set(ρ=rho, θ=cmp_theta, u=3.0, v=-2.0, w=0.0, qᵗ=cmp_qv)
+            m = bz.compressible.SlabCompressibleModel(G, rank, world, dynamics(), advection=bz.WENO(), device="cuda:0", decomp=decomp,
+                                                      **mkw)
+            m.set(**ic)
             for _ in range(steps):
                 m.time_step(dt)
             m.synchronize()
@@ -254,6 +287,9 @@ def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, worl
                "ρw": lambda m: m.momentum["ρw"], "ρθ": lambda m: m.potential_temperature_density,
                "ρq": lambda m: m.moisture_density, "T": lambda m: m.temperature, "p": lambda m: m.dynamics.pressure,
                "w̄": lambda m: m.timestepper.substepper.time_averaged_w}
+    if kessler:
+        for key in ("ρqᶜˡ", "ρqʳ", "qᶜˡ", "𝕎ʳ"):
+            getters[key] = lambda m, key=key: m.microphysical_fields[key]
     mom = max(np.abs(getters[k](ref).interior_cpu()).max() for k in ("ρu", "ρv", "ρw"))
     for name, getter in getters.items():
         got = np.concatenate([getter(m).interior_cpu() for m in models], axis=1)

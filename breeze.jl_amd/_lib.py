@@ -57,6 +57,10 @@ class bz_saturation_adjustment(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class bz_smagorinsky_lilly(C.Structure):
+    _fields_ = [("smagorinsky_coefficient", C.c_double), ("reduction_factor", C.c_double), ("prandtl_number", C.c_double)]
+
+
 class bz_column_forcings(C.Structure):
     _fields_ = [("u_forcing", _dp), ("v_forcing", _dp), ("theta_forcing", _dp), ("moisture_forcing", _dp),
                 ("energy_forcing", _dp), ("subsidence_vertical_velocity", _dp),
@@ -186,6 +190,8 @@ SYMBOLS = {
                                               C.c_double]),
     "bz_kessler_model_update": (C.c_int, [_ctx, _sp, _pp, C.c_double]),
     "bz_compressible_kessler_update": (C.c_int, [_ctx, _csp, _cpp, _asp, C.c_double]),
+    "bz_set_closure": (C.c_int, [_ctx, C.POINTER(bz_smagorinsky_lilly), C.c_void_p]),
+    "bz_compute_closure_fields": (C.c_int, [_ctx, _sp]),
     "bz_set_forcings": (C.c_int, [_ctx, C.POINTER(bz_column_forcings)]),
     "bz_compute_forcings": (C.c_int, [_ctx, _sp]),
     "bz_compute_flux_bc_tendencies": (C.c_int, [_ctx, _sp, _pp]),

@@ -1,0 +1,240 @@
+// bz_closure.hip — closure = SmagorinskyLilly() on the anelastic potential-temperature model (BASELINE configs[2]).
+//   Breeze side (followed line by line):
+//     dynamic stresses T_ij = rho x viscous flux, scalar fluxes J = rho x diffusive flux
+//                                           /root/reference/src/TurbulenceClosures/TurbulenceClosures.jl:44-101
+//     - d_j T_1j, - d_j T_2j, - d_j T_3j    /root/reference/src/AtmosphereModels/dynamics_kernel_functions.jl:80,100,128
+//     - div J for theta, moisture           /root/reference/src/PotentialTemperatureFormulations/potential_temperature_tendency.jl:102,
+//                                           /root/reference/src/AtmosphereModels/dynamics_kernel_functions.jl:157
+//     N^2 = g dz(log theta_v)               /root/reference/src/AtmosphereModels/atmosphere_model_buoyancy.jl:46-68
+//     compute_closure_fields!               /root/reference/src/AtmosphereModels/update_atmosphere_model_state.jl:218
+//   Oceananigans side (0.110.14, Project.toml:43, not vendored; restated from its published Smagorinsky-Lilly form — DESIGN.md,
+//   "parity unpinned"): nu_e = varsigma (C_s Delta)^2 sqrt(2 Sigma^2), varsigma = sqrt(1 - min(1, C_b N^2+/Sigma^2)),
+//   viscous flux_ij = -2 nu Sigma_ij with nu averaged to the flux location, diffusive flux = -(nu/Pr) grad c.
+// Two kernels: the eddy viscosity (one centre array), then one pass that adds the five divergences to the tendencies.  Every
+// flux is recomputed by the two cells that share it instead of being stored: 9 stress + 6 scalar-flux arrays would cost
+// 30 words/cell of traffic, the recomputation reads u, v, w, nu, theta, q through L2 (7 words/cell) and is arithmetic otherwise.
+#include "bz_internal.h"
+
+struct ClosureFields {
+    const double *u, *v, *w, *nu, *theta, *q;
+    double C2, Cb, Pr;
+};
+
+// strain components; (i, j, k) may sit one cell outside the interior in x / y (u, v, w carry periodic halos there)
+__device__ __forceinline__ double S11(const DevGrid &g, const double *u, long long n) { return (u[n + 1] - u[n]) * g.rdx; }
+__device__ __forceinline__ double S22(const DevGrid &g, const double *v, long long n) { return (v[n + g.Sx] - v[n]) * g.rdy; }
+__device__ __forceinline__ double S33(const DevGrid &g, const double *w, long long n, int k) { return (w[n + g.Sxy] - w[n]) * g.rdzc[k]; }
+__device__ __forceinline__ double S12(const DevGrid &g, const double *u, const double *v, long long n)
+{
+    return ((u[n] - u[n - g.Sx]) * g.rdy + (v[n] - v[n - 1]) * g.rdx) * 0.5;
+}
+// at (x face i, z face k): zero on the walls (u has no-flux z halos there, w = 0)
+__device__ __forceinline__ double S13(const DevGrid &g, const double *u, const double *w, long long n, int k)
+{
+    if (k <= 0 || k >= g.Nz) return 0.0;
+    return ((u[n] - u[n - g.Sxy]) * g.rdzf[k] + (w[n] - w[n - 1]) * g.rdx) * 0.5;
+}
+__device__ __forceinline__ double S23(const DevGrid &g, const double *v, const double *w, long long n, int k)
+{
+    if (k <= 0 || k >= g.Nz) return 0.0;
+    return ((v[n] - v[n - g.Sxy]) * g.rdzf[k] + (w[n] - w[n - g.Sx]) * g.rdy) * 0.5;
+}
+
+// XCD-aware block order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2); give every
+// XCD a contiguous slab of (row, level) space so that the j +- 1 / k +- 1 neighbour rows of a block are hits in its own L2
+__device__ __forceinline__ void xcd_block(int &bx, int &by, int &bz)
+{
+    const int nb = gridDim.x * gridDim.y * gridDim.z;
+    int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (nb % 8 == 0) b = (b % 8) * (nb / 8) + b / 8;
+    bx = b % gridDim.x;
+    by = (b / gridDim.x) % gridDim.y;
+    bz = b / (gridDim.x * gridDim.y);
+}
+
+// ipi[k] = (pst / p_r[k])^(Rd/cpd), k = -1 .. Nz (k_inverse_exner_column): the only pow of the buoyancy gradient depends on k alone
+__device__ __forceinline__ double log_theta_v(const DevGrid &g, const double *ipi, const double *T, const double *qv, long long n, int k)
+{
+    const double q = qv[n];
+    const double Rm = (1.0 - (q + 0.0 + 0.0)) * g.Rd + q * g.Rv;
+    return log(Rm / g.Rd * T[n] * ipi[k]);
+}
+
+__global__ void k_inverse_exner_column(DevGrid g, double *ipi)
+{
+    for (int k = (int)threadIdx.x - 1; k <= g.Nz; k += blockDim.x) ipi[k] = pow(g.pst / g.p_r[k], g.Rd / g.cpd);
+}
+
+__global__ __launch_bounds__(256) void k_smagorinsky_viscosity(DevGrid g, ClosureFields F, const double *__restrict__ T,
+                                                               const double *__restrict__ qv, const double *__restrict__ ipi,
+                                                               double *__restrict__ nu)
+{
+    int bx, by, bz;
+    xcd_block(bx, by, bz);
+    const int i = bx * 256 + threadIdx.x, j = by, k = bz;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k), sx = 1, sy = g.Sx, sz = g.Sxy;
+    const double *u = F.u, *v = F.v, *w = F.w;
+    const double s11 = S11(g, u, n), s22 = S22(g, v, n), s33 = S33(g, w, n, k);
+    auto sq = [](double a) { return a * a; };
+    const double a12 = ((sq(S12(g, u, v, n)) + sq(S12(g, u, v, n + sx))) / 2 +
+                        (sq(S12(g, u, v, n + sy)) + sq(S12(g, u, v, n + sy + sx))) / 2) / 2;
+    const double a13 = ((sq(S13(g, u, w, n, k)) + sq(S13(g, u, w, n + sx, k))) / 2 +
+                        (sq(S13(g, u, w, n + sz, k + 1)) + sq(S13(g, u, w, n + sz + sx, k + 1))) / 2) / 2;
+    const double a23 = ((sq(S23(g, v, w, n, k)) + sq(S23(g, v, w, n + sy, k))) / 2 +
+                        (sq(S23(g, v, w, n + sz, k + 1)) + sq(S23(g, v, w, n + sz + sy, k + 1))) / 2) / 2;
+    const double Sig2 = (s11 * s11 + s22 * s22 + s33 * s33) + 2 * a12 + 2 * a13 + 2 * a23;
+    // N^2: T, q^v carry no-flux z halos, the reference pressure column its own first halo cell
+    const double lm = log_theta_v(g, ipi, T, qv, n - sz, k - 1), lc = log_theta_v(g, ipi, T, qv, n, k), lp = log_theta_v(g, ipi, T, qv, n + sz, k + 1);
+    const double bdn = g.g * ((lc - lm) * g.rdzf[k]), bup = g.g * ((lp - lc) * g.rdzf[k + 1]);
+    const double N2 = (bdn + bup) / 2;
+    const double N2p = fmax(0.0, N2);
+    const double stab = (Sig2 == 0.0) ? 0.0 : sqrt(1.0 - fmin(1.0, F.Cb * N2p / Sig2));
+    const double delta = cbrt(g.dx * g.dy * g.dzc[k]);
+    nu[n] = (stab * F.C2) * (delta * delta) * sqrt(2 * Sig2);
+}
+
+__global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFields F, double *__restrict__ Gu,
+                                                            double *__restrict__ Gv, double *__restrict__ Gw,
+                                                            double *__restrict__ Gth, double *__restrict__ Gq, double scale)
+{
+    int bx, by, bz;
+    xcd_block(bx, by, bz);
+    const int i = bx * 256 + threadIdx.x, j = by, k = bz;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k), sx = 1, sy = g.Sx, sz = g.Sxy;
+    const double *u = F.u, *v = F.v, *w = F.w, *nu = F.nu;
+    const double dx = g.dx, dy = g.dy, dz = g.dzc[k];
+    const double rVc = g.rdx * g.rdy * g.rdzc[k];
+    const double rho = g.rho[k];
+    const double Ax = dy * dz, Ay = dx * dz, Az = dx * dy;
+    // eddy viscosity of the 3 x 3 x 3 neighbourhood that the flux locations of this cell touch
+    double nun[3][3][3];      // [dk+1][dj+1][di+1]; the 8 corners are never used
+    {
+        const long long oi[3] = {(i == 0) ? (long long)(g.Nx - 1) : -1, 0, (i == g.Nx - 1) ? -(long long)(g.Nx - 1) : 1};
+        const long long oj[3] = {((j == 0) ? (long long)(g.Ny - 1) : -1) * sy, 0, ((j == g.Ny - 1) ? -(long long)(g.Ny - 1) : 1) * sy};
+        const long long ok[3] = {(k == 0) ? 0 : -sz, 0, (k == g.Nz - 1) ? 0 : sz};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    nun[c][b][a] = ((a != 1) + (b != 1) + (c != 1) == 3) ? 0.0 : nu[n + ok[c] + oj[b] + oi[a]];
+    }
+    auto NU = [&](int di, int dj, int dk) { return nun[dk + 1][dj + 1][di + 1]; };
+    auto nu_ffc = [&](int di, int dj) {      // corner (i + di, j + dj) at level k
+        return ((NU(di - 1, dj - 1, 0) + NU(di, dj - 1, 0)) / 2 + (NU(di - 1, dj, 0) + NU(di, dj, 0)) / 2) / 2;
+    };
+    auto nu_fcf = [&](int di, int dk) {      // x face i + di, z face k + dk, row j
+        return ((NU(di - 1, 0, dk - 1) + NU(di, 0, dk - 1)) / 2 + (NU(di - 1, 0, dk) + NU(di, 0, dk)) / 2) / 2;
+    };
+    auto nu_cff = [&](int dj, int dk) {      // y face j + dj, z face k + dk, column i
+        return ((NU(0, dj - 1, dk - 1) + NU(0, dj, dk - 1)) / 2 + (NU(0, dj - 1, dk) + NU(0, dj, dk)) / 2) / 2;
+    };
+    auto T11 = [&](int di) { return rho * (-2 * NU(di, 0, 0) * S11(g, u, n + di * sx)); };
+    auto T22 = [&](int dj) { return rho * (-2 * NU(0, dj, 0) * S22(g, v, n + dj * sy)); };
+    auto T33 = [&](int dk) { return g.rho[k + dk] * (-2 * NU(0, 0, dk) * S33(g, w, n + dk * sz, k + dk)); };
+    auto T12 = [&](int di, int dj) { return rho * (-2 * nu_ffc(di, dj) * S12(g, u, v, n + di * sx + dj * sy)); };
+    auto T13 = [&](int di, int dk) { return g.rho_f[k + dk] * (-2 * nu_fcf(di, dk) * S13(g, u, w, n + di * sx + dk * sz, k + dk)); };
+    auto T23 = [&](int dj, int dk) { return g.rho_f[k + dk] * (-2 * nu_cff(dj, dk) * S23(g, v, w, n + dj * sy + dk * sz, k + dk)); };
+
+    const double t12_00 = T12(0, 0), t13_00 = T13(0, 0), t23_00 = T23(0, 0);
+    {   // x momentum at face i
+        const double div = (Ax * T11(0) - Ax * T11(-1)) + (Ay * T12(0, 1) - Ay * t12_00) + (Az * T13(0, 1) - Az * t13_00);
+        Gu[n] -= scale * (div * rVc);
+    }
+    {   // y momentum at face j
+        const double div = (Ax * T12(1, 0) - Ax * t12_00) + (Ay * T22(0) - Ay * T22(-1)) + (Az * T23(0, 1) - Az * t23_00);
+        Gv[n] -= scale * (div * rVc);
+    }
+    if (k >= 1) {   // z momentum at the interior face k (between centres k-1 and k)
+        const double dzf = g.dzf[k];
+        const double Axf = dy * dzf, Ayf = dx * dzf;
+        const double div = (Axf * T13(1, 0) - Axf * t13_00) + (Ayf * T23(1, 0) - Ayf * t23_00) + (Az * T33(0) - Az * T33(-1));
+        Gw[n] -= scale * (div * (g.rdx * g.rdy * g.rdzf[k]));
+    }
+    // scalars: J = rho x (-(nu / Pr) grad c) on the six faces of the cell
+    const double rPr = 1.0 / F.Pr;
+    const double kc = NU(0, 0, 0) * rPr;
+    const double kxm = (NU(-1, 0, 0) * rPr + kc) / 2, kxp = (kc + NU(1, 0, 0) * rPr) / 2;
+    const double kym = (NU(0, -1, 0) * rPr + kc) / 2, kyp = (kc + NU(0, 1, 0) * rPr) / 2;
+    const double kzm = (NU(0, 0, -1) * rPr + kc) / 2, kzp = (kc + NU(0, 0, 1) * rPr) / 2;
+    const double rfm = g.rho_f[k], rfp = g.rho_f[k + 1];
+    const double rdzfm = g.rdzf[k], rdzfp = g.rdzf[k + 1];
+    auto scalar = [&](const double *c, double *G) {
+        const double c0 = c[n];
+        const double Jxm = rho * (-kxm * ((c0 - c[n - sx]) * g.rdx)), Jxp = rho * (-kxp * ((c[n + sx] - c0) * g.rdx));
+        const double Jym = rho * (-kym * ((c0 - c[n - sy]) * g.rdy)), Jyp = rho * (-kyp * ((c[n + sy] - c0) * g.rdy));
+        const double Jzm = (k == 0) ? 0.0 : rfm * (-kzm * ((c0 - c[n - sz]) * rdzfm));
+        const double Jzp = (k == g.Nz - 1) ? 0.0 : rfp * (-kzp * ((c[n + sz] - c0) * rdzfp));
+        const double div = (Ax * Jxp - Ax * Jxm) + (Ay * Jyp - Ay * Jym) + (Az * Jzp - Az * Jzm);
+        G[n] -= scale * (div * rVc);
+    };
+    scalar(F.theta, Gth);
+    scalar(F.q, Gq);
+}
+
+extern "C" int bz_set_closure(bz_ctx *ctx, const bz_smagorinsky_lilly *closure, double *eddy_viscosity)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    if (!closure) { ctx->has_closure = false; ctx->closure_nu = nullptr; return BZ_OK; }
+    if (!eddy_viscosity) return BZ_ERR_INVALID;
+    if (ctx->compressible || ctx->slab_mode || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {
+        ctx->last_error = "bz_set_closure: SmagorinskyLilly is implemented for the single-device anelastic "
+                          "potential-temperature model (microphysics nothing or SaturationAdjustment)";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    if (ctx->dg.Hx < 1 || ctx->dg.Hy < 1 || ctx->dg.Hz < 1) { ctx->last_error = "bz_set_closure: needs halos >= 1"; return BZ_ERR_UNSUPPORTED; }
+    ctx->closure = *closure;
+    ctx->closure_nu = eddy_viscosity;
+    if (!ctx->d_closure_ipi) BZ_HIP(hipMalloc(&ctx->d_closure_ipi, (size_t)(ctx->dg.Nz + 2) * sizeof(double)));
+    hipLaunchKernelGGL(k_inverse_exner_column, dim3(1), dim3(256), 0, ctx->stream, ctx->dg, ctx->d_closure_ipi + 1);
+    BZ_LAUNCH_CHECK();
+    ctx->has_closure = true;
+    return BZ_OK;
+}
+
+static ClosureFields closure_fields(bz_ctx *ctx, const bz_state *s)
+{
+    ClosureFields F;
+    F.u = s->u; F.v = s->v; F.w = s->w; F.nu = ctx->closure_nu; F.theta = s->theta; F.q = s->q;
+    F.C2 = ctx->closure.smagorinsky_coefficient * ctx->closure.smagorinsky_coefficient;
+    F.Cb = ctx->closure.reduction_factor;
+    F.Pr = ctx->closure.prandtl_number;
+    return F;
+}
+
+// compute_closure_fields!(model.closure_fields, model.closure, model): nu_e on the interior
+extern "C" int bz_compute_closure_fields(bz_ctx *ctx, const bz_state *s)
+{
+    if (!ctx || !s) return BZ_ERR_INVALID;
+    if (!ctx->has_closure) return BZ_OK;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "smagorinsky_viscosity");
+    const double *qv = (g.microphysics == 1) ? g.qv_field : s->q;      // specific_humidity(model)
+    hipLaunchKernelGGL(k_smagorinsky_viscosity, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
+                       closure_fields(ctx, s), s->T, qv, ctx->d_closure_ipi + 1, ctx->closure_nu);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// closure terms of compute_tendencies!; scale = 1 subtracts the divergences from tendencies, the whole-step seam passes
+// alpha dt and the arrays its fused RK update just wrote (see bzi_apply_forcings)
+void bzi_closure_teardown(bz_ctx *ctx)
+{
+    if (ctx->d_closure_ipi) hipFree(ctx->d_closure_ipi);
+    ctx->d_closure_ipi = nullptr;
+}
+
+int bzi_apply_closure(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gw, double *Gth, double *Gq, double scale)
+{
+    int rc = bz_compute_closure_fields(ctx, s);
+    if (rc) return rc;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "closure_tendencies");
+    hipLaunchKernelGGL(k_closure_tendencies, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
+                       closure_fields(ctx, s), Gu, Gv, Gw, Gth, Gq, scale);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}

@@ -262,6 +262,7 @@ extern "C" void bz_destroy(bz_ctx *ctx)
     bzi_compressible_teardown(ctx);
     if (ctx->d_columns) hipFree(ctx->d_columns);
     bzi_forcing_teardown(ctx);
+    bzi_closure_teardown(ctx);
     if (ctx->d_scalar) hipFree(ctx->d_scalar);
     delete ctx;
 }

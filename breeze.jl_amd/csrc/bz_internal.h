@@ -192,6 +192,11 @@ struct bz_ctx {
     double *d_forcing = nullptr;      // static profiles, subsidence velocity, level averages, subsidence profiles, partial sums
     int forcing_static_mask = 0, forcing_subsidence_mask = 0;
     double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0;
+    // closure = SmagorinskyLilly() (bz_set_closure, bz_closure.hip)
+    bool has_closure = false;
+    bz_smagorinsky_lilly closure;
+    double *closure_nu = nullptr;     // model.closure_fields.nu_e (caller-owned centre field)
+    double *d_closure_ipi = nullptr;  // (pst/p_r[k])^(Rd/cpd), k = -1 .. Nz
     double *up2_user = nullptr, *vp2_user = nullptr;   // caller-owned replacements of d_up2 / d_vp2 (bz_set_acoustic_scratch)
     alignas(8) unsigned char ac_stage_storage[160] = {0};   // AcStage of the stage in flight (bz_compressible.hip)
     // profiling
@@ -240,6 +245,8 @@ int bzi_fill_halo(bz_ctx *ctx, double *f, int kind);
 int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale);
 int bzi_flux_bc(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale);
 void bzi_forcing_teardown(bz_ctx *ctx);
+void bzi_closure_teardown(bz_ctx *ctx);
+int bzi_apply_closure(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gw, double *Gth, double *Gq, double scale);
 int bzi_kessler_tendencies(bz_ctx *ctx, const bz_state *s);
 int bzi_kessler_rk3(bz_ctx *ctx, double dt, double alpha, bool first);
 int bzi_kessler_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt);

@@ -44,6 +44,8 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
         for (int stage = 0; stage < 3; ++stage) {
             const double alpha = alphas[stage];
             if ((rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+            if (ctx->has_closure &&
+                (rc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, s->rho_theta, s->rho_q, alpha * dt))) return rc;
             if (ctx->has_forcings) {
                 // forcing, Coriolis and bottom fluxes of the stage, evaluated from the still-intact previous-stage state and
                 // added to what the fused RK update just wrote, weighted alpha dt

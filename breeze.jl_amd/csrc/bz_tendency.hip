@@ -360,6 +360,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
         hipLaunchKernelGGL(k_energy_buoyancy_flux, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
                            G->rho_theta, s->w, s->T, s->q);
     }
+    if (ctx->has_closure) {
+        int rcc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, 1.0);
+        if (rcc) return rcc;
+    }
     if (ctx->has_forcings) {
         int rcf = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0);
         if (rcf) return rcf;

@@ -16,6 +16,13 @@ import numpy as np
 from . import _lib
 
 
+class SmagorinskyLilly:
+    """SmagorinskyLilly(; C = 0.16, Cb = 1.0, Pr = 1.0) (Oceananigans.TurbulenceClosures, re-exported src/Breeze.jl:186,220)."""
+
+    def __init__(self, C=0.16, Cb=1.0, Pr=1.0):
+        self.C, self.Cb, self.Pr = float(C), float(Cb), float(Pr)
+
+
 class FPlane:
     """FPlane(f=...) (Oceananigans.Coriolis)."""
 

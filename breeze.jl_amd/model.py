@@ -112,8 +112,10 @@ class AtmosphereModel:
         self.formulation = formulation
         if timestepper not in ("SSPRungeKutta3", ":SSPRungeKutta3"):
             raise NotImplementedError("only SSPRungeKutta3 is implemented")
-        if closure is not None:
-            raise NotImplementedError("closure is outside the hot-path scope of this build")
+        from .forcings import SmagorinskyLilly
+        if closure is not None and not isinstance(closure, SmagorinskyLilly):
+            raise NotImplementedError("closure: SmagorinskyLilly() is implemented")
+        self.closure = closure
         self.coriolis, self.forcing, self.boundary_conditions = coriolis, forcing, boundary_conditions
         from .microphysics import DCMIP2016KesslerMicrophysics, SaturationAdjustment, TetensFormula
         if microphysics is not None and not isinstance(microphysics, (SaturationAdjustment, DCMIP2016KesslerMicrophysics)):
@@ -217,6 +219,13 @@ class AtmosphereModel:
                                                          C.c_void_p(self.microphysical_fields["qᵛ"].ptr()),
                                                          C.c_void_p(self.microphysical_fields["qˡ"].ptr())),
                         "bz_set_saturation_adjustment")
+        self.closure_fields = {}
+        if closure is not None:      # build_closure_fields: nu_e (atmosphere_model.jl:276)
+            if self._kessler or formulation != "LiquidIcePotentialTemperature":
+                raise NotImplementedError("SmagorinskyLilly is implemented for the potential-temperature formulation without Kessler")
+            self.closure_fields = {"νₑ": fld("ccc")}
+            cl = _lib.bz_smagorinsky_lilly(closure.C, closure.Cb, closure.Pr)
+            self._check(lib.bz_set_closure(self._ctx, C.byref(cl), C.c_void_p(self.closure_fields["νₑ"].ptr())), "bz_set_closure")
         # coriolis / forcing / boundary_conditions of the BOMEX configuration -> one column-forcing stack (forcings.py)
         from .forcings import materialize_forcings
         F, self._forcing_keepalive = materialize_forcings(grid, coriolis, forcing, boundary_conditions)
@@ -315,6 +324,11 @@ def update_state_(model, compute_tendencies=True):
 def compute_tendencies_(model):
     model._check(model._lib.bz_compute_tendencies(model._ctx, C.byref(model._state), C.byref(model._G)),
                  "bz_compute_tendencies")
+
+
+def compute_closure_fields_(model):
+    """compute_closure_fields!(model.closure_fields, model.closure, model) (update_atmosphere_model_state.jl:218)."""
+    model._check(model._lib.bz_compute_closure_fields(model._ctx, C.byref(model._state)), "bz_compute_closure_fields")
 
 
 def compute_flux_bc_tendencies_(model):

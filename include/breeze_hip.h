@@ -417,6 +417,23 @@ int bz_compute_forcings(bz_ctx *ctx, const bz_state *s);
 /* compute_flux_bc_tendencies!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:418-434) */
 int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 
+/* ---- closure = SmagorinskyLilly() (BASELINE configs[2]) ----
+ * Breeze's part — density-weighted stress and flux divergences (src/TurbulenceClosures/TurbulenceClosures.jl:44-101), their place
+ * in the tendencies (src/AtmosphereModels/dynamics_kernel_functions.jl:80,100,128,157), N^2 = g dz(log theta_v)
+ * (src/AtmosphereModels/atmosphere_model_buoyancy.jl:46-68) and compute_closure_fields! at the end of
+ * compute_auxiliary_variables! (src/AtmosphereModels/update_atmosphere_model_state.jl:218) — is followed line by line; the eddy
+ * viscosity and kinematic fluxes are Oceananigans' SmagorinskyLilly (0.110.14, not vendored), restated from its published form
+ * (oracle/closure.py: parity unpinned).  eddy_viscosity is model.closure_fields.nu_e (centre field parent, caller-owned).
+ * With a closure attached bz_compute_tendencies subtracts the divergences after the advective terms.  Single-device anelastic
+ * potential-temperature contexts only. */
+typedef struct bz_smagorinsky_lilly {
+    double smagorinsky_coefficient;   /* C  = 0.16 */
+    double reduction_factor;          /* Cb = 1.0: varsigma = sqrt(1 - min(1, Cb N^2+ / Sigma^2)) */
+    double prandtl_number;            /* Pr = 1.0 (every scalar) */
+} bz_smagorinsky_lilly;
+int bz_set_closure(bz_ctx *ctx, const bz_smagorinsky_lilly *closure, double *eddy_viscosity);   /* NULL detaches */
+int bz_compute_closure_fields(bz_ctx *ctx, const bz_state *s);
+
 /* ---- the reductions of the run! loop around the step ---- */
 /* cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): minimum over the interior of
  * 1 / (|u|/dx + |v|/dy + |w|/dz) into *out (host; +Inf for a fluid at rest); w == NULL gives the HorizontalFormulation.

@@ -256,7 +256,7 @@ class OracleModel:
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
                  standard_pressure=1e5, reference_density=None, initialize=True,
                  formulation="LiquidIcePotentialTemperature", microphysics=None, sa_abstol=1e-4, sa_maxiter=20,
-                 forcings=None):
+                 forcings=None, closure=None):
         # formulation "StaticEnergy": self.theta holds e, self.rtheta holds rho*e
         # (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21)
         assert formulation in ("LiquidIcePotentialTemperature", "StaticEnergy")
@@ -267,6 +267,8 @@ class OracleModel:
         assert not (microphysics and formulation == "StaticEnergy"), "oracle: saturation adjustment with theta only"
         self.microphysics = microphysics
         self.forcings = forcings           # oracle.forcings.ColumnForcings (BOMEX forcing stack) or None
+        self.closure = closure             # oracle.closure.SmagorinskyLilly or None
+        assert not (closure and (formulation == "StaticEnergy" or microphysics == "Kessler"))
         assert not (forcings and (formulation == "StaticEnergy" or microphysics == "Kessler"))
         self.grid = g = grid
         self.constants = c = constants or Constants()
@@ -455,6 +457,9 @@ class OracleModel:
             self.lib.og_compute_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.rtheta), _p(self.rq))
         for f in (self.T, self.q, self.theta):
             self._halo_center(f)
+        if self.closure is not None:       # compute_closure_fields! closes compute_auxiliary_variables! (:218)
+            from .closure import compute_closure_fields
+            compute_closure_fields(self)
         if self.forcings is not None:
             from .forcings import compute_forcings
             compute_forcings(self)
@@ -478,6 +483,9 @@ class OracleModel:
         L.og_scalar_tendency(cg, _p(G["rq"]), _p(self.u), _p(self.v), _p(self.w), _p(self.q))
         if self.formulation == "StaticEnergy":
             L.og_energy_buoyancy_flux(cg, _p(G["rtheta"]), _p(self.w), _p(self.T), _p(self.q))
+        if self.closure is not None:
+            from .closure import add_closure_tendencies
+            add_closure_tendencies(self)
         if self.forcings is not None:
             from .forcings import add_forcing_tendencies
             add_forcing_tendencies(self)

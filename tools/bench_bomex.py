@@ -4,8 +4,8 @@
 Workload: 256 x 256 x 128 cells over 6.4 km x 6.4 km x 3 km (the example's 25 m x 25 m x 23.4 m... grid scaled to the config
 size), AnelasticDynamics + WENO-5 + SaturationAdjustment(WarmPhaseEquilibrium) + the example's forcing stack: f-plane Coriolis,
 geostrophic forcing, subsidence of u, v, theta, q^e (horizontal averages every stage), drying, radiative cooling through the
-energy forcing, bottom sensible / latent / drag fluxes.  No Smagorinsky closure (out of scope): this is the
-advective + moist-thermodynamic + forcing part of the configuration.  Float64.  One JSON line with per-kernel milliseconds.
+energy forcing, bottom sensible / latent / drag fluxes, and closure = SmagorinskyLilly() — the physics list of the configuration
+(WENO5 instead of the example's WENO9).  Float64.  One JSON line with per-kernel milliseconds.
 
     python tools/bench_bomex.py --size 256 256 128 --dt 2.0 --steps 10 --warmup 3 [--no-forcing]
 """
@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-forcing", action="store_true")
+    ap.add_argument("--no-closure", action="store_true")
     a = ap.parse_args()
     import torch
     import breeze_jl_amd as bz
@@ -37,6 +38,8 @@ def main():
     grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 6400.0), y=(0.0, 6400.0), z=(0.0, 3000.0))
     ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
     kw = {} if a.no_forcing else _hip_forcing_kwargs(bz, full=True)
+    if not a.no_closure:
+        kw["closure"] = bz.SmagorinskyLilly()
     m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5),
                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), **kw)
     rng = np.random.default_rng(0)
@@ -72,9 +75,9 @@ def main():
     cells = Nx * Ny * Nz
     ql = m.microphysical_fields["qˡ"].interior
     w = m.velocities["w"].interior
-    out = {"metric": "grid-cells advanced/sec, BOMEX-shaped anelastic SSP-RK3 step (WENO5 + saturation adjustment + forcing stack)",
+    out = {"metric": "grid-cells advanced/sec, BOMEX-shaped anelastic SSP-RK3 step (WENO5 + saturation adjustment + SmagorinskyLilly + forcing stack)",
            "value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": a.dt,
-           "forcing": not a.no_forcing, "dtype": "f64",
+           "forcing": not a.no_forcing, "closure": None if a.no_closure else "SmagorinskyLilly", "dtype": "f64",
            "kernels_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items())},
            "step_contract_frac_of_8TBs": cells * 2000 / (ms * 1e-3) / 8e12,
            "finite": bool(torch.isfinite(w).all().item()), "w_max": float(w.abs().max().item()),

@@ -2,9 +2,16 @@
 oracle/forcings.py — CPU restatement of the forcing / Coriolis / bottom-flux terms of the BOMEX configuration
 (BASELINE configs[2], examples/bomex.jl:80-207) for the anelastic OracleModel.  TEST INFRASTRUCTURE ONLY.
 
-PARITY STATUS: **parity unpinned** — the reference holds no golden numbers for these terms (its tests check them against
-analytic expectations only) and the Coriolis and boundary-flux arithmetic lives in Oceananigans, which is not vendored;
-it is restated from its published operators.  Breeze-side formulas are followed line by line:
+PARITY STATUS: **pinned by the reference's own known-answer tests, restated in tests/test_forcings.py** — the reference holds
+no golden arrays for these terms, its tests check closed-form expectations, and the oracle reproduces each of them:
+  test/geostrophic_subsidence_forcings.jl:296-339  one step of w_s = 1 on phi = Gamma z changes rho phi by rho_r (-dt w_s Gamma)
+                                                   in the bottom and top cells (theta, q^v, u; rtol 1e-3)
+  test/geostrophic_subsidence_forcings.jl:233-294  five steps accumulate linearly (1e-3)
+  test/geostrophic_subsidence_forcings.jl:12-38,163-187  u_g = -10: rho v < 0 after one step, alone and with subsidence
+  test/forcing_and_boundary_conditions.jl:89-128   a bottom FluxBoundaryCondition J lands as +J/dz in G[.,.,1] with the field
+                                                   dependencies taken at the boundary location
+The Coriolis and boundary-flux arithmetic itself lives in Oceananigans (not vendored) and is restated from its published
+operators; beyond those anchors the digits are unpinned.  Breeze-side formulas are followed line by line:
 
   SubsidenceForcing  F = -zb-average(w_s dz(avg phi))     src/Forcings/subsidence_forcing.jl:75-91,104-126
   geostrophic_forcings  F_u = -f v_g, F_v = +f u_g         src/Forcings/geostrophic_forcings.jl (GeostrophicForcing call)

@@ -102,7 +102,8 @@ def test_subsidence_profile_of_a_linear_mean_is_minus_w_times_slope():
 
 def test_geostrophic_balance_and_flux_bcs_in_the_oracle(oracle):
     """u = u_g, v = v_g: Coriolis and the geostrophic forcing cancel in both momentum tendencies (uniform-in-x,y flow has
-    no advective tendency); the bottom fluxes land in the first level only, as J / dz."""
+    no advective tendency); the bottom fluxes land in the first level only, as +J / dz (the reference's
+    test/forcing_and_boundary_conditions.jl:89-128 asserts exactly that for a flux function of (rho u, rho v))."""
     from oracle.forcings import ColumnForcings
     og = oracle.Grid((8, 6, 10), x=(0, 800.0), y=(0, 600.0), z=(0, 1000.0))
     zc = og.zc
@@ -140,6 +141,67 @@ def test_energy_forcing_enters_theta_as_F_over_cpm_exner(oracle):
     rho, p = r.density[g.Hz:g.Hz + g.Nz], r.pressure[g.Hz:g.Hz + g.Nz]
     want = rho * Fe / (c.cpd * (p / r.pst) ** (c.Rd / c.cpd))
     np.testing.assert_allclose(g.interior(om.G["rtheta"])[:, 1, 2], want, rtol=1e-12)
+
+
+# ---- CPU: the reference's own known-answer tests for these forcings, restated on the oracle ----------------------------------------
+
+@pytest.mark.parametrize("name", ["theta", "q", "u"])
+def test_reference_subsidence_constant_gradient_known_answer(oracle, name):
+    """test/geostrophic_subsidence_forcings.jl:296-339 ("Subsidence forcing gradient"): w_s = 1, phi = Gamma z, one step of
+    dt = 1e-2 changes rho phi by rho_r (-dt w_s Gamma) in the bottom and in the top cell (rtol 1e-3) — the one-sided ends of the
+    zb-average.  The reference runs it with advection = nothing; the oracle always advects, so phi rides on a resting,
+    nearly neutral column (theta0 + Gamma z), where the advective change over one step is negligible at that tolerance."""
+    from oracle.forcings import ColumnForcings
+    og = oracle.Grid((4, 4, 4), x=(0, 10), y=(0, 10), z=(0, 16))
+    ws, Gam, dt = 1.0, 1e-2, 1e-2
+    F = ColumnForcings(w_subsidence=ws * np.ones(5), subsidence_on=(name,))
+    m = oracle.OracleModel(og, forcings=F)
+    lin = lambda x, y, z: Gam * z + 0 * x + 0 * y
+    if name == "theta":
+        m.set(theta=lambda x, y, z: m.ref.theta0 + lin(x, y, z))
+    elif name == "q":
+        m.set(theta=m.ref.theta0, qt=lin)
+    else:
+        m.set(theta=m.ref.theta0, u=lin, enforce_mass_conservation=False)
+    key = {"theta": "rtheta", "q": "rq", "u": "ru"}[name]
+    g = og
+    before = g.interior(getattr(m, key)).copy()
+    m.time_step(dt)
+    after = g.interior(getattr(m, key))
+    rho = m.ref.density[g.Hz:g.Hz + g.Nz]
+    dphi = -dt * ws * Gam
+    for k in (0, 3):
+        assert (after - before)[k, 0, 0] == pytest.approx(rho[k] * dphi, rel=1e-3)
+
+
+def test_reference_subsidence_multi_step_linear_accumulation(oracle):
+    """test/geostrophic_subsidence_forcings.jl:233-294: the constant gradient is preserved, so N = 5 steps change rho theta by
+    N rho_r (-dt w_s Gamma) everywhere (1e-3 of the expected change)."""
+    from oracle.forcings import ColumnForcings
+    og = oracle.Grid((4, 4, 4), x=(0, 10), y=(0, 10), z=(0, 16))
+    ws, Gam, dt, N = 1.0, 1e-2, 1e-2, 5
+    m = oracle.OracleModel(og, forcings=ColumnForcings(w_subsidence=ws * np.ones(5), subsidence_on=("theta",)))
+    m.set(theta=lambda x, y, z: m.ref.theta0 + Gam * z + 0 * x + 0 * y)
+    g = og
+    before = g.interior(m.rtheta).copy()
+    for _ in range(N):
+        m.time_step(dt)
+    rho = m.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    expected = N * rho * (-dt * ws * Gam) + 0 * before
+    assert np.abs((g.interior(m.rtheta) - before) - expected).max() < 1e-3 * np.abs(expected).max()
+
+
+def test_reference_geostrophic_smoke_signs(oracle):
+    """test/geostrophic_subsidence_forcings.jl:12-38,163-187: u_g = -10, v_g = 0, f = 1e-4, one step of 1e-6 from rest gives
+    rho v < 0 everywhere (F_rho_v = +f rho_r u_g), also combined with subsidence."""
+    from oracle.forcings import ColumnForcings
+    og = oracle.Grid((4, 4, 4), x=(0, 100), y=(0, 100), z=(0, 100))
+    for sub in (False, True):
+        F = ColumnForcings(Fu=-1e-4 * np.zeros(4), Fv=1e-4 * (-10.0) * np.ones(4), coriolis_f=1e-4,
+                           w_subsidence=-0.01 * np.ones(5) if sub else None, subsidence_on=("u", "v"))
+        m = oracle.OracleModel(og, forcings=F)
+        m.time_step(1e-6)
+        assert og.interior(m.rv).max() < 0
 
 
 # ---- GPU: parity through the C ABI ------------------------------------------------------------------------------------------------

@@ -57,6 +57,10 @@ class bz_saturation_adjustment(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class bz_tracer_fields(C.Structure):
+    _fields_ = [("density", C.c_void_p), ("specific", C.c_void_p), ("U0", C.c_void_p), ("G", C.c_void_p)]
+
+
 class bz_smagorinsky_lilly(C.Structure):
     _fields_ = [("smagorinsky_coefficient", C.c_double), ("reduction_factor", C.c_double), ("prandtl_number", C.c_double)]
 
@@ -190,6 +194,7 @@ SYMBOLS = {
                                               C.c_double]),
     "bz_kessler_model_update": (C.c_int, [_ctx, _sp, _pp, C.c_double]),
     "bz_compressible_kessler_update": (C.c_int, [_ctx, _csp, _cpp, _asp, C.c_double]),
+    "bz_set_tracers": (C.c_int, [_ctx, C.c_int32, C.POINTER(bz_tracer_fields)]),
     "bz_set_closure": (C.c_int, [_ctx, C.POINTER(bz_smagorinsky_lilly), C.c_void_p]),
     "bz_compute_closure_fields": (C.c_int, [_ctx, _sp]),
     "bz_set_forcings": (C.c_int, [_ctx, C.POINTER(bz_column_forcings)]),

@@ -192,6 +192,9 @@ struct bz_ctx {
     double *d_forcing = nullptr;      // static profiles, subsidence velocity, level averages, subsidence profiles, partial sums
     int forcing_static_mask = 0, forcing_subsidence_mask = 0;
     double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0;
+    // user tracers (bz_set_tracers, bz_tracers.hip)
+    int n_tracers = 0;
+    bz_tracer_fields tracers[BZ_MAX_TRACERS];
     // closure = SmagorinskyLilly() (bz_set_closure, bz_closure.hip)
     bool has_closure = false;
     bz_smagorinsky_lilly closure;
@@ -245,6 +248,10 @@ int bzi_fill_halo(bz_ctx *ctx, double *f, int kind);
 int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale);
 int bzi_flux_bc(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale);
 void bzi_forcing_teardown(bz_ctx *ctx);
+int bzi_tracer_specific(bz_ctx *ctx);
+int bzi_tracer_rk3(bz_ctx *ctx, double dt, double alpha, bool first);
+int bzi_tracer_store_initial_state(bz_ctx *ctx);
+int bzi_tracer_tendencies(bz_ctx *ctx, const bz_state *s);
 void bzi_closure_teardown(bz_ctx *ctx);
 int bzi_apply_closure(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gw, double *Gth, double *Gq, double scale);
 int bzi_kessler_tendencies(bz_ctx *ctx, const bz_state *s);

@@ -168,7 +168,9 @@ extern "C" int bz_compute_auxiliary_thermodynamic_variables(bz_ctx *ctx, const b
     }
     double *f[6] = {s->T, s->q, s->theta, g.qv_field, g.microphysics == 2 ? g.qcl_field : g.ql_field, g.qr_field};
     int kd[6] = {0, 0, 0, 0, 0, 0};
-    return bzi_fill_halos_multi(ctx, f, kd, g.microphysics == 2 ? 6 : (g.microphysics ? 5 : 3));
+    int rch = bzi_fill_halos_multi(ctx, f, kd, g.microphysics == 2 ? 6 : (g.microphysics ? 5 : 3));
+    if (rch) return rch;
+    return bzi_tracer_specific(ctx);       // tracer_density_to_specific! (update_atmosphere_model_state.jl:43)
 }
 
 extern "C" int bz_store_initial_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0)
@@ -180,6 +182,10 @@ extern "C" int bz_store_initial_state(bz_ctx *ctx, const bz_state *s, const bz_p
     hipLaunchKernelGGL(k_copy5, dim3(256 * 32), dim3(256), 0, ctx->stream, nc, U0->rho_u, s->rho_u, U0->rho_v,
                        s->rho_v, U0->rho_theta, s->rho_theta, U0->rho_q, s->rho_q, nw, U0->rho_w, s->rho_w);
     BZ_LAUNCH_CHECK();
+    if (ctx->n_tracers) {
+        int rct = bzi_tracer_store_initial_state(ctx);
+        if (rct) return rct;
+    }
     if (g.microphysics == 2) {
         BZ_HIP(hipMemcpyAsync(ctx->kessler.U0_cloud_liquid_density, ctx->kessler.cloud_liquid_density, nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         BZ_HIP(hipMemcpyAsync(ctx->kessler.U0_rain_density, ctx->kessler.rain_density, nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -203,6 +209,10 @@ extern "C" int bz_ssp_rk3_substep(bz_ctx *ctx, const bz_state *s, const bz_progn
     F.G[0] = G->rho_u; F.G[1] = G->rho_v; F.G[2] = G->rho_w; F.G[3] = G->rho_theta; F.G[4] = G->rho_q;
     hipLaunchKernelGGL(k_rk3_substep, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, F, dt, alpha);
     BZ_LAUNCH_CHECK();
+    if (ctx->n_tracers) {
+        int rct = bzi_tracer_rk3(ctx, dt, alpha, false);
+        if (rct) return rct;
+    }
     if (g.microphysics == 2) return bzi_kessler_rk3(ctx, dt, alpha, false);
     return BZ_OK;
 }

@@ -44,6 +44,10 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
         for (int stage = 0; stage < 3; ++stage) {
             const double alpha = alphas[stage];
             if ((rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+            if (ctx->n_tracers) {       // tracers ride beside the fused kernels: tendency from the previous-stage state, RK in place
+                if ((rc = bzi_tracer_tendencies(ctx, s))) return rc;
+                if ((rc = bzi_tracer_rk3(ctx, dt, alpha, stage == 0))) return rc;
+            }
             if (ctx->has_closure &&
                 (rc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, s->rho_theta, s->rho_q, alpha * dt))) return rc;
             if (ctx->has_forcings) {
@@ -55,6 +59,7 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
             if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G))) return rc;
+            if ((rc = bzi_tracer_specific(ctx))) return rc;
         }
         ctx->G_is_predictor = true;
         return BZ_OK;
@@ -69,9 +74,11 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
             if ((rc = bz_compute_flux_bc_tendencies(ctx, s, G))) return rc;          // :229,243,257
             if ((rc = bzi_rk3_fused(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
             if (ctx->dg.microphysics == 2 && (rc = bzi_kessler_rk3(ctx, dt, alpha, stage == 0))) return rc;
+            if ((rc = bzi_tracer_rk3(ctx, dt, alpha, stage == 0))) return rc;
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
             if ((rc = bzi_project_diagnose(ctx, s, alpha * dt))) return rc;
+            if ((rc = bzi_tracer_specific(ctx))) return rc;
             if ((rc = bz_compute_tendencies(ctx, s, G))) return rc;
         }
         // microphysics_model_update!(model.microphysics, model) closes the step (ssp_runge_kutta_3.jl:262-263)

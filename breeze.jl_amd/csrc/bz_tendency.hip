@@ -360,6 +360,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
         hipLaunchKernelGGL(k_energy_buoyancy_flux, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
                            G->rho_theta, s->w, s->T, s->q);
     }
+    if (ctx->n_tracers) {
+        int rct = bzi_tracer_tendencies(ctx, s);
+        if (rct) return rct;
+    }
     if (ctx->has_closure) {
         int rcc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, 1.0);
         if (rcc) return rcc;
@@ -403,6 +407,21 @@ int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
     if (rc) return rc;
     rc = bzi_scalar_pair_tendency(ctx, s, G, U0, &E);
     if (rc) return rc;
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// scalar tendencies of the user tracers: G = -div_rhoUc(c)  (update_atmosphere_model_state.jl:352-372)
+int bzi_tracer_tendencies(bz_ctx *ctx, const bz_state *s)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "tracer_tendencies");
+    dim3 block(64, TYB);
+    int kc = pick_kchunk(g, g.Nz);
+    dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
+    for (int t = 0; t < ctx->n_tracers; ++t)
+        hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, ctx->tracers[t].G, s->u, s->v, s->w,
+                           ctx->tracers[t].specific, kc);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -100,7 +100,7 @@ class AtmosphereModel:
     def __init__(self, grid, dynamics=None, advection=None, thermodynamic_constants=None,
                  formulation="LiquidIcePotentialTemperature", timestepper="SSPRungeKutta3",
                  closure=None, coriolis=None, microphysics=None, forcing=None, boundary_conditions=None,
-                 device="cuda:0"):
+                 tracers=(), device="cuda:0"):
         import torch
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
@@ -166,6 +166,12 @@ class AtmosphereModel:
             self.microphysical_fields = {k: fld("ccc") for k in ("ρqᶜˡ", "ρqʳ", "qᵛ", "qᶜˡ", "qʳ", "𝕎ʳ")}
             self.microphysical_fields["precipitation_rate"] = torch.zeros((grid.Ny + 2 * grid.Hy, grid.Nx + 2 * grid.Hx),
                                                                           dtype=torch.float64, device=self.device)
+        # tracers = (:a, :b): prognostic density fields model.tracers[name]; the specific field sits beside it
+        tracers = (tracers,) if isinstance(tracers, str) else tuple(tracers)
+        self.tracers = {str(n).lstrip(":"): fld("ccc") for n in tracers}
+        self.specific_tracers = {n: fld("ccc") for n in self.tracers}
+        if self.tracers and closure is not None:
+            raise NotImplementedError("user tracers with a closure are not implemented")
         prog = self.prognostic_fields()
         self.U0 = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}     # timestepper.U⁰
         self.G = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}      # timestepper.Gⁿ
@@ -219,6 +225,12 @@ class AtmosphereModel:
                                                          C.c_void_p(self.microphysical_fields["qᵛ"].ptr()),
                                                          C.c_void_p(self.microphysical_fields["qˡ"].ptr())),
                         "bz_set_saturation_adjustment")
+        if self.tracers:
+            arr = (_lib.bz_tracer_fields * len(self.tracers))()
+            for t, n in enumerate(self.tracers):
+                arr[t].density, arr[t].specific = self.tracers[n].ptr(), self.specific_tracers[n].ptr()
+                arr[t].U0, arr[t].G = self.U0[n].ptr(), self.G[n].ptr()
+            self._check(lib.bz_set_tracers(self._ctx, len(self.tracers), arr), "bz_set_tracers")
         self.closure_fields = {}
         if closure is not None:      # build_closure_fields: nu_e (atmosphere_model.jl:276)
             if self._kessler or formulation != "LiquidIcePotentialTemperature":
@@ -248,6 +260,7 @@ class AtmosphereModel:
                "ρθ": self.potential_temperature_density, "ρq": self.moisture_density}
         if getattr(self, "_kessler", False):
             out["ρqᶜˡ"], out["ρqʳ"] = self.microphysical_fields["ρqᶜˡ"], self.microphysical_fields["ρqʳ"]
+        out.update(getattr(self, "tracers", {}))
         return out
 
     def _make_state(self):

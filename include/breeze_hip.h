@@ -417,6 +417,20 @@ int bz_compute_forcings(bz_ctx *ctx, const bz_state *s);
 /* compute_flux_bc_tendencies!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:418-434) */
 int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 
+/* ---- user tracers of the anelastic model: AtmosphereModel(grid; tracers = (:a, :b)) ----
+ * density = model.tracers.c (prognostic rho c), specific = c = rho c / rho_r (the reference converts in place around the tendency
+ * evaluation, src/AtmosphereModels/update_atmosphere_model_state.jl:43,65,88-112; here it is a separate centre array), U0 / G the
+ * timestepper mirrors.  Each tracer gets the WENO-5 scalar tendency -div_rhoUc(c) (:352-372) and the SSP-RK3 update.  At most
+ * BZ_MAX_TRACERS; n = 0 detaches.  Single-device anelastic contexts; not combined with a closure in this build. */
+#define BZ_MAX_TRACERS 8
+typedef struct bz_tracer_fields {
+    double *density;
+    double *specific;
+    double *U0;
+    double *G;
+} bz_tracer_fields;
+int bz_set_tracers(bz_ctx *ctx, int32_t n, const bz_tracer_fields *tracers);
+
 /* ---- closure = SmagorinskyLilly() (BASELINE configs[2]) ----
  * Breeze's part — density-weighted stress and flux divergences (src/TurbulenceClosures/TurbulenceClosures.jl:44-101), their place
  * in the tendencies (src/AtmosphereModels/dynamics_kernel_functions.jl:80,100,128,157), N^2 = g dz(log theta_v)

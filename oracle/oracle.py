@@ -256,7 +256,7 @@ class OracleModel:
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
                  standard_pressure=1e5, reference_density=None, initialize=True,
                  formulation="LiquidIcePotentialTemperature", microphysics=None, sa_abstol=1e-4, sa_maxiter=20,
-                 forcings=None, closure=None):
+                 forcings=None, closure=None, tracers=0):
         # formulation "StaticEnergy": self.theta holds e, self.rtheta holds rho*e
         # (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21)
         assert formulation in ("LiquidIcePotentialTemperature", "StaticEnergy")
@@ -302,6 +302,13 @@ class OracleModel:
         self.rw = g.zface_field()
         self.u, self.v, self.theta, self.q, self.T, self.phi = (g.center_field() for _ in range(6))
         self.w = g.zface_field()
+        # user tracers (tracers = (:a, :b)): prognostic rho c ("rc0", "rc1", ...), specific c ("c0", ...)
+        self.n_tracers = int(tracers)
+        if self.n_tracers:
+            self.PROGNOSTIC = tuple(self.PROGNOSTIC) + tuple(f"rc{t}" for t in range(self.n_tracers))
+            for t in range(self.n_tracers):
+                setattr(self, f"rc{t}", g.center_field())
+                setattr(self, f"c{t}", g.center_field())
         self.U0 = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
         self.G = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
         # Poisson solver setup (dynamics_pressure_solver, anelastic_pressure_solver.jl:11-24)
@@ -405,6 +412,8 @@ class OracleModel:
                 g.interior(self.rtheta)[...] = self._eval(value, "ccc")
             elif name == "rtheta":
                 g.interior(self.rtheta)[...] = self._eval(value, "ccc")
+            elif name.startswith("rc") and name[2:].isdigit() and int(name[2:]) < self.n_tracers:
+                g.interior(getattr(self, name))[...] = self._eval(value, "ccc")
             else:
                 raise ValueError(f"Cannot set {name} in OracleModel")
         self.update_state(compute_tendencies=False)
@@ -457,6 +466,13 @@ class OracleModel:
             self.lib.og_compute_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.rtheta), _p(self.rq))
         for f in (self.T, self.q, self.theta):
             self._halo_center(f)
+        if self.n_tracers:        # tracer_density_to_specific! (update_atmosphere_model_state.jl:43,97-103) + halo fill
+            g = self.grid
+            rho = self.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+            for t in range(self.n_tracers):
+                c = getattr(self, f"c{t}")
+                g.interior(c)[...] = g.interior(getattr(self, f"rc{t}")) / rho
+                self._halo_center(c)
         if self.closure is not None:       # compute_closure_fields! closes compute_auxiliary_variables! (:218)
             from .closure import compute_closure_fields
             compute_closure_fields(self)
@@ -483,6 +499,8 @@ class OracleModel:
         L.og_scalar_tendency(cg, _p(G["rq"]), _p(self.u), _p(self.v), _p(self.w), _p(self.q))
         if self.formulation == "StaticEnergy":
             L.og_energy_buoyancy_flux(cg, _p(G["rtheta"]), _p(self.w), _p(self.T), _p(self.q))
+        for t in range(self.n_tracers):     # scalar_tendency per tracer (update_atmosphere_model_state.jl:352-372)
+            L.og_scalar_tendency(cg, _p(G[f"rc{t}"]), _p(self.u), _p(self.v), _p(self.w), _p(getattr(self, f"c{t}")))
         if self.closure is not None:
             from .closure import add_closure_tendencies
             add_closure_tendencies(self)

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64 * TY) void k_scalar_pair_lds(DevGrid g, const do
     const int ie = i0 + nact, le = nact - 1;
     const int kbeg = blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);
     if (kbeg >= kend) return;                           // block-uniform
-    const long long sy = g.Sx, sz = g.Sxy;
+    const long long sz = g.Sxy;
     const bool store = (i < g.Nx) && (j < g.Ny);
     long long n = g.idx(ic, jc, kbeg);
 
@@ -206,9 +206,9 @@ __global__ __launch_bounds__(64 * TY) void k_u_tend_lds(DevGrid g, Tend3Fields F
     const int ie = i0 - 1, le = 0;                      // centre-type x flux: lane 0 needs the flux of centre i0-1
     const int kbeg = blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);
     if (kbeg >= kend) return;
-    const long long sy = g.Sx, sz = g.Sxy;
+    const long long sz = g.Sxy;
     const bool store = (i < g.Nx) && (j < g.Ny);
-    const double *u = F.c, *ru = F.ru, *rv = F.rv, *rw = F.rw;
+    const double *u = F.c, *ru = F.ru, *rv = F.rv;
     long long n = g.idx(ic, jc, kbeg);
     // frame row handled by this thread (6 rows x 64 columns)
     // frame rows (3 below + 3 above the tile, 64 columns): HPT cells per thread
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * TY) void k_w_tend_lds(DevGrid g, Tend3Fields F
     const int ie = i0 + nact, le = nact - 1;
     const int kbeg = 1 + blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);
     if (kbeg >= kend) return;
-    const long long sy = g.Sx, sz = g.Sxy;
+    const long long sz = g.Sxy;
     const bool store = (i < g.Nx) && (j < g.Ny);
     const double *w = F.c, *ru = F.ru, *rv = F.rv, *rw = F.rw;
     const double Az = g.Az;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * TY) void k_v_tend_lds(DevGrid g, Tend3Fields F
     const int ie = i0 + nact, le = nact - 1;              // x flux at x-faces: last lane needs face i0+nact
     const int kbeg = blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);
     if (kbeg >= kend) return;
-    const long long sy = g.Sx, sz = g.Sxy;
+    const long long sz = g.Sxy;
     const bool store = (i < g.Nx) && (j < g.Ny);
     const double *v = F.c, *ru = F.ru, *rv = F.rv, *rw = F.rw;
     const double Az = g.Az;

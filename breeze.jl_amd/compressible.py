@@ -82,13 +82,14 @@ def _z_metrics(grid):
 
 
 class ExnerReferenceState:
-    """Dry, 1-D, isentropic-mode ExnerReferenceState: the discrete hydrostatic balance
-    (p[k]-p[k-1])/Δzᶠ + g (ρ[k]+ρ[k-1])/2 = 0 holds to rounding at every interior face."""
+    """1-D, isentropic-mode ExnerReferenceState, dry or moist (`vapor_mass_fraction` a number or qᵛ(z)): the discrete
+    hydrostatic balance (p[k]-p[k-1])/Δzᶠ + g (ρ[k]+ρ[k-1])/2 = 0 holds to rounding at every interior face
+    (src/Thermodynamics/reference_states.jl:572-672,718-827)."""
 
     def __init__(self, grid, constants=None, surface_pressure=101325, potential_temperature=288, standard_pressure=1e5,
                  vapor_mass_fraction=None, reference_temperature=None):
-        if vapor_mass_fraction is not None or reference_temperature is not None:
-            raise NotImplementedError("moist / isothermal ExnerReferenceState modes are not implemented")
+        if reference_temperature is not None:
+            raise NotImplementedError("the isothermal ExnerReferenceState mode is not implemented")
         c = constants or ThermodynamicConstants()
         self.constants = c
         Nz, Hz = grid.Nz, grid.Hz
@@ -96,19 +97,34 @@ class ExnerReferenceState:
         self.standard_pressure = pst = float(standard_pressure)
         θfun = potential_temperature if callable(potential_temperature) else (lambda z: float(potential_temperature) + 0.0 * z)
         self.surface_potential_temperature = float(θfun(np.float64(0.0)))
-        Rd, cpd, g = dry_air_gas_constant(c), c.dry_air_heat_capacity, c.gravitational_acceleration
-        κ = Rd / cpd
+        Rd, Rv = dry_air_gas_constant(c), vapor_gas_constant(c)
+        cpd, cpv, g = c.dry_air_heat_capacity, c.vapor_heat_capacity, c.gravitational_acceleration
         dzc, dzf = _z_metrics(grid)
         θ = np.asarray(θfun(grid.zᶜ), dtype=np.float64)
+        if vapor_mass_fraction is None:
+            qv = np.zeros(Nz)
+        elif callable(vapor_mass_fraction):
+            qv = np.array([float(vapor_mass_fraction(z)) for z in grid.zᶜ])
+        else:
+            qv = np.full(Nz, float(vapor_mass_fraction))
+        self.vapor_mass_fraction = qv
+
+        def moist(q):      # moist_reference_constants (reference_states.jl:572-577); exactly the dry constants for q = 0
+            qd = 1 - q
+            Rm, cpm = qd * Rd + q * Rv, qd * cpd + q * cpv
+            return Rm, cpm, Rm / cpm
+
         π, p, ρ = np.zeros(Nz), np.zeros(Nz), np.zeros(Nz)
-        π_surface = (p0 / pst) ** κ
-        π[0] = π_surface - g * dzc[0] / (2 * cpd * θ[0])
-        p[0] = pst * π[0] ** (1 / κ)
-        ρ[0] = p[0] / (Rd * θ[0] * π[0])
+        Rm1, cpm1, κ1 = moist(qv[0])
+        π_surface = (p0 / pst) ** κ1
+        π[0] = π_surface - g * dzc[0] / (2 * cpm1 * θ[0])
+        p[0] = pst * π[0] ** (1 / κ1)
+        ρ[0] = p[0] / (Rm1 * θ[0] * π[0])
         for k in range(1, Nz):
+            Rm, cpm, κ = moist(qv[k])
             θface = (θ[k] + θ[k - 1]) / 2
-            pk = pst * (π[k - 1] - g * dzf[k] / (cpd * θface)) ** (1 / κ)
-            A = g * pst ** κ / (2 * Rd * θ[k])
+            pk = pst * (π[k - 1] - g * dzf[k] / (cpm * θface)) ** (1 / κ)
+            A = g * pst ** κ / (2 * Rm * θ[k])
             Cc = p[k - 1] / dzf[k] - g * ρ[k - 1] / 2
             for _ in range(5):                                   # FixedIterations(5) Newton on the discrete balance
                 ρp = pk ** (-κ)
@@ -117,8 +133,8 @@ class ExnerReferenceState:
                 pk -= f / df
             p[k] = pk
             π[k] = (pk / pst) ** κ
-            ρ[k] = pk / (Rd * θ[k] * π[k])
-        self.surface_density = ρ0 = p0 / (Rd * self.surface_potential_temperature * π_surface)
+            ρ[k] = pk / (Rm * θ[k] * π[k])
+        self.surface_density = ρ0 = p0 / (Rm1 * self.surface_potential_temperature * π_surface)
 
         def with_halos(a, bottom_value=None):
             out = np.zeros(Nz + 2 * Hz)
@@ -136,7 +152,7 @@ class ExnerReferenceState:
 
 class CompressibleDynamics:
     def __init__(self, time_discretization=None, standard_pressure=1e5, surface_pressure=101325.0,
-                 reference_potential_temperature=None, reference_state="auto"):
+                 reference_potential_temperature=None, reference_vapor_mass_fraction=None, reference_state="auto"):
         if time_discretization is None or not isinstance(time_discretization, SplitExplicitTimeDiscretization):
             raise NotImplementedError("the HIP path implements CompressibleDynamics(SplitExplicitTimeDiscretization(...)); "
                                       "ExplicitTimeStepping is outside the hot-path scope")
@@ -148,6 +164,7 @@ class CompressibleDynamics:
         self.time_discretization = time_discretization
         self.standard_pressure = float(standard_pressure)
         self.surface_pressure = float(surface_pressure)
+        self._reference_vapor = reference_vapor_mass_fraction
         self._reference_spec = None if reference_state is None else (
             288.0 if reference_potential_temperature is None else reference_potential_temperature)
         # materialised by the model
@@ -254,6 +271,7 @@ class CompressibleAtmosphereModel:
         if dynamics._reference_spec is not None:
             dynamics.reference_state = ExnerReferenceState(grid, c, surface_pressure=dynamics.surface_pressure,
                                                            potential_temperature=dynamics._reference_spec,
+                                                           vapor_mass_fraction=dynamics._reference_vapor,
                                                            standard_pressure=dynamics.standard_pressure)
         self.timestepper = AcousticRungeKutta3(grid, self.prognostic_fields(), dynamics, self.device)
         self.U0, self.G = self.timestepper.U0, self.timestepper.Gn

@@ -32,8 +32,12 @@ from .oracle import BOUNDED, FLAT, Constants, Grid, _OGGrid, _dp, _p, lib  # noq
 # ExnerReferenceState: dry, 1-D column, isentropic mode (reference_states.jl:588-672)
 # ---------------------------------------------------------------------------
 class ExnerReferenceState:
+    """ExnerReferenceState(grid, constants; surface_pressure, potential_temperature, standard_pressure, vapor_mass_fraction)
+    — isentropic mode, dry or moist (src/Thermodynamics/reference_states.jl:572-577 moist_reference_constants, :588-598 Newton on
+    the discrete balance, :609-672 _compute_exner_column! / integrate_exner_column!, :718-827 constructor)."""
+
     def __init__(self, grid, constants, surface_pressure=101325.0, potential_temperature=288.0,
-                 standard_pressure=1e5):
+                 standard_pressure=1e5, vapor_mass_fraction=None):
         g, c = grid, constants
         Nz, Hz = g.Nz, g.Hz
         self.p0, self.pst = float(surface_pressure), float(standard_pressure)
@@ -43,21 +47,35 @@ class ExnerReferenceState:
         theta[Hz:Hz + Nz] = th_fun(g.zc)
         theta[Hz - 1] = theta[Hz]
         theta[Hz + Nz] = theta[Hz + Nz - 1]
-        Rm, cpm = 1.0 * c.Rd + 0.0 * c.Rv, 1.0 * c.cpd + 0.0 * c.cpv
-        kap = Rm / cpm
+        if vapor_mass_fraction is None:
+            qv = np.zeros(Nz)
+        elif callable(vapor_mass_fraction):
+            qv = np.array([float(vapor_mass_fraction(z)) for z in g.zc])
+        else:
+            qv = np.full(Nz, float(vapor_mass_fraction))
+        self.vapor_mass_fraction = qv
+
+        def moist(q):          # moist_reference_constants
+            qd = 1 - q
+            Rm = qd * c.Rd + q * c.Rv
+            cpm = qd * c.cpd + q * c.cpv
+            return Rm, cpm, Rm / cpm
+
         grav, pst = c.g, self.pst
         pi = np.zeros(g.Szc)
         p = np.zeros(g.Szc)
         rho = np.zeros(g.Szc)
-        pi_surf = (self.p0 / pst) ** kap
+        Rm1, cpm1, kap1 = moist(qv[0])
+        pi_surf = (self.p0 / pst) ** kap1
         th1 = theta[Hz]
-        Pi1 = pi_surf - grav * g.dzc[Hz] / (2 * cpm * th1)
-        p1 = pst * Pi1 ** (1 / kap)
-        pi[Hz], p[Hz], rho[Hz] = Pi1, p1, p1 / (Rm * th1 * Pi1)
+        Pi1 = pi_surf - grav * g.dzc[Hz] / (2 * cpm1 * th1)
+        p1 = pst * Pi1 ** (1 / kap1)
+        pi[Hz], p[Hz], rho[Hz] = Pi1, p1, p1 / (Rm1 * th1 * Pi1)
         pm, rm = p[Hz], rho[Hz]
         for k in range(1, Nz):
             dzf = g.dzf[k + Hz]
             thk, thm = theta[Hz + k], theta[Hz + k - 1]
+            Rm, cpm, kap = moist(qv[k])
             thf = (thk + thm) / 2
             Pi_init = pi[Hz + k - 1] - grav * dzf / (cpm * thf)
             pk = pst * Pi_init ** (1 / kap)
@@ -72,7 +90,7 @@ class ExnerReferenceState:
             rk = pk / (Rm * thk * Pik)
             pi[Hz + k], p[Hz + k], rho[Hz + k] = Pik, pk, rk
             pm, rm = pk, rk
-        self.rho0 = self.p0 / (Rm * self.theta0 * pi_surf)
+        self.rho0 = self.p0 / (Rm1 * self.theta0 * pi_surf)
         # halos: bottom Value BC for p, rho; zero-gradient elsewhere (first halo cell)
         p[Hz - 1] = 2 * self.p0 - p[Hz]
         rho[Hz - 1] = 2 * self.rho0 - rho[Hz]
@@ -134,7 +152,7 @@ class CompressibleOracleModel:
 
     def __init__(self, grid, constants=None, time_discretization=None, surface_pressure=101325.0,
                  standard_pressure=1e5, reference_potential_temperature=288.0, reference_state=True,
-                 newton_abstol=1e-4, newton_maxiter=8, microphysics=None):
+                 newton_abstol=1e-4, newton_maxiter=8, microphysics=None, reference_vapor_mass_fraction=None):
         # microphysics "Kessler": DCMIP2016KesslerMicrophysics — rho q^cl, rho q^r prognostic (dcmip2016_kessler.jl:216)
         assert microphysics in (None, "Kessler")
         self.microphysics = microphysics
@@ -143,7 +161,8 @@ class CompressibleOracleModel:
         self.td = time_discretization or SplitExplicit()
         self.pst = float(standard_pressure)
         self.p0 = float(surface_pressure)
-        self.ref = (ExnerReferenceState(g, c, surface_pressure, reference_potential_temperature, standard_pressure)
+        self.ref = (ExnerReferenceState(g, c, surface_pressure, reference_potential_temperature, standard_pressure,
+                                        vapor_mass_fraction=reference_vapor_mass_fraction)
                     if reference_state else None)
         self.newton = (float(newton_abstol), int(newton_maxiter))
         self.lib = lib()

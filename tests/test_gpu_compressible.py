@@ -335,3 +335,35 @@ def test_compressible_kessler_model_matches_oracle(oracle, oc, bz):
         assert np.abs(μ[k].interior_cpu() - want).max() <= 1e-8 * max(np.abs(want).max(), 1e-9), n
     assert g.interior(om.W).max() > 0.5
     print("compressible kessler parity:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_compressible_kessler_on_moist_reference_matches_oracle(oracle, oc, bz):
+    """The configuration shape of BASELINE configs[4]: z-dependent reference theta and reference vapour (moist
+    ExnerReferenceState), pressure-balanced bubble, Kessler; two steps against the oracle."""
+    size = (16, 12, 16)
+    extent = dict(x=(0.0, 16e3), y=(0.0, 12e3), z=(0.0, 8e3))
+    thb = lambda z: 300.0 + 0.0035 * z
+    qvb = lambda z: float(0.013 * np.exp(-z / 2800.0))
+    og = oracle.Grid(size, **extent)
+    om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), surface_pressure=1e5,
+                                    reference_potential_temperature=thb, reference_vapor_mass_fraction=qvb, microphysics="Kessler")
+    grid = bz.RectilinearGrid(size, **extent)
+    tc = bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula())
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), surface_pressure=1e5,
+                                  reference_potential_temperature=thb, reference_vapor_mass_fraction=qvb)
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), thermodynamic_constants=tc,
+                                        microphysics=bz.DCMIP2016KesslerMicrophysics())
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt(((x - 8e3) / 4e3) ** 2 + ((y - 6e3) / 4e3) ** 2 + ((z - 1500.0) / 1500.0) ** 2))
+    th = lambda x, y, z: thb(z) + 2.0 * bub(x, y, z)
+    qv = lambda x, y, z: np.vectorize(qvb)(z) + 0.003 * bub(x, y, z) + 0 * x + 0 * y
+    rho_ref = om.ref.density[og.Hz:og.Hz + og.Nz][:, None, None]
+    x, y, z = og.nodes("ccc")
+    rho = rho_ref * thb(z) / th(x, y, z)            # pressure_balanced_density
+    om.set(rho=rho, theta=th, u=5.0, v=0.0, w=0.0, qv=qv)
+    hm.set(ρ=rho, θ=th, u=5.0, v=0.0, w=0.0, qᵗ=qv)
+    cmp_interior(om, hm, ("rho_d", "rho", "rtheta", "rq", "T", "p"), 1e-13)
+    for _ in range(2):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rw", "T", "p"), 1e-8)
+    assert np.abs(og.interior(om.rw, True)).max() > 1e-3

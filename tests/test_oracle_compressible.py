@@ -212,3 +212,51 @@ def test_tiny_dry_bubble_consistency_with_anelastic(oracle, oc):
     assert abs(g.interior(m.rho_d).sum() - M0) / M0 < 1e-13
     assert abs(g.interior(m.rtheta).sum() - H0) / H0 < 1e-13
     print("tiny bubble: split-explicit w_max %.4f zW %.1f | anelastic w_max %.4f zW %.1f" % (ws, zs, wa, za))
+
+
+def test_moist_exner_reference_state_discrete_balance_and_dry_limit(oracle, oc):
+    """ExnerReferenceState with vapor_mass_fraction (reference_states.jl:572-672): level-local R_m, c_pm, kappa_m; the discrete
+    balance holds to rounding at every interior face, the moist EOS holds level by level, q^v = 0 reproduces the dry column
+    bit for bit, and a moist column is lighter than the dry one at the same pressure."""
+    g = oracle.Grid((4, 4, 40), x=(0, 4e3), y=(0, 4e3), z=(0, 20e3))
+    c = oracle.Constants()
+    th = lambda z: 300.0 + 43.0 * (np.minimum(z, 12e3) / 12e3) ** 1.25 + 0.02 * np.maximum(z - 12e3, 0.0)
+    qv = lambda z: 0.014 * np.exp(-z / 3e3)
+    dry = oc.ExnerReferenceState(g, c, 1e5, th, 1e5)
+    dry0 = oc.ExnerReferenceState(g, c, 1e5, th, 1e5, vapor_mass_fraction=0.0)
+    moist = oc.ExnerReferenceState(g, c, 1e5, th, 1e5, vapor_mass_fraction=qv)
+    Hz, Nz = g.Hz, g.Nz
+    for a in ("pressure", "density", "exner_function"):
+        assert np.array_equal(getattr(dry, a), getattr(dry0, a))
+    p, rho = moist.pressure[Hz:Hz + Nz], moist.density[Hz:Hz + Nz]
+    res = (p[1:] - p[:-1]) / g.dzf[Hz + 1:Hz + Nz] + c.g * (rho[1:] + rho[:-1]) / 2
+    assert np.abs(res).max() < 1e-10 * c.g * rho.max()
+    q = np.array([qv(z) for z in g.zc])
+    Rm = (1 - q) * c.Rd + q * c.Rv
+    cpm = (1 - q) * c.cpd + q * c.cpv
+    T = th(g.zc) * (p / 1e5) ** (Rm / cpm)
+    np.testing.assert_allclose(rho, p / (Rm * T), rtol=1e-13)
+    assert moist.density[Hz] < dry.density[Hz]
+    # the model picks it up: a resting moist column on its own reference has no slow vertical-momentum tendency
+    m = oc.CompressibleOracleModel(g, time_discretization=oc.SplitExplicit(substeps=4), surface_pressure=1e5,
+                                   reference_potential_temperature=th, reference_vapor_mass_fraction=qv)
+    m.set(rho=m.ref.density[Hz:Hz + Nz][:, None, None], theta=lambda x, y, z: th(z) + 0 * x + 0 * y,
+          qv=lambda x, y, z: qv(z) + 0 * x + 0 * y, u=0.0, v=0.0, w=0.0)
+    m.time_step(2.0)
+    assert np.abs(g.interior(m.rw, True)).max() < 1e-8
+
+
+def test_host_moist_exner_reference_state_equals_oracle(oracle, oc, bz):
+    """The host-side column builder (breeze.jl_amd/compressible.py) and the oracle's follow the same recurrence: identical digits."""
+    size, ext = (4, 4, 24), dict(x=(0, 4e3), y=(0, 4e3), z=(0, 18e3))
+    th = lambda z: 300.0 + 40.0 * (np.minimum(z, 12e3) / 12e3) ** 1.25 + 0.015 * np.maximum(z - 12e3, 0.0)
+    qv = lambda z: float(0.012 * np.exp(-z / 2500.0))
+    og = oracle.Grid(size, **ext)
+    ro = oc.ExnerReferenceState(og, oracle.Constants(), 1e5, th, 1e5, vapor_mass_fraction=qv)
+    grid = bz.RectilinearGrid(size, **ext)
+    rh = bz.compressible.ExnerReferenceState(grid, surface_pressure=1e5, potential_temperature=th, standard_pressure=1e5,
+                                             vapor_mass_fraction=qv)
+    Hz, Nz = og.Hz, og.Nz
+    sl = slice(Hz - 1, Hz + Nz + 1)
+    for a in ("pressure", "density", "exner_function"):
+        np.testing.assert_allclose(getattr(rh, a)[sl], getattr(ro, a)[sl], rtol=1e-15, atol=0)

@@ -120,6 +120,63 @@ end
 
 
 ##### ---------------------------------------------------------------------------------------------------------------
+##### Physics attachments of the BOMEX / supercell configurations: the context builder calls these once, right after
+##### bz_create, when the model carries the corresponding component (include/breeze_hip.h, same section names).
+##### ---------------------------------------------------------------------------------------------------------------
+struct BzSmagorinskyLilly
+    smagorinsky_coefficient::Cdouble; reduction_factor::Cdouble; prandtl_number::Cdouble
+end
+
+struct BzColumnForcings
+    u_forcing::Ptr{Cdouble}; v_forcing::Ptr{Cdouble}; theta_forcing::Ptr{Cdouble}; moisture_forcing::Ptr{Cdouble}
+    energy_forcing::Ptr{Cdouble}; subsidence_vertical_velocity::Ptr{Cdouble}
+    subsidence_u::Int32; subsidence_v::Int32; subsidence_theta::Int32; subsidence_moisture::Int32
+    coriolis_f::Cdouble; bottom_theta_flux::Cdouble; bottom_moisture_flux::Cdouble; bottom_drag_rho0_ustar2::Cdouble
+end
+
+struct BzTracerFields
+    density::Ptr{Cdouble}; specific::Ptr{Cdouble}; U0::Ptr{Cdouble}; G::Ptr{Cdouble}
+end
+
+"closure = SmagorinskyLilly(): νₑ is `model.closure_fields.νₑ` (src/AtmosphereModels/atmosphere_model.jl:272-276)."
+function attach_closure!(ctx, closure, νₑ)
+    c = closure.coefficient              # LillyCoefficient(smagorinsky, reduction_factor); Pr from closure.Pr
+    cl = BzSmagorinskyLilly(c.smagorinsky, c.reduction_factor, first(values(closure.Pr)))
+    check(ccall((:bz_set_closure, libbreeze_hip), Cint, (Ptr{Cvoid}, Ref{BzSmagorinskyLilly}, Ptr{Cdouble}),
+                ctx, cl, pointer(parent(νₑ))), "bz_set_closure", ctx)
+end
+
+"""
+Column forcings of examples/bomex.jl:104-207.  `profiles` holds host `Vector{Float64}`s evaluated once from the model's
+materialized forcings (Array(interior(field, 1, 1, :))): geostrophic -f vᵍ / +f uᵍ, Forcing(field) profiles, the subsidence wˢ
+on faces; `flags` says which specific fields carry a SubsidenceForcing; fluxes are the bottom FluxBoundaryCondition values.
+"""
+function attach_forcings!(ctx, profiles::NamedTuple, flags::NamedTuple, f, Jθ, Jq, ρ₀u★²)
+    p(name) = haskey(profiles, name) ? pointer(profiles[name]) : Ptr{Cdouble}(C_NULL)
+    F = BzColumnForcings(p(:u), p(:v), p(:θ), p(:q), p(:e), p(:wˢ),
+                         flags.u, flags.v, flags.θ, flags.q, f, Jθ, Jq, ρ₀u★²)
+    GC.@preserve profiles check(ccall((:bz_set_forcings, libbreeze_hip), Cint, (Ptr{Cvoid}, Ref{BzColumnForcings}), ctx, F),
+                                "bz_set_forcings", ctx)
+end
+
+"tracers = (:a, :b): density = model.tracers[n]; `specific` is an extra centre field owned by the extension."
+function attach_tracers!(ctx, model, specific_fields)
+    ts = model.timestepper
+    t = [BzTracerFields(pointer(parent(model.tracers[n])), pointer(parent(specific_fields[n])),
+                        pointer(parent(ts.U⁰[n])), pointer(parent(ts.Gⁿ[n]))) for n in keys(model.tracers)]
+    check(ccall((:bz_set_tracers, libbreeze_hip), Cint, (Ptr{Cvoid}, Int32, Ptr{BzTracerFields}), ctx, length(t), t),
+          "bz_set_tracers", ctx)
+end
+
+"compute_flux_bc_tendencies!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:418-434)"
+function OceananigansTimeSteppers.compute_flux_bc_tendencies!(model::HIPModel)
+    ctx = context(model)
+    check(ccall((:bz_compute_flux_bc_tendencies, libbreeze_hip), Cint, (Ptr{Cvoid}, Ref{BzState}, Ref{BzPrognostic}),
+                ctx, state(model), prognostic(model.timestepper.Gⁿ)), "bz_compute_flux_bc_tendencies", ctx)
+    return nothing
+end
+
+##### ---------------------------------------------------------------------------------------------------------------
 ##### CompressibleDynamics + SplitExplicitTimeDiscretization (src/TimeSteppers/acoustic_runge_kutta_3.jl,
 ##### src/CompressibleEquations/acoustic_substepping.jl)
 ##### ---------------------------------------------------------------------------------------------------------------

@@ -148,7 +148,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (grid->topo[0] != BZ_PERIODIC || grid->topo[1] != BZ_PERIODIC || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
     if (grid->Hx < 3 || grid->Hy < 3 || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
-    if (grid->Nx < 8 || grid->Ny < 1 || grid->Nz < 6 || (grid->Nx & 1)) return BZ_ERR_UNSUPPORTED;
+    if (grid->Nx < grid->Hx || grid->Ny < 1 || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;      // Oceananigans: N >= H
 
     bz_ctx *ctx = new (std::nothrow) bz_ctx();
     if (!ctx) return BZ_ERR_ALLOC;

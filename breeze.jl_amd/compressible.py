@@ -233,11 +233,15 @@ class CompressibleAtmosphereModel:
         for name, val in (("closure", closure), ("coriolis", coriolis), ("forcing", forcing)):
             if val is not None:
                 raise NotImplementedError(f"{name} is outside the hot-path scope of this build")
-        from .microphysics import DCMIP2016KesslerMicrophysics, TetensFormula
-        if microphysics is not None and not isinstance(microphysics, DCMIP2016KesslerMicrophysics):
-            raise NotImplementedError("compressible microphysics: DCMIP2016KesslerMicrophysics() is implemented")
+        from .microphysics import DCMIP2016KesslerMicrophysics, SaturationAdjustment, TetensFormula
+        if microphysics is not None and not isinstance(microphysics, (DCMIP2016KesslerMicrophysics, SaturationAdjustment)):
+            raise NotImplementedError("compressible microphysics: DCMIP2016KesslerMicrophysics() and "
+                                      "SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) are implemented")
         self.microphysics = microphysics
-        self._kessler = microphysics is not None
+        self._kessler = isinstance(microphysics, DCMIP2016KesslerMicrophysics)
+        self._sa = isinstance(microphysics, SaturationAdjustment)
+        if self._sa and getattr(self, "_pending_decomp", None) is not None:
+            raise NotImplementedError("saturation adjustment on compressible y-slabs is not implemented")
         if self._kessler:      # validate_microphysics (dcmip2016_kessler.jl:196-207)
             tcs = thermodynamic_constants
             if tcs is None or not isinstance(getattr(tcs, "saturation_vapor_pressure", None), TetensFormula):
@@ -316,6 +320,17 @@ class CompressibleAtmosphereModel:
         self._state = self._make_state()
         self._U0, self._G = self._make_prog(self.U0), self._make_prog(self.G)
         self._sub = self.timestepper.substepper.struct()
+        if self._sa:      # materialize_microphysical_fields(::WarmPhaseSaturationAdjustment): (q^v, q^l, q^e); q^e is the moisture slot
+            self.microphysical_fields = {"qᵛ": Field(grid, _LOC["ccc"], self.device), "qˡ": Field(grid, _LOC["ccc"], self.device),
+                                         "qᵉ": self.specific_moisture}
+            sa = _lib.bz_saturation_adjustment(c.liquid_reference_latent_heat, c.liquid_heat_capacity,
+                                               c.energy_reference_temperature, c.triple_point_temperature,
+                                               c.triple_point_pressure, microphysics.solver.abstol,
+                                               microphysics.solver.maxiter, 0)
+            self._check(lib.bz_set_saturation_adjustment(self._ctx, C.byref(sa),
+                                                         C.c_void_p(self.microphysical_fields["qᵛ"].ptr()),
+                                                         C.c_void_p(self.microphysical_fields["qˡ"].ptr())),
+                        "bz_set_saturation_adjustment")
         if self._kessler:
             from .microphysics import kessler_parameter_struct
             μ = self.microphysical_fields

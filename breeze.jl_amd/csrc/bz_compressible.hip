@@ -78,9 +78,13 @@ struct DiagFields {
 // FULL: everything; !FULL: halos of rho_d, rho_theta, momentum + velocities only (tail of acoustic_rk3_substep_loop!)
 // KES: DCMIP2016 Kessler species — total density includes rho q^cl + rho q^r, q = (q^v, q^cl + q^r) in R_m, c_pm and the
 // latent term of the temperature inversion, q^cl / q^r / q^v diagnosed (dcmip2016_kessler.jl:222-227,298-303,860-865)
-template <bool FULL, bool LIN, bool KES = false>
+// MP = 1: SaturationAdjustment(WarmPhaseEquilibrium) on the density-based state — rho q is the total moisture, q^v / q^l are
+// diagnosed by bz_ds_adjust at the cell's own total density and the temperature is the same Newton inversion with the latent
+// term (compressible_time_stepping.jl:191-250; saturation_adjustment.jl:236-301)
+template <bool FULL, bool LIN, int MP = 0>
 __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, double abstol, int maxiter)
 {
+    constexpr bool KES = (MP == 2), SA = (MP == 1);
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
     if (i >= g.Nx) return;
     const long long sz = g.Sxy;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
         cst_img(F.rw, n + sz, 0.0, ox, oy);
         cst_img(F.w, n + sz, 0.0, ox, oy);
     }
-    double r = 0.0, q = 0.0, th = 0.0, T = 0.0, p = 0.0, rq = 0.0, qcl_v = 0.0, qr_v = 0.0;
+    double r = 0.0, q = 0.0, th = 0.0, T = 0.0, p = 0.0, rq = 0.0, qcl_v = 0.0, qr_v = 0.0, sa_qv = 0.0, sa_ql = 0.0;
     if (FULL) {
         rq = F.rq[n];
         double rqcl = 0.0, rqr = 0.0, ql = 0.0;
@@ -132,18 +136,27 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
             qr_v = rqr / r;
             ql = qcl_v + qr_v;
         }
-        const double qd = 1.0 - (q + ql);
-        const double Rm = qd * g.Rd + q * g.Rv;
-        const double cpm = KES ? qd * g.cpd + q * g.cpv + ql * g.sa_cl : qd * g.cpd + q * g.cpv;
-        const double kap = Rm / cpm;
-        const double gam = cpm / (cpm - Rm);
-        const double Lt = KES ? (g.sa_Ll * ql) / cpm : 0.0;
-        T = pow(th, gam) * pow(r * Rm / g.pst, gam - 1.0) + Lt;
-        double dT = T;
-        for (int it = 0; it < maxiter && fabs(dT) > abstol; ++it) {
-            const double Phi = pow(r * Rm * T / g.pst, kap) * th;
-            dT = -(T - Phi - Lt) / (1.0 - kap * Phi / T);
-            T += dT;
+        double qvap = q;        // vapour fraction of the mixture constants (q itself unless the adjustment partitions it)
+        if (SA) {
+            T = bz_ds_adjust(g, th, q, r, abstol, maxiter, qvap, ql);
+            cst_img(g.qv_field, n, qvap, ox, oy);
+            cst_img(g.ql_field, n, ql, ox, oy);
+            sa_qv = qvap; sa_ql = ql;
+        }
+        const double qd = 1.0 - (qvap + ql);
+        const double Rm = qd * g.Rd + qvap * g.Rv;
+        const double cpm = (KES || SA) ? qd * g.cpd + qvap * g.cpv + ql * g.sa_cl : qd * g.cpd + qvap * g.cpv;
+        if (!SA) {
+            const double kap = Rm / cpm;
+            const double gam = cpm / (cpm - Rm);
+            const double Lt = KES ? (g.sa_Ll * ql) / cpm : 0.0;
+            T = pow(th, gam) * pow(r * Rm / g.pst, gam - 1.0) + Lt;
+            double dT = T;
+            for (int it = 0; it < maxiter && fabs(dT) > abstol; ++it) {
+                const double Phi = pow(r * Rm * T / g.pst, kap) * th;
+                dT = -(T - Phi - Lt) / (1.0 - kap * Phi / T);
+                T += dT;
+            }
         }
         p = r * Rm * T;
         if (KES) {
@@ -184,6 +197,10 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
             cst_img(F.q, n + h, q, ox, oy);
             cst_img(F.T, n + h, T, ox, oy);
             cst_img(F.p, n + h, p, ox, oy);
+            if (SA) {
+                cst_img(g.qv_field, n + h, sa_qv, ox, oy);
+                cst_img(g.ql_field, n + h, sa_ql, ox, oy);
+            }
             if (KES) {
                 cst_img(g.rqcl_field, n + h, g.rqcl_field[n], ox, oy);
                 cst_img(g.rqr_field, n + h, g.rqr_field[n], ox, oy);
@@ -206,11 +223,11 @@ __global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k);
     const double rd = rho_d[n];
-    const double q = qv[n];
-    const double ql = (g.microphysics == 2) ? g.qcl_field[n] + g.qr_field[n] : 0.0;
+    const double q = (g.microphysics == 1) ? g.qv_field[n] : qv[n];
+    const double ql = (g.microphysics == 2) ? g.qcl_field[n] + g.qr_field[n] : ((g.microphysics == 1) ? g.ql_field[n] : 0.0);
     const double qd = 1.0 - q - ql;
     const double Rm = qd * g.Rd + q * g.Rv;
-    const double cpm = (g.microphysics == 2) ? qd * g.cpd + q * g.cpv + ql * g.sa_cl : qd * g.cpd + q * g.cpv;
+    const double cpm = g.microphysics ? qd * g.cpd + q * g.cpv + ql * g.sa_cl : qd * g.cpd + q * g.cpv;
     const double P = pow(p[n] / g.pst, g.Rd / g.cpd);
     const double gr = cpm * Rm / (cpm - Rm);
     Pi[n] = P;
@@ -768,15 +785,19 @@ static int bzi_compressible_update_state(bz_ctx *ctx, const bz_compressible_stat
         ProfileScope ps(ctx, with_linearization ? "update_state+linearization" : "update_state");
         DiagFields F = diag_fields(ctx, s, sub);
         dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
-        const bool kes = g.microphysics == 2;
-        if (with_linearization && kes)
-            hipLaunchKernelGGL((k_cmp_diagnose<true, true, true>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
-        else if (with_linearization)
-            hipLaunchKernelGGL((k_cmp_diagnose<true, true>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
-        else if (kes)
-            hipLaunchKernelGGL((k_cmp_diagnose<true, false, true>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
-        else
-            hipLaunchKernelGGL((k_cmp_diagnose<true, false>), grid, block, 0, ctx->stream, g, F, ctx->se.newton_abstol, ctx->se.newton_maxiter);
+        const double na = ctx->se.newton_abstol;
+        const int nm = ctx->se.newton_maxiter;
+#define BZ_DIAG(LIN, MP) hipLaunchKernelGGL((k_cmp_diagnose<true, LIN, MP>), grid, block, 0, ctx->stream, g, F, na, nm)
+        if (with_linearization) {
+            if (g.microphysics == 2) BZ_DIAG(true, 2);
+            else if (g.microphysics == 1) BZ_DIAG(true, 1);
+            else BZ_DIAG(true, 0);
+        } else {
+            if (g.microphysics == 2) BZ_DIAG(false, 2);
+            else if (g.microphysics == 1) BZ_DIAG(false, 1);
+            else BZ_DIAG(false, 0);
+        }
+#undef BZ_DIAG
         BZ_LAUNCH_CHECK();
     }
     if (compute_tendencies) return bz_compute_moisture_tendency(ctx, s, G, sub);

@@ -137,6 +137,63 @@ __device__ __forceinline__ double bz_sa_diagnose(const DevGrid &g, double th, do
     bz_sa_adjust(g, x2, qt, pr, qv, ql);
     return bz_sa_T(g, th, qv, ql, pr);
 }
+// ---- density-based liquid-ice potential temperature state of CompressibleDynamics (LiquidIceDensityState) ----------------------------
+// temperature(::LiquidIceDensityState): Newton on T = (rho R_m T / p_st)^kappa theta + L  (dynamic_states.jl:197-232)
+__device__ __forceinline__ double bz_ds_temperature(const DevGrid &g, double th, double qv, double ql, double rho, double abstol,
+                                                    int maxiter)
+{
+    const double qd = 1.0 - (qv + ql);
+    const double Rm = qd * g.Rd + qv * g.Rv;
+    const double cpm = qd * g.cpd + qv * g.cpv + ql * g.sa_cl;
+    const double kap = Rm / cpm, gam = cpm / (cpm - Rm);
+    const double L = (g.sa_Ll * ql) / cpm;
+    double T = pow(th, gam) * pow(rho * Rm / g.pst, gam - 1.0) + L;
+    double dT = T;
+    for (int it = 0; it < maxiter && fabs(dT) > abstol; ++it) {
+        const double Phi = pow(rho * Rm * T / g.pst, kap) * th;
+        dT = -(T - Phi - L) / (1.0 - kap * Phi / T);
+        T += dT;
+    }
+    return T;
+}
+// saturated_density_residual (saturation_adjustment.jl:236-253): theta^li(T) - theta0 of the state saturated at its own density
+__device__ __forceinline__ double bz_ds_residual(const DevGrid &g, double T, double th0, double rho, double qt, double &qv, double &ql)
+{
+    const double qs = bz_sa_psat(g, T) / (rho * g.Rv * T);
+    ql = fmax(0.0, qt - qs);
+    qv = qt - ql;
+    const double qd = 1.0 - (qv + ql);
+    const double Rm = qd * g.Rd + qv * g.Rv;
+    const double cpm = qd * g.cpd + qv * g.cpv + ql * g.sa_cl;
+    const double L = (g.sa_Ll * ql) / cpm;
+    const double p = rho * Rm * T;
+    return (T - L) * pow(g.pst / p, Rm / cpm) - th0;
+}
+// adjust_thermodynamic_state(::LiquidIceDensityState, ::SaturationAdjustment) (saturation_adjustment.jl:264-301) -> T; sets qv, ql
+__device__ __forceinline__ double bz_ds_adjust(const DevGrid &g, double th, double qt, double rho, double nabstol, int nmaxiter,
+                                               double &qv, double &ql)
+{
+    qv = qt; ql = 0.0;
+    if (th == 0.0) return 0.0;
+    const double T1 = bz_ds_temperature(g, th, qt, 0.0, rho, nabstol, nmaxiter);
+    if (qt <= bz_sa_psat(g, T1) / (rho * g.Rv * T1)) return T1;
+    double qv1, ql1;
+    bz_ds_residual(g, T1, th, rho, qt, qv1, ql1);
+    const double dT = (g.sa_Ll * ql1) / ((1.0 - (qv1 + ql1)) * g.cpd + qv1 * g.cpv + ql1 * g.sa_cl);
+    double x1 = T1, x2 = T1 + fmax(0.01, dT / 2.0);
+    double a, b;
+    double r1 = bz_ds_residual(g, x1, th, rho, qt, a, b), r2 = bz_ds_residual(g, x2, th, rho, qt, a, b);
+    for (int it = 0; it < g.sa_maxiter && fabs(r2) > g.sa_abstol; ++it) {
+        double s = (x2 - x1) / (r2 - r1);
+        const bool valid = isfinite(s);
+        s = valid ? s : 0.0;
+        x1 = x2; r1 = r2;
+        x2 -= r2 * s;
+        r2 = valid ? bz_ds_residual(g, x2, th, rho, qt, a, b) : 0.0;
+    }
+    bz_ds_residual(g, x2, th, rho, qt, qv, ql);
+    return bz_ds_temperature(g, th, qv, ql, rho, nabstol, nmaxiter);
+}
 #endif
 
 struct ProfileSlot {

@@ -116,7 +116,9 @@ typedef struct bz_saturation_adjustment {
     double liquid_latent_heat, liquid_heat_capacity;
     double energy_reference_temperature, triple_point_temperature, triple_point_pressure;
     double abstol;            /* SecantSolver abstol (default 1e-4), reltol = 0 */
-    int32_t maxiter;          /* default 20 */
+    int32_t maxiter;          /* default 20 * On a CompressibleDynamics context (bz_create_compressible) the same call attaches the density-based adjustment
+ * (adjust_thermodynamic_state(::LiquidIceDensityState, ::SaturationAdjustment), src/Microphysics/saturation_adjustment.jl:236-301):
+ * saturation at the cell's own total density, one Newton temperature for dynamics and microphysics. */
     int32_t reserved;
 } bz_saturation_adjustment;
 int bz_set_saturation_adjustment(bz_ctx *ctx, const bz_saturation_adjustment *params, double *q_vapor, double *q_liquid);

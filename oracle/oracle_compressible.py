@@ -154,7 +154,9 @@ class CompressibleOracleModel:
                  standard_pressure=1e5, reference_potential_temperature=288.0, reference_state=True,
                  newton_abstol=1e-4, newton_maxiter=8, microphysics=None, reference_vapor_mass_fraction=None):
         # microphysics "Kessler": DCMIP2016KesslerMicrophysics — rho q^cl, rho q^r prognostic (dcmip2016_kessler.jl:216)
-        assert microphysics in (None, "Kessler")
+        # "SaturationAdjustment": SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) on the density-based state
+        # (saturation_adjustment.jl:236-301); self.q / self.rq hold the total (equilibrium) moisture, self.qv / self.ql the partition
+        assert microphysics in (None, "Kessler", "SaturationAdjustment")
         self.microphysics = microphysics
         self.grid = g = grid
         self.constants = c = constants or Constants()
@@ -184,6 +186,11 @@ class CompressibleOracleModel:
             self.kessler = KesslerParameters()
             self.tetens = TetensConstants(molar_gas_constant=c.R, dry_air_molar_mass=c.Md, vapor_molar_mass=c.Mv,
                                           dry_air_heat_capacity=c.cpd, vapor_heat_capacity=c.cpv)
+        if microphysics == "SaturationAdjustment":
+            from .thermo import ThermoConstants
+            self.qv, self.ql = cf(), cf()
+            self.thermo = ThermoConstants()
+            self.sa_solver = (1e-4, 20)            # SecantSolver(abstol, maxiter) (saturation_adjustment.jl:55-59)
         self.U0 = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
         self.G = {n: np.zeros_like(getattr(self, n)) for n in self.PROGNOSTIC}
         # AcousticSubstepper storage (acoustic_substepping.jl:207-231)
@@ -283,11 +290,14 @@ class CompressibleOracleModel:
         self._halo_w(self.w)
         if kes:
             self._kessler_thermo()
+        elif self.microphysics == "SaturationAdjustment":
+            self._sa_thermo()
         else:
             L.og_compressible_thermo(cg, _p(self.theta), _p(self.q), _p(self.T), _p(self.p), _p(self.rho_d),
                                      _p(self.rho), _p(self.rtheta), _p(self.rq),
                                      C.c_double(self.newton[0]), C.c_int(self.newton[1]))
-        for f in (self.theta, self.q, self.T, self.p) + ((self.qcl, self.qr) if kes else ()):
+        extra = (self.qcl, self.qr) if kes else ((self.qv, self.ql) if self.microphysics == "SaturationAdjustment" else ())
+        for f in (self.theta, self.q, self.T, self.p) + extra:
             self._halo_center(f)
         if compute_tendencies:
             # moisture: total density carrier, acoustic-mean transport velocities
@@ -298,6 +308,22 @@ class CompressibleOracleModel:
             if kes:
                 L.og_scalar_tendency_3d(cg, _p(self.G["rqcl"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qcl))
                 L.og_scalar_tendency_3d(cg, _p(self.G["rqr"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qr))
+
+    def _sa_thermo(self):
+        """maybe_adjust_thermodynamic_state on the LiquidIceDensityState of every cell (theta = rho theta / rho_d, q^t = rho q / rho,
+        total rho), update_microphysical_fields!, then _compute_temperature_and_pressure! with the adjusted fractions — the same
+        Newton inversion, so one temperature (compressible_time_stepping.jl:191-250; saturation_adjustment.jl:236-301)."""
+        from .thermo import adjust_warm_phase_density, mixture_gas_constant
+        g, tc = self.grid, self.thermo
+        I = g.interior
+        rd, r = I(self.rho_d), I(self.rho)
+        th, qt = I(self.rtheta) / rd, I(self.rq) / r
+        I(self.theta)[...], I(self.q)[...] = th, qt
+        T, qv, ql, p = I(self.T), I(self.qv), I(self.ql), I(self.p)
+        for idx in np.ndindex(th.shape):
+            T[idx], qv[idx], ql[idx] = adjust_warm_phase_density(float(th[idx]), float(qt[idx]), float(r[idx]), self.pst, tc,
+                                                                 self.sa_solver[0], self.sa_solver[1], self.newton[0], self.newton[1])
+            p[idx] = r[idx] * mixture_gas_constant(qv[idx], ql[idx], 0.0, tc) * T[idx]
 
     def _kessler_thermo(self):
         """theta, q^v, q^cl, q^r (update_microphysical_auxiliaries!) then _compute_temperature_and_pressure! with the fresh
@@ -341,6 +367,14 @@ class CompressibleOracleModel:
             qd = 1 - qv - ql - 0.0
             Rm = qd * c.Rd + qv * c.Rv
             cpm = qd * c.cpd + qv * c.cpv + ql * t.cl + 0.0 * 0.0
+            I(self.gR)[...] = cpm * Rm / (cpm - Rm)
+        elif self.microphysics == "SaturationAdjustment":
+            g, c, tc = self.grid, self.constants, self.thermo
+            I = g.interior
+            qv, ql = I(self.qv), I(self.ql)
+            qd = 1 - qv - ql - 0.0
+            Rm = qd * c.Rd + qv * c.Rv
+            cpm = qd * c.cpd + qv * c.cpv + ql * tc.cl + 0.0 * 0.0
             I(self.gR)[...] = cpm * Rm / (cpm - Rm)
         for f in (self.Pi, self.thL, self.gR):
             self._halo_center(f)

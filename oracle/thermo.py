@@ -132,3 +132,49 @@ def adjust_warm_phase(theta, qt, pr, pst, c, abstol=1e-4, maxiter=20):
     Ts = secant_solve(residual, T1, T2, T2, abstol=abstol, maxiter=maxiter)
     qv, ql = adjust(Ts)
     return theta_state_temperature(theta, qv, ql, pr, pst, c), qv, ql
+
+
+# ---- density-based liquid-ice potential temperature state (CompressibleDynamics) -----------------------------------------------
+#   LiquidIceDensityState temperature (Newton on T = (rho R_m T / p_st)^kappa theta + L)   src/Thermodynamics/dynamic_states.jl:161-232
+#   saturated_density_residual, adjust_thermodynamic_state(::LiquidIceDensityState, ::SA)    src/Microphysics/saturation_adjustment.jl:236-301
+# Pinned by the reference's known-answer tests test/compressible_saturation_adjustment.jl:31-66 (tests/test_golden_reference.py).
+
+def density_state_temperature(theta, qv, ql, rho, pst, c, abstol=1e-4, maxiter=8):
+    Rm, cpm = mixture_gas_constant(qv, ql, 0.0, c), mixture_heat_capacity(qv, ql, 0.0, c)
+    kap, gam = Rm / cpm, cpm / (cpm - Rm)
+    L = (c.Ll * ql + c.Li * 0.0) / cpm
+    T = theta ** gam * (rho * Rm / pst) ** (gam - 1.0) + L
+
+    def rd(T):
+        Phi = (rho * Rm * T / pst) ** kap * theta
+        return T - Phi - L, 1.0 - kap * Phi / T
+
+    return newton_solve(rd, T, abstol=abstol, maxiter=maxiter)
+
+
+def saturated_density_residual(T, theta0, rho, qt, pst, c):
+    qs = saturation_specific_humidity(T, rho, c, "liquid")
+    ql = max(0, qt - qs)
+    qv = qt - ql
+    Rm, cpm = mixture_gas_constant(qv, ql, 0.0, c), mixture_heat_capacity(qv, ql, 0.0, c)
+    kap = Rm / cpm
+    L = (c.Ll * ql + c.Li * 0.0) / cpm
+    p = rho * Rm * T
+    theta = (T - L) * (pst / p) ** kap
+    return theta - theta0, (qv, ql)
+
+
+def adjust_warm_phase_density(theta, qt, rho, pst, c, abstol=1e-4, maxiter=20, newton_abstol=1e-4, newton_maxiter=8):
+    """adjust_thermodynamic_state(LiquidIceDensityState, SaturationAdjustment(WarmPhaseEquilibrium)) -> (T, qv, ql)."""
+    if theta == 0:
+        return 0.0, qt, 0.0
+    T1 = density_state_temperature(theta, qt, 0.0, rho, pst, c, newton_abstol, newton_maxiter)
+    if qt <= saturation_specific_humidity(T1, rho, c, "liquid"):
+        return T1, qt, 0.0
+    _, (qv1, ql1) = saturated_density_residual(T1, theta, rho, qt, pst, c)
+    dT = (c.Ll * ql1 + c.Li * 0.0) / mixture_heat_capacity(qv1, ql1, 0.0, c)
+    T2 = T1 + max(0.01, dT / 2)
+    residual = lambda T: saturated_density_residual(T, theta, rho, qt, pst, c)[0]
+    Ts = secant_solve(residual, T1, T2, T2, abstol=abstol, maxiter=maxiter)
+    _, (qv, ql) = saturated_density_residual(Ts, theta, rho, qt, pst, c)
+    return density_state_temperature(theta, qv, ql, rho, pst, c, newton_abstol, newton_maxiter), qv, ql

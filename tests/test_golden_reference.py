@@ -4,6 +4,7 @@ prints a full Float64, 10 digits where it prints a rounded value.  No GPU needed
 import json
 import os
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -95,3 +96,42 @@ def test_field_level_adjustment_matches_scalar_restatement(oracle, thermo):
         m.time_step(2.0)
     assert np.isfinite(I(m.T)).all() and (I(m.ql) >= 0).all()
     np.testing.assert_allclose(I(m.qv) + I(m.ql), I(m.q), rtol=1e-14)
+
+
+def test_density_based_saturation_adjustment_reference_known_answers(thermo):
+    """test/compressible_saturation_adjustment.jl:54-74: a supersaturated all-vapour parcel (theta = 300 K, rho = 1 kg/m3,
+    q^t = 0.020) condenses onto the saturation curve evaluated at its OWN density (atol 1e-5), theta^li is conserved by the
+    self-consistent inversion, and a subsaturated parcel (q^t = 0.002) is left alone."""
+    c = thermo.ThermoConstants()
+    T, qv, ql = thermo.adjust_warm_phase_density(300.0, 0.020, 1.0, 1e5, c)
+    assert ql > 0
+    assert qv == pytest.approx(thermo.saturation_specific_humidity(T, 1.0, c, "liquid"), abs=1e-5)
+    Rm, cpm = thermo.mixture_gas_constant(qv, ql, 0.0, c), thermo.mixture_heat_capacity(qv, ql, 0.0, c)
+    theta_back = (T - c.Ll * ql / cpm) * (1e5 / (1.0 * Rm * T)) ** (Rm / cpm)
+    assert theta_back == pytest.approx(300.0, rel=1e-9)
+    Td, qvd, qld = thermo.adjust_warm_phase_density(300.0, 0.002, 1.0, 1e5, c)
+    assert qld == 0.0 and qvd == 0.002
+
+
+def test_moist_compressible_update_state_is_density_consistent(oracle):
+    """test/compressible_saturation_adjustment.jl:114-148: 8^3 cells over 2 km, theta_ref(z) = 300 exp(g z / (c_p 300)),
+    rho = reference density, theta = 300, q^t = 0.030: condensation occurs and in every saturated cell q^v sits on the
+    saturation curve at the cell's own total density (atol 1e-4); one tiny step stays finite."""
+    from oracle import oracle_compressible as oc
+    from oracle import thermo as th
+    g = oracle.Grid((8, 8, 8), x=(0, 2e3), y=(0, 2e3), z=(0, 2e3))
+    thref = lambda z: 300.0 * np.exp(9.80616 * z / (1005 * 300.0))
+    m = oc.CompressibleOracleModel(g, time_discretization=oc.SplitExplicit(), surface_pressure=1e5,
+                                   reference_potential_temperature=thref, microphysics="SaturationAdjustment")
+    rho = m.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    m.set(rho=rho, theta=300.0, qv=0.030, u=0.0, v=0.0, w=0.0)
+    I = g.interior
+    T, p, r, ql, qv = I(m.T), I(m.p), I(m.rho), I(m.ql), I(m.qv)
+    assert np.isfinite(T).all() and (T > 0).all() and np.isfinite(p).all() and (p > 0).all()
+    assert ql.max() > 0
+    tc = th.ThermoConstants()
+    for idx in np.ndindex(T.shape):
+        if ql[idx] > 1e-6:
+            assert qv[idx] == pytest.approx(th.saturation_specific_humidity(T[idx], r[idx], tc, "liquid"), abs=1e-4)
+    m.time_step(1e-3)
+    assert np.isfinite(I(m.T)).all()

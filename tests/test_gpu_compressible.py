@@ -367,3 +367,43 @@ def test_compressible_kessler_on_moist_reference_matches_oracle(oracle, oc, bz):
         hm.time_step(2.0)
     cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rw", "T", "p"), 1e-8)
     assert np.abs(og.interior(om.rw, True)).max() > 1e-3
+
+
+def test_compressible_saturation_adjustment_matches_oracle(oracle, oc, bz):
+    """CompressibleDynamics + SaturationAdjustment(WarmPhaseEquilibrium): the density-based adjustment (q^v on the saturation
+    curve at the cell's own total density), one Newton temperature for dynamics and microphysics, gamma R_m with the liquid
+    fraction; the reference's integration scenario (test/compressible_saturation_adjustment.jl:114-148) plus two full steps."""
+    from oracle import thermo as th_mod
+    size = (16, 12, 12)
+    extent = dict(x=(0.0, 4e3), y=(0.0, 3e3), z=(0.0, 3e3))
+    thref = lambda z: 300.0 * np.exp(9.80616 * z / (1005 * 300.0))
+    og = oracle.Grid(size, **extent)
+    om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), surface_pressure=1e5,
+                                    reference_potential_temperature=thref, microphysics="SaturationAdjustment")
+    grid = bz.RectilinearGrid(size, **extent)
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), surface_pressure=1e5, reference_potential_temperature=thref)
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5),
+                                        microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()))
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt((x - 2e3) ** 2 + (y - 1.5e3) ** 2 + (z - 1200.0) ** 2) / 900.0)
+    th = lambda x, y, z: 300.0 + 0.5 * bub(x, y, z) + 0 * z
+    qt = lambda x, y, z: 0.012 + 0.014 * bub(x, y, z) + 0.004 * (z / 3e3)
+    rho = om.ref.density[og.Hz:og.Hz + og.Nz][:, None, None]
+    om.set(rho=rho, theta=th, u=2.0, v=0.0, w=0.0, qv=qt)
+    hm.set(ρ=rho, θ=th, u=2.0, v=0.0, w=0.0, qᵗ=qt)
+    μ = hm.microphysical_fields
+    g = om.grid
+    ql = g.interior(om.ql)
+    assert 0.02 < (ql > 0).mean() < 0.98           # cloudy and clear cells
+    cmp_interior(om, hm, ("rho_d", "rho", "rtheta", "rq", "T", "p"), 1e-12)
+    assert np.abs(μ["qˡ"].interior_cpu() - ql).max() < 1e-13
+    assert np.abs(μ["qᵛ"].interior_cpu() - g.interior(om.qv)).max() < 1e-13
+    # the reference's own check on the device fields: q^v on the saturation curve at the cell's density in saturated cells
+    tc = th_mod.ThermoConstants()
+    T, r, qv = hm.temperature.interior_cpu(), hm.dynamics.total_density.interior_cpu(), μ["qᵛ"].interior_cpu()
+    for idx in zip(*np.nonzero(μ["qˡ"].interior_cpu() > 1e-6)):
+        assert abs(qv[idx] - th_mod.saturation_specific_humidity(T[idx], r[idx], tc, "liquid")) < 1e-4
+    for _ in range(2):
+        om.time_step(1.0)
+        hm.time_step(1.0)
+    cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rw", "T", "p"), 1e-8)
+    assert np.abs(μ["qˡ"].interior_cpu() - g.interior(om.ql)).max() < 1e-9

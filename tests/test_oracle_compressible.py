@@ -260,3 +260,34 @@ def test_host_moist_exner_reference_state_equals_oracle(oracle, oc, bz):
     sl = slice(Hz - 1, Hz + Nz + 1)
     for a in ("pressure", "density", "exner_function"):
         np.testing.assert_allclose(getattr(rh, a)[sl], getattr(ro, a)[sl], rtol=1e-15, atol=0)
+
+
+def test_density_based_temperature_inversion_reference_known_answers(oracle, oc):
+    """test/compressible_saturation_adjustment.jl:31-44,76-96 (NumericalEarth/Breeze.jl#765): the density-based theta^li -> T
+    inversion is the self-consistent fixed point T = (rho R_m T / p_st)^kappa theta + L (rtol 1e-9 with the default Newton
+    solver), lies above the non-iterated closed form theta^gamma (rho R_m / p_st)^(gamma-1) + L by about 1.39 kappa L
+    (rtol 0.15), and reduces to the closed form without condensate."""
+    g = oracle.Grid((4, 4, 4), x=(0, 400.0), y=(0, 400.0), z=(0, 400.0))
+    m = oc.CompressibleOracleModel(g, time_discretization=oc.SplitExplicit(substeps=2), surface_pressure=1e5,
+                                   reference_potential_temperature=300.0, microphysics="Kessler")
+    I = g.interior
+    c, t = m.constants, m.tetens
+    for qv, ql in ((0.020, 0.0), (0.018, 0.005)):
+        rho = 1.0
+        I(m.rho_d)[...] = rho * (1 - qv - ql)
+        I(m.rq)[...], I(m.rqcl)[...], I(m.rqr)[...] = rho * qv, rho * ql, 0.0
+        I(m.rtheta)[...] = I(m.rho_d) * 300.0
+        m.update_state(compute_tendencies=False)
+        T, th, r = I(m.T)[1, 1, 1], I(m.theta)[1, 1, 1], I(m.rho)[1, 1, 1]
+        assert th == pytest.approx(300.0, rel=1e-15) and r == pytest.approx(1.0, rel=1e-15)
+        Rm = (1 - qv - ql) * c.Rd + qv * c.Rv
+        cpm = (1 - qv - ql) * c.cpd + qv * c.cpv + ql * t.cl
+        kap, gam = Rm / cpm, cpm / (cpm - Rm)
+        L = t.Ll * ql / cpm
+        assert T == pytest.approx((r * Rm * T / 1e5) ** kap * th + L, rel=1e-9)
+        T_noniter = th ** gam * (r * Rm / 1e5) ** (gam - 1) + L
+        if ql == 0.0:
+            assert T == pytest.approx(T_noniter, rel=1e-9)
+        else:
+            assert T > T_noniter
+            assert T - T_noniter == pytest.approx(1.39 * kap * L, rel=0.15)

@@ -111,14 +111,15 @@ int bz_set_formulation(bz_ctx *ctx, int formulation);
  * rho q^e (bz_state.rho_q / q), T comes from the secant iteration on the adjusted state, and q^v, q^l are diagnosed into
  * model.microphysical_fields.q^v / q^l (device parent arrays given here), which the buoyancy then reads
  * (grid_moisture_fractions, :127-131).  Constants: liquid CondensedPhase, energy reference temperature and triple point of
- * ThermodynamicConstants (src/Thermodynamics/thermodynamics_constants.jl:92,182-194).  params == NULL: microphysics = nothing. */
+ * ThermodynamicConstants (src/Thermodynamics/thermodynamics_constants.jl:92,182-194).  params == NULL: microphysics = nothing.
+ * On a CompressibleDynamics context (bz_create_compressible) the same call attaches the density-based adjustment
+ * (adjust_thermodynamic_state(::LiquidIceDensityState, ::SaturationAdjustment), src/Microphysics/saturation_adjustment.jl:236-301):
+ * saturation at the cell's own total density, one Newton temperature for dynamics and microphysics. */
 typedef struct bz_saturation_adjustment {
     double liquid_latent_heat, liquid_heat_capacity;
     double energy_reference_temperature, triple_point_temperature, triple_point_pressure;
     double abstol;            /* SecantSolver abstol (default 1e-4), reltol = 0 */
-    int32_t maxiter;          /* default 20 * On a CompressibleDynamics context (bz_create_compressible) the same call attaches the density-based adjustment
- * (adjust_thermodynamic_state(::LiquidIceDensityState, ::SaturationAdjustment), src/Microphysics/saturation_adjustment.jl:236-301):
- * saturation at the cell's own total density, one Newton temperature for dynamics and microphysics. */
+    int32_t maxiter;          /* default 20 */
     int32_t reserved;
 } bz_saturation_adjustment;
 int bz_set_saturation_adjustment(bz_ctx *ctx, const bz_saturation_adjustment *params, double *q_vapor, double *q_liquid);

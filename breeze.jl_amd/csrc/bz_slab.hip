@@ -49,6 +49,45 @@ extern "C" int bz_spectral_tridiagonal_solve(bz_ctx *ctx, double *hat, double sc
     return BZ_OK;
 }
 
+// Transposing pack of the distributed transform: out[k][b][a] = in[k][a][c0 + b] for a < A, b < B (zero where c0 + b >= valid),
+// complex Float64.  `in` is (Nz, A, ld), `out` (Nz, B, A).  32 x 32 tiles through LDS so that both the read (along the last
+// axis of `in`) and the write (along the last axis of `out`) are coalesced; this replaces the strided elementwise copy of
+// tensor.permute(0, 2, 1).contiguous(), measured at 2 TB/s, and the zero padding of the half spectrum.
+__global__ __launch_bounds__(256) void k_pack_transpose(const double2 *__restrict__ in, double2 *__restrict__ out, int A, int ld,
+                                                        int c0, int B, int valid)
+{
+    __shared__ double2 tile[32][33];
+    const int k = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const double2 *src = in + (long long)k * A * ld;
+    double2 *dst = out + (long long)k * B * A;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int a = a0 + ty + r, b = b0 + tx;
+        double2 v = make_double2(0.0, 0.0);
+        if (a < A && b < B && c0 + b < valid) v = src[(long long)a * ld + c0 + b];
+        tile[ty + r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int b = b0 + ty + r, a = a0 + tx;
+        if (a < A && b < B) dst[(long long)b * A + a] = tile[tx][ty + r];
+    }
+}
+
+extern "C" int bz_pack_transpose(bz_ctx *ctx, const double *in, double *out, int32_t Nz, int32_t A, int32_t ld, int32_t c0,
+                                 int32_t B, int32_t valid)
+{
+    if (!ctx || !in || !out || Nz < 1 || A < 1 || B < 1 || ld < 1 || c0 < 0) return BZ_ERR_INVALID;
+    ProfileScope ps(ctx, "poisson_transpose_pack");
+    hipLaunchKernelGGL(k_pack_transpose, dim3((B + 31) / 32, (A + 31) / 32, Nz), dim3(256), 0, ctx->stream,
+                       (const double2 *)in, (double2 *)out, A, ld, c0, B, valid);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
 extern "C" int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below,
                                        double dt)
 {

@@ -47,6 +47,20 @@ class SlabDecomposition:
         self.lower = (rank - 1) % world
         if Ny_local < Hy:
             raise ValueError("a slab must hold at least Hy rows")
+        # optional device kernel for the transposing packs: pack(src (Nz, A, ld) complex, c0, B, valid) -> (Nz, B, A) complex
+        # (SlabAtmosphereModel installs bz_pack_transpose; CPU backends use the torch expression)
+        self.pack = None
+
+    def _pack(self, T, c0, B, valid=None):
+        """(Nz, A, ld) complex -> contiguous (Nz, B, A) with out[k, b, a] = T[k, a, c0 + b] (zero for c0 + b >= valid)."""
+        import torch
+        valid = T.shape[2] if valid is None else valid
+        if self.pack is not None:
+            return self.pack(T, c0, B, valid)
+        blk = T[:, :, c0:min(c0 + B, valid)]
+        if blk.shape[2] < B:
+            blk = torch.nn.functional.pad(blk, (0, B - blk.shape[2]))
+        return blk.permute(0, 2, 1).contiguous()
 
     # -- point-to-point helper -------------------------------------------------
     def _p2p(self, sends, recvs):
@@ -97,12 +111,12 @@ class SlabDecomposition:
     # column index run along contiguous memory (a strided torch.fft.ifft along dim 1 costs 7.9 ms at 512^3 on
     # MI355X, the contiguous one 0.8 ms).  The transposition rides on the pack copy that the exchange needs anyway.
     def to_kx_slabs(self, R):
-        """(Nz, Ny_local, nxh_pad) complex, y-slab  ->  (Nz, nkx, Ny_global) complex, kx-slab."""
+        """(Nz, Ny_local, nxh) complex, y-slab  ->  (Nz, nkx, Ny_global) complex, kx-slab (columns >= nxh are the zero padding)."""
         import torch
         Nz, Ny, nkx, W = self.Nz, self.Ny, self.nkx, self.world
         if W == 1:
-            return R.permute(0, 2, 1).contiguous()
-        send = [torch.view_as_real(R[:, :, p * nkx:(p + 1) * nkx].permute(0, 2, 1).contiguous()) for p in range(W)]
+            return self._pack(R, 0, nkx, self.nxh)
+        send = [torch.view_as_real(self._pack(R, p * nkx, nkx, self.nxh)) for p in range(W)]
         recv = [torch.empty_like(send[0]) for _ in range(W)]          # (Nz, nkx, Ny_local, 2) from each rank
         recv[self.rank].copy_(send[self.rank])
         peers = [p for p in range(W) if p != self.rank]
@@ -114,8 +128,8 @@ class SlabDecomposition:
         import torch
         Ny, W = self.Ny, self.world
         if W == 1:
-            return S.permute(0, 2, 1).contiguous()
-        send = [torch.view_as_real(S[:, :, q * Ny:(q + 1) * Ny].permute(0, 2, 1).contiguous()) for q in range(W)]
+            return self._pack(S, 0, Ny)
+        send = [torch.view_as_real(self._pack(S, q * Ny, Ny)) for q in range(W)]
         recv = [torch.empty_like(send[0]) for _ in range(W)]          # (Nz, Ny_local, nkx, 2) from each rank
         recv[self.rank].copy_(send[self.rank])
         peers = [p for p in range(W) if p != self.rank]
@@ -143,15 +157,15 @@ class SlabStepper:
     def poisson_solve(self, rhs):
         import torch
         d = self.decomp
-        R = torch.fft.rfft(rhs, dim=2)                                  # local x transform
-        if d.nxh_pad != d.nxh:
-            R = torch.nn.functional.pad(R, (0, d.nxh_pad - d.nxh))
-        S = d.to_kx_slabs(R)                                            # (Nz, nkx, Ny_global)
+        R = torch.fft.rfft(rhs, dim=2)                                  # local x transform, (Nz, Ny, nxh)
+        S = d.to_kx_slabs(R)                                            # (Nz, nkx, Ny_global); the pack pads kx >= nxh with zeros
         S = torch.fft.fft(S, dim=2)                                     # y transform, contiguous, all rows present
-        self.local_spectral_solve(S)
-        S = torch.fft.ifft(S, dim=2)
+        # the inverse transforms run unnormalised (norm="forward": no scaling pass over the data); 1/(Nx Ny) rides on the
+        # right-hand side inside the tridiagonal kernel
+        self.local_spectral_solve(S, 1.0 / (d.Nx * d.Ny_global))
+        S = torch.fft.ifft(S, dim=2, norm="forward")
         R = d.to_y_slabs(S)
-        return torch.fft.irfft(R[:, :, :d.nxh], n=d.Nx, dim=2).contiguous()
+        return torch.fft.irfft(R[:, :, :d.nxh], n=d.Nx, dim=2, norm="forward").contiguous()
 
     fused_rk = False      # backend folds the RK update into its tendency kernels (predictor momentum in separate arrays)
 
@@ -252,6 +266,8 @@ class SlabAtmosphereModel(SlabStepper):
             raise _lib.BreezeHIPError(f"bz_create_slab failed with code {rc}")
         self._check(lib.bz_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "bz_set_stream")
         self._state, self._U0, self._G = self._make_state(), self._make_prog(self.U0), self._make_prog(self.G)
+        if getattr(self.decomp, "pack", None) is None and hasattr(self.decomp, "_pack"):
+            self.decomp.pack = self._device_pack
         self.set(θ=ref.potential_temperature)
 
     # plumbing shared with AtmosphereModel -------------------------------------------------
@@ -337,10 +353,20 @@ class SlabAtmosphereModel(SlabStepper):
                         "bz_poisson_source_term")
         return rhs
 
-    def local_spectral_solve(self, S):
+    def local_spectral_solve(self, S, scale=1.0):
         assert S.is_contiguous()
-        self._check(self._lib.bz_spectral_tridiagonal_solve(self._ctx, C.c_void_p(S.data_ptr()), 1.0),
+        self._check(self._lib.bz_spectral_tridiagonal_solve(self._ctx, C.c_void_p(S.data_ptr()), float(scale)),
                     "bz_spectral_tridiagonal_solve")
+
+    def _device_pack(self, T, c0, B, valid):
+        import torch
+        assert T.is_contiguous() and T.dtype == torch.complex128
+        Nz, A, ld = T.shape
+        out = torch.empty((Nz, B, A), dtype=torch.complex128, device=T.device)
+        self._check(self._lib.bz_pack_transpose(self._ctx, C.c_void_p(T.data_ptr()), C.c_void_p(out.data_ptr()), Nz, A, ld,
+                                                int(c0), int(B), int(valid)), "bz_pack_transpose")
+        self._keep_pack = T          # the source must outlive the enqueued kernel
+        return out
 
     def local_project_diagnose(self, phi, below, dt, predictor=False):
         assert phi.is_contiguous()

@@ -186,6 +186,10 @@ int bz_poisson_source_term(bz_ctx *ctx, const bz_state *s, double dt, double *rh
 /* Thomas solve along z of every horizontal wavenumber of this rank's spectral block, in place; `scale` multiplies
  * the right-hand side (inverse-transform normalisation); the (0,0) column gets its z-mean removed. */
 int bz_spectral_tridiagonal_solve(bz_ctx *ctx, double *hat, double scale);
+/* Transposing pack of the distributed transform (complex Float64, interleaved re/im): in is (Nz, A, ld), out (Nz, B, A),
+ * out[k][b][a] = in[k][a][c0 + b], zero where c0 + b >= valid.  One call per destination rank builds its send block. */
+int bz_pack_transpose(bz_ctx *ctx, const double *in, double *out, int32_t Nz, int32_t A, int32_t ld, int32_t c0, int32_t B,
+                      int32_t valid);
 /* make_pressure_correction! + compute_velocities! + thermodynamic diagnosis + x/z halo fills in one pass from the
  * contiguous solution phi_c (Nx*Ny*Nz); phi_below = phi of row j = -1, layout [k][i] (slab mode; else NULL). */
 int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below, double dt);

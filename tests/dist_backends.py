@@ -56,9 +56,9 @@ def make_oracle_slab(orc, bz_dist, size, extent, rank, world, theta0=300.0, grou
             self.lib.og_poisson_source(C.byref(self.cg), orc._p(rhs), orc._p(self.ru), orc._p(self.rv), orc._p(self.rw), C.c_double(dt))
             return torch.from_numpy(rhs)
 
-        def local_spectral_solve(self, S):
+        def local_spectral_solve(self, S, scale=1.0):
             d = self.decomp
-            f = np.ascontiguousarray(S.permute(0, 2, 1).numpy())       # oracle layout: [k][ky][kx]
+            f = np.ascontiguousarray(S.permute(0, 2, 1).numpy()) * scale       # oracle layout: [k][ky][kx]; scale = 1/(Nx Ny)
             out = np.zeros_like(f)
             scratch = np.zeros(f.shape)
             dp = C.POINTER(C.c_double)

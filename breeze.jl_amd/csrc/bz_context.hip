@@ -77,6 +77,11 @@ extern "C" int bz_set_stream(bz_ctx *ctx, void *hip_stream)
         BZ_FFT(hipfftSetStream(ctx->plan_fwd, ctx->stream));
         BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
     }
+    if (ctx->slab_plans_ok) {
+        BZ_FFT(hipfftSetStream(ctx->slab_plan_x_fwd, ctx->stream));
+        BZ_FFT(hipfftSetStream(ctx->slab_plan_x_inv, ctx->stream));
+        BZ_FFT(hipfftSetStream(ctx->slab_plan_y, ctx->stream));
+    }
     return BZ_OK;
 }
 

@@ -216,6 +216,10 @@ struct bz_ctx {
     int NXH = 0;                      // Nx/2+1
     hipfftHandle plan_fwd = 0, plan_inv = 0;
     bool plans_ok = false;
+    // y-slab mode: 1-D batched plans of the distributed transform (bz_slab_transform, created on first use)
+    hipfftHandle slab_plan_x_fwd = 0, slab_plan_x_inv = 0, slab_plan_y = 0;
+    bool slab_plans_ok = false;
+    int slab_inv_ld = 0;              // leading dimension (complex elements per row) the inverse x plan was built for
     double *d_rhs = nullptr;          // Nx*Ny*Nz real (source term, then inverse-transform output)
     hipfftDoubleComplex *d_hat = nullptr;   // NXH*Ny*Nz
     double *d_ibeta = nullptr;        // NXH*Ny*Nz : 1/beta_k

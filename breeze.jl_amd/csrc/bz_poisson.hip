@@ -197,6 +197,12 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
 
 void bzi_poisson_teardown(bz_ctx *ctx)
 {
+    if (ctx->slab_plans_ok) {
+        hipfftDestroy(ctx->slab_plan_x_fwd);
+        hipfftDestroy(ctx->slab_plan_x_inv);
+        hipfftDestroy(ctx->slab_plan_y);
+        ctx->slab_plans_ok = false;
+    }
     if (ctx->plans_ok) {
         hipfftDestroy(ctx->plan_fwd);
         hipfftDestroy(ctx->plan_inv);

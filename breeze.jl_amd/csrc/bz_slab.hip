@@ -88,6 +88,52 @@ extern "C" int bz_pack_transpose(bz_ctx *ctx, const double *in, double *out, int
     return BZ_OK;
 }
 
+// The four local transforms of the distributed Poisson solve as 1-D batched rocFFT plans (no normalisation anywhere; 1/(Nx Ny)
+// rides on bz_spectral_tridiagonal_solve's scale):
+//   which 0  x forward   rhs (Nz, Ny, Nx) real            -> out (Nz, Ny, Nx/2+1) complex
+//   which 1  y forward   in place on (Nz, nkx, Ny_global) complex (in == out)
+//   which 2  y backward  in place
+//   which 3  x backward  in (Nz, Ny, ld) complex, ld >= Nx/2+1 (the padded half spectrum) -> out (Nz, Ny, Nx) real; destroys `in`
+static int slab_plans(bz_ctx *ctx, int ld)
+{
+    const DevGrid &g = ctx->dg;
+    if (ctx->slab_plans_ok && ctx->slab_inv_ld == ld) return BZ_OK;
+    if (ctx->slab_plans_ok) {
+        hipfftDestroy(ctx->slab_plan_x_fwd); hipfftDestroy(ctx->slab_plan_x_inv); hipfftDestroy(ctx->slab_plan_y);
+        ctx->slab_plans_ok = false;
+    }
+    const int nxh = g.Nx / 2 + 1;
+    int nx[1] = {g.Nx}, ny[1] = {ctx->Ny_global};
+    int real_embed[1] = {g.Nx}, half_embed[1] = {nxh}, pad_embed[1] = {ld}, y_embed[1] = {ctx->Ny_global};
+    BZ_FFT(hipfftPlanMany(&ctx->slab_plan_x_fwd, 1, nx, real_embed, 1, g.Nx, half_embed, 1, nxh, HIPFFT_D2Z, g.Nz * g.Ny));
+    BZ_FFT(hipfftPlanMany(&ctx->slab_plan_x_inv, 1, nx, pad_embed, 1, ld, real_embed, 1, g.Nx, HIPFFT_Z2D, g.Nz * g.Ny));
+    BZ_FFT(hipfftPlanMany(&ctx->slab_plan_y, 1, ny, y_embed, 1, ctx->Ny_global, y_embed, 1, ctx->Ny_global, HIPFFT_Z2Z, g.Nz * ctx->NXH));
+    BZ_FFT(hipfftSetStream(ctx->slab_plan_x_fwd, ctx->stream));
+    BZ_FFT(hipfftSetStream(ctx->slab_plan_x_inv, ctx->stream));
+    BZ_FFT(hipfftSetStream(ctx->slab_plan_y, ctx->stream));
+    ctx->slab_plans_ok = true;
+    ctx->slab_inv_ld = ld;
+    return BZ_OK;
+}
+
+extern "C" int bz_slab_transform(bz_ctx *ctx, int32_t which, double *in, double *out, int32_t ld)
+{
+    if (!ctx || !in || !out || which < 0 || which > 3) return BZ_ERR_INVALID;
+    if (!ctx->slab_mode) { ctx->last_error = "bz_slab_transform: y-slab contexts only"; return BZ_ERR_UNSUPPORTED; }
+    const int nxh = ctx->dg.Nx / 2 + 1;
+    if (which == 3 && ld < nxh) return BZ_ERR_INVALID;
+    int rc = slab_plans(ctx, which == 3 ? ld : (ctx->slab_plans_ok ? ctx->slab_inv_ld : nxh));
+    if (rc) return rc;
+    ProfileScope ps(ctx, which == 0 ? "poisson_fft_x_forward" : (which == 3 ? "poisson_fft_x_inverse" : "poisson_fft_y"));
+    switch (which) {
+        case 0: BZ_FFT(hipfftExecD2Z(ctx->slab_plan_x_fwd, in, (hipfftDoubleComplex *)out)); break;
+        case 1: BZ_FFT(hipfftExecZ2Z(ctx->slab_plan_y, (hipfftDoubleComplex *)in, (hipfftDoubleComplex *)out, HIPFFT_FORWARD)); break;
+        case 2: BZ_FFT(hipfftExecZ2Z(ctx->slab_plan_y, (hipfftDoubleComplex *)in, (hipfftDoubleComplex *)out, HIPFFT_BACKWARD)); break;
+        default: BZ_FFT(hipfftExecZ2D(ctx->slab_plan_x_inv, (hipfftDoubleComplex *)in, out)); break;
+    }
+    return BZ_OK;
+}
+
 extern "C" int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below,
                                        double dt)
 {

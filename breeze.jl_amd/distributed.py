@@ -157,14 +157,28 @@ class SlabStepper:
     def poisson_solve(self, rhs):
         import torch
         d = self.decomp
-        R = torch.fft.rfft(rhs, dim=2)                                  # local x transform, (Nz, Ny, nxh)
+        R = self.fft_x_forward(rhs)                                     # local x transform, (Nz, Ny, nxh)
         S = d.to_kx_slabs(R)                                            # (Nz, nkx, Ny_global); the pack pads kx >= nxh with zeros
-        S = torch.fft.fft(S, dim=2)                                     # y transform, contiguous, all rows present
-        # the inverse transforms run unnormalised (norm="forward": no scaling pass over the data); 1/(Nx Ny) rides on the
-        # right-hand side inside the tridiagonal kernel
+        S = self.fft_y(S, inverse=False)                                # y transform, contiguous, all rows present
+        # the inverse transforms run unnormalised (no scaling pass over the data); 1/(Nx Ny) rides on the right-hand side
+        # inside the tridiagonal kernel
         self.local_spectral_solve(S, 1.0 / (d.Nx * d.Ny_global))
-        S = torch.fft.ifft(S, dim=2, norm="forward")
+        S = self.fft_y(S, inverse=True)
         R = d.to_y_slabs(S)
+        return self.fft_x_inverse(R)
+
+    # local transforms: torch.fft by default (any device; the CPU tests), rocFFT plans of the C library on the GPU backend
+    def fft_x_forward(self, rhs):
+        import torch
+        return torch.fft.rfft(rhs, dim=2)
+
+    def fft_y(self, S, inverse):
+        import torch
+        return torch.fft.ifft(S, dim=2, norm="forward") if inverse else torch.fft.fft(S, dim=2)
+
+    def fft_x_inverse(self, R):
+        import torch
+        d = self.decomp
         return torch.fft.irfft(R[:, :, :d.nxh], n=d.Nx, dim=2, norm="forward").contiguous()
 
     fused_rk = False      # backend folds the RK update into its tendency kernels (predictor momentum in separate arrays)
@@ -357,6 +371,32 @@ class SlabAtmosphereModel(SlabStepper):
         assert S.is_contiguous()
         self._check(self._lib.bz_spectral_tridiagonal_solve(self._ctx, C.c_void_p(S.data_ptr()), float(scale)),
                     "bz_spectral_tridiagonal_solve")
+
+    def fft_x_forward(self, rhs):
+        import torch
+        d = self.decomp
+        assert rhs.is_contiguous()
+        out = torch.empty((d.Nz, d.Ny, d.nxh), dtype=torch.complex128, device=rhs.device)
+        self._check(self._lib.bz_slab_transform(self._ctx, 0, C.c_void_p(rhs.data_ptr()), C.c_void_p(out.data_ptr()), 0),
+                    "bz_slab_transform")
+        self._keep_fft = rhs
+        return out
+
+    def fft_y(self, S, inverse):
+        assert S.is_contiguous()
+        self._check(self._lib.bz_slab_transform(self._ctx, 2 if inverse else 1, C.c_void_p(S.data_ptr()), C.c_void_p(S.data_ptr()), 0),
+                    "bz_slab_transform")
+        return S
+
+    def fft_x_inverse(self, R):
+        import torch
+        d = self.decomp
+        assert R.is_contiguous() and R.shape[2] >= d.nxh
+        out = torch.empty((d.Nz, d.Ny, d.Nx), dtype=torch.float64, device=R.device)
+        self._check(self._lib.bz_slab_transform(self._ctx, 3, C.c_void_p(R.data_ptr()), C.c_void_p(out.data_ptr()), int(R.shape[2])),
+                    "bz_slab_transform")
+        self._keep_fft = R
+        return out
 
     def _device_pack(self, T, c0, B, valid):
         import torch

@@ -190,6 +190,10 @@ int bz_spectral_tridiagonal_solve(bz_ctx *ctx, double *hat, double scale);
  * out[k][b][a] = in[k][a][c0 + b], zero where c0 + b >= valid.  One call per destination rank builds its send block. */
 int bz_pack_transpose(bz_ctx *ctx, const double *in, double *out, int32_t Nz, int32_t A, int32_t ld, int32_t c0, int32_t B,
                       int32_t valid);
+/* The local transforms of the distributed Poisson solve (1-D batched rocFFT plans, unnormalised): which = 0 x forward
+ * (real (Nz, Ny, Nx) -> complex (Nz, Ny, Nx/2+1)), 1 / 2 y forward / backward in place on this rank's (Nz, nkx, Ny_global) block,
+ * 3 x backward (complex (Nz, Ny, ld), ld >= Nx/2+1 -> real (Nz, Ny, Nx); overwrites its input).  ld is read for which = 3 only. */
+int bz_slab_transform(bz_ctx *ctx, int32_t which, double *in, double *out, int32_t ld);
 /* make_pressure_correction! + compute_velocities! + thermodynamic diagnosis + x/z halo fills in one pass from the
  * contiguous solution phi_c (Nx*Ny*Nz); phi_below = phi of row j = -1, layout [k][i] (slab mode; else NULL). */
 int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below, double dt);

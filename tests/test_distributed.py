@@ -298,4 +298,5 @@ def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, worl
         err = np.max(np.abs(got - want)) / scale
         # slab ranks replay the stage through begin / substep / end (per-substep exchanges), the reference run through the fused loop:
         # same arithmetic, different kernels; the Kessler column physics amplifies the last-digit differences a little
-        assert err < (5e-11 if kessler else 1e-11), (name, err)
+        # (threshold branches: 1e-9, the tolerance of the other multi-step Kessler comparisons)
+        assert err < (1e-9 if kessler else 1e-11), (name, err)

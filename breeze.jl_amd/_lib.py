@@ -195,6 +195,7 @@ SYMBOLS = {
     "bz_kessler_model_update": (C.c_int, [_ctx, _sp, _pp, C.c_double]),
     "bz_compressible_kessler_update": (C.c_int, [_ctx, _csp, _cpp, _asp, C.c_double]),
     "bz_pack_transpose": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "bz_pack_rows": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "bz_slab_transform": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "bz_set_tracers": (C.c_int, [_ctx, C.c_int32, C.POINTER(bz_tracer_fields)]),
     "bz_set_closure": (C.c_int, [_ctx, C.POINTER(bz_smagorinsky_lilly), C.c_void_p]),

@@ -569,6 +569,8 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
         dev = device if device is not None else f"cuda:{torch.cuda.current_device()}"
         super().__init__(grid, dynamics, advection=advection, device=dev, **kw)
         self.decomp = self._pending_decomp
+        if getattr(self.decomp, "rows", "absent") is None:      # one gather / scatter launch per direction for the halo rows
+            self.decomp.rows = self._device_rows
         # second buffers of the (ρu)′, (ρv)′ ping-pong are owned here so that their halos can be exchanged
         self._up2, self._vp2 = Field(grid, _LOC["fcc"], self.device), Field(grid, _LOC["cfc"], self.device)
         self._check(self._lib.bz_set_acoustic_scratch(self._ctx, C.c_void_p(self._up2.ptr()), C.c_void_p(self._vp2.ptr())),
@@ -586,6 +588,13 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
     def _exchange(self, tensors):
         d = self.decomp or self._pending_decomp
         d.exchange_y_halos(list(tensors))
+
+    def _device_rows(self, fields, row0, nrows, buffer, unpack):
+        n = len(fields)
+        ptrs = (C.c_void_p * n)(*[f.data_ptr() for f in fields])
+        levels = (C.c_int32 * n)(*[f.shape[0] for f in fields])
+        self._check(self._lib.bz_pack_rows(self._ctx, ptrs, levels, n, int(row0), int(nrows), C.c_void_p(buffer.data_ptr()),
+                                           1 if unpack else 0), "bz_pack_rows")
 
     # field groups ----------------------------------------------------------------------------------------------------
     def _prognostic_tensors(self):

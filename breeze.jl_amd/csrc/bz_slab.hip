@@ -134,6 +134,57 @@ extern "C" int bz_slab_transform(bz_ctx *ctx, int32_t which, double *in, double 
     return BZ_OK;
 }
 
+// y-halo exchange helpers: gather (unpack == 0) / scatter (unpack != 0) `nrows` rows starting at parent row `row0` of up to
+// BZ_MAX_ROW_FIELDS parent arrays (all z levels, full x width) into / out of one contiguous buffer — one launch per direction
+// instead of one strided copy per field.  Buffer layout: field-major, then (level, row, x).
+#define BZ_MAX_ROW_FIELDS 24
+struct RowFields {
+    double *f[BZ_MAX_ROW_FIELDS];
+    int levels[BZ_MAX_ROW_FIELDS];
+    long long offset[BZ_MAX_ROW_FIELDS];      // start of the field's block in the buffer (elements)
+    int n;
+};
+
+__global__ __launch_bounds__(256) void k_row_pack(RowFields R, double *__restrict__ buf, int Sx, long long Sxy, int row0, int nrows,
+                                                  int unpack)
+{
+    const int m = blockIdx.z;
+    const int per_level = nrows * Sx;
+    const long long total = (long long)R.levels[m] * per_level;
+    double *f = R.f[m];
+    double *b = buf + R.offset[m];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int lev = (int)(e / per_level), rem = (int)(e % per_level);
+        const long long n = Sxy * lev + (long long)(row0 + rem / Sx) * Sx + rem % Sx;
+        if (unpack) f[n] = b[e];
+        else b[e] = f[n];
+    }
+}
+
+extern "C" int bz_pack_rows(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n, int32_t row0, int32_t nrows,
+                            double *buffer, int32_t unpack)
+{
+    if (!ctx || !fields || !levels || !buffer || n < 1 || n > BZ_MAX_ROW_FIELDS || nrows < 1 || row0 < 0) return BZ_ERR_INVALID;
+    const DevGrid &g = ctx->dg;
+    RowFields R;
+    R.n = n;
+    long long off = 0, maxtot = 0;
+    for (int m = 0; m < n; ++m) {
+        if (!fields[m] || levels[m] < 1) return BZ_ERR_INVALID;
+        R.f[m] = fields[m];
+        R.levels[m] = levels[m];
+        R.offset[m] = off;
+        const long long tot = (long long)levels[m] * nrows * g.Sx;
+        off += tot;
+        if (tot > maxtot) maxtot = tot;
+    }
+    ProfileScope ps(ctx, unpack ? "halo_rows_unpack" : "halo_rows_pack");
+    const unsigned bx = (unsigned)((maxtot + 255) / 256 > 4096 ? 4096 : (maxtot + 255) / 256);
+    hipLaunchKernelGGL(k_row_pack, dim3(bx, 1, n), dim3(256), 0, ctx->stream, R, buffer, g.Sx, g.Sxy, row0, nrows, unpack);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
 extern "C" int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below,
                                        double dt)
 {

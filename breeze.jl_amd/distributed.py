@@ -50,6 +50,9 @@ class SlabDecomposition:
         # optional device kernel for the transposing packs: pack(src (Nz, A, ld) complex, c0, B, valid) -> (Nz, B, A) complex
         # (SlabAtmosphereModel installs bz_pack_transpose; CPU backends use the torch expression)
         self.pack = None
+        # optional device kernel for the halo rows: rows(fields, row0, nrows, buffer, unpack) gathers / scatters parent rows of
+        # every field through one contiguous buffer (bz_pack_rows); CPU backends use slicing
+        self.rows = None
 
     def _pack(self, T, c0, B, valid=None):
         """(Nz, A, ld) complex -> contiguous (Nz, B, A) with out[k, b, a] = T[k, a, c0 + b] (zero for c0 + b >= valid)."""
@@ -80,10 +83,20 @@ class SlabDecomposition:
         Hy, Ny = self.Hy, self.Ny
         if not fields:
             return
-        if self.world == 1:
+        if self.world == 1:      # direct row copies (measured faster than a gather + scatter through a buffer)
             for f in fields:
                 f[:, :Hy, :] = f[:, Ny:Ny + Hy, :]
                 f[:, Hy + Ny:, :] = f[:, Hy:2 * Hy, :]
+            return
+        if self.rows is not None and fields[0].is_cuda:
+            total = sum(f.shape[0] * Hy * f.shape[2] for f in fields)
+            up, down = (torch.empty(total, dtype=fields[0].dtype, device=fields[0].device) for _ in range(2))
+            self.rows(fields, Ny, Hy, up, 0)                                     # my top rows -> upper's bottom halo
+            self.rows(fields, Hy, Hy, down, 0)                                   # my bottom rows -> lower's top halo
+            from_lower, from_upper = torch.empty_like(up), torch.empty_like(down)
+            self._p2p([(up, self.upper), (down, self.lower)], [(from_lower, self.lower), (from_upper, self.upper)])
+            self.rows(fields, 0, Hy, from_lower, 1)
+            self.rows(fields, Hy + Ny, Hy, from_upper, 1)
             return
         up = torch.cat([f[:, Ny:Ny + Hy, :].reshape(-1) for f in fields])        # my top rows -> upper's bottom halo
         down = torch.cat([f[:, Hy:2 * Hy, :].reshape(-1) for f in fields])       # my bottom rows -> lower's top halo
@@ -282,6 +295,9 @@ class SlabAtmosphereModel(SlabStepper):
         self._state, self._U0, self._G = self._make_state(), self._make_prog(self.U0), self._make_prog(self.G)
         if getattr(self.decomp, "pack", None) is None and hasattr(self.decomp, "_pack"):
             self.decomp.pack = self._device_pack
+            import os
+            if not os.environ.get("BZ_NO_ROW_PACK"):
+                self.decomp.rows = self._device_rows
         self.set(θ=ref.potential_temperature)
 
     # plumbing shared with AtmosphereModel -------------------------------------------------
@@ -397,6 +413,13 @@ class SlabAtmosphereModel(SlabStepper):
                     "bz_slab_transform")
         self._keep_fft = R
         return out
+
+    def _device_rows(self, fields, row0, nrows, buffer, unpack):
+        n = len(fields)
+        ptrs = (C.c_void_p * n)(*[f.data_ptr() for f in fields])
+        levels = (C.c_int32 * n)(*[f.shape[0] for f in fields])
+        self._check(self._lib.bz_pack_rows(self._ctx, ptrs, levels, n, int(row0), int(nrows), C.c_void_p(buffer.data_ptr()),
+                                           1 if unpack else 0), "bz_pack_rows")
 
     def _device_pack(self, T, c0, B, valid):
         import torch

@@ -194,6 +194,11 @@ int bz_pack_transpose(bz_ctx *ctx, const double *in, double *out, int32_t Nz, in
  * (real (Nz, Ny, Nx) -> complex (Nz, Ny, Nx/2+1)), 1 / 2 y forward / backward in place on this rank's (Nz, nkx, Ny_global) block,
  * 3 x backward (complex (Nz, Ny, ld), ld >= Nx/2+1 -> real (Nz, Ny, Nx); overwrites its input).  ld is read for which = 3 only. */
 int bz_slab_transform(bz_ctx *ctx, int32_t which, double *in, double *out, int32_t ld);
+/* y-halo exchange helper of the slab drivers: gathers (unpack = 0) or scatters (unpack != 0) parent rows [row0, row0 + nrows) of n
+ * parent arrays (levels[m] z-levels each: Nz + 2 Hz for centre fields, Nz + 1 + 2 Hz for z-face fields; full x width) into / out of
+ * one contiguous device buffer, field-major then (level, row, x).  n <= 24. */
+int bz_pack_rows(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n, int32_t row0, int32_t nrows, double *buffer,
+                 int32_t unpack);
 /* make_pressure_correction! + compute_velocities! + thermodynamic diagnosis + x/z halo fills in one pass from the
  * contiguous solution phi_c (Nx*Ny*Nz); phi_below = phi of row j = -1, layout [k][i] (slab mode; else NULL). */
 int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below, double dt);

@@ -180,3 +180,44 @@ def test_bomex_stack_time_steps_match_oracle(oracle, bz, whole_step):
         scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
         assert np.abs(got - want).max() / scale < 2e-9, n
     assert om.nu_e.max() > 0.01
+
+
+@pytest.mark.gpu
+def test_closure_and_forcings_on_a_stretched_vertical_grid(oracle, bz):
+    """Variable dz: every metric the closure and the subsidence profile use (dzc, dzf, face densities, the first-level flux
+    divisor) differs from level to level."""
+    from oracle.closure import SmagorinskyLilly
+    from test_forcings import _hip_forcing_kwargs, _oracle_forcings
+    size = (32, 20, 16)
+    zf = 3e3 * (np.linspace(0.0, 1.0, size[2] + 1) ** 1.6)
+    og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=zf)
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment",
+                            closure=SmagorinskyLilly(), forcings=_oracle_forcings(oracle, og))
+    grid = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=zf)
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), closure=bz.SmagorinskyLilly(),
+                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), **_hip_forcing_kwargs(bz))
+    om.set(**_turbulent_ic(om, 21))
+    om.update_state()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=True)
+    hm.synchronize()
+    g = om.grid
+    assert np.abs(hm.closure_fields["νₑ"].interior_cpu() - om.nu_e).max() < 1e-11 * om.nu_e.max()
+    strict = "refdiv" in bz.LIB_PATH
+    for n, k in PROG.items():
+        zfc = n == "rw"
+        want, got = g.interior(om.G[n], zface=zfc), hm.G[k].interior_cpu()
+        assert relerr(got, want) < (1e-12 if strict else 5e-9), n
+    ic = _turbulent_ic(om, 22)
+    om.set(**ic)
+    hm.set(θ=ic["theta"], qᵗ=ic["qt"], u=ic["u"], v=ic["v"])
+    for _ in range(2):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    mom = max(np.abs(g.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    for n, k in PROG.items():
+        want = g.interior(getattr(om, n), zface=(n == "rw"))
+        got = hm.prognostic_fields()[k].interior_cpu()
+        assert np.abs(got - want).max() / (mom if n in ("ru", "rv", "rw") else np.abs(want).max()) < 2e-9, n

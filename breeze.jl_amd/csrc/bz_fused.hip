@@ -96,6 +96,7 @@ struct PDFields {
     double *phi;                            // out (halo-inclusive)
     const double *phi_c;                    // in: contiguous Nx*Ny*Nz, zero-mean solution
     const double *phi_below;                // y-slab only: phi of row j = -1 (neighbour rank), layout [k][i]
+    int store_phi;                          // 0: skip the scatter into pressure_anomaly (stages whose phi nobody reads)
 };
 
 template <int SA>       // 0: no microphysics, 1: warm-phase saturation adjustment, 2: Kessler condensate species
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     } else if (SA == 1) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
     else T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : pow(g.p_r[k] / g.pst, Rm / cpm) * th;
 
-    st_img(F.phi, n, p, ox, oy);
+    if (F.store_phi) st_img(F.phi, n, p, ox, oy);
     st_img(F.ru, n, ru, ox, oy);
     st_img(F.rv, n, rv, ox, oy);
     st_img(F.u, n, u, ox, oy);
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     }
     if (bot || top) {    // first z-halo cell of no-flux centre fields; u, v: level Nz only
         const long long h = bot ? -sz : sz;
-        st_img(F.phi, n + h, p, ox, oy);
+        if (F.store_phi) st_img(F.phi, n + h, p, ox, oy);
         st_img(F.ru, n + h, ru, ox, oy);
         st_img(F.rv, n + h, rv, ox, oy);
         st_img(F.theta, n + h, th, ox, oy);
@@ -231,7 +232,7 @@ int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *
 }
 
 int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below,
-                         const bz_prognostic *predictor)
+                         const bz_prognostic *predictor, bool store_phi)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "project_and_diagnose");
@@ -244,6 +245,7 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double
     F.phi = s->phi;
     F.phi_c = phi_c ? phi_c : ctx->d_rhs;
     F.phi_below = phi_below;
+    F.store_phi = store_phi ? 1 : 0;
     dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
     if (g.microphysics == 2)
         hipLaunchKernelGGL((k_project_diagnose<2>), grid, block, 0, ctx->stream, g, F, dt);

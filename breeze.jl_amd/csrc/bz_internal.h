@@ -329,7 +329,7 @@ int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const
 int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *rhs = nullptr,
                              const bz_prognostic *predictor = nullptr);
 int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c = nullptr,
-                         const double *phi_below = nullptr, const bz_prognostic *predictor = nullptr);
+                         const double *phi_below = nullptr, const bz_prognostic *predictor = nullptr, bool store_phi = true);
 int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                             double alpha, bool first);
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,

@@ -58,7 +58,8 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
             }
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
-            if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G))) return rc;
+            // pressure_anomaly is a diagnostic nobody reads inside the step: only the last stage scatters it
+            if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, stage == 2))) return rc;
             if ((rc = bzi_tracer_specific(ctx))) return rc;
         }
         ctx->G_is_predictor = true;

@@ -353,10 +353,12 @@ class SlabAtmosphereModel(SlabStepper):
         return [self.momentum[k].parent for k in ("ρu", "ρv", "ρw")]
 
     def tendency_halo_fields(self):
+        """What the tendency kernels read across the slab edge: the advecting mass fluxes, the advected velocities and the two
+        advected scalars.  T (buoyancy: own column only), rho theta / rho q (RK update: own cell) and the pressure anomaly
+        (diagnostic) are never read in y-halo rows, so they do not travel."""
         return ([self.momentum[k].parent for k in ("ρu", "ρv", "ρw")] +
                 [self.velocities[k].parent for k in ("u", "v", "w")] +
-                [self.potential_temperature.parent, self.specific_moisture.parent, self.temperature.parent,
-                 self.potential_temperature_density.parent, self.moisture_density.parent, self.pressure_anomaly.parent])
+                [self.potential_temperature.parent, self.specific_moisture.parent])
 
     fused_rk = True
 

@@ -57,6 +57,16 @@ class bz_saturation_adjustment(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class bz_bulk_surface_fluxes(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "drag_coefficient", "drag_gustiness", "drag_surface_temperature",
+        "heat_coefficient", "heat_gustiness", "heat_surface_temperature",
+        "vapor_coefficient", "vapor_gustiness", "vapor_surface_temperature",
+        "surface_pressure", "standard_pressure",
+        "liquid_latent_heat", "liquid_heat_capacity", "energy_reference_temperature", "triple_point_temperature",
+        "triple_point_pressure")]
+
+
 class bz_tracer_fields(C.Structure):
     _fields_ = [("density", C.c_void_p), ("specific", C.c_void_p), ("U0", C.c_void_p), ("G", C.c_void_p)]
 
@@ -200,6 +210,7 @@ SYMBOLS = {
     "bz_set_tracers": (C.c_int, [_ctx, C.c_int32, C.POINTER(bz_tracer_fields)]),
     "bz_set_closure": (C.c_int, [_ctx, C.POINTER(bz_smagorinsky_lilly), C.c_void_p]),
     "bz_compute_closure_fields": (C.c_int, [_ctx, _sp]),
+    "bz_set_bulk_surface_fluxes": (C.c_int, [_ctx, C.POINTER(bz_bulk_surface_fluxes)]),
     "bz_set_forcings": (C.c_int, [_ctx, C.POINTER(bz_column_forcings)]),
     "bz_compute_forcings": (C.c_int, [_ctx, _sp]),
     "bz_compute_flux_bc_tendencies": (C.c_int, [_ctx, _sp, _pp]),

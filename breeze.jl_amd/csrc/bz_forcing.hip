@@ -158,6 +158,43 @@ __global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, doub
     }
 }
 
+// BulkDrag / BulkSensibleHeatFlux / BulkVaporFlux with constant coefficients on unfiltered fields
+// (/root/reference/src/BoundaryConditions/bulk_drag.jl:114-135, bulk_scalar_fluxes.jl:82-90,123-137,206-232,
+//  BoundaryConditions.jl:64-85; surface density reference_states.jl:73-76): J^u = -rho0 C^D U~ u at the x face with
+// U~^2 = u^2 + xy-average(v^2) + gustiness^2, scalar fluxes at centres with U~^2 = x-average(u^2) + y-average(v^2) + gustiness^2.
+struct BulkParams {
+    double drag_c, drag_g2, drag_rho0;        // rho0 = p0 / (Rd T0) of each condition's own surface temperature
+    double heat_c, heat_g2, heat_rho0, heat_theta0;
+    double vap_c, vap_g2, vap_rho0, vap_q0;
+    int drag, heat, vapor;
+};
+
+__global__ __launch_bounds__(256) void k_bulk_bottom_flux(DevGrid g, BulkParams B, double *__restrict__ Gu, double *__restrict__ Gv,
+                                                          double *__restrict__ Gth, double *__restrict__ Gq,
+                                                          const double *__restrict__ u, const double *__restrict__ v,
+                                                          const double *__restrict__ th, const double *__restrict__ qv, double scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, 0);
+    const double dz = g.dzc[0];
+    const long long sx = g.Hx ? 1 : 0, sy = g.Hy ? g.Sx : 0;
+    auto sq = [](double a) { return a * a; };
+    if (B.drag) {
+        const double v2 = ((sq(v[n - sx]) + sq(v[n - sx + sy])) / 2 + (sq(v[n]) + sq(v[n + sy])) / 2) / 2;
+        const double u2 = ((sq(u[n - sy]) + sq(u[n - sy + sx])) / 2 + (sq(u[n]) + sq(u[n + sx])) / 2) / 2;
+        const double Ju = -B.drag_rho0 * B.drag_c * sqrt(sq(u[n]) + v2 + B.drag_g2) * u[n];
+        const double Jv = -B.drag_rho0 * B.drag_c * sqrt(u2 + sq(v[n]) + B.drag_g2) * v[n];
+        Gu[n] += scale * (Ju / dz);
+        Gv[n] += scale * (Jv / dz);
+    }
+    if (B.heat || B.vapor) {
+        const double U2 = (sq(u[n]) + sq(u[n + sx])) / 2 + (sq(v[n]) + sq(v[n + sy])) / 2;
+        if (B.heat) Gth[n] += scale * ((-B.heat_rho0 * B.heat_c * sqrt(U2 + B.heat_g2) * (th[n] - B.heat_theta0)) / dz);
+        if (B.vapor) Gq[n] += scale * ((-B.vap_rho0 * B.vap_c * sqrt(U2 + B.vap_g2) * (qv[n] - B.vap_q0)) / dz);
+    }
+}
+
 static void free_forcings(bz_ctx *ctx)
 {
     if (ctx->d_forcing) hipFree(ctx->d_forcing);
@@ -202,6 +239,50 @@ extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
     ctx->forcing_flux_q = f->bottom_moisture_flux;
     ctx->forcing_drag = f->bottom_drag_rho0_ustar2;
     ctx->has_forcings = true;
+    return BZ_OK;
+}
+
+extern "C" int bz_set_bulk_surface_fluxes(bz_ctx *ctx, const bz_bulk_surface_fluxes *b)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    if (!b) { ctx->has_bulk = false; return BZ_OK; }
+    if (ctx->compressible || ctx->slab_mode || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {
+        ctx->last_error = "bz_set_bulk_surface_fluxes: implemented for the single-device anelastic potential-temperature model";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    ctx->bulk = *b;
+    ctx->has_bulk = (b->drag_coefficient > 0.0) || (b->heat_coefficient > 0.0) || (b->vapor_coefficient > 0.0);
+    return BZ_OK;
+}
+
+static int bulk_flux(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale)
+{
+    const DevGrid &g = ctx->dg;
+    const bz_bulk_surface_fluxes &b = ctx->bulk;
+    const double Rd = g.Rd;
+    BulkParams B;
+    B.drag = b.drag_coefficient > 0.0; B.heat = b.heat_coefficient > 0.0; B.vapor = b.vapor_coefficient > 0.0;
+    B.drag_c = b.drag_coefficient; B.drag_g2 = b.drag_gustiness * b.drag_gustiness;
+    B.drag_rho0 = B.drag ? b.surface_pressure / (Rd * b.drag_surface_temperature) : 0.0;
+    B.heat_c = b.heat_coefficient; B.heat_g2 = b.heat_gustiness * b.heat_gustiness;
+    B.heat_rho0 = B.heat ? b.surface_pressure / (Rd * b.heat_surface_temperature) : 0.0;
+    B.heat_theta0 = B.heat ? b.heat_surface_temperature / pow(b.surface_pressure / b.standard_pressure, Rd / g.cpd) : 0.0;
+    B.vap_c = b.vapor_coefficient; B.vap_g2 = b.vapor_gustiness * b.vapor_gustiness;
+    B.vap_rho0 = 0.0; B.vap_q0 = 0.0;
+    if (B.vapor) {      // saturation_specific_humidity(T0, rho0, constants, PlanarLiquidSurface()) (Clausius-Clapeyron)
+        const double T0 = b.vapor_surface_temperature;
+        B.vap_rho0 = b.surface_pressure / (Rd * T0);
+        const double dc = ctx->constants.vapor_heat_capacity - b.liquid_heat_capacity;
+        const double L0 = b.liquid_latent_heat - dc * b.energy_reference_temperature;
+        const double ps = b.triple_point_pressure * pow(T0 / b.triple_point_temperature, dc / g.Rv) *
+                          exp((1.0 / b.triple_point_temperature - 1.0 / T0) * L0 / g.Rv);
+        B.vap_q0 = ps / (B.vap_rho0 * g.Rv * T0);
+    }
+    ProfileScope ps(ctx, "bulk_surface_fluxes");
+    const double *qv = (g.microphysics == 1) ? g.qv_field : s->q;
+    hipLaunchKernelGGL(k_bulk_bottom_flux, dim3((g.Nx + 255) / 256, g.Ny), dim3(256), 0, ctx->stream, g, B, Gu, Gv, Gth, Gq,
+                       s->u, s->v, s->theta, qv, scale);
+    BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
 
@@ -255,6 +336,10 @@ extern "C" int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, con
 
 int bzi_flux_bc(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale)
 {
+    if (ctx->has_bulk) {
+        int rcb = bulk_flux(ctx, s, Gu, Gv, Gth, Gq, scale);
+        if (rcb) return rcb;
+    }
     if (!ctx->has_forcings) return BZ_OK;
     if (ctx->forcing_flux_theta == 0.0 && ctx->forcing_flux_q == 0.0 && ctx->forcing_drag == 0.0) return BZ_OK;
     const DevGrid &g = ctx->dg;

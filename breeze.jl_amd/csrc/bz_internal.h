@@ -253,6 +253,9 @@ struct bz_ctx {
     double *d_forcing = nullptr;      // static profiles, subsidence velocity, level averages, subsidence profiles, partial sums
     int forcing_static_mask = 0, forcing_subsidence_mask = 0;
     double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0;
+    // BulkDrag / BulkSensibleHeatFlux / BulkVaporFlux bottom conditions (bz_set_bulk_surface_fluxes, bz_forcing.hip)
+    bool has_bulk = false;
+    bz_bulk_surface_fluxes bulk;
     // user tracers (bz_set_tracers, bz_tracers.hip)
     int n_tracers = 0;
     bz_tracer_fields tracers[BZ_MAX_TRACERS];

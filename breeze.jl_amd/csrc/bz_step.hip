@@ -54,8 +54,9 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
                 // forcing, Coriolis and bottom fluxes of the stage, evaluated from the still-intact previous-stage state and
                 // added to what the fused RK update just wrote, weighted alpha dt
                 if ((rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
-                if ((rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
             }
+            if ((ctx->has_forcings || ctx->has_bulk) &&
+                (rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
             // pressure_anomaly is a diagnostic nobody reads inside the step: only the last stage scatters it

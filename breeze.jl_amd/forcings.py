@@ -66,6 +66,29 @@ class FrictionVelocityDrag:
         self.ρ0, self.ustar = float(ρ0), float(ustar)
 
 
+class BulkDrag:
+    """BulkDrag(; coefficient = 1e-3, gustiness = 0, surface_temperature = nothing) (src/BoundaryConditions/bulk_drag.jl:60-84);
+    without a surface temperature the anelastic default Π₀ θ₀ of the reference state is used
+    (src/AnelasticEquations/anelastic_dynamics.jl:99-105)."""
+
+    def __init__(self, coefficient=1e-3, gustiness=0.0, surface_temperature=None):
+        self.coefficient, self.gustiness, self.surface_temperature = float(coefficient), float(gustiness), surface_temperature
+
+
+class BulkSensibleHeatFlux:
+    """BulkSensibleHeatFlux(; coefficient, gustiness = 0, surface_temperature) (bulk_scalar_fluxes.jl:53-56)."""
+
+    def __init__(self, coefficient, surface_temperature, gustiness=0.0):
+        self.coefficient, self.gustiness, self.surface_temperature = float(coefficient), float(gustiness), float(surface_temperature)
+
+
+class BulkVaporFlux:
+    """BulkVaporFlux(; coefficient, gustiness = 0, surface_temperature) (bulk_scalar_fluxes.jl:172-176)."""
+
+    def __init__(self, coefficient, surface_temperature, gustiness=0.0):
+        self.coefficient, self.gustiness, self.surface_temperature = float(coefficient), float(gustiness), float(surface_temperature)
+
+
 class FluxBoundaryCondition:
     def __init__(self, condition):
         self.condition = condition
@@ -150,6 +173,8 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions):
         if bottom is None:
             continue
         cond = bottom.condition if isinstance(bottom, FluxBoundaryCondition) else bottom
+        if isinstance(cond, (BulkDrag, BulkSensibleHeatFlux, BulkVaporFlux)):
+            continue                      # collected by materialize_bulk_fluxes
         if k == "ρθ":
             S.bottom_theta_flux = float(cond)
         elif k in ("ρqe", "ρqv", "ρqt"):
@@ -164,4 +189,48 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions):
         else:
             raise NotImplementedError(f"boundary condition on {name!r} is not implemented")
     S.bottom_drag_rho0_ustar2 = drag or 0.0
+    if not static and ws is None and f == 0.0 and not (S.bottom_theta_flux or S.bottom_moisture_flux or S.bottom_drag_rho0_ustar2):
+        return None, None                 # e.g. only bulk conditions were given
     return S, keep
+
+
+def materialize_bulk_fluxes(boundary_conditions, reference_state, constants):
+    """-> bz_bulk_surface_fluxes or None.  BulkDrag belongs on ρu / ρv (one coefficient for both), BulkSensibleHeatFlux on ρθ,
+    BulkVaporFlux on the moisture density; anything else raises like the reference's regularization does."""
+    B, found = _lib.bz_bulk_surface_fluxes(), False
+    for name, bcs in (boundary_conditions or {}).items():
+        k = _key(name)
+        bottom = bcs.bottom if isinstance(bcs, FieldBoundaryConditions) else bcs
+        cond = bottom.condition if isinstance(bottom, FluxBoundaryCondition) else bottom
+        if isinstance(cond, BulkDrag):
+            if k not in ("ρu", "ρv"):
+                raise ValueError("BulkDrag is a momentum boundary condition (ρu, ρv)")
+            T0 = cond.surface_temperature
+            if T0 is None:      # default_drag_surface_temperature(::AnelasticDynamics)
+                from .thermodynamics import dry_air_gas_constant
+                Π0 = (reference_state.surface_pressure / reference_state.standard_pressure) ** (
+                    dry_air_gas_constant(constants) / constants.dry_air_heat_capacity)
+                T0 = Π0 * reference_state.potential_temperature
+            new = (cond.coefficient, cond.gustiness, float(T0))
+            if found and B.drag_coefficient > 0 and (B.drag_coefficient, B.drag_gustiness, B.drag_surface_temperature) != new:
+                raise NotImplementedError("ρu and ρv share one BulkDrag")
+            B.drag_coefficient, B.drag_gustiness, B.drag_surface_temperature = new
+            found = True
+        elif isinstance(cond, BulkSensibleHeatFlux):
+            if k != "ρθ":
+                raise ValueError("BulkSensibleHeatFlux belongs on ρθ")
+            B.heat_coefficient, B.heat_gustiness, B.heat_surface_temperature = cond.coefficient, cond.gustiness, cond.surface_temperature
+            found = True
+        elif isinstance(cond, BulkVaporFlux):
+            if k not in ("ρqe", "ρqv", "ρqt"):
+                raise ValueError("BulkVaporFlux belongs on the moisture density")
+            B.vapor_coefficient, B.vapor_gustiness, B.vapor_surface_temperature = cond.coefficient, cond.gustiness, cond.surface_temperature
+            found = True
+    if not found:
+        return None
+    B.surface_pressure, B.standard_pressure = reference_state.surface_pressure, reference_state.standard_pressure
+    c = constants
+    B.liquid_latent_heat, B.liquid_heat_capacity = c.liquid_reference_latent_heat, c.liquid_heat_capacity
+    B.energy_reference_temperature = c.energy_reference_temperature
+    B.triple_point_temperature, B.triple_point_pressure = c.triple_point_temperature, c.triple_point_pressure
+    return B

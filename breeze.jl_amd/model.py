@@ -245,6 +245,12 @@ class AtmosphereModel:
             if self._kessler or formulation != "LiquidIcePotentialTemperature":
                 raise NotImplementedError("forcings are implemented for the potential-temperature formulation without Kessler")
             self._check(lib.bz_set_forcings(self._ctx, C.byref(F)), "bz_set_forcings")
+        from .forcings import materialize_bulk_fluxes
+        Bk = materialize_bulk_fluxes(boundary_conditions, ref, c)
+        if Bk is not None:
+            if self._kessler or formulation != "LiquidIcePotentialTemperature":
+                raise NotImplementedError("bulk surface fluxes are implemented for the potential-temperature formulation without Kessler")
+            self._check(lib.bz_set_bulk_surface_fluxes(self._ctx, C.byref(Bk)), "bz_set_bulk_surface_fluxes")
         self._state = self._make_state()
         self._U0 = self._make_prog(self.U0)
         self._G = self._make_prog(self.G)

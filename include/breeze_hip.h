@@ -434,6 +434,23 @@ int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *forcings);       /* N
 int bz_compute_forcings(bz_ctx *ctx, const bz_state *s);
 /* compute_flux_bc_tendencies!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:418-434) */
 int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+/* Bulk aerodynamic bottom conditions with constant transfer coefficients on unfiltered fields:
+ *   BulkDrag on rho u, rho v               J^u = -rho0 C^D U~ u          (src/BoundaryConditions/bulk_drag.jl:114-135)
+ *   BulkSensibleHeatFlux on rho theta      J^th = -rho0 C^T U~ (theta - theta0)  (bulk_scalar_fluxes.jl:82-90,123-137)
+ *   BulkVaporFlux on the moisture density  J^v = -rho0 C^v U~ (q^v - q^v+(T0, rho0))  (bulk_scalar_fluxes.jl:206-232)
+ * with U~ = sqrt(U^2 + gustiness^2), U^2 interpolated to the flux location (BoundaryConditions.jl:64-85), rho0 = p0 / (R^d T0)
+ * (src/Thermodynamics/reference_states.jl:73-76), theta0 = T0 / (p0/p_st)^(R^d/c_pd).  A coefficient <= 0 switches that
+ * condition off.  Applied by bz_compute_flux_bc_tendencies (and inside bz_time_step_anelastic) next to the constant fluxes of
+ * bz_column_forcings.  PolynomialCoefficient and FilteredSurfaceVelocities are not implemented. */
+typedef struct bz_bulk_surface_fluxes {
+    double drag_coefficient, drag_gustiness, drag_surface_temperature;
+    double heat_coefficient, heat_gustiness, heat_surface_temperature;
+    double vapor_coefficient, vapor_gustiness, vapor_surface_temperature;
+    double surface_pressure, standard_pressure;
+    /* liquid CondensedPhase + triple point of ThermodynamicConstants, for q^v+ of the vapour flux */
+    double liquid_latent_heat, liquid_heat_capacity, energy_reference_temperature, triple_point_temperature, triple_point_pressure;
+} bz_bulk_surface_fluxes;
+int bz_set_bulk_surface_fluxes(bz_ctx *ctx, const bz_bulk_surface_fluxes *fluxes);      /* NULL detaches */
 
 /* ---- user tracers of the anelastic model: AtmosphereModel(grid; tracers = (:a, :b)) ----
  * density = model.tracers.c (prognostic rho c), specific = c = rho c / rho_r (the reference converts in place around the tendency

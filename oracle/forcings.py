@@ -33,13 +33,27 @@ class ColumnForcings:
 
     def __init__(self, Fu=None, Fv=None, Ftheta=None, Fq=None, Fe=None, w_subsidence=None,
                  subsidence_on=("u", "v", "theta", "q"), coriolis_f=0.0, flux_theta=0.0, flux_q=0.0,
-                 drag_rho0_ustar2=0.0):
+                 drag_rho0_ustar2=0.0, bulk=None):
         self.Fu, self.Fv, self.Ftheta, self.Fq, self.Fe = Fu, Fv, Ftheta, Fq, Fe
         self.w_subsidence = w_subsidence              # Nz+1 faces
         self.subsidence_on = tuple(subsidence_on) if w_subsidence is not None else ()
         self.f = float(coriolis_f)
         self.flux_theta, self.flux_q, self.drag = float(flux_theta), float(flux_q), float(drag_rho0_ustar2)
+        self.bulk = bulk                              # BulkFluxes or None
         self.sub = {}
+
+
+class BulkFluxes:
+    """BulkDrag / BulkSensibleHeatFlux / BulkVaporFlux with constant coefficients and unfiltered fields
+    (src/BoundaryConditions/bulk_drag.jl:114-135, bulk_scalar_fluxes.jl:82-90,123-137,206-232, BoundaryConditions.jl:64-85):
+      J^u = -rho0 C^D U~ u,  J^theta = -rho0 C^T U~ (theta - theta0),  J^v = -rho0 C^v U~ (q^v - q^v+(T0, rho0)),
+      U~ = sqrt(U^2 + gustiness^2) with U^2 interpolated to the flux location, rho0 = p0 / (R^d T0) (reference_states.jl:73-76),
+      theta0 = T0 / (p0/p_st)^(R^d/c_pd) (dynamic_states.jl:111-124)."""
+
+    def __init__(self, surface_pressure, standard_pressure=1e5, drag=None, heat=None, vapor=None):
+        # each of drag / heat / vapor: None or (coefficient, gustiness, surface_temperature)
+        self.p0, self.pst = float(surface_pressure), float(standard_pressure)
+        self.drag_params, self.heat, self.vapor = drag, heat, vapor
 
 
 def subsidence_profile(ws, avg, dzf):
@@ -142,3 +156,39 @@ def add_flux_bc_tendencies(m):
         I(m.G["ru"])[0] += Ju * 1.0 / dz
         I(m.G["rv"])[0] += Jv * 1.0 / dz
     del k
+    if F.bulk is not None:
+        _add_bulk_fluxes(m, F.bulk, dz)
+
+
+def _add_bulk_fluxes(m, B, dz):
+    from .thermo import ThermoConstants, saturation_specific_humidity
+    g, c = m.grid, m.constants
+    I = g.interior
+    z = g.Hz
+    y0, y1, x0, x1 = g.Hy, g.Hy + g.Ny, g.Hx, g.Hx + g.Nx
+    u, v = m.u[z], m.v[z]                       # first level with halos
+    sq = lambda a, jo, io: a[y0 + jo:y1 + jo, x0 + io:x1 + io] ** 2
+    if B.drag_params is not None:
+        C, gust, T0 = B.drag_params
+        rho0 = B.p0 / (c.Rd * T0)
+        # wind_speed2 at (f,c): u^2 + xy-average of v^2; at (c,f): xy-average of u^2 + v^2
+        v2_fc = ((sq(v, 0, -1) + sq(v, 1, -1)) / 2 + (sq(v, 0, 0) + sq(v, 1, 0)) / 2) / 2
+        u2_cf = ((sq(u, -1, 0) + sq(u, -1, 1)) / 2 + (sq(u, 0, 0) + sq(u, 0, 1)) / 2) / 2
+        ui, vi = u[y0:y1, x0:x1], v[y0:y1, x0:x1]
+        Ju = -rho0 * C * np.sqrt(ui ** 2 + v2_fc + gust ** 2) * ui
+        Jv = -rho0 * C * np.sqrt(u2_cf + vi ** 2 + gust ** 2) * vi
+        I(m.G["ru"])[0] += Ju * 1.0 / dz
+        I(m.G["rv"])[0] += Jv * 1.0 / dz
+    U2c = (sq(u, 0, 0) + sq(u, 0, 1)) / 2 + (sq(v, 0, 0) + sq(v, 1, 0)) / 2
+    if B.heat is not None:
+        C, gust, T0 = B.heat
+        rho0 = B.p0 / (c.Rd * T0)
+        theta0 = T0 / (B.p0 / B.pst) ** (c.Rd / c.cpd)
+        th = I(m.theta)[0]
+        I(m.G["rtheta"])[0] += (-rho0 * C * np.sqrt(U2c + gust ** 2) * (th - theta0)) * 1.0 / dz
+    if B.vapor is not None:
+        C, gust, T0 = B.vapor
+        rho0 = B.p0 / (c.Rd * T0)
+        qv0 = saturation_specific_humidity(T0, rho0, ThermoConstants(), "liquid")
+        qv = I(m.qv)[0] if m.microphysics == "SaturationAdjustment" else I(m.q)[0]
+        I(m.G["rq"])[0] += (-rho0 * C * np.sqrt(U2c + gust ** 2) * (qv - qv0)) * 1.0 / dz

@@ -290,3 +290,87 @@ def test_forcing_interface_errors(bz):
         mk(forcing={"u": bz.geostrophic_forcings(ug_profile, vg_profile).u})
     with pytest.raises(NotImplementedError):
         mk(forcing={"w": bz.Forcing(lambda z: 0.0)})
+
+
+# ---- bulk aerodynamic bottom conditions ----------------------------------------------------------------------------------------
+
+def test_reference_bulk_drag_known_answer(oracle):
+    """test/forcing_and_boundary_conditions.jl:309-343: uniform u = 5, C^D = 1e-3, gustiness 0.1, T0 = 290 gives
+    J^u = -rho0 C^D sqrt(U^2 + gustiness^2) U with rho0 = p0 / (R^d T0)."""
+    from oracle.forcings import BulkFluxes, ColumnForcings, add_flux_bc_tendencies
+    g = oracle.Grid((4, 4, 4), x=(0, 100), y=(0, 100), z=(0, 100))
+    m = oracle.OracleModel(g, forcings=ColumnForcings(bulk=BulkFluxes(101325.0, 1e5, drag=(1e-3, 0.1, 290.0))))
+    m.set(theta=m.ref.theta0, u=5.0, enforce_mass_conservation=False)
+    m.update_state()
+    for n in m.G:
+        m.G[n][...] = 0.0
+    add_flux_bc_tendencies(m)
+    rho0 = 101325.0 / (m.constants.Rd * 290.0)
+    want = -rho0 * 1e-3 * np.sqrt(25.0 + 0.01) * 5.0
+    np.testing.assert_allclose(g.interior(m.G["ru"])[0] * 25.0, want, rtol=1e-13)
+    assert np.all(g.interior(m.G["ru"])[1:] == 0) and np.all(g.interior(m.G["rv"]) == 0)
+
+
+def test_reference_bulk_sensible_heat_vanishes_at_the_surface_equivalent_theta(oracle):
+    """test/forcing_and_boundary_conditions.jl:252-276: with p0 != p_st the flux compares theta with the surface-equivalent
+    theta0 = T0 (p_st/p0)^(R^d/c_pd); setting the air to exactly that value gives zero flux although theta != T0."""
+    from oracle.forcings import BulkFluxes, ColumnForcings, add_flux_bc_tendencies
+    g = oracle.Grid((4, 4, 4), x=(0, 100), y=(0, 100), z=(0, 100))
+    T0, p0 = 290.0, 101325.0
+    m = oracle.OracleModel(g, surface_pressure=p0, forcings=ColumnForcings(bulk=BulkFluxes(p0, 1e5, heat=(1e-3, 0.1, T0))))
+    c = m.constants
+    theta_s = T0 / (p0 / 1e5) ** (c.Rd / c.cpd)
+    assert abs(theta_s - T0) > 0.5
+    m.set(theta=theta_s, u=3.0, enforce_mass_conservation=False)
+    m.update_state()
+    for n in m.G:
+        m.G[n][...] = 0.0
+    add_flux_bc_tendencies(m)
+    assert np.abs(g.interior(m.G["rtheta"])).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_bulk_surface_fluxes_match_oracle(oracle, bz):
+    from oracle.forcings import BulkFluxes, ColumnForcings, add_flux_bc_tendencies
+    size = (32, 20, 16)
+    og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    B = BulkFluxes(101500.0, 1e5, drag=(1.2e-3, 0.2, 299.8), heat=(1.1e-3, 0.2, 300.4), vapor=(1.3e-3, 0.1, 300.4))
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment",
+                            forcings=ColumnForcings(bulk=B))
+    grid = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+    bcs = {"ρu": bz.FieldBoundaryConditions(bottom=bz.BulkDrag(coefficient=1.2e-3, gustiness=0.2, surface_temperature=299.8)),
+           "ρv": bz.FieldBoundaryConditions(bottom=bz.BulkDrag(coefficient=1.2e-3, gustiness=0.2, surface_temperature=299.8)),
+           "ρθ": bz.FieldBoundaryConditions(bottom=bz.BulkSensibleHeatFlux(coefficient=1.1e-3, gustiness=0.2, surface_temperature=300.4)),
+           "ρqᵉ": bz.FieldBoundaryConditions(bottom=bz.BulkVaporFlux(coefficient=1.3e-3, gustiness=0.1, surface_temperature=300.4))}
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5),
+                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), boundary_conditions=bcs)
+    ic = _ic(seed=13)
+    om.set(**ic)
+    om.update_state()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=True)
+    before = {k: hm.G[k].interior_cpu().copy() for k in PROG.values()}
+    G0 = {n: og.interior(om.G[n], zface=(n == "rw")).copy() for n in PROG}
+    add_flux_bc_tendencies(om)
+    bz.compute_flux_bc_tendencies_(hm)
+    hm.synchronize()
+    for n, k in PROG.items():
+        want = og.interior(om.G[n], zface=(n == "rw")) - G0[n]
+        got = hm.G[k].interior_cpu() - before[k]
+        if n == "rw":
+            assert np.all(got == 0)
+            continue
+        assert np.abs(want).max() > 0, n
+        assert np.abs(got - want).max() < 1e-9 * np.abs(want).max(), n
+    om.set(**ic)
+    hm.set(θ=ic["theta"], qᵗ=ic["qt"], u=ic["u"], v=ic["v"])
+    for _ in range(3):
+        om.time_step(3.0)
+        hm.time_step(3.0)
+    hm.synchronize()
+    for n, k in PROG.items():
+        want = og.interior(getattr(om, n), zface=(n == "rw"))
+        got = hm.prognostic_fields()[k].interior_cpu()
+        scale = max(np.abs(og.interior(om.ru)).max(), 1e-3) if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() / scale < 1e-9, n

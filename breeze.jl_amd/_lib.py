@@ -239,24 +239,33 @@ def build(verbose=False):
 _lib = None
 
 
-def load():
-    """Load libbreeze_hip.so and bind every declared symbol.  Raises if the library is absent."""
+CENTERED2_LIB_PATH = os.path.join(_HERE, "lib", "libbreeze_hip_centered2.so")
+_libs = {}
+
+
+def load(advection_order=5):
+    """Load libbreeze_hip.so (advection = WENO(order = 5)) or, for advection_order = 2, libbreeze_hip_centered2.so — the same
+    sources built with the reconstructions collapsed to Centered(order = 2) — and bind every declared symbol.  Raises if the
+    library is absent."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH if advection_order == 5 else CENTERED2_LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            f"{path} not found: the HIP extension is required (no CPU fallback). "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C breeze.jl_amd/csrc`.")
     # torch bundles its own HIP runtime; load it first so that libbreeze_hip.so binds to the same
     # libamdhip64 instance (two runtimes in one process cannot both see the device).
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
+    if advection_order == 5:
+        _lib = lib
     return lib
 
 

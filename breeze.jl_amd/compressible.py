@@ -248,7 +248,8 @@ class CompressibleAtmosphereModel:
                 raise ValueError("DCMIP2016KesslerMicrophysics requires `thermodynamic_constants` with a `TetensFormula` "
                                  "saturation vapor pressure formulation.")
         if advection is None:
-            raise NotImplementedError("the HIP path requires advection=WENO(order=5)")
+            from .model import Centered
+            advection = Centered(order=2)          # the reference's default
         if not torch.cuda.is_available():
             raise RuntimeError("CompressibleAtmosphereModel needs a GPU: the HIP path has no CPU fallback")
         self.grid, self.advection, self.dynamics = grid, advection, dynamics
@@ -257,7 +258,7 @@ class CompressibleAtmosphereModel:
         self.clock = Clock()
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self._lib = lib = _lib.load()
+        self._lib = lib = _lib.load(advection.order)
 
         def fld(loc):
             return Field(grid, _LOC[loc], self.device)

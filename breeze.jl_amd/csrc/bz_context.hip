@@ -148,7 +148,11 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (!out || !grid || !constants || !ref || !grid->zf || !ref->density || !ref->pressure || !ref->temperature)
         return BZ_ERR_INVALID;
     *out = nullptr;
+#ifdef BZ_CENTERED2
+    if (weno_order != 2) return BZ_ERR_UNSUPPORTED;      // this build is Centered(order = 2)
+#else
     if (weno_order != 5) return BZ_ERR_UNSUPPORTED;
+#endif
     if (grid->ftype != 8) return BZ_ERR_UNSUPPORTED;
     if (grid->topo[0] != BZ_PERIODIC || grid->topo[1] != BZ_PERIODIC || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;

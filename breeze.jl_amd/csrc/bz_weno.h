@@ -98,6 +98,15 @@ __device__ __forceinline__ double bz_weno3(double a, double b, double c)
     return (a0 * p0 + a1 * p1) / (a0 + a1);
 }
 
+#ifdef BZ_CENTERED2
+// libbreeze_hip_centered2.so: advection = Centered(order = 2), the AtmosphereModel constructor's default
+// (/root/reference/src/AtmosphereModels/atmosphere_model.jl advection keyword; Oceananigans Centered: the advected quantity and
+// the advecting mass flux are both 2-point symmetric interpolations, no upwinding, no order reduction at walls).  The kernels
+// are unchanged; every reconstruction collapses to the mean of the two cells adjacent to the target.
+__device__ __forceinline__ double bz_up5(double, double, double m1, double p0, double, double, bool) { return 0.5 * (m1 + p0); }
+__device__ __forceinline__ double bz_up3(double, double m1, double p0, double, bool) { return 0.5 * (m1 + p0); }
+__device__ __forceinline__ double bz_upB(double, double, double m1, double p0, double, double, bool, int) { return 0.5 * (m1 + p0); }
+#else
 // Six values straddling the target (which lies between m1 and p0).  left = advecting flux > 0.
 __device__ __forceinline__ double bz_up5(double m3, double m2, double m1, double p0, double p1,
                                          double p2, bool left)
@@ -124,6 +133,7 @@ __device__ __forceinline__ double bz_upB(double m3, double m2, double m1, double
     if (B == 2) return bz_up3(m2, m1, p0, p1, left);
     return left ? m1 : p0;
 }
+#endif
 
 // Largest buffer usable at index idx of a Bounded direction with N cells
 // (face target: B <= idx <= N-B; centre target: B-1 <= idx <= N-B).
@@ -143,6 +153,10 @@ __device__ __forceinline__ int bz_buffer_center(int idx, int N)
 // Centered(order 4) of four values straddling the target (between qm1 and q0); order 2 fallback.
 __device__ __forceinline__ double bz_symm4(double qm2, double qm1, double q0, double qp1)
 {
+#ifdef BZ_CENTERED2
+    return 0.5 * (qm1 + q0);
+#else
     return (7.0 / 12.0) * (qm1 + q0) - (1.0 / 12.0) * (qm2 + qp1);
+#endif
 }
 __device__ __forceinline__ double bz_symm2(double qm1, double q0) { return 0.5 * (qm1 + q0); }

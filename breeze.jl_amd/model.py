@@ -21,6 +21,15 @@ from .thermodynamics import (ReferenceState, ThermodynamicConstants, dry_air_gas
                              vapor_gas_constant)
 
 
+class Centered:
+    """Centered(order = 2): the AtmosphereModel constructor's default advection in the reference."""
+
+    def __init__(self, order=2):
+        if order != 2:
+            raise NotImplementedError("Centered(order = 2) is implemented")
+        self.order = 2
+
+
 class WENO:
     """WENO(order=5): only the 5th-order scheme is implemented on the device."""
 
@@ -132,8 +141,7 @@ class AtmosphereModel:
                                  "saturation vapor pressure formulation. Construct the model with, e.g., "
                                  "`thermodynamic_constants = ThermodynamicConstants(saturation_vapor_pressure = TetensFormula())`.")
         if advection is None:
-            raise NotImplementedError("the HIP path requires advection=WENO(order=5) "
-                                      "(the reference default Centered(order=2) is not implemented)")
+            advection = Centered(order=2)          # the reference's default
         if not torch.cuda.is_available():
             raise RuntimeError("AtmosphereModel needs a GPU: the HIP path has no CPU fallback")
         self.grid = grid
@@ -145,7 +153,7 @@ class AtmosphereModel:
         self.clock = Clock()
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self._lib = lib = _lib.load()
+        self._lib = lib = _lib.load(advection.order)
 
         def fld(loc):
             return Field(grid, _LOC[loc], self.device)

@@ -119,6 +119,10 @@ static inline int buffer_at(int idx, int N, int bounded, int at_face)
 /* Upwind-biased value at FACE idx of cell-centred data; p points at cell idx. */
 static inline double biased_face(const double *p, ptrdiff_t s, int left, int idx, int N, int bounded)
 {
+#ifdef OG_CENTERED2   /* libbreeze_oracle_centered2.so: advection = Centered(order = 2): symmetric 2-point interpolation */
+    (void)left; (void)idx; (void)N; (void)bounded;
+    return 0.5 * (p[-s] + p[0]);
+#endif
     int B = buffer_at(idx, N, bounded, 1);
     if (B == 3)
         return left ? weno5(p[-3 * s], p[-2 * s], p[-s], p[0], p[s])
@@ -131,6 +135,10 @@ static inline double biased_face(const double *p, ptrdiff_t s, int left, int idx
 /* Upwind-biased value at CENTRE idx of face data; p points at face idx. */
 static inline double biased_center(const double *p, ptrdiff_t s, int left, int idx, int N, int bounded)
 {
+#ifdef OG_CENTERED2
+    (void)left; (void)idx; (void)N; (void)bounded;
+    return 0.5 * (p[0] + p[s]);
+#endif
     int B = buffer_at(idx, N, bounded, 0);
     if (B == 3)
         return left ? weno5(p[-2 * s], p[-s], p[0], p[s], p[2 * s])
@@ -144,7 +152,12 @@ static inline double biased_center(const double *p, ptrdiff_t s, int left, int i
  * values (q[-2], q[-1], q[0], q[+1]) straddling the target (between q[-1], q[0]). */
 static inline double symm4(double qm2, double qm1, double q0, double qp1)
 {
+#ifdef OG_CENTERED2
+    (void)qm2; (void)qp1;
+    return 0.5 * (qm1 + q0);
+#else
     return (7.0 / 12.0) * (qm1 + q0) - (1.0 / 12.0) * (qm2 + qp1);
+#endif
 }
 static inline double symm2(double qm1, double q0) { return 0.5 * (qm1 + q0); }
 

@@ -38,7 +38,9 @@ _TOPO = {"Periodic": PERIODIC, "Bounded": BOUNDED, "Flat": FLAT, "Slab": SLAB,
 def build(force=False):
     """Compile the C oracle with gcc (recipe: oracle/Makefile)."""
     srcs = [os.path.join(_HERE, f) for f in ("breeze_oracle.c", "breeze_oracle_compressible.inc.c")]
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(map(os.path.getmtime, srcs)):
+    c2 = _LIB_PATH.replace("libbreeze_oracle.so", "libbreeze_oracle_centered2.so")
+    stale = lambda p: not os.path.exists(p) or os.path.getmtime(p) < max(map(os.path.getmtime, srcs))
+    if force or stale(_LIB_PATH) or stale(c2):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -65,18 +67,29 @@ class _OGSA(C.Structure):
 _lib = None
 
 
-def lib():
+_libs = {}
+
+
+def lib(advection="WENO5"):
+    """The C oracle for advection = WENO(order = 5) (default) or "Centered2" = Centered(order = 2), the reference constructor's
+    default scheme (the same sources compiled with -DOG_CENTERED2: every reconstruction is the 2-point symmetric mean)."""
     global _lib
-    if _lib is None:
+    if advection not in ("WENO5", "Centered2"):
+        raise ValueError(advection)
+    if advection not in _libs:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.og_weno5.restype = C.c_double
-        _lib.og_weno5.argtypes = [C.c_double] * 5
-        _lib.og_weno3.restype = C.c_double
-        _lib.og_weno3.argtypes = [C.c_double] * 3
-        _lib.og_buffer_at.restype = C.c_int
-        _lib.og_buffer_at.argtypes = [C.c_int] * 4
-    return _lib
+        path = _LIB_PATH if advection == "WENO5" else _LIB_PATH.replace("libbreeze_oracle.so", "libbreeze_oracle_centered2.so")
+        L = C.CDLL(path)
+        L.og_weno5.restype = C.c_double
+        L.og_weno5.argtypes = [C.c_double] * 5
+        L.og_weno3.restype = C.c_double
+        L.og_weno3.argtypes = [C.c_double] * 3
+        L.og_buffer_at.restype = C.c_int
+        L.og_buffer_at.argtypes = [C.c_int] * 4
+        _libs[advection] = L
+        if advection == "WENO5":
+            _lib = L
+    return _libs[advection]
 
 
 def _p(a):
@@ -256,7 +269,7 @@ class OracleModel:
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
                  standard_pressure=1e5, reference_density=None, initialize=True,
                  formulation="LiquidIcePotentialTemperature", microphysics=None, sa_abstol=1e-4, sa_maxiter=20,
-                 forcings=None, closure=None, tracers=0):
+                 forcings=None, closure=None, tracers=0, advection="WENO5"):
         # formulation "StaticEnergy": self.theta holds e, self.rtheta holds rho*e
         # (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21)
         assert formulation in ("LiquidIcePotentialTemperature", "StaticEnergy")
@@ -277,7 +290,7 @@ class OracleModel:
         if reference_density is not None:      # test hook: set!(reference_state.density, f(z))
             self.ref.density[g.Hz:g.Hz + g.Nz] = reference_density(g.zc)
             self.ref._fill(g)
-        self.lib = lib()
+        self.lib = lib(advection)
         self._mk_cgrid()
         self.qv, self.ql = g.center_field(), g.center_field()
         # DCMIP2016KesslerMicrophysics: prognostic rho q^cl, rho q^r; diagnostic q^cl, q^r, W^r, precipitation_rate; self.q = q^v

@@ -152,7 +152,8 @@ class CompressibleOracleModel:
 
     def __init__(self, grid, constants=None, time_discretization=None, surface_pressure=101325.0,
                  standard_pressure=1e5, reference_potential_temperature=288.0, reference_state=True,
-                 newton_abstol=1e-4, newton_maxiter=8, microphysics=None, reference_vapor_mass_fraction=None):
+                 newton_abstol=1e-4, newton_maxiter=8, microphysics=None, reference_vapor_mass_fraction=None,
+                 advection="WENO5"):
         # microphysics "Kessler": DCMIP2016KesslerMicrophysics — rho q^cl, rho q^r prognostic (dcmip2016_kessler.jl:216)
         # "SaturationAdjustment": SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) on the density-based state
         # (saturation_adjustment.jl:236-301); self.q / self.rq hold the total (equilibrium) moisture, self.qv / self.ql the partition
@@ -167,7 +168,7 @@ class CompressibleOracleModel:
                                         vapor_mass_fraction=reference_vapor_mass_fraction)
                     if reference_state else None)
         self.newton = (float(newton_abstol), int(newton_maxiter))
-        self.lib = lib()
+        self.lib = lib(advection)
         zeros = np.zeros(g.Szc)
         self._zc = zeros
         self.cg = _OGGrid(g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz, g.topo[0], g.topo[1], g.topo[2],

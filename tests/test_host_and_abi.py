@@ -26,6 +26,11 @@ def test_library_exports_every_declared_symbol(bz):
         assert hasattr(lib, name), f"{name} declared in include/breeze_hip.h but not exported"
     assert sorted(bz.SYMBOLS) == declared, "ctypes binding out of sync with the header"
     bz.load()
+    # the Centered(order = 2) build of the same sources exports the same ABI
+    from breeze_jl_amd import _lib
+    lib2 = ctypes.CDLL(_lib.CENTERED2_LIB_PATH)
+    for name in declared:
+        assert hasattr(lib2, name), f"{name} missing from libbreeze_hip_centered2.so"
 
 
 def test_struct_layouts_match_header(bz):
@@ -65,10 +70,12 @@ def test_model_requires_gpu_and_weno5(bz):
     with pytest.raises(NotImplementedError):
         bz.WENO(order=9)
     with pytest.raises(NotImplementedError):
-        bz.AtmosphereModel(g)                      # reference default Centered(2) not implemented
+        bz.Centered(order=4)
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             bz.AtmosphereModel(g, advection=bz.WENO())   # no CPU fallback
+        with pytest.raises(RuntimeError):
+            bz.AtmosphereModel(g)                        # reference default Centered(order = 2): same rule
 
 
 def test_product_never_imports_oracle():

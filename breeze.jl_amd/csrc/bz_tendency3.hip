@@ -27,11 +27,13 @@ static int pick_chunk_lds(const DevGrid &g, int nlev, int rows_per_block)
     long long maxchunks = nlev / 128 > 0 ? nlev / 128 : 1;
     if (want > maxchunks) want = maxchunks;
     if (want < 1) want = 1;
-    // small grids (BOMEX 256 x 256 x 128: 128 tiles): filling the 256 CUs matters more than the prologue, go down to
-    // 32-level chunks until there are two blocks per CU
+    // small grids (BOMEX 256 x 256 x 128: 128 tiles; the 168 x 168 x 40 supercell box: 63): filling the 256 CUs matters more
+    // than the prologue, go down to 8-level chunks until there are two blocks per CU (measured: supercell box 3.3 -> 2.5 ms/step,
+    // BOMEX 128 x 128 x 96 2.6 -> 1.7 ms/step against a 32-level floor; 512^3 is not affected)
     if (tiles * want < 512 && !getenv("BZ_NO_SMALL_CHUNKS")) {
         long long fill = (512 + tiles - 1) / tiles;
-        long long cap = nlev / 32 > 0 ? nlev / 32 : 1;
+        const int minlev = getenv("BZ_MIN_CHUNK") ? atoi(getenv("BZ_MIN_CHUNK")) : 8;
+        long long cap = nlev / minlev > 0 ? nlev / minlev : 1;
         if (fill > cap) fill = cap;
         if (fill > want) want = fill;
     }

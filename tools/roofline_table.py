@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""tools/roofline_table.py — per-kernel roofline table (markdown) from a bench.py JSON line and the PMC traffic file.
+
+    python tools/roofline_table.py profiles/r01_bench512_v12_default.json profiles/r01_pmc_traffic.json > profiles/r01_roofline_table.md
+Columns: HIP-event ms per step and per launch, algorithmic bytes per launch (SURVEY §8d words x 8 B x cells), the rate that
+implies against the 8 TB/s HBM peak, and the HBM bytes the kernel really moved (rocprofv3 PMC passes) with the rate that implies.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    bench, pmc = sys.argv[1], sys.argv[2]
+    from bench import WORDS_PER_CELL
+    b = json.load(open(bench))
+    p = json.load(open(pmc))["per_kernel_group"]
+    cells = 1
+    for n in b["config"]["grid_per_gpu"] if "grid_per_gpu" in b["config"] else b["config"]["grid"]:
+        cells *= n
+    launches = {"poisson_fft_forward": 3, "poisson_fft_inverse": 3}
+    print(f"# Per-kernel roofline, {b['config']['workload']}\n")
+    print(f"Step: {b['ms_per_step']:.2f} ms, {b['value'] / 1e9:.3f} Gcells/s, step fraction of the 8 TB/s roofline at 2000 B/cell/step: "
+          f"{b['step_roofline']['frac']:.3f}.  Source: `{os.path.basename(bench)}` (HIP events on the launch stream), "
+          f"`{os.path.basename(pmc)}` (rocprofv3 PMC, HBM-side bytes per launch).\n")
+    print("| kernel group | ms/step | ms/launch | algorithmic GB/launch | algorithmic TB/s | frac of 8 TB/s | PMC GB/launch | PMC TB/s |")
+    print("|---|---|---|---|---|---|---|---|")
+    tot = 0.0
+    for name, ms in sorted(b["kernels_ms_per_step"].items(), key=lambda kv: -kv[1]):
+        tot += ms
+        per_launch = ms / launches.get(name, 3)
+        w = WORDS_PER_CELL.get(name)
+        alg = w * 8 * cells / 1e9 if w else None
+        traffic = p.get(name, {}).get("hbm_bytes_per_launch")
+        row = [name, f"{ms:.2f}", f"{per_launch:.3f}",
+               f"{alg:.2f}" if alg else "—", f"{alg / per_launch:.2f}" if alg else "—", f"{alg / per_launch / 8:.3f}" if alg else "—",
+               f"{traffic / 1e9:.2f}" if traffic else "—", f"{traffic / 1e9 / per_launch:.2f}" if traffic else "—"]
+        print("| " + " | ".join(row) + " |")
+    print(f"\nSum of kernel time {tot:.2f} ms of the {b['ms_per_step']:.2f} ms step (the rest is launch gaps and two memsets).")
+
+
+if __name__ == "__main__":
+    main()

@@ -94,7 +94,7 @@ _ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "ρθ": "ρθ", "rho_the
             "u": "u", "v": "v", "w": "w", "ρu": "ρu", "ρv": "ρv", "ρw": "ρw",
             "rho_u": "ρu", "rho_v": "ρv", "rho_w": "ρw",
             "qᵗ": "q", "qt": "q", "qᵛ": "q", "qv": "q", "qᵉ": "q", "qe": "q", "ρqᵗ": "ρq", "ρqᵛ": "ρq", "ρqᵉ": "ρq", "ρqe": "ρq",
-            "rho_q": "ρq", "qᶜˡ": "qcl", "qcl": "qcl", "qʳ": "qr", "qr": "qr",
+            "rho_q": "ρq", "qᶜˡ": "qcl", "qcl": "qcl", "qʳ": "qr", "qr": "qr", "T": "T", "ℋ": "ℋ", "H": "ℋ", "relative_humidity": "ℋ",      # Python NFKC-normalises the keyword ℋ to H
             # NFKC-normalised spellings (Python normalises identifiers used as keywords)
             "θli": "θ", "ρqt": "ρq", "ρqv": "ρq"}
 
@@ -409,10 +409,52 @@ def set_(model, enforce_mass_conservation=True, **kw):
     ρc = torch.from_numpy(ref.density[Hz:Hz + Nz].copy()).to(model.device)[:, None, None]
     ρf_host = 0.5 * (ref.density[Hz - 1:Hz + Nz] + ref.density[Hz:Hz + Nz + 1])
     ρf = torch.from_numpy(ρf_host).to(model.device)[:, None, None]
-    for name, value in sorted(kw.items(), key=lambda kv: 0 if _ALIASES.get(kv[0]) in ("q", "ρq") else 1):   # moisture first
+    order = {"q": 0, "ρq": 0, "ℋ": 2}        # moisture first; ℋ after everything else (it needs the diagnosed temperature)
+    for name, value in sorted(kw.items(), key=lambda kv: order.get(_ALIASES.get(kv[0]), 1)):
         key = _ALIASES.get(name)
         if key in ("e", "ρe") and model.formulation != "StaticEnergy":
             key = None
+        if key in ("T", "ℋ") and (model.formulation != "LiquidIcePotentialTemperature" or getattr(model, "_kessler", False)):
+            raise NotImplementedError(f"set!(model; {name}) is implemented for the potential-temperature formulation "
+                                      "(microphysics nothing or SaturationAdjustment)")
+        if key == "T":
+            # set_thermodynamic_variable!(model, Val(:T), value) (potential_temperature_tendency.jl:202-250): theta^li from the
+            # in-situ temperature with the current moisture fractions, theta = (T - L q^l / c_pm) / Pi
+            c = model.thermodynamic_constants
+            Rd, Rv = dry_air_gas_constant(c), vapor_gas_constant(c)
+            model.temperature.set_interior(value)
+            if model.microphysics is not None:
+                qv, ql = model.microphysical_fields["qᵛ"].interior, model.microphysical_fields["qˡ"].interior
+                cl, Ll = c.liquid_heat_capacity, c.liquid_reference_latent_heat
+            else:
+                qv, ql, cl, Ll = model.specific_moisture.interior, 0.0, 0.0, 0.0
+            qd = 1.0 - (qv + ql)
+            Rm, cpm = qd * Rd + qv * Rv, qd * c.dry_air_heat_capacity + qv * c.vapor_heat_capacity + ql * cl
+            pr = torch.from_numpy(ref.pressure[Hz:Hz + Nz].copy()).to(model.device)[:, None, None]
+            Π = (pr / ref.standard_pressure) ** (Rm / cpm)
+            model.potential_temperature.interior.copy_((model.temperature.interior - Ll * ql / cpm) / Π)
+            model.potential_temperature_density.interior.copy_(ρc * model.potential_temperature.interior)
+            continue
+        if key == "ℋ":
+            # set!(model; ℋ) (set_atmosphere_model.jl:280-297): update_state!, q^v+ = SaturationSpecificHumidity(model, :equilibrium)
+            # (vapor_saturation.jl:216-230) materialised before the moisture is overwritten, q = ℋ q^v+, rho q = rho_r q
+            update_state_(model, compute_tendencies=False)
+            c = model.thermodynamic_constants
+            Rd, Rv = dry_air_gas_constant(c), vapor_gas_constant(c)
+            T, qt = model.temperature.interior, model.specific_moisture.interior
+            pr = torch.from_numpy(ref.pressure[Hz:Hz + Nz].copy()).to(model.device)[:, None, None]
+            dc = c.vapor_heat_capacity - c.liquid_heat_capacity
+            L0 = c.liquid_reference_latent_heat - dc * c.energy_reference_temperature
+            ps = c.triple_point_pressure * (T / c.triple_point_temperature) ** (dc / Rv) * \
+                torch.exp((1.0 / c.triple_point_temperature - 1.0 / T) * L0 / Rv)
+            q1 = (Rd / Rv) * (1.0 - qt) * ps / (pr - ps)
+            ρ = pr / ((Rd * (1.0 - qt) + Rv * qt) * T)
+            q0 = ps / (ρ * Rv * T)
+            qsat = torch.where(qt >= q0, q1, q0)
+            model.specific_moisture.set_interior(value)
+            model.specific_moisture.interior.mul_(qsat)
+            model.moisture_density.interior.copy_(ρc * model.specific_moisture.interior)
+            continue
         if key is None:
             raise ValueError(f"Cannot set! {name} in AtmosphereModel because {name} is neither a prognostic "
                              "variable, a settable thermodynamic variable, nor a settable diagnostic variable!")

@@ -533,3 +533,60 @@ def test_minimal_and_ragged_grids_step_like_the_oracle(oracle, bz, size):
         scale = mom if n in ("ru", "rv", "rw") else max(np.abs(want).max(), 1e-3)
         assert np.abs(got - want).max() / scale < 1e-10, (n, size)
     assert np.isfinite(hm.temperature.interior_cpu()).all()
+
+
+@pytest.mark.gpu
+def test_reference_set_temperature_and_relative_humidity(bz):
+    """test/set_atmosphere_model.jl:100-155 and :157-215 restated on the device model: set!(model; T) reproduces the lapse-rate
+    profile (rtol 1e-4) with theta increasing upward and a T -> theta -> T round trip; set!(model; θ, ℋ) yields the requested
+    relative humidity (rtol 5e-2), a function ℋ(z) is followed level by level, and ℋ = 1.5 condenses everywhere with the
+    adjusted state capped at saturation."""
+    grid = bz.RectilinearGrid((4, 4, 10), x=(0, 1000.0), y=(0, 1000.0), z=(0, 5000.0))
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=300.0)
+    m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5))
+    T_profile = lambda x, y, z: 300.0 - 0.0065 * z + 0 * x + 0 * y
+    m.set(T=T_profile, qᵗ=0.0)
+    zc = np.asarray(grid.zᶜ)
+    T = m.temperature.interior_cpu()
+    np.testing.assert_allclose(T[:, 0, 0], 300.0 - 0.0065 * zc, rtol=1e-4)
+    th = m.potential_temperature.interior_cpu()[:, 0, 0]
+    assert np.all(np.diff(th) > 0)
+    m.set(T=280.0, qᵗ=0.0)
+    assert m.temperature.interior_cpu()[4, 1, 1] == pytest.approx(280.0, rel=1e-4)
+
+    # relative humidity with warm-phase saturation adjustment
+    grid1 = bz.RectilinearGrid((8, 8, 8), x=(0, 1e3), y=(0, 1e3), z=(0, 1e3))
+    ref1 = bz.ReferenceState(grid1, surface_pressure=101325.0, potential_temperature=300.0)
+    c = bz.ThermodynamicConstants()
+    from breeze_jl_amd.thermodynamics import dry_air_gas_constant, vapor_gas_constant
+    Rd, Rv = dry_air_gas_constant(c), vapor_gas_constant(c)
+
+    def relative_humidity(model):      # p^v / p^v+ with p^v = q^v rho R^v T, rho = p_r / (R^m T)
+        T = model.temperature.interior_cpu()
+        qv, ql = model.microphysical_fields["qᵛ"].interior_cpu(), model.microphysical_fields["qˡ"].interior_cpu()
+        Hz, Nz = grid1.Hz, grid1.Nz
+        pr = ref1.pressure[Hz:Hz + Nz][:, None, None]
+        Rm = (1 - qv - ql) * Rd + qv * Rv
+        rho = pr / (Rm * T)
+        dc = c.vapor_heat_capacity - c.liquid_heat_capacity
+        L0 = c.liquid_reference_latent_heat - dc * c.energy_reference_temperature
+        ps = c.triple_point_pressure * (T / c.triple_point_temperature) ** (dc / Rv) * np.exp((1 / c.triple_point_temperature - 1 / T) * L0 / Rv)
+        return qv * rho * Rv * T / ps
+
+    def moist_model():
+        return bz.AtmosphereModel(grid1, dynamics=bz.AnelasticDynamics(ref1), advection=bz.WENO(order=5), thermodynamic_constants=c,
+                                  microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()))
+
+    m1 = moist_model()
+    m1.set(θ=300.0, ℋ=0.5)
+    np.testing.assert_allclose(relative_humidity(m1), 0.5, rtol=5e-2)
+    assert (m1.microphysical_fields["qᵛ"].interior_cpu() > 0).all()
+    m2 = moist_model()
+    H = lambda x, y, z: 0.8 * np.exp(-z / 500.0) + 0 * x + 0 * y
+    m2.set(θ=300.0, ℋ=H)
+    zc1 = np.asarray(grid1.zᶜ)
+    np.testing.assert_allclose(relative_humidity(m2)[:, 0, 0], 0.8 * np.exp(-zc1 / 500.0), rtol=5e-2)
+    m3 = moist_model()
+    m3.set(θ=300.0, ℋ=1.5)
+    assert (m3.microphysical_fields["qˡ"].interior_cpu() > 0).all()
+    assert (relative_humidity(m3) <= 1.01).all()

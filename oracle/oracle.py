@@ -7,7 +7,13 @@ bench.py's cpu_baseline leg; never by the product package (breeze.jl_amd/).
 PARITY STATUS: "parity unpinned" for the WENO reconstruction arithmetic and the
 Oceananigans pieces (see breeze_oracle.c header).  Pinned parts: thermodynamic
 constants / reference columns / Poisson solve / projection / conservation via the
-reference's own known-answer tests restated in tests/.
+reference's own known-answer tests restated in tests/; and, with REFERENCE-GENERATED
+numbers (the Field summaries its model-level jldoctests print with six digits, kept in
+tests/golden/reference_doctests.json): the default ReferenceState pressure column and
+the theta -> T diagnosis (StaticEnergy doctest), the vapour-only virtual potential
+temperature, the saturation-adjustment state + Clausius-Clapeyron pressure
+(RelativeHumidity doctest, 128 levels) and the dewpoint inversion
+(tests/test_golden_reference.py; the device model repeats two of them on the GPU).
 
 Reference call stack restated here (file:line relative to /root/reference):
   time_step!            src/TimeSteppers/ssp_runge_kutta_3.jl:209-278

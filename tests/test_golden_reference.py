@@ -135,3 +135,89 @@ def test_moist_compressible_update_state_is_density_consistent(oracle):
             assert qv[idx] == pytest.approx(th.saturation_specific_humidity(T[idx], r[idx], tc, "liquid"), abs=1e-4)
     m.time_step(1e-3)
     assert np.isfinite(I(m.T)).all()
+
+
+# ---- model-level doctest outputs: reference-generated numbers for the reference column + temperature diagnosis -----------------
+
+def _sig(x, digits=6):
+    """Tolerance of a value printed with `digits` significant digits (Julia's Field summary prints 6)."""
+    return 0.6 * 10.0 ** (np.floor(np.log10(abs(x))) - (digits - 1))
+
+
+def _column_model(oracle, Nz, microphysics=None):
+    g = oracle.Grid((4, 4, Nz), x=(0, 1.0), y=(0, 1.0), z=(-1000.0, 0.0))     # extent = (., ., 1e3): z in (-1000, 0)
+    return oracle.OracleModel(g, microphysics=microphysics)                         # every default: p0 = 101325, theta0 = 288, p_st = 1e5
+
+
+def test_static_energy_doctest_pins_reference_column_and_temperature(oracle, golden):
+    """StaticEnergy(model) after set!(model, θ = 300) on the default model: e = c_pm T + g z with T = Pi(p_r(z)) theta — the printed
+    max / min / mean (6 significant digits) pin the reference pressure column (ReferenceState defaults, adiabatic hydrostatic
+    closed form) and the theta -> T diagnosis of the oracle to reference-generated numbers."""
+    gd = golden["model_diagnostics"]["static_energy"]
+    m = _column_model(oracle, 8)
+    m.set(theta=300.0)
+    g, c = m.grid, m.constants
+    T = g.interior(m.T)[:, 0, 0]
+    e = c.cpd * T + c.g * g.zc
+    for key, val in (("max", e.max()), ("min", e.min()), ("mean", e.mean())):
+        assert abs(val - gd[key]) <= _sig(gd[key]), (key, val, gd[key])
+
+
+def test_virtual_potential_temperature_doctest(oracle, golden):
+    """VirtualPotentialTemperature after set!(model, θ = 300, qᵗ = 0.01): (T / Pi_d)(1 + (R_v/R_d - 1) q^v)
+    (potential_temperatures.jl:574-579); printed with 5 significant digits."""
+    gd = golden["model_diagnostics"]["virtual_potential_temperature"]
+    m = _column_model(oracle, 8)
+    m.set(qt=0.01, theta=300.0)
+    g, c, r = m.grid, m.constants, m.ref
+    T, q = g.interior(m.T)[:, 0, 0], g.interior(m.q)[:, 0, 0]
+    p = r.pressure[g.Hz:g.Hz + g.Nz]
+    thv = T / (p / r.pst) ** (c.Rd / c.cpd) * (1 + (c.Rv / c.Rd - 1) * q)
+    for key, val in (("max", thv.max()), ("min", thv.min()), ("mean", thv.mean())):
+        assert abs(val - gd[key]) <= 0.006, (key, val, gd[key])
+
+
+def test_relative_humidity_doctest_pins_saturation_adjustment_state(oracle, golden, thermo):
+    """RelativeHumidity on the default SaturationAdjustment model, θ = 300, qᵗ = 0.005 (subsaturated), 128 levels: p^v / p^v+ with
+    p^v = rho q^v R_v T, rho = p_r / (R_m T) (microphysics_diagnostics.jl:139-170).  Six printed digits pin the adjusted
+    temperature, the Clausius-Clapeyron saturation pressure and the reference column together."""
+    gd = golden["model_diagnostics"]["relative_humidity"]
+    m = _column_model(oracle, 128, microphysics="SaturationAdjustment")
+    m.set(qt=0.005, theta=300.0)
+    g, c, r = m.grid, m.constants, m.ref
+    T, qv, ql = (g.interior(f)[:, 0, 0] for f in (m.T, m.qv, m.ql))
+    assert np.all(ql == 0)
+    p = r.pressure[g.Hz:g.Hz + g.Nz]
+    rho = p / (((1 - qv - ql) * c.Rd + qv * c.Rv) * T)
+    tc = thermo.ThermoConstants()
+    ps = np.array([thermo.saturation_vapor_pressure(t, tc, "liquid") for t in T])
+    rh = rho * qv * c.Rv * T / ps
+    for key, val in (("max", rh.max()), ("min", rh.min()), ("mean", rh.mean())):
+        assert abs(val - gd[key]) <= _sig(gd[key]), (key, val, gd[key])
+
+
+def test_dewpoint_temperature_doctest(oracle, golden, thermo):
+    """DewpointTemperature on the default SaturationAdjustment model, θ = 300, qᵗ = 0.01, 8 levels: secant inversion of the
+    saturation vapour pressure (vapor_saturation.jl:313-331: guesses T and T - 20 (1 - ℋ), SecantSolver(reltol = 1e-4, abstol = 0,
+    maxiter = 10) scaled by p^v) of p^v = rho q^v R_v T.  Six printed digits."""
+    gd = golden["model_diagnostics"]["dewpoint_temperature"]
+    m = _column_model(oracle, 8, microphysics="SaturationAdjustment")
+    m.set(qt=0.01, theta=300.0)
+    g, c, r = m.grid, m.constants, m.ref
+    T, qv, ql = (g.interior(f)[:, 0, 0] for f in (m.T, m.qv, m.ql))
+    p = r.pressure[g.Hz:g.Hz + g.Nz]
+    tc = thermo.ThermoConstants()
+    out = []
+    for Tk, qvk, qlk, pk in zip(T, qv, ql, p):
+        rho = pk / (((1 - qvk - qlk) * c.Rd + qvk * c.Rv) * Tk)
+        pv = rho * qvk * c.Rv * Tk
+        ps1 = thermo.saturation_vapor_pressure(Tk, tc, "liquid")
+        if ps1 - pv <= 0:
+            out.append(Tk)
+            continue
+        T2 = Tk - (1 - pv / ps1) * 20
+        out.append(thermo.secant_solve(lambda x: thermo.saturation_vapor_pressure(x, tc, "liquid") - pv, Tk, T2, pv,
+                                       reltol=1e-4, abstol=0.0, maxiter=10))
+    Td = np.array(out)
+    for key, val in (("max", Td.max()), ("min", Td.min()), ("mean", Td.mean())):
+        assert abs(val - gd[key]) <= _sig(gd[key]), (key, val, gd[key])

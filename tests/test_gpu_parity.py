@@ -590,3 +590,37 @@ def test_reference_set_temperature_and_relative_humidity(bz):
     m3.set(θ=300.0, ℋ=1.5)
     assert (m3.microphysical_fields["qˡ"].interior_cpu() > 0).all()
     assert (relative_humidity(m3) <= 1.01).all()
+
+
+@pytest.mark.gpu
+def test_device_reproduces_reference_doctest_numbers(bz):
+    """The reference-generated Field summaries of the StaticEnergy and RelativeHumidity doctests (tests/golden/reference_doctests.json,
+    six printed digits), recomputed from the DEVICE model's temperature / moisture fields on the doctests' default models."""
+    import json
+    import os
+    gd = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_doctests.json"), encoding="utf-8"))["model_diagnostics"]
+    sig = lambda x: 0.6 * 10.0 ** (np.floor(np.log10(abs(x))) - 5)
+    c = bz.ThermodynamicConstants()
+    from breeze_jl_amd.thermodynamics import dry_air_gas_constant, vapor_gas_constant
+    Rd, Rv = dry_air_gas_constant(c), vapor_gas_constant(c)
+    grid = bz.RectilinearGrid((8, 8, 8), x=(0, 1.0), y=(0, 1.0), z=(-1000.0, 0.0))
+    m = bz.AtmosphereModel(grid)                    # every default, as in the doctest (advection Centered(2), ReferenceState defaults)
+    m.set(θ=300.0)
+    T = m.temperature.interior_cpu()[:, 0, 0]
+    e = c.dry_air_heat_capacity * T + c.gravitational_acceleration * np.asarray(grid.zᶜ)
+    for key, val in (("max", e.max()), ("min", e.min()), ("mean", e.mean())):
+        assert abs(val - gd["static_energy"][key]) <= sig(gd["static_energy"][key]), (key, val)
+    grid2 = bz.RectilinearGrid((8, 8, 128), x=(0, 1e3), y=(0, 1e3), z=(-1000.0, 0.0))
+    m2 = bz.AtmosphereModel(grid2, microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()))
+    m2.set(θ=300.0, qᵗ=0.005)
+    T = m2.temperature.interior_cpu()[:, 0, 0]
+    qv = m2.microphysical_fields["qᵛ"].interior_cpu()[:, 0, 0]
+    ref = m2.dynamics.reference_state
+    p = ref.pressure[grid2.Hz:grid2.Hz + grid2.Nz]
+    rho = p / (((1 - qv) * Rd + qv * Rv) * T)
+    dc = c.vapor_heat_capacity - c.liquid_heat_capacity
+    L0 = c.liquid_reference_latent_heat - dc * c.energy_reference_temperature
+    ps = c.triple_point_pressure * (T / c.triple_point_temperature) ** (dc / Rv) * np.exp((1 / c.triple_point_temperature - 1 / T) * L0 / Rv)
+    rh = rho * qv * Rv * T / ps
+    for key, val in (("max", rh.max()), ("min", rh.min()), ("mean", rh.mean())):
+        assert abs(val - gd["relative_humidity"][key]) <= sig(gd["relative_humidity"][key]), (key, val)

@@ -54,5 +54,39 @@ out = {
         "output": grab("src/Solvers.jl", r"secant_solve\(x -> x\^2 - 2, solver, 1\.0, 2\.0, 1\.0\)\nround\(x, digits=10\)\n\n# output\n([0-9.eE+-]+)"),
     },
 }
+
+
+def stats(path, after):
+    """max / min / mean of the Field summary printed after the first occurrence of `after` in the docstrings of `path`."""
+    text = open(f"{root}/{path}", encoding="utf-8").read()
+    i = text.index(after)
+    m = re.search(r"max=([0-9.eE+-]+), min=([0-9.eE+-]+), mean=([0-9.eE+-]+)", text[i:])
+    return {"max": float(m.group(1)), "min": float(m.group(2)), "mean": float(m.group(3))}
+
+
+# model-level doctests: AtmosphereModel(grid) with every default (ReferenceState p0 = 101325 Pa, theta0 = 288 K, p_st = 1e5 Pa) on
+# RectilinearGrid(size = (1, 1, N), extent = (1, 1, 1e3)), i.e. z in (-1000, 0)
+out["model_diagnostics"] = {
+    "static_energy": {
+        "source": "src/AtmosphereModels/Diagnostics/static_energy.jl (jldoctest of StaticEnergy)",
+        "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300}},
+        **stats("src/AtmosphereModels/Diagnostics/static_energy.jl", "e = StaticEnergy(model)"),
+    },
+    "virtual_potential_temperature": {
+        "source": "src/AtmosphereModels/Diagnostics/potential_temperatures.jl (jldoctest of VirtualPotentialTemperature)",
+        "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300, "qt": 0.01}},
+        **stats("src/AtmosphereModels/Diagnostics/potential_temperatures.jl", "θᵛ = VirtualPotentialTemperature(model)\nField(θᵛ)"),
+    },
+    "dewpoint_temperature": {
+        "source": "src/AtmosphereModels/Diagnostics/dewpoint_temperature.jl (jldoctest dewpoint): SaturationAdjustment() defaults",
+        "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300, "qt": 0.01}},
+        **stats("src/AtmosphereModels/Diagnostics/dewpoint_temperature.jl", "T⁺_field = Field(T⁺)"),
+    },
+    "relative_humidity": {
+        "source": "src/Microphysics/microphysics_diagnostics.jl (jldoctest rh): SaturationAdjustment() defaults",
+        "inputs": {"size": [1, 1, 128], "extent": [1e3, 1e3, 1e3], "set": {"theta": 300, "qt": 0.005}},
+        **stats("src/Microphysics/microphysics_diagnostics.jl", "ℋ_field = RelativeHumidity(model) |> Field"),
+    },
+}
 json.dump(out, sys.stdout, indent=1, ensure_ascii=False)
 sys.stdout.write("\n")

@@ -7,16 +7,24 @@ grid_points_per_second = Nx*Ny*Nz / time_per_step).  Workload: BASELINE.json con
 thermal bubble on a 512^3 RectilinearGrid (SURVEY.md §8d "C2"), Float64, fixed dt = 1 s,
 deterministic synthetic initial state resident in HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W [--size 512]
+    python bench.py --gpus N --steps K --warmup W [--size 512] [--scaling weak|strong] [--workload bubble|config3]
 
-Prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run, one rank per GPU over RCCL:
-weak scaling, every rank owns a 512 x 512 x 512 y-slab of a 512 x (512 N) x 512 periodic domain
-(breeze.jl_amd/distributed.py: y-halo exchange + FFT transposes); `value` is the aggregate over ranks.
-`--replicas` runs N independent copies of the N=1 workload instead (no collective in the data path).
+Prints ONE JSON line (rank 0).  N > 1: one rank per GPU over RCCL, y-slab decomposition
+(breeze.jl_amd/distributed.py: y-halo exchange + FFT transposes):
+  --scaling weak    (default) every rank owns a size^3 slab of a size x (size N) x size periodic domain
+  --scaling strong  the size^3 domain of the N = 1 run is split N ways ("1/2/4/8-GPU cells/s for 512^3")
+  --workload config3  BASELINE.json configs[3]: 1024 x 1024 x 512 split over the N ranks (8 ranks -> 1024 x 128 x 512 each)
+`value` is the aggregate over ranks; `comm_ms_per_step` / `compute_ms_per_step` split the step of the slowest rank.
+If the ranks are not there yet (WORLD_SIZE unset, as in `python bench.py --gpus 8`), the script launches itself under
+torch.distributed.run and relays the ranks' line; a failed multi-GPU run prints a JSON line with an "error" field and
+exits non-zero — it never silently measures something else.  `--replicas` (explicit only) runs N independent copies.
 """
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,6 +51,7 @@ WORDS_PER_CELL = {
     "scalar_tendencies+rk3": 19,
 }
 A_STEP_WORDS = 250          # 3 stages x 80 + 10
+METRIC = "grid-cells advanced/sec (tendency+Poisson step), 512^3 anelastic"
 
 
 def bubble(x, y, z):
@@ -100,23 +109,330 @@ def compressible_milestone(bz, device, steps=2):
     return out
 
 
-def cpu_baseline(n, steps):
-    """The CPU oracle ("port": this repo's C/OpenMP restatement, not Breeze CPU()) timed on this
-    box's host cores on a bounded sample of the same workload: the bubble at n^3."""
+def cpu_baseline(n, budget_s=25.0):
+    """The CPU oracle ("port": this repo's C/OpenMP restatement, not Breeze CPU() — Julia is not installed)
+    timed on this box's host cores on a bounded sample of the same workload: the bubble at n^3 (default 256^3, an eighth
+    of the 512^3 domain at the same spacing ratio), as many steps as fit in `budget_s` seconds after one warm-up step.
+    Threads: one per physical core up to 64 (the stencil kernels stop scaling beyond that on a 16 M-cell grid, and a
+    256-thread team on a 2 M-cell grid measured *slower* in round 1); the horizontal transforms run pocketfft on the same
+    number of threads.  Both the all-cores and the chosen count are printed."""
     from oracle import oracle as orc
     cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    threads = max(1, min(64, cores // 2 if cores >= 16 else cores))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     g = orc.Grid((n, n, n), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
     m = orc.OracleModel(g, potential_temperature=300.0)
+    m.fft_workers = threads
     m.set(theta=bubble)
+    t0 = time.perf_counter()
     m.time_step(1.0)                       # warm-up (also the first-step update_state)
+    first = time.perf_counter() - t0
+    steps = int(max(2, min(20, budget_s / max(first, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
         m.time_step(1.0)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": n ** 3 / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+    return {"value": n ** 3 / dt, "unit": "cells/s", "cores": threads, "host_cores_available": cores, "kind": "port",
+            "s_per_step": dt,
             "sample": f"dry thermal bubble {n}^3 Float64, {steps} steps after 1 warm-up, "
-                      f"C/OpenMP oracle ({cores} threads) + numpy pocketfft"}
+                      f"C/OpenMP oracle on {threads} threads + pocketfft on {threads} threads"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a rendezvous environment starts its own ranks
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def error_line(args, message, **extra):
+    out = {"metric": METRIC, "value": None, "unit": "cells/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic", "config": {"workload": args.workload, "parallelism": f"{args.gpus} y-slabs"},
+           "error": message}
+    out.update(extra)
+    return json.dumps(out)
+
+
+def launch_self(args, argv):
+    """Re-execute this script under torch.distributed.run with one rank per GPU and relay the ranks' JSON line."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)        # exactly the process group started above
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        print(error_line(args, f"ranks did not finish within {args.launch_timeout} s (hang in a collective?)"))
+        return 1
+    line = None
+    for ln in (out or "").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    if line is None:
+        print(error_line(args, f"ranks exited with code {proc.returncode} without a result line"))
+        return proc.returncode or 1
+    print(line)
+    return 0 if (proc.returncode == 0 and "\"error\"" not in line) else (proc.returncode or 1)
+
+
+def comm_selfcheck(decomp, device, Nz=4):
+    """Pre-flight check of the transport on small tensors, before the model commits to it: one y-halo exchange and both
+    spectral transposes with rank-coded contents, verified against what the neighbours must have sent.  Raises on mismatch."""
+    import torch
+    d = decomp
+    Sy, Sx = d.Ny + 2 * d.Hy, d.Nx + 6
+    f = torch.zeros((Nz, Sy, Sx), dtype=torch.float64, device=device)
+    rows = torch.arange(d.Ny, dtype=torch.float64, device=device)
+    f[:, d.Hy:d.Hy + d.Ny, :] = (1000.0 * d.rank + rows)[None, :, None]
+    d.exchange_y_halos([f])
+    lo = 1000.0 * d.lower + torch.arange(d.Ny - d.Hy, d.Ny, dtype=torch.float64, device=device)
+    hi = 1000.0 * d.upper + torch.arange(0, d.Hy, dtype=torch.float64, device=device)
+    if not (torch.equal(f[0, :d.Hy, 0], lo) and torch.equal(f[-1, d.Hy + d.Ny:, -1], hi)):
+        raise RuntimeError(f"rank {d.rank}: y-halo exchange delivered wrong rows")
+    # transposes: R[k, j, kx] = global row + 1000 kx  ->  S[k, kx_local, J] must equal J + 1000 (kx0 + kx_local)
+    jj = (d.rank * d.Ny + torch.arange(d.Ny, device=device, dtype=torch.float64))[None, :, None]
+    kk = torch.arange(d.nxh, device=device, dtype=torch.float64)[None, None, :]
+    R = (jj + 1000.0 * kk).expand(Nz, d.Ny, d.nxh).to(torch.complex128).contiguous()
+    save_Nz, d.Nz = d.Nz, Nz
+    try:
+        S = d.to_kx_slabs(R)
+        J = torch.arange(d.Ny_global, device=device, dtype=torch.float64)[None, None, :]
+        kx = d.kx0 + torch.arange(d.nkx, device=device, dtype=torch.float64)[None, :, None]
+        want = torch.where(kx < d.nxh, J + 1000.0 * kx, torch.zeros((), dtype=torch.float64, device=device)).expand(Nz, d.nkx, d.Ny_global)
+        if not torch.equal(S.real, want):
+            raise RuntimeError(f"rank {d.rank}: transpose to kx-slabs delivered wrong blocks")
+        back = d.to_y_slabs(S)
+        if not torch.equal(back[:, :, :d.nxh].real, R.real):
+            raise RuntimeError(f"rank {d.rank}: transpose back to y-slabs delivered wrong blocks")
+    finally:
+        d.Nz = save_Nz
+
+
+def problem(args, world):
+    """Global grid size, per-rank slab and the label of the workload."""
+    N = args.size
+    if args.workload == "config3":
+        G = (1024, 1024, 512)
+        label = ("dry thermal bubble 1024x1024x512 RectilinearGrid (Periodic,Periodic,Bounded), halo 3, AnelasticDynamics + WENO5 + "
+                 "SSP-RK3, Float64, dt=1s, y-slabs (BASELINE.json configs[3])")
+        scaling = "strong"
+    elif args.scaling == "strong" or world == 1:
+        G = (N, N, N)
+        label = (f"dry thermal bubble {N}^3 RectilinearGrid (Periodic,Periodic,Bounded), halo 3, AnelasticDynamics + WENO5 + "
+                 "SSP-RK3, Float64, dt=1s (BASELINE.json configs[1])")
+        scaling = "strong" if world > 1 else args.scaling
+    else:
+        G = (N, N * world, N)
+        label = (f"dry thermal bubble {N}^3 per GPU: {N}x{N * world}x{N} RectilinearGrid (Periodic,Periodic,Bounded), halo 3, "
+                 "AnelasticDynamics + WENO5 + SSP-RK3, Float64, dt=1s (BASELINE.json configs[1] per rank)")
+        scaling = "weak"
+    if G[1] % world:
+        raise ValueError(f"Ny = {G[1]} is not divisible by {world} ranks")
+    return G, label, scaling
+
+
+def run_rank(args):
+    import torch
+    import breeze_jl_amd as bz
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    cpu_selftest = args.selftest_launcher
+    dist = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        timeout = datetime.timedelta(seconds=args.collective_timeout)
+        if cpu_selftest:
+            dist.init_process_group("gloo", timeout=timeout)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=timeout)
+    device = "cpu" if cpu_selftest else f"cuda:{local_rank}"
+
+    def fail(message):
+        """Every rank reports; rank 0 prints the JSON error line.  Never falls back to a different measurement."""
+        print(f"[bench rank {rank}] {message}", file=sys.stderr, flush=True)
+        if rank == 0:
+            print(error_line(args, message), flush=True)
+        os._exit(1)          # peers may be blocked in a collective: leave without the process-group teardown
+
+    if rank == 0 and world > 1:
+        # torch.distributed.run sends SIGTERM to the surviving ranks when one dies: still leave a result line
+        signal.signal(signal.SIGTERM, lambda *_: (print(error_line(args, "terminated by the launcher: another rank failed"),
+                                                        flush=True), os._exit(1)))
+
+    if cpu_selftest:
+        # launcher self-test (tests/test_bench_launcher.py): rendezvous, the slab communication pattern on CPU tensors
+        # under gloo, result line — no model, no GPU
+        from breeze_jl_amd.distributed import SlabDecomposition
+        d = SlabDecomposition(20, 6, 4, 3, rank, world)
+        try:
+            comm_selfcheck(d, "cpu")
+        except Exception as exc:   # noqa: BLE001
+            fail(f"communication self-check failed: {exc!r}")
+        ok = torch.ones(1, dtype=torch.int32)
+        if dist is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": "ok", "n_gpus": world, "backend": "gloo"}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
+
+    dt = 1.0
+    G, label, scaling = problem(args, world)
+    use_slabs = (world > 1 and not args.replicas) or (world == 1 and args.slab)
+    parallelism = "single GPU"
+    decomp = None
+    if use_slabs:
+        from breeze_jl_amd.distributed import SlabAtmosphereModel
+        Ly = (EXTENT[1][1] - EXTENT[1][0]) * (G[1] / G[0]) if args.workload != "config3" else (EXTENT[1][1] - EXTENT[1][0])
+        ggrid = bz.RectilinearGrid(G, x=EXTENT[0], y=(EXTENT[1][0], EXTENT[1][0] + Ly), z=EXTENT[2])
+
+        def bubbles(x, y, z):          # one bubble per 20 km of y
+            yy = np.mod(y - EXTENT[1][0], EXTENT[1][1] - EXTENT[1][0]) + EXTENT[1][0]
+            return bubble(x, yy, z)
+
+        try:
+            model = SlabAtmosphereModel(ggrid, rank, world, advection=bz.WENO(order=5), surface_pressure=101325,
+                                        potential_temperature=300, device=device)
+            decomp = model.decomp
+            if world > 1:
+                comm_selfcheck(decomp, device)
+            model.set(θ=bubbles)
+            model.time_step(dt)
+            torch.cuda.synchronize()
+        except Exception as exc:      # noqa: BLE001
+            fail(f"slab driver failed: {exc!r}")
+        per = (G[0], G[1] // world, G[2])
+        parallelism = f"{world} y-slabs of {per[0]}x{per[1]}x{per[2]} (RCCL halo exchange + FFT transposes)"
+    else:
+        local = G if world == 1 else (args.size,) * 3
+        grid = bz.RectilinearGrid(local, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+        ref = bz.ReferenceState(grid, surface_pressure=101325, potential_temperature=300)
+        model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), device=device)
+        model.set(θ=bubble)          # u = v = w = 0, dry
+        if world > 1:
+            parallelism = f"{world} independent replicas (--replicas)"
+            G, scaling = (args.size, args.size * world, args.size), "weak"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    try:
+        for _ in range(args.warmup):
+            model.time_step(dt)
+        model.profile_reset()
+        model.profile_enable(True)           # HIP events on the kernels' own stream, over the timed region
+        if decomp is not None:
+            decomp.profile_reset()
+            decomp.profile = True
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.time_step(dt)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        model.profile_enable(False)
+        comm_ms = decomp.comm_ms() / args.steps if decomp is not None else 0.0
+        if decomp is not None:
+            decomp.profile = False
+        finite = bool(torch.isfinite(model.momentum["ρw"].parent).all().item())
+        if dist is not None:
+            t = torch.tensor([elapsed, comm_ms, 0.0 if finite else 1.0], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, comm_ms, finite = t[0].item(), t[1].item(), t[2].item() == 0.0
+    except Exception as exc:          # noqa: BLE001
+        fail(f"timed region failed: {exc!r}")
+
+    cells = G[0] * G[1] * G[2]                      # all ranks together
+    cells_rank = cells // world
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = cells * args.steps / elapsed
+
+    prof = model.profile()
+    if rank == 0:
+        kernels = {}
+        for name, (ms, n) in prof.items():
+            if n:
+                kernels[name] = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
+        dom = max((k for k in kernels if k in WORDS_PER_CELL), key=lambda k: kernels[k]["total_ms"])
+        dom_bytes = WORDS_PER_CELL[dom] * 8 * cells_rank
+        achieved = dom_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        # HBM-side bytes per launch of that kernel group measured by rocprofv3 PMC passes (committed under profiles/,
+        # collected at 512^3 on one GPU with the same build: a reference figure, not a measurement of this very run)
+        traffic, traffic_src = None, None
+        if cells_rank == 512 ** 3:
+            for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                        traffic = json.load(fh)["per_kernel_group"][dom]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/" + fn
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"]}
+        step_achieved = (cells_rank * args.steps / elapsed) * A_STEP_WORDS * 8 / 1e9
+        kernel_ms = sum(v["total_ms"] for v in kernels.values()) / args.steps
+        out = {
+            "metric": METRIC,
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": label, "grid": list(G), "grid_per_gpu": [G[0], G[1] // world, G[2]], "dt": dt,
+                       "parallelism": parallelism},
+            "roofline": roofline,
+            "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": step_achieved / HBM_PEAK_GBS, "per": "GPU",
+                              "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 8},
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(kernels.items())},
+            "finite": finite,
+        }
+        if use_slabs:
+            out["comm_ms_per_step"] = comm_ms                       # inside point-to-point batches (slowest rank)
+            out["compute_ms_per_step"] = kernel_ms                  # library kernels of rank 0 (HIP events)
+            out["other_ms_per_step"] = max(0.0, ms_per_step - comm_ms - kernel_ms)   # packs, transforms' glue, launch gaps, waits
+            out["comm_bytes_sent_per_step_per_gpu"] = decomp.comm_bytes // args.steps
+        if world == 1 and not args.no_compressible and not use_slabs and args.workload == "bubble":
+            try:
+                del model
+                torch.cuda.empty_cache()
+                out["second_milestone"] = compressible_milestone(bz, device)
+            except Exception as exc:       # never let the side measurement take the headline line down
+                out["second_milestone"] = {"error": repr(exc)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -125,154 +441,24 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--workload", choices=("bubble", "config3"), default="bubble")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the slab decomposition")
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the slab decomposition (explicit only)")
     ap.add_argument("--slab", action="store_true", help="N=1: run the slab driver (world 1) instead of the whole-step seam")
-    ap.add_argument("--cpu-size", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-size", type=int, default=256)
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-compressible", action="store_true",
                     help="skip the short compressible split-explicit measurement reported under `second_milestone`")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks are killed after this many seconds")
+    ap.add_argument("--collective-timeout", type=float, default=300.0, help="process-group timeout (seconds)")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU/gloo: exercise the launcher and the slab communication pattern without a GPU")
     args = ap.parse_args()
-
-    import torch
-    import breeze_jl_amd as bz
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    device = f"cuda:{local_rank}"
-
-    N = args.size
-    dt = 1.0
-    use_slabs = (world > 1 and not args.replicas) or (world == 1 and args.slab)
-    parallelism = "single GPU"
-    if use_slabs:
-        # weak scaling: the domain grows in y with the number of ranks, one bubble per 20 km of y
-        from breeze_jl_amd.distributed import SlabAtmosphereModel
-        Ly = (EXTENT[1][1] - EXTENT[1][0]) * world
-        ggrid = bz.RectilinearGrid((N, N * world, N), x=EXTENT[0], y=(EXTENT[1][0], EXTENT[1][0] + Ly), z=EXTENT[2])
-
-        def bubbles(x, y, z):
-            yy = np.mod(y - EXTENT[1][0], EXTENT[1][1] - EXTENT[1][0]) + EXTENT[1][0]
-            return bubble(x, yy, z)
-
-        # the RCCL transport cannot be exercised from the 1-GPU build box: if constructing the slab model or its first step
-        # raises on any rank, every rank falls back to independent replicas and the JSON line says so
-        slab_error = None
-        try:
-            model = SlabAtmosphereModel(ggrid, rank, world, advection=bz.WENO(order=5), surface_pressure=101325,
-                                        potential_temperature=300, device=device)
-            model.set(θ=bubbles)
-            model.time_step(dt)
-            torch.cuda.synchronize()
-        except Exception as exc:      # noqa: BLE001
-            slab_error = repr(exc)
-            print(f"[bench rank {rank}] slab driver failed: {slab_error}", file=sys.stderr, flush=True)
-        if dist is not None:
-            flag = torch.tensor([0 if slab_error else 1], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if flag.item() == 0:
-                slab_error = slab_error or "another rank failed"
-        if slab_error:
-            use_slabs = False
-            model = None
-            torch.cuda.empty_cache()
-        parallelism = f"{world} y-slabs of {N}x{N}x{N} (RCCL halo exchange + FFT transposes)"
-    if not use_slabs:
-        grid = bz.RectilinearGrid((N, N, N), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
-        ref = bz.ReferenceState(grid, surface_pressure=101325, potential_temperature=300)
-        model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), device=device)
-        model.set(θ=bubble)          # u = v = w = 0, dry
-        if world > 1:
-            parallelism = f"{world} independent replicas"
-            if not args.replicas:
-                parallelism += f" (fallback: slab driver failed: {slab_error})"
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        model.time_step(dt)
-    model.profile_reset()
-    model.profile_enable(True)           # HIP events on the kernels' own stream, over the timed region
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.time_step(dt)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    model.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-
-    cells = N ** 3
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * cells * args.steps / elapsed
-
-    prof = model.profile()
-    finite = bool(torch.isfinite(model.momentum["ρw"].parent).all().item())
-    if rank == 0:
-        kernels = {}
-        for name, (ms, n) in prof.items():
-            if n:
-                kernels[name] = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
-        dom = max((k for k in kernels if k in WORDS_PER_CELL), key=lambda k: kernels[k]["total_ms"])
-        dom_bytes = WORDS_PER_CELL[dom] * 8 * cells
-        achieved = dom_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        # measured HBM-side bytes per launch of that kernel group (rocprofv3 PMC passes, committed under profiles/;
-        # collected at the default 512^3 size only)
-        traffic = None
-        try:
-            if N == 512:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                    traffic = json.load(fh)["per_kernel_group"][dom]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"]}
-        step_achieved = (cells * args.steps / elapsed) * A_STEP_WORDS * 8 / 1e9
-        out = {
-            "metric": "grid-cells advanced/sec (tendency+Poisson step), 512^3 anelastic",
-            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"dry thermal bubble {N}^3 RectilinearGrid (Periodic,Periodic,Bounded), halo 3, "
-                                   "AnelasticDynamics + WENO5 + SSP-RK3, Float64, dt=1s (BASELINE.json configs[1])",
-                       "grid": [N, N * world, N] if use_slabs else [N, N, N], "grid_per_gpu": [N, N, N], "dt": dt,
-                       "parallelism": parallelism},
-            "roofline": roofline,
-            "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": step_achieved / HBM_PEAK_GBS,
-                              "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 8},
-            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(kernels.items())},
-            "finite": finite,
-        }
-        if world == 1 and not args.no_compressible and not use_slabs:
-            try:
-                del model
-                torch.cuda.empty_cache()
-                out["second_milestone"] = compressible_milestone(bz, device)
-            except Exception as exc:       # never let the side measurement take the headline line down
-                out["second_milestone"] = {"error": repr(exc)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_self(args, sys.argv[1:])
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

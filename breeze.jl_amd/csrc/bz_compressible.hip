@@ -1220,8 +1220,13 @@ extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_stat
             BZ_HIP(hipMemcpyAsync(K.U0_rain_density, K.rain_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
         }
     }
-    // freeze_linearization_state!: the linearisation of stage 1 (refreshed again by prepare_acoustic_cache! from the
-    // same state) + seeding of the transport velocities
+    // freeze_linearization_state! (acoustic_substepping.jl:288-292): the linearisation of stage 1 (refreshed again by
+    // prepare_acoustic_cache! from the same state).  Its second half, seed_time_averaged_velocities!, is deliberately not
+    // issued here: nothing between this point and stage 1's substep loop reads the time-averaged velocities (the slow
+    // rho theta tendency of stage 1 uses model.velocities, the stage-1 moisture tendency was built by the previous
+    // update_state!), and k_ac_stage_init zeroes the three accumulators before the loop refills them — the seed is
+    // unobservable inside a whole step (tests/test_gpu_compressible.py::test_whole_step_matches_operator_sequence runs the
+    // per-operator sequence WITH the seed against this seam).  Per-operator drivers call bz_seed_time_averaged_velocities.
     rc = bz_refresh_linearization(ctx, s, sub);
     if (rc) return rc;
     const double betas[3] = {1.0 / 3.0, 1.0 / 2.0, 1.0};

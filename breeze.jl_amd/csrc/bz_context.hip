@@ -157,7 +157,8 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (grid->topo[0] != BZ_PERIODIC || grid->topo[1] != BZ_PERIODIC || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
     if (grid->Hx < 3 || grid->Hy < 3 || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
-    if (grid->Nx < grid->Hx || grid->Ny < 1 || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;      // Oceananigans: N >= H
+    // Oceananigans: N >= H in every direction (k_halo_y's wrap copy would otherwise read a halo row that is not filled yet)
+    if (grid->Nx < grid->Hx || grid->Ny < grid->Hy || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;
 
     bz_ctx *ctx = new (std::nothrow) bz_ctx();
     if (!ctx) return BZ_ERR_ALLOC;
@@ -217,9 +218,16 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
         if (k >= 1 && k < nc) col(C_RHOF)[k] = 0.5 * (ref->density[k - 1] + ref->density[k]);
     }
 
-    BZ_HIP(hipMalloc(&ctx->d_columns, cols.size() * sizeof(double)));
-    BZ_HIP(hipMemcpy(ctx->d_columns, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice));
-    BZ_HIP(hipMalloc(&ctx->d_scalar, 64 * sizeof(double)));
+    {   // a failed allocation must not leak the half-built context
+        hipError_t e = hipMalloc(&ctx->d_columns, cols.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_columns, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_scalar, 64 * sizeof(double));
+        if (e != hipSuccess) {
+            fprintf(stderr, "bz_create: column tables: %s\n", hipGetErrorString(e));
+            bz_destroy(ctx);
+            return -(int)e;
+        }
+    }
 
     DevGrid &g = ctx->dg;
     g.Nx = Nx; g.Ny = Ny; g.Nz = Nz;

@@ -331,6 +331,10 @@ int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, d
 extern "C" int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
     if (!ctx || !s || !G) return BZ_ERR_INVALID;
+    if (ctx->G_is_predictor) {      // a fused whole step left predictor momentum in G: the fluxes must land on tendencies
+        int rc = bz_compute_tendencies(ctx, s, G);
+        if (rc) return rc;
+    }
     return bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0);
 }
 

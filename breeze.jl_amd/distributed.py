@@ -50,6 +50,7 @@ class SlabDecomposition:
         # optional device kernel for the transposing packs: pack(src (Nz, A, ld) complex, c0, B, valid) -> (Nz, B, A) complex
         # (SlabAtmosphereModel installs bz_pack_transpose; CPU backends use the torch expression)
         self.pack = None
+        self._comm_events = []
         # optional device kernel for the halo rows: rows(fields, row0, nrows, buffer, unpack) gathers / scatters parent rows of
         # every field through one contiguous buffer (bz_pack_rows); CPU backends use slicing
         self.rows = None
@@ -71,9 +72,43 @@ class SlabDecomposition:
         import torch.distributed as dist
         ops = [dist.P2POp(dist.isend, t, d, group=self.group) for t, d in sends]
         ops += [dist.P2POp(dist.irecv, t, s, group=self.group) for t, s in recvs]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        if not ops:
+            return
+        timed = self.profile
+        if timed:
+            import time
+            import torch
+            cuda = sends[0][0].is_cuda if sends else recvs[0][0].is_cuda
+            if cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            else:
+                t0 = time.perf_counter()
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if timed:
+            self.comm_bytes += sum(t.numel() * t.element_size() for t, _ in sends)
+            if cuda:
+                e1.record()
+                self._comm_events.append((e0, e1))
+            else:
+                self._comm_ms += 1e3 * (time.perf_counter() - t0)
+
+    # -- instrumentation: time spent inside the point-to-point batches (HIP events on the stream the exchange runs on) --
+    profile = False
+    comm_bytes = 0
+    _comm_ms = 0.0
+
+    def profile_reset(self):
+        self._comm_events, self._comm_ms, self.comm_bytes = [], 0.0, 0
+
+    def comm_ms(self):
+        """Milliseconds spent in exchanges since profile_reset() (synchronises the recorded events)."""
+        ms = self._comm_ms
+        for e0, e1 in getattr(self, "_comm_events", []):
+            e1.synchronize()
+            ms += e0.elapsed_time(e1)
+        return ms
 
     # -- halos -----------------------------------------------------------------
     def exchange_y_halos(self, fields):

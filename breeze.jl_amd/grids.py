@@ -42,6 +42,9 @@ class RectilinearGrid:
             N[d], H[d] = int(n), int(h)
         self.Nx, self.Ny, self.Nz = N
         self.Hx, self.Hy, self.Hz = H
+        for d in nonflat:       # Oceananigans' validate_halo: a halo cannot be wider than the domain it wraps
+            if N[d] < H[d]:
+                raise ValueError(f"halo ({H[d]}) must be ≤ size ({N[d]}) in dimension {'xyz'[d]}")
         ext = {0: x, 1: y, 2: z}
         for d in nonflat:
             if ext[d] is None:

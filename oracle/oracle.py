@@ -543,14 +543,22 @@ class OracleModel:
         """solve!(phi, FourierTridiagonalPoissonSolver) (Oceananigans, recalled):
         FFT x,y -> complex Thomas in z -> inverse FFT -> subtract mean -> real part."""
         g = self.grid
-        rhat = np.ascontiguousarray(np.fft.fft2(rhs.astype(np.complex128), axes=(1, 2)))
+        workers = getattr(self, "fft_workers", 1)
+        if workers > 1:       # bench.py's cpu_baseline leg: the same pocketfft transforms on several host threads
+            import scipy.fft as sfft
+            fft2 = lambda a: sfft.fft2(a, axes=(1, 2), workers=workers)
+            ifft2 = lambda a: sfft.ifft2(a, axes=(1, 2), workers=workers)
+        else:
+            fft2 = lambda a: np.fft.fft2(a, axes=(1, 2))
+            ifft2 = lambda a: np.fft.ifft2(a, axes=(1, 2))
+        rhat = np.ascontiguousarray(fft2(rhs.astype(np.complex128)))
         phat = np.zeros_like(rhat)
         scratch = np.zeros(rhs.shape)
         self.lib.og_tridiagonal_solve(C.c_int(g.Nx), C.c_int(g.Ny), C.c_int(g.Nz), _p(self.lower),
                                       _p(self.diag0), _p(self.mass), _p(self.lam),
                                       rhat.view(np.float64).ctypes.data_as(_dp),
                                       phat.view(np.float64).ctypes.data_as(_dp), _p(scratch))
-        phi = np.fft.ifft2(phat, axes=(1, 2))
+        phi = ifft2(phat)
         phi = phi - phi.mean()
         return np.ascontiguousarray(phi.real)
 

@@ -26,3 +26,9 @@ def oracle():
 def bz():
     import breeze_jl_amd
     return breeze_jl_amd
+
+
+@pytest.fixture(scope="session")
+def oc(oracle):
+    from oracle import oracle_compressible
+    return oracle_compressible

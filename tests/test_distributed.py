@@ -92,10 +92,11 @@ def test_single_rank_transposes_and_halos_are_identities(bz):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [1, 2, 4])
-def test_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, world):
+def test_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, oracle, world):
     """All slab entry points of the C ABI (wrap_y = 0 kernels, spectral block solve, fused projection with the
-    neighbour's phi row) against the single-GPU whole-step seam: `world` rank objects share cuda:0, exchanging
-    through an in-process mailbox."""
+    neighbour's phi row) against the single-GPU whole-step seam AND, directly, against the CPU oracle run on the whole
+    domain (the configs[3] decomposition tied to the oracle without the single-GPU HIP path in between): `world` rank
+    objects share cuda:0, exchanging through an in-process mailbox."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_backends
@@ -138,6 +139,19 @@ def test_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, world):
         want = getter(ref).interior_cpu()
         err = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-3)
         assert err < 1e-10, (name, err)
+    # slab HIP path vs the oracle (Float64; 1e-9 of the field scale after two full steps, the whole-step tolerance of
+    # tests/test_gpu_parity.py::test_time_steps_match_oracle)
+    og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    om = oracle.OracleModel(og, potential_temperature=300.0)
+    om.set(theta=theta_ic, u=3.0, v=-2.0)
+    for _ in range(steps):
+        om.time_step(dt)
+    for oname, getter in (("ru", lambda m: m.momentum["ρu"]), ("rv", lambda m: m.momentum["ρv"]), ("rw", lambda m: m.momentum["ρw"]),
+                          ("rtheta", lambda m: m.potential_temperature_density), ("T", lambda m: m.temperature)):
+        got = np.concatenate([getter(m).interior_cpu() for m in models], axis=1)
+        want = og.interior(getattr(om, oname), zface=(oname == "rw"))
+        err = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-3)
+        assert err < 1e-9, ("oracle", oname, err)
 
 
 # ---- compressible split-explicit path on y-slabs (halo exchanges only) ---------------------------------
@@ -231,9 +245,10 @@ def test_compressible_kessler_slab_steps_match_single_process_oracle(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,kessler", [(1, False), (2, False), (4, False), (2, True), (4, True)])
-def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, world, kessler):
+def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, oracle, oc, world, kessler):
     """SlabCompressibleModel (bz_create_compressible_slab, stage begin / substep / end with the per-substep exchange of
-    (rho theta)' and (rho v)') against the single-GPU whole-step seam; `world` ranks share cuda:0 through a mailbox."""
+    (rho theta)' and (rho v)') against the single-GPU whole-step seam and, directly, against the CPU oracle on the whole
+    domain (dry and with the Kessler physics of BASELINE configs[4]); `world` ranks share cuda:0 through a mailbox."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_backends
@@ -301,3 +316,26 @@ def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, worl
         # same arithmetic, different kernels; the Kessler column physics amplifies the last-digit differences a little
         # (threshold branches: 1e-9, the tolerance of the other multi-step Kessler comparisons)
         assert err < (1e-9 if kessler else 1e-11), (name, err)
+    if world == 1:
+        return
+    # slab HIP path vs the oracle on the whole domain (1e-8: the tolerance of the single-GPU multi-step comparisons in
+    # tests/test_gpu_compressible.py)
+    og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), reference_potential_temperature=300.0,
+                                    microphysics="Kessler" if kessler else None)
+    orho = om.ref.density[og.Hz:og.Hz + og.Nz][:, None, None]
+    oic = dict(rho=orho, theta=cmp_theta, u=3.0, v=-2.0, w=0.0, qv=cmp_qv)
+    if kessler:
+        oic.update(qcl=cmp_qcl, qr=cmp_qr)
+    om.set(**oic)
+    for _ in range(steps):
+        om.time_step(dt)
+    pairs = {"rho_d": "ρᵈ", "ru": "ρu", "rv": "ρv", "rw": "ρw", "rtheta": "ρθ", "rq": "ρq", "T": "T", "p": "p"}
+    if kessler:
+        pairs.update({"rqcl": "ρqᶜˡ", "rqr": "ρqʳ"})
+    for oname, name in pairs.items():
+        got = np.concatenate([getters[name](m).interior_cpu() for m in models], axis=1)
+        want = og.interior(getattr(om, oname), oname == "rw")
+        scale = mom if name in ("ρu", "ρv", "ρw") else max(np.max(np.abs(want)), 1e-3)
+        err = np.max(np.abs(got - want)) / scale
+        assert err < 1e-8, ("oracle", oname, err)

@@ -195,7 +195,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     }
 
     // ---- column tables: 11 columns of nf entries each ----
-    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_RDZC, C_ZC, C_COUNT };
+    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_RDZC, C_ZC, C_RRHO, C_RRHOF, C_COUNT };
     std::vector<double> cols((size_t)C_COUNT * nf, 0.0);
     auto col = [&](int c) { return cols.data() + (size_t)c * nf; };
     const double dx = grid->dx, dy = grid->dy;
@@ -207,6 +207,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
         col(C_AY)[k] = dx * dzc[k];
         col(C_VIC)[k] = 1.0 / (dx * dy * dzc[k]);
         col(C_RHO)[k] = ref->density[k];
+        col(C_RRHO)[k] = 1.0 / ref->density[k];
         col(C_PR)[k] = ref->pressure[k];
         col(C_TR)[k] = ref->temperature[k];
     }
@@ -215,7 +216,10 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
         col(C_RDZF)[k] = 1.0 / dzf[k];
         col(C_VIF)[k] = 1.0 / (dx * dy * dzf[k]);
         // Iz(rho) at face k: 0.5*(rho[k-1]+rho[k]); defined where both exist
-        if (k >= 1 && k < nc) col(C_RHOF)[k] = 0.5 * (ref->density[k - 1] + ref->density[k]);
+        if (k >= 1 && k < nc) {
+            col(C_RHOF)[k] = 0.5 * (ref->density[k - 1] + ref->density[k]);
+            col(C_RRHOF)[k] = 1.0 / col(C_RHOF)[k];
+        }
     }
 
     {   // a failed allocation must not leak the half-built context
@@ -244,6 +248,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.Ax = dcol(C_AX); g.Ay = dcol(C_AY);
     g.Vinv_c = dcol(C_VIC); g.Vinv_f = dcol(C_VIF);
     g.rho = dcol(C_RHO); g.rho_f = dcol(C_RHOF);
+    g.rrho = dcol(C_RRHO); g.rrho_f = dcol(C_RRHOF);
     g.p_r = dcol(C_PR); g.T_r = dcol(C_TR);
     g.g = constants->gravitational_acceleration;
     g.Rd = constants->dry_air_gas_constant;
@@ -262,6 +267,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     ctx->dz_min = dzc[Hz];
     for (int k = 0; k < Nz; ++k) ctx->dz_min = std::fmin(ctx->dz_min, dzc[Hz + k]);
     int rc = compressible ? BZ_OK : bzi_poisson_setup(ctx, ref->density);
+    if (rc == BZ_OK && !compressible) rc = bzi_lean_setup(ctx);
     if (rc != BZ_OK) {
         fprintf(stderr, "bz_create: Poisson setup failed (%d): %s\n", rc, ctx->last_error.c_str());
         bz_destroy(ctx);
@@ -276,6 +282,7 @@ extern "C" void bz_destroy(bz_ctx *ctx)
     if (!ctx) return;
     profile_drain(ctx);
     bzi_poisson_teardown(ctx);
+    bzi_lean_teardown(ctx);
     bzi_compressible_teardown(ctx);
     if (ctx->d_columns) hipFree(ctx->d_columns);
     bzi_forcing_teardown(ctx);

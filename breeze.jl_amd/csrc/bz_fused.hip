@@ -90,7 +90,8 @@ __device__ __forceinline__ void st_img_only(double *__restrict__ f, long long n,
 }
 
 struct PDFields {
-    double *ru, *rv, *rw, *rtheta, *rq;     // out (rtheta, rq: halos only)
+    double *ru, *rv, *rw, *rtheta, *rq;     // out (rtheta, rq: halos only, unless rtheta_in / rq_in differ: then the whole field)
+    const double *rtheta_in, *rq_in;        // rho theta, rho q to diagnose from (the lean seam leaves them in the other ping-pong buffer)
     const double *ru_in, *rv_in, *rw_in;    // predictor momentum (= ru, rv, rw unless the RK update was fused into the tendencies)
     double *u, *v, *w, *theta, *q, *T;      // out
     double *phi;                            // out (halo-inclusive)
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     // _compute_velocities!
     double u = ru / rc, v = rv / rc;
     // thermodynamic diagnosis
-    const double rth = F.rtheta[n], rq = F.rq[n];
+    const double rth = F.rtheta_in[n], rq = F.rq_in[n];
+    const bool copy_scalars = (F.rtheta_in != F.rtheta);
     const double th = rth / rc, q = rq / rc;
     const double qd = 1.0 - q;
     const double Rm = qd * g.Rd + q * g.Rv;
@@ -161,8 +163,13 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
         st_img_only(g.rqcl_field, n, g.rqcl_field[n], ox, oy);
         st_img_only(g.rqr_field, n, g.rqr_field[n], ox, oy);
     }
-    st_img_only(F.rtheta, n, rth, ox, oy);
-    st_img_only(F.rq, n, rq, ox, oy);
+    if (copy_scalars) {
+        st_img(F.rtheta, n, rth, ox, oy);
+        st_img(F.rq, n, rq, ox, oy);
+    } else {
+        st_img_only(F.rtheta, n, rth, ox, oy);
+        st_img_only(F.rq, n, rq, ox, oy);
+    }
     if (!bot) {      // wall face k = 0 keeps rho_w = w = 0
         const double p_km = F.phi_c[m - cplane];
         double rw = F.rw_in[n];
@@ -195,6 +202,55 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
             st_img(F.u, n + sz, u, ox, oy);
             st_img(F.v, n + sz, v, ox, oy);
         }
+    }
+}
+
+
+// make_pressure_correction! alone, for the stages of the lean whole-step seam whose diagnostics nobody reads (bz_step.hip):
+// projected momentum + its periodic images and z-halo copies.  7 words per cell instead of 18.
+struct PLFields {
+    double *ru, *rv, *rw;
+    const double *ru_in, *rv_in, *rw_in;
+    const double *phi_c;
+    const double *phi_below;
+    double *sa, *sb;             // rho theta, rho q just advanced by the lean scalar kernel (interior): their periodic images are stored here
+};
+__global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, double dt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long sz = g.Sxy;
+    const long long ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
+    const long long oy = !g.wrap_y ? 0 : (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
+    const long long cplane = (long long)g.Nx * g.Ny;
+    const long long m = (long long)i + (long long)g.Nx * j + cplane * k;
+    const long long c_im = (i > 0) ? -1 : g.Nx - 1;
+    const long long c_jm = (j > 0) ? -(long long)g.Nx : (long long)g.Nx * (g.Ny - 1);
+    const long long n = g.idx(i, j, k);
+    const bool bot = (k == 0), top = (k == g.Nz - 1);
+    const double rc = g.rho[k], rf = g.rho_f[k];
+    const double p = F.phi_c[m];
+    const double p_im = F.phi_c[m + c_im];
+    const double p_jm = (j == 0 && !g.wrap_y) ? F.phi_below[(long long)i + (long long)g.Nx * k] : F.phi_c[m + c_jm];
+    double ru = F.ru_in[n], rv = F.rv_in[n];
+    ru -= rc * dt * ((p - p_im) * g.rdx);
+    rv -= rc * dt * ((p - p_jm) * g.rdy);
+    st_img(F.ru, n, ru, ox, oy);
+    st_img(F.rv, n, rv, ox, oy);
+    if (!bot) {
+        const double p_km = F.phi_c[m - cplane];
+        double rw = F.rw_in[n];
+        rw -= rf * dt * ((p - p_km) * g.rdzf[k]);
+        st_img(F.rw, n, rw, ox, oy);
+    }
+    if (bot || top) {
+        const long long h = bot ? -sz : sz;
+        st_img(F.ru, n + h, ru, ox, oy);
+        st_img(F.rv, n + h, rv, ox, oy);
+    }
+    if (ox | oy) {          // edge cells only: the halo images of the scalars
+        st_img_only(F.sa, n, F.sa[n], ox, oy);
+        st_img_only(F.sb, n, F.sb[n], ox, oy);
     }
 }
 
@@ -231,13 +287,31 @@ int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *
     return BZ_OK;
 }
 
+int bzi_project_lean(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below,
+                     const bz_prognostic *predictor, double *sa, double *sb)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "project_momentum");
+    PLFields F;
+    F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w;
+    F.ru_in = predictor->rho_u; F.rv_in = predictor->rho_v; F.rw_in = predictor->rho_w;
+    F.phi_c = phi_c ? phi_c : ctx->d_rhs;
+    F.phi_below = phi_below;
+    F.sa = sa; F.sb = sb;
+    dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+    hipLaunchKernelGGL(k_project_lean, grid, block, 0, ctx->stream, g, F, dt);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
 int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below,
-                         const bz_prognostic *predictor, bool store_phi)
+                         const bz_prognostic *predictor, bool store_phi, const double *rtheta_in, const double *rq_in)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "project_and_diagnose");
     PDFields F;
     F.ru = s->rho_u; F.rv = s->rho_v; F.rw = s->rho_w; F.rtheta = s->rho_theta; F.rq = s->rho_q;
+    F.rtheta_in = rtheta_in ? rtheta_in : s->rho_theta; F.rq_in = rq_in ? rq_in : s->rho_q;
     F.ru_in = predictor ? predictor->rho_u : s->rho_u;
     F.rv_in = predictor ? predictor->rho_v : s->rho_v;
     F.rw_in = predictor ? predictor->rho_w : s->rho_w;

@@ -25,6 +25,7 @@ struct DevGrid {
     const double *Ax, *Ay;               // dy*dzc[k], dx*dzc[k]
     const double *Vinv_c, *Vinv_f;       // 1/(dx*dy*dzc[k]), 1/(dx*dy*dzf[k])
     const double *rho, *rho_f;           // rho_r at centres;  0.5*(rho[k-1]+rho[k]) at faces
+    const double *rrho, *rrho_f;         // their correctly rounded reciprocals (host 1.0/x), for bz_cdiv
     const double *p_r, *T_r;
     double g, Rd, Rv, cpd, cpv, pst;
     int formulation;       // 0: liquid-ice potential temperature (theta), 1: static energy (e) in the `theta` slots
@@ -55,6 +56,15 @@ struct RKEpilogue {
     double *u0b_out = nullptr;
 };
 #ifdef __HIPCC__
+// a / b for a column constant b whose correctly rounded reciprocal rb = RN(1/b) is tabulated: q0 = a rb, one fused
+// residual, one fused correction (Markstein's division: the result is the correctly rounded quotient, i.e. bit-identical
+// to the IEEE `a / b` the diagnosis kernels use — checked on 4e8 random pairs, tools/check_cdiv.c), 3 instructions instead
+// of the ~12 of a full FP64 division.  Lets the lean tendency kernels derive u = rho_u / rho_r(k) etc. on the fly.
+__device__ __forceinline__ double bz_cdiv(double a, double b, double rb)
+{
+    const double q0 = a * rb;
+    return fma(fma(-q0, b, a), rb, q0);
+}
 __device__ __forceinline__ double bz_rk_apply(int mode, double dt, double alpha, double oma, const double *u0,
                                               double *u0_out, double G, double uold, long long n)
 {
@@ -62,6 +72,14 @@ __device__ __forceinline__ double bz_rk_apply(int mode, double dt, double alpha,
     double u0v;
     if (mode == 1) { u0_out[n] = uold; u0v = uold; }
     else u0v = u0[n];
+    return oma * u0v + alpha * (uold + dt * G);
+}
+// the same update with u0 already in a register (loaded at the top of the level by the caller so that its latency overlaps the
+// flux arithmetic): u0v is ignored in the first stage
+__device__ __forceinline__ double bz_rk_apply_pre(int mode, double dt, double alpha, double oma, double u0v, double *u0_out, double G,
+                                                  double uold, long long n)
+{
+    if (mode == 1) { u0_out[n] = uold; u0v = uold; }
     return oma * u0v + alpha * (uold + dt * G);
 }
 #endif
@@ -235,6 +253,9 @@ struct bz_ctx {
     bool fuse_rk = true;              // whole-step seam: RK update folded into the tendency kernels (BZ_NO_FUSE_RK=1 disables)
     bool G_is_predictor = false;      // after a fused step the G arrays hold predictor momentum, not tendencies
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
+    bool lean = true;                 // whole-step seam on prognostic-only kernels (bz_tendency5_kernels.h; BZ_NO_LEAN=1 disables)
+    bool lean_xcd = true;             // XCD-contiguous block order of the lean kernels (BZ_NO_XCD=1 disables)
+    double *d_pi_dry = nullptr;       // (p_r[k]/p_st)^(Rd/cpd), k = -Hz .. Nz+Hz-1: Exner factor of a dry cell, built with the device pow()
     // CompressibleDynamics + SplitExplicitTimeDiscretization (bz_create_compressible)
     bool compressible = false;
     bool has_reference = false;       // ExnerReferenceState columns present (else p_r = rho_r = 0)
@@ -323,6 +344,8 @@ int bzi_kessler_rk3(bz_ctx *ctx, double dt, double alpha, bool first);
 int bzi_kessler_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt);
 int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, int n);
 int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
+int bzi_lean_setup(bz_ctx *ctx);
+void bzi_lean_teardown(bz_ctx *ctx);
 void bzi_poisson_teardown(bz_ctx *ctx);
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);
 int bzi_poisson_spectral(bz_ctx *ctx);
@@ -332,7 +355,13 @@ int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const
 int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *rhs = nullptr,
                              const bz_prognostic *predictor = nullptr);
 int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c = nullptr,
-                         const double *phi_below = nullptr, const bz_prognostic *predictor = nullptr, bool store_phi = true);
+                         const double *phi_below = nullptr, const bz_prognostic *predictor = nullptr, bool store_phi = true,
+                         const double *rtheta_in = nullptr, const double *rq_in = nullptr);
+int bzi_project_lean(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below,
+                     const bz_prognostic *predictor, double *sa, double *sb);
+// lean whole-step tendencies (bz_tendency5.hip): prognostic-only inputs, rho theta / rho q advance from (pa, pb) into (oa, ob)
+int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
+                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first);
 int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                             double alpha, bool first);
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,

@@ -33,6 +33,31 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
     }
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
+    if (ctx->fused_ok && ctx->fuse_rk && ctx->lean && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
+        !ctx->has_forcings && !ctx->has_bulk && !ctx->has_closure && ctx->n_tracers == 0 &&
+        (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32)) {
+        // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,
+        // q^v, T on the fly (bit-identical to the stored diagnostics), rho theta / rho q ping-pong between their own arrays
+        // and the G slots, the projection of stages 1-2 writes momentum only; stage 3 runs the full projection + diagnosis
+        // kernel, so on return every field of `s` (halos included) is what the per-operator sequence leaves.
+        const DevGrid &g = ctx->dg;
+        BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));                 // wall faces of the
+        BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));        // predictor stay 0
+        for (int stage = 0; stage < 3; ++stage) {
+            const double alpha = alphas[stage];
+            const bool from_state = (stage != 1);
+            const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
+            double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
+            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0))) return rc;
+            if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
+            if ((rc = bzi_poisson_spectral(ctx))) return rc;
+            if (stage < 2) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+            else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, G->rho_theta, G->rho_q);
+            if (rc) return rc;
+        }
+        ctx->G_is_predictor = true;
+        return BZ_OK;
+    }
     if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !(ctx->has_forcings && getenv("BZ_NO_FUSE_FORCING"))) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state

@@ -1,0 +1,106 @@
+// bz_tendency5.hip — launcher of the lean (prognostic-only) tendency kernels of the whole-step seam
+// (bz_tendency5_kernels.h) and of their dry Exner table.
+#include <cstdlib>
+
+#include "bz_tendency5_kernels.h"
+
+__global__ void k_pi_dry(DevGrid g, double *__restrict__ pi, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int k = t - g.Hz;
+    // the expression of k_project_diagnose<0> / buoyancy5 for q = 0: qd = 1, Rm = Rd, cpm = cpd exactly
+    const double q = 0.0, qd = 1.0 - q;
+    const double Rm = qd * g.Rd + q * g.Rv;
+    const double cpm = qd * g.cpd + q * g.cpv;
+    pi[t] = pow(g.p_r[k] / g.pst, Rm / cpm);
+}
+
+int bzi_lean_setup(bz_ctx *ctx)
+{
+    const DevGrid &g = ctx->dg;
+    const int n = g.Nz + 2 * g.Hz;
+    BZ_HIP(hipMalloc(&ctx->d_pi_dry, n * sizeof(double)));
+    hipLaunchKernelGGL(k_pi_dry, dim3((n + 63) / 64), dim3(64), 0, 0, g, ctx->d_pi_dry, n);
+    BZ_HIP(hipGetLastError());
+    BZ_HIP(hipDeviceSynchronize());
+    ctx->lean = !getenv("BZ_NO_LEAN");
+    ctx->lean_xcd = !getenv("BZ_NO_XCD");
+    return BZ_OK;
+}
+
+void bzi_lean_teardown(bz_ctx *ctx)
+{
+    if (ctx->d_pi_dry) hipFree(ctx->d_pi_dry);
+    ctx->d_pi_dry = nullptr;
+}
+
+// z-chunking of the LDS-tiled kernels (same rule as pick_chunk_lds of bz_tendency3.hip)
+static int pick_chunk5(const DevGrid &g, int nlev, int rows_per_block)
+{
+    long long tiles = (long long)((g.Nx + 63) / 64) * ((g.Ny + rows_per_block - 1) / rows_per_block);
+    long long want = (1024 + tiles - 1) / tiles;
+    long long maxchunks = nlev / 128 > 0 ? nlev / 128 : 1;
+    if (const char *e = getenv("BZ_LEAN_MAXCHUNK_LEVELS")) { int m = atoi(e); if (m > 0) maxchunks = nlev / m > 0 ? nlev / m : 1; }
+    if (want > maxchunks) want = maxchunks;
+    if (want < 1) want = 1;
+    if (tiles * want < 512) {
+        long long fill = (512 + tiles - 1) / tiles;
+        long long cap = nlev / 8 > 0 ? nlev / 8 : 1;
+        if (fill > cap) fill = cap;
+        if (fill > want) want = fill;
+    }
+    return (int)((nlev + want - 1) / want);
+}
+
+int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
+                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first)
+{
+    const DevGrid &g = ctx->dg;
+    constexpr int TY = 8;
+    RKEpilogue E;
+    E.mode = first ? 1 : 2; E.dt = dt; E.alpha = alpha; E.oma = 1.0 - alpha;
+    Lean5 L;
+    L.ru = s->rho_u; L.rv = s->rho_v; L.rw = s->rho_w; L.pa = pa; L.pb = pb; L.oa = oa; L.ob = ob; L.out = nullptr;
+    L.T = s->T;
+    L.pi_dry = getenv("BZ_NO_PI_DRY") ? nullptr : ctx->d_pi_dry + g.Hz;
+    const dim3 block(64, TY);
+    const int tx = (g.Nx + 63) / 64, ty = (g.Ny + TY - 1) / TY;
+    auto shape = [&](int nlev, int &kc) {
+        kc = pick_chunk5(g, nlev, TY);
+        dim3 grid(tx, ty, (nlev + kc - 1) / kc);
+        L.xcd = (ctx->lean_xcd && ((long long)grid.x * grid.y * grid.z) % 8 == 0) ? 1 : 0;
+        return grid;
+    };
+    int kc;
+    {
+        ProfileScope ps(ctx, "x_momentum_tendency+rk3");
+        E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
+        L.out = G->rho_u;
+        const dim3 grid = shape(g.Nz, kc);
+        hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+    }
+    {
+        ProfileScope ps(ctx, "y_momentum_tendency+rk3");
+        E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
+        L.out = G->rho_v;
+        const dim3 grid = shape(g.Nz, kc);
+        hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+    }
+    {
+        ProfileScope ps(ctx, "z_momentum_tendency+rk3");
+        E.u0 = U0->rho_w; E.u0_out = U0->rho_w;
+        L.out = G->rho_w;
+        const dim3 grid = shape(g.Nz - 1, kc);
+        hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+    }
+    {
+        ProfileScope ps(ctx, "scalar_tendencies+rk3");
+        E.u0 = U0->rho_theta; E.u0_out = U0->rho_theta; E.u0b = U0->rho_q; E.u0b_out = U0->rho_q;
+        L.out = nullptr;
+        const dim3 grid = shape(g.Nz, kc);
+        hipLaunchKernelGGL((k5_scalar_pair<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+    }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}

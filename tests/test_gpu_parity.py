@@ -4,6 +4,8 @@ Tolerances (Float64): the HIP kernels execute the oracle's operation order but h
 mul+add into FMA and uses its own pow/sin, so single kernels agree to ~1e-13 of the field scale;
 the Poisson solve differs by FFT algorithm (rocFFT real-to-complex vs pocketfft complex): 1e-11;
 after full time steps: 1e-9 (last row)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -624,3 +626,63 @@ def test_device_reproduces_reference_doctest_numbers(bz):
     rh = rho * qv * Rv * T / ps
     for key, val in (("max", rh.max()), ("min", rh.min()), ("mean", rh.mean())):
         assert abs(val - gd["relative_humidity"][key]) <= sig(gd["relative_humidity"][key]), (key, val)
+
+
+def _moist_q(x, y, z):
+    r = np.sqrt(x ** 2 + (y - 1000.0) ** 2 + (z - 2500.0) ** 2)
+    return 8e-3 * np.exp(-z / 2500.0) * (1.0 + 0.3 * np.maximum(0.0, 1.0 - r / 3e3))
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("size,moist", [((32, 20, 16), False), ((32, 20, 16), True), ((72, 24, 40), True), ((130, 16, 12), False)])
+def test_lean_seam_matches_the_diagnostic_seam(oracle, bz, size, moist, strict, monkeypatch):
+    """The lean whole-step seam (bz_tendency5_kernels.h: tendency kernels on prognostic fields only, u, v, w, theta, q^v, T derived
+    on the fly with the correctly rounded column division, momentum-only projection in stages 1-2) against the generation-4 seam
+    that reads stored diagnostics (BZ_NO_LEAN=1), three steps, dry (table-driven Exner factor) and with vapour (pow() behind the
+    noinline call), full and ragged tiles.
+      strict: the -ffp-contract=off build (lib/libbreeze_hip_refdiv.so): every field, halos included, carries the SAME BITS —
+              the derived quantities are exactly the stored ones (tools/check_cdiv_gpu.hip: 0 mismatches in 4e9 divisions);
+      default build: hipcc contracts mul+add into FMA differently in the two kernel generations, so the last bit of a few
+              per cent of the momentum values differs after the third step: 1e-13 of the field scale (the tolerance of the
+              whole-step-versus-operator-sequence test)."""
+    from breeze_jl_amd import _lib
+    if strict:
+        monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(os.path.dirname(_lib.LIB_PATH), "libbreeze_hip_refdiv.so"))
+    th = bubble_theta(300.0, 9.81)
+    runs = []
+    for lean in (True, False):
+        if lean:
+            monkeypatch.delenv("BZ_NO_LEAN", raising=False)
+        else:
+            monkeypatch.setenv("BZ_NO_LEAN", "1")
+        om, hm = make_pair(oracle, bz, size)
+        kw = dict(θ=th, u=3.0, v=-2.0)
+        if moist:
+            kw["qᵗ"] = _moist_q
+        hm.set(**kw)
+        for _ in range(3):
+            hm.time_step(1.5)
+        hm.synchronize()
+        runs.append(hm)
+    a, b = runs
+    fields = {"ρu": lambda m: m.momentum["ρu"], "ρv": lambda m: m.momentum["ρv"], "ρw": lambda m: m.momentum["ρw"],
+              "ρθ": lambda m: m.potential_temperature_density, "ρq": lambda m: m.moisture_density,
+              "u": lambda m: m.velocities["u"], "w": lambda m: m.velocities["w"], "θ": lambda m: m.potential_temperature,
+              "q": lambda m: m.specific_moisture, "T": lambda m: m.temperature, "ϕ": lambda m: m.dynamics.pressure_anomaly}
+    for name, get in fields.items():
+        fa, fb = get(a), get(b)
+        if strict:
+            assert np.array_equal(fa.interior_cpu(), fb.interior_cpu()), name
+            if name not in ("u", "w"):          # velocity z-halos are `nothing` boundary conditions: never filled
+                assert np.array_equal(fa.cpu(), fb.cpu()), name + " (halos)"
+        else:
+            assert relerr(fa.interior_cpu(), fb.interior_cpu()) < 1e-13, name
+    if moist and not strict:               # and the moist lean seam against the oracle
+        om, _ = make_pair(oracle, bz, size)
+        om.set(theta=th, u=3.0, v=-2.0, qt=_moist_q)
+        for _ in range(3):
+            om.time_step(1.5)
+        for n, k in PROG.items():
+            got = a.prognostic_fields()[k].interior_cpu()
+            want = _interior(om, n)
+            assert np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-3) < 1e-9, n

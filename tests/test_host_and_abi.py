@@ -43,11 +43,13 @@ def test_struct_layouts_match_header(bz):
 
 
 def test_grid_layout(bz):
-    g = bz.RectilinearGrid((8, 6, 4), x=(0, 8), y=(0, 12), z=(0, 2), halo=(3, 4, 5))
+    g = bz.RectilinearGrid((8, 6, 4), x=(0, 8), y=(0, 12), z=(0, 2), halo=(3, 4, 4))
     assert (g.Sx, g.Sy) == (14, 14)
-    assert g.parent_shape() == (14, 14, 14) and g.parent_shape(zface=True) == (15, 14, 14)
+    assert g.parent_shape() == (12, 14, 14) and g.parent_shape(zface=True) == (13, 14, 14)
     assert g.Δx == 1.0 and g.Δy == 2.0 and g.Δz == 0.5
     assert np.allclose(g.zᶜ, [0.25, 0.75, 1.25, 1.75])
+    with pytest.raises(ValueError):          # Oceananigans: a halo cannot be wider than the domain (Ny < Hy read unfilled rows)
+        bz.RectilinearGrid((8, 2, 4), x=(0, 8), y=(0, 12), z=(0, 2))
     with pytest.raises(ValueError):
         bz.RectilinearGrid((8, 6), x=(0, 1), y=(0, 1), z=(0, 1))
     with pytest.raises(ValueError):

@@ -49,6 +49,11 @@ WORDS_PER_CELL = {
     # tendency kernels with the RK update folded in: tendency words + the RK update words of their fields
     "x_momentum_tendency+rk3": 9, "y_momentum_tendency+rk3": 9, "z_momentum_tendency+rk3": 11,
     "scalar_tendencies+rk3": 19,
+    # lean whole-step seam (bz_tendency5_kernels.h): the diagnostics are no separate passes any more — each momentum kernel derives its
+    # velocity component (compute_velocities: 2 of its 6 words), the scalar kernel does the theta, q^v, T diagnosis (5 words), the
+    # projection of stages 1-2 is make_pressure_correction alone (7).  Per stage: 24 + 11 + 11 + 13 + 7 + Poisson 14 = 80, as before.
+    "x_momentum_tendency+rk3+velocity": 11, "y_momentum_tendency+rk3+velocity": 11, "z_momentum_tendency+rk3+velocity": 13,
+    "scalar_tendencies+rk3+thermo": 24, "project_momentum": 7,
 }
 A_STEP_WORDS = 250          # 3 stages x 80 + 10
 METRIC = "grid-cells advanced/sec (tendency+Poisson step), 512^3 anelastic"

@@ -71,6 +71,11 @@ class bz_tracer_fields(C.Structure):
     _fields_ = [("density", C.c_void_p), ("specific", C.c_void_p), ("U0", C.c_void_p), ("G", C.c_void_p)]
 
 
+class bz_bounds_preserving_advection(C.Structure):
+    _fields_ = [("lower", C.c_double), ("upper", C.c_double), ("moisture", C.c_int32), ("microphysical_species", C.c_int32),
+                ("tracers", C.c_int32), ("reserved", C.c_int32)]
+
+
 class bz_smagorinsky_lilly(C.Structure):
     _fields_ = [("smagorinsky_coefficient", C.c_double), ("reduction_factor", C.c_double), ("prandtl_number", C.c_double)]
 
@@ -209,6 +214,7 @@ SYMBOLS = {
     "bz_slab_transform": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "bz_set_tracers": (C.c_int, [_ctx, C.c_int32, C.POINTER(bz_tracer_fields)]),
     "bz_set_closure": (C.c_int, [_ctx, C.POINTER(bz_smagorinsky_lilly), C.c_void_p]),
+    "bz_set_bounds_preserving_advection": (C.c_int, [_ctx, C.POINTER(bz_bounds_preserving_advection)]),
     "bz_compute_closure_fields": (C.c_int, [_ctx, _sp]),
     "bz_set_bulk_surface_fluxes": (C.c_int, [_ctx, C.POINTER(bz_bulk_surface_fluxes)]),
     "bz_set_forcings": (C.c_int, [_ctx, C.POINTER(bz_column_forcings)]),

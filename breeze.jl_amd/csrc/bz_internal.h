@@ -287,6 +287,9 @@ struct bz_ctx {
     double *d_closure_ipi = nullptr;  // (pst/p_r[k])^(Rd/cpd), k = -1 .. Nz
     double *up2_user = nullptr, *vp2_user = nullptr;   // caller-owned replacements of d_up2 / d_vp2 (bz_set_acoustic_scratch)
     alignas(8) unsigned char ac_stage_storage[160] = {0};   // AcStage of the stage in flight (bz_compressible.hip)
+    // advection = (; rho_q = WENO(order = 5, bounds = (lo, hi))) (bz_set_bounds_preserving_advection, bz_bounded.hip)
+    int bounded_mask = 0;             // 1 moisture, 2 microphysical species, 4 tracers
+    double bounded_lo = 0.0, bounded_hi = 1.0;
     // profiling
     bool profiling = false;
     std::vector<ProfileSlot> slots;
@@ -344,6 +347,7 @@ int bzi_kessler_rk3(bz_ctx *ctx, double dt, double alpha, bool first);
 int bzi_kessler_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt);
 int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, int n);
 int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
+int bzi_bounded_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_lean_setup(bz_ctx *ctx);
 void bzi_lean_teardown(bz_ctx *ctx);
 void bzi_poisson_teardown(bz_ctx *ctx);

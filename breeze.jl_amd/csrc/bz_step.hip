@@ -34,7 +34,7 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
     if (ctx->fused_ok && ctx->fuse_rk && ctx->lean && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
-        !ctx->has_forcings && !ctx->has_bulk && !ctx->has_closure && ctx->n_tracers == 0 &&
+        !ctx->has_forcings && !ctx->has_bulk && !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask &&
         (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32)) {
         // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,
         // q^v, T on the fly (bit-identical to the stored diagnostics), rho theta / rho q ping-pong between their own arrays
@@ -58,7 +58,8 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
         ctx->G_is_predictor = true;
         return BZ_OK;
     }
-    if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !(ctx->has_forcings && getenv("BZ_NO_FUSE_FORCING"))) {
+    if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !ctx->bounded_mask &&
+        !(ctx->has_forcings && getenv("BZ_NO_FUSE_FORCING"))) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state
         // left by stage s-1), the predictor momentum goes to the G arrays and is projected from there into the

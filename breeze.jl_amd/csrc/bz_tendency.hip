@@ -302,6 +302,7 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     }
     if (ctx->tend_gen >= 3) {
         // gen-3 kernels for the scalars and horizontal momentum; w stays gen-1 unless BZ_TEND_GEN=4
+        if (ctx->bounded_mask) { ctx->last_error = "BZ_TEND_GEN >= 3 does not implement bounds-preserving advection"; return BZ_ERR_UNSUPPORTED; }
         int rc = bzi_compute_tendencies3(ctx, s, G, ctx->tend_gen >= 4);
         if (rc || ctx->tend_gen >= 4) return rc;
         ProfileScope ps(ctx, "z_momentum_tendency");
@@ -363,6 +364,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     if (ctx->n_tracers) {
         int rct = bzi_tracer_tendencies(ctx, s);
         if (rct) return rct;
+    }
+    if (ctx->bounded_mask) {
+        int rcb = bzi_bounded_tendencies(ctx, s, G);
+        if (rcb) return rcb;
     }
     if (ctx->has_closure) {
         int rcc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, 1.0);

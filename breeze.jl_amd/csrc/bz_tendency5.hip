@@ -74,28 +74,28 @@ int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
     };
     int kc;
     {
-        ProfileScope ps(ctx, "x_momentum_tendency+rk3");
+        ProfileScope ps(ctx, "x_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         L.out = G->rho_u;
         const dim3 grid = shape(g.Nz, kc);
         hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     {
-        ProfileScope ps(ctx, "y_momentum_tendency+rk3");
+        ProfileScope ps(ctx, "y_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
         L.out = G->rho_v;
         const dim3 grid = shape(g.Nz, kc);
         hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     {
-        ProfileScope ps(ctx, "z_momentum_tendency+rk3");
+        ProfileScope ps(ctx, "z_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_w; E.u0_out = U0->rho_w;
         L.out = G->rho_w;
         const dim3 grid = shape(g.Nz - 1, kc);
         hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     {
-        ProfileScope ps(ctx, "scalar_tendencies+rk3");
+        ProfileScope ps(ctx, "scalar_tendencies+rk3+thermo");
         E.u0 = U0->rho_theta; E.u0_out = U0->rho_theta; E.u0b = U0->rho_q; E.u0b_out = U0->rho_q;
         L.out = nullptr;
         const dim3 grid = shape(g.Nz, kc);

@@ -31,12 +31,58 @@ class Centered:
 
 
 class WENO:
-    """WENO(order=5): only the 5th-order scheme is implemented on the device."""
+    """WENO(order=5; bounds=nothing): only the 5th-order scheme is implemented on the device.  `bounds = (lo, hi)` makes it the
+    bounds-preserving scheme (Oceananigans' BoundsPreservingWENO) that the reference's moist examples give their moisture
+    densities (examples/rico.jl:184-190, examples/tropical_cyclone_world.jl:169); it is a per-scalar scheme:
+    `advection = {"momentum": WENO(), "ρθ": WENO(), "ρqᵉ": WENO(bounds=(0, 1))}`."""
 
-    def __init__(self, order=5):
+    def __init__(self, order=5, bounds=None):
         if order != 5:
             raise NotImplementedError("only WENO(order=5) is implemented in the HIP path")
         self.order = order
+        if bounds is not None:
+            bounds = (float(bounds[0]), float(bounds[1]))
+            if not bounds[1] > bounds[0]:
+                raise ValueError("bounds must be (lower, upper) with upper > lower")
+        self.bounds = bounds
+
+
+_MOISTURE_KEYS = ("ρq", "ρqᵛ", "ρqᵉ", "ρqᵗ")
+_SPECIES_KEYS = ("ρqᶜˡ", "ρqʳ")
+
+
+def _split_advection(advection, tracer_names):
+    """The reference accepts one scheme or a NamedTuple of schemes keyed by `momentum` and the scalar names
+    (atmosphere_model.jl advection keyword; examples/rico.jl:186-190).  Returns (base scheme, bounds-preserving request or None)."""
+    if not isinstance(advection, dict):
+        if getattr(advection, "bounds", None) is not None:
+            raise NotImplementedError("bounds-preserving WENO is a scalar scheme: pass advection = {'momentum': WENO(), ..., 'ρqᵉ': WENO(bounds=(0, 1))}")
+        return advection, None
+    base = advection.get("momentum") or next(iter(advection.values()))
+    bounded, lo_hi = {"moisture": 0, "microphysical_species": 0, "tracers": 0}, None
+    for key, scheme in advection.items():
+        key = str(key).lstrip(":")
+        if getattr(scheme, "order", None) != base.order:
+            raise NotImplementedError("every component of `advection` must have the order of the momentum scheme")
+        b = getattr(scheme, "bounds", None)
+        if b is None:
+            continue
+        if key in ("momentum", "ρθ", "ρe"):
+            raise NotImplementedError(f"bounds-preserving advection of {key} is not implemented (moisture, microphysical species, tracers)")
+        if lo_hi is not None and b != lo_hi:
+            raise NotImplementedError("one pair of bounds for all bounds-preserving scalars")
+        lo_hi = b
+        if key in _MOISTURE_KEYS:
+            bounded["moisture"] = 1
+        elif key in _SPECIES_KEYS:
+            bounded["microphysical_species"] = 1
+        elif key.lstrip("ρ") in tracer_names or key in tracer_names:
+            bounded["tracers"] = 1
+        else:
+            raise ValueError(f"advection key {key!r} names no prognostic scalar of this model")
+    if lo_hi is None:
+        return base, None
+    return base, dict(bounded, lower=lo_hi[0], upper=lo_hi[1])
 
 
 class AnelasticDynamics:
@@ -142,6 +188,8 @@ class AtmosphereModel:
                                  "`thermodynamic_constants = ThermodynamicConstants(saturation_vapor_pressure = TetensFormula())`.")
         if advection is None:
             advection = Centered(order=2)          # the reference's default
+        advection, self._bounded_advection = _split_advection(advection, tuple(str(n).lstrip(":") for n in
+                                                                                 ((tracers,) if isinstance(tracers, str) else tracers)))
         if not torch.cuda.is_available():
             raise RuntimeError("AtmosphereModel needs a GPU: the HIP path has no CPU fallback")
         self.grid = grid
@@ -240,6 +288,12 @@ class AtmosphereModel:
                 arr[t].U0, arr[t].G = self.U0[n].ptr(), self.G[n].ptr()
             self._check(lib.bz_set_tracers(self._ctx, len(self.tracers), arr), "bz_set_tracers")
         self.closure_fields = {}
+        if self._bounded_advection is not None:
+            ba = self._bounded_advection
+            if ba["tracers"] and ba["tracers"] != 0 and len(self.tracers) == 0:
+                raise ValueError("bounds-preserving tracer advection without tracers")
+            bs = _lib.bz_bounds_preserving_advection(ba["lower"], ba["upper"], ba["moisture"], ba["microphysical_species"], ba["tracers"], 0)
+            self._check(lib.bz_set_bounds_preserving_advection(self._ctx, C.byref(bs)), "bz_set_bounds_preserving_advection")
         if closure is not None:      # build_closure_fields: nu_e (atmosphere_model.jl:276)
             if self._kessler or formulation != "LiquidIcePotentialTemperature":
                 raise NotImplementedError("SmagorinskyLilly is implemented for the potential-temperature formulation without Kessler")

@@ -466,6 +466,20 @@ typedef struct bz_tracer_fields {
 } bz_tracer_fields;
 int bz_set_tracers(bz_ctx *ctx, int32_t n, const bz_tracer_fields *tracers);
 
+/* ---- bounds-preserving WENO for moisture-like scalars (second half) ----
+ * advection = (; rho_q^e = WENO(order = 5, bounds = (0, 1)), ...) (examples/rico.jl:184-190, examples/tropical_cyclone_world.jl:169):
+ * div_rhoUc(i, j, k, grid, ::BoundsPreservingWENO, rho, U, c) = V^-1 (bounded_tracer_flux_divergence_x + _y + _z)
+ * (src/Advection.jl:42-47); the three divergences are Oceananigans' positivity-preserving limiter (not vendored; restated in
+ * oracle/breeze_oracle.c: parity unpinned).  Flags select the scalars that use it: the moisture density (rho q^v / rho q^e), the
+ * prognostic species of the attached microphysics (rho q^cl, rho q^r), the user tracers.  With any flag set bz_compute_tendencies
+ * replaces those scalars' advective tendencies and bz_time_step_anelastic runs its operator-sequence tier.  Single-device anelastic
+ * contexts of the WENO build; NULL detaches. */
+typedef struct bz_bounds_preserving_advection {
+    double lower, upper;
+    int32_t moisture, microphysical_species, tracers, reserved;
+} bz_bounds_preserving_advection;
+int bz_set_bounds_preserving_advection(bz_ctx *ctx, const bz_bounds_preserving_advection *bounds);
+
 /* ---- closure = SmagorinskyLilly() (BASELINE configs[2]) ----
  * Breeze's part — density-weighted stress and flux divergences (src/TurbulenceClosures/TurbulenceClosures.jl:44-101), their place
  * in the tendencies (src/AtmosphereModels/dynamics_kernel_functions.jl:80,100,128,157), N^2 = g dz(log theta_v)

@@ -308,6 +308,73 @@ void og_scalar_tendency(const og_grid *G, double *Gc, const double *u, const dou
             }
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* f4: bounds-preserving WENO for moisture, WENO(order = 5, bounds = (lo, hi)). */
+/* Breeze: div_rhoUc(i, j, k, grid, advection::BoundsPreservingWENO, rho, U, c) =  */
+/*   V^-1 (bounded_tracer_flux_divergence_x + _y + _z)   (src/Advection.jl:42-47).  */
+/* The three divergences are Oceananigans' (0.110.x, not vendored; PARITY UNPINNED): */
+/* the positivity-preserving limiter of Zhang & Shu (2010) as Oceananigans applies  */
+/* it to its WENO reconstructions (positivity_preserving_tracer_advection_operators): */
+/*   c+L, c+R = left / right biased value at the cell's upper face, c-L, c-R at its   */
+/*   lower face;  p~ = (c - w1 c-R - wn c+L) / (1 - 2 w1), w1 = wn = 5/18;            */
+/*   M, m = max, min(p~, c+L, c-R);  theta = min(|(hi - c)/(M - c + eps2)|,           */
+/*   |(lo - c)/(m - c + eps2)|, 1), eps2 = 1e-20;  the two reconstructions that start */
+/*   in this cell are limited, c+L <- theta (c+L - c) + c, c-R likewise;  divergence = */
+/*   rho A u (+) (c+L, c+R) at the upper face minus the same at the lower face with    */
+/*   upwind_biased_product(u, L, R) = ((u + |u|) L + (u - |u|) R) / 2.                 */
+/* The density rides on the face as in tracer_mass_flux_* (src/Advection.jl:20-27).    */
+/* Note: theta belongs to the cell, the inflow value of a face is the neighbour's      */
+/* unlimited reconstruction: not strictly conservative / bounds-preserving (tests).    */
+/* ------------------------------------------------------------------------- */
+static inline double upwind_biased_product(double u, double cl, double cr)
+{
+    return ((u + fabs(u)) * cl + (u - fabs(u)) * cr) / 2.0;
+}
+static inline double bounded_div_1d(const double *c, ptrdiff_t s, int idx, int N, int bounded, double lo, double hi,
+                                    double flux_hi /* rho A u at face idx+1 */, double flux_lo /* at face idx */)
+{
+    const double w1 = 5.0 / 18.0, eps2 = 1e-20;
+    const double cij = c[0];
+    double cpL = biased_face(c + s, s, 1, idx + 1, N, bounded);
+    double cpR = biased_face(c + s, s, 0, idx + 1, N, bounded);
+    double cmL = biased_face(c, s, 1, idx, N, bounded);
+    double cmR = biased_face(c, s, 0, idx, N, bounded);
+    double pt = (cij - w1 * cmR - w1 * cpL) / (1.0 - 2.0 * w1);
+    double M = fmax(pt, fmax(cpL, cmR));
+    double m = fmin(pt, fmin(cpL, cmR));
+    double th = fmin(fmin(fabs((hi - cij) / (M - cij + eps2)), fabs((lo - cij) / (m - cij + eps2))), 1.0);
+    cpL = th * (cpL - cij) + cij;
+    cmR = th * (cmR - cij) + cij;
+    return upwind_biased_product(flux_hi, cpL, cpR) - upwind_biased_product(flux_lo, cmL, cmR);
+}
+
+void og_scalar_tendency_bounded(const og_grid *G, double *Gc, const double *u, const double *v, const double *w,
+                                const double *c, double lo, double hi)
+{
+    const ptrdiff_t sy = (ptrdiff_t)SX(G), sz = (ptrdiff_t)(SX(G) * SY(G));
+    const double *rho = G->rho_r + G->Hz;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < G->Nz; ++k)
+        for (int j = 0; j < G->Ny; ++j)
+            for (int i = 0; i < G->Nx; ++i) {
+                size_t n = IDX(G, i, j, k);
+                double dzc = G->dzc[k + G->Hz];
+                double Vinv = 1.0 / (G->dx * G->dy * dzc);
+                double Ax = G->dy * dzc, Ay = G->dx * dzc, Az = G->dx * G->dy;
+                double rc = 0.5 * (rho[k] + rho[k]);
+                double dxF = 0.0, dyF = 0.0, dzF = 0.0;
+                if (G->tx != FLAT)
+                    dxF = bounded_div_1d(c + n, 1, i, G->Nx, G->tx == BOUNDED, lo, hi, rc * (Ax * u[n + 1]), rc * (Ax * u[n]));
+                if (G->ty != FLAT)
+                    dyF = bounded_div_1d(c + n, sy, j, G->Ny, G->ty == BOUNDED, lo, hi, rc * (Ay * v[n + sy]), rc * (Ay * v[n]));
+                if (G->tz != FLAT)
+                    dzF = bounded_div_1d(c + n, sz, k, G->Nz, G->tz == BOUNDED, lo, hi,
+                                         (0.5 * (rho[k] + rho[k + 1])) * (Az * w[n + sz]), (0.5 * (rho[k - 1] + rho[k])) * (Az * w[n]));
+                Gc[n] = -(Vinv * (dxF + dyF + dzF));
+            }
+}
+
 /* ------------------------------------------------------------------------- */
 /* a2/a3: momentum tendencies (dynamics_kernel_functions.jl:54-130).          */
 /* Advecting field = momentum (rho u), advected = velocity component.        */

@@ -520,6 +520,13 @@ class OracleModel:
             L.og_energy_buoyancy_flux(cg, _p(G["rtheta"]), _p(self.w), _p(self.T), _p(self.q))
         for t in range(self.n_tracers):     # scalar_tendency per tracer (update_atmosphere_model_state.jl:352-372)
             L.og_scalar_tendency(cg, _p(G[f"rc{t}"]), _p(self.u), _p(self.v), _p(self.w), _p(getattr(self, f"c{t}")))
+        # advection = (; rho_q = WENO(order = 5, bounds = (lo, hi))) (examples/rico.jl:184-190): bounds-preserving divergence
+        for key, (lo, hi) in getattr(self, "bounded", {}).items():
+            specific = {"rq": self.q, "rqcl": getattr(self, "qcl", None), "rqr": getattr(self, "qr", None)}.get(key)
+            if key.startswith("rc"):
+                specific = getattr(self, key[1:])
+            L.og_scalar_tendency_bounded(cg, _p(G[key]), _p(self.u), _p(self.v), _p(self.w), _p(specific),
+                                         C.c_double(lo), C.c_double(hi))
         if self.closure is not None:
             from .closure import add_closure_tendencies
             add_closure_tendencies(self)

@@ -221,3 +221,47 @@ def test_dewpoint_temperature_doctest(oracle, golden, thermo):
     Td = np.array(out)
     for key, val in (("max", Td.max()), ("min", Td.min()), ("mean", Td.mean())):
         assert abs(val - gd[key]) <= _sig(gd[key]), (key, val, gd[key])
+
+
+def _theta_column(oracle):
+    """The default model of the potential-temperature doctests after set!(model, θ = 300, qᵗ = 0.01): T, q, p_r on 8 levels."""
+    m = _column_model(oracle, 8)
+    m.set(qt=0.01, theta=300.0)
+    g, c, r = m.grid, m.constants, m.ref
+    return g.interior(m.T)[:, 0, 0], g.interior(m.q)[:, 0, 0], r.pressure[g.Hz:g.Hz + g.Nz], r.pst, c
+
+
+def _check(val, gd, digits_tol):
+    for key, x in (("max", val.max()), ("min", val.min()), ("mean", val.mean())):
+        assert abs(x - gd[key]) <= digits_tol, (key, x, gd[key])
+
+
+def test_plain_and_liquid_ice_potential_temperature_doctests(oracle, golden):
+    """PotentialTemperature = T / Pi_m and LiquidIcePotentialTemperature = theta (1 - L q^l / (c_pm T)) of a vapour-only state
+    (potential_temperatures.jl:556-573): both must return the 300 K that was set — the theta -> T -> theta round trip through the
+    oracle's moist Exner function."""
+    T, q, p, pst, c = _theta_column(oracle)
+    qd = 1.0 - q
+    Rm, cpm = qd * c.Rd + q * c.Rv, qd * c.cpd + q * c.cpv
+    theta = T / (p / pst) ** (Rm / cpm)
+    _check(theta, golden["model_diagnostics"]["potential_temperature"], 1e-9)
+    _check(theta * (1.0 - 0.0 / (cpm * T)), golden["model_diagnostics"]["liquid_ice_potential_temperature"], 1e-9)
+
+
+def test_equivalent_potential_temperature_doctests(oracle, golden, thermo):
+    """EquivalentPotentialTemperature (Emanuel 1994 eq. 4.5.11 as written in potential_temperatures.jl:580-605):
+    theta_e = T (p_st/p)^(R_d/c_pm) exp(L_l(T) q^v / (c_pm T)) H^(-R_v q^v / c_pm), H = p^v / p^v+ over liquid with
+    rho = p / (R_m T); and the stability-equivalent flavour, identical for q^l = 0.  Six printed digits (326.162 / 325.851 / 326.006)
+    pin the diagnosed temperature, the reference pressure column, L_l(T) and the Clausius-Clapeyron pressure together."""
+    T, q, p, pst, c = _theta_column(oracle)
+    tc = thermo.ThermoConstants()
+    qd = 1.0 - q
+    Rm, cpm = qd * c.Rd + q * c.Rv, qd * c.cpd + q * c.cpv
+    rho = p / (Rm * T)
+    ps = np.array([thermo.saturation_vapor_pressure(t, tc, "liquid") for t in T])
+    H = rho * q * c.Rv * T / ps
+    Ll = tc.Ll + (tc.cpv - tc.cl) * (T - tc.T_energy)
+    theta_e = T * (pst / p) ** (c.Rd / cpm) * np.exp(Ll * q / (cpm * T)) * H ** (-c.Rv * q / cpm)
+    _check(theta_e, golden["model_diagnostics"]["equivalent_potential_temperature"], 6e-4)
+    theta_b = theta_e * (T / tc.T_energy) ** (tc.cl * 0.0 / cpm)
+    _check(theta_b, golden["model_diagnostics"]["stability_equivalent_potential_temperature"], 6e-4)

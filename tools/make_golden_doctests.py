@@ -77,6 +77,26 @@ out["model_diagnostics"] = {
         "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300, "qt": 0.01}},
         **stats("src/AtmosphereModels/Diagnostics/potential_temperatures.jl", "θᵛ = VirtualPotentialTemperature(model)\nField(θᵛ)"),
     },
+    "potential_temperature": {
+        "source": "src/AtmosphereModels/Diagnostics/potential_temperatures.jl (jldoctest of PotentialTemperature)",
+        "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300, "qt": 0.01}},
+        **stats("src/AtmosphereModels/Diagnostics/potential_temperatures.jl", "θ = PotentialTemperature(model)\nField(θ)"),
+    },
+    "liquid_ice_potential_temperature": {
+        "source": "src/AtmosphereModels/Diagnostics/potential_temperatures.jl (jldoctest of LiquidIcePotentialTemperature)",
+        "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300, "qt": 0.01}},
+        **stats("src/AtmosphereModels/Diagnostics/potential_temperatures.jl", "θˡⁱ = LiquidIcePotentialTemperature(model)\nField(θˡⁱ)"),
+    },
+    "equivalent_potential_temperature": {
+        "source": "src/AtmosphereModels/Diagnostics/potential_temperatures.jl (jldoctest of EquivalentPotentialTemperature)",
+        "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300, "qt": 0.01}},
+        **stats("src/AtmosphereModels/Diagnostics/potential_temperatures.jl", "θᵉ = EquivalentPotentialTemperature(model)\nField(θᵉ)"),
+    },
+    "stability_equivalent_potential_temperature": {
+        "source": "src/AtmosphereModels/Diagnostics/potential_temperatures.jl (jldoctest of StabilityEquivalentPotentialTemperature)",
+        "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300, "qt": 0.01}},
+        **stats("src/AtmosphereModels/Diagnostics/potential_temperatures.jl", "θᵇ = StabilityEquivalentPotentialTemperature(model)\nField(θᵇ)"),
+    },
     "dewpoint_temperature": {
         "source": "src/AtmosphereModels/Diagnostics/dewpoint_temperature.jl (jldoctest dewpoint): SaturationAdjustment() defaults",
         "inputs": {"size": [1, 1, 8], "extent": [1, 1, 1e3], "set": {"theta": 300, "qt": 0.01}},

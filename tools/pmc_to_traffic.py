@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""tools/pmc_to_traffic.py PMC_SUMMARY.json > profiles/rNN_pmc_traffic.json — HBM-side bytes per launch of every kernel group of
+bench.py from a tools/pmc_summary.py file (FETCH_SIZE / WRITE_SIZE passes).  Units per /opt/skills/guides/MI355X_MICROARCH.md:
+both counters in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads, so read bytes = 2 x FETCH_SIZE
+x 1024 (calibrated in round 1 on the 15-array RK update: expected 16.7 GB, 2 x FETCH_SIZE = 17.3 GB).  The counters sit at the
+L2-fabric boundary: Infinity-Cache hits are included."""
+import json
+import sys
+
+GROUPS = {
+    "k5_scalar_pair<8>": "scalar_tendencies+rk3+thermo", "k5_u<8>": "x_momentum_tendency+rk3+velocity",
+    "k5_v<8>": "y_momentum_tendency+rk3+velocity", "k5_w<8>": "z_momentum_tendency+rk3+velocity",
+    "k_project_lean": "project_momentum", "k_project_diagnose<0>": "project_and_diagnose",
+    "k_poisson_source_rows": "poisson_source_term", "k_tridiag_solve": "poisson_tridiagonal", "k_tridiag_lds": "poisson_tridiagonal",
+    "k_scalar_pair_lds<8>": "scalar_tendencies+rk3", "k_u_tend_lds<8>": "x_momentum_tendency+rk3",
+    "k_v_tend_lds<8>": "y_momentum_tendency+rk3", "k_w_tend_lds<8, 0>": "z_momentum_tendency+rk3",
+}
+FFT = {"fwd": "poisson_fft_forward", "back": "poisson_fft_inverse"}
+
+
+def main():
+    d = json.load(open(sys.argv[1]))
+    out = {"note": __doc__.split("—", 1)[1].strip(), "source": sys.argv[1], "per_kernel_group": {}}
+    per = out["per_kernel_group"]
+    for k, v in d.items():
+        if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        rd, wr = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
+        if k in GROUPS:
+            per[GROUPS[k]] = {"kernel": k, "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+        elif k.startswith("fft_rtc_"):
+            g = FFT["fwd" if "_fwd_" in k else "back"]
+            e = per.setdefault(g, {"kernel": "rocFFT 2-D plan (two kernels)", "read_bytes": 0.0, "write_bytes": 0.0, "hbm_bytes_per_launch": 0.0})
+            e["read_bytes"] += rd; e["write_bytes"] += wr; e["hbm_bytes_per_launch"] += rd + wr
+    json.dump(out, sys.stdout, indent=1)
+    sys.stdout.write("\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -229,6 +229,29 @@ def comm_selfcheck(decomp, device, Nz=4):
         d.Nz = save_Nz
 
 
+def library_halo_selfcheck(model):
+    """Rank-coded rows through bz_comm_exchange_y_halos (the library's own transport), verified against what the ring neighbours
+    must have delivered.  Raises on mismatch."""
+    import ctypes as C
+    import torch
+    g, r, W = model.grid, model.rank, model.world
+    f = model.temperature.parent
+    keep = f.clone()
+    rows = torch.arange(g.Ny, dtype=torch.float64, device=f.device)
+    f.zero_()
+    f[:, g.Hy:g.Hy + g.Ny, :] = (1000.0 * r + rows)[None, :, None]
+    ptrs = (C.c_void_p * 1)(f.data_ptr())
+    levels = (C.c_int32 * 1)(f.shape[0])
+    model._check(model._lib.bz_comm_exchange_y_halos(model._ctx, ptrs, levels, 1), "bz_comm_exchange_y_halos")
+    model.synchronize()
+    lo = 1000.0 * ((r - 1) % W) + torch.arange(g.Ny - g.Hy, g.Ny, dtype=torch.float64, device=f.device)
+    hi = 1000.0 * ((r + 1) % W) + torch.arange(0, g.Hy, dtype=torch.float64, device=f.device)
+    ok = torch.equal(f[0, :g.Hy, 0], lo) and torch.equal(f[-1, g.Hy + g.Ny:, -1], hi)
+    f.copy_(keep)
+    if not ok:
+        raise RuntimeError(f"rank {r}: the library's y-halo exchange delivered wrong rows")
+
+
 def problem(args, world):
     """Global grid size, per-rank slab and the label of the workload."""
     N = args.size
@@ -320,19 +343,48 @@ def run_rank(args):
             yy = np.mod(y - EXTENT[1][0], EXTENT[1][1] - EXTENT[1][0]) + EXTENT[1][0]
             return bubble(x, yy, z)
 
-        try:
-            model = SlabAtmosphereModel(ggrid, rank, world, advection=bz.WENO(order=5), surface_pressure=101325,
-                                        potential_temperature=300, device=device)
-            decomp = model.decomp
-            if world > 1:
-                comm_selfcheck(decomp, device)
-            model.set(θ=bubbles)
-            model.time_step(dt)
+        # Transport: "rccl" = the communicator inside the C library (bz_comm.hip: the whole step is one C call, halo exchange
+        # overlapped with interior tiles); "torch" = the Python orchestration over torch.distributed.  "auto" tries the library
+        # first — its first contact with more than one GPU is this very run — verifies a rank-coded halo exchange through it, and
+        # only if that raises on some rank do ALL ranks switch to the torch transport.  The line says which one carried the run.
+        def build(transport):
+            m = SlabAtmosphereModel(ggrid, rank, world, advection=bz.WENO(order=5), surface_pressure=101325,
+                                    potential_temperature=300, device=device, transport=transport)
+            if transport == "rccl":
+                library_halo_selfcheck(m)
+            elif world > 1:
+                comm_selfcheck(m.decomp, device)
+            m.set(θ=bubbles)
+            m.time_step(dt)
             torch.cuda.synchronize()
+            return m
+
+        transport, transport_note = ("rccl" if args.transport == "auto" else args.transport), None
+        try:
+            err = None
+            try:
+                model = build(transport)
+            except Exception as exc:      # noqa: BLE001
+                err = repr(exc)
+                print(f"[bench rank {rank}] transport {transport}: {err}", file=sys.stderr, flush=True)
+            if args.transport == "auto":
+                bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
+                if dist is not None:
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if bad.item():
+                    transport_note = f"library transport failed on a rank ({err or 'another rank'}); torch.distributed carried the run"
+                    model = None
+                    torch.cuda.empty_cache()
+                    transport = "torch"
+                    model = build(transport)
+            elif err:
+                raise RuntimeError(err)
+            decomp = model.decomp if transport == "torch" else None
         except Exception as exc:      # noqa: BLE001
             fail(f"slab driver failed: {exc!r}")
         per = (G[0], G[1] // world, G[2])
-        parallelism = f"{world} y-slabs of {per[0]}x{per[1]}x{per[2]} (RCCL halo exchange + FFT transposes)"
+        parallelism = (f"{world} y-slabs of {per[0]}x{per[1]}x{per[2]}, halo exchange + FFT all-to-all over " +
+                       ("RCCL inside the C library (bz_comm.hip)" if transport == "rccl" else "torch.distributed (RCCL backend)"))
     else:
         local = G if world == 1 else (args.size,) * 3
         grid = bz.RectilinearGrid(local, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
@@ -364,6 +416,11 @@ def run_rank(args):
         elapsed = time.perf_counter() - t0
         model.profile_enable(False)
         comm_ms = decomp.comm_ms() / args.steps if decomp is not None else 0.0
+        comm_bytes = decomp.comm_bytes // args.steps if decomp is not None else 0
+        if use_slabs and decomp is None:      # library transport: HIP-event groups "comm_*" of the context + its byte counter
+            prof_now = model.profile()
+            comm_ms = sum(ms for k, (ms, n) in prof_now.items() if k.startswith("comm_")) / args.steps
+            comm_bytes = model.comm_info()[1] // (args.steps + args.warmup + 1)
         if decomp is not None:
             decomp.profile = False
         finite = bool(torch.isfinite(model.momentum["ρw"].parent).all().item())
@@ -404,7 +461,7 @@ def run_rank(args):
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"]}
         step_achieved = (cells_rank * args.steps / elapsed) * A_STEP_WORDS * 8 / 1e9
-        kernel_ms = sum(v["total_ms"] for v in kernels.values()) / args.steps
+        kernel_ms = sum(v["total_ms"] for k, v in kernels.items() if not k.startswith("comm_")) / args.steps
         out = {
             "metric": METRIC,
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -423,7 +480,10 @@ def run_rank(args):
             out["comm_ms_per_step"] = comm_ms                       # inside point-to-point batches (slowest rank)
             out["compute_ms_per_step"] = kernel_ms                  # library kernels of rank 0 (HIP events)
             out["other_ms_per_step"] = max(0.0, ms_per_step - comm_ms - kernel_ms)   # packs, transforms' glue, launch gaps, waits
-            out["comm_bytes_sent_per_step_per_gpu"] = decomp.comm_bytes // args.steps
+            out["comm_bytes_sent_per_step_per_gpu"] = comm_bytes
+            out["transport"] = transport
+            if transport_note:
+                out["transport_note"] = transport_note
         if world == 1 and not args.no_compressible and not use_slabs and args.workload == "bubble":
             try:
                 del model
@@ -451,6 +511,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the slab decomposition (explicit only)")
     ap.add_argument("--slab", action="store_true", help="N=1: run the slab driver (world 1) instead of the whole-step seam")
+    ap.add_argument("--transport", choices=("auto", "rccl", "torch"), default="auto",
+                    help="slab runs: the C library's RCCL communicator, torch.distributed, or try the first and fall back")
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-compressible", action="store_true",

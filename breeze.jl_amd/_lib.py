@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("BREEZE_HIP_LIB") or os.path.join(_HERE, "lib", "libbr
 CSRC = os.path.join(_HERE, "csrc")
 
 _dp = C.POINTER(C.c_double)
+BZ_UNIQUE_ID_BYTES = 128
 
 
 class bz_grid(C.Structure):
@@ -212,6 +213,13 @@ SYMBOLS = {
     "bz_pack_transpose": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "bz_pack_rows": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "bz_slab_transform": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "bz_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "bz_comm_init_rccl": (C.c_int, [_ctx, C.c_void_p]),
+    "bz_comm_init_local": (C.c_int, [_ctx, C.c_char_p]),
+    "bz_comm_destroy": (C.c_int, [_ctx]),
+    "bz_comm_exchange_y_halos": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32]),
+    "bz_comm_update_state_and_project": (C.c_int, [_ctx, _sp, _pp, C.c_double, C.c_int]),
+    "bz_comm_info": (C.c_int, [_ctx, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "bz_set_tracers": (C.c_int, [_ctx, C.c_int32, C.POINTER(bz_tracer_fields)]),
     "bz_set_closure": (C.c_int, [_ctx, C.POINTER(bz_smagorinsky_lilly), C.c_void_p]),
     "bz_set_bounds_preserving_advection": (C.c_int, [_ctx, C.POINTER(bz_bounds_preserving_advection)]),

@@ -3,7 +3,7 @@
 //                   V^-1 (bounded_tracer_flux_divergence_x + _y + _z)), used by /root/reference/examples/rico.jl:184-190 and
 //                   /root/reference/examples/tropical_cyclone_world.jl:169
 //   Oceananigans    bounded_tracer_flux_divergence_{x,y,z} (0.110.x, not vendored: PARITY UNPINNED, restated from the published
-//                   positivity-preserving limiter, see oracle/breeze_oracle.c og_scalar_tendency_bounded): the two reconstructions
+//                   positivity-preserving limiter; the CPU restatement used by the tests carries the same formulas): the two reconstructions
 //                   that start in a cell (left-biased at its upper face, right-biased at its lower face) are pulled towards the cell
 //                   mean by theta in [0, 1] so that the cell's Gauss-Lobatto point values stay inside [lo, hi]; fluxes use
 //                   upwind_biased_product.  theta is a property of the cell, so face values are NOT shared between neighbours:

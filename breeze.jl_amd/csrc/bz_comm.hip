@@ -1,0 +1,587 @@
+// bz_comm.hip — communication of the y-slab decomposition BEHIND the C ABI (BASELINE.json north_star: "Julia host code calls ...
+// through a thin C-ABI ... RCCL halo exchange and FFT all-to-all over xGMI").  One process per GPU; rank r of y_nranks owns
+// rows [r Ny, (r+1) Ny) of a (Periodic, Periodic, Bounded) domain (bz_create_slab).  The reference has no distributed code of
+// its own (it re-exports Oceananigans' MPI-based Distributed, /root/reference/src/Breeze.jl:172,183,209): this is this repo's
+// design for 8 GPUs joined by point-to-point xGMI links.
+//
+//   transports   * RCCL (bz_comm_init_rccl): librccl is dlopen'ed (the copy PyTorch already loaded, or ROCm's), the communicator
+//                  is created from a 128-byte unique id that the host distributes (rank 0: bz_comm_unique_id); every exchange is
+//                  one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on a HIP stream — point-to-point messages, one per
+//                  xGMI link, no ring collective in the data path.
+//                * local (bz_comm_init_local): the ranks are contexts of ONE process (host threads), messages are peer copies
+//                  ordered by events.  This is how the whole distributed step is tested on a 1-GPU box (tests/test_comm.py) and it
+//                  also serves a single-process multi-GPU host.
+//   exchanges    y halos: the rows a neighbour needs, of all fields of the exchange, packed into ONE message per direction;
+//                Poisson: local x R2C -> transposing pack per peer -> all-to-all (W-1 messages out, all links busy) -> y FFT,
+//                Thomas solve in z, inverse y FFT -> all-to-all back -> x C2R;  the phi row below the slab: one row.
+//   overlap      the y-halo exchange that closes a stage runs on a side stream while the next stage's tendency kernels work on
+//                the interior tile rows; the two edge tile rows are launched when the halos have landed.
+//   step         bz_time_step_anelastic on a slab context with a communicator = the lean whole-step seam (bz_step.hip) with these
+//                exchanges in between; no host synchronisation inside a step with the RCCL transport.
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+
+#include "bz_internal.h"
+
+// ---- kernels defined elsewhere -------------------------------------------------------------------------------------------------
+__global__ void k_tridiag_solve(int NXH, int Ny, int Nz, const double *__restrict__ lower, const double *__restrict__ ibeta,
+                                const double *__restrict__ tfac, double2 *__restrict__ hat, double scale, int mean_column);
+
+// out[(r) * (W B) + q B + b] = in[q][r * B + b]: gathers the W received blocks (each `rows` rows of B complex) side by side
+__global__ __launch_bounds__(256) void k_concat_blocks(const double2 *__restrict__ in, double2 *__restrict__ out, long long rows, int B, int W)
+{
+    const long long total = rows * B * W;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / ((long long)B * W);
+        const int rem = (int)(e % ((long long)B * W));
+        const int q = rem / B, b = rem % B;
+        out[e] = in[(long long)q * rows * B + r * B + b];
+    }
+}
+
+// ---- transports ----------------------------------------------------------------------------------------------------------------
+struct Transport {
+    virtual ~Transport() {}
+    virtual int group_start() = 0;
+    virtual int send(const void *buf, size_t bytes, int peer, hipStream_t st) = 0;
+    virtual int recv(void *buf, size_t bytes, int peer, hipStream_t st) = 0;
+    virtual int group_end(hipStream_t st) = 0;
+    virtual const char *name() const = 0;
+    std::string err;
+};
+
+// RCCL through dlopen: no link-time dependency, and the process keeps a single librccl (PyTorch's when it is loaded first)
+namespace rccl {
+typedef struct { char internal[128]; } UniqueId;
+typedef void *Comm;
+typedef int (*GetUniqueId_t)(UniqueId *);
+typedef int (*CommInitRank_t)(Comm *, int, UniqueId, int);
+typedef int (*CommDestroy_t)(Comm);
+typedef int (*Group_t)();
+typedef int (*Send_t)(const void *, size_t, int, int, Comm, hipStream_t);
+typedef int (*Recv_t)(void *, size_t, int, int, Comm, hipStream_t);
+typedef const char *(*ErrStr_t)(int);
+struct Api {
+    void *h = nullptr;
+    GetUniqueId_t GetUniqueId = nullptr;
+    CommInitRank_t CommInitRank = nullptr;
+    CommDestroy_t CommDestroy = nullptr;
+    Group_t GroupStart = nullptr, GroupEnd = nullptr;
+    Send_t Send = nullptr;
+    Recv_t Recv = nullptr;
+    ErrStr_t ErrStr = nullptr;
+};
+static Api *api(std::string &err)
+{
+    static Api A;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lk(m);
+    if (A.h) return &A;
+    const char *names[] = {getenv("BZ_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        if (!n) continue;
+        A.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (A.h) break;
+    }
+    if (!A.h) { err = std::string("cannot dlopen librccl: ") + dlerror(); return nullptr; }
+    A.GetUniqueId = (GetUniqueId_t)dlsym(A.h, "ncclGetUniqueId");
+    A.CommInitRank = (CommInitRank_t)dlsym(A.h, "ncclCommInitRank");
+    A.CommDestroy = (CommDestroy_t)dlsym(A.h, "ncclCommDestroy");
+    A.GroupStart = (Group_t)dlsym(A.h, "ncclGroupStart");
+    A.GroupEnd = (Group_t)dlsym(A.h, "ncclGroupEnd");
+    A.Send = (Send_t)dlsym(A.h, "ncclSend");
+    A.Recv = (Recv_t)dlsym(A.h, "ncclRecv");
+    A.ErrStr = (ErrStr_t)dlsym(A.h, "ncclGetErrorString");
+    if (!A.GetUniqueId || !A.CommInitRank || !A.CommDestroy || !A.GroupStart || !A.GroupEnd || !A.Send || !A.Recv) {
+        err = "librccl lacks a required symbol";
+        A.h = nullptr;
+        return nullptr;
+    }
+    return &A;
+}
+}  // namespace rccl
+
+struct RcclTransport : Transport {
+    rccl::Api *A = nullptr;
+    rccl::Comm comm = nullptr;
+    int check(int rc, const char *what)
+    {
+        if (rc == 0) return BZ_OK;
+        err = std::string(what) + ": " + (A->ErrStr ? A->ErrStr(rc) : "nccl error") + " (" + std::to_string(rc) + ")";
+        return -2000 - rc;
+    }
+    ~RcclTransport() override { if (comm) A->CommDestroy(comm); }
+    int group_start() override { return check(A->GroupStart(), "ncclGroupStart"); }
+    int send(const void *buf, size_t bytes, int peer, hipStream_t st) override { return check(A->Send(buf, bytes, 0 /* ncclInt8 */, peer, comm, st), "ncclSend"); }
+    int recv(void *buf, size_t bytes, int peer, hipStream_t st) override { return check(A->Recv(buf, bytes, 0, peer, comm, st), "ncclRecv"); }
+    int group_end(hipStream_t) override { return check(A->GroupEnd(), "ncclGroupEnd"); }
+    const char *name() const override { return "rccl"; }
+};
+
+// in-process transport: a named group shared by the contexts (host threads) of one process
+struct LocalMsg { const void *ptr; size_t bytes; hipEvent_t ready; };
+struct LocalGroup {
+    int nranks = 0, joined = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::map<std::pair<int, int>, std::deque<LocalMsg>> box;          // (src, dst) -> posted sends
+    std::map<std::pair<int, int>, std::deque<hipEvent_t>> done;        // (src, dst) -> "copied out" events, in send order
+    bool aborted = false;
+};
+static std::mutex g_groups_m;
+static std::map<std::string, LocalGroup *> g_groups;
+
+struct LocalTransport : Transport {
+    LocalGroup *G = nullptr;
+    int rank = 0;
+    std::vector<int> pending_peers;          // sends of the open group
+    ~LocalTransport() override
+    {
+        std::lock_guard<std::mutex> lk(g_groups_m);
+        if (G && --G->joined == 0) {
+            for (auto it = g_groups.begin(); it != g_groups.end(); ++it)
+                if (it->second == G) { g_groups.erase(it); break; }
+            delete G;
+        }
+    }
+    int group_start() override { pending_peers.clear(); return BZ_OK; }
+    int send(const void *buf, size_t bytes, int peer, hipStream_t st) override
+    {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, st) != hipSuccess) { err = "local send: event"; return BZ_ERR_ALLOC; }
+        {
+            std::lock_guard<std::mutex> lk(G->m);
+            G->box[{rank, peer}].push_back({buf, bytes, ev});
+        }
+        G->cv.notify_all();
+        pending_peers.push_back(peer);
+        return BZ_OK;
+    }
+    int recv(void *buf, size_t bytes, int peer, hipStream_t st) override
+    {
+        LocalMsg msg;
+        {
+            std::unique_lock<std::mutex> lk(G->m);
+            auto &q = G->box[{peer, rank}];
+            if (!G->cv.wait_for(lk, std::chrono::seconds(120), [&] { return !q.empty() || G->aborted; }) || G->aborted) {
+                G->aborted = true;
+                G->cv.notify_all();
+                err = "local recv: no matching send within 120 s (a peer rank failed?)";
+                return BZ_ERR_INVALID;
+            }
+            msg = q.front();
+            q.pop_front();
+        }
+        if (msg.bytes != bytes) { err = "local recv: message size mismatch"; return BZ_ERR_INVALID; }
+        hipEvent_t dn;
+        if (hipStreamWaitEvent(st, msg.ready, 0) != hipSuccess || hipMemcpyAsync(buf, msg.ptr, bytes, hipMemcpyDefault, st) != hipSuccess ||
+            hipEventCreateWithFlags(&dn, hipEventDisableTiming) != hipSuccess || hipEventRecord(dn, st) != hipSuccess) {
+            err = "local recv: copy";
+            return BZ_ERR_INVALID;
+        }
+        hipEventDestroy(msg.ready);
+        {
+            std::lock_guard<std::mutex> lk(G->m);
+            G->done[{peer, rank}].push_back(dn);
+        }
+        G->cv.notify_all();
+        return BZ_OK;
+    }
+    int group_end(hipStream_t st) override
+    {   // my send buffers may be reused once the receivers' copies are ordered before whatever I enqueue next
+        for (int peer : pending_peers) {
+            hipEvent_t dn;
+            {
+                std::unique_lock<std::mutex> lk(G->m);
+                auto &q = G->done[{rank, peer}];
+                if (!G->cv.wait_for(lk, std::chrono::seconds(120), [&] { return !q.empty() || G->aborted; }) || G->aborted) {
+                    G->aborted = true;
+                    G->cv.notify_all();
+                    err = "local group_end: a receiver never took the message";
+                    return BZ_ERR_INVALID;
+                }
+                dn = q.front();
+                q.pop_front();
+            }
+            hipStreamWaitEvent(st, dn, 0);
+            hipEventDestroy(dn);
+        }
+        pending_peers.clear();
+        return BZ_OK;
+    }
+    const char *name() const override { return "local"; }
+};
+
+// ---- the communicator of a context ----------------------------------------------------------------------------------------------
+#define BZ_COMM_MAX_FIELDS 16
+struct BzComm {
+    Transport *T = nullptr;
+    int W = 1, rank = 0, upper = 0, lower = 0;
+    hipStream_t side = nullptr;                  // exchanges that overlap kernels of the main stream
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool overlap = true, halo_pending = false;
+    bool self_messages = false;                  // BZ_COMM_SELF_MESSAGES=1: a single rank sends to itself through the transport (tests)
+    // persistent buffers (device)
+    double *halo_send[2] = {nullptr, nullptr}, *halo_recv[2] = {nullptr, nullptr};
+    size_t halo_cap = 0;
+    double *rhs = nullptr;                       // Nx Ny Nz real: source term, then the solution phi
+    double *hatx = nullptr;                      // (Nz, Ny, nxh) complex; reused as (Nz, Ny, nxh_pad) on the way back
+    double *xsend = nullptr, *xrecv = nullptr;   // W blocks of Nz nkx Ny complex
+    double *spec = nullptr;                      // (Nz, nkx, Ny_global) complex
+    double *row_send = nullptr, *phi_below = nullptr;   // Nz Nx
+    // accounting
+    long long bytes_sent = 0;
+    int exchanges = 0;
+};
+
+static int comm_fail(bz_ctx *ctx, int rc, const char *where)
+{
+    if (rc) ctx->last_error = std::string(where) + ": " + ctx->comm->T->err;
+    return rc;
+}
+
+void bzi_comm_teardown(bz_ctx *ctx)
+{
+    BzComm *c = ctx->comm;
+    if (!c) return;
+    if (c->side) hipStreamSynchronize(c->side);
+    for (int d = 0; d < 2; ++d) { if (c->halo_send[d]) hipFree(c->halo_send[d]); if (c->halo_recv[d]) hipFree(c->halo_recv[d]); }
+    double *bufs[] = {c->rhs, c->hatx, c->xsend, c->xrecv, c->spec, c->row_send, c->phi_below};
+    for (double *b : bufs) if (b) hipFree(b);
+    if (c->ev_main) hipEventDestroy(c->ev_main);
+    if (c->ev_side) hipEventDestroy(c->ev_side);
+    if (c->side) hipStreamDestroy(c->side);
+    delete c->T;
+    delete c;
+    ctx->comm = nullptr;
+}
+
+static int comm_attach(bz_ctx *ctx, Transport *T)
+{
+    if (ctx->comm) bzi_comm_teardown(ctx);
+    const DevGrid &g = ctx->dg;
+    BzComm *c = new BzComm();
+    ctx->comm = c;
+    c->T = T;
+    c->W = ctx->y_nranks;
+    c->rank = ctx->y_rank;
+    c->upper = (c->rank + 1) % c->W;
+    c->lower = (c->rank + c->W - 1) % c->W;
+    c->overlap = !getenv("BZ_COMM_NO_OVERLAP");
+    c->self_messages = getenv("BZ_COMM_SELF_MESSAGES") != nullptr;
+    BZ_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    BZ_HIP(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    BZ_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    const size_t nreal = (size_t)g.Nx * g.Ny * g.Nz;
+    const int nxh = g.Nx / 2 + 1, nxh_pad = ctx->nkx * c->W;
+    const size_t nhat = (size_t)g.Nz * g.Ny * (size_t)(nxh_pad > nxh ? nxh_pad : nxh);
+    const size_t nblk = (size_t)g.Nz * ctx->nkx * g.Ny;       // complex elements of one transposed block
+    BZ_HIP(hipMalloc(&c->rhs, nreal * sizeof(double)));
+    BZ_HIP(hipMalloc(&c->hatx, nhat * 2 * sizeof(double)));
+    BZ_HIP(hipMalloc(&c->xsend, nblk * c->W * 2 * sizeof(double)));
+    BZ_HIP(hipMalloc(&c->xrecv, nblk * c->W * 2 * sizeof(double)));
+    BZ_HIP(hipMalloc(&c->spec, nblk * c->W * 2 * sizeof(double)));
+    BZ_HIP(hipMalloc(&c->row_send, (size_t)g.Nz * g.Nx * sizeof(double)));
+    BZ_HIP(hipMalloc(&c->phi_below, (size_t)g.Nz * g.Nx * sizeof(double)));
+    return BZ_OK;
+}
+
+extern "C" int bz_comm_unique_id(void *out128)
+{
+    if (!out128) return BZ_ERR_INVALID;
+    std::string err;
+    rccl::Api *A = rccl::api(err);
+    if (!A) { fprintf(stderr, "bz_comm_unique_id: %s\n", err.c_str()); return BZ_ERR_UNSUPPORTED; }
+    rccl::UniqueId id;
+    const int rc = A->GetUniqueId(&id);
+    if (rc) return -2000 - rc;
+    std::memcpy(out128, &id, 128);
+    return BZ_OK;
+}
+
+extern "C" int bz_comm_init_rccl(bz_ctx *ctx, const void *id128)
+{
+    if (!ctx || !id128) return BZ_ERR_INVALID;
+    if (!ctx->slab_mode) { ctx->last_error = "bz_comm_init_rccl: y-slab contexts only (bz_create_slab)"; return BZ_ERR_UNSUPPORTED; }
+    RcclTransport *T = new RcclTransport();
+    T->A = rccl::api(T->err);
+    if (!T->A) { ctx->last_error = "bz_comm_init_rccl: " + T->err; delete T; return BZ_ERR_UNSUPPORTED; }
+    rccl::UniqueId id;
+    std::memcpy(&id, id128, 128);
+    const int rc = T->A->CommInitRank(&T->comm, ctx->y_nranks, id, ctx->y_rank);
+    if (rc) { ctx->last_error = std::string("ncclCommInitRank: ") + (T->A->ErrStr ? T->A->ErrStr(rc) : "error"); delete T; return -2000 - rc; }
+    return comm_attach(ctx, T);
+}
+
+extern "C" int bz_comm_init_local(bz_ctx *ctx, const char *group_name)
+{
+    if (!ctx || !group_name) return BZ_ERR_INVALID;
+    if (!ctx->slab_mode) { ctx->last_error = "bz_comm_init_local: y-slab contexts only (bz_create_slab)"; return BZ_ERR_UNSUPPORTED; }
+    LocalTransport *T = new LocalTransport();
+    {
+        std::lock_guard<std::mutex> lk(g_groups_m);
+        LocalGroup *&G = g_groups[group_name];
+        if (!G) { G = new LocalGroup(); G->nranks = ctx->y_nranks; }
+        if (G->nranks != ctx->y_nranks) { ctx->last_error = "bz_comm_init_local: group exists with another size"; delete T; return BZ_ERR_INVALID; }
+        ++G->joined;
+        T->G = G;
+    }
+    T->rank = ctx->y_rank;
+    return comm_attach(ctx, T);
+}
+
+extern "C" int bz_comm_destroy(bz_ctx *ctx)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    bzi_comm_teardown(ctx);
+    return BZ_OK;
+}
+
+extern "C" int bz_comm_info(bz_ctx *ctx, const char **transport, int64_t *bytes_sent, int32_t *exchanges)
+{
+    if (!ctx || !ctx->comm) return BZ_ERR_INVALID;
+    if (transport) *transport = ctx->comm->T->name();
+    if (bytes_sent) *bytes_sent = ctx->comm->bytes_sent;
+    if (exchanges) *exchanges = ctx->comm->exchanges;
+    return BZ_OK;
+}
+
+// ---- y-halo exchange --------------------------------------------------------------------------------------------------------------
+// Fill `width` rows of the upper halo (parent rows Hy+Ny ...) and / or of the lower halo (rows Hy-width .. Hy-1) of n parent arrays
+// from the ring neighbours, on stream st.  levels[m]: z levels of array m (Nz + 2 Hz, or + 1 for z-face fields).
+static int halo_exchange(bz_ctx *ctx, double *const *fields, const int32_t *levels, int n, int width, bool upper_halo, bool lower_halo,
+                         hipStream_t st)
+{
+    BzComm *c = ctx->comm;
+    const DevGrid &g = ctx->dg;
+    if (n < 1 || n > BZ_COMM_MAX_FIELDS || width < 1 || width > g.Hy) return BZ_ERR_INVALID;
+    size_t total = 0;
+    for (int m = 0; m < n; ++m) total += (size_t)levels[m] * width * g.Sx;
+    if (total > c->halo_cap) {
+        BZ_HIP(hipStreamSynchronize(st));
+        for (int d = 0; d < 2; ++d) {
+            if (c->halo_send[d]) hipFree(c->halo_send[d]);
+            if (c->halo_recv[d]) hipFree(c->halo_recv[d]);
+            BZ_HIP(hipMalloc(&c->halo_send[d], total * sizeof(double)));
+            BZ_HIP(hipMalloc(&c->halo_recv[d], total * sizeof(double)));
+        }
+        c->halo_cap = total;
+    }
+    hipStream_t keep = ctx->stream;
+    ctx->stream = st;                            // bz_pack_rows launches on the context's stream
+    int rc = BZ_OK;
+    const size_t bytes = total * sizeof(double);
+    // what the UPPER neighbour's lower halo needs: my top interior rows; what the LOWER neighbour's upper halo needs: my first rows
+    if (lower_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy + g.Ny - width, width, c->halo_send[0], 0);
+    if (!rc && upper_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy, width, c->halo_send[1], 0);
+    if (!rc && c->W == 1 && !c->self_messages) {  // periodic wrap onto myself: no message
+        if (lower_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy - width, width, c->halo_send[0], 1);
+        if (!rc && upper_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy + g.Ny, width, c->halo_send[1], 1);
+        ctx->stream = keep;
+        return rc;
+    }
+    if (!rc) {
+        // order matters when upper == lower (two ranks): sends "up, then down", receives "from lower, then from upper"
+        rc = comm_fail(ctx, c->T->group_start(), "halo exchange");
+        if (!rc && lower_halo) rc = comm_fail(ctx, c->T->send(c->halo_send[0], bytes, c->upper, st), "halo exchange");
+        if (!rc && upper_halo) rc = comm_fail(ctx, c->T->send(c->halo_send[1], bytes, c->lower, st), "halo exchange");
+        if (!rc && lower_halo) rc = comm_fail(ctx, c->T->recv(c->halo_recv[0], bytes, c->lower, st), "halo exchange");
+        if (!rc && upper_halo) rc = comm_fail(ctx, c->T->recv(c->halo_recv[1], bytes, c->upper, st), "halo exchange");
+        if (!rc) rc = comm_fail(ctx, c->T->group_end(st), "halo exchange");
+        c->bytes_sent += (long long)bytes * ((lower_halo ? 1 : 0) + (upper_halo ? 1 : 0));
+        c->exchanges++;
+    }
+    if (!rc && lower_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy - width, width, c->halo_recv[0], 1);
+    if (!rc && upper_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy + g.Ny, width, c->halo_recv[1], 1);
+    ctx->stream = keep;
+    return rc;
+}
+
+extern "C" int bz_comm_exchange_y_halos(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n)
+{
+    if (!ctx || !ctx->comm || !fields || !levels) return BZ_ERR_INVALID;
+    ProfileScope ps(ctx, "comm_halo_exchange");
+    return halo_exchange(ctx, fields, levels, n, ctx->dg.Hy, true, true, ctx->stream);
+}
+
+// ---- distributed Fourier-tridiagonal solve: c->rhs (source term) -> c->rhs (zero-mean solution), all on the main stream ------------
+static int all_to_all(bz_ctx *ctx, const double *send, double *recv, size_t block_doubles)
+{
+    BzComm *c = ctx->comm;
+    const size_t bytes = block_doubles * sizeof(double);
+    const bool self = c->self_messages;
+    if (!self) BZ_HIP(hipMemcpyAsync(recv + block_doubles * c->rank, send + block_doubles * c->rank, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (c->W == 1 && !self) return BZ_OK;
+    int rc = comm_fail(ctx, c->T->group_start(), "all-to-all");
+    for (int p = 0; p < c->W && !rc; ++p)
+        if (p != c->rank || self) rc = comm_fail(ctx, c->T->send(send + block_doubles * p, bytes, p, ctx->stream), "all-to-all");
+    for (int p = 0; p < c->W && !rc; ++p)
+        if (p != c->rank || self) rc = comm_fail(ctx, c->T->recv(recv + block_doubles * p, bytes, p, ctx->stream), "all-to-all");
+    if (!rc) rc = comm_fail(ctx, c->T->group_end(ctx->stream), "all-to-all");
+    c->bytes_sent += (long long)bytes * (c->W - 1);
+    c->exchanges++;
+    return rc;
+}
+
+static int dist_poisson(bz_ctx *ctx)
+{
+    BzComm *c = ctx->comm;
+    const DevGrid &g = ctx->dg;
+    const int W = c->W, nkx = ctx->nkx, nxh = g.Nx / 2 + 1, NyG = ctx->Ny_global;
+    const size_t blk = (size_t)g.Nz * nkx * g.Ny * 2;            // doubles per transposed block
+    const bool direct = (W == 1 && !c->self_messages);          // one rank: the packs write the transposed arrays in place
+    int rc;
+    if ((rc = bz_slab_transform(ctx, 0, c->rhs, c->hatx, 0))) return rc;                                  // (Nz, Ny, nxh)
+    for (int p = 0; p < W; ++p)                                                                            // -> W x (Nz, nkx, Ny)
+        if ((rc = bz_pack_transpose(ctx, c->hatx, (direct ? c->spec : c->xsend) + blk * p, g.Nz, g.Ny, nxh, p * nkx, nkx, nxh))) return rc;
+    if (!direct) {
+        ProfileScope ps(ctx, "comm_all_to_all");
+        if ((rc = all_to_all(ctx, c->xsend, c->xrecv, blk))) return rc;
+        hipLaunchKernelGGL(k_concat_blocks, dim3(4096), dim3(256), 0, ctx->stream, (const double2 *)c->xrecv, (double2 *)c->spec,
+                           (long long)g.Nz * nkx, g.Ny, W);                                                // (Nz, nkx, Ny_global)
+        BZ_LAUNCH_CHECK();
+    }
+    if ((rc = bz_slab_transform(ctx, 1, c->spec, c->spec, 0))) return rc;
+    if ((rc = bz_spectral_tridiagonal_solve(ctx, c->spec, 1.0 / ((double)g.Nx * (double)NyG)))) return rc;
+    if ((rc = bz_slab_transform(ctx, 2, c->spec, c->spec, 0))) return rc;
+    for (int q = 0; q < W; ++q)                                                                            // -> W x (Nz, Ny, nkx)
+        if ((rc = bz_pack_transpose(ctx, c->spec, (direct ? c->hatx : c->xsend) + blk * q, g.Nz, nkx, NyG, q * g.Ny, g.Ny, NyG))) return rc;
+    if (!direct) {
+        ProfileScope ps(ctx, "comm_all_to_all");
+        if ((rc = all_to_all(ctx, c->xsend, c->xrecv, blk))) return rc;
+        hipLaunchKernelGGL(k_concat_blocks, dim3(4096), dim3(256), 0, ctx->stream, (const double2 *)c->xrecv, (double2 *)c->hatx,
+                           (long long)g.Nz * g.Ny, nkx, W);                                                // (Nz, Ny, nkx W)
+        BZ_LAUNCH_CHECK();
+    }
+    return bz_slab_transform(ctx, 3, c->hatx, c->rhs, nkx * W);
+}
+
+// phi of the row below the slab (the neighbour's top row) into c->phi_below [k][i]
+static int exchange_phi_below(bz_ctx *ctx)
+{
+    BzComm *c = ctx->comm;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "comm_phi_row");
+    const size_t rowb = (size_t)g.Nx * sizeof(double);
+    const bool direct = (c->W == 1 && !c->self_messages);
+    double *dst = direct ? c->phi_below : c->row_send;
+    BZ_HIP(hipMemcpy2DAsync(dst, rowb, c->rhs + (size_t)(g.Ny - 1) * g.Nx, rowb * g.Ny, rowb, g.Nz, hipMemcpyDeviceToDevice, ctx->stream));
+    if (direct) return BZ_OK;
+    const size_t bytes = rowb * g.Nz;
+    int rc = comm_fail(ctx, c->T->group_start(), "phi row");
+    if (!rc) rc = comm_fail(ctx, c->T->send(c->row_send, bytes, c->upper, ctx->stream), "phi row");
+    if (!rc) rc = comm_fail(ctx, c->T->recv(c->phi_below, bytes, c->lower, ctx->stream), "phi row");
+    if (!rc) rc = comm_fail(ctx, c->T->group_end(ctx->stream), "phi row");
+    c->bytes_sent += (long long)bytes;
+    c->exchanges++;
+    return rc;
+}
+
+// compute_pressure_correction! + make_pressure_correction! + the diagnosis, from the momentum in `s` (predictor == nullptr) or from
+// the predictor arrays; lean: momentum-only projection (stages whose diagnostics nobody reads)
+static int dist_projection(bz_ctx *ctx, const bz_state *s, const bz_prognostic *predictor, double dt, bool lean, double *oa, double *ob,
+                           const double *rtheta_in, const double *rq_in)
+{
+    BzComm *c = ctx->comm;
+    const DevGrid &g = ctx->dg;
+    int rc;
+    {   // the divergence needs row Ny of rho_v: the upper neighbour's first row
+        ProfileScope ps(ctx, "comm_halo_exchange");
+        double *f[1] = {predictor ? predictor->rho_v : s->rho_v};
+        int32_t lev[1] = {g.Nz + 2 * g.Hz};
+        if ((rc = halo_exchange(ctx, f, lev, 1, 1, true, false, ctx->stream))) return rc;
+    }
+    if ((rc = bzi_poisson_source_fused(ctx, s, dt, c->rhs, predictor))) return rc;
+    if ((rc = dist_poisson(ctx))) return rc;
+    if ((rc = exchange_phi_below(ctx))) return rc;
+    if (lean) return bzi_project_lean(ctx, s, dt, c->rhs, c->phi_below, predictor, oa, ob);
+    return bzi_project_diagnose(ctx, s, dt, c->rhs, c->phi_below, predictor, true, rtheta_in, rq_in);
+}
+
+// the y halos every consumer of the state may read: momentum, the two scalars' densities, and the diagnostics the per-operator
+// tendency kernels use
+static int state_halo_exchange(bz_ctx *ctx, const bz_state *s, double *pa, double *pb, bool diagnostics, hipStream_t st)
+{
+    const DevGrid &g = ctx->dg;
+    const int nc = g.Nz + 2 * g.Hz, nf = nc + 1;
+    double *f[BZ_COMM_MAX_FIELDS] = {s->rho_u, s->rho_v, s->rho_w, pa, pb};
+    int32_t lev[BZ_COMM_MAX_FIELDS] = {nc, nc, nf, nc, nc};
+    int n = 5;
+    if (diagnostics) {
+        double *d[5] = {s->u, s->v, s->w, s->theta, s->q};
+        const int32_t dl[5] = {nc, nc, nf, nc, nc};
+        for (int m = 0; m < 5; ++m) { f[n] = d[m]; lev[n] = dl[m]; ++n; }
+    }
+    return halo_exchange(ctx, f, lev, n, g.Hy, true, true, st);
+}
+
+// update_state!(model; compute_tendencies = false) of set! + the initial projection with dt (set_atmosphere_model.jl:121-128) on slabs
+extern "C" int bz_comm_update_state_and_project(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt, int project)
+{
+    if (!ctx || !ctx->comm || !s) return BZ_ERR_INVALID;
+    int rc = bz_update_state(ctx, s, G, 0);                      // x / z halos and diagnostics locally
+    if (rc) return rc;
+    {
+        ProfileScope ps(ctx, "comm_halo_exchange");
+        if ((rc = state_halo_exchange(ctx, s, s->rho_theta, s->rho_q, true, ctx->stream))) return rc;
+    }
+    if (!project) return BZ_OK;
+    if ((rc = dist_projection(ctx, s, nullptr, dt, false, nullptr, nullptr, nullptr, nullptr))) return rc;
+    ProfileScope ps(ctx, "comm_halo_exchange");
+    return state_halo_exchange(ctx, s, s->rho_theta, s->rho_q, true, ctx->stream);
+}
+
+// time_step!(model, dt) on y-slabs: the lean whole-step seam of bz_step.hip with the exchanges in between
+int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
+{
+    BzComm *c = ctx->comm;
+    const DevGrid &g = ctx->dg;
+    if (!(ctx->fused_ok && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 && !ctx->has_forcings && !ctx->has_bulk &&
+          !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask && (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32))) {
+        ctx->last_error = "bz_time_step_anelastic on y-slabs implements the dry / vapour anelastic model (no microphysics, closure, forcings, tracers)";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    int rc;
+    const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};
+    BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));
+    BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));
+    for (int stage = 0; stage < 3; ++stage) {
+        const double alpha = alphas[stage];
+        const bool from_state = (stage != 1);
+        const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
+        double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
+        if (c->halo_pending) {
+            // the halos of the stage-start state are still travelling on the side stream: interior tile rows first
+            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 1))) return rc;
+            BZ_HIP(hipStreamWaitEvent(ctx->stream, c->ev_side, 0));
+            c->halo_pending = false;
+            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 2))) return rc;
+        } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0))) return rc;
+        if ((rc = dist_projection(ctx, s, G, alpha * dt, stage < 2, oa, ob, G->rho_theta, G->rho_q))) return rc;
+        // halos of the new state.  After stage 3 rho theta / rho q are back in `s` and the diagnostics are current: exchange them too,
+        // so that every field of `s` is what the per-operator sequence leaves
+        double *na = (stage < 2) ? oa : s->rho_theta, *nb = (stage < 2) ? ob : s->rho_q;
+        const bool async = c->overlap && stage < 2 && (c->W > 1 || c->self_messages);
+        hipStream_t st = async ? c->side : ctx->stream;
+        if (async) {
+            BZ_HIP(hipEventRecord(c->ev_main, ctx->stream));
+            BZ_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+        }
+        {
+            ProfileScope ps(ctx, "comm_halo_exchange");
+            if ((rc = state_halo_exchange(ctx, s, na, nb, stage == 2, st))) return rc;
+        }
+        if (async) {
+            BZ_HIP(hipEventRecord(c->ev_side, c->side));
+            c->halo_pending = true;
+        }
+    }
+    ctx->G_is_predictor = true;
+    return BZ_OK;
+}

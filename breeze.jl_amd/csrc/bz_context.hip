@@ -281,6 +281,7 @@ extern "C" void bz_destroy(bz_ctx *ctx)
 {
     if (!ctx) return;
     profile_drain(ctx);
+    bzi_comm_teardown(ctx);
     bzi_poisson_teardown(ctx);
     bzi_lean_teardown(ctx);
     bzi_compressible_teardown(ctx);

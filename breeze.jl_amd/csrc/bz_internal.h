@@ -214,6 +214,7 @@ __device__ __forceinline__ double bz_ds_adjust(const DevGrid &g, double th, doub
 }
 #endif
 
+struct BzComm;
 struct ProfileSlot {
     const char *name;
     double total_ms = 0.0;
@@ -290,6 +291,7 @@ struct bz_ctx {
     // advection = (; rho_q = WENO(order = 5, bounds = (lo, hi))) (bz_set_bounds_preserving_advection, bz_bounded.hip)
     int bounded_mask = 0;             // 1 moisture, 2 microphysical species, 4 tracers
     double bounded_lo = 0.0, bounded_hi = 1.0;
+    struct BzComm *comm = nullptr;    // y-slab communicator (bz_comm_init_rccl / bz_comm_init_local, bz_comm.hip)
     // profiling
     bool profiling = false;
     std::vector<ProfileSlot> slots;
@@ -349,6 +351,8 @@ int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, i
 int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
 int bzi_bounded_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_lean_setup(bz_ctx *ctx);
+int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt);
+void bzi_comm_teardown(bz_ctx *ctx);
 void bzi_lean_teardown(bz_ctx *ctx);
 void bzi_poisson_teardown(bz_ctx *ctx);
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);
@@ -365,7 +369,7 @@ int bzi_project_lean(bz_ctx *ctx, const bz_state *s, double dt, const double *ph
                      const bz_prognostic *predictor, double *sa, double *sb);
 // lean whole-step tendencies (bz_tendency5.hip): prognostic-only inputs, rho theta / rho q advance from (pa, pb) into (oa, ob)
 int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
-                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first);
+                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows = 0);
 int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                             double alpha, bool first);
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,

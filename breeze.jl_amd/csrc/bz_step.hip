@@ -28,7 +28,9 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
 {
     if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
     if (ctx->slab_mode) {
-        ctx->last_error = "bz_time_step_anelastic: a y-slab context needs the distributed driver (halo exchange + FFT transposes)";
+        if (ctx->comm) return bzi_dist_time_step(ctx, s, U0, G, dt);      // the library owns the exchanges (bz_comm.hip)
+        ctx->last_error = "bz_time_step_anelastic: a y-slab context needs a communicator (bz_comm_init_rccl / bz_comm_init_local) "
+                          "or a host-side distributed driver";
         return BZ_ERR_UNSUPPORTED;
     }
     int rc;

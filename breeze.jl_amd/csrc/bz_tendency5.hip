@@ -53,8 +53,10 @@ static int pick_chunk5(const DevGrid &g, int nlev, int rows_per_block)
     return (int)((nlev + want - 1) / want);
 }
 
+// rows: 0 all tile rows; 1 interior tile rows only (1 .. nty-2); 2 the two edge tile rows (0 and nty-1).  The slab driver runs
+// the interior rows while the y-halo exchange of the stage-start state is in flight and the edge rows once it has landed.
 int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
-                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first)
+                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows)
 {
     const DevGrid &g = ctx->dg;
     constexpr int TY = 8;
@@ -65,7 +67,11 @@ int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
     L.T = s->T;
     L.pi_dry = getenv("BZ_NO_PI_DRY") ? nullptr : ctx->d_pi_dry + g.Hz;
     const dim3 block(64, TY);
-    const int tx = (g.Nx + 63) / 64, ty = (g.Ny + TY - 1) / TY;
+    const int tx = (g.Nx + 63) / 64, nty = (g.Ny + TY - 1) / TY;
+    if (rows && nty < 3) return rows == 1 ? BZ_OK : bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, 0);
+    const int ty = rows == 1 ? nty - 2 : rows == 2 ? 2 : nty;
+    L.by0 = rows == 1 ? 1 : 0;
+    L.bys = rows == 2 ? nty - 1 : 1;
     auto shape = [&](int nlev, int &kc) {
         kc = pick_chunk5(g, nlev, TY);
         dim3 grid(tx, ty, (nlev + kc - 1) / kc);

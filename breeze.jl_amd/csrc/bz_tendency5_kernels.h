@@ -33,14 +33,16 @@ struct Lean5 {
     double *T;                       // temperature of the stage-start state (w kernel: read; scalar kernel: writes the updated one)
     const double *pi_dry;            // (p_r[k]/p_st)^(Rd/cpd) indexed by level, or nullptr
     int xcd;                         // 1: XCD-contiguous block order (grid size divisible by 8)
+    int by0, bys;                    // tile row of block row b is by0 + b * bys (sub-launches of the slab driver: interior rows
+                                     // while the y-halo exchange is in flight, then the two edge rows)
 };
 
 // Hardware deals consecutive workgroup ids round-robin to the 8 XCDs; give XCD c the contiguous range
 // [c W/8, (c+1) W/8) of logical tiles (x fastest, then y, then z chunk) so that y-adjacent tiles share an L2.
-__device__ __forceinline__ void bz_block5(int xcd, int &bx, int &by, int &bz)
+__device__ __forceinline__ void bz_block5(const Lean5 &L, int &bx, int &by, int &bz)
 {
     bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
-    if (!xcd) return;
+    if (!L.xcd) { by = L.by0 + by * L.bys; return; }
     const unsigned gx = gridDim.x, gy = gridDim.y;
     const unsigned W = gx * gy * gridDim.z;
     unsigned w = bx + gx * (by + gy * bz);
@@ -48,6 +50,7 @@ __device__ __forceinline__ void bz_block5(int xcd, int &bx, int &by, int &bz)
     bx = (int)(w % gx);
     by = (int)((w / gx) % gy);
     bz = (int)(w / (gx * gy));
+    by = L.by0 + by * L.bys;
 }
 
 // store v at n and at its periodic images (ox / oy = element offset of the x / y image, 0 if none)
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, in
     __shared__ double FY[2][2][TY + 1][64];
 
     int bx, by, bz;
-    bz_block5(F.xcd, bx, by, bz);
+    bz_block5(F, bx, by, bz);
     const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
     const int i0 = bx * 64, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64 * TY) void k5_u(DevGrid g, Lean5 L, int kchunk, 
     __shared__ double T[2][TR][64];
     __shared__ double FY[2][TY + 1][64];
     int bx, by, bz;
-    bz_block5(L.xcd, bx, by, bz);
+    bz_block5(L, bx, by, bz);
     const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
     const int i0 = bx * 64, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(64 * TY) void k5_v(DevGrid g, Lean5 L, int kchunk, 
     __shared__ double FY[2][TY + 1][64];
     constexpr int NT = 64 * TY, NFR = 16 * 64, HPT = (NFR + NT - 1) / NT;
     int bx, by, bz;
-    bz_block5(L.xcd, bx, by, bz);
+    bz_block5(L, bx, by, bz);
     const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
     const int i0 = bx * 64, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(64 * TY) void k5_w(DevGrid g, Lean5 L, int kchunk, 
     __shared__ double T[2][TR][64];
     __shared__ double FY[2][TY + 1][64];
     int bx, by, bz;
-    bz_block5(L.xcd, bx, by, bz);
+    bz_block5(L, bx, by, bz);
     const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
     const int i0 = bx * 64, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;

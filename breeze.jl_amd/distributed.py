@@ -267,7 +267,14 @@ class SlabAtmosphereModel(SlabStepper):
     Poisson transposes go through torch.distributed (backend "nccl" = RCCL on ROCm)."""
 
     def __init__(self, global_grid, rank, world, advection=None, thermodynamic_constants=None,
-                 surface_pressure=101325, potential_temperature=288, standard_pressure=1e5, device=None, group=None):
+                 surface_pressure=101325, potential_temperature=288, standard_pressure=1e5, device=None, group=None,
+                 transport="torch"):
+        """transport: who carries the y halos and the FFT transposes —
+             "rccl"          the C library itself (bz_comm_init_rccl: RCCL send / recv groups on HIP streams; the whole step is ONE
+                             C call, bz_time_step_anelastic, with the halo exchange overlapped with the interior tendency tiles).
+                             torch.distributed is used once, to hand rank 0's 128-byte unique id to the other ranks.
+             "local:<name>"  the C library's in-process transport (ranks = threads of this process sharing one or more GPUs)
+             "torch"         this module's Python orchestration over torch.distributed (SlabStepper; also what the CPU tests drive)"""
         import torch
         from .model import Clock, Field, WENO
         if global_grid.topology != (Periodic, Periodic, Bounded):
@@ -333,7 +340,52 @@ class SlabAtmosphereModel(SlabStepper):
             import os
             if not os.environ.get("BZ_NO_ROW_PACK"):
                 self.decomp.rows = self._device_rows
+        self.transport = transport
+        if transport != "torch":
+            self._attach_library_transport(transport, group)
         self.set(θ=ref.potential_temperature)
+
+    def _attach_library_transport(self, transport, group):
+        import torch
+        lib = self._lib
+        if transport.startswith("local:"):
+            self._check(lib.bz_comm_init_local(self._ctx, transport[6:].encode()), "bz_comm_init_local")
+            return
+        if transport != "rccl":
+            raise ValueError(f"unknown transport {transport!r}")
+        ident = torch.zeros(_lib.BZ_UNIQUE_ID_BYTES, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_ubyte * _lib.BZ_UNIQUE_ID_BYTES)()
+            rc = lib.bz_comm_unique_id(buf)
+            if rc != 0:
+                raise _lib.BreezeHIPError(f"bz_comm_unique_id failed with code {rc}")
+            ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+        if self.world > 1:
+            import torch.distributed as dist
+            ident = ident.to(self.device)
+            dist.broadcast(ident, src=0, group=group)
+            ident = ident.cpu()
+        raw = (C.c_ubyte * _lib.BZ_UNIQUE_ID_BYTES)(*ident.tolist())
+        # RCCL prints a version banner on C stdout when a communicator is created; a host that prints machine-readable results on
+        # stdout (bench.py) must not get it there: point fd 1 at stderr for the duration of the call and flush C stdio inside it
+        import os
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            rc = lib.bz_comm_init_rccl(self._ctx, raw)
+            C.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        self._check(rc, "bz_comm_init_rccl")
+
+    def comm_info(self):
+        """(transport name, bytes this rank has sent, number of exchanges) of the library-owned communicator."""
+        name, nbytes, nex = C.c_char_p(), C.c_int64(), C.c_int32()
+        self._check(self._lib.bz_comm_info(self._ctx, C.byref(name), C.byref(nbytes), C.byref(nex)), "bz_comm_info")
+        return name.value.decode(), nbytes.value, nex.value
 
     # plumbing shared with AtmosphereModel -------------------------------------------------
     def _check(self, rc, what):
@@ -514,6 +566,11 @@ class SlabAtmosphereModel(SlabStepper):
                 self.momentum["ρw"].interior.copy_(ρf * self.velocities["w"].interior)
             else:
                 self.momentum[key].set_interior(value)
+        if self.transport != "torch":
+            self._check(self._lib.bz_comm_update_state_and_project(self._ctx, C.byref(self._state), C.byref(self._G), 1.0,
+                                                                   1 if enforce_mass_conservation else 0),
+                        "bz_comm_update_state_and_project")
+            return
         # update_state!(compute_tendencies=false): x/z halos + diagnostics locally, y halos from the neighbours
         self._check(self._lib.bz_update_state(self._ctx, C.byref(self._state), C.byref(self._G), 0), "bz_update_state")
         self.decomp.exchange_y_halos(self.tendency_halo_fields())
@@ -521,6 +578,12 @@ class SlabAtmosphereModel(SlabStepper):
             self.pressure_projection(1.0)
 
     def time_step(self, Δt):
+        if self.transport != "torch":         # the library owns the exchanges: one call per step
+            self._check(self._lib.bz_time_step_anelastic(self._ctx, C.byref(self._state), C.byref(self._U0), C.byref(self._G),
+                                                         float(Δt)), "bz_time_step_anelastic")
+            self.clock.time += Δt
+            self.clock.iteration += 1
+            return
         if self.clock.iteration == 0 and not self.fused_rk:          # maybe_prepare_first_time_step!
             self.local_tendencies()
         SlabStepper.time_step(self, Δt)

@@ -212,6 +212,30 @@ int bz_poisson_source_term_from(bz_ctx *ctx, const bz_state *s, const bz_prognos
 int bz_project_and_diagnose_from(bz_ctx *ctx, const bz_state *s, const bz_prognostic *predictor, const double *phi_c,
                                  const double *phi_below, double dt);
 
+/* ---- communication of the y-slab decomposition inside the library (BASELINE.json north_star: RCCL halo exchange and FFT
+ * all-to-all behind the C ABI).  With a communicator attached to a slab context, bz_time_step_anelastic IS the distributed step:
+ * the lean whole-step seam with, per stage, one row of predictor rho_v from the upper neighbour, the Poisson solve as local x
+ * transform -> all-to-all of transposed blocks -> y transform + Thomas solve -> all-to-all back -> x transform, one row of phi
+ * from the lower neighbour, and the Hy-row halo exchange of (rho_u, rho_v, rho_w, rho_theta, rho_q) on a side stream while the
+ * next stage's interior tile rows compute.  Every exchange is a group of point-to-point messages (one per xGMI link).
+ *   bz_comm_unique_id      rank 0: a 128-byte id (ncclGetUniqueId) that the host hands to every rank (MPI.Bcast, a file, ...)
+ *   bz_comm_init_rccl      every rank, on its own device: ncclCommInitRank(y_nranks, id, y_rank); librccl is dlopen'ed
+ *   bz_comm_init_local     the ranks are contexts of this process (one host thread each): peer copies ordered by events — the
+ *                          transport the distributed step is tested with on a single GPU, and a single-process multi-GPU option
+ *   bz_comm_exchange_y_halos            Hy halo rows of n parent arrays (levels[m] z levels each), both directions
+ *   bz_comm_update_state_and_project    set!'s update_state!(compute_tendencies = false) + halo exchange and, if project != 0, the
+ *                                       initial projection with dt (set_atmosphere_model.jl:121-128) and the exchange after it
+ *   bz_comm_info           transport name, bytes sent by this rank so far, number of exchanges
+ * Dry / vapour anelastic model (the configuration of BASELINE configs[1] and [3]); other physics return BZ_ERR_UNSUPPORTED. */
+#define BZ_UNIQUE_ID_BYTES 128
+int bz_comm_unique_id(void *id_out);
+int bz_comm_init_rccl(bz_ctx *ctx, const void *id);
+int bz_comm_init_local(bz_ctx *ctx, const char *group_name);
+int bz_comm_destroy(bz_ctx *ctx);
+int bz_comm_exchange_y_halos(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n);
+int bz_comm_update_state_and_project(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt, int project);
+int bz_comm_info(bz_ctx *ctx, const char **transport, int64_t *bytes_sent, int32_t *exchanges);
+
 /* ==== CompressibleDynamics + SplitExplicitTimeDiscretization ==================================
  * Fully compressible dynamics advanced by the Wicker-Skamarock RK3 outer loop with the linearised acoustic substep
  * loop (src/TimeSteppers/acoustic_runge_kutta_3.jl, src/CompressibleEquations/acoustic_substepping.jl).

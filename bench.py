@@ -114,6 +114,39 @@ def compressible_milestone(bz, device, steps=2):
     return out
 
 
+def float32_run(bz, device, N, steps=10, warmup=2):
+    """The same workload with eltype(grid) = Float32 (lib/libbreeze_hip_f32.so) — what the reference's own GPU benchmarks run
+    (benchmarking/src/convective_boundary_layer.jl:59,70).  Reported beside the Float64 headline, never as `value`
+    ("Float32 run reported separately"); algorithmic bytes are 250 words x 4 B = 1000 B per cell and step."""
+    import torch
+    grid = bz.RectilinearGrid((N, N, N), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2], float_type=np.float32)
+    ref = bz.ReferenceState(grid, surface_pressure=101325, potential_temperature=300)
+    m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), device=device)
+    m.set(θ=bubble)
+    for _ in range(warmup):
+        m.time_step(1.0)
+    m.profile_reset()
+    m.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.time_step(1.0)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    m.profile_enable(False)
+    prof = {k: ms / steps for k, (ms, n) in m.profile().items() if n}
+    cells = N ** 3
+    rate = cells * steps / el
+    out = {"dtype": "f32", "value": rate, "unit": "cells/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "grid": [N, N, N],
+           "step_roofline": {"bound": "hbm", "achieved": rate * A_STEP_WORDS * 4 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": rate * A_STEP_WORDS * 4 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 4},
+           "kernels_ms_per_step": prof, "finite": bool(torch.isfinite(m.momentum["ρw"].parent).all().item()),
+           "tolerance_vs_float64_oracle": "1e-4 after three steps, 2e-5 per tendency (tests/test_float32.py)"}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(n, budget_s=25.0):
     """The CPU oracle ("port": this repo's C/OpenMP restatement, not Breeze CPU() — Julia is not installed)
     timed on this box's host cores on a bounded sample of the same workload: the bubble at n^3 (default 256^3, an eighth
@@ -491,6 +524,11 @@ def run_rank(args):
                 out["second_milestone"] = compressible_milestone(bz, device)
             except Exception as exc:       # never let the side measurement take the headline line down
                 out["second_milestone"] = {"error": repr(exc)}
+        if world == 1 and not args.no_float32 and not use_slabs and args.workload == "bubble":
+            try:
+                out["float32"] = float32_run(bz, device, args.size)
+            except Exception as exc:
+                out["float32"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_budget)
         print(json.dumps(out), flush=True)
@@ -515,6 +553,7 @@ def main():
                     help="slab runs: the C library's RCCL communicator, torch.distributed, or try the first and fall back")
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--no-float32", action="store_true", help="skip the Float32 run reported under `float32`")
     ap.add_argument("--no-compressible", action="store_true",
                     help="skip the short compressible split-explicit measurement reported under `second_milestone`")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks are killed after this many seconds")

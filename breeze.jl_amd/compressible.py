@@ -32,6 +32,14 @@ class ThermalDivergenceDamping:
         self.coefficient, self.length_scale, self.damp_vertical = float(coefficient), None, bool(damp_vertical)
 
 
+class DirectDivergenceDamping:
+    """DirectDivergenceDamping(coefficient=0.1) (time_discretizations.jl:269-274): the horizontal theta-flux divergence of the
+    perturbation momentum is differenced directly (acoustic_substepping.jl:1146-1188); horizontal only."""
+
+    def __init__(self, coefficient=0.1):
+        self.coefficient = float(coefficient)
+
+
 class ProportionalSubsteps:
     pass
 
@@ -41,7 +49,7 @@ class SplitExplicitTimeDiscretization:
                  vertical_momentum_tendency_factor=1, apply_first_substep_pressure_gradient=False, damping=None,
                  sponge=None, substep_distribution=None):
         damping = ThermalDivergenceDamping(coefficient=0.1) if damping is None else damping
-        if not isinstance(damping, (ThermalDivergenceDamping, NoDivergenceDamping)):
+        if not isinstance(damping, (ThermalDivergenceDamping, DirectDivergenceDamping, NoDivergenceDamping)):
             raise ValueError("`damping` must be an `AcousticDampingStrategy`")
         if sponge is not None:
             raise NotImplementedError("UpperSponge is not implemented in the HIP path")
@@ -309,7 +317,8 @@ class CompressibleAtmosphereModel:
         bt.apply_first_substep_pressure_gradient = int(td.apply_first_substep_pressure_gradient)
         bt.newton_maxiter = self.temperature_solver.maxiter
         bt.acoustic_cfl, bt.forward_weight = td.acoustic_cfl, td.forward_weight
-        bt.damping_coefficient = damp.coefficient if isinstance(damp, ThermalDivergenceDamping) else -1.0
+        bt.damping_coefficient = damp.coefficient if isinstance(damp, (ThermalDivergenceDamping, DirectDivergenceDamping)) else -1.0
+        bt.direct_divergence_damping = int(isinstance(damp, DirectDivergenceDamping))
         bt.thermodynamic_tendency_factor = td.thermodynamic_tendency_factor
         bt.vertical_momentum_tendency_factor = td.vertical_momentum_tendency_factor
         bt.newton_abstol = self.temperature_solver.abstol

@@ -700,6 +700,7 @@ extern "C" int bz_create_compressible_slab(bz_ctx **out, const bz_grid *local_gr
                                            const bz_exner_reference_state *ref, const bz_split_explicit *td, int weno_order,
                                            int y_nranks, int y_rank)
 {
+    if (td && td->direct_divergence_damping) return BZ_ERR_UNSUPPORTED;   // delta would need its own y-halo exchange
     if (y_nranks < 1 || y_rank < 0 || y_rank >= y_nranks) return BZ_ERR_INVALID;
     return bzi_create_compressible(out, local_grid, constants, ref, td, weno_order, y_nranks, y_rank, true);
 }
@@ -908,10 +909,38 @@ static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_
     return F;
 }
 
+// apply_divergence_damping!(::DirectDivergenceDamping) (acoustic_substepping.jl:1158-1188): delta = V^-1 (dx(thetaF^x) + dy(thetaF^y))
+// into the density predictor (free between recovery and the next predictor build), then the theta_L-scaled gradient of delta onto the
+// horizontal momentum perturbations.  Periodic neighbours by wrap indexing: no halo fill of delta, (rho u)', (rho v)' or theta_L.
+__global__ __launch_bounds__(256) void k_ac_direct_delta(DevGrid g, double *__restrict__ delta, const double *__restrict__ thL,
+                                                         const double *__restrict__ up, const double *__restrict__ vp)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k);
+    const long long ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx, im = (i > 0) ? -1 : g.Nx - 1;
+    const long long jp = (j + 1 < g.Ny) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny), jm = (j > 0) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
+    const double Ax = g.Ax[k], Ay = g.Ay[k];
+    const double fx = Ax * ((thL[n + ip] + thL[n]) / 2.0) * up[n + ip] - Ax * ((thL[n] + thL[n + im]) / 2.0) * up[n];
+    const double fy = Ay * ((thL[n + jp] + thL[n]) / 2.0) * vp[n + jp] - Ay * ((thL[n] + thL[n + jm]) / 2.0) * vp[n];
+    delta[n] = (fx + fy) * g.Vinv_c[k];
+}
+__global__ __launch_bounds__(256) void k_ac_direct_apply(DevGrid g, const double *__restrict__ delta, const double *__restrict__ thL,
+                                                         double *__restrict__ up, double *__restrict__ vp, double alpha)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k);
+    const long long im = (i > 0) ? -1 : g.Nx - 1;
+    const long long jm = (j > 0) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
+    up[n] += alpha * (g.dx * g.dx) * ((delta[n] - delta[n + im]) * g.rdx) / ((thL[n] + thL[n + im]) / 2.0);
+    vp[n] += alpha * (g.dy * g.dy) * ((delta[n] - delta[n + jm]) * g.rdy) / ((thL[n] + thL[n + jm]) / 2.0);
+}
+
 // ---- one WS-RK3 stage of the acoustic loop in three pieces (the y-slab driver exchanges halos between them) ---------
 struct AcStage {
     int ntau = 0, cur = 0, done = 0;
-    bool damping = false, fused = true;
+    bool damping = false, fused = true, direct = false;
     AcParams P;
 };
 static AcStage &stage_of(bz_ctx *ctx)
@@ -943,7 +972,8 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     AcParams &P = S.P;
     P.dtau = dtau; P.dtn = om * dtau; P.dto = (1.0 - om) * dtau;
     P.d_new = 0.0; P.d_old = 0.0;
-    S.damping = ctx->se.damping_coefficient >= 0.0;
+    S.direct = ctx->se.damping_coefficient >= 0.0 && ctx->se.direct_divergence_damping != 0;
+    S.damping = ctx->se.damping_coefficient >= 0.0 && !S.direct;      // the thermal form, folded into the substep kernels
     if (S.damping && ctx->se.damp_vertical) {
         const double base = ctx->se.damping_coefficient * (ctx->dz_min * ctx->dz_min);
         P.d_new = om * base;
@@ -1031,6 +1061,15 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
             ProfileScope ps(ctx, "acoustic_column_backward");
             hipLaunchKernelGGL(k_ac_column_backward, colsb, bcolb, 0, ctx->stream, g, F, P);
         }
+    }
+    if (S.direct) {      // DirectDivergenceDamping closes every substep (also the last one) on the current perturbation buffers
+        ProfileScope ps(ctx, "acoustic_direct_damping");
+        double *th_buf[2], *u_buf[2], *v_buf[2];
+        stage_buffers(ctx, F, th_buf, u_buf, v_buf);
+        double *up = S.fused ? u_buf[S.cur] : F.rup, *vp = S.fused ? v_buf[S.cur] : F.rvp;
+        hipLaunchKernelGGL(k_ac_direct_delta, rows, b256, 0, ctx->stream, g, sub->density_predictor, sub->potential_temperature, up, vp);
+        hipLaunchKernelGGL(k_ac_direct_apply, rows, b256, 0, ctx->stream, g, sub->density_predictor, sub->potential_temperature, up, vp,
+                           ctx->se.damping_coefficient);
     }
     S.done = sstep;
     BZ_LAUNCH_CHECK();

@@ -287,6 +287,9 @@ typedef struct bz_split_explicit {
     double damping_coefficient;       /* ThermalDivergenceDamping alpha (default 0.1); < 0: NoDivergenceDamping */
     double thermodynamic_tendency_factor, vertical_momentum_tendency_factor;   /* default 1                   */
     double newton_abstol;             /* NewtonSolver abstol (default 1e-4), reltol = 0                       */
+    int32_t direct_divergence_damping; /* != 0: DirectDivergenceDamping(damping_coefficient) (time_discretizations.jl:269-274,
+                                         acoustic_substepping.jl:1146-1188) instead of ThermalDivergenceDamping; horizontal only  */
+    int32_t reserved;
 } bz_split_explicit;
 
 /* ExnerReferenceState columns (src/Thermodynamics/reference_states.jl:717-815): HOST arrays of length Nz+2Hz

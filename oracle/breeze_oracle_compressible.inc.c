@@ -466,6 +466,40 @@ void og_thermal_divergence_damping(const og_grid *G, double *rup, double *rvp, c
             }
 }
 
+
+/* apply_divergence_damping!(::DirectDivergenceDamping) (acoustic_substepping.jl:1158-1188): delta = V^-1 (dx(thetaF^x) + dy(thetaF^y))
+ * with thetaF^x = Ax Ix(theta_L) (rho u)' (:962-963), halo fill of delta, then
+ * (rho u)' += alpha dx^2 d_x(delta) / Ix(theta_L), (rho v)' += alpha dy^2 d_y(delta) / Iy(theta_L).  delta: scratch (density predictor). */
+void og_direct_divergence_damping(const og_grid *G, double *rup, double *rvp, double *delta, const double *thL, double alpha)
+{
+    const ptrdiff_t sy = STRY(G);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < G->Nz; ++k)
+        for (int j = 0; j < G->Ny; ++j)
+            for (int i = 0; i < G->Nx; ++i) {
+                size_t n = IDX(G, i, j, k);
+                double dzc = G->dzc[k + G->Hz];
+                double Ax = G->dy * dzc, Ay = G->dx * dzc, Vinv = 1.0 / (G->dx * G->dy * dzc);
+                double fx = 0.0, fy = 0.0;
+                if (G->tx != FLAT)
+                    fx = Ax * ((thL[n + 1] + thL[n]) / 2.0) * rup[n + 1] - Ax * ((thL[n] + thL[n - 1]) / 2.0) * rup[n];
+                if (G->ty != FLAT)
+                    fy = Ay * ((thL[n + sy] + thL[n]) / 2.0) * rvp[n + sy] - Ay * ((thL[n] + thL[n - sy]) / 2.0) * rvp[n];
+                delta[n] = (fx + fy) * Vinv;
+            }
+    og_fill_halo_periodic_xy(G, delta, G->Nz + 2 * G->Hz);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < G->Nz; ++k)
+        for (int j = 0; j < G->Ny; ++j)
+            for (int i = 0; i < G->Nx; ++i) {
+                size_t n = IDX(G, i, j, k);
+                if (G->tx != FLAT)
+                    rup[n] += alpha * (G->dx * G->dx) * ((delta[n] - delta[n - 1]) * (1.0 / G->dx)) / ((thL[n] + thL[n - 1]) / 2.0);
+                if (G->ty != FLAT)
+                    rvp[n] += alpha * (G->dy * G->dy) * ((delta[n] - delta[n - sy]) * (1.0 / G->dy)) / ((thL[n] + thL[n - sy]) / 2.0);
+            }
+}
+
 /* _finalize_time_averaged_velocity! (acoustic_substepping.jl:1225-1250) */
 void og_finalize_time_averaged_velocity(const og_grid *G, double *au, double *av, double *aw,
                                         const double *ru, const double *rv, const double *rw,

@@ -107,7 +107,8 @@ class SplitExplicit:
     def __init__(self, substeps=None, acoustic_cfl=0.5, forward_weight=0.65,
                  damping_coefficient=0.1, damp_vertical=False,
                  apply_first_substep_pressure_gradient=False,
-                 thermodynamic_tendency_factor=1.0, vertical_momentum_tendency_factor=1.0):
+                 thermodynamic_tendency_factor=1.0, vertical_momentum_tendency_factor=1.0, direct_damping=False):
+        self.direct_damping = bool(direct_damping)      # DirectDivergenceDamping(coefficient) instead of ThermalDivergenceDamping
         self.substeps = substeps
         self.acoustic_cfl = float(acoustic_cfl)
         self.forward_weight = float(forward_weight)
@@ -401,7 +402,7 @@ class CompressibleOracleModel:
 
     def implicit_damping_factors(self):
         td, g = self.td, self.grid
-        if td.damping_coefficient is None or not td.damp_vertical:
+        if td.damping_coefficient is None or not td.damp_vertical or getattr(td, "direct_damping", False):
             return 0.0, 0.0
         base = td.damping_coefficient * float(np.min(g.dzc[g.Hz:g.Hz + g.Nz])) ** 2
         return td.forward_weight * base, (1 - td.forward_weight) * base
@@ -451,7 +452,11 @@ class CompressibleOracleModel:
                                      _p(self.thL), C.c_double(dtn))
             self._halo_center(self.rp)
             self._halo_center(self.rthp)
-            if td.damping_coefficient is not None:
+            if td.damping_coefficient is not None and getattr(td, "direct_damping", False):
+                # DirectDivergenceDamping: delta lives in the density predictor, free between recovery and the next build
+                L.og_direct_divergence_damping(cg, _p(self.rup), _p(self.rvp), _p(self.rs), _p(self.thL),
+                                               C.c_double(td.damping_coefficient))
+            elif td.damping_coefficient is not None:
                 L.og_thermal_divergence_damping(cg, _p(self.rup), _p(self.rvp), _p(self.rthp), _p(self.rth_old),
                                                 _p(self.thL), C.c_double(td.damping_coefficient), C.c_double(dtau))
             self._halo_center(self.rup)

@@ -24,6 +24,7 @@ def make_pair(oracle, oc, bz, size=(24, 16, 20), theta_ref=300.0, reference=True
                                     reference_state=reference)
     grid = bz.RectilinearGrid(size, x=EXTENT["x"], y=EXTENT["y"], z=z)
     damping = (bz.NoDivergenceDamping() if otd.damping_coefficient is None
+               else bz.DirectDivergenceDamping(coefficient=otd.damping_coefficient) if otd.direct_damping
                else bz.ThermalDivergenceDamping(coefficient=otd.damping_coefficient, damp_vertical=otd.damp_vertical))
     btd = bz.SplitExplicitTimeDiscretization(substeps=otd.substeps, acoustic_cfl=otd.acoustic_cfl,
                                              forward_weight=otd.forward_weight, damping=damping,
@@ -186,6 +187,8 @@ CASES = [
     dict(substeps=1),                                            # degenerate one-substep stages (gate always on)
     dict(substeps=6, apply_first_substep_pressure_gradient=True),
     dict(),                                                      # adaptive substep count from the acoustic CFL
+    dict(substeps=6, direct_damping=True),                       # DirectDivergenceDamping (acoustic_substepping.jl:1146-1188)
+    dict(substeps=1, direct_damping=True, damping_coefficient=0.15),
 ]
 
 
@@ -228,7 +231,8 @@ def test_acoustic_substep_loop_matches_oracle(oracle, oc, bz, td, beta):
     cmp_interior(om, hm, ("rho_d", "rtheta", "ru", "rv", "rw", "u", "v", "w"), 1e-12)
 
 
-@pytest.mark.parametrize("td", [dict(substeps=6), dict(), dict(substeps=4, damping_coefficient=0.05, damp_vertical=True)])
+@pytest.mark.parametrize("td", [dict(substeps=6), dict(), dict(substeps=4, damping_coefficient=0.05, damp_vertical=True),
+                                dict(substeps=6, direct_damping=True)])
 def test_time_steps_match_oracle(oracle, oc, bz, td):
     """Three full WS-RK3 steps of a warm bubble with a moist tracer, whole-step seam: 1e-9 of max-abs."""
     om, hm = make_pair(oracle, oc, bz, size=(24, 16, 24), **td)

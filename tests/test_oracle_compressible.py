@@ -291,3 +291,33 @@ def test_density_based_temperature_inversion_reference_known_answers(oracle, oc)
         else:
             assert T > T_noniter
             assert T - T_noniter == pytest.approx(1.39 * kap * L, rel=0.15)
+
+
+def test_direct_divergence_damping_properties(oracle, oc):
+    """DirectDivergenceDamping (acoustic_substepping.jl:1146-1188) has no known-answer test in the reference; its defining properties on
+    the oracle kernel: (1) a horizontally non-divergent theta-flux field is left untouched; (2) for uniform theta_L the correction is
+    alpha dx^2 grad(div (rho u)') — a plane compression wave (rho u)' = sin(k x) has its amplitude reduced by the exact discrete factor
+    1 - alpha (2 sin(k dx / 2))^2, the Laplacian-diffusion stability bound alpha <~ 0.25 quoted in time_discretizations.jl:262-267."""
+    import ctypes as C
+    g = oracle.Grid((16, 12, 6), x=(0.0, 1600.0), y=(0.0, 1200.0), z=(0.0, 600.0))
+    m = oc.CompressibleOracleModel(g, time_discretization=oc.SplitExplicit(substeps=2, direct_damping=True), reference_potential_temperature=300.0)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    L, cg = m.lib, C.byref(m.cg)
+    thL = np.full_like(m.rup, 300.0)
+    x = g.xf[None, None, :] + 0 * g.yc[None, :, None]
+    kx = 2 * np.pi * 3 / 1600.0
+    up, vp, delta = np.zeros_like(m.rup), np.zeros_like(m.rup), np.zeros_like(m.rup)
+    g.interior(up)[...] = np.sin(kx * x)
+    m._halo_center(up)
+    before = g.interior(up).copy()
+    L.og_direct_divergence_damping(cg, p(up), p(vp), p(delta), p(thL), C.c_double(0.1))
+    factor = 1.0 - 0.1 * (2 * np.sin(kx * g.dx / 2)) ** 2
+    assert np.allclose(g.interior(up), factor * before, rtol=0, atol=1e-13)
+    assert np.max(np.abs(g.interior(vp))) < 1e-13
+    # non-divergent: (rho u)' = f(y) only
+    up[...] = 0.0
+    g.interior(up)[...] = np.cos(2 * np.pi * g.yc / 1200.0)[None, :, None]
+    m._halo_center(up)
+    before = g.interior(up).copy()
+    L.og_direct_divergence_damping(cg, p(up), p(vp), p(delta), p(thL), C.c_double(0.1))
+    assert np.max(np.abs(g.interior(up) - before)) < 1e-14

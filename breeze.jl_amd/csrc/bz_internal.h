@@ -357,6 +357,7 @@ void bzi_lean_teardown(bz_ctx *ctx);
 void bzi_poisson_teardown(bz_ctx *ctx);
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);
 int bzi_poisson_spectral(bz_ctx *ctx);
+int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column);
 // fused streaming kernels (bz_fused.hip)
 int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                   double alpha, bool first);

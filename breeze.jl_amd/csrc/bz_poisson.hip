@@ -115,6 +115,190 @@ __global__ void __launch_bounds__(64) k_tridiag_solve(int NXH, int Ny, int Nz, c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Cooperative single-pass solve (round 2).  The Thomas kernel above reads and writes the spectrum twice (forward + backward sweep)
+// and reads two factor tables: 5 words moved per 2 algorithmic ones (PMC 5.37 GB per launch at 512^3) on a 512-deep dependent chain
+// with one thread per column.  Here a block of 512 threads owns 8 adjacent columns (one 128-byte line per level) and 64 segments of
+// <= 8 levels each; thread (column c, segment s) keeps its rows in registers, so the spectrum is read once and written once and no
+// table is read (the factors are recomputed: one division per row).  Partition method (Wang 1981):
+//   A  local forward elimination started at the segment's first row, with a fill-in column g for the unknown above the segment:
+//        x_k + cp_k x_{k+1} + g_k x_prev = dp_k
+//   B  local backward elimination towards the segment's last unknown x_l:   x_k + g_k x_prev + h_k x_l = dp_k   (k < l)
+//   C  the 64 last unknowns X_s of a column satisfy a tridiagonal system
+//        g_l(s) X_{s-1} + (1 - cp_l(s) g_f(s+1)) X_s - cp_l(s) h_f(s+1) X_{s+1} = dp_l(s) - cp_l(s) dp_f(s+1)
+//      (f: first row of the next segment), solved through LDS by one thread per column;
+//   D  x_k = dp_k - g_k X_{s-1} - h_k X_s.
+// The singular (kx, ky) = (0, 0) column is made regular the way the sequential kernel's |beta| guard does it — its last row is
+// replaced by x = 0 — and then loses its mean (Oceananigans' solve! subtracts the mean of phi).
+// Requires 128 <= Nz <= 512 and a column count divisible by 8; other shapes use the sequential kernel.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define TCO_COLS 8
+#define TCO_SEGS 64
+#define TCO_M 8
+__global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, int Ny, int Nz, int kx0, int nxh_real, int ky_fastest, TriCols C,
+                                                                      double2 *__restrict__ hat, double scale, int mean_column)
+{
+    __shared__ double sR[TCO_SEGS][TCO_COLS][6];      // g_f, h_f, g_l, cp_l of a segment; then sub / diag / sup of the reduced system
+    __shared__ double2 sD[TCO_SEGS][TCO_COLS][2];     // dp_f, dp_l; then [0] = X_s
+    __shared__ double sSum[TCO_SEGS];
+    const int t = threadIdx.x, cc = t & (TCO_COLS - 1), s = t >> 3;
+    const long long plane = (long long)NXH * Ny;
+    const long long c = (long long)blockIdx.x * TCO_COLS + cc;          // plane % 8 == 0: always inside
+    const int kx = ky_fastest ? (int)(c / Ny) : (int)(c % NXH), ky = ky_fastest ? (int)(c % Ny) : (int)(c / NXH);
+    const bool padding = (kx0 + kx >= nxh_real);
+    const bool pinned = mean_column && c == 0;                           // the (0, 0) column of the whole spectrum lives here
+    const double lam = padding ? 0.0 : C.lam_x[kx0 + kx] + C.lam_y[ky];
+    const int q = Nz / TCO_SEGS, r = Nz % TCO_SEGS;
+    const int L = q + (s < r ? 1 : 0), k0 = s * q + min(s, r);
+    double2 dp[TCO_M];
+    double g[TCO_M], h[TCO_M];
+    double2 *col = hat + c;
+#pragma unroll
+    for (int j = 0; j < TCO_M; ++j)
+        if (j < L) dp[j] = col[plane * (k0 + j)];
+    // ---- A: local forward elimination ----
+    double cp_prev = 0.0, g_prev = 0.0;
+    double2 d_prev = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < TCO_M; ++j) {
+        if (j < L) {
+            const int k = k0 + j;
+            double a = (k > 0) ? C.lower[k - 1] : 0.0, cu = (k < Nz - 1) ? C.lower[k] : 0.0;
+            double b = C.diag0[k] - C.mass[k] * lam;
+            double2 d = make_double2(dp[j].x * scale, dp[j].y * scale);
+            if (pinned && k == Nz - 1) { a = 0.0; b = 1.0; cu = 0.0; d = make_double2(0.0, 0.0); }
+            if (padding) { a = 0.0; b = 1.0; cu = 0.0; d = make_double2(0.0, 0.0); }
+            double inv, gk;
+            if (j == 0) { inv = 1.0 / b; gk = a * inv; d.x *= inv; d.y *= inv; }
+            else {
+                inv = 1.0 / (b - a * cp_prev);
+                gk = -(a * g_prev) * inv;
+                d.x = (d.x - a * d_prev.x) * inv;
+                d.y = (d.y - a * d_prev.y) * inv;
+            }
+            cp_prev = cu * inv;
+            g_prev = gk;
+            d_prev = d;
+            dp[j] = d; g[j] = gk; h[j] = cp_prev;        // h holds cp until stage B
+        }
+    }
+    // ---- B: local backward elimination towards the last unknown (row L-1 keeps its coupling cp to the next segment) ----
+    const double cp_l = cp_prev;                       // cp of the last row
+#pragma unroll
+    for (int j = TCO_M - 3; j >= 0; --j) {
+        if (j <= L - 3) {
+            const double cpk = h[j];
+            dp[j].x -= cpk * dp[j + 1].x;
+            dp[j].y -= cpk * dp[j + 1].y;
+            g[j] -= cpk * g[j + 1];
+            h[j] = -cpk * h[j + 1];
+        }
+    }
+    // row L-2 already reads x_k + cp_k x_l + g_k x_prev = dp_k: h[L-2] = cp[L-2] as stored
+    // ---- C: reduced system of the segment-last unknowns ----
+    {
+        double gl = 0.0;
+        double2 dl = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < TCO_M; ++j)
+            if (j == L - 1) { gl = g[j]; dl = dp[j]; }
+        sR[s][cc][0] = g[0]; sR[s][cc][1] = h[0]; sR[s][cc][2] = gl; sR[s][cc][3] = cp_l;
+        sD[s][cc][0] = dp[0]; sD[s][cc][1] = dl;
+    }
+    __syncthreads();
+    if (s == 0) {        // one thread per column: Thomas over the 64 reduced unknowns, in LDS
+        double beta = 0.0, tprev = 0.0;
+        double2 vprev = make_double2(0.0, 0.0);
+        for (int m = 0; m < TCO_SEGS; ++m) {
+            const double glm = sR[m][cc][2], cpl = sR[m][cc][3];
+            double diag = 1.0, sup = 0.0;
+            double2 rhs = sD[m][cc][1];
+            if (m + 1 < TCO_SEGS) {
+                diag = 1.0 - cpl * sR[m + 1][cc][0];
+                sup = -cpl * sR[m + 1][cc][1];
+                const double2 df = sD[m + 1][cc][0];
+                rhs.x -= cpl * df.x;
+                rhs.y -= cpl * df.y;
+            }
+            beta = diag - glm * tprev;
+            const double ib = 1.0 / beta;
+            double2 v;
+            v.x = (rhs.x - glm * vprev.x) * ib;
+            v.y = (rhs.y - glm * vprev.y) * ib;
+            tprev = sup * ib;
+            sR[m][cc][4] = tprev;
+            sD[m][cc][0] = v;
+            vprev = v;
+        }
+        double2 next = sD[TCO_SEGS - 1][cc][0];
+        for (int m = TCO_SEGS - 2; m >= 0; --m) {
+            double2 v = sD[m][cc][0];
+            const double tt = sR[m][cc][4];
+            v.x -= tt * next.x;
+            v.y -= tt * next.y;
+            sD[m][cc][0] = v;
+            next = v;
+        }
+    }
+    __syncthreads();
+    // ---- D: back substitution ----
+    const double2 Xs = sD[s][cc][0];
+    const double2 Xp = (s > 0) ? sD[s - 1][cc][0] : make_double2(0.0, 0.0);
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < TCO_M; ++j) {
+        if (j < L) {
+            if (j == L - 1) dp[j] = Xs;
+            else {
+                dp[j].x -= g[j] * Xp.x + h[j] * Xs.x;
+                dp[j].y -= g[j] * Xp.y + h[j] * Xs.y;
+            }
+            sum += dp[j].x;
+        }
+    }
+    if (mean_column && blockIdx.x == 0) {       // block-uniform branch: the global mean of phi is the z-mean of the (0, 0) column
+        if (cc == 0) sSum[s] = sum;
+        __syncthreads();
+        double tot = 0.0;
+        for (int m = 0; m < TCO_SEGS; ++m) tot += sSum[m];
+        if (cc == 0) {
+            const double mean = tot / Nz;
+#pragma unroll
+            for (int j = 0; j < TCO_M; ++j)
+                if (j < L) dp[j].x -= mean;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TCO_M; ++j)
+        if (j < L) col[plane * (k0 + j)] = dp[j];
+}
+
+static bool tridiag_coop_ok(const bz_ctx *ctx, int Ny)
+{
+    const long long plane = (long long)ctx->NXH * Ny;
+    return ctx->dg.Nz >= 2 * TCO_SEGS && ctx->dg.Nz <= TCO_SEGS * TCO_M && plane % TCO_COLS == 0 && !getenv("BZ_NO_TRIDIAG_COOP");
+}
+
+// Thomas solve of this context's spectral block, in place: the cooperative kernel when the shape allows it, else the sequential one
+int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column)
+{
+    const long long plane = (long long)ctx->NXH * Ny;
+    if (tridiag_coop_ok(ctx, Ny)) {
+        const int nxh_real = ctx->dg.Nx / 2 + 1;
+        double *d_cols = ctx->d_lower;
+        const int Nz = ctx->dg.Nz;
+        TriCols C{d_cols, d_cols + Nz, d_cols + 2 * Nz, d_cols + 3 * Nz, d_cols + 3 * Nz + nxh_real};
+        hipLaunchKernelGGL(k_tridiag_coop, dim3((unsigned)(plane / TCO_COLS)), dim3(TCO_COLS * TCO_SEGS), 0, ctx->stream, ctx->NXH, Ny, Nz,
+                           ctx->kx0, nxh_real, ctx->slab_mode ? 1 : 0, C, (double2 *)hat, scale, mean_column);
+    } else {
+        hipLaunchKernelGGL(k_tridiag_solve, dim3((unsigned)((plane + 63) / 64)), dim3(64), 0, ctx->stream, ctx->NXH, Ny, ctx->dg.Nz,
+                           ctx->d_lower, ctx->d_ibeta, ctx->d_tfac, (double2 *)hat, scale, mean_column);
+    }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
 __global__ __launch_bounds__(TX *TY) void k_phi_scatter(DevGrid g, double *__restrict__ phi,
                                                        const double *__restrict__ src)
 {
@@ -228,11 +412,8 @@ int bzi_poisson_spectral(bz_ctx *ctx)
     }
     {
         ProfileScope ps(ctx, "poisson_tridiagonal");
-        long long plane = (long long)ctx->NXH * g.Ny;
-        hipLaunchKernelGGL(k_tridiag_solve, dim3((unsigned)((plane + 63) / 64)), dim3(64), 0, ctx->stream, ctx->NXH,
-                           g.Ny, g.Nz, ctx->d_lower, ctx->d_ibeta, ctx->d_tfac, (double2 *)ctx->d_hat,
-                           1.0 / ((double)g.Nx * (double)g.Ny), 1);
-        BZ_LAUNCH_CHECK();
+        int rct = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1);
+        if (rct) return rct;
     }
     {
         ProfileScope ps(ctx, "poisson_fft_inverse");

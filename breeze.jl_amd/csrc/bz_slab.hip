@@ -41,12 +41,7 @@ extern "C" int bz_spectral_tridiagonal_solve(bz_ctx *ctx, double *hat, double sc
     if (!ctx || !hat) return BZ_ERR_INVALID;
     ProfileScope ps(ctx, "poisson_tridiagonal");
     const int Ny = ctx->slab_mode ? ctx->Ny_global : ctx->dg.Ny;
-    long long plane = (long long)ctx->NXH * Ny;
-    hipLaunchKernelGGL(k_tridiag_solve, dim3((unsigned)((plane + 63) / 64)), dim3(64), 0, ctx->stream, ctx->NXH, Ny,
-                       ctx->dg.Nz, ctx->d_lower, ctx->d_ibeta, ctx->d_tfac, (double2 *)hat, scale,
-                       ctx->kx0 == 0 ? 1 : 0);
-    BZ_LAUNCH_CHECK();
-    return BZ_OK;
+    return bzi_tridiag_launch(ctx, hat, scale, Ny, ctx->kx0 == 0 ? 1 : 0);
 }
 
 // Transposing pack of the distributed transform: out[k][b][a] = in[k][a][c0 + b] for a < A, b < B (zero where c0 + b >= valid),

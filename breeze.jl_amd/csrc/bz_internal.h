@@ -10,6 +10,22 @@
 
 #include "../../include/breeze_hip.h"
 
+// A column table (Nz + 2 Hz + 1 entries, written once at bz_create).  On the device `table[k]` reads through the CONSTANT address
+// space: with a wave-uniform level index that is an s_load from the scalar cache, batched by the compiler at the top of a level,
+// instead of a vector load with its own s_waitcnt (the generic-pointer form could not be scalarised because the tables might alias
+// the kernel's stores: the ISA of the tendency kernels had 4-7 such loads per level, each followed by a full wait).
+struct ColPtr {
+    const double *p = nullptr;
+    ColPtr() = default;
+    __host__ __device__ ColPtr(const double *q) : p(q) {}
+    __host__ __device__ operator const double *() const { return p; }
+#ifdef __HIPCC__
+    typedef const double __attribute__((address_space(4))) *cptr;
+    __device__ __forceinline__ double operator[](int k) const { return ((cptr)p)[k]; }
+    __device__ __forceinline__ double operator[](long long k) const { return ((cptr)p)[k]; }
+#endif
+};
+
 // Device view of the grid + reference columns.  Passed by value (kernarg) to every kernel.
 // Column pointers are pre-offset so that index k (0-based interior) is valid for
 // k = -Hz .. Nz+Hz-1 (centres) / Nz+Hz (faces).
@@ -19,14 +35,14 @@ struct DevGrid {
     int Sx, Sy;            // parent row length / rows per plane
     long long Sxy;         // plane stride
     double dx, dy, rdx, rdy, Az;
-    const double *dzc, *dzf, *rdzf;      // thickness at centres; centre spacing at faces; 1/dzf
-    const double *rdzc;                  // 1/dzc
-    const double *zc;                    // cell-centre heights
-    const double *Ax, *Ay;               // dy*dzc[k], dx*dzc[k]
-    const double *Vinv_c, *Vinv_f;       // 1/(dx*dy*dzc[k]), 1/(dx*dy*dzf[k])
-    const double *rho, *rho_f;           // rho_r at centres;  0.5*(rho[k-1]+rho[k]) at faces
-    const double *rrho, *rrho_f;         // their correctly rounded reciprocals (host 1.0/x), for bz_cdiv
-    const double *p_r, *T_r;
+    ColPtr dzc, dzf, rdzf;               // thickness at centres; centre spacing at faces; 1/dzf
+    ColPtr rdzc;                         // 1/dzc
+    ColPtr zc;                           // cell-centre heights
+    ColPtr Ax, Ay;                       // dy*dzc[k], dx*dzc[k]
+    ColPtr Vinv_c, Vinv_f;               // 1/(dx*dy*dzc[k]), 1/(dx*dy*dzf[k])
+    ColPtr rho, rho_f;                   // rho_r at centres;  0.5*(rho[k-1]+rho[k]) at faces
+    ColPtr rrho, rrho_f;                 // their correctly rounded reciprocals (host 1.0/x), for bz_cdiv
+    ColPtr p_r, T_r;
     double g, Rd, Rv, cpd, cpv, pst;
     int formulation;       // 0: liquid-ice potential temperature (theta), 1: static energy (e) in the `theta` slots
     // microphysics = SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) (bz_set_saturation_adjustment)

@@ -65,7 +65,7 @@ int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
     Lean5 L;
     L.ru = s->rho_u; L.rv = s->rho_v; L.rw = s->rho_w; L.pa = pa; L.pb = pb; L.oa = oa; L.ob = ob; L.out = nullptr;
     L.T = s->T;
-    L.pi_dry = getenv("BZ_NO_PI_DRY") ? nullptr : ctx->d_pi_dry + g.Hz;
+    L.pi_dry = ColPtr(getenv("BZ_NO_PI_DRY") ? nullptr : ctx->d_pi_dry + g.Hz);
     const dim3 block(64, TY);
     const int tx = (g.Nx + 63) / 64, nty = (g.Ny + TY - 1) / TY;
     if (rows && nty < 3) return rows == 1 ? BZ_OK : bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, 0);
@@ -84,7 +84,8 @@ int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         L.out = G->rho_u;
         const dim3 grid = shape(g.Nz, kc);
-        hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (getenv("BZ_U_GEN5")) hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     {
         ProfileScope ps(ctx, "y_momentum_tendency+rk3+velocity");

@@ -31,7 +31,7 @@ struct Lean5 {
     double *out;                     // momentum kernels: predictor momentum (the G slot of the component)
     double *oa, *ob;                 // scalar kernel: updated rho theta, rho q (the other buffer of the ping-pong pair)
     double *T;                       // temperature of the stage-start state (w kernel: read; scalar kernel: writes the updated one)
-    const double *pi_dry;            // (p_r[k]/p_st)^(Rd/cpd) indexed by level, or nullptr
+    ColPtr pi_dry;                   // (p_r[k]/p_st)^(Rd/cpd) indexed by level, or nullptr
     int xcd;                         // 1: XCD-contiguous block order (grid size divisible by 8)
     int by0, bys;                    // tile row of block row b is by0 + b * bys (sub-launches of the slab driver: interior rows
                                      // while the y-halo exchange is in flight, then the two edge rows)
@@ -42,15 +42,21 @@ struct Lean5 {
 __device__ __forceinline__ void bz_block5(const Lean5 &L, int &bx, int &by, int &bz)
 {
     bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
-    if (!L.xcd) { by = L.by0 + by * L.bys; return; }
-    const unsigned gx = gridDim.x, gy = gridDim.y;
-    const unsigned W = gx * gy * gridDim.z;
-    unsigned w = bx + gx * (by + gy * bz);
-    w = (w & 7u) * (W >> 3) + (w >> 3);
-    bx = (int)(w % gx);
-    by = (int)((w / gx) % gy);
-    bz = (int)(w / (gx * gy));
+    if (L.xcd) {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned W = gx * gy * gridDim.z;
+        unsigned w = bx + gx * (by + gy * bz);
+        w = (w & 7u) * (W >> 3) + (w >> 3);
+        bx = (int)(w % gx);
+        by = (int)((w / gx) % gy);
+        bz = (int)(w / (gx * gy));
+    }
     by = L.by0 + by * L.bys;
+    // the divisions above run on the vector ALU; tell the compiler the results are wave-uniform, otherwise the level index lives in
+    // a VGPR and every column-table read (g.rho[k], g.Ax[k], ...) becomes a vector load with its own s_waitcnt instead of an s_load
+    bx = __builtin_amdgcn_readfirstlane(bx);
+    by = __builtin_amdgcn_readfirstlane(by);
+    bz = __builtin_amdgcn_readfirstlane(bz);
 }
 
 // store v at n and at its periodic images (ox / oy = element offset of the x / y image, 0 if none)
@@ -71,11 +77,11 @@ __device__ __forceinline__ void st_img5(double *__restrict__ f, long long n, dou
 // The moist branch sits behind a call on purpose: inlined, pow() raises the register allocation of the whole kernel by ~40 VGPRs
 // (4 -> 3 waves per SIMD for every wave, dry or not); as a call only the wavefronts that hold vapour pay (save / restore around it).
 __device__ __attribute__((noinline)) double bz_exner_pow5(double x, double y) { return pow(x, y); }
-__device__ __forceinline__ double bz_temperature5(const DevGrid &g, double rth, double rq, int k, const double *__restrict__ pi_dry)
+__device__ __forceinline__ double bz_temperature5(const DevGrid &g, double rth, double rq, int k, const ColPtr pi_dry)
 {
     const double rho = g.rho[k], rrho = g.rrho[k];
     const double th = bz_cdiv(rth, rho, rrho), q = bz_cdiv(rq, rho, rrho);
-    if (pi_dry && __all(q == 0.0)) return pi_dry[k] * th;
+    if (pi_dry.p && __all(q == 0.0)) return pi_dry[k] * th;
     const double qd = 1.0 - q;
     const double Rm = qd * g.Rd + q * g.Rv;
     const double cpm = qd * g.cpd + q * g.cpv;
@@ -396,6 +402,152 @@ __global__ __launch_bounds__(64 * TY) void k5_u(DevGrid g, Lean5 L, int kchunk, 
 #pragma unroll
         for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
         r[5] = tnew;
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// x-momentum, sixth generation: EVERYTHING a level needs from its neighbours comes from LDS, and every global load of an iteration
+// is a prefetch for the NEXT level (register -> LDS at the end of the iteration).  Why: the ISA of k5_u has 28 vector loads and 19
+// s_waitcnt per level; with 128 VGPRs the compiler cannot hoist them, so each wave stalls on L1/L2 latency ~19 times per level and
+// the SIMDs idle (VALU busy 13 % of wave cycles at 4 waves / SIMD: 40-50 % of issue capacity) while neither HBM nor the ALUs are
+// saturated.  Here a level issues <= 6 loads per thread at its top (ring top of the next level, own rho_v / rho_w elements, u0, and
+// <= 2 frame cells), consumes them at its end, and reads its stencils with ds_read (tiles: u derived (TY+6) x 70; raw rho_u TY x 67;
+// raw rho_v (TY+1) x 67; raw rho_w TY x 67 at the upper face; double-buffered).  Same arithmetic, same bits as k5_u.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TY>
+__global__ __launch_bounds__(64 * TY) void k6_u(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
+{
+    constexpr int TR = TY + 6, TC = 72, NT = 64 * TY;
+    constexpr int NH1 = TR * 70 - TY * 64;               // frame of the u tile (468 for TY = 8): one cell per thread
+    constexpr int NH2 = 3 * (TY + 1) + 64 + 3 * TY;      // rho_v side columns + its top row + rho_w side columns (115)
+    static_assert(NH1 <= NT && NH2 <= NT, "one frame cell of each kind per thread");
+    __shared__ double U[2][TR][TC];
+    __shared__ double RU[2][TY][TC];
+    __shared__ double RV[2][TY + 1][TC];
+    __shared__ double RW[2][TY][TC];
+    __shared__ double FY[2][TY + 1][64];
+    int bx, by, bz;
+    bz_block5(L, bx, by, bz);
+    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx, tc = tx + 3;
+    const int i0 = bx * 64, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
+    const int ie = i0 - 1, le = 0;
+    const int kbeg = bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    if (kbeg >= kend) return;
+    const ix_t sz = (ix_t)g.Sxy;
+    const bool store = (i < g.Nx) && (j < g.Ny);
+    const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
+    Tend3Fields F;
+    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
+    ix_t n = (ix_t)g.idx(ic, jc, kbeg);
+    // frame cell 1: the u tile's frame (raw rho_u; its side cells next to the interior also feed the raw rho_u tile)
+    const bool h1ok = t < NH1;
+    int h1r = 0, h1c = 0;
+    {
+        const int h = h1ok ? t : 0;
+        if (h < 6 * 70) { const int rr = h / 70; h1c = h - rr * 70; h1r = (rr < 3) ? rr : TY + rr; }
+        else { const int hh = h - 6 * 70, rr = hh / 6, cc = hh - rr * 6; h1r = 3 + rr; h1c = (cc < 3) ? cc : 64 + cc; }
+    }
+    const ix_t h1n = (ix_t)g.idx(min(i0 - 3 + h1c, g.Nx + 2), min(j0 - 3 + h1r, g.Ny + 2), kbeg);
+    const bool h1raw = h1ok && h1r >= 3 && h1r < TY + 3 && (h1c == 2 || h1c == 67 || h1c == 68);
+    // frame cell 2: rho_v side columns (cols i0-2, i0-1, i0+64; rows j0 .. j0+TY), rho_v top row, rho_w side columns (upper face)
+    const bool h2ok = t < NH2;
+    int h2sel = 0, h2r = 0, h2c = 0;             // sel 0: rho_v, 1: rho_w
+    {
+        const int id = h2ok ? t : 0;
+        if (id < 3 * (TY + 1)) { h2r = id / 3; const int cc = id - 3 * h2r; h2c = (cc < 2) ? 1 + cc : 67; }
+        else if (id < 3 * (TY + 1) + 64) { h2r = TY; h2c = 3 + (id - 3 * (TY + 1)); }
+        else { h2sel = 1; const int m = id - 3 * (TY + 1) - 64; h2r = m / 3; const int cc = m - 3 * h2r; h2c = (cc < 2) ? 1 + cc : 67; }
+    }
+    const double *__restrict__ h2src = h2sel ? rw : rv;
+    const ix_t h2n = (ix_t)g.idx(min(i0 - 3 + h2c, g.Nx + 2), min(j0 + h2r, g.Ny + 2), kbeg) + (h2sel ? sz : (ix_t)0);
+
+    double r[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) r[s] = bz_cdiv(ru[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
+    double fz_lo = vflux<T3_U>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
+    double q0 = ru[n], q1 = ru[n + sz], q2 = ru[n + 2 * sz];          // raw rho_u of the own column at levels k, k+1, k+2
+    // tiles of level kbeg
+    U[0][ty + 3][tc] = r[3];
+    RU[0][ty][tc] = q0;
+    RV[0][ty][tc] = rv[n];
+    RW[0][ty][tc] = rw[n + sz];
+    if (h1ok) {
+        const double raw = ru[h1n];
+        U[0][h1r][h1c] = bz_cdiv(raw, g.rho[kbeg], g.rrho[kbeg]);
+        if (h1raw) RU[0][h1r - 3][h1c] = raw;
+    }
+    if (h2ok) { if (h2sel) RW[0][h2r][h2c] = h2src[h2n]; else RV[0][h2r][h2c] = h2src[h2n]; }
+    double tcur_raw = ru[n + 3 * sz];
+    double u0cur = (E.mode == 2) ? E.u0[n] : 0.0;
+    __syncthreads();
+
+    double edge = 0.0;
+    int buf = 0;
+    for (int k = kbeg; k < kend; ++k, n += sz) {
+        const ix_t lev1 = (ix_t)(k + 1 - kbeg) * sz;
+        // ---- prefetch for level k+1 (consumed at the end of this iteration / in the next one) ----
+        const double p_h1 = h1ok ? ru[h1n + lev1] : 0.0;
+        const double p_h2 = h2ok ? h2src[h2n + lev1] : 0.0;
+        const double p_rv = rv[n + sz], p_rw = rw[n + 2 * sz];
+        const double p_top = ru[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];
+        const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
+        if (((k - kbeg) & 63) == 0) {
+            const int kk = min(k + tx, kend - 1);
+            edge = flux_x_lean<T3_U>(g, F, ru, ie, jc, kk);
+        }
+        const int src = (k - kbeg) & 63;
+        const double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
+        const double c0 = r[3];
+        const double(*Uk)[TC] = U[buf];
+        // ---- x: flux at centre i ----
+        const double *rur = RU[buf][ty] + tc, *ur = Uk[ty + 3] + tc;
+        const double ax = bz_symm4(Ax * rur[-1], Ax * q0, Ax * rur[1], Ax * rur[2]);
+        const double fx = ax * bz_up5(ur[-2], ur[-1], c0, ur[1], ur[2], ur[3], ax > 0.0);
+        // ---- y: flux at the own low y-face ----
+        const double *rvr = RV[buf][ty] + tc;
+        const double ay = bz_symm4(Ay * rvr[-2], Ay * rvr[-1], Ay * rvr[0], Ay * rvr[1]);
+        const double fy = ay * bz_up5(Uk[ty][tc], Uk[ty + 1][tc], Uk[ty + 2][tc], c0, Uk[ty + 4][tc], Uk[ty + 5][tc], ay > 0.0);
+        FY[buf][ty][tx] = fy;
+        if (ty == 0) {
+            const double *rvt = RV[buf][TY] + tc;
+            const double at = bz_symm4(Ay * rvt[-2], Ay * rvt[-1], Ay * rvt[0], Ay * rvt[1]);
+            FY[buf][TY][tx] = at * bz_up5(Uk[TY][tc], Uk[TY + 1][tc], Uk[TY + 2][tc], Uk[TY + 3][tc], Uk[TY + 4][tc], Uk[TY + 5][tc], at > 0.0);
+        }
+        // ---- z: upper face k+1 ----
+        const double tnew = bz_cdiv(tcur_raw, g.rho[k + 3], g.rrho[k + 3]);
+        const double *rwr = RW[buf][ty] + tc;
+        const double wt = bz_symm4(Az * rwr[-2], Az * rwr[-1], Az * rwr[0], Az * rwr[1]);
+        const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
+        // ---- stage level k+1 from the prefetch registers ----
+        U[buf ^ 1][ty + 3][tc] = r[4];
+        RU[buf ^ 1][ty][tc] = q1;
+        RV[buf ^ 1][ty][tc] = p_rv;
+        RW[buf ^ 1][ty][tc] = p_rw;
+        if (h1ok) {
+            U[buf ^ 1][h1r][h1c] = bz_cdiv(p_h1, g.rho[k + 1], g.rrho[k + 1]);
+            if (h1raw) RU[buf ^ 1][h1r - 3][h1c] = p_h1;
+        }
+        if (h2ok) { if (h2sel) RW[buf ^ 1][h2r][h2c] = p_h2; else RV[buf ^ 1][h2r][h2c] = p_h2; }
+        __syncthreads();
+        {
+            double nb = __shfl_up(fx, 1);
+            const double e = __shfl(edge, src);
+            if (tx == le) nb = e;
+            const double dx = fx - nb;
+            const double dy = FY[buf][ty + 1][tx] - fy;
+            if (store)
+                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out,
+                                           -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo))), q0, n);
+        }
+        fz_lo = fz_hi;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
+        r[5] = tnew;
+        q0 = q1; q1 = q2; q2 = tcur_raw;
+        tcur_raw = p_top; u0cur = p_u0;
         buf ^= 1;
     }
 }

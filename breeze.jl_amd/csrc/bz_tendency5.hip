@@ -92,14 +92,16 @@ int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
         E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
         L.out = G->rho_v;
         const dim3 grid = shape(g.Nz, kc);
-        hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (getenv("BZ_V_GEN5")) hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     {
         ProfileScope ps(ctx, "z_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_w; E.u0_out = U0->rho_w;
         L.out = G->rho_w;
         const dim3 grid = shape(g.Nz - 1, kc);
-        hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (getenv("BZ_W_GEN5")) hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     {
         ProfileScope ps(ctx, "scalar_tendencies+rk3+thermo");

@@ -690,6 +690,156 @@ __global__ __launch_bounds__(64 * TY) void k5_v(DevGrid g, Lean5 L, int kchunk, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// y-momentum, sixth generation (see k6_u): the v tile carries its x halo, so the x-stencil is five ds_reads instead of five loads +
+// five column divisions; ring top and u0 are loaded one level ahead.  Same arithmetic, same bits as k5_v.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TY>
+__global__ __launch_bounds__(64 * TY) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
+{
+    constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles
+    constexpr int TC = 72;                                // v tile with its x halo: columns i0-3 .. i0+65 at offset 3
+    __shared__ double Tv[2][RV][TC];
+    __shared__ double Tm[2][3][RM][64];                   // 0: Ax*rho_u, 1: Ay*rho_v, 2: Az*rho_w at the upper z-face
+    __shared__ double FY[2][TY + 1][64];
+    constexpr int NT = 64 * TY, NFR = 16 * 64, HPT = (NFR + NT - 1) / NT;
+    int bx, by, bz;
+    bz_block5(L, bx, by, bz);
+    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx, tc = tx + 3;
+    const int i0 = bx * 64, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
+    const int nact = min(64, g.Nx - i0);
+    const int ie = i0 + nact, le = nact - 1;              // x flux at x-faces: last lane needs face i0+nact
+    const int kbeg = bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    if (kbeg >= kend) return;
+    const ix_t sz = (ix_t)g.Sxy;
+    const bool store = (i < g.Nx) && (j < g.Ny);
+    const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
+    Tend3Fields F;
+    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
+    const double Az = g.Az;
+    ix_t n = (ix_t)g.idx(ic, jc, kbeg);
+
+    // frame rows: id 0..5 v tile rows {0,1,2,TY+3,TY+4,TY+5}; 6..8 rho_u rows {0,1,TY+2}; 9..12 rho_v rows
+    // {0,1,TY+2,TY+3}; 13..15 rho_w rows {0,1,TY+2}   (momentum-tile row r' <-> grid row j0-2+r').  A frame row is staged by
+    // one wave (id = wave index + TY q), so the source array and the scaling are wave-uniform: kept in scalar registers.
+    bool hok[HPT];
+    int hsel[HPT], hrow[HPT];
+    ix_t hn[HPT];
+    const double *hsrc[HPT];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q) {
+        const int h = t + q * NT;
+        hok[q] = h < NFR;
+        const int id = __builtin_amdgcn_readfirstlane(hok[q] ? (h >> 6) : 0);
+        int sel, row, grow;                                // sel: 0 v, 1 rho_u, 2 rho_v, 3 rho_w
+        if (id < 6) { sel = 0; row = (id < 3) ? id : TY + id; grow = j0 - 3 + row; }
+        else if (id < 9) { sel = 1; const int m = id - 6; row = (m < 2) ? m : TY + 2; grow = j0 - 2 + row; }
+        else if (id < 13) { sel = 2; const int m = id - 9; row = (m < 2) ? m : TY + m; grow = j0 - 2 + row; }
+        else { sel = 3; const int m = id - 13; row = (m < 2) ? m : TY + 2; grow = j0 - 2 + row; }
+        hsel[q] = sel; hrow[q] = row;
+        hsrc[q] = (sel == 1) ? ru : (sel == 3) ? rw : rv;
+        hn[q] = (ix_t)g.idx(min(i0 + tx, g.Nx + 2), min(grow, g.Ny + 2), kbeg) + (sel == 3 ? sz : (ix_t)0);
+    }
+    auto frame_load = [&](int q, ix_t lev) -> double { return hsrc[q][hn[q] + lev]; };   // raw value at the level offset
+    auto frame_store = [&](int b, int q, double raw, int klev) {          // scale / derive and stage for level klev
+        if (hsel[q] == 0) Tv[b][hrow[q]][tc] = bz_cdiv(raw, g.rho[klev], g.rrho[klev]);
+        else Tm[b][hsel[q] - 1][hrow[q]][tx] = ((hsel[q] == 1) ? g.Ax[klev] : (hsel[q] == 2) ? g.Ay[klev] : Az) * raw;
+    };
+
+    // side cells of the own rows (x halo of the v tile: columns i0-3 .. i0-1 and i0+64, i0+65): one cell for the first 5 TY threads
+    const bool sok = t < 5 * TY;
+    const int srow = sok ? t / 5 : 0, scc = sok ? t % 5 : 0, scol = (scc < 3) ? scc : 64 + scc;
+    const ix_t sn = (ix_t)g.idx(min(i0 - 3 + scol, g.Nx + 2), min(j0 + srow, g.Ny + 2), kbeg);
+
+    double r[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) r[s] = bz_cdiv(rv[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
+    double fz_lo = vflux<T3_V>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
+    // raw rho_v of the own column at levels k .. k+2 (the ring-top load of level k+3 enters at the end of each iteration)
+    double q0 = rv[n], q1 = rv[n + sz], q2 = rv[n + 2 * sz];
+    Tv[0][ty + 3][tc] = r[3];
+    if (sok) Tv[0][srow + 3][scol] = bz_cdiv(rv[sn], g.rho[kbeg], g.rrho[kbeg]);
+    Tm[0][0][ty + 2][tx] = g.Ax[kbeg] * ru[n];
+    Tm[0][1][ty + 2][tx] = g.Ay[kbeg] * q0;
+    Tm[0][2][ty + 2][tx] = Az * rw[n + sz];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q)
+        if (hok[q]) frame_store(0, q, frame_load(q, 0), kbeg);
+    __syncthreads();
+
+    double tcur_raw = rv[n + 3 * sz];
+    double u0cur = (E.mode == 2) ? E.u0[n] : 0.0;
+    double edge = 0.0;
+    int buf = 0;
+    for (int k = kbeg; k < kend; ++k, n += sz) {
+        const ix_t lev = (ix_t)(k + 1 - kbeg) * sz;
+        double hnext[HPT];
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? frame_load(q, lev) : 0.0;
+        const double p_side = sok ? rv[sn + lev] : 0.0;
+        const double p_top = rv[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];
+        const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
+        const double tnew_raw = tcur_raw, u0v = u0cur;
+        const double ru_n = g.Ax[k + 1] * ru[n + sz], rw_n = Az * rw[n + 2 * sz];
+        if (((k - kbeg) & 63) == 0) {
+            const int kk = min(k + tx, kend - 1);
+            edge = flux_x_lean<T3_V>(g, F, rv, ie, jc, kk);
+        }
+        const int src = (k - kbeg) & 63;
+        const double rho = g.rho[k], rrho = g.rrho[k];
+        const double c0 = r[3];
+        const double(*V)[TC] = Tv[buf];
+        const double *vrow = V[ty + 3] + tc;
+        const double(*MU)[64] = Tm[buf][0];
+        const double(*MV)[64] = Tm[buf][1];
+        const double(*MW)[64] = Tm[buf][2];
+        // ---- x: flux at (x-face i, y-face j): rho_u rows j-2..j+1, v x-stencil derived from the rho_v row ----
+        const double ut = bz_symm4(MU[ty][tx], MU[ty + 1][tx], MU[ty + 2][tx], MU[ty + 3][tx]);
+        const double fx = ut * bz_up5(vrow[-3], vrow[-2], vrow[-1], c0, vrow[1], vrow[2], ut > 0.0);
+        // ---- y: flux at centre j: rho_v rows j-1..j+2, v rows j-2..j+3 ----
+        const double vt = bz_symm4(MV[ty + 1][tx], MV[ty + 2][tx], MV[ty + 3][tx], MV[ty + 4][tx]);
+        const double fy = vt * bz_up5(V[ty + 1][tc], V[ty + 2][tc], c0, V[ty + 4][tc], V[ty + 5][tc], V[ty + 6][tc], vt > 0.0);
+        FY[buf][ty + 1][tx] = fy;
+        if (ty == 0) {       // centre j0-1: rho_v rows j0-2..j0+1, v rows j0-3..j0+2
+            const double vb = bz_symm4(MV[0][tx], MV[1][tx], MV[2][tx], MV[3][tx]);
+            FY[buf][0][tx] = vb * bz_up5(V[0][tc], V[1][tc], V[2][tc], V[3][tc], V[4][tc], V[5][tc], vb > 0.0);
+        }
+        // ---- z: advecting flux at (y-face j, z-face k+1) from the rho_w tile rows j-2..j+1 ----
+        const double tnew = bz_cdiv(tnew_raw, g.rho[k + 3], g.rrho[k + 3]);
+        const double wt = bz_symm4(MW[ty][tx], MW[ty + 1][tx], MW[ty + 2][tx], MW[ty + 3][tx]);
+        const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
+        // ---- stage level k+1 ----
+        Tv[buf ^ 1][ty + 3][tc] = r[4];
+        if (sok) Tv[buf ^ 1][srow + 3][scol] = bz_cdiv(p_side, g.rho[k + 1], g.rrho[k + 1]);
+        Tm[buf ^ 1][0][ty + 2][tx] = ru_n;
+        Tm[buf ^ 1][1][ty + 2][tx] = g.Ay[k + 1] * q1;
+        Tm[buf ^ 1][2][ty + 2][tx] = rw_n;
+#pragma unroll
+        for (int q = 0; q < HPT; ++q)
+            if (hok[q]) frame_store(buf ^ 1, q, hnext[q], k + 1);
+        __syncthreads();
+        {
+            double nb = __shfl_down(fx, 1);
+            const double e = __shfl(edge, src);
+            if (tx == le) nb = e;
+            const double dx = nb - fx;
+            const double dy = fy - FY[buf][ty][tx];
+            if (store)
+                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out,
+                                       -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo))), q0, n);
+        }
+        fz_lo = fz_hi;
+        q0 = q1; q1 = q2; q2 = tnew_raw;
+        tcur_raw = p_top; u0cur = p_u0;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
+        r[5] = tnew;
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // z-momentum: k_w_tend_lds<TY, 0> with w = rho_w / Iz(rho_r)(k) derived at staging time and the anelastic buoyancy from the
 // temperature the scalar kernel of the previous stage (or the full diagnosis at the end of the previous step) left for the
 // stage-start state, q = rho q / rho_r.
@@ -832,6 +982,144 @@ __global__ __launch_bounds__(64 * TY) void k5_w(DevGrid g, Lean5 L, int kchunk, 
         for (int s = 0; s < 3; ++s) { qu[s] = qu[s + 1]; qv[s] = qv[s + 1]; qt[s] = qt[s + 1]; qw[s] = qw[s + 1]; }
         qu[3] = qun; qv[3] = qvn; qt[3] = qtn; qw[3] = qwnew;
         raw5 = wnew_raw;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) wr[s] = wr[s + 1];
+        wr[5] = wnew;
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// z-momentum, sixth generation (see k6_u): the w tile carries its x halo (70 columns), so the x-stencil is five ds_reads instead of
+// five loads + five column divisions; the ring top, the own T / rho q values and u0 are loaded one level ahead; the raw rho_w of the
+// own column rides a register delay line (advecting-flux ring and RK update).  Same arithmetic, same bits as k5_w.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TY>
+__global__ __launch_bounds__(64 * TY) void k6_w(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
+{
+    constexpr int TR = TY + 6, TC = 72, NT = 64 * TY, NH = TR * 70 - TY * 64;
+    static_assert(NH <= NT, "one frame cell per thread");
+    __shared__ double T[2][TR][TC];
+    __shared__ double FY[2][TY + 1][64];
+    int bx, by, bz;
+    bz_block5(L, bx, by, bz);
+    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx, tc = tx + 3;
+    const int i0 = bx * 64, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
+    const int nact = min(64, g.Nx - i0);
+    const int ie = i0 + nact, le = nact - 1;
+    const int kbeg = 1 + bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    if (kbeg >= kend) return;
+    const ix32_t sz = (ix32_t)g.Sxy;
+    const bool store = (i < g.Nx) && (j < g.Ny);
+    const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
+    const double *__restrict__ pa = L.T, *__restrict__ pb = L.pb;       // temperature, rho q of the stage-start state
+    Tend3Fields F;
+    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
+    const double Az = g.Az;
+    ix32_t n = (ix32_t)g.idx(ic, jc, kbeg);
+    const bool hok = t < NH;
+    int hr = 0, hc = 0;
+    {
+        const int h = hok ? t : 0;
+        if (h < 6 * 70) { const int rr = h / 70; hc = h - rr * 70; hr = (rr < 3) ? rr : TY + rr; }
+        else { const int hh = h - 6 * 70, rr = hh / 6, cc = hh - rr * 6; hr = 3 + rr; hc = (cc < 3) ? cc : 64 + cc; }
+    }
+    const ix32_t hn = (ix32_t)g.idx(min(i0 - 3 + hc, g.Nx + 2), min(j0 - 3 + hr, g.Ny + 2), kbeg);
+    const ix32_t ntop0 = (ix32_t)g.idx(ic, min(j0 + TY, g.Ny), kbeg);
+    const bool top = (ty == 0);
+
+    double wr[6], qu[4], qv[4], qt[4], qw[4];       // qt: rho_v ring of the row above the tile (wave 0 only)
+    double raw0 = 0.0, raw1 = 0.0, raw2 = 0.0;      // raw rho_w of the own column at levels k, k+1, k+2
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const double x = rw[n + s * sz - 3 * sz];
+        wr[s] = bz_cdiv(x, g.rho_f[kbeg + s - 3], g.rrho_f[kbeg + s - 3]);
+        if (s >= 1 && s <= 4) qw[s - 1] = Az * x;   // levels kbeg-2 .. kbeg+1
+        if (s == 3) raw0 = x;
+        if (s == 4) raw1 = x;
+        if (s == 5) raw2 = x;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int kk = kbeg - 2 + s;
+        qu[s] = g.Ax[kk] * ru[n + s * sz - 2 * sz];
+        qv[s] = g.Ay[kk] * rv[n + s * sz - 2 * sz];
+        qt[s] = top ? g.Ay[kk] * rv[ntop0 + s * sz - 2 * sz] : 0.0;
+    }
+    double fz_lo, b_lo;
+    {
+        const int B = bz_buffer_center(kbeg - 1, g.Nz);
+        const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
+        fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
+        b_lo = buoyancy5(g, pa[n - sz], pb[n - sz], kbeg - 1);
+    }
+    T[0][ty + 3][tc] = wr[3];
+    if (hok) T[0][hr][hc] = bz_cdiv(rw[hn], g.rho_f[kbeg], g.rrho_f[kbeg]);
+    double tcur_raw = rw[n + 3 * sz];
+    double u0cur = (E.mode == 2) ? E.u0[n] : 0.0;
+    __syncthreads();
+
+    double edge = 0.0;
+    int buf = 0;
+    for (int k = kbeg; k < kend; ++k, n += sz) {
+        const ix32_t lev = (ix32_t)(k - kbeg) * sz;
+        // ---- prefetch for level k+1 ----
+        const double p_h = hok ? rw[hn + lev + sz] : 0.0;
+        const double p_top = rw[n + ((k + 4 <= g.Nz + g.Hz) ? 4 * sz : 3 * sz)];
+        const double Tcur = pa[n], rqcur = pb[n];          // consumed mid-level (buoyancy): not worth two more registers each
+        const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
+        const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
+        const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];
+        const double qtn = top ? Ayn * rv[ntop0 + lev + 2 * sz] : 0.0;
+        if (((k - kbeg) & 63) == 0) {
+            const int kk = min(k + tx, kend - 1);
+            edge = flux_x_lean<T3_W>(g, F, rw, ie, jc, kk);
+        }
+        const int src = (k - kbeg) & 63;
+        const int Bf = bz_buffer_face(k, g.Nz);
+        const double w0 = wr[3];
+        const double qwnew = Az * raw2;
+        const double(*Tk)[TC] = T[buf];
+        const double *wrow = Tk[ty + 3] + tc;
+        const double ut = (Bf == 3) ? bz_symm4(qu[0], qu[1], qu[2], qu[3]) : bz_symm2(qu[1], qu[2]);
+        const double fx = ut * bz_up5(wrow[-3], wrow[-2], wrow[-1], w0, wrow[1], wrow[2], ut > 0.0);
+        const double vt = (Bf == 3) ? bz_symm4(qv[0], qv[1], qv[2], qv[3]) : bz_symm2(qv[1], qv[2]);
+        const double fy = vt * bz_up5(Tk[ty][tc], Tk[ty + 1][tc], Tk[ty + 2][tc], w0, Tk[ty + 4][tc], Tk[ty + 5][tc], vt > 0.0);
+        FY[buf][ty][tx] = fy;
+        if (top) {
+            const double v2 = (Bf == 3) ? bz_symm4(qt[0], qt[1], qt[2], qt[3]) : bz_symm2(qt[1], qt[2]);
+            FY[buf][TY][tx] = v2 * bz_up5(Tk[TY][tc], Tk[TY + 1][tc], Tk[TY + 2][tc], Tk[TY + 3][tc], Tk[TY + 4][tc], Tk[TY + 5][tc], v2 > 0.0);
+        }
+        const double wnew = bz_cdiv(tcur_raw, g.rho_f[k + 3], g.rrho_f[k + 3]);
+        double fz_hi;
+        {
+            const int B = bz_buffer_center(k, g.Nz);
+            const double wt = (B == 3) ? bz_symm4(qw[1], qw[2], qw[3], qwnew) : bz_symm2(qw[2], qw[3]);
+            fz_hi = wt * bz_upB(wr[1], wr[2], wr[3], wr[4], wr[5], wnew, wt > 0.0, B);
+        }
+        const double b_hi = buoyancy5(g, Tcur, rqcur, k);
+        T[buf ^ 1][ty + 3][tc] = wr[4];
+        if (hok) T[buf ^ 1][hr][hc] = bz_cdiv(p_h, g.rho_f[k + 1], g.rrho_f[k + 1]);
+        __syncthreads();
+        {
+            double nb = __shfl_down(fx, 1);
+            const double e = __shfl(edge, src);
+            if (tx == le) nb = e;
+            const double dx = nb - fx;
+            const double dy = FY[buf][ty + 1][tx] - fy;
+            const double adv = -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo)));
+            if (store)
+                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out, adv + 0.5 * (b_lo + b_hi), raw0, n);
+        }
+        fz_lo = fz_hi;
+        b_lo = b_hi;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { qu[s] = qu[s + 1]; qv[s] = qv[s + 1]; qt[s] = qt[s + 1]; qw[s] = qw[s + 1]; }
+        qu[3] = qun; qv[3] = qvn; qt[3] = qtn; qw[3] = qwnew;
+        raw0 = raw1; raw1 = raw2; raw2 = tcur_raw;
+        tcur_raw = p_top; u0cur = p_u0;
 #pragma unroll
         for (int s = 0; s < 5; ++s) wr[s] = wr[s + 1];
         wr[5] = wnew;

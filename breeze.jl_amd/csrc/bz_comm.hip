@@ -486,7 +486,7 @@ static int exchange_phi_below(bz_ctx *ctx)
 // compute_pressure_correction! + make_pressure_correction! + the diagnosis, from the momentum in `s` (predictor == nullptr) or from
 // the predictor arrays; lean: momentum-only projection (stages whose diagnostics nobody reads)
 static int dist_projection(bz_ctx *ctx, const bz_state *s, const bz_prognostic *predictor, double dt, bool lean, double *oa, double *ob,
-                           const double *rtheta_in, const double *rq_in)
+                           const double *rtheta_in, const double *rq_in, bool join_side = false)
 {
     BzComm *c = ctx->comm;
     const DevGrid &g = ctx->dg;
@@ -500,6 +500,7 @@ static int dist_projection(bz_ctx *ctx, const bz_state *s, const bz_prognostic *
     if ((rc = bzi_poisson_source_fused(ctx, s, dt, c->rhs, predictor))) return rc;
     if ((rc = dist_poisson(ctx))) return rc;
     if ((rc = exchange_phi_below(ctx))) return rc;
+    if (join_side) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the scalar-pair kernel of this stage has finished
     if (lean) return bzi_project_lean(ctx, s, dt, c->rhs, c->phi_below, predictor, oa, ob);
     return bzi_project_diagnose(ctx, s, dt, c->rhs, c->phi_below, predictor, true, rtheta_in, rq_in);
 }
@@ -556,14 +557,28 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         const bool from_state = (stage != 1);
         const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
         double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
+        // The scalar-pair kernel feeds nothing of the pressure solve: with messages in flight (W > 1) it runs on the context's second
+        // stream beside the source term, the transforms and both all-to-alls, and is joined before the projection kernel.
+        const bool fork = (c->W > 1 || c->self_messages || ctx->side_scalar) && !getenv("BZ_COMM_NO_SIDE_SCALAR");
+        const int first_part = fork ? 1 : 3;
         if (c->halo_pending) {
             // the halos of the stage-start state are still travelling on the side stream: interior tile rows first
-            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 1))) return rc;
+            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 1, first_part))) return rc;
             BZ_HIP(hipStreamWaitEvent(ctx->stream, c->ev_side, 0));
             c->halo_pending = false;
-            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 2))) return rc;
-        } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0))) return rc;
-        if ((rc = dist_projection(ctx, s, G, alpha * dt, stage < 2, oa, ob, G->rho_theta, G->rho_q))) return rc;
+            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 2, first_part))) return rc;
+        } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, first_part))) return rc;
+        if (fork) {
+            BZ_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            BZ_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+            hipStream_t keep = ctx->stream;
+            ctx->stream = ctx->side_stream;
+            rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 2);
+            ctx->stream = keep;
+            if (rc) return rc;
+            BZ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+        }
+        if ((rc = dist_projection(ctx, s, G, alpha * dt, stage < 2, oa, ob, G->rho_theta, G->rho_q, fork))) return rc;
         // halos of the new state.  After stage 3 rho theta / rho q are back in `s` and the diagnostics are current: exchange them too,
         // so that every field of `s` is what the per-operator sequence leaves
         double *na = (stage < 2) ? oa : s->rho_theta, *nb = (stage < 2) ? ob : s->rho_q;

@@ -272,6 +272,9 @@ struct bz_ctx {
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
     bool lean = true;                 // whole-step seam on prognostic-only kernels (bz_tendency5_kernels.h; BZ_NO_LEAN=1 disables)
     bool lean_xcd = true;             // XCD-contiguous block order of the lean kernels (BZ_NO_XCD=1 disables)
+    hipStream_t side_stream = nullptr;   // the scalar-pair kernel of a stage runs here, beside the pressure solve on the main stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_scalar = false;         // BZ_SIDE_SCALAR=1: single-GPU seam too (the distributed step does it whenever W > 1)
     double *d_pi_dry = nullptr;       // (p_r[k]/p_st)^(Rd/cpd), k = -Hz .. Nz+Hz-1: Exner factor of a dry cell, built with the device pow()
     // CompressibleDynamics + SplitExplicitTimeDiscretization (bz_create_compressible)
     bool compressible = false;
@@ -386,7 +389,7 @@ int bzi_project_lean(bz_ctx *ctx, const bz_state *s, double dt, const double *ph
                      const bz_prognostic *predictor, double *sa, double *sb);
 // lean whole-step tendencies (bz_tendency5.hip): prognostic-only inputs, rho theta / rho q advance from (pa, pb) into (oa, ob)
 int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
-                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows = 0);
+                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows = 0, int which = 3);
 int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                             double alpha, bool first);
 int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants, const bz_reference_state *ref,

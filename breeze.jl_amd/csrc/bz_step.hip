@@ -50,9 +50,22 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
             const bool from_state = (stage != 1);
             const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
             double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
-            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0))) return rc;
+            if (ctx->side_scalar) {
+                // the scalar-pair kernel feeds nothing of the pressure solve: it runs on the side stream beside the source term,
+                // the transforms and the Thomas solve (issue-bound stencil kernel next to bandwidth-bound streaming kernels)
+                if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 1))) return rc;
+                BZ_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+                BZ_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+                hipStream_t keep = ctx->stream;
+                ctx->stream = ctx->side_stream;
+                rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 2);
+                ctx->stream = keep;
+                if (rc) return rc;
+                BZ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
+            } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0))) return rc;
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
+            if (ctx->side_scalar) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             if (stage < 2) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
             else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, G->rho_theta, G->rho_q);
             if (rc) return rc;

@@ -288,4 +288,44 @@ function OceananigansTimeSteppers.update_state!(model::HIPAcousticModel, callbac
     return nothing
 end
 
+
+#####
+##### Multi-GPU: one process per GPU, y-slabs, the communicator lives inside libbreeze_hip (bz_comm.hip)
+#####
+##### The rank-local RectilinearGrid is this rank's y-slab of the global (Periodic, Periodic, Bounded) domain.  MPI.jl (or any
+##### launcher) is used for exactly two things: starting the ranks and broadcasting RCCL's 128-byte unique id.
+#####
+
+const BZ_UNIQUE_ID_BYTES = 128
+
+"Create the slab context of this rank and attach the RCCL communicator to it."
+function slab_context!(model, y_nranks::Integer, y_rank::Integer, bcast_bytes!::Function)
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    grid, constants, reference = bz_grid(model.grid), bz_constants(model), bz_reference_state(model)
+    rc = ccall((:bz_create_slab, libbreeze_hip), Cint,
+               (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzReferenceState}, Cint, Cint, Cint),
+               ctx, grid, constants, reference, 5, y_nranks, y_rank)
+    rc == 0 || error("bz_create_slab failed with code $rc")
+    id = zeros(UInt8, BZ_UNIQUE_ID_BYTES)
+    if y_rank == 0
+        rc = ccall((:bz_comm_unique_id, libbreeze_hip), Cint, (Ptr{UInt8},), id)
+        rc == 0 || error("bz_comm_unique_id failed with code $rc")
+    end
+    bcast_bytes!(id)                     # e.g. id -> MPI.Bcast!(id, 0, MPI.COMM_WORLD)
+    rc = ccall((:bz_comm_init_rccl, libbreeze_hip), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx[], id)
+    rc == 0 || error(unsafe_string(ccall((:bz_last_error, libbreeze_hip), Cstring, (Ptr{Cvoid},), ctx[])))
+    return ctx[]
+end
+
+"set!(model; ...) on slabs ends with update_state! + halo exchange + the initial projection, all inside the library."
+function finish_set!(model, ctx; enforce_mass_conservation = true)
+    rc = ccall((:bz_comm_update_state_and_project, libbreeze_hip), Cint,
+               (Ptr{Cvoid}, Ref{BzState}, Ref{BzPrognostic}, Cdouble, Cint),
+               ctx, state(model), prognostic(model.timestepper.Gⁿ), 1.0, enforce_mass_conservation ? 1 : 0)
+    rc == 0 || error(unsafe_string(ccall((:bz_last_error, libbreeze_hip), Cstring, (Ptr{Cvoid},), ctx)))
+    return nothing
+end
+
+# time_step! needs no distributed method: bz_time_step_anelastic on a slab context with a communicator is the distributed step.
+
 end # module

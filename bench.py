@@ -54,6 +54,13 @@ WORDS_PER_CELL = {
     # projection of stages 1-2 is make_pressure_correction alone (7).  Per stage: 24 + 11 + 11 + 13 + 7 + Poisson 14 = 80, as before.
     "x_momentum_tendency+rk3+velocity": 11, "y_momentum_tendency+rk3+velocity": 11, "z_momentum_tendency+rk3+velocity": 13,
     "scalar_tendencies+rk3+thermo": 24, "project_momentum": 7,
+    # chunked Poisson pipeline (level ranges go source -> x -> y transforms, and y -> x -> projection, back to back)
+    "poisson_source_term+fft_forward": 8, "poisson_fft_inverse+project_momentum": 11,
+    "poisson_fft_inverse+project_and_diagnose": 22,
+    # hand-written x transforms (bz_xfft_kernels.h): source term inside the forward x pass (4 + 2), y passes and the vertical
+    # solves on the transposed spectrum (2 each), momentum projection inside the inverse x pass (2 + 7)
+    "poisson_source_term+fft_x": 6, "poisson_fft_y_forward": 2, "poisson_fft_y_inverse": 2,
+    "poisson_fft_x+project_momentum": 9, "poisson_fft_x_inverse": 2,
 }
 A_STEP_WORDS = 250          # 3 stages x 80 + 10
 METRIC = "grid-cells advanced/sec (tendency+Poisson step), 512^3 anelastic"
@@ -507,6 +514,7 @@ def run_rank(args):
                               "frac": step_achieved / HBM_PEAK_GBS, "per": "GPU",
                               "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 8},
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(kernels.items())},
+            "kernel_launches_per_step": {k: v["launches"] / args.steps for k, v in sorted(kernels.items())},
             "finite": finite,
         }
         if use_slabs:

@@ -7,7 +7,7 @@
 
 ProfileScope::ProfileScope(bz_ctx *c, const char *name) : ctx(c)
 {
-    if (!ctx->profiling) return;
+    if (!ctx->profiling || ctx->profile_mute) return;
     for (size_t s = 0; s < ctx->slots.size(); ++s)
         if (ctx->slots[s].name == name || std::strcmp(ctx->slots[s].name, name) == 0) slot = (int)s;
     if (slot < 0) {

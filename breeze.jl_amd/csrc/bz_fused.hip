@@ -52,9 +52,9 @@ __global__ __launch_bounds__(256) void k_rk3_rows(DevGrid g, RKFieldsW F, double
 __global__ __launch_bounds__(256) void k_poisson_source_rows(DevGrid g, double *__restrict__ rhs,
                                                              const double *__restrict__ ru,
                                                              const double *__restrict__ rv,
-                                                             const double *__restrict__ rw, double dt)
+                                                             const double *__restrict__ rw, double dt, int k0)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z + k0;
     if (i >= g.Nx) return;
     // periodic neighbours by wrap indexing: momentum halos need not be current here
     const long long ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx;
@@ -98,12 +98,13 @@ struct PDFields {
     const double *phi_c;                    // in: contiguous Nx*Ny*Nz, zero-mean solution
     const double *phi_below;                // y-slab only: phi of row j = -1 (neighbour rank), layout [k][i]
     int store_phi;                          // 0: skip the scatter into pressure_anomaly (stages whose phi nobody reads)
+    int k0;                                 // first level of this launch (the chunked Poisson pipeline launches level ranges)
 };
 
 template <int SA>       // 0: no microphysics, 1: warm-phase saturation adjustment, 2: Kessler condensate species
 __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F, double dt)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z + F.k0;
     if (i >= g.Nx) return;
     const long long sz = g.Sxy;
     // periodic images of this column in the halo (requires Nx >= 2Hx, Ny >= 2Hy: at most one per direction)
@@ -214,10 +215,11 @@ struct PLFields {
     const double *phi_c;
     const double *phi_below;
     double *sa, *sb;             // rho theta, rho q just advanced by the lean scalar kernel (interior): their periodic images are stored here
+    int k0;                      // first level of this launch
 };
 __global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, double dt)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z + F.k0;
     if (i >= g.Nx) return;
     const long long sz = g.Sxy;
     const long long ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
@@ -254,6 +256,47 @@ __global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, dou
     }
 }
 
+#include "bz_xfft_kernels.h"
+
+static size_t xf_lds_bytes(int n2) { return ((size_t)XF_RB * (XF_P(n2) + 1) + 3 * n2 / 2) * sizeof(double2); }
+static int xf_chunk(const char *env, int dflt, int Nz)
+{
+    int kc = dflt;
+    if (const char *e = getenv(env)) { const int v = atoi(e); if (v > 0) kc = v; }
+    return kc < Nz ? kc : Nz;
+}
+
+// x transform of the rows of the source term into the transposed half spectrum ctx->d_hat; predictor != nullptr (or s != nullptr):
+// the source term is evaluated on the fly from that momentum, else the rows come from ctx->d_rhs
+int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor)
+{
+    const DevGrid &g = ctx->dg;
+    const int n2 = g.Nx / 2, kc = xf_chunk("BZ_XF_KCHUNK_F", 16, g.Nz);
+    const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
+    const size_t lds = xf_lds_bytes(n2);
+    if (s || predictor)
+        hipLaunchKernelGGL(k_x_forward<1>, grid, block, lds, ctx->stream, g, (const double *)nullptr,
+                           predictor ? predictor->rho_u : s->rho_u, predictor ? predictor->rho_v : s->rho_v,
+                           predictor ? predictor->rho_w : s->rho_w, dt, (double2 *)ctx->d_hat, (const double2 *)ctx->d_wtab, kc);
+    else
+        hipLaunchKernelGGL(k_x_forward<0>, grid, block, lds, ctx->stream, g, (const double *)ctx->d_rhs, (const double *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr, dt, (double2 *)ctx->d_hat, (const double2 *)ctx->d_wtab, kc);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// inverse x transform of the transposed half spectrum: phi into ctx->d_rhs
+int bzi_xf_inverse(bz_ctx *ctx)
+{
+    const DevGrid &g = ctx->dg;
+    const int n2 = g.Nx / 2, kc = xf_chunk("BZ_XF_KCHUNK_I", 16, g.Nz);
+    const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
+    hipLaunchKernelGGL(k_x_inverse, grid, block, xf_lds_bytes(n2), ctx->stream, g, (const double2 *)ctx->d_hat, ctx->d_rhs,
+                       (const double2 *)ctx->d_wtab, kc);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
 // NOTE (y-slab mode): the periodic images stored by k_project_diagnose cover x and z only; the caller exchanges
 // the y halos of the fields the tendencies read (bz_* slab entry points in bz_slab.hip).
 int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
@@ -279,10 +322,11 @@ int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "poisson_source_term");
-    dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+    const int k0 = ctx->krn ? ctx->kr0 : 0, nk = ctx->krn ? ctx->krn : g.Nz;      // level range (chunked Poisson pipeline) or all
+    dim3 grid((g.Nx + 255) / 256, g.Ny, nk), block(256);
     hipLaunchKernelGGL(k_poisson_source_rows, grid, block, 0, ctx->stream, g, rhs ? rhs : ctx->d_rhs,
                        predictor ? predictor->rho_u : s->rho_u, predictor ? predictor->rho_v : s->rho_v,
-                       predictor ? predictor->rho_w : s->rho_w, dt);
+                       predictor ? predictor->rho_w : s->rho_w, dt, k0);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -298,7 +342,8 @@ int bzi_project_lean(bz_ctx *ctx, const bz_state *s, double dt, const double *ph
     F.phi_c = phi_c ? phi_c : ctx->d_rhs;
     F.phi_below = phi_below;
     F.sa = sa; F.sb = sb;
-    dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+    F.k0 = ctx->krn ? ctx->kr0 : 0;
+    dim3 grid((g.Nx + 255) / 256, g.Ny, ctx->krn ? ctx->krn : g.Nz), block(256);
     hipLaunchKernelGGL(k_project_lean, grid, block, 0, ctx->stream, g, F, dt);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
@@ -320,7 +365,8 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double
     F.phi_c = phi_c ? phi_c : ctx->d_rhs;
     F.phi_below = phi_below;
     F.store_phi = store_phi ? 1 : 0;
-    dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
+    F.k0 = ctx->krn ? ctx->kr0 : 0;
+    dim3 grid((g.Nx + 255) / 256, g.Ny, ctx->krn ? ctx->krn : g.Nz), block(256);
     if (g.microphysics == 2)
         hipLaunchKernelGGL((k_project_diagnose<2>), grid, block, 0, ctx->stream, g, F, dt);
     else if (g.microphysics == 1)

@@ -251,6 +251,16 @@ struct bz_ctx {
     int NXH = 0;                      // Nx/2+1
     hipfftHandle plan_fwd = 0, plan_inv = 0;
     bool plans_ok = false;
+    // chunked Poisson pipeline (bz_poisson.hip): 2-D plans over `pchunk` levels, so that source term -> x transform -> y transform
+    // (and y -> x -> projection on the way back) of one level range run back to back while the range sits in the 256 MiB Infinity Cache
+    hipfftHandle plan_fwd_c = 0, plan_inv_c = 0;
+    int pchunk = 0;
+    int kr0 = 0, krn = 0;            // level range of the next source / projection launch (krn = 0: all levels)
+    // hand-written x transforms with a transposed (ky-fastest) half spectrum (bz_xfft_kernels.h)
+    bool xf = false;
+    void *d_wtab = nullptr;          // exp(-2 pi i t / Nx), t < 3 Nx / 4
+    hipfftHandle plan_y = 0;         // contiguous batched 1-D transform along y of the transposed spectrum
+    int profile_mute = 0;            // > 0: ProfileScope objects record nothing (an enclosing scope covers the launches)
     // y-slab mode: 1-D batched plans of the distributed transform (bz_slab_transform, created on first use)
     hipfftHandle slab_plan_x_fwd = 0, slab_plan_x_inv = 0, slab_plan_y = 0;
     bool slab_plans_ok = false;
@@ -376,6 +386,10 @@ void bzi_lean_teardown(bz_ctx *ctx);
 void bzi_poisson_teardown(bz_ctx *ctx);
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);
 int bzi_poisson_spectral(bz_ctx *ctx);
+int bzi_fft_chunk(bz_ctx *ctx, int k0, bool forward);
+int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor);
+int bzi_xf_inverse(bz_ctx *ctx);
+int bzi_xf_y(bz_ctx *ctx, bool forward);
 int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column);
 // fused streaming kernels (bz_fused.hip)
 int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,

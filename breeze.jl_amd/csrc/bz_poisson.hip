@@ -290,7 +290,7 @@ int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_
         const int Nz = ctx->dg.Nz;
         TriCols C{d_cols, d_cols + Nz, d_cols + 2 * Nz, d_cols + 3 * Nz, d_cols + 3 * Nz + nxh_real};
         hipLaunchKernelGGL(k_tridiag_coop, dim3((unsigned)(plane / TCO_COLS)), dim3(TCO_COLS * TCO_SEGS), 0, ctx->stream, ctx->NXH, Ny, Nz,
-                           ctx->kx0, nxh_real, ctx->slab_mode ? 1 : 0, C, (double2 *)hat, scale, mean_column);
+                           ctx->kx0, nxh_real, (ctx->slab_mode || ctx->xf) ? 1 : 0, C, (double2 *)hat, scale, mean_column);
     } else {
         hipLaunchKernelGGL(k_tridiag_solve, dim3((unsigned)((plane + 63) / 64)), dim3(64), 0, ctx->stream, ctx->NXH, Ny, ctx->dg.Nz,
                            ctx->d_lower, ctx->d_ibeta, ctx->d_tfac, (double2 *)hat, scale, mean_column);
@@ -313,6 +313,9 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     const int Nx = g.Nx, Nz = g.Nz, Hz = g.Hz;
     const bool slab = ctx->slab_mode;
     const int nxh_real = Nx / 2 + 1;
+    // hand-written x transforms + transposed spectrum: Nx a power of two in [16, 512] (one team of Nx / 8 <= 64 threads per row, 8 rows per
+    // workgroup in 45 KiB of LDS)
+    ctx->xf = !slab && Nx >= 16 && Nx <= 512 && (Nx & (Nx - 1)) == 0 && g.Ny % 8 == 0 && g.wrap_y && !getenv("BZ_NO_XFFT");
     int Ny = g.Ny;                       // rows of the spectral block: local rows, or ALL rows in slab mode
     if (slab) {
         ctx->nkx = (nxh_real + ctx->y_nranks - 1) / ctx->y_nranks;
@@ -363,7 +366,7 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
 
     TriCols C{ctx->d_lower, d_diag0, d_mass, d_lx, d_ly};
     long long plane = (long long)ctx->NXH * Ny;
-    hipLaunchKernelGGL(k_tridiag_setup, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, 0, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, slab ? 1 : 0, C,
+    hipLaunchKernelGGL(k_tridiag_setup, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, 0, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, (slab || ctx->xf) ? 1 : 0, C,
                        ctx->d_ibeta, ctx->d_tfac);
     BZ_HIP(hipGetLastError());
     BZ_HIP(hipDeviceSynchronize());
@@ -371,11 +374,48 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     if (slab) return BZ_OK;          // horizontal transforms are the caller's (distributed) in slab mode
     // ---- rocFFT plans: 2-D (y,x) transforms batched over z ----
     int n[2] = {Ny, Nx};
-    BZ_FFT(hipfftPlanMany(&ctx->plan_fwd, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, Nz));
-    BZ_FFT(hipfftPlanMany(&ctx->plan_inv, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, Nz));
-    ctx->plans_ok = true;
-    BZ_FFT(hipfftSetStream(ctx->plan_fwd, ctx->stream));
-    BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
+    if (!ctx->xf) {
+        BZ_FFT(hipfftPlanMany(&ctx->plan_fwd, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, Nz));
+        BZ_FFT(hipfftPlanMany(&ctx->plan_inv, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, Nz));
+        ctx->plans_ok = true;
+        BZ_FFT(hipfftSetStream(ctx->plan_fwd, ctx->stream));
+        BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
+    }
+    if (ctx->xf) {
+        const int nw = 3 * Nx / 4;
+        std::vector<double> w(2 * (size_t)nw);
+        for (int t = 0; t < nw; ++t) {
+            const double a = (double)(2.0 * pi * (double)t / (double)Nx);
+            w[2 * t] = std::cos(a);
+            w[2 * t + 1] = -std::sin(a);
+        }
+        BZ_HIP(hipMalloc(&ctx->d_wtab, w.size() * sizeof(double)));
+        BZ_HIP(hipMemcpy(ctx->d_wtab, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+        int ny[1] = {Ny};
+        BZ_FFT(hipfftPlanMany(&ctx->plan_y, 1, ny, ny, 1, Ny, ny, 1, Ny, HIPFFT_Z2Z, ctx->NXH * Nz));
+        BZ_FFT(hipfftSetStream(ctx->plan_y, ctx->stream));
+    }
+    // chunk plans of the L3-resident pipeline
+    int ch = 0;
+    if (const char *e = getenv("BZ_POISSON_CHUNK")) ch = atoi(e);
+    if (ch > 0 && ch < Nz && Nz % ch == 0 && !ctx->xf) {
+        BZ_FFT(hipfftPlanMany(&ctx->plan_fwd_c, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, ch));
+        BZ_FFT(hipfftPlanMany(&ctx->plan_inv_c, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, ch));
+        BZ_FFT(hipfftSetStream(ctx->plan_fwd_c, ctx->stream));
+        BZ_FFT(hipfftSetStream(ctx->plan_inv_c, ctx->stream));
+        ctx->pchunk = ch;
+    }
+    return BZ_OK;
+}
+
+// 2-D transforms of levels k0 .. k0 + pchunk - 1
+int bzi_fft_chunk(bz_ctx *ctx, int k0, bool forward)
+{
+    const DevGrid &g = ctx->dg;
+    double *real = ctx->d_rhs + (size_t)g.Nx * g.Ny * k0;
+    hipfftDoubleComplex *hat = ctx->d_hat + (size_t)ctx->NXH * g.Ny * k0;
+    if (forward) BZ_FFT(hipfftExecD2Z(ctx->plan_fwd_c, real, hat));
+    else BZ_FFT(hipfftExecZ2D(ctx->plan_inv_c, hat, real));
     return BZ_OK;
 }
 
@@ -387,9 +427,15 @@ void bzi_poisson_teardown(bz_ctx *ctx)
         hipfftDestroy(ctx->slab_plan_y);
         ctx->slab_plans_ok = false;
     }
+    if (ctx->xf) {
+        if (ctx->plan_y) hipfftDestroy(ctx->plan_y);
+        if (ctx->d_wtab) hipFree(ctx->d_wtab);
+        ctx->plan_y = 0; ctx->d_wtab = nullptr; ctx->xf = false;
+    }
     if (ctx->plans_ok) {
         hipfftDestroy(ctx->plan_fwd);
         hipfftDestroy(ctx->plan_inv);
+        if (ctx->pchunk) { hipfftDestroy(ctx->plan_fwd_c); hipfftDestroy(ctx->plan_inv_c); ctx->pchunk = 0; }
         ctx->plans_ok = false;
     }
     if (ctx->d_lower) hipFree(ctx->d_lower);
@@ -403,9 +449,33 @@ void bzi_poisson_teardown(bz_ctx *ctx)
 
 // solve!(phi, FourierTridiagonalPoissonSolver) on the source term held in ctx->d_rhs; the zero-mean
 // solution is left in ctx->d_rhs (contiguous Nx*Ny*Nz).
+int bzi_xf_y(bz_ctx *ctx, bool forward)
+{
+    BZ_FFT(hipfftExecZ2Z(ctx->plan_y, ctx->d_hat, ctx->d_hat, forward ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+    return BZ_OK;
+}
+
 int bzi_poisson_spectral(bz_ctx *ctx)
 {
     const DevGrid &g = ctx->dg;
+    if (ctx->xf) {
+        int rc;
+        {
+            ProfileScope ps(ctx, "poisson_fft_forward");
+            if ((rc = bzi_xf_forward(ctx, nullptr, 1.0, nullptr))) return rc;
+            if ((rc = bzi_xf_y(ctx, true))) return rc;
+        }
+        {
+            ProfileScope ps(ctx, "poisson_tridiagonal");
+            if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1))) return rc;
+        }
+        {
+            ProfileScope ps(ctx, "poisson_fft_inverse");
+            if ((rc = bzi_xf_y(ctx, false))) return rc;
+            if ((rc = bzi_xf_inverse(ctx))) return rc;
+        }
+        return BZ_OK;
+    }
     {
         ProfileScope ps(ctx, "poisson_fft_forward");
         BZ_FFT(hipfftExecD2Z(ctx->plan_fwd, ctx->d_rhs, ctx->d_hat));

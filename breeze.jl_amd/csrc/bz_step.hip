@@ -63,6 +63,73 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
                 if (rc) return rc;
                 BZ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
             } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0))) return rc;
+            if (ctx->pchunk) {
+                // chunked pipeline: each level range goes source term -> x transform -> y transform (and, after the vertical solves,
+                // y -> x -> projection) back to back, so the intermediate passes find the range in the Infinity Cache
+                const int ch = ctx->pchunk;
+                rc = 0;
+                {
+                    ProfileScope ps(ctx, "poisson_source_term+fft_forward");
+                    ctx->profile_mute++;
+                    for (int k0 = 0; k0 < g.Nz && !rc; k0 += ch) {
+                        ctx->kr0 = k0; ctx->krn = ch;
+                        rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G);
+                        if (!rc) rc = bzi_fft_chunk(ctx, k0, true);
+                    }
+                    ctx->krn = 0;
+                    ctx->profile_mute--;
+                }
+                if (rc) return rc;
+                {
+                    ProfileScope ps(ctx, "poisson_tridiagonal");
+                    if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1))) return rc;
+                }
+                if (ctx->side_scalar) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                {
+                    ProfileScope ps(ctx, stage < 2 ? "poisson_fft_inverse+project_momentum" : "poisson_fft_inverse+project_and_diagnose");
+                    ctx->profile_mute++;
+                    for (int k0 = 0; k0 < g.Nz && !rc; k0 += ch) {
+                        rc = bzi_fft_chunk(ctx, k0, false);
+                        ctx->kr0 = k0; ctx->krn = ch;
+                        if (rc) break;
+                        if (stage < 2) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+                        else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, G->rho_theta, G->rho_q);
+                    }
+                    ctx->krn = 0;
+                    ctx->profile_mute--;
+                }
+                if (rc) return rc;
+                continue;
+            }
+            if (ctx->xf && !ctx->pchunk) {
+                // hand-written x transforms (bz_xfft_kernels.h): the source term is evaluated inside the forward x pass; y transforms
+                // (contiguous) and vertical solves on the transposed spectrum
+                {
+                    ProfileScope ps(ctx, "poisson_source_term+fft_x");
+                    if ((rc = bzi_xf_forward(ctx, s, alpha * dt, G))) return rc;
+                }
+                {
+                    ProfileScope ps(ctx, "poisson_fft_y_forward");
+                    if ((rc = bzi_xf_y(ctx, true))) return rc;
+                }
+                {
+                    ProfileScope ps(ctx, "poisson_tridiagonal");
+                    if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1))) return rc;
+                }
+                {
+                    ProfileScope ps(ctx, "poisson_fft_y_inverse");
+                    if ((rc = bzi_xf_y(ctx, false))) return rc;
+                }
+                if (ctx->side_scalar) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                {
+                    ProfileScope ps(ctx, "poisson_fft_x_inverse");
+                    if ((rc = bzi_xf_inverse(ctx))) return rc;
+                }
+                if (stage < 2) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+                else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, G->rho_theta, G->rho_q);
+                if (rc) return rc;
+                continue;
+            }
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
             if (ctx->side_scalar) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));

@@ -67,11 +67,11 @@ static int pick_chunk5(const DevGrid &g, int nlev, int rows_per_block)
 // drivers may run it on a second stream beside the solve).
 // rows: 0 all tile rows; 1 interior tile rows only (1 .. nty-2); 2 the two edge tile rows (0 and nty-1).  The slab driver runs
 // the interior rows while the y-halo exchange of the stage-start state is in flight and the edge rows once it has landed.
-int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
-                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows, int which)
+template <int TY>
+static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
+                       const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows, int which)
 {
     const DevGrid &g = ctx->dg;
-    constexpr int TY = 8;
     RKEpilogue E;
     E.mode = first ? 1 : 2; E.dt = dt; E.alpha = alpha; E.oma = 1.0 - alpha;
     Lean5 L;
@@ -80,7 +80,7 @@ int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
     L.pi_dry = ColPtr(getenv("BZ_NO_PI_DRY") ? nullptr : ctx->d_pi_dry + g.Hz);
     const dim3 block(64, TY);
     const int tx = (g.Nx + 63) / 64, nty = (g.Ny + TY - 1) / TY;
-    if (rows && nty < 3) return rows == 1 ? BZ_OK : bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, 0, which);
+    if (rows && nty < 3) return rows == 1 ? BZ_OK : lean_launch<TY>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, 0, which);
     const int ty = rows == 1 ? nty - 2 : rows == 2 ? 2 : nty;
     L.by0 = rows == 1 ? 1 : 0;
     L.bys = rows == 2 ? nty - 1 : 1;
@@ -96,24 +96,30 @@ int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         L.out = G->rho_u;
         const dim3 grid = shape(g.Nz, kc);
-        if (getenv("BZ_U_GEN5")) hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-        else hipLaunchKernelGGL((k6_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if constexpr (TY == 8) {
+            if (getenv("BZ_U_GEN5")) hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+            else hipLaunchKernelGGL((k6_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        } else hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 1) {
         ProfileScope ps(ctx, "y_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
         L.out = G->rho_v;
         const dim3 grid = shape(g.Nz, kc);
-        if (getenv("BZ_V_GEN5")) hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-        else hipLaunchKernelGGL((k6_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if constexpr (TY == 8) {
+            if (getenv("BZ_V_GEN5")) hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+            else hipLaunchKernelGGL((k6_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        } else hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 1) {
         ProfileScope ps(ctx, "z_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_w; E.u0_out = U0->rho_w;
         L.out = G->rho_w;
         const dim3 grid = shape(g.Nz - 1, kc);
-        if (getenv("BZ_W_GEN5")) hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-        else hipLaunchKernelGGL((k6_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if constexpr (TY == 8) {
+            if (getenv("BZ_W_GEN5")) hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+            else hipLaunchKernelGGL((k6_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        } else hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 2) {
         ProfileScope ps(ctx, "scalar_tendencies+rk3+thermo");
@@ -123,5 +129,18 @@ int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
         hipLaunchKernelGGL((k5_scalar_pair<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
+                        const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows, int which)
+{
+    // tile rows per workgroup: tuning probes (BZ_LEAN_TY: all four kernels, BZ_SCALAR_TY: the scalar-pair kernel alone)
+    static const int ty = getenv("BZ_LEAN_TY") ? atoi(getenv("BZ_LEAN_TY")) : 8;
+    static const int tys = getenv("BZ_SCALAR_TY") ? atoi(getenv("BZ_SCALAR_TY")) : ty;
+    if ((which & 1) && ty == 4) { if (int e = lean_launch<4>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, 1)) return e; }
+    else if (which & 1) { if (int e = lean_launch<8>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, 1)) return e; }
+    if ((which & 2) && tys == 4) return lean_launch<4>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, 2);
+    if (which & 2) return lean_launch<8>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, 2);
     return BZ_OK;
 }

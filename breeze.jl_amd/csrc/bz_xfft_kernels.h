@@ -1,0 +1,216 @@
+// bz_xfft_kernels.h — hand-written x transforms of the pressure solve, fused with their neighbours.
+//
+// The library pipeline  source term -> 2-D R2C (x rows, then y columns at stride Nx/2+1) -> vertical solves -> 2-D C2R -> projection
+// spends two full passes over the grid on work that needs no pass of its own, and its column transforms run at half the rate of
+// the row transforms (profiles/r02_v2_rocprofv3_kernel_stats.csv: 0.72 ms against 0.38 ms per launch at 512^3).  Here
+//   * k_x_forward  evaluates the source term (compute_anelastic_source_term!, /root/reference/src/AnelasticEquations/
+//     anelastic_pressure_solver.jl:90-105) of RB rows into LDS, transforms the rows there (real transform of length Nx = complex
+//     transform of length Nx/2 + split) and stores the half spectrum TRANSPOSED, hatT[(k * NXH + kx) * Ny + ky-index], so that
+//   * the y transforms are contiguous batched 1-D plans (the library's fast case) and the vertical solves run in the ky-fastest
+//     layout the slab mode already uses, and
+//   * k_x_inverse  reads RB transposed rows, inverts them in LDS and stores phi for the projection kernels.  (Applying
+//     make_pressure_correction! straight from LDS in the same kernel was built and measured at 512^3: 2.3 ms with two level buffers
+//     in LDS, 4.0-4.4 ms with the previous level in registers — 168 VGPRs, one workgroup per CU — against 0.6 + 1.5 ms for this
+//     kernel followed by k_project_lean, so it was dropped; so was requesting level k+1 into registers before transforming level k:
+//     the extra registers cost a workgroup per CU and 10-20 % of the rate.)
+// Transform: Stockham autosort, radix-4 stages plus one radix-2 stage when log2(Nx/2) is odd, a team of Nx/8 threads per row,
+// twiddles from a table in LDS (exp(-2 pi i t / Nx), t < 3 Nx / 4, computed on the host in the working precision).
+// Included by bz_fused.hip.
+#pragma once
+
+#define XF_RB 8        // rows of y per workgroup: a transposed store / load moves XF_RB consecutive complex numbers (128 B) per kx
+
+// LDS slot of element p of a row: one slot of padding per 16 (a 16-byte element spans 4 banks, 16 elements span all 64: the radix-4
+// stages store at strides of 4, 16, 64 elements, which without the padding land on the same banks)
+#define XF_P(p) ((p) + ((p) >> 4))
+
+__device__ __forceinline__ double2 xf_cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// In-place complex transform of length n2 (a power of two >= 8) of `row` by the team's T = n2 / 4 threads (tid = 0 .. T-1).
+// Every thread of the workgroup calls it (barriers inside); teams with active = false only keep the barriers company.
+// INV: conjugated twiddles (unnormalised inverse).
+template <bool INV>
+__device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, int tid, bool active, const double2 *__restrict__ W)
+{
+    const int T = n2 >> 2;
+    int Ns = 1;
+    for (; Ns * 4 <= n2; Ns <<= 2) {
+        double2 o0 = make_double2(0.0, 0.0), o1 = o0, o2 = o0, o3 = o0;
+        int j0 = 0;
+        if (active) {
+            const int k = tid & (Ns - 1);
+            double2 v0 = row[XF_P(tid)], v1 = row[XF_P(tid + T)], v2 = row[XF_P(tid + 2 * T)], v3 = row[XF_P(tid + 3 * T)];
+            if (Ns > 1) {
+                const int tw = k * (n2 / (2 * Ns));
+                double2 w1 = W[tw], w2 = W[2 * tw], w3 = W[3 * tw];
+                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+                v1 = xf_cmul(v1, w1); v2 = xf_cmul(v2, w2); v3 = xf_cmul(v3, w3);
+            }
+            const double2 a0 = make_double2(v0.x + v2.x, v0.y + v2.y), a1 = make_double2(v0.x - v2.x, v0.y - v2.y);
+            const double2 a2 = make_double2(v1.x + v3.x, v1.y + v3.y), d = make_double2(v1.x - v3.x, v1.y - v3.y);
+            const double2 a3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);        // (v1 - v3) times +i / -i
+            o0 = make_double2(a0.x + a2.x, a0.y + a2.y);
+            o1 = make_double2(a1.x + a3.x, a1.y + a3.y);
+            o2 = make_double2(a0.x - a2.x, a0.y - a2.y);
+            o3 = make_double2(a1.x - a3.x, a1.y - a3.y);
+            j0 = ((tid - k) << 2) + k;
+        }
+        __syncthreads();
+        if (active) { row[XF_P(j0)] = o0; row[XF_P(j0 + Ns)] = o1; row[XF_P(j0 + 2 * Ns)] = o2; row[XF_P(j0 + 3 * Ns)] = o3; }
+        __syncthreads();
+    }
+    if (Ns < n2) {      // n2 = 2 Ns: two radix-2 butterflies per thread, outputs land on their own inputs
+        if (active) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int b = tid + h * T;
+                double2 w = W[2 * b];
+                if (INV) w.y = -w.y;
+                const double2 u0 = row[XF_P(b)], u1 = xf_cmul(row[XF_P(b + Ns)], w);
+                row[XF_P(b)] = make_double2(u0.x + u1.x, u0.y + u1.y);
+                row[XF_P(b + Ns)] = make_double2(u0.x - u1.x, u0.y - u1.y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Z = transform of the packed row z[n] = x[2n] + i x[2n+1]  ->  X[0 .. n2] of the real row, in place (row has n2 + 1 slots).
+// Pairs (p, n2 - p) are independent: no barrier between a pair's reads and writes.
+__device__ __forceinline__ void xf_split_forward(double2 *__restrict__ row, int n2, int tid, const double2 *__restrict__ W)
+{
+    const int T = n2 >> 2;
+    for (int p = tid; p <= (n2 >> 1); p += T) {
+        if (p == 0) {
+            const double2 z = row[0];
+            row[0] = make_double2(z.x + z.y, 0.0);
+            row[XF_P(n2)] = make_double2(z.x - z.y, 0.0);
+        } else {
+            const int m = n2 - p;
+            const double2 A = row[XF_P(p)], B = row[XF_P(m)];
+            const double2 E = make_double2(0.5 * (A.x + B.x), 0.5 * (A.y - B.y));
+            const double2 D = make_double2(0.5 * (A.x - B.x), 0.5 * (A.y + B.y));
+            const double2 WD = xf_cmul(W[p], D);
+            row[XF_P(p)] = make_double2(E.x + WD.y, E.y - WD.x);      // E - i W D
+            row[XF_P(m)] = make_double2(E.x - WD.y, -(E.y + WD.x));   // conj(E + i W D)
+        }
+    }
+}
+// inverse of the above up to the factor 2 of the unnormalised transform: X[0 .. n2] -> Z'[0 .. n2-1]
+__device__ __forceinline__ void xf_split_inverse(double2 *__restrict__ row, int n2, int tid, const double2 *__restrict__ W)
+{
+    const int T = n2 >> 2;
+    for (int p = tid; p <= (n2 >> 1); p += T) {
+        if (p == 0) {
+            const double a = row[0].x, b = row[XF_P(n2)].x;
+            row[0] = make_double2(a + b, a - b);
+        } else {
+            const int m = n2 - p;
+            const double2 P = row[XF_P(p)], Q = row[XF_P(m)];
+            const double2 S = make_double2(P.x + Q.x, P.y - Q.y);
+            const double2 Dd = make_double2(P.x - Q.x, P.y + Q.y);
+            double2 w = W[p];
+            w.y = -w.y;
+            const double2 V = xf_cmul(w, Dd);
+            row[XF_P(p)] = make_double2(S.x - V.y, S.y + V.x);        // S + i V
+            row[XF_P(m)] = make_double2(S.x + V.y, -(S.y - V.x));     // conj(S - i V)
+        }
+    }
+}
+
+// SRC 1: source term from the predictor momentum (arithmetic of k_poisson_source_rows); SRC 0: rows of the contiguous rhs buffer.
+// grid (Ny / XF_RB, ceil(Nz / kchunk)), block XF_RB * Nx / 8, dynamic LDS (XF_RB * (XF_P(n2) + 1) + 3 n2 / 2) * sizeof(double2).
+// Thread (row r, tid) owns the cell pairs i = 2 (tid + q Nx / 8), i + 1, q = 0 .. 3 — the four packed complex elements its first
+// butterfly reads; wlo carries rho_w of the lower faces from the previous level's upper faces (the block marches in z).
+template <int SRC>
+__global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const double *__restrict__ rhs, const double *__restrict__ ru,
+                                                          const double *__restrict__ rv, const double *__restrict__ rw, double dt,
+                                                          double2 *__restrict__ hatT, const double2 *__restrict__ Wg, int kchunk)
+{
+    extern __shared__ double2 xf_sm[];
+    const int Nx = g.Nx, n2 = Nx >> 1, T = n2 >> 2, RS = XF_P(n2) + 1, NXH = n2 + 1;
+    const int nthreads = blockDim.x;
+    const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
+    double2 *__restrict__ W = xf_sm + XF_RB * RS;
+    for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
+    const int j0 = blockIdx.x * XF_RB, j = j0 + r;
+    const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    double2 *__restrict__ row = xf_sm + r * RS;
+    const long long jp = (j + 1 < g.Ny) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
+    double wlo[8];
+    if (SRC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long n = g.idx(2 * (tid + T * q), j, kbeg);
+            wlo[2 * q] = rw[n]; wlo[2 * q + 1] = rw[n + 1];
+        }
+    }
+    for (int k = kbeg; k < kend; ++k) {
+        if (SRC) {
+            const double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az, Vi = g.Vinv_c[k], dz = g.dzc[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 2 * (tid + T * q);
+                const long long n = g.idx(i, j, k);
+                const double u0 = ru[n], u1 = ru[n + 1], u2 = ru[n + ((i + 2 < Nx) ? 2 : 2 - Nx)];
+                const double v0 = rv[n], v1 = rv[n + 1], vp0 = rv[n + jp], vp1 = rv[n + jp + 1];
+                const double wh0 = rw[n + g.Sxy], wh1 = rw[n + g.Sxy + 1];
+                double a = Ax * u1 - Ax * u0, b = Ay * vp0 - Ay * v0, c = Az * wh0 - Az * wlo[2 * q];
+                const double x0 = dz * (Vi * (a + b + c)) / dt;
+                a = Ax * u2 - Ax * u1; b = Ay * vp1 - Ay * v1; c = Az * wh1 - Az * wlo[2 * q + 1];
+                const double x1 = dz * (Vi * (a + b + c)) / dt;
+                wlo[2 * q] = wh0; wlo[2 * q + 1] = wh1;
+                row[XF_P(tid + T * q)] = make_double2(x0, x1);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 2 * (tid + T * q);
+                const long long m = (long long)i + (long long)Nx * ((long long)j + (long long)g.Ny * k);
+                row[XF_P(tid + T * q)] = *(const double2 *)(rhs + m);           // i even, Nx even: 16-byte aligned
+            }
+        }
+        __syncthreads();
+        xf_team_fft<false>(row, n2, tid, true, W);
+        xf_split_forward(row, n2, tid, W);
+        __syncthreads();
+        const long long base = (long long)k * NXH * g.Ny + j0;
+        for (int e = threadIdx.x; e < NXH * XF_RB; e += nthreads) {
+            const int kx = e / XF_RB, rr = e - kx * XF_RB;
+            hatT[base + (long long)kx * g.Ny + rr] = xf_sm[rr * RS + XF_P(kx)];
+        }
+        __syncthreads();
+    }
+}
+
+// Transposed half spectrum -> rows of phi in the contiguous buffer phi_c (Nx * Ny * Nz).  Same grid, block and LDS as k_x_forward.
+__global__ __launch_bounds__(XF_RB * 64) void k_x_inverse(DevGrid g, const double2 *__restrict__ hatT, double *__restrict__ phi_c,
+                                                          const double2 *__restrict__ Wg, int kchunk)
+{
+    extern __shared__ double2 xf_sm[];
+    const int Nx = g.Nx, n2 = Nx >> 1, T = n2 >> 2, RS = XF_P(n2) + 1, NXH = n2 + 1;
+    const int nthreads = blockDim.x;
+    const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
+    double2 *__restrict__ W = xf_sm + XF_RB * RS;
+    for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
+    const int j0 = blockIdx.x * XF_RB;
+    const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    double2 *__restrict__ row = xf_sm + r * RS;
+    for (int k = kbeg; k < kend; ++k) {
+        const long long base = (long long)k * NXH * g.Ny + j0;
+        for (int e = threadIdx.x; e < NXH * XF_RB; e += nthreads) {
+            const int kx = e / XF_RB, rr = e - kx * XF_RB;
+            xf_sm[rr * RS + XF_P(kx)] = hatT[base + (long long)kx * g.Ny + rr];
+        }
+        __syncthreads();
+        xf_split_inverse(row, n2, tid, W);
+        __syncthreads();
+        xf_team_fft<true>(row, n2, tid, true, W);
+        for (int e = threadIdx.x; e < XF_RB * n2; e += nthreads) {
+            const int rr = e / n2, c = e - rr * n2;
+            const double2 v = xf_sm[rr * RS + XF_P(c)];
+            *(double2 *)(phi_c + 2 * c + (long long)Nx * ((long long)(j0 + rr) + (long long)g.Ny * k)) = v;
+        }
+        __syncthreads();
+    }
+}

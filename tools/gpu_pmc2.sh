@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 O=$1; shift
 mkdir -p $O
-B="env $* python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compressible"
+B="env $* python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compressible --no-float32"
 run() { name=$1; shift; timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $O/$name -- $B > $O/$name.log 2>&1; }
 run tlb TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum
 run lat TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum

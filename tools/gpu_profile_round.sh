@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=$1
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-compressible > $O/bench_prof.json 2> $O/stats.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py > $O/bench_prof.json 2> $O/stats.log
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null
 bash tools/gpu_pmc.sh $O/pmc > $O/pmc.log 2>&1
 bash tools/gpu_pmc2.sh $O/pmc2 > $O/pmc2.log 2>&1

@@ -21,21 +21,22 @@ def main():
     cells = 1
     for n in b["config"]["grid_per_gpu"] if "grid_per_gpu" in b["config"] else b["config"]["grid"]:
         cells *= n
-    launches = {"poisson_fft_forward": 3, "poisson_fft_inverse": 3}
+    launches = b.get("kernel_launches_per_step", {})
     print(f"# Per-kernel roofline, {b['config']['workload']}\n")
     print(f"Step: {b['ms_per_step']:.2f} ms, {b['value'] / 1e9:.3f} Gcells/s, step fraction of the 8 TB/s roofline at 2000 B/cell/step: "
           f"{b['step_roofline']['frac']:.3f}.  Source: `{os.path.basename(bench)}` (HIP events on the launch stream), "
           f"`{os.path.basename(pmc)}` (rocprofv3 PMC, HBM-side bytes per launch).\n")
-    print("| kernel group | ms/step | ms/launch | algorithmic GB/launch | algorithmic TB/s | frac of 8 TB/s | PMC GB/launch | PMC TB/s |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("| kernel group | launches/step | ms/step | ms/launch | algorithmic GB/launch | algorithmic TB/s | frac of 8 TB/s | PMC GB/launch | PMC TB/s |")
+    print("|---|---|---|---|---|---|---|---|---|")
     tot = 0.0
     for name, ms in sorted(b["kernels_ms_per_step"].items(), key=lambda kv: -kv[1]):
         tot += ms
-        per_launch = ms / launches.get(name, 3)
+        n = launches.get(name, 3)
+        per_launch = ms / n
         w = WORDS_PER_CELL.get(name)
         alg = w * 8 * cells / 1e9 if w else None
         traffic = p.get(name, {}).get("hbm_bytes_per_launch")
-        row = [name, f"{ms:.2f}", f"{per_launch:.3f}",
+        row = [name, f"{n:g}", f"{ms:.2f}", f"{per_launch:.3f}",
                f"{alg:.2f}" if alg else "—", f"{alg / per_launch:.2f}" if alg else "—", f"{alg / per_launch / 8:.3f}" if alg else "—",
                f"{traffic / 1e9:.2f}" if traffic else "—", f"{traffic / 1e9 / per_launch:.2f}" if traffic else "—"]
         print("| " + " | ".join(row) + " |")

@@ -429,7 +429,10 @@ static int all_to_all(bz_ctx *ctx, const double *send, double *recv, size_t bloc
     return rc;
 }
 
-static int dist_poisson(bz_ctx *ctx)
+// With the hand-written x transforms (ctx->xf_slab, bz_xfft_kernels.h) the source term is evaluated inside the forward x pass, which
+// stores the W messages of the first all-to-all directly (no rhs round trip, no library x transform, no pack launches), and the inverse x
+// pass reads the W messages of the second all-to-all where they landed (no concatenation); the blocks sent back are plain strided copies.
+static int dist_poisson(bz_ctx *ctx, const bz_state *s, const bz_prognostic *predictor, double dt)
 {
     BzComm *c = ctx->comm;
     const DevGrid &g = ctx->dg;
@@ -437,6 +440,36 @@ static int dist_poisson(bz_ctx *ctx)
     const size_t blk = (size_t)g.Nz * nkx * g.Ny * 2;            // doubles per transposed block
     const bool direct = (W == 1 && !c->self_messages);          // one rank: the packs write the transposed arrays in place
     int rc;
+    if (ctx->xf_slab) {
+        {
+            ProfileScope ps(ctx, "poisson_source_term+fft_x");
+            if ((rc = bzi_xf_forward(ctx, s, dt, predictor, nullptr, direct ? c->spec : c->xsend, W))) return rc;
+        }
+        if (!direct) {
+            ProfileScope ps(ctx, "comm_all_to_all");
+            if ((rc = all_to_all(ctx, c->xsend, c->xrecv, blk))) return rc;
+            hipLaunchKernelGGL(k_concat_blocks, dim3(4096), dim3(256), 0, ctx->stream, (const double2 *)c->xrecv, (double2 *)c->spec,
+                               (long long)g.Nz * nkx, g.Ny, W);                                            // (Nz, nkx, Ny_global)
+            BZ_LAUNCH_CHECK();
+        }
+        if ((rc = bz_slab_transform(ctx, 1, c->spec, c->spec, 0))) return rc;
+        if ((rc = bz_spectral_tridiagonal_solve(ctx, c->spec, 1.0 / ((double)g.Nx * (double)NyG)))) return rc;
+        if ((rc = bz_slab_transform(ctx, 2, c->spec, c->spec, 0))) return rc;
+        if (!direct) {
+            {
+                ProfileScope ps(ctx, "poisson_split_rows");
+                const size_t rowb = (size_t)g.Ny * 2 * sizeof(double);                                     // the destination's rows of one (k, kx)
+                for (int q = 0; q < W; ++q)
+                    BZ_HIP(hipMemcpy2DAsync(c->xsend + blk * q, rowb, c->spec + (size_t)q * g.Ny * 2, (size_t)NyG * 2 * sizeof(double), rowb,
+                                            (size_t)g.Nz * nkx, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            ProfileScope ps(ctx, "comm_all_to_all");
+            if ((rc = all_to_all(ctx, c->xsend, c->xrecv, blk))) return rc;
+        }
+        ProfileScope ps(ctx, "poisson_fft_x_inverse");
+        return bzi_xf_inverse(ctx, direct ? c->spec : c->xrecv, c->rhs, W);
+    }
+    if ((rc = bzi_poisson_source_fused(ctx, s, dt, c->rhs, predictor))) return rc;
     if ((rc = bz_slab_transform(ctx, 0, c->rhs, c->hatx, 0))) return rc;                                  // (Nz, Ny, nxh)
     for (int p = 0; p < W; ++p)                                                                            // -> W x (Nz, nkx, Ny)
         if ((rc = bz_pack_transpose(ctx, c->hatx, (direct ? c->spec : c->xsend) + blk * p, g.Nz, g.Ny, nxh, p * nkx, nkx, nxh))) return rc;
@@ -497,8 +530,7 @@ static int dist_projection(bz_ctx *ctx, const bz_state *s, const bz_prognostic *
         int32_t lev[1] = {g.Nz + 2 * g.Hz};
         if ((rc = halo_exchange(ctx, f, lev, 1, 1, true, false, ctx->stream))) return rc;
     }
-    if ((rc = bzi_poisson_source_fused(ctx, s, dt, c->rhs, predictor))) return rc;
-    if ((rc = dist_poisson(ctx))) return rc;
+    if ((rc = dist_poisson(ctx, s, predictor, dt))) return rc;
     if ((rc = exchange_phi_below(ctx))) return rc;
     if (join_side) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the scalar-pair kernel of this stage has finished
     if (lean) return bzi_project_lean(ctx, s, dt, c->rhs, c->phi_below, predictor, oa, ob);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, dou
 
 #include "bz_xfft_kernels.h"
 
-static size_t xf_lds_bytes(int n2) { return ((size_t)XF_RB * (XF_P(n2) + 1) + 3 * n2 / 2) * sizeof(double2); }
+static size_t xf_lds_bytes(int n2) { return ((size_t)XF_RB * XF_ROW_STRIDE(n2) + 3 * n2 / 2) * sizeof(double2); }
 static int xf_chunk(const char *env, int dflt, int Nz)
 {
     int kc = dflt;
@@ -266,33 +266,43 @@ static int xf_chunk(const char *env, int dflt, int Nz)
     return kc < Nz ? kc : Nz;
 }
 
-// x transform of the rows of the source term into the transposed half spectrum ctx->d_hat; predictor != nullptr (or s != nullptr):
-// the source term is evaluated on the fly from that momentum, else the rows come from ctx->d_rhs
-int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor)
+// x transform of the rows of the source term into the transposed half spectrum `hat` (nullptr: ctx->d_hat); predictor != nullptr
+// (or s != nullptr): the source term is evaluated on the fly from that momentum, else the rows come from rhs (nullptr: ctx->d_rhs).
+// blocks > 1 (y-slab ranks): `hat` is `blocks` messages of ctx->nkx wavenumbers each (XfLayout).
+int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor, const double *rhs, double *hat, int blocks)
 {
     const DevGrid &g = ctx->dg;
     const int n2 = g.Nx / 2, kc = xf_chunk("BZ_XF_KCHUNK_F", 16, g.Nz);
     const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
     const size_t lds = xf_lds_bytes(n2);
+    XfLayout L;
+    L.nkx = blocks > 1 ? ctx->nkx : n2 + 1;
+    L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;
+    L.blk = (long long)g.Nz * L.nkx * g.Ny;
+    double2 *out = (double2 *)(hat ? hat : (double *)ctx->d_hat);
     if (s || predictor)
         hipLaunchKernelGGL(k_x_forward<1>, grid, block, lds, ctx->stream, g, (const double *)nullptr,
                            predictor ? predictor->rho_u : s->rho_u, predictor ? predictor->rho_v : s->rho_v,
-                           predictor ? predictor->rho_w : s->rho_w, dt, (double2 *)ctx->d_hat, (const double2 *)ctx->d_wtab, kc);
+                           predictor ? predictor->rho_w : s->rho_w, dt, out, L, (const double2 *)ctx->d_wtab, kc);
     else
-        hipLaunchKernelGGL(k_x_forward<0>, grid, block, lds, ctx->stream, g, (const double *)ctx->d_rhs, (const double *)nullptr,
-                           (const double *)nullptr, (const double *)nullptr, dt, (double2 *)ctx->d_hat, (const double2 *)ctx->d_wtab, kc);
+        hipLaunchKernelGGL(k_x_forward<0>, grid, block, lds, ctx->stream, g, rhs ? rhs : (const double *)ctx->d_rhs, (const double *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr, dt, out, L, (const double2 *)ctx->d_wtab, kc);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
 
-// inverse x transform of the transposed half spectrum: phi into ctx->d_rhs
-int bzi_xf_inverse(bz_ctx *ctx)
+// inverse x transform of the transposed half spectrum `hat` (nullptr: ctx->d_hat; blocks as above): phi into `phi` (nullptr: ctx->d_rhs)
+int bzi_xf_inverse(bz_ctx *ctx, const double *hat, double *phi, int blocks)
 {
     const DevGrid &g = ctx->dg;
     const int n2 = g.Nx / 2, kc = xf_chunk("BZ_XF_KCHUNK_I", 16, g.Nz);
     const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
-    hipLaunchKernelGGL(k_x_inverse, grid, block, xf_lds_bytes(n2), ctx->stream, g, (const double2 *)ctx->d_hat, ctx->d_rhs,
-                       (const double2 *)ctx->d_wtab, kc);
+    XfLayout L;
+    L.nkx = blocks > 1 ? ctx->nkx : n2 + 1;
+    L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;
+    L.blk = (long long)g.Nz * L.nkx * g.Ny;
+    hipLaunchKernelGGL(k_x_inverse, grid, block, xf_lds_bytes(n2), ctx->stream, g, (const double2 *)(hat ? hat : (const double *)ctx->d_hat), L,
+                       phi ? phi : ctx->d_rhs, (const double2 *)ctx->d_wtab, kc);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -258,6 +258,7 @@ struct bz_ctx {
     int kr0 = 0, krn = 0;            // level range of the next source / projection launch (krn = 0: all levels)
     // hand-written x transforms with a transposed (ky-fastest) half spectrum (bz_xfft_kernels.h)
     bool xf = false;
+    bool xf_slab = false;            // y-slab context whose rows the same kernels transform (bz_comm.hip: dist_poisson)
     void *d_wtab = nullptr;          // exp(-2 pi i t / Nx), t < 3 Nx / 4
     hipfftHandle plan_y = 0;         // contiguous batched 1-D transform along y of the transposed spectrum
     int profile_mute = 0;            // > 0: ProfileScope objects record nothing (an enclosing scope covers the launches)
@@ -387,8 +388,9 @@ void bzi_poisson_teardown(bz_ctx *ctx);
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);
 int bzi_poisson_spectral(bz_ctx *ctx);
 int bzi_fft_chunk(bz_ctx *ctx, int k0, bool forward);
-int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor);
-int bzi_xf_inverse(bz_ctx *ctx);
+int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor, const double *rhs = nullptr,
+                   double *hat = nullptr, int blocks = 1);
+int bzi_xf_inverse(bz_ctx *ctx, const double *hat = nullptr, double *phi = nullptr, int blocks = 1);
 int bzi_xf_y(bz_ctx *ctx, bool forward);
 int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column);
 // fused streaming kernels (bz_fused.hip)

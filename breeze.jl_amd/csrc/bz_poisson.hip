@@ -315,7 +315,9 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     const int nxh_real = Nx / 2 + 1;
     // hand-written x transforms + transposed spectrum: Nx a power of two in [16, 512] (one team of Nx / 8 <= 64 threads per row, 8 rows per
     // workgroup in 45 KiB of LDS)
-    ctx->xf = !slab && Nx >= 16 && Nx <= 512 && (Nx & (Nx - 1)) == 0 && g.Ny % 8 == 0 && g.wrap_y && !getenv("BZ_NO_XFFT");
+    const bool xf_shape = Nx >= 16 && Nx <= 512 && (Nx & (Nx - 1)) == 0 && g.Ny % 8 == 0 && !getenv("BZ_NO_XFFT");
+    ctx->xf = !slab && xf_shape && g.wrap_y;
+    ctx->xf_slab = slab && xf_shape;
     int Ny = g.Ny;                       // rows of the spectral block: local rows, or ALL rows in slab mode
     if (slab) {
         ctx->nkx = (nxh_real + ctx->y_nranks - 1) / ctx->y_nranks;
@@ -371,6 +373,17 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     BZ_HIP(hipGetLastError());
     BZ_HIP(hipDeviceSynchronize());
 
+    if (ctx->xf || ctx->xf_slab) {       // twiddles of the hand-written x transforms
+        const int nw = 3 * Nx / 4;
+        std::vector<double> w(2 * (size_t)nw);
+        for (int t = 0; t < nw; ++t) {
+            const double a = (double)(2.0 * pi * (double)t / (double)Nx);
+            w[2 * t] = std::cos(a);
+            w[2 * t + 1] = -std::sin(a);
+        }
+        BZ_HIP(hipMalloc(&ctx->d_wtab, w.size() * sizeof(double)));
+        BZ_HIP(hipMemcpy(ctx->d_wtab, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (slab) return BZ_OK;          // horizontal transforms are the caller's (distributed) in slab mode
     // ---- rocFFT plans: 2-D (y,x) transforms batched over z ----
     int n[2] = {Ny, Nx};
@@ -382,15 +395,6 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
         BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
     }
     if (ctx->xf) {
-        const int nw = 3 * Nx / 4;
-        std::vector<double> w(2 * (size_t)nw);
-        for (int t = 0; t < nw; ++t) {
-            const double a = (double)(2.0 * pi * (double)t / (double)Nx);
-            w[2 * t] = std::cos(a);
-            w[2 * t + 1] = -std::sin(a);
-        }
-        BZ_HIP(hipMalloc(&ctx->d_wtab, w.size() * sizeof(double)));
-        BZ_HIP(hipMemcpy(ctx->d_wtab, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
         int ny[1] = {Ny};
         BZ_FFT(hipfftPlanMany(&ctx->plan_y, 1, ny, ny, 1, Ny, ny, 1, Ny, HIPFFT_Z2Z, ctx->NXH * Nz));
         BZ_FFT(hipfftSetStream(ctx->plan_y, ctx->stream));
@@ -427,11 +431,9 @@ void bzi_poisson_teardown(bz_ctx *ctx)
         hipfftDestroy(ctx->slab_plan_y);
         ctx->slab_plans_ok = false;
     }
-    if (ctx->xf) {
-        if (ctx->plan_y) hipfftDestroy(ctx->plan_y);
-        if (ctx->d_wtab) hipFree(ctx->d_wtab);
-        ctx->plan_y = 0; ctx->d_wtab = nullptr; ctx->xf = false;
-    }
+    if (ctx->xf && ctx->plan_y) hipfftDestroy(ctx->plan_y);
+    if (ctx->d_wtab) hipFree(ctx->d_wtab);
+    ctx->plan_y = 0; ctx->d_wtab = nullptr; ctx->xf = ctx->xf_slab = false;
     if (ctx->plans_ok) {
         hipfftDestroy(ctx->plan_fwd);
         hipfftDestroy(ctx->plan_inv);

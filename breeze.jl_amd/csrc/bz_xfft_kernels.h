@@ -20,9 +20,20 @@
 
 #define XF_RB 8        // rows of y per workgroup: a transposed store / load moves XF_RB consecutive complex numbers (128 B) per kx
 
-// LDS slot of element p of a row: one slot of padding per 16 (a 16-byte element spans 4 banks, 16 elements span all 64: the radix-4
-// stages store at strides of 4, 16, 64 elements, which without the padding land on the same banks)
-#define XF_P(p) ((p) + ((p) >> 4))
+// LDS slot of element p < n2 of a row: the low four bits (the 16-byte slot inside a 256-byte bank period) are XOR-swizzled with a
+// function of bits 4-7, chosen by exhaustive search over linear swizzles against the access patterns of this file on the wave64
+// ds_read/write_b128 lane groups (MI355X_MICROARCH.md, LDS): strided stores of the radix-4 stages (4, 16, 64 elements apart), the
+// contiguous loads, the split pairs — 99 LDS passes per row transform against 192 unswizzled or padded (96 = conflict-free).
+// Element n2 (the Nyquist slot of the real transform) keeps its own index; rows are n2 + 4 slots apart, which makes the transposed
+// (kx, row) accesses of 8 rows conflict-free as well.
+__device__ __forceinline__ int xf_slot(int p, int n2)
+{
+    const int h = p >> 4;
+    const int x = ((h & 2) ? 6 : 0) ^ ((h & 4) ? 15 : 0) ^ ((h & 8) ? 9 : 0);
+    return (p < n2) ? (p ^ x) : p;
+}
+#define XF_P(p) xf_slot((p), n2)
+#define XF_ROW_STRIDE(n2) ((n2) + 4)
 
 __device__ __forceinline__ double2 xf_cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
@@ -118,17 +129,30 @@ __device__ __forceinline__ void xf_split_inverse(double2 *__restrict__ row, int 
     }
 }
 
+// Where element (level k, wavenumber kx, row) of the transposed half spectrum lives: one array hatT[(k NXH + kx) Ny + row] on a single
+// GPU (nkx = nxp = NXH, blk = 0); on a y-slab rank W blocks of nkx wavenumbers each, block d being the message for / from rank d
+// (bz_comm.hip: all-to-all of the blocks), with the zero padding of the last block (nxp = W nkx >= NXH) written by k_x_forward.
+struct XfLayout {
+    int nkx, nxp;
+    long long blk;       // elements (double2) per block
+};
+__device__ __forceinline__ long long xf_addr(const XfLayout &L, int Ny, int k, int kx, int row)
+{
+    const int d = kx / L.nkx, kxl = kx - d * L.nkx;
+    return (long long)d * L.blk + ((long long)k * L.nkx + kxl) * Ny + row;
+}
+
 // SRC 1: source term from the predictor momentum (arithmetic of k_poisson_source_rows); SRC 0: rows of the contiguous rhs buffer.
-// grid (Ny / XF_RB, ceil(Nz / kchunk)), block XF_RB * Nx / 8, dynamic LDS (XF_RB * (XF_P(n2) + 1) + 3 n2 / 2) * sizeof(double2).
+// grid (Ny / XF_RB, ceil(Nz / kchunk)), block XF_RB * Nx / 8, dynamic LDS (XF_RB * (n2 + 4) + 3 n2 / 2) * sizeof(double2).
 // Thread (row r, tid) owns the cell pairs i = 2 (tid + q Nx / 8), i + 1, q = 0 .. 3 — the four packed complex elements its first
 // butterfly reads; wlo carries rho_w of the lower faces from the previous level's upper faces (the block marches in z).
 template <int SRC>
 __global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const double *__restrict__ rhs, const double *__restrict__ ru,
                                                           const double *__restrict__ rv, const double *__restrict__ rw, double dt,
-                                                          double2 *__restrict__ hatT, const double2 *__restrict__ Wg, int kchunk)
+                                                          double2 *__restrict__ hatT, XfLayout L, const double2 *__restrict__ Wg, int kchunk)
 {
     extern __shared__ double2 xf_sm[];
-    const int Nx = g.Nx, n2 = Nx >> 1, T = n2 >> 2, RS = XF_P(n2) + 1, NXH = n2 + 1;
+    const int Nx = g.Nx, n2 = Nx >> 1, T = n2 >> 2, RS = XF_ROW_STRIDE(n2), NXH = n2 + 1;
     const int nthreads = blockDim.x;
     const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
     double2 *__restrict__ W = xf_sm + XF_RB * RS;
@@ -136,7 +160,8 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const doubl
     const int j0 = blockIdx.x * XF_RB, j = j0 + r;
     const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, g.Nz);
     double2 *__restrict__ row = xf_sm + r * RS;
-    const long long jp = (j + 1 < g.Ny) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
+    // y-slab: row Ny is the neighbour rank's first row, delivered into the halo by the caller's exchange
+    const long long jp = (j + 1 < g.Ny || !g.wrap_y) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
     double wlo[8];
     if (SRC) {
 #pragma unroll
@@ -174,21 +199,20 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const doubl
         xf_team_fft<false>(row, n2, tid, true, W);
         xf_split_forward(row, n2, tid, W);
         __syncthreads();
-        const long long base = (long long)k * NXH * g.Ny + j0;
-        for (int e = threadIdx.x; e < NXH * XF_RB; e += nthreads) {
+        for (int e = threadIdx.x; e < L.nxp * XF_RB; e += nthreads) {
             const int kx = e / XF_RB, rr = e - kx * XF_RB;
-            hatT[base + (long long)kx * g.Ny + rr] = xf_sm[rr * RS + XF_P(kx)];
+            hatT[xf_addr(L, g.Ny, k, kx, j0 + rr)] = (kx < NXH) ? xf_sm[rr * RS + XF_P(kx)] : make_double2(0.0, 0.0);
         }
         __syncthreads();
     }
 }
 
 // Transposed half spectrum -> rows of phi in the contiguous buffer phi_c (Nx * Ny * Nz).  Same grid, block and LDS as k_x_forward.
-__global__ __launch_bounds__(XF_RB * 64) void k_x_inverse(DevGrid g, const double2 *__restrict__ hatT, double *__restrict__ phi_c,
+__global__ __launch_bounds__(XF_RB * 64) void k_x_inverse(DevGrid g, const double2 *__restrict__ hatT, XfLayout L, double *__restrict__ phi_c,
                                                           const double2 *__restrict__ Wg, int kchunk)
 {
     extern __shared__ double2 xf_sm[];
-    const int Nx = g.Nx, n2 = Nx >> 1, T = n2 >> 2, RS = XF_P(n2) + 1, NXH = n2 + 1;
+    const int Nx = g.Nx, n2 = Nx >> 1, T = n2 >> 2, RS = XF_ROW_STRIDE(n2), NXH = n2 + 1;
     const int nthreads = blockDim.x;
     const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
     double2 *__restrict__ W = xf_sm + XF_RB * RS;
@@ -197,10 +221,9 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_inverse(DevGrid g, const doubl
     const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, g.Nz);
     double2 *__restrict__ row = xf_sm + r * RS;
     for (int k = kbeg; k < kend; ++k) {
-        const long long base = (long long)k * NXH * g.Ny + j0;
         for (int e = threadIdx.x; e < NXH * XF_RB; e += nthreads) {
             const int kx = e / XF_RB, rr = e - kx * XF_RB;
-            xf_sm[rr * RS + XF_P(kx)] = hatT[base + (long long)kx * g.Ny + rr];
+            xf_sm[rr * RS + XF_P(kx)] = hatT[xf_addr(L, g.Ny, k, kx, j0 + rr)];
         }
         __syncthreads();
         xf_split_inverse(row, n2, tid, W);

@@ -74,7 +74,10 @@ def test_local_transport_self_messages(bz, oracle, monkeypatch):
     assert models[0].comm_info()[1] > 0
 
 
-@pytest.mark.parametrize("world,size,moist", [(1, (32, 24, 16), False), (2, (32, 24, 16), True), (4, (32, 48, 16), False), (2, (70, 32, 12), True)])
+@pytest.mark.parametrize("world,size,moist", [(1, (32, 24, 16), False), (2, (32, 24, 16), True), (4, (32, 48, 16), False), (2, (70, 32, 12), True),
+                                              # shapes the hand-written x transforms take on slab ranks (Nx a power of two, 8 | local Ny): messages of
+                                              # the all-to-alls written / read in place, zero padding of the last wavenumber block
+                                              (2, (64, 32, 16), True), (4, (32, 64, 12), False), (2, (16, 16, 8), False)])
 def test_library_owned_slab_step_matches_the_oracle(bz, oracle, world, size, moist):
     steps, dt = 2, 2.0
     models = run_slabs(bz, size, world, steps, dt, moist)

@@ -10,14 +10,14 @@ import sys
 GROUPS = {
     "k5_scalar_pair<8>": "scalar_tendencies+rk3+thermo", "k5_u<8>": "x_momentum_tendency+rk3+velocity",
     "k6_u<8>": "x_momentum_tendency+rk3+velocity", "k6_v<8>": "y_momentum_tendency+rk3+velocity", "k6_w<8>": "z_momentum_tendency+rk3+velocity",
-    "k_tridiag_coop": "poisson_tridiagonal",
+    "k_tridiag_coop": "poisson_tridiagonal", "k_x_forward<1>": "poisson_source_term+fft_x", "k_x_inverse": "poisson_fft_x_inverse",
     "k5_v<8>": "y_momentum_tendency+rk3+velocity", "k5_w<8>": "z_momentum_tendency+rk3+velocity",
     "k_project_lean": "project_momentum", "k_project_diagnose<0>": "project_and_diagnose",
     "k_poisson_source_rows": "poisson_source_term", "k_tridiag_solve": "poisson_tridiagonal", "k_tridiag_lds": "poisson_tridiagonal",
     "k_scalar_pair_lds<8>": "scalar_tendencies+rk3", "k_u_tend_lds<8>": "x_momentum_tendency+rk3",
     "k_v_tend_lds<8>": "y_momentum_tendency+rk3", "k_w_tend_lds<8, 0>": "z_momentum_tendency+rk3",
 }
-FFT = {"fwd": "poisson_fft_forward", "back": "poisson_fft_inverse"}
+FFT = {"fwd": "poisson_fft_y_forward", "back": "poisson_fft_y_inverse"}      # library y transforms of the transposed spectrum
 
 
 def main():
@@ -32,7 +32,7 @@ def main():
             per[GROUPS[k]] = {"kernel": k, "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
         elif k.startswith("fft_rtc_"):
             g = FFT["fwd" if "_fwd_" in k else "back"]
-            e = per.setdefault(g, {"kernel": "rocFFT 2-D plan (two kernels)", "read_bytes": 0.0, "write_bytes": 0.0, "hbm_bytes_per_launch": 0.0})
+            e = per.setdefault(g, {"kernel": "rocFFT batched 1-D C2C plan along y", "read_bytes": 0.0, "write_bytes": 0.0, "hbm_bytes_per_launch": 0.0})
             e["read_bytes"] += rd; e["write_bytes"] += wr; e["hbm_bytes_per_launch"] += rd + wr
     json.dump(out, sys.stdout, indent=1)
     sys.stdout.write("\n")

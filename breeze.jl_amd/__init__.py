@@ -16,7 +16,8 @@ from .model import (AnelasticDynamics, AtmosphereModel, Centered, Field, WENO, c
 from . import compressible  # noqa: F401,E402
 from .compressible import (AcousticRungeKutta3, AcousticSubstepper, CompressibleAtmosphereModel, CompressibleDynamics,  # noqa: F401,E402
                            ExnerReferenceState, NewtonSolver, NoDivergenceDamping, ProportionalSubsteps,
-                           SplitExplicitTimeDiscretization, ThermalDivergenceDamping, DirectDivergenceDamping)
+                           SplitExplicitTimeDiscretization, ThermalDivergenceDamping, DirectDivergenceDamping, UpperSponge,
+                           LinearRamp, CubicRamp, Sin2Ramp)
 from .microphysics import SaturationAdjustment, SecantSolver, WarmPhaseEquilibrium  # noqa: F401,E402
 from .model import cell_advection_timescale, nan_checker  # noqa: F401,E402
 from .microphysics import (DCMIP2016KesslerMicrophysics, KesslerMicrophysicalFields, TetensFormula,  # noqa: F401,E402

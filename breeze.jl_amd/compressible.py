@@ -44,6 +44,30 @@ class ProportionalSubsteps:
     pass
 
 
+class LinearRamp:
+    code = 1
+
+
+class CubicRamp:
+    code = 2
+
+
+class Sin2Ramp:
+    code = 3
+
+
+class UpperSponge:
+    """UpperSponge(damping_rate=0.2, depth=5e3, ramp=CubicRamp()) (time_discretizations.jl:435-512): implicit Rayleigh damping of
+    (ρw)′ in a layer of thickness `depth` below z = grid.Lz, inside the column system of the acoustic substeps
+    (acoustic_substepping.jl:584-602,639,948)."""
+
+    def __init__(self, damping_rate=0.2, depth=5e3, ramp=None):
+        ramp = CubicRamp() if ramp is None else ramp
+        if not isinstance(ramp, (LinearRamp, CubicRamp, Sin2Ramp)):
+            raise ValueError("`ramp` must be an `<:AbstractRamp` (e.g. `CubicRamp()`, `Sin2Ramp()`, `LinearRamp()`)")
+        self.damping_rate, self.depth, self.ramp = float(damping_rate), float(depth), ramp
+
+
 class SplitExplicitTimeDiscretization:
     def __init__(self, substeps=None, acoustic_cfl=0.5, forward_weight=0.65, thermodynamic_tendency_factor=1,
                  vertical_momentum_tendency_factor=1, apply_first_substep_pressure_gradient=False, damping=None,
@@ -51,8 +75,8 @@ class SplitExplicitTimeDiscretization:
         damping = ThermalDivergenceDamping(coefficient=0.1) if damping is None else damping
         if not isinstance(damping, (ThermalDivergenceDamping, DirectDivergenceDamping, NoDivergenceDamping)):
             raise ValueError("`damping` must be an `AcousticDampingStrategy`")
-        if sponge is not None:
-            raise NotImplementedError("UpperSponge is not implemented in the HIP path")
+        if sponge is not None and not isinstance(sponge, UpperSponge):
+            raise ValueError("`sponge` must be an `UpperSponge` or None")
         if substep_distribution is not None and not isinstance(substep_distribution, ProportionalSubsteps):
             raise NotImplementedError("only ProportionalSubsteps is implemented in the HIP path")
         if not acoustic_cfl > 0:
@@ -64,7 +88,7 @@ class SplitExplicitTimeDiscretization:
         self.vertical_momentum_tendency_factor = float(vertical_momentum_tendency_factor)
         self.apply_first_substep_pressure_gradient = bool(apply_first_substep_pressure_gradient)
         self.damping = damping
-        self.sponge = None
+        self.sponge = sponge
         self.substep_distribution = substep_distribution or ProportionalSubsteps()
 
 
@@ -322,6 +346,8 @@ class CompressibleAtmosphereModel:
         bt.thermodynamic_tendency_factor = td.thermodynamic_tendency_factor
         bt.vertical_momentum_tendency_factor = td.vertical_momentum_tendency_factor
         bt.newton_abstol = self.temperature_solver.abstol
+        if td.sponge is not None:
+            bt.sponge_ramp, bt.sponge_damping_rate, bt.sponge_depth = td.sponge.ramp.code, td.sponge.damping_rate, td.sponge.depth
         self._ctx = C.c_void_p()
         rc = self._create_context(lib, bg, bc, br, bt, advection.order)
         if rc != 0:

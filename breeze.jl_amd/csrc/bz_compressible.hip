@@ -340,6 +340,7 @@ struct AcFields {
     const double *U0_rqcl, *U0_rqr, *G_rqcl, *G_rqr;
     double *Gs, *phi;             // slow vertical momentum tendency; forward-eliminated right-hand side
     double *tfac;                 // Thomas factors t_k
+    const double *sponge;         // UpperSponge: damping_rate * ramp(z_face) per face k = 0 .. Nz (all zero without a sponge)
 };
 
 // assemble_slow_vertical_momentum_tendency! + initialize_stage_perturbations! (acoustic_substepping.jl:727-752,793-838)
@@ -524,11 +525,12 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
             const double Gb = g.g * (P.dto * ((rp + rp_m) / 2.0) + P.dtn * ((rs + rs_m) / 2.0));
             const double d2 = ((w_p - w_0) * rdc - (w_0 - w_m) * rdm) * rdf;
             const double Gd = -P.d_old * d2;
-            const double f = w_0 + P.dtau * P.f_w * F.Gs[n] - Gp - Gb - Gd - 0.0;
+            const double sp = F.sponge[k];                // sponge_rhs / sponge_term_diag (acoustic_substepping.jl:591-602)
+            const double f = w_0 + P.dtau * P.f_w * F.Gs[n] - Gp - Gb - Gd - fabs(P.dto) * sp * w_0;
             // coefficients of row k
             const double a = -dtn2 * C_m * thf_m * rdm * rdf + dtn2 * g.g * rdm / 2.0 + (-P.d_new * rdm * rdf);
             const double b = 1.0 + (dtn2 * thf_0 * (C_0 * rdc + C_m * rdm) * rdf + dtn2 * g.g * (rdc - rdm) / 2.0 +
-                                    P.d_new * (rdc + rdm) * rdf + 0.0);
+                                    P.d_new * (rdc + rdm) * rdf + fabs(P.dtn) * sp);
             const double t = c_m / beta;
             beta = b - a * t;
             phi = (f - a * phi_m) / beta;
@@ -712,6 +714,7 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
     if (!out || !grid || !constants || !ref || !td) return BZ_ERR_INVALID;
     if ((ref->pressure == nullptr) != (ref->density == nullptr)) return BZ_ERR_INVALID;
     if (td->substeps < 0 || !(td->acoustic_cfl > 0.0) || td->newton_maxiter < 0) return BZ_ERR_INVALID;
+    if (td->sponge_ramp < 0 || td->sponge_ramp > 3 || (td->sponge_ramp && !(td->sponge_depth > 0.0))) return BZ_ERR_INVALID;
     const int nc = grid->Nz + 2 * grid->Hz;
     std::vector<double> zeros((size_t)nc, 0.0);
     bz_reference_state r;
@@ -740,6 +743,24 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
     (void)hipMemset(ctx->d_tfac_ac, 0, ncell * sizeof(double));
     (void)hipMemset(ctx->d_up2, 0, ncell * sizeof(double));
     (void)hipMemset(ctx->d_vp2, 0, ncell * sizeof(double));
+    // UpperSponge profile on the faces: rate * ramp(z, grid.Lz, depth), ramp = 0 below Lz - depth and 1 at z = Lz
+    // (time_discretizations.jl:398-433; the reference passes grid.Lz as the sponge top, whatever z[0] is)
+    std::vector<double> sp((size_t)grid->Nz + 1, 0.0);
+    if (td->sponge_ramp) {
+        const double Lz = grid->zf[grid->Nz] - grid->zf[0], depth = td->sponge_depth, pi = 3.14159265358979323846;
+        for (int k = 0; k <= grid->Nz; ++k) {
+            double sN = (grid->zf[k] - (Lz - depth)) / depth;
+            sN = sN < 0.0 ? 0.0 : (sN > 1.0 ? 1.0 : sN);
+            const double ramp = td->sponge_ramp == 1 ? sN : td->sponge_ramp == 2 ? sN * sN * (3.0 - 2.0 * sN) : std::sin(pi / 2.0 * sN) * std::sin(pi / 2.0 * sN);
+            sp[k] = td->sponge_damping_rate * ramp;
+        }
+    }
+    if (hipMalloc(&ctx->d_sponge, sp.size() * sizeof(double)) != hipSuccess) {
+        bz_destroy(ctx);
+        *out = nullptr;
+        return BZ_ERR_ALLOC;
+    }
+    BZ_HIP(hipMemcpy(ctx->d_sponge, sp.data(), sp.size() * sizeof(double), hipMemcpyHostToDevice));
     return BZ_OK;
 }
 
@@ -749,7 +770,8 @@ void bzi_compressible_teardown(bz_ctx *ctx)
     if (ctx->d_tfac_ac) (void)hipFree(ctx->d_tfac_ac);
     if (ctx->d_up2) (void)hipFree(ctx->d_up2);
     if (ctx->d_vp2) (void)hipFree(ctx->d_vp2);
-    ctx->d_Clin = ctx->d_tfac_ac = ctx->d_up2 = ctx->d_vp2 = nullptr;
+    if (ctx->d_sponge) (void)hipFree(ctx->d_sponge);
+    ctx->d_Clin = ctx->d_tfac_ac = ctx->d_up2 = ctx->d_vp2 = ctx->d_sponge = nullptr;
 }
 
 static DiagFields diag_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_acoustic_substepper *sub)
@@ -901,6 +923,7 @@ static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_
     F.au = a->time_averaged_u; F.av = a->time_averaged_v; F.aw = a->time_averaged_w;
     F.Gs = a->slow_vertical_momentum_tendency; F.phi = a->vertical_solver_source_term;
     F.tfac = ctx->d_tfac_ac;
+    F.sponge = ctx->d_sponge;
     F.rup_in = F.rup; F.rvp_in = F.rvp; F.rthp_out = F.rthp;
     const bz_kessler_model_fields &K = ctx->kessler;
     F.rqcl = K.cloud_liquid_density; F.rqr = K.rain_density;

@@ -292,6 +292,7 @@ struct bz_ctx {
     bool has_reference = false;       // ExnerReferenceState columns present (else p_r = rho_r = 0)
     bz_split_explicit se;
     double dz_min = 0.0;              // minimum_zspacing(grid)
+    double *d_sponge = nullptr;       // UpperSponge rate * ramp per face (compressible contexts)
     double *d_Clin = nullptr;         // centre array: gamma R_m * Pi of the current linearisation
     double *d_tfac_ac = nullptr;      // centre array: Thomas factors t_k of the acoustic column system (per stage)
     double *d_up2 = nullptr, *d_vp2 = nullptr;   // second buffers of the (rho u)', (rho v)' ping-pong (fused substep)
@@ -355,6 +356,12 @@ struct bz_ctx {
     } while (0)
 
 // Scoped profiling region: records start/stop events on the ctx stream when enabled.
+// Bit pattern of a non-negative real for atomicMax reductions (monotone in the value).  tools/gen_f32_sources.py swaps these three
+// definitions for their 32-bit counterparts in the Float32 build.
+typedef unsigned long long bz_bits_t;
+__device__ __forceinline__ bz_bits_t bz_real_bits(double d) { return (bz_bits_t)__double_as_longlong(d); }
+__device__ __forceinline__ double bz_real_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
 struct ProfileScope {
     bz_ctx *ctx;
     int slot = -1;

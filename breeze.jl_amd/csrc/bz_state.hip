@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_copy5(long long count, double *d0, cons
 __global__ __launch_bounds__(TX *TY) void k_max_abs_div(DevGrid g, const double *__restrict__ ru,
                                                        const double *__restrict__ rv,
                                                        const double *__restrict__ rw,
-                                                       unsigned long long *out)
+                                                       bz_bits_t *out)
 {
     int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
     double d = 0.0;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(TX *TY) void k_max_abs_div(DevGrid g, const double 
         d = fabs(g.Vinv_c[k] * (a + b + c));
     }
     for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_down(d, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(d));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, bz_real_bits(d));
 }
 
 static inline dim3 cell_grid(const DevGrid &g, int nz) { return dim3((g.Nx + TX - 1) / TX, (g.Ny + TY - 1) / TY, nz); }
@@ -238,7 +238,7 @@ extern "C" int bz_max_abs_divergence(bz_ctx *ctx, const bz_state *s, double *out
     if (rc) return rc;
     BZ_HIP(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
     hipLaunchKernelGGL(k_max_abs_div, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, s->rho_u, s->rho_v,
-                       s->rho_w, (unsigned long long *)ctx->d_scalar);
+                       s->rho_w, (bz_bits_t *)ctx->d_scalar);
     BZ_LAUNCH_CHECK();
     BZ_HIP(hipMemcpyAsync(out, ctx->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     BZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -253,7 +253,7 @@ extern "C" int bz_max_abs_divergence(bz_ctx *ctx, const bz_state *s, double *out
 __global__ __launch_bounds__(TX *TY) void k_max_inverse_advection_timescale(DevGrid g, const double *__restrict__ u,
                                                                            const double *__restrict__ v,
                                                                            const double *__restrict__ w, int with_w,
-                                                                           unsigned long long *out)
+                                                                           bz_bits_t *out)
 {
     int i = blockIdx.x * TX + threadIdx.x, j = blockIdx.y * TY + threadIdx.y, k = blockIdx.z;
     double d = 0.0;
@@ -262,10 +262,10 @@ __global__ __launch_bounds__(TX *TY) void k_max_inverse_advection_timescale(DevG
         const double ix = fabs(u[n]) / g.dx, iy = fabs(v[n]) / g.dy;
         const double iz = with_w ? fabs(w[n]) / g.dzf[k] : 0.0;
         d = ix + iy + iz;
-        if (d != d) d = __longlong_as_double(0x7ff0000000000000LL);      // NaN velocity: timescale 0
+        if (d != d) d = bz_real_inf();      // NaN velocity: timescale 0
     }
     for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_down(d, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(d));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, bz_real_bits(d));
 }
 
 extern "C" int bz_cell_advection_timescale(bz_ctx *ctx, const double *u, const double *v, const double *w, double *out)
@@ -274,7 +274,7 @@ extern "C" int bz_cell_advection_timescale(bz_ctx *ctx, const double *u, const d
     const DevGrid &g = ctx->dg;
     BZ_HIP(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
     hipLaunchKernelGGL(k_max_inverse_advection_timescale, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, u, v,
-                       w ? w : u, w ? 1 : 0, (unsigned long long *)ctx->d_scalar);
+                       w ? w : u, w ? 1 : 0, (bz_bits_t *)ctx->d_scalar);
     BZ_LAUNCH_CHECK();
     double inv = 0.0;
     BZ_HIP(hipMemcpyAsync(&inv, ctx->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -289,7 +289,10 @@ typedef struct bz_split_explicit {
     double newton_abstol;             /* NewtonSolver abstol (default 1e-4), reltol = 0                       */
     int32_t direct_divergence_damping; /* != 0: DirectDivergenceDamping(damping_coefficient) (time_discretizations.jl:269-274,
                                          acoustic_substepping.jl:1146-1188) instead of ThermalDivergenceDamping; horizontal only  */
-    int32_t reserved;
+    int32_t sponge_ramp;              /* UpperSponge (time_discretizations.jl:381-512; acoustic_substepping.jl:584-602,639,948):
+                                         0 = sponge = nothing, 1 LinearRamp, 2 CubicRamp (the default ramp), 3 Sin2Ramp                 */
+    double sponge_damping_rate;       /* peak rate at the lid, 1/s (default 0.2)                                                       */
+    double sponge_depth;              /* layer thickness below z = grid.Lz, m (default 5e3)                                            */
 } bz_split_explicit;
 
 /* ExnerReferenceState columns (src/Thermodynamics/reference_states.jl:717-815): HOST arrays of length Nz+2Hz

@@ -202,7 +202,12 @@ struct BzSplitExplicit
     substeps::Int32; damp_vertical::Int32; apply_first::Int32; newton_maxiter::Int32
     acoustic_cfl::Float64; forward_weight::Float64; damping_coefficient::Float64
     f_θ::Float64; f_w::Float64; newton_abstol::Float64
+    direct_divergence_damping::Int32; sponge_ramp::Int32          # ramp: 0 none, 1 LinearRamp, 2 CubicRamp, 3 Sin2Ramp
+    sponge_damping_rate::Float64; sponge_depth::Float64
 end
+rampcode(::Nothing) = Int32(0)
+rampcode(s::UpperSponge) = s.ramp isa LinearRamp ? Int32(1) : s.ramp isa CubicRamp ? Int32(2) : s.ramp isa Sin2Ramp ? Int32(3) :
+                           error("BreezeHIP: custom sponge ramps are not supported")
 struct BzExnerReference
     pst::Float64; pressure::Ptr{Float64}; density::Ptr{Float64}
 end
@@ -238,8 +243,10 @@ function create_compressible_context(model)
     damp = a.damping
     td = BzSplitExplicit(something(a.substeps, 0), damp isa ThermalDivergenceDamping && damp.damp_vertical,
                          a.apply_first_substep_pressure_gradient, solver.maxiter, a.acoustic_cfl, a.forward_weight,
-                         damp isa ThermalDivergenceDamping ? damp.coefficient : -1.0,
-                         a.thermodynamic_tendency_factor, a.vertical_momentum_tendency_factor, solver.abstol)
+                         damp isa Union{ThermalDivergenceDamping, DirectDivergenceDamping} ? damp.coefficient : -1.0,
+                         a.thermodynamic_tendency_factor, a.vertical_momentum_tendency_factor, solver.abstol,
+                         damp isa DirectDivergenceDamping, rampcode(a.sponge),
+                         a.sponge === nothing ? 0.0 : a.sponge.damping_rate, a.sponge === nothing ? 0.0 : a.sponge.depth)
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve zf p ρ begin
         g = BzGrid(Nx, Ny, Nz, Hx, Hy, Hz, map(topocode, topology(grid)), 8, grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, pointer(zf),

@@ -14,7 +14,8 @@
  *
  * Index convention: 0-based; cell k has faces k (below) and k+1 (above); Julia face K = k+1.
  * Scope: (Periodic|Flat, Periodic|Flat, Bounded), microphysics = nothing (vapour only),
- * ProportionalSubsteps, ThermalDivergenceDamping (optionally damp_vertical) or none, no sponge.
+ * ProportionalSubsteps, ThermalDivergenceDamping (optionally damp_vertical), DirectDivergenceDamping or none, optional UpperSponge
+ * (a per-face profile rate * ramp(z) built by the caller: acoustic_substepping.jl:584-602).
  */
 
 /* boundary-aware centre->face z interpolation (acoustic_substepping.jl:539-550) */
@@ -321,7 +322,8 @@ void og_build_predictors(const og_grid *G, double *rs, double *rths, double *rth
 void og_build_vertical_rhs(const og_grid *G, double *rhs, const double *rs, const double *rths,
                            const double *rp, const double *rthp, const double *rwp,
                            const double *Pi, const double *gR, const double *Gs,
-                           double dtau, double dtau_new, double dtau_old, double d_old, double f_w)
+                           double dtau, double dtau_new, double dtau_old, double d_old, double f_w,
+                           const double *sponge /* rate * ramp per face 0..Nz, or NULL */)
 {
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k <= G->Nz; ++k)
@@ -341,7 +343,7 @@ void og_build_vertical_rhs(const og_grid *G, double *rhs, const double *rs, cons
                 double Gb = G->g * (dtau_old * rfo + dtau_new * rfs);
                 double d2 = ((rwp[up] - rwp[n]) * rdzc_at(G, k) - (rwp[n] - rwp[m]) * rdzc_at(G, k - 1)) * rdzf_at(G, k);
                 double Gd = -d_old * d2;
-                double Gsp = 0.0;
+                double Gsp = sponge ? fabs(dtau_old) * sponge[k] * rwp[n] : 0.0;      /* sponge_rhs, :598-603 */
                 rhs[n] = rwp[n] + dtau * f_w * Gs[n] - Gp - Gb - Gd - Gsp;
             }
 }
@@ -351,7 +353,7 @@ void og_build_vertical_rhs(const og_grid *G, double *rhs, const double *rs, cons
  * i.e. Julia get_coefficient(k = r, Lower), kf = r+1 in Julia = face r here), 1 diagonal, 2 upper. */
 static inline double acoustic_coefficient(const og_grid *G, const double *Pi, const double *thL,
                                           const double *gR, int i, int j, int r, int which,
-                                          double dtn, double d_new)
+                                          double dtn, double d_new, const double *sponge)
 {
     size_t n = IDX(G, i, j, r), m = n - STRZ(G);
     double rdf = rdzf_at(G, r);
@@ -370,7 +372,8 @@ static inline double acoustic_coefficient(const og_grid *G, const double *Pi, co
         double pgf = (dtn * dtn) * th * (Cp * rdp + Cm * rdm) * rdf;
         double buoy = (dtn * dtn) * G->g * (rdp - rdm) / 2.0;
         double damp = d_new * (rdp + rdm) * rdf;
-        return 1.0 + (pgf + buoy + damp + 0.0) * (r > 0 ? 1.0 : 0.0);
+        double spg = sponge ? fabs(dtn) * sponge[r] : 0.0;                              /* sponge_term_diag, :591-596 */
+        return 1.0 + (pgf + buoy + damp + spg) * (r > 0 ? 1.0 : 0.0);
     } else {
         double rdp = rdzc_at(G, r);
         double Cp = gR[n] * Pi[n];
@@ -385,12 +388,12 @@ static inline double acoustic_coefficient(const og_grid *G, const double *Pi, co
 double og_acoustic_coefficient(const og_grid *G, const double *Pi, const double *thL, const double *gR,
                                int i, int j, int r, int which, double dtn, double d_new)
 {
-    return acoustic_coefficient(G, Pi, thL, gR, i, j, r, which, dtn, d_new);
+    return acoustic_coefficient(G, Pi, thL, gR, i, j, r, which, dtn, d_new, NULL);
 }
 
 /* BatchedTridiagonalSolver (Oceananigans, recalled): Thomas, rows r = 0..Nz-1, result into rwp */
 void og_acoustic_tridiagonal_solve(const og_grid *G, double *rwp, const double *rhs, const double *Pi,
-                                   const double *thL, const double *gR, double dtn, double d_new)
+                                   const double *thL, const double *gR, double dtn, double d_new, const double *sponge)
 {
     const double EPS10 = 10.0 * 2.220446049250313e-16;
     int Nz = G->Nz;
@@ -398,14 +401,14 @@ void og_acoustic_tridiagonal_solve(const og_grid *G, double *rwp, const double *
     for (int j = 0; j < G->Ny; ++j)
         for (int i = 0; i < G->Nx; ++i) {
             double *t = (double *)malloc(sizeof(double) * (size_t)(Nz + 1));
-            double beta = acoustic_coefficient(G, Pi, thL, gR, i, j, 0, 1, dtn, d_new);
+            double beta = acoustic_coefficient(G, Pi, thL, gR, i, j, 0, 1, dtn, d_new, sponge);
             size_t n0 = IDX(G, i, j, 0);
             rwp[n0] = rhs[n0] / beta;
             for (int r = 1; r < Nz; ++r) {
                 size_t n = IDX(G, i, j, r), m = n - STRZ(G);
-                double cm = acoustic_coefficient(G, Pi, thL, gR, i, j, r - 1, 2, dtn, d_new);
-                double b = acoustic_coefficient(G, Pi, thL, gR, i, j, r, 1, dtn, d_new);
-                double a = acoustic_coefficient(G, Pi, thL, gR, i, j, r, 0, dtn, d_new);
+                double cm = acoustic_coefficient(G, Pi, thL, gR, i, j, r - 1, 2, dtn, d_new, sponge);
+                double b = acoustic_coefficient(G, Pi, thL, gR, i, j, r, 1, dtn, d_new, sponge);
+                double a = acoustic_coefficient(G, Pi, thL, gR, i, j, r, 0, dtn, d_new, sponge);
                 t[r] = cm / beta;
                 beta = b - a * t[r];
                 if (fabs(beta) > EPS10) rwp[n] = (rhs[n] - a * rwp[m]) / beta;

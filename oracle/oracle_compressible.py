@@ -107,8 +107,9 @@ class SplitExplicit:
     def __init__(self, substeps=None, acoustic_cfl=0.5, forward_weight=0.65,
                  damping_coefficient=0.1, damp_vertical=False,
                  apply_first_substep_pressure_gradient=False,
-                 thermodynamic_tendency_factor=1.0, vertical_momentum_tendency_factor=1.0, direct_damping=False):
+                 thermodynamic_tendency_factor=1.0, vertical_momentum_tendency_factor=1.0, direct_damping=False, sponge=None):
         self.direct_damping = bool(direct_damping)      # DirectDivergenceDamping(coefficient) instead of ThermalDivergenceDamping
+        self.sponge = sponge                            # None or (damping_rate, depth, ramp) with ramp in {"linear", "cubic", "sin2"}
         self.substeps = substeps
         self.acoustic_cfl = float(acoustic_cfl)
         self.forward_weight = float(forward_weight)
@@ -117,6 +118,14 @@ class SplitExplicit:
         self.apply_first = bool(apply_first_substep_pressure_gradient)
         self.f_theta = float(thermodynamic_tendency_factor)
         self.f_w = float(vertical_momentum_tendency_factor)
+
+
+def upper_sponge_profile(zf, Lz, damping_rate=0.2, depth=5e3, ramp="cubic"):
+    """damping_rate * ramp(z, Lz, depth) on the faces zf (time_discretizations.jl:398-433: LinearRamp, CubicRamp, Sin2Ramp; the
+    reference passes grid.Lz as the sponge top; UpperSponge defaults :497)."""
+    s = np.clip((np.asarray(zf, dtype=np.float64) - (Lz - depth)) / depth, 0.0, 1.0)
+    shape = {"linear": s, "cubic": s * s * (3 - 2 * s), "sin2": np.sin(np.pi / 2 * s) ** 2}[ramp]
+    return np.ascontiguousarray(damping_rate * shape)
 
 
 def compute_acoustic_substeps(grid, dt, constants, acoustic_cfl):
@@ -430,6 +439,11 @@ class CompressibleOracleModel:
             self._halo_center(f)
         self._halo_w(self.rwp)
         d_new, d_old = self.implicit_damping_factors()
+        sponge = None
+        if getattr(td, "sponge", None) is not None:
+            zf = np.asarray(g.zf, dtype=np.float64)
+            self._sponge = upper_sponge_profile(zf, zf[-1] - zf[0], *td.sponge)
+            sponge = _p(self._sponge)
         for s in range(1, n_tau + 1):
             gate = apply_horizontal_pressure_gradient_substep(s, n_tau, td.apply_first)
             L.og_explicit_horizontal_step(cg, _p(self.rup), _p(self.rvp), _p(self.p), _p(self.rthp), _p(self.Pi),
@@ -444,9 +458,9 @@ class CompressibleOracleModel:
             self._halo_center(self.rth_old)
             L.og_build_vertical_rhs(cg, _p(self.rhs), _p(self.rs), _p(self.rths), _p(self.rp), _p(self.rthp),
                                     _p(self.rwp), _p(self.Pi), _p(self.gR), _p(self.Gs), C.c_double(dtau),
-                                    C.c_double(dtn), C.c_double(dto), C.c_double(d_old), C.c_double(td.f_w))
+                                    C.c_double(dtn), C.c_double(dto), C.c_double(d_old), C.c_double(td.f_w), sponge)
             L.og_acoustic_tridiagonal_solve(cg, _p(self.rwp), _p(self.rhs), _p(self.Pi), _p(self.thL),
-                                            _p(self.gR), C.c_double(dtn), C.c_double(d_new))
+                                            _p(self.gR), C.c_double(dtn), C.c_double(d_new), sponge)
             L.og_post_solve_recovery(cg, _p(self.rp), _p(self.rthp), _p(self.rwp), _p(self.rup), _p(self.rvp),
                                      _p(self.rs), _p(self.rths), _p(self.au), _p(self.av), _p(self.aw),
                                      _p(self.thL), C.c_double(dtn))

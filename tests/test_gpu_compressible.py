@@ -26,8 +26,12 @@ def make_pair(oracle, oc, bz, size=(24, 16, 20), theta_ref=300.0, reference=True
     damping = (bz.NoDivergenceDamping() if otd.damping_coefficient is None
                else bz.DirectDivergenceDamping(coefficient=otd.damping_coefficient) if otd.direct_damping
                else bz.ThermalDivergenceDamping(coefficient=otd.damping_coefficient, damp_vertical=otd.damp_vertical))
+    sponge = None
+    if otd.sponge is not None:
+        ramp = {"linear": bz.LinearRamp, "cubic": bz.CubicRamp, "sin2": bz.Sin2Ramp}[otd.sponge[2]]()
+        sponge = bz.UpperSponge(damping_rate=otd.sponge[0], depth=otd.sponge[1], ramp=ramp)
     btd = bz.SplitExplicitTimeDiscretization(substeps=otd.substeps, acoustic_cfl=otd.acoustic_cfl,
-                                             forward_weight=otd.forward_weight, damping=damping,
+                                             forward_weight=otd.forward_weight, damping=damping, sponge=sponge,
                                              apply_first_substep_pressure_gradient=otd.apply_first)
     dyn = bz.CompressibleDynamics(btd, reference_potential_temperature=theta_ref if reference else None,
                                   reference_state="auto" if reference else None)
@@ -189,6 +193,9 @@ CASES = [
     dict(),                                                      # adaptive substep count from the acoustic CFL
     dict(substeps=6, direct_damping=True),                       # DirectDivergenceDamping (acoustic_substepping.jl:1146-1188)
     dict(substeps=1, direct_damping=True, damping_coefficient=0.15),
+    dict(substeps=6, sponge=(0.2, 3000.0, "cubic")),             # UpperSponge (acoustic_substepping.jl:584-602), each ramp shape
+    dict(substeps=4, sponge=(0.5, 2000.0, "linear"), damp_vertical=True),
+    dict(sponge=(0.1, 4000.0, "sin2")),
 ]
 
 
@@ -232,7 +239,7 @@ def test_acoustic_substep_loop_matches_oracle(oracle, oc, bz, td, beta):
 
 
 @pytest.mark.parametrize("td", [dict(substeps=6), dict(), dict(substeps=4, damping_coefficient=0.05, damp_vertical=True),
-                                dict(substeps=6, direct_damping=True)])
+                                dict(substeps=6, direct_damping=True), dict(substeps=6, sponge=(0.2, 3000.0, "cubic"))])
 def test_time_steps_match_oracle(oracle, oc, bz, td):
     """Three full WS-RK3 steps of a warm bubble with a moist tracer, whole-step seam: 1e-9 of max-abs."""
     om, hm = make_pair(oracle, oc, bz, size=(24, 16, 24), **td)

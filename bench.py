@@ -183,6 +183,83 @@ def cpu_baseline(n, budget_s=25.0):
                       f"C/OpenMP oracle on {threads} threads + pocketfft on {threads} threads"}
 
 
+def config4_run(args, bz, rank, world, dist, device, fail):
+    """--workload config4: BASELINE configs[4], the splitting-supercell shape — CompressibleDynamics, split-explicit WS-RK3 with
+    acoustic substeps, DCMIP2016 Kessler microphysics, 512 x 512 x 128 cells on the example's 168 km x 168 km x 20 km box
+    (/root/reference/examples/splitting_supercell.jl:88-96), moist column + 3 K warm bubble + sheared wind, Float64, dt = 2 s —
+    on one GPU or split into `world` y-slabs with the library-owned communicator (bz_comm.hip: per-substep halo exchange of
+    (rho theta)' and (rho v)', per-stage exchange of the rest).  A second milestone: never the headline `value` of the default run."""
+    import torch
+    Nx, Ny, Nz, dt = 512, 512, 128, 2.0
+    G = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 168e3), y=(0.0, 168e3), z=(0.0, 20e3))
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), surface_pressure=1e5, reference_potential_temperature=300.0)
+    mkw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
+               microphysics=bz.DCMIP2016KesslerMicrophysics())
+    slabs = world > 1 or args.slab
+    transport = "rccl" if args.transport in ("auto", "rccl") else "torch"
+    try:
+        if slabs:
+            m = bz.compressible.SlabCompressibleModel(G, rank, world, dyn, advection=bz.WENO(order=5), device=device,
+                                                      transport=transport, **mkw)
+        else:
+            m = bz.CompressibleAtmosphereModel(G, dyn, advection=bz.WENO(order=5), device=device, **mkw)
+        Hz = m.grid.Hz
+        col = m.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
+
+        def theta(x, y, z):      # neutral column + the example's bubble: 3 K at (84 km, 84 km, 1.5 km), radii 10 km x 1.5 km
+            r = np.sqrt(((x - 84e3) / 10e3) ** 2 + ((y - 84e3) / 10e3) ** 2 + ((z - 1500.0) / 1500.0) ** 2)
+            return 300.0 + 3.0 * np.cos(np.pi / 2 * np.minimum(r, 1.0)) ** 2
+
+        m.set(ρ=lambda x, y, z: col * 300.0 / theta(x, y, z), θ=theta, v=0.0, w=0.0,
+              u=lambda x, y, z: 0.0015 * np.minimum(z, 5e3) + 0 * x + 0 * y,
+              qᵗ=lambda x, y, z: 0.014 * np.exp(-z / 2500.0) + 0 * x + 0 * y)
+        for _ in range(max(1, args.warmup)):
+            m.time_step(dt)
+        m.profile_reset()
+        m.profile_enable(True)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        sent0 = m.comm_info()[1] if slabs and transport == "rccl" else 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            m.time_step(dt)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        m.profile_enable(False)
+        finite = bool(torch.isfinite(m.velocities["w"].parent).all().item())
+        if dist is not None:
+            t = torch.tensor([elapsed, 0.0 if finite else 1.0], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, finite = t[0].item(), t[1].item() == 0.0
+    except Exception as exc:      # noqa: BLE001
+        fail(f"config4 run failed: {exc!r}")
+    if rank == 0:
+        prof = {k: v[0] / args.steps for k, v in sorted(m.profile().items())}
+        nsub = [m.stage_substeps(dt, b)[0] for b in (1 / 3, 1 / 2, 1.0)]
+        out = {"metric": "grid-cells advanced/sec (compressible split-explicit + Kessler step), 512x512x128",
+               "value": Nx * Ny * Nz * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps,
+               "warmup": max(1, args.warmup), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[4]: splitting-supercell shape 512x512x128, CompressibleDynamics + "
+                                      "SplitExplicitTimeDiscretization defaults + DCMIP2016 Kessler, WENO5, dt=2s",
+                          "grid": [Nx, Ny, Nz], "dt": dt, "substeps_per_stage": nsub,
+                          "parallelism": "single GPU" if not slabs else
+                          f"{world} y-slabs of {Nx}x{Ny // world}x{Nz}, halo exchanges over " +
+                          ("RCCL inside the C library (bz_comm.hip)" if transport == "rccl" else "torch.distributed (RCCL backend)")},
+               "kernels_ms_per_step": prof, "finite": finite,
+               "comm_ms_per_step": sum(v for k, v in prof.items() if k.startswith("comm_")),
+               "note": "second milestone (SURVEY.md §8 a15-a17); the headline metric is the default workload"}
+        if slabs and transport == "rccl":
+            out["comm_bytes_sent_per_step_per_gpu"] = (m.comm_info()[1] - sent0) // args.steps
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without a rendezvous environment starts its own ranks
 # ---------------------------------------------------------------------------------------------------------------------
@@ -369,6 +446,8 @@ def run_rank(args):
             dist.destroy_process_group()
         return 0
 
+    if args.workload == "config4":
+        return config4_run(args, bz, rank, world, dist, device, fail)
     dt = 1.0
     G, label, scaling = problem(args, world)
     use_slabs = (world > 1 and not args.replicas) or (world == 1 and args.slab)
@@ -553,7 +632,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--workload", choices=("bubble", "config3"), default="bubble")
+    ap.add_argument("--workload", choices=("bubble", "config3", "config4"), default="bubble",
+                    help="bubble: the headline workload (configs[1]); config3: 1024 x (128 N) x 512 slabs; config4: compressible + "
+                         "Kessler 512x512x128 (second milestone, split over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the slab decomposition (explicit only)")
     ap.add_argument("--slab", action="store_true", help="N=1: run the slab driver (world 1) instead of the whole-step seam")

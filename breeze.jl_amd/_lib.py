@@ -221,6 +221,7 @@ SYMBOLS = {
     "bz_comm_exchange_y_halos": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32]),
     "bz_comm_update_state_and_project": (C.c_int, [_ctx, _sp, _pp, C.c_double, C.c_int]),
     "bz_comm_info": (C.c_int, [_ctx, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "bz_comm_compressible_update_state": (C.c_int, [_ctx, _csp, _cpp, _asp, C.c_int]),
     "bz_set_tracers": (C.c_int, [_ctx, C.c_int32, C.POINTER(bz_tracer_fields)]),
     "bz_set_closure": (C.c_int, [_ctx, C.POINTER(bz_smagorinsky_lilly), C.c_void_p]),
     "bz_set_bounds_preserving_advection": (C.c_int, [_ctx, C.POINTER(bz_bounds_preserving_advection)]),

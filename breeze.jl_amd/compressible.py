@@ -585,9 +585,12 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
     ((ρθ)′ and (ρv)′) are exchanged with the ring neighbours, everything else once per stage
     (breeze.jl_amd/distributed.py: SlabDecomposition, torch.distributed; backend "nccl" = RCCL on ROCm)."""
 
-    def __init__(self, global_grid, rank, world, dynamics, advection=None, group=None, device=None, decomp=None, **kw):
+    def __init__(self, global_grid, rank, world, dynamics, advection=None, group=None, device=None, decomp=None,
+                 transport="torch", **kw):
+        """transport: "torch" — exchanges issued from Python through torch.distributed (`decomp` / `group`); "rccl" or
+        "local:<name>" — the library owns the communicator (csrc/bz_comm.hip) and `time_step` is one C call per step."""
         import torch
-        from .distributed import SlabDecomposition
+        from .distributed import LibraryComm, SlabDecomposition, attach_library_transport
         if global_grid.topology != (Periodic, Periodic, Bounded):
             raise NotImplementedError("slab decomposition implements topology (Periodic, Periodic, Bounded)")
         if global_grid.Ny % world:
@@ -601,21 +604,33 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
                                halo=(G.Hx, G.Hy, G.Hz))
         grid.Δx, grid.Δy = G.Δx, G.Δy          # bit-identical spacings on every rank
         self.decomp = None                     # set after construction: the constructor's set-up is rank-local
-        self._pending_decomp = decomp or SlabDecomposition(G.Nx, Ny, G.Nz, G.Hy, rank, world, group)
+        self.transport = transport
+        library = transport != "torch"
+        self._pending_decomp = LibraryComm(self) if library else (decomp or SlabDecomposition(G.Nx, Ny, G.Nz, G.Hy, rank, world, group))
         dev = device if device is not None else f"cuda:{torch.cuda.current_device()}"
         super().__init__(grid, dynamics, advection=advection, device=dev, **kw)
+        if library:
+            attach_library_transport(self, transport, group)
         self.decomp = self._pending_decomp
         if getattr(self.decomp, "rows", "absent") is None:      # one gather / scatter launch per direction for the halo rows
             self.decomp.rows = self._device_rows
-        # second buffers of the (ρu)′, (ρv)′ ping-pong are owned here so that their halos can be exchanged
+        # second buffers of the (ρu)′, (ρv)′ ping-pong are owned here so that their halos can be exchanged (the library-owned
+        # step exchanges the context's own scratch buffers)
         self._up2, self._vp2 = Field(grid, _LOC["fcc"], self.device), Field(grid, _LOC["cfc"], self.device)
-        self._check(self._lib.bz_set_acoustic_scratch(self._ctx, C.c_void_p(self._up2.ptr()), C.c_void_p(self._vp2.ptr())),
-                    "bz_set_acoustic_scratch")
+        if not library:
+            self._check(self._lib.bz_set_acoustic_scratch(self._ctx, C.c_void_p(self._up2.ptr()), C.c_void_p(self._vp2.ptr())),
+                        "bz_set_acoustic_scratch")
         sub = self.timestepper.substepper
         self._th_buf = (sub.density_potential_temperature_perturbation.parent,
                         sub.previous_density_potential_temperature_perturbation.parent)
         self._v_buf = (sub.momentum_perturbation_v.parent, self._vp2.parent)
         self._exchange([self.dynamics.pressure.parent])
+
+    def comm_info(self):
+        """(transport name, bytes this rank has sent, number of exchanges) of the library-owned communicator."""
+        name, nbytes, nex = C.c_char_p(), C.c_int64(), C.c_int32()
+        self._check(self._lib.bz_comm_info(self._ctx, C.byref(name), C.byref(nbytes), C.byref(nex)), "bz_comm_info")
+        return name.value.decode(), nbytes.value, nex.value
 
     def _create_context(self, lib, bg, bc, br, bt, order):
         return lib.bz_create_compressible_slab(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), C.byref(bt), order,
@@ -648,6 +663,10 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
         """update_state! with the neighbour exchanges of the slab decomposition.  The diagnosis needs ρᵈ of row -1 (face
         velocities); everything else is exchanged after it, when the x halos of the edge rows (written by the diagnosis
         kernel) are valid, so that the corner cells the WENO stencils touch arrive with the rows."""
+        if self.transport != "torch":
+            self._check(self._lib.bz_comm_compressible_update_state(self._ctx, C.byref(self._state), C.byref(self._G), C.byref(self._sub),
+                                                                    1 if compute_tendencies else 0), "bz_comm_compressible_update_state")
+            return
         self._exchange([self.dynamics.dry_density.parent])
         self._check(self._lib.bz_compressible_update_state(self._ctx, C.byref(self._state), C.byref(self._G), C.byref(self._sub), 0),
                     "bz_compressible_update_state")
@@ -673,6 +692,10 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
         self._check(lib.bz_acoustic_stage_end(ctx, st, U0, G, sub, float(Δt), float(β), 1), "bz_acoustic_stage_end")
 
     def time_step_slab(self, Δt):
+        if self.transport != "torch":       # the whole distributed step behind one call (bz_comm.hip: bzi_dist_time_step_compressible)
+            self._check(self._lib.bz_time_step_compressible(self._ctx, C.byref(self._state), C.byref(self._U0), C.byref(self._G),
+                                                            C.byref(self._sub), float(Δt)), "bz_time_step_compressible")
+            return
         store_initial_state_(self)
         for β in (self.timestepper.β1, self.timestepper.β2, self.timestepper.β3):
             self.acoustic_rk3_substep_slab(Δt, β)

@@ -219,7 +219,7 @@ struct LocalTransport : Transport {
 };
 
 // ---- the communicator of a context ----------------------------------------------------------------------------------------------
-#define BZ_COMM_MAX_FIELDS 16
+#define BZ_COMM_MAX_FIELDS 24
 struct BzComm {
     Transport *T = nullptr;
     int W = 1, rank = 0, upper = 0, lower = 0;
@@ -278,6 +278,7 @@ static int comm_attach(bz_ctx *ctx, Transport *T)
     BZ_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     BZ_HIP(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     BZ_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    if (ctx->compressible) return BZ_OK;          // halo exchanges only: the acoustic column solve is rank-local
     const size_t nreal = (size_t)g.Nx * g.Ny * g.Nz;
     const int nxh = g.Nx / 2 + 1, nxh_pad = ctx->nkx * c->W;
     const size_t nhat = (size_t)g.Nz * g.Ny * (size_t)(nxh_pad > nxh ? nxh_pad : nxh);
@@ -630,5 +631,97 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         }
     }
     ctx->G_is_predictor = true;
+    return BZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Library-owned distributed COMPRESSIBLE step (BASELINE configs[4]: split-explicit WS-RK3 + acoustic substeps [+ Kessler] on y-slabs).
+// The sequence of breeze.jl_amd/compressible.py: SlabCompressibleModel.time_step_slab, issued from here so that a host needs one call
+// per step: inside a stage only the two perturbation fields the next substep reads across the slab edge are exchanged per substep
+// ((rho theta)' and (rho v)' of the current ping-pong buffer, Hy rows each way); G_rho_v, the recovered prognostics, the diagnostics
+// and the time-averaged velocities travel once per stage, after the diagnosis kernel has written the x-halo images of the edge rows.
+// Reference: acoustic_rk3_substep! / time_step! (/root/reference/src/TimeSteppers/acoustic_runge_kutta_3.jl:172-208,264-319),
+// halo fills of the substep loop (/root/reference/src/CompressibleEquations/acoustic_substepping.jl:1462-1463,1493,1537-1545).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct FieldList {
+    double *f[BZ_COMM_MAX_FIELDS];
+    int32_t lev[BZ_COMM_MAX_FIELDS];
+    int n = 0;
+    void add(double *p, int32_t levels) { if (p && n < BZ_COMM_MAX_FIELDS) { f[n] = p; lev[n] = levels; ++n; } }
+};
+
+static int cmp_exchange(bz_ctx *ctx, const FieldList &L)
+{
+    if (!L.n) return BZ_OK;
+    ProfileScope ps(ctx, "comm_halo_exchange");
+    return halo_exchange(ctx, L.f, L.lev, L.n, ctx->dg.Hy, true, true, ctx->stream);
+}
+
+// update_state! with the neighbour exchanges: rho_d first (face velocities divide by the dry density of row -1), then everything the
+// next stage's stencils read across the slab edge
+static int cmp_update_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                            const bz_acoustic_substepper *sub, bool tendencies)
+{
+    const DevGrid &g = ctx->dg;
+    const int32_t nc = g.Nz + 2 * g.Hz, nf = nc + 1;
+    int rc;
+    FieldList A;
+    A.add(s->rho_d, nc);
+    if ((rc = cmp_exchange(ctx, A))) return rc;
+    if ((rc = bz_compressible_update_state(ctx, s, G, sub, 0))) return rc;
+    FieldList B;
+    B.add(s->rho_d, nc); B.add(s->rho_u, nc); B.add(s->rho_v, nc); B.add(s->rho_w, nf); B.add(s->rho_theta, nc); B.add(s->rho_q, nc);
+    B.add(sub->time_averaged_u, nc); B.add(sub->time_averaged_v, nc); B.add(sub->time_averaged_w, nf);
+    B.add(s->rho, nc); B.add(s->p, nc); B.add(s->u, nc); B.add(s->v, nc); B.add(s->w, nf); B.add(s->theta, nc); B.add(s->q, nc); B.add(s->T, nc);
+    if (g.microphysics == 2) {
+        const bz_kessler_model_fields &K = ctx->kessler;
+        B.add(K.cloud_liquid_density, nc); B.add(K.rain_density, nc);
+        B.add(K.vapor_mass_fraction, nc); B.add(K.cloud_liquid_mass_fraction, nc); B.add(K.rain_mass_fraction, nc);
+    }
+    if ((rc = cmp_exchange(ctx, B))) return rc;
+    return tendencies ? bz_compute_moisture_tendency(ctx, s, G, sub) : BZ_OK;
+}
+
+extern "C" int bz_comm_compressible_update_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G,
+                                                 const bz_acoustic_substepper *sub, int compute_tendencies)
+{
+    if (!ctx || !ctx->comm || !ctx->compressible || !s || !G || !sub) return BZ_ERR_INVALID;
+    return cmp_update_state(ctx, s, G, sub, compute_tendencies != 0);
+}
+
+int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                    const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt)
+{
+    const DevGrid &g = ctx->dg;
+    const int32_t nc = g.Nz + 2 * g.Hz;
+    int rc = bzi_compressible_store_initial_state(ctx, s, U0);
+    if (rc) return rc;
+    double *th_buf[2] = {sub->density_potential_temperature_perturbation, sub->previous_density_potential_temperature_perturbation};
+    double *v_buf[2] = {sub->momentum_perturbation_v, ctx->vp2_user ? ctx->vp2_user : ctx->d_vp2};
+    const double betas[3] = {1.0 / 3.0, 1.0 / 2.0, 1.0};
+    for (int st = 0; st < 3; ++st) {
+        if ((rc = bz_refresh_linearization(ctx, s, sub))) return rc;               // prepare_acoustic_cache!
+        if ((rc = bz_compute_slow_tendencies(ctx, s, G))) return rc;
+        FieldList Gv;
+        Gv.add(G->rho_v, nc);
+        if ((rc = cmp_exchange(ctx, Gv))) return rc;
+        int32_t ntau = 0, cur = 0;
+        if ((rc = bz_acoustic_stage_begin(ctx, s, U0, G, sub, dt, betas[st], &ntau, &cur))) return rc;
+        for (int32_t k = 1; k <= ntau; ++k) {
+            FieldList P;
+            P.add(th_buf[cur], nc); P.add(v_buf[cur], nc);
+            if ((rc = cmp_exchange(ctx, P))) return rc;
+            if ((rc = bz_acoustic_substep(ctx, s, U0, G, sub, k, &cur))) return rc;
+        }
+        FieldList T;
+        T.add(th_buf[cur], nc);
+        if ((rc = cmp_exchange(ctx, T))) return rc;
+        if ((rc = bz_acoustic_stage_end(ctx, s, U0, G, sub, dt, betas[st], 1))) return rc;
+        if ((rc = cmp_update_state(ctx, s, G, sub, true))) return rc;
+    }
+    if (g.microphysics == 2) {      // microphysics_model_update!: rank-local columns, then the exchanging update_state!
+        if ((rc = bz_compressible_kessler_update(ctx, s, G, sub, dt))) return rc;
+        if ((rc = cmp_update_state(ctx, s, G, sub, true))) return rc;
+    }
     return BZ_OK;
 }

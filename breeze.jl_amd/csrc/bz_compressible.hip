@@ -1258,30 +1258,37 @@ extern "C" int bz_acoustic_rk3_substep(bz_ctx *ctx, const bz_compressible_state 
     return bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, beta, true, true);
 }
 
+// store_initial_state! (prognostic fields incl. the Kessler species into timestepper.U0)
+int bzi_compressible_store_initial_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0)
+{
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "store_initial_state");
+    const size_t nc = (size_t)g.Sxy * (size_t)(g.Nz + 2 * g.Hz) * sizeof(double);
+    const size_t nf = (size_t)g.Sxy * (size_t)(g.Nz + 1 + 2 * g.Hz) * sizeof(double);
+    BZ_HIP(hipMemcpyAsync(U0->rho_d, s->rho_d, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    BZ_HIP(hipMemcpyAsync(U0->rho_u, s->rho_u, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    BZ_HIP(hipMemcpyAsync(U0->rho_v, s->rho_v, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    BZ_HIP(hipMemcpyAsync(U0->rho_w, s->rho_w, nf, hipMemcpyDeviceToDevice, ctx->stream));
+    BZ_HIP(hipMemcpyAsync(U0->rho_theta, s->rho_theta, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    BZ_HIP(hipMemcpyAsync(U0->rho_q, s->rho_q, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    if (g.microphysics == 2) {
+        const bz_kessler_model_fields &K = ctx->kessler;
+        BZ_HIP(hipMemcpyAsync(K.U0_cloud_liquid_density, K.cloud_liquid_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        BZ_HIP(hipMemcpyAsync(K.U0_rain_density, K.rain_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return BZ_OK;
+}
+
 extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                                          const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt)
 {
     BZ_REQUIRE_COMPRESSIBLE();
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
+    if (ctx->slab_mode && ctx->comm) return bzi_dist_time_step_compressible(ctx, s, U0, G, sub, dt);     // bz_comm.hip owns the exchanges
     if ((rc = require_no_slab(ctx, "bz_time_step_compressible"))) return rc;
     const DevGrid &g = ctx->dg;
-    {   // store_initial_state!
-        ProfileScope ps(ctx, "store_initial_state");
-        const size_t nc = (size_t)g.Sxy * (size_t)(g.Nz + 2 * g.Hz) * sizeof(double);
-        const size_t nf = (size_t)g.Sxy * (size_t)(g.Nz + 1 + 2 * g.Hz) * sizeof(double);
-        BZ_HIP(hipMemcpyAsync(U0->rho_d, s->rho_d, nc, hipMemcpyDeviceToDevice, ctx->stream));
-        BZ_HIP(hipMemcpyAsync(U0->rho_u, s->rho_u, nc, hipMemcpyDeviceToDevice, ctx->stream));
-        BZ_HIP(hipMemcpyAsync(U0->rho_v, s->rho_v, nc, hipMemcpyDeviceToDevice, ctx->stream));
-        BZ_HIP(hipMemcpyAsync(U0->rho_w, s->rho_w, nf, hipMemcpyDeviceToDevice, ctx->stream));
-        BZ_HIP(hipMemcpyAsync(U0->rho_theta, s->rho_theta, nc, hipMemcpyDeviceToDevice, ctx->stream));
-        BZ_HIP(hipMemcpyAsync(U0->rho_q, s->rho_q, nc, hipMemcpyDeviceToDevice, ctx->stream));
-        if (g.microphysics == 2) {
-            const bz_kessler_model_fields &K = ctx->kessler;
-            BZ_HIP(hipMemcpyAsync(K.U0_cloud_liquid_density, K.cloud_liquid_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
-            BZ_HIP(hipMemcpyAsync(K.U0_rain_density, K.rain_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-    }
+    if ((rc = bzi_compressible_store_initial_state(ctx, s, U0))) return rc;
     // freeze_linearization_state! (acoustic_substepping.jl:288-292): the linearisation of stage 1 (refreshed again by
     // prepare_acoustic_cache! from the same state).  Its second half, seed_time_averaged_velocities!, is deliberately not
     // issued here: nothing between this point and stage 1's substep loop reads the time-averaged velocities (the slow

@@ -389,6 +389,9 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
 int bzi_bounded_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_lean_setup(bz_ctx *ctx);
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt);
+int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                    const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt);
+int bzi_compressible_store_initial_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0);
 void bzi_comm_teardown(bz_ctx *ctx);
 void bzi_lean_teardown(bz_ctx *ctx);
 void bzi_poisson_teardown(bz_ctx *ctx);

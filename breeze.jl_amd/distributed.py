@@ -261,6 +261,61 @@ _LOC = {"ccc": (Center, Center, Center), "fcc": (Face, Center, Center),
         "cfc": (Center, Face, Center), "ccf": (Center, Center, Face)}
 
 
+def attach_library_transport(self, transport, group):
+    """Give the slab context `self._ctx` a library-owned communicator (csrc/bz_comm.hip): "rccl" (unique id made on rank 0 and
+    broadcast over the torch.distributed group) or "local:<name>" (in-process transport between contexts of one process)."""
+    import torch
+    lib = self._lib
+    if transport.startswith("local:"):
+        self._check(lib.bz_comm_init_local(self._ctx, transport[6:].encode()), "bz_comm_init_local")
+        return
+    if transport != "rccl":
+        raise ValueError(f"unknown transport {transport!r}")
+    ident = torch.zeros(_lib.BZ_UNIQUE_ID_BYTES, dtype=torch.uint8)
+    if self.rank == 0:
+        buf = (C.c_ubyte * _lib.BZ_UNIQUE_ID_BYTES)()
+        rc = lib.bz_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.BreezeHIPError(f"bz_comm_unique_id failed with code {rc}")
+        ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+    if self.world > 1:
+        import torch.distributed as dist
+        ident = ident.to(self.device)
+        dist.broadcast(ident, src=0, group=group)
+        ident = ident.cpu()
+    raw = (C.c_ubyte * _lib.BZ_UNIQUE_ID_BYTES)(*ident.tolist())
+    # RCCL prints a version banner on C stdout when a communicator is created; a host that prints machine-readable results on
+    # stdout (bench.py) must not get it there: point fd 1 at stderr for the duration of the call and flush C stdio inside it
+    import os
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rc = lib.bz_comm_init_rccl(self._ctx, raw)
+        C.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    self._check(rc, "bz_comm_init_rccl")
+
+
+
+class LibraryComm:
+    """Stand-in for SlabDecomposition when the library owns the communicator: the only thing the host still asks for is a y-halo
+    exchange of a list of parent arrays (bz_comm_exchange_y_halos)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def exchange_y_halos(self, tensors):
+        m = self.model
+        n = len(tensors)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        levels = (C.c_int32 * n)(*[t.shape[0] for t in tensors])
+        m._check(m._lib.bz_comm_exchange_y_halos(m._ctx, ptrs, levels, n), "bz_comm_exchange_y_halos")
+
+
 class SlabAtmosphereModel(SlabStepper):
     """AtmosphereModel on one y-slab of a (Periodic, Periodic, Bounded) global grid: rank r of `world` owns rows
     [r*Ny/world, (r+1)*Ny/world).  Same fields, kernels and call order as `AtmosphereModel`; halos in y and the
@@ -346,40 +401,7 @@ class SlabAtmosphereModel(SlabStepper):
         self.set(θ=ref.potential_temperature)
 
     def _attach_library_transport(self, transport, group):
-        import torch
-        lib = self._lib
-        if transport.startswith("local:"):
-            self._check(lib.bz_comm_init_local(self._ctx, transport[6:].encode()), "bz_comm_init_local")
-            return
-        if transport != "rccl":
-            raise ValueError(f"unknown transport {transport!r}")
-        ident = torch.zeros(_lib.BZ_UNIQUE_ID_BYTES, dtype=torch.uint8)
-        if self.rank == 0:
-            buf = (C.c_ubyte * _lib.BZ_UNIQUE_ID_BYTES)()
-            rc = lib.bz_comm_unique_id(buf)
-            if rc != 0:
-                raise _lib.BreezeHIPError(f"bz_comm_unique_id failed with code {rc}")
-            ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
-        if self.world > 1:
-            import torch.distributed as dist
-            ident = ident.to(self.device)
-            dist.broadcast(ident, src=0, group=group)
-            ident = ident.cpu()
-        raw = (C.c_ubyte * _lib.BZ_UNIQUE_ID_BYTES)(*ident.tolist())
-        # RCCL prints a version banner on C stdout when a communicator is created; a host that prints machine-readable results on
-        # stdout (bench.py) must not get it there: point fd 1 at stderr for the duration of the call and flush C stdio inside it
-        import os
-        import sys
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            rc = lib.bz_comm_init_rccl(self._ctx, raw)
-            C.CDLL(None).fflush(None)
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
-        self._check(rc, "bz_comm_init_rccl")
+        attach_library_transport(self, transport, group)
 
     def comm_info(self):
         """(transport name, bytes this rank has sent, number of exchanges) of the library-owned communicator."""

@@ -235,6 +235,13 @@ int bz_comm_destroy(bz_ctx *ctx);
 int bz_comm_exchange_y_halos(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n);
 int bz_comm_update_state_and_project(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, double dt, int project);
 int bz_comm_info(bz_ctx *ctx, const char **transport, int64_t *bytes_sent, int32_t *exchanges);
+/* Compressible y-slab contexts (bz_create_compressible_slab) take the same communicators: bz_time_step_compressible then runs
+ * the whole distributed WS-RK3 step in the library (per-substep exchange of (rho theta)' and (rho v)', per-stage exchange of
+ * G_rho_v, prognostics, diagnostics and time-averaged velocities; the Kessler column update stays rank-local), and
+ * bz_comm_compressible_update_state is update_state! with those exchanges (for set! and drivers stepping operator by operator). */
+struct bz_compressible_state; struct bz_compressible_prognostic; struct bz_acoustic_substepper;
+int bz_comm_compressible_update_state(bz_ctx *ctx, const struct bz_compressible_state *s, const struct bz_compressible_prognostic *G,
+                                      const struct bz_acoustic_substepper *sub, int compute_tendencies);
 
 /* ==== CompressibleDynamics + SplitExplicitTimeDiscretization ==================================
  * Fully compressible dynamics advanced by the Wicker-Skamarock RK3 outer loop with the linearised acoustic substep

@@ -244,11 +244,14 @@ def test_compressible_kessler_slab_steps_match_single_process_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("library", [False, True])
 @pytest.mark.parametrize("world,kessler", [(1, False), (2, False), (4, False), (2, True), (4, True)])
-def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, oracle, oc, world, kessler):
+def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, oracle, oc, world, kessler, library):
     """SlabCompressibleModel (bz_create_compressible_slab, stage begin / substep / end with the per-substep exchange of
     (rho theta)' and (rho v)') against the single-GPU whole-step seam and, directly, against the CPU oracle on the whole
-    domain (dry and with the Kessler physics of BASELINE configs[4]); `world` ranks share cuda:0 through a mailbox."""
+    domain (dry and with the Kessler physics of BASELINE configs[4]); `world` ranks share cuda:0 through a mailbox
+    (library = False: exchanges issued from Python) or through the library-owned communicator's in-process transport
+    (library = True: csrc/bz_comm.hip runs the whole distributed step, one C call per step and rank)."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_backends
@@ -276,10 +279,22 @@ def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, orac
 
     mb = dist_backends.Mailbox(world)
     models, errors = [None] * world, []
+    import uuid
+    group = "local:" + uuid.uuid4().hex
 
     def run(rank):
         try:
             torch.cuda.set_device(0)
+            if library:
+                with torch.cuda.stream(torch.cuda.Stream()):      # one HIP stream per rank, as one process per GPU would have
+                    m = bz.compressible.SlabCompressibleModel(G, rank, world, dynamics(), advection=bz.WENO(), device="cuda:0",
+                                                              transport=group, **mkw)
+                    m.set(**ic)
+                    for _ in range(steps):
+                        m.time_step(dt)
+                    m.synchronize()
+                models[rank] = m
+                return
             decomp = dist_backends.make_threaded_decomposition(bz_dist, mb, size[0], size[1] // world, size[2], 3, rank, world)
             m = bz.compressible.SlabCompressibleModel(G, rank, world, dynamics(), advection=bz.WENO(), device="cuda:0", decomp=decomp,
                                                       **mkw)

@@ -114,8 +114,10 @@ def _profile(value, z):
     return a
 
 
-def materialize_forcings(grid, coriolis, forcing, boundary_conditions):
-    """-> (bz_column_forcings, keepalive arrays) or (None, None) when nothing is attached."""
+def materialize_forcings(grid, coriolis, forcing, boundary_conditions, T=None):
+    """-> (bz_column_forcings, keepalive arrays) or (None, None) when nothing is attached.  T: _lib.types(grid.ftype) — the struct
+    classes and scalar type of the grid's precision (profiles are evaluated in Float64 and stored in eltype(grid))."""
+    T = T or _lib.types(8)
     if coriolis is None and not forcing and not boundary_conditions:
         return None, None
     if coriolis is not None and not isinstance(coriolis, FPlane):
@@ -127,7 +129,7 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions):
     sub_flags = {"u": "subsidence_u", "v": "subsidence_v", "θ": "subsidence_theta", "qe": "subsidence_moisture",
                  "qv": "subsidence_moisture", "qt": "subsidence_moisture"}
     static, keep = {}, []
-    S = _lib.bz_column_forcings()
+    S = T.bz_column_forcings()
     ws = None
     for name, entry in (forcing or {}).items():
         k = _key(name)
@@ -159,12 +161,13 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions):
             else:
                 raise NotImplementedError(f"forcing {item!r} is not implemented")
     for slot, prof in static.items():
-        a = np.ascontiguousarray(prof, dtype=np.float64)
+        a = np.ascontiguousarray(prof, dtype=T.np_real)
         keep.append(a)
-        setattr(S, slot, a.ctypes.data_as(C.POINTER(C.c_double)))
+        setattr(S, slot, a.ctypes.data_as(C.POINTER(T.real)))
     if ws is not None:
+        ws = np.ascontiguousarray(ws, dtype=T.np_real)
         keep.append(ws)
-        S.subsidence_vertical_velocity = ws.ctypes.data_as(C.POINTER(C.c_double))
+        S.subsidence_vertical_velocity = ws.ctypes.data_as(C.POINTER(T.real))
     S.coriolis_f = f
     drag = None
     for name, bcs in (boundary_conditions or {}).items():
@@ -194,10 +197,10 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions):
     return S, keep
 
 
-def materialize_bulk_fluxes(boundary_conditions, reference_state, constants):
+def materialize_bulk_fluxes(boundary_conditions, reference_state, constants, T=None):
     """-> bz_bulk_surface_fluxes or None.  BulkDrag belongs on ρu / ρv (one coefficient for both), BulkSensibleHeatFlux on ρθ,
     BulkVaporFlux on the moisture density; anything else raises like the reference's regularization does."""
-    B, found = _lib.bz_bulk_surface_fluxes(), False
+    B, found = (T or _lib.types(8)).bz_bulk_surface_fluxes(), False
     for name, bcs in (boundary_conditions or {}).items():
         k = _key(name)
         bottom = bcs.bottom if isinstance(bcs, FieldBoundaryConditions) else bcs

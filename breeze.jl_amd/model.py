@@ -204,10 +204,11 @@ class AtmosphereModel:
         torch.cuda.set_device(self.device)
         self._T = T = _lib.types(grid.ftype)
         if grid.ftype == 4:
-            if advection.order != 5 or closure is not None or microphysics is not None or forcing is not None or tracers or \
-                    boundary_conditions is not None or coriolis is not None or formulation != "LiquidIcePotentialTemperature" or \
+            from .microphysics import DCMIP2016KesslerMicrophysics as _Kessler
+            if advection.order != 5 or isinstance(microphysics, _Kessler) or tracers or formulation != "LiquidIcePotentialTemperature" or \
                     self._bounded_advection is not None:
-                raise NotImplementedError("Float32 grids: the dry / vapour anelastic WENO(order=5) model is wired up on the host side "
+                raise NotImplementedError("Float32 grids: the anelastic WENO(order=5) potential-temperature model with saturation "
+                                          "adjustment, SmagorinskyLilly, column forcings and bottom fluxes is wired up on the host side "
                                           "(the Float32 library itself is the whole ABI)")
             self._lib = lib = _lib.load_f32()
         else:
@@ -283,7 +284,7 @@ class AtmosphereModel:
                         "bz_set_kessler_microphysics")
         elif microphysics is not None:
             self.microphysical_fields = {"qᵛ": fld("ccc"), "qˡ": fld("ccc"), "qᵉ": self.specific_moisture}
-            sa = _lib.bz_saturation_adjustment(c.liquid_reference_latent_heat, c.liquid_heat_capacity,
+            sa = T.bz_saturation_adjustment(c.liquid_reference_latent_heat, c.liquid_heat_capacity,
                                                c.energy_reference_temperature, c.triple_point_temperature,
                                                c.triple_point_pressure, microphysics.solver.abstol,
                                                microphysics.solver.maxiter, 0)
@@ -308,17 +309,17 @@ class AtmosphereModel:
             if self._kessler or formulation != "LiquidIcePotentialTemperature":
                 raise NotImplementedError("SmagorinskyLilly is implemented for the potential-temperature formulation without Kessler")
             self.closure_fields = {"νₑ": fld("ccc")}
-            cl = _lib.bz_smagorinsky_lilly(closure.C, closure.Cb, closure.Pr)
+            cl = T.bz_smagorinsky_lilly(closure.C, closure.Cb, closure.Pr)
             self._check(lib.bz_set_closure(self._ctx, C.byref(cl), C.c_void_p(self.closure_fields["νₑ"].ptr())), "bz_set_closure")
         # coriolis / forcing / boundary_conditions of the BOMEX configuration -> one column-forcing stack (forcings.py)
         from .forcings import materialize_forcings
-        F, self._forcing_keepalive = materialize_forcings(grid, coriolis, forcing, boundary_conditions)
+        F, self._forcing_keepalive = materialize_forcings(grid, coriolis, forcing, boundary_conditions, T)
         if F is not None:
             if self._kessler or formulation != "LiquidIcePotentialTemperature":
                 raise NotImplementedError("forcings are implemented for the potential-temperature formulation without Kessler")
             self._check(lib.bz_set_forcings(self._ctx, C.byref(F)), "bz_set_forcings")
         from .forcings import materialize_bulk_fluxes
-        Bk = materialize_bulk_fluxes(boundary_conditions, ref, c)
+        Bk = materialize_bulk_fluxes(boundary_conditions, ref, c, T)
         if Bk is not None:
             if self._kessler or formulation != "LiquidIcePotentialTemperature":
                 raise NotImplementedError("bulk surface fluxes are implemented for the potential-temperature formulation without Kessler")

@@ -79,3 +79,50 @@ def test_float32_time_steps_match_the_float64_oracle(oracle, bz, lean, monkeypat
     assert relerr(hm.temperature.interior_cpu().astype(np.float64), om.grid.interior(om.T)) < 1e-5
     # the projected momentum is divergence-free to Float32 round-off
     assert hm.max_abs_divergence() < 5e-4
+
+
+@pytest.mark.gpu
+def test_float32_bomex_physics_steps_match_the_float64_oracle(oracle, bz):
+    """The physics list of BASELINE configs[2] in the precision its example runs in (examples/bomex.jl:40, Float32): WENO5 + warm-phase
+    saturation adjustment + SmagorinskyLilly + Coriolis / geostrophic / subsidence / profile forcings + bottom fluxes on a Float32
+    grid, against the Float64 oracle.  Tolerances: 1e-4 of the field scale after three steps; the liquid water of
+    cells sitting on the saturation threshold may switch branch under Float32 rounding, so q^l is compared in the mean."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from oracle.closure import SmagorinskyLilly
+    from test_closure import _turbulent_ic
+    from test_forcings import EXTENT, _hip_forcing_kwargs, _oracle_forcings
+    size = (32, 24, 16)
+    og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment",
+                            closure=SmagorinskyLilly(), forcings=_oracle_forcings(oracle, og))
+    grid = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2], float_type=np.float32)
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), closure=bz.SmagorinskyLilly(),
+                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), **_hip_forcing_kwargs(bz))
+    ic = _turbulent_ic(om, 5)
+    om.set(**ic)
+    hm.set(θ=ic["theta"], qᵗ=ic["qt"], u=ic["u"], v=ic["v"])
+    g = om.grid
+    # eddy viscosity of the initial state (after the steps the device's field is the one of the last stage's start: the whole-step
+    # seam computes it where the tendencies need it).  The stability factor sqrt(1 - min(1, C_b N^2 / Sigma^2)) switches on a
+    # threshold, so single cells may flip under Float32 rounding: compared in the mean
+    om.update_state()
+    bz.update_state_(hm, compute_tendencies=True)
+    hm.synchronize()
+    nu = hm.closure_fields["νₑ"].interior_cpu().astype(np.float64)
+    assert np.abs(nu - om.nu_e).mean() < 1e-3 * om.nu_e.mean() and om.nu_e.max() > 0.01
+    for _ in range(3):
+        om.time_step(3.0)
+        hm.time_step(3.0)
+    hm.synchronize()
+    mom = max(np.abs(g.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    for n, k in PROG.items():
+        want = g.interior(getattr(om, n), zface=(n == "rw"))
+        got = hm.prognostic_fields()[k].interior_cpu().astype(np.float64)
+        scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() / scale < 1e-4, (n, np.abs(got - want).max() / scale)
+    assert relerr(hm.temperature.interior_cpu().astype(np.float64), g.interior(om.T)) < 1e-5
+    ql = hm.microphysical_fields["qˡ"].interior_cpu().astype(np.float64)
+    assert abs(ql.mean() - g.interior(om.ql).mean()) < 1e-3 * max(g.interior(om.ql).mean(), 1e-8) + 1e-9

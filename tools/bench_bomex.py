@@ -30,12 +30,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-forcing", action="store_true")
     ap.add_argument("--no-closure", action="store_true")
+    ap.add_argument("--float32", action="store_true", help="eltype(grid) = Float32, the precision of examples/bomex.jl (libbreeze_hip_f32.so)")
     a = ap.parse_args()
     import torch
     import breeze_jl_amd as bz
     from test_forcings import _hip_forcing_kwargs
     Nx, Ny, Nz = a.size
-    grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 6400.0), y=(0.0, 6400.0), z=(0.0, 3000.0))
+    grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 6400.0), y=(0.0, 6400.0), z=(0.0, 3000.0),
+                              float_type=np.float32 if a.float32 else np.float64)
     ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
     kw = {} if a.no_forcing else _hip_forcing_kwargs(bz, full=True)
     if not a.no_closure:
@@ -77,9 +79,9 @@ def main():
     w = m.velocities["w"].interior
     out = {"metric": "grid-cells advanced/sec, BOMEX-shaped anelastic SSP-RK3 step (WENO5 + saturation adjustment + SmagorinskyLilly + forcing stack)",
            "value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": a.dt,
-           "forcing": not a.no_forcing, "closure": None if a.no_closure else "SmagorinskyLilly", "dtype": "f64",
+           "forcing": not a.no_forcing, "closure": None if a.no_closure else "SmagorinskyLilly", "dtype": "f32" if a.float32 else "f64",
            "kernels_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items())},
-           "step_contract_frac_of_8TBs": cells * 2000 / (ms * 1e-3) / 8e12,
+           "step_contract_frac_of_8TBs": cells * (1000 if a.float32 else 2000) / (ms * 1e-3) / 8e12,
            "finite": bool(torch.isfinite(w).all().item()), "w_max": float(w.abs().max().item()),
            "cloud_fraction": float((ql > 0).double().mean().item())}
     print(json.dumps(out))

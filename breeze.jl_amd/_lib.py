@@ -264,7 +264,7 @@ def load(advection_order=5):
     sources built with the reconstructions collapsed to Centered(order = 2) — and bind every declared symbol.  Raises if the
     library is absent."""
     global _lib
-    path = LIB_PATH if advection_order == 5 else CENTERED2_LIB_PATH
+    path = CENTERED2_LIB_PATH if advection_order == 2 else LIB_PATH      # WENO orders 5, 7, 9 live in the same library
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -280,7 +280,7 @@ def load(advection_order=5):
         fn.restype = res
         fn.argtypes = args
     _libs[path] = lib
-    if advection_order == 5:
+    if advection_order != 2:
         _lib = lib
     return lib
 

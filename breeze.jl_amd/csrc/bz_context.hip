@@ -151,7 +151,11 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
 #ifdef BZ_CENTERED2
     if (weno_order != 2) return BZ_ERR_UNSUPPORTED;      // this build is Centered(order = 2)
 #else
-    if (weno_order != 5) return BZ_ERR_UNSUPPORTED;
+    // 5: the tuned path; 7, 9: generic kernels (bz_tendency_generic.hip), anelastic single-GPU contexts, halos >= (order + 1) / 2
+    if (weno_order != 5 && weno_order != 7 && weno_order != 9) return BZ_ERR_UNSUPPORTED;
+    if (weno_order != 5 && (compressible || slab_mode)) return BZ_ERR_UNSUPPORTED;
+    const int weno_R = (weno_order + 1) / 2;
+    if (grid->Hx < weno_R || grid->Hy < weno_R || grid->Hz < weno_R) return BZ_ERR_UNSUPPORTED;
 #endif
     if (grid->ftype != 8) return BZ_ERR_UNSUPPORTED;
     if (grid->topo[0] != BZ_PERIODIC || grid->topo[1] != BZ_PERIODIC || grid->topo[2] != BZ_BOUNDED)
@@ -259,6 +263,10 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.wrap_y = slab_mode ? 0 : 1;
 
     ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !getenv("BZ_NO_FUSED");
+#ifndef BZ_CENTERED2
+    ctx->weno_R = weno_R;
+    if (weno_R != 3) ctx->fused_ok = false;      // the fused / lean tiers are order-5 kernels: orders 7, 9 step operator by operator
+#endif
     if (slab_mode && (Ny < grid->Hy || Nx < 2 * grid->Hx)) { delete ctx; return BZ_ERR_UNSUPPORTED; }
     if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);
     ctx->fuse_rk = !getenv("BZ_NO_FUSE_RK");

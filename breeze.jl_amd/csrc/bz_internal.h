@@ -291,6 +291,7 @@ struct bz_ctx {
     bool compressible = false;
     bool has_reference = false;       // ExnerReferenceState columns present (else p_r = rho_r = 0)
     bz_split_explicit se;
+    int weno_R = 3;                   // stencil half-width of the advection scheme: WENO(order = 2 R - 1)
     double dz_min = 0.0;              // minimum_zspacing(grid)
     double *d_sponge = nullptr;       // UpperSponge rate * ramp per face (compressible contexts)
     double *d_Clin = nullptr;         // centre array: gamma R_m * Pi of the current linearisation
@@ -387,6 +388,7 @@ int bzi_kessler_update(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, d
 int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, int n);
 int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
 int bzi_bounded_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_compute_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_lean_setup(bz_ctx *ctx);
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt);
 int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,

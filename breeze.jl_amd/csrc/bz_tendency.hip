@@ -296,6 +296,17 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     ctx->G_is_predictor = false;
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
+    if (ctx->weno_R != 3) {      // WENO(order = 7 / 9): generic kernels for the five prognostic fields, then the order-independent terms
+        if (g.formulation != 0 || g.microphysics == 2 || ctx->n_tracers || ctx->bounded_mask) {
+            ctx->last_error = "WENO(order = 7 / 9) implements the potential-temperature model without Kessler species, tracers or bounds";
+            return BZ_ERR_UNSUPPORTED;
+        }
+        int rcg = bzi_compute_tendencies_generic(ctx, s, G);
+        if (rcg) return rcg;
+        if (ctx->has_closure && (rcg = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, 1.0))) return rcg;
+        if (ctx->has_forcings && (rcg = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0))) return rcg;
+        return BZ_OK;
+    }
     if (ctx->tend_gen >= 3 && g.formulation != 0) {
         ctx->last_error = "BZ_TEND_GEN >= 3 implements the potential-temperature formulation only";
         return BZ_ERR_UNSUPPORTED;

@@ -1,0 +1,255 @@
+// bz_tendency_generic.hip — advection tendencies for WENO(order = 7) and WENO(order = 9), the order the reference's examples use
+// (/root/reference/examples/dry_thermal_bubble.jl:15-25, bomex.jl:204, splitting_supercell.jl:279).
+//
+// Not a tuned path: one thread per cell, every face flux evaluated by the two cells that share it, stencils read straight from
+// global memory (L1 / L2 resident).  The headline path (WENO-5) is bz_tendency5_kernels.h; this file exists so that a model built
+// with the examples' scheme runs on the device with the reference's semantics:
+//   * reconstruction tables of order 2r-1 (r = 4, 5) from tools/gen_weno_tables.py (exact rational derivation; they reproduce the
+//     order-5 table of bz_weno.h and the Balsara & Shu tables), WENO-Z weights with tau_7 = |b0 + 3 b1 - 3 b2 - b3|,
+//     tau_9 = |b0 + 2 b1 - 6 b2 + 2 b3 + b4|, eps = 1e-8 — Oceananigans.Advection is not vendored: recalled, PARITY UNPINNED;
+//   * buffer cascade next to the Bounded z walls: order 9 -> 7 -> 5 -> 3 -> 1 (the largest stencil that fits);
+//   * the advecting mass flux is interpolated with Centered(order 2r-2) and the same cascade (8 -> 6 -> 4 -> 2).
+// Fluxes and their order of operations follow oracle/breeze_oracle.c (F_Uu ... F_Ww, flux_*_scalar), i.e.
+// /root/reference/src/Advection.jl:20-35 and src/AtmosphereModels/dynamics_kernel_functions.jl:54-130.
+#include "bz_internal.h"
+#include "bz_weno.h"
+#include "bz_weno_tables.h"
+
+#define BZ_WENO_GENERIC(R)                                                                                       \
+    __device__ __forceinline__ double bz_weno_r##R(const double *v)                                             \
+    {                                                                                                           \
+        double beta[R], p[R], tau = 0.0, num = 0.0, den = 0.0;                                                  \
+        _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                         \
+            const double *w = v + (R - 1 - s);                                                                  \
+            double b = 0.0, q = 0.0;                                                                            \
+            _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                     \
+                double in = BZW_B##R[s][j][j] * w[j];                                                           \
+                _Pragma("unroll") for (int l = j + 1; l < R; ++l) in += BZW_B##R[s][j][l] * w[l];               \
+                b = (j == 0) ? w[j] * in : b + w[j] * in;                                                       \
+                q = (j == 0) ? BZW_C##R[s][j] * w[j] : q + BZW_C##R[s][j] * w[j];                               \
+            }                                                                                                   \
+            beta[s] = b; p[s] = q;                                                                              \
+            tau = (s == 0) ? BZW_T##R[s] * b : tau + BZW_T##R[s] * b;                                           \
+        }                                                                                                       \
+        tau = fabs(tau);                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                         \
+            const double rr = tau / (beta[s] + BZ_WENO_EPS);                                                    \
+            const double a = BZW_D##R[s] * (1.0 + rr * rr);                                                     \
+            num = (s == 0) ? a * p[s] : num + a * p[s];                                                         \
+            den = (s == 0) ? a : den + a;                                                                       \
+        }                                                                                                       \
+        return num / den;                                                                                       \
+    }
+BZ_WENO_GENERIC(4)
+BZ_WENO_GENERIC(5)
+
+// largest buffer B <= R usable at index idx of the Bounded z direction (face target: B <= idx <= N-B; centre: B-1 <= idx <= N-B)
+template <int R>
+__device__ __forceinline__ int buf_face(int idx, int N)
+{
+#pragma unroll
+    for (int B = R; B >= 2; --B)
+        if (idx >= B && idx <= N - B) return B;
+    return 1;
+}
+template <int R>
+__device__ __forceinline__ int buf_center(int idx, int N)
+{
+#pragma unroll
+    for (int B = R; B >= 2; --B)
+        if (idx >= B - 1 && idx <= N - B) return B;
+    return 1;
+}
+
+// upwind-biased value at FACE idx of centred data (p at cell idx) / at CENTRE idx of face data (p at face idx), stride s, buffer B
+__device__ __forceinline__ double biased_face_g(const double *__restrict__ p, long long s, bool left, int B)
+{
+    if (B >= 4) {
+        double v[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (j < 2 * B - 1) v[j] = left ? p[(j - B) * s] : p[(B - 1 - j) * s];
+        return B == 5 ? bz_weno_r5(v) : bz_weno_r4(v);
+    }
+    if (B == 3) return left ? bz_weno5(p[-3 * s], p[-2 * s], p[-s], p[0], p[s]) : bz_weno5(p[2 * s], p[s], p[0], p[-s], p[-2 * s]);
+    if (B == 2) return left ? bz_weno3(p[-2 * s], p[-s], p[0]) : bz_weno3(p[s], p[0], p[-s]);
+    return left ? p[-s] : p[0];
+}
+__device__ __forceinline__ double biased_center_g(const double *__restrict__ p, long long s, bool left, int B)
+{
+    if (B >= 4) {
+        double v[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (j < 2 * B - 1) v[j] = left ? p[(j - (B - 1)) * s] : p[(B - j) * s];
+        return B == 5 ? bz_weno_r5(v) : bz_weno_r4(v);
+    }
+    if (B == 3) return left ? bz_weno5(p[-2 * s], p[-s], p[0], p[s], p[2 * s]) : bz_weno5(p[3 * s], p[2 * s], p[s], p[0], p[-s]);
+    if (B == 2) return left ? bz_weno3(p[-s], p[0], p[s]) : bz_weno3(p[2 * s], p[s], p[0]);
+    return left ? p[0] : p[s];
+}
+
+// Centered(order 2 (B - 1)) (order 2 for B <= 2) of q(m) = A(m) M(m) along stride s; `first` = offset (in cells) of the first of the
+// 2 h values (h = max(B - 1, 1)): -h for a face target from centres (centres idx-h .. idx+h-1), -(h-1) for a centre target from faces.
+// A == nullptr: constant factor a0.
+__device__ __forceinline__ double symm_g(const double *__restrict__ M, long long n, long long s, int B, int first, const ColPtr A, int k,
+                                         double a0)
+{
+    const int h = B > 2 ? B - 1 : 1;
+    double q[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        if (m < 2 * h) q[m] = (A.p ? A[k + first + m] : a0) * M[n + (long long)(first + m) * s];
+    if (h == 1) return bz_symm2(q[0], q[1]);
+    if (h == 2) return bz_symm4(q[0], q[1], q[2], q[3]);
+    const double *c = (h == 4) ? BZW_S8 : BZW_S6;
+    double acc = c[0] * (q[h - 1] + q[h]);
+#pragma unroll
+    for (int d = 1; d < 4; ++d)
+        if (d < h) acc += c[d] * (q[h - 1 - d] + q[h + d]);
+    return acc;
+}
+
+// ---- scalars: G = -div_rhoUc(c) -----------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__restrict__ Gc, const double *__restrict__ u,
+                                                           const double *__restrict__ v, const double *__restrict__ w,
+                                                           const double *__restrict__ c)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
+    const double rho = g.rho[k], Ax = g.Ax[k], Ay = g.Ay[k];
+    auto fx = [&](long long m) { const double ut = u[m]; return rho * ((Ax * ut) * biased_face_g(c + m, 1, ut > 0.0, R)); };
+    auto fy = [&](long long m) { const double vt = v[m]; return rho * ((Ay * vt) * biased_face_g(c + m, sy, vt > 0.0, R)); };
+    auto fz = [&](long long m, int kf) {
+        const double wt = w[m];
+        return g.rho_f[kf] * ((g.Az * wt) * biased_face_g(c + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz)));
+    };
+    const double dx = fx(n + 1) - fx(n), dy = fy(n + sy) - fy(n), dz = fz(n + sz, k + 1) - fz(n, k);
+    Gc[n] = -(g.Vinv_c[k] * (dx + dy + dz));
+}
+
+// ---- momentum -------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_u_tendency_g(DevGrid g, double *__restrict__ Gu, const double *__restrict__ ru,
+                                                      const double *__restrict__ rv, const double *__restrict__ rw,
+                                                      const double *__restrict__ u)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
+    const ColPtr none(nullptr);
+    const double Ax = g.Ax[k], Ay = g.Ay[k];
+    auto FUu = [&](long long m) {      // at centre: advecting flux from faces
+        const double ut = symm_g(ru, m, 1, R, -(R - 2), none, 0, Ax);
+        return ut * biased_center_g(u + m, 1, ut > 0.0, R);
+    };
+    auto FVu = [&](long long m) {      // at (f, f, c): Centered in x of Ay rho_v to x-face
+        const double vt = symm_g(rv, m, 1, R, -(R - 1), none, 0, Ay);
+        return vt * biased_face_g(u + m, sy, vt > 0.0, R);
+    };
+    auto FWu = [&](long long m, int kf) {
+        const double wt = symm_g(rw, m, 1, R, -(R - 1), none, 0, g.Az);
+        return wt * biased_face_g(u + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz));
+    };
+    const double a = FUu(n) - FUu(n - 1), b = FVu(n + sy) - FVu(n), c = FWu(n + sz, k + 1) - FWu(n, k);
+    Gu[n] = -(g.Vinv_c[k] * (a + b + c));
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_v_tendency_g(DevGrid g, double *__restrict__ Gv, const double *__restrict__ ru,
+                                                      const double *__restrict__ rv, const double *__restrict__ rw,
+                                                      const double *__restrict__ v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
+    const ColPtr none(nullptr);
+    const double Ax = g.Ax[k], Ay = g.Ay[k];
+    auto FUv = [&](long long m) {
+        const double ut = symm_g(ru, m, sy, R, -(R - 1), none, 0, Ax);
+        return ut * biased_face_g(v + m, 1, ut > 0.0, R);
+    };
+    auto FVv = [&](long long m) {
+        const double vt = symm_g(rv, m, sy, R, -(R - 2), none, 0, Ay);
+        return vt * biased_center_g(v + m, sy, vt > 0.0, R);
+    };
+    auto FWv = [&](long long m, int kf) {
+        const double wt = symm_g(rw, m, sy, R, -(R - 1), none, 0, g.Az);
+        return wt * biased_face_g(v + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz));
+    };
+    const double a = FUv(n + 1) - FUv(n), b = FVv(n) - FVv(n - sy), c = FWv(n + sz, k + 1) - FWv(n, k);
+    Gv[n] = -(g.Vinv_c[k] * (a + b + c));
+}
+
+// faces k = 1 .. Nz-1 (blockIdx.z + 1); + Iz(buoyancy)
+template <int R>
+__global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restrict__ Gw, const double *__restrict__ ru,
+                                                      const double *__restrict__ rv, const double *__restrict__ rw,
+                                                      const double *__restrict__ w, const double *__restrict__ T,
+                                                      const double *__restrict__ qv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z + 1;
+    if (i >= g.Nx) return;
+    const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
+    const ColPtr none(nullptr);
+    const int Bf = buf_face<R>(k, g.Nz);
+    auto FUw = [&](long long m) {      // Centered in z of Ax(k) rho_u to z-face k
+        const int h = Bf > 2 ? Bf - 1 : 1;
+        const double ut = symm_g(ru, m, sz, Bf, -h, g.Ax, k, 0.0);
+        return ut * biased_face_g(w + m, 1, ut > 0.0, R);
+    };
+    auto FVw = [&](long long m) {
+        const int h = Bf > 2 ? Bf - 1 : 1;
+        const double vt = symm_g(rv, m, sz, Bf, -h, g.Ay, k, 0.0);
+        return vt * biased_face_g(w + m, sy, vt > 0.0, R);
+    };
+    auto FWw = [&](long long m, int kc) {      // at centre kc
+        const int B = buf_center<R>(kc, g.Nz);
+        const int h = B > 2 ? B - 1 : 1;
+        const double wt = symm_g(rw, m, sz, B, -(h - 1), none, 0, g.Az);
+        return wt * biased_center_g(w + m, sz, wt > 0.0, B);
+    };
+    const double a = FUw(n + 1) - FUw(n), b = FVw(n + sy) - FVw(n), c = FWw(n, k) - FWw(n - sz, k - 1);
+    const double bf = 0.5 * (bz_buoyancy(g, T, qv, n - sz, k - 1) + bz_buoyancy(g, T, qv, n, k));
+    Gw[n] = -(g.Vinv_f[k] * (a + b + c)) + bf;
+}
+
+template <int R>
+static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    const DevGrid &g = ctx->dg;
+    const dim3 block(256), grid((g.Nx + 255) / 256, g.Ny, g.Nz), gridw((g.Nx + 255) / 256, g.Ny, g.Nz - 1);
+    {
+        ProfileScope ps(ctx, "x_momentum_tendency");
+        hipLaunchKernelGGL((k_u_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u);
+    }
+    {
+        ProfileScope ps(ctx, "y_momentum_tendency");
+        hipLaunchKernelGGL((k_v_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v);
+    }
+    if (g.Nz > 1) {
+        ProfileScope ps(ctx, "z_momentum_tendency");
+        hipLaunchKernelGGL((k_w_tendency_g<R>), gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w, s->T, s->q);
+    }
+    {
+        ProfileScope ps(ctx, "potential_temperature_tendency");
+        hipLaunchKernelGGL((k_scalar_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_theta, s->u, s->v, s->w, s->theta);
+    }
+    {
+        ProfileScope ps(ctx, "moisture_tendency");
+        hipLaunchKernelGGL((k_scalar_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q);
+    }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// advection (+ buoyancy) tendencies of the five prognostic fields for ctx->weno_R = 4 (order 7) or 5 (order 9)
+int bzi_compute_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    if (ctx->weno_R == 5) return launch_generic<5>(ctx, s, G);
+    if (ctx->weno_R == 4) return launch_generic<4>(ctx, s, G);
+    ctx->last_error = "bzi_compute_tendencies_generic: WENO order 7 or 9";
+    return BZ_ERR_INVALID;
+}

@@ -31,14 +31,18 @@ class Centered:
 
 
 class WENO:
-    """WENO(order=5; bounds=nothing): only the 5th-order scheme is implemented on the device.  `bounds = (lo, hi)` makes it the
+    """WENO(order=5; bounds=nothing).  order = 5 is the tuned path; orders 7 and 9 (the examples' choice) run through generic
+    kernels (csrc/bz_tendency_generic.hip) on single-GPU anelastic potential-temperature models whose grid carries halos of at
+    least (order + 1) / 2 cells, as Oceananigans requires.  `bounds = (lo, hi)` (order 5) makes it the
     bounds-preserving scheme (Oceananigans' BoundsPreservingWENO) that the reference's moist examples give their moisture
     densities (examples/rico.jl:184-190, examples/tropical_cyclone_world.jl:169); it is a per-scalar scheme:
     `advection = {"momentum": WENO(), "ρθ": WENO(), "ρqᵉ": WENO(bounds=(0, 1))}`."""
 
     def __init__(self, order=5, bounds=None):
-        if order != 5:
-            raise NotImplementedError("only WENO(order=5) is implemented in the HIP path")
+        if order not in (5, 7, 9):
+            raise NotImplementedError("WENO orders 5, 7 and 9 are implemented in the HIP path")
+        if order != 5 and bounds is not None:
+            raise NotImplementedError("bounds-preserving WENO is implemented for order 5")
         self.order = order
         if bounds is not None:
             bounds = (float(bounds[0]), float(bounds[1]))
@@ -195,6 +199,15 @@ class AtmosphereModel:
             raise RuntimeError("AtmosphereModel needs a GPU: the HIP path has no CPU fallback")
         self.grid = grid
         self.advection = advection
+        if isinstance(advection, WENO) and advection.order != 5:
+            need = (advection.order + 1) // 2
+            if min(grid.Hx, grid.Hy, grid.Hz) < need:
+                raise ValueError(f"WENO(order={advection.order}) needs halos of at least {need} cells in every direction "
+                                 f"(got {(grid.Hx, grid.Hy, grid.Hz)}): RectilinearGrid(..., halo=({need}, {need}, {need}))")
+            if self._kessler or tracers or formulation != "LiquidIcePotentialTemperature" or self._bounded_advection is not None or \
+                    grid.ftype != 8:
+                raise NotImplementedError(f"WENO(order={advection.order}) is implemented for the Float64 potential-temperature model "
+                                          "(optionally with saturation adjustment, closure and forcings)")
         self.thermodynamic_constants = c = thermodynamic_constants or ThermodynamicConstants()
         if dynamics is None:
             dynamics = AnelasticDynamics(ReferenceState(grid, c))      # default_dynamics

@@ -101,6 +101,46 @@ static inline double weno3(double a, double b, double c)
     return (a0 * p0 + a1 * p1) / (a0 + a1);
 }
 
+/* ---- orders 7 and 9 (WENO(order = 9) and its buffer cascade 9 -> 7 -> 5 -> 3 -> 1): tables derived in exact arithmetic by
+ * tools/gen_weno_tables.py (they reproduce the order-5 table above and the Balsara & Shu (2000) tables for r = 4, 5 that
+ * Oceananigans tabulates; WENO-Z with tau = |b0 + 3 b1 - 3 b2 - b3| (r = 4), |b0 + 2 b1 - 6 b2 + 2 b3 + b4| (r = 5): recalled from
+ * Oceananigans.Advection, PARITY UNPINNED).  v[0 .. 2r-2], upwind cell v[r-1], value at the face between v[r-1] and v[r].
+ * Same order of operations as weno5 above: nested upper-triangular smoothness sums, three-quotient WENO-Z weights, normalisation. */
+#include "weno_tables.h"
+#define OG_WENO_GENERIC(R)                                                                                    \
+    static inline double weno_r##R(const double *v)                                                          \
+    {                                                                                                        \
+        double beta[R], p[R], tau = 0.0, num = 0.0, den = 0.0;                                               \
+        for (int s = 0; s < R; ++s) {                                                                        \
+            const double *w = v + (R - 1 - s);                                                               \
+            double b = 0.0, q = 0.0;                                                                         \
+            for (int j = 0; j < R; ++j) {                                                                    \
+                double in = OGW_B##R[s][j][j] * w[j];                                                        \
+                for (int l = j + 1; l < R; ++l) in += OGW_B##R[s][j][l] * w[l];                              \
+                b = (j == 0) ? w[j] * in : b + w[j] * in;                                                    \
+                q = (j == 0) ? OGW_C##R[s][j] * w[j] : q + OGW_C##R[s][j] * w[j];                            \
+            }                                                                                                \
+            beta[s] = b; p[s] = q;                                                                           \
+            tau = (s == 0) ? OGW_T##R[s] * b : tau + OGW_T##R[s] * b;                                        \
+        }                                                                                                    \
+        tau = fabs(tau);                                                                                     \
+        for (int s = 0; s < R; ++s) {                                                                        \
+            double rr = tau / (beta[s] + WENO_EPS);                                                          \
+            double a = OGW_D##R[s] * (1.0 + rr * rr);                                                        \
+            num = (s == 0) ? a * p[s] : num + a * p[s];                                                      \
+            den = (s == 0) ? a : den + a;                                                                    \
+        }                                                                                                    \
+        return num / den;                                                                                    \
+    }
+OG_WENO_GENERIC(4)
+OG_WENO_GENERIC(5)
+OG_WENO_GENERIC(3)      /* cross-check of the generic form against weno5 (tests) */
+
+/* WENO(order = 2 R - 1) selected for the run: R = 3 (order 5, default), 4 or 5.  Process-wide: the oracle is single-model test infrastructure. */
+static int og_weno_R = 3;
+void og_set_weno_order(int order) { og_weno_R = (order == 9) ? 5 : (order == 7) ? 4 : 3; }
+int og_get_weno_order(void) { return 2 * og_weno_R - 1; }
+
 /* Largest buffer (3,2,1) usable at index idx of a Bounded direction with N cells.
  * at_face: interpolation target is face idx; else centre idx (from face data).
  * Oceananigans topologically_conditional_interpolation: buffer B is used when
@@ -108,8 +148,8 @@ static inline double weno3(double a, double b, double c)
  *   centre: B-1 <= idx <= N-B    (Julia: B   <= I <= N+1-B) */
 static inline int buffer_at(int idx, int N, int bounded, int at_face)
 {
-    if (!bounded) return 3;
-    for (int B = 3; B >= 2; --B) {
+    if (!bounded) return og_weno_R;
+    for (int B = og_weno_R; B >= 2; --B) {
         int lo = at_face ? B : B - 1;
         if (idx >= lo && idx <= N - B) return B;
     }
@@ -124,6 +164,11 @@ static inline double biased_face(const double *p, ptrdiff_t s, int left, int idx
     return 0.5 * (p[-s] + p[0]);
 #endif
     int B = buffer_at(idx, N, bounded, 1);
+    if (B >= 4) {
+        double v[9];
+        for (int j = 0; j < 2 * B - 1; ++j) v[j] = left ? p[(j - B) * s] : p[(B - 1 - j) * s];
+        return B == 5 ? weno_r5(v) : weno_r4(v);
+    }
     if (B == 3)
         return left ? weno5(p[-3 * s], p[-2 * s], p[-s], p[0], p[s])
                     : weno5(p[2 * s], p[s], p[0], p[-s], p[-2 * s]);
@@ -140,6 +185,11 @@ static inline double biased_center(const double *p, ptrdiff_t s, int left, int i
     return 0.5 * (p[0] + p[s]);
 #endif
     int B = buffer_at(idx, N, bounded, 0);
+    if (B >= 4) {
+        double v[9];
+        for (int j = 0; j < 2 * B - 1; ++j) v[j] = left ? p[(j - (B - 1)) * s] : p[(B - j) * s];
+        return B == 5 ? weno_r5(v) : weno_r4(v);
+    }
     if (B == 3)
         return left ? weno5(p[-2 * s], p[-s], p[0], p[s], p[2 * s])
                     : weno5(p[3 * s], p[2 * s], p[s], p[0], p[-s]);
@@ -160,6 +210,15 @@ static inline double symm4(double qm2, double qm1, double q0, double qp1)
 #endif
 }
 static inline double symm2(double qm1, double q0) { return 0.5 * (qm1 + q0); }
+/* Centered(order 2 (B - 1)) of the 2 (B - 1) values q[0 .. 2B-3] straddling the target (between q[B-2] and q[B-1]); B >= 4 */
+static inline double symm_wide(const double *q, int B)
+{
+    const double *c = (B == 5) ? OGW_S8 : OGW_S6;
+    const int h = B - 1;
+    double acc = c[0] * (q[h - 1] + q[h]);
+    for (int d = 1; d < h; ++d) acc += c[d] * (q[h - 1 - d] + q[h + d]);
+    return acc;
+}
 
 /* bias(u) = u > 0 ? LeftBias : RightBias */
 static inline int left_bias(double u) { return u > 0.0; }
@@ -391,24 +450,44 @@ static inline double symm_x_center(const og_grid *G, const double *M, size_t n, 
 {   /* to centre i from faces; Periodic/Flat-free x => always order 4 */
     (void)i;
     if (G->tx == FLAT) return A * M[n];
+    if (og_weno_R >= 4) {        /* Centered(order 2 (R - 1)): faces i-(R-2) .. i+R-1 */
+        double q[8]; const int h = og_weno_R - 1;
+        for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - (h - 1))];
+        return symm_wide(q, og_weno_R);
+    }
     return symm4(A * M[n - 1], A * M[n], A * M[n + 1], A * M[n + 2]);
 }
 static inline double symm_x_face(const og_grid *G, const double *M, size_t n, int i, double A)
 {   /* to face i from centres */
     (void)i;
     if (G->tx == FLAT) return A * M[n];
+    if (og_weno_R >= 4) {        /* centres i-(R-1) .. i+R-2 */
+        double q[8]; const int h = og_weno_R - 1;
+        for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - h)];
+        return symm_wide(q, og_weno_R);
+    }
     return symm4(A * M[n - 2], A * M[n - 1], A * M[n], A * M[n + 1]);
 }
 static inline double symm_y_center(const og_grid *G, const double *M, size_t n, int j, double A)
 {
     ptrdiff_t s = STRY(G); (void)j;
     if (G->ty == FLAT) return A * M[n];
+    if (og_weno_R >= 4) {
+        double q[8]; const int h = og_weno_R - 1;
+        for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - (h - 1)) * s];
+        return symm_wide(q, og_weno_R);
+    }
     return symm4(A * M[n - s], A * M[n], A * M[n + s], A * M[n + 2 * s]);
 }
 static inline double symm_y_face(const og_grid *G, const double *M, size_t n, int j, double A)
 {
     ptrdiff_t s = STRY(G); (void)j;
     if (G->ty == FLAT) return A * M[n];
+    if (og_weno_R >= 4) {
+        double q[8]; const int h = og_weno_R - 1;
+        for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - h) * s];
+        return symm_wide(q, og_weno_R);
+    }
     return symm4(A * M[n - 2 * s], A * M[n - s], A * M[n], A * M[n + s]);
 }
 /* z is Bounded: order 4 only where the WENO5 buffer fits, else order 2.
@@ -417,6 +496,11 @@ static inline double symm_z_face_area(const og_grid *G, const double *M, size_t 
 {   /* q(k) = Ah*dzc(k)*M(k), to face k from centres k-2..k+1 */
     ptrdiff_t s = STRZ(G);
     int B = buffer_at(k, G->Nz, G->tz == BOUNDED, 1);
+    if (B >= 4) {
+        double q[8]; const int h = B - 1;
+        for (int m = 0; m < 2 * h; ++m) q[m] = Ah * dzc_at(G, k + m - h) * M[n + (m - h) * s];
+        return symm_wide(q, B);
+    }
     if (B == 3)
         return symm4(Ah * dzc_at(G, k - 2) * M[n - 2 * s], Ah * dzc_at(G, k - 1) * M[n - s],
                      Ah * dzc_at(G, k) * M[n], Ah * dzc_at(G, k + 1) * M[n + s]);
@@ -426,6 +510,11 @@ static inline double symm_z_center(const og_grid *G, const double *M, size_t n, 
 {   /* to centre k from faces k-1..k+2, area constant */
     ptrdiff_t s = STRZ(G);
     int B = buffer_at(k, G->Nz, G->tz == BOUNDED, 0);
+    if (B >= 4) {
+        double q[8]; const int h = B - 1;
+        for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - (h - 1)) * s];
+        return symm_wide(q, B);
+    }
     if (B == 3) return symm4(A * M[n - s], A * M[n], A * M[n + s], A * M[n + 2 * s]);
     return symm2(A * M[n], A * M[n + s]);
 }
@@ -698,6 +787,7 @@ void og_divergence(const og_grid *G, double *div, const double *ru, const double
 /* exposed for unit tests of the reconstruction itself */
 double og_weno5(double a, double b, double c, double d, double e) { return weno5(a, b, c, d, e); }
 double og_weno3(double a, double b, double c) { return weno3(a, b, c); }
+double og_weno_generic(int r, const double *v) { return r == 5 ? weno_r5(v) : r == 4 ? weno_r4(v) : weno_r3(v); }
 int og_buffer_at(int idx, int N, int bounded, int at_face) { return buffer_at(idx, N, bounded, at_face); }
 
 /* Compressible split-explicit path. */

@@ -296,7 +296,13 @@ class OracleModel:
         if reference_density is not None:      # test hook: set!(reference_state.density, f(z))
             self.ref.density[g.Hz:g.Hz + g.Nz] = reference_density(g.zc)
             self.ref._fill(g)
-        self.lib = lib(advection)
+        # advection: "WENO5" (default), "WENO7", "WENO9" (the order is a process-wide switch of the C library, set before every
+        # tendency evaluation; halos must be at least (order + 1) / 2 wide) or "Centered2" (a separate build of the library)
+        self.weno_order = {"WENO5": 5, "WENO7": 7, "WENO9": 9}.get(advection, 5)
+        if advection.startswith("WENO"):
+            need = (self.weno_order + 1) // 2
+            assert min(g.Hx if g.Nx > 1 else need, g.Hy if g.Ny > 1 else need, g.Hz) >= need, f"{advection} needs halos >= {need}"
+        self.lib = lib("WENO5" if advection.startswith("WENO") else advection)
         self._mk_cgrid()
         self.qv, self.ql = g.center_field(), g.center_field()
         # DCMIP2016KesslerMicrophysics: prognostic rho q^cl, rho q^r; diagnostic q^cl, q^r, W^r, precipitation_rate; self.q = q^v
@@ -504,6 +510,7 @@ class OracleModel:
     def compute_tendencies(self):
         cg = C.byref(self.cg)
         L, G = self.lib, self.G
+        L.og_set_weno_order(C.c_int(self.weno_order))
         L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
         L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
         if self.microphysics == "Kessler":

@@ -315,6 +315,7 @@ class CompressibleOracleModel:
             # (update_atmosphere_model_state.jl:330-343, acoustic_runge_kutta_3.jl:352-358);
             # the momentum / theta / rho_d tendencies computed here by the reference are overwritten
             # by compute_slow_*_tendencies! before they are used.
+            L.og_set_weno_order(C.c_int(5))
             L.og_scalar_tendency_3d(cg, _p(self.G["rq"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.q))
             if kes:
                 L.og_scalar_tendency_3d(cg, _p(self.G["rqcl"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qcl))
@@ -397,6 +398,7 @@ class CompressibleOracleModel:
 
     def compute_slow_tendencies(self):
         cg, L, G = C.byref(self.cg), self.lib, self.G
+        L.og_set_weno_order(C.c_int(5))           # the order is a process-wide switch of the C library (oracle.py): this path is WENO-5
         L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
         L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
         L.og_w_tendency_slow(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w))

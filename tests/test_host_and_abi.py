@@ -66,11 +66,14 @@ def test_reference_state_matches_oracle(bz, oracle):
     assert np.array_equal(r.temperature, o.temperature)
 
 
-def test_model_requires_gpu_and_weno5(bz):
+def test_model_requires_gpu_and_an_implemented_scheme(bz):
     import torch
     g = bz.RectilinearGrid((16, 16, 16), x=(0, 1), y=(0, 1), z=(0, 1))
+    assert bz.WENO(order=9).order == 9 and bz.WENO(order=7).order == 7      # generic kernels (tests/test_weno_orders.py)
     with pytest.raises(NotImplementedError):
-        bz.WENO(order=9)
+        bz.WENO(order=11)
+    with pytest.raises(NotImplementedError):
+        bz.WENO(order=9, bounds=(0, 1))
     with pytest.raises(NotImplementedError):
         bz.Centered(order=4)
     if not torch.cuda.is_available():

@@ -9,7 +9,7 @@
 //     tau_9 = |b0 + 2 b1 - 6 b2 + 2 b3 + b4|, eps = 1e-8 — Oceananigans.Advection is not vendored: recalled, PARITY UNPINNED;
 //   * buffer cascade next to the Bounded z walls: order 9 -> 7 -> 5 -> 3 -> 1 (the largest stencil that fits);
 //   * the advecting mass flux is interpolated with Centered(order 2r-2) and the same cascade (8 -> 6 -> 4 -> 2).
-// Fluxes and their order of operations follow oracle/breeze_oracle.c (F_Uu ... F_Ww, flux_*_scalar), i.e.
+// Fluxes and their order of operations are those of the order-5 kernels (and of the CPU restatement the tests compare with), i.e.
 // /root/reference/src/Advection.jl:20-35 and src/AtmosphereModels/dynamics_kernel_functions.jl:54-130.
 #include "bz_internal.h"
 #include "bz_weno.h"

@@ -69,8 +69,8 @@ function create_context(model::AtmosphereModel)
         r = BzReferenceState(ref.surface_pressure, ref.potential_temperature, ref.standard_pressure,
                              pointer(ρ), pointer(p), pointer(T))
         rc = ccall((:bz_create, libbreeze_hip), Cint,
-                   (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzReferenceState}, Cint), ctx, g, k, r, 5)
-        rc == 0 || error("bz_create failed with code $rc")
+                   (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzReferenceState}, Cint), ctx, g, k, r, weno_order(model.advection))
+        rc == 0 || error("bz_create failed with code $rc (WENO orders 5, 7, 9 with halos >= (order + 1) / 2)")
     end
     return ctx[]
 end
@@ -305,6 +305,9 @@ end
 
 const BZ_UNIQUE_ID_BYTES = 128
 
+"WENO(order = N) of the model's momentum scheme -> the weno_order argument of bz_create (5: tuned kernels; 7, 9: generic kernels)."
+weno_order(advection) = 2 * Oceananigans.Advection.required_halo_size_x(advection isa NamedTuple ? advection.momentum : advection) - 1
+
 "Create the slab context of this rank and attach the RCCL communicator to it."
 function slab_context!(model, y_nranks::Integer, y_rank::Integer, bcast_bytes!::Function)
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
@@ -334,5 +337,32 @@ function finish_set!(model, ctx; enforce_mass_conservation = true)
 end
 
 # time_step! needs no distributed method: bz_time_step_anelastic on a slab context with a communicator is the distributed step.
+
+"Compressible model on slabs: the same communicator calls on a context made by bz_create_compressible_slab; time_step! is then
+bz_time_step_compressible (per-substep halo exchange of the acoustic loop inside the library), update_state! the call below."
+function compressible_slab_context!(model, y_nranks::Integer, y_rank::Integer, bcast_bytes!::Function, g, k, r, td)
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:bz_create_compressible_slab, libbreeze_hip), Cint,
+               (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzExnerReference}, Ref{BzSplitExplicit}, Cint, Cint, Cint),
+               ctx, g, k, r, td, 5, y_nranks, y_rank)
+    rc == 0 || error("bz_create_compressible_slab failed with code $rc")
+    id = zeros(UInt8, BZ_UNIQUE_ID_BYTES)
+    if y_rank == 0
+        rc = ccall((:bz_comm_unique_id, libbreeze_hip), Cint, (Ptr{UInt8},), id)
+        rc == 0 || error("bz_comm_unique_id failed with code $rc")
+    end
+    bcast_bytes!(id)
+    rc = ccall((:bz_comm_init_rccl, libbreeze_hip), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx[], id)
+    rc == 0 || error(unsafe_string(ccall((:bz_last_error, libbreeze_hip), Cstring, (Ptr{Cvoid},), ctx[])))
+    return ctx[]
+end
+
+function compressible_update_state!(model, ctx; compute_tendencies = true)
+    rc = ccall((:bz_comm_compressible_update_state, libbreeze_hip), Cint,
+               (Ptr{Cvoid}, Ref{BzCompressibleState}, Ref{BzCompressiblePrognostic}, Ref{BzAcousticSubstepper}, Cint),
+               ctx, cstate(model), cprognostic(model.timestepper.Gⁿ), substepper(model.timestepper.substepper), compute_tendencies ? 1 : 0)
+    rc == 0 || error(unsafe_string(ccall((:bz_last_error, libbreeze_hip), Cstring, (Ptr{Cvoid},), ctx)))
+    return nothing
+end
 
 end # module

@@ -18,6 +18,8 @@
 struct ClosureFields {
     const double *u, *v, *w, *nu, *theta, *q;
     double C2, Cb, Pr;
+    int jofs;      // y-slab contexts: the viscosity kernel also covers rows -1 and Ny (launched over Ny + 2 rows with jofs = -1), which
+                   // the tendency kernel then reads in place of the periodic wrap
 };
 
 // strain components; (i, j, k) may sit one cell outside the interior in x / y (u, v, w carry periodic halos there)
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void k_smagorinsky_viscosity(DevGrid g, Closur
 {
     int bx, by, bz;
     xcd_block(bx, by, bz);
-    const int i = bx * 256 + threadIdx.x, j = by, k = bz;
+    const int i = bx * 256 + threadIdx.x, j = by + F.jofs, k = bz;
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k), sx = 1, sy = g.Sx, sz = g.Sxy;
     const double *u = F.u, *v = F.v, *w = F.w;
@@ -112,7 +114,9 @@ __global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFi
     double nun[3][3][3];      // [dk+1][dj+1][di+1]; the 8 corners are never used
     {
         const long long oi[3] = {(i == 0) ? (long long)(g.Nx - 1) : -1, 0, (i == g.Nx - 1) ? -(long long)(g.Nx - 1) : 1};
-        const long long oj[3] = {((j == 0) ? (long long)(g.Ny - 1) : -1) * sy, 0, ((j == g.Ny - 1) ? -(long long)(g.Ny - 1) : 1) * sy};
+        // y-slab (wrap_y == 0): rows -1 and Ny hold the viscosity the extended launch of k_smagorinsky_viscosity computed there
+        const long long oj[3] = {((j == 0 && g.wrap_y) ? (long long)(g.Ny - 1) : -1) * sy, 0,
+                                 ((j == g.Ny - 1 && g.wrap_y) ? -(long long)(g.Ny - 1) : 1) * sy};
         const long long ok[3] = {(k == 0) ? 0 : -sz, 0, (k == g.Nz - 1) ? 0 : sz};
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -180,8 +184,8 @@ extern "C" int bz_set_closure(bz_ctx *ctx, const bz_smagorinsky_lilly *closure, 
     if (!ctx) return BZ_ERR_INVALID;
     if (!closure) { ctx->has_closure = false; ctx->closure_nu = nullptr; return BZ_OK; }
     if (!eddy_viscosity) return BZ_ERR_INVALID;
-    if (ctx->compressible || ctx->slab_mode || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {
-        ctx->last_error = "bz_set_closure: SmagorinskyLilly is implemented for the single-device anelastic "
+    if (ctx->compressible || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {      // y-slab contexts: through the library-owned distributed step (bz_comm.hip)
+        ctx->last_error = "bz_set_closure: SmagorinskyLilly is implemented for the anelastic "
                           "potential-temperature model (microphysics nothing or SaturationAdjustment)";
         return BZ_ERR_UNSUPPORTED;
     }
@@ -202,6 +206,7 @@ static ClosureFields closure_fields(bz_ctx *ctx, const bz_state *s)
     F.C2 = ctx->closure.smagorinsky_coefficient * ctx->closure.smagorinsky_coefficient;
     F.Cb = ctx->closure.reduction_factor;
     F.Pr = ctx->closure.prandtl_number;
+    F.jofs = 0;
     return F;
 }
 
@@ -213,8 +218,11 @@ extern "C" int bz_compute_closure_fields(bz_ctx *ctx, const bz_state *s)
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "smagorinsky_viscosity");
     const double *qv = (g.microphysics == 1) ? g.qv_field : s->q;      // specific_humidity(model)
-    hipLaunchKernelGGL(k_smagorinsky_viscosity, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
-                       closure_fields(ctx, s), s->T, qv, ctx->d_closure_ipi + 1, ctx->closure_nu);
+    ClosureFields F = closure_fields(ctx, s);
+    // y-slabs: one more row on each side (u, v, w, T, q^v carry Hy >= 2 exchanged rows there), so nu_e needs no exchange of its own
+    F.jofs = ctx->slab_mode ? -1 : 0;
+    hipLaunchKernelGGL(k_smagorinsky_viscosity, dim3((g.Nx + 255) / 256, g.Ny + (ctx->slab_mode ? 2 : 0), g.Nz), dim3(256), 0, ctx->stream, g,
+                       F, s->T, qv, ctx->d_closure_ipi + 1, ctx->closure_nu);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -235,6 +235,8 @@ struct BzComm {
     double *xsend = nullptr, *xrecv = nullptr;   // W blocks of Nz nkx Ny complex
     double *spec = nullptr;                      // (Nz, nkx, Ny_global) complex
     double *row_send = nullptr, *phi_below = nullptr;   // Nz Nx
+    double *gather = nullptr;                    // W blocks of gather_cap doubles (all-reduce of small column data)
+    size_t gather_cap = 0;
     // accounting
     long long bytes_sent = 0;
     int exchanges = 0;
@@ -252,7 +254,7 @@ void bzi_comm_teardown(bz_ctx *ctx)
     if (!c) return;
     if (c->side) hipStreamSynchronize(c->side);
     for (int d = 0; d < 2; ++d) { if (c->halo_send[d]) hipFree(c->halo_send[d]); if (c->halo_recv[d]) hipFree(c->halo_recv[d]); }
-    double *bufs[] = {c->rhs, c->hatx, c->xsend, c->xrecv, c->spec, c->row_send, c->phi_below};
+    double *bufs[] = {c->rhs, c->hatx, c->xsend, c->xrecv, c->spec, c->row_send, c->phi_below, c->gather};
     for (double *b : bufs) if (b) hipFree(b);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->ev_side) hipEventDestroy(c->ev_side);
@@ -551,6 +553,8 @@ static int state_halo_exchange(bz_ctx *ctx, const bz_state *s, double *pa, doubl
         double *d[5] = {s->u, s->v, s->w, s->theta, s->q};
         const int32_t dl[5] = {nc, nc, nf, nc, nc};
         for (int m = 0; m < 5; ++m) { f[n] = d[m]; lev[n] = dl[m]; ++n; }
+        if (ctx->has_closure || g.microphysics == 1) { f[n] = s->T; lev[n++] = nc; }      // the viscosity kernel covers the rows next to the slab
+        if (g.microphysics == 1) { f[n] = g.qv_field; lev[n++] = nc; f[n] = g.ql_field; lev[n++] = nc; }
     }
     return halo_exchange(ctx, f, lev, n, g.Hy, true, true, st);
 }
@@ -572,15 +576,90 @@ extern "C" int bz_comm_update_state_and_project(bz_ctx *ctx, const bz_state *s, 
 }
 
 // time_step!(model, dt) on y-slabs: the lean whole-step seam of bz_step.hip with the exchanges in between
+// ---- small all-reduce (column data: horizontal averages of the forcing stack) ---------------------------------------------------------
+__global__ void k_sum_blocks(const double *__restrict__ blocks, double *__restrict__ out, int n, int W)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double acc = blocks[t];
+    for (int p = 1; p < W; ++p) acc += blocks[(size_t)p * n + t];      // rank order: the same bits on every rank
+    out[t] = acc;
+}
+
+// buf[0 .. n) <- sum over the ranks of the slab communicator.  Every rank sends its block to every other one (n is a few thousand) and
+// adds the W blocks in rank order, so all ranks hold identical bits whatever the transport.
+int bzi_comm_allreduce_sum(bz_ctx *ctx, double *buf, int n)
+{
+    BzComm *c = ctx->comm;
+    if (!c || n < 1) return BZ_ERR_INVALID;
+    if (c->W == 1 && !c->self_messages) return BZ_OK;
+    ProfileScope ps(ctx, "comm_allreduce");
+    if ((size_t)n > c->gather_cap) {
+        BZ_HIP(hipStreamSynchronize(ctx->stream));
+        if (c->gather) hipFree(c->gather);
+        BZ_HIP(hipMalloc(&c->gather, (size_t)n * c->W * sizeof(double)));
+        c->gather_cap = (size_t)n;
+    }
+    const size_t bytes = (size_t)n * sizeof(double);
+    const bool self = c->self_messages;
+    if (!self) BZ_HIP(hipMemcpyAsync(c->gather + (size_t)c->rank * n, buf, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = comm_fail(ctx, c->T->group_start(), "all-reduce");
+    for (int p = 0; p < c->W && !rc; ++p)
+        if (p != c->rank || self) rc = comm_fail(ctx, c->T->send(buf, bytes, p, ctx->stream), "all-reduce");
+    for (int p = 0; p < c->W && !rc; ++p)
+        if (p != c->rank || self) rc = comm_fail(ctx, c->T->recv(c->gather + (size_t)p * n, bytes, p, ctx->stream), "all-reduce");
+    if (!rc) rc = comm_fail(ctx, c->T->group_end(ctx->stream), "all-reduce");
+    if (rc) return rc;
+    c->bytes_sent += (long long)bytes * (c->W - 1);
+    c->exchanges++;
+    hipLaunchKernelGGL(k_sum_blocks, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, c->gather, buf, n, c->W);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// ---- distributed step of the models the lean seam does not cover: saturation adjustment, SmagorinskyLilly, column forcings, bottom
+// fluxes (the physics list of BASELINE configs[2]) — the fused-RK tier of bz_time_step_anelastic (bz_step.hip) with the exchanges of the
+// slab decomposition: per stage the tendency kernels with the RK update folded in, the closure (its viscosity kernel covers one row
+// beyond each slab edge, so nu_e needs no exchange), the forcing stack (horizontal averages all-reduced over the ranks), bottom fluxes,
+// the distributed pressure solve + projection + diagnosis, and one y-halo exchange of everything the next stage's stencils read.
+static int dist_time_step_general(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
+{
+    const DevGrid &g = ctx->dg;
+    if (!(ctx->fused_ok && ctx->fuse_rk && g.formulation == 0 && g.microphysics != 2 && ctx->n_tracers == 0 && !ctx->bounded_mask)) {
+        ctx->last_error = "bz_time_step_anelastic on y-slabs implements the potential-temperature model (optionally with saturation "
+                          "adjustment, SmagorinskyLilly, column forcings and bottom fluxes): no Kessler species, tracers or bounds";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    const int32_t nc = g.Nz + 2 * g.Hz, nf = nc + 1;
+    const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};
+    int rc;
+    BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));
+    BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));
+    for (int stage = 0; stage < 3; ++stage) {
+        const double alpha = alphas[stage];
+        if ((rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+        if (ctx->has_closure && (rc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, s->rho_theta, s->rho_q, alpha * dt))) return rc;
+        if (ctx->has_forcings && (rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
+        if ((ctx->has_forcings || ctx->has_bulk) && (rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
+        if ((rc = dist_projection(ctx, s, G, alpha * dt, false, nullptr, nullptr, nullptr, nullptr))) return rc;
+        double *f[BZ_COMM_MAX_FIELDS] = {s->rho_u, s->rho_v, s->rho_w, s->u, s->v, s->w, s->theta, s->q, s->T, s->rho_theta, s->rho_q};
+        int32_t lev[BZ_COMM_MAX_FIELDS] = {nc, nc, nf, nc, nc, nf, nc, nc, nc, nc, nc};
+        int n = 11;
+        if (g.microphysics == 1) { f[n] = g.qv_field; lev[n++] = nc; f[n] = g.ql_field; lev[n++] = nc; }
+        ProfileScope ps(ctx, "comm_halo_exchange");
+        if ((rc = halo_exchange(ctx, f, lev, n, g.Hy, true, true, ctx->stream))) return rc;
+    }
+    ctx->G_is_predictor = true;
+    return BZ_OK;
+}
+
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
 {
     BzComm *c = ctx->comm;
     const DevGrid &g = ctx->dg;
     if (!(ctx->fused_ok && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 && !ctx->has_forcings && !ctx->has_bulk &&
-          !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask && (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32))) {
-        ctx->last_error = "bz_time_step_anelastic on y-slabs implements the dry / vapour anelastic model (no microphysics, closure, forcings, tracers)";
-        return BZ_ERR_UNSUPPORTED;
-    }
+          !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask && (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32)))
+        return dist_time_step_general(ctx, s, U0, G, dt);
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};
     BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));

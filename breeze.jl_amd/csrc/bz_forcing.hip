@@ -41,10 +41,9 @@ __global__ __launch_bounds__(256) void k_level_sums(DevGrid g, const double *__r
 
 // Average(specific field, dims=(1,2)) then F = -zb-average(w_s dz(avg)) (subsidence_forcing.jl:75-91); one block
 __global__ void k_subsidence_profiles(DevGrid g, const double *__restrict__ partial, const double *__restrict__ ws,
-                                      double *__restrict__ avg, double *__restrict__ sub, int mask)
+                                      double *__restrict__ avg, double *__restrict__ sub, int mask, double count)
 {
     const int Nz = g.Nz;
-    const double count = (double)g.Nx * (double)g.Ny;
     for (int t = threadIdx.x; t < 4 * Nz; t += blockDim.x) {
         double sum = 0.0;
         for (int s = 0; s < FSLICES; ++s) sum += partial[(long long)t * FSLICES + s];
@@ -209,8 +208,8 @@ extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
     if (!ctx) return BZ_ERR_INVALID;
     free_forcings(ctx);
     if (!f) return BZ_OK;
-    if (ctx->compressible || ctx->slab_mode || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {
-        ctx->last_error = "bz_set_forcings: the forcing stack is implemented for the single-device anelastic "
+    if (ctx->compressible || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {      // y-slab contexts: through the library-owned distributed step (bz_comm.hip)
+        ctx->last_error = "bz_set_forcings: the forcing stack is implemented for the anelastic "
                           "potential-temperature model (microphysics nothing or SaturationAdjustment)";
         return BZ_ERR_UNSUPPORTED;
     }
@@ -246,8 +245,8 @@ extern "C" int bz_set_bulk_surface_fluxes(bz_ctx *ctx, const bz_bulk_surface_flu
 {
     if (!ctx) return BZ_ERR_INVALID;
     if (!b) { ctx->has_bulk = false; return BZ_OK; }
-    if (ctx->compressible || ctx->slab_mode || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {
-        ctx->last_error = "bz_set_bulk_surface_fluxes: implemented for the single-device anelastic potential-temperature model";
+    if (ctx->compressible || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {      // y-slab contexts: through the library-owned distributed step (bz_comm.hip)
+        ctx->last_error = "bz_set_bulk_surface_fluxes: implemented for the anelastic potential-temperature model";
         return BZ_ERR_UNSUPPORTED;
     }
     ctx->bulk = *b;
@@ -296,8 +295,13 @@ extern "C" int bz_compute_forcings(bz_ctx *ctx, const bz_state *s)
     ProfileScope ps(ctx, "subsidence_averages");
     double *ws = ctx->d_forcing + (size_t)5 * Nz, *avg = ws + (Nz + 1), *sub = avg + (size_t)4 * Nz, *partial = sub + (size_t)4 * Nz;
     hipLaunchKernelGGL(k_level_sums, dim3(Nz, FSLICES), dim3(256), 0, ctx->stream, g, s->u, s->v, s->theta, s->q, partial);
+    if (ctx->slab_mode) {      // horizontal averages run over the whole domain: add the other ranks' partial sums (rank order: same bits everywhere)
+        if (!ctx->comm) { ctx->last_error = "bz_compute_forcings: a y-slab context needs a communicator for the horizontal averages"; return BZ_ERR_UNSUPPORTED; }
+        int rc = bzi_comm_allreduce_sum(ctx, partial, 4 * Nz * FSLICES);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_subsidence_profiles, dim3(1), dim3(256), 0, ctx->stream, g, partial, ws, avg, sub,
-                       ctx->forcing_subsidence_mask);
+                       ctx->forcing_subsidence_mask, (double)g.Nx * (double)ctx->Ny_global);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -395,6 +395,7 @@ int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s,
                                     const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt);
 int bzi_compressible_store_initial_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0);
 void bzi_comm_teardown(bz_ctx *ctx);
+int bzi_comm_allreduce_sum(bz_ctx *ctx, double *buf, int n);
 void bzi_lean_teardown(bz_ctx *ctx);
 void bzi_poisson_teardown(bz_ctx *ctx);
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);

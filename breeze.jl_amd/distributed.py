@@ -28,6 +28,7 @@ import numpy as np
 
 from . import _lib
 from .grids import Bounded, Center, Face, Periodic, RectilinearGrid
+from .model import AnelasticDynamics, AtmosphereModel
 from .thermodynamics import (ReferenceState, ThermodynamicConstants, dry_air_gas_constant,
                              vapor_gas_constant)
 
@@ -314,6 +315,65 @@ class LibraryComm:
         ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
         levels = (C.c_int32 * n)(*[t.shape[0] for t in tensors])
         m._check(m._lib.bz_comm_exchange_y_halos(m._ctx, ptrs, levels, n), "bz_comm_exchange_y_halos")
+
+
+class LibrarySlabAtmosphereModel(AtmosphereModel):
+    """AtmosphereModel on one y-slab with the library-owned communicator (transport "rccl" or "local:<name>"): every component
+    AtmosphereModel wires up — saturation adjustment, SmagorinskyLilly, column forcings, bottom fluxes, the physics list of
+    BASELINE configs[2] — runs decomposed; `time_step` is one C call per step and rank (csrc/bz_comm.hip: the lean seam for the
+    dry / vapour model; otherwise the fused-RK tier with halo exchanges, all-reduced horizontal averages and a viscosity kernel
+    that covers the rows next to the slab)."""
+
+    def __init__(self, global_grid, rank, world, transport="rccl", group=None, surface_pressure=101325, potential_temperature=288,
+                 standard_pressure=1e5, thermodynamic_constants=None, device=None, **kw):
+        import torch
+        G = global_grid
+        if G.topology != (Periodic, Periodic, Bounded):
+            raise NotImplementedError("slab decomposition implements topology (Periodic, Periodic, Bounded)")
+        if G.Ny % world:
+            raise ValueError(f"Ny={G.Ny} is not divisible by {world} ranks")
+        if transport == "torch":
+            raise ValueError('LibrarySlabAtmosphereModel runs on the library-owned communicator: transport "rccl" or "local:<name>"')
+        self.global_grid, self.rank, self.world, self.transport = G, rank, world, transport
+        self._comm_ready = False
+        Ny = G.Ny // world
+        y0 = G.yᶠ[0] + rank * Ny * G.Δy
+        z = (G.zᶠ[0], G.zᶠ[-1]) if G.regular_z else G.zᶠ
+        grid = RectilinearGrid((G.Nx, Ny, G.Nz), x=(G.xᶠ[0], G.xᶠ[0] + G.Nx * G.Δx), y=(y0, y0 + Ny * G.Δy), z=z,
+                               halo=(G.Hx, G.Hy, G.Hz))
+        grid.Δx, grid.Δy = G.Δx, G.Δy          # bit-identical spacings on every rank
+        c = thermodynamic_constants or ThermodynamicConstants()
+        ref = ReferenceState(grid, c, surface_pressure, potential_temperature, standard_pressure)
+        dev = device if device is not None else f"cuda:{torch.cuda.current_device()}"
+        super().__init__(grid, dynamics=AnelasticDynamics(ref), thermodynamic_constants=c, device=dev, **kw)
+        attach_library_transport(self, transport, group)
+        self._comm_ready = True
+        self.set(θ=ref.potential_temperature)
+
+    def _create_context(self, lib, bg, bc, br, order):
+        return lib.bz_create_slab(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), order, self.world, self.rank)
+
+    def _finish_set(self, enforce_mass_conservation):
+        if not self._comm_ready:
+            return                                   # the constructor's own set-up runs before the communicator exists
+        self._check(self._lib.bz_comm_update_state_and_project(self._ctx, C.byref(self._state), C.byref(self._G), 1.0,
+                                                               1 if enforce_mass_conservation else 0), "bz_comm_update_state_and_project")
+
+    def time_step(self, Δt):
+        if self.clock.iteration == 0:                 # maybe_prepare_first_time_step!: update_state! with the exchanges
+            self._check(self._lib.bz_comm_update_state_and_project(self._ctx, C.byref(self._state), C.byref(self._G), 1.0, 0),
+                        "bz_comm_update_state_and_project")
+        self._check(self._lib.bz_time_step_anelastic(self._ctx, C.byref(self._state), C.byref(self._U0), C.byref(self._G), float(Δt)),
+                    "bz_time_step_anelastic")
+        self.clock.time += float(Δt)
+        self.clock.last_Δt = float(Δt)
+        self.clock.iteration += 1
+
+    def comm_info(self):
+        """(transport name, bytes this rank has sent, number of exchanges) of the library-owned communicator."""
+        name, nbytes, nex = C.c_char_p(), C.c_int64(), C.c_int32()
+        self._check(self._lib.bz_comm_info(self._ctx, C.byref(name), C.byref(nbytes), C.byref(nex)), "bz_comm_info")
+        return name.value.decode(), nbytes.value, nex.value
 
 
 class SlabAtmosphereModel(SlabStepper):

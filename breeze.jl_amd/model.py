@@ -275,7 +275,7 @@ class AtmosphereModel:
         br = T.bz_reference_state(ref.surface_pressure, ref.potential_temperature, ref.standard_pressure,
                                   *[a.ctypes.data_as(C.POINTER(T.real)) for a in self._ref_arrays])
         self._ctx = C.c_void_p()
-        rc = lib.bz_create(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), advection.order)
+        rc = self._create_context(lib, bg, bc, br, advection.order)
         if rc != 0:
             raise _lib.BreezeHIPError(f"bz_create failed with code {rc}")
         self._check(lib.bz_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
@@ -379,6 +379,9 @@ class AtmosphereModel:
             pass
 
     # method spellings of the module-level functions
+    def _create_context(self, lib, bg, bc, br, order):
+        return lib.bz_create(C.byref(self._ctx), C.byref(bg), C.byref(bc), C.byref(br), order)
+
     def set(self, **kw):
         return set_(self, **kw)
 
@@ -575,6 +578,9 @@ def set_(model, enforce_mass_conservation=True, **kw):
             model.momentum["ρw"].interior.copy_(ρf * model.velocities["w"].interior)
         else:   # ρu, ρv, ρw
             model.momentum[key].set_interior(value)
+    if hasattr(model, "_finish_set"):      # y-slab models: update_state! + exchanges + the distributed projection, inside the library
+        model._finish_set(enforce_mass_conservation)
+        return
     update_state_(model, compute_tendencies=False)
     if enforce_mass_conservation:
         enforce_mass_conservation_(model)

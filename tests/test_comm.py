@@ -156,3 +156,66 @@ def test_rccl_transport_with_one_rank(bz, oracle, self_messages, monkeypatch):
     got = models[0].momentum["ρw"].interior_cpu()
     want = og.interior(om.rw, zface=True)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-9
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_bomex_physics_on_library_slabs_matches_the_oracle(bz, oracle, world):
+    """The physics list of BASELINE configs[2] — WENO5 + saturation adjustment + SmagorinskyLilly + Coriolis / geostrophic /
+    subsidence / profile forcings + bottom fluxes — decomposed into y-slabs with the library-owned communicator (fused-RK tier with
+    halo exchanges, horizontal averages all-reduced over the ranks, viscosity kernel covering the rows next to the slab), against
+    the single-process oracle: 2e-9 of the field scale after three steps, the tolerance of the single-GPU test of the same physics
+    (tests/test_closure.py::test_bomex_stack_time_steps_match_oracle)."""
+    import sys
+    import os
+    import torch
+    sys.path.insert(0, os.path.dirname(__file__))
+    from breeze_jl_amd import distributed as bz_dist
+    from oracle.closure import SmagorinskyLilly
+    from test_closure import _turbulent_ic
+    from test_forcings import EXTENT as FEXT, _hip_forcing_kwargs, _oracle_forcings
+    size = (32, 32, 16)
+    og = oracle.Grid(size, x=FEXT[0], y=FEXT[1], z=FEXT[2])
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment",
+                            closure=SmagorinskyLilly(), forcings=_oracle_forcings(oracle, og))
+    ic = _turbulent_ic(om, 5)
+    om.set(**ic)
+    for _ in range(3):
+        om.time_step(3.0)
+    G = bz.RectilinearGrid(size, x=FEXT[0], y=FEXT[1], z=FEXT[2])
+    group = "local:" + uuid.uuid4().hex
+    Ny = size[1] // world
+    models, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                m = bz_dist.LibrarySlabAtmosphereModel(G, rank, world, transport=group, surface_pressure=101500.0,
+                                                       potential_temperature=299.1, advection=bz.WENO(order=5), device="cuda:0",
+                                                       closure=bz.SmagorinskyLilly(),
+                                                       microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()),
+                                                       **_hip_forcing_kwargs(bz))
+                sl = slice(rank * Ny, (rank + 1) * Ny)
+                m.set(θ=ic["theta"][:, sl, :], qᵗ=ic["qt"][:, sl, :], u=ic["u"][:, sl, :], v=ic["v"][:, sl, :])
+                for _ in range(3):
+                    m.time_step(3.0)
+                m.synchronize()
+            models[rank] = m
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    mom = max(np.abs(og.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    for name in ("ru", "rv", "rw", "rtheta", "rq", "T"):
+        got = np.concatenate([FIELDS[name](m).interior_cpu() for m in models], axis=1)
+        want = og.interior(getattr(om, name), zface=(name == "rw"))
+        scale = mom if name in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() / scale < 2e-9, (name, np.abs(got - want).max() / scale)
+    ql = np.concatenate([m.microphysical_fields["qˡ"].interior_cpu() for m in models], axis=1)
+    assert np.abs(ql - og.interior(om.ql)).max() < 1e-9

@@ -272,8 +272,6 @@ class CompressibleAtmosphereModel:
         self.microphysics = microphysics
         self._kessler = isinstance(microphysics, DCMIP2016KesslerMicrophysics)
         self._sa = isinstance(microphysics, SaturationAdjustment)
-        if self._sa and getattr(self, "_pending_decomp", None) is not None:
-            raise NotImplementedError("saturation adjustment on compressible y-slabs is not implemented")
         if self._kessler:      # validate_microphysics (dcmip2016_kessler.jl:196-207)
             tcs = thermodynamic_constants
             if tcs is None or not isinstance(getattr(tcs, "saturation_vapor_pressure", None), TetensFormula):
@@ -656,6 +654,8 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
     def _diagnostic_tensors(self):
         d = self.dynamics
         μ = [self.microphysical_fields[k].parent for k in ("qᵛ", "qᶜˡ", "qʳ")] if self._kessler else []
+        if self._sa:       # the halo rows' linearisation reads the liquid fraction
+            μ = [self.microphysical_fields[k].parent for k in ("qᵛ", "qˡ")]
         return ([d.total_density.parent, d.pressure.parent] + [self.velocities[k].parent for k in ("u", "v", "w")] +
                 [self.potential_temperature.parent, self.specific_moisture.parent, self.temperature.parent] + μ)
 

@@ -757,6 +757,7 @@ static int cmp_update_state(bz_ctx *ctx, const bz_compressible_state *s, const b
         B.add(K.cloud_liquid_density, nc); B.add(K.rain_density, nc);
         B.add(K.vapor_mass_fraction, nc); B.add(K.cloud_liquid_mass_fraction, nc); B.add(K.rain_mass_fraction, nc);
     }
+    if (g.microphysics == 1) { B.add(g.qv_field, nc); B.add(g.ql_field, nc); }      // the halo rows' linearisation reads the liquid fraction
     if ((rc = cmp_exchange(ctx, B))) return rc;
     return tendencies ? bz_compute_moisture_tendency(ctx, s, G, sub) : BZ_OK;
 }

@@ -104,8 +104,8 @@ extern "C" int bz_set_saturation_adjustment(bz_ctx *ctx, const bz_saturation_adj
     DevGrid &g = ctx->dg;
     if (!params) { g.microphysics = 0; g.qv_field = g.ql_field = nullptr; return BZ_OK; }
     if (!q_vapor || !q_liquid || params->maxiter < 0) return BZ_ERR_INVALID;
-    if (g.formulation != 0 || (ctx->compressible && ctx->slab_mode)) {
-        ctx->last_error = "saturation adjustment is implemented for the potential-temperature formulation (anelastic, or single-device compressible)";
+    if (g.formulation != 0) {
+        ctx->last_error = "saturation adjustment is implemented for the potential-temperature formulation";
         return BZ_ERR_UNSUPPORTED;
     }
     g.microphysics = 1;

@@ -508,9 +508,17 @@ class OracleModel:
             self.compute_tendencies()
 
     def compute_tendencies(self):
+        # the WENO order is a process-wide switch of the C library: select this model's order for the evaluation and put the
+        # default back afterwards, so that direct callers of og_*_tendency (tests) always see order 5
+        self.lib.og_set_weno_order(C.c_int(self.weno_order))
+        try:
+            self._compute_tendencies()
+        finally:
+            self.lib.og_set_weno_order(C.c_int(5))
+
+    def _compute_tendencies(self):
         cg = C.byref(self.cg)
         L, G = self.lib, self.G
-        L.og_set_weno_order(C.c_int(self.weno_order))
         L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
         L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
         if self.microphysics == "Kessler":

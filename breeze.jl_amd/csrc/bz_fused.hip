@@ -296,13 +296,14 @@ int bzi_xf_inverse(bz_ctx *ctx, const double *hat, double *phi, int blocks)
 {
     const DevGrid &g = ctx->dg;
     const int n2 = g.Nx / 2, kc = xf_chunk("BZ_XF_KCHUNK_I", 16, g.Nz);
-    const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
     XfLayout L;
     L.nkx = blocks > 1 ? ctx->nkx : n2 + 1;
     L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;
     L.blk = (long long)g.Nz * L.nkx * g.Ny;
-    hipLaunchKernelGGL(k_x_inverse, grid, block, xf_lds_bytes(n2), ctx->stream, g, (const double2 *)(hat ? hat : (const double *)ctx->d_hat), L,
-                       phi ? phi : ctx->d_rhs, (const double2 *)ctx->d_wtab, kc);
+    const double2 *in = (const double2 *)(hat ? hat : (const double *)ctx->d_hat);
+    double *out = phi ? phi : ctx->d_rhs;
+    const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
+    hipLaunchKernelGGL(k_x_inverse, grid, block, xf_lds_bytes(n2), ctx->stream, g, in, L, out, (const double2 *)ctx->d_wtab, kc);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -35,10 +35,20 @@ __device__ __forceinline__ int xf_slot(int p, int n2)
 #define XF_P(p) xf_slot((p), n2)
 #define XF_ROW_STRIDE(n2) ((n2) + 4)
 
+// A team (Nx / 8 <= 64 threads) sits inside one wavefront and a row's transform touches that row only, so the stages need ordering
+// inside the wave, not a workgroup barrier: LDS instructions of one wave execute in order; the fences keep the compiler from moving
+// LDS accesses across the point.  Workgroup barriers remain where rows change hands (transposed loads / stores).
+__device__ __forceinline__ void xf_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double2 xf_cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // In-place complex transform of length n2 (a power of two >= 8) of `row` by the team's T = n2 / 4 threads (tid = 0 .. T-1).
-// Every thread of the workgroup calls it (barriers inside); teams with active = false only keep the barriers company.
+// Wave-level ordering only (xf_wave_sync): callers put a workgroup barrier where other waves' data is involved.
 // INV: conjugated twiddles (unnormalised inverse).
 template <bool INV>
 __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, int tid, bool active, const double2 *__restrict__ W)
@@ -66,9 +76,9 @@ __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, i
             o3 = make_double2(a1.x - a3.x, a1.y - a3.y);
             j0 = ((tid - k) << 2) + k;
         }
-        __syncthreads();
+        xf_wave_sync();
         if (active) { row[XF_P(j0)] = o0; row[XF_P(j0 + Ns)] = o1; row[XF_P(j0 + 2 * Ns)] = o2; row[XF_P(j0 + 3 * Ns)] = o3; }
-        __syncthreads();
+        xf_wave_sync();
     }
     if (Ns < n2) {      // n2 = 2 Ns: two radix-2 butterflies per thread, outputs land on their own inputs
         if (active) {
@@ -82,7 +92,7 @@ __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, i
                 row[XF_P(b + Ns)] = make_double2(u0.x - u1.x, u0.y - u1.y);
             }
         }
-        __syncthreads();
+        xf_wave_sync();
     }
 }
 
@@ -157,6 +167,7 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const doubl
     const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
     double2 *__restrict__ W = xf_sm + XF_RB * RS;
     for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
+    __syncthreads();                                       // the twiddle table is loaded by all waves
     const int j0 = blockIdx.x * XF_RB, j = j0 + r;
     const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, g.Nz);
     double2 *__restrict__ row = xf_sm + r * RS;
@@ -195,10 +206,10 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const doubl
                 row[XF_P(tid + T * q)] = *(const double2 *)(rhs + m);           // i even, Nx even: 16-byte aligned
             }
         }
-        __syncthreads();
+        xf_wave_sync();
         xf_team_fft<false>(row, n2, tid, true, W);
         xf_split_forward(row, n2, tid, W);
-        __syncthreads();
+        __syncthreads();                                   // rows change hands: the transposed store reads all of them
         for (int e = threadIdx.x; e < L.nxp * XF_RB; e += nthreads) {
             const int kx = e / XF_RB, rr = e - kx * XF_RB;
             hatT[xf_addr(L, g.Ny, k, kx, j0 + rr)] = (kx < NXH) ? xf_sm[rr * RS + XF_P(kx)] : make_double2(0.0, 0.0);
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const doubl
 }
 
 // Transposed half spectrum -> rows of phi in the contiguous buffer phi_c (Nx * Ny * Nz).  Same grid, block and LDS as k_x_forward.
+// (16 rows per workgroup — 256-byte segments per kx — measured the same 0.54 ms per launch at 512^3 as 8 rows: not the segment size.)
 __global__ __launch_bounds__(XF_RB * 64) void k_x_inverse(DevGrid g, const double2 *__restrict__ hatT, XfLayout L, double *__restrict__ phi_c,
                                                           const double2 *__restrict__ Wg, int kchunk)
 {
@@ -225,15 +237,18 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_inverse(DevGrid g, const doubl
             const int kx = e / XF_RB, rr = e - kx * XF_RB;
             xf_sm[rr * RS + XF_P(kx)] = hatT[xf_addr(L, g.Ny, k, kx, j0 + rr)];
         }
-        __syncthreads();
+        __syncthreads();                                   // rows loaded by all waves
         xf_split_inverse(row, n2, tid, W);
-        __syncthreads();
+        xf_wave_sync();
         xf_team_fft<true>(row, n2, tid, true, W);
-        for (int e = threadIdx.x; e < XF_RB * n2; e += nthreads) {
-            const int rr = e / n2, c = e - rr * n2;
-            const double2 v = xf_sm[rr * RS + XF_P(c)];
-            *(double2 *)(phi_c + 2 * c + (long long)Nx * ((long long)(j0 + rr) + (long long)g.Ny * k)) = v;
+        {   // every team stores its own row: 16-byte elements, consecutive lanes
+            double *dst = phi_c + (long long)Nx * ((long long)(j0 + r) + (long long)g.Ny * k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = tid + T * q;
+                *(double2 *)(dst + 2 * c) = row[XF_P(c)];
+            }
         }
-        __syncthreads();
+        __syncthreads();                                   // before the next level's loads overwrite the rows
     }
 }

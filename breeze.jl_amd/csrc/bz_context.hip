@@ -155,12 +155,16 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (weno_order != 5 && weno_order != 7 && weno_order != 9) return BZ_ERR_UNSUPPORTED;
     if (weno_order != 5 && (compressible || slab_mode)) return BZ_ERR_UNSUPPORTED;
     const int weno_R = (weno_order + 1) / 2;
-    if (grid->Hx < weno_R || grid->Hy < weno_R || grid->Hz < weno_R) return BZ_ERR_UNSUPPORTED;
+    if (grid->Hx < weno_R || (grid->topo[1] != BZ_FLAT && grid->Hy < weno_R) || grid->Hz < weno_R) return BZ_ERR_UNSUPPORTED;
 #endif
     if (grid->ftype != 8) return BZ_ERR_UNSUPPORTED;
-    if (grid->topo[0] != BZ_PERIODIC || grid->topo[1] != BZ_PERIODIC || grid->topo[2] != BZ_BOUNDED)
+    // (Periodic, Periodic, Bounded), or (Periodic, Flat, Bounded) — the reference's 2-D x-z cases (README.md:67-75, examples/
+    // dry_thermal_bubble.jl): Ny = 1, Hy = 0, single-GPU anelastic WENO-5 contexts, operator-by-operator kernels
+    const bool flat_y = grid->topo[1] == BZ_FLAT;
+    if (grid->topo[0] != BZ_PERIODIC || (grid->topo[1] != BZ_PERIODIC && !flat_y) || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
-    if (grid->Hx < 3 || grid->Hy < 3 || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
+    if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode || compressible || weno_order != 5)) return BZ_ERR_UNSUPPORTED;
+    if (grid->Hx < 3 || (!flat_y && grid->Hy < 3) || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
     // Oceananigans: N >= H in every direction (k_halo_y's wrap copy would otherwise read a halo row that is not filled yet)
     if (grid->Nx < grid->Hx || grid->Ny < grid->Hy || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;
 
@@ -261,6 +265,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.cpv = constants->vapor_heat_capacity;
     g.pst = ref->standard_pressure;
     g.wrap_y = slab_mode ? 0 : 1;
+    g.flat_y = flat_y ? 1 : 0;
 
     ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !getenv("BZ_NO_FUSED");
 #ifndef BZ_CENTERED2
@@ -271,6 +276,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);
     ctx->fuse_rk = !getenv("BZ_NO_FUSE_RK");
     ctx->tend_lds = !getenv("BZ_NO_TEND_LDS");
+    if (flat_y) { ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }      // one kernel per reference kernel (bz_tendency.hip)
     ctx->compressible = compressible;
     ctx->dz_min = dzc[Hz];
     for (int k = 0; k < Nz; ++k) ctx->dz_min = std::fmin(ctx->dz_min, dzc[Hz + k]);

@@ -54,6 +54,7 @@ struct DevGrid {
     // microphysics == 2: DCMIP2016KesslerMicrophysics — prognostic rho q^cl, rho q^r, diagnostic q^cl, q^r (qv_field = mu.q^v)
     double *rqcl_field, *rqr_field, *qcl_field, *qr_field;
     int wrap_y;            // 1: y halos are this rank's own periodic images; 0: y-slab, halos filled by the neighbour ranks
+    int flat_y;            // 1: topology (Periodic, Flat, Bounded): Ny = 1, Hy = 0, no y neighbours (per-operator kernels only)
 
     __host__ __device__ inline long long idx(int i, int j, int k) const {
         return (long long)(i + Hx) + (long long)Sx * ((long long)(j + Hy)) + Sxy * (long long)(k + Hz);

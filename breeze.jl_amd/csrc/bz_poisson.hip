@@ -24,7 +24,7 @@ __global__ __launch_bounds__(TX *TY) void k_poisson_source(DevGrid g, double *__
     long long n = g.idx(i, j, k);
     double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
     double a = Ax * ru[n + 1] - Ax * ru[n];
-    double b = Ay * rv[n + g.Sx] - Ay * rv[n];
+    double b = g.flat_y ? 0.0 : Ay * rv[n + g.Sx] - Ay * rv[n];
     double c = Az * rw[n + g.Sxy] - Az * rw[n];
     double div = g.Vinv_c[k] * (a + b + c);
     rhs[(long long)i + (long long)g.Nx * ((long long)j + (long long)g.Ny * k)] = g.dzc[k] * div / dt;
@@ -387,7 +387,14 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     if (slab) return BZ_OK;          // horizontal transforms are the caller's (distributed) in slab mode
     // ---- rocFFT plans: 2-D (y,x) transforms batched over z ----
     int n[2] = {Ny, Nx};
-    if (!ctx->xf) {
+    if (!ctx->xf && Ny == 1) {      // Flat y: rows only
+        int n1[1] = {Nx};
+        BZ_FFT(hipfftPlanMany(&ctx->plan_fwd, 1, n1, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, Nz));
+        BZ_FFT(hipfftPlanMany(&ctx->plan_inv, 1, n1, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, Nz));
+        ctx->plans_ok = true;
+        BZ_FFT(hipfftSetStream(ctx->plan_fwd, ctx->stream));
+        BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
+    } else if (!ctx->xf) {
         BZ_FFT(hipfftPlanMany(&ctx->plan_fwd, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, Nz));
         BZ_FFT(hipfftPlanMany(&ctx->plan_inv, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, Nz));
         ctx->plans_ok = true;

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(TX *TY) void k_pressure_correct(DevGrid g, double *
     double rc = g.rho[k], rf = g.rho_f[k];
     double p = phi[n];
     ru[n] -= rc * dt * ((p - phi[n - 1]) * g.rdx);
-    rv[n] -= rc * dt * ((p - phi[n - g.Sx]) * g.rdy);
+    if (!g.flat_y) rv[n] -= rc * dt * ((p - phi[n - g.Sx]) * g.rdy);
     rw[n] -= rf * dt * ((p - phi[n - g.Sxy]) * g.rdzf[k]);
 }
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(TX *TY) void k_max_abs_div(DevGrid g, const double 
         long long n = g.idx(i, j, k);
         double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
         double a = Ax * ru[n + 1] - Ax * ru[n];
-        double b = Ay * rv[n + g.Sx] - Ay * rv[n];
+        double b = g.flat_y ? 0.0 : Ay * rv[n + g.Sx] - Ay * rv[n];
         double c = Az * rw[n + g.Sxy] - Az * rw[n];
         d = fabs(g.Vinv_c[k] * (a + b + c));
     }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(TX *TY) void k_max_inverse_advection_timescale(DevG
     double d = 0.0;
     if (i < g.Nx && j < g.Ny) {
         long long n = g.idx(i, j, k);
-        const double ix = fabs(u[n]) / g.dx, iy = fabs(v[n]) / g.dy;
+        const double ix = fabs(u[n]) / g.dx, iy = g.flat_y ? 0.0 : fabs(v[n]) / g.dy;
         const double iz = with_w ? fabs(w[n]) / g.dzf[k] : 0.0;
         d = ix + iy + iz;
         if (d != d) d = bz_real_inf();      // NaN velocity: timescale 0

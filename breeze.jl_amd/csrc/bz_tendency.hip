@@ -53,10 +53,13 @@ __global__ __launch_bounds__(64 * TYB) void k_scalar_tendency(DevGrid g, double 
         double Fx_lo = rho * ((Ax * u0) * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, u0 > 0.0));
         double Fx_hi = rho * ((Ax * u1) * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, u1 > 0.0));
 
-        double ym3 = c[n - 3 * sy], ym2 = c[n - 2 * sy], ym1 = c[n - sy], yp1 = c[n + sy], yp2 = c[n + 2 * sy], yp3 = c[n + 3 * sy];
-        double v0 = v[n], v1 = v[n + sy];
-        double Fy_lo = rho * ((Ay * v0) * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0));
-        double Fy_hi = rho * ((Ay * v1) * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, v1 > 0.0));
+        double Fy_lo = 0.0, Fy_hi = 0.0;
+        if (!g.flat_y) {      // a Flat y direction has no faces
+            double ym3 = c[n - 3 * sy], ym2 = c[n - 2 * sy], ym1 = c[n - sy], yp1 = c[n + sy], yp2 = c[n + 2 * sy], yp3 = c[n + 3 * sy];
+            double v0 = v[n], v1 = v[n + sy];
+            Fy_lo = rho * ((Ay * v0) * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0));
+            Fy_hi = rho * ((Ay * v1) * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, v1 > 0.0));
+        }
 
         Gc[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
 
@@ -109,11 +112,14 @@ __global__ __launch_bounds__(64 * TYB) void k_u_tendency(DevGrid g, double *__re
         double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
 
         // y: F_Vu at y-faces j (lo) and j+1 (hi)
-        double vt_lo = bz_symm4(Ay * rv[n - 2], Ay * rv[n - 1], Ay * rv[n], Ay * rv[n + 1]);
-        double vt_hi = bz_symm4(Ay * rv[n + sy - 2], Ay * rv[n + sy - 1], Ay * rv[n + sy], Ay * rv[n + sy + 1]);
-        double ym3 = u[n - 3 * sy], ym2 = u[n - 2 * sy], ym1 = u[n - sy], yp1 = u[n + sy], yp2 = u[n + 2 * sy], yp3 = u[n + 3 * sy];
-        double Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
-        double Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+        double Fy_lo = 0.0, Fy_hi = 0.0;
+        if (!g.flat_y) {
+            double vt_lo = bz_symm4(Ay * rv[n - 2], Ay * rv[n - 1], Ay * rv[n], Ay * rv[n + 1]);
+            double vt_hi = bz_symm4(Ay * rv[n + sy - 2], Ay * rv[n + sy - 1], Ay * rv[n + sy], Ay * rv[n + sy + 1]);
+            double ym3 = u[n - 3 * sy], ym2 = u[n - 2 * sy], ym1 = u[n - sy], yp1 = u[n + sy], yp2 = u[n + 2 * sy], yp3 = u[n + 3 * sy];
+            Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
+            Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+        }
 
         Gu[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
                             -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo))), ru[n], n);
@@ -132,7 +138,7 @@ __device__ __forceinline__ double flux_Wv(const DevGrid &g, const double *__rest
 {   // at (c,f,f): Centered4 in y of Az*rho_w to y-face j
     double Az = g.Az;
     long long sy = g.Sx;
-    double wt = bz_symm4(Az * rw[nf - 2 * sy], Az * rw[nf - sy], Az * rw[nf], Az * rw[nf + sy]);
+    double wt = g.flat_y ? Az * rw[nf] : bz_symm4(Az * rw[nf - 2 * sy], Az * rw[nf - sy], Az * rw[nf], Az * rw[nf + sy]);
     double vR = bz_upB(m3, m2, m1, p0, p1, p2, wt > 0.0, bz_buffer_face(kface, g.Nz));
     return wt * vR;
 }
@@ -160,19 +166,23 @@ __global__ __launch_bounds__(64 * TYB) void k_v_tendency(DevGrid g, double *__re
         const double Ax = g.Ax[k], Ay = g.Ay[k];
 
         // x: F_Uv at x-faces i (lo) and i+1 (hi); advecting flux = Centered4 in y of Ax*rho_u
-        double ut_lo = bz_symm4(Ax * ru[n - 2 * sy], Ax * ru[n - sy], Ax * ru[n], Ax * ru[n + sy]);
-        double ut_hi = bz_symm4(Ax * ru[n + 1 - 2 * sy], Ax * ru[n + 1 - sy], Ax * ru[n + 1], Ax * ru[n + 1 + sy]);
+        // (Flat y: the y face of the v cell coincides with its centre, no interpolation)
+        double ut_lo = g.flat_y ? Ax * ru[n] : bz_symm4(Ax * ru[n - 2 * sy], Ax * ru[n - sy], Ax * ru[n], Ax * ru[n + sy]);
+        double ut_hi = g.flat_y ? Ax * ru[n + 1] : bz_symm4(Ax * ru[n + 1 - 2 * sy], Ax * ru[n + 1 - sy], Ax * ru[n + 1], Ax * ru[n + 1 + sy]);
         double xm3 = v[n - 3], xm2 = v[n - 2], xm1 = v[n - 1], xp1 = v[n + 1], xp2 = v[n + 2], xp3 = v[n + 3];
         double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
         double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
 
         // y: F_Vv at centres j (hi) and j-1 (lo)
-        double q_m2 = Ay * rv[n - 2 * sy], q_m1 = Ay * rv[n - sy], q_0 = Ay * rv[n], q_p1 = Ay * rv[n + sy], q_p2 = Ay * rv[n + 2 * sy];
-        double ym3 = v[n - 3 * sy], ym2 = v[n - 2 * sy], ym1 = v[n - sy], yp1 = v[n + sy], yp2 = v[n + 2 * sy], yp3 = v[n + 3 * sy];
-        double vt_hi = bz_symm4(q_m1, q_0, q_p1, q_p2);
-        double vt_lo = bz_symm4(q_m2, q_m1, q_0, q_p1);
-        double Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
-        double Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
+        double Fy_hi = 0.0, Fy_lo = 0.0;
+        if (!g.flat_y) {
+            double q_m2 = Ay * rv[n - 2 * sy], q_m1 = Ay * rv[n - sy], q_0 = Ay * rv[n], q_p1 = Ay * rv[n + sy], q_p2 = Ay * rv[n + 2 * sy];
+            double ym3 = v[n - 3 * sy], ym2 = v[n - 2 * sy], ym1 = v[n - sy], yp1 = v[n + sy], yp2 = v[n + 2 * sy], yp3 = v[n + 3 * sy];
+            double vt_hi = bz_symm4(q_m1, q_0, q_p1, q_p2);
+            double vt_lo = bz_symm4(q_m2, q_m1, q_0, q_p1);
+            Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+            Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
+        }
 
         Gv[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
                             -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo))), rv[n], n);
@@ -250,11 +260,14 @@ __global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__re
         double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
 
         // y: F_Vw at y-faces j (lo), j+1 (hi)
-        double vt_lo = symm_z_face(g, g.Ay, rv, n, k, Bf);
-        double vt_hi = symm_z_face(g, g.Ay, rv, n + sy, k, Bf);
-        double ym3 = w[n - 3 * sy], ym2 = w[n - 2 * sy], ym1 = w[n - sy], yp1 = w[n + sy], yp2 = w[n + 2 * sy], yp3 = w[n + 3 * sy];
-        double Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
-        double Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+        double Fy_lo = 0.0, Fy_hi = 0.0;
+        if (!g.flat_y) {
+            double vt_lo = symm_z_face(g, g.Ay, rv, n, k, Bf);
+            double vt_hi = symm_z_face(g, g.Ay, rv, n + sy, k, Bf);
+            double ym3 = w[n - 3 * sy], ym2 = w[n - 2 * sy], ym1 = w[n - sy], yp1 = w[n + sy], yp2 = w[n + 2 * sy], yp3 = w[n + 3 * sy];
+            Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
+            Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+        }
 
         double bf = 0.5 * (b_lo + b_hi);
         Gw[n] = -(g.Vinv_f[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo))) + bf;

@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .grids import Bounded, Center, Face, Periodic, RectilinearGrid
+from .grids import Bounded, Center, Face, Flat, Periodic, RectilinearGrid
 from .thermodynamics import (ReferenceState, ThermodynamicConstants, dry_air_gas_constant,
                              vapor_gas_constant)
 
@@ -125,7 +125,10 @@ class Field:
         g = self.grid
         if callable(value):
             x, y, z = g.nodes(self.loc)
-            value = value(x, y, z)
+            import inspect
+            # functions of the non-Flat coordinates, as in Oceananigans: f(x, z) on a (Periodic, Flat, Bounded) grid
+            two = g.topology[1] == "Flat" and len(inspect.signature(value).parameters) == 2
+            value = value(x, z) if two else value(x, y, z)
         shape = tuple(self.interior.shape)
         arr = np.broadcast_to(np.asarray(value, dtype=np.float64), shape)
         self.interior.copy_(torch.from_numpy(np.array(arr, dtype=np.float64, order="C")).to(self.dtype))
@@ -164,8 +167,13 @@ class AtmosphereModel:
         import torch
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
-        if grid.topology != (Periodic, Periodic, Bounded):
-            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded)")
+        flat_y = grid.topology == (Periodic, Flat, Bounded)
+        if grid.topology != (Periodic, Periodic, Bounded) and not flat_y:
+            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded) and (Periodic, Flat, Bounded)")
+        if flat_y and (closure is not None or coriolis is not None or forcing is not None or boundary_conditions is not None or
+                       grid.ftype != 8 or (advection is not None and getattr(advection, "order", 5) != 5)):
+            # the reference's 2-D x-z cases (README.md:67-75): the per-operator WENO-5 kernels drop the y terms
+            raise NotImplementedError("(Periodic, Flat, Bounded): the Float64 WENO(order=5) model without closure / forcings is implemented")
         formulation = str(formulation).lstrip(":")
         if formulation not in ("LiquidIcePotentialTemperature", "StaticEnergy"):
             raise NotImplementedError(f"formulation {formulation!r} is not implemented")

@@ -555,6 +555,7 @@ static int state_halo_exchange(bz_ctx *ctx, const bz_state *s, double *pa, doubl
         for (int m = 0; m < 5; ++m) { f[n] = d[m]; lev[n] = dl[m]; ++n; }
         if (ctx->has_closure || g.microphysics == 1) { f[n] = s->T; lev[n++] = nc; }      // the viscosity kernel covers the rows next to the slab
         if (g.microphysics == 1) { f[n] = g.qv_field; lev[n++] = nc; f[n] = g.ql_field; lev[n++] = nc; }
+        for (int t = 0; t < ctx->n_tracers && n < BZ_COMM_MAX_FIELDS; ++t) { f[n] = ctx->tracers[t].specific; lev[n++] = nc; }
     }
     return halo_exchange(ctx, f, lev, n, g.Hy, true, true, st);
 }
@@ -625,9 +626,9 @@ int bzi_comm_allreduce_sum(bz_ctx *ctx, double *buf, int n)
 static int dist_time_step_general(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
 {
     const DevGrid &g = ctx->dg;
-    if (!(ctx->fused_ok && ctx->fuse_rk && g.formulation == 0 && g.microphysics != 2 && ctx->n_tracers == 0 && !ctx->bounded_mask)) {
+    if (!(ctx->fused_ok && ctx->fuse_rk && g.formulation == 0 && g.microphysics != 2 && !ctx->bounded_mask)) {
         ctx->last_error = "bz_time_step_anelastic on y-slabs implements the potential-temperature model (optionally with saturation "
-                          "adjustment, SmagorinskyLilly, column forcings and bottom fluxes): no Kessler species, tracers or bounds";
+                          "adjustment, SmagorinskyLilly, column forcings, bottom fluxes, tracers): no Kessler species or bounds";
         return BZ_ERR_UNSUPPORTED;
     }
     const int32_t nc = g.Nz + 2 * g.Hz, nf = nc + 1;
@@ -638,14 +639,20 @@ static int dist_time_step_general(bz_ctx *ctx, const bz_state *s, const bz_progn
     for (int stage = 0; stage < 3; ++stage) {
         const double alpha = alphas[stage];
         if ((rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+        if (ctx->n_tracers) {       // tracers ride beside the fused kernels: tendency from the previous-stage state, RK in place
+            if ((rc = bzi_tracer_tendencies(ctx, s))) return rc;
+            if ((rc = bzi_tracer_rk3(ctx, dt, alpha, stage == 0))) return rc;
+        }
         if (ctx->has_closure && (rc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, s->rho_theta, s->rho_q, alpha * dt))) return rc;
         if (ctx->has_forcings && (rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
         if ((ctx->has_forcings || ctx->has_bulk) && (rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
         if ((rc = dist_projection(ctx, s, G, alpha * dt, false, nullptr, nullptr, nullptr, nullptr))) return rc;
+        if ((rc = bzi_tracer_specific(ctx))) return rc;
         double *f[BZ_COMM_MAX_FIELDS] = {s->rho_u, s->rho_v, s->rho_w, s->u, s->v, s->w, s->theta, s->q, s->T, s->rho_theta, s->rho_q};
         int32_t lev[BZ_COMM_MAX_FIELDS] = {nc, nc, nf, nc, nc, nf, nc, nc, nc, nc, nc};
         int n = 11;
         if (g.microphysics == 1) { f[n] = g.qv_field; lev[n++] = nc; f[n] = g.ql_field; lev[n++] = nc; }
+        for (int t = 0; t < ctx->n_tracers && n < BZ_COMM_MAX_FIELDS; ++t) { f[n] = ctx->tracers[t].specific; lev[n++] = nc; }
         ProfileScope ps(ctx, "comm_halo_exchange");
         if ((rc = halo_exchange(ctx, f, lev, n, g.Hy, true, true, ctx->stream))) return rc;
     }

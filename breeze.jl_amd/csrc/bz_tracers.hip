@@ -39,8 +39,8 @@ extern "C" int bz_set_tracers(bz_ctx *ctx, int32_t n, const bz_tracer_fields *tr
 {
     if (!ctx || n < 0 || (n > 0 && !tracers)) return BZ_ERR_INVALID;
     if (n > BZ_MAX_TRACERS) { ctx->last_error = "bz_set_tracers: more than BZ_MAX_TRACERS tracers"; return BZ_ERR_UNSUPPORTED; }
-    if (n > 0 && (ctx->compressible || ctx->slab_mode)) {
-        ctx->last_error = "bz_set_tracers: user tracers are implemented for the single-device anelastic model";
+    if (n > 0 && ctx->compressible) {
+        ctx->last_error = "bz_set_tracers: user tracers are implemented for the anelastic model";
         return BZ_ERR_UNSUPPORTED;
     }
     for (int t = 0; t < n; ++t)

@@ -131,11 +131,12 @@ __global__ void __launch_bounds__(64) k_tridiag_solve(int NXH, int Ny, int Nz, c
 //   D  x_k = dp_k - g_k X_{s-1} - h_k X_s.
 // The singular (kx, ky) = (0, 0) column is made regular the way the sequential kernel's |beta| guard does it — its last row is
 // replaced by x = 0 — and then loses its mean (Oceananigans' solve! subtracts the mean of phi).
-// Requires 128 <= Nz <= 512 and a column count divisible by 8; other shapes use the sequential kernel.
+// Segments per column are a template parameter (64 / 16 / 8 for 128..512 / 32..127 / 16..31 levels, tridiag_coop_segs); shorter or
+// longer columns use the sequential kernel.
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define TCO_COLS 8
-#define TCO_SEGS 64
 #define TCO_M 8
+template <int TCO_SEGS>
 __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, int Ny, int Nz, int kx0, int nxh_real, int ky_fastest, TriCols C,
                                                                       double2 *__restrict__ hat, double scale, int mean_column)
 {
@@ -144,9 +145,10 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
     __shared__ double sSum[TCO_SEGS];
     const int t = threadIdx.x, cc = t & (TCO_COLS - 1), s = t >> 3;
     const long long plane = (long long)NXH * Ny;
-    const long long c = (long long)blockIdx.x * TCO_COLS + cc;          // plane % 8 == 0: always inside
+    const long long c = (long long)blockIdx.x * TCO_COLS + cc;
+    const bool live = c < plane;                                         // ragged last block (2-D grids: plane = Nx/2 + 1 columns)
     const int kx = ky_fastest ? (int)(c / Ny) : (int)(c % NXH), ky = ky_fastest ? (int)(c % Ny) : (int)(c / NXH);
-    const bool padding = (kx0 + kx >= nxh_real);
+    const bool padding = (kx0 + kx >= nxh_real) || !live;
     const bool pinned = mean_column && c == 0;                           // the (0, 0) column of the whole spectrum lives here
     const double lam = padding ? 0.0 : C.lam_x[kx0 + kx] + C.lam_y[ky];
     const int q = Nz / TCO_SEGS, r = Nz % TCO_SEGS;
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
     double2 *col = hat + c;
 #pragma unroll
     for (int j = 0; j < TCO_M; ++j)
-        if (j < L) dp[j] = col[plane * (k0 + j)];
+        if (j < L) dp[j] = live ? col[plane * (k0 + j)] : make_double2(0.0, 0.0);
     // ---- A: local forward elimination ----
     double cp_prev = 0.0, g_prev = 0.0;
     double2 d_prev = make_double2(0.0, 0.0);
@@ -271,26 +273,39 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
     }
 #pragma unroll
     for (int j = 0; j < TCO_M; ++j)
-        if (j < L) col[plane * (k0 + j)] = dp[j];
+        if (j < L && live) col[plane * (k0 + j)] = dp[j];
 }
 
-static bool tridiag_coop_ok(const bz_ctx *ctx, int Ny)
+// segments per column: 64 for 128 <= Nz <= 512 (the tuned shape), 16 / 8 for shorter columns, where the sequential kernel's
+// NXH * Ny threads of Nz dependent steps each leave the chip idle (64^3: 39 us sequential).  Every segment holds >= 2 rows.
+static int tridiag_coop_segs(const bz_ctx *ctx, int Ny)
 {
     const long long plane = (long long)ctx->NXH * Ny;
-    return ctx->dg.Nz >= 2 * TCO_SEGS && ctx->dg.Nz <= TCO_SEGS * TCO_M && plane % TCO_COLS == 0 && !getenv("BZ_NO_TRIDIAG_COOP");
+    const int Nz = ctx->dg.Nz;
+    if (getenv("BZ_NO_TRIDIAG_COOP")) return 0;
+    if (Nz >= 128 && Nz <= 64 * TCO_M) return 64;
+    if (Nz >= 32 && Nz < 128) return 16;
+    if (Nz >= 16 && Nz < 32) return 8;
+    return 0;
 }
 
 // Thomas solve of this context's spectral block, in place: the cooperative kernel when the shape allows it, else the sequential one
 int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column)
 {
     const long long plane = (long long)ctx->NXH * Ny;
-    if (tridiag_coop_ok(ctx, Ny)) {
+    if (const int segs = tridiag_coop_segs(ctx, Ny)) {
         const int nxh_real = ctx->dg.Nx / 2 + 1;
         double *d_cols = ctx->d_lower;
         const int Nz = ctx->dg.Nz;
         TriCols C{d_cols, d_cols + Nz, d_cols + 2 * Nz, d_cols + 3 * Nz, d_cols + 3 * Nz + nxh_real};
-        hipLaunchKernelGGL(k_tridiag_coop, dim3((unsigned)(plane / TCO_COLS)), dim3(TCO_COLS * TCO_SEGS), 0, ctx->stream, ctx->NXH, Ny, Nz,
-                           ctx->kx0, nxh_real, (ctx->slab_mode || ctx->xf) ? 1 : 0, C, (double2 *)hat, scale, mean_column);
+        const dim3 grid((unsigned)((plane + TCO_COLS - 1) / TCO_COLS)), block(TCO_COLS * segs);
+        const int kyf = (ctx->slab_mode || ctx->xf) ? 1 : 0;
+        if (segs == 64)
+            hipLaunchKernelGGL(k_tridiag_coop<64>, grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column);
+        else if (segs == 16)
+            hipLaunchKernelGGL(k_tridiag_coop<16>, grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column);
+        else
+            hipLaunchKernelGGL(k_tridiag_coop<8>, grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column);
     } else {
         hipLaunchKernelGGL(k_tridiag_solve, dim3((unsigned)((plane + 63) / 64)), dim3(64), 0, ctx->stream, ctx->NXH, Ny, ctx->dg.Nz,
                            ctx->d_lower, ctx->d_ibeta, ctx->d_tfac, (double2 *)hat, scale, mean_column);

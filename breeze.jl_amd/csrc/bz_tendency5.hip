@@ -57,6 +57,9 @@ static int pick_chunk5(const DevGrid &g, int nlev, int rows_per_block)
     if (tiles * want < 512) {
         long long fill = (512 + tiles - 1) / tiles;
         long long cap = nlev / 8 > 0 ? nlev / 8 : 1;
+        // latency-bound boxes (64^3: 64 blocks of 8 levels): the march is a chain of dependent level loads, so shorter chunks
+        // finish sooner even though each re-reads the stencil levels below it
+        if (tiles * cap < 256) cap = nlev / 2 > 0 ? nlev / 2 : 1;
         if (fill > cap) fill = cap;
         if (fill > want) want = fill;
     }

@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .grids import Bounded, Center, Face, Periodic, RectilinearGrid  # noqa: F401
+from .grids import Bounded, Center, Face, Flat, Periodic, RectilinearGrid  # noqa: F401
 from .model import WENO, Clock, Field, _LOC
 from .thermodynamics import ThermodynamicConstants, dry_air_gas_constant, vapor_gas_constant
 
@@ -258,8 +258,11 @@ class CompressibleAtmosphereModel:
         import torch
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
-        if grid.topology != (Periodic, Periodic, Bounded):
-            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded)")
+        # (Periodic, Flat, Bounded): the 2-D x-z cases of examples/acoustic_wave.jl:51 and inertia_gravity_wave.jl:70
+        if grid.topology not in ((Periodic, Periodic, Bounded), (Periodic, Flat, Bounded)):
+            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded) and (Periodic, Flat, Bounded)")
+        if grid.topology[1] == Flat and not (isinstance(advection, WENO) and advection.order == 5 and advection.bounds is None):
+            raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order=5) model is implemented")
         if not isinstance(dynamics, CompressibleDynamics):
             raise TypeError("dynamics must be CompressibleDynamics")
         for name, val in (("closure", closure), ("coriolis", coriolis), ("forcing", forcing)):
@@ -537,7 +540,8 @@ def set_(model, **kw):
         model.momentum["ρu"].interior.copy_(ρx * model.velocities["u"].interior)
     if "v" in keys:
         model.velocities["v"].set_interior(keys["v"])
-        ρy = (ρd.interior + P[Hz:Hz + Nz, Hy - 1:Hy - 1 + Ny, Hx:Hx + Nx]) / 2
+        # ℑy of a Flat direction is the identity
+        ρy = ρd.interior if g.topology[1] == Flat else (ρd.interior + P[Hz:Hz + Nz, Hy - 1:Hy - 1 + Ny, Hx:Hx + Nx]) / 2
         model.momentum["ρv"].interior.copy_(ρy * model.velocities["v"].interior)
     if "w" in keys:
         model.velocities["w"].set_interior(keys["w"])

@@ -280,14 +280,17 @@ __global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d(DevGrid g, d
         const double u0 = u[n], u1 = u[n + 1];
         const double Fx_lo = ((r0 + rho[n - 1]) / 2.0) * ((Ax * u0) * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, u0 > 0.0));
         const double Fx_hi = ((rho[n + 1] + r0) / 2.0) * ((Ax * u1) * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, u1 > 0.0));
-        const double ym3 = c[n - 3 * sy], ym2 = c[n - 2 * sy], ym1 = c[n - sy], yp1 = c[n + sy], yp2 = c[n + 2 * sy], yp3 = c[n + 3 * sy];
-        const double v0 = v[n], v1 = v[n + sy];
-        const double Fy_lo = ((r0 + rho[n - sy]) / 2.0) * ((Ay * v0) * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0));
-        const double Fy_hi = ((rho[n + sy] + r0) / 2.0) * ((Ay * v1) * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, v1 > 0.0));
+        double Fy_lo = 0.0, Fy_hi = 0.0;
+        if (!g.flat_y) {
+            const double ym3 = c[n - 3 * sy], ym2 = c[n - 2 * sy], ym1 = c[n - sy], yp1 = c[n + sy], yp2 = c[n + 2 * sy], yp3 = c[n + 3 * sy];
+            const double v0 = v[n], v1 = v[n + sy];
+            Fy_lo = ((r0 + rho[n - sy]) / 2.0) * ((Ay * v0) * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0));
+            Fy_hi = ((rho[n + sy] + r0) / 2.0) * ((Ay * v1) * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, v1 > 0.0));
+        }
         Gc[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
         if (Grho) {
             const double a = Ax * ru[n + 1] - Ax * ru[n];
-            const double b = Ay * rv[n + sy] - Ay * rv[n];
+            const double b = g.flat_y ? 0.0 : Ay * rv[n + sy] - Ay * rv[n];
             const double cc = g.Az * rw[n + sz] - g.Az * rw[n];
             Grho[n] = -(g.Vinv_c[k] * (a + b + cc));
         }
@@ -874,12 +877,17 @@ extern "C" int bz_compute_slow_tendencies(bz_ctx *ctx, const bz_compressible_sta
     a.rho_theta = s->rho_theta; a.rho_q = s->rho_q; a.theta = s->theta;
     bz_prognostic Ga;
     Ga.rho_u = G->rho_u; Ga.rho_v = G->rho_v; Ga.rho_w = G->rho_w; Ga.rho_theta = G->rho_theta; Ga.rho_q = G->rho_q;
-    int rc = bzi_u_tendency_lds(ctx, &a, &Ga);
-    if (rc) return rc;
-    rc = bzi_v_tendency_lds(ctx, &a, &Ga);
-    if (rc) return rc;
-    rc = bzi_w_tendency_ring(ctx, &a, &Ga, nullptr, nullptr, 1);
-    if (rc) return rc;
+    int rc;
+    if (ctx->dg.flat_y) {
+        if ((rc = bzi_momentum_advection_gen1(ctx, &a, &Ga))) return rc;
+    } else {
+        rc = bzi_u_tendency_lds(ctx, &a, &Ga);
+        if (rc) return rc;
+        rc = bzi_v_tendency_lds(ctx, &a, &Ga);
+        if (rc) return rc;
+        rc = bzi_w_tendency_ring(ctx, &a, &Ga, nullptr, nullptr, 1);
+        if (rc) return rc;
+    }
     return launch_scalar_rho3d(ctx, "density+potential_temperature_tendency", G->rho_theta, G->rho_d, s->rho_d, s->u, s->v,
                                s->w, s->theta, s->rho_u, s->rho_v, s->rho_w);
 }
@@ -890,7 +898,7 @@ static int acoustic_substeps_for(const bz_ctx *ctx, double dt)
     const double Rd = ctx->constants.dry_air_gas_constant, cpd = ctx->constants.dry_air_heat_capacity;
     const double gam = cpd / (cpd - Rd);
     const double cs = std::sqrt(gam * Rd * 300.0);
-    const double dmin = std::fmin(ctx->dg.dx, ctx->dg.dy);
+    const double dmin = ctx->dg.flat_y ? ctx->dg.dx : std::fmin(ctx->dg.dx, ctx->dg.dy);      // Flat directions do not bound the acoustic CFL (acoustic_substepping.jl:458-465)
     const double n = std::ceil(std::fabs(dt) * cs / (ctx->se.acoustic_cfl * dmin));
     return (int)std::fmax(1.0, n);
 }
@@ -1004,7 +1012,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     }
     P.f_theta = ctx->se.thermodynamic_tendency_factor;
     P.f_w = ctx->se.vertical_momentum_tendency_factor;
-    const double lmin = std::fmin(g.dx, g.dy);
+    const double lmin = g.flat_y ? g.dx : std::fmin(g.dx, g.dy);                             // acoustic_substepping.jl:1102-1110
     P.kdamp = S.damping ? ctx->se.damping_coefficient * (lmin * lmin) / dtau : 0.0;
     P.inv_N = 1.0 / (double)ntau;
     P.gate = 1.0;

@@ -159,11 +159,11 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
 #endif
     if (grid->ftype != 8) return BZ_ERR_UNSUPPORTED;
     // (Periodic, Periodic, Bounded), or (Periodic, Flat, Bounded) — the reference's 2-D x-z cases (README.md:67-75, examples/
-    // dry_thermal_bubble.jl): Ny = 1, Hy = 0, single-GPU anelastic WENO-5 contexts, operator-by-operator kernels
+    // dry_thermal_bubble.jl, acoustic_wave.jl, inertia_gravity_wave.jl): Ny = 1, Hy = 0, single-GPU WENO-5 contexts
     const bool flat_y = grid->topo[1] == BZ_FLAT;
     if (grid->topo[0] != BZ_PERIODIC || (grid->topo[1] != BZ_PERIODIC && !flat_y) || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
-    if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode || compressible || weno_order != 5)) return BZ_ERR_UNSUPPORTED;
+    if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode || weno_order != 5)) return BZ_ERR_UNSUPPORTED;
     if (grid->Hx < 3 || (!flat_y && grid->Hy < 3) || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
     // Oceananigans: N >= H in every direction (k_halo_y's wrap copy would otherwise read a halo row that is not filled yet)
     if (grid->Nx < grid->Hx || grid->Ny < grid->Hy || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;
@@ -247,7 +247,10 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.Sx = Nx + 2 * grid->Hx;
     g.Sy = Ny + 2 * grid->Hy;
     g.Sxy = (long long)g.Sx * g.Sy;
-    g.dx = dx; g.dy = dy; g.rdx = 1.0 / dx; g.rdy = 1.0 / dy; g.Az = dx * dy;
+    g.dx = dx; g.dy = dy; g.rdx = 1.0 / dx; g.Az = dx * dy;
+    // a Flat direction has zero derivatives: with 1/dy = 0 every y difference quotient of the wrap-indexed kernels (whose y neighbour
+    // is the cell itself) is an exact zero, also where hipcc contracts c0 - C*rt into an FMA that would return c0's rounding error
+    g.rdy = flat_y ? 0.0 : 1.0 / dy;
     auto dcol = [&](int c) { return ctx->d_columns + (size_t)c * nf + Hz; };
     g.dzc = dcol(C_DZC); g.dzf = dcol(C_DZF); g.rdzf = dcol(C_RDZF); g.rdzc = dcol(C_RDZC); g.zc = dcol(C_ZC);
     g.formulation = 0;
@@ -276,7 +279,9 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);
     ctx->fuse_rk = !getenv("BZ_NO_FUSE_RK");
     ctx->tend_lds = !getenv("BZ_NO_TEND_LDS");
-    if (flat_y) { ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }      // one kernel per reference kernel (bz_tendency.hip)
+    // Flat y: the anelastic model steps with one kernel per reference kernel (bz_tendency.hip); the compressible kernels reach their
+    // y neighbours through wrap offsets, which are zero when Ny = 1 (bz_compressible.hip: wrap_of), and keep their fused sequence
+    if (flat_y) { if (!compressible) ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }
     ctx->compressible = compressible;
     ctx->dz_min = dzc[Hz];
     for (int k = 0; k < Nz; ++k) ctx->dz_min = std::fmin(ctx->dz_min, dzc[Hz + k]);

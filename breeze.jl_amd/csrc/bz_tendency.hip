@@ -224,6 +224,7 @@ __device__ __forceinline__ double flux_Ww(const DevGrid &g, const double *__rest
     return wt * wR;
 }
 
+template <bool BUOY = true>
 __global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__restrict__ Gw,
                                                         const double *__restrict__ ru,
                                                         const double *__restrict__ rv,
@@ -244,12 +245,12 @@ __global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__re
     // ring of w around centre k-1 (faces k-3 .. k+2) to start; centre k needs faces k-2..k+3
     double zm3 = w[n - 3 * sz], zm2 = w[n - 2 * sz], zm1 = w[n - sz], z0 = w[n], zp1 = w[n + sz], zp2 = w[n + 2 * sz];
     double Fz_lo = flux_Ww(g, rw, n - sz, k0 - 1, zm3, zm2, zm1, z0, zp1, zp2);
-    double b_lo = bz_buoyancy(g, T, qv, n - sz, k0 - 1);
+    double b_lo = BUOY ? bz_buoyancy(g, T, qv, n - sz, k0 - 1) : 0.0;
 
     for (int k = k0; k < k1; ++k, n += sz) {
         double zp3 = w[n + 3 * sz];
         double Fz_hi = flux_Ww(g, rw, n, k, zm2, zm1, z0, zp1, zp2, zp3);
-        double b_hi = bz_buoyancy(g, T, qv, n, k);
+        double b_hi = BUOY ? bz_buoyancy(g, T, qv, n, k) : 0.0;
         const int Bf = bz_buffer_face(k, g.Nz);
 
         // x: F_Uw at x-faces i (lo), i+1 (hi): advecting flux = centred-in-z of Ax(k)*rho_u to face k
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__re
             Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
         }
 
-        double bf = 0.5 * (b_lo + b_hi);
-        Gw[n] = -(g.Vinv_f[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo))) + bf;
+        const double adv = -(g.Vinv_f[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
+        Gw[n] = BUOY ? adv + 0.5 * (b_lo + b_hi) : adv;
 
         zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
         Fz_lo = Fz_hi;
@@ -303,6 +304,32 @@ static int pick_kchunk(const DevGrid &g, int nlev)
     return (int)((nlev + want - 1) / want);
 }
 
+// momentum advection by the per-operator kernels alone (no buoyancy): the slow momentum tendencies of the split-explicit compressible
+// model on (Periodic, Flat, Bounded) grids, where the LDS-tiled kernels (y halo rows in their tiles) do not apply
+int bzi_momentum_advection_gen1(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    const DevGrid &g = ctx->dg;
+    const dim3 block(64, TYB);
+    const int kc = pick_kchunk(g, g.Nz), kcw = pick_kchunk(g, g.Nz - 1);
+    const dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
+    const dim3 gridw(grid.x, grid.y, (g.Nz - 1 + kcw - 1) / kcw);
+    {
+        ProfileScope ps(ctx, "x_momentum_tendency");
+        hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, RKEpilogue());
+    }
+    {
+        ProfileScope ps(ctx, "y_momentum_tendency");
+        hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc, RKEpilogue());
+    }
+    {
+        ProfileScope ps(ctx, "z_momentum_tendency");
+        hipLaunchKernelGGL(k_w_tendency<false>, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
+                           (const double *)nullptr, (const double *)nullptr, kcw);
+    }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
 extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
     if (!ctx || !s || !G) return BZ_ERR_INVALID;
@@ -332,7 +359,7 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
         ProfileScope ps(ctx, "z_momentum_tendency");
         int kcw = pick_kchunk(g, g.Nz - 1);
         dim3 gridw((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz - 1 + kcw - 1) / kcw);
-        hipLaunchKernelGGL(k_w_tendency, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
+        hipLaunchKernelGGL(k_w_tendency<true>, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
                            s->T, s->q, kcw);
         BZ_LAUNCH_CHECK();
         return BZ_OK;
@@ -360,7 +387,7 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
         ProfileScope ps(ctx, "z_momentum_tendency");
         int kcw = pick_kchunk(g, g.Nz - 1);
         dim3 gridw(grid.x, grid.y, (g.Nz - 1 + kcw - 1) / kcw);
-        hipLaunchKernelGGL(k_w_tendency, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
+        hipLaunchKernelGGL(k_w_tendency<true>, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
                            s->T, s->q, kcw);
     }
     if (ctx->tend_gen >= 2) {

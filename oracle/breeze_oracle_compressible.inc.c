@@ -273,14 +273,16 @@ void og_explicit_horizontal_step(const og_grid *G, double *rup, double *rvp, con
                     double dpp = (gR[n] * Pi[n] * rthp[n] - gR[m] * Pi[m] * rthp[m]) * (1.0 / G->dx);
                     double dp = dpL + f * dpp;
                     rup[n] += dtau * (Gu[n] - dp);
-                }
+                } else
+                    rup[n] += dtau * Gu[n];      /* the kernel updates both components; a Flat direction has a zero gradient */
                 if (G->ty != FLAT) {
                     size_t m = n - STRY(G);
                     double dpL = (p[n] - p[m]) * (1.0 / G->dy);
                     double dpp = (gR[n] * Pi[n] * rthp[n] - gR[m] * Pi[m] * rthp[m]) * (1.0 / G->dy);
                     double dp = dpL + f * dpp;
                     rvp[n] += dtau * (Gv[n] - dp);
-                }
+                } else
+                    rvp[n] += dtau * Gv[n];
             }
 }
 

@@ -90,3 +90,107 @@ def test_two_dimensional_run_equals_the_y_invariant_three_dimensional_run(bz):
     for k in out[0]:
         scale = max(np.abs(out[1][k]).max(), 1e-3)
         assert np.abs(out[0][k] - out[1][k]).max() / scale < 1e-10, k
+
+
+# ---- compressible split-explicit model on (Periodic, Flat, Bounded): examples/acoustic_wave.jl:51, inertia_gravity_wave.jl:70 ----------
+
+def _cpair(oracle, bz, size=(40, 24), zext=(0.0, 8e3), xext=(-4e3, 4e3), theta_ref=300.0, **td):
+    from oracle import oracle_compressible as oc
+    og = oracle.Grid(size, x=xext, z=zext, topology=("Periodic", "Flat", "Bounded"))
+    otd = oc.SplitExplicit(**td)
+    om = oc.CompressibleOracleModel(og, time_discretization=otd, reference_potential_temperature=theta_ref, reference_state=True)
+    grid = bz.RectilinearGrid(size, x=xext, z=zext, topology=(bz.Periodic, bz.Flat, bz.Bounded))
+    damping = (bz.NoDivergenceDamping() if otd.damping_coefficient is None
+               else bz.DirectDivergenceDamping(coefficient=otd.damping_coefficient) if otd.direct_damping
+               else bz.ThermalDivergenceDamping(coefficient=otd.damping_coefficient, damp_vertical=otd.damp_vertical))
+    sponge = None
+    if otd.sponge is not None:
+        ramp = {"linear": bz.LinearRamp, "cubic": bz.CubicRamp, "sin2": bz.Sin2Ramp}[otd.sponge[2]]()
+        sponge = bz.UpperSponge(damping_rate=otd.sponge[0], depth=otd.sponge[1], ramp=ramp)
+    btd = bz.SplitExplicitTimeDiscretization(substeps=otd.substeps, acoustic_cfl=otd.acoustic_cfl, forward_weight=otd.forward_weight,
+                                             damping=damping, sponge=sponge,
+                                             apply_first_substep_pressure_gradient=otd.apply_first)
+    dyn = bz.CompressibleDynamics(btd, reference_potential_temperature=theta_ref, reference_state="auto")
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5))
+    return oc, om, hm
+
+
+def test_compressible_two_dimensional_update_state_and_slow_tendencies_match_oracle(oracle, bz):
+    import test_gpu_compressible as tc
+    oc, om, hm = _cpair(oracle, bz)
+    tc.seeded_state(om, 11)
+    om.compute_slow_tendencies()
+    tc.push(om, hm, substepper=False)
+    bz.compressible.update_state_(hm)
+    tc.cmp_interior(om, hm, ("rho", "u", "v", "w", "theta", "q", "T", "p"), 1e-14)
+    for k in hm.G:
+        if k != "ρq":
+            hm.G[k].parent.zero_()
+    bz.compressible.compute_slow_tendencies_(hm)
+    g = om.grid
+    for n, k in tc.PROG.items():
+        if n == "rq":
+            continue
+        a, b = hm.G[k].interior_cpu(), g.interior(om.G[n], n == "rw")
+        if n == "rw":
+            a, b = a[1:-1], b[1:-1]
+        assert tc.rel(a, b) <= 1e-12, (n, tc.rel(a, b))
+
+
+@pytest.mark.parametrize("td", [dict(substeps=6), dict(), dict(substeps=4, damping_coefficient=0.05, damp_vertical=True),
+                                dict(substeps=6, direct_damping=True), dict(substeps=6, sponge=(0.2, 3000.0, "cubic"))])
+def test_compressible_two_dimensional_acoustic_loop_matches_oracle(oracle, bz, td):
+    """acoustic_rk3_substep_loop! on a Flat-y grid: the y neighbours of every column are the column itself, Flat spacings do not enter
+    the acoustic CFL or the damping length (acoustic_substepping.jl:458-465, 1102-1110)."""
+    import test_gpu_compressible as tc
+    oc, om, hm = _cpair(oracle, bz, **td)
+    tc.seeded_state(om, 4)
+    for n in om.PROGNOSTIC:
+        om.U0[n][...] = getattr(om, n)
+    g = om.grid
+    rng = np.random.default_rng(5)
+    for n in ("rho_d", "rtheta", "ru", "rv"):
+        g.interior(getattr(om, n))[...] *= 1 + 1e-3 * rng.standard_normal((g.Nz, g.Ny, g.Nx))
+    g.interior(om.rw, True)[1:-1] *= 1 + 1e-3 * rng.standard_normal((g.Nz - 1, g.Ny, g.Nx))
+    om.update_state(compute_tendencies=True)
+    om.refresh_linearization()
+    om.compute_slow_tendencies()
+    tc.push(om, hm)
+    bz.compressible.refresh_linearization_(hm)
+    dt, beta = 2.0, 1.0
+    om.acoustic_substep_loop(dt, beta)
+    bz.compressible.acoustic_rk3_substep_loop_(hm, dt, beta)
+    n_tau, _ = hm.stage_substeps(dt, beta)
+    assert n_tau == om.last_substeps[-1]
+    sub = hm.timestepper.substepper
+    for n, k in tc.SUB.items():
+        if n in ("Pi", "thL", "gR"):
+            continue
+        zf = n in ("rwp", "aw", "Gs")
+        a, b = getattr(sub, k).interior_cpu(), g.interior(getattr(om, n), zf)
+        scale = {"rp": np.abs(g.interior(om.rho_d)).max() * 1e-3, "rthp": np.abs(g.interior(om.rtheta)).max() * 1e-3}.get(n)
+        err = np.abs(a - b).max() / (scale or max(np.abs(b).max(), 1e-300))
+        assert err <= 2e-10, (n, err, n_tau)      # rounding level: rp / rthp are scaled by 1e-3 of the full density
+    tc.cmp_interior(om, hm, ("rho_d", "rtheta", "ru", "rv", "rw", "u", "v", "w"), 5e-12)
+
+
+def test_compressible_inertia_gravity_wave_steps_match_oracle(oracle, bz):
+    """examples/inertia_gravity_wave.jl:63-95 (Skamarock & Klemp 1994) at reduced length: theta_bg(z) = theta_0 exp(N^2 z / g) with the
+    0.01 K perturbation, 20 m/s mean wind, split-explicit compressible dynamics; three steps against the oracle."""
+    Nx, Nz, Lx, Lz = 96, 10, 96e3, 10e3
+    th0, N2, grav = 300.0, 1e-4, 9.80665
+    thbg = lambda z: th0 * np.exp(N2 * z / grav)
+    thi = lambda x, z: thbg(z) + 0.01 * np.sin(np.pi * z / Lz) / (1 + (x - Lx / 3) ** 2 / 5000.0 ** 2)
+    oc, om, hm = _cpair(oracle, bz, size=(Nx, Nz), zext=(0.0, Lz), xext=(0.0, Lx), theta_ref=thbg)
+    g = om.grid
+    rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None] + np.zeros((Nz, 1, Nx))
+    om.set(rho=rho, theta=lambda x, y, z: thi(x, z) + 0 * y, u=20.0, v=0.0, w=0.0)
+    hm.set(ρ=rho, θ=thi, u=20.0, v=0.0, w=0.0)
+    import test_gpu_compressible as tc
+    tc.cmp_interior(om, hm, ("rho_d", "rho", "rtheta", "ru", "T", "p"), 1e-14)
+    for _ in range(3):
+        om.time_step(6.0)
+        hm.time_step(6.0)
+    assert np.abs(g.interior(om.rw, True)).max() > 1e-6
+    tc.cmp_interior(om, hm, ("rho_d", "rtheta", "ru", "rw", "u", "w", "theta", "T", "p"), 5e-9)
+    assert np.abs(hm.momentum["ρv"].interior_cpu()).max() == 0.0

@@ -164,6 +164,8 @@ SYMBOLS = {
     "bz_set_formulation": (C.c_int, [_ctx, C.c_int]),
     "bz_set_saturation_adjustment": (C.c_int, [_ctx, C.POINTER(bz_saturation_adjustment), C.c_void_p, C.c_void_p]),
     "bz_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "bz_graph_enable": (C.c_int, [_ctx, C.c_int]),
+    "bz_graph_info": (C.c_int, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "bz_sync": (C.c_int, [_ctx]),
     "bz_last_error": (C.c_char_p, [_ctx]),
     "bz_fill_halo_regions": (C.c_int, [_ctx, C.c_void_p, C.c_int]),

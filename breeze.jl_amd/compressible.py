@@ -436,6 +436,16 @@ class CompressibleAtmosphereModel:
     def synchronize(self):
         self._check(self._lib.bz_sync(self._ctx), "bz_sync")
 
+    def graph_enable(self, on=True):
+        """hipGraph replay of whole steps (csrc/bz_graph.hip); opt-in, bit-identical to launched steps."""
+        self._check(self._lib.bz_graph_enable(self._ctx, 1 if on else 0), "bz_graph_enable")
+
+    def graph_info(self):
+        """(enabled, steps recorded, steps replayed)"""
+        en, cap, rep = C.c_int32(), C.c_int64(), C.c_int64()
+        self._check(self._lib.bz_graph_info(self._ctx, C.byref(en), C.byref(cap), C.byref(rep)), "bz_graph_info")
+        return bool(en.value), cap.value, rep.value
+
     def profile_enable(self, on=True):
         self._check(self._lib.bz_profile_enable(self._ctx, 1 if on else 0), "bz_profile_enable")
 

@@ -1217,6 +1217,7 @@ extern "C" int bz_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s
 
 extern "C" int bz_set_acoustic_scratch(bz_ctx *ctx, double *momentum_u_second_buffer, double *momentum_v_second_buffer)
 {
+    if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     BZ_REQUIRE_COMPRESSIBLE();
     if ((momentum_u_second_buffer == nullptr) != (momentum_v_second_buffer == nullptr)) return BZ_ERR_INVALID;
     ctx->up2_user = momentum_u_second_buffer;
@@ -1287,6 +1288,9 @@ int bzi_compressible_store_initial_state(bz_ctx *ctx, const bz_compressible_stat
     return BZ_OK;
 }
 
+static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                  const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt);
+
 extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                                          const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt)
 {
@@ -1295,6 +1299,21 @@ extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_stat
     if (rc) return rc;
     if (ctx->slab_mode && ctx->comm) return bzi_dist_time_step_compressible(ctx, s, U0, G, sub, dt);     // bz_comm.hip owns the exchanges
     if ((rc = require_no_slab(ctx, "bz_time_step_compressible"))) return rc;
+    // launch-bound grids replay the recorded step (bz_graph.hip); a failed recording has executed nothing and falls through
+    const uint64_t key = bzi_graph_key(ctx, 2, dt, s, sizeof(*s), U0, sizeof(*U0), G, sizeof(*G), sub, sizeof(*sub));
+    bool capture = false;
+    if (bzi_graph_begin(ctx, key, &capture) == 1) return BZ_OK;
+    if (capture) {
+        rc = compressible_step_body(ctx, s, U0, G, sub, dt);
+        if ((rc = bzi_graph_end(ctx, key, rc)) != -1) return rc;
+    }
+    return compressible_step_body(ctx, s, U0, G, sub, dt);
+}
+
+static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                  const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt)
+{
+    int rc;
     const DevGrid &g = ctx->dg;
     if ((rc = bzi_compressible_store_initial_state(ctx, s, U0))) return rc;
     // freeze_linearization_state! (acoustic_substepping.jl:288-292): the linearisation of stage 1 (refreshed again by

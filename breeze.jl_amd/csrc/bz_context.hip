@@ -69,13 +69,18 @@ extern "C" int bz_profile_get(bz_ctx *ctx, int idx, const char **name, double *t
 
 extern "C" const char *bz_last_error(const bz_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
 
-extern "C" int bz_set_stream(bz_ctx *ctx, void *hip_stream)
+// every launch of the library goes to ctx->stream; rocFFT executes on the stream its plan carries
+int bzi_apply_stream(bz_ctx *ctx, hipStream_t stream)
 {
-    if (!ctx) return BZ_ERR_INVALID;
-    ctx->stream = (hipStream_t)hip_stream;
+    ctx->stream = stream;
     if (ctx->plans_ok) {
         BZ_FFT(hipfftSetStream(ctx->plan_fwd, ctx->stream));
         BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
+    }
+    if (ctx->xf && ctx->plan_y) BZ_FFT(hipfftSetStream(ctx->plan_y, ctx->stream));      // the y transforms of the LDS x-transform pipeline
+    if (ctx->pchunk) {
+        BZ_FFT(hipfftSetStream(ctx->plan_fwd_c, ctx->stream));
+        BZ_FFT(hipfftSetStream(ctx->plan_inv_c, ctx->stream));
     }
     if (ctx->slab_plans_ok) {
         BZ_FFT(hipfftSetStream(ctx->slab_plan_x_fwd, ctx->stream));
@@ -85,10 +90,18 @@ extern "C" int bz_set_stream(bz_ctx *ctx, void *hip_stream)
     return BZ_OK;
 }
 
+extern "C" int bz_set_stream(bz_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    ++ctx->config_epoch;
+    return bzi_apply_stream(ctx, (hipStream_t)hip_stream);
+}
+
 // thermodynamic formulation of the anelastic model: 0 = :LiquidIcePotentialTemperature, 1 = :StaticEnergy
 // (src/StaticEnergyFormulations/static_energy_formulation.jl); with 1 the rho_theta / theta slots carry rho_e / e.
 extern "C" int bz_set_formulation(bz_ctx *ctx, int formulation)
 {
+    if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx || formulation < 0 || formulation > 1) return BZ_ERR_INVALID;
     if (ctx->compressible && formulation != 0) return BZ_ERR_UNSUPPORTED;
     ctx->dg.formulation = formulation;
@@ -100,6 +113,7 @@ extern "C" int bz_set_formulation(bz_ctx *ctx, int formulation)
 extern "C" int bz_set_saturation_adjustment(bz_ctx *ctx, const bz_saturation_adjustment *params, double *q_vapor,
                                             double *q_liquid)
 {
+    if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx) return BZ_ERR_INVALID;
     DevGrid &g = ctx->dg;
     if (!params) { g.microphysics = 0; g.qv_field = g.ql_field = nullptr; return BZ_OK; }
@@ -292,6 +306,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
         bz_destroy(ctx);
         return rc;
     }
+    bzi_graph_configure(ctx);
     *out = ctx;
     return BZ_OK;
 }
@@ -300,6 +315,7 @@ extern "C" void bz_destroy(bz_ctx *ctx)
 {
     if (!ctx) return;
     profile_drain(ctx);
+    bzi_graph_destroy(ctx);
     bzi_comm_teardown(ctx);
     bzi_poisson_teardown(ctx);
     bzi_lean_teardown(ctx);

@@ -205,6 +205,7 @@ void bzi_forcing_teardown(bz_ctx *ctx) { free_forcings(ctx); }
 
 extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
 {
+    if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx) return BZ_ERR_INVALID;
     free_forcings(ctx);
     if (!f) return BZ_OK;
@@ -243,6 +244,7 @@ extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
 
 extern "C" int bz_set_bulk_surface_fluxes(bz_ctx *ctx, const bz_bulk_surface_fluxes *b)
 {
+    if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx) return BZ_ERR_INVALID;
     if (!b) { ctx->has_bulk = false; return BZ_OK; }
     if (ctx->compressible || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {      // y-slab contexts: through the library-owned distributed step (bz_comm.hip)

@@ -328,7 +328,33 @@ struct bz_ctx {
     // profiling
     bool profiling = false;
     std::vector<ProfileSlot> slots;
+    // hipGraph replay of whole steps on launch-bound grids (bz_graph.hip)
+    int graph_mode = 0;               // 0: off, 1: capture a step the second time it is asked for with the same arguments, then replay
+    bool graph_capturing = false;
+    uint64_t config_epoch = 0;        // bumped by every bz_set_* call: a captured step is valid for one configuration
+    struct GraphSlot {
+        uint64_t key = 0;
+        int seen = 0;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool g_is_predictor = false;
+    } graph_slots[2];
+    int graph_next = 0;
+    hipStream_t graph_stream = nullptr, graph_user_stream = nullptr;      // recording stream (the legacy default stream cannot be captured)
+    long long graph_replays = 0, graph_captures = 0;
 };
+
+// ---- bz_graph.hip ----
+uint64_t bzi_graph_key(const bz_ctx *ctx, int kind, double dt, const void *a, size_t na, const void *b, size_t nb, const void *c, size_t nc,
+                       const void *d, size_t nd);
+// begin: 1 = the step was replayed from its graph (done), 0 = run the body now; *capture = the stream is recording, bracket the body
+// with bzi_graph_end.  end: BZ_OK = recorded and launched, -1 = recording failed and nothing has executed (run the body the ordinary
+// way), otherwise the body's own error code
+int bzi_graph_begin(bz_ctx *ctx, uint64_t key, bool *capture);
+int bzi_graph_end(bz_ctx *ctx, uint64_t key, int body_rc);
+void bzi_graph_destroy(bz_ctx *ctx);
+void bzi_graph_configure(bz_ctx *ctx);
+int bzi_apply_stream(bz_ctx *ctx, hipStream_t stream);
 
 #define BZ_HIP(expr)                                                                        \
     do {                                                                                    \

@@ -23,6 +23,8 @@ extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognost
     return BZ_OK;
 }
 
+static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt);
+
 extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
                                       const bz_prognostic *G, double dt)
 {
@@ -33,6 +35,20 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
                           "or a host-side distributed driver";
         return BZ_ERR_UNSUPPORTED;
     }
+    // launch-bound grids replay the recorded step (bz_graph.hip); a failed recording has executed nothing and falls through
+    const uint64_t key = bzi_graph_key(ctx, 1, dt, s, sizeof(*s), U0, sizeof(*U0), G, sizeof(*G), nullptr, 0);
+    bool capture = false;
+    int rc;
+    if (bzi_graph_begin(ctx, key, &capture) == 1) return BZ_OK;
+    if (capture) {
+        rc = anelastic_step_body(ctx, s, U0, G, dt);
+        if ((rc = bzi_graph_end(ctx, key, rc)) != -1) return rc;
+    }
+    return anelastic_step_body(ctx, s, U0, G, dt);
+}
+
+static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
+{
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
     if (ctx->fused_ok && ctx->fuse_rk && ctx->lean && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&

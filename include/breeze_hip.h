@@ -558,6 +558,15 @@ int bz_profile_get(bz_ctx *ctx, int idx, const char **name, double *total_ms, in
  * (test/anelastic_pressure_solver_nonhydrostatic.jl:45-46). Synchronises. */
 int bz_max_abs_divergence(bz_ctx *ctx, const bz_state *s, double *out);
 
+/* hipGraph replay of whole time steps (csrc/bz_graph.hip).  bz_time_step_anelastic / bz_time_step_compressible are pure functions of
+ * (argument structs, dt, configuration); on launch-bound grids the second call with the same arguments records the step with stream
+ * capture and later calls replay it with one hipGraphLaunch.  Opt-in (bz_graph_enable, or BZ_GRAPH=1 in the environment): measured gain
+ * on MI355X is 0-5 % on launch-bound grids and recording costs ~1 ms, so it pays only with a fixed dt.  Inactive while profiling is
+ * enabled and on contexts with a communicator.  The arrays named by the structs must stay where they are, as
+ * Oceananigans fields do.  No reference counterpart. */
+int bz_graph_enable(bz_ctx *ctx, int on);
+int bz_graph_info(bz_ctx *ctx, int32_t *enabled, int64_t *captures, int64_t *replays);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,6 +220,7 @@ struct LocalTransport : Transport {
 
 // ---- the communicator of a context ----------------------------------------------------------------------------------------------
 #define BZ_COMM_MAX_FIELDS 24
+static_assert(BZ_COMM_MAX_FIELDS >= 14 + BZ_MAX_TRACERS, "a stage exchange carries 14 model fields and every user tracer");
 struct BzComm {
     Transport *T = nullptr;
     int W = 1, rank = 0, upper = 0, lower = 0;
@@ -555,7 +556,7 @@ static int state_halo_exchange(bz_ctx *ctx, const bz_state *s, double *pa, doubl
         for (int m = 0; m < 5; ++m) { f[n] = d[m]; lev[n] = dl[m]; ++n; }
         if (ctx->has_closure || g.microphysics == 1) { f[n] = s->T; lev[n++] = nc; }      // the viscosity kernel covers the rows next to the slab
         if (g.microphysics == 1) { f[n] = g.qv_field; lev[n++] = nc; f[n] = g.ql_field; lev[n++] = nc; }
-        for (int t = 0; t < ctx->n_tracers && n < BZ_COMM_MAX_FIELDS; ++t) { f[n] = ctx->tracers[t].specific; lev[n++] = nc; }
+        for (int t = 0; t < ctx->n_tracers; ++t) { f[n] = ctx->tracers[t].specific; lev[n++] = nc; }
     }
     return halo_exchange(ctx, f, lev, n, g.Hy, true, true, st);
 }
@@ -652,7 +653,7 @@ static int dist_time_step_general(bz_ctx *ctx, const bz_state *s, const bz_progn
         int32_t lev[BZ_COMM_MAX_FIELDS] = {nc, nc, nf, nc, nc, nf, nc, nc, nc, nc, nc};
         int n = 11;
         if (g.microphysics == 1) { f[n] = g.qv_field; lev[n++] = nc; f[n] = g.ql_field; lev[n++] = nc; }
-        for (int t = 0; t < ctx->n_tracers && n < BZ_COMM_MAX_FIELDS; ++t) { f[n] = ctx->tracers[t].specific; lev[n++] = nc; }
+        for (int t = 0; t < ctx->n_tracers; ++t) { f[n] = ctx->tracers[t].specific; lev[n++] = nc; }
         ProfileScope ps(ctx, "comm_halo_exchange");
         if ((rc = halo_exchange(ctx, f, lev, n, g.Hy, true, true, ctx->stream))) return rc;
     }

@@ -209,44 +209,60 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
         sD[s][cc][0] = dp[0]; sD[s][cc][1] = dl;
     }
     __syncthreads();
-    if (s == 0) {        // one thread per column: Thomas over the 64 reduced unknowns, in LDS
-        double beta = 0.0, tprev = 0.0;
-        double2 vprev = make_double2(0.0, 0.0);
-        for (int m = 0; m < TCO_SEGS; ++m) {
-            const double glm = sR[m][cc][2], cpl = sR[m][cc][3];
-            double diag = 1.0, sup = 0.0;
-            double2 rhs = sD[m][cc][1];
-            if (m + 1 < TCO_SEGS) {
-                diag = 1.0 - cpl * sR[m + 1][cc][0];
-                sup = -cpl * sR[m + 1][cc][1];
-                const double2 df = sD[m + 1][cc][0];
-                rhs.x -= cpl * df.x;
-                rhs.y -= cpl * df.y;
-            }
-            beta = diag - glm * tprev;
-            const double ib = 1.0 / beta;
-            double2 v;
-            v.x = (rhs.x - glm * vprev.x) * ib;
-            v.y = (rhs.y - glm * vprev.y) * ib;
-            tprev = sup * ib;
-            sR[m][cc][4] = tprev;
-            sD[m][cc][0] = v;
-            vprev = v;
+    // Parallel cyclic reduction over the TCO_SEGS reduced unknowns of a column, one thread per unknown (the threads of a column are
+    // t = s * 8 + cc).  Rows are kept normalised, a X_{m-h} + X_m + c X_{m+h} = d; one step with stride h eliminates both neighbours:
+    //   r = 1 / (1 - a c_{m-h} - c a_{m+h}),  a' = -a a_{m-h} r,  c' = -c c_{m+h} r,  d' = (d - a d_{m-h} - c d_{m+h}) r
+    // (rows beyond the ends are identity rows: a = c = d = 0), and after log2(TCO_SEGS) steps X_m = d.  The system inherits the
+    // diagonal dominance of the column's own tridiagonal matrix, so no pivoting is needed.  The serial Thomas sweep this replaces kept
+    // 8 of the block's 512 threads busy for 2 x 64 dependent LDS round trips.
+    double pa, pc;
+    double2 pd;
+    {
+        const double glm = sR[s][cc][2], cpl = sR[s][cc][3];
+        double diag = 1.0, sup = 0.0;
+        double2 rhs = sD[s][cc][1];
+        if (s + 1 < TCO_SEGS) {
+            diag = 1.0 - cpl * sR[s + 1][cc][0];
+            sup = -cpl * sR[s + 1][cc][1];
+            const double2 df = sD[s + 1][cc][0];
+            rhs.x -= cpl * df.x;
+            rhs.y -= cpl * df.y;
         }
-        double2 next = sD[TCO_SEGS - 1][cc][0];
-        for (int m = TCO_SEGS - 2; m >= 0; --m) {
-            double2 v = sD[m][cc][0];
-            const double tt = sR[m][cc][4];
-            v.x -= tt * next.x;
-            v.y -= tt * next.y;
-            sD[m][cc][0] = v;
-            next = v;
-        }
+        const double r = 1.0 / diag;
+        pa = glm * r; pc = sup * r;
+        pd = make_double2(rhs.x * r, rhs.y * r);
     }
-    __syncthreads();
+    __syncthreads();                                   // sR / sD are read; their storage becomes the two exchange buffers
+    constexpr int NT = TCO_SEGS * TCO_COLS;
+    static_assert(sizeof(sR) >= 4 * NT * sizeof(double) && sizeof(sD) >= 4 * NT * sizeof(double), "exchange buffers alias sR / sD");
+    double *xb[2] = {&sR[0][0][0], (double *)&sD[0][0][0]};
+    int pb = 0;
+#pragma unroll
+    for (int h = 1; h < TCO_SEGS; h <<= 1) {
+        double *B = xb[pb];
+        B[t] = pa; B[NT + t] = pc; B[2 * NT + t] = pd.x; B[3 * NT + t] = pd.y;
+        __syncthreads();
+        const int tm = t - h * TCO_COLS, tp = t + h * TCO_COLS;
+        double am = 0.0, cm = 0.0, ap = 0.0, cp = 0.0;
+        double2 dm = make_double2(0.0, 0.0), dq = make_double2(0.0, 0.0);
+        if (s - h >= 0) { am = B[tm]; cm = B[NT + tm]; dm = make_double2(B[2 * NT + tm], B[3 * NT + tm]); }
+        if (s + h < TCO_SEGS) { ap = B[tp]; cp = B[NT + tp]; dq = make_double2(B[2 * NT + tp], B[3 * NT + tp]); }
+        const double r = 1.0 / (1.0 - pa * cm - pc * ap);
+        pd.x = (pd.x - pa * dm.x - pc * dq.x) * r;
+        pd.y = (pd.y - pa * dm.y - pc * dq.y) * r;
+        pa = -pa * am * r;
+        pc = -pc * cp * r;
+        pb ^= 1;
+    }
     // ---- D: back substitution ----
-    const double2 Xs = sD[s][cc][0];
-    const double2 Xp = (s > 0) ? sD[s - 1][cc][0] : make_double2(0.0, 0.0);
+    const double2 Xs = pd;
+    double2 Xp = make_double2(0.0, 0.0);
+    {
+        double *B = xb[pb];
+        B[2 * NT + t] = pd.x; B[3 * NT + t] = pd.y;
+        __syncthreads();
+        if (s > 0) Xp = make_double2(B[2 * NT + t - TCO_COLS], B[3 * NT + t - TCO_COLS]);
+    }
     double sum = 0.0;
 #pragma unroll
     for (int j = 0; j < TCO_M; ++j) {
@@ -278,9 +294,8 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
 
 // segments per column: 64 for 128 <= Nz <= 512 (the tuned shape), 16 / 8 for shorter columns, where the sequential kernel's
 // NXH * Ny threads of Nz dependent steps each leave the chip idle (64^3: 39 us sequential).  Every segment holds >= 2 rows.
-static int tridiag_coop_segs(const bz_ctx *ctx, int Ny)
+static int tridiag_coop_segs(const bz_ctx *ctx, int)
 {
-    const long long plane = (long long)ctx->NXH * Ny;
     const int Nz = ctx->dg.Nz;
     if (getenv("BZ_NO_TRIDIAG_COOP")) return 0;
     if (Nz >= 128 && Nz <= 64 * TCO_M) return 64;

@@ -261,8 +261,14 @@ class CompressibleAtmosphereModel:
         # (Periodic, Flat, Bounded): the 2-D x-z cases of examples/acoustic_wave.jl:51 and inertia_gravity_wave.jl:70
         if grid.topology not in ((Periodic, Periodic, Bounded), (Periodic, Flat, Bounded)):
             raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded) and (Periodic, Flat, Bounded)")
-        if grid.topology[1] == Flat and not (isinstance(advection, WENO) and advection.order == 5 and advection.bounds is None):
-            raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order=5) model is implemented")
+        if grid.topology[1] == Flat and not (isinstance(advection, WENO) and advection.bounds is None):
+            raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model is implemented")
+        if isinstance(advection, WENO) and advection.order != 5:      # examples/splitting_supercell.jl:279 uses WENO(order = 9)
+            need = (advection.order + 1) // 2
+            if min(h for h, t in zip((grid.Hx, grid.Hy, grid.Hz), grid.topology) if t != Flat) < need:
+                raise ValueError(f"WENO(order={advection.order}) needs halos of at least {need} cells in every direction")
+            if advection.bounds is not None:
+                raise NotImplementedError("bounds-preserving WENO is implemented for order 5")
         if not isinstance(dynamics, CompressibleDynamics):
             raise TypeError("dynamics must be CompressibleDynamics")
         for name, val in (("closure", closure), ("coriolis", coriolis), ("forcing", forcing)):

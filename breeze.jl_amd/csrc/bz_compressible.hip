@@ -795,6 +795,7 @@ static int launch_scalar_rho3d(bz_ctx *ctx, const char *name, double *Gc, double
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, name);
+    if (ctx->weno_R != 3) return bzi_scalar_rho3d_generic(ctx, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
     const int kc = pick_kchunk_c(g, g.Nz);
     dim3 block(64, CTY), grid((g.Nx + 63) / 64, (g.Ny + CTY - 1) / CTY, (g.Nz + kc - 1) / kc);
     hipLaunchKernelGGL(k_scalar_tendency_rho3d, grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw, kc);
@@ -878,7 +879,9 @@ extern "C" int bz_compute_slow_tendencies(bz_ctx *ctx, const bz_compressible_sta
     bz_prognostic Ga;
     Ga.rho_u = G->rho_u; Ga.rho_v = G->rho_v; Ga.rho_w = G->rho_w; Ga.rho_theta = G->rho_theta; Ga.rho_q = G->rho_q;
     int rc;
-    if (ctx->dg.flat_y) {
+    if (ctx->weno_R != 3) {      // WENO(order = 7 / 9): generic kernels (bz_tendency_generic.hip)
+        if ((rc = bzi_momentum_advection_generic(ctx, &a, &Ga))) return rc;
+    } else if (ctx->dg.flat_y) {
         if ((rc = bzi_momentum_advection_gen1(ctx, &a, &Ga))) return rc;
     } else {
         rc = bzi_u_tendency_lds(ctx, &a, &Ga);

@@ -167,7 +167,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
 #else
     // 5: the tuned path; 7, 9: generic kernels (bz_tendency_generic.hip), anelastic single-GPU contexts, halos >= (order + 1) / 2
     if (weno_order != 5 && weno_order != 7 && weno_order != 9) return BZ_ERR_UNSUPPORTED;
-    if (weno_order != 5 && (compressible || slab_mode)) return BZ_ERR_UNSUPPORTED;
+    if (weno_order != 5 && slab_mode) return BZ_ERR_UNSUPPORTED;
     const int weno_R = (weno_order + 1) / 2;
     if (grid->Hx < weno_R || (grid->topo[1] != BZ_FLAT && grid->Hy < weno_R) || grid->Hz < weno_R) return BZ_ERR_UNSUPPORTED;
 #endif
@@ -177,7 +177,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     const bool flat_y = grid->topo[1] == BZ_FLAT;
     if (grid->topo[0] != BZ_PERIODIC || (grid->topo[1] != BZ_PERIODIC && !flat_y) || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
-    if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode || weno_order != 5)) return BZ_ERR_UNSUPPORTED;
+    if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode)) return BZ_ERR_UNSUPPORTED;
     if (grid->Hx < 3 || (!flat_y && grid->Hy < 3) || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
     // Oceananigans: N >= H in every direction (k_halo_y's wrap copy would otherwise read a halo row that is not filled yet)
     if (grid->Nx < grid->Hx || grid->Ny < grid->Hy || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;
@@ -287,7 +287,9 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !getenv("BZ_NO_FUSED");
 #ifndef BZ_CENTERED2
     ctx->weno_R = weno_R;
-    if (weno_R != 3) ctx->fused_ok = false;      // the fused / lean tiers are order-5 kernels: orders 7, 9 step operator by operator
+    // the fused / lean tiers of the anelastic model are order-5 kernels: orders 7, 9 step operator by operator (the compressible
+    // sequence takes its slow tendencies from the generic kernels and is otherwise independent of the advection order)
+    if (weno_R != 3 && !compressible) ctx->fused_ok = false;
 #endif
     if (slab_mode && (Ny < grid->Hy || Nx < 2 * grid->Hx)) { delete ctx; return BZ_ERR_UNSUPPORTED; }
     if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);

@@ -408,6 +408,9 @@ int bzi_tracer_rk3(bz_ctx *ctx, double dt, double alpha, bool first);
 int bzi_tracer_store_initial_state(bz_ctx *ctx);
 int bzi_tracer_tendencies(bz_ctx *ctx, const bz_state *s);
 int bzi_momentum_advection_gen1(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_momentum_advection_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_scalar_rho3d_generic(bz_ctx *ctx, double *Gc, double *Grho, const double *rho, const double *u, const double *v, const double *w,
+                             const double *c, const double *ru, const double *rv, const double *rw);
 void bzi_closure_teardown(bz_ctx *ctx);
 int bzi_apply_closure(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gw, double *Gth, double *Gq, double scale);
 int bzi_kessler_tendencies(bz_ctx *ctx, const bz_state *s);

@@ -337,12 +337,17 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
     if (ctx->weno_R != 3) {      // WENO(order = 7 / 9): generic kernels for the five prognostic fields, then the order-independent terms
-        if (g.formulation != 0 || g.microphysics == 2 || ctx->n_tracers || ctx->bounded_mask) {
-            ctx->last_error = "WENO(order = 7 / 9) implements the potential-temperature model without Kessler species, tracers or bounds";
+        if (g.microphysics == 2 || ctx->n_tracers || ctx->bounded_mask) {
+            ctx->last_error = "WENO(order = 7 / 9) implements the model without Kessler species, tracers or bounds";
             return BZ_ERR_UNSUPPORTED;
         }
         int rcg = bzi_compute_tendencies_generic(ctx, s, G);
         if (rcg) return rcg;
+        if (g.formulation == 1) {      // StaticEnergy (examples/dry_thermal_bubble.jl:25): the buoyancy flux term has no advection scheme in it
+            ProfileScope ps(ctx, "static_energy_buoyancy_flux");
+            hipLaunchKernelGGL(k_energy_buoyancy_flux, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
+                               G->rho_theta, s->w, s->T, s->q);
+        }
         if (ctx->has_closure && (rcg = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, 1.0))) return rcg;
         if (ctx->has_forcings && (rcg = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0))) return rcg;
         return BZ_OK;

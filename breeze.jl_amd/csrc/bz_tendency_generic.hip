@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__
         const double wt = w[m];
         return g.rho_f[kf] * ((g.Az * wt) * biased_face_g(c + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz)));
     };
-    const double dx = fx(n + 1) - fx(n), dy = fy(n + sy) - fy(n), dz = fz(n + sz, k + 1) - fz(n, k);
+    const double dx = fx(n + 1) - fx(n), dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n), dz = fz(n + sz, k + 1) - fz(n, k);      // a Flat y has no faces
     Gc[n] = -(g.Vinv_c[k] * (dx + dy + dz));
 }
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_u_tendency_g(DevGrid g, double *__restr
         const double wt = symm_g(rw, m, 1, R, -(R - 1), none, 0, g.Az);
         return wt * biased_face_g(u + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz));
     };
-    const double a = FUu(n) - FUu(n - 1), b = FVu(n + sy) - FVu(n), c = FWu(n + sz, k + 1) - FWu(n, k);
+    const double a = FUu(n) - FUu(n - 1), b = g.flat_y ? 0.0 : FVu(n + sy) - FVu(n), c = FWu(n + sz, k + 1) - FWu(n, k);
     Gu[n] = -(g.Vinv_c[k] * (a + b + c));
 }
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_v_tendency_g(DevGrid g, double *__restr
     const ColPtr none(nullptr);
     const double Ax = g.Ax[k], Ay = g.Ay[k];
     auto FUv = [&](long long m) {
-        const double ut = symm_g(ru, m, sy, R, -(R - 1), none, 0, Ax);
+        const double ut = g.flat_y ? Ax * ru[m] : symm_g(ru, m, sy, R, -(R - 1), none, 0, Ax);      // Iy of a Flat direction: identity
         return ut * biased_face_g(v + m, 1, ut > 0.0, R);
     };
     auto FVv = [&](long long m) {
@@ -176,15 +176,15 @@ __global__ __launch_bounds__(256) void k_v_tendency_g(DevGrid g, double *__restr
         return vt * biased_center_g(v + m, sy, vt > 0.0, R);
     };
     auto FWv = [&](long long m, int kf) {
-        const double wt = symm_g(rw, m, sy, R, -(R - 1), none, 0, g.Az);
+        const double wt = g.flat_y ? g.Az * rw[m] : symm_g(rw, m, sy, R, -(R - 1), none, 0, g.Az);
         return wt * biased_face_g(v + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz));
     };
-    const double a = FUv(n + 1) - FUv(n), b = FVv(n) - FVv(n - sy), c = FWv(n + sz, k + 1) - FWv(n, k);
+    const double a = FUv(n + 1) - FUv(n), b = g.flat_y ? 0.0 : FVv(n) - FVv(n - sy), c = FWv(n + sz, k + 1) - FWv(n, k);
     Gv[n] = -(g.Vinv_c[k] * (a + b + c));
 }
 
-// faces k = 1 .. Nz-1 (blockIdx.z + 1); + Iz(buoyancy)
-template <int R>
+// faces k = 1 .. Nz-1 (blockIdx.z + 1); + Iz(buoyancy) unless !BUOY (slow tendency of the split-explicit compressible model)
+template <int R, bool BUOY = true>
 __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restrict__ Gw, const double *__restrict__ ru,
                                                       const double *__restrict__ rv, const double *__restrict__ rw,
                                                       const double *__restrict__ w, const double *__restrict__ T,
@@ -211,9 +211,39 @@ __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restr
         const double wt = symm_g(rw, m, sz, B, -(h - 1), none, 0, g.Az);
         return wt * biased_center_g(w + m, sz, wt > 0.0, B);
     };
-    const double a = FUw(n + 1) - FUw(n), b = FVw(n + sy) - FVw(n), c = FWw(n, k) - FWw(n - sz, k - 1);
-    const double bf = 0.5 * (bz_buoyancy(g, T, qv, n - sz, k - 1) + bz_buoyancy(g, T, qv, n, k));
-    Gw[n] = -(g.Vinv_f[k] * (a + b + c)) + bf;
+    const double a = FUw(n + 1) - FUw(n), b = g.flat_y ? 0.0 : FVw(n + sy) - FVw(n), c = FWw(n, k) - FWw(n - sz, k - 1);
+    const double adv = -(g.Vinv_f[k] * (a + b + c));
+    if (BUOY) Gw[n] = adv + 0.5 * (bz_buoyancy(g, T, qv, n - sz, k - 1) + bz_buoyancy(g, T, qv, n, k));
+    else Gw[n] = adv;
+}
+
+// scalar tendency with a 3-D carrier density, G = -div(Ix/y/z(rho) U c~) (src/Advection.jl:20-35 with the compressible model's density
+// field), and, when Grho != nullptr, the dry-density tendency -div(momentum) (compressible_density_tendency.jl:52-55)
+template <int R>
+__global__ __launch_bounds__(256) void k_scalar_tendency_rho3d_g(DevGrid g, double *__restrict__ Gc, double *__restrict__ Grho,
+                                                                 const double *__restrict__ rho, const double *__restrict__ u,
+                                                                 const double *__restrict__ v, const double *__restrict__ w,
+                                                                 const double *__restrict__ c, const double *__restrict__ ru,
+                                                                 const double *__restrict__ rv, const double *__restrict__ rw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
+    const double Ax = g.Ax[k], Ay = g.Ay[k];
+    auto fx = [&](long long m) { const double ut = u[m]; return ((rho[m] + rho[m - 1]) / 2.0) * ((Ax * ut) * biased_face_g(c + m, 1, ut > 0.0, R)); };
+    auto fy = [&](long long m) { const double vt = v[m]; return ((rho[m] + rho[m - sy]) / 2.0) * ((Ay * vt) * biased_face_g(c + m, sy, vt > 0.0, R)); };
+    auto fz = [&](long long m, int kf) {
+        const double wt = w[m];
+        return ((rho[m] + rho[m - sz]) / 2.0) * ((g.Az * wt) * biased_face_g(c + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz)));
+    };
+    const double dx = fx(n + 1) - fx(n), dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n), dz = fz(n + sz, k + 1) - fz(n, k);
+    Gc[n] = -(g.Vinv_c[k] * (dx + dy + dz));
+    if (Grho) {
+        const double a = Ax * ru[n + 1] - Ax * ru[n];
+        const double b = g.flat_y ? 0.0 : Ay * rv[n + sy] - Ay * rv[n];
+        const double cc = g.Az * rw[n + sz] - g.Az * rw[n];
+        Grho[n] = -(g.Vinv_c[k] * (a + b + cc));
+    }
 }
 
 template <int R>
@@ -241,6 +271,49 @@ static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G
         ProfileScope ps(ctx, "moisture_tendency");
         hipLaunchKernelGGL((k_scalar_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q);
     }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// compressible split-explicit model with WENO(order = 7 / 9) (examples/splitting_supercell.jl:279): slow momentum tendencies =
+// advection alone, scalars with the 3-D carrier density
+template <int R>
+static int launch_generic_momentum_advection(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    const DevGrid &g = ctx->dg;
+    const dim3 block(256), grid((g.Nx + 255) / 256, g.Ny, g.Nz), gridw((g.Nx + 255) / 256, g.Ny, g.Nz - 1);
+    {
+        ProfileScope ps(ctx, "x_momentum_tendency");
+        hipLaunchKernelGGL((k_u_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u);
+    }
+    {
+        ProfileScope ps(ctx, "y_momentum_tendency");
+        hipLaunchKernelGGL((k_v_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v);
+    }
+    if (g.Nz > 1) {
+        ProfileScope ps(ctx, "z_momentum_tendency");
+        hipLaunchKernelGGL((k_w_tendency_g<R, false>), gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
+                           (const double *)nullptr, (const double *)nullptr);
+    }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+int bzi_momentum_advection_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    if (ctx->weno_R == 5) return launch_generic_momentum_advection<5>(ctx, s, G);
+    if (ctx->weno_R == 4) return launch_generic_momentum_advection<4>(ctx, s, G);
+    return BZ_ERR_INVALID;
+}
+
+int bzi_scalar_rho3d_generic(bz_ctx *ctx, double *Gc, double *Grho, const double *rho, const double *u, const double *v, const double *w,
+                             const double *c, const double *ru, const double *rv, const double *rw)
+{
+    const DevGrid &g = ctx->dg;
+    const dim3 block(256), grid((g.Nx + 255) / 256, g.Ny, g.Nz);
+    if (ctx->weno_R == 5) hipLaunchKernelGGL((k_scalar_tendency_rho3d_g<5>), grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
+    else if (ctx->weno_R == 4) hipLaunchKernelGGL((k_scalar_tendency_rho3d_g<4>), grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
+    else return BZ_ERR_INVALID;
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -171,9 +171,10 @@ class AtmosphereModel:
         if grid.topology != (Periodic, Periodic, Bounded) and not flat_y:
             raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded) and (Periodic, Flat, Bounded)")
         if flat_y and (closure is not None or coriolis is not None or forcing is not None or boundary_conditions is not None or
-                       grid.ftype != 8 or (advection is not None and getattr(advection, "order", 5) != 5)):
-            # the reference's 2-D x-z cases (README.md:67-75): the per-operator WENO-5 kernels drop the y terms
-            raise NotImplementedError("(Periodic, Flat, Bounded): the Float64 WENO(order=5) model without closure / forcings is implemented")
+                       grid.ftype != 8 or (advection is not None and getattr(advection, "order", 5) not in (5, 7, 9))):
+            # the reference's 2-D x-z cases (README.md:67-75, examples/dry_thermal_bubble.jl with WENO(order = 9)): the per-operator
+            # kernels drop the y terms
+            raise NotImplementedError("(Periodic, Flat, Bounded): the Float64 WENO(order = 5 | 7 | 9) model without closure / forcings is implemented")
         formulation = str(formulation).lstrip(":")
         if formulation not in ("LiquidIcePotentialTemperature", "StaticEnergy"):
             raise NotImplementedError(f"formulation {formulation!r} is not implemented")
@@ -209,13 +210,12 @@ class AtmosphereModel:
         self.advection = advection
         if isinstance(advection, WENO) and advection.order != 5:
             need = (advection.order + 1) // 2
-            if min(grid.Hx, grid.Hy, grid.Hz) < need:
+            if min(h for h, t in zip((grid.Hx, grid.Hy, grid.Hz), grid.topology) if t != Flat) < need:
                 raise ValueError(f"WENO(order={advection.order}) needs halos of at least {need} cells in every direction "
                                  f"(got {(grid.Hx, grid.Hy, grid.Hz)}): RectilinearGrid(..., halo=({need}, {need}, {need}))")
-            if self._kessler or tracers or formulation != "LiquidIcePotentialTemperature" or self._bounded_advection is not None or \
-                    grid.ftype != 8:
-                raise NotImplementedError(f"WENO(order={advection.order}) is implemented for the Float64 potential-temperature model "
-                                          "(optionally with saturation adjustment, closure and forcings)")
+            if self._kessler or tracers or self._bounded_advection is not None or grid.ftype != 8:
+                raise NotImplementedError(f"WENO(order={advection.order}) is implemented for the Float64 model without Kessler species, "
+                                          "tracers or bounds (optionally with saturation adjustment, closure and forcings)")
         self.thermodynamic_constants = c = thermodynamic_constants or ThermodynamicConstants()
         if dynamics is None:
             dynamics = AnelasticDynamics(ReferenceState(grid, c))      # default_dynamics

@@ -365,4 +365,8 @@ function compressible_update_state!(model, ctx; compute_tendencies = true)
     return nothing
 end
 
+# hipGraph replay of whole steps (csrc/bz_graph.hip): opt-in, pays with a fixed Δt on launch-bound grids; Oceananigans fields keep
+# their device arrays for the life of the model, which is what a recorded step relies on
+graph_replay!(ctx, on::Bool = true) = check(ccall((:bz_graph_enable, libbreeze_hip), Cint, (Ptr{Cvoid}, Cint), ctx, on), "bz_graph_enable", ctx)
+
 end # module

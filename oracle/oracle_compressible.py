@@ -178,7 +178,13 @@ class CompressibleOracleModel:
                                         vapor_mass_fraction=reference_vapor_mass_fraction)
                     if reference_state else None)
         self.newton = (float(newton_abstol), int(newton_maxiter))
-        self.lib = lib(advection)
+        # advection "WENO7" / "WENO9" (examples/splitting_supercell.jl:279): the order is a process-wide switch of the C library, selected
+        # around every tendency evaluation and put back to 5 afterwards (oracle.py does the same)
+        self.weno_order = {"WENO5": 5, "WENO7": 7, "WENO9": 9}.get(advection, 5)
+        if self.weno_order != 5:
+            need = (self.weno_order + 1) // 2
+            assert min(h for h, t in zip((g.Hx, g.Hy, g.Hz), g.topo) if t != FLAT) >= need, "halo too narrow for this WENO order"
+        self.lib = lib("WENO5" if self.weno_order != 5 else advection)
         zeros = np.zeros(g.Szc)
         self._zc = zeros
         self.cg = _OGGrid(g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz, g.topo[0], g.topo[1], g.topo[2],
@@ -315,11 +321,12 @@ class CompressibleOracleModel:
             # (update_atmosphere_model_state.jl:330-343, acoustic_runge_kutta_3.jl:352-358);
             # the momentum / theta / rho_d tendencies computed here by the reference are overwritten
             # by compute_slow_*_tendencies! before they are used.
-            L.og_set_weno_order(C.c_int(5))
+            L.og_set_weno_order(C.c_int(self.weno_order))
             L.og_scalar_tendency_3d(cg, _p(self.G["rq"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.q))
             if kes:
                 L.og_scalar_tendency_3d(cg, _p(self.G["rqcl"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qcl))
                 L.og_scalar_tendency_3d(cg, _p(self.G["rqr"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qr))
+            L.og_set_weno_order(C.c_int(5))
 
     def _sa_thermo(self):
         """maybe_adjust_thermodynamic_state on the LiquidIceDensityState of every cell (theta = rho theta / rho_d, q^t = rho q / rho,
@@ -398,12 +405,13 @@ class CompressibleOracleModel:
 
     def compute_slow_tendencies(self):
         cg, L, G = C.byref(self.cg), self.lib, self.G
-        L.og_set_weno_order(C.c_int(5))           # the order is a process-wide switch of the C library (oracle.py): this path is WENO-5
+        L.og_set_weno_order(C.c_int(self.weno_order))           # process-wide switch of the C library (oracle.py)
         L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
         L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
         L.og_w_tendency_slow(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w))
         L.og_density_tendency(cg, _p(G["rho_d"]), _p(self.ru), _p(self.rv), _p(self.rw))
         L.og_scalar_tendency_3d(cg, _p(G["rtheta"]), _p(self.rho_d), _p(self.u), _p(self.v), _p(self.w), _p(self.theta))
+        L.og_set_weno_order(C.c_int(5))
 
     def assemble_slow_vertical_momentum(self):
         pr = _p(self.ref.pressure) if self.ref is not None else None

@@ -194,3 +194,33 @@ def test_compressible_inertia_gravity_wave_steps_match_oracle(oracle, bz):
     assert np.abs(g.interior(om.rw, True)).max() > 1e-6
     tc.cmp_interior(om, hm, ("rho_d", "rtheta", "ru", "rw", "u", "w", "theta", "T", "p"), 5e-9)
     assert np.abs(hm.momentum["ρv"].interior_cpu()).max() == 0.0
+
+
+def test_dry_thermal_bubble_example_configuration_matches_oracle(oracle, bz):
+    """examples/dry_thermal_bubble.jl:15-25 as written, at reduced resolution: (Periodic, Flat, Bounded) with halo (5, 5),
+    formulation = :StaticEnergy, advection = WENO(order = 9), the 10 K bubble on a weakly stratified background."""
+    size, ext = (64, 48), dict(x=(-10e3, 10e3), z=(0.0, 10e3))
+    og = oracle.Grid(size, topology=("Periodic", "Flat", "Bounded"), halo=(5, 5), **ext)
+    om = oracle.OracleModel(og, surface_pressure=101325.0, potential_temperature=288.0, formulation="StaticEnergy", advection="WENO9")
+    grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Flat, bz.Bounded), halo=(5, 5), **ext)
+    ref = bz.ReferenceState(grid, surface_pressure=101325.0, potential_temperature=288.0)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), formulation=":StaticEnergy", advection=bz.WENO(order=9))
+
+    def thi(x, z):      # :36-48: theta_0 exp(N^2 z / g) + 10 K cos^2 bubble of radius 2 km at 0.3 Lz
+        r = np.sqrt(x ** 2 + (z - 3000.0) ** 2)
+        return 288.0 * np.exp(1e-6 * z / 9.80665) + 10.0 * np.where(r < 2000.0, np.cos(np.pi / 2 * r / 2000.0) ** 2, 0.0)
+
+    om.set(theta=lambda x, y, z: thi(x, z) + 0 * y)
+    hm.set(θ=thi)
+    for _ in range(3):
+        om.time_step(1.0)
+        hm.time_step(1.0)
+    hm.synchronize()
+    g = om.grid
+    assert np.abs(g.interior(om.rw, True)).max() > 1e-2
+    for n, k in PROG.items():
+        got = hm.prognostic_fields()[k].interior_cpu()
+        want = g.interior(getattr(om, n), zface=(n == "rw"))
+        scale = max(np.max(np.abs(want)), 1e-3)
+        assert np.max(np.abs(got - want)) / scale < 2e-8, (n, np.max(np.abs(got - want)) / scale)      # the WENO-9 tolerance of tests/test_weno_orders.py
+    assert np.abs(hm.momentum["ρv"].interior_cpu()).max() == 0.0

@@ -141,3 +141,68 @@ def test_order_nine_needs_wide_halos(bz):
     with pytest.raises(ValueError, match="halos"):
         bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)),
                            advection=bz.WENO(order=9))
+
+
+# ---- compressible split-explicit model with WENO(order = 7 / 9): examples/splitting_supercell.jl:279 --------------------------------
+
+def _cpair(oracle, bz, size, order, kessler=False):
+    from oracle import oracle_compressible as oc
+    ext = dict(x=(0.0, 16e3), y=(0.0, 12e3), z=(0.0, 8e3))
+    thb = lambda z: 300.0 + 0.0035 * z
+    qvb = (lambda z: float(0.013 * np.exp(-z / 2800.0))) if kessler else None
+    og = oracle.Grid(size, halo=(5, 5, 5), **ext)
+    om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), surface_pressure=1e5,
+                                    reference_potential_temperature=thb, reference_vapor_mass_fraction=qvb,
+                                    microphysics="Kessler" if kessler else None, advection=f"WENO{order}")
+    grid = bz.RectilinearGrid(size, halo=(5, 5, 5), **ext)
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), surface_pressure=1e5,
+                                  reference_potential_temperature=thb, reference_vapor_mass_fraction=qvb)
+    kw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
+              microphysics=bz.DCMIP2016KesslerMicrophysics()) if kessler else {}
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=order), **kw)
+    return om, hm, thb, qvb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [7, 9])
+def test_compressible_slow_tendencies_match_oracle(oracle, bz, order):
+    import test_gpu_compressible as tc
+    om, hm, _, _ = _cpair(oracle, bz, (24, 16, 14), order)
+    tc.seeded_state(om, 3)
+    om.compute_slow_tendencies()
+    tc.push(om, hm)
+    for k in hm.G:
+        if k != "ρq":
+            hm.G[k].parent.zero_()
+    bz.compressible.compute_slow_tendencies_(hm)
+    g = om.grid
+    for n, k in tc.PROG.items():
+        if n == "rq":
+            continue
+        a, b = hm.G[k].interior_cpu(), g.interior(om.G[n], n == "rw")
+        if n == "rw":
+            a, b = a[1:-1], b[1:-1]
+        assert tc.rel(a, b) <= 1e-11, (n, tc.rel(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [7, 9])
+def test_compressible_kessler_steps_match_oracle(oracle, bz, order):
+    """the supercell example's scheme list at test size: split-explicit compressible dynamics + DCMIP2016 Kessler + WENO(order = 9)"""
+    import test_gpu_compressible as tc
+    size = (24, 16, 20)
+    om, hm, thb, qvb = _cpair(oracle, bz, size, order, kessler=True)
+    og = om.grid
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt(((x - 8e3) / 4e3) ** 2 + ((y - 6e3) / 4e3) ** 2 + ((z - 1500.0) / 1500.0) ** 2))
+    th = lambda x, y, z: thb(z) + 2.0 * bub(x, y, z)
+    qv = lambda x, y, z: np.vectorize(qvb)(z) + 0.003 * bub(x, y, z) + 0 * x + 0 * y
+    rho_ref = om.ref.density[og.Hz:og.Hz + og.Nz][:, None, None]
+    x, y, z = og.nodes("ccc")
+    rho = rho_ref * thb(z) / th(x, y, z)
+    om.set(rho=rho, theta=th, u=5.0, v=0.0, w=0.0, qv=qv)
+    hm.set(ρ=rho, θ=th, u=5.0, v=0.0, w=0.0, qᵗ=qv)
+    for _ in range(2):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    tc.cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rw", "T", "p"), 2e-8)
+    assert np.abs(og.interior(om.rw, True)).max() > 1e-3

@@ -32,8 +32,8 @@ class Centered:
 
 class WENO:
     """WENO(order=5; bounds=nothing).  order = 5 is the tuned path; orders 7 and 9 (the examples' choice) run through generic
-    kernels (csrc/bz_tendency_generic.hip) on single-GPU anelastic potential-temperature models whose grid carries halos of at
-    least (order + 1) / 2 cells, as Oceananigans requires.  `bounds = (lo, hi)` (order 5) makes it the
+    kernels (csrc/bz_tendency_generic.hip) on single-GPU anelastic models (θ or StaticEnergy, 2-D Flat grids too) and on compressible
+    models (single GPU or y-slabs, with Kessler) whose grid carries halos of at least (order + 1) / 2 cells, as Oceananigans requires.  `bounds = (lo, hi)` (order 5) makes it the
     bounds-preserving scheme (Oceananigans' BoundsPreservingWENO) that the reference's moist examples give their moisture
     densities (examples/rico.jl:184-190, examples/tropical_cyclone_world.jl:169); it is a per-scalar scheme:
     `advection = {"momentum": WENO(), "ρθ": WENO(), "ρqᵉ": WENO(bounds=(0, 1))}`."""

@@ -191,7 +191,10 @@ def config4_run(args, bz, rank, world, dist, device, fail):
     (rho theta)' and (rho v)', per-stage exchange of the rest).  A second milestone: never the headline `value` of the default run."""
     import torch
     Nx, Ny, Nz, dt = 512, 512, 128, 2.0
-    G = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 168e3), y=(0.0, 168e3), z=(0.0, 20e3))
+    f32 = bool(getattr(args, "config4_float32", False))      # the example's own precision (splitting_supercell.jl:86), single GPU
+    if f32 and (world > 1 or args.slab):
+        fail("--config4-float32 runs on one GPU (the Float32 twin's slab path has no test)")
+    G = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 168e3), y=(0.0, 168e3), z=(0.0, 20e3), **({"float_type": np.float32} if f32 else {}))
     dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), surface_pressure=1e5, reference_potential_temperature=300.0)
     mkw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
                microphysics=bz.DCMIP2016KesslerMicrophysics())
@@ -242,9 +245,10 @@ def config4_run(args, bz, rank, world, dist, device, fail):
         out = {"metric": "grid-cells advanced/sec (compressible split-explicit + Kessler step), 512x512x128",
                "value": Nx * Ny * Nz * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps,
                "warmup": max(1, args.warmup), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[4]: splitting-supercell shape 512x512x128, CompressibleDynamics + "
-                                      "SplitExplicitTimeDiscretization defaults + DCMIP2016 Kessler, WENO5, dt=2s",
+                                      "SplitExplicitTimeDiscretization defaults + DCMIP2016 Kessler, WENO5, dt=2s" +
+                                      (", Float32 (libbreeze_hip_f32.so)" if f32 else ""),
                           "grid": [Nx, Ny, Nz], "dt": dt, "substeps_per_stage": nsub,
                           "parallelism": "single GPU" if not slabs else
                           f"{world} y-slabs of {Nx}x{Ny // world}x{Nz}, halo exchanges over " +
@@ -643,6 +647,7 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-float32", action="store_true", help="skip the Float32 run reported under `float32`")
+    ap.add_argument("--config4-float32", action="store_true", help="--workload config4 in Float32, the example's own precision (one GPU)")
     ap.add_argument("--no-compressible", action="store_true",
                     help="skip the short compressible split-explicit measurement reported under `second_milestone`")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks are killed after this many seconds")

@@ -297,7 +297,13 @@ class CompressibleAtmosphereModel:
         self.clock = Clock()
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self._lib = lib = _lib.load(advection.order)
+        self._T = T = _lib.types(grid.ftype)
+        if grid.ftype == 4:      # eltype(grid) = Float32 (examples/splitting_supercell.jl:86): the Float32 twin of the library
+            if getattr(advection, "order", None) != 5:
+                raise NotImplementedError("Float32 grids: the WENO(order=5) build of the library is wired up")
+            self._lib = lib = _lib.load_f32()
+        else:
+            self._lib = lib = _lib.load(advection.order)
 
         def fld(loc):
             return Field(grid, _LOC[loc], self.device)
@@ -311,7 +317,7 @@ class CompressibleAtmosphereModel:
         if self._kessler:      # materialize_microphysical_fields(::DCMIP2016KM) (dcmip2016_kessler.jl:255-290)
             self.microphysical_fields = {k: fld("ccc") for k in ("ρqᶜˡ", "ρqʳ", "qᵛ", "qᶜˡ", "qʳ", "𝕎ʳ")}
             self.microphysical_fields["precipitation_rate"] = torch.zeros((grid.Ny + 2 * grid.Hy, grid.Nx + 2 * grid.Hx),
-                                                                          dtype=torch.float64, device=self.device)
+                                                                          dtype=self.potential_temperature.dtype, device=self.device)
         if dynamics._reference_spec is not None:
             dynamics.reference_state = ExnerReferenceState(grid, c, surface_pressure=dynamics.surface_pressure,
                                                            potential_temperature=dynamics._reference_spec,
@@ -321,27 +327,27 @@ class CompressibleAtmosphereModel:
         self.U0, self.G = self.timestepper.U0, self.timestepper.Gn
 
         # ---- context ----
-        self._zf = np.ascontiguousarray(grid.zᶠ, dtype=np.float64)
-        bg = _lib.bz_grid()
+        self._zf = np.ascontiguousarray(grid.zᶠ, dtype=T.np_real)
+        bg = T.bz_grid()
         bg.Nx, bg.Ny, bg.Nz = grid.Nx, grid.Ny, grid.Nz
         bg.Hx, bg.Hy, bg.Hz = grid.Hx, grid.Hy, grid.Hz
         for d, t in enumerate(grid.topology_codes()):
             bg.topo[d] = t
-        bg.ftype = 8
+        bg.ftype = grid.ftype
         bg.dx, bg.dy = grid.Δx, grid.Δy
-        bg.zf = self._zf.ctypes.data_as(C.POINTER(C.c_double))
+        bg.zf = self._zf.ctypes.data_as(C.POINTER(T.real))
         bg.regular_z = 1 if grid.regular_z else 0
-        bc = _lib.bz_constants(c.gravitational_acceleration, dry_air_gas_constant(c), vapor_gas_constant(c),
+        bc = T.bz_constants(c.gravitational_acceleration, dry_air_gas_constant(c), vapor_gas_constant(c),
                                c.dry_air_heat_capacity, c.vapor_heat_capacity)
         ref = dynamics.reference_state
-        br = _lib.bz_exner_reference_state()
+        br = T.bz_exner_reference_state()
         br.standard_pressure = dynamics.standard_pressure
         self._ref_arrays = None
         if ref is not None:
-            self._ref_arrays = [np.ascontiguousarray(a, dtype=np.float64) for a in (ref.pressure, ref.density)]
-            br.pressure, br.density = (a.ctypes.data_as(C.POINTER(C.c_double)) for a in self._ref_arrays)
+            self._ref_arrays = [np.ascontiguousarray(a, dtype=T.np_real) for a in (ref.pressure, ref.density)]
+            br.pressure, br.density = (a.ctypes.data_as(C.POINTER(T.real)) for a in self._ref_arrays)
         td = dynamics.time_discretization
-        bt = _lib.bz_split_explicit()
+        bt = T.bz_split_explicit()
         bt.substeps = 0 if td.substeps is None else td.substeps
         damp = td.damping
         bt.damp_vertical = int(isinstance(damp, ThermalDivergenceDamping) and damp.damp_vertical)
@@ -366,7 +372,7 @@ class CompressibleAtmosphereModel:
         if self._sa:      # materialize_microphysical_fields(::WarmPhaseSaturationAdjustment): (q^v, q^l, q^e); q^e is the moisture slot
             self.microphysical_fields = {"qᵛ": Field(grid, _LOC["ccc"], self.device), "qˡ": Field(grid, _LOC["ccc"], self.device),
                                          "qᵉ": self.specific_moisture}
-            sa = _lib.bz_saturation_adjustment(c.liquid_reference_latent_heat, c.liquid_heat_capacity,
+            sa = T.bz_saturation_adjustment(c.liquid_reference_latent_heat, c.liquid_heat_capacity,
                                                c.energy_reference_temperature, c.triple_point_temperature,
                                                c.triple_point_pressure, microphysics.solver.abstol,
                                                microphysics.solver.maxiter, 0)
@@ -377,8 +383,8 @@ class CompressibleAtmosphereModel:
         if self._kessler:
             from .microphysics import kessler_parameter_struct
             μ = self.microphysical_fields
-            P = kessler_parameter_struct(microphysics, c)
-            K = _lib.bz_kessler_model_fields()
+            P = kessler_parameter_struct(microphysics, c, ftype=grid.ftype)
+            K = T.bz_kessler_model_fields()
             K.cloud_liquid_density, K.rain_density = μ["ρqᶜˡ"].ptr(), μ["ρqʳ"].ptr()
             K.U0_cloud_liquid_density, K.U0_rain_density = self.U0["ρqᶜˡ"].ptr(), self.U0["ρqʳ"].ptr()
             K.G_cloud_liquid_density, K.G_rain_density = self.G["ρqᶜˡ"].ptr(), self.G["ρqʳ"].ptr()
@@ -461,13 +467,13 @@ class CompressibleAtmosphereModel:
     def profile(self):
         out = {}
         for i in range(self._lib.bz_profile_count(self._ctx)):
-            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            name, ms, n = C.c_char_p(), self._T.real(), C.c_int64()
             self._check(self._lib.bz_profile_get(self._ctx, i, C.byref(name), C.byref(ms), C.byref(n)), "bz_profile_get")
             out[name.value.decode()] = (ms.value, n.value)
         return out
 
     def stage_substeps(self, Δt, β):
-        n, dτ = C.c_int32(), C.c_double()
+        n, dτ = C.c_int32(), self._T.real()
         self._check(self._lib.bz_stage_substeps(self._ctx, float(Δt), float(β), C.byref(n), C.byref(dτ)), "bz_stage_substeps")
         return n.value, dτ.value
 

@@ -74,11 +74,11 @@ class KesslerMicrophysicalFields:
         self.precipitation_rate = torch.zeros((g.Ny + 2 * g.Hy, g.Nx + 2 * g.Hx), dtype=torch.float64, device=model.device)
 
 
-def kessler_parameter_struct(microphysics, constants, tetens=None):
+def kessler_parameter_struct(microphysics, constants, tetens=None, ftype=8):
     """bz_kessler_microphysics from DCMIP2016KesslerMicrophysics + the TetensFormula / liquid phase of the constants."""
     from . import _lib
     tf = tetens or getattr(constants, "saturation_vapor_pressure", None) or TetensFormula()
-    P = _lib.bz_kessler_microphysics()
+    P = _lib.types(ftype).bz_kessler_microphysics()
     for k in DCMIP2016KesslerMicrophysics.DEFAULTS:
         setattr(P, k, getattr(microphysics, k))
     P.tetens_reference_saturation_vapor_pressure = tf.reference_saturation_vapor_pressure

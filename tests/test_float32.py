@@ -127,3 +127,51 @@ def test_float32_bomex_physics_steps_match_the_float64_oracle(oracle, bz):
     assert relerr(hm.temperature.interior_cpu().astype(np.float64), g.interior(om.T)) < 1e-5
     ql = hm.microphysical_fields["qˡ"].interior_cpu().astype(np.float64)
     assert abs(ql.mean() - g.interior(om.ql).mean()) < 1e-3 * max(g.interior(om.ql).mean(), 1e-8) + 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kessler", [False, True])
+def test_float32_compressible_steps_match_the_float64_oracle(oracle, bz, kessler):
+    """The precision of examples/splitting_supercell.jl:86 (Oceananigans.defaults.FloatType = Float32) on the split-explicit compressible
+    model, dry and with the DCMIP2016 Kessler physics: two steps against the Float64 oracle at Appendix C's 1e-4 (density-like
+    fields, whose perturbations are what Float32 resolves worst, relative to their own scale; momentum relative to the momentum scale)."""
+    import torch
+    from oracle import oracle_compressible as oc
+    size, extent = (24, 16, 20), dict(x=(0.0, 16e3), y=(0.0, 12e3), z=(0.0, 8e3))
+    thb = lambda z: 300.0 + 0.0035 * z
+    qvb = lambda z: float(0.013 * np.exp(-z / 2800.0))
+    og = oracle.Grid(size, **extent)
+    om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), surface_pressure=1e5,
+                                    reference_potential_temperature=thb, reference_vapor_mass_fraction=qvb,
+                                    microphysics="Kessler" if kessler else None)
+    grid = bz.RectilinearGrid(size, float_type=np.float32, **extent)
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), surface_pressure=1e5,
+                                  reference_potential_temperature=thb, reference_vapor_mass_fraction=qvb)
+    kw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
+              microphysics=bz.DCMIP2016KesslerMicrophysics()) if kessler else {}
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), **kw)
+    assert hm.momentum["ρu"].parent.dtype == torch.float32
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt(((x - 8e3) / 4e3) ** 2 + ((y - 6e3) / 4e3) ** 2 + ((z - 1500.0) / 1500.0) ** 2))
+    th = lambda x, y, z: thb(z) + 2.0 * bub(x, y, z)
+    qv = lambda x, y, z: np.vectorize(qvb)(z) + 0.003 * bub(x, y, z) + 0 * x + 0 * y
+    rho_ref = om.ref.density[og.Hz:og.Hz + og.Nz][:, None, None]
+    x, y, z = og.nodes("ccc")
+    rho = rho_ref * thb(z) / th(x, y, z)
+    om.set(rho=rho, theta=th, u=5.0, v=0.0, w=0.0, qv=qv)
+    hm.set(ρ=rho, θ=th, u=5.0, v=0.0, w=0.0, qᵗ=qv)
+    for _ in range(2):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    I = og.interior
+    mom = max(np.abs(I(om.ru)).max(), np.abs(I(om.rw, True)).max())
+    got = {"rho_d": hm.dynamics.dry_density, "rtheta": hm.potential_temperature_density, "rq": hm.moisture_density, "T": hm.temperature,
+           "p": hm.dynamics.pressure, "ru": hm.momentum["ρu"], "rw": hm.momentum["ρw"]}
+    worst = {}
+    for n, f in got.items():
+        want = I(getattr(om, n), n == "rw")
+        scale = mom if n in ("ru", "rw") else np.abs(want).max()
+        worst[n] = np.abs(f.interior_cpu().astype(np.float64) - want).max() / scale
+    print("float32 compressible vs float64 oracle:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert np.abs(I(om.rw, True)).max() > 1e-3
+    assert max(worst.values()) < 1e-4, worst

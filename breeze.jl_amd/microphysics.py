@@ -101,7 +101,7 @@ def microphysics_model_update_(microphysics, model, fields=None, Δt=None, teten
         model._check(model._lib.bz_kessler_model_update(model._ctx, C.byref(model._state), C.byref(model._G), float(Δt)),
                      "bz_kessler_model_update")
         return
-    P = kessler_parameter_struct(microphysics, model.thermodynamic_constants, tetens)
+    P = kessler_parameter_struct(microphysics, model.thermodynamic_constants, tetens, ftype=getattr(model.grid, "ftype", 8))
     F = _lib.bz_kessler_fields()
     F.density = density.ptr() if density is not None else None
     F.pressure = pressure.ptr() if pressure is not None else None

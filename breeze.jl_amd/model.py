@@ -225,12 +225,9 @@ class AtmosphereModel:
         torch.cuda.set_device(self.device)
         self._T = T = _lib.types(grid.ftype)
         if grid.ftype == 4:
-            from .microphysics import DCMIP2016KesslerMicrophysics as _Kessler
-            if advection.order != 5 or isinstance(microphysics, _Kessler) or tracers or formulation != "LiquidIcePotentialTemperature" or \
-                    self._bounded_advection is not None:
-                raise NotImplementedError("Float32 grids: the anelastic WENO(order=5) potential-temperature model with saturation "
-                                          "adjustment, SmagorinskyLilly, column forcings and bottom fluxes is wired up on the host side "
-                                          "(the Float32 library itself is the whole ABI)")
+            if advection.order != 5 or self._bounded_advection is not None:
+                raise NotImplementedError("Float32 grids: the WENO(order=5) build of the Float32 library, without bounds-preserving "
+                                          "advection, is wired up on the host side")
             self._lib = lib = _lib.load_f32()
         else:
             self._lib = lib = _lib.load(advection.order)
@@ -294,7 +291,7 @@ class AtmosphereModel:
         if self._kessler:
             from .microphysics import kessler_parameter_struct
             μ = self.microphysical_fields
-            P = kessler_parameter_struct(microphysics, c)
+            P = kessler_parameter_struct(microphysics, c, ftype=grid.ftype)
             K = _lib.bz_kessler_model_fields()
             K.cloud_liquid_density, K.rain_density = μ["ρqᶜˡ"].ptr(), μ["ρqʳ"].ptr()
             K.U0_cloud_liquid_density, K.U0_rain_density = self.U0["ρqᶜˡ"].ptr(), self.U0["ρqʳ"].ptr()
@@ -324,7 +321,7 @@ class AtmosphereModel:
             ba = self._bounded_advection
             if ba["tracers"] and ba["tracers"] != 0 and len(self.tracers) == 0:
                 raise ValueError("bounds-preserving tracer advection without tracers")
-            bs = _lib.bz_bounds_preserving_advection(ba["lower"], ba["upper"], ba["moisture"], ba["microphysical_species"], ba["tracers"], 0)
+            bs = T.bz_bounds_preserving_advection(ba["lower"], ba["upper"], ba["moisture"], ba["microphysical_species"], ba["tracers"], 0)
             self._check(lib.bz_set_bounds_preserving_advection(self._ctx, C.byref(bs)), "bz_set_bounds_preserving_advection")
         if closure is not None:      # build_closure_fields: nu_e (atmosphere_model.jl:276)
             if self._kessler or formulation != "LiquidIcePotentialTemperature":

@@ -175,3 +175,68 @@ def test_float32_compressible_steps_match_the_float64_oracle(oracle, bz, kessler
     print("float32 compressible vs float64 oracle:", {k: f"{v:.1e}" for k, v in worst.items()})
     assert np.abs(I(om.rw, True)).max() > 1e-3
     assert max(worst.values()) < 1e-4, worst
+
+
+def _steps_errors(om, hm, names):
+    g = om.grid
+    mom = max(np.abs(g.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rv", "rw"))
+    out = {}
+    for n, f in names:
+        want = g.interior(getattr(om, n), n == "rw")
+        scale = mom if n in ("ru", "rv", "rw") else max(np.abs(want).max(), 1e-6)
+        out[n] = float(np.abs(f.interior_cpu().astype(np.float64) - want).max() / scale)
+    return out
+
+
+@pytest.mark.gpu
+def test_float32_anelastic_kessler_tracers_and_static_energy(oracle, bz):
+    """The remaining model options on Float32 grids — DCMIP2016 Kessler species, user tracers, formulation = :StaticEnergy — two / three
+    steps each against the Float64 oracle at Appendix C's 1e-4 of each field's scale."""
+    # Kessler
+    size, extent = (16, 12, 20), ((0.0, 4e3), (0.0, 3e3), (0.0, 5e3))
+    og = oracle.Grid(size, x=extent[0], y=extent[1], z=extent[2])
+    om = oracle.OracleModel(og, surface_pressure=1e5, potential_temperature=300.0, microphysics="Kessler")
+    grid = bz.RectilinearGrid(size, x=extent[0], y=extent[1], z=extent[2], float_type=np.float32)
+    tc = bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula())
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, tc, surface_pressure=1e5, potential_temperature=300.0)),
+                            advection=bz.WENO(order=5), thermodynamic_constants=tc, microphysics=bz.DCMIP2016KesslerMicrophysics())
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt((x - 2e3) ** 2 + (y - 1.5e3) ** 2 + (z - 1500.0) ** 2) / 1200.0)
+    ic = dict(qt=lambda x, y, z: 0.016 * np.exp(-z / 3000.0) + 0.004 * bub(x, y, z), theta=lambda x, y, z: 300.0 + 0.004 * z + 1.0 * bub(x, y, z),
+              qcl=lambda x, y, z: 0.003 * bub(x, y, z), qr=lambda x, y, z: 0.001 * bub(x, y, z), u=2.0)
+    om.set(**ic)
+    hm.set(qᵗ=ic["qt"], θ=ic["theta"], qcl=ic["qcl"], qr=ic["qr"], u=ic["u"])
+    for _ in range(2):
+        om.time_step(5.0)
+        hm.time_step(5.0)
+    hm.synchronize()
+    μ = hm.microphysical_fields
+    e = _steps_errors(om, hm, (("ru", hm.momentum["ρu"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density),
+                               ("rq", hm.moisture_density), ("rqcl", μ["ρqᶜˡ"]), ("rqr", μ["ρqʳ"]), ("T", hm.temperature)))
+    print("float32 anelastic Kessler:", {k: f"{v:.1e}" for k, v in e.items()})
+    assert max(e.values()) < 2e-4, e
+    # tracers + StaticEnergy on the dry bubble
+    og = oracle.Grid((32, 20, 16), x=EXT[0], y=EXT[1], z=EXT[2])
+    for formulation in ("LiquidIcePotentialTemperature", "StaticEnergy"):
+        tr = formulation == "LiquidIcePotentialTemperature"
+        om = oracle.OracleModel(og, potential_temperature=300.0, formulation=formulation, tracers=1 if tr else 0)
+        grid = bz.RectilinearGrid((32, 20, 16), x=EXT[0], y=EXT[1], z=EXT[2], float_type=np.float32)
+        hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO(),
+                                formulation=formulation, tracers=("a",) if tr else ())
+        th = bubble_theta(300.0, om.constants.g)
+        a = lambda x, y, z: 1.0 + 0.5 * np.cos(2 * np.pi * y / 20e3) * (z / 10e3) + 0 * x
+        if tr:
+            om.set(theta=th, u=3.0, v=-2.0, rc0=a)
+            hm.tracers["a"].set_interior(a)
+        else:
+            om.set(theta=th, u=3.0, v=-2.0)
+        hm.set(θ=th, u=3.0, v=-2.0)
+        for _ in range(3):
+            om.time_step(2.0)
+            hm.time_step(2.0)
+        hm.synchronize()
+        names = [(n, hm.prognostic_fields()[k]) for n, k in PROG.items() if n != "rq"]
+        if tr:
+            names.append(("rc0", hm.tracers["a"]))
+        e = _steps_errors(om, hm, names)
+        print("float32", formulation, {k: f"{v:.1e}" for k, v in e.items()})
+        assert max(e.values()) < 1e-4, (formulation, e)

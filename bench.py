@@ -194,7 +194,11 @@ def config4_run(args, bz, rank, world, dist, device, fail):
     f32 = bool(getattr(args, "config4_float32", False))      # the example's own precision (splitting_supercell.jl:86), single GPU
     if f32 and (world > 1 or args.slab):
         fail("--config4-float32 runs on one GPU (the Float32 twin's slab path has no test)")
-    G = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 168e3), y=(0.0, 168e3), z=(0.0, 20e3), **({"float_type": np.float32} if f32 else {}))
+    order = int(getattr(args, "config4_order", 5))           # splitting_supercell.jl:279 uses WENO(order = 9): generic kernels, 5-cell halos
+    gkw = {"float_type": np.float32} if f32 else {}
+    if order != 5:
+        gkw["halo"] = (5, 5, 5)
+    G = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 168e3), y=(0.0, 168e3), z=(0.0, 20e3), **gkw)
     dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), surface_pressure=1e5, reference_potential_temperature=300.0)
     mkw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
                microphysics=bz.DCMIP2016KesslerMicrophysics())
@@ -202,10 +206,10 @@ def config4_run(args, bz, rank, world, dist, device, fail):
     transport = "rccl" if args.transport in ("auto", "rccl") else "torch"
     try:
         if slabs:
-            m = bz.compressible.SlabCompressibleModel(G, rank, world, dyn, advection=bz.WENO(order=5), device=device,
+            m = bz.compressible.SlabCompressibleModel(G, rank, world, dyn, advection=bz.WENO(order=order), device=device,
                                                       transport=transport, **mkw)
         else:
-            m = bz.CompressibleAtmosphereModel(G, dyn, advection=bz.WENO(order=5), device=device, **mkw)
+            m = bz.CompressibleAtmosphereModel(G, dyn, advection=bz.WENO(order=order), device=device, **mkw)
         Hz = m.grid.Hz
         col = m.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
 
@@ -247,7 +251,7 @@ def config4_run(args, bz, rank, world, dist, device, fail):
                "warmup": max(1, args.warmup), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[4]: splitting-supercell shape 512x512x128, CompressibleDynamics + "
-                                      "SplitExplicitTimeDiscretization defaults + DCMIP2016 Kessler, WENO5, dt=2s" +
+                                      f"SplitExplicitTimeDiscretization defaults + DCMIP2016 Kessler, WENO{order}, dt=2s" +
                                       (", Float32 (libbreeze_hip_f32.so)" if f32 else ""),
                           "grid": [Nx, Ny, Nz], "dt": dt, "substeps_per_stage": nsub,
                           "parallelism": "single GPU" if not slabs else
@@ -647,6 +651,7 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-float32", action="store_true", help="skip the Float32 run reported under `float32`")
+    ap.add_argument("--config4-order", type=int, default=5, choices=(5, 7, 9), help="--workload config4: WENO order (the example uses 9)")
     ap.add_argument("--config4-float32", action="store_true", help="--workload config4 in Float32, the example's own precision (one GPU)")
     ap.add_argument("--no-compressible", action="store_true",
                     help="skip the short compressible split-explicit measurement reported under `second_milestone`")

@@ -299,8 +299,8 @@ class CompressibleAtmosphereModel:
         torch.cuda.set_device(self.device)
         self._T = T = _lib.types(grid.ftype)
         if grid.ftype == 4:      # eltype(grid) = Float32 (examples/splitting_supercell.jl:86): the Float32 twin of the library
-            if getattr(advection, "order", None) != 5:
-                raise NotImplementedError("Float32 grids: the WENO(order=5) build of the library is wired up")
+            if not isinstance(advection, WENO):
+                raise NotImplementedError("Float32 grids: WENO(order = 5 | 7 | 9) is wired up")
             self._lib = lib = _lib.load_f32()
         else:
             self._lib = lib = _lib.load(advection.order)

@@ -15,6 +15,37 @@
 #include "bz_weno.h"
 #include "bz_weno_tables.h"
 
+#if BZ_WENO_ONE_DIVISION == 2
+// Float32 build: smoothness indicators and candidate values from the first differences of the cells (tables BD / CD of
+// tools/gen_weno_tables.py, the same quadratic forms after the substitution w_j = w_0 + sum d_i).  The expanded form above multiplies
+// integer coefficients up to 2.5e6 with squares of a 300 K field and loses every Float32 digit; differences of neighbouring cells do not.
+#define BZ_WENO_GENERIC(R)                                                                                       \
+    __device__ __forceinline__ double bz_weno_r##R(const double *v)                                             \
+    {                                                                                                           \
+        double d[2 * R - 2], beta[R], p[R], tau = 0.0, num = 0.0, den = 0.0;                                    \
+        _Pragma("unroll") for (int j = 0; j < 2 * R - 2; ++j) d[j] = v[j + 1] - v[j];                           \
+        _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                         \
+            const double *w = d + (R - 1 - s);                                                                  \
+            double b = 0.0, q = 0.0;                                                                            \
+            _Pragma("unroll") for (int j = 0; j < R - 1; ++j) {                                                 \
+                double in = BZW_BD##R[s][j][j] * w[j];                                                          \
+                _Pragma("unroll") for (int l = j + 1; l < R - 1; ++l) in += BZW_BD##R[s][j][l] * w[l];          \
+                b = (j == 0) ? w[j] * in : b + w[j] * in;                                                       \
+                q = (j == 0) ? BZW_CD##R[s][j] * w[j] : q + BZW_CD##R[s][j] * w[j];                             \
+            }                                                                                                   \
+            beta[s] = b; p[s] = q;                                                                              \
+            tau = (s == 0) ? BZW_T##R[s] * b : tau + BZW_T##R[s] * b;                                           \
+        }                                                                                                       \
+        tau = fabs(tau);                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                         \
+            const double rr = tau / (beta[s] + BZ_WENO_EPS);                                                    \
+            const double a = BZW_D##R[s] * (1.0 + rr * rr);                                                     \
+            num = (s == 0) ? a * p[s] : num + a * p[s];                                                         \
+            den = (s == 0) ? a : den + a;                                                                       \
+        }                                                                                                       \
+        return v[R - 1] + num / den;                                                                            \
+    }
+#else
 #define BZ_WENO_GENERIC(R)                                                                                       \
     __device__ __forceinline__ double bz_weno_r##R(const double *v)                                             \
     {                                                                                                           \
@@ -40,6 +71,7 @@
         }                                                                                                       \
         return num / den;                                                                                       \
     }
+#endif
 BZ_WENO_GENERIC(4)
 BZ_WENO_GENERIC(5)
 

@@ -213,8 +213,8 @@ class AtmosphereModel:
             if min(h for h, t in zip((grid.Hx, grid.Hy, grid.Hz), grid.topology) if t != Flat) < need:
                 raise ValueError(f"WENO(order={advection.order}) needs halos of at least {need} cells in every direction "
                                  f"(got {(grid.Hx, grid.Hy, grid.Hz)}): RectilinearGrid(..., halo=({need}, {need}, {need}))")
-            if self._kessler or tracers or self._bounded_advection is not None or grid.ftype != 8:
-                raise NotImplementedError(f"WENO(order={advection.order}) is implemented for the Float64 model without Kessler species, "
+            if self._kessler or tracers or self._bounded_advection is not None:
+                raise NotImplementedError(f"WENO(order={advection.order}) is implemented for the model without Kessler species, "
                                           "tracers or bounds (optionally with saturation adjustment, closure and forcings)")
         self.thermodynamic_constants = c = thermodynamic_constants or ThermodynamicConstants()
         if dynamics is None:
@@ -225,9 +225,8 @@ class AtmosphereModel:
         torch.cuda.set_device(self.device)
         self._T = T = _lib.types(grid.ftype)
         if grid.ftype == 4:
-            if advection.order != 5 or self._bounded_advection is not None:
-                raise NotImplementedError("Float32 grids: the WENO(order=5) build of the Float32 library, without bounds-preserving "
-                                          "advection, is wired up on the host side")
+            if not isinstance(advection, WENO) or self._bounded_advection is not None:
+                raise NotImplementedError("Float32 grids: WENO(order = 5 | 7 | 9) without bounds-preserving advection is wired up on the host side")
             self._lib = lib = _lib.load_f32()
         else:
             self._lib = lib = _lib.load(advection.order)

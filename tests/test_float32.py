@@ -240,3 +240,82 @@ def test_float32_anelastic_kessler_tracers_and_static_energy(oracle, bz):
         e = _steps_errors(om, hm, names)
         print("float32", formulation, {k: f"{v:.1e}" for k, v in e.items()})
         assert max(e.values()) < 1e-4, (formulation, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [7, 9])
+def test_float32_high_order_weno_matches_the_float64_oracle(oracle, bz, order):
+    """WENO(order = 7 / 9) on Float32 grids — the scheme AND the precision of examples/bomex.jl and splitting_supercell.jl.  The Float32
+    build evaluates the smoothness indicators from first differences (tables BD / CD, tools/gen_weno_tables.py); with the expanded
+    integer tables a 300 K field would lose every digit.  Tendencies 2e-5 of the flux scale, three steps 1e-4."""
+    import torch
+    from helpers import ORACLE_TO_HIP
+    size = (24, 16, 14)
+    og = oracle.Grid(size, x=EXT[0], y=EXT[1], z=EXT[2], halo=(5, 5, 5))
+    om = oracle.OracleModel(og, potential_temperature=300.0, advection=f"WENO{order}")
+    grid = bz.RectilinearGrid(size, x=EXT[0], y=EXT[1], z=EXT[2], halo=(5, 5, 5), float_type=np.float32)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO(order=order))
+    randomize(om, seed=11)
+    om.compute_tendencies()
+    for n in ("ru", "rv", "rw", "rtheta", "rq", "u", "v", "w", "theta", "q", "T"):
+        ORACLE_TO_HIP[n](hm).parent.copy_(torch.from_numpy(getattr(om, n)).to(torch.float32))
+    bz.compute_tendencies_(hm)
+    hm.synchronize()
+    worst = {}
+    for n, k in PROG.items():
+        got, want = hm.G[k].interior_cpu().astype(np.float64), om.grid.interior(om.G[n], zface=(n == "rw"))
+        scale = np.max(np.abs(want)) if n != "rtheta" else 300.0 * np.max(np.abs(om.grid.interior(om.G["rq"]))) / 5e-3
+        worst[n] = np.max(np.abs(got - want)) / scale
+    print(f"float32 WENO{order} tendencies:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert all(v < (5e-5 if n == "rw" else 2e-5) for n, v in worst.items()), worst
+    # three steps of the bubble
+    om = oracle.OracleModel(og, potential_temperature=300.0, advection=f"WENO{order}")
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO(order=order))
+    th = bubble_theta(300.0, om.constants.g)
+    om.set(theta=th, u=3.0, v=-2.0)
+    hm.set(θ=th, u=3.0, v=-2.0)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    e = _steps_errors(om, hm, [(n, hm.prognostic_fields()[k]) for n, k in PROG.items() if n != "rq"])
+    print(f"float32 WENO{order} steps:", {k: f"{v:.1e}" for k, v in e.items()})
+    assert max(e.values()) < 1e-4, e
+
+
+@pytest.mark.gpu
+def test_float32_order_nine_compressible_kessler_matches_the_float64_oracle(oracle, bz):
+    """examples/splitting_supercell.jl's scheme list in its own precision: CompressibleDynamics (split-explicit) + DCMIP2016 Kessler +
+    WENO(order = 9) + Float32, two steps against the Float64 oracle."""
+    from oracle import oracle_compressible as oc
+    size, extent = (24, 16, 20), dict(x=(0.0, 16e3), y=(0.0, 12e3), z=(0.0, 8e3))
+    thb = lambda z: 300.0 + 0.0035 * z
+    qvb = lambda z: float(0.013 * np.exp(-z / 2800.0))
+    og = oracle.Grid(size, halo=(5, 5, 5), **extent)
+    om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), surface_pressure=1e5, reference_potential_temperature=thb,
+                                    reference_vapor_mass_fraction=qvb, microphysics="Kessler", advection="WENO9")
+    grid = bz.RectilinearGrid(size, halo=(5, 5, 5), float_type=np.float32, **extent)
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), surface_pressure=1e5, reference_potential_temperature=thb,
+                                  reference_vapor_mass_fraction=qvb)
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=9), microphysics=bz.DCMIP2016KesslerMicrophysics(),
+                                        thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()))
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt(((x - 8e3) / 4e3) ** 2 + ((y - 6e3) / 4e3) ** 2 + ((z - 1500.0) / 1500.0) ** 2))
+    th = lambda x, y, z: thb(z) + 2.0 * bub(x, y, z)
+    qv = lambda x, y, z: np.vectorize(qvb)(z) + 0.003 * bub(x, y, z) + 0 * x + 0 * y
+    x, y, z = og.nodes("ccc")
+    rho = om.ref.density[og.Hz:og.Hz + og.Nz][:, None, None] * thb(z) / th(x, y, z)
+    om.set(rho=rho, theta=th, u=5.0, v=0.0, w=0.0, qv=qv)
+    hm.set(ρ=rho, θ=th, u=5.0, v=0.0, w=0.0, qᵗ=qv)
+    for _ in range(2):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    I = og.interior
+    mom = max(np.abs(I(om.ru)).max(), np.abs(I(om.rw, True)).max())
+    worst = {}
+    for n, f in (("rho_d", hm.dynamics.dry_density), ("rtheta", hm.potential_temperature_density), ("rq", hm.moisture_density),
+                 ("T", hm.temperature), ("ru", hm.momentum["ρu"]), ("rw", hm.momentum["ρw"])):
+        want = I(getattr(om, n), n == "rw")
+        worst[n] = np.abs(f.interior_cpu().astype(np.float64) - want).max() / (mom if n in ("ru", "rw") else np.abs(want).max())
+    print("float32 WENO9 compressible Kessler:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < 1e-4, worst

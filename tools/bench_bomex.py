@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-forcing", action="store_true")
     ap.add_argument("--no-closure", action="store_true")
+    ap.add_argument("--order", type=int, default=5, choices=(5, 7, 9), help="WENO order (examples/bomex.jl:204 uses 9; generic kernels)")
     ap.add_argument("--float32", action="store_true", help="eltype(grid) = Float32, the precision of examples/bomex.jl (libbreeze_hip_f32.so)")
     a = ap.parse_args()
     import torch
@@ -37,12 +38,12 @@ def main():
     from test_forcings import _hip_forcing_kwargs
     Nx, Ny, Nz = a.size
     grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 6400.0), y=(0.0, 6400.0), z=(0.0, 3000.0),
-                              float_type=np.float32 if a.float32 else np.float64)
+                              float_type=np.float32 if a.float32 else np.float64, **({"halo": (5, 5, 5)} if a.order != 5 else {}))
     ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
     kw = {} if a.no_forcing else _hip_forcing_kwargs(bz, full=True)
     if not a.no_closure:
         kw["closure"] = bz.SmagorinskyLilly()
-    m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5),
+    m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=a.order),
                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), **kw)
     rng = np.random.default_rng(0)
     noise_t = rng.standard_normal((Nz, Ny, Nx))
@@ -77,7 +78,7 @@ def main():
     cells = Nx * Ny * Nz
     ql = m.microphysical_fields["qˡ"].interior
     w = m.velocities["w"].interior
-    out = {"metric": "grid-cells advanced/sec, BOMEX-shaped anelastic SSP-RK3 step (WENO5 + saturation adjustment + SmagorinskyLilly + forcing stack)",
+    out = {"metric": "grid-cells advanced/sec, BOMEX-shaped anelastic SSP-RK3 step (WENO + saturation adjustment + SmagorinskyLilly + forcing stack)", "weno_order": a.order,
            "value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": a.dt,
            "forcing": not a.no_forcing, "closure": None if a.no_closure else "SmagorinskyLilly", "dtype": "f32" if a.float32 else "f64",
            "kernels_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items())},

@@ -113,6 +113,30 @@ def tables(r):
 TAU = {2: (1, -1), 3: (1, 0, -1), 4: (1, 3, -3, -1), 5: (1, 2, -6, 2, 1)}
 
 
+def difference_form(r):
+    """The same tables expressed through the first differences d_i = w_{i+1} - w_i of a stencil (beta and p - w_centre do not change when
+    a constant is added to the cells): beta_s = sum_i d_i (sum_{k>=i} BD[s][i][k] d_k), p_s = w[s] + sum_i CD[s][i] d_i, where w[s] is the
+    upwind cell (local index s in stencil s).  What the Float32 build evaluates: on a 300 K field the expanded form loses every digit."""
+    C, D, B = tables(r)
+    BD, CD = [], []
+    for s in range(r):
+        # symmetric matrix of the quadratic form, then T^t Q T with w_j = w_0 + sum_{i<j} d_i
+        Q = [[(B[s][min(j, l)][max(j, l)] / (1 if j == l else 2)) for l in range(r)] for j in range(r)]
+        for j in range(r):                        # invariance under constants: every row of Q sums to zero
+            assert sum(Q[j]) == 0, (r, s, j)
+        M = [[sum(Q[j][l] for j in range(i + 1, r) for l in range(k + 1, r)) for k in range(r - 1)] for i in range(r - 1)]
+        BD.append([[(M[i][k] if i == k else (2 * M[i][k] if k > i else Fr(0))) for k in range(r - 1)] for i in range(r - 1)])
+        assert sum(C[s]) == 1
+        cd = []
+        for i in range(r - 1):                    # w_j - w_s = sum_{i=s}^{j-1} d_i (j > s),  -sum_{i=j}^{s-1} d_i (j < s)
+            if i >= s:
+                cd.append(sum(C[s][j] for j in range(i + 1, r)))
+            else:
+                cd.append(-sum(C[s][j] for j in range(0, i + 1)))
+        CD.append(cd)
+    return BD, CD
+
+
 def centered(order):
     """Finite-volume centred reconstruction at the face between cells -1 and 0 from `order` cells: coefficient of the pair at distance d."""
     h = order // 2
@@ -141,6 +165,11 @@ def emit(prefix, qual):
         out.append(f"{qual} double {prefix}B{r}[{r}][{r}][{r}] = {{" + ", ".join(
             "{" + ", ".join("{" + ", ".join(fmt(x) for x in row) + "}" for row in Bs) + "}" for Bs in B) + "};")
         out.append(f"{qual} double {prefix}T{r}[{r}] = {{" + ", ".join(fmt(x) for x in TAU[r]) + "};")
+        if r >= 3:
+            BD, CD = difference_form(r)
+            out.append(f"{qual} double {prefix}BD{r}[{r}][{r - 1}][{r - 1}] = {{" + ", ".join(
+                "{" + ", ".join("{" + ", ".join(fmt(x) for x in row) + "}" for row in Bs) + "}" for Bs in BD) + "};   /* difference form */")
+            out.append(f"{qual} double {prefix}CD{r}[{r}][{r - 1}] = {{" + ", ".join("{" + ", ".join(fmt(x) for x in row) + "}" for row in CD) + "};")
     for order in (2, 4, 6, 8):
         c = centered(order)
         out.append(f"{qual} double {prefix}S{order}[{order // 2}] = {{" + ", ".join(fmt(x) for x in c) + f"}};   /* Centered(order {order}) */")

@@ -326,5 +326,6 @@ extern "C" void bz_destroy(bz_ctx *ctx)
     bzi_forcing_teardown(ctx);
     bzi_closure_teardown(ctx);
     if (ctx->d_scalar) hipFree(ctx->d_scalar);
+    if (ctx->d_gflux) hipFree(ctx->d_gflux);
     delete ctx;
 }

@@ -293,6 +293,7 @@ struct bz_ctx {
     bool has_reference = false;       // ExnerReferenceState columns present (else p_r = rho_r = 0)
     bz_split_explicit se;
     int weno_R = 3;                   // stencil half-width of the advection scheme: WENO(order = 2 R - 1)
+    double *d_gflux = nullptr;        // flux scratch of the generic (order 7 / 9) kernels' two-pass evaluation: 3 parent-shaped arrays
     double dz_min = 0.0;              // minimum_zspacing(grid)
     double *d_sponge = nullptr;       // UpperSponge rate * ramp per face (compressible contexts)
     double *d_Clin = nullptr;         // centre array: gamma R_m * Pi of the current linearisation

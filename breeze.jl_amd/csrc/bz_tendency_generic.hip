@@ -142,97 +142,158 @@ __device__ __forceinline__ double symm_g(const double *__restrict__ M, long long
     return acc;
 }
 
+// ---- two-pass evaluation ---------------------------------------------------------------------------------------------------------
+// A face flux belongs to two cells.  PASS 0 lets both of them evaluate it (one launch, 6 reconstructions per cell and field); the
+// shipped path is PASS 1 + PASS 2: every thread evaluates the three fluxes of its own index once and stores them in parent-shaped
+// scratch arrays (ctx->d_gflux), a second launch differences them.  Order-9 reconstructions cost ~700 instructions each, the scratch
+// traffic (3 words written, 6 read per cell) is noise beside that.  Bit-identical to PASS 0: the same expressions, evaluated once.
+struct FluxBuf { double *x, *y, *z; };
+
+// PASS 1 covers the interior (x is Periodic and y wraps unless the context is a y-slab or Flat: the flux at face N is the flux at face 0,
+// bit for bit, because halos are exact periodic images; the Bounded z direction has zero mass flux through its wall faces) plus, on
+// y-slabs, one row either side (the fluxes at the slab edges come from exchanged halo rows)
+struct GenericWrap { long long xp, xm, yp, ym; bool top; };
+template <int PASS>
+__device__ __forceinline__ bool generic_index(const DevGrid &g, int &i, int &j, int &k, int k0, GenericWrap &W)
+{
+    const bool ext_y = !g.wrap_y && !g.flat_y;
+    i = blockIdx.x * 256 + threadIdx.x;
+    j = (int)blockIdx.y - ((PASS == 1 && ext_y) ? 1 : 0);
+    k = (PASS == 1 ? 0 : k0) + (int)blockIdx.z;
+    const long long sy = g.Sx;
+    W.xp = (i + 1 < g.Nx) ? 1 : 1 - g.Nx;
+    W.xm = (i > 0) ? -1 : g.Nx - 1;
+    W.yp = (j + 1 < g.Ny || ext_y) ? sy : sy * (1 - g.Ny);
+    W.ym = (j > 0 || ext_y) ? -sy : sy * (g.Ny - 1);
+    W.top = (k + 1 >= g.Nz);
+    return i < g.Nx;
+}
+#define IN(a, lo, hi) ((a) >= (lo) && (a) <= (hi))
+
 // ---- scalars: G = -div_rhoUc(c) -----------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, int PASS>
 __global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__restrict__ Gc, const double *__restrict__ u,
                                                            const double *__restrict__ v, const double *__restrict__ w,
-                                                           const double *__restrict__ c)
+                                                           const double *__restrict__ c, FluxBuf F)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= g.Nx) return;
+    int i, j, k;
+    GenericWrap W;
+    if (!generic_index<PASS>(g, i, j, k, 0, W)) return;
+    const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
-    const double rho = g.rho[k], Ax = g.Ax[k], Ay = g.Ay[k];
-    auto fx = [&](long long m) { const double ut = u[m]; return rho * ((Ax * ut) * biased_face_g(c + m, 1, ut > 0.0, R)); };
-    auto fy = [&](long long m) { const double vt = v[m]; return rho * ((Ay * vt) * biased_face_g(c + m, sy, vt > 0.0, R)); };
+    auto fx = [&](long long m) { const double ut = u[m]; return g.rho[k] * ((g.Ax[k] * ut) * biased_face_g(c + m, 1, ut > 0.0, R)); };
+    auto fy = [&](long long m) { const double vt = v[m]; return g.rho[k] * ((g.Ay[k] * vt) * biased_face_g(c + m, sy, vt > 0.0, R)); };
     auto fz = [&](long long m, int kf) {
         const double wt = w[m];
         return g.rho_f[kf] * ((g.Az * wt) * biased_face_g(c + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz)));
     };
-    const double dx = fx(n + 1) - fx(n), dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n), dz = fz(n + sz, k + 1) - fz(n, k);      // a Flat y has no faces
+    if (PASS == 1) {
+        const bool cj = IN(j, 0, g.Ny - 1);
+        if (cj) F.x[n] = fx(n);
+        if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = fy(n);
+        if (cj) F.z[n] = fz(n, k);
+        return;
+    }
+    double dx, dy, dz;
+    if (PASS == 2) { dx = F.x[n + W.xp] - F.x[n]; dy = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; dz = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
+    else { dx = fx(n + 1) - fx(n); dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n); dz = fz(n + sz, k + 1) - fz(n, k); }      // a Flat y has no faces
     Gc[n] = -(g.Vinv_c[k] * (dx + dy + dz));
 }
 
 // ---- momentum -------------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, int PASS>
 __global__ __launch_bounds__(256) void k_u_tendency_g(DevGrid g, double *__restrict__ Gu, const double *__restrict__ ru,
                                                       const double *__restrict__ rv, const double *__restrict__ rw,
-                                                      const double *__restrict__ u)
+                                                      const double *__restrict__ u, FluxBuf F)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= g.Nx) return;
+    int i, j, k;
+    GenericWrap W;
+    if (!generic_index<PASS>(g, i, j, k, 0, W)) return;
+    const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
     const ColPtr none(nullptr);
-    const double Ax = g.Ax[k], Ay = g.Ay[k];
     auto FUu = [&](long long m) {      // at centre: advecting flux from faces
-        const double ut = symm_g(ru, m, 1, R, -(R - 2), none, 0, Ax);
+        const double ut = symm_g(ru, m, 1, R, -(R - 2), none, 0, g.Ax[k]);
         return ut * biased_center_g(u + m, 1, ut > 0.0, R);
     };
     auto FVu = [&](long long m) {      // at (f, f, c): Centered in x of Ay rho_v to x-face
-        const double vt = symm_g(rv, m, 1, R, -(R - 1), none, 0, Ay);
+        const double vt = symm_g(rv, m, 1, R, -(R - 1), none, 0, g.Ay[k]);
         return vt * biased_face_g(u + m, sy, vt > 0.0, R);
     };
     auto FWu = [&](long long m, int kf) {
         const double wt = symm_g(rw, m, 1, R, -(R - 1), none, 0, g.Az);
         return wt * biased_face_g(u + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz));
     };
-    const double a = FUu(n) - FUu(n - 1), b = g.flat_y ? 0.0 : FVu(n + sy) - FVu(n), c = FWu(n + sz, k + 1) - FWu(n, k);
+    if (PASS == 1) {
+        const bool cj = IN(j, 0, g.Ny - 1);
+        if (cj) F.x[n] = FUu(n);
+        if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = FVu(n);
+        if (cj) F.z[n] = FWu(n, k);
+        return;
+    }
+    double a, b, c;
+    if (PASS == 2) { a = F.x[n] - F.x[n + W.xm]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
+    else { a = FUu(n) - FUu(n - 1); b = g.flat_y ? 0.0 : FVu(n + sy) - FVu(n); c = FWu(n + sz, k + 1) - FWu(n, k); }
     Gu[n] = -(g.Vinv_c[k] * (a + b + c));
 }
 
-template <int R>
+template <int R, int PASS>
 __global__ __launch_bounds__(256) void k_v_tendency_g(DevGrid g, double *__restrict__ Gv, const double *__restrict__ ru,
                                                       const double *__restrict__ rv, const double *__restrict__ rw,
-                                                      const double *__restrict__ v)
+                                                      const double *__restrict__ v, FluxBuf F)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= g.Nx) return;
+    int i, j, k;
+    GenericWrap W;
+    if (!generic_index<PASS>(g, i, j, k, 0, W)) return;
+    const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
     const ColPtr none(nullptr);
-    const double Ax = g.Ax[k], Ay = g.Ay[k];
     auto FUv = [&](long long m) {
-        const double ut = g.flat_y ? Ax * ru[m] : symm_g(ru, m, sy, R, -(R - 1), none, 0, Ax);      // Iy of a Flat direction: identity
+        const double ut = g.flat_y ? g.Ax[k] * ru[m] : symm_g(ru, m, sy, R, -(R - 1), none, 0, g.Ax[k]);      // Iy of a Flat direction: identity
         return ut * biased_face_g(v + m, 1, ut > 0.0, R);
     };
     auto FVv = [&](long long m) {
-        const double vt = symm_g(rv, m, sy, R, -(R - 2), none, 0, Ay);
+        const double vt = symm_g(rv, m, sy, R, -(R - 2), none, 0, g.Ay[k]);
         return vt * biased_center_g(v + m, sy, vt > 0.0, R);
     };
     auto FWv = [&](long long m, int kf) {
         const double wt = g.flat_y ? g.Az * rw[m] : symm_g(rw, m, sy, R, -(R - 1), none, 0, g.Az);
         return wt * biased_face_g(v + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz));
     };
-    const double a = FUv(n + 1) - FUv(n), b = g.flat_y ? 0.0 : FVv(n) - FVv(n - sy), c = FWv(n + sz, k + 1) - FWv(n, k);
+    if (PASS == 1) {
+        const bool cj = IN(j, 0, g.Ny - 1);
+        if (cj) F.x[n] = FUv(n);
+        if (!g.flat_y && IN(j, ext_y ? -1 : 0, g.Ny - 1)) F.y[n] = FVv(n);
+        if (cj) F.z[n] = FWv(n, k);
+        return;
+    }
+    double a, b, c;
+    if (PASS == 2) { a = F.x[n + W.xp] - F.x[n]; b = g.flat_y ? 0.0 : F.y[n] - F.y[n + W.ym]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
+    else { a = FUv(n + 1) - FUv(n); b = g.flat_y ? 0.0 : FVv(n) - FVv(n - sy); c = FWv(n + sz, k + 1) - FWv(n, k); }
     Gv[n] = -(g.Vinv_c[k] * (a + b + c));
 }
 
-// faces k = 1 .. Nz-1 (blockIdx.z + 1); + Iz(buoyancy) unless !BUOY (slow tendency of the split-explicit compressible model)
-template <int R, bool BUOY = true>
+// faces k = 1 .. Nz-1; + Iz(buoyancy) unless !BUOY (slow tendency of the split-explicit compressible model)
+template <int R, int PASS, bool BUOY = true>
 __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restrict__ Gw, const double *__restrict__ ru,
                                                       const double *__restrict__ rv, const double *__restrict__ rw,
                                                       const double *__restrict__ w, const double *__restrict__ T,
-                                                      const double *__restrict__ qv)
+                                                      const double *__restrict__ qv, FluxBuf F)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z + 1;
-    if (i >= g.Nx) return;
+    int i, j, k;
+    GenericWrap W;
+    if (!generic_index<PASS>(g, i, j, k, 1, W)) return;      // PASS 1: k = 0 .. Nz-1 (the centre fluxes are needed from 0 on)
+    const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
     const ColPtr none(nullptr);
-    const int Bf = buf_face<R>(k, g.Nz);
     auto FUw = [&](long long m) {      // Centered in z of Ax(k) rho_u to z-face k
+        const int Bf = buf_face<R>(k, g.Nz);
         const int h = Bf > 2 ? Bf - 1 : 1;
         const double ut = symm_g(ru, m, sz, Bf, -h, g.Ax, k, 0.0);
         return ut * biased_face_g(w + m, 1, ut > 0.0, R);
     };
     auto FVw = [&](long long m) {
+        const int Bf = buf_face<R>(k, g.Nz);
         const int h = Bf > 2 ? Bf - 1 : 1;
         const double vt = symm_g(rv, m, sz, Bf, -h, g.Ay, k, 0.0);
         return vt * biased_face_g(w + m, sy, vt > 0.0, R);
@@ -243,7 +304,16 @@ __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restr
         const double wt = symm_g(rw, m, sz, B, -(h - 1), none, 0, g.Az);
         return wt * biased_center_g(w + m, sz, wt > 0.0, B);
     };
-    const double a = FUw(n + 1) - FUw(n), b = g.flat_y ? 0.0 : FVw(n + sy) - FVw(n), c = FWw(n, k) - FWw(n - sz, k - 1);
+    if (PASS == 1) {
+        const bool cj = IN(j, 0, g.Ny - 1), ck = k >= 1;
+        if (cj && ck) F.x[n] = FUw(n);
+        if (!g.flat_y && ck && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = FVw(n);
+        if (cj) F.z[n] = FWw(n, k);
+        return;
+    }
+    double a, b, c;
+    if (PASS == 2) { a = F.x[n + W.xp] - F.x[n]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = F.z[n] - F.z[n - sz]; }
+    else { a = FUw(n + 1) - FUw(n); b = g.flat_y ? 0.0 : FVw(n + sy) - FVw(n); c = FWw(n, k) - FWw(n - sz, k - 1); }
     const double adv = -(g.Vinv_f[k] * (a + b + c));
     if (BUOY) Gw[n] = adv + 0.5 * (bz_buoyancy(g, T, qv, n - sz, k - 1) + bz_buoyancy(g, T, qv, n, k));
     else Gw[n] = adv;
@@ -251,57 +321,102 @@ __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restr
 
 // scalar tendency with a 3-D carrier density, G = -div(Ix/y/z(rho) U c~) (src/Advection.jl:20-35 with the compressible model's density
 // field), and, when Grho != nullptr, the dry-density tendency -div(momentum) (compressible_density_tendency.jl:52-55)
-template <int R>
+template <int R, int PASS>
 __global__ __launch_bounds__(256) void k_scalar_tendency_rho3d_g(DevGrid g, double *__restrict__ Gc, double *__restrict__ Grho,
                                                                  const double *__restrict__ rho, const double *__restrict__ u,
                                                                  const double *__restrict__ v, const double *__restrict__ w,
                                                                  const double *__restrict__ c, const double *__restrict__ ru,
-                                                                 const double *__restrict__ rv, const double *__restrict__ rw)
+                                                                 const double *__restrict__ rv, const double *__restrict__ rw, FluxBuf F)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= g.Nx) return;
+    int i, j, k;
+    GenericWrap W;
+    if (!generic_index<PASS>(g, i, j, k, 0, W)) return;
+    const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
-    const double Ax = g.Ax[k], Ay = g.Ay[k];
-    auto fx = [&](long long m) { const double ut = u[m]; return ((rho[m] + rho[m - 1]) / 2.0) * ((Ax * ut) * biased_face_g(c + m, 1, ut > 0.0, R)); };
-    auto fy = [&](long long m) { const double vt = v[m]; return ((rho[m] + rho[m - sy]) / 2.0) * ((Ay * vt) * biased_face_g(c + m, sy, vt > 0.0, R)); };
+    auto fx = [&](long long m) { const double ut = u[m]; return ((rho[m] + rho[m - 1]) / 2.0) * ((g.Ax[k] * ut) * biased_face_g(c + m, 1, ut > 0.0, R)); };
+    auto fy = [&](long long m) { const double vt = v[m]; return ((rho[m] + rho[m - sy]) / 2.0) * ((g.Ay[k] * vt) * biased_face_g(c + m, sy, vt > 0.0, R)); };
     auto fz = [&](long long m, int kf) {
         const double wt = w[m];
         return ((rho[m] + rho[m - sz]) / 2.0) * ((g.Az * wt) * biased_face_g(c + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz)));
     };
-    const double dx = fx(n + 1) - fx(n), dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n), dz = fz(n + sz, k + 1) - fz(n, k);
+    if (PASS == 1) {
+        const bool cj = IN(j, 0, g.Ny - 1);
+        if (cj) F.x[n] = fx(n);
+        if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = fy(n);
+        if (cj) F.z[n] = fz(n, k);
+        return;
+    }
+    double dx, dy, dz;
+    if (PASS == 2) { dx = F.x[n + W.xp] - F.x[n]; dy = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; dz = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
+    else { dx = fx(n + 1) - fx(n); dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n); dz = fz(n + sz, k + 1) - fz(n, k); }
     Gc[n] = -(g.Vinv_c[k] * (dx + dy + dz));
     if (Grho) {
+        const double Ax = g.Ax[k], Ay = g.Ay[k];
         const double a = Ax * ru[n + 1] - Ax * ru[n];
         const double b = g.flat_y ? 0.0 : Ay * rv[n + sy] - Ay * rv[n];
         const double cc = g.Az * rw[n + sz] - g.Az * rw[n];
         Grho[n] = -(g.Vinv_c[k] * (a + b + cc));
     }
 }
+#undef IN
 
-template <int R>
-static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+// scratch of the two-pass path: three parent-shaped arrays with z-face levels
+static int generic_flux_buffers(bz_ctx *ctx, FluxBuf &F)
 {
     const DevGrid &g = ctx->dg;
-    const dim3 block(256), grid((g.Nx + 255) / 256, g.Ny, g.Nz), gridw((g.Nx + 255) / 256, g.Ny, g.Nz - 1);
+    const size_t n = (size_t)g.Sxy * (size_t)(g.Nz + 2 * g.Hz + 1);
+    if (!ctx->d_gflux) BZ_HIP(hipMalloc(&ctx->d_gflux, 3 * n * sizeof(double)));
+    const long long origin = (long long)g.Sxy * g.Hz + (long long)g.Sx * g.Hy + g.Hx;      // g.idx(0, 0, 0) of a parent array
+    (void)origin;
+    F.x = ctx->d_gflux; F.y = ctx->d_gflux + n; F.z = ctx->d_gflux + 2 * n;
+    return BZ_OK;
+}
+
+// launch `kernel<R, PASS>`(args..., F): one pass with BZ_GENERIC_ONEPASS=1, else flux pass over the extended box + divergence pass
+#define GENERIC_LAUNCH(KERNEL, TARGS, k0, nk, ...)                                                                                  \
+    do {                                                                                                                            \
+        const dim3 block(256);                                                                                                      \
+        if (onepass) {                                                                                                              \
+            hipLaunchKernelGGL((KERNEL<R, 0 TARGS>), dim3((g.Nx + 255) / 256, g.Ny, (nk)), block, 0, ctx->stream, g, __VA_ARGS__, F);  \
+        } else {                                                                                                                    \
+            hipLaunchKernelGGL((KERNEL<R, 1 TARGS>), dim3((g.Nx + 255) / 256, g.Ny + ((!g.wrap_y && !g.flat_y) ? 2 : 0), g.Nz), block, 0, \
+                               ctx->stream, g, __VA_ARGS__, F);                                                                     \
+            hipLaunchKernelGGL((KERNEL<R, 2 TARGS>), dim3((g.Nx + 255) / 256, g.Ny, (nk)), block, 0, ctx->stream, g, __VA_ARGS__, F);  \
+        }                                                                                                                           \
+    } while (0)
+#define COMMA_FALSE , false
+
+template <int R>
+static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool buoyancy, bool scalars)
+{
+    const DevGrid &g = ctx->dg;
+    const bool onepass = getenv("BZ_GENERIC_ONEPASS") != nullptr;
+    FluxBuf F{nullptr, nullptr, nullptr};
+    int rc;
+    if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;
     {
         ProfileScope ps(ctx, "x_momentum_tendency");
-        hipLaunchKernelGGL((k_u_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u);
+        GENERIC_LAUNCH(k_u_tendency_g, , 0, g.Nz, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u);
     }
     {
         ProfileScope ps(ctx, "y_momentum_tendency");
-        hipLaunchKernelGGL((k_v_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v);
+        GENERIC_LAUNCH(k_v_tendency_g, , 0, g.Nz, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v);
     }
     if (g.Nz > 1) {
         ProfileScope ps(ctx, "z_momentum_tendency");
-        hipLaunchKernelGGL((k_w_tendency_g<R>), gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w, s->T, s->q);
+        if (buoyancy) GENERIC_LAUNCH(k_w_tendency_g, , 1, g.Nz - 1, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w, s->T, s->q);
+        else GENERIC_LAUNCH(k_w_tendency_g, COMMA_FALSE, 1, g.Nz - 1, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w, (const double *)nullptr,
+                            (const double *)nullptr);
     }
-    {
-        ProfileScope ps(ctx, "potential_temperature_tendency");
-        hipLaunchKernelGGL((k_scalar_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_theta, s->u, s->v, s->w, s->theta);
-    }
-    {
-        ProfileScope ps(ctx, "moisture_tendency");
-        hipLaunchKernelGGL((k_scalar_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_q, s->u, s->v, s->w, s->q);
+    if (scalars) {
+        {
+            ProfileScope ps(ctx, "potential_temperature_tendency");
+            GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, G->rho_theta, s->u, s->v, s->w, s->theta);
+        }
+        {
+            ProfileScope ps(ctx, "moisture_tendency");
+            GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, G->rho_q, s->u, s->v, s->w, s->q);
+        }
     }
     BZ_LAUNCH_CHECK();
     return BZ_OK;
@@ -309,52 +424,40 @@ static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G
 
 // compressible split-explicit model with WENO(order = 7 / 9) (examples/splitting_supercell.jl:279): slow momentum tendencies =
 // advection alone, scalars with the 3-D carrier density
-template <int R>
-static int launch_generic_momentum_advection(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
-{
-    const DevGrid &g = ctx->dg;
-    const dim3 block(256), grid((g.Nx + 255) / 256, g.Ny, g.Nz), gridw((g.Nx + 255) / 256, g.Ny, g.Nz - 1);
-    {
-        ProfileScope ps(ctx, "x_momentum_tendency");
-        hipLaunchKernelGGL((k_u_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u);
-    }
-    {
-        ProfileScope ps(ctx, "y_momentum_tendency");
-        hipLaunchKernelGGL((k_v_tendency_g<R>), grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v);
-    }
-    if (g.Nz > 1) {
-        ProfileScope ps(ctx, "z_momentum_tendency");
-        hipLaunchKernelGGL((k_w_tendency_g<R, false>), gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w,
-                           (const double *)nullptr, (const double *)nullptr);
-    }
-    BZ_LAUNCH_CHECK();
-    return BZ_OK;
-}
-
 int bzi_momentum_advection_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
-    if (ctx->weno_R == 5) return launch_generic_momentum_advection<5>(ctx, s, G);
-    if (ctx->weno_R == 4) return launch_generic_momentum_advection<4>(ctx, s, G);
+    if (ctx->weno_R == 5) return launch_generic<5>(ctx, s, G, false, false);
+    if (ctx->weno_R == 4) return launch_generic<4>(ctx, s, G, false, false);
     return BZ_ERR_INVALID;
+}
+
+template <int R>
+static int launch_rho3d(bz_ctx *ctx, double *Gc, double *Grho, const double *rho, const double *u, const double *v, const double *w,
+                        const double *c, const double *ru, const double *rv, const double *rw)
+{
+    const DevGrid &g = ctx->dg;
+    const bool onepass = getenv("BZ_GENERIC_ONEPASS") != nullptr;
+    FluxBuf F{nullptr, nullptr, nullptr};
+    int rc;
+    if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;
+    GENERIC_LAUNCH(k_scalar_tendency_rho3d_g, , 0, g.Nz, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
 }
 
 int bzi_scalar_rho3d_generic(bz_ctx *ctx, double *Gc, double *Grho, const double *rho, const double *u, const double *v, const double *w,
                              const double *c, const double *ru, const double *rv, const double *rw)
 {
-    const DevGrid &g = ctx->dg;
-    const dim3 block(256), grid((g.Nx + 255) / 256, g.Ny, g.Nz);
-    if (ctx->weno_R == 5) hipLaunchKernelGGL((k_scalar_tendency_rho3d_g<5>), grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
-    else if (ctx->weno_R == 4) hipLaunchKernelGGL((k_scalar_tendency_rho3d_g<4>), grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
-    else return BZ_ERR_INVALID;
-    BZ_LAUNCH_CHECK();
-    return BZ_OK;
+    if (ctx->weno_R == 5) return launch_rho3d<5>(ctx, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
+    if (ctx->weno_R == 4) return launch_rho3d<4>(ctx, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
+    return BZ_ERR_INVALID;
 }
 
 // advection (+ buoyancy) tendencies of the five prognostic fields for ctx->weno_R = 4 (order 7) or 5 (order 9)
 int bzi_compute_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
-    if (ctx->weno_R == 5) return launch_generic<5>(ctx, s, G);
-    if (ctx->weno_R == 4) return launch_generic<4>(ctx, s, G);
+    if (ctx->weno_R == 5) return launch_generic<5>(ctx, s, G, true, true);
+    if (ctx->weno_R == 4) return launch_generic<4>(ctx, s, G, true, true);
     ctx->last_error = "bzi_compute_tendencies_generic: WENO order 7 or 9";
     return BZ_ERR_INVALID;
 }

@@ -337,12 +337,21 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
     if (ctx->weno_R != 3) {      // WENO(order = 7 / 9): generic kernels for the five prognostic fields, then the order-independent terms
-        if (g.microphysics == 2 || ctx->n_tracers || ctx->bounded_mask) {
-            ctx->last_error = "WENO(order = 7 / 9) implements the model without Kessler species, tracers or bounds";
+        if (ctx->bounded_mask) {
+            ctx->last_error = "WENO(order = 7 / 9) does not implement bounds-preserving advection";
             return BZ_ERR_UNSUPPORTED;
         }
         int rcg = bzi_compute_tendencies_generic(ctx, s, G);
         if (rcg) return rcg;
+        if (g.microphysics == 2) {      // Kessler condensate species (bzi_kessler_tendencies, order-generic)
+            ProfileScope ps(ctx, "kessler_species_tendencies");
+            if ((rcg = bzi_scalar_tendency_generic(ctx, ctx->kessler.G_cloud_liquid_density, s->u, s->v, s->w, ctx->kessler.cloud_liquid_mass_fraction))) return rcg;
+            if ((rcg = bzi_scalar_tendency_generic(ctx, ctx->kessler.G_rain_density, s->u, s->v, s->w, ctx->kessler.rain_mass_fraction))) return rcg;
+        }
+        for (int t = 0; t < ctx->n_tracers; ++t) {
+            ProfileScope ps(ctx, "tracer_tendencies");
+            if ((rcg = bzi_scalar_tendency_generic(ctx, ctx->tracers[t].G, s->u, s->v, s->w, ctx->tracers[t].specific))) return rcg;
+        }
         if (g.formulation == 1) {      // StaticEnergy (examples/dry_thermal_bubble.jl:25): the buoyancy flux term has no advection scheme in it
             ProfileScope ps(ctx, "static_energy_buoyancy_flux");
             hipLaunchKernelGGL(k_energy_buoyancy_flux, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,

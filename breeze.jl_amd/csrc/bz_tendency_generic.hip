@@ -453,6 +453,27 @@ int bzi_scalar_rho3d_generic(bz_ctx *ctx, double *Gc, double *Grho, const double
     return BZ_ERR_INVALID;
 }
 
+// G = -div_rhoUc(c) of one more scalar (Kessler species, user tracers)
+template <int R>
+static int launch_scalar(bz_ctx *ctx, double *Gc, const double *u, const double *v, const double *w, const double *c)
+{
+    const DevGrid &g = ctx->dg;
+    const bool onepass = getenv("BZ_GENERIC_ONEPASS") != nullptr;
+    FluxBuf F{nullptr, nullptr, nullptr};
+    int rc;
+    if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;
+    GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, Gc, u, v, w, c);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+int bzi_scalar_tendency_generic(bz_ctx *ctx, double *Gc, const double *u, const double *v, const double *w, const double *c)
+{
+    if (ctx->weno_R == 5) return launch_scalar<5>(ctx, Gc, u, v, w, c);
+    if (ctx->weno_R == 4) return launch_scalar<4>(ctx, Gc, u, v, w, c);
+    return BZ_ERR_INVALID;
+}
+
 // advection (+ buoyancy) tendencies of the five prognostic fields for ctx->weno_R = 4 (order 7) or 5 (order 9)
 int bzi_compute_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {

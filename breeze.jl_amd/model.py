@@ -213,9 +213,8 @@ class AtmosphereModel:
             if min(h for h, t in zip((grid.Hx, grid.Hy, grid.Hz), grid.topology) if t != Flat) < need:
                 raise ValueError(f"WENO(order={advection.order}) needs halos of at least {need} cells in every direction "
                                  f"(got {(grid.Hx, grid.Hy, grid.Hz)}): RectilinearGrid(..., halo=({need}, {need}, {need}))")
-            if self._kessler or tracers or self._bounded_advection is not None:
-                raise NotImplementedError(f"WENO(order={advection.order}) is implemented for the model without Kessler species, "
-                                          "tracers or bounds (optionally with saturation adjustment, closure and forcings)")
+            if self._bounded_advection is not None:
+                raise NotImplementedError(f"WENO(order={advection.order}): bounds-preserving advection is implemented for order 5")
         self.thermodynamic_constants = c = thermodynamic_constants or ThermodynamicConstants()
         if dynamics is None:
             dynamics = AnelasticDynamics(ReferenceState(grid, c))      # default_dynamics

@@ -94,7 +94,7 @@ typedef struct bz_ctx bz_ctx;
 
 /* dynamics_pressure_solver + materialize_advection: builds FFT plans, tridiagonal factors and
  * column tables.  weno_order: 5 (the tuned kernels), or 7 / 9 (WENO(order = 7 | 9), the examples' scheme: generic kernels, halos >=
- * (order + 1) / 2, anelastic or compressible model without tracers / bounds (Kessler: compressible only), operator-by-operator anelastic stepping; Centered(order = 2)
+ * (order + 1) / 2, anelastic or compressible model without bounds-preserving advection, operator-by-operator anelastic stepping; Centered(order = 2)
  * is weno_order = 2 of libbreeze_hip_centered2.so); topology (Periodic, Periodic, Bounded) or — single-GPU contexts —
  * (Periodic, Flat, Bounded) with Ny = 1, Hy = 0 (the reference's 2-D x-z cases, anelastic and compressible); halos >= 3, Float64; every extent at least its
  * halo (Oceananigans' own N >= H rule — the reference's 4 x 4 x 4 smoke-test boxes work, odd extents too); anything else returns

@@ -206,3 +206,53 @@ def test_compressible_kessler_steps_match_oracle(oracle, bz, order):
         hm.time_step(2.0)
     tc.cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rw", "T", "p"), 2e-8)
     assert np.abs(og.interior(om.rw, True)).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [7, 9])
+def test_anelastic_kessler_and_tracers_with_high_order_weno(oracle, bz, order):
+    """The remaining scalars through the generic kernels: DCMIP2016 Kessler species and user tracers on the anelastic core."""
+    size, extent = (16, 12, 20), ((0.0, 4e3), (0.0, 3e3), (0.0, 5e3))
+    og = oracle.Grid(size, x=extent[0], y=extent[1], z=extent[2], halo=(5, 5, 5))
+    om = oracle.OracleModel(og, surface_pressure=1e5, potential_temperature=300.0, microphysics="Kessler", advection=f"WENO{order}")
+    grid = bz.RectilinearGrid(size, x=extent[0], y=extent[1], z=extent[2], halo=(5, 5, 5))
+    tc = bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula())
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, tc, surface_pressure=1e5, potential_temperature=300.0)),
+                            advection=bz.WENO(order=order), thermodynamic_constants=tc, microphysics=bz.DCMIP2016KesslerMicrophysics())
+    bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt((x - 2e3) ** 2 + (y - 1.5e3) ** 2 + (z - 1500.0) ** 2) / 1200.0)
+    ic = dict(qt=lambda x, y, z: 0.016 * np.exp(-z / 3000.0) + 0.004 * bub(x, y, z), theta=lambda x, y, z: 300.0 + 0.004 * z + 1.0 * bub(x, y, z),
+              qcl=lambda x, y, z: 0.003 * bub(x, y, z), qr=lambda x, y, z: 0.001 * bub(x, y, z), u=2.0)
+    om.set(**ic)
+    hm.set(qᵗ=ic["qt"], θ=ic["theta"], qcl=ic["qcl"], qr=ic["qr"], u=ic["u"])
+    for _ in range(2):
+        om.time_step(5.0)
+        hm.time_step(5.0)
+    hm.synchronize()
+    g, μ = om.grid, hm.microphysical_fields
+    mom = max(np.abs(g.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rv", "rw"))
+    for n, f in (("ru", hm.momentum["ρu"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density), ("rq", hm.moisture_density),
+                 ("rqcl", μ["ρqᶜˡ"]), ("rqr", μ["ρqʳ"]), ("T", hm.temperature)):
+        want = g.interior(getattr(om, n), n == "rw")
+        scale = mom if n in ("ru", "rw") else max(np.abs(want).max(), 1e-6)
+        # the Kessler threshold branches amplify last-digit differences about tenfold (order 5: 1e-8 against 1e-9 for the dry model)
+        assert np.abs(f.interior_cpu() - want).max() / scale < 2e-7, n
+    # tracers
+    og = oracle.Grid((32, 20, 16), x=(-4e3, 4e3), y=(-3e3, 3e3), z=(0.0, 8e3), halo=(5, 5, 5))
+    om = oracle.OracleModel(og, potential_temperature=300.0, tracers=2, advection=f"WENO{order}")
+    grid = bz.RectilinearGrid((32, 20, 16), x=(-4e3, 4e3), y=(-3e3, 3e3), z=(0.0, 8e3), halo=(5, 5, 5))
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO(order=order),
+                            tracers=("a", "b"))
+    th = bubble_theta(300.0, 9.81, r0=2e3, zc=2500.0)
+    a = lambda x, y, z: np.sin(2 * np.pi * x / 8e3) * np.exp(-z / 4e3) + 0 * y
+    b = lambda x, y, z: 1.0 + 0.5 * np.cos(2 * np.pi * y / 6e3) * (z / 8e3) + 0 * x
+    om.set(theta=th, u=3.0, rc0=a, rc1=b)
+    hm.tracers["a"].set_interior(a)
+    hm.tracers["b"].set_interior(b)
+    hm.set(θ=th, u=3.0)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    for n, k in (("rc0", "a"), ("rc1", "b")):
+        want = og.interior(getattr(om, n))
+        assert np.abs(hm.tracers[k].interior_cpu() - want).max() < 2e-8 * np.abs(want).max(), n

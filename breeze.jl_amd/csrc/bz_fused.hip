@@ -284,13 +284,18 @@ int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognosti
     L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;
     L.blk = (long long)g.Nz * L.nkx * g.Ny;
     double2 *out = (double2 *)(hat ? hat : (double *)ctx->d_hat);
-    if (s || predictor)
-        hipLaunchKernelGGL(k_x_forward<1>, grid, block, lds, ctx->stream, g, (const double *)nullptr,
-                           predictor ? predictor->rho_u : s->rho_u, predictor ? predictor->rho_v : s->rho_v,
-                           predictor ? predictor->rho_w : s->rho_w, dt, out, L, (const double2 *)ctx->d_wtab, kc);
-    else
-        hipLaunchKernelGGL(k_x_forward<0>, grid, block, lds, ctx->stream, g, rhs ? rhs : (const double *)ctx->d_rhs, (const double *)nullptr,
-                           (const double *)nullptr, (const double *)nullptr, dt, out, L, (const double2 *)ctx->d_wtab, kc);
+    const double *pu = predictor ? predictor->rho_u : s ? s->rho_u : nullptr, *pv = predictor ? predictor->rho_v : s ? s->rho_v : nullptr,
+                 *pw = predictor ? predictor->rho_w : s ? s->rho_w : nullptr;
+    const double *rows = (s || predictor) ? nullptr : (rhs ? rhs : (const double *)ctx->d_rhs);
+    const double2 *W = (const double2 *)ctx->d_wtab;
+    if (n2 / 4 > 64) {      // Nx = 1024: teams of two wavefronts, 78 KB of LDS per workgroup
+        static bool once[2] = {false, false};
+        if (!once[0]) { BZ_HIP(hipFuncSetAttribute((const void *)k_x_forward<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once[0] = true; }
+        if (!once[1]) { BZ_HIP(hipFuncSetAttribute((const void *)k_x_forward<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once[1] = true; }
+        if (rows) hipLaunchKernelGGL((k_x_forward<0, 2>), grid, block, lds, ctx->stream, g, rows, pu, pv, pw, dt, out, L, W, kc);
+        else hipLaunchKernelGGL((k_x_forward<1, 2>), grid, block, lds, ctx->stream, g, rows, pu, pv, pw, dt, out, L, W, kc);
+    } else if (rows) hipLaunchKernelGGL((k_x_forward<0, 1>), grid, block, lds, ctx->stream, g, rows, pu, pv, pw, dt, out, L, W, kc);
+    else hipLaunchKernelGGL((k_x_forward<1, 1>), grid, block, lds, ctx->stream, g, rows, pu, pv, pw, dt, out, L, W, kc);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -307,7 +312,12 @@ int bzi_xf_inverse(bz_ctx *ctx, const double *hat, double *phi, int blocks)
     const double2 *in = (const double2 *)(hat ? hat : (const double *)ctx->d_hat);
     double *out = phi ? phi : ctx->d_rhs;
     const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
-    hipLaunchKernelGGL(k_x_inverse, grid, block, xf_lds_bytes(n2), ctx->stream, g, in, L, out, (const double2 *)ctx->d_wtab, kc);
+    const size_t lds = xf_lds_bytes(n2);
+    if (n2 / 4 > 64) {
+        static bool once = false;
+        if (!once) { BZ_HIP(hipFuncSetAttribute((const void *)k_x_inverse<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        hipLaunchKernelGGL(k_x_inverse<2>, grid, block, lds, ctx->stream, g, in, L, out, (const double2 *)ctx->d_wtab, kc);
+    } else hipLaunchKernelGGL(k_x_inverse<1>, grid, block, lds, ctx->stream, g, in, L, out, (const double2 *)ctx->d_wtab, kc);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -343,9 +343,9 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     const int Nx = g.Nx, Nz = g.Nz, Hz = g.Hz;
     const bool slab = ctx->slab_mode;
     const int nxh_real = Nx / 2 + 1;
-    // hand-written x transforms + transposed spectrum: Nx a power of two in [16, 512] (one team of Nx / 8 <= 64 threads per row, 8 rows per
+    // hand-written x transforms + transposed spectrum: Nx a power of two in [16, 1024] (one team of Nx / 8 <= 128 threads per row, 8 rows per
     // workgroup in 45 KiB of LDS)
-    const bool xf_shape = Nx >= 16 && Nx <= 512 && (Nx & (Nx - 1)) == 0 && g.Ny % 8 == 0 && !getenv("BZ_NO_XFFT");
+    const bool xf_shape = Nx >= 16 && Nx <= 1024 && (Nx & (Nx - 1)) == 0 && g.Ny % 8 == 0 && !getenv("BZ_NO_XFFT");
     ctx->xf = !slab && xf_shape && g.wrap_y;
     ctx->xf_slab = slab && xf_shape;
     int Ny = g.Ny;                       // rows of the spectral block: local rows, or ALL rows in slab mode

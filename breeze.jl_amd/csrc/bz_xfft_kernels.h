@@ -35,7 +35,7 @@ __device__ __forceinline__ int xf_slot(int p, int n2)
 #define XF_P(p) xf_slot((p), n2)
 #define XF_ROW_STRIDE(n2) ((n2) + 4)
 
-// A team (Nx / 8 <= 64 threads) sits inside one wavefront and a row's transform touches that row only, so the stages need ordering
+// A team of Nx / 8 <= 64 threads sits inside one wavefront and a row's transform touches that row only, so the stages need ordering
 // inside the wave, not a workgroup barrier: LDS instructions of one wave execute in order; the fences keep the compiler from moving
 // LDS accesses across the point.  Workgroup barriers remain where rows change hands (transposed loads / stores).
 __device__ __forceinline__ void xf_wave_sync()
@@ -45,12 +45,21 @@ __device__ __forceinline__ void xf_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// TW = wavefronts per team: rows of 1024 cells have teams of 128 threads, whose stages need the workgroup barrier (every team of the
+// workgroup runs the same sequence of stages, so the barrier is reached uniformly)
+template <int TW>
+__device__ __forceinline__ void xf_sync()
+{
+    if (TW == 1) xf_wave_sync();
+    else __syncthreads();
+}
+
 __device__ __forceinline__ double2 xf_cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // In-place complex transform of length n2 (a power of two >= 8) of `row` by the team's T = n2 / 4 threads (tid = 0 .. T-1).
 // Wave-level ordering only (xf_wave_sync): callers put a workgroup barrier where other waves' data is involved.
 // INV: conjugated twiddles (unnormalised inverse).
-template <bool INV>
+template <bool INV, int TW = 1>
 __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, int tid, bool active, const double2 *__restrict__ W)
 {
     const int T = n2 >> 2;
@@ -76,9 +85,9 @@ __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, i
             o3 = make_double2(a1.x - a3.x, a1.y - a3.y);
             j0 = ((tid - k) << 2) + k;
         }
-        xf_wave_sync();
+        xf_sync<TW>();
         if (active) { row[XF_P(j0)] = o0; row[XF_P(j0 + Ns)] = o1; row[XF_P(j0 + 2 * Ns)] = o2; row[XF_P(j0 + 3 * Ns)] = o3; }
-        xf_wave_sync();
+        xf_sync<TW>();
     }
     if (Ns < n2) {      // n2 = 2 Ns: two radix-2 butterflies per thread, outputs land on their own inputs
         if (active) {
@@ -92,7 +101,7 @@ __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, i
                 row[XF_P(b + Ns)] = make_double2(u0.x - u1.x, u0.y - u1.y);
             }
         }
-        xf_wave_sync();
+        xf_sync<TW>();
     }
 }
 
@@ -156,8 +165,8 @@ __device__ __forceinline__ long long xf_addr(const XfLayout &L, int Ny, int k, i
 // grid (Ny / XF_RB, ceil(Nz / kchunk)), block XF_RB * Nx / 8, dynamic LDS (XF_RB * (n2 + 4) + 3 n2 / 2) * sizeof(double2).
 // Thread (row r, tid) owns the cell pairs i = 2 (tid + q Nx / 8), i + 1, q = 0 .. 3 — the four packed complex elements its first
 // butterfly reads; wlo carries rho_w of the lower faces from the previous level's upper faces (the block marches in z).
-template <int SRC>
-__global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const double *__restrict__ rhs, const double *__restrict__ ru,
+template <int SRC, int TW = 1>
+__global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_forward(DevGrid g, const double *__restrict__ rhs, const double *__restrict__ ru,
                                                           const double *__restrict__ rv, const double *__restrict__ rw, double dt,
                                                           double2 *__restrict__ hatT, XfLayout L, const double2 *__restrict__ Wg, int kchunk)
 {
@@ -206,8 +215,8 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const doubl
                 row[XF_P(tid + T * q)] = *(const double2 *)(rhs + m);           // i even, Nx even: 16-byte aligned
             }
         }
-        xf_wave_sync();
-        xf_team_fft<false>(row, n2, tid, true, W);
+        xf_sync<TW>();
+        xf_team_fft<false, TW>(row, n2, tid, true, W);
         xf_split_forward(row, n2, tid, W);
         __syncthreads();                                   // rows change hands: the transposed store reads all of them
         for (int e = threadIdx.x; e < L.nxp * XF_RB; e += nthreads) {
@@ -220,7 +229,8 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_forward(DevGrid g, const doubl
 
 // Transposed half spectrum -> rows of phi in the contiguous buffer phi_c (Nx * Ny * Nz).  Same grid, block and LDS as k_x_forward.
 // (16 rows per workgroup — 256-byte segments per kx — measured the same 0.54 ms per launch at 512^3 as 8 rows: not the segment size.)
-__global__ __launch_bounds__(XF_RB * 64) void k_x_inverse(DevGrid g, const double2 *__restrict__ hatT, XfLayout L, double *__restrict__ phi_c,
+template <int TW = 1>
+__global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_inverse(DevGrid g, const double2 *__restrict__ hatT, XfLayout L, double *__restrict__ phi_c,
                                                           const double2 *__restrict__ Wg, int kchunk)
 {
     extern __shared__ double2 xf_sm[];
@@ -239,8 +249,8 @@ __global__ __launch_bounds__(XF_RB * 64) void k_x_inverse(DevGrid g, const doubl
         }
         __syncthreads();                                   // rows loaded by all waves
         xf_split_inverse(row, n2, tid, W);
-        xf_wave_sync();
-        xf_team_fft<true>(row, n2, tid, true, W);
+        xf_sync<TW>();
+        xf_team_fft<true, TW>(row, n2, tid, true, W);
         {   // every team stores its own row: 16-byte elements, consecutive lanes
             double *dst = phi_c + (long long)Nx * ((long long)(j0 + r) + (long long)g.Ny * k);
 #pragma unroll

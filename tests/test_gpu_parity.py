@@ -142,9 +142,9 @@ def test_time_steps_match_oracle(oracle, bz, size, dt):
     assert np.isfinite(hm.velocities["w"].cpu()).all()
 
 
-@pytest.mark.parametrize("size", [(16, 8, 6), (32, 16, 5), (64, 8, 12), (128, 24, 9), (256, 8, 4), (512, 8, 3)])
+@pytest.mark.parametrize("size", [(16, 8, 6), (32, 16, 5), (64, 8, 12), (128, 24, 9), (256, 8, 4), (512, 8, 3), (1024, 8, 3)])
 def test_fused_x_transform_pipeline_matches_oracle(oracle, bz, size):
-    """Hand-written x transforms + transposed half spectrum (csrc/bz_xfft_kernels.h; taken when Nx is a power of two in [16, 512]
+    """Hand-written x transforms + transposed half spectrum (csrc/bz_xfft_kernels.h; taken when Nx is a power of two in [16, 1024]
     and Ny % 8 == 0): every radix mix (Nx/2 = 4^m and 2 * 4^m).  Per-operator solve (rows of the rhs buffer in, phi out) and whole
     steps (source term evaluated inside the forward pass, stage 1-2 projection inside the inverse pass) against the oracle, whose
     transforms are pocketfft's complex ones — same tolerances as the library-transform path."""
@@ -170,10 +170,11 @@ def test_fused_x_transform_pipeline_matches_oracle(oracle, bz, size):
         om.time_step(1.0)
         hm.time_step(1.0)
     hm.synchronize()
+    mom = max(np.max(np.abs(_interior(om, n))) for n in ("ru", "rv", "rw"))      # the components of a vector share its scale
     for n, k in PROG.items():
         got = hm.prognostic_fields()[k].interior_cpu()
         want = _interior(om, n)
-        scale = max(np.max(np.abs(want)), 1e-3)
+        scale = mom if n in ("ru", "rv", "rw") else max(np.max(np.abs(want)), 1e-3)
         assert np.max(np.abs(got - want)) / scale < 1e-9, n
     for n, f in (("u", hm.velocities["u"]), ("theta", hm.potential_temperature), ("T", hm.temperature), ("rv", hm.momentum["ρv"])):
         assert relerr(f.cpu(), getattr(om, n)) < 1e-9, n        # whole parent arrays: the fused projection stores the halo images

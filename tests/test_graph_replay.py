@@ -97,3 +97,24 @@ def test_compressible_kessler_replay_is_bit_identical(bz):
               qᵗ=lambda x, y, z: np.vectorize(qvb)(z) + 0.003 * bub(x, y, z) + 0 * x + 0 * y)
         return m
     _check(make, steps=5)
+
+
+def test_replay_on_a_non_default_stream(bz):
+    """The context follows PyTorch's current stream (bz_set_stream); recording happens on the library's own stream and the replay is
+    enqueued on the caller's, also when that is not the legacy default stream."""
+    import torch
+    out = []
+    for graph in (True, False):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            g = bz.RectilinearGrid((32, 16, 16), x=(-4e3, 4e3), y=(-2e3, 2e3), z=(0.0, 8e3))
+            m = bz.AtmosphereModel(g, dynamics=bz.AnelasticDynamics(bz.ReferenceState(g, potential_temperature=300.0)), advection=bz.WENO(order=5))
+            m.set(θ=bubble_theta(300.0, 9.81, r0=2e3, zc=2500.0), u=2.0)
+            m.graph_enable(graph)
+            for _ in range(5):
+                m.time_step(2.0)
+            m.synchronize()
+            torch.cuda.current_stream().synchronize()
+            out.append(({k: f.interior_cpu().copy() for k, f in m.prognostic_fields().items()}, m.graph_info()))
+    assert out[0][1][1] == 1 and out[0][1][2] == 3, out[0][1]
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k

@@ -220,7 +220,7 @@ struct LocalTransport : Transport {
 
 // ---- the communicator of a context ----------------------------------------------------------------------------------------------
 #define BZ_COMM_MAX_FIELDS 24
-static_assert(BZ_COMM_MAX_FIELDS >= 14 + BZ_MAX_TRACERS, "a stage exchange carries 14 model fields and every user tracer");
+static_assert(BZ_COMM_MAX_FIELDS >= 16 + BZ_MAX_TRACERS, "a stage exchange carries up to 16 model fields and every user tracer");
 struct BzComm {
     Transport *T = nullptr;
     int W = 1, rank = 0, upper = 0, lower = 0;
@@ -556,6 +556,10 @@ static int state_halo_exchange(bz_ctx *ctx, const bz_state *s, double *pa, doubl
         for (int m = 0; m < 5; ++m) { f[n] = d[m]; lev[n] = dl[m]; ++n; }
         if (ctx->has_closure || g.microphysics == 1) { f[n] = s->T; lev[n++] = nc; }      // the viscosity kernel covers the rows next to the slab
         if (g.microphysics == 1) { f[n] = g.qv_field; lev[n++] = nc; f[n] = g.ql_field; lev[n++] = nc; }
+        if (g.microphysics == 2) {      // the Kessler species are advected as specific fields
+            f[n] = ctx->kessler.cloud_liquid_mass_fraction; lev[n++] = nc;
+            f[n] = ctx->kessler.rain_mass_fraction; lev[n++] = nc;
+        }
         for (int t = 0; t < ctx->n_tracers; ++t) { f[n] = ctx->tracers[t].specific; lev[n++] = nc; }
     }
     return halo_exchange(ctx, f, lev, n, g.Hy, true, true, st);
@@ -567,6 +571,7 @@ extern "C" int bz_comm_update_state_and_project(bz_ctx *ctx, const bz_state *s, 
     if (!ctx || !ctx->comm || !s) return BZ_ERR_INVALID;
     int rc = bz_update_state(ctx, s, G, 0);                      // x / z halos and diagnostics locally
     if (rc) return rc;
+    ctx->G_is_predictor = true;                                  // the state changed and no tendencies were computed: G is stale
     {
         ProfileScope ps(ctx, "comm_halo_exchange");
         if ((rc = state_halo_exchange(ctx, s, s->rho_theta, s->rho_q, true, ctx->stream))) return rc;
@@ -624,14 +629,51 @@ int bzi_comm_allreduce_sum(bz_ctx *ctx, double *buf, int n)
 // slab decomposition: per stage the tendency kernels with the RK update folded in, the closure (its viscosity kernel covers one row
 // beyond each slab edge, so nu_e needs no exchange), the forcing stack (horizontal averages all-reduced over the ranks), bottom fluxes,
 // the distributed pressure solve + projection + diagnosis, and one y-halo exchange of everything the next stage's stencils read.
+// Operator-by-operator distributed step: the reference's own call order (ssp_runge_kutta_3.jl:223-270) with the exchanges of
+// bz_comm_update_state_and_project in place of the local halo fills.  Every model option the single-GPU per-operator tier runs takes
+// this path on slabs when the fused tiers do not apply: StaticEnergy, Kessler species, bounds-preserving advection, WENO(order = 7 / 9).
+static int dist_time_step_operators(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
+{
+    const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};
+    int rc;
+    if (ctx->G_is_predictor && (rc = bz_compute_tendencies(ctx, s, G))) return rc;      // state and halos are current since the last step's end
+    if ((rc = bz_store_initial_state(ctx, s, U0))) return rc;
+    for (int stage = 0; stage < 3; ++stage) {
+        const double alpha = alphas[stage];
+        if ((rc = bz_compute_flux_bc_tendencies(ctx, s, G))) return rc;
+        if ((rc = bz_ssp_rk3_substep(ctx, s, U0, G, dt, alpha))) return rc;
+        // pressure solve with its all-to-alls, projection + diagnostics in one kernel, exchange.  The diagnostics run ONCE per stage, as
+        // in update_state!: with Kessler species the temperature is diagnosed from the condensate fractions of the previous update
+        // (dcmip2016_kessler.jl:222-227 — the microphysical fields are refreshed after the thermodynamic variables), so a second
+        // diagnosis in the same stage would not reproduce the reference
+        if ((rc = dist_projection(ctx, s, nullptr, alpha * dt, false, nullptr, nullptr, nullptr, nullptr))) return rc;
+        {
+            ProfileScope ps(ctx, "comm_halo_exchange");
+            if ((rc = state_halo_exchange(ctx, s, s->rho_theta, s->rho_q, true, ctx->stream))) return rc;
+        }
+        if ((rc = bz_compute_tendencies(ctx, s, G))) return rc;
+    }
+    if (ctx->dg.microphysics == 2) {      // microphysics_model_update! closes the step: rank-local columns, then update_state! with exchanges
+        const bz_kessler_model_fields &K = ctx->kessler;
+        bz_kessler_fields F;
+        F.density = nullptr; F.pressure = nullptr;
+        F.potential_temperature = s->theta; F.potential_temperature_density = s->rho_theta;
+        F.moisture_density = s->rho_q; F.cloud_liquid_density = K.cloud_liquid_density; F.rain_density = K.rain_density;
+        F.vapor_mass_fraction = K.vapor_mass_fraction; F.cloud_liquid_mass_fraction = K.cloud_liquid_mass_fraction;
+        F.rain_mass_fraction = K.rain_mass_fraction; F.rain_terminal_velocity = K.rain_terminal_velocity;
+        F.precipitation_rate = K.precipitation_rate;
+        if ((rc = bz_kessler_microphysics_update(ctx, &ctx->kessler_params, &F, dt, ctx->kessler_pst))) return rc;
+        if ((rc = bz_comm_update_state_and_project(ctx, s, G, dt, 0))) return rc;
+        if ((rc = bz_compute_tendencies(ctx, s, G))) return rc;
+    }
+    return BZ_OK;
+}
+
 static int dist_time_step_general(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
 {
     const DevGrid &g = ctx->dg;
-    if (!(ctx->fused_ok && ctx->fuse_rk && g.formulation == 0 && g.microphysics != 2 && !ctx->bounded_mask)) {
-        ctx->last_error = "bz_time_step_anelastic on y-slabs implements the potential-temperature model (optionally with saturation "
-                          "adjustment, SmagorinskyLilly, column forcings, bottom fluxes, tracers): no Kessler species or bounds";
-        return BZ_ERR_UNSUPPORTED;
-    }
+    if (!(ctx->fused_ok && ctx->fuse_rk && g.formulation == 0 && g.microphysics != 2 && !ctx->bounded_mask && ctx->weno_R == 3))
+        return dist_time_step_operators(ctx, s, U0, G, dt);
     const int32_t nc = g.Nz + 2 * g.Hz, nf = nc + 1;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};
     int rc;

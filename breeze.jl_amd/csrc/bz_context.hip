@@ -167,7 +167,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
 #else
     // 5: the tuned path; 7, 9: generic kernels (bz_tendency_generic.hip), anelastic single-GPU contexts, halos >= (order + 1) / 2
     if (weno_order != 5 && weno_order != 7 && weno_order != 9) return BZ_ERR_UNSUPPORTED;
-    if (weno_order != 5 && slab_mode && !compressible) return BZ_ERR_UNSUPPORTED;      // the anelastic slab steps are the order-5 fused tiers
+    
     const int weno_R = (weno_order + 1) / 2;
     if (grid->Hx < weno_R || (grid->topo[1] != BZ_FLAT && grid->Hy < weno_R) || grid->Hz < weno_R) return BZ_ERR_UNSUPPORTED;
 #endif

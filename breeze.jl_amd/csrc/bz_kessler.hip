@@ -207,8 +207,8 @@ extern "C" int bz_set_kessler_microphysics(bz_ctx *ctx, const bz_kessler_microph
         !f->G_cloud_liquid_density || !f->G_rain_density || !f->vapor_mass_fraction || !f->cloud_liquid_mass_fraction ||
         !f->rain_mass_fraction || !f->rain_terminal_velocity || !f->precipitation_rate)
         return BZ_ERR_INVALID;
-    if (g.formulation != 0 || (ctx->slab_mode && !ctx->compressible)) {
-        ctx->last_error = "Kessler microphysics is attached to potential-temperature models: single-GPU anelastic, or compressible (also on y-slabs)";
+    if (g.formulation != 0) {
+        ctx->last_error = "Kessler microphysics is attached to potential-temperature models";
         return BZ_ERR_UNSUPPORTED;
     }
     ctx->kessler_params = *params;

@@ -321,8 +321,9 @@ class LibrarySlabAtmosphereModel(AtmosphereModel):
     """AtmosphereModel on one y-slab with the library-owned communicator (transport "rccl" or "local:<name>"): every component
     AtmosphereModel wires up — saturation adjustment, SmagorinskyLilly, column forcings, bottom fluxes, the physics list of
     BASELINE configs[2] — runs decomposed; `time_step` is one C call per step and rank (csrc/bz_comm.hip: the lean seam for the
-    dry / vapour model; otherwise the fused-RK tier with halo exchanges, all-reduced horizontal averages and a viscosity kernel
-    that covers the rows next to the slab)."""
+    dry / vapour model; the fused-RK tier with halo exchanges, all-reduced horizontal averages and a viscosity kernel that covers
+    the rows next to the slab for the BOMEX list and tracers; an operator-by-operator distributed step for StaticEnergy, Kessler
+    species and WENO(order = 7 / 9))."""
 
     def __init__(self, global_grid, rank, world, transport="rccl", group=None, surface_pressure=101325, potential_temperature=288,
                  standard_pressure=1e5, thermodynamic_constants=None, device=None, **kw):

@@ -283,3 +283,82 @@ def test_tracers_on_library_slabs_match_the_oracle(bz, oracle, world):
     want = og.interior(om.rtheta)
     got = np.concatenate([m.potential_temperature_density.interior_cpu() for m in models], axis=1)
     assert np.abs(got - want).max() < 1e-10 * np.abs(want).max()
+
+
+def _library_slabs(bz, G, world, make_kwargs, setter, steps, dt):
+    import torch
+    from breeze_jl_amd import distributed as bz_dist
+    group = "local:" + uuid.uuid4().hex
+    models, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                m = bz_dist.LibrarySlabAtmosphereModel(G, rank, world, transport=group, device="cuda:0", **make_kwargs())
+                Ny = G.Ny // world
+                setter(m, slice(rank * Ny, (rank + 1) * Ny))
+                for _ in range(steps):
+                    m.time_step(dt)
+                m.synchronize()
+            models[rank] = m
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    return models
+
+
+@pytest.mark.parametrize("case", ["weno9", "static_energy", "kessler"])
+def test_operator_by_operator_slab_step_matches_the_oracle(bz, oracle, case):
+    """Model options outside the fused tiers take the operator-by-operator distributed step (bz_comm.hip: dist_time_step_operators — the
+    reference's call order with the library's exchanges in place of the local halo fills): WENO(order = 9), formulation = :StaticEnergy
+    and DCMIP2016 Kessler species on the anelastic core, two ranks, against the single-process oracle."""
+    world, steps = 2, 2
+    if case == "kessler":
+        size, ext, dt = (16, 16, 20), ((0.0, 4e3), (0.0, 4e3), (0.0, 5e3)), 5.0
+        og = oracle.Grid(size, x=ext[0], y=ext[1], z=ext[2])
+        om = oracle.OracleModel(og, surface_pressure=1e5, potential_temperature=300.0, microphysics="Kessler")
+        G = bz.RectilinearGrid(size, x=ext[0], y=ext[1], z=ext[2])
+        tc = bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula())
+        mk = lambda: dict(surface_pressure=1e5, potential_temperature=300.0, advection=bz.WENO(order=5), thermodynamic_constants=tc,
+                          microphysics=bz.DCMIP2016KesslerMicrophysics())
+        bub = lambda x, y, z: np.maximum(0.0, 1.0 - np.sqrt((x - 2e3) ** 2 + (y - 2e3) ** 2 + (z - 1500.0) ** 2) / 1200.0)
+        ic = dict(qt=lambda x, y, z: 0.016 * np.exp(-z / 3000.0) + 0.004 * bub(x, y, z), theta=lambda x, y, z: 300.0 + 0.004 * z + 1.0 * bub(x, y, z),
+                  qcl=lambda x, y, z: 0.003 * bub(x, y, z), qr=lambda x, y, z: 0.001 * bub(x, y, z), u=2.0, v=-1.0)
+        om.set(**ic)
+        x, y, z = og.nodes("ccc")
+        full = {k: (np.broadcast_to(v(x, y, z), (size[2], size[1], size[0])).copy() if callable(v) else v) for k, v in ic.items()}
+        setter = lambda m, sl: m.set(qᵗ=full["qt"][:, sl, :], θ=full["theta"][:, sl, :], qcl=full["qcl"][:, sl, :], qr=full["qr"][:, sl, :], u=2.0, v=-1.0)
+        names, tol = ("ru", "rv", "rw", "rtheta", "rq", "T"), 1e-8
+    else:
+        order = 9 if case == "weno9" else 5
+        size, dt = (32, 24, 16), 2.0
+        halo = (5, 5, 5) if order == 9 else (3, 3, 3)
+        og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2], halo=halo)
+        form = "StaticEnergy" if case == "static_energy" else "LiquidIcePotentialTemperature"
+        om = oracle.OracleModel(og, potential_temperature=300.0, advection=f"WENO{order}", formulation=form)
+        G = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2], halo=halo)
+        mk = lambda: dict(potential_temperature=300.0, advection=bz.WENO(order=order), formulation=form)
+        om.set(theta=theta_ic, u=3.0, v=-2.0)
+        x, y, z = og.nodes("ccc")
+        th = np.broadcast_to(theta_ic(x, y, z), (size[2], size[1], size[0])).copy()
+        setter = lambda m, sl: m.set(θ=th[:, sl, :], u=3.0, v=-2.0)
+        names, tol = ("ru", "rv", "rw", "rtheta", "T"), (2e-8 if order == 9 else 1e-9)
+    for _ in range(steps):
+        om.time_step(dt)
+    models = _library_slabs(bz, G, world, mk, setter, steps, dt)
+    get = dict(FIELDS)
+    get["rtheta"] = lambda m: (m.energy_density if case == "static_energy" else m.potential_temperature_density)
+    mom = max(np.abs(og.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    for name in names:
+        got = np.concatenate([get[name](m).interior_cpu() for m in models], axis=1)
+        want = og.interior(getattr(om, name), zface=(name == "rw"))
+        scale = mom if name in ("ru", "rv", "rw") else max(np.max(np.abs(want)), 1e-3)
+        assert np.max(np.abs(got - want)) / scale < tol, (case, name, np.max(np.abs(got - want)) / scale)

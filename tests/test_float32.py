@@ -319,3 +319,55 @@ def test_float32_order_nine_compressible_kessler_matches_the_float64_oracle(orac
         worst[n] = np.abs(f.interior_cpu().astype(np.float64) - want).max() / (mom if n in ("ru", "rw") else np.abs(want).max())
     print("float32 WENO9 compressible Kessler:", {k: f"{v:.1e}" for k, v in worst.items()})
     assert max(worst.values()) < 1e-4, worst
+
+
+@pytest.mark.gpu
+def test_float32_library_slabs_match_the_float64_oracle(oracle, bz):
+    """Float32 on y-slabs: the Float32 twin's own communicator (messages of 4-byte reals), two ranks sharing the GPU through the in-process
+    transport, the dry bubble through the lean distributed step against the Float64 oracle at 1e-4."""
+    import threading
+    import uuid
+    import torch
+    from breeze_jl_amd import distributed as bz_dist
+    size = (32, 24, 16)
+    og = oracle.Grid(size, x=EXT[0], y=EXT[1], z=EXT[2])
+    om = oracle.OracleModel(og, potential_temperature=300.0)
+    th = bubble_theta(300.0, om.constants.g)
+    om.set(theta=th, u=3.0, v=-2.0)
+    for _ in range(3):
+        om.time_step(2.0)
+    G = bz.RectilinearGrid(size, x=EXT[0], y=EXT[1], z=EXT[2], float_type=np.float32)
+    x, y, z = og.nodes("ccc")
+    full = np.broadcast_to(th(x, y, z), (size[2], size[1], size[0])).copy()
+    world, group = 2, "local:" + uuid.uuid4().hex
+    models, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                m = bz_dist.LibrarySlabAtmosphereModel(G, rank, world, transport=group, device="cuda:0", potential_temperature=300.0, advection=bz.WENO())
+                Ny = size[1] // world
+                m.set(θ=full[:, rank * Ny:(rank + 1) * Ny, :], u=3.0, v=-2.0)
+                for _ in range(3):
+                    m.time_step(2.0)
+                m.synchronize()
+            models[rank] = m
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    mom = max(np.abs(og.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rv", "rw"))
+    for n, k in PROG.items():
+        if n == "rq":
+            continue
+        got = np.concatenate([m.prognostic_fields()[k].interior_cpu().astype(np.float64) for m in models], axis=1)
+        want = og.interior(getattr(om, n), n == "rw")
+        scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() / scale < 1e-4, (n, np.abs(got - want).max() / scale)

@@ -71,8 +71,8 @@ extern "C" int bz_set_bounds_preserving_advection(bz_ctx *ctx, const bz_bounds_p
     if (!ctx) return BZ_ERR_INVALID;
     if (!b) { ctx->bounded_mask = 0; return BZ_OK; }
     if (!(b->upper > b->lower)) return BZ_ERR_INVALID;
-    if (ctx->compressible || ctx->slab_mode) {
-        ctx->last_error = "bz_set_bounds_preserving_advection: implemented for the single-device anelastic model";
+    if (ctx->compressible) {
+        ctx->last_error = "bz_set_bounds_preserving_advection: implemented for the anelastic model";
         return BZ_ERR_UNSUPPORTED;
     }
 #ifdef BZ_CENTERED2

@@ -224,8 +224,8 @@ class AtmosphereModel:
         torch.cuda.set_device(self.device)
         self._T = T = _lib.types(grid.ftype)
         if grid.ftype == 4:
-            if not isinstance(advection, WENO) or self._bounded_advection is not None:
-                raise NotImplementedError("Float32 grids: WENO(order = 5 | 7 | 9) without bounds-preserving advection is wired up on the host side")
+            if not isinstance(advection, WENO):
+                raise NotImplementedError("Float32 grids: WENO(order = 5 | 7 | 9) is wired up on the host side")
             self._lib = lib = _lib.load_f32()
         else:
             self._lib = lib = _lib.load(advection.order)

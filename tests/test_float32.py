@@ -371,3 +371,27 @@ def test_float32_library_slabs_match_the_float64_oracle(oracle, bz):
         want = og.interior(getattr(om, n), n == "rw")
         scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
         assert np.abs(got - want).max() / scale < 1e-4, (n, np.abs(got - want).max() / scale)
+
+
+@pytest.mark.gpu
+def test_float32_bounded_moisture_steps_match_the_float64_oracle(oracle, bz):
+    """examples/rico.jl:40,184-190: Float32 + bounds-preserving WENO for the moisture density; three steps of the sharp-edged blob against the
+    Float64 oracle (1e-4 of each field's scale) and no overshoot beyond the limiter's own tolerance."""
+    import test_bounded_weno as tb
+    size = (24, 24, 20)
+    og = oracle.Grid(size, x=tb.EXT[0], y=tb.EXT[1], z=tb.EXT[2])
+    om = oracle.OracleModel(og, potential_temperature=300.0)
+    om.bounded = {"rq": (0.0, tb.QMAX)}
+    grid = bz.RectilinearGrid(size, x=tb.EXT[0], y=tb.EXT[1], z=tb.EXT[2], float_type=np.float32)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)),
+                            advection={"momentum": bz.WENO(), "ρθ": bz.WENO(), "ρqᵛ": bz.WENO(bounds=(0.0, tb.QMAX))})
+    th = bubble_theta(300.0, 9.81)
+    om.set(theta=th, u=12.0, v=-7.0, qt=tb._blob)
+    hm.set(θ=th, u=12.0, v=-7.0, qᵗ=tb._blob)
+    for _ in range(3):
+        om.time_step(5.0)
+        hm.time_step(5.0)
+    hm.synchronize()
+    e = _steps_errors(om, hm, [(n, hm.prognostic_fields()[k]) for n, k in PROG.items()])
+    print("float32 bounded:", {k: f"{v:.1e}" for k, v in e.items()})
+    assert max(e.values()) < 1e-4, e

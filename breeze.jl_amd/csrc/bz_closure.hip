@@ -179,6 +179,34 @@ __global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFi
     scalar(F.q, Gq);
 }
 
+// - div J^c of one more scalar (user tracers): the `scalar` part of k_closure_tendencies for a field of its own
+__global__ __launch_bounds__(256) void k_closure_scalar(DevGrid g, const double *__restrict__ nu, double rPr, const double *__restrict__ c,
+                                                        double *__restrict__ G, double scale)
+{
+    int bx, by, bz;
+    xcd_block(bx, by, bz);
+    const int i = bx * 256 + threadIdx.x, j = by, k = bz;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k), sy = g.Sx, sz = g.Sxy;
+    const long long oxm = (i == 0) ? (long long)(g.Nx - 1) : -1, oxp = (i == g.Nx - 1) ? -(long long)(g.Nx - 1) : 1;
+    const long long oym = ((j == 0 && g.wrap_y) ? (long long)(g.Ny - 1) : -1) * sy, oyp = ((j == g.Ny - 1 && g.wrap_y) ? -(long long)(g.Ny - 1) : 1) * sy;
+    const long long ozm = (k == 0) ? 0 : -sz, ozp = (k == g.Nz - 1) ? 0 : sz;
+    const double dx = g.dx, dy = g.dy, dz = g.dzc[k];
+    const double rVc = g.rdx * g.rdy * g.rdzc[k], rho = g.rho[k];
+    const double Ax = dy * dz, Ay = dx * dz, Az = dx * dy;
+    const double kc = nu[n] * rPr;
+    const double kxm = (nu[n + oxm] * rPr + kc) / 2, kxp = (kc + nu[n + oxp] * rPr) / 2;
+    const double kym = (nu[n + oym] * rPr + kc) / 2, kyp = (kc + nu[n + oyp] * rPr) / 2;
+    const double kzm = (nu[n + ozm] * rPr + kc) / 2, kzp = (kc + nu[n + ozp] * rPr) / 2;
+    const double c0 = c[n];
+    const double Jxm = rho * (-kxm * ((c0 - c[n - 1]) * g.rdx)), Jxp = rho * (-kxp * ((c[n + 1] - c0) * g.rdx));
+    const double Jym = rho * (-kym * ((c0 - c[n - sy]) * g.rdy)), Jyp = rho * (-kyp * ((c[n + sy] - c0) * g.rdy));
+    const double Jzm = (k == 0) ? 0.0 : g.rho_f[k] * (-kzm * ((c0 - c[n - sz]) * g.rdzf[k]));
+    const double Jzp = (k == g.Nz - 1) ? 0.0 : g.rho_f[k + 1] * (-kzp * ((c[n + sz] - c0) * g.rdzf[k + 1]));
+    const double div = (Ax * Jxp - Ax * Jxm) + (Ay * Jyp - Ay * Jym) + (Az * Jzp - Az * Jzm);
+    G[n] -= scale * (div * rVc);
+}
+
 extern "C" int bz_set_closure(bz_ctx *ctx, const bz_smagorinsky_lilly *closure, double *eddy_viscosity)
 {
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
@@ -244,6 +272,13 @@ int bzi_apply_closure(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, do
     ProfileScope ps(ctx, "closure_tendencies");
     hipLaunchKernelGGL(k_closure_tendencies, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g,
                        closure_fields(ctx, s), Gu, Gv, Gw, Gth, Gq, scale);
+    // user tracers diffuse like every other scalar.  The whole-step seam updates rho c in place (bzi_tracer_rk3), so there the
+    // divergence goes to the density array with the stage weight, exactly as for rho theta / rho q; per-operator callers pass scale = 1
+    // and the tendency arrays
+    const ClosureFields F = closure_fields(ctx, s);
+    for (int t = 0; t < ctx->n_tracers; ++t)
+        hipLaunchKernelGGL(k_closure_scalar, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, F.nu, 1.0 / F.Pr,
+                           (const double *)ctx->tracers[t].specific, (Gth == s->rho_theta) ? ctx->tracers[t].density : ctx->tracers[t].G, scale);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -253,8 +253,6 @@ class AtmosphereModel:
         tracers = (tracers,) if isinstance(tracers, str) else tuple(tracers)
         self.tracers = {str(n).lstrip(":"): fld("ccc") for n in tracers}
         self.specific_tracers = {n: fld("ccc") for n in self.tracers}
-        if self.tracers and closure is not None:
-            raise NotImplementedError("user tracers with a closure are not implemented")
         prog = self.prognostic_fields()
         self.U0 = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}     # timestepper.U⁰
         self.G = {k: Field(grid, f.loc, self.device) for k, f in prog.items()}      # timestepper.Gⁿ

@@ -166,7 +166,10 @@ def add_closure_tendencies(m):
             (Az * T33[1:] - Az * T33[:-1])
     g.interior(m.G["rw"], zface=True)[1:Nz] -= div_w / Vf
     # scalars
-    for name, field in (("rtheta", m.theta), ("rq", m.q)):
+    # every scalar of the model diffuses with kappa = nu_e / Pr (scalar_tendency: - div J^c for the thermodynamic variable, the moisture
+    # and each user tracer alike; update_atmosphere_model_state.jl:352-372)
+    scalars = [("rtheta", m.theta), ("rq", m.q)] + [(f"rc{t}", getattr(m, f"c{t}")) for t in range(getattr(m, "n_tracers", 0))]
+    for name, field in scalars:
         c = _pad_center(g, field)
         kap = nup / cl.Pr
         kx = (kap[1:-1, 1:-1, 0:Nx + 1] + kap[1:-1, 1:-1, 1:Nx + 2]) / 2                    # x faces 0..Nx

@@ -104,3 +104,27 @@ def test_rico_jl_advection_list(bz):
     model.synchronize()
     q = model.specific_moisture.interior_cpu()
     assert _finite(model) and q.min() >= -1e-7 and q.max() <= 1.0
+
+
+def test_cloudy_kelvin_helmholtz_jl(bz, oracle):
+    """examples/cloudy_kelvin_helmholtz.jl:33-40: 2-D (Periodic, Flat, Bounded), default dynamics, WENO(order = 5), SaturationAdjustment;
+    a sheared moist layer — here also against the oracle's Flat implementation (two steps, 1e-9)."""
+    size, ext = (96, 32), dict(x=(0.0, 10e3), z=(0.0, 3e3))
+    grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Flat, bz.Bounded), **ext)
+    model = bz.AtmosphereModel(grid, advection=bz.WENO(order=5), microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()))
+    θ0 = 288.0
+    θ = lambda x, z: θ0 * np.exp(1e-4 * z / 9.80665) + 0.01 * np.sin(2 * np.pi * x / 10e3) * np.exp(-((z - 1.5e3) / 200.0) ** 2)
+    u = lambda x, z: 5.0 * np.tanh((z - 1.5e3) / 150.0)
+    q = lambda x, z: 0.012 * np.exp(-z / 2500.0) * (1.0 + 0.5 * np.exp(-((z - 1.5e3) / 300.0) ** 2))
+    model.set(θ=θ, u=u, qᵗ=q)
+    og = oracle.Grid(size, topology=("Periodic", "Flat", "Bounded"), **ext)
+    om = oracle.OracleModel(og, microphysics="SaturationAdjustment")
+    om.set(theta=lambda x, y, z: θ(x, z) + 0 * y, u=lambda x, y, z: u(x, z) + 0 * y, qt=lambda x, y, z: q(x, z) + 0 * y)
+    for _ in range(2):
+        model.time_step(1.0)
+        om.time_step(1.0)
+    model.synchronize()
+    assert _finite(model) and model.microphysical_fields["qˡ"].interior_cpu().max() > 0.0      # the moist layer is cloudy
+    for n, f in (("ru", model.momentum["ρu"]), ("rtheta", model.potential_temperature_density), ("rq", model.moisture_density), ("T", model.temperature)):
+        want = og.interior(getattr(om, n))
+        assert np.abs(f.interior_cpu() - want).max() < 1e-9 * np.abs(want).max(), n

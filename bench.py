@@ -192,8 +192,6 @@ def config4_run(args, bz, rank, world, dist, device, fail):
     import torch
     Nx, Ny, Nz, dt = 512, 512, 128, 2.0
     f32 = bool(getattr(args, "config4_float32", False))      # the example's own precision (splitting_supercell.jl:86), single GPU
-    if f32 and (world > 1 or args.slab):
-        fail("--config4-float32 runs on one GPU (the Float32 twin's compressible slab path has no test)")
     order = int(getattr(args, "config4_order", 5))           # splitting_supercell.jl:279 uses WENO(order = 9): generic kernels, 5-cell halos
     gkw = {"float_type": np.float32} if f32 else {}
     if order != 5:

@@ -449,3 +449,48 @@ def test_float32_compressible_kessler_on_library_slabs_matches_the_single_gpu_mo
         want = get(ref).interior_cpu().astype(np.float64)
         scale = mom if name in ("ρu", "ρw") else np.abs(want).max()
         assert np.abs(got - want).max() / scale < 1e-4, (name, np.abs(got - want).max() / scale)      # Float32 round-off through different kernel sequences (App. C: 1e-4 after steps)
+
+
+@pytest.mark.gpu
+def test_float32_two_dimensional_models_match_the_float64_oracle(oracle, bz):
+    """(Periodic, Flat, Bounded) on Float32 grids, both dynamical cores: the 2-D bubble through the anelastic per-operator kernels and the
+    inertia-gravity-wave set-up through the compressible split-explicit model, three steps each against the Float64 oracle."""
+    from oracle import oracle_compressible as oc
+    topo = ("Periodic", "Flat", "Bounded")
+    # anelastic
+    size, ext = (64, 48), dict(x=(-10e3, 10e3), z=(0.0, 10e3))
+    og = oracle.Grid(size, topology=topo, **ext)
+    om = oracle.OracleModel(og, potential_temperature=300.0)
+    grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Flat, bz.Bounded), float_type=np.float32, **ext)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO())
+    θ = lambda x, z: 300.0 + 2.0 * np.cos(np.pi / 2 * np.minimum(1.0, np.hypot(x, z - 2000.0) / 2000.0)) ** 2
+    om.set(theta=lambda x, y, z: θ(x, z) + 0 * y, u=2.0)
+    hm.set(θ=θ, u=2.0)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    e = _steps_errors(om, hm, [(n, hm.prognostic_fields()[k]) for n, k in PROG.items() if n not in ("rq", "rv")])
+    print("float32 2-D anelastic:", {k: f"{v:.1e}" for k, v in e.items()})
+    assert max(e.values()) < 1e-4, e
+    # compressible inertia-gravity wave
+    Nx, Nz, Lx, Lz = 96, 10, 96e3, 10e3
+    θbg = lambda z: 300.0 * np.exp(1e-4 * z / 9.80665)
+    θi = lambda x, z: θbg(z) + 0.01 * np.sin(np.pi * z / Lz) / (1 + (x - Lx / 3) ** 2 / 5000.0 ** 2)
+    og = oracle.Grid((Nx, Nz), x=(0.0, Lx), z=(0.0, Lz), topology=topo)
+    om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(), reference_potential_temperature=θbg, reference_state=True)
+    grid = bz.RectilinearGrid((Nx, Nz), x=(0.0, Lx), z=(0.0, Lz), topology=(bz.Periodic, bz.Flat, bz.Bounded), float_type=np.float32)
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), reference_potential_temperature=θbg, reference_state="auto")
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO())
+    rho = om.ref.density[og.Hz:og.Hz + og.Nz][:, None, None] + np.zeros((Nz, 1, Nx))
+    om.set(rho=rho, theta=lambda x, y, z: θi(x, z) + 0 * y, u=20.0, v=0.0, w=0.0)
+    hm.set(ρ=rho, θ=θi, u=20.0, v=0.0, w=0.0)
+    for _ in range(3):
+        om.time_step(6.0)
+        hm.time_step(6.0)
+    hm.synchronize()
+    I = og.interior
+    for n, f in (("rho_d", hm.dynamics.dry_density), ("rtheta", hm.potential_temperature_density), ("ru", hm.momentum["ρu"])):
+        want = I(getattr(om, n))
+        assert np.abs(f.interior_cpu().astype(np.float64) - want).max() / np.abs(want).max() < 1e-5, n
+    assert np.abs(hm.momentum["ρv"].interior_cpu()).max() == 0.0

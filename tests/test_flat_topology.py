@@ -224,3 +224,32 @@ def test_dry_thermal_bubble_example_configuration_matches_oracle(oracle, bz):
         scale = max(np.max(np.abs(want)), 1e-3)
         assert np.max(np.abs(got - want)) / scale < 2e-8, (n, np.max(np.abs(got - want)) / scale)      # the WENO-9 tolerance of tests/test_weno_orders.py
     assert np.abs(hm.momentum["ρv"].interior_cpu()).max() == 0.0
+
+
+def test_two_dimensional_kessler_and_tracer_model_matches_oracle(oracle, bz):
+    """2-D moist convection ingredients: DCMIP2016 Kessler species and a user tracer on (Periodic, Flat, Bounded), two steps against the oracle."""
+    size, ext = (48, 24), dict(x=(0.0, 12e3), z=(0.0, 6e3))
+    og = oracle.Grid(size, topology=("Periodic", "Flat", "Bounded"), **ext)
+    om = oracle.OracleModel(og, surface_pressure=1e5, potential_temperature=300.0, microphysics="Kessler", tracers=1)
+    grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Flat, bz.Bounded), **ext)
+    tc = bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula())
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, tc, surface_pressure=1e5, potential_temperature=300.0)),
+                            advection=bz.WENO(order=5), thermodynamic_constants=tc, microphysics=bz.DCMIP2016KesslerMicrophysics(), tracers=("a",))
+    bub = lambda x, z: np.maximum(0.0, 1.0 - np.hypot(x - 6e3, z - 1500.0) / 1200.0)
+    ic = dict(qt=lambda x, z: 0.016 * np.exp(-z / 3000.0) + 0.004 * bub(x, z), theta=lambda x, z: 300.0 + 0.004 * z + 1.0 * bub(x, z),
+              qcl=lambda x, z: 0.003 * bub(x, z), qr=lambda x, z: 0.001 * bub(x, z))
+    a = lambda x, z: 1.0 + 0.5 * np.sin(2 * np.pi * x / 12e3) * (z / 6e3)
+    om.set(u=2.0, rc0=lambda x, y, z: a(x, z) + 0 * y, **{k: (lambda f: (lambda x, y, z: f(x, z) + 0 * y))(v) for k, v in ic.items()})
+    hm.tracers["a"].set_interior(a)
+    hm.set(qᵗ=ic["qt"], θ=ic["theta"], qcl=ic["qcl"], qr=ic["qr"], u=2.0)
+    for _ in range(2):
+        om.time_step(5.0)
+        hm.time_step(5.0)
+    hm.synchronize()
+    g, μ = om.grid, hm.microphysical_fields
+    mom = max(np.abs(g.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rw"))
+    for n, f in (("ru", hm.momentum["ρu"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density), ("rq", hm.moisture_density),
+                 ("rqr", μ["ρqʳ"]), ("T", hm.temperature), ("rc0", hm.tracers["a"])):
+        want = g.interior(getattr(om, n), n == "rw")
+        scale = mom if n in ("ru", "rw") else max(np.abs(want).max(), 1e-6)
+        assert np.abs(f.interior_cpu() - want).max() / scale < 1e-8, n

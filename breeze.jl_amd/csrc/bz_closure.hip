@@ -79,12 +79,14 @@ __global__ __launch_bounds__(256) void k_smagorinsky_viscosity(DevGrid g, Closur
     const double *u = F.u, *v = F.v, *w = F.w;
     const double s11 = S11(g, u, n), s22 = S22(g, v, n), s33 = S33(g, w, n, k);
     auto sq = [](double a) { return a * a; };
+    // a Flat y direction (Ny = 1, no halo rows, 1/dy stored as 0): the corners at j and j + 1 coincide
+    const long long cy = g.flat_y ? 0 : sy;
     const double a12 = ((sq(S12(g, u, v, n)) + sq(S12(g, u, v, n + sx))) / 2 +
-                        (sq(S12(g, u, v, n + sy)) + sq(S12(g, u, v, n + sy + sx))) / 2) / 2;
+                        (sq(S12(g, u, v, n + cy)) + sq(S12(g, u, v, n + cy + sx))) / 2) / 2;
     const double a13 = ((sq(S13(g, u, w, n, k)) + sq(S13(g, u, w, n + sx, k))) / 2 +
                         (sq(S13(g, u, w, n + sz, k + 1)) + sq(S13(g, u, w, n + sz + sx, k + 1))) / 2) / 2;
-    const double a23 = ((sq(S23(g, v, w, n, k)) + sq(S23(g, v, w, n + sy, k))) / 2 +
-                        (sq(S23(g, v, w, n + sz, k + 1)) + sq(S23(g, v, w, n + sz + sy, k + 1))) / 2) / 2;
+    const double a23 = ((sq(S23(g, v, w, n, k)) + sq(S23(g, v, w, n + cy, k))) / 2 +
+                        (sq(S23(g, v, w, n + sz, k + 1)) + sq(S23(g, v, w, n + sz + cy, k + 1))) / 2) / 2;
     const double Sig2 = (s11 * s11 + s22 * s22 + s33 * s33) + 2 * a12 + 2 * a13 + 2 * a23;
     // N^2: T, q^v carry no-flux z halos, the reference pressure column its own first halo cell
     const double lm = log_theta_v(g, ipi, T, qv, n - sz, k - 1), lc = log_theta_v(g, ipi, T, qv, n, k), lp = log_theta_v(g, ipi, T, qv, n + sz, k + 1);
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFi
     const long long n = g.idx(i, j, k), sx = 1, sy = g.Sx, sz = g.Sxy;
     const double *u = F.u, *v = F.v, *w = F.w, *nu = F.nu;
     const double dx = g.dx, dy = g.dy, dz = g.dzc[k];
-    const double rVc = g.rdx * g.rdy * g.rdzc[k];
+    const double rVc = g.rdx * (1.0 / dy) * g.rdzc[k];      // not g.rdy: that is the derivative quotient, stored as 0 on Flat grids
     const double rho = g.rho[k];
     const double Ax = dy * dz, Ay = dx * dz, Az = dx * dy;
     // eddy viscosity of the 3 x 3 x 3 neighbourhood that the flux locations of this cell touch
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFi
 
     const double t12_00 = T12(0, 0), t13_00 = T13(0, 0), t23_00 = T23(0, 0);
     {   // x momentum at face i
-        const double div = (Ax * T11(0) - Ax * T11(-1)) + (Ay * T12(0, 1) - Ay * t12_00) + (Az * T13(0, 1) - Az * t13_00);
+        const double div = (Ax * T11(0) - Ax * T11(-1)) + (g.flat_y ? 0.0 : Ay * T12(0, 1) - Ay * t12_00) + (Az * T13(0, 1) - Az * t13_00);
         Gu[n] -= scale * (div * rVc);
     }
     {   // y momentum at face j
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFi
     if (k >= 1) {   // z momentum at the interior face k (between centres k-1 and k)
         const double dzf = g.dzf[k];
         const double Axf = dy * dzf, Ayf = dx * dzf;
-        const double div = (Axf * T13(1, 0) - Axf * t13_00) + (Ayf * T23(1, 0) - Ayf * t23_00) + (Az * T33(0) - Az * T33(-1));
-        Gw[n] -= scale * (div * (g.rdx * g.rdy * g.rdzf[k]));
+        const double div = (Axf * T13(1, 0) - Axf * t13_00) + (g.flat_y ? 0.0 : Ayf * T23(1, 0) - Ayf * t23_00) + (Az * T33(0) - Az * T33(-1));
+        Gw[n] -= scale * (div * (g.rdx * (1.0 / dy) * g.rdzf[k]));
     }
     // scalars: J = rho x (-(nu / Pr) grad c) on the six faces of the cell
     const double rPr = 1.0 / F.Pr;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void k_closure_scalar(DevGrid g, const double 
     const long long oym = ((j == 0 && g.wrap_y) ? (long long)(g.Ny - 1) : -1) * sy, oyp = ((j == g.Ny - 1 && g.wrap_y) ? -(long long)(g.Ny - 1) : 1) * sy;
     const long long ozm = (k == 0) ? 0 : -sz, ozp = (k == g.Nz - 1) ? 0 : sz;
     const double dx = g.dx, dy = g.dy, dz = g.dzc[k];
-    const double rVc = g.rdx * g.rdy * g.rdzc[k], rho = g.rho[k];
+    const double rVc = g.rdx * (1.0 / dy) * g.rdzc[k], rho = g.rho[k];
     const double Ax = dy * dz, Ay = dx * dz, Az = dx * dy;
     const double kc = nu[n] * rPr;
     const double kxm = (nu[n + oxm] * rPr + kc) / 2, kxp = (kc + nu[n + oxp] * rPr) / 2;
@@ -218,7 +220,7 @@ extern "C" int bz_set_closure(bz_ctx *ctx, const bz_smagorinsky_lilly *closure, 
                           "potential-temperature model (microphysics nothing or SaturationAdjustment)";
         return BZ_ERR_UNSUPPORTED;
     }
-    if (ctx->dg.Hx < 1 || ctx->dg.Hy < 1 || ctx->dg.Hz < 1) { ctx->last_error = "bz_set_closure: needs halos >= 1"; return BZ_ERR_UNSUPPORTED; }
+    if (ctx->dg.Hx < 1 || (ctx->dg.Hy < 1 && !ctx->dg.flat_y) || ctx->dg.Hz < 1) { ctx->last_error = "bz_set_closure: needs halos >= 1"; return BZ_ERR_UNSUPPORTED; }
     ctx->closure = *closure;
     ctx->closure_nu = eddy_viscosity;
     if (!ctx->d_closure_ipi) BZ_HIP(hipMalloc(&ctx->d_closure_ipi, (size_t)(ctx->dg.Nz + 2) * sizeof(double)));

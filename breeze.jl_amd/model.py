@@ -170,11 +170,11 @@ class AtmosphereModel:
         flat_y = grid.topology == (Periodic, Flat, Bounded)
         if grid.topology != (Periodic, Periodic, Bounded) and not flat_y:
             raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded) and (Periodic, Flat, Bounded)")
-        if flat_y and (closure is not None or coriolis is not None or forcing is not None or boundary_conditions is not None or
+        if flat_y and (coriolis is not None or forcing is not None or boundary_conditions is not None or
                        (advection is not None and getattr(advection, "order", 5) not in (5, 7, 9))):
             # the reference's 2-D x-z cases (README.md:67-75, examples/dry_thermal_bubble.jl with WENO(order = 9)): the per-operator
             # kernels drop the y terms
-            raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model without closure / forcings is implemented")
+            raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model without Coriolis / forcings / flux boundary conditions is implemented")
         formulation = str(formulation).lstrip(":")
         if formulation not in ("LiquidIcePotentialTemperature", "StaticEnergy"):
             raise NotImplementedError(f"formulation {formulation!r} is not implemented")

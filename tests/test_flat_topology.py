@@ -253,3 +253,36 @@ def test_two_dimensional_kessler_and_tracer_model_matches_oracle(oracle, bz):
         want = g.interior(getattr(om, n), n == "rw")
         scale = mom if n in ("ru", "rw") else max(np.abs(want).max(), 1e-6)
         assert np.abs(f.interior_cpu() - want).max() / scale < 1e-8, n
+
+
+def test_two_dimensional_smagorinsky_model_matches_oracle(oracle, bz):
+    """SmagorinskyLilly on (Periodic, Flat, Bounded): the y derivatives of the strain vanish, the corner averages in y collapse onto the row
+    and the filter width uses the unit spacing of the Flat direction; sheared moist layer, three steps against the oracle's closure."""
+    from oracle.closure import SmagorinskyLilly
+    size, ext = (64, 32), dict(x=(0.0, 6.4e3), z=(0.0, 3e3))
+    og = oracle.Grid(size, topology=("Periodic", "Flat", "Bounded"), **ext)
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment", closure=SmagorinskyLilly())
+    grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Flat, bz.Bounded), **ext)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)),
+                            advection=bz.WENO(order=5), closure=bz.SmagorinskyLilly(),
+                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()))
+    rng = np.random.default_rng(4)
+    noise = rng.standard_normal((size[1], 1, size[0]))
+    x, y, z = og.nodes("ccc")
+    th = 298.7 + 0.004 * np.maximum(z - 520.0, 0.0) + 0.2 * noise
+    qt = 0.0185 * np.exp(-z / 2200.0) * (1 + 0.02 * noise)
+    u = -8.75 + 3e-3 * z + 0.6 * noise
+    om.set(theta=th, qt=qt, u=u, v=0.3 * noise)
+    hm.set(θ=th, qᵗ=qt, u=u, v=0.3 * noise)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    assert om.nu_e.max() > 0.01
+    mom = max(np.abs(og.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rv", "rw"))
+    for n, k in PROG.items():
+        want = og.interior(getattr(om, n), zface=(n == "rw"))
+        got = hm.prognostic_fields()[k].interior_cpu()
+        scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() / scale < 2e-9, (n, np.abs(got - want).max() / scale)
+    assert relerr(hm.closure_fields["νₑ"].interior_cpu(), om.nu_e) < 1e-9

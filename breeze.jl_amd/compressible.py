@@ -625,7 +625,7 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
         y0 = G.yᶠ[0] + rank * Ny * G.Δy
         z = (G.zᶠ[0], G.zᶠ[-1]) if G.regular_z else G.zᶠ
         grid = RectilinearGrid((G.Nx, Ny, G.Nz), x=(G.xᶠ[0], G.xᶠ[0] + G.Nx * G.Δx), y=(y0, y0 + Ny * G.Δy), z=z,
-                               halo=(G.Hx, G.Hy, G.Hz))
+                               halo=(G.Hx, G.Hy, G.Hz), float_type=G.float_type)      # eltype(grid) travels with the slab
         grid.Δx, grid.Δy = G.Δx, G.Δy          # bit-identical spacings on every rank
         self.decomp = None                     # set after construction: the constructor's set-up is rank-local
         self.transport = transport

@@ -54,11 +54,17 @@ __global__ __launch_bounds__(64 * TYB) void k_scalar_tendency_bounded(DevGrid g,
         for (int s = 0; s < 6; ++s) z[s] = z[s + 1];
         z[6] = c[n + 3 * sz];
         const double rho = g.rho[k], Ax = g.Ax[k], Ay = g.Ay[k];
-        double x[7], y[7];
+        double x[7];
 #pragma unroll
-        for (int s = 0; s < 7; ++s) { x[s] = (s == 3) ? z[3] : c[n + (s - 3)]; y[s] = (s == 3) ? z[3] : c[n + (s - 3) * sy]; }
+        for (int s = 0; s < 7; ++s) x[s] = (s == 3) ? z[3] : c[n + (s - 3)];
         const double dxF = bounded_div(x, 3, 3, rho * (Ax * u[n]), rho * (Ax * u[n + 1]), lo, hi);
-        const double dyF = bounded_div(y, 3, 3, rho * (Ay * v[n]), rho * (Ay * v[n + sy]), lo, hi);
+        double dyF = 0.0;
+        if (!g.flat_y) {      // a Flat y direction has no faces (Ny = 1, Hy = 0: rows +-1 would be other z levels)
+            double y[7];
+#pragma unroll
+            for (int s = 0; s < 7; ++s) y[s] = (s == 3) ? z[3] : c[n + (s - 3) * sy];
+            dyF = bounded_div(y, 3, 3, rho * (Ay * v[n]), rho * (Ay * v[n + sy]), lo, hi);
+        }
         const double dzF = bounded_div(z, bz_buffer_face(k, g.Nz), bz_buffer_face(k + 1, g.Nz), g.rho_f[k] * (g.Az * w[n]),
                                        g.rho_f[k + 1] * (g.Az * w[n + sz]), lo, hi);
         Gc[n] = -(g.Vinv_c[k] * (dxF + dyF + dzF));

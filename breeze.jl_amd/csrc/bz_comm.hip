@@ -776,11 +776,21 @@ struct FieldList {
     double *f[BZ_COMM_MAX_FIELDS];
     int32_t lev[BZ_COMM_MAX_FIELDS];
     int n = 0;
-    void add(double *p, int32_t levels) { if (p && n < BZ_COMM_MAX_FIELDS) { f[n] = p; lev[n] = levels; ++n; } }
+    bool overflow = false;      // a field beyond BZ_COMM_MAX_FIELDS must fail the exchange, not silently stay unexchanged
+    void add(double *p, int32_t levels)
+    {
+        if (!p) return;
+        if (n >= BZ_COMM_MAX_FIELDS) { overflow = true; return; }
+        f[n] = p; lev[n] = levels; ++n;
+    }
 };
 
 static int cmp_exchange(bz_ctx *ctx, const FieldList &L)
 {
+    if (L.overflow) {
+        ctx->last_error = "halo exchange list exceeds BZ_COMM_MAX_FIELDS";
+        return BZ_ERR_UNSUPPORTED;
+    }
     if (!L.n) return BZ_OK;
     ProfileScope ps(ctx, "comm_halo_exchange");
     return halo_exchange(ctx, L.f, L.lev, L.n, ctx->dg.Hy, true, true, ctx->stream);

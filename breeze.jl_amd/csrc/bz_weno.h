@@ -32,16 +32,20 @@ __device__ __forceinline__ double bz_weno5_ref(double a, double b, double c, dou
 }
 
 // Fast form used by the shipped kernels.  Same weights and candidate polynomials, rearranged for
-// FP64 issue slots (one WENO-5 is ~60 FP64 instructions instead of ~85 + 3 extra divisions):
+// FP64 issue slots (46 FP64 instructions + one v_rcp_f64 against ~85 + 4 divisions of the reference order; round 2's form of the
+// same idea needed 57 — measured on MI355X every FP64 instruction of a wave64 costs ~2.1 ns of SIMD time, tools/valu_rates.hip):
 //  * everything is expressed through the first differences D1..D4 of the five cells: the smoothness
 //    indicators (3 x Jiang-Shu, as Oceananigans tabulates them) are
 //        beta_2 = 13/4 (D2-D1)^2 + 3/4 (3 D2 - D1)^2,  beta_1 = 13/4 (D3-D2)^2 + 3/4 (D2+D3)^2,
 //        beta_0 = 13/4 (D4-D3)^2 + 3/4 (D4 - 3 D3)^2,
 //    and the candidates are c + delta_s with delta_2 = 5/6 D2 - 1/3 D1, delta_1 = 1/3 D3 + 1/6 D2,
 //    delta_0 = 2/3 D3 - 1/6 D4 (less cancellation than the cell-value form);
-//  * alpha_s = C_s (1 + tau^2/d_s^2), d_s = beta_s + eps, is multiplied through by d_0^2 d_1^2 d_2^2
-//    (positive, so the normalised weights are unchanged) and by 10: one division instead of four.
-//    FP64 range: d_s in [1e-8, ~1e6] => products in [1e-48, 1e37];
+//  * the weights depend on the indicators only through tau / (beta_s + eps), which is unchanged when beta_s, tau and eps are all
+//    divided by 3/4: d_s = (beta_s + eps) / (3/4) = L_s^2 + (13/3 S_s^2 + 4/3 eps) is two FMAs after S_s^2, and tau / (3/4) = d_0 - d_2;
+//  * alpha_s = C_s (1 + tau^2/d_s^2) is multiplied through by d_0^2 d_1^2 d_2^2 (positive, so the normalised weights are
+//    unchanged) and by 10: with s_j = d_j^2, Q = s_0 s_1 s_2 and P_s = Q / s_s the scaled weights are w_s = 10 C_s (Q + tau^2 P_s):
+//    one division instead of four, and the constants 10 C_s = (3, 6, 1) are folded into the candidate increments
+//    (3 delta_0 = 2 D3 - D4/2, 6 delta_1 = 2 D3 + D2).  FP64 range: d_s in [1e-8, ~1e6] => products in [1e-48, 1e37];
 //  * that division is a v_rcp_f64 seed plus two Newton steps (denominator positive and normal, so the
 //    div_scale / div_fixup special-casing is unnecessary): relative error ~1e-16.  The reference itself
 //    evaluates tau/(beta+eps) with a reduced-precision reciprocal and one Newton step (newton_div).
@@ -50,22 +54,22 @@ __device__ __forceinline__ double bz_weno5_fast(double a, double b, double c, do
 {
     const double D1 = b - a, D2 = c - b, D3 = d - c, D4 = e - d;
     const double S1 = D2 - D1, S2 = D3 - D2, S3 = D4 - D3;
-    const double L2 = 3.0 * D2 - D1, L1 = D2 + D3, L0 = D4 - 3.0 * D3;
-    const double b2 = (3.25 * S1) * S1 + (0.75 * L2) * L2;
-    const double b1 = (3.25 * S2) * S2 + (0.75 * L1) * L1;
-    const double b0 = (3.25 * S3) * S3 + (0.75 * L0) * L0;
-    const double tau = b0 - b2;
+    const double L2 = fma(3.0, D2, -D1), L1 = D2 + D3, L0 = fma(-3.0, D3, D4);
+    const double E43 = (4.0 / 3.0) * BZ_WENO_EPS, C133 = 13.0 / 3.0;
+    const double d2 = fma(L2, L2, fma(C133, S1 * S1, E43));
+    const double d1 = fma(L1, L1, fma(C133, S2 * S2, E43));
+    const double d0 = fma(L0, L0, fma(C133, S3 * S3, E43));
+    const double tau = d0 - d2;
     const double t2 = tau * tau;
-    const double d0 = b0 + BZ_WENO_EPS, d1 = b1 + BZ_WENO_EPS, d2 = b2 + BZ_WENO_EPS;
     const double s0 = d0 * d0, s1 = d1 * d1, s2 = d2 * d2;
-    const double a0 = 3.0 * ((s0 + t2) * (s1 * s2));
-    const double a1 = 6.0 * ((s1 + t2) * (s0 * s2));
-    const double a2 = (s2 + t2) * (s0 * s1);
-    const double e0 = (2.0 / 3.0) * D3 - (1.0 / 6.0) * D4;
-    const double e1 = (1.0 / 3.0) * D3 + (1.0 / 6.0) * D2;
-    const double e2 = (5.0 / 6.0) * D2 - (1.0 / 3.0) * D1;
-    const double num = a0 * e0 + a1 * e1 + a2 * e2;
-    const double den = a0 + a1 + a2;
+    const double P0 = s1 * s2, P1 = s0 * s2, P2 = s0 * s1;
+    const double Q = s0 * P0;
+    const double a0 = fma(t2, P0, Q), a1 = fma(t2, P1, Q), a2 = fma(t2, P2, Q);      // w_0 / 3, w_1 / 6, w_2
+    const double e0 = fma(2.0, D3, -0.5 * D4);                                       // 3 delta_0
+    const double e1 = fma(2.0, D3, D2);                                              // 6 delta_1
+    const double e2 = fma(5.0 / 6.0, D2, -(1.0 / 3.0) * D1);
+    const double num = fma(a2, e2, fma(a1, e1, a0 * e0));
+    const double den = fma(3.0, a0, fma(6.0, a1, a2));
     double r = __builtin_amdgcn_rcp(den);
     r = fma(fma(-den, r, 1.0), r, r);
     r = fma(fma(-den, r, 1.0), r, r);
@@ -76,21 +80,27 @@ __device__ __forceinline__ double bz_weno5_fast(double a, double b, double c, do
 // product of squared indicators (range-safe in Float32, where the one-division form underflows at 1e-48) and no expanded
 // polynomial of the cell values (in Float32 the expanded beta of a field with a large mean — theta ~ 300 K — loses every digit:
 // measured 3e-4 of the tendency scale against 2e-5 for this form).  The Float32 build uses it (BZ_WENO_ONE_DIVISION=2).
+// The quotients are reciprocal-multiplies (v_rcp: 1 ulp in Float32, where this form is used; the reference's own newton_div is a
+// reduced-precision reciprocal + one Newton step) — an IEEE division costs ~10 instructions, four of them per reconstruction.
+// Indicators scaled by 4/3 as in bz_weno5_fast; the optimal weights (3, 6, 1) / 10 are folded into the candidate increments.
 __device__ __forceinline__ double bz_weno5_diff(double a, double b, double c, double d, double e)
 {
     const double D1 = b - a, D2 = c - b, D3 = d - c, D4 = e - d;
     const double S1 = D2 - D1, S2 = D3 - D2, S3 = D4 - D3;
-    const double L2 = 3.0 * D2 - D1, L1 = D2 + D3, L0 = D4 - 3.0 * D3;
-    const double b2 = (3.25 * S1) * S1 + (0.75 * L2) * L2;
-    const double b1 = (3.25 * S2) * S2 + (0.75 * L1) * L1;
-    const double b0 = (3.25 * S3) * S3 + (0.75 * L0) * L0;
-    const double tau = fabs(b0 - b2);
-    const double r0 = tau / (b0 + BZ_WENO_EPS), r1 = tau / (b1 + BZ_WENO_EPS), r2 = tau / (b2 + BZ_WENO_EPS);
-    const double a0 = (3.0 / 10.0) * (1.0 + r0 * r0), a1 = (3.0 / 5.0) * (1.0 + r1 * r1), a2 = (1.0 / 10.0) * (1.0 + r2 * r2);
-    const double e0 = (2.0 / 3.0) * D3 - (1.0 / 6.0) * D4;
-    const double e1 = (1.0 / 3.0) * D3 + (1.0 / 6.0) * D2;
-    const double e2 = (5.0 / 6.0) * D2 - (1.0 / 3.0) * D1;
-    return c + (a0 * e0 + a1 * e1 + a2 * e2) / (a0 + a1 + a2);
+    const double L2 = fma(3.0, D2, -D1), L1 = D2 + D3, L0 = fma(-3.0, D3, D4);
+    const double E43 = (4.0 / 3.0) * BZ_WENO_EPS, C133 = 13.0 / 3.0;
+    const double d2 = fma(L2, L2, fma(C133, S1 * S1, E43));
+    const double d1 = fma(L1, L1, fma(C133, S2 * S2, E43));
+    const double d0 = fma(L0, L0, fma(C133, S3 * S3, E43));
+    const double tau = fabs(d0 - d2);
+    const double r0 = tau * __builtin_amdgcn_rcp(d0), r1 = tau * __builtin_amdgcn_rcp(d1), r2 = tau * __builtin_amdgcn_rcp(d2);
+    const double a0 = fma(r0, r0, 1.0), a1 = fma(r1, r1, 1.0), a2 = fma(r2, r2, 1.0);
+    const double e0 = fma(2.0, D3, -0.5 * D4);                  // 3 delta_0
+    const double e1 = fma(2.0, D3, D2);                         // 6 delta_1
+    const double e2 = fma(5.0 / 6.0, D2, -(1.0 / 3.0) * D1);
+    const double num = fma(a2, e2, fma(a1, e1, a0 * e0));
+    const double den = fma(3.0, a0, fma(6.0, a1, a2));
+    return fma(num, __builtin_amdgcn_rcp(den), c);
 }
 
 __device__ __forceinline__ double bz_weno5(double a, double b, double c, double d, double e)
@@ -130,22 +140,46 @@ __device__ __forceinline__ double bz_up5(double, double, double m1, double p0, d
 __device__ __forceinline__ double bz_up3(double, double m1, double p0, double, bool) { return 0.5 * (m1 + p0); }
 __device__ __forceinline__ double bz_upB(double, double, double m1, double p0, double, double, bool, int) { return 0.5 * (m1 + p0); }
 #else
+// Lane-mask select m ? a : b as v_cndmask_b32_e64 with the mask in an SGPR pair.  Why not the ternary operator: hipcc emits a
+// share of its selects as the VOP2 form that reads VCC, and on MI355X that encoding issues at ~9.5 ns of SIMD time per wave64
+// instruction against ~1.9 ns for the VOP3 form with an explicit SGPR-pair mask (tools/valu_rates.hip, profiles/r03_valu_rates.txt);
+// an upwind WENO-5 selects five doubles = ten of them.
+template <class R>
+__device__ __forceinline__ R bz_sel(unsigned long long m, R a, R b)
+{
+    if constexpr (sizeof(R) == 8) {
+        const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+        int lo, hi;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(blo), "v"(alo), "s"(m));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(bhi), "v"(ahi), "s"(m));
+        return __hiloint2double(hi, lo);
+    } else {
+        const int ai = __float_as_int(a), bi = __float_as_int(b);
+        int r;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(bi), "v"(ai), "s"(m));
+        return __int_as_float(r);
+    }
+}
+__device__ __forceinline__ unsigned long long bz_lanes(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Six values straddling the target (which lies between m1 and p0).  left = advecting flux > 0.
 __device__ __forceinline__ double bz_up5(double m3, double m2, double m1, double p0, double p1,
                                          double p2, bool left)
 {
-    double a = left ? m3 : p2;
-    double b = left ? m2 : p1;
-    double c = left ? m1 : p0;
-    double d = left ? p0 : m1;
-    double e = left ? p1 : m2;
+    const unsigned long long m = bz_lanes(left);
+    double a = bz_sel(m, m3, p2);
+    double b = bz_sel(m, m2, p1);
+    double c = bz_sel(m, m1, p0);
+    double d = bz_sel(m, p0, m1);
+    double e = bz_sel(m, p1, m2);
     return bz_weno5(a, b, c, d, e);
 }
 __device__ __forceinline__ double bz_up3(double m2, double m1, double p0, double p1, bool left)
 {
-    double a = left ? m2 : p1;
-    double b = left ? m1 : p0;
-    double c = left ? p0 : m1;
+    const unsigned long long m = bz_lanes(left);
+    double a = bz_sel(m, m2, p1);
+    double b = bz_sel(m, m1, p0);
+    double c = bz_sel(m, p0, m1);
     return bz_weno3(a, b, c);
 }
 // buffer-aware (B wave-uniform: 3, 2 or 1)
@@ -154,7 +188,7 @@ __device__ __forceinline__ double bz_upB(double m3, double m2, double m1, double
 {
     if (B == 3) return bz_up5(m3, m2, m1, p0, p1, p2, left);
     if (B == 2) return bz_up3(m2, m1, p0, p1, left);
-    return left ? m1 : p0;
+    return bz_sel(bz_lanes(left), m1, p0);
 }
 #endif
 

@@ -341,7 +341,7 @@ class LibrarySlabAtmosphereModel(AtmosphereModel):
         y0 = G.yᶠ[0] + rank * Ny * G.Δy
         z = (G.zᶠ[0], G.zᶠ[-1]) if G.regular_z else G.zᶠ
         grid = RectilinearGrid((G.Nx, Ny, G.Nz), x=(G.xᶠ[0], G.xᶠ[0] + G.Nx * G.Δx), y=(y0, y0 + Ny * G.Δy), z=z,
-                               halo=(G.Hx, G.Hy, G.Hz))
+                               halo=(G.Hx, G.Hy, G.Hz), float_type=G.float_type)      # eltype(grid) travels with the slab
         grid.Δx, grid.Δy = G.Δx, G.Δy          # bit-identical spacings on every rank
         c = thermodynamic_constants or ThermodynamicConstants()
         ref = ReferenceState(grid, c, surface_pressure, potential_temperature, standard_pressure)
@@ -402,6 +402,9 @@ class SlabAtmosphereModel(SlabStepper):
         if not torch.cuda.is_available():
             raise RuntimeError("SlabAtmosphereModel needs a GPU: the HIP path has no CPU fallback")
         self.global_grid = G = global_grid
+        if G.ftype != 8:
+            raise NotImplementedError('SlabAtmosphereModel(transport="torch") is the Float64 cross-check of the library-owned step; '
+                                      "Float32 grids decompose through LibrarySlabAtmosphereModel")
         self.rank, self.world = rank, world
         Ny = G.Ny // world
         y0 = G.yᶠ[0] + rank * Ny * G.Δy

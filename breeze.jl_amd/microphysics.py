@@ -71,7 +71,7 @@ class KesslerMicrophysicalFields:
         # ASCII attribute names (Python normalises superscript identifiers): rho_qcl = ρqᶜˡ, rho_qr = ρqʳ, qv, qcl, qr, W = 𝕎ʳ
         for name in ("rho_qcl", "rho_qr", "qv", "qcl", "qr", "W"):
             setattr(self, name, Field(g, _LOC["ccc"], model.device))
-        self.precipitation_rate = torch.zeros((g.Ny + 2 * g.Hy, g.Nx + 2 * g.Hx), dtype=torch.float64, device=model.device)
+        self.precipitation_rate = torch.zeros((g.Ny + 2 * g.Hy, g.Nx + 2 * g.Hx), dtype=self.qv.parent.dtype, device=model.device)      # eltype(grid): the Float32 library writes 4-byte reals
 
 
 def kessler_parameter_struct(microphysics, constants, tetens=None, ftype=8):

@@ -170,8 +170,11 @@ class AtmosphereModel:
         flat_y = grid.topology == (Periodic, Flat, Bounded)
         if grid.topology != (Periodic, Periodic, Bounded) and not flat_y:
             raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded) and (Periodic, Flat, Bounded)")
+        if advection is None:
+            advection = Centered(order=2)          # the reference's default (resolved before the Flat guard: ADVICE r02)
+        _base = advection.get("momentum") or next(iter(advection.values())) if isinstance(advection, dict) else advection
         if flat_y and (coriolis is not None or forcing is not None or boundary_conditions is not None or
-                       (advection is not None and getattr(advection, "order", 5) not in (5, 7, 9))):
+                       not isinstance(_base, WENO) or _base.order not in (5, 7, 9)):
             # the reference's 2-D x-z cases (README.md:67-75, examples/dry_thermal_bubble.jl with WENO(order = 9)): the per-operator
             # kernels drop the y terms
             raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model without Coriolis / forcings / flux boundary conditions is implemented")
@@ -200,8 +203,6 @@ class AtmosphereModel:
                 raise ValueError("DCMIP2016KesslerMicrophysics requires `thermodynamic_constants` with a `TetensFormula` "
                                  "saturation vapor pressure formulation. Construct the model with, e.g., "
                                  "`thermodynamic_constants = ThermodynamicConstants(saturation_vapor_pressure = TetensFormula())`.")
-        if advection is None:
-            advection = Centered(order=2)          # the reference's default
         advection, self._bounded_advection = _split_advection(advection, tuple(str(n).lstrip(":") for n in
                                                                                  ((tracers,) if isinstance(tracers, str) else tracers)))
         if not torch.cuda.is_available():
@@ -248,7 +249,7 @@ class AtmosphereModel:
         if self._kessler:      # materialize_microphysical_fields(::DCMIP2016KM) (dcmip2016_kessler.jl:255-290)
             self.microphysical_fields = {k: fld("ccc") for k in ("ρqᶜˡ", "ρqʳ", "qᵛ", "qᶜˡ", "qʳ", "𝕎ʳ")}
             self.microphysical_fields["precipitation_rate"] = torch.zeros((grid.Ny + 2 * grid.Hy, grid.Nx + 2 * grid.Hx),
-                                                                          dtype=torch.float64, device=self.device)
+                                                                          dtype=self.momentum["ρu"].parent.dtype, device=self.device)
         # tracers = (:a, :b): prognostic density fields model.tracers[name]; the specific field sits beside it
         tracers = (tracers,) if isinstance(tracers, str) else tuple(tracers)
         self.tracers = {str(n).lstrip(":"): fld("ccc") for n in tracers}

@@ -314,7 +314,7 @@ function slab_context!(model, y_nranks::Integer, y_rank::Integer, bcast_bytes!::
     grid, constants, reference = bz_grid(model.grid), bz_constants(model), bz_reference_state(model)
     rc = ccall((:bz_create_slab, libbreeze_hip), Cint,
                (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzReferenceState}, Cint, Cint, Cint),
-               ctx, grid, constants, reference, 5, y_nranks, y_rank)
+               ctx, grid, constants, reference, weno_order(model.advection), y_nranks, y_rank)
     rc == 0 || error("bz_create_slab failed with code $rc")
     id = zeros(UInt8, BZ_UNIQUE_ID_BYTES)
     if y_rank == 0
@@ -344,7 +344,7 @@ function compressible_slab_context!(model, y_nranks::Integer, y_rank::Integer, b
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:bz_create_compressible_slab, libbreeze_hip), Cint,
                (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzExnerReference}, Ref{BzSplitExplicit}, Cint, Cint, Cint),
-               ctx, g, k, r, td, 5, y_nranks, y_rank)
+               ctx, g, k, r, td, weno_order(model.advection), y_nranks, y_rank)
     rc == 0 || error("bz_create_compressible_slab failed with code $rc")
     id = zeros(UInt8, BZ_UNIQUE_ID_BYTES)
     if y_rank == 0

@@ -363,6 +363,9 @@ def test_float32_library_slabs_match_the_float64_oracle(oracle, bz):
     for t in threads:
         t.join()
     assert not errors, errors
+    for m in models:      # the rank-local grids carry the global grid's eltype: the Float32 twin is what ran
+        assert m.grid.ftype == 4 and m.momentum["ρu"].parent.dtype == torch.float32
+        assert m._lib is bz._lib.load_f32()
     mom = max(np.abs(og.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rv", "rw"))
     for n, k in PROG.items():
         if n == "rq":
@@ -441,6 +444,9 @@ def test_float32_compressible_kessler_on_library_slabs_matches_the_single_gpu_mo
     for t in threads:
         t.join()
     assert not errors, errors
+    for m in models:
+        assert m.grid.ftype == 4 and m.momentum["ρu"].parent.dtype == torch.float32
+        assert m._lib is bz._lib.load_f32()
     getters = {"ρᵈ": lambda m: m.dynamics.dry_density, "ρu": lambda m: m.momentum["ρu"], "ρw": lambda m: m.momentum["ρw"],
                "ρθ": lambda m: m.potential_temperature_density, "ρq": lambda m: m.moisture_density}
     mom = max(np.abs(getters[k](ref).interior_cpu()).max() for k in ("ρu", "ρw"))

@@ -287,6 +287,7 @@ struct bz_ctx {
     hipStream_t side_stream = nullptr;   // the scalar-pair kernel of a stage runs here, beside the pressure solve on the main stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_scalar = false;         // BZ_SIDE_SCALAR=1: single-GPU seam too (the distributed step does it whenever W > 1)
+    void *d_lev_rows = nullptr;       // LevRow5[Nz + 2 Hz]: the lean kernels' column constants, one 64-byte row per level (bz_tendency5.hip)
     double *d_pi_dry = nullptr;       // (p_r[k]/p_st)^(Rd/cpd), k = -Hz .. Nz+Hz-1: Exner factor of a dry cell, built with the device pow()
     // CompressibleDynamics + SplitExplicitTimeDiscretization (bz_create_compressible)
     bool compressible = false;

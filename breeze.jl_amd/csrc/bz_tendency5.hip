@@ -16,12 +16,26 @@ __global__ void k_pi_dry(DevGrid g, double *__restrict__ pi, int n)
     pi[t] = pow(g.p_r[k] / g.pst, Rm / cpm);
 }
 
+// the packed per-level rows of the lean kernels (LevRow5), copied from the column tables and the dry Exner table
+__global__ void k_lev_rows(DevGrid g, const double *__restrict__ pi, LevRow5 *__restrict__ rows, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int k = t - g.Hz;
+    LevRow5 r;
+    r.rho = g.rho[k]; r.rrho = g.rrho[k]; r.rho_f = g.rho_f[k]; r.rrho_f = g.rrho_f[k];
+    r.Ax = g.Ax[k]; r.Ay = g.Ay[k]; r.Vinv_c = g.Vinv_c[k]; r.pi = pi[t];
+    rows[t] = r;
+}
+
 int bzi_lean_setup(bz_ctx *ctx)
 {
     const DevGrid &g = ctx->dg;
     const int n = g.Nz + 2 * g.Hz;
     BZ_HIP(hipMalloc(&ctx->d_pi_dry, n * sizeof(double)));
     hipLaunchKernelGGL(k_pi_dry, dim3((n + 63) / 64), dim3(64), 0, 0, g, ctx->d_pi_dry, n);
+    BZ_HIP(hipMalloc(&ctx->d_lev_rows, n * sizeof(LevRow5)));
+    hipLaunchKernelGGL(k_lev_rows, dim3((n + 63) / 64), dim3(64), 0, 0, g, ctx->d_pi_dry, (LevRow5 *)ctx->d_lev_rows, n);
     BZ_HIP(hipGetLastError());
     BZ_HIP(hipDeviceSynchronize());
     BZ_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
@@ -39,6 +53,8 @@ void bzi_lean_teardown(bz_ctx *ctx)
 {
     if (ctx->d_pi_dry) hipFree(ctx->d_pi_dry);
     ctx->d_pi_dry = nullptr;
+    if (ctx->d_lev_rows) hipFree(ctx->d_lev_rows);
+    ctx->d_lev_rows = nullptr;
     if (ctx->side_stream) { hipStreamSynchronize(ctx->side_stream); hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
@@ -80,7 +96,8 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
     Lean5 L;
     L.ru = s->rho_u; L.rv = s->rho_v; L.rw = s->rho_w; L.pa = pa; L.pb = pb; L.oa = oa; L.ob = ob; L.out = nullptr;
     L.T = s->T;
-    L.pi_dry = ColPtr(getenv("BZ_NO_PI_DRY") ? nullptr : ctx->d_pi_dry + g.Hz);
+    L.pi_dry = ColPtr(ctx->d_pi_dry + g.Hz);
+    L.lev = (const LevRow5 *)ctx->d_lev_rows + g.Hz;
     const dim3 block(64, TY);
     const int tx = (g.Nx + 63) / 64, nty = (g.Ny + TY - 1) / TY;
     if (rows && nty < 3) return rows == 1 ? BZ_OK : lean_launch<TY>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, 0, which);

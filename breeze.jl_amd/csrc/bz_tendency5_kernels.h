@@ -25,6 +25,33 @@
 typedef long long ix_t;
 typedef unsigned ix32_t;     // z-momentum kernel: 32-bit (138 -> 121 VGPRs, 3 -> 4 waves per SIMD; measured 3.61 -> 2.94 ms)
 
+// Column constants of one level, packed: the scalar-pair kernel reads eleven column-table entries per level; as separate tables that
+// is eleven address computations + s_loads and 22 SGPRs of pointers (the kernel spilled 44 SGPRs to VGPR lanes: ~50 v_readlane per
+// level); as one row it is one s_load_dwordx16 (+ two narrow ones for the levels above).  Built on the device from the same tables
+// (k_lev_rows, bz_tendency5.hip), so every value carries the bits the separate tables hold.
+struct LevRow5 {
+    double rho, rrho;        // rho_r[k] and its correctly rounded reciprocal
+    double rho_f, rrho_f;    // the same at the lower face of level k
+    double Ax, Ay, Vinv_c;
+    double pi;               // dry Exner factor (p_r[k]/p_st)^(Rd/cpd)
+};
+// row access through the constant address space, field by field (adjacent fields merge into one wide s_load)
+struct Lev5 {
+    const LevRow5 *p;
+#ifdef __HIPCC__
+    __device__ __forceinline__ double at(int k, int f) const { return ((ColPtr::cptr)(const double *)p)[(long long)k * 8 + f]; }
+    __device__ __forceinline__ double rho(int k) const { return at(k, 0); }
+    __device__ __forceinline__ double rrho(int k) const { return at(k, 1); }
+    __device__ __forceinline__ double rho_f(int k) const { return at(k, 2); }
+    __device__ __forceinline__ double rrho_f(int k) const { return at(k, 3); }
+    __device__ __forceinline__ double Ax(int k) const { return at(k, 4); }
+    __device__ __forceinline__ double Ay(int k) const { return at(k, 5); }
+    __device__ __forceinline__ double Vinv_c(int k) const { return at(k, 6); }
+    __device__ __forceinline__ double pi(int k) const { return at(k, 7); }
+#endif
+};
+static_assert(sizeof(LevRow5) == 8 * sizeof(double), "LevRow5 is eight reals");
+
 struct Lean5 {
     const double *ru, *rv, *rw;      // stage-start momentum (halos valid)
     const double *pa, *pb;           // stage-start rho theta, rho q (halos valid)
@@ -32,6 +59,7 @@ struct Lean5 {
     double *oa, *ob;                 // scalar kernel: updated rho theta, rho q (the other buffer of the ping-pong pair)
     double *T;                       // temperature of the stage-start state (w kernel: read; scalar kernel: writes the updated one)
     ColPtr pi_dry;                   // (p_r[k]/p_st)^(Rd/cpd) indexed by level, or nullptr
+    const LevRow5 *lev;              // the column constants of a level packed in one 64-byte row (indexed by level, -Hz .. Nz+Hz-1)
     int xcd;                         // 1: XCD-contiguous block order (grid size divisible by 8)
     int by0, bys;                    // tile row of block row b is by0 + b * bys (sub-launches of the slab driver: interior rows
                                      // while the y-halo exchange is in flight, then the two edge rows)
@@ -88,6 +116,17 @@ __device__ __forceinline__ double bz_temperature5(const DevGrid &g, double rth, 
     return bz_exner_pow5(g.p_r[k] / g.pst, Rm / cpm) * th;
 }
 
+// the same with the level's constants already in registers (LevRow5)
+__device__ __forceinline__ double bz_temperature5r(const DevGrid &g, double rth, double rq, int k, double rho, double rrho, double pi)
+{
+    const double th = bz_cdiv(rth, rho, rrho), q = bz_cdiv(rq, rho, rrho);
+    if (__all(q == 0.0)) return pi * th;
+    const double qd = 1.0 - q;
+    const double Rm = qd * g.Rd + q * g.Rv;
+    const double cpm = qd * g.cpd + q * g.cpv;
+    return bz_exner_pow5(g.p_r[k] / g.pst, Rm / cpm) * th;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // rho theta + rho q: tendencies -div_rhoUc(theta), -div_rhoUc(q) and their SSP-RK3 update, from rho u, rho v, rho w,
 // rho theta, rho q alone.  Structure of k_scalar_pair_lds: 64 x TY tile marching in z, (TY+6) x 70 frame of theta and q in LDS
@@ -95,7 +134,7 @@ __device__ __forceinline__ double bz_temperature5(const DevGrid &g, double rth, 
 // shuffle + the batched out-of-wave flux, z stencils in register rings.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TY>
-__global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
+__global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4))) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72;                 // tile rows, padded row length (70 used)
     constexpr int NHALO = TR * 70 - TY * 64;            // frame cells per field
@@ -107,6 +146,8 @@ __global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, in
     int bx, by, bz;
     bz_block5(F, bx, by, bz);
     const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
+    const int tyu = __builtin_amdgcn_readfirstlane(ty);      // one tile row per wavefront: wave-uniform, kept in an SGPR for the duty tests below
+    const Lev5 LV{F.lev};
     const int i0 = bx * 64, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
     const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
@@ -177,6 +218,9 @@ __global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, in
 
     double ea = 0.0, eb = 0.0;
     int buf = 0;
+    // the level's own momentum elements arrive one level ahead (software pipeline: the advecting fluxes are the first thing a level
+    // computes, so loads issued at its top were waited for at once — a full memory latency per level and wave)
+    double ru_n = ru[n], rv_n = rv[n], rw_n = rw[n + sz];
     for (int k = kbeg; k < kend; ++k, n += sz) {
         // ---- loads: next level's frame cells, ring tops, momentum of this level ----
         double ha[HPT], hb[HPT];
@@ -184,9 +228,20 @@ __global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, in
 #pragma unroll
         for (int q = 0; q < HPT; ++q) { ha[q] = hok[q] ? pa[hn[q] + lev] : 0.0; hb[q] = hok[q] ? pb[hn[q] + lev] : 0.0; }
         const double ta_raw = pa[n + 3 * sz], tb_raw = pb[n + 3 * sz];
-        const double ru_t = ru[n], rv_t = rv[n], rw_t = rw[n + sz];
-        const double rvtop = (ty == 0) ? rv[ntop0 + lev - sz] : 0.0;
-        const double rho = g.rho[k], rrho = g.rrho[k];
+        const double ru_t = ru_n, rv_t = rv_n, rw_t = rw_n;
+        ru_n = ru[n + sz]; rv_n = rv[n + sz]; rw_n = rw[n + 2 * sz];      // level k + 1 (level kend of the last trip is a halo level: in bounds, unused)
+        // U0 of both fields is needed by the RK update at the very end of the level: issue the loads here (round 2 loaded them at the
+        // point of use, two exposed memory latencies per level and wave)
+        const double u0a = (E.mode == 2) ? E.u0[n] : 0.0, u0b = (E.mode == 2) ? E.u0b[n] : 0.0;
+        // The y face above the tile belongs to no row of the tile: one wavefront per field evaluates it, and the duty rotates with the
+        // level (field a: row (k - kbeg) mod TY, field b: half a turn later).  With a fixed wave 0 doing both, that wave ran 8 WENOs per
+        // level against 6 of the others, every level's barrier waited for it, and its SIMD carried 19 % more work than the other three.
+        const int turn = (k - kbeg) & (TY - 1);
+        const bool duty_a = tyu == turn, duty_b = tyu == ((turn + TY / 2) & (TY - 1));
+        const double rvtop = (duty_a || duty_b) ? rv[ntop0 + lev - sz] : 0.0;
+        const double rho = LV.rho(k), rrho = LV.rrho(k), Ax_k = LV.Ax(k), Ay_k = LV.Ay(k), Vi_k = LV.Vinv_c(k), pi_k = LV.pi(k);
+        const double rho1 = LV.rho(k + 1), rrho1 = LV.rrho(k + 1), rhof1 = LV.rho_f(k + 1), rrhof1 = LV.rrho_f(k + 1);
+        const double rho3 = LV.rho(k + 3), rrho3 = LV.rrho(k + 3);
         if (((k - kbeg) & 63) == 0) {       // out-of-wave x flux for the next 64 levels (lane l <-> level k + l)
             const int kk = min(k + tx, kend - 1);
             const long long ne = g.idx(ie, jc, kk);
@@ -202,40 +257,40 @@ __global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, in
         const int src = (k - kbeg) & 63;
         // advecting fluxes of the three low/upper faces (shared by both fields)
         const double ut = bz_cdiv(ru_t, rho, rrho), vt = bz_cdiv(rv_t, rho, rrho);
-        const double wt = bz_cdiv(rw_t, g.rho_f[k + 1], g.rrho_f[k + 1]);
-        const double cfx = g.Ax[k] * ut, cfy = g.Ay[k] * vt, cfz = g.Az * wt, rf = g.rho_f[k + 1];
+        const double wt = bz_cdiv(rw_t, rhof1, rrhof1);
+        const double cfx = Ax_k * ut, cfy = Ay_k * vt, cfz = g.Az * wt, rf = rhof1;
         const bool lx = ut > 0.0, ly = vt > 0.0, lz = wt > 0.0;
         const int Bz = bz_buffer_face(k + 1, g.Nz);
         double cfy2 = 0.0;
         bool ly2 = false;
-        if (ty == 0) {
+        if (duty_a || duty_b) {
             const double vtop = bz_cdiv(rvtop, rho, rrho);
             ly2 = vtop > 0.0;
-            cfy2 = g.Ay[k] * vtop;
+            cfy2 = Ay_k * vtop;
         }
         const int c = tx + 3;
         // one field at a time (keeps the live set of the WENO evaluations small): x low face from the tile row, y low face from
         // the tile column (wave 0 also the face above the tile), upper z face from the ring
         double fxa, fya, fza_hi, fxb, fyb, fzb_hi;
-        const double ta = bz_cdiv(ta_raw, g.rho[k + 3], g.rrho[k + 3]);
+        const double ta = bz_cdiv(ta_raw, rho3, rrho3);
         {
             const double(*Tk)[TC] = T[buf][0];
             const double *rr_ = Tk[ty + 3] + tx;
             fxa = rho * (cfx * bz_up5(rr_[0], rr_[1], rr_[2], a[3], rr_[4], rr_[5], lx));
             fya = rho * (cfy * bz_up5(Tk[ty][c], Tk[ty + 1][c], Tk[ty + 2][c], a[3], Tk[ty + 4][c], Tk[ty + 5][c], ly));
             FY[buf][0][ty][tx] = fya;
-            if (ty == 0)
+            if (duty_a)
                 FY[buf][0][TY][tx] = rho * (cfy2 * bz_up5(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2));
             fza_hi = rf * (cfz * bz_upB(a[1], a[2], a[3], a[4], a[5], ta, lz, Bz));
         }
-        const double tb = bz_cdiv(tb_raw, g.rho[k + 3], g.rrho[k + 3]);
+        const double tb = bz_cdiv(tb_raw, rho3, rrho3);
         {
             const double(*Tk)[TC] = T[buf][1];
             const double *rr_ = Tk[ty + 3] + tx;
             fxb = rho * (cfx * bz_up5(rr_[0], rr_[1], rr_[2], b[3], rr_[4], rr_[5], lx));
             fyb = rho * (cfy * bz_up5(Tk[ty][c], Tk[ty + 1][c], Tk[ty + 2][c], b[3], Tk[ty + 4][c], Tk[ty + 5][c], ly));
             FY[buf][1][ty][tx] = fyb;
-            if (ty == 0)
+            if (duty_b)
                 FY[buf][1][TY][tx] = rho * (cfy2 * bz_up5(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2));
             fzb_hi = rf * (cfz * bz_upB(b[1], b[2], b[3], b[4], b[5], tb, lz, Bz));
         }
@@ -243,7 +298,7 @@ __global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, in
         T[buf ^ 1][0][ty + 3][tx + 3] = a[4];
         T[buf ^ 1][1][ty + 3][tx + 3] = b[4];
         {
-            const double rh = g.rho[k + 1], rr = g.rrho[k + 1];
+            const double rh = rho1, rr = rrho1;
 #pragma unroll
             for (int q = 0; q < HPT; ++q)
                 if (hok[q]) {
@@ -251,7 +306,11 @@ __global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, in
                     T[buf ^ 1][1][hr[q]][hc[q]] = bz_cdiv(hb[q], rh, rr);
                 }
         }
+#ifdef BZ_EXP_NO_REREAD
+        const double pa_n = ta_raw, pb_n = tb_raw;      // timing experiment only (wrong values): what does the own-cell re-read cost?
+#else
         const double pa_n = pa[n], pb_n = pb[n];      // the cell's own prognostic values (read three levels ago as ring tops)
+#endif
         __syncthreads();
         // ---- combine, SSP-RK3 update, temperature of the updated cell for the next stage's buoyancy ----
         {
@@ -260,15 +319,15 @@ __global__ __launch_bounds__(64 * TY) void k5_scalar_pair(DevGrid g, Lean5 F, in
             if (tx == le) { na = xa; nb = xb; }
             const double dya = FY[buf][0][ty + 1][tx] - fya;
             const double dyb = FY[buf][1][ty + 1][tx] - fyb;
-            const double Vi = g.Vinv_c[k];
+            const double Vi = Vi_k;
             const double ga = -(Vi * ((na - fxa) + dya + (fza_hi - fza)));
             const double gb = -(Vi * ((nb - fxb) + dyb + (fzb_hi - fzb)));
             if (store) {
-                const double rth = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out, ga, pa_n, n);
-                const double rq = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0b, E.u0b_out, gb, pb_n, n);
+                const double rth = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0a, E.u0_out, ga, pa_n, n);
+                const double rq = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0b, E.u0b_out, gb, pb_n, n);
                 F.oa[n] = rth;        // interior only: the projection kernel that follows stores the periodic images
                 F.ob[n] = rq;
-                F.T[n] = bz_temperature5(g, rth, rq, k, F.pi_dry);
+                F.T[n] = bz_temperature5r(g, rth, rq, k, rho, rrho, pi_k);
             }
         }
         fza = fza_hi; fzb = fzb_hi;

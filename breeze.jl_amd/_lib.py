@@ -87,7 +87,7 @@ class bz_column_forcings(C.Structure):
                 ("subsidence_u", C.c_int32), ("subsidence_v", C.c_int32), ("subsidence_theta", C.c_int32),
                 ("subsidence_moisture", C.c_int32), ("coriolis_f", C.c_double),
                 ("bottom_theta_flux", C.c_double), ("bottom_moisture_flux", C.c_double),
-                ("bottom_drag_rho0_ustar2", C.c_double)]
+                ("bottom_drag_rho0_ustar2", C.c_double), ("bottom_drag_epsilon", C.c_double)]
 
 
 _KESSLER_PARAMS = ("dcmip_temperature_scale", "terminal_velocity_coefficient", "density_scale", "terminal_velocity_exponent",

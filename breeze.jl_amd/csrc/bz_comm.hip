@@ -276,8 +276,8 @@ static int comm_attach(bz_ctx *ctx, Transport *T)
     c->rank = ctx->y_rank;
     c->upper = (c->rank + 1) % c->W;
     c->lower = (c->rank + c->W - 1) % c->W;
-    c->overlap = !getenv("BZ_COMM_NO_OVERLAP");
-    c->self_messages = getenv("BZ_COMM_SELF_MESSAGES") != nullptr;
+    c->overlap = !ctx->tune.comm_no_overlap;
+    c->self_messages = ctx->tune.comm_self_messages;
     BZ_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     BZ_HIP(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     BZ_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
@@ -721,7 +721,7 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
         // The scalar-pair kernel feeds nothing of the pressure solve: with messages in flight (W > 1) it runs on the context's second
         // stream beside the source term, the transforms and both all-to-alls, and is joined before the projection kernel.
-        const bool fork = (c->W > 1 || c->self_messages || ctx->side_scalar) && !getenv("BZ_COMM_NO_SIDE_SCALAR");
+        const bool fork = (c->W > 1 || c->self_messages || ctx->side_scalar) && !ctx->tune.comm_no_side_scalar;
         const int first_part = fork ? 1 : 3;
         if (c->halo_pending) {
             // the halos of the stage-start state are still travelling on the side stream: interior tile rows first

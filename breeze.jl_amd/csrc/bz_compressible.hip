@@ -733,7 +733,7 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
     ctx->se = *td;
     ctx->has_reference = ref->density != nullptr;
     const size_t ncell = (size_t)ctx->dg.Sxy * (size_t)nc;
-    ctx->ac_fused = !getenv("BZ_NO_AC_FUSE");
+    ctx->ac_fused = !ctx->tune.no_ac_fuse;
     if (hipMalloc(&ctx->d_Clin, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_tfac_ac, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_up2, ncell * sizeof(double)) != hipSuccess ||

@@ -42,6 +42,32 @@ static void profile_drain(bz_ctx *ctx)
     }
 }
 
+void bzi_read_tuning(bz_tuning &t)
+{
+    auto on = [](const char *n) { return getenv(n) != nullptr; };
+    auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
+    t.no_fused = on("BZ_NO_FUSED");
+    t.no_fuse_rk = on("BZ_NO_FUSE_RK");
+    t.no_tend_lds = on("BZ_NO_TEND_LDS");
+    t.tend_gen = num("BZ_TEND_GEN", 0);
+    t.no_lean = on("BZ_NO_LEAN");
+    t.no_xcd = on("BZ_NO_XCD");
+    t.side_scalar = on("BZ_SIDE_SCALAR");
+    t.no_fuse_forcing = on("BZ_NO_FUSE_FORCING");
+    t.no_tridiag_coop = on("BZ_NO_TRIDIAG_COOP");
+    t.no_xfft = on("BZ_NO_XFFT");
+    t.poisson_chunk = num("BZ_POISSON_CHUNK", 0);
+    t.xf_kchunk_f = num("BZ_XF_KCHUNK_F", 0);
+    t.xf_kchunk_i = num("BZ_XF_KCHUNK_I", 0);
+    t.generic_onepass = on("BZ_GENERIC_ONEPASS");
+    t.no_ac_fuse = on("BZ_NO_AC_FUSE");
+    t.comm_no_overlap = on("BZ_COMM_NO_OVERLAP");
+    t.comm_self_messages = on("BZ_COMM_SELF_MESSAGES");
+    t.comm_no_side_scalar = on("BZ_COMM_NO_SIDE_SCALAR");
+    t.graph = num("BZ_GRAPH", -1);
+    t.graph_debug = on("BZ_GRAPH_DEBUG");
+}
+
 extern "C" int bz_profile_enable(bz_ctx *ctx, int on)
 {
     if (!ctx) return BZ_ERR_INVALID;
@@ -183,6 +209,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (grid->Nx < grid->Hx || grid->Ny < grid->Hy || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;
 
     bz_ctx *ctx = new (std::nothrow) bz_ctx();
+    if (ctx) bzi_read_tuning(ctx->tune);      // the only place the environment is read
     if (!ctx) return BZ_ERR_ALLOC;
     ctx->grid = *grid;
     ctx->grid.zf = nullptr;
@@ -284,7 +311,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.wrap_y = slab_mode ? 0 : 1;
     g.flat_y = flat_y ? 1 : 0;
 
-    ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !getenv("BZ_NO_FUSED");
+    ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !ctx->tune.no_fused;
 #ifndef BZ_CENTERED2
     ctx->weno_R = weno_R;
     // the fused / lean tiers of the anelastic model are order-5 kernels: orders 7, 9 step operator by operator (the compressible
@@ -292,9 +319,9 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (weno_R != 3 && !compressible) ctx->fused_ok = false;
 #endif
     if (slab_mode && (Ny < grid->Hy || Nx < 2 * grid->Hx)) { delete ctx; return BZ_ERR_UNSUPPORTED; }
-    if (const char *tg = getenv("BZ_TEND_GEN")) ctx->tend_gen = atoi(tg);
-    ctx->fuse_rk = !getenv("BZ_NO_FUSE_RK");
-    ctx->tend_lds = !getenv("BZ_NO_TEND_LDS");
+    if (ctx->tune.tend_gen) ctx->tend_gen = ctx->tune.tend_gen;
+    ctx->fuse_rk = !ctx->tune.no_fuse_rk;
+    ctx->tend_lds = !ctx->tune.no_tend_lds;
     // Flat y: the anelastic model steps with one kernel per reference kernel (bz_tendency.hip); the compressible kernels reach their
     // y neighbours through wrap offsets, which are zero when Ny = 1 (bz_compressible.hip: wrap_of), and keep their fused sequence
     if (flat_y) { if (!compressible) ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }

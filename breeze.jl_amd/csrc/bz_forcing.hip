@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F
 }
 
 // bottom FluxBoundaryConditions: G[i,j,1] += J / dz_1 (Oceananigans apply_z_bcs!); the drag flux of examples/bomex.jl:95-101
-__global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, double Jq, double drag, double *__restrict__ Gu,
+__global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, double Jq, double drag, double drag_eps, double *__restrict__ Gu,
                                                      double *__restrict__ Gv, double *__restrict__ Gth,
                                                      double *__restrict__ Gq, const double *__restrict__ ru,
                                                      const double *__restrict__ rv, double scale)
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, doub
         const double v_fc = (va + vb) / 2;
         const double ua = (ru[n - sy] + ru[n - sy + sx]) / 2, ub = (ru[n] + ru[n + sx]) / 2;
         const double u_cf = (ua + ub) / 2;
-        Gu[n] += scale * ((-drag * u / sqrt(u * u + v_fc * v_fc)) / dz);
-        Gv[n] += scale * ((-drag * v / sqrt(u_cf * u_cf + v * v)) / dz);
+        Gu[n] += scale * ((-drag * u / sqrt(u * u + v_fc * v_fc + drag_eps)) / dz);
+        Gv[n] += scale * ((-drag * v / sqrt(u_cf * u_cf + v * v + drag_eps)) / dz);
     }
 }
 
@@ -238,6 +238,7 @@ extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
     ctx->forcing_flux_theta = f->bottom_theta_flux;
     ctx->forcing_flux_q = f->bottom_moisture_flux;
     ctx->forcing_drag = f->bottom_drag_rho0_ustar2;
+    ctx->forcing_drag_eps = f->bottom_drag_epsilon;
     ctx->has_forcings = true;
     return BZ_OK;
 }
@@ -355,7 +356,7 @@ int bzi_flux_bc(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "flux_bc_tendencies");
     hipLaunchKernelGGL(k_bottom_flux, dim3((g.Nx + 255) / 256, g.Ny), dim3(256), 0, ctx->stream, g, ctx->forcing_flux_theta,
-                       ctx->forcing_flux_q, ctx->forcing_drag, Gu, Gv, Gth, Gq, s->rho_u, s->rho_v, scale);
+                       ctx->forcing_flux_q, ctx->forcing_drag, ctx->forcing_drag_eps, Gu, Gv, Gth, Gq, s->rho_u, s->rho_v, scale);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -296,12 +296,12 @@ __global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, dou
 static size_t xf_lds_bytes(int n2) { return ((size_t)XF_RB * XF_ROW_STRIDE(n2) + 3 * n2 / 2) * sizeof(double2); }
 // levels one block of the x-transform kernels walks: 16 on large grids (the twiddle table is staged once per block), fewer when
 // that would leave less than ~1024 blocks for the 256 CUs (64^3: 32 blocks of 16 levels took 52 us, 512 blocks of one level 1/3 of that)
-static int xf_chunk(const char *env, int dflt, const DevGrid &g)
+static int xf_chunk(int forced, int dflt, const DevGrid &g)
 {
     int kc = dflt;
     const long long rows = (long long)(g.Ny / XF_RB) * g.Nz;
     while (kc > 1 && rows / kc < 1024) kc >>= 1;
-    if (const char *e = getenv(env)) { const int v = atoi(e); if (v > 0) kc = v; }
+    if (forced > 0) kc = forced;
     return kc < g.Nz ? kc : g.Nz;
 }
 
@@ -311,7 +311,7 @@ static int xf_chunk(const char *env, int dflt, const DevGrid &g)
 int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor, const double *rhs, double *hat, int blocks)
 {
     const DevGrid &g = ctx->dg;
-    const int n2 = g.Nx / 2, kc = xf_chunk("BZ_XF_KCHUNK_F", 16, g);
+    const int n2 = g.Nx / 2, kc = xf_chunk(ctx->tune.xf_kchunk_f, 16, g);
     const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
     const size_t lds = xf_lds_bytes(n2);
     XfLayout L;
@@ -339,7 +339,7 @@ int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognosti
 int bzi_xf_inverse(bz_ctx *ctx, const double *hat, double *phi, int blocks)
 {
     const DevGrid &g = ctx->dg;
-    const int n2 = g.Nx / 2, kc = xf_chunk("BZ_XF_KCHUNK_I", 16, g);
+    const int n2 = g.Nx / 2, kc = xf_chunk(ctx->tune.xf_kchunk_i, 16, g);
     XfLayout L;
     L.nkx = blocks > 1 ? ctx->nkx : n2 + 1;
     L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;

@@ -23,7 +23,7 @@
 static void give_up(bz_ctx *ctx, const char *where, hipError_t e, int body_rc)
 {
     ctx->graph_mode = 0;
-    if (getenv("BZ_GRAPH_DEBUG"))
+    if (ctx->tune.graph_debug)
         fprintf(stderr, "[bz_graph] replay disabled at %s: hip error %d (%s), body rc %d (%s)\n", where, (int)e, hipGetErrorString(e), body_rc,
                 ctx->last_error.c_str());
     (void)hipGetLastError();
@@ -149,7 +149,7 @@ int bzi_graph_end(bz_ctx *ctx, uint64_t key, int body_rc)
 void bzi_graph_configure(bz_ctx *ctx)
 {
     ctx->graph_mode = 0;
-    if (const char *e = getenv("BZ_GRAPH")) ctx->graph_mode = atoi(e) != 0 ? 1 : 0;
+    if (ctx->tune.graph >= 0) ctx->graph_mode = ctx->tune.graph != 0 ? 1 : 0;
 }
 
 extern "C" int bz_graph_info(bz_ctx *ctx, int32_t *enabled, int64_t *captures, int64_t *replays)

@@ -239,7 +239,33 @@ struct ProfileSlot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// Every BZ_* environment switch of the library, read ONCE when a context is created (bzi_read_tuning, bz_context.hip): nothing on a
+// launch path calls getenv.  They select measured alternatives for A/B runs; defaults are the shipped choices.
+struct bz_tuning {
+    bool no_fused = false;            // BZ_NO_FUSED: per-operator sequence instead of the fused whole-step tiers
+    bool no_fuse_rk = false;          // BZ_NO_FUSE_RK
+    bool no_tend_lds = false;         // BZ_NO_TEND_LDS: generation-1 (untiled) tendency kernels
+    int tend_gen = 0;                 // BZ_TEND_GEN (0: default)
+    bool no_lean = false;             // BZ_NO_LEAN: fused-RK tier instead of the lean (prognostic-only) seam
+    bool no_xcd = false;              // BZ_NO_XCD: hardware block order in the lean kernels
+    bool side_scalar = false;         // BZ_SIDE_SCALAR: scalar kernel beside the pressure solve on one GPU too
+    bool no_fuse_forcing = false;     // BZ_NO_FUSE_FORCING
+    bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
+    bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms
+    int poisson_chunk = 0;            // BZ_POISSON_CHUNK: level-chunked Poisson pipeline (needs BZ_NO_XFFT)
+    int xf_kchunk_f = 0, xf_kchunk_i = 0;      // BZ_XF_KCHUNK_F / _I: levels per block of the x transforms (0: automatic)
+    bool generic_onepass = false;     // BZ_GENERIC_ONEPASS: WENO 7 / 9 with every flux evaluated by both of its cells
+    bool no_ac_fuse = false;          // BZ_NO_AC_FUSE: three kernels per acoustic substep
+    bool comm_no_overlap = false;     // BZ_COMM_NO_OVERLAP
+    bool comm_self_messages = false;  // BZ_COMM_SELF_MESSAGES: world 1 sends every message to itself
+    bool comm_no_side_scalar = false; // BZ_COMM_NO_SIDE_SCALAR
+    int graph = -1;                   // BZ_GRAPH (-1: unset)
+    bool graph_debug = false;         // BZ_GRAPH_DEBUG
+};
+void bzi_read_tuning(bz_tuning &t);
+
 struct bz_ctx {
+    bz_tuning tune;
     bz_grid grid;
     bz_constants constants;
     DevGrid dg;
@@ -309,7 +335,7 @@ struct bz_ctx {
     bool has_forcings = false;
     double *d_forcing = nullptr;      // static profiles, subsidence velocity, level averages, subsidence profiles, partial sums
     int forcing_static_mask = 0, forcing_subsidence_mask = 0;
-    double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0;
+    double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0, forcing_drag_eps = 0.0;
     // BulkDrag / BulkSensibleHeatFlux / BulkVaporFlux bottom conditions (bz_set_bulk_surface_fluxes, bz_forcing.hip)
     bool has_bulk = false;
     bz_bulk_surface_fluxes bulk;

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
 static int tridiag_coop_segs(const bz_ctx *ctx, int)
 {
     const int Nz = ctx->dg.Nz;
-    if (getenv("BZ_NO_TRIDIAG_COOP")) return 0;
+    if (ctx->tune.no_tridiag_coop) return 0;
     if (Nz >= 128 && Nz <= 64 * TCO_M) return 64;
     if (Nz >= 32 && Nz < 128) return 16;
     if (Nz >= 16 && Nz < 32) return 8;
@@ -345,7 +345,7 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     const int nxh_real = Nx / 2 + 1;
     // hand-written x transforms + transposed spectrum: Nx a power of two in [16, 1024] (one team of Nx / 8 <= 128 threads per row, 8 rows per
     // workgroup in 45 KiB of LDS)
-    const bool xf_shape = Nx >= 16 && Nx <= 1024 && (Nx & (Nx - 1)) == 0 && g.Ny % 8 == 0 && !getenv("BZ_NO_XFFT");
+    const bool xf_shape = Nx >= 16 && Nx <= 1024 && (Nx & (Nx - 1)) == 0 && g.Ny % 8 == 0 && !ctx->tune.no_xfft;
     ctx->xf = !slab && xf_shape && g.wrap_y;
     ctx->xf_slab = slab && xf_shape;
     int Ny = g.Ny;                       // rows of the spectral block: local rows, or ALL rows in slab mode
@@ -437,8 +437,7 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
         BZ_FFT(hipfftSetStream(ctx->plan_y, ctx->stream));
     }
     // chunk plans of the L3-resident pipeline
-    int ch = 0;
-    if (const char *e = getenv("BZ_POISSON_CHUNK")) ch = atoi(e);
+    int ch = ctx->tune.poisson_chunk;
     if (ch > 0 && ch < Nz && Nz % ch == 0 && !ctx->xf) {
         BZ_FFT(hipfftPlanMany(&ctx->plan_fwd_c, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, ch));
         BZ_FFT(hipfftPlanMany(&ctx->plan_inv_c, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, ch));

@@ -157,7 +157,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
         return BZ_OK;
     }
     if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !ctx->bounded_mask &&
-        !(ctx->has_forcings && getenv("BZ_NO_FUSE_FORCING"))) {
+        !(ctx->has_forcings && ctx->tune.no_fuse_forcing)) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state
         // left by stage s-1), the predictor momentum goes to the G arrays and is projected from there into the

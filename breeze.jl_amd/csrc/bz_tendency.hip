@@ -380,21 +380,21 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     }
     int kc = pick_kchunk(g, g.Nz);
     dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
-    if (ctx->tend_gen >= 2 && ctx->tend_lds && !getenv("BZ_NO_U_LDS")) {
+    if (ctx->tend_gen >= 2 && ctx->tend_lds) {
         int rc = bzi_u_tendency_lds(ctx, s, G);
         if (rc) return rc;
     } else {
         ProfileScope ps(ctx, "x_momentum_tendency");
         hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, RKEpilogue());
     }
-    if (ctx->tend_gen >= 2 && ctx->tend_lds && !getenv("BZ_NO_V_LDS")) {
+    if (ctx->tend_gen >= 2 && ctx->tend_lds) {
         int rc = bzi_v_tendency_lds(ctx, s, G);
         if (rc) return rc;
     } else {
         ProfileScope ps(ctx, "y_momentum_tendency");
         hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc, RKEpilogue());
     }
-    if (ctx->tend_gen >= 2 && !getenv("BZ_W_GEN1")) {
+    if (ctx->tend_gen >= 2) {
         int rc = bzi_w_tendency_ring(ctx, s, G);
         if (rc) return rc;
     } else {
@@ -465,7 +465,7 @@ int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, E);
     }
-    if (ctx->tend_lds && !getenv("BZ_NO_V_LDS")) {
+    if (ctx->tend_lds) {
         int rcv = bzi_v_tendency_lds(ctx, s, G, U0, &E);
         if (rcv) return rcv;
     } else {

@@ -30,9 +30,9 @@ static int pick_chunk_lds(const DevGrid &g, int nlev, int rows_per_block)
     // small grids (BOMEX 256 x 256 x 128: 128 tiles; the 168 x 168 x 40 supercell box: 63): filling the 256 CUs matters more
     // than the prologue, go down to 8-level chunks until there are two blocks per CU (measured: supercell box 3.3 -> 2.5 ms/step,
     // BOMEX 128 x 128 x 96 2.6 -> 1.7 ms/step against a 32-level floor; 512^3 is not affected)
-    if (tiles * want < 512 && !getenv("BZ_NO_SMALL_CHUNKS")) {
+    if (tiles * want < 512) {
         long long fill = (512 + tiles - 1) / tiles;
-        const int minlev = getenv("BZ_MIN_CHUNK") ? atoi(getenv("BZ_MIN_CHUNK")) : 8;
+        const int minlev = 8;
         long long cap = nlev / minlev > 0 ? nlev / minlev : 1;
         if (fill > cap) fill = cap;
         if (fill > want) want = fill;
@@ -85,7 +85,7 @@ int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, Ein ? "scalar_tendencies+rk3" : "scalar_tendencies");
-    const bool gen3 = !Ein && getenv("BZ_PAIR_GEN3");
+    const bool gen3 = false;      // the generation-3 pair kernel stays for reference; the LDS-tiled one is what runs
     const int TYP = gen3 ? T3_TYW : 8;
     const int kc = gen3 ? pick_chunk3(g, g.Nz, T3_TYW) : pick_chunk_lds(g, g.Nz, 8);
     dim3 block(64, TYP), grid((g.Nx + 63) / 64, (g.Ny + TYP - 1) / TYP, (g.Nz + kc - 1) / kc);
@@ -128,7 +128,7 @@ int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, 
         dim3 block(64, 8), grid((g.Nx + 63) / 64, (g.Ny + 7) / 8, (nlev + kc - 1) / kc);
         if (buoyancy_mode == 1) hipLaunchKernelGGL((k_w_tend_lds<8, 1>), grid, block, 0, ctx->stream, g, F, kc, E);
         else hipLaunchKernelGGL((k_w_tend_lds<8, 2>), grid, block, 0, ctx->stream, g, F, kc, E);
-    } else if (ctx->tend_lds && !getenv("BZ_NO_W_LDS")) {
+    } else if (ctx->tend_lds) {
         // in situ (512^3 bubble): ring 3.3 ms, LDS tile with 8 rows 2.9 ms, with 4 rows 3.9 ms per launch
         const int kc = pick_chunk_lds(g, nlev, 8);
         dim3 block(64, 8), grid((g.Nx + 63) / 64, (g.Ny + 7) / 8, (nlev + kc - 1) / kc);

@@ -43,9 +43,9 @@ int bzi_lean_setup(bz_ctx *ctx)
     BZ_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     // single GPU: measured 47.4 -> 46.4 ms/step at 512^3 when on, but concurrent kernels make per-kernel durations (and the roofline
     // bookkeeping built on them) meaningless, so it is opt-in there; the distributed step turns it on whenever messages are in flight
-    ctx->side_scalar = getenv("BZ_SIDE_SCALAR") != nullptr;
-    ctx->lean = !getenv("BZ_NO_LEAN");
-    ctx->lean_xcd = !getenv("BZ_NO_XCD");
+    ctx->side_scalar = ctx->tune.side_scalar;
+    ctx->lean = !ctx->tune.no_lean;
+    ctx->lean_xcd = !ctx->tune.no_xcd;
     return BZ_OK;
 }
 
@@ -67,7 +67,6 @@ static int pick_chunk5(const DevGrid &g, int nlev, int rows_per_block)
     long long tiles = (long long)((g.Nx + 63) / 64) * ((g.Ny + rows_per_block - 1) / rows_per_block);
     long long want = (1024 + tiles - 1) / tiles;
     long long maxchunks = nlev / 128 > 0 ? nlev / 128 : 1;
-    if (const char *e = getenv("BZ_LEAN_MAXCHUNK_LEVELS")) { int m = atoi(e); if (m > 0) maxchunks = nlev / m > 0 ? nlev / m : 1; }
     if (want > maxchunks) want = maxchunks;
     if (want < 1) want = 1;
     if (tiles * want < 512) {
@@ -116,30 +115,21 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         L.out = G->rho_u;
         const dim3 grid = shape(g.Nz, kc);
-        if constexpr (TY == 8) {
-            if (getenv("BZ_U_GEN5")) hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-            else hipLaunchKernelGGL((k6_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-        } else hipLaunchKernelGGL((k5_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        hipLaunchKernelGGL((k6_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 1) {
         ProfileScope ps(ctx, "y_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
         L.out = G->rho_v;
         const dim3 grid = shape(g.Nz, kc);
-        if constexpr (TY == 8) {
-            if (getenv("BZ_V_GEN5")) hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-            else hipLaunchKernelGGL((k6_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-        } else hipLaunchKernelGGL((k5_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        hipLaunchKernelGGL((k6_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 1) {
         ProfileScope ps(ctx, "z_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_w; E.u0_out = U0->rho_w;
         L.out = G->rho_w;
         const dim3 grid = shape(g.Nz - 1, kc);
-        if constexpr (TY == 8) {
-            if (getenv("BZ_W_GEN5")) hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-            else hipLaunchKernelGGL((k6_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
-        } else hipLaunchKernelGGL((k5_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        hipLaunchKernelGGL((k6_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 2) {
         ProfileScope ps(ctx, "scalar_tendencies+rk3+thermo");
@@ -155,12 +145,6 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
 int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
                         const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows, int which)
 {
-    // tile rows per workgroup: tuning probes (BZ_LEAN_TY: all four kernels, BZ_SCALAR_TY: the scalar-pair kernel alone)
-    static const int ty = getenv("BZ_LEAN_TY") ? atoi(getenv("BZ_LEAN_TY")) : 8;
-    static const int tys = getenv("BZ_SCALAR_TY") ? atoi(getenv("BZ_SCALAR_TY")) : ty;
-    if ((which & 1) && ty == 4) { if (int e = lean_launch<4>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, 1)) return e; }
-    else if (which & 1) { if (int e = lean_launch<8>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, 1)) return e; }
-    if ((which & 2) && tys == 4) return lean_launch<4>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, 2);
-    if (which & 2) return lean_launch<8>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, 2);
-    return BZ_OK;
+    // 64 x 8 tiles (64 x 4 measured +8 % on the momentum kernels: more frame cells per interior cell)
+    return lean_launch<8>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, which);
 }

@@ -354,116 +354,6 @@ __device__ __forceinline__ double flux_x_lean(const DevGrid &g, const Tend3Field
                           bz_cdiv(m[n + 1], rh, rr), bz_cdiv(m[n + 2], rh, rr), a > 0.0);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// x-momentum: k_u_tend_lds with u = rho_u / rho_r(k) derived at staging time.  The x-row of rho_u that the centred advecting
-// flux needs (i-1 .. i+2) is also the raw material of the upwind stencil (i-2 .. i+3): six loads serve both.
-// ---------------------------------------------------------------------------------------------------------------------
-// Probes on MI355X (512^3): replacing bz_cdiv by a plain multiply changes this kernel by -4 %, taking the x-stencil from a stored u
-// array instead of deriving it by 0 %: the kernel is bound by instruction issue (4 waves / SIMD, ~75 % of issue cycles busy), not by bytes.
-template <int TY>
-__global__ __launch_bounds__(64 * TY) void k5_u(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
-{
-    constexpr int TR = TY + 6;
-    __shared__ double T[2][TR][64];
-    __shared__ double FY[2][TY + 1][64];
-    int bx, by, bz;
-    bz_block5(L, bx, by, bz);
-    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
-    const int i0 = bx * 64, j0 = by * TY;
-    const int i = i0 + tx, j = j0 + ty;
-    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
-    const int ie = i0 - 1, le = 0;                      // centre-type x flux: lane 0 needs the flux of centre i0-1
-    const int kbeg = bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
-    if (kbeg >= kend) return;
-    const ix_t sz = (ix_t)g.Sxy;
-    const bool store = (i < g.Nx) && (j < g.Ny);
-    const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv;
-    Tend3Fields F;
-    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
-    ix_t n = (ix_t)g.idx(ic, jc, kbeg);
-    constexpr int NT = 64 * TY, HPT = (6 * 64 + NT - 1) / NT;
-    bool hok[HPT];
-    int hr[HPT], hcol[HPT];
-    ix_t hn[HPT];
-#pragma unroll
-    for (int q = 0; q < HPT; ++q) {
-        const int h = t + q * NT;
-        hok[q] = h < 6 * 64;
-        const int hrr = h >> 6;
-        hcol[q] = h & 63;
-        hr[q] = hok[q] ? ((hrr < 3) ? hrr : TY + hrr) : 0;
-        hn[q] = (ix_t)g.idx(min(i0 + hcol[q], g.Nx + 2), min(j0 - 3 + hr[q], g.Ny + 2), kbeg);
-    }
-    const ix_t ntop0 = (ix_t)g.idx(ic, min(j0 + TY, g.Ny), kbeg);      // row of the face above the tile (wave 0)
-    auto dv = [&](double a, double rh, double rr) { return bz_cdiv(a, rh, rr); };
-
-    double r[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) r[s] = dv(ru[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
-    double fz_lo = vflux<T3_U>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
-    T[0][ty + 3][tx] = r[3];
-#pragma unroll
-    for (int q = 0; q < HPT; ++q)
-        if (hok[q]) T[0][hr[q]][hcol[q]] = dv(ru[hn[q]], g.rho[kbeg], g.rrho[kbeg]);
-    __syncthreads();
-
-    double edge = 0.0;
-    int buf = 0;
-    for (int k = kbeg; k < kend; ++k, n += sz) {
-        const ix_t lev = (ix_t)(k - kbeg) * sz;
-        double hnext[HPT];
-#pragma unroll
-        for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? ru[hn[q] + lev + sz] : 0.0;
-        const double tnew_raw = ru[n + 3 * sz];
-        const double u0v = (E.mode == 2) ? E.u0[n] : 0.0;
-        const double m2 = ru[n - 2], m1 = ru[n - 1], m0 = ru[n], p1 = ru[n + 1], p2 = ru[n + 2], p3 = ru[n + 3];
-        if (((k - kbeg) & 63) == 0) {
-            const int kk = min(k + tx, kend - 1);
-            edge = flux_x_lean<T3_U>(g, F, ru, ie, jc, kk);
-        }
-        const int src = (k - kbeg) & 63;
-        const double Ax = g.Ax[k], Ay = g.Ay[k];
-        const double rho = g.rho[k], rrho = g.rrho[k];
-        const double c0 = r[3];
-        // ---- x: flux at centre i ----
-        const double ax = bz_symm4(Ax * m1, Ax * m0, Ax * p1, Ax * p2);
-        const double fx = ax * bz_up5(dv(m2, rho, rrho), dv(m1, rho, rrho), c0, dv(p1, rho, rrho), dv(p2, rho, rrho), dv(p3, rho, rrho), ax > 0.0);
-        // ---- y: flux at the own low y-face, advected stencil from the tile column ----
-        const double ay = bz_symm4(Ay * rv[n - 2], Ay * rv[n - 1], Ay * rv[n], Ay * rv[n + 1]);
-        const double(*Tk)[64] = T[buf];
-        const double fy = ay * bz_up5(Tk[ty][tx], Tk[ty + 1][tx], Tk[ty + 2][tx], c0, Tk[ty + 4][tx], Tk[ty + 5][tx], ay > 0.0);
-        FY[buf][ty][tx] = fy;
-        if (ty == 0) {
-            const ix_t nt = ntop0 + lev;
-            const double at = bz_symm4(Ay * rv[nt - 2], Ay * rv[nt - 1], Ay * rv[nt], Ay * rv[nt + 1]);
-            FY[buf][TY][tx] = at * bz_up5(Tk[TY][tx], Tk[TY + 1][tx], Tk[TY + 2][tx], Tk[TY + 3][tx], Tk[TY + 4][tx], Tk[TY + 5][tx], at > 0.0);
-        }
-        // ---- z ----
-        const double tnew = dv(tnew_raw, g.rho[k + 3], g.rrho[k + 3]);
-        const double fz_hi = vflux<T3_U>(g, F, n + sz, k + 1, r[1], r[2], r[3], r[4], r[5], tnew);
-        // ---- stage level k+1 ----
-        T[buf ^ 1][ty + 3][tx] = r[4];
-#pragma unroll
-        for (int q = 0; q < HPT; ++q)
-            if (hok[q]) T[buf ^ 1][hr[q]][hcol[q]] = dv(hnext[q], g.rho[k + 1], g.rrho[k + 1]);
-        __syncthreads();
-        {
-            double nb = __shfl_up(fx, 1);
-            const double e = __shfl(edge, src);
-            if (tx == le) nb = e;
-            const double dx = fx - nb;
-            const double dy = FY[buf][ty + 1][tx] - fy;
-            if (store)
-                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out,
-                                           -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo))), m0, n);
-        }
-        fz_lo = fz_hi;
-#pragma unroll
-        for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
-        r[5] = tnew;
-        buf ^= 1;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // x-momentum, sixth generation: EVERYTHING a level needs from its neighbours comes from LDS, and every global load of an iteration
@@ -611,142 +501,6 @@ __global__ __launch_bounds__(64 * TY) void k6_u(DevGrid g, Lean5 L, int kchunk, 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// y-momentum: k_v_tend_lds with v = rho_v / rho_r(k) derived at staging time.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int TY>
-__global__ __launch_bounds__(64 * TY) void k5_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
-{
-    constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles
-    __shared__ double Tv[2][RV][64];
-    __shared__ double Tm[2][3][RM][64];                   // 0: Ax*rho_u, 1: Ay*rho_v, 2: Az*rho_w at the upper z-face
-    __shared__ double FY[2][TY + 1][64];
-    constexpr int NT = 64 * TY, NFR = 16 * 64, HPT = (NFR + NT - 1) / NT;
-    int bx, by, bz;
-    bz_block5(L, bx, by, bz);
-    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
-    const int i0 = bx * 64, j0 = by * TY;
-    const int i = i0 + tx, j = j0 + ty;
-    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
-    const int nact = min(64, g.Nx - i0);
-    const int ie = i0 + nact, le = nact - 1;              // x flux at x-faces: last lane needs face i0+nact
-    const int kbeg = bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
-    if (kbeg >= kend) return;
-    const ix_t sz = (ix_t)g.Sxy;
-    const bool store = (i < g.Nx) && (j < g.Ny);
-    const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
-    Tend3Fields F;
-    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
-    const double Az = g.Az;
-    ix_t n = (ix_t)g.idx(ic, jc, kbeg);
-
-    // frame rows: id 0..5 v tile rows {0,1,2,TY+3,TY+4,TY+5}; 6..8 rho_u rows {0,1,TY+2}; 9..12 rho_v rows
-    // {0,1,TY+2,TY+3}; 13..15 rho_w rows {0,1,TY+2}   (momentum-tile row r' <-> grid row j0-2+r').  A frame row is staged by
-    // one wave (id = wave index + TY q), so the source array and the scaling are wave-uniform: kept in scalar registers.
-    bool hok[HPT];
-    int hsel[HPT], hrow[HPT];
-    ix_t hn[HPT];
-    const double *hsrc[HPT];
-#pragma unroll
-    for (int q = 0; q < HPT; ++q) {
-        const int h = t + q * NT;
-        hok[q] = h < NFR;
-        const int id = __builtin_amdgcn_readfirstlane(hok[q] ? (h >> 6) : 0);
-        int sel, row, grow;                                // sel: 0 v, 1 rho_u, 2 rho_v, 3 rho_w
-        if (id < 6) { sel = 0; row = (id < 3) ? id : TY + id; grow = j0 - 3 + row; }
-        else if (id < 9) { sel = 1; const int m = id - 6; row = (m < 2) ? m : TY + 2; grow = j0 - 2 + row; }
-        else if (id < 13) { sel = 2; const int m = id - 9; row = (m < 2) ? m : TY + m; grow = j0 - 2 + row; }
-        else { sel = 3; const int m = id - 13; row = (m < 2) ? m : TY + 2; grow = j0 - 2 + row; }
-        hsel[q] = sel; hrow[q] = row;
-        hsrc[q] = (sel == 1) ? ru : (sel == 3) ? rw : rv;
-        hn[q] = (ix_t)g.idx(min(i0 + tx, g.Nx + 2), min(grow, g.Ny + 2), kbeg) + (sel == 3 ? sz : (ix_t)0);
-    }
-    auto frame_load = [&](int q, ix_t lev) -> double { return hsrc[q][hn[q] + lev]; };   // raw value at the level offset
-    auto frame_store = [&](int b, int q, double raw, int klev) {          // scale / derive and stage for level klev
-        if (hsel[q] == 0) Tv[b][hrow[q]][tx] = bz_cdiv(raw, g.rho[klev], g.rrho[klev]);
-        else Tm[b][hsel[q] - 1][hrow[q]][tx] = ((hsel[q] == 1) ? g.Ax[klev] : (hsel[q] == 2) ? g.Ay[klev] : Az) * raw;
-    };
-
-    double r[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) r[s] = bz_cdiv(rv[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
-    double fz_lo = vflux<T3_V>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
-    // raw rho_v of the own column at levels k .. k+2 (the ring-top load of level k+3 enters at the end of each iteration)
-    double q0 = rv[n], q1 = rv[n + sz], q2 = rv[n + 2 * sz];
-    Tv[0][ty + 3][tx] = r[3];
-    Tm[0][0][ty + 2][tx] = g.Ax[kbeg] * ru[n];
-    Tm[0][1][ty + 2][tx] = g.Ay[kbeg] * q0;
-    Tm[0][2][ty + 2][tx] = Az * rw[n + sz];
-#pragma unroll
-    for (int q = 0; q < HPT; ++q)
-        if (hok[q]) frame_store(0, q, frame_load(q, 0), kbeg);
-    __syncthreads();
-
-    double edge = 0.0;
-    int buf = 0;
-    for (int k = kbeg; k < kend; ++k, n += sz) {
-        const ix_t lev = (ix_t)(k + 1 - kbeg) * sz;
-        double hnext[HPT];
-#pragma unroll
-        for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? frame_load(q, lev) : 0.0;
-        const double tnew_raw = rv[n + 3 * sz];
-        const double u0v = (E.mode == 2) ? E.u0[n] : 0.0;
-        const double ru_n = g.Ax[k + 1] * ru[n + sz], rw_n = Az * rw[n + 2 * sz];
-        const double m3 = rv[n - 3], m2 = rv[n - 2], m1 = rv[n - 1], p1 = rv[n + 1], p2 = rv[n + 2];
-        if (((k - kbeg) & 63) == 0) {
-            const int kk = min(k + tx, kend - 1);
-            edge = flux_x_lean<T3_V>(g, F, rv, ie, jc, kk);
-        }
-        const int src = (k - kbeg) & 63;
-        const double rho = g.rho[k], rrho = g.rrho[k];
-        const double c0 = r[3];
-        const double(*V)[64] = Tv[buf];
-        const double(*MU)[64] = Tm[buf][0];
-        const double(*MV)[64] = Tm[buf][1];
-        const double(*MW)[64] = Tm[buf][2];
-        // ---- x: flux at (x-face i, y-face j): rho_u rows j-2..j+1, v x-stencil derived from the rho_v row ----
-        const double ut = bz_symm4(MU[ty][tx], MU[ty + 1][tx], MU[ty + 2][tx], MU[ty + 3][tx]);
-        const double fx = ut * bz_up5(bz_cdiv(m3, rho, rrho), bz_cdiv(m2, rho, rrho), bz_cdiv(m1, rho, rrho), c0,
-                                      bz_cdiv(p1, rho, rrho), bz_cdiv(p2, rho, rrho), ut > 0.0);
-        // ---- y: flux at centre j: rho_v rows j-1..j+2, v rows j-2..j+3 ----
-        const double vt = bz_symm4(MV[ty + 1][tx], MV[ty + 2][tx], MV[ty + 3][tx], MV[ty + 4][tx]);
-        const double fy = vt * bz_up5(V[ty + 1][tx], V[ty + 2][tx], c0, V[ty + 4][tx], V[ty + 5][tx], V[ty + 6][tx], vt > 0.0);
-        FY[buf][ty + 1][tx] = fy;
-        if (ty == 0) {       // centre j0-1: rho_v rows j0-2..j0+1, v rows j0-3..j0+2
-            const double vb = bz_symm4(MV[0][tx], MV[1][tx], MV[2][tx], MV[3][tx]);
-            FY[buf][0][tx] = vb * bz_up5(V[0][tx], V[1][tx], V[2][tx], V[3][tx], V[4][tx], V[5][tx], vb > 0.0);
-        }
-        // ---- z: advecting flux at (y-face j, z-face k+1) from the rho_w tile rows j-2..j+1 ----
-        const double tnew = bz_cdiv(tnew_raw, g.rho[k + 3], g.rrho[k + 3]);
-        const double wt = bz_symm4(MW[ty][tx], MW[ty + 1][tx], MW[ty + 2][tx], MW[ty + 3][tx]);
-        const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
-        // ---- stage level k+1 ----
-        Tv[buf ^ 1][ty + 3][tx] = r[4];
-        Tm[buf ^ 1][0][ty + 2][tx] = ru_n;
-        Tm[buf ^ 1][1][ty + 2][tx] = g.Ay[k + 1] * q1;
-        Tm[buf ^ 1][2][ty + 2][tx] = rw_n;
-#pragma unroll
-        for (int q = 0; q < HPT; ++q)
-            if (hok[q]) frame_store(buf ^ 1, q, hnext[q], k + 1);
-        __syncthreads();
-        {
-            double nb = __shfl_down(fx, 1);
-            const double e = __shfl(edge, src);
-            if (tx == le) nb = e;
-            const double dx = nb - fx;
-            const double dy = fy - FY[buf][ty][tx];
-            if (store)
-                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out,
-                                       -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo))), q0, n);
-        }
-        fz_lo = fz_hi;
-        q0 = q1; q1 = q2; q2 = tnew_raw;
-#pragma unroll
-        for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
-        r[5] = tnew;
-        buf ^= 1;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // y-momentum, sixth generation (see k6_u): the v tile carries its x halo, so the x-stencil is five ds_reads instead of five loads +
@@ -908,145 +662,6 @@ __device__ __forceinline__ double buoyancy5(const DevGrid &g, double T, double r
     return buoyancy3(g, T, bz_cdiv(rq, g.rho[k], g.rrho[k]), k);
 }
 
-template <int TY>
-__global__ __launch_bounds__(64 * TY) void k5_w(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
-{
-    constexpr int TR = TY + 6;
-    __shared__ double T[2][TR][64];
-    __shared__ double FY[2][TY + 1][64];
-    int bx, by, bz;
-    bz_block5(L, bx, by, bz);
-    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
-    const int i0 = bx * 64, j0 = by * TY;
-    const int i = i0 + tx, j = j0 + ty;
-    const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
-    const int nact = min(64, g.Nx - i0);
-    const int ie = i0 + nact, le = nact - 1;
-    const int kbeg = 1 + bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
-    if (kbeg >= kend) return;
-    const ix32_t sz = (ix32_t)g.Sxy;
-    const bool store = (i < g.Nx) && (j < g.Ny);
-    const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
-    const double *__restrict__ pa = L.T, *__restrict__ pb = L.pb;       // temperature, rho q of the stage-start state
-    Tend3Fields F;
-    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
-    const double Az = g.Az;
-    ix32_t n = (ix32_t)g.idx(ic, jc, kbeg);
-    constexpr int NT = 64 * TY, HPT = (6 * 64 + NT - 1) / NT;
-    bool hok[HPT];
-    int hr[HPT], hcol[HPT];
-    ix32_t hn[HPT];
-#pragma unroll
-    for (int q = 0; q < HPT; ++q) {
-        const int h = t + q * NT;
-        hok[q] = h < 6 * 64;
-        const int hrr = h >> 6;
-        hcol[q] = h & 63;
-        hr[q] = hok[q] ? ((hrr < 3) ? hrr : TY + hrr) : 0;
-        hn[q] = (ix32_t)g.idx(min(i0 + hcol[q], g.Nx + 2), min(j0 - 3 + hr[q], g.Ny + 2), kbeg);
-    }
-    const ix32_t ntop0 = (ix32_t)g.idx(ic, min(j0 + TY, g.Ny), kbeg);
-    const bool top = (ty == 0);
-
-    double wr[6], qu[4], qv[4], qt[4], qw[4];       // qt: rho_v ring of the row above the tile (wave 0 only)
-    double raw5;                                    // raw rho_w of level k+2 (becomes the top of the qw ring next iteration)
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const double x = rw[n + s * sz - 3 * sz];
-        wr[s] = bz_cdiv(x, g.rho_f[kbeg + s - 3], g.rrho_f[kbeg + s - 3]);
-        if (s >= 1 && s <= 4) qw[s - 1] = Az * x;   // levels kbeg-2 .. kbeg+1
-        if (s == 5) raw5 = x;
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int kk = kbeg - 2 + s;
-        qu[s] = g.Ax[kk] * ru[n + s * sz - 2 * sz];
-        qv[s] = g.Ay[kk] * rv[n + s * sz - 2 * sz];
-        qt[s] = top ? g.Ay[kk] * rv[ntop0 + s * sz - 2 * sz] : 0.0;
-    }
-    double fz_lo, b_lo;
-    {
-        const int B = bz_buffer_center(kbeg - 1, g.Nz);
-        const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
-        fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
-        b_lo = buoyancy5(g, pa[n - sz], pb[n - sz], kbeg - 1);
-    }
-    T[0][ty + 3][tx] = wr[3];
-#pragma unroll
-    for (int q = 0; q < HPT; ++q)
-        if (hok[q]) T[0][hr[q]][hcol[q]] = bz_cdiv(rw[hn[q]], g.rho_f[kbeg], g.rrho_f[kbeg]);
-    __syncthreads();
-
-    double edge = 0.0;
-    int buf = 0;
-    for (int k = kbeg; k < kend; ++k, n += sz) {
-        const ix32_t lev = (ix32_t)(k - kbeg) * sz;
-        double hnext[HPT];
-#pragma unroll
-        for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? rw[hn[q] + lev + sz] : 0.0;
-        const double wnew_raw = rw[n + 3 * sz];
-        const double u0v = (E.mode == 2) ? E.u0[n] : 0.0;
-        const double m3 = rw[n - 3], m2 = rw[n - 2], m1 = rw[n - 1], m0 = rw[n], p1 = rw[n + 1], p2 = rw[n + 2];
-        const double rth = pa[n], rq = pb[n];
-        const double qwnew = Az * raw5;
-        if (((k - kbeg) & 63) == 0) {
-            const int kk = min(k + tx, kend - 1);
-            edge = flux_x_lean<T3_W>(g, F, rw, ie, jc, kk);
-        }
-        const int src = (k - kbeg) & 63;
-        const int Bf = bz_buffer_face(k, g.Nz);
-        const double rhf = g.rho_f[k], rrhf = g.rrho_f[k];
-        const double w0 = wr[3];
-        const double ut = (Bf == 3) ? bz_symm4(qu[0], qu[1], qu[2], qu[3]) : bz_symm2(qu[1], qu[2]);
-        const double fx = ut * bz_up5(bz_cdiv(m3, rhf, rrhf), bz_cdiv(m2, rhf, rrhf), bz_cdiv(m1, rhf, rrhf), w0,
-                                      bz_cdiv(p1, rhf, rrhf), bz_cdiv(p2, rhf, rrhf), ut > 0.0);
-        const double vt = (Bf == 3) ? bz_symm4(qv[0], qv[1], qv[2], qv[3]) : bz_symm2(qv[1], qv[2]);
-        const double(*Tk)[64] = T[buf];
-        const double fy = vt * bz_up5(Tk[ty][tx], Tk[ty + 1][tx], Tk[ty + 2][tx], w0, Tk[ty + 4][tx], Tk[ty + 5][tx], vt > 0.0);
-        FY[buf][ty][tx] = fy;
-        if (top) {
-            const double v2 = (Bf == 3) ? bz_symm4(qt[0], qt[1], qt[2], qt[3]) : bz_symm2(qt[1], qt[2]);
-            FY[buf][TY][tx] = v2 * bz_up5(Tk[TY][tx], Tk[TY + 1][tx], Tk[TY + 2][tx], Tk[TY + 3][tx], Tk[TY + 4][tx], Tk[TY + 5][tx], v2 > 0.0);
-        }
-        const double wnew = bz_cdiv(wnew_raw, g.rho_f[k + 3], g.rrho_f[k + 3]);
-        double fz_hi;
-        {
-            const int B = bz_buffer_center(k, g.Nz);
-            const double wt = (B == 3) ? bz_symm4(qw[1], qw[2], qw[3], qwnew) : bz_symm2(qw[2], qw[3]);
-            fz_hi = wt * bz_upB(wr[1], wr[2], wr[3], wr[4], wr[5], wnew, wt > 0.0, B);
-        }
-        T[buf ^ 1][ty + 3][tx] = wr[4];
-#pragma unroll
-        for (int q = 0; q < HPT; ++q)
-            if (hok[q]) T[buf ^ 1][hr[q]][hcol[q]] = bz_cdiv(hnext[q], g.rho_f[k + 1], g.rrho_f[k + 1]);
-        const double b_hi = buoyancy5(g, rth, rq, k);
-        // ring advance loads (level k+2)
-        const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
-        const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];
-        const double qtn = top ? Ayn * rv[ntop0 + lev + 2 * sz] : 0.0;
-        __syncthreads();
-        {
-            double nb = __shfl_down(fx, 1);
-            const double e = __shfl(edge, src);
-            if (tx == le) nb = e;
-            const double dx = nb - fx;
-            const double dy = FY[buf][ty + 1][tx] - fy;
-            const double adv = -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo)));
-            if (store)
-                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out, adv + 0.5 * (b_lo + b_hi), m0, n);
-        }
-        fz_lo = fz_hi;
-        b_lo = b_hi;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) { qu[s] = qu[s + 1]; qv[s] = qv[s + 1]; qt[s] = qt[s + 1]; qw[s] = qw[s + 1]; }
-        qu[3] = qun; qv[3] = qvn; qt[3] = qtn; qw[3] = qwnew;
-        raw5 = wnew_raw;
-#pragma unroll
-        for (int s = 0; s < 5; ++s) wr[s] = wr[s + 1];
-        wr[5] = wnew;
-        buf ^= 1;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // z-momentum, sixth generation (see k6_u): the w tile carries its x halo (70 columns), so the x-stencil is five ds_reads instead of

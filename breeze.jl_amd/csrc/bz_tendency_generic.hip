@@ -390,7 +390,7 @@ template <int R>
 static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool buoyancy, bool scalars)
 {
     const DevGrid &g = ctx->dg;
-    const bool onepass = getenv("BZ_GENERIC_ONEPASS") != nullptr;
+    const bool onepass = ctx->tune.generic_onepass;
     FluxBuf F{nullptr, nullptr, nullptr};
     int rc;
     if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;
@@ -436,7 +436,7 @@ static int launch_rho3d(bz_ctx *ctx, double *Gc, double *Grho, const double *rho
                         const double *c, const double *ru, const double *rv, const double *rw)
 {
     const DevGrid &g = ctx->dg;
-    const bool onepass = getenv("BZ_GENERIC_ONEPASS") != nullptr;
+    const bool onepass = ctx->tune.generic_onepass;
     FluxBuf F{nullptr, nullptr, nullptr};
     int rc;
     if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;
@@ -458,7 +458,7 @@ template <int R>
 static int launch_scalar(bz_ctx *ctx, double *Gc, const double *u, const double *v, const double *w, const double *c)
 {
     const DevGrid &g = ctx->dg;
-    const bool onepass = getenv("BZ_GENERIC_ONEPASS") != nullptr;
+    const bool onepass = ctx->tune.generic_onepass;
     FluxBuf F{nullptr, nullptr, nullptr};
     int rc;
     if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;

@@ -62,8 +62,9 @@ class Forcing:
 class FrictionVelocityDrag:
     """The example's bulk drag closure -ρ₀ u★² ρu / √(ρu² + ρv²) (examples/bomex.jl:95-99) as data."""
 
-    def __init__(self, ρ0, ustar):
-        self.ρ0, self.ustar = float(ρ0), float(ustar)
+    def __init__(self, ρ0, ustar, epsilon=0.0):
+        # epsilon: the ϵ under the square root of benchmarking/src/convective_boundary_layer.jl:142-146 (1e-10 there)
+        self.ρ0, self.ustar, self.epsilon = float(ρ0), float(ustar), float(epsilon)
 
 
 class BulkDrag:
@@ -185,13 +186,13 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions, T=None):
         elif k in ("ρu", "ρv"):
             if not isinstance(cond, FrictionVelocityDrag):
                 raise NotImplementedError("momentum bottom flux: FrictionVelocityDrag(ρ₀, u★)")
-            d = cond.ρ0 * cond.ustar ** 2
+            d = (cond.ρ0 * cond.ustar ** 2, cond.epsilon)
             if drag is not None and drag != d:
                 raise NotImplementedError("ρu and ρv share one drag")
             drag = d
         else:
             raise NotImplementedError(f"boundary condition on {name!r} is not implemented")
-    S.bottom_drag_rho0_ustar2 = drag or 0.0
+    S.bottom_drag_rho0_ustar2, S.bottom_drag_epsilon = drag or (0.0, 0.0)
     if not static and ws is None and f == 0.0 and not (S.bottom_theta_flux or S.bottom_moisture_flux or S.bottom_drag_rho0_ustar2):
         return None, None                 # e.g. only bulk conditions were given
     return S, keep

@@ -453,6 +453,8 @@ int bz_compressible_kessler_update(bz_ctx *ctx, const bz_compressible_state *s, 
  *   coriolis_f                   FPlane(f): -x_f_cross_U, -y_f_cross_U (src/AtmosphereModels/dynamics_kernel_functions.jl:79,99)
  *   bottom_*_flux                FluxBoundaryCondition values on rho theta / rho q (examples/bomex.jl:80-87)
  *   bottom_drag_rho0_ustar2      rho0 u*^2 of the bulk drag FluxBoundaryCondition on rho u, rho v (examples/bomex.jl:95-101)
+ *   bottom_drag_epsilon          the regulariser under the square root, J = -rho0 u*^2 rho_u / sqrt(rho_u^2 + rho_v^2 + eps)
+ *                                (benchmarking/src/convective_boundary_layer.jl:142-146 uses 1e-10; the BOMEX example none)
  * All pointers are HOST arrays (cell centres, length Nz; the subsidence velocity Nz+1 faces), copied by the call; NULL = absent.
  * With a stack attached bz_compute_tendencies adds the forcing + Coriolis terms, and bz_time_step_anelastic calls
  * bz_compute_flux_bc_tendencies before every RK substep (src/TimeSteppers/ssp_runge_kutta_3.jl:229,243,257).
@@ -468,6 +470,7 @@ typedef struct bz_column_forcings {
     double coriolis_f;
     double bottom_theta_flux, bottom_moisture_flux;
     double bottom_drag_rho0_ustar2;
+    double bottom_drag_epsilon;
 } bz_column_forcings;
 int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *forcings);       /* NULL detaches the stack */
 /* compute_forcings!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:81-86) */

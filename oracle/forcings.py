@@ -33,12 +33,13 @@ class ColumnForcings:
 
     def __init__(self, Fu=None, Fv=None, Ftheta=None, Fq=None, Fe=None, w_subsidence=None,
                  subsidence_on=("u", "v", "theta", "q"), coriolis_f=0.0, flux_theta=0.0, flux_q=0.0,
-                 drag_rho0_ustar2=0.0, bulk=None):
+                 drag_rho0_ustar2=0.0, bulk=None, drag_epsilon=0.0):
         self.Fu, self.Fv, self.Ftheta, self.Fq, self.Fe = Fu, Fv, Ftheta, Fq, Fe
         self.w_subsidence = w_subsidence              # Nz+1 faces
         self.subsidence_on = tuple(subsidence_on) if w_subsidence is not None else ()
         self.f = float(coriolis_f)
         self.flux_theta, self.flux_q, self.drag = float(flux_theta), float(flux_q), float(drag_rho0_ustar2)
+        self.drag_eps = float(drag_epsilon)           # benchmarking/src/convective_boundary_layer.jl:142-146
         self.bulk = bulk                              # BulkFluxes or None
         self.sub = {}
 
@@ -151,8 +152,8 @@ def add_flux_bc_tendencies(m):
         ru, rv = I(m.ru)[0], I(m.rv)[0]
         rv_fc = _xy_to_fc(m, m.rv)[0]
         ru_cf = _xy_to_cf(m, m.ru)[0]
-        Ju = -F.drag * ru / np.sqrt(ru ** 2 + rv_fc ** 2)
-        Jv = -F.drag * rv / np.sqrt(ru_cf ** 2 + rv ** 2)
+        Ju = -F.drag * ru / np.sqrt(ru ** 2 + rv_fc ** 2 + F.drag_eps)
+        Jv = -F.drag * rv / np.sqrt(ru_cf ** 2 + rv ** 2 + F.drag_eps)
         I(m.G["ru"])[0] += Ju * 1.0 / dz
         I(m.G["rv"])[0] += Jv * 1.0 / dz
     del k

@@ -183,6 +183,62 @@ def cpu_baseline(n, budget_s=25.0):
                       f"C/OpenMP oracle on {threads} threads + pocketfft on {threads} threads"}
 
 
+def cbl_run(args, bz, device):
+    """--workload cbl: the reference's own published benchmark case (BreezeBenchmarks), one GPU.  Physics and set-up of
+    /root/reference/benchmarking/src/convective_boundary_layer.jl:59-185 (host mirror: breeze.jl_amd/benchmarks.py): dry convective
+    boundary layer, AnelasticDynamics, FPlane + geostrophic forcing + u* drag + 0.35 K m/s surface heat flux, halo 5, Float32 unless
+    --cbl-float64, WENO(order = --cbl-order), dt = 0.05 s (benchmarking/src/utils.jl:18).  The CI protocol is 5 warm-up + 150 timed
+    steps on 256x256x128, 512x512x256 and 768x768x256 with WENO5 and WENO9 (.github/workflows/Benchmarks.yml:34-45);
+    tools/gpu_cbl.sh runs that matrix.  The metric is the reference's grid_points_per_second (benchmarking/src/utils.jl:141).
+    An NVIDIA L4 produced the external BreezeBenchmarks table: a context number, not a target, and none of it is in BASELINE.md."""
+    import torch
+    Nx, Ny, Nz = (int(v) for v in args.cbl_size.lower().split("x"))
+    f32 = not args.cbl_float64
+    dt = 0.05
+    m = bz.benchmarks.convective_boundary_layer((Nx, Ny, Nz), float_type=np.float32 if f32 else np.float64,
+                                                advection=bz.WENO(order=args.cbl_order), device=device)
+    for _ in range(args.warmup):
+        m.time_step(dt)
+    m.profile_reset()
+    m.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.time_step(dt)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    m.profile_enable(False)
+    cells, word = Nx * Ny * Nz, 4 if f32 else 8
+    kernels = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms} for k, (ms, n) in m.profile().items() if n}
+    known = [k for k in kernels if k in WORDS_PER_CELL]
+    roofline = None
+    if known:
+        dom = max(known, key=lambda k: kernels[k]["total_ms"])
+        dom_bytes = WORDS_PER_CELL[dom] * word * cells
+        achieved = dom_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"]}
+    rate = cells * args.steps / elapsed
+    step_achieved = rate * A_STEP_WORDS * word / 1e9
+    out = {"metric": "grid points per second (time_step!), convective boundary layer benchmark case",
+           "value": rate, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if f32 else "f64", "data": "synthetic",
+           "config": {"workload": f"BreezeBenchmarks convective_boundary_layer {Nx}x{Ny}x{Nz} (benchmarking/src/convective_boundary_layer.jl): "
+                                  f"AnelasticDynamics, WENO{args.cbl_order}, halo 5, FPlane + geostrophic forcing + u* drag + surface heat flux, "
+                                  f"{'Float32' if f32 else 'Float64'}, dt={dt}s", "grid": [Nx, Ny, Nz], "dt": dt, "parallelism": "single GPU"},
+           "roofline": roofline,
+           "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_achieved / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_cell_step": A_STEP_WORDS * word,
+                             "note": "the dry-bubble contract figure (250 words per cell and step); the forcing and flux kernels of this case move a few words more"},
+           "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(kernels.items())},
+           "kernel_launches_per_step": {k: v["launches"] / args.steps for k, v in sorted(kernels.items())},
+           "finite": bool(torch.isfinite(m.momentum["ρw"].parent).all().item()),
+           "w_max": float(m.velocities["w"].interior.abs().max().item())}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def config4_run(args, bz, rank, world, dist, device, fail):
     """--workload config4: BASELINE configs[4], the splitting-supercell shape — CompressibleDynamics, split-explicit WS-RK3 with
     acoustic substeps, DCMIP2016 Kessler microphysics, 512 x 512 x 128 cells on the example's 168 km x 168 km x 20 km box
@@ -454,6 +510,10 @@ def run_rank(args):
 
     if args.workload == "config4":
         return config4_run(args, bz, rank, world, dist, device, fail)
+    if args.workload == "cbl":
+        if world > 1:
+            fail("--workload cbl is the reference's single-GPU benchmark case")
+        return cbl_run(args, bz, device)
     dt = 1.0
     G, label, scaling = problem(args, world)
     use_slabs = (world > 1 and not args.replicas) or (world == 1 and args.slab)
@@ -638,7 +698,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--workload", choices=("bubble", "config3", "config4"), default="bubble",
+    ap.add_argument("--cbl-size", default="512x512x256", help="--workload cbl: NxxNyxNz (CI sizes: 256x256x128, 512x512x256, 768x768x256)")
+    ap.add_argument("--cbl-order", type=int, default=5, choices=(5, 7, 9), help="--workload cbl: WENO order (CI: 5 and 9)")
+    ap.add_argument("--cbl-float64", action="store_true", help="--workload cbl in Float64 (the reference benchmarks Float32)")
+    ap.add_argument("--workload", choices=("bubble", "config3", "config4", "cbl"), default="bubble",
                     help="bubble: the headline workload (configs[1]); config3: 1024 x (128 N) x 512 slabs; config4: compressible + "
                          "Kessler 512x512x128 (second milestone, split over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -25,3 +25,4 @@ from .microphysics import (DCMIP2016KesslerMicrophysics, KesslerMicrophysicalFie
 from .forcings import (BulkDrag, BulkSensibleHeatFlux, BulkVaporFlux, FPlane, FieldBoundaryConditions, FluxBoundaryCondition, Forcing, FrictionVelocityDrag,  # noqa: F401,E402
                        GeostrophicForcing, SmagorinskyLilly, SubsidenceForcing, geostrophic_forcings)
 from .model import compute_closure_fields_, compute_flux_bc_tendencies_  # noqa: F401,E402
+from . import benchmarks  # noqa: F401,E402

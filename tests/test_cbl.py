@@ -1,0 +1,82 @@
+"""The reference's own benchmark case — the dry convective boundary layer of benchmarking/src/convective_boundary_layer.jl:59-185
+(BreezeBenchmarks; .github/workflows/Benchmarks.yml:34-45) — through the host mirror breeze.jl_amd/benchmarks.py:
+AnelasticDynamics on a 309 K reference state, 5-cell halos, FPlane, geostrophic forcing (9, 0) m/s, a 0.35 K m/s surface heat flux and
+the u* = 0.4 m/s drag conditions with the case's regulariser epsilon = 1e-10.  Compared with the oracle carrying the same physics list
+(oracle/forcings.py; parity status as in tests/test_forcings.py: the Oceananigans side of the flux application is restated)."""
+import numpy as np
+import pytest
+
+from helpers import PROG
+
+
+def _oracle_cbl(oracle, size, order=5):
+    from oracle.forcings import ColumnForcings
+    from breeze_jl_amd import benchmarks as bm
+    C = bm.CBL
+    og = oracle.Grid(size, x=(0.0, C["Lx"]), y=(0.0, C["Ly"]), z=(0.0, C["Lz"]), halo=(5, 5, 5))
+    f, rho0 = bm.cbl_coriolis_parameter(), bm.cbl_surface_density()
+    ones = np.ones(size[2])
+    F = ColumnForcings(Fu=-f * C["Vg"] * ones, Fv=f * C["Ug"] * ones, coriolis_f=f, flux_theta=rho0 * C["heat_flux"],
+                       drag_rho0_ustar2=rho0 * C["ustar"] ** 2, drag_epsilon=C["drag_epsilon"])
+    kw = {} if order == 5 else {"advection": f"WENO{order}"}
+    om = oracle.OracleModel(og, surface_pressure=C["p0"], potential_temperature=C["theta0"], forcings=F, **kw)
+    om.set(theta=bm.cbl_initial_theta(size, seed=0), u=C["Ug"], v=C["Vg"])
+    return om
+
+
+def test_cbl_case_constants():
+    """f = 2 Omega sin(33.5 deg) ~ 8.0e-5 1/s and rho0 = p0 / (R^d theta0) (convective_boundary_layer.jl:114-127)"""
+    from breeze_jl_amd import benchmarks as bm
+    assert abs(bm.cbl_coriolis_parameter() - 8.05e-5) < 1e-6
+    assert abs(bm.cbl_surface_density() - 101325.0 / (8.314462618 / 0.02897 * 309.0)) < 1e-12
+    th = bm.cbl_initial_theta((8, 8, 30))
+    zc = (np.arange(30) + 0.5) * 100.0
+    assert np.all(np.abs(th[zc < 400.0] - 309.0) <= 0.25) and np.all(th[zc > 600.0, 0, 0] == 309.0 + (zc[zc > 600.0] - 600.0) * 0.004)
+    assert np.all(th[(zc > 400.0) & (zc < 600.0)] == 309.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [5, 9])
+def test_cbl_float64_steps_match_oracle(oracle, bz, order):
+    """three steps of the case's physics list in Float64 against the oracle: 1e-9 of the field scale (WENO9: 2e-8, the tolerance of
+    tests/test_weno_orders.py for wide stencils on kinked data)"""
+    size = (32, 24, 16)
+    om = _oracle_cbl(oracle, size, order)
+    hm = bz.benchmarks.convective_boundary_layer(size, float_type=np.float64, advection=bz.WENO(order=order))
+    for _ in range(3):
+        om.time_step(0.5)
+        hm.time_step(0.5)
+    hm.synchronize()
+    g = om.grid
+    mom = max(np.abs(g.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    tol = 1e-9 if order == 5 else 2e-8
+    for n, k in PROG.items():
+        want, got = g.interior(getattr(om, n), zface=(n == "rw")), hm.prognostic_fields()[k].interior_cpu()
+        scale = mom if n in ("ru", "rv", "rw") else max(np.abs(want).max(), 1e-3)
+        assert np.abs(got - want).max() / scale < tol, (n, np.abs(got - want).max() / scale)
+    # the surface fluxes did something: the lowest level slowed down below the geostrophic wind it started from, and warmed
+    assert g.interior(om.u)[0].mean() < 9.0 - 1e-4 and g.interior(om.u)[-1].mean() > 9.0 - 1e-6
+    assert g.interior(om.theta)[0].mean() > 309.0
+
+
+@pytest.mark.gpu
+def test_cbl_float32_steps_match_the_float64_oracle(oracle, bz):
+    """the case in the precision the reference benchmarks it in (Float32), three steps against the Float64 oracle: App. C tolerances
+    (1e-4 of the field scale after steps)"""
+    import torch
+    size = (32, 24, 16)
+    om = _oracle_cbl(oracle, size)
+    hm = bz.benchmarks.convective_boundary_layer(size, float_type=np.float32)
+    assert hm.momentum["ρu"].parent.dtype == torch.float32
+    for _ in range(3):
+        om.time_step(0.5)
+        hm.time_step(0.5)
+    hm.synchronize()
+    g = om.grid
+    mom = max(np.abs(g.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    for n, k in PROG.items():
+        if n == "rq":
+            continue
+        want, got = g.interior(getattr(om, n), zface=(n == "rw")), hm.prognostic_fields()[k].interior_cpu().astype(np.float64)
+        scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() / scale < 1e-4, (n, np.abs(got - want).max() / scale)

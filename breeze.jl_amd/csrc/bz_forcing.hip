@@ -71,6 +71,9 @@ struct ForcingCols {
     double f;
 };
 
+// SCALARS = false: the stack holds momentum terms only (Coriolis, geostrophic / u, v profiles — the CBL benchmark case): the
+// theta / moisture arrays are not touched (the general form read-modify-writes all four: 8 words per cell instead of 4 + 2)
+template <bool SCALARS>
 __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F, double *__restrict__ Gu,
                                                         double *__restrict__ Gv, double *__restrict__ Gth,
                                                         double *__restrict__ Gq, const double *__restrict__ ru,
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F
         if (any) G += scale * t;
         Gv[n] = G;
     }
+    if constexpr (!SCALARS) return;
     {
         double G = Gth[n];
         const double t = column(F.Fth, 2, any);
@@ -329,8 +333,47 @@ int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, d
     F.Fe = (m & 16) ? base + (size_t)4 * Nz : nullptr;
     F.sub = ctx->forcing_subsidence_mask ? base + (size_t)5 * Nz + (Nz + 1) + (size_t)4 * Nz : nullptr;
     F.f = ctx->forcing_f;
-    hipLaunchKernelGGL(k_apply_forcings, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, F, Gu, Gv, Gth, Gq,
-                       s->rho_u, s->rho_v, s->q, scale);
+    if (F.Fth || F.Fq || F.Fe || (ctx->forcing_subsidence_mask & 12))
+        hipLaunchKernelGGL(k_apply_forcings<true>, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, F, Gu, Gv, Gth, Gq,
+                           s->rho_u, s->rho_v, s->q, scale);
+    else
+        hipLaunchKernelGGL(k_apply_forcings<false>, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, F, Gu, Gv, Gth, Gq,
+                           s->rho_u, s->rho_v, s->q, scale);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// Forcing stacks the lean whole-step seam carries (bz_step.hip): the kernels above read rho u, rho v of the previous stage only — which
+// the lean seam keeps intact while the predictor sits in the G slots — when there is no subsidence (its horizontal averages need
+// the stored u, v, theta, q diagnostics) and no bulk condition (it reads u, v, theta); theta / moisture / energy profiles would change
+// rho theta everywhere after the scalar kernel has written T, so those stacks stay on the fused-RK tier.  What remains is the
+// reference's own benchmark case: FPlane + geostrophic forcing + bottom fluxes (benchmarking/src/convective_boundary_layer.jl).
+bool bzi_lean_forcings_ok(const bz_ctx *ctx)
+{
+    return ctx->has_forcings && !ctx->has_bulk && ctx->forcing_subsidence_mask == 0 && (ctx->forcing_static_mask & (4 | 8 | 16)) == 0;
+}
+
+// T of the lowest level from the rho theta / rho q the bottom heat / moisture flux has just changed (the lean scalar kernel wrote T of
+// the pre-flux values; the expressions are k_project_diagnose<0>'s, so the bits are those of the full diagnosis)
+__global__ __launch_bounds__(256) void k_lean_bottom_T(DevGrid g, const double *__restrict__ rth, const double *__restrict__ rq,
+                                                       double *__restrict__ T)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, 0);
+    const double rc = g.rho[0];
+    const double th = rth[n] / rc, q = rq[n] / rc;
+    const double qd = 1.0 - q;
+    const double Rm = qd * g.Rd + q * g.Rv;
+    const double cpm = qd * g.cpd + q * g.cpv;
+    T[n] = pow(g.p_r[0] / g.pst, Rm / cpm) * th;
+}
+
+int bzi_lean_bottom_temperature(bz_ctx *ctx, const double *rth, const double *rq, double *T)
+{
+    if (ctx->forcing_flux_theta == 0.0 && ctx->forcing_flux_q == 0.0) return BZ_OK;
+    const DevGrid &g = ctx->dg;
+    hipLaunchKernelGGL(k_lean_bottom_T, dim3((g.Nx + 255) / 256, g.Ny), dim3(256), 0, ctx->stream, g, rth, rq, T);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -263,6 +263,9 @@ struct bz_tuning {
     bool graph_debug = false;         // BZ_GRAPH_DEBUG
 };
 void bzi_read_tuning(bz_tuning &t);
+struct bz_ctx;
+bool bzi_lean_forcings_ok(const bz_ctx *ctx);
+int bzi_lean_bottom_temperature(bz_ctx *ctx, const double *rth, const double *rq, double *T);
 
 struct bz_ctx {
     bz_tuning tune;

@@ -52,7 +52,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
     if (ctx->fused_ok && ctx->fuse_rk && ctx->lean && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
-        !ctx->has_forcings && !ctx->has_bulk && !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask &&
+        (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask &&
         (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32)) {
         // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,
         // q^v, T on the fly (bit-identical to the stored diagnostics), rho theta / rho q ping-pong between their own arrays
@@ -66,7 +66,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             const bool from_state = (stage != 1);
             const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
             double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
-            if (ctx->side_scalar) {
+            if (ctx->side_scalar && !ctx->has_forcings) {
                 // the scalar-pair kernel feeds nothing of the pressure solve: it runs on the side stream beside the source term,
                 // the transforms and the Thomas solve (issue-bound stencil kernel next to bandwidth-bound streaming kernels)
                 if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 1))) return rc;
@@ -79,6 +79,14 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                 if (rc) return rc;
                 BZ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
             } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0))) return rc;
+            if (ctx->has_forcings) {
+                // Coriolis, u / v profiles and the bottom fluxes of the stage (bzi_lean_forcings_ok), evaluated from the intact
+                // previous-stage momentum and added, weighted alpha dt, to what the fused RK updates just wrote: the predictor momentum
+                // in the G slots and rho theta / rho q in the stage's output buffers — as the fused-RK tier below does
+                if ((rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, oa, ob, alpha * dt))) return rc;
+                if ((rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, oa, ob, alpha * dt))) return rc;
+                if (stage < 2 && (rc = bzi_lean_bottom_temperature(ctx, oa, ob, s->T))) return rc;
+            }
             if (ctx->pchunk) {
                 // chunked pipeline: each level range goes source term -> x transform -> y transform (and, after the vertical solves,
                 // y -> x -> projection) back to back, so the intermediate passes find the range in the Infinity Cache
@@ -100,7 +108,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                     ProfileScope ps(ctx, "poisson_tridiagonal");
                     if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1))) return rc;
                 }
-                if (ctx->side_scalar) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                if (ctx->side_scalar && !ctx->has_forcings) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 {
                     ProfileScope ps(ctx, stage < 2 ? "poisson_fft_inverse+project_momentum" : "poisson_fft_inverse+project_and_diagnose");
                     ctx->profile_mute++;
@@ -136,7 +144,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                     ProfileScope ps(ctx, "poisson_fft_y_inverse");
                     if ((rc = bzi_xf_y(ctx, false))) return rc;
                 }
-                if (ctx->side_scalar) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                if (ctx->side_scalar && !ctx->has_forcings) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 {
                     ProfileScope ps(ctx, "poisson_fft_x_inverse");
                     if ((rc = bzi_xf_inverse(ctx))) return rc;
@@ -148,7 +156,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             }
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
-            if (ctx->side_scalar) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            if (ctx->side_scalar && !ctx->has_forcings) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             if (stage < 2) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
             else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, G->rho_theta, G->rho_q);
             if (rc) return rc;

@@ -80,3 +80,23 @@ def test_cbl_float32_steps_match_the_float64_oracle(oracle, bz):
         want, got = g.interior(getattr(om, n), zface=(n == "rw")), hm.prognostic_fields()[k].interior_cpu().astype(np.float64)
         scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
         assert np.abs(got - want).max() / scale < 1e-4, (n, np.abs(got - want).max() / scale)
+
+
+@pytest.mark.gpu
+def test_cbl_lean_seam_equals_the_operator_sequence(bz):
+    """The case's forcing stack (momentum profiles + Coriolis + bottom fluxes, no subsidence) rides the lean whole-step seam
+    (csrc/bz_step.hip: bzi_lean_forcings_ok); three steps against the reference's call sequence through the per-operator entry
+    points, whole parent arrays incl. halos: same arithmetic up to the rounding of alpha dt (G + F) against alpha dt G + alpha dt F."""
+    models = []
+    for whole in (True, False):
+        m = bz.benchmarks.convective_boundary_layer((32, 24, 16), float_type=np.float64)
+        for _ in range(3):
+            bz.time_step_(m, 0.5, whole_step=whole)
+        m.synchronize()
+        models.append(m)
+    a, b = models
+    for k in a.prognostic_fields():
+        x, y = a.prognostic_fields()[k].cpu(), b.prognostic_fields()[k].cpu()
+        assert np.abs(x - y).max() / max(np.abs(y).max(), 1e-3) < 1e-12, k
+    for fa, fb in ((a.temperature, b.temperature), (a.velocities["u"], b.velocities["u"]), (a.velocities["w"], b.velocities["w"])):
+        assert np.abs(fa.cpu() - fb.cpu()).max() / np.abs(fb.cpu()).max() < 1e-12

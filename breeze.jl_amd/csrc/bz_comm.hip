@@ -707,7 +707,7 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
 {
     BzComm *c = ctx->comm;
     const DevGrid &g = ctx->dg;
-    if (!(ctx->fused_ok && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 && !ctx->has_forcings && !ctx->has_bulk &&
+    if (!(ctx->fused_ok && ctx->weno_R == 3 && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 && !ctx->has_forcings && !ctx->has_bulk &&
           !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask && (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32)))
         return dist_time_step_general(ctx, s, U0, G, dt);
     int rc;

@@ -51,7 +51,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
 {
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
-    if (ctx->fused_ok && ctx->fuse_rk && ctx->lean && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
+    if (ctx->fused_ok && ctx->fuse_rk && ctx->lean && ctx->weno_R == 3 && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
         (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask &&
         (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32)) {
         // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,
@@ -164,7 +164,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
         ctx->G_is_predictor = true;
         return BZ_OK;
     }
-    if (ctx->fused_ok && ctx->fuse_rk && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !ctx->bounded_mask &&
+    if (ctx->fused_ok && ctx->fuse_rk && ctx->weno_R == 3 && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !ctx->bounded_mask &&
         !(ctx->has_forcings && ctx->tune.no_fuse_forcing)) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state

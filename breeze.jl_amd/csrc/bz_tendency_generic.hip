@@ -15,10 +15,12 @@
 #include "bz_weno.h"
 #include "bz_weno_tables.h"
 
-#if BZ_WENO_ONE_DIVISION == 2
-// Float32 build: smoothness indicators and candidate values from the first differences of the cells (tables BD / CD of
-// tools/gen_weno_tables.py, the same quadratic forms after the substitution w_j = w_0 + sum d_i).  The expanded form above multiplies
-// integer coefficients up to 2.5e6 with squares of a 300 K field and loses every Float32 digit; differences of neighbouring cells do not.
+// Smoothness indicators and candidate values from the first differences of the cells (tables BD / CD of tools/gen_weno_tables.py: the
+// quadratic forms of the expanded tables after the exact substitution w_j = w_0 + sum d_i).  Both precisions use this form since
+// round 3: it needs 14 instead of 20 multiply-adds per sub-stencil, and it keeps its digits — the expanded form multiplies integer
+// coefficients up to 2.5e6 with squares of a 300 K field, which costs Float64 five digits and Float32 all of them.  The six quotients
+// of a reconstruction (tau / (beta_s + eps), the normalisation) are reciprocal-multiplies (bz_recip: v_rcp + Newton steps in Float64,
+// v_rcp alone in Float32): an IEEE division is ~14 instructions, and the kernels below are bound by instruction issue.
 #define BZ_WENO_GENERIC(R)                                                                                       \
     __device__ __forceinline__ double bz_weno_r##R(const double *v)                                             \
     {                                                                                                           \
@@ -38,40 +40,13 @@
         }                                                                                                       \
         tau = fabs(tau);                                                                                        \
         _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                         \
-            const double rr = tau / (beta[s] + BZ_WENO_EPS);                                                    \
+            const double rr = tau * bz_recip<1>(beta[s] + BZ_WENO_EPS);                                         \
             const double a = BZW_D##R[s] * (1.0 + rr * rr);                                                     \
             num = (s == 0) ? a * p[s] : num + a * p[s];                                                         \
             den = (s == 0) ? a : den + a;                                                                       \
         }                                                                                                       \
-        return v[R - 1] + num / den;                                                                            \
+        return v[R - 1] + num * bz_recip<2>(den);                                                               \
     }
-#else
-#define BZ_WENO_GENERIC(R)                                                                                       \
-    __device__ __forceinline__ double bz_weno_r##R(const double *v)                                             \
-    {                                                                                                           \
-        double beta[R], p[R], tau = 0.0, num = 0.0, den = 0.0;                                                  \
-        _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                         \
-            const double *w = v + (R - 1 - s);                                                                  \
-            double b = 0.0, q = 0.0;                                                                            \
-            _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                     \
-                double in = BZW_B##R[s][j][j] * w[j];                                                           \
-                _Pragma("unroll") for (int l = j + 1; l < R; ++l) in += BZW_B##R[s][j][l] * w[l];               \
-                b = (j == 0) ? w[j] * in : b + w[j] * in;                                                       \
-                q = (j == 0) ? BZW_C##R[s][j] * w[j] : q + BZW_C##R[s][j] * w[j];                               \
-            }                                                                                                   \
-            beta[s] = b; p[s] = q;                                                                              \
-            tau = (s == 0) ? BZW_T##R[s] * b : tau + BZW_T##R[s] * b;                                           \
-        }                                                                                                       \
-        tau = fabs(tau);                                                                                        \
-        _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                         \
-            const double rr = tau / (beta[s] + BZ_WENO_EPS);                                                    \
-            const double a = BZW_D##R[s] * (1.0 + rr * rr);                                                     \
-            num = (s == 0) ? a * p[s] : num + a * p[s];                                                         \
-            den = (s == 0) ? a : den + a;                                                                       \
-        }                                                                                                       \
-        return num / den;                                                                                       \
-    }
-#endif
 BZ_WENO_GENERIC(4)
 BZ_WENO_GENERIC(5)
 
@@ -93,32 +68,42 @@ __device__ __forceinline__ int buf_center(int idx, int N)
     return 1;
 }
 
-// upwind-biased value at FACE idx of centred data (p at cell idx) / at CENTRE idx of face data (p at face idx), stride s, buffer B
+// upwind-biased value at FACE idx of centred data (p at cell idx) / at CENTRE idx of face data (p at face idx), stride s, buffer B.
+// The 2 B values straddling the target are loaded once; the biased stencil is q[0 .. 2B-2] or its mirror image q[2B-1 .. 1], picked with
+// lane-mask selects (bz_sel: the VOP3 select; the ternary form compiled to two loads per value and VCC selects).
 __device__ __forceinline__ double biased_face_g(const double *__restrict__ p, long long s, bool left, int B)
 {
     if (B >= 4) {
-        double v[9];
+        const unsigned long long m = bz_lanes(left);
+        double q[10], v[9];
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+            if (j < 2 * B) q[j] = p[(j - B) * s];
 #pragma unroll
         for (int j = 0; j < 9; ++j)
-            if (j < 2 * B - 1) v[j] = left ? p[(j - B) * s] : p[(B - 1 - j) * s];
+            if (j < 2 * B - 1) v[j] = bz_sel(m, q[j], q[2 * B - 1 - j]);
         return B == 5 ? bz_weno_r5(v) : bz_weno_r4(v);
     }
-    if (B == 3) return left ? bz_weno5(p[-3 * s], p[-2 * s], p[-s], p[0], p[s]) : bz_weno5(p[2 * s], p[s], p[0], p[-s], p[-2 * s]);
-    if (B == 2) return left ? bz_weno3(p[-2 * s], p[-s], p[0]) : bz_weno3(p[s], p[0], p[-s]);
-    return left ? p[-s] : p[0];
+    if (B == 3) return bz_up5(p[-3 * s], p[-2 * s], p[-s], p[0], p[s], p[2 * s], left);
+    if (B == 2) return bz_up3(p[-2 * s], p[-s], p[0], p[s], left);
+    return bz_sel(bz_lanes(left), p[-s], p[0]);
 }
 __device__ __forceinline__ double biased_center_g(const double *__restrict__ p, long long s, bool left, int B)
 {
     if (B >= 4) {
-        double v[9];
+        const unsigned long long m = bz_lanes(left);
+        double q[10], v[9];
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+            if (j < 2 * B) q[j] = p[(j - (B - 1)) * s];
 #pragma unroll
         for (int j = 0; j < 9; ++j)
-            if (j < 2 * B - 1) v[j] = left ? p[(j - (B - 1)) * s] : p[(B - j) * s];
+            if (j < 2 * B - 1) v[j] = bz_sel(m, q[j], q[2 * B - 1 - j]);
         return B == 5 ? bz_weno_r5(v) : bz_weno_r4(v);
     }
-    if (B == 3) return left ? bz_weno5(p[-2 * s], p[-s], p[0], p[s], p[2 * s]) : bz_weno5(p[3 * s], p[2 * s], p[s], p[0], p[-s]);
-    if (B == 2) return left ? bz_weno3(p[-s], p[0], p[s]) : bz_weno3(p[2 * s], p[s], p[0]);
-    return left ? p[0] : p[s];
+    if (B == 3) return bz_up5(p[-2 * s], p[-s], p[0], p[s], p[2 * s], p[3 * s], left);
+    if (B == 2) return bz_up3(p[-s], p[0], p[s], p[2 * s], left);
+    return bz_sel(bz_lanes(left), p[0], p[s]);
 }
 
 // Centered(order 2 (B - 1)) (order 2 for B <= 2) of q(m) = A(m) M(m) along stride s; `first` = offset (in cells) of the first of the

@@ -116,6 +116,19 @@ __device__ __forceinline__ double bz_weno5(double a, double b, double c, double 
 #endif
 }
 
+// 1 / x for a positive normal x: v_rcp seed (~2^-23 relative in Float64 as the ISA documents it, 1 ulp in Float32) + NR Newton
+// steps in Float64 (1: ~1e-14, 2: full precision); Float32 needs none
+template <int NR>
+__device__ __forceinline__ double bz_recip(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    if (sizeof(double) == 8) {
+#pragma unroll
+        for (int it = 0; it < NR; ++it) r = fma(fma(-x, r, 1.0), r, r);
+    }
+    return r;
+}
+
 // cells (a,b,c), upwind cell b, value at the face between b and c
 __device__ __forceinline__ double bz_weno3(double a, double b, double c)
 {
@@ -131,15 +144,6 @@ __device__ __forceinline__ double bz_weno3(double a, double b, double c)
     return (a0 * p0 + a1 * p1) / (a0 + a1);
 }
 
-#ifdef BZ_CENTERED2
-// libbreeze_hip_centered2.so: advection = Centered(order = 2), the AtmosphereModel constructor's default
-// (/root/reference/src/AtmosphereModels/atmosphere_model.jl advection keyword; Oceananigans Centered: the advected quantity and
-// the advecting mass flux are both 2-point symmetric interpolations, no upwinding, no order reduction at walls).  The kernels
-// are unchanged; every reconstruction collapses to the mean of the two cells adjacent to the target.
-__device__ __forceinline__ double bz_up5(double, double, double m1, double p0, double, double, bool) { return 0.5 * (m1 + p0); }
-__device__ __forceinline__ double bz_up3(double, double m1, double p0, double, bool) { return 0.5 * (m1 + p0); }
-__device__ __forceinline__ double bz_upB(double, double, double m1, double p0, double, double, bool, int) { return 0.5 * (m1 + p0); }
-#else
 // Lane-mask select m ? a : b as v_cndmask_b32_e64 with the mask in an SGPR pair.  Why not the ternary operator: hipcc emits a
 // share of its selects as the VOP2 form that reads VCC, and on MI355X that encoding issues at ~9.5 ns of SIMD time per wave64
 // instruction against ~1.9 ns for the VOP3 form with an explicit SGPR-pair mask (tools/valu_rates.hip, profiles/r03_valu_rates.txt);
@@ -162,6 +166,15 @@ __device__ __forceinline__ R bz_sel(unsigned long long m, R a, R b)
 }
 __device__ __forceinline__ unsigned long long bz_lanes(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+#ifdef BZ_CENTERED2
+// libbreeze_hip_centered2.so: advection = Centered(order = 2), the AtmosphereModel constructor's default
+// (/root/reference/src/AtmosphereModels/atmosphere_model.jl advection keyword; Oceananigans Centered: the advected quantity and
+// the advecting mass flux are both 2-point symmetric interpolations, no upwinding, no order reduction at walls).  The kernels
+// are unchanged; every reconstruction collapses to the mean of the two cells adjacent to the target.
+__device__ __forceinline__ double bz_up5(double, double, double m1, double p0, double, double, bool) { return 0.5 * (m1 + p0); }
+__device__ __forceinline__ double bz_up3(double, double m1, double p0, double, bool) { return 0.5 * (m1 + p0); }
+__device__ __forceinline__ double bz_upB(double, double, double m1, double p0, double, double, bool, int) { return 0.5 * (m1 + p0); }
+#else
 // Six values straddling the target (which lies between m1 and p0).  left = advecting flux > 0.
 __device__ __forceinline__ double bz_up5(double m3, double m2, double m1, double p0, double p1,
                                          double p2, bool left)

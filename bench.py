@@ -154,6 +154,38 @@ def float32_run(bz, device, N, steps=10, warmup=2):
     return out
 
 
+def _mem_available_gb():
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline_full_size(n=512):
+    """The same oracle on the HEADLINE size (512^3, ~45 GB of host arrays) when the box has the memory: all host cores up to 128
+    threads, one warm-up step and one timed step (~20-40 s of CPU work).  Reported beside the bounded 256^3 sample."""
+    if _mem_available_gb() < 96.0:
+        return {"skipped": f"MemAvailable {_mem_available_gb():.0f} GB < 96 GB"}
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0))
+    threads = max(1, min(128, cores))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    g = orc.Grid((n, n, n), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    m = orc.OracleModel(g, potential_temperature=300.0)
+    m.fft_workers = threads
+    m.set(theta=bubble)
+    m.time_step(1.0)
+    t0 = time.perf_counter()
+    m.time_step(1.0)
+    dt = time.perf_counter() - t0
+    return {"value": n ** 3 / dt, "unit": "cells/s", "cores": threads, "host_cores_available": cores, "kind": "port", "s_per_step": dt,
+            "sample": f"dry thermal bubble {n}^3 Float64 (the headline size), 1 step after 1 warm-up, C/OpenMP oracle + pocketfft on {threads} threads"}
+
+
 def cpu_baseline(n, budget_s=25.0):
     """The CPU oracle ("port": this repo's C/OpenMP restatement, not Breeze CPU() — Julia is not installed)
     timed on this box's host cores on a bounded sample of the same workload: the bubble at n^3 (default 256^3, an eighth
@@ -634,7 +666,7 @@ def run_rank(args):
         # collected at 512^3 on one GPU with the same build: a reference figure, not a measurement of this very run)
         traffic, traffic_src = None, None
         if cells_rank == 512 ** 3:
-            for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as fh:
                         traffic = json.load(fh)["per_kernel_group"][dom]["hbm_bytes_per_launch"]
@@ -684,6 +716,11 @@ def run_rank(args):
                 out["float32"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_budget)
+            if args.workload == "bubble" and args.size == 512 and not args.no_cpu_full_size:
+                try:
+                    out["cpu_baseline_full_size"] = cpu_baseline_full_size(512)
+                except Exception as exc:      # never let the side measurement take the headline line down
+                    out["cpu_baseline_full_size"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -705,6 +742,7 @@ def main():
                     help="bubble: the headline workload (configs[1]); config3: 1024 x (128 N) x 512 slabs; config4: compressible + "
                          "Kessler 512x512x128 (second milestone, split over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-full-size", action="store_true", help="skip the 512^3 leg of the CPU baseline (runs only when the host has >= 96 GB free)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the slab decomposition (explicit only)")
     ap.add_argument("--slab", action="store_true", help="N=1: run the slab driver (world 1) instead of the whole-step seam")
     ap.add_argument("--transport", choices=("auto", "rccl", "torch"), default="auto",

@@ -96,3 +96,20 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 m = bad.search(text)
                 assert m is None, (dirpath, f, m.group(0))
+
+
+def test_float32_abi_header_is_committed_and_current():
+    """include/breeze_hip_f32.h (the Float32 boundary) is the generator's output for the current Float64 header, declares
+    every entry point, and carries no double"""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_f32_sources as gen
+    with open(os.path.join(ROOT, "include", "breeze_hip_f32.h"), encoding="utf-8") as f:
+        text = f.read()
+    assert text == gen.f32_header_text()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert not re.search(r"\bdouble\b", code)
+    from breeze_jl_amd import _lib
+    for name in _lib.SYMBOLS:
+        assert re.search(r"\b%s\s*\(" % name, code), name

@@ -440,6 +440,8 @@ int bzi_tracer_store_initial_state(bz_ctx *ctx);
 int bzi_tracer_tendencies(bz_ctx *ctx, const bz_state *s);
 int bzi_momentum_advection_gen1(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_momentum_advection_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_generic_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, double alpha,
+                                    bool first);
 int bzi_scalar_tendency_generic(bz_ctx *ctx, double *Gc, const double *u, const double *v, const double *w, const double *c);
 int bzi_scalar_rho3d_generic(bz_ctx *ctx, double *Gc, double *Grho, const double *rho, const double *u, const double *v, const double *w,
                              const double *c, const double *ru, const double *rv, const double *rw);

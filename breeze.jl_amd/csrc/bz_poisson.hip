@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "bz_internal.h"
+#include "bz_weno.h"      // bz_recip
 
 #define TX 64
 #define TY 4
@@ -172,9 +173,9 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
             if (pinned && k == Nz - 1) { a = 0.0; b = 1.0; cu = 0.0; d = make_double2(0.0, 0.0); }
             if (padding) { a = 0.0; b = 1.0; cu = 0.0; d = make_double2(0.0, 0.0); }
             double inv, gk;
-            if (j == 0) { inv = 1.0 / b; gk = a * inv; d.x *= inv; d.y *= inv; }
+            if (j == 0) { inv = bz_recip<2>(b); gk = a * inv; d.x *= inv; d.y *= inv; }
             else {
-                inv = 1.0 / (b - a * cp_prev);
+                inv = bz_recip<2>(b - a * cp_prev);      // pivots of a diagonally dominant matrix: normal, never zero (reciprocal by v_rcp + Newton steps)
                 gk = -(a * g_prev) * inv;
                 d.x = (d.x - a * d_prev.x) * inv;
                 d.y = (d.y - a * d_prev.y) * inv;
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
             rhs.x -= cpl * df.x;
             rhs.y -= cpl * df.y;
         }
-        const double r = 1.0 / diag;
+        const double r = bz_recip<2>(diag);
         pa = glm * r; pc = sup * r;
         pd = make_double2(rhs.x * r, rhs.y * r);
     }
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, in
         double2 dm = make_double2(0.0, 0.0), dq = make_double2(0.0, 0.0);
         if (s - h >= 0) { am = B[tm]; cm = B[NT + tm]; dm = make_double2(B[2 * NT + tm], B[3 * NT + tm]); }
         if (s + h < TCO_SEGS) { ap = B[tp]; cp = B[NT + tp]; dq = make_double2(B[2 * NT + tp], B[3 * NT + tp]); }
-        const double r = 1.0 / (1.0 - pa * cm - pc * ap);
+        const double r = bz_recip<2>(1.0 - pa * cm - pc * ap);
         pd.x = (pd.x - pa * dm.x - pc * dq.x) * r;
         pd.y = (pd.y - pa * dm.y - pc * dq.y) * r;
         pa = -pa * am * r;

@@ -164,7 +164,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
         ctx->G_is_predictor = true;
         return BZ_OK;
     }
-    if (ctx->fused_ok && ctx->fuse_rk && ctx->weno_R == 3 && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !ctx->bounded_mask &&
+    if (ctx->fused_ok && ctx->fuse_rk && (ctx->weno_R == 3 || ctx->n_tracers == 0) && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !ctx->bounded_mask &&
         !(ctx->has_forcings && ctx->tune.no_fuse_forcing)) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state

@@ -451,6 +451,7 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
 int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                             double alpha, bool first)
 {
+    if (ctx->weno_R != 3) return bzi_generic_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, first);      // WENO 7 / 9: bz_tendency_generic.hip
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
     int kc = pick_kchunk(g, g.Nz);

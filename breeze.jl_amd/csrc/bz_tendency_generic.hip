@@ -71,36 +71,31 @@ __device__ __forceinline__ int buf_center(int idx, int N)
 // upwind-biased value at FACE idx of centred data (p at cell idx) / at CENTRE idx of face data (p at face idx), stride s, buffer B.
 // The 2 B values straddling the target are loaded once; the biased stencil is q[0 .. 2B-2] or its mirror image q[2B-1 .. 1], picked with
 // lane-mask selects (bz_sel: the VOP3 select; the ternary form compiled to two loads per value and VCC selects).
+// (B is a template parameter of the wide branches: a run-time B in q[2 B - 1 - j] is a dynamic register-array index, i.e. scratch memory)
+template <int B>
+__device__ __forceinline__ double biased_wide_g(const double *__restrict__ p, long long s, bool left, int first)
+{
+    const unsigned long long m = bz_lanes(left);
+    double q[2 * B], v[2 * B - 1];
+#pragma unroll
+    for (int j = 0; j < 2 * B; ++j) q[j] = p[(j + first) * s];
+#pragma unroll
+    for (int j = 0; j < 2 * B - 1; ++j) v[j] = bz_sel(m, q[j], q[2 * B - 1 - j]);
+    if constexpr (B == 5) return bz_weno_r5(v);
+    else return bz_weno_r4(v);
+}
 __device__ __forceinline__ double biased_face_g(const double *__restrict__ p, long long s, bool left, int B)
 {
-    if (B >= 4) {
-        const unsigned long long m = bz_lanes(left);
-        double q[10], v[9];
-#pragma unroll
-        for (int j = 0; j < 10; ++j)
-            if (j < 2 * B) q[j] = p[(j - B) * s];
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            if (j < 2 * B - 1) v[j] = bz_sel(m, q[j], q[2 * B - 1 - j]);
-        return B == 5 ? bz_weno_r5(v) : bz_weno_r4(v);
-    }
+    if (B == 5) return biased_wide_g<5>(p, s, left, -5);
+    if (B == 4) return biased_wide_g<4>(p, s, left, -4);
     if (B == 3) return bz_up5(p[-3 * s], p[-2 * s], p[-s], p[0], p[s], p[2 * s], left);
     if (B == 2) return bz_up3(p[-2 * s], p[-s], p[0], p[s], left);
     return bz_sel(bz_lanes(left), p[-s], p[0]);
 }
 __device__ __forceinline__ double biased_center_g(const double *__restrict__ p, long long s, bool left, int B)
 {
-    if (B >= 4) {
-        const unsigned long long m = bz_lanes(left);
-        double q[10], v[9];
-#pragma unroll
-        for (int j = 0; j < 10; ++j)
-            if (j < 2 * B) q[j] = p[(j - (B - 1)) * s];
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            if (j < 2 * B - 1) v[j] = bz_sel(m, q[j], q[2 * B - 1 - j]);
-        return B == 5 ? bz_weno_r5(v) : bz_weno_r4(v);
-    }
+    if (B == 5) return biased_wide_g<5>(p, s, left, -4);
+    if (B == 4) return biased_wide_g<4>(p, s, left, -3);
     if (B == 3) return bz_up5(p[-2 * s], p[-s], p[0], p[s], p[2 * s], p[3 * s], left);
     if (B == 2) return bz_up3(p[-s], p[0], p[s], p[2 * s], left);
     return bz_sel(bz_lanes(left), p[0], p[s]);
@@ -109,22 +104,30 @@ __device__ __forceinline__ double biased_center_g(const double *__restrict__ p, 
 // Centered(order 2 (B - 1)) (order 2 for B <= 2) of q(m) = A(m) M(m) along stride s; `first` = offset (in cells) of the first of the
 // 2 h values (h = max(B - 1, 1)): -h for a face target from centres (centres idx-h .. idx+h-1), -(h-1) for a centre target from faces.
 // A == nullptr: constant factor a0.
+// (H = number of values either side is a template parameter of the implementation: with a run-time h the unrolled q[h - 1 - d] is a
+// dynamic register-array index, and the table `c` a run-time pointer)
+template <int H>
+__device__ __forceinline__ double symm_h(const double *__restrict__ M, long long n, long long s, int first, const ColPtr A, int k, double a0)
+{
+    double q[2 * H];
+#pragma unroll
+    for (int m = 0; m < 2 * H; ++m) q[m] = (A.p ? A[k + first + m] : a0) * M[n + (long long)(first + m) * s];
+    if constexpr (H == 1) return bz_symm2(q[0], q[1]);
+    else if constexpr (H == 2) return bz_symm4(q[0], q[1], q[2], q[3]);
+    else {
+        double acc = (H == 4 ? BZW_S8[0] : BZW_S6[0]) * (q[H - 1] + q[H]);
+#pragma unroll
+        for (int d = 1; d < H; ++d) acc += (H == 4 ? BZW_S8[d] : BZW_S6[d]) * (q[H - 1 - d] + q[H + d]);
+        return acc;
+    }
+}
 __device__ __forceinline__ double symm_g(const double *__restrict__ M, long long n, long long s, int B, int first, const ColPtr A, int k,
                                          double a0)
 {
-    const int h = B > 2 ? B - 1 : 1;
-    double q[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-        if (m < 2 * h) q[m] = (A.p ? A[k + first + m] : a0) * M[n + (long long)(first + m) * s];
-    if (h == 1) return bz_symm2(q[0], q[1]);
-    if (h == 2) return bz_symm4(q[0], q[1], q[2], q[3]);
-    const double *c = (h == 4) ? BZW_S8 : BZW_S6;
-    double acc = c[0] * (q[h - 1] + q[h]);
-#pragma unroll
-    for (int d = 1; d < 4; ++d)
-        if (d < h) acc += c[d] * (q[h - 1 - d] + q[h + d]);
-    return acc;
+    if (B == 5) return symm_h<4>(M, n, s, first, A, k, a0);
+    if (B == 4) return symm_h<3>(M, n, s, first, A, k, a0);
+    if (B == 3) return symm_h<2>(M, n, s, first, A, k, a0);
+    return symm_h<1>(M, n, s, first, A, k, a0);
 }
 
 // ---- two-pass evaluation ---------------------------------------------------------------------------------------------------------
@@ -132,7 +135,18 @@ __device__ __forceinline__ double symm_g(const double *__restrict__ M, long long
 // shipped path is PASS 1 + PASS 2: every thread evaluates the three fluxes of its own index once and stores them in parent-shaped
 // scratch arrays (ctx->d_gflux), a second launch differences them.  Order-9 reconstructions cost ~700 instructions each, the scratch
 // traffic (3 words written, 6 read per cell) is noise beside that.  Bit-identical to PASS 0: the same expressions, evaluated once.
-struct FluxBuf { double *x, *y, *z; };
+struct FluxBuf {
+    double *x, *y, *z;
+    // optional SSP-RK3 epilogue of the divergence pass (fused-RK tier of the whole-step seam): instead of the tendency G the kernel
+    // stores (1 - alpha) u0 + alpha (uold + dt G); uold = the prognostic field the tendency belongs to (E.mode 0: store G)
+    RKEpilogue E;
+    const double *uold;
+};
+__device__ __forceinline__ double rk_out(const FluxBuf &F, double G, long long n)
+{
+    if (F.E.mode == 0) return G;
+    return bz_rk_apply(F.E.mode, F.E.dt, F.E.alpha, F.E.oma, F.E.u0, F.E.u0_out, G, F.uold[n], n);
+}
 
 // PASS 1 covers the interior (x is Periodic and y wraps unless the context is a y-slab or Flat: the flux at face N is the flux at face 0,
 // bit for bit, because halos are exact periodic images; the Bounded z direction has zero mass flux through its wall faces) plus, on
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__
     double dx, dy, dz;
     if (PASS == 2) { dx = F.x[n + W.xp] - F.x[n]; dy = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; dz = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
     else { dx = fx(n + 1) - fx(n); dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n); dz = fz(n + sz, k + 1) - fz(n, k); }      // a Flat y has no faces
-    Gc[n] = -(g.Vinv_c[k] * (dx + dy + dz));
+    Gc[n] = rk_out(F, -(g.Vinv_c[k] * (dx + dy + dz)), n);
 }
 
 // ---- momentum -------------------------------------------------------------------------------------------------------------------
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(256) void k_u_tendency_g(DevGrid g, double *__restr
     double a, b, c;
     if (PASS == 2) { a = F.x[n] - F.x[n + W.xm]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
     else { a = FUu(n) - FUu(n - 1); b = g.flat_y ? 0.0 : FVu(n + sy) - FVu(n); c = FWu(n + sz, k + 1) - FWu(n, k); }
-    Gu[n] = -(g.Vinv_c[k] * (a + b + c));
+    Gu[n] = rk_out(F, -(g.Vinv_c[k] * (a + b + c)), n);
 }
 
 template <int R, int PASS>
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(256) void k_v_tendency_g(DevGrid g, double *__restr
     double a, b, c;
     if (PASS == 2) { a = F.x[n + W.xp] - F.x[n]; b = g.flat_y ? 0.0 : F.y[n] - F.y[n + W.ym]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
     else { a = FUv(n + 1) - FUv(n); b = g.flat_y ? 0.0 : FVv(n) - FVv(n - sy); c = FWv(n + sz, k + 1) - FWv(n, k); }
-    Gv[n] = -(g.Vinv_c[k] * (a + b + c));
+    Gv[n] = rk_out(F, -(g.Vinv_c[k] * (a + b + c)), n);
 }
 
 // faces k = 1 .. Nz-1; + Iz(buoyancy) unless !BUOY (slow tendency of the split-explicit compressible model)
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restr
     if (PASS == 2) { a = F.x[n + W.xp] - F.x[n]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = F.z[n] - F.z[n - sz]; }
     else { a = FUw(n + 1) - FUw(n); b = g.flat_y ? 0.0 : FVw(n + sy) - FVw(n); c = FWw(n, k) - FWw(n - sz, k - 1); }
     const double adv = -(g.Vinv_f[k] * (a + b + c));
-    if (BUOY) Gw[n] = adv + 0.5 * (bz_buoyancy(g, T, qv, n - sz, k - 1) + bz_buoyancy(g, T, qv, n, k));
+    if (BUOY) Gw[n] = rk_out(F, adv + 0.5 * (bz_buoyancy(g, T, qv, n - sz, k - 1) + bz_buoyancy(g, T, qv, n, k)), n);
     else Gw[n] = adv;
 }
 
@@ -371,40 +385,64 @@ static int generic_flux_buffers(bz_ctx *ctx, FluxBuf &F)
     } while (0)
 #define COMMA_FALSE , false
 
+// E != nullptr: the fused-RK tier of the whole-step seam (bz_step.hip) — the divergence pass of every field applies the SSP-RK3 update:
+// the predictor momentum goes to the G slots (the prognostic momentum keeps feeding the advecting fluxes of the kernels that follow),
+// rho theta / rho q advance in place (the scalar kernels read the specific diagnostics, not the densities)
 template <int R>
-static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool buoyancy, bool scalars)
+static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool buoyancy, bool scalars, const RKEpilogue *E = nullptr,
+                          const bz_prognostic *U0 = nullptr)
 {
     const DevGrid &g = ctx->dg;
     const bool onepass = ctx->tune.generic_onepass;
-    FluxBuf F{nullptr, nullptr, nullptr};
+    FluxBuf F{};
     int rc;
     if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;
+    auto epi = [&](double *u0, const double *uold) {
+        if (!E) return;
+        F.E = *E; F.E.u0 = u0; F.E.u0_out = u0; F.uold = uold;
+    };
     {
-        ProfileScope ps(ctx, "x_momentum_tendency");
+        ProfileScope ps(ctx, E ? "x_momentum_tendency+rk3" : "x_momentum_tendency");
+        epi(U0 ? U0->rho_u : nullptr, s->rho_u);
         GENERIC_LAUNCH(k_u_tendency_g, , 0, g.Nz, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u);
     }
     {
-        ProfileScope ps(ctx, "y_momentum_tendency");
+        ProfileScope ps(ctx, E ? "y_momentum_tendency+rk3" : "y_momentum_tendency");
+        epi(U0 ? U0->rho_v : nullptr, s->rho_v);
         GENERIC_LAUNCH(k_v_tendency_g, , 0, g.Nz, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v);
     }
     if (g.Nz > 1) {
-        ProfileScope ps(ctx, "z_momentum_tendency");
+        ProfileScope ps(ctx, E ? "z_momentum_tendency+rk3" : "z_momentum_tendency");
+        epi(U0 ? U0->rho_w : nullptr, s->rho_w);
         if (buoyancy) GENERIC_LAUNCH(k_w_tendency_g, , 1, g.Nz - 1, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w, s->T, s->q);
         else GENERIC_LAUNCH(k_w_tendency_g, COMMA_FALSE, 1, g.Nz - 1, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w, (const double *)nullptr,
                             (const double *)nullptr);
     }
     if (scalars) {
         {
-            ProfileScope ps(ctx, "potential_temperature_tendency");
-            GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, G->rho_theta, s->u, s->v, s->w, s->theta);
+            ProfileScope ps(ctx, E ? "potential_temperature_tendency+rk3" : "potential_temperature_tendency");
+            epi(U0 ? U0->rho_theta : nullptr, s->rho_theta);
+            GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, E ? s->rho_theta : G->rho_theta, s->u, s->v, s->w, s->theta);
         }
         {
-            ProfileScope ps(ctx, "moisture_tendency");
-            GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, G->rho_q, s->u, s->v, s->w, s->q);
+            ProfileScope ps(ctx, E ? "moisture_tendency+rk3" : "moisture_tendency");
+            epi(U0 ? U0->rho_q : nullptr, s->rho_q);
+            GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, E ? s->rho_q : G->rho_q, s->u, s->v, s->w, s->q);
         }
     }
     BZ_LAUNCH_CHECK();
     return BZ_OK;
+}
+
+// tendencies + SSP-RK3 update of the five prognostic fields for WENO(order = 7 / 9): the fused-RK tier of bz_step.hip
+int bzi_generic_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, double alpha,
+                                    bool first)
+{
+    RKEpilogue E;
+    E.mode = first ? 1 : 2; E.dt = dt; E.alpha = alpha; E.oma = 1.0 - alpha;
+    if (ctx->weno_R == 5) return launch_generic<5>(ctx, s, G, true, true, &E, U0);
+    if (ctx->weno_R == 4) return launch_generic<4>(ctx, s, G, true, true, &E, U0);
+    return BZ_ERR_INVALID;
 }
 
 // compressible split-explicit model with WENO(order = 7 / 9) (examples/splitting_supercell.jl:279): slow momentum tendencies =
@@ -422,7 +460,7 @@ static int launch_rho3d(bz_ctx *ctx, double *Gc, double *Grho, const double *rho
 {
     const DevGrid &g = ctx->dg;
     const bool onepass = ctx->tune.generic_onepass;
-    FluxBuf F{nullptr, nullptr, nullptr};
+    FluxBuf F{};
     int rc;
     if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;
     GENERIC_LAUNCH(k_scalar_tendency_rho3d_g, , 0, g.Nz, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
@@ -444,7 +482,7 @@ static int launch_scalar(bz_ctx *ctx, double *Gc, const double *u, const double 
 {
     const DevGrid &g = ctx->dg;
     const bool onepass = ctx->tune.generic_onepass;
-    FluxBuf F{nullptr, nullptr, nullptr};
+    FluxBuf F{};
     int rc;
     if (!onepass && (rc = generic_flux_buffers(ctx, F))) return rc;
     GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, Gc, u, v, w, c);

@@ -221,24 +221,30 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // the level's own momentum elements arrive one level ahead (software pipeline: the advecting fluxes are the first thing a level
     // computes, so loads issued at its top were waited for at once — a full memory latency per level and wave)
     double ru_n = ru[n], rv_n = rv[n], rw_n = rw[n + sz];
+    double rvtop_n = (tyu == 0 || tyu == TY / 2) ? rv[ntop0] : 0.0;      // top-face duties of the first level: rows 0 and TY / 2
     for (int k = kbeg; k < kend; ++k, n += sz) {
-        // ---- loads: next level's frame cells, ring tops, momentum of this level ----
+        // ---- loads, issued in the order their values are needed (s_waitcnt counts vector loads in order, so waiting for a load
+        //      waits for everything issued before it): ring tops (vertical flux, mid-level), next level's frame cells (staging, end of
+        //      the level), U0 (RK update, very end), and last what only the NEXT level reads — its own momentum elements and the
+        //      velocity row of its top-face duty (round 2 loaded those at the top of the level that used them: a full memory
+        //      latency per level and wave, because the advecting fluxes are the first thing a level computes) ----
         double ha[HPT], hb[HPT];
         const unsigned lev = (unsigned)(k + 1 - kbeg) * sz;
+        const double ta_raw = pa[n + 3 * sz], tb_raw = pb[n + 3 * sz];
 #pragma unroll
         for (int q = 0; q < HPT; ++q) { ha[q] = hok[q] ? pa[hn[q] + lev] : 0.0; hb[q] = hok[q] ? pb[hn[q] + lev] : 0.0; }
-        const double ta_raw = pa[n + 3 * sz], tb_raw = pb[n + 3 * sz];
-        const double ru_t = ru_n, rv_t = rv_n, rw_t = rw_n;
-        ru_n = ru[n + sz]; rv_n = rv[n + sz]; rw_n = rw[n + 2 * sz];      // level k + 1 (level kend of the last trip is a halo level: in bounds, unused)
-        // U0 of both fields is needed by the RK update at the very end of the level: issue the loads here (round 2 loaded them at the
-        // point of use, two exposed memory latencies per level and wave)
         const double u0a = (E.mode == 2) ? E.u0[n] : 0.0, u0b = (E.mode == 2) ? E.u0b[n] : 0.0;
+        const double ru_t = ru_n, rv_t = rv_n, rw_t = rw_n, rvtop = rvtop_n;
         // The y face above the tile belongs to no row of the tile: one wavefront per field evaluates it, and the duty rotates with the
-        // level (field a: row (k - kbeg) mod TY, field b: half a turn later).  With a fixed wave 0 doing both, that wave ran 8 WENOs per
-        // level against 6 of the others, every level's barrier waited for it, and its SIMD carried 19 % more work than the other three.
+        // level (field a: row (k - kbeg) mod TY, field b: half a turn later).
         const int turn = (k - kbeg) & (TY - 1);
         const bool duty_a = tyu == turn, duty_b = tyu == ((turn + TY / 2) & (TY - 1));
-        const double rvtop = (duty_a || duty_b) ? rv[ntop0 + lev - sz] : 0.0;
+        ru_n = ru[n + sz]; rv_n = rv[n + sz]; rw_n = rw[n + 2 * sz];      // level k + 1 (level kend of the last trip is a halo level: in bounds, unused)
+        {
+            const int turn_n = (turn + 1) & (TY - 1);
+            const bool duty_n = tyu == turn_n || tyu == ((turn_n + TY / 2) & (TY - 1));
+            rvtop_n = duty_n ? rv[ntop0 + lev] : 0.0;
+        }
         const double rho = LV.rho(k), rrho = LV.rrho(k), Ax_k = LV.Ax(k), Ay_k = LV.Ay(k), Vi_k = LV.Vinv_c(k), pi_k = LV.pi(k);
         const double rho1 = LV.rho(k + 1), rrho1 = LV.rrho(k + 1), rhof1 = LV.rho_f(k + 1), rrhof1 = LV.rrho_f(k + 1);
         const double rho3 = LV.rho(k + 3), rrho3 = LV.rrho(k + 3);
@@ -294,6 +300,9 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 FY[buf][1][TY][tx] = rho * (cfy2 * bz_up5(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2));
             fzb_hi = rf * (cfz * bz_upB(b[1], b[2], b[3], b[4], b[5], tb, lz, Bz));
         }
+        // the cell's own prognostic values (read three levels ago as ring tops: an L2 / Infinity-Cache hit), requested before the staging
+        // arithmetic so that the RK update after the barrier finds them
+        const double pa_n = pa[n], pb_n = pb[n];
         // ---- stage level k+1 in the other buffer ----
         T[buf ^ 1][0][ty + 3][tx + 3] = a[4];
         T[buf ^ 1][1][ty + 3][tx + 3] = b[4];
@@ -306,11 +315,6 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     T[buf ^ 1][1][hr[q]][hc[q]] = bz_cdiv(hb[q], rh, rr);
                 }
         }
-#ifdef BZ_EXP_NO_REREAD
-        const double pa_n = ta_raw, pb_n = tb_raw;      // timing experiment only (wrong values): what does the own-cell re-read cost?
-#else
-        const double pa_n = pa[n], pb_n = pb[n];      // the cell's own prognostic values (read three levels ago as ring tops)
-#endif
         __syncthreads();
         // ---- combine, SSP-RK3 update, temperature of the updated cell for the next stage's buoyancy ----
         {

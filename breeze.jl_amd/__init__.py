@@ -15,7 +15,7 @@ from .model import (AnelasticDynamics, AtmosphereModel, Centered, Field, WENO, c
                     ssp_rk3_substep_, store_initial_state_, time_step_, update_state_)
 from . import compressible  # noqa: F401,E402
 from .compressible import (AcousticRungeKutta3, AcousticSubstepper, CompressibleAtmosphereModel, CompressibleDynamics,  # noqa: F401,E402
-                           ExnerReferenceState, NewtonSolver, NoDivergenceDamping, ProportionalSubsteps,
+                           ExnerReferenceState, NewtonSolver, NoDivergenceDamping, ProportionalSubsteps, ConstantSubstepSize, MonolithicFirstStage,
                            SplitExplicitTimeDiscretization, ThermalDivergenceDamping, DirectDivergenceDamping, UpperSponge,
                            LinearRamp, CubicRamp, Sin2Ramp)
 from .microphysics import SaturationAdjustment, SecantSolver, WarmPhaseEquilibrium  # noqa: F401,E402

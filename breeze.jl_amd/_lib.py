@@ -146,7 +146,8 @@ class bz_split_explicit(C.Structure):
                 ("acoustic_cfl", C.c_double), ("forward_weight", C.c_double), ("damping_coefficient", C.c_double),
                 ("thermodynamic_tendency_factor", C.c_double), ("vertical_momentum_tendency_factor", C.c_double),
                 ("newton_abstol", C.c_double), ("direct_divergence_damping", C.c_int32), ("sponge_ramp", C.c_int32),
-                ("sponge_damping_rate", C.c_double), ("sponge_depth", C.c_double)]
+                ("sponge_damping_rate", C.c_double), ("sponge_depth", C.c_double),
+                ("substep_distribution", C.c_int32)]
 
 
 class bz_exner_reference_state(C.Structure):

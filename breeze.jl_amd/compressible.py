@@ -41,7 +41,18 @@ class DirectDivergenceDamping:
 
 
 class ProportionalSubsteps:
-    pass
+    """each stage covers beta dt with ceil(beta N) substeps sized to tile it (acoustic_substepping.jl:491-495; the default)"""
+    code = 0
+
+
+class ConstantSubstepSize:
+    """one substep size dt / N for all stages, N rounded up to a multiple of 6 (acoustic_substepping.jl:497-501)"""
+    code = 1
+
+
+class MonolithicFirstStage:
+    """stage 1 collapses to one substep of dt / 3, stages 2-3 as ConstantSubstepSize (acoustic_substepping.jl:503-508)"""
+    code = 2
 
 
 class LinearRamp:
@@ -77,8 +88,8 @@ class SplitExplicitTimeDiscretization:
             raise ValueError("`damping` must be an `AcousticDampingStrategy`")
         if sponge is not None and not isinstance(sponge, UpperSponge):
             raise ValueError("`sponge` must be an `UpperSponge` or None")
-        if substep_distribution is not None and not isinstance(substep_distribution, ProportionalSubsteps):
-            raise NotImplementedError("only ProportionalSubsteps is implemented in the HIP path")
+        if substep_distribution is not None and not isinstance(substep_distribution, (ProportionalSubsteps, ConstantSubstepSize, MonolithicFirstStage)):
+            raise ValueError("`substep_distribution` must be ProportionalSubsteps(), ConstantSubstepSize() or MonolithicFirstStage()")
         if not acoustic_cfl > 0:
             raise ValueError(f"`acoustic_cfl` must be positive (got {acoustic_cfl})")
         self.substeps = None if substeps is None else int(substeps)
@@ -359,6 +370,7 @@ class CompressibleAtmosphereModel:
         bt.thermodynamic_tendency_factor = td.thermodynamic_tendency_factor
         bt.vertical_momentum_tendency_factor = td.vertical_momentum_tendency_factor
         bt.newton_abstol = self.temperature_solver.abstol
+        bt.substep_distribution = td.substep_distribution.code
         if td.sponge is not None:
             bt.sponge_ramp, bt.sponge_damping_rate, bt.sponge_depth = td.sponge.ramp.code, td.sponge.damping_rate, td.sponge.depth
         self._ctx = C.c_void_p()

@@ -911,10 +911,23 @@ extern "C" int bz_stage_substeps(bz_ctx *ctx, double dt, double beta, int32_t *n
     BZ_REQUIRE_COMPRESSIBLE();
     const double dt_stage = beta * dt;
     int n;
-    if (ctx->se.substeps > 0) n = (int)std::fmax(1.0, std::ceil(beta * (double)ctx->se.substeps));
-    else n = acoustic_substeps_for(ctx, dt_stage);
+    double dtau_v;
+    const int dist = ctx->se.substep_distribution;
+    if (dist == 2 && beta < (1.0 / 3.0 + 1.0 / 2.0) / 2.0) {      // MonolithicFirstStage: stage 1 collapses to one substep of dt / 3 (:503-508)
+        n = 1;
+        dtau_v = dt / 3.0;
+    } else if (dist == 1 || dist == 2) {      // ConstantSubstepSize (:497-501): one size dt / N for all stages, N a multiple of 6 so that beta N is integral
+        const int n_raw = ctx->se.substeps > 0 ? ctx->se.substeps : acoustic_substeps_for(ctx, dt);
+        const int N = std::max(6, 6 * ((n_raw + 5) / 6));
+        n = std::max(1, (int)std::lround(beta * (double)N));
+        dtau_v = dt / (double)N;
+    } else {                                  // ProportionalSubsteps (:491-495)
+        if (ctx->se.substeps > 0) n = (int)std::fmax(1.0, std::ceil(beta * (double)ctx->se.substeps));
+        else n = acoustic_substeps_for(ctx, dt_stage);
+        dtau_v = dt_stage / (double)n;
+    }
     if (n_substeps) *n_substeps = n;
-    if (dtau) *dtau = dt_stage / (double)n;
+    if (dtau) *dtau = dtau_v;
     return BZ_OK;
 }
 

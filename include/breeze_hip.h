@@ -303,6 +303,9 @@ typedef struct bz_split_explicit {
                                          0 = sponge = nothing, 1 LinearRamp, 2 CubicRamp (the default ramp), 3 Sin2Ramp                 */
     double sponge_damping_rate;       /* peak rate at the lid, 1/s (default 0.2)                                                       */
     double sponge_depth;              /* layer thickness below z = grid.Lz, m (default 5e3)                                            */
+    int32_t substep_distribution;     /* stage substep counts and sizes (acoustic_substepping.jl:468-508): 0 ProportionalSubsteps (default:
+                                         ceil(beta N) substeps tiling beta dt), 1 ConstantSubstepSize (N rounded up to a multiple of 6,
+                                         round(beta N) substeps of dt / N), 2 MonolithicFirstStage (stage 1: one substep of dt / 3)          */
 } bz_split_explicit;
 
 /* ExnerReferenceState columns (src/Thermodynamics/reference_states.jl:717-815): HOST arrays of length Nz+2Hz

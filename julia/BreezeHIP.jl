@@ -181,7 +181,7 @@ end
 ##### src/CompressibleEquations/acoustic_substepping.jl)
 ##### ---------------------------------------------------------------------------------------------------------------
 using Breeze.TimeSteppers: AcousticRungeKutta3
-using Breeze.CompressibleEquations: CompressibleDynamics, ThermalDivergenceDamping, ProportionalSubsteps
+using Breeze.CompressibleEquations: CompressibleDynamics, ThermalDivergenceDamping, ProportionalSubsteps, ConstantSubstepSize, MonolithicFirstStage
 import Breeze.CompressibleEquations: acoustic_rk3_substep_loop!
 
 struct BzCompressibleState
@@ -204,7 +204,11 @@ struct BzSplitExplicit
     f_θ::Float64; f_w::Float64; newton_abstol::Float64
     direct_divergence_damping::Int32; sponge_ramp::Int32          # ramp: 0 none, 1 LinearRamp, 2 CubicRamp, 3 Sin2Ramp
     sponge_damping_rate::Float64; sponge_depth::Float64
+    substep_distribution::Int32                                   # 0 ProportionalSubsteps, 1 ConstantSubstepSize, 2 MonolithicFirstStage
 end
+distcode(::ProportionalSubsteps) = Int32(0)
+distcode(::ConstantSubstepSize) = Int32(1)
+distcode(::MonolithicFirstStage) = Int32(2)
 rampcode(::Nothing) = Int32(0)
 rampcode(s::UpperSponge) = s.ramp isa LinearRamp ? Int32(1) : s.ramp isa CubicRamp ? Int32(2) : s.ramp isa Sin2Ramp ? Int32(3) :
                            error("BreezeHIP: custom sponge ramps are not supported")
@@ -246,7 +250,8 @@ function create_compressible_context(model)
                          damp isa Union{ThermalDivergenceDamping, DirectDivergenceDamping} ? damp.coefficient : -1.0,
                          a.thermodynamic_tendency_factor, a.vertical_momentum_tendency_factor, solver.abstol,
                          damp isa DirectDivergenceDamping, rampcode(a.sponge),
-                         a.sponge === nothing ? 0.0 : a.sponge.damping_rate, a.sponge === nothing ? 0.0 : a.sponge.depth)
+                         a.sponge === nothing ? 0.0 : a.sponge.damping_rate, a.sponge === nothing ? 0.0 : a.sponge.depth,
+                         distcode(a.substep_distribution))
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve zf p ρ begin
         g = BzGrid(Nx, Ny, Nz, Hx, Hy, Hz, map(topocode, topology(grid)), 8, grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, pointer(zf),

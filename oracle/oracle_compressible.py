@@ -107,9 +107,12 @@ class SplitExplicit:
     def __init__(self, substeps=None, acoustic_cfl=0.5, forward_weight=0.65,
                  damping_coefficient=0.1, damp_vertical=False,
                  apply_first_substep_pressure_gradient=False,
-                 thermodynamic_tendency_factor=1.0, vertical_momentum_tendency_factor=1.0, direct_damping=False, sponge=None):
+                 thermodynamic_tendency_factor=1.0, vertical_momentum_tendency_factor=1.0, direct_damping=False, sponge=None,
+                 substep_distribution="proportional"):
         self.direct_damping = bool(direct_damping)      # DirectDivergenceDamping(coefficient) instead of ThermalDivergenceDamping
         self.sponge = sponge                            # None or (damping_rate, depth, ramp) with ramp in {"linear", "cubic", "sin2"}
+        assert substep_distribution in ("proportional", "constant", "monolithic_first_stage")
+        self.substep_distribution = substep_distribution
         self.substeps = substeps
         self.acoustic_cfl = float(acoustic_cfl)
         self.forward_weight = float(forward_weight)
@@ -138,8 +141,14 @@ def compute_acoustic_substeps(grid, dt, constants, acoustic_cfl):
     return max(1, math.ceil(abs(float(dt)) * cs / (acoustic_cfl * min(dx, dy))))
 
 
-def stage_substep_count_and_size(substeps, beta, dt, grid, constants, acoustic_cfl):
-    """ProportionalSubsteps (acoustic_substepping.jl:491-495)"""
+def stage_substep_count_and_size(substeps, beta, dt, grid, constants, acoustic_cfl, distribution="proportional"):
+    """ProportionalSubsteps (acoustic_substepping.jl:491-495), ConstantSubstepSize (:497-501), MonolithicFirstStage (:503-508)"""
+    if distribution == "monolithic_first_stage" and beta < (1 / 3 + 1 / 2) / 2:
+        return 1, dt / 3
+    if distribution in ("constant", "monolithic_first_stage"):
+        n_raw = substeps if substeps is not None else compute_acoustic_substeps(grid, dt, constants, acoustic_cfl)
+        N = max(6, 6 * -(-n_raw // 6))          # _uniform_substep_count (:484-487)
+        return max(1, round(beta * N)), dt / N
     dt_stage = beta * dt
     if substeps is None:
         n = compute_acoustic_substeps(grid, dt_stage, constants, acoustic_cfl)
@@ -431,7 +440,7 @@ class CompressibleOracleModel:
         g, td, c = self.grid, self.td, self.constants
         cg, L = C.byref(self.cg), self.lib
         Nz = g.Nz
-        n_tau, dtau = stage_substep_count_and_size(td.substeps, beta, float(dt), g, c, td.acoustic_cfl)
+        n_tau, dtau = stage_substep_count_and_size(td.substeps, beta, float(dt), g, c, td.acoustic_cfl, td.substep_distribution)
         self.last_substeps.append(n_tau)
         om = td.forward_weight
         dtn, dto = om * dtau, (1 - om) * dtau

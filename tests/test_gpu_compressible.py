@@ -32,7 +32,9 @@ def make_pair(oracle, oc, bz, size=(24, 16, 20), theta_ref=300.0, reference=True
         sponge = bz.UpperSponge(damping_rate=otd.sponge[0], depth=otd.sponge[1], ramp=ramp)
     btd = bz.SplitExplicitTimeDiscretization(substeps=otd.substeps, acoustic_cfl=otd.acoustic_cfl,
                                              forward_weight=otd.forward_weight, damping=damping, sponge=sponge,
-                                             apply_first_substep_pressure_gradient=otd.apply_first)
+                                             apply_first_substep_pressure_gradient=otd.apply_first,
+                                             substep_distribution={"proportional": bz.ProportionalSubsteps, "constant": bz.ConstantSubstepSize,
+                                                                   "monolithic_first_stage": bz.MonolithicFirstStage}[otd.substep_distribution]())
     dyn = bz.CompressibleDynamics(btd, reference_potential_temperature=theta_ref if reference else None,
                                   reference_state="auto" if reference else None)
     hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5))
@@ -418,3 +420,30 @@ def test_compressible_saturation_adjustment_matches_oracle(oracle, oc, bz):
         hm.time_step(1.0)
     cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rw", "T", "p"), 1e-8)
     assert np.abs(μ["qˡ"].interior_cpu() - g.interior(om.ql)).max() < 1e-9
+
+
+@pytest.mark.parametrize("td", [dict(substeps=8, substep_distribution="constant"), dict(substep_distribution="constant"),
+                                dict(substeps=8, substep_distribution="monolithic_first_stage")])
+def test_substep_distributions_match_oracle(oracle, oc, bz, td):
+    """ConstantSubstepSize / MonolithicFirstStage (acoustic_substepping.jl:468-508): the stage counts and sizes the library computes
+    are the oracle's, and two full steps agree as for the default distribution"""
+    om, hm = make_pair(oracle, oc, bz, size=(24, 16, 20), **td)
+    g, c = om.grid, om.constants
+    for dt in (0.7, 2.0, 5.0):
+        for beta in (1 / 3, 1 / 2, 1.0):
+            n, dtau = hm.stage_substeps(dt, beta)
+            want = oc.stage_substep_count_and_size(om.td.substeps, beta, dt, g, c, om.td.acoustic_cfl, om.td.substep_distribution)
+            assert n == want[0] and abs(dtau - want[1]) <= 1e-15 * dt, (dt, beta, n, dtau, want)
+
+    def theta(x, y, z):
+        r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+        return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+    rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    om.set(rho=rho, theta=theta, u=lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z, v=0.0, w=0.0, qv=0.0)
+    hm.set(ρ=rho, θ=theta, u=lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z, v=0.0, w=0.0, qᵗ=0.0)
+    for _ in range(2):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    cmp_interior(om, hm, ("rho_d", "rtheta", "ru", "rv", "rw", "T", "p"), 5e-9)
+    assert om.last_substeps == [hm.stage_substeps(2.0, b)[0] for b in (1 / 3, 1 / 2, 1.0)]

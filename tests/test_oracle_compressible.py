@@ -358,3 +358,26 @@ def test_upper_sponge_coefficients_known_answers(oracle, oc):
     assert np.sum(out["on"][top] ** 2) < 0.98 * np.sum(out["off"][top] ** 2)
     assert np.allclose(out["on"][:6], out["off"][:6], rtol=0.2, atol=1e-3 * np.abs(out["off"]).max())
     assert np.all(np.isfinite(out["on"]))
+
+
+def test_substep_distributions(oracle, oc):
+    """stage_substep_count_and_size for the three distributions (acoustic_substepping.jl:468-508): ProportionalSubsteps tiles beta dt
+    with ceil(beta N) substeps; ConstantSubstepSize rounds N up to a multiple of 6 and uses dt / N in every stage (beta N integral, so
+    every stage is covered exactly); MonolithicFirstStage takes stage 1 in one substep of dt / 3"""
+    g = oracle.Grid((16, 16, 8), x=(0, 16e3), y=(0, 16e3), z=(0, 8e3))
+    c = oracle.Constants()
+    dt = 12.0
+    for N in (None, 4, 6, 8, 13):
+        for beta in (1 / 3, 1 / 2, 1.0):
+            n, dtau = oc.stage_substep_count_and_size(N, beta, dt, g, c, 0.5, "proportional")
+            assert abs(n * dtau - beta * dt) < 1e-12
+            n, dtau = oc.stage_substep_count_and_size(N, beta, dt, g, c, 0.5, "constant")
+            n_raw = N if N is not None else oc.compute_acoustic_substeps(g, dt, c, 0.5)
+            Nu = max(6, 6 * -(-n_raw // 6))
+            assert Nu % 6 == 0 and Nu >= n_raw and dtau == dt / Nu and n == round(beta * Nu) and abs(n * dtau - beta * dt) < 1e-12
+            n, dtau = oc.stage_substep_count_and_size(N, beta, dt, g, c, 0.5, "monolithic_first_stage")
+            if beta < 0.4:
+                assert (n, dtau) == (1, dt / 3)
+            else:
+                assert dtau == dt / Nu and n == round(beta * Nu)
+    assert oc.stage_substep_count_and_size(8, 1.0, dt, g, c, 0.5, "constant")[0] == 12

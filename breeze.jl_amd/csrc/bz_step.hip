@@ -80,10 +80,10 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                 BZ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
             } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0))) return rc;
             if (ctx->has_forcings) {
-                // Coriolis, u / v profiles and the bottom fluxes of the stage (bzi_lean_forcings_ok), evaluated from the intact
-                // previous-stage momentum and added, weighted alpha dt, to what the fused RK updates just wrote: the predictor momentum
-                // in the G slots and rho theta / rho q in the stage's output buffers — as the fused-RK tier below does
-                if ((rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, oa, ob, alpha * dt))) return rc;
+                // the bottom fluxes of the stage (bzi_lean_forcings_ok), evaluated from the intact previous-stage momentum and added,
+                // weighted alpha dt, to what the fused RK updates just wrote: the predictor momentum in the G slots and rho theta /
+                // rho q in the stage's output buffers — as the fused-RK tier below does
+                // (the Coriolis / profile terms went into the RK epilogues of the momentum kernels: Lean5::mforce, bz_tendency5.hip)
                 if ((rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, oa, ob, alpha * dt))) return rc;
                 if (stage < 2 && (rc = bzi_lean_bottom_temperature(ctx, oa, ob, s->T))) return rc;
             }

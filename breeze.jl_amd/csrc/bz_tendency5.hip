@@ -97,6 +97,14 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
     L.T = s->T;
     L.pi_dry = ColPtr(ctx->d_pi_dry + g.Hz);
     L.lev = (const LevRow5 *)ctx->d_lev_rows + g.Hz;
+    L.mforce = 0; L.cor_f = 0.0; L.Fu = ColPtr(nullptr); L.Fv = ColPtr(nullptr);
+    if (ctx->has_forcings && bzi_lean_forcings_ok(ctx)) {      // the stack's momentum terms ride the RK epilogues of k6_u / k6_v
+        const int m = ctx->forcing_static_mask;
+        L.cor_f = ctx->forcing_f;
+        if (m & 1) L.Fu = ColPtr(ctx->d_forcing);
+        if (m & 2) L.Fv = ColPtr(ctx->d_forcing + (size_t)g.Nz);
+        L.mforce = (ctx->forcing_f != 0.0 ? 1 : 0) | ((m & 1) ? 2 : 0) | ((m & 2) ? 4 : 0);
+    }
     const dim3 block(64, TY);
     const int tx = (g.Nx + 63) / 64, nty = (g.Ny + TY - 1) / TY;
     if (rows && nty < 3) return rows == 1 ? BZ_OK : lean_launch<TY>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, 0, which);
@@ -115,14 +123,16 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         L.out = G->rho_u;
         const dim3 grid = shape(g.Nz, kc);
-        hipLaunchKernelGGL((k6_u<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (L.mforce) hipLaunchKernelGGL((k6_u<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_u<TY, false>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 1) {
         ProfileScope ps(ctx, "y_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
         L.out = G->rho_v;
         const dim3 grid = shape(g.Nz, kc);
-        hipLaunchKernelGGL((k6_v<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (L.mforce) hipLaunchKernelGGL((k6_v<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_v<TY, false>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 1) {
         ProfileScope ps(ctx, "z_momentum_tendency+rk3+velocity");

@@ -60,6 +60,12 @@ struct Lean5 {
     double *T;                       // temperature of the stage-start state (w kernel: read; scalar kernel: writes the updated one)
     ColPtr pi_dry;                   // (p_r[k]/p_st)^(Rd/cpd) indexed by level, or nullptr
     const LevRow5 *lev;              // the column constants of a level packed in one 64-byte row (indexed by level, -Hz .. Nz+Hz-1)
+    // momentum terms of a forcing stack folded into the RK epilogue of k6_u / k6_v (bz_step.hip: lean seam with bzi_lean_forcings_ok):
+    // f-plane Coriolis f * (4-point average of the other momentum component) and the specific u / v profiles times rho_r (geostrophic
+    // forcing).  mforce: 0 none, else bit 0 Coriolis, bit 1 Fu, bit 2 Fv.  Terms and order as k_apply_forcings (bz_forcing.hip).
+    int mforce;
+    double cor_f;
+    ColPtr Fu, Fv;
     int xcd;                         // 1: XCD-contiguous block order (grid size divisible by 8)
     int by0, bys;                    // tile row of block row b is by0 + b * bys (sub-launches of the slab driver: interior rows
                                      // while the y-halo exchange is in flight, then the two edge rows)
@@ -368,7 +374,7 @@ __device__ __forceinline__ double flux_x_lean(const DevGrid &g, const Tend3Field
 // <= 2 frame cells), consumes them at its end, and reads its stencils with ds_read (tiles: u derived (TY+6) x 70; raw rho_u TY x 67;
 // raw rho_v (TY+1) x 67; raw rho_w TY x 67 at the upper face; double-buffered).  Same arithmetic, same bits as k5_u.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY>
+template <int TY, bool MF = false>      // MF: momentum terms of a forcing stack in the RK epilogue (Lean5::mforce)
 __global__ __launch_bounds__(64 * TY) void k6_u(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY;
@@ -491,9 +497,16 @@ __global__ __launch_bounds__(64 * TY) void k6_u(DevGrid g, Lean5 L, int kchunk, 
             if (tx == le) nb = e;
             const double dx = fx - nb;
             const double dy = FY[buf][ty + 1][tx] - fy;
-            if (store)
-                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out,
-                                           -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo))), q0, n);
+            double Gu = -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo)));
+            if constexpr (MF) {      // -x_f_cross_U + rho F_u: rho_v at (i-1, j), (i-1, j+1), (i, j), (i, j+1) from the raw rho_v tile
+                if (L.mforce & 1) {
+                    const double *rv0 = RV[buf][ty] + tc, *rv1 = RV[buf][ty + 1] + tc;
+                    const double a = (rv0[-1] + rv1[-1]) / 2, b = (rv0[0] + rv1[0]) / 2;
+                    Gu -= -L.cor_f * ((a + b) / 2);
+                }
+                if (L.mforce & 2) Gu += g.rho[k] * L.Fu[k];
+            }
+            if (store) L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out, Gu, q0, n);
         }
         fz_lo = fz_hi;
 #pragma unroll
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(64 * TY) void k6_u(DevGrid g, Lean5 L, int kchunk, 
 // y-momentum, sixth generation (see k6_u): the v tile carries its x halo, so the x-stencil is five ds_reads instead of five loads +
 // five column divisions; ring top and u0 are loaded one level ahead.  Same arithmetic, same bits as k5_v.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY>
+template <int TY, bool MF = false>
 __global__ __launch_bounds__(64 * TY) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles
@@ -599,6 +612,10 @@ __global__ __launch_bounds__(64 * TY) void k6_v(DevGrid g, Lean5 L, int kchunk, 
         const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
         const double tnew_raw = tcur_raw, u0v = u0cur;
         const double ru_n = g.Ax[k + 1] * ru[n + sz], rw_n = Az * rw[n + 2 * sz];
+        // Coriolis: rho_u at (i, j-1), (i+1, j-1), (i, j), (i+1, j) — the Ax rho_u tile has no x halo and is premultiplied, so four
+        // loads (L1 / L2 hits of rows this tile has just staged), issued here and used after the barrier
+        double cu0 = 0.0, cu1 = 0.0, cu2 = 0.0, cu3 = 0.0;
+        if constexpr (MF) { if (L.mforce & 1) { const ix_t sy = (ix_t)g.Sx; cu0 = ru[n - sy]; cu1 = ru[n - sy + 1]; cu2 = ru[n]; cu3 = ru[n + 1]; } }
         if (((k - kbeg) & 63) == 0) {
             const int kk = min(k + tx, kend - 1);
             edge = flux_x_lean<T3_V>(g, F, rv, ie, jc, kk);
@@ -642,9 +659,12 @@ __global__ __launch_bounds__(64 * TY) void k6_v(DevGrid g, Lean5 L, int kchunk, 
             if (tx == le) nb = e;
             const double dx = nb - fx;
             const double dy = fy - FY[buf][ty][tx];
-            if (store)
-                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out,
-                                       -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo))), q0, n);
+            double Gv = -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo)));
+            if constexpr (MF) {      // -y_f_cross_U + rho F_v
+                if (L.mforce & 1) { const double a = (cu0 + cu1) / 2, b = (cu2 + cu3) / 2; Gv -= L.cor_f * ((a + b) / 2); }
+                if (L.mforce & 4) Gv += rho * L.Fv[k];
+            }
+            if (store) L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out, Gv, q0, n);
         }
         fz_lo = fz_hi;
         q0 = q1; q1 = q2; q2 = tnew_raw;

@@ -75,14 +75,17 @@ def bubble(x, y, z):
 EXTENT = ((-10e3, 10e3), (-10e3, 10e3), (0.0, 10e3))
 
 
-def compressible_milestone(bz, device, steps=2):
+def compressible_milestone(bz, device, steps=2, substep_float32=False):
     """Second milestone, reported beside the headline metric, never as `value`: the compressible
-    split-explicit WS-RK3 step (acoustic substep loop) on a 512 x 512 x 256 bubble, Float64, dt = 1 s."""
+    split-explicit WS-RK3 step (acoustic substep loop) on a 512 x 512 x 256 bubble, Float64, dt = 1 s.
+    substep_float32: the same model with substep_floattype = Float32 (acoustic_substepping.jl:199-235): the substepper's ten working
+    fields stored as Float32, arithmetic and every model field Float64 — reported under `substep_floattype_float32`."""
     import torch
     Nx, Ny, Nz = 512, 512, 256
     grid = bz.RectilinearGrid((Nx, Ny, Nz), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
     dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), surface_pressure=1e5, reference_potential_temperature=300.0)
-    m = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), device=device)
+    m = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), device=device,
+                                       substep_floattype=np.float32 if substep_float32 else None)
     c = m.thermodynamic_constants
     Rd, cpd, g = 8.314462618 / c.dry_air_molar_mass, c.dry_air_heat_capacity, c.gravitational_acceleration
 
@@ -118,6 +121,13 @@ def compressible_milestone(bz, device, steps=2):
            "finite": bool(torch.isfinite(m.velocities["w"].interior).all().item())}
     del m
     torch.cuda.empty_cache()
+    if not substep_float32:
+        try:
+            r = compressible_milestone(bz, device, steps, substep_float32=True)
+            out["substep_floattype_float32"] = {k: r[k] for k in ("value", "ms_per_step", "acoustic_substep_ms", "finite")}
+            out["substep_floattype_float32"]["tolerance"] = "2e-6 of the field scale after three steps against the Float64 oracle (tests/test_gpu_compressible.py)"
+        except Exception as exc:      # noqa: BLE001
+            out["substep_floattype_float32"] = {"error": repr(exc)}
     return out
 
 

@@ -226,12 +226,21 @@ class AcousticSubstepper:
               ("time_averaged_u", "fcc"), ("time_averaged_v", "cfc"), ("time_averaged_w", "ccf"),
               ("slow_vertical_momentum_tendency", "ccf"), ("vertical_solver_source_term", "ccf"))
 
-    def __init__(self, grid, time_discretization, device):
+    # stored in substep_floattype (acoustic_substepping.jl:207-223); (rho w)', the solver's right-hand side, the slow vertical tendency
+    # and the time-averaged velocities keep eltype(grid)
+    WORKING = ("exner", "potential_temperature", "gamma_R_mixture", "density_perturbation", "density_potential_temperature_perturbation",
+               "momentum_perturbation_u", "momentum_perturbation_v", "density_predictor", "density_potential_temperature_predictor",
+               "previous_density_potential_temperature_perturbation")
+
+    def __init__(self, grid, time_discretization, device, substep_floattype=None):
         td = time_discretization
         self.substeps, self.acoustic_cfl, self.forward_weight = td.substeps, td.acoustic_cfl, td.forward_weight
         self.damping = td.damping
+        self.substep_floattype = np.dtype(grid.float_type if substep_floattype is None else substep_floattype).type
+        if self.substep_floattype not in (np.float32, np.float64) or np.dtype(self.substep_floattype).itemsize > grid.ftype:
+            raise NotImplementedError("substep_floattype: eltype(grid) or Float32 inside a Float64 model")
         for name, loc in self.FIELDS:
-            setattr(self, name, Field(grid, _LOC[loc], device))
+            setattr(self, name, Field(grid, _LOC[loc], device, float_type=self.substep_floattype if name in self.WORKING else None))
         self.linearization_exner = self.exner
         self.linearization_potential_temperature = self.potential_temperature
         self.linearization_gamma_R_mixture = self.gamma_R_mixture
@@ -249,11 +258,11 @@ class AcousticSubstepper:
 class AcousticRungeKutta3:
     """Wicker-Skamarock RK3 with acoustic substepping: β = (1/3, 1/2, 1) (acoustic_runge_kutta_3.jl:64-103)."""
 
-    def __init__(self, grid, prognostic_fields, dynamics, device):
+    def __init__(self, grid, prognostic_fields, dynamics, device, substep_floattype=None):
         self.β1, self.β2, self.β3 = 1.0 / 3.0, 1.0 / 2.0, 1.0
         self.U0 = {k: Field(grid, f.loc, device) for k, f in prognostic_fields.items()}
         self.Gn = {k: Field(grid, f.loc, device) for k, f in prognostic_fields.items()}
-        self.substepper = AcousticSubstepper(grid, dynamics.time_discretization, device)
+        self.substepper = AcousticSubstepper(grid, dynamics.time_discretization, device, substep_floattype=substep_floattype)
 
 
 _ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "θli": "θ", "ρ": "ρ", "rho": "ρ", "u": "u", "v": "v", "w": "w",
@@ -265,7 +274,10 @@ class CompressibleAtmosphereModel:
     — timestepper :AcousticRungeKutta3, microphysics / closure / coriolis / forcing = nothing."""
 
     def __init__(self, grid, dynamics, advection=None, thermodynamic_constants=None, temperature_solver=None,
-                 closure=None, coriolis=None, microphysics=None, forcing=None, device="cuda:0"):
+                 closure=None, coriolis=None, microphysics=None, forcing=None, device="cuda:0", substep_floattype=None):
+        """substep_floattype: storage type of the acoustic substepper's working fields (the keyword of the reference's
+        AcousticSubstepper constructor, acoustic_substepping.jl:181,199-235): None = eltype(grid); numpy.float32 inside a Float64
+        model halves the bytes the substep kernels stream."""
         import torch
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
@@ -334,7 +346,7 @@ class CompressibleAtmosphereModel:
                                                            potential_temperature=dynamics._reference_spec,
                                                            vapor_mass_fraction=dynamics._reference_vapor,
                                                            standard_pressure=dynamics.standard_pressure)
-        self.timestepper = AcousticRungeKutta3(grid, self.prognostic_fields(), dynamics, self.device)
+        self.timestepper = AcousticRungeKutta3(grid, self.prognostic_fields(), dynamics, self.device, substep_floattype=substep_floattype)
         self.U0, self.G = self.timestepper.U0, self.timestepper.Gn
 
         # ---- context ----
@@ -371,6 +383,8 @@ class CompressibleAtmosphereModel:
         bt.vertical_momentum_tendency_factor = td.vertical_momentum_tendency_factor
         bt.newton_abstol = self.temperature_solver.abstol
         bt.substep_distribution = td.substep_distribution.code
+        sft = self.timestepper.substepper.substep_floattype
+        bt.substep_float_bytes = 4 if (sft is np.float32 and grid.ftype == 8) else 0
         if td.sponge is not None:
             bt.sponge_ramp, bt.sponge_damping_rate, bt.sponge_depth = td.sponge.ramp.code, td.sponge.damping_rate, td.sponge.depth
         self._ctx = C.c_void_p()

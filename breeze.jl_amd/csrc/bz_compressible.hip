@@ -73,7 +73,14 @@ struct DiagFields {
     double *rho_d, *rho, *ru, *rv, *rw, *rth, *rq;
     double *u, *v, *w, *theta, *q, *T, *p;
     double *Pi, *thL, *gR, *Clin;       // LIN
+    int st32;                           // LIN: the four linearisation arrays are stored as float (substep_floattype = Float32)
 };
+// store into a working array of the substepper in its storage type (wave-uniform branch)
+__device__ __forceinline__ void st_store(double *p, long long n, double v, int st32)
+{
+    if (st32) ((float *)p)[n] = (float)v;
+    else p[n] = v;
+}
 
 // FULL: everything; !FULL: halos of rho_d, rho_theta, momentum + velocities only (tail of acoustic_rk3_substep_loop!)
 // KES: DCMIP2016 Kessler species — total density includes rho q^cl + rho q^r, q = (q^v, q^cl + q^r) in R_m, c_pm and the
@@ -176,10 +183,10 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
             const double Pi = pow(p / g.pst, g.Rd / g.cpd);
             const double thl = rth / ((rd == 0.0) ? 1.0 : rd);
             const double gr = cpm * Rm / (cpm - Rm);
-            F.Pi[n] = Pi;
-            F.thL[n] = thl;
-            F.gR[n] = gr;
-            F.Clin[n] = gr * Pi;
+            st_store(F.Pi, n, Pi, F.st32);
+            st_store(F.thL, n, thl, F.st32);
+            st_store(F.gR, n, gr, F.st32);
+            st_store(F.Clin, n, gr * Pi, F.st32);
         }
     }
     if (bot || top) {     // first z-halo cell of the no-flux centre fields
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
 __global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__restrict__ Pi, double *__restrict__ thL,
                                                            double *__restrict__ gR, double *__restrict__ Clin,
                                                            const double *__restrict__ p, const double *__restrict__ rho_d,
-                                                           const double *__restrict__ rth, const double *__restrict__ qv)
+                                                           const double *__restrict__ rth, const double *__restrict__ qv, int st32)
 {
     // y-slab mode: one halo row on each side is linearised locally (its inputs arrive with the state's halo exchange)
     const int i = blockIdx.x * 256 + threadIdx.x, j = (int)blockIdx.y - (g.wrap_y ? 0 : 1), k = blockIdx.z;
@@ -230,10 +237,10 @@ __global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__
     const double cpm = g.microphysics ? qd * g.cpd + q * g.cpv + ql * g.sa_cl : qd * g.cpd + q * g.cpv;
     const double P = pow(p[n] / g.pst, g.Rd / g.cpd);
     const double gr = cpm * Rm / (cpm - Rm);
-    Pi[n] = P;
-    thL[n] = rth[n] / ((rd == 0.0) ? 1.0 : rd);
-    gR[n] = gr;
-    Clin[n] = gr * P;
+    st_store(Pi, n, P, st32);
+    st_store(thL, n, rth[n] / ((rd == 0.0) ? 1.0 : rd), st32);
+    st_store(gR, n, gr, st32);
+    st_store(Clin, n, gr * P, st32);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -322,7 +329,12 @@ struct AcParams {
     double inv_N;                 // 1 / N_tau
 };
 
-struct AcFields {
+// ST = substep_floattype (acoustic_substepping.jl:199-235): the storage type of the acoustic perturbation / predictor / linearisation
+// working fields.  Kernels read ST, promote to the grid's real, compute there and store ST; (rho w)', the tridiagonal right-hand side and
+// factors, the time-averaged velocities and every model field stay in the grid's type.  ST = float inside a Float64 model halves the
+// bytes of 12 of the arrays the substep kernels stream.
+template <class ST>
+struct AcFieldsT {
     // model state (stage-entry U^L; untouched by the loop)
     double *rho_d, *rth, *ru, *rv, *rw, *rq;
     const double *rho, *p;
@@ -330,14 +342,15 @@ struct AcFields {
     const double *U0_rho_d, *U0_rth, *U0_ru, *U0_rv, *U0_rw, *U0_rq;
     const double *G_rho_d, *G_rth, *G_ru, *G_rv, *G_rw, *G_rq;
     // substepper
-    const double *thL, *Clin;
-    double *rp, *rthp, *rup, *rvp, *rwp;
-    double *rs, *rths, *rth_old;
+    const ST *thL, *Clin;
+    ST *rp, *rthp, *rup, *rvp;
+    double *rwp;
+    ST *rs, *rths, *rth_old;
     // fused substep (k_ac_column_forward<.., FUSED = true>): (rho u)', (rho v)' ping-pong between rup_in (read) and rup
     // (written); (rho theta)' ping-pongs between rthp (current, read) / rth_old (previous, read) and rthp_out (written
     // by the backward sweep), so no thread reads a location another thread of the same launch writes.
-    const double *rup_in, *rvp_in;
-    double *rthp_out;
+    const ST *rup_in, *rvp_in;
+    ST *rthp_out;
     double *au, *av, *aw;
     double *rqcl, *rqr;           // Kessler species (k_ac_recover<2>)
     const double *U0_rqcl, *U0_rqr, *G_rqcl, *G_rqr;
@@ -345,9 +358,41 @@ struct AcFields {
     double *tfac;                 // Thomas factors t_k
     const double *sponge;         // UpperSponge: damping_rate * ramp(z_face) per face k = 0 .. Nz (all zero without a sponge)
 };
+typedef AcFieldsT<double> AcFields;
+#define COMMA ,
+// the same fields with the working arrays seen as ST (the host allocated them in that type; every other member is copied)
+template <class ST>
+static AcFieldsT<ST> ac_cast(const AcFields &F)
+{
+    AcFieldsT<ST> R;
+    R.rho_d = F.rho_d; R.rth = F.rth; R.ru = F.ru; R.rv = F.rv; R.rw = F.rw; R.rq = F.rq; R.rho = F.rho; R.p = F.p;
+    R.U0_rho_d = F.U0_rho_d; R.U0_rth = F.U0_rth; R.U0_ru = F.U0_ru; R.U0_rv = F.U0_rv; R.U0_rw = F.U0_rw; R.U0_rq = F.U0_rq;
+    R.G_rho_d = F.G_rho_d; R.G_rth = F.G_rth; R.G_ru = F.G_ru; R.G_rv = F.G_rv; R.G_rw = F.G_rw; R.G_rq = F.G_rq;
+    R.thL = (const ST *)F.thL; R.Clin = (const ST *)F.Clin;
+    R.rp = (ST *)F.rp; R.rthp = (ST *)F.rthp; R.rup = (ST *)F.rup; R.rvp = (ST *)F.rvp; R.rwp = F.rwp;
+    R.rs = (ST *)F.rs; R.rths = (ST *)F.rths; R.rth_old = (ST *)F.rth_old;
+    R.rup_in = (const ST *)F.rup_in; R.rvp_in = (const ST *)F.rvp_in; R.rthp_out = (ST *)F.rthp_out;
+    R.au = F.au; R.av = F.av; R.aw = F.aw; R.rqcl = F.rqcl; R.rqr = F.rqr;
+    R.U0_rqcl = F.U0_rqcl; R.U0_rqr = F.U0_rqr; R.G_rqcl = F.G_rqcl; R.G_rqr = F.G_rqr;
+    R.Gs = F.Gs; R.phi = F.phi; R.tfac = F.tfac; R.sponge = F.sponge;
+    return R;
+}
+// launch an acoustic kernel in the context's substep storage type: KERNEL is the template name, TA its leading template arguments
+// with a trailing comma (or empty)
+#define AC_LAUNCH(KERNEL, TA, GRID, BLOCK, FIELDS, ...)                                                                         \
+    do {                                                                                                                         \
+        if (ctx->substep_f32) hipLaunchKernelGGL((KERNEL<TA float>), GRID, BLOCK, 0, ctx->stream, g, ac_cast<float>(FIELDS), __VA_ARGS__);   \
+        else hipLaunchKernelGGL((KERNEL<TA double>), GRID, BLOCK, 0, ctx->stream, g, FIELDS, __VA_ARGS__);                       \
+    } while (0)
+#define AC_LAUNCH0(KERNEL, TA, GRID, BLOCK, FIELDS)                                                                             \
+    do {                                                                                                                         \
+        if (ctx->substep_f32) hipLaunchKernelGGL((KERNEL<TA float>), GRID, BLOCK, 0, ctx->stream, g, ac_cast<float>(FIELDS));    \
+        else hipLaunchKernelGGL((KERNEL<TA double>), GRID, BLOCK, 0, ctx->stream, g, FIELDS);                                    \
+    } while (0)
 
 // assemble_slow_vertical_momentum_tendency! + initialize_stage_perturbations! (acoustic_substepping.jl:727-752,793-838)
-__global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFields F)
+template <class ST>
+__global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> F)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
     if (i >= g.Nx) return;
@@ -377,8 +422,8 @@ __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFields F)
 
 // Klemp-Skamarock-Ha damping of the previous substep (acoustic_substepping.jl:1123-1139) followed by the explicit
 // horizontal step of this substep (:860-881) and the time-average accumulation (:999-1000).
-template <bool DAMP, bool STEP>
-__global__ __launch_bounds__(256) void k_ac_horizontal(DevGrid g, AcFields F, AcParams P)
+template <bool DAMP, bool STEP, class ST>
+__global__ __launch_bounds__(256) void k_ac_horizontal(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
     if (i >= g.Nx) return;
@@ -457,8 +502,8 @@ __device__ __forceinline__ double ac_face_update(double up, double G, double rt_
 // column is evaluated in place of loading (rho u)', (rho v)': each face is computed by its two adjacent columns with
 // identical arithmetic and stored by its owner, which removes one read + one write of (rho u)', (rho v)' and the separate
 // pass over (rho theta)', theta^L, C per substep.
-template <bool FIRST, bool FUSED, bool DAMP>
-__global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGrid g, AcFields F, AcParams P)
+template <bool FIRST, bool FUSED, bool DAMP, class ST>
+__global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
     const int i = blockIdx.x * ACX + threadIdx.x, j = blockIdx.y * ACY + threadIdx.y;
     if (i >= g.Nx || j >= g.Ny) return;
@@ -560,7 +605,8 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
 }
 
 // back substitution + _post_solve_recovery! (acoustic_substepping.jl:993-1002)
-__global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcFields F, AcParams P)
+template <class ST>
+__global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
     const int i = blockIdx.x * ABX + threadIdx.x, j = blockIdx.y * ABY + threadIdx.y;
     if (i >= g.Nx || j >= g.Ny) return;
@@ -592,8 +638,8 @@ __global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcF
 
 // last substep's damping + _finalize_time_averaged_velocity! (acoustic_substepping.jl:1225-1250); writes the periodic
 // halo images and z-halo copies of the averaged velocities (they feed WENO stencils of the moisture tendency).
-template <bool DAMP>
-__global__ __launch_bounds__(256) void k_ac_finalize(DevGrid g, AcFields F, AcParams P)
+template <bool DAMP, class ST>
+__global__ __launch_bounds__(256) void k_ac_finalize(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
     if (i >= g.Nx) return;
@@ -633,8 +679,8 @@ __global__ __launch_bounds__(256) void k_ac_finalize(DevGrid g, AcFields F, AcPa
 
 // _recover_full_state! (acoustic_substepping.jl:1274-1292) [+ WS-RK3 update of the moisture density,
 // acoustic_runge_kutta_3.jl:189-192, when dt_stage_q != 0 pointer-wise]
-template <int MOIST>      // 0: acoustic prognostics only; 1: + rho q^v; 2: + rho q^v and the Kessler species
-__global__ __launch_bounds__(256) void k_ac_recover(DevGrid g, AcFields F, double dt_stage)
+template <int MOIST, class ST>      // MOIST 0: acoustic prognostics only; 1: + rho q^v; 2: + rho q^v and the Kessler species
+__global__ __launch_bounds__(256) void k_ac_recover(DevGrid g, AcFieldsT<ST> F, double dt_stage)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)g.Ny * g.Sx) return;
@@ -706,6 +752,7 @@ extern "C" int bz_create_compressible_slab(bz_ctx **out, const bz_grid *local_gr
                                            int y_nranks, int y_rank)
 {
     if (td && td->direct_divergence_damping) return BZ_ERR_UNSUPPORTED;   // delta would need its own y-halo exchange
+    if (td && td->substep_float_bytes != 0 && td->substep_float_bytes != (int32_t)sizeof(double)) return BZ_ERR_UNSUPPORTED;   // the per-substep halo messages carry the grid's real
     if (y_nranks < 1 || y_rank < 0 || y_rank >= y_nranks) return BZ_ERR_INVALID;
     return bzi_create_compressible(out, local_grid, constants, ref, td, weno_order, y_nranks, y_rank, true);
 }
@@ -718,6 +765,10 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
     if ((ref->pressure == nullptr) != (ref->density == nullptr)) return BZ_ERR_INVALID;
     if (td->substeps < 0 || !(td->acoustic_cfl > 0.0) || td->newton_maxiter < 0) return BZ_ERR_INVALID;
     if (td->sponge_ramp < 0 || td->sponge_ramp > 3 || (td->sponge_ramp && !(td->sponge_depth > 0.0))) return BZ_ERR_INVALID;
+    if (td->substep_distribution < 0 || td->substep_distribution > 2) return BZ_ERR_INVALID;
+    // substep_floattype: 0 = eltype(grid); 4 = Float32 working fields (inside a Float64 model: half the bytes; in the Float32 library: eltype)
+    if (td->substep_float_bytes != 0 && td->substep_float_bytes != 4 && td->substep_float_bytes != (int32_t)sizeof(double)) return BZ_ERR_UNSUPPORTED;
+    if (td->substep_float_bytes == 4 && sizeof(double) == 8 && td->direct_divergence_damping) return BZ_ERR_UNSUPPORTED;   // its two kernels read the working fields as the grid's real
     const int nc = grid->Nz + 2 * grid->Hz;
     std::vector<double> zeros((size_t)nc, 0.0);
     bz_reference_state r;
@@ -734,6 +785,7 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
     ctx->has_reference = ref->density != nullptr;
     const size_t ncell = (size_t)ctx->dg.Sxy * (size_t)nc;
     ctx->ac_fused = !ctx->tune.no_ac_fuse;
+    ctx->substep_f32 = (td->substep_float_bytes == 4) && sizeof(double) == 8;
     if (hipMalloc(&ctx->d_Clin, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_tfac_ac, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_up2, ncell * sizeof(double)) != hipSuccess ||
@@ -786,6 +838,7 @@ static DiagFields diag_fields(bz_ctx *ctx, const bz_compressible_state *s, const
     F.thL = sub ? sub->potential_temperature : nullptr;
     F.gR = sub ? sub->gamma_R_mixture : nullptr;
     F.Clin = ctx->d_Clin;
+    F.st32 = ctx->substep_f32 ? 1 : 0;
     return F;
 }
 
@@ -849,7 +902,7 @@ extern "C" int bz_refresh_linearization(bz_ctx *ctx, const bz_compressible_state
     ProfileScope ps(ctx, "refresh_linearization");
     dim3 grid((g.Nx + 255) / 256, g.Ny + (g.wrap_y ? 0 : 2), g.Nz), block(256);
     hipLaunchKernelGGL(k_cmp_linearization, grid, block, 0, ctx->stream, g, sub->exner, sub->potential_temperature,
-                       sub->gamma_R_mixture, ctx->d_Clin, s->p, s->rho_d, s->rho_theta, s->q);
+                       sub->gamma_R_mixture, ctx->d_Clin, s->p, s->rho_d, s->rho_theta, s->q, ctx->substep_f32 ? 1 : 0);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -1043,7 +1096,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     AcFields Fi = F;
     Fi.rthp_out = th_buf[S.cur]; Fi.rup = u_buf[S.cur]; Fi.rvp = v_buf[S.cur];
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
-    hipLaunchKernelGGL(k_ac_stage_init, rows, b256, 0, ctx->stream, g, Fi);
+    AC_LAUNCH0(k_ac_stage_init, , rows, b256, Fi);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -1078,35 +1131,35 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
         {
             ProfileScope ps(ctx, "acoustic_horizontal+column_forward");
             if (sstep == 1)
-                hipLaunchKernelGGL((k_ac_column_forward<true, true, false>), cols, bcol, 0, ctx->stream, g, Fs, P);
+                AC_LAUNCH(k_ac_column_forward, true COMMA true COMMA false COMMA, cols, bcol, Fs, P);
             else if (damp)
-                hipLaunchKernelGGL((k_ac_column_forward<false, true, true>), cols, bcol, 0, ctx->stream, g, Fs, P);
+                AC_LAUNCH(k_ac_column_forward, false COMMA true COMMA true COMMA, cols, bcol, Fs, P);
             else
-                hipLaunchKernelGGL((k_ac_column_forward<false, true, false>), cols, bcol, 0, ctx->stream, g, Fs, P);
+                AC_LAUNCH(k_ac_column_forward, false COMMA true COMMA false COMMA, cols, bcol, Fs, P);
         }
         {
             ProfileScope ps(ctx, "acoustic_column_backward");
-            hipLaunchKernelGGL(k_ac_column_backward, colsb, bcolb, 0, ctx->stream, g, Fs, P);
+            AC_LAUNCH(k_ac_column_backward, , colsb, bcolb, Fs, P);
         }
         S.cur ^= 1;
     } else {
         {
             ProfileScope ps(ctx, "acoustic_horizontal");
             if (damp)
-                hipLaunchKernelGGL((k_ac_horizontal<true, true>), rows, b256, 0, ctx->stream, g, F, P);
+                AC_LAUNCH(k_ac_horizontal, true COMMA true COMMA, rows, b256, F, P);
             else
-                hipLaunchKernelGGL((k_ac_horizontal<false, true>), rows, b256, 0, ctx->stream, g, F, P);
+                AC_LAUNCH(k_ac_horizontal, false COMMA true COMMA, rows, b256, F, P);
         }
         {
             ProfileScope ps(ctx, "acoustic_column_forward");
             if (sstep == 1)
-                hipLaunchKernelGGL((k_ac_column_forward<true, false, false>), cols, bcol, 0, ctx->stream, g, F, P);
+                AC_LAUNCH(k_ac_column_forward, true COMMA false COMMA false COMMA, cols, bcol, F, P);
             else
-                hipLaunchKernelGGL((k_ac_column_forward<false, false, false>), cols, bcol, 0, ctx->stream, g, F, P);
+                AC_LAUNCH(k_ac_column_forward, false COMMA false COMMA false COMMA, cols, bcol, F, P);
         }
         {
             ProfileScope ps(ctx, "acoustic_column_backward");
-            hipLaunchKernelGGL(k_ac_column_backward, colsb, bcolb, 0, ctx->stream, g, F, P);
+            AC_LAUNCH(k_ac_column_backward, , colsb, bcolb, F, P);
         }
     }
     if (S.direct) {      // DirectDivergenceDamping closes every substep (also the last one) on the current perturbation buffers
@@ -1140,20 +1193,20 @@ static int bzi_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, c
     {
         ProfileScope ps(ctx, "acoustic_finalize");
         if (S.damping)
-            hipLaunchKernelGGL((k_ac_finalize<true>), rows, b256, 0, ctx->stream, g, F, S.P);
+            AC_LAUNCH(k_ac_finalize, true COMMA, rows, b256, F, S.P);
         else
-            hipLaunchKernelGGL((k_ac_finalize<false>), rows, b256, 0, ctx->stream, g, F, S.P);
+            AC_LAUNCH(k_ac_finalize, false COMMA, rows, b256, F, S.P);
     }
     {
         ProfileScope ps(ctx, "acoustic_recover");
         const long long per_level = (long long)g.Ny * g.Sx;
         dim3 grid((unsigned)((per_level + 255) / 256), g.Nz);
         if (moist && g.microphysics == 2)
-            hipLaunchKernelGGL((k_ac_recover<2>), grid, b256, 0, ctx->stream, g, F, beta * dt);
+            AC_LAUNCH(k_ac_recover, 2 COMMA, grid, b256, F, beta * dt);
         else if (moist)
-            hipLaunchKernelGGL((k_ac_recover<1>), grid, b256, 0, ctx->stream, g, F, beta * dt);
+            AC_LAUNCH(k_ac_recover, 1 COMMA, grid, b256, F, beta * dt);
         else
-            hipLaunchKernelGGL((k_ac_recover<0>), grid, b256, 0, ctx->stream, g, F, beta * dt);
+            AC_LAUNCH(k_ac_recover, 0 COMMA, grid, b256, F, beta * dt);
     }
     if (velocities) {
         ProfileScope ps(ctx, "acoustic_velocities");

@@ -329,6 +329,7 @@ struct bz_ctx {
     double *d_Clin = nullptr;         // centre array: gamma R_m * Pi of the current linearisation
     double *d_tfac_ac = nullptr;      // centre array: Thomas factors t_k of the acoustic column system (per stage)
     double *d_up2 = nullptr, *d_vp2 = nullptr;   // second buffers of the (rho u)', (rho v)' ping-pong (fused substep)
+    bool substep_f32 = false;         // substep_floattype = Float32 inside the Float64 library: the substepper's working fields are float arrays
     bool ac_fused = true;             // horizontal step folded into the forward column sweep (BZ_NO_AC_FUSE=1 disables)
     // DCMIP2016KesslerMicrophysics attached to the model (bz_set_kessler_microphysics)
     bz_kessler_microphysics kessler_params;

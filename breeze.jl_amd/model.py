@@ -106,11 +106,13 @@ class Field:
     """A device-resident Oceananigans-style field: `.parent` is the halo-inclusive array
     ((z, y, x)-shaped, x fastest), `.interior` a view of the interior."""
 
-    def __init__(self, grid, loc, device):
+    def __init__(self, grid, loc, device, float_type=None):
         import torch
         self.grid, self.loc = grid, loc
         self.zface = loc[2] is Face
-        self.dtype = torch.float32 if getattr(grid, "ftype", 8) == 4 else torch.float64
+        # float_type: CenterField(grid, FT) of another element type than eltype(grid) (the substepper's working fields)
+        ft = getattr(grid, "ftype", 8) if float_type is None else np.dtype(float_type).itemsize
+        self.dtype = torch.float32 if ft == 4 else torch.float64
         self.parent = torch.zeros(grid.parent_shape(self.zface), dtype=self.dtype, device=device)
 
     @property

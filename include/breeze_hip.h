@@ -306,6 +306,13 @@ typedef struct bz_split_explicit {
     int32_t substep_distribution;     /* stage substep counts and sizes (acoustic_substepping.jl:468-508): 0 ProportionalSubsteps (default:
                                          ceil(beta N) substeps tiling beta dt), 1 ConstantSubstepSize (N rounded up to a multiple of 6,
                                          round(beta N) substeps of dt / N), 2 MonolithicFirstStage (stage 1: one substep of dt / 3)          */
+    int32_t substep_float_bytes;      /* substep_floattype (acoustic_substepping.jl:199-235): storage type of the substepper's working fields
+                                         — exner, potential_temperature, gamma_R_mixture, density_perturbation,
+                                         density_potential_temperature_perturbation, momentum_perturbation_u / _v, density_predictor,
+                                         density_potential_temperature_predictor, previous_density_potential_temperature_perturbation —
+                                         0 = eltype(grid); 4 = Float32 (those ten pointers of bz_acoustic_substepper then address float arrays;
+                                         (rho w)', the solver's right-hand side and the time-averaged velocities stay eltype(grid)).
+                                         Single-device contexts, thermal or no divergence damping. */
 } bz_split_explicit;
 
 /* ExnerReferenceState columns (src/Thermodynamics/reference_states.jl:717-815): HOST arrays of length Nz+2Hz

@@ -205,6 +205,7 @@ struct BzSplitExplicit
     direct_divergence_damping::Int32; sponge_ramp::Int32          # ramp: 0 none, 1 LinearRamp, 2 CubicRamp, 3 Sin2Ramp
     sponge_damping_rate::Float64; sponge_depth::Float64
     substep_distribution::Int32                                   # 0 ProportionalSubsteps, 1 ConstantSubstepSize, 2 MonolithicFirstStage
+    substep_float_bytes::Int32                                    # 0: eltype(grid); 4: the substepper's working fields are Float32 arrays
 end
 distcode(::ProportionalSubsteps) = Int32(0)
 distcode(::ConstantSubstepSize) = Int32(1)
@@ -251,7 +252,8 @@ function create_compressible_context(model)
                          a.thermodynamic_tendency_factor, a.vertical_momentum_tendency_factor, solver.abstol,
                          damp isa DirectDivergenceDamping, rampcode(a.sponge),
                          a.sponge === nothing ? 0.0 : a.sponge.damping_rate, a.sponge === nothing ? 0.0 : a.sponge.depth,
-                         distcode(a.substep_distribution))
+                         distcode(a.substep_distribution),
+                         eltype(a.density_perturbation) === Float32 && eltype(grid) === Float64 ? Int32(4) : Int32(0))
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve zf p ρ begin
         g = BzGrid(Nx, Ny, Nz, Hx, Hy, Hz, map(topocode, topology(grid)), 8, grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, pointer(zf),

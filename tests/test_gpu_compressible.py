@@ -16,7 +16,7 @@ def oc(oracle):
 EXTENT = dict(x=(-4e3, 4e3), y=(-3e3, 3e3), z=(0.0, 8e3))
 
 
-def make_pair(oracle, oc, bz, size=(24, 16, 20), theta_ref=300.0, reference=True, z_faces=None, **td):
+def make_pair(oracle, oc, bz, size=(24, 16, 20), theta_ref=300.0, reference=True, z_faces=None, substep_floattype=None, **td):
     z = z_faces if z_faces is not None else EXTENT["z"]
     og = oracle.Grid(size, x=EXTENT["x"], y=EXTENT["y"], z=z)
     otd = oc.SplitExplicit(**td)
@@ -37,7 +37,7 @@ def make_pair(oracle, oc, bz, size=(24, 16, 20), theta_ref=300.0, reference=True
                                                                    "monolithic_first_stage": bz.MonolithicFirstStage}[otd.substep_distribution]())
     dyn = bz.CompressibleDynamics(btd, reference_potential_temperature=theta_ref if reference else None,
                                   reference_state="auto" if reference else None)
-    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5))
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), substep_floattype=substep_floattype)
     return om, hm
 
 
@@ -447,3 +447,55 @@ def test_substep_distributions_match_oracle(oracle, oc, bz, td):
         hm.time_step(2.0)
     cmp_interior(om, hm, ("rho_d", "rtheta", "ru", "rv", "rw", "T", "p"), 5e-9)
     assert om.last_substeps == [hm.stage_substeps(2.0, b)[0] for b in (1 / 3, 1 / 2, 1.0)]
+
+
+@pytest.mark.parametrize("td", [dict(substeps=6), dict(), dict(substeps=4, damping_coefficient=0.05, damp_vertical=True),
+                                dict(substeps=6, damping_coefficient=None), dict(substeps=6, sponge=(0.2, 3000.0, "cubic")),
+                                dict(substeps=8, substep_distribution="constant")])
+def test_float32_substep_storage_in_a_float64_model(oracle, oc, bz, td):
+    """substep_floattype = Float32 (acoustic_substepping.jl:199-235): the ten working fields of the substepper are float arrays, the
+    kernels read them, compute in Float64 and store Float32; everything else stays Float64.  Three steps of the six time-discretisation
+    variants against the Float64 oracle.  Tolerance 2e-6 of the field scale: a stored perturbation carries 6e-8 of its own size, the
+    linearisation arrays theta^L, gamma R^m Pi 6e-8 of theirs, accumulated over 3 steps x 3 stages x up to 18 substeps (measured: a
+    few 1e-7; the Float64-storage run of the same cases agrees to 5e-9).  And the path is exercised: the result differs from the
+    Float64-storage run by more than rounding."""
+    import torch
+    om, hm = make_pair(oracle, oc, bz, size=(24, 16, 24), substep_floattype=np.float32, **td)
+    _, h64 = make_pair(oracle, oc, bz, size=(24, 16, 24), **td)
+    sub = hm.timestepper.substepper
+    for name, _ in sub.FIELDS:
+        want = torch.float32 if name in sub.WORKING else torch.float64
+        assert getattr(sub, name).parent.dtype == want, name
+    assert hm.momentum["ρu"].parent.dtype == torch.float64
+    g = om.grid
+
+    def theta(x, y, z):
+        r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+        return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+    def qv(x, y, z):
+        return 5e-3 * np.exp(-z / 2e3) * (1 + 0.2 * np.sin(2 * np.pi * x / 8e3)) + 0 * y
+
+    rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    u0 = lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z
+    om.set(rho=rho, theta=theta, u=u0, v=0.0, w=0.0, qv=qv)
+    for m in (hm, h64):
+        m.set(ρ=rho, θ=theta, u=u0, v=0.0, w=0.0, qᵗ=qv)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+        h64.time_step(2.0)
+    worst = cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rv", "rw", "T", "p"), 2e-6)
+    print("float32 substep storage vs float64 oracle:", {k: f"{v:.1e}" for k, v in worst.items()})
+    diff = np.abs(hm.momentum["ρw"].interior_cpu() - h64.momentum["ρw"].interior_cpu()).max()
+    assert diff > 1e-12 * np.abs(h64.momentum["ρw"].interior_cpu()).max()
+
+
+def test_float32_substep_storage_is_rejected_where_it_is_not_built(bz):
+    grid = bz.RectilinearGrid((16, 16, 8), x=(0, 4e3), y=(0, 4e3), z=(0, 4e3))
+    dyn = lambda **kw: bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6, **kw), reference_potential_temperature=300.0)
+    with pytest.raises(Exception):      # DirectDivergenceDamping reads the working fields as the grid's real
+        bz.CompressibleAtmosphereModel(grid, dyn(damping=bz.DirectDivergenceDamping(coefficient=0.1)), advection=bz.WENO(), substep_floattype=np.float32)
+    with pytest.raises(NotImplementedError):
+        bz.CompressibleAtmosphereModel(bz.RectilinearGrid((16, 16, 8), x=(0, 4e3), y=(0, 4e3), z=(0, 4e3), float_type=np.float32), dyn(),
+                                       advection=bz.WENO(), substep_floattype=np.float64)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--substeps", type=int, default=0)
+    ap.add_argument("--substep-float32", action="store_true", help="substep_floattype = Float32 inside the Float64 model")
     ap.add_argument("--kessler", action="store_true",
                     help="BASELINE configs[4] physics: DCMIP2016 Kessler on the 168 km x 168 km x 20 km supercell box "
                          "(examples/splitting_supercell.jl:88-96), moist sounding + warm bubble")
@@ -45,7 +46,8 @@ def main():
     if a.kessler:
         mkw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
                    microphysics=bz.DCMIP2016KesslerMicrophysics())
-    m = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), **mkw)
+    import numpy as _np
+    m = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), substep_floattype=_np.float32 if a.substep_float32 else None, **mkw)
     c = m.thermodynamic_constants
     Rd, cpd, g = 8.314462618 / c.dry_air_molar_mass, c.dry_air_heat_capacity, c.gravitational_acceleration
     kap = Rd / cpd

@@ -226,6 +226,7 @@ struct BzComm {
     int W = 1, rank = 0, upper = 0, lower = 0;
     hipStream_t side = nullptr;                  // exchanges that overlap kernels of the main stream
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr};      // level chunks of the pipelined all-to-all (BZ_A2A_MAX_CHUNKS)
     bool overlap = true, halo_pending = false;
     bool self_messages = false;                  // BZ_COMM_SELF_MESSAGES=1: a single rank sends to itself through the transport (tests)
     // persistent buffers (device)
@@ -259,6 +260,7 @@ void bzi_comm_teardown(bz_ctx *ctx)
     for (double *b : bufs) if (b) hipFree(b);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->ev_side) hipEventDestroy(c->ev_side);
+    for (hipEvent_t e : c->ev_chunk) if (e) hipEventDestroy(e);
     if (c->side) hipStreamDestroy(c->side);
     delete c->T;
     delete c;
@@ -281,6 +283,7 @@ static int comm_attach(bz_ctx *ctx, Transport *T)
     BZ_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     BZ_HIP(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     BZ_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    for (hipEvent_t &e : c->ev_chunk) BZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (ctx->compressible) return BZ_OK;          // halo exchanges only: the acoustic column solve is rank-local
     const size_t nreal = (size_t)g.Nx * g.Ny * g.Nz;
     const int nxh = g.Nx / 2 + 1, nxh_pad = ctx->nkx * c->W;
@@ -415,22 +418,39 @@ extern "C" int bz_comm_exchange_y_halos(bz_ctx *ctx, double *const *fields, cons
 }
 
 // ---- distributed Fourier-tridiagonal solve: c->rhs (source term) -> c->rhs (zero-mean solution), all on the main stream ------------
-static int all_to_all(bz_ctx *ctx, const double *send, double *recv, size_t block_doubles)
+// part of every block: `count` doubles starting `offset` doubles into each of the W blocks (count = 0: whole blocks), on stream st
+static int all_to_all(bz_ctx *ctx, const double *send, double *recv, size_t block_doubles, size_t offset = 0, size_t count = 0,
+                      hipStream_t st = nullptr)
 {
     BzComm *c = ctx->comm;
-    const size_t bytes = block_doubles * sizeof(double);
+    if (!st) st = ctx->stream;
+    if (!count) count = block_doubles;
+    const size_t bytes = count * sizeof(double);
     const bool self = c->self_messages;
-    if (!self) BZ_HIP(hipMemcpyAsync(recv + block_doubles * c->rank, send + block_doubles * c->rank, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!self) BZ_HIP(hipMemcpyAsync(recv + block_doubles * c->rank + offset, send + block_doubles * c->rank + offset, bytes, hipMemcpyDeviceToDevice, st));
     if (c->W == 1 && !self) return BZ_OK;
     int rc = comm_fail(ctx, c->T->group_start(), "all-to-all");
     for (int p = 0; p < c->W && !rc; ++p)
-        if (p != c->rank || self) rc = comm_fail(ctx, c->T->send(send + block_doubles * p, bytes, p, ctx->stream), "all-to-all");
+        if (p != c->rank || self) rc = comm_fail(ctx, c->T->send(send + block_doubles * p + offset, bytes, p, st), "all-to-all");
     for (int p = 0; p < c->W && !rc; ++p)
-        if (p != c->rank || self) rc = comm_fail(ctx, c->T->recv(recv + block_doubles * p, bytes, p, ctx->stream), "all-to-all");
-    if (!rc) rc = comm_fail(ctx, c->T->group_end(ctx->stream), "all-to-all");
+        if (p != c->rank || self) rc = comm_fail(ctx, c->T->recv(recv + block_doubles * p + offset, bytes, p, st), "all-to-all");
+    if (!rc) rc = comm_fail(ctx, c->T->group_end(st), "all-to-all");
     c->bytes_sent += (long long)bytes * (c->W - 1);
     c->exchanges++;
     return rc;
+}
+
+// level chunks of the pipelined transposes: the x transforms walk 16 levels per block, so chunk edges are multiples of 16; columns
+// shorter than 64 levels go in one piece
+#define BZ_A2A_MAX_CHUNKS 4
+static int a2a_chunks(const DevGrid &g, int edges[BZ_A2A_MAX_CHUNKS + 1])
+{
+    int n = (g.Nz >= 64 && g.Nz % 16 == 0) ? BZ_A2A_MAX_CHUNKS : 1;
+    const int units = g.Nz / 16;
+    if (n > 1 && units < n) n = units;
+    edges[0] = 0;
+    for (int i = 1; i <= n; ++i) edges[i] = (n == 1) ? g.Nz : 16 * (int)(((long long)units * i) / n);
+    return n;
 }
 
 // With the hand-written x transforms (ctx->xf_slab, bz_xfft_kernels.h) the source term is evaluated inside the forward x pass, which
@@ -445,13 +465,34 @@ static int dist_poisson(bz_ctx *ctx, const bz_state *s, const bz_prognostic *pre
     const bool direct = (W == 1 && !c->self_messages);          // one rank: the packs write the transposed arrays in place
     int rc;
     if (ctx->xf_slab) {
-        {
+        // The all-to-all is pipelined with the x transforms in level chunks (a block of a message is (Nz, nkx, Ny): a level range is
+        // contiguous): chunk c's messages travel on the communication stream while the main stream transforms chunk c + 1, and on the
+        // way back chunk c is transformed while chunk c + 1 travels.  Only the first / last chunk's transform stays exposed.
+        int edges[BZ_A2A_MAX_CHUNKS + 1];
+        const int nch = direct ? 1 : a2a_chunks(g, edges);
+        const size_t lev_doubles = (size_t)nkx * g.Ny * 2;      // doubles per level of one block
+        if (direct) {
             ProfileScope ps(ctx, "poisson_source_term+fft_x");
-            if ((rc = bzi_xf_forward(ctx, s, dt, predictor, nullptr, direct ? c->spec : c->xsend, W))) return rc;
-        }
-        if (!direct) {
-            ProfileScope ps(ctx, "comm_all_to_all");
-            if ((rc = all_to_all(ctx, c->xsend, c->xrecv, blk))) return rc;
+            if ((rc = bzi_xf_forward(ctx, s, dt, predictor, nullptr, c->spec, W))) return rc;
+        } else {
+            for (int ch = 0; ch < nch; ++ch) {
+                {
+                    ProfileScope ps(ctx, "poisson_source_term+fft_x");
+                    if ((rc = bzi_xf_forward(ctx, s, dt, predictor, nullptr, c->xsend, W, edges[ch], edges[ch + 1]))) return rc;
+                }
+                BZ_HIP(hipEventRecord(c->ev_chunk[ch], ctx->stream));
+                BZ_HIP(hipStreamWaitEvent(c->side, c->ev_chunk[ch], 0));
+                hipStream_t keep = ctx->stream;
+                ctx->stream = c->side;
+                {
+                    ProfileScope ps(ctx, "comm_all_to_all");
+                    rc = all_to_all(ctx, c->xsend, c->xrecv, blk, lev_doubles * edges[ch], lev_doubles * (edges[ch + 1] - edges[ch]), c->side);
+                }
+                ctx->stream = keep;
+                if (rc) return rc;
+            }
+            BZ_HIP(hipEventRecord(c->ev_side, c->side));
+            BZ_HIP(hipStreamWaitEvent(ctx->stream, c->ev_side, 0));
             hipLaunchKernelGGL(k_concat_blocks, dim3(4096), dim3(256), 0, ctx->stream, (const double2 *)c->xrecv, (double2 *)c->spec,
                                (long long)g.Nz * nkx, g.Ny, W);                                            // (Nz, nkx, Ny_global)
             BZ_LAUNCH_CHECK();
@@ -467,11 +508,28 @@ static int dist_poisson(bz_ctx *ctx, const bz_state *s, const bz_prognostic *pre
                     BZ_HIP(hipMemcpy2DAsync(c->xsend + blk * q, rowb, c->spec + (size_t)q * g.Ny * 2, (size_t)NyG * 2 * sizeof(double), rowb,
                                             (size_t)g.Nz * nkx, hipMemcpyDeviceToDevice, ctx->stream));
             }
-            ProfileScope ps(ctx, "comm_all_to_all");
-            if ((rc = all_to_all(ctx, c->xsend, c->xrecv, blk))) return rc;
+            BZ_HIP(hipEventRecord(c->ev_main, ctx->stream));
+            BZ_HIP(hipStreamWaitEvent(c->side, c->ev_main, 0));
+            hipStream_t keep = ctx->stream;
+            ctx->stream = c->side;
+            for (int ch = 0; ch < nch && !rc; ++ch) {
+                {
+                    ProfileScope ps(ctx, "comm_all_to_all");
+                    rc = all_to_all(ctx, c->xsend, c->xrecv, blk, lev_doubles * edges[ch], lev_doubles * (edges[ch + 1] - edges[ch]), c->side);
+                }
+                if (!rc && hipEventRecord(c->ev_chunk[ch], c->side) != hipSuccess) rc = BZ_ERR_INVALID;
+            }
+            ctx->stream = keep;
+            if (rc) return rc;
+            for (int ch = 0; ch < nch; ++ch) {
+                BZ_HIP(hipStreamWaitEvent(ctx->stream, c->ev_chunk[ch], 0));
+                ProfileScope ps(ctx, "poisson_fft_x_inverse");
+                if ((rc = bzi_xf_inverse(ctx, c->xrecv, c->rhs, W, edges[ch], edges[ch + 1]))) return rc;
+            }
+            return BZ_OK;
         }
         ProfileScope ps(ctx, "poisson_fft_x_inverse");
-        return bzi_xf_inverse(ctx, direct ? c->spec : c->xrecv, c->rhs, W);
+        return bzi_xf_inverse(ctx, c->spec, c->rhs, W);
     }
     if ((rc = bzi_poisson_source_fused(ctx, s, dt, c->rhs, predictor))) return rc;
     if ((rc = bz_slab_transform(ctx, 0, c->rhs, c->hatx, 0))) return rc;                                  // (Nz, Ny, nxh)

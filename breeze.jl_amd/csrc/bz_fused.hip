@@ -308,16 +308,19 @@ static int xf_chunk(int forced, int dflt, const DevGrid &g)
 // x transform of the rows of the source term into the transposed half spectrum `hat` (nullptr: ctx->d_hat); predictor != nullptr
 // (or s != nullptr): the source term is evaluated on the fly from that momentum, else the rows come from rhs (nullptr: ctx->d_rhs).
 // blocks > 1 (y-slab ranks): `hat` is `blocks` messages of ctx->nkx wavenumbers each (XfLayout).
-int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor, const double *rhs, double *hat, int blocks)
+int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor, const double *rhs, double *hat, int blocks, int klo,
+                   int khi)
 {
     const DevGrid &g = ctx->dg;
+    if (khi <= 0) { klo = 0; khi = g.Nz; }      // whole column
     const int n2 = g.Nx / 2, kc = xf_chunk(ctx->tune.xf_kchunk_f, 16, g);
-    const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
+    const dim3 grid(g.Ny / XF_RB, (khi - klo + kc - 1) / kc), block(XF_RB * (n2 / 4));
     const size_t lds = xf_lds_bytes(n2);
     XfLayout L;
     L.nkx = blocks > 1 ? ctx->nkx : n2 + 1;
     L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;
     L.blk = (long long)g.Nz * L.nkx * g.Ny;
+    L.klo = klo; L.khi = khi;
     double2 *out = (double2 *)(hat ? hat : (double *)ctx->d_hat);
     const double *pu = predictor ? predictor->rho_u : s ? s->rho_u : nullptr, *pv = predictor ? predictor->rho_v : s ? s->rho_v : nullptr,
                  *pw = predictor ? predictor->rho_w : s ? s->rho_w : nullptr;
@@ -336,17 +339,19 @@ int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognosti
 }
 
 // inverse x transform of the transposed half spectrum `hat` (nullptr: ctx->d_hat; blocks as above): phi into `phi` (nullptr: ctx->d_rhs)
-int bzi_xf_inverse(bz_ctx *ctx, const double *hat, double *phi, int blocks)
+int bzi_xf_inverse(bz_ctx *ctx, const double *hat, double *phi, int blocks, int klo, int khi)
 {
     const DevGrid &g = ctx->dg;
+    if (khi <= 0) { klo = 0; khi = g.Nz; }
     const int n2 = g.Nx / 2, kc = xf_chunk(ctx->tune.xf_kchunk_i, 16, g);
     XfLayout L;
     L.nkx = blocks > 1 ? ctx->nkx : n2 + 1;
     L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;
     L.blk = (long long)g.Nz * L.nkx * g.Ny;
+    L.klo = klo; L.khi = khi;
     const double2 *in = (const double2 *)(hat ? hat : (const double *)ctx->d_hat);
     double *out = phi ? phi : ctx->d_rhs;
-    const dim3 grid(g.Ny / XF_RB, (g.Nz + kc - 1) / kc), block(XF_RB * (n2 / 4));
+    const dim3 grid(g.Ny / XF_RB, (khi - klo + kc - 1) / kc), block(XF_RB * (n2 / 4));
     const size_t lds = xf_lds_bytes(n2);
     if (n2 / 4 > 64) {
         static bool once = false;

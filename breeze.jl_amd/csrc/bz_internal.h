@@ -468,8 +468,8 @@ int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);
 int bzi_poisson_spectral(bz_ctx *ctx);
 int bzi_fft_chunk(bz_ctx *ctx, int k0, bool forward);
 int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor, const double *rhs = nullptr,
-                   double *hat = nullptr, int blocks = 1);
-int bzi_xf_inverse(bz_ctx *ctx, const double *hat = nullptr, double *phi = nullptr, int blocks = 1);
+                   double *hat = nullptr, int blocks = 1, int klo = 0, int khi = 0);      // khi = 0: all levels
+int bzi_xf_inverse(bz_ctx *ctx, const double *hat = nullptr, double *phi = nullptr, int blocks = 1, int klo = 0, int khi = 0);
 int bzi_xf_y(bz_ctx *ctx, bool forward);
 int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column);
 // fused streaming kernels (bz_fused.hip)

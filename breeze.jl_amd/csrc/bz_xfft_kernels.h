@@ -154,6 +154,7 @@ __device__ __forceinline__ void xf_split_inverse(double2 *__restrict__ row, int 
 struct XfLayout {
     int nkx, nxp;
     long long blk;       // elements (double2) per block
+    int klo, khi;        // level range of this launch (the slab driver pipelines level chunks with the all-to-all messages)
 };
 __device__ __forceinline__ long long xf_addr(const XfLayout &L, int Ny, int k, int kx, int row)
 {
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_forward(DevGrid g, const 
     for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
     __syncthreads();                                       // the twiddle table is loaded by all waves
     const int j0 = blockIdx.x * XF_RB, j = j0 + r;
-    const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    const int kbeg = L.klo + blockIdx.y * kchunk, kend = min(kbeg + kchunk, L.khi);
     double2 *__restrict__ row = xf_sm + r * RS;
     // y-slab: row Ny is the neighbour rank's first row, delivered into the halo by the caller's exchange
     const long long jp = (j + 1 < g.Ny || !g.wrap_y) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_inverse(DevGrid g, const 
     double2 *__restrict__ W = xf_sm + XF_RB * RS;
     for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
     const int j0 = blockIdx.x * XF_RB;
-    const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    const int kbeg = L.klo + blockIdx.y * kchunk, kend = min(kbeg + kchunk, L.khi);
     double2 *__restrict__ row = xf_sm + r * RS;
     for (int k = kbeg; k < kend; ++k) {
         for (int e = threadIdx.x; e < NXH * XF_RB; e += nthreads) {

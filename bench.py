@@ -63,6 +63,22 @@ WORDS_PER_CELL = {
     "poisson_fft_x+project_momentum": 9, "poisson_fft_x_inverse": 2,
 }
 A_STEP_WORDS = 250          # 3 stages x 80 + 10
+
+# Compulsory words per cell per launch of the FUSED kernels of the lean whole-step seam: every distinct 3-D array the kernel has to
+# read or write, once.  The contract figures above were written for the reference's unfused kernel list (a fused kernel inherits the
+# sum of what it replaces: 24 words for the scalar-pair kernel), so a fused kernel that got faster can exceed the 8 TB/s roof in
+# contract bytes (round 3: 1.02) — which says nothing.  `roofline.achieved` is therefore priced in compulsory bytes; the contract
+# figure is reported beside it (`contract_frac`), and `traffic` is what the counters saw.
+COMPULSORY_WORDS = {
+    "scalar_tendencies+rk3+thermo": 10,        # R rho_u, rho_v, rho_w, rho_theta, rho_q; U0 x 2 (read, or written in stage 1); W rho_theta, rho_q, T
+    "x_momentum_tendency+rk3+velocity": 5,     # R rho_u, rho_v, rho_w; U0; W predictor
+    "y_momentum_tendency+rk3+velocity": 5,
+    "z_momentum_tendency+rk3+velocity": 7,     # + R T, rho_q (buoyancy)
+    "project_momentum": 7, "project_and_diagnose": 18,
+    "poisson_source_term+fft_x": 4,            # R predictor rho_u, rho_v, rho_w; W half spectrum
+    "poisson_fft_y_forward": 2, "poisson_tridiagonal": 2, "poisson_fft_y_inverse": 2, "poisson_fft_x_inverse": 2,
+}
+A_STEP_COMPULSORY_WORDS = 3 * (10 + 5 + 5 + 7 + 4 + 2 + 2 + 2 + 2) + 2 * 7 + 18      # = 149 words per cell and step (lean seam)
 METRIC = "grid-cells advanced/sec (tendency+Poisson step), 512^3 anelastic"
 
 
@@ -670,8 +686,10 @@ def run_rank(args):
             if n:
                 kernels[name] = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
         dom = max((k for k in kernels if k in WORDS_PER_CELL), key=lambda k: kernels[k]["total_ms"])
-        dom_bytes = WORDS_PER_CELL[dom] * 8 * cells_rank
+        contract_bytes = WORDS_PER_CELL[dom] * 8 * cells_rank
+        dom_bytes = COMPULSORY_WORDS.get(dom, WORDS_PER_CELL[dom]) * 8 * cells_rank
         achieved = dom_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        contract_achieved = contract_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
         # HBM-side bytes per launch of that kernel group measured by rocprofv3 PMC passes (committed under profiles/,
         # collected at 512^3 on one GPU with the same build: a reference figure, not a measurement of this very run)
         traffic, traffic_src = None, None
@@ -686,7 +704,11 @@ def run_rank(args):
                     continue
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"]}
+                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"],
+                    "algorithmic_words_per_cell": COMPULSORY_WORDS.get(dom, WORDS_PER_CELL[dom]),
+                    "contract_words_per_cell": WORDS_PER_CELL[dom], "contract_achieved": contract_achieved,
+                    "contract_frac": contract_achieved / HBM_PEAK_GBS,
+                    "traffic_frac": (traffic / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}
         step_achieved = (cells_rank * args.steps / elapsed) * A_STEP_WORDS * 8 / 1e9
         kernel_ms = sum(v["total_ms"] for k, v in kernels.items() if not k.startswith("comm_")) / args.steps
         out = {
@@ -699,7 +721,9 @@ def run_rank(args):
             "roofline": roofline,
             "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": step_achieved / HBM_PEAK_GBS, "per": "GPU",
-                              "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 8},
+                              "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 8,
+                              "compulsory_bytes_per_cell_step": A_STEP_COMPULSORY_WORDS * 8,
+                              "compulsory_frac": (cells_rank * args.steps / elapsed) * A_STEP_COMPULSORY_WORDS * 8 / 1e9 / HBM_PEAK_GBS},
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(kernels.items())},
             "kernel_launches_per_step": {k: v["launches"] / args.steps for k, v in sorted(kernels.items())},
             "finite": finite,

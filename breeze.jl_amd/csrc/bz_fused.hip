@@ -326,7 +326,7 @@ int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognosti
                  *pw = predictor ? predictor->rho_w : s ? s->rho_w : nullptr;
     const double *rows = (s || predictor) ? nullptr : (rhs ? rhs : (const double *)ctx->d_rhs);
     const double2 *W = (const double2 *)ctx->d_wtab;
-    if (n2 / 4 > 64) {      // Nx = 1024: teams of two wavefronts, 78 KB of LDS per workgroup
+    if (n2 / 4 > 64 || n2 % 3 == 0) {      // Nx = 1024: teams of two wavefronts, 78 KB of LDS per workgroup; Nx = 3 * 2^m: teams of 12 ... 96 threads straddle wavefronts — workgroup barriers between the stages
         static bool once[2] = {false, false};
         if (!once[0]) { BZ_HIP(hipFuncSetAttribute((const void *)k_x_forward<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once[0] = true; }
         if (!once[1]) { BZ_HIP(hipFuncSetAttribute((const void *)k_x_forward<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once[1] = true; }
@@ -353,7 +353,7 @@ int bzi_xf_inverse(bz_ctx *ctx, const double *hat, double *phi, int blocks, int 
     double *out = phi ? phi : ctx->d_rhs;
     const dim3 grid(g.Ny / XF_RB, (khi - klo + kc - 1) / kc), block(XF_RB * (n2 / 4));
     const size_t lds = xf_lds_bytes(n2);
-    if (n2 / 4 > 64) {
+    if (n2 / 4 > 64 || n2 % 3 == 0) {
         static bool once = false;
         if (!once) { BZ_HIP(hipFuncSetAttribute((const void *)k_x_inverse<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
         hipLaunchKernelGGL(k_x_inverse<2>, grid, block, lds, ctx->stream, g, in, L, out, (const double2 *)ctx->d_wtab, kc);

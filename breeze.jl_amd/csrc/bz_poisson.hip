@@ -346,7 +346,8 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     const int nxh_real = Nx / 2 + 1;
     // hand-written x transforms + transposed spectrum: Nx a power of two in [16, 1024] (one team of Nx / 8 <= 128 threads per row, 8 rows per
     // workgroup in 45 KiB of LDS)
-    const bool xf_shape = Nx >= 16 && Nx <= 1024 && (Nx & (Nx - 1)) == 0 && g.Ny % 8 == 0 && !ctx->tune.no_xfft;
+    const bool pow2 = (Nx & (Nx - 1)) == 0, three_pow2 = Nx % 3 == 0 && ((Nx / 3) & (Nx / 3 - 1)) == 0;      // 96, 192, 384, 768: one radix-3 stage
+    const bool xf_shape = ((pow2 && Nx >= 16 && Nx <= 1024) || (three_pow2 && Nx >= 96 && Nx <= 768)) && g.Ny % 8 == 0 && !ctx->tune.no_xfft;
     ctx->xf = !slab && xf_shape && g.wrap_y;
     ctx->xf_slab = slab && xf_shape;
     int Ny = g.Ny;                       // rows of the spectral block: local rows, or ALL rows in slab mode

@@ -13,7 +13,8 @@
 //     in LDS, 4.0-4.4 ms with the previous level in registers — 168 VGPRs, one workgroup per CU — against 0.6 + 1.5 ms for this
 //     kernel followed by k_project_lean, so it was dropped; so was requesting level k+1 into registers before transforming level k:
 //     the extra registers cost a workgroup per CU and 10-20 % of the rate.)
-// Transform: Stockham autosort, radix-4 stages plus one radix-2 stage when log2(Nx/2) is odd, a team of Nx/8 threads per row,
+// Transform: Stockham autosort, radix-4 stages plus one radix-2 stage when log2(Nx/2) is odd (and a leading radix-3 stage for rows of
+// 3 * 2^m cells), a team of Nx/8 threads per row,
 // twiddles from a table in LDS (exp(-2 pi i t / Nx), t < 3 Nx / 4, computed on the host in the working precision).
 // Included by bz_fused.hip.
 #pragma once
@@ -56,7 +57,7 @@ __device__ __forceinline__ void xf_sync()
 
 __device__ __forceinline__ double2 xf_cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// In-place complex transform of length n2 (a power of two >= 8) of `row` by the team's T = n2 / 4 threads (tid = 0 .. T-1).
+// In-place complex transform of length n2 (a power of two >= 8, or 3 * 2^m >= 48) of `row` by the team's T = n2 / 4 threads (tid = 0 .. T-1).
 // Wave-level ordering only (xf_wave_sync): callers put a workgroup barrier where other waves' data is involved.
 // INV: conjugated twiddles (unnormalised inverse).
 template <bool INV, int TW = 1>
@@ -64,11 +65,45 @@ __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, i
 {
     const int T = n2 >> 2;
     int Ns = 1;
+    const bool r3 = (n2 % 3) == 0;
+    if (r3) {
+        // n2 = 3 * 2^m (rows of 96, 192, 384, 768 cells — 768 x 768 x 256 is one of the reference's three CI grids): one radix-3 stage
+        // first (Ns = 1, no twiddles): n2 / 3 = 4 T / 3 butterflies, thread tid takes butterfly tid and, if tid < T / 3, tid + T
+        const int M = n2 / 3;
+        const double S3 = 0.8660254037844386;      // sin(pi / 3)
+        double2 o[2][3];
+        bool has[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = tid + h * T;
+            has[h] = active && j < M;
+            o[h][0] = o[h][1] = o[h][2] = make_double2(0.0, 0.0);
+            if (has[h]) {
+                const double2 v0 = row[XF_P(j)], v1 = row[XF_P(j + M)], v2 = row[XF_P(j + 2 * M)];
+                const double2 t1 = make_double2(v1.x + v2.x, v1.y + v2.y);
+                const double2 t2 = make_double2(v0.x - 0.5 * t1.x, v0.y - 0.5 * t1.y);
+                const double2 t3 = make_double2(S3 * (v1.x - v2.x), S3 * (v1.y - v2.y));
+                const double2 lo = make_double2(t2.x + t3.y, t2.y - t3.x), hi = make_double2(t2.x - t3.y, t2.y + t3.x);      // t2 -/+ i t3
+                o[h][0] = make_double2(v0.x + t1.x, v0.y + t1.y);
+                o[h][1] = INV ? hi : lo;
+                o[h][2] = INV ? lo : hi;
+            }
+        }
+        xf_sync<TW>();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (has[h]) {
+                const int j = tid + h * T;
+                row[XF_P(3 * j)] = o[h][0]; row[XF_P(3 * j + 1)] = o[h][1]; row[XF_P(3 * j + 2)] = o[h][2];
+            }
+        xf_sync<TW>();
+        Ns = 3;
+    }
     for (; Ns * 4 <= n2; Ns <<= 2) {
         double2 o0 = make_double2(0.0, 0.0), o1 = o0, o2 = o0, o3 = o0;
         int j0 = 0;
         if (active) {
-            const int k = tid & (Ns - 1);
+            const int k = r3 ? tid % Ns : tid & (Ns - 1);
             double2 v0 = row[XF_P(tid)], v1 = row[XF_P(tid + T)], v2 = row[XF_P(tid + 2 * T)], v3 = row[XF_P(tid + 3 * T)];
             if (Ns > 1) {
                 const int tw = k * (n2 / (2 * Ns));

@@ -142,7 +142,8 @@ def test_time_steps_match_oracle(oracle, bz, size, dt):
     assert np.isfinite(hm.velocities["w"].cpu()).all()
 
 
-@pytest.mark.parametrize("size", [(16, 8, 6), (32, 16, 5), (64, 8, 12), (128, 24, 9), (256, 8, 4), (512, 8, 3), (1024, 8, 3)])
+@pytest.mark.parametrize("size", [(16, 8, 6), (32, 16, 5), (64, 8, 12), (128, 24, 9), (256, 8, 4), (512, 8, 3), (1024, 8, 3),
+                                  (96, 8, 6), (192, 16, 5), (384, 8, 4), (768, 8, 3)])      # 3 * 2^m: the leading radix-3 stage
 def test_fused_x_transform_pipeline_matches_oracle(oracle, bz, size):
     """Hand-written x transforms + transposed half spectrum (csrc/bz_xfft_kernels.h; taken when Nx is a power of two in [16, 1024]
     and Ny % 8 == 0): every radix mix (Nx/2 = 4^m and 2 * 4^m).  Per-operator solve (rows of the rhs buffer in, phi out) and whole

@@ -137,8 +137,12 @@ __global__ void __launch_bounds__(64) k_tridiag_solve(int NXH, int Ny, int Nz, c
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define TCO_COLS 8
 #define TCO_M 8
+// minimum waves per SIMD the register allocation must leave room for: 4 = two 512-thread workgroups per CU in Float64 (116 VGPRs as
+// compiled); the Float32 build holds half the bytes per value but compiled to 133 VGPRs without a bound — one workgroup per CU, and the
+// same 0.60 ms per launch as Float64 — so it asks for 6 (three workgroups, <= 85 VGPRs)
+#define TCO_MIN_WAVES 4
 template <int TCO_SEGS>
-__global__ void __launch_bounds__(TCO_COLS *TCO_SEGS) k_tridiag_coop(int NXH, int Ny, int Nz, int kx0, int nxh_real, int ky_fastest, TriCols C,
+__global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_coop(int NXH, int Ny, int Nz, int kx0, int nxh_real, int ky_fastest, TriCols C,
                                                                       double2 *__restrict__ hat, double scale, int mean_column)
 {
     __shared__ double sR[TCO_SEGS][TCO_COLS][6];      // g_f, h_f, g_l, cp_l of a segment; then sub / diag / sup of the reduced system

@@ -52,6 +52,12 @@ struct Lev5 {
 };
 static_assert(sizeof(LevRow5) == 8 * sizeof(double), "LevRow5 is eight reals");
 
+// Waves per SIMD the lean kernels are compiled for: 4 in Float64 (two 512-thread workgroups per CU, <= 128 VGPRs), 6 in the Float32
+// build (three workgroups, <= 80 VGPRs: a Float32 value is one register, and the Float32 kernels sat at 84-85 — allocated as 88,
+// i.e. five waves per SIMD = still two workgroups).  Measured at 512^3 Float32: scalar-pair kernel 2.04 -> 1.88 ms with three spilled
+// registers; the z-momentum kernel and the forcing variant of the y-momentum kernel spill eight and lose 7-13 %, so they keep the default.
+#define BZ_LEAN_WAVES (sizeof(double) == 8 ? 4 : 6)
+
 struct Lean5 {
     const double *ru, *rv, *rw;      // stage-start momentum (halos valid)
     const double *pa, *pb;           // stage-start rho theta, rho q (halos valid)
@@ -140,7 +146,7 @@ __device__ __forceinline__ double bz_temperature5r(const DevGrid &g, double rth,
 // shuffle + the batched out-of-wave flux, z stencils in register rings.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TY>
-__global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(4, 4))) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
+__global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN_WAVES, BZ_LEAN_WAVES))) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72;                 // tile rows, padded row length (70 used)
     constexpr int NHALO = TR * 70 - TY * 64;            // frame cells per field
@@ -375,7 +381,7 @@ __device__ __forceinline__ double flux_x_lean(const DevGrid &g, const Tend3Field
 // raw rho_v (TY+1) x 67; raw rho_w TY x 67 at the upper face; double-buffered).  Same arithmetic, same bits as k5_u.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TY, bool MF = false>      // MF: momentum terms of a forcing stack in the RK epilogue (Lean5::mforce)
-__global__ __launch_bounds__(64 * TY) void k6_u(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
+__global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY;
     constexpr int NH1 = TR * 70 - TY * 64;               // frame of the u tile (468 for TY = 8): one cell per thread
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(64 * TY) void k6_u(DevGrid g, Lean5 L, int kchunk, 
 // five column divisions; ring top and u0 are loaded one level ahead.  Same arithmetic, same bits as k5_v.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TY, bool MF = false>
-__global__ __launch_bounds__(64 * TY) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
+__global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles
     constexpr int TC = 72;                                // v tile with its x halo: columns i0-3 .. i0+65 at offset 3

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     bench, pmc = sys.argv[1], sys.argv[2]
-    from bench import WORDS_PER_CELL
+    from bench import COMPULSORY_WORDS, WORDS_PER_CELL
     b = json.load(open(bench))
     p = json.load(open(pmc))["per_kernel_group"]
     cells = 1
@@ -26,8 +26,11 @@ def main():
     print(f"Step: {b['ms_per_step']:.2f} ms, {b['value'] / 1e9:.3f} Gcells/s, step fraction of the 8 TB/s roofline at 2000 B/cell/step: "
           f"{b['step_roofline']['frac']:.3f}.  Source: `{os.path.basename(bench)}` (HIP events on the launch stream), "
           f"`{os.path.basename(pmc)}` (rocprofv3 PMC, HBM-side bytes per launch).\n")
-    print("| kernel group | launches/step | ms/step | ms/launch | algorithmic GB/launch | algorithmic TB/s | frac of 8 TB/s | PMC GB/launch | PMC TB/s |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print("Columns: `compulsory` = every distinct 3-D array the (fused) kernel must read or write, once — what `bench.py`'s `roofline.achieved` is priced in; "
+          "`contract` = SURVEY §8(d)'s words of the unfused kernel list the fused kernel replaces (the step figure of 250 words = 2000 B per cell and step); "
+          "`PMC` = bytes seen at the L2-fabric boundary (FETCH_SIZE / WRITE_SIZE passes).\n")
+    print("| kernel group | launches/step | ms/step | ms/launch | compulsory GB/launch | compulsory TB/s (frac of 8) | contract GB/launch | contract frac of 8 TB/s | PMC GB/launch | PMC TB/s (frac of 8) |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     tot = 0.0
     for name, ms in sorted(b["kernels_ms_per_step"].items(), key=lambda kv: -kv[1]):
         tot += ms
@@ -36,9 +39,12 @@ def main():
         w = WORDS_PER_CELL.get(name)
         alg = w * 8 * cells / 1e9 if w else None
         traffic = p.get(name, {}).get("hbm_bytes_per_launch")
+        cw = COMPULSORY_WORDS.get(name)
+        comp = cw * 8 * cells / 1e9 if cw else None
         row = [name, f"{n:g}", f"{ms:.2f}", f"{per_launch:.3f}",
-               f"{alg:.2f}" if alg else "—", f"{alg / per_launch:.2f}" if alg else "—", f"{alg / per_launch / 8:.3f}" if alg else "—",
-               f"{traffic / 1e9:.2f}" if traffic else "—", f"{traffic / 1e9 / per_launch:.2f}" if traffic else "—"]
+               f"{comp:.2f}" if comp else "—", f"{comp / per_launch:.2f} ({comp / per_launch / 8:.2f})" if comp else "—",
+               f"{alg:.2f}" if alg else "—", f"{alg / per_launch / 8:.3f}" if alg else "—",
+               f"{traffic / 1e9:.2f}" if traffic else "—", f"{traffic / 1e9 / per_launch:.2f} ({traffic / 1e9 / per_launch / 8:.2f})" if traffic else "—"]
         print("| " + " | ".join(row) + " |")
     print(f"\nSum of kernel time {tot:.2f} ms of the {b['ms_per_step']:.2f} ms step (the rest is launch gaps and two memsets).")
 

@@ -466,6 +466,7 @@ void bzi_lean_teardown(bz_ctx *ctx);
 void bzi_poisson_teardown(bz_ctx *ctx);
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt);
 int bzi_poisson_spectral(bz_ctx *ctx);
+int bzi_poisson_from_momentum(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor);
 int bzi_fft_chunk(bz_ctx *ctx, int k0, bool forward);
 int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor, const double *rhs = nullptr,
                    double *hat = nullptr, int blocks = 1, int klo = 0, int khi = 0);      // khi = 0: all levels

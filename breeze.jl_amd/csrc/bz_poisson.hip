@@ -536,6 +536,37 @@ int bzi_poisson_spectral(bz_ctx *ctx)
     return BZ_OK;
 }
 
+// compute_anelastic_source_term! + solve! from the momentum in `s` (predictor == nullptr) or from the predictor arrays, for the fused tiers
+// of the whole-step seam: with the hand-written x transforms the source term is evaluated inside the forward x pass (no rhs round trip,
+// as the lean seam does); otherwise source kernel + library transforms.  The zero-mean solution is left in ctx->d_rhs.
+int bzi_poisson_from_momentum(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognostic *predictor)
+{
+    const DevGrid &g = ctx->dg;
+    int rc;
+    if (ctx->xf && !ctx->pchunk) {
+        {
+            ProfileScope ps(ctx, "poisson_source_term+fft_x");
+            if ((rc = bzi_xf_forward(ctx, s, dt, predictor))) return rc;
+        }
+        {
+            ProfileScope ps(ctx, "poisson_fft_y_forward");
+            if ((rc = bzi_xf_y(ctx, true))) return rc;
+        }
+        {
+            ProfileScope ps(ctx, "poisson_tridiagonal");
+            if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1))) return rc;
+        }
+        {
+            ProfileScope ps(ctx, "poisson_fft_y_inverse");
+            if ((rc = bzi_xf_y(ctx, false))) return rc;
+        }
+        ProfileScope ps(ctx, "poisson_fft_x_inverse");
+        return bzi_xf_inverse(ctx);
+    }
+    if ((rc = bzi_poisson_source_fused(ctx, s, dt, nullptr, predictor))) return rc;
+    return bzi_poisson_spectral(ctx);
+}
+
 // solve_for_anelastic_pressure!(phi, solver, rhoU, dt)  (anelastic_pressure_solver.jl:84-88)
 int bzi_poisson_solve(bz_ctx *ctx, const bz_state *s, double dt)
 {

@@ -189,8 +189,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             }
             if ((ctx->has_forcings || ctx->has_bulk) &&
                 (rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
-            if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
-            if ((rc = bzi_poisson_spectral(ctx))) return rc;
+            if ((rc = bzi_poisson_from_momentum(ctx, s, alpha * dt, G))) return rc;
             // pressure_anomaly is a diagnostic nobody reads inside the step: only the last stage scatters it
             if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, stage == 2))) return rc;
             if ((rc = bzi_tracer_specific(ctx))) return rc;
@@ -209,8 +208,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             if ((rc = bzi_rk3_fused(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
             if (ctx->dg.microphysics == 2 && (rc = bzi_kessler_rk3(ctx, dt, alpha, stage == 0))) return rc;
             if ((rc = bzi_tracer_rk3(ctx, dt, alpha, stage == 0))) return rc;
-            if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt))) return rc;
-            if ((rc = bzi_poisson_spectral(ctx))) return rc;
+            if ((rc = bzi_poisson_from_momentum(ctx, s, alpha * dt, nullptr))) return rc;
             if ((rc = bzi_project_diagnose(ctx, s, alpha * dt))) return rc;
             if ((rc = bzi_tracer_specific(ctx))) return rc;
             if ((rc = bz_compute_tendencies(ctx, s, G))) return rc;

@@ -62,21 +62,33 @@ __device__ __forceinline__ double log_theta_v(const DevGrid &g, const double *ip
     return log(Rm / g.Rd * T[n] * ipi[k]);
 }
 
-__global__ void k_inverse_exner_column(DevGrid g, double *ipi)
+// ... and so does the filter width: delta2[k] = cbrt(dx dy dz_k)^2 (round 2 evaluated cbrt per cell)
+__global__ void k_inverse_exner_column(DevGrid g, double *ipi, double *delta2)
 {
-    for (int k = (int)threadIdx.x - 1; k <= g.Nz; k += blockDim.x) ipi[k] = pow(g.pst / g.p_r[k], g.Rd / g.cpd);
+    for (int k = (int)threadIdx.x - 1; k <= g.Nz; k += blockDim.x) {
+        ipi[k] = pow(g.pst / g.p_r[k], g.Rd / g.cpd);
+        if (k < 0 || k >= g.Nz) continue;
+        const double delta = cbrt(g.dx * g.dy * g.dzc[k]);
+        delta2[k] = delta * delta;
+    }
 }
 
+// A workgroup walks `kchunk` levels of its row: log(theta_v) of a cell enters N^2 of three levels, and the march evaluates it once (ring of
+// three) instead of three times — the logarithm is the most expensive thing in this kernel.
+#define SMAG_KCHUNK 1      // 8 measured slower (0.36 -> 0.46 ms at 256x256x128 Float32): the strain loads bound this kernel, not the logarithms
 __global__ __launch_bounds__(256) void k_smagorinsky_viscosity(DevGrid g, ClosureFields F, const double *__restrict__ T,
                                                                const double *__restrict__ qv, const double *__restrict__ ipi,
-                                                               double *__restrict__ nu)
+                                                               const double *__restrict__ delta2, double *__restrict__ nu)
 {
     int bx, by, bz;
     xcd_block(bx, by, bz);
-    const int i = bx * 256 + threadIdx.x, j = by + F.jofs, k = bz;
+    const int i = bx * 256 + threadIdx.x, j = by + F.jofs, kbeg = bz * SMAG_KCHUNK, kend = min(kbeg + SMAG_KCHUNK, g.Nz);
     if (i >= g.Nx) return;
-    const long long n = g.idx(i, j, k), sx = 1, sy = g.Sx, sz = g.Sxy;
+    const long long sx = 1, sy = g.Sx, sz = g.Sxy;
     const double *u = F.u, *v = F.v, *w = F.w;
+    long long n = g.idx(i, j, kbeg);
+    double lm = log_theta_v(g, ipi, T, qv, n - sz, kbeg - 1), lc = log_theta_v(g, ipi, T, qv, n, kbeg);
+    for (int k = kbeg; k < kend; ++k, n += sz) {
     const double s11 = S11(g, u, n), s22 = S22(g, v, n), s33 = S33(g, w, n, k);
     auto sq = [](double a) { return a * a; };
     // a Flat y direction (Ny = 1, no halo rows, 1/dy stored as 0): the corners at j and j + 1 coincide
@@ -89,13 +101,14 @@ __global__ __launch_bounds__(256) void k_smagorinsky_viscosity(DevGrid g, Closur
                         (sq(S23(g, v, w, n + sz, k + 1)) + sq(S23(g, v, w, n + sz + cy, k + 1))) / 2) / 2;
     const double Sig2 = (s11 * s11 + s22 * s22 + s33 * s33) + 2 * a12 + 2 * a13 + 2 * a23;
     // N^2: T, q^v carry no-flux z halos, the reference pressure column its own first halo cell
-    const double lm = log_theta_v(g, ipi, T, qv, n - sz, k - 1), lc = log_theta_v(g, ipi, T, qv, n, k), lp = log_theta_v(g, ipi, T, qv, n + sz, k + 1);
+    const double lp = log_theta_v(g, ipi, T, qv, n + sz, k + 1);
     const double bdn = g.g * ((lc - lm) * g.rdzf[k]), bup = g.g * ((lp - lc) * g.rdzf[k + 1]);
     const double N2 = (bdn + bup) / 2;
     const double N2p = fmax(0.0, N2);
     const double stab = (Sig2 == 0.0) ? 0.0 : sqrt(1.0 - fmin(1.0, F.Cb * N2p / Sig2));
-    const double delta = cbrt(g.dx * g.dy * g.dzc[k]);
-    nu[n] = (stab * F.C2) * (delta * delta) * sqrt(2 * Sig2);
+    nu[n] = (stab * F.C2) * delta2[k] * sqrt(2 * Sig2);
+    lm = lc; lc = lp;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFields F, double *__restrict__ Gu,
@@ -223,8 +236,8 @@ extern "C" int bz_set_closure(bz_ctx *ctx, const bz_smagorinsky_lilly *closure, 
     if (ctx->dg.Hx < 1 || (ctx->dg.Hy < 1 && !ctx->dg.flat_y) || ctx->dg.Hz < 1) { ctx->last_error = "bz_set_closure: needs halos >= 1"; return BZ_ERR_UNSUPPORTED; }
     ctx->closure = *closure;
     ctx->closure_nu = eddy_viscosity;
-    if (!ctx->d_closure_ipi) BZ_HIP(hipMalloc(&ctx->d_closure_ipi, (size_t)(ctx->dg.Nz + 2) * sizeof(double)));
-    hipLaunchKernelGGL(k_inverse_exner_column, dim3(1), dim3(256), 0, ctx->stream, ctx->dg, ctx->d_closure_ipi + 1);
+    if (!ctx->d_closure_ipi) BZ_HIP(hipMalloc(&ctx->d_closure_ipi, (size_t)2 * (ctx->dg.Nz + 2) * sizeof(double)));      // ipi, delta2: Nz + 2 entries each
+    hipLaunchKernelGGL(k_inverse_exner_column, dim3(1), dim3(256), 0, ctx->stream, ctx->dg, ctx->d_closure_ipi + 1, ctx->d_closure_ipi + (ctx->dg.Nz + 2) + 1);
     BZ_LAUNCH_CHECK();
     ctx->has_closure = true;
     return BZ_OK;
@@ -252,8 +265,8 @@ extern "C" int bz_compute_closure_fields(bz_ctx *ctx, const bz_state *s)
     ClosureFields F = closure_fields(ctx, s);
     // y-slabs: one more row on each side (u, v, w, T, q^v carry Hy >= 2 exchanged rows there), so nu_e needs no exchange of its own
     F.jofs = ctx->slab_mode ? -1 : 0;
-    hipLaunchKernelGGL(k_smagorinsky_viscosity, dim3((g.Nx + 255) / 256, g.Ny + (ctx->slab_mode ? 2 : 0), g.Nz), dim3(256), 0, ctx->stream, g,
-                       F, s->T, qv, ctx->d_closure_ipi + 1, ctx->closure_nu);
+    hipLaunchKernelGGL(k_smagorinsky_viscosity, dim3((g.Nx + 255) / 256, g.Ny + (ctx->slab_mode ? 2 : 0), (g.Nz + SMAG_KCHUNK - 1) / SMAG_KCHUNK),
+                       dim3(256), 0, ctx->stream, g, F, s->T, qv, ctx->d_closure_ipi + 1, ctx->d_closure_ipi + (g.Nz + 2) + 1, ctx->closure_nu);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -699,7 +699,7 @@ __device__ __forceinline__ double buoyancy5(const DevGrid &g, double T, double r
 // own column rides a register delay line (advecting-flux ring and RK update).  Same arithmetic, same bits as k5_w.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TY>
-__global__ __launch_bounds__(64 * TY) void k6_w(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
+__global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY, NH = TR * 70 - TY * 64;
     static_assert(NH <= NT, "one frame cell per thread");

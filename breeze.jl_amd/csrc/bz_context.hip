@@ -218,6 +218,10 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     ctx->y_rank = y_rank;
     ctx->slab_mode = slab_mode;
     ctx->Ny_global = grid->Ny * y_nranks;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ctx->num_cus = cus;
+    }
 
     const int Nx = grid->Nx, Ny = grid->Ny, Nz = grid->Nz, Hz = grid->Hz;
     const int nc = Nz + 2 * Hz, nf = Nz + 1 + 2 * Hz;

@@ -273,6 +273,7 @@ struct bz_ctx {
     bz_constants constants;
     DevGrid dg;
     hipStream_t stream = nullptr;
+    int num_cus = 256;                // compute units of the device (persistent-workgroup launches size their grids with it)
     std::string last_error;
 
     // column tables (one device allocation)

@@ -140,39 +140,95 @@ __global__ void __launch_bounds__(64) k_tridiag_solve(int NXH, int Ny, int Nz, c
 // minimum waves per SIMD the register allocation must leave room for: 4 = two 512-thread workgroups per CU in Float64 (116 VGPRs as
 // compiled); the Float32 build holds half the bytes per value but compiled to 133 VGPRs without a bound — one workgroup per CU, and the
 // same 0.60 ms per launch as Float64 — so it asks for 6 (three workgroups, <= 85 VGPRs)
-#define TCO_MIN_WAVES 4
-template <int TCO_SEGS>
+#define TCO_MIN_WAVES 2
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over every address space: hipcc then waits
+// for the global stores of the previous column group before it lets the next group's arithmetic start (s_waitcnt vmcnt(10) in the loop
+// of k_tridiag_coop), i.e. the store drain of every group is exposed.  Every barrier of that kernel protects LDS exchange buffers.
+__device__ __forceinline__ void tco_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// M rows per segment held in registers; EXACT: Nz == TCO_SEGS * M and the plane is a whole number of column groups, so every thread
+// holds exactly M rows of a real column (no row or column predicates: straight-line loads and stores, whose completion the in-order
+// memory counter can be waited on precisely — behind a predicate the compiler waits for everything outstanding, which drained every
+// store of a group before the next group's loads could be used)
+template <int TCO_SEGS, int M, bool EXACT>
 __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_coop(int NXH, int Ny, int Nz, int kx0, int nxh_real, int ky_fastest, TriCols C,
-                                                                      double2 *__restrict__ hat, double scale, int mean_column)
+                                                                      double2 *__restrict__ hat, double scale, int mean_column, int ngroups)
 {
     __shared__ double sR[TCO_SEGS][TCO_COLS][6];      // g_f, h_f, g_l, cp_l of a segment; then sub / diag / sup of the reduced system
     __shared__ double2 sD[TCO_SEGS][TCO_COLS][2];     // dp_f, dp_l; then [0] = X_s
     __shared__ double sSum[TCO_SEGS];
+    // column coefficients of every level, staged once per workgroup: read through LDS they stay off the vector-memory counter, which
+    // returns in order — a coefficient load issued after the next group's rows would make its wait a wait for those rows as well
+    __shared__ double sLow[TCO_SEGS * M + 1], sDiag[TCO_SEGS * M], sMass[TCO_SEGS * M];      // sLow[k] = lower[k - 1], 0 at both ends
     const int t = threadIdx.x, cc = t & (TCO_COLS - 1), s = t >> 3;
+    for (int k = t; k <= Nz; k += TCO_COLS * TCO_SEGS) {
+        sLow[k] = (k > 0 && k < Nz) ? C.lower[k - 1] : 0.0;
+        if (k < Nz) { sDiag[k] = C.diag0[k]; sMass[k] = C.mass[k]; }
+    }
+    tco_lds_barrier();
     const long long plane = (long long)NXH * Ny;
-    const long long c = (long long)blockIdx.x * TCO_COLS + cc;
-    const bool live = c < plane;                                         // ragged last block (2-D grids: plane = Nx/2 + 1 columns)
-    const int kx = ky_fastest ? (int)(c / Ny) : (int)(c % NXH), ky = ky_fastest ? (int)(c % Ny) : (int)(c / NXH);
+    const int q = Nz / TCO_SEGS, r = Nz % TCO_SEGS;
+    const int L = EXACT ? M : q + (s < r ? 1 : 0), k0 = EXACT ? s * M : s * q + min(s, r);
+    // A workgroup walks column groups grp = blockIdx.x, + gridDim.x, ... and requests the rows of its NEXT group before it starts on the
+    // current one: with one group per workgroup (round 2) the two workgroups of a CU drifted into the same phase — both waiting for
+    // their loads, then both in the dependent elimination chains — and the kernel took load time + arithmetic time (0.57 ms at 512^3
+    // for 2.15 GB).  The loads of the next group now fly under the ~550 instructions of the current one.
+    double2 dpn[M];
+    double lxn, lyn;                                                     // lam_x, lam_y of the next group's column, fetched with its rows (unconditional
+    auto lam_of = [&](long long c, double &lx, double &ly) {             // clamped loads, added where they are used: nothing here waits)
+        const unsigned cu = (unsigned)min(c, plane - 1), den = (unsigned)(ky_fastest ? Ny : NXH), quo = cu / den, rem = cu - quo * den;      // plane < 2^31
+        const int kx = ky_fastest ? (int)quo : (int)rem, ky = ky_fastest ? (int)rem : (int)quo;
+        lx = C.lam_x[min(kx0 + kx, nxh_real - 1)];
+        ly = C.lam_y[ky];
+    };
+    {
+        const long long c = (long long)blockIdx.x * TCO_COLS + cc;
+        lam_of(c, lxn, lyn);
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            if constexpr (EXACT) dpn[j] = hat[c + plane * (k0 + j)];
+            else if (j < L) dpn[j] = (c < plane) ? hat[c + plane * (k0 + j)] : make_double2(0.0, 0.0);
+        }
+    }
+    auto trip = [&](const int grp) {
+    const long long c = (long long)grp * TCO_COLS + cc;
+    const bool live = EXACT || c < plane;                                // ragged last block (2-D grids: plane = Nx/2 + 1 columns)
+    const unsigned den = (unsigned)(ky_fastest ? Ny : NXH), quo = (unsigned)c / den;
+    const int kx = ky_fastest ? (int)quo : (int)((unsigned)c - quo * den);
     const bool padding = (kx0 + kx >= nxh_real) || !live;
     const bool pinned = mean_column && c == 0;                           // the (0, 0) column of the whole spectrum lives here
-    const double lam = padding ? 0.0 : C.lam_x[kx0 + kx] + C.lam_y[ky];
-    const int q = Nz / TCO_SEGS, r = Nz % TCO_SEGS;
-    const int L = q + (s < r ? 1 : 0), k0 = s * q + min(s, r);
-    double2 dp[TCO_M];
-    double g[TCO_M], h[TCO_M];
+    const double lam = padding ? 0.0 : lxn + lyn;
+    double2 dp[M];
+    double g[M], h[M];
     double2 *col = hat + c;
 #pragma unroll
-    for (int j = 0; j < TCO_M; ++j)
-        if (j < L) dp[j] = live ? col[plane * (k0 + j)] : make_double2(0.0, 0.0);
+    for (int j = 0; j < M; ++j) dp[j] = dpn[j];
+    if constexpr (EXACT) {                                               // the last trip re-reads its own group (in bounds, unused)
+        const long long cn = (grp + (int)gridDim.x < ngroups) ? c + (long long)gridDim.x * TCO_COLS : c;
+        lam_of(cn, lxn, lyn);
+#pragma unroll
+        for (int j = 0; j < M; ++j) dpn[j] = hat[cn + plane * (k0 + j)];
+    } else if (grp + (int)gridDim.x < ngroups) {                         // block-uniform
+        const long long cn = c + (long long)gridDim.x * TCO_COLS;
+        lam_of(cn, lxn, lyn);
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            if (j < L) dpn[j] = (cn < plane) ? hat[cn + plane * (k0 + j)] : make_double2(0.0, 0.0);
+    }
     // ---- A: local forward elimination ----
     double cp_prev = 0.0, g_prev = 0.0;
     double2 d_prev = make_double2(0.0, 0.0);
 #pragma unroll
-    for (int j = 0; j < TCO_M; ++j) {
+    for (int j = 0; j < M; ++j) {
         if (j < L) {
             const int k = k0 + j;
-            double a = (k > 0) ? C.lower[k - 1] : 0.0, cu = (k < Nz - 1) ? C.lower[k] : 0.0;
-            double b = C.diag0[k] - C.mass[k] * lam;
+            double a = sLow[k], cu = sLow[k + 1];
+            double b = sDiag[k] - sMass[k] * lam;
             double2 d = make_double2(dp[j].x * scale, dp[j].y * scale);
             if (pinned && k == Nz - 1) { a = 0.0; b = 1.0; cu = 0.0; d = make_double2(0.0, 0.0); }
             if (padding) { a = 0.0; b = 1.0; cu = 0.0; d = make_double2(0.0, 0.0); }
@@ -193,7 +249,7 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
     // ---- B: local backward elimination towards the last unknown (row L-1 keeps its coupling cp to the next segment) ----
     const double cp_l = cp_prev;                       // cp of the last row
 #pragma unroll
-    for (int j = TCO_M - 3; j >= 0; --j) {
+    for (int j = M - 3; j >= 0; --j) {
         if (j <= L - 3) {
             const double cpk = h[j];
             dp[j].x -= cpk * dp[j + 1].x;
@@ -208,12 +264,12 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
         double gl = 0.0;
         double2 dl = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int j = 0; j < TCO_M; ++j)
+        for (int j = 0; j < M; ++j)
             if (j == L - 1) { gl = g[j]; dl = dp[j]; }
         sR[s][cc][0] = g[0]; sR[s][cc][1] = h[0]; sR[s][cc][2] = gl; sR[s][cc][3] = cp_l;
         sD[s][cc][0] = dp[0]; sD[s][cc][1] = dl;
     }
-    __syncthreads();
+    tco_lds_barrier();
     // Parallel cyclic reduction over the TCO_SEGS reduced unknowns of a column, one thread per unknown (the threads of a column are
     // t = s * 8 + cc).  Rows are kept normalised, a X_{m-h} + X_m + c X_{m+h} = d; one step with stride h eliminates both neighbours:
     //   r = 1 / (1 - a c_{m-h} - c a_{m+h}),  a' = -a a_{m-h} r,  c' = -c c_{m+h} r,  d' = (d - a d_{m-h} - c d_{m+h}) r
@@ -237,7 +293,7 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
         pa = glm * r; pc = sup * r;
         pd = make_double2(rhs.x * r, rhs.y * r);
     }
-    __syncthreads();                                   // sR / sD are read; their storage becomes the two exchange buffers
+    tco_lds_barrier();                                   // sR / sD are read; their storage becomes the two exchange buffers
     constexpr int NT = TCO_SEGS * TCO_COLS;
     static_assert(sizeof(sR) >= 4 * NT * sizeof(double) && sizeof(sD) >= 4 * NT * sizeof(double), "exchange buffers alias sR / sD");
     double *xb[2] = {&sR[0][0][0], (double *)&sD[0][0][0]};
@@ -246,7 +302,7 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
     for (int h = 1; h < TCO_SEGS; h <<= 1) {
         double *B = xb[pb];
         B[t] = pa; B[NT + t] = pc; B[2 * NT + t] = pd.x; B[3 * NT + t] = pd.y;
-        __syncthreads();
+        tco_lds_barrier();
         const int tm = t - h * TCO_COLS, tp = t + h * TCO_COLS;
         double am = 0.0, cm = 0.0, ap = 0.0, cp = 0.0;
         double2 dm = make_double2(0.0, 0.0), dq = make_double2(0.0, 0.0);
@@ -265,12 +321,12 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
     {
         double *B = xb[pb];
         B[2 * NT + t] = pd.x; B[3 * NT + t] = pd.y;
-        __syncthreads();
+        tco_lds_barrier();
         if (s > 0) Xp = make_double2(B[2 * NT + t - TCO_COLS], B[3 * NT + t - TCO_COLS]);
     }
     double sum = 0.0;
 #pragma unroll
-    for (int j = 0; j < TCO_M; ++j) {
+    for (int j = 0; j < M; ++j) {
         if (j < L) {
             if (j == L - 1) dp[j] = Xs;
             else {
@@ -280,21 +336,31 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
             sum += dp[j].x;
         }
     }
-    if (mean_column && blockIdx.x == 0) {       // block-uniform branch: the global mean of phi is the z-mean of the (0, 0) column
+    if (mean_column && grp == 0) {       // block-uniform branch: the global mean of phi is the z-mean of the (0, 0) column
         if (cc == 0) sSum[s] = sum;
-        __syncthreads();
+        tco_lds_barrier();
         double tot = 0.0;
         for (int m = 0; m < TCO_SEGS; ++m) tot += sSum[m];
         if (cc == 0) {
             const double mean = tot / Nz;
 #pragma unroll
-            for (int j = 0; j < TCO_M; ++j)
+            for (int j = 0; j < M; ++j)
                 if (j < L) dp[j].x -= mean;
         }
     }
 #pragma unroll
-    for (int j = 0; j < TCO_M; ++j)
+    for (int j = 0; j < M; ++j)
         if (j < L && live) col[plane * (k0 + j)] = dp[j];
+    tco_lds_barrier();                                   // the exchange buffers are rewritten by the next group
+    };
+    // EXACT: the first group runs outside the loop.  The memory counter returns in order and the compiler derives its waits from what
+    // may be outstanding on ANY path into a point: entered straight from the prologue the loop head would see "rows still loading,
+    // no stores behind them" on one path and "rows + 8 stores" on the other, and settle for waits that drain the stores of the
+    // previous group in every trip (s_waitcnt vmcnt(17..10) through phase A).  Peeled, both paths into the head look alike.
+    int grp = blockIdx.x;
+    if constexpr (EXACT) { trip(grp); grp += gridDim.x; }
+#pragma nounroll
+    for (; grp < ngroups; grp += gridDim.x) trip(grp);
 }
 
 // segments per column: 64 for 128 <= Nz <= 512 (the tuned shape), 16 / 8 for shorter columns, where the sequential kernel's
@@ -318,14 +384,21 @@ int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_
         double *d_cols = ctx->d_lower;
         const int Nz = ctx->dg.Nz;
         TriCols C{d_cols, d_cols + Nz, d_cols + 2 * Nz, d_cols + 3 * Nz, d_cols + 3 * Nz + nxh_real};
-        const dim3 grid((unsigned)((plane + TCO_COLS - 1) / TCO_COLS)), block(TCO_COLS * segs);
+        const int ngroups = (int)((plane + TCO_COLS - 1) / TCO_COLS);
+        // 64 segments = 512 threads: two workgroups per CU resident, each walks ngroups / grid column groups (a multiple of the grid keeps the tail short)
+        const int resident = (TCO_MIN_WAVES / 2) * ctx->num_cus * (segs == 64 ? 1 : 64 / segs);
+        const int per_block = (ngroups + resident - 1) / resident;
+        const dim3 grid((unsigned)((ngroups + per_block - 1) / per_block)), block(TCO_COLS * segs);
         const int kyf = (ctx->slab_mode || ctx->xf) ? 1 : 0;
-        if (segs == 64)
-            hipLaunchKernelGGL(k_tridiag_coop<64>, grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column);
-        else if (segs == 16)
-            hipLaunchKernelGGL(k_tridiag_coop<16>, grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column);
-        else
-            hipLaunchKernelGGL(k_tridiag_coop<8>, grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column);
+#define TCO_GO(SEGS, M, EXACT) hipLaunchKernelGGL((k_tridiag_coop<SEGS, M, EXACT>), grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column, ngroups)
+        const bool whole = plane % TCO_COLS == 0;
+        if (segs == 64 && Nz == 64 * 8 && whole) TCO_GO(64, 8, true);
+        else if (segs == 64 && Nz == 64 * 4 && whole) TCO_GO(64, 4, true);
+        else if (segs == 64 && Nz == 64 * 2 && whole) TCO_GO(64, 2, true);
+        else if (segs == 64) TCO_GO(64, TCO_M, false);
+        else if (segs == 16) TCO_GO(16, TCO_M, false);
+        else TCO_GO(8, TCO_M, false);
+#undef TCO_GO
     } else {
         hipLaunchKernelGGL(k_tridiag_solve, dim3((unsigned)((plane + 63) / 64)), dim3(64), 0, ctx->stream, ctx->NXH, Ny, ctx->dg.Nz,
                            ctx->d_lower, ctx->d_ibeta, ctx->d_tfac, (double2 *)hat, scale, mean_column);

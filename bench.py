@@ -297,6 +297,74 @@ def cbl_run(args, bz, device):
     return 0
 
 
+def tendency_run(args, bz, device):
+    """--workload scalar_tendency | model_tendency: the reference's tendency micro-benchmarks (BASELINE.md row 4;
+    .github/workflows/Benchmarks.yml:88-109: 256x256x128, Float32, WENO 5 / 7 / 9, 320 repeats).
+      scalar_tendency  benchmarking/src/scalar_tendency.jl:16-61 — one launch of Gc = -div_Uc(c) with U = (1, 0, 0),
+                       c = sin(2 pi x) sin(2 pi y) on a unit box, halo = cld(order + 1, 2); here bz_compute_scalar_tendency of the
+                       anelastic model on the same box (the reference density of a 1 m deep box is constant to 1e-4).
+      model_tendency   benchmarking/src/model_tendency.jl:25-45 — compute_tendencies!(model) of a CompressibleDynamics model at rest
+                       (theta = 300, rho = 1) on a 1 km box; here bz_compute_slow_tendencies.
+    The metric is the reference's grid_points_per_second of one evaluation (tendency_profiling.jl:37-124)."""
+    import torch
+    Nx, Ny, Nz = (int(v) for v in args.tend_size.lower().split("x"))
+    f32 = not args.tend_float64
+    ft = np.float32 if f32 else np.float64
+    order = args.tend_order
+    h = max(3, (order + 2) // 2)      # cld(order + 1, 2); this library's kernels want >= 3
+    scalar = args.workload == "scalar_tendency"
+    L = 1.0 if scalar else 1e3
+    grid = bz.RectilinearGrid((Nx, Ny, Nz), x=(0, L), y=(0, L), z=(0, L), halo=(h, h, h), float_type=ft)
+    if scalar:
+        m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)),
+                               advection=bz.WENO(order=order), device=device)
+        m.velocities["u"].parent.fill_(1.0)
+        ccc = (bz.Center, bz.Center, bz.Center)
+        c, Gc = bz.Field(grid, ccc, device), bz.Field(grid, ccc, device)
+        c.set_interior(lambda x, y, z: np.sin(2 * np.pi * x) * np.sin(2 * np.pi * y) + 0 * z)
+        bz.fill_halo_regions_(m, c)
+        run = lambda: bz.compute_scalar_tendency_(m, c, Gc)      # noqa: E731
+        words, kernel = 5, "scalar_tendency"      # u, v, w, c read; Gc written
+        finite = lambda: bool(torch.isfinite(Gc.interior).all().item())      # noqa: E731
+    else:
+        dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), surface_pressure=1e5, reference_potential_temperature=300.0)
+        m = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=order), device=device)
+        m.set(ρ=1.0, θ=300.0, u=0.0, v=0.0, w=0.0, qᵗ=0.0)
+        run = lambda: bz.compressible.compute_slow_tendencies_(m)      # noqa: E731
+        words, kernel = None, "compute_slow_tendencies"
+        finite = lambda: True      # noqa: E731
+    for _ in range(max(1, args.warmup)):
+        run()
+    m.profile_reset()
+    m.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    m.profile_enable(False)
+    cells, word = Nx * Ny * Nz, 4 if f32 else 8
+    kernels = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms} for k, (ms, n) in m.profile().items() if n}
+    roofline = None
+    if words and kernel in kernels:
+        nbytes = words * word * cells
+        achieved = nbytes / (kernels[kernel]["avg_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": kernels[kernel]["avg_ms"]}
+    out = {"metric": f"grid points per second, one {'scalar tendency' if scalar else 'compute_tendencies!'} evaluation (BreezeBenchmarks {args.workload})",
+           "value": cells * args.steps / elapsed, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if f32 else "f64", "data": "synthetic",
+           "config": {"workload": f"BreezeBenchmarks {args.workload} {Nx}x{Ny}x{Nz}, WENO{order}, halo {h}, {'Float32' if f32 else 'Float64'} "
+                                  f"(benchmarking/src/{args.workload}.jl)", "grid": [Nx, Ny, Nz], "parallelism": "single GPU"},
+           "roofline": roofline,
+           "kernels_ms_per_evaluation": {k: v["total_ms"] / args.steps for k, v in sorted(kernels.items())},
+           "finite": finite()}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def config4_run(args, bz, rank, world, dist, device, fail):
     """--workload config4: BASELINE configs[4], the splitting-supercell shape — CompressibleDynamics, split-explicit WS-RK3 with
     acoustic substeps, DCMIP2016 Kessler microphysics, 512 x 512 x 128 cells on the example's 168 km x 168 km x 20 km box
@@ -568,6 +636,10 @@ def run_rank(args):
 
     if args.workload == "config4":
         return config4_run(args, bz, rank, world, dist, device, fail)
+    if args.workload in ("scalar_tendency", "model_tendency"):
+        if world != 1:
+            fail(f"--workload {args.workload} is a single-GPU micro-benchmark")
+        return tendency_run(args, bz, device)
     if args.workload == "cbl":
         if world > 1:
             fail("--workload cbl is the reference's single-GPU benchmark case")
@@ -772,7 +844,10 @@ def main():
     ap.add_argument("--cbl-size", default="512x512x256", help="--workload cbl: NxxNyxNz (CI sizes: 256x256x128, 512x512x256, 768x768x256)")
     ap.add_argument("--cbl-order", type=int, default=5, choices=(5, 7, 9), help="--workload cbl: WENO order (CI: 5 and 9)")
     ap.add_argument("--cbl-float64", action="store_true", help="--workload cbl in Float64 (the reference benchmarks Float32)")
-    ap.add_argument("--workload", choices=("bubble", "config3", "config4", "cbl"), default="bubble",
+    ap.add_argument("--tend-size", default="256x256x128", help="--workload scalar_tendency / model_tendency: NxxNyxNz (CI: 256x256x128)")
+    ap.add_argument("--tend-order", type=int, default=5, choices=(5, 7, 9), help="--workload scalar_tendency / model_tendency: WENO order (CI: 5, 7, 9)")
+    ap.add_argument("--tend-float64", action="store_true", help="the tendency micro-benchmarks in Float64 (the reference runs Float32)")
+    ap.add_argument("--workload", choices=("bubble", "config3", "config4", "cbl", "scalar_tendency", "model_tendency"), default="bubble",
                     help="bubble: the headline workload (configs[1]); config3: 1024 x (128 N) x 512 slabs; config4: compressible + "
                          "Kessler 512x512x128 (second milestone, split over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

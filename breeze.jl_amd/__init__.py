@@ -10,7 +10,7 @@ from ._lib import BreezeHIPError, LIB_PATH, SYMBOLS, build, load  # noqa: F401
 from .grids import Bounded, Center, Face, Flat, Periodic, RectilinearGrid  # noqa: F401
 from .thermodynamics import ReferenceState, ThermodynamicConstants  # noqa: F401
 from .model import (AnelasticDynamics, AtmosphereModel, Centered, Field, WENO, compute_auxiliary_thermodynamic_variables_,  # noqa: F401
-                    compute_pressure_correction_, compute_tendencies_, compute_velocities_,
+                    compute_pressure_correction_, compute_scalar_tendency_, compute_tendencies_, compute_velocities_,
                     enforce_mass_conservation_, fill_halo_regions_, make_pressure_correction_, set_,
                     ssp_rk3_substep_, store_initial_state_, time_step_, update_state_)
 from . import compressible  # noqa: F401,E402

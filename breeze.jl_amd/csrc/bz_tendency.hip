@@ -482,6 +482,22 @@ int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic 
     return BZ_OK;
 }
 
+// one scalar: Gc = -div_rhoUc(c) (include/breeze_hip.h)
+extern "C" int bz_compute_scalar_tendency(bz_ctx *ctx, const double *u, const double *v, const double *w, const double *c, double *Gc)
+{
+    if (!ctx || !u || !v || !w || !c || !Gc) return BZ_ERR_INVALID;
+    if (ctx->compressible) { ctx->last_error = "bz_compute_scalar_tendency: anelastic contexts (the compressible model: bz_compute_moisture_tendency)"; return BZ_ERR_UNSUPPORTED; }
+    ProfileScope ps(ctx, "scalar_tendency");
+    if (ctx->weno_R != 3) return bzi_scalar_tendency_generic(ctx, Gc, u, v, w, c);
+    const DevGrid &g = ctx->dg;
+    dim3 block(64, TYB);
+    const int kc = pick_kchunk(g, g.Nz);
+    dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
+    hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, Gc, u, v, w, c, kc);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
 // scalar tendencies of the user tracers: G = -div_rhoUc(c)  (update_atmosphere_model_state.jl:352-372)
 int bzi_tracer_tendencies(bz_ctx *ctx, const bz_state *s)
 {

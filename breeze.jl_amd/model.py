@@ -448,6 +448,14 @@ def compute_tendencies_(model):
                  "bz_compute_tendencies")
 
 
+def compute_scalar_tendency_(model, c, Gc):
+    """Gc = -div_rhoUc(c) for one centre field c (halo-filled) with the model's velocities: compute_scalar_tendency!
+    (update_atmosphere_model_state.jl:390-393), the launch the reference's scalar_tendency micro-benchmark times."""
+    v = model.velocities
+    model._check(model._lib.bz_compute_scalar_tendency(model._ctx, v["u"].ptr(), v["v"].ptr(), v["w"].ptr(), c.ptr(), Gc.ptr()),
+                 "bz_compute_scalar_tendency")
+
+
 def compute_closure_fields_(model):
     """compute_closure_fields!(model.closure_fields, model.closure, model) (update_atmosphere_model_state.jl:218)."""
     model._check(model._lib.bz_compute_closure_fields(model._ctx, C.byref(model._state)), "bz_compute_closure_fields")

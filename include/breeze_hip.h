@@ -142,6 +142,11 @@ int bz_compute_velocities(bz_ctx *ctx, const bz_state *s);
 int bz_compute_auxiliary_thermodynamic_variables(bz_ctx *ctx, const bz_state *s);
 /* AtmosphereModels.compute_tendencies! (:294-387): G.rho_u, rho_v, rho_w, rho_theta, rho_q. */
 int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+/* scalar_tendency of ONE field: Gc = -div_rhoUc(c) from the velocities u, v, w (all halo-filled) — compute_scalar_tendency!
+ * (update_atmosphere_model_state.jl:390-393, dynamics_kernel_functions.jl:132-159 without forcing), the kernel group the reference's
+ * own micro-benchmark times (benchmarking/src/scalar_tendency.jl:16-25: Gc = -div_Uc; here with the reference density of the
+ * anelastic model, rho_r = const on that benchmark's 1 m deep box).  WENO order of the context (5, 7 or 9). */
+int bz_compute_scalar_tendency(bz_ctx *ctx, const double *u, const double *v, const double *w, const double *c, double *Gc);
 /* TimeSteppers.update_state!(model; compute_tendencies) (:41-68); G may be NULL iff compute_tendencies == 0. */
 int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, int compute_tendencies);
 

@@ -118,6 +118,15 @@ function AtmosphereModels.make_pressure_correction!(model::HIPModel, Δt)
                 ctx, state(model), Δt), "bz_make_pressure_correction", ctx)
 end
 
+# Gc = -div_ρUc(c) of one centre field with the model's velocities: the launch of compute_scalar_tendency!
+# (update_atmosphere_model_state.jl:390-393) and what benchmarking/src/scalar_tendency.jl:16-25 times
+function compute_scalar_tendency!(Gc, model::HIPModel, c)
+    ctx = context(model)
+    U = model.velocities
+    check(ccall((:bz_compute_scalar_tendency, libbreeze_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                ctx, pointer(parent(U.u)), pointer(parent(U.v)), pointer(parent(U.w)), pointer(parent(c)), pointer(parent(Gc))),
+          "bz_compute_scalar_tendency", ctx)
+end
 
 ##### ---------------------------------------------------------------------------------------------------------------
 ##### Physics attachments of the BOMEX / supercell configurations: the context builder calls these once, right after

@@ -115,6 +115,22 @@ def test_tendencies_match_oracle(oracle, bz, order, stretched):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("order", [5, 7, 9])
+def test_single_scalar_tendency_entry_matches_oracle(oracle, bz, order):
+    """bz_compute_scalar_tendency — the launch of compute_scalar_tendency! for one field, what the reference's scalar_tendency
+    micro-benchmark times (benchmarking/src/scalar_tendency.jl:16-25) — against the oracle's -div_rhoUc(theta)."""
+    om, hm = _pair(oracle, bz, (24, 16, 14), order)
+    randomize(om, seed=5)
+    om.compute_tendencies()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq", "u", "v", "w", "theta", "q", "T"))
+    Gc = bz.Field(hm.grid, (bz.Center, bz.Center, bz.Center), hm.device)
+    bz.compute_scalar_tendency_(hm, hm.potential_temperature, Gc)
+    hm.synchronize()
+    want = om.grid.interior(om.G["rtheta"])
+    assert relerr(Gc.interior_cpu(), want) < 1e-11
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("order", [7, 9])
 def test_time_steps_match_oracle(oracle, bz, order):
     om, hm = _pair(oracle, bz, (32, 16, 16), order)

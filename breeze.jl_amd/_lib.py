@@ -206,6 +206,7 @@ SYMBOLS = {
     "bz_acoustic_stage_begin": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double, C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32)]),
     "bz_acoustic_substep": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_int32, C.POINTER(C.c_int32)]),
+    "bz_acoustic_direct_damping": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp]),
     "bz_acoustic_stage_end": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double, C.c_int]),
     "bz_set_acoustic_scratch": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "bz_compute_moisture_tendency": (C.c_int, [_ctx, _csp, _cpp, _asp]),

@@ -674,6 +674,8 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
         self._th_buf = (sub.density_potential_temperature_perturbation.parent,
                         sub.previous_density_potential_temperature_perturbation.parent)
         self._v_buf = (sub.momentum_perturbation_v.parent, self._vp2.parent)
+        self._u_buf = (sub.momentum_perturbation_u.parent, self._up2.parent)
+        self._direct = isinstance(self.dynamics.time_discretization.damping, DirectDivergenceDamping)
         self._exchange([self.dynamics.pressure.parent])
 
     def comm_info(self):
@@ -740,6 +742,9 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
         for s in range(1, n.value + 1):
             self._exchange([self._th_buf[cur.value], self._v_buf[cur.value]])
             self._check(lib.bz_acoustic_substep(ctx, st, U0, G, sub, s, C.byref(cur)), "bz_acoustic_substep")
+            if self._direct:      # apply_divergence_damping!(::DirectDivergenceDamping): needs the neighbours' freshly advanced rows
+                self._exchange([self._u_buf[cur.value], self._v_buf[cur.value]])
+                self._check(lib.bz_acoustic_direct_damping(ctx, st, U0, G, sub), "bz_acoustic_direct_damping")
         self._exchange([self._th_buf[cur.value]])
         self._check(lib.bz_acoustic_stage_end(ctx, st, U0, G, sub, float(Δt), float(β), 1), "bz_acoustic_stage_end")
 

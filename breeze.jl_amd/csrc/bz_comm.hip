@@ -896,6 +896,7 @@ int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s,
     if (rc) return rc;
     double *th_buf[2] = {sub->density_potential_temperature_perturbation, sub->previous_density_potential_temperature_perturbation};
     double *v_buf[2] = {sub->momentum_perturbation_v, ctx->vp2_user ? ctx->vp2_user : ctx->d_vp2};
+    double *u_buf[2] = {sub->momentum_perturbation_u, ctx->up2_user ? ctx->up2_user : ctx->d_up2};
     const double betas[3] = {1.0 / 3.0, 1.0 / 2.0, 1.0};
     for (int st = 0; st < 3; ++st) {
         if ((rc = bz_refresh_linearization(ctx, s, sub))) return rc;               // prepare_acoustic_cache!
@@ -910,6 +911,12 @@ int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s,
             P.add(th_buf[cur], nc); P.add(v_buf[cur], nc);
             if ((rc = cmp_exchange(ctx, P))) return rc;
             if ((rc = bz_acoustic_substep(ctx, s, U0, G, sub, k, &cur))) return rc;
+            if (ctx->se.direct_divergence_damping && ctx->se.damping_coefficient >= 0.0) {      // apply_divergence_damping!(::DirectDivergenceDamping)
+                FieldList D;
+                D.add(u_buf[cur], nc); D.add(v_buf[cur], nc);
+                if ((rc = cmp_exchange(ctx, D))) return rc;
+                if ((rc = bz_acoustic_direct_damping(ctx, s, U0, G, sub))) return rc;
+            }
         }
         FieldList T;
         T.add(th_buf[cur], nc);

@@ -223,10 +223,11 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
 __global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__restrict__ Pi, double *__restrict__ thL,
                                                            double *__restrict__ gR, double *__restrict__ Clin,
                                                            const double *__restrict__ p, const double *__restrict__ rho_d,
-                                                           const double *__restrict__ rth, const double *__restrict__ qv, int st32)
+                                                           const double *__restrict__ rth, const double *__restrict__ qv, int st32, int hrows)
 {
-    // y-slab mode: one halo row on each side is linearised locally (its inputs arrive with the state's halo exchange)
-    const int i = blockIdx.x * 256 + threadIdx.x, j = (int)blockIdx.y - (g.wrap_y ? 0 : 1), k = blockIdx.z;
+    // y-slab mode: hrows halo rows on each side are linearised locally (their inputs arrive with the state's halo exchange): one for
+    // the substep kernels, two with DirectDivergenceDamping, whose delta of row -1 averages theta_L of rows -2 and -1
+    const int i = blockIdx.x * 256 + threadIdx.x, j = (int)blockIdx.y - hrows, k = blockIdx.z;
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k);
     const double rd = rho_d[n];
@@ -751,7 +752,6 @@ extern "C" int bz_create_compressible_slab(bz_ctx **out, const bz_grid *local_gr
                                            const bz_exner_reference_state *ref, const bz_split_explicit *td, int weno_order,
                                            int y_nranks, int y_rank)
 {
-    if (td && td->direct_divergence_damping) return BZ_ERR_UNSUPPORTED;   // delta would need its own y-halo exchange
     if (td && td->substep_float_bytes != 0 && td->substep_float_bytes != (int32_t)sizeof(double)) return BZ_ERR_UNSUPPORTED;   // the per-substep halo messages carry the grid's real
     if (y_nranks < 1 || y_rank < 0 || y_rank >= y_nranks) return BZ_ERR_INVALID;
     return bzi_create_compressible(out, local_grid, constants, ref, td, weno_order, y_nranks, y_rank, true);
@@ -900,9 +900,10 @@ extern "C" int bz_refresh_linearization(bz_ctx *ctx, const bz_compressible_state
     if (!valid_state(s) || !valid_sub(sub)) return BZ_ERR_INVALID;
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "refresh_linearization");
-    dim3 grid((g.Nx + 255) / 256, g.Ny + (g.wrap_y ? 0 : 2), g.Nz), block(256);
+    const int hrows = g.wrap_y ? 0 : ((ctx->se.direct_divergence_damping && ctx->se.damping_coefficient >= 0.0) ? 2 : 1);
+    dim3 grid((g.Nx + 255) / 256, g.Ny + 2 * hrows, g.Nz), block(256);
     hipLaunchKernelGGL(k_cmp_linearization, grid, block, 0, ctx->stream, g, sub->exner, sub->potential_temperature,
-                       sub->gamma_R_mixture, ctx->d_Clin, s->p, s->rho_d, s->rho_theta, s->q, ctx->substep_f32 ? 1 : 0);
+                       sub->gamma_R_mixture, ctx->d_Clin, s->p, s->rho_d, s->rho_theta, s->q, ctx->substep_f32 ? 1 : 0, hrows);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -1012,14 +1013,18 @@ static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_
 // apply_divergence_damping!(::DirectDivergenceDamping) (acoustic_substepping.jl:1158-1188): delta = V^-1 (dx(thetaF^x) + dy(thetaF^y))
 // into the density predictor (free between recovery and the next predictor build), then the theta_L-scaled gradient of delta onto the
 // horizontal momentum perturbations.  Periodic neighbours by wrap indexing: no halo fill of delta, (rho u)', (rho v)' or theta_L.
+// y-slabs (wrap_y == 0): the neighbours are halo rows — theta_L is linearised on one halo row each side, (rho u)' and (rho v)' are
+// exchanged by the driver between the column solve and this pair (bz_acoustic_direct_damping) — and delta is evaluated from row -1
+// (jofs = -1, Ny + 1 rows) so that the gradient at row 0 needs no exchange of its own.
 __global__ __launch_bounds__(256) void k_ac_direct_delta(DevGrid g, double *__restrict__ delta, const double *__restrict__ thL,
-                                                         const double *__restrict__ up, const double *__restrict__ vp)
+                                                         const double *__restrict__ up, const double *__restrict__ vp, int jofs)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    const int i = blockIdx.x * 256 + threadIdx.x, j = (int)blockIdx.y + jofs, k = blockIdx.z;
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k);
     const long long ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx, im = (i > 0) ? -1 : g.Nx - 1;
-    const long long jp = (j + 1 < g.Ny) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny), jm = (j > 0) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
+    const long long jp = (j + 1 < g.Ny || !g.wrap_y) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
+    const long long jm = (j > 0 || !g.wrap_y) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
     const double Ax = g.Ax[k], Ay = g.Ay[k];
     const double fx = Ax * ((thL[n + ip] + thL[n]) / 2.0) * up[n + ip] - Ax * ((thL[n] + thL[n + im]) / 2.0) * up[n];
     const double fy = Ay * ((thL[n + jp] + thL[n]) / 2.0) * vp[n + jp] - Ay * ((thL[n] + thL[n + jm]) / 2.0) * vp[n];
@@ -1032,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_ac_direct_apply(DevGrid g, const double
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k);
     const long long im = (i > 0) ? -1 : g.Nx - 1;
-    const long long jm = (j > 0) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
+    const long long jm = (j > 0 || !g.wrap_y) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
     up[n] += alpha * (g.dx * g.dx) * ((delta[n] - delta[n + im]) * g.rdx) / ((thL[n] + thL[n + im]) / 2.0);
     vp[n] += alpha * (g.dy * g.dy) * ((delta[n] - delta[n + jm]) * g.rdy) / ((thL[n] + thL[n + jm]) / 2.0);
 }
@@ -1057,6 +1062,24 @@ static void stage_buffers(bz_ctx *ctx, const AcFields &F, double *th_buf[2], dou
     th_buf[0] = F.rthp; th_buf[1] = F.rth_old;
     u_buf[0] = F.rup; u_buf[1] = ctx->up2_user ? ctx->up2_user : ctx->d_up2;
     v_buf[0] = F.rvp; v_buf[1] = ctx->vp2_user ? ctx->vp2_user : ctx->d_vp2;
+}
+
+// apply_divergence_damping!(::DirectDivergenceDamping) on the current perturbation buffers
+static int direct_damping(bz_ctx *ctx, const AcFields &F, const bz_acoustic_substepper *sub)
+{
+    const DevGrid &g = ctx->dg;
+    const AcStage &S = stage_of(ctx);
+    ProfileScope ps(ctx, "acoustic_direct_damping");
+    double *th_buf[2], *u_buf[2], *v_buf[2];
+    stage_buffers(ctx, F, th_buf, u_buf, v_buf);
+    double *up = S.fused ? u_buf[S.cur] : (double *)F.rup, *vp = S.fused ? v_buf[S.cur] : (double *)F.rvp;
+    const int extra = ctx->slab_mode ? 1 : 0;      // slab: delta from row -1
+    dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), rows_d((g.Nx + 255) / 256, g.Ny + extra, g.Nz), b256(256);
+    hipLaunchKernelGGL(k_ac_direct_delta, rows_d, b256, 0, ctx->stream, g, sub->density_predictor, sub->potential_temperature, up, vp, -extra);
+    hipLaunchKernelGGL(k_ac_direct_apply, rows, b256, 0, ctx->stream, g, sub->density_predictor, sub->potential_temperature, up, vp,
+                       ctx->se.damping_coefficient);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
 }
 
 // assemble_slow_vertical_momentum_tendency! + initialize_stage_perturbations!
@@ -1162,18 +1185,24 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
             AC_LAUNCH(k_ac_column_backward, , colsb, bcolb, F, P);
         }
     }
-    if (S.direct) {      // DirectDivergenceDamping closes every substep (also the last one) on the current perturbation buffers
-        ProfileScope ps(ctx, "acoustic_direct_damping");
-        double *th_buf[2], *u_buf[2], *v_buf[2];
-        stage_buffers(ctx, F, th_buf, u_buf, v_buf);
-        double *up = S.fused ? u_buf[S.cur] : F.rup, *vp = S.fused ? v_buf[S.cur] : F.rvp;
-        hipLaunchKernelGGL(k_ac_direct_delta, rows, b256, 0, ctx->stream, g, sub->density_predictor, sub->potential_temperature, up, vp);
-        hipLaunchKernelGGL(k_ac_direct_apply, rows, b256, 0, ctx->stream, g, sub->density_predictor, sub->potential_temperature, up, vp,
-                           ctx->se.damping_coefficient);
-    }
     S.done = sstep;
+    // DirectDivergenceDamping closes every substep (also the last one) on the current perturbation buffers; on a y-slab the driver
+    // exchanges (rho u)', (rho v)' first and then calls bz_acoustic_direct_damping
+    if (S.direct && !ctx->slab_mode) return direct_damping(ctx, F, sub);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
+}
+
+extern "C" int bz_acoustic_direct_damping(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                          const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub)
+{
+    BZ_REQUIRE_COMPRESSIBLE();
+    if (!valid_state(s) || !valid_prog(U0) || !valid_prog(G) || !valid_sub(sub)) return BZ_ERR_INVALID;
+    AcStage &S = stage_of(ctx);
+    if (!S.direct || !ctx->slab_mode) return BZ_OK;      // single-GPU contexts damp inside bz_acoustic_substep
+    if (S.done < 1) { ctx->last_error = "bz_acoustic_direct_damping: no substep has run in this stage"; return BZ_ERR_INVALID; }
+    AcFields F = ac_fields(ctx, s, U0, G, sub);
+    return direct_damping(ctx, F, sub);
 }
 
 // last substep's damping + time-averaged velocities + recovery of the full state [+ WS-RK3 moisture update]

@@ -374,6 +374,8 @@ int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const
  *   bz_acoustic_stage_begin             returns N_tau and which buffer pair is current (0: the substepper's own
  *                                       (rho theta)', (rho u)', (rho v)' fields, 1: previous_(rho theta)' / the scratch pair)
  *   for n = 1..N_tau:  exchange current (rho theta)' and (rho v)'  ->  bz_acoustic_substep(n)
+ *                      [DirectDivergenceDamping: -> exchange the (rho u)', (rho v)' buffers bz_acoustic_substep made current
+ *                       -> bz_acoustic_direct_damping]
  *   exchange current (rho theta)'  ->  bz_acoustic_stage_end
  *   exchange rho_d, momentum, rho_theta, rho_q, time-averaged velocities  ->  bz_compressible_update_state(compute_tendencies = 0)
  *   exchange rho, u, v, w, theta, q, T, p  ->  bz_compute_moisture_tendency */
@@ -391,6 +393,12 @@ int bz_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, const bz_co
 int bz_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                           const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta,
                           int update_moisture);
+/* apply_divergence_damping!(::DirectDivergenceDamping) (acoustic_substepping.jl:1158-1188) of the substep that just ran, on a y-slab
+ * context: the divergence of the theta-weighted momentum perturbations reads (rho v)' of the neighbour's first row and the gradient
+ * reads it one row below the slab, so the driver exchanges the current (rho u)', (rho v)' buffers between bz_acoustic_substep and this
+ * call.  Single-GPU contexts damp inside bz_acoustic_substep; there, and without DirectDivergenceDamping, this is a no-op. */
+int bz_acoustic_direct_damping(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                               const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub);
 /* Caller-owned second buffers of the (rho u)', (rho v)' ping-pong (XFace / YFace parent arrays), so that the slab driver can
  * exchange their halos; NULL, NULL returns to the context's own scratch. */
 int bz_set_acoustic_scratch(bz_ctx *ctx, double *momentum_u_second_buffer, double *momentum_v_second_buffer);

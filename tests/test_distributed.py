@@ -358,6 +358,81 @@ def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, orac
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("library", [False, True])
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_divergence_damping_on_slabs_matches_single_gpu_model(bz, world, library):
+    """DirectDivergenceDamping (acoustic_substepping.jl:1158-1188) on y-slabs: the driver exchanges the (rho u)', (rho v)' buffers the
+    substep made current and calls bz_acoustic_direct_damping (delta is evaluated from row -1, so it needs no exchange of its own).
+    Against the single-GPU model, whose damping runs inside the substep and is compared with the oracle in
+    tests/test_gpu_compressible.py::test_acoustic_substep_loop_matches_oracle."""
+    import torch
+    import uuid
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_backends
+    from breeze_jl_amd import distributed as bz_dist
+    size, steps, dt = (32, 24, 16), 2, 2.0
+    G = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+
+    def dynamics():
+        td = bz.SplitExplicitTimeDiscretization(substeps=6, damping=bz.DirectDivergenceDamping(coefficient=0.1))
+        return bz.CompressibleDynamics(td, reference_potential_temperature=300.0)
+
+    ref = bz.CompressibleAtmosphereModel(G, dynamics(), advection=bz.WENO())
+    Hz, Nz = G.Hz, G.Nz
+    rho = ref.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
+    ic = dict(ρ=rho, θ=cmp_theta, u=3.0, v=-2.0, w=0.0, qᵗ=cmp_qv)
+    ref.set(**ic)
+    for _ in range(steps):
+        ref.time_step(dt)
+    ref.synchronize()
+    undamped = bz.CompressibleAtmosphereModel(G, bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6, damping=bz.NoDivergenceDamping()),
+                                                                         reference_potential_temperature=300.0), advection=bz.WENO())
+    undamped.set(**ic)
+    for _ in range(steps):
+        undamped.time_step(dt)
+    undamped.synchronize()
+
+    mb = dist_backends.Mailbox(world)
+    models, errors = [None] * world, []
+    group = "local:" + uuid.uuid4().hex
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            kw = dict(transport=group) if library else dict(decomp=dist_backends.make_threaded_decomposition(bz_dist, mb, size[0], size[1] // world,
+                                                                                                            size[2], 3, rank, world))
+            with torch.cuda.stream(torch.cuda.Stream()):
+                m = bz.compressible.SlabCompressibleModel(G, rank, world, dynamics(), advection=bz.WENO(), device="cuda:0", **kw)
+                m.set(**ic)
+                for _ in range(steps):
+                    m.time_step(dt)
+                m.synchronize()
+            models[rank] = m
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            mb.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    getters = {"ρᵈ": lambda m: m.dynamics.dry_density, "ρu": lambda m: m.momentum["ρu"], "ρv": lambda m: m.momentum["ρv"],
+               "ρw": lambda m: m.momentum["ρw"], "ρθ": lambda m: m.potential_temperature_density}
+    mom = max(np.abs(getters[k](ref).interior_cpu()).max() for k in ("ρu", "ρv", "ρw"))
+    for name, getter in getters.items():
+        got = np.concatenate([getter(m).interior_cpu() for m in models], axis=1)
+        want = getter(ref).interior_cpu()
+        scale = mom if name in ("ρu", "ρv", "ρw") else np.max(np.abs(want))
+        assert np.max(np.abs(got - want)) / scale < 1e-11, name
+    # the damping does something: the undamped model differs by far more than the tolerance above
+    dv = np.abs(getters["ρv"](ref).interior_cpu() - getters["ρv"](undamped).interior_cpu()).max() / mom
+    assert dv > 1e-8, dv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("library", [False, True])
 def test_compressible_saturation_adjustment_on_slabs_matches_single_gpu_model(bz, library):
     """Density-based warm-phase saturation adjustment (saturation_adjustment.jl:236-301) on two compressible y-slabs: q^v, q^l ride the
     per-stage exchange (the halo rows' gamma R_m linearisation reads the liquid fraction); against the single-GPU whole-step seam."""

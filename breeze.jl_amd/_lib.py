@@ -147,7 +147,7 @@ class bz_split_explicit(C.Structure):
                 ("thermodynamic_tendency_factor", C.c_double), ("vertical_momentum_tendency_factor", C.c_double),
                 ("newton_abstol", C.c_double), ("direct_divergence_damping", C.c_int32), ("sponge_ramp", C.c_int32),
                 ("sponge_damping_rate", C.c_double), ("sponge_depth", C.c_double),
-                ("substep_distribution", C.c_int32), ("substep_float_bytes", C.c_int32)]
+                ("substep_distribution", C.c_int32), ("substep_float_bytes", C.c_int32), ("damping_length_scale", C.c_double)]
 
 
 class bz_exner_reference_state(C.Structure):

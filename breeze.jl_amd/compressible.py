@@ -27,9 +27,10 @@ class NoDivergenceDamping:
 
 class ThermalDivergenceDamping:
     def __init__(self, coefficient=0.1, length_scale=None, damp_vertical=False):
-        if length_scale is not None:
-            raise NotImplementedError("ThermalDivergenceDamping(length_scale=...) is not implemented in the HIP path")
-        self.coefficient, self.length_scale, self.damp_vertical = float(coefficient), None, bool(damp_vertical)
+        if length_scale is not None and not float(length_scale) > 0:
+            raise ValueError(f"`length_scale` must be positive (got {length_scale})")
+        self.coefficient, self.damp_vertical = float(coefficient), bool(damp_vertical)
+        self.length_scale = None if length_scale is None else float(length_scale)      # fixed diffusivity alpha l^2 / dtau
 
 
 class DirectDivergenceDamping:
@@ -379,6 +380,7 @@ class CompressibleAtmosphereModel:
         bt.acoustic_cfl, bt.forward_weight = td.acoustic_cfl, td.forward_weight
         bt.damping_coefficient = damp.coefficient if isinstance(damp, (ThermalDivergenceDamping, DirectDivergenceDamping)) else -1.0
         bt.direct_divergence_damping = int(isinstance(damp, DirectDivergenceDamping))
+        bt.damping_length_scale = (damp.length_scale or 0.0) if isinstance(damp, ThermalDivergenceDamping) else 0.0
         bt.thermodynamic_tendency_factor = td.thermodynamic_tendency_factor
         bt.vertical_momentum_tendency_factor = td.vertical_momentum_tendency_factor
         bt.newton_abstol = self.temperature_solver.abstol

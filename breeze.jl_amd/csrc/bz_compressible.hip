@@ -1105,7 +1105,8 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     P.f_theta = ctx->se.thermodynamic_tendency_factor;
     P.f_w = ctx->se.vertical_momentum_tendency_factor;
     const double lmin = g.flat_y ? g.dx : std::fmin(g.dx, g.dy);                             // acoustic_substepping.jl:1102-1110
-    P.kdamp = S.damping ? ctx->se.damping_coefficient * (lmin * lmin) / dtau : 0.0;
+    const double lfix = ctx->se.damping_length_scale;                                        // ThermalDivergenceDamping(length_scale): :1085-1092
+    P.kdamp = !S.damping ? 0.0 : (lfix > 0.0) ? (ctx->se.damping_coefficient * (lfix * lfix)) / dtau : ctx->se.damping_coefficient * (lmin * lmin) / dtau;
     P.inv_N = 1.0 / (double)ntau;
     P.gate = 1.0;
     S.ntau = ntau;

@@ -215,6 +215,7 @@ struct BzSplitExplicit
     sponge_damping_rate::Float64; sponge_depth::Float64
     substep_distribution::Int32                                   # 0 ProportionalSubsteps, 1 ConstantSubstepSize, 2 MonolithicFirstStage
     substep_float_bytes::Int32                                    # 0: eltype(grid); 4: the substepper's working fields are Float32 arrays
+    damping_length_scale::Float64                                 # ThermalDivergenceDamping(length_scale): 0 = nothing (local scale)
 end
 distcode(::ProportionalSubsteps) = Int32(0)
 distcode(::ConstantSubstepSize) = Int32(1)
@@ -262,7 +263,8 @@ function create_compressible_context(model)
                          damp isa DirectDivergenceDamping, rampcode(a.sponge),
                          a.sponge === nothing ? 0.0 : a.sponge.damping_rate, a.sponge === nothing ? 0.0 : a.sponge.depth,
                          distcode(a.substep_distribution),
-                         eltype(a.density_perturbation) === Float32 && eltype(grid) === Float64 ? Int32(4) : Int32(0))
+                         eltype(a.density_perturbation) === Float32 && eltype(grid) === Float64 ? Int32(4) : Int32(0),
+                         damp isa ThermalDivergenceDamping && damp.length_scale !== nothing ? Float64(damp.length_scale) : 0.0)
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve zf p ρ begin
         g = BzGrid(Nx, Ny, Nz, Hx, Hy, Hz, map(topocode, topology(grid)), 8, grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, pointer(zf),

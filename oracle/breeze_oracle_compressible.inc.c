@@ -443,14 +443,15 @@ void og_post_solve_recovery(const og_grid *G, double *rp, double *rthp, const do
             }
 }
 
-/* _thermal_divergence_damping! (acoustic_substepping.jl:1123-1139); kappa = alpha*lmin^2/dtau */
+/* _thermal_divergence_damping! (acoustic_substepping.jl:1123-1139); kappa = alpha*lmin^2/dtau (LocalHorizontalDampingScale, :1100-1110)
+ * or, with ThermalDivergenceDamping(length_scale = l), (alpha l^2)/dtau (FixedHorizontalDampingScale, :1085-1092; length_scale <= 0: none) */
 void og_thermal_divergence_damping(const og_grid *G, double *rup, double *rvp, const double *rthp,
-                                   const double *rth_old, const double *thL, double alpha, double dtau)
+                                   const double *rth_old, const double *thL, double alpha, double dtau, double length_scale)
 {
     double lmin = INFINITY;
     if (G->tx != FLAT) lmin = fmin(lmin, G->dx);
     if (G->ty != FLAT) lmin = fmin(lmin, G->dy);
-    double kap = alpha * (lmin * lmin) / dtau;
+    double kap = (length_scale > 0.0) ? (alpha * (length_scale * length_scale)) / dtau : alpha * (lmin * lmin) / dtau;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < G->Nz; ++k)
         for (int j = 0; j < G->Ny; ++j)

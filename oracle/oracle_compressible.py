@@ -108,7 +108,8 @@ class SplitExplicit:
                  damping_coefficient=0.1, damp_vertical=False,
                  apply_first_substep_pressure_gradient=False,
                  thermodynamic_tendency_factor=1.0, vertical_momentum_tendency_factor=1.0, direct_damping=False, sponge=None,
-                 substep_distribution="proportional"):
+                 substep_distribution="proportional", damping_length_scale=None):
+        self.damping_length_scale = None if damping_length_scale is None else float(damping_length_scale)   # ThermalDivergenceDamping(length_scale)
         self.direct_damping = bool(direct_damping)      # DirectDivergenceDamping(coefficient) instead of ThermalDivergenceDamping
         self.sponge = sponge                            # None or (damping_rate, depth, ramp) with ramp in {"linear", "cubic", "sin2"}
         assert substep_distribution in ("proportional", "constant", "monolithic_first_stage")
@@ -491,7 +492,8 @@ class CompressibleOracleModel:
                                                C.c_double(td.damping_coefficient))
             elif td.damping_coefficient is not None:
                 L.og_thermal_divergence_damping(cg, _p(self.rup), _p(self.rvp), _p(self.rthp), _p(self.rth_old),
-                                                _p(self.thL), C.c_double(td.damping_coefficient), C.c_double(dtau))
+                                                _p(self.thL), C.c_double(td.damping_coefficient), C.c_double(dtau),
+                                                C.c_double(getattr(td, "damping_length_scale", None) or 0.0))
             self._halo_center(self.rup)
             self._halo_center(self.rvp)
         L.og_finalize_time_averaged_velocity(cg, _p(self.au), _p(self.av), _p(self.aw), _p(self.ru), _p(self.rv),

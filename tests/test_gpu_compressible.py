@@ -25,7 +25,8 @@ def make_pair(oracle, oc, bz, size=(24, 16, 20), theta_ref=300.0, reference=True
     grid = bz.RectilinearGrid(size, x=EXTENT["x"], y=EXTENT["y"], z=z)
     damping = (bz.NoDivergenceDamping() if otd.damping_coefficient is None
                else bz.DirectDivergenceDamping(coefficient=otd.damping_coefficient) if otd.direct_damping
-               else bz.ThermalDivergenceDamping(coefficient=otd.damping_coefficient, damp_vertical=otd.damp_vertical))
+               else bz.ThermalDivergenceDamping(coefficient=otd.damping_coefficient, damp_vertical=otd.damp_vertical,
+                                                length_scale=otd.damping_length_scale))
     sponge = None
     if otd.sponge is not None:
         ramp = {"linear": bz.LinearRamp, "cubic": bz.CubicRamp, "sin2": bz.Sin2Ramp}[otd.sponge[2]]()
@@ -194,6 +195,7 @@ CASES = [
     dict(substeps=6, apply_first_substep_pressure_gradient=True),
     dict(),                                                      # adaptive substep count from the acoustic CFL
     dict(substeps=6, direct_damping=True),                       # DirectDivergenceDamping (acoustic_substepping.jl:1146-1188)
+    dict(substeps=6, damping_length_scale=180.0, damp_vertical=True),   # ThermalDivergenceDamping(length_scale = l): fixed alpha l^2 / dtau (:1085-1092)
     dict(substeps=1, direct_damping=True, damping_coefficient=0.15),
     dict(substeps=6, sponge=(0.2, 3000.0, "cubic")),             # UpperSponge (acoustic_substepping.jl:584-602), each ramp shape
     dict(substeps=4, sponge=(0.5, 2000.0, "linear"), damp_vertical=True),

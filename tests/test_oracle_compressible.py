@@ -323,6 +323,35 @@ def test_direct_divergence_damping_properties(oracle, oc):
     assert np.max(np.abs(g.interior(up) - before)) < 1e-14
 
 
+def test_thermal_damping_length_scale_is_a_fixed_diffusivity(oracle, oc):
+    """ThermalDivergenceDamping(length_scale = l) (time_discretizations.jl:215-218, acoustic_substepping.jl:1085-1092): the correction is
+    (alpha l^2 / dtau) d[(rho theta)' - (rho theta)'_old] / theta_L in both directions; l = min(dx, dy) reproduces the local default
+    (:1100-1110) bit for bit, and the correction scales with l^2."""
+    import ctypes as C
+    g = oracle.Grid((16, 12, 6), x=(0.0, 1600.0), y=(0.0, 2400.0), z=(0.0, 600.0))      # dx = 100, dy = 200
+    m = oc.CompressibleOracleModel(g, time_discretization=oc.SplitExplicit(substeps=2), reference_potential_temperature=300.0)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    L, cg = m.lib, C.byref(m.cg)
+    rng = np.random.default_rng(3)
+    thL = 300.0 + rng.random(m.rup.shape)
+    rthp, rth_old = rng.standard_normal(m.rup.shape), rng.standard_normal(m.rup.shape)
+
+    def run(length_scale):
+        up, vp = np.zeros_like(m.rup), np.zeros_like(m.rup)
+        L.og_thermal_divergence_damping(cg, p(up), p(vp), p(rthp), p(rth_old), p(thL), C.c_double(0.1), C.c_double(0.5), C.c_double(length_scale))
+        return g.interior(up).copy(), g.interior(vp).copy()
+
+    u0, v0 = run(0.0)
+    u1, v1 = run(100.0)                       # = min(dx, dy)
+    assert np.array_equal(u0, u1) and np.array_equal(v0, v1)
+    u2, v2 = run(300.0)
+    assert np.allclose(u2, 9.0 * u0, rtol=1e-14, atol=0) and np.allclose(v2, 9.0 * v0, rtol=1e-14, atol=0)
+    i, j, k = 5, 4, 2
+    n = lambda a, di=0, dj=0: g.interior(a)[k, j + dj, i + di]
+    want = -(0.1 * 300.0 ** 2 / 0.5) * (((n(rthp) - n(rth_old)) - (n(rthp, -1) - n(rth_old, -1))) / 100.0) / ((n(thL) + n(thL, -1)) / 2)
+    assert abs(u2[k, j, i] - want) < 1e-12 * abs(want)
+
+
 def test_upper_sponge_coefficients_known_answers(oracle, oc):
     """test/acoustic_substepping_components.jl:476-499 restated on the oracle's profile: LinearRamp, depth 2000 on z = (0, 8000):
     zero at the bottom face, damping_rate at the lid, so the diagonal term is |dtau_new| rate and the rhs term |dtau_old| rate rho_w;

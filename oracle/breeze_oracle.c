@@ -251,6 +251,32 @@ void og_fill_halo_periodic_xy(const og_grid *G, double *f, int nz_tot)
     }
 }
 
+/* Bounded y (round 3: (Periodic, Bounded, Bounded), the reference benchmark's PBB option, benchmarking/run_benchmarks.jl:130): the same
+ * conventions as Bounded z below — a field that is a centre in y gets its first halo row from the adjacent interior row (no-flux), a
+ * y-face field (rho v, v) carries zeros on its wall faces j = 0 and j = Ny (impenetrable walls; face Ny lives in the first upper halo row). */
+void og_fill_halo_y_noflux(const og_grid *G, double *f, int nz_tot)
+{
+    size_t sx = SX(G), sy = SY(G);
+    if (G->ty != BOUNDED) return;
+#pragma omp parallel for schedule(static)
+    for (int kk = 0; kk < nz_tot; ++kk) {
+        double *pl = f + sx * sy * (size_t)kk;
+        memcpy(pl + sx * (size_t)(G->Hy - 1), pl + sx * (size_t)G->Hy, sx * sizeof(double));
+        memcpy(pl + sx * (size_t)(G->Hy + G->Ny), pl + sx * (size_t)(G->Hy + G->Ny - 1), sx * sizeof(double));
+    }
+}
+void og_fill_halo_y_wall(const og_grid *G, double *v, int nz_tot)
+{
+    size_t sx = SX(G), sy = SY(G);
+    if (G->ty != BOUNDED) return;
+#pragma omp parallel for schedule(static)
+    for (int kk = 0; kk < nz_tot; ++kk) {
+        double *pl = v + sx * sy * (size_t)kk;
+        memset(pl + sx * (size_t)G->Hy, 0, sx * sizeof(double));
+        memset(pl + sx * (size_t)(G->Hy + G->Ny), 0, sx * sizeof(double));
+    }
+}
+
 /* Centre field on Bounded z with the default no-flux BC: first halo cell only,
  * c[-1] = c[0], c[Nz] = c[Nz-1]. */
 void og_fill_halo_z_noflux(const og_grid *G, double *f)
@@ -468,10 +494,21 @@ static inline double symm_x_face(const og_grid *G, const double *M, size_t n, in
     }
     return symm4(A * M[n - 2], A * M[n - 1], A * M[n], A * M[n + 1]);
 }
+/* Bounded y: the order drops with the distance to the wall like the z interpolations below (order 2 (B - 1), B the WENO buffer that fits) */
 static inline double symm_y_center(const og_grid *G, const double *M, size_t n, int j, double A)
 {
-    ptrdiff_t s = STRY(G); (void)j;
+    ptrdiff_t s = STRY(G);
     if (G->ty == FLAT) return A * M[n];
+    if (G->ty == BOUNDED) {      /* to centre j from faces j-1 .. j+2 */
+        int B = buffer_at(j, G->Ny, 1, 0);
+        if (B >= 4) {
+            double q[8]; const int h = B - 1;
+            for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - (h - 1)) * s];
+            return symm_wide(q, B);
+        }
+        if (B == 3) return symm4(A * M[n - s], A * M[n], A * M[n + s], A * M[n + 2 * s]);
+        return symm2(A * M[n], A * M[n + s]);
+    }
     if (og_weno_R >= 4) {
         double q[8]; const int h = og_weno_R - 1;
         for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - (h - 1)) * s];
@@ -481,8 +518,18 @@ static inline double symm_y_center(const og_grid *G, const double *M, size_t n, 
 }
 static inline double symm_y_face(const og_grid *G, const double *M, size_t n, int j, double A)
 {
-    ptrdiff_t s = STRY(G); (void)j;
+    ptrdiff_t s = STRY(G);
     if (G->ty == FLAT) return A * M[n];
+    if (G->ty == BOUNDED) {      /* to face j from centres j-2 .. j+1 */
+        int B = buffer_at(j, G->Ny, 1, 1);
+        if (B >= 4) {
+            double q[8]; const int h = B - 1;
+            for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - h) * s];
+            return symm_wide(q, B);
+        }
+        if (B == 3) return symm4(A * M[n - 2 * s], A * M[n - s], A * M[n], A * M[n + s]);
+        return symm2(A * M[n - s], A * M[n]);
+    }
     if (og_weno_R >= 4) {
         double q[8]; const int h = og_weno_R - 1;
         for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - h) * s];
@@ -605,9 +652,10 @@ void og_u_tendency(const og_grid *G, double *Gu, const double *ru, const double 
 void og_v_tendency(const og_grid *G, double *Gv, const double *ru, const double *rv,
                    const double *rw, const double *v)
 {
+    const int j0 = (G->ty == BOUNDED) ? 1 : 0;      /* Bounded y: the wall face j = 0 is never updated (like w at k = 0) */
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < G->Nz; ++k)
-        for (int j = 0; j < G->Ny; ++j)
+        for (int j = j0; j < G->Ny; ++j)
             for (int i = 0; i < G->Nx; ++i) {
                 double Vinv = 1.0 / (G->dx * G->dy * dzc_at(G, k));
                 double a = 0.0, b = 0.0, c = 0.0;
@@ -759,7 +807,7 @@ void og_pressure_correct(const og_grid *G, double *ru, double *rv, double *rw,
                 double rf = 0.5 * (rho[k - 1] + rho[k]);
                 double rc = rho[k];
                 if (G->tx != FLAT) ru[n] -= rc * dt * ((phi[n] - phi[n - 1]) * (1.0 / G->dx));
-                if (G->ty != FLAT) rv[n] -= rc * dt * ((phi[n] - phi[n - STRY(G)]) * (1.0 / G->dy));
+                if (G->ty != FLAT && !(G->ty == BOUNDED && j == 0)) rv[n] -= rc * dt * ((phi[n] - phi[n - STRY(G)]) * (1.0 / G->dy));
                 rw[n] -= rf * dt * ((phi[n] - phi[n - STRZ(G)]) * (1.0 / G->dzf[k + G->Hz]));
             }
 }

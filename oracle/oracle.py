@@ -165,7 +165,7 @@ class Grid:
         self.Nx, self.Ny, self.Nz = N
         self.Hx, self.Hy, self.Hz = H
         assert topo[2] == BOUNDED, "oracle supports Bounded z only"
-        assert topo[0] in (PERIODIC, FLAT) and topo[1] in (PERIODIC, FLAT, SLAB)
+        assert topo[0] in (PERIODIC, FLAT) and topo[1] in (PERIODIC, FLAT, SLAB, BOUNDED)      # Bounded y: (Periodic, Bounded, Bounded)
 
         def regular(ext, n, flat):
             if flat:
@@ -258,11 +258,14 @@ class ReferenceState:
 
 
 def poisson_eigenvalues(N, delta, topo):
-    """Oceananigans poisson_eigenvalues (recalled): Periodic (2 sin(pi (i-1)/N)/Delta)^2, Flat 0."""
+    """Oceananigans poisson_eigenvalues (recalled): Periodic (2 sin(pi (i-1)/N)/Delta)^2, Bounded (2 sin(pi (i-1)/(2N))/Delta)^2
+    (the cosine modes of the staggered Neumann problem), Flat 0."""
     if topo == FLAT:
         return np.zeros(1)
-    assert topo == PERIODIC
     i = np.arange(N)
+    if topo == BOUNDED:
+        return (2 * np.sin(i * np.pi / (2 * N)) / delta) ** 2
+    assert topo == PERIODIC
     return (2 * np.sin(i * np.pi / N) / delta) ** 2
 
 
@@ -357,22 +360,29 @@ class OracleModel:
                           _p(r.temperature), c.g, c.Rd, c.Rv, c.cpd, c.cpv, r.pst)
 
     # -- halo filling -------------------------------------------------------
-    def _halo_center(self, f):
-        self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
+    def _halo_xy(self, f, yface=False):
+        # x / y of every field: periodic wrap; a Bounded y adds the no-flux row (centres in y) or the impenetrable wall faces (y-faces)
+        cg = C.byref(self.cg)
+        self.lib.og_fill_halo_periodic_xy(cg, _p(f), C.c_int(f.shape[0]))
+        if self.grid.topo[1] == BOUNDED:
+            (self.lib.og_fill_halo_y_wall if yface else self.lib.og_fill_halo_y_noflux)(cg, _p(f), C.c_int(f.shape[0]))
+
+    def _halo_center(self, f, yface=False):
+        self._halo_xy(f, yface)
         if self.grid.Hz > 0:
             self.lib.og_fill_halo_z_noflux(C.byref(self.cg), _p(f))
 
     def _halo_w(self, f, wall=True):
-        self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
+        self._halo_xy(f)
         if wall:
             self.lib.og_fill_halo_z_wall(C.byref(self.cg), _p(f))
 
-    def _halo_velocity(self, f):   # `nothing` BC in z: periodic wrap only (anelastic_dynamics.jl:174-182)
-        self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
+    def _halo_velocity(self, f, yface=False):   # `nothing` BC in z: periodic wrap only (anelastic_dynamics.jl:174-182)
+        self._halo_xy(f, yface)
 
     def fill_momentum_halos(self):
         self._halo_center(self.ru)
-        self._halo_center(self.rv)
+        self._halo_center(self.rv, yface=True)
         self._halo_w(self.rw)
 
     # -- set! ----------------------------------------------------------------
@@ -455,7 +465,7 @@ class OracleModel:
         self._halo_center(self.rq)
         self.lib.og_compute_velocities(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv), _p(self.rw))
         for f in (self.u, self.v, self.w):
-            self._halo_velocity(f)
+            self._halo_velocity(f, yface=f is self.v)
         if self.microphysics == "Kessler":
             # microphysical_state + grid_moisture_fractions + update_microphysical_auxiliaries! (dcmip2016_kessler.jl:222-227,
             # 298-303,860-865): q = (q^v, q^cl + q^r), T = Pi(q) theta + L q^l / c_pm
@@ -566,7 +576,11 @@ class OracleModel:
         FFT x,y -> complex Thomas in z -> inverse FFT -> subtract mean -> real part."""
         g = self.grid
         workers = getattr(self, "fft_workers", 1)
-        if workers > 1:       # bench.py's cpu_baseline leg: the same pocketfft transforms on several host threads
+        if g.topo[1] == BOUNDED:       # cosine transform along the Bounded direction (DCT-II forward, its inverse back), FFT along x
+            import scipy.fft as sfft
+            fft2 = lambda a: sfft.fft(sfft.dct(a.real, type=2, axis=1) + 1j * sfft.dct(a.imag, type=2, axis=1), axis=2)
+            ifft2 = lambda a: (lambda b: sfft.idct(b.real, type=2, axis=1) + 1j * sfft.idct(b.imag, type=2, axis=1))(sfft.ifft(a, axis=2))
+        elif workers > 1:       # bench.py's cpu_baseline leg: the same pocketfft transforms on several host threads
             import scipy.fft as sfft
             fft2 = lambda a: sfft.fft2(a, axes=(1, 2), workers=workers)
             ifft2 = lambda a: sfft.ifft2(a, axes=(1, 2), workers=workers)

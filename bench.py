@@ -253,8 +253,10 @@ def cbl_run(args, bz, device):
     Nx, Ny, Nz = (int(v) for v in args.cbl_size.lower().split("x"))
     f32 = not args.cbl_float64
     dt = 0.05
+    pbb = args.cbl_topology == "PBB"      # (Periodic, Bounded, Bounded): benchmarking/run_benchmarks.jl:130 (operator-by-operator tier, cosine transform in y)
     m = bz.benchmarks.convective_boundary_layer((Nx, Ny, Nz), float_type=np.float32 if f32 else np.float64,
-                                                advection=bz.WENO(order=args.cbl_order), device=device)
+                                                advection=bz.WENO(order=args.cbl_order), device=device,
+                                                topology=(bz.Periodic, bz.Bounded if pbb else bz.Periodic, bz.Bounded))
     for _ in range(args.warmup):
         m.time_step(dt)
     m.profile_reset()
@@ -283,7 +285,7 @@ def cbl_run(args, bz, device):
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32" if f32 else "f64", "data": "synthetic",
            "config": {"workload": f"BreezeBenchmarks convective_boundary_layer {Nx}x{Ny}x{Nz} (benchmarking/src/convective_boundary_layer.jl): "
-                                  f"AnelasticDynamics, WENO{args.cbl_order}, halo 5, FPlane + geostrophic forcing + u* drag + surface heat flux, "
+                                  f"AnelasticDynamics, WENO{args.cbl_order}, halo 5, topology {args.cbl_topology}, FPlane + geostrophic forcing + u* drag + surface heat flux, "
                                   f"{'Float32' if f32 else 'Float64'}, dt={dt}s", "grid": [Nx, Ny, Nz], "dt": dt, "parallelism": "single GPU"},
            "roofline": roofline,
            "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_achieved / HBM_PEAK_GBS,
@@ -844,6 +846,7 @@ def main():
     ap.add_argument("--cbl-size", default="512x512x256", help="--workload cbl: NxxNyxNz (CI sizes: 256x256x128, 512x512x256, 768x768x256)")
     ap.add_argument("--cbl-order", type=int, default=5, choices=(5, 7, 9), help="--workload cbl: WENO order (CI: 5 and 9)")
     ap.add_argument("--cbl-float64", action="store_true", help="--workload cbl in Float64 (the reference benchmarks Float32)")
+    ap.add_argument("--cbl-topology", choices=("PPB", "PBB"), default="PPB", help="--workload cbl: (Periodic, Periodic, Bounded) or (Periodic, Bounded, Bounded)")
     ap.add_argument("--tend-size", default="256x256x128", help="--workload scalar_tendency / model_tendency: NxxNyxNz (CI: 256x256x128)")
     ap.add_argument("--tend-order", type=int, default=5, choices=(5, 7, 9), help="--workload scalar_tendency / model_tendency: WENO order (CI: 5, 7, 9)")
     ap.add_argument("--tend-float64", action="store_true", help="the tendency micro-benchmarks in Float64 (the reference runs Float32)")

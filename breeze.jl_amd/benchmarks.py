@@ -38,11 +38,11 @@ def cbl_initial_theta(size, seed=0):
 
 
 def convective_boundary_layer(size=(64, 64, 64), float_type=np.float32, advection=None, closure=None, device="cuda:0", seed=0,
-                              halo=(5, 5, 5)):
+                              halo=(5, 5, 5), topology=(Periodic, Periodic, Bounded)):
     """AtmosphereModel of the CBL benchmark case with its initial condition set (simplified = false branch of the reference)."""
     Nx, Ny, Nz = size
     grid = RectilinearGrid((Nx, Ny, Nz), x=(0.0, CBL["Lx"]), y=(0.0, CBL["Ly"]), z=(0.0, CBL["Lz"]), halo=halo,
-                           topology=(Periodic, Periodic, Bounded), float_type=float_type)
+                           topology=topology, float_type=float_type)      # PBB = (Periodic, Bounded, Bounded): run_benchmarks.jl:130
     constants = ThermodynamicConstants()
     ref = ReferenceState(grid, constants, surface_pressure=CBL["p0"], potential_temperature=CBL["theta0"])
     rho0 = cbl_surface_density(constants)

@@ -201,9 +201,13 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     // (Periodic, Periodic, Bounded), or (Periodic, Flat, Bounded) — the reference's 2-D x-z cases (README.md:67-75, examples/
     // dry_thermal_bubble.jl, acoustic_wave.jl, inertia_gravity_wave.jl): Ny = 1, Hy = 0, single-GPU WENO-5 contexts
     const bool flat_y = grid->topo[1] == BZ_FLAT;
-    if (grid->topo[0] != BZ_PERIODIC || (grid->topo[1] != BZ_PERIODIC && !flat_y) || grid->topo[2] != BZ_BOUNDED)
+    // (Periodic, Bounded, Bounded) — the reference benchmark driver's PBB option (benchmarking/run_benchmarks.jl:130): single-GPU
+    // anelastic WENO-5 contexts, stepped operator by operator
+    const bool bounded_y = grid->topo[1] == BZ_BOUNDED;
+    if (grid->topo[0] != BZ_PERIODIC || (grid->topo[1] != BZ_PERIODIC && !flat_y && !bounded_y) || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
     if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode)) return BZ_ERR_UNSUPPORTED;
+    if (bounded_y && (slab_mode || compressible || weno_order != 5 || grid->Ny < 2 * grid->Hy)) return BZ_ERR_UNSUPPORTED;
     if (grid->Hx < 3 || (!flat_y && grid->Hy < 3) || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
     // Oceananigans: N >= H in every direction (k_halo_y's wrap copy would otherwise read a halo row that is not filled yet)
     if (grid->Nx < grid->Hx || grid->Ny < grid->Hy || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;
@@ -312,8 +316,9 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.cpd = constants->dry_air_heat_capacity;
     g.cpv = constants->vapor_heat_capacity;
     g.pst = ref->standard_pressure;
-    g.wrap_y = slab_mode ? 0 : 1;
+    g.wrap_y = (slab_mode || bounded_y) ? 0 : 1;
     g.flat_y = flat_y ? 1 : 0;
+    g.bounded_y = bounded_y ? 1 : 0;
 
     ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !ctx->tune.no_fused;
 #ifndef BZ_CENTERED2
@@ -329,6 +334,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     // Flat y: the anelastic model steps with one kernel per reference kernel (bz_tendency.hip); the compressible kernels reach their
     // y neighbours through wrap offsets, which are zero when Ny = 1 (bz_compressible.hip: wrap_of), and keep their fused sequence
     if (flat_y) { if (!compressible) ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }
+    if (bounded_y) { ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }      // one kernel per reference kernel, row-wise buffers (bz_tendency.hip)
     ctx->compressible = compressible;
     ctx->dz_min = dzc[Hz];
     for (int k = 0; k < Nz; ++k) ctx->dz_min = std::fmin(ctx->dz_min, dzc[Hz + k]);

@@ -5,6 +5,9 @@
 //   Bounded z    : kind 0 centre field, default no-flux BC -> first halo cell = adjacent interior cell
 //                  kind 1 z-face field, impenetrable walls  -> wall faces k=0 and k=Nz set to 0
 //                  kind 2/3 `nothing` BC (diagnostic velocities) -> untouched in z.
+//   Bounded y    : (topology (Periodic, Bounded, Bounded)) the same two conventions by row: a field that is a centre in y takes its
+//                  first halo row from the adjacent interior row; a y-face field (kind | BZ_HALO_YFACE: rho v, v) gets zeros on its
+//                  wall faces j = 0 and j = Ny (face Ny lives in the first upper halo row).
 #include "bz_internal.h"
 
 #define BZ_MAX_HALO_FIELDS 12
@@ -41,10 +44,27 @@ __global__ __launch_bounds__(256) void k_halo_y(DevGrid g, HaloList L)
     }
 }
 
+__global__ __launch_bounds__(256) void k_halo_y_bounded(DevGrid g, HaloList L)
+{
+    int fi = blockIdx.z, kk = blockIdx.y;
+    if (kk >= L.nzt[fi]) return;
+    int ii = blockIdx.x * 256 + threadIdx.x;
+    if (ii >= g.Sx) return;
+    double *pl = L.f[fi] + g.Sxy * kk + ii;
+    const long long sy = g.Sx;
+    if (L.kind[fi] & BZ_HALO_YFACE) {
+        pl[sy * g.Hy] = 0.0;
+        pl[sy * (g.Hy + g.Ny)] = 0.0;
+    } else {
+        pl[sy * (g.Hy - 1)] = pl[sy * g.Hy];
+        pl[sy * (g.Hy + g.Ny)] = pl[sy * (g.Hy + g.Ny - 1)];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_halo_z(DevGrid g, HaloList L)
 {
     int fi = blockIdx.z;
-    int kind = L.kind[fi];
+    int kind = L.kind[fi] & 3;
     if (kind >= 2) return;
     long long n = (long long)blockIdx.x * 256 + threadIdx.x;
     if (n >= g.Sxy) return;
@@ -71,13 +91,16 @@ int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, i
         if (!fields[i]) return BZ_ERR_INVALID;
         L.f[i] = fields[i];
         L.kind[i] = kinds[i];
-        L.nzt[i] = g.Nz + 2 * g.Hz + ((kinds[i] == 1 || kinds[i] == 3) ? 1 : 0);
+        const int zk = kinds[i] & 3;
+        L.nzt[i] = g.Nz + 2 * g.Hz + ((zk == 1 || zk == 3) ? 1 : 0);
         if (L.nzt[i] > nzmax) nzmax = L.nzt[i];
-        if (kinds[i] < 2) anyz = true;
+        if (zk < 2) anyz = true;
     }
     hipLaunchKernelGGL(k_halo_x, dim3((g.Ny + 63) / 64, nzmax, n), dim3(64), 0, ctx->stream, g, L);
     if (g.wrap_y)
         hipLaunchKernelGGL(k_halo_y, dim3((g.Sx + 255) / 256, nzmax, n), dim3(256), 0, ctx->stream, g, L);
+    else if (g.bounded_y)      // after the x fill: whole rows, x halos included
+        hipLaunchKernelGGL(k_halo_y_bounded, dim3((g.Sx + 255) / 256, nzmax, n), dim3(256), 0, ctx->stream, g, L);
     if (anyz)
         hipLaunchKernelGGL(k_halo_z, dim3((unsigned)((g.Sxy + 255) / 256), 1, n), dim3(256), 0, ctx->stream, g, L);
     BZ_LAUNCH_CHECK();
@@ -88,6 +111,6 @@ int bzi_fill_halo(bz_ctx *ctx, double *f, int kind) { return bzi_fill_halos_mult
 
 extern "C" int bz_fill_halo_regions(bz_ctx *ctx, double *field, int kind)
 {
-    if (!ctx || !field || kind < 0 || kind > 3) return BZ_ERR_INVALID;
+    if (!ctx || !field || kind < 0 || kind > 7) return BZ_ERR_INVALID;
     return bzi_fill_halo(ctx, field, kind);
 }

@@ -55,6 +55,9 @@ struct DevGrid {
     double *rqcl_field, *rqr_field, *qcl_field, *qr_field;
     int wrap_y;            // 1: y halos are this rank's own periodic images; 0: y-slab, halos filled by the neighbour ranks
     int flat_y;            // 1: topology (Periodic, Flat, Bounded): Ny = 1, Hy = 0, no y neighbours (per-operator kernels only)
+    int bounded_y;         // 1: topology (Periodic, Bounded, Bounded): walls in y (wrap_y = 0: y neighbours are halo rows — a no-flux row for
+                           // fields that are centres in y, impenetrable wall faces j = 0, Ny for rho v and v; WENO / Centered buffers by row;
+                           // cosine transform along y in the pressure solve; per-operator kernels only)
 
     __host__ __device__ inline long long idx(int i, int j, int k) const {
         return (long long)(i + Hx) + (long long)Sx * ((long long)(j + Hy)) + Sxy * (long long)(k + Hz);
@@ -263,6 +266,7 @@ struct bz_tuning {
     bool graph_debug = false;         // BZ_GRAPH_DEBUG
 };
 void bzi_read_tuning(bz_tuning &t);
+#define BZ_HALO_YFACE 4      // halo kind bit: the field sits on y faces (rho v, v): wall faces instead of a no-flux row on a Bounded y
 struct bz_ctx;
 bool bzi_lean_forcings_ok(const bz_ctx *ctx);
 int bzi_lean_bottom_temperature(bz_ctx *ctx, const double *rth, const double *rq, double *T);

@@ -425,7 +425,12 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     // workgroup in 45 KiB of LDS)
     const bool pow2 = (Nx & (Nx - 1)) == 0, three_pow2 = Nx % 3 == 0 && ((Nx / 3) & (Nx / 3 - 1)) == 0;      // 96, 192, 384, 768: one radix-3 stage
     const bool xf_shape = ((pow2 && Nx >= 16 && Nx <= 1024) || (three_pow2 && Nx >= 96 && Nx <= 768)) && g.Ny % 8 == 0 && !ctx->tune.no_xfft;
-    ctx->xf = !slab && xf_shape && g.wrap_y;
+    ctx->xf = !slab && xf_shape && (g.wrap_y || g.bounded_y);
+    if (g.bounded_y && (!ctx->xf || g.Ny > 4096 || (g.Ny & 1))) {
+        ctx->last_error = "(Periodic, Bounded, Bounded): the cosine-transform solve rides the hand-written x transforms — Nx a power of two in "
+                          "[16, 1024] or 3 * 2^m in [96, 768], Ny a multiple of 8";
+        return BZ_ERR_UNSUPPORTED;
+    }
     ctx->xf_slab = slab && xf_shape;
     int Ny = g.Ny;                       // rows of the spectral block: local rows, or ALL rows in slab mode
     if (slab) {
@@ -455,7 +460,8 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     }
     const double pi = 3.14159265358979323846;
     for (int i = 0; i < nxh_real; ++i) { double s = 2.0 * std::sin(i * pi / Nx) / g.dx; lam_x[i] = s * s; }
-    for (int j = 0; j < Ny; ++j) { double s = 2.0 * std::sin(j * pi / Ny) / g.dy; lam_y[j] = s * s; }
+    // Bounded y: the cosine modes of the staggered Neumann problem (Oceananigans poisson_eigenvalues(N, L, dim, ::Bounded))
+    for (int j = 0; j < Ny; ++j) { double s = 2.0 * std::sin(j * pi / (g.bounded_y ? 2.0 * Ny : (double)Ny)) / g.dy; lam_y[j] = s * s; }
 
     double *d_cols = nullptr;
     size_t ncols = (size_t)3 * Nz + nxh_real + Ny;
@@ -566,9 +572,60 @@ void bzi_poisson_teardown(bz_ctx *ctx)
 
 // solve!(phi, FourierTridiagonalPoissonSolver) on the source term held in ctx->d_rhs; the zero-mean
 // solution is left in ctx->d_rhs (contiguous Nx*Ny*Nz).
+// Cosine transform along a Bounded y through the complex FFT of the same length (Makhoul 1980), on the ky-contiguous lines of the
+// transposed spectrum.  The transform is real-linear and the lines are complex (x is already transformed), so the combination steps are
+// written in their complex-linear form.  N = Ny (even), w_k = exp(-i pi k / (2N)):
+//   forward  (DCT-II, X_k = 2 sum_n x_n cos(pi k (2n+1) / (2N))):  v_n = x_{2n}, v_{N-1-n} = x_{2n+1};  V = FFT(v);  X_k = w_k V_k + conj(w_k) V_{(N-k) mod N}
+//   backward (its inverse up to N, like the unnormalised FFT pair): V_k = conj(w_k) (X_k - i X_{N-k}) / 2 (X_N = 0);  v = N IFFT(V);  x_{2n} = v_n, x_{2n+1} = v_{N-1-n}
+// MODE 0: forward permutation, 1: forward combination, 2: backward combination, 3: backward permutation.  One line per workgroup, staged in LDS.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dct_line(double2 *__restrict__ hat, int N)
+{
+    extern __shared__ double2 dct_line[];
+    double2 *line = hat + (long long)blockIdx.x * N;
+    for (int m = threadIdx.x; m < N; m += 256) dct_line[m] = line[m];
+    __syncthreads();
+    for (int m = threadIdx.x; m < N; m += 256) {
+        double2 out;
+        if (MODE == 0) out = (m < N / 2) ? dct_line[2 * m] : dct_line[2 * (N - 1 - m) + 1];
+        else if (MODE == 3) out = (m & 1) ? dct_line[N - 1 - (m - 1) / 2] : dct_line[m / 2];
+        else {
+            const double ang = 3.14159265358979323846 * (double)m / (2.0 * (double)N);      // w_m = cs - i sn
+            const double sn = sin(ang), cs = cos(ang);
+            if (MODE == 1) {
+                const double2 a = dct_line[m], b = dct_line[m ? N - m : 0];
+                // w a + conj(w) b
+                out = make_double2(cs * a.x + sn * a.y + cs * b.x - sn * b.y, cs * a.y - sn * a.x + cs * b.y + sn * b.x);
+            } else {
+                const double2 a = dct_line[m], b = m ? dct_line[N - m] : make_double2(0.0, 0.0);
+                const double2 d = make_double2(a.x + b.y, a.y - b.x);          // X_m - i X_{N-m}
+                out = make_double2(0.5 * (cs * d.x - sn * d.y), 0.5 * (cs * d.y + sn * d.x));      // conj(w) d / 2
+            }
+        }
+        line[m] = out;
+    }
+}
+
 int bzi_xf_y(bz_ctx *ctx, bool forward)
 {
-    BZ_FFT(hipfftExecZ2Z(ctx->plan_y, ctx->d_hat, ctx->d_hat, forward ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+    const DevGrid &g = ctx->dg;
+    if (!g.bounded_y) {
+        BZ_FFT(hipfftExecZ2Z(ctx->plan_y, ctx->d_hat, ctx->d_hat, forward ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+        return BZ_OK;
+    }
+    const unsigned lines = (unsigned)(ctx->NXH * g.Nz);
+    const size_t lds = (size_t)g.Ny * sizeof(double2);
+    double2 *hat = (double2 *)ctx->d_hat;
+    if (forward) {
+        hipLaunchKernelGGL(k_dct_line<0>, dim3(lines), dim3(256), lds, ctx->stream, hat, g.Ny);
+        BZ_FFT(hipfftExecZ2Z(ctx->plan_y, ctx->d_hat, ctx->d_hat, HIPFFT_FORWARD));
+        hipLaunchKernelGGL(k_dct_line<1>, dim3(lines), dim3(256), lds, ctx->stream, hat, g.Ny);
+    } else {
+        hipLaunchKernelGGL(k_dct_line<2>, dim3(lines), dim3(256), lds, ctx->stream, hat, g.Ny);
+        BZ_FFT(hipfftExecZ2Z(ctx->plan_y, ctx->d_hat, ctx->d_hat, HIPFFT_BACKWARD));
+        hipLaunchKernelGGL(k_dct_line<3>, dim3(lines), dim3(256), lds, ctx->stream, hat, g.Ny);
+    }
+    BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
 
@@ -670,7 +727,7 @@ extern "C" int bz_compute_pressure_correction(bz_ctx *ctx, const bz_state *s, do
         return BZ_ERR_UNSUPPORTED;
     }
     double *mf[3] = {s->rho_u, s->rho_v, s->rho_w};
-    int mk[3] = {0, 0, 1};
+    int mk[3] = {0, BZ_HALO_YFACE, 1};
     int rc = bzi_fill_halos_multi(ctx, mf, mk, 3);   // anelastic_time_stepping.jl:29
     if (rc) return rc;
     rc = bzi_poisson_solve(ctx, s, dt);

@@ -18,6 +18,15 @@
 
 #define TYB 4
 
+// Bounded y ((Periodic, Bounded, Bounded)): the WENO buffer that fits at y-face / y-centre j — wave-uniform (a wavefront is one row) —
+// and the Centered advecting-flux interpolation of the same order, as in z (symm_z_face below); 3 everywhere on a periodic y
+__device__ __forceinline__ int by_face(const DevGrid &g, int j) { return g.bounded_y ? bz_buffer_face(j, g.Ny) : 3; }
+__device__ __forceinline__ int by_center(const DevGrid &g, int j) { return g.bounded_y ? bz_buffer_center(j, g.Ny) : 3; }
+__device__ __forceinline__ double symm_y(double qm2, double qm1, double q0, double qp1, int B)
+{
+    return (B == 3) ? bz_symm4(qm2, qm1, q0, qp1) : bz_symm2(qm1, q0);
+}
+
 __device__ __forceinline__ double flux_z_scalar(const DevGrid &g, double wt, double m3, double m2,
                                                 double m1, double p0, double p1, double p2, int kface)
 {
@@ -57,8 +66,8 @@ __global__ __launch_bounds__(64 * TYB) void k_scalar_tendency(DevGrid g, double 
         if (!g.flat_y) {      // a Flat y direction has no faces
             double ym3 = c[n - 3 * sy], ym2 = c[n - 2 * sy], ym1 = c[n - sy], yp1 = c[n + sy], yp2 = c[n + 2 * sy], yp3 = c[n + 3 * sy];
             double v0 = v[n], v1 = v[n + sy];
-            Fy_lo = rho * ((Ay * v0) * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0));
-            Fy_hi = rho * ((Ay * v1) * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, v1 > 0.0));
+            Fy_lo = rho * ((Ay * v0) * bz_upB(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0, by_face(g, j)));
+            Fy_hi = rho * ((Ay * v1) * bz_upB(ym2, ym1, z0, yp1, yp2, yp3, v1 > 0.0, by_face(g, j + 1)));
         }
 
         Gc[n] = -(g.Vinv_c[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(64 * TYB) void k_u_tendency(DevGrid g, double *__re
             double vt_lo = bz_symm4(Ay * rv[n - 2], Ay * rv[n - 1], Ay * rv[n], Ay * rv[n + 1]);
             double vt_hi = bz_symm4(Ay * rv[n + sy - 2], Ay * rv[n + sy - 1], Ay * rv[n + sy], Ay * rv[n + sy + 1]);
             double ym3 = u[n - 3 * sy], ym2 = u[n - 2 * sy], ym1 = u[n - sy], yp1 = u[n + sy], yp2 = u[n + 2 * sy], yp3 = u[n + 3 * sy];
-            Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
-            Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+            Fy_lo = vt_lo * bz_upB(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0, by_face(g, j));
+            Fy_hi = vt_hi * bz_upB(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0, by_face(g, j + 1));
         }
 
         Gu[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
@@ -134,11 +143,11 @@ __global__ __launch_bounds__(64 * TYB) void k_u_tendency(DevGrid g, double *__re
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double flux_Wv(const DevGrid &g, const double *__restrict__ rw, long long nf,
                                           double m3, double m2, double m1, double p0, double p1, double p2,
-                                          int kface)
+                                          int kface, int j)
 {   // at (c,f,f): Centered4 in y of Az*rho_w to y-face j
     double Az = g.Az;
     long long sy = g.Sx;
-    double wt = g.flat_y ? Az * rw[nf] : bz_symm4(Az * rw[nf - 2 * sy], Az * rw[nf - sy], Az * rw[nf], Az * rw[nf + sy]);
+    double wt = g.flat_y ? Az * rw[nf] : symm_y(Az * rw[nf - 2 * sy], Az * rw[nf - sy], Az * rw[nf], Az * rw[nf + sy], by_face(g, j));
     double vR = bz_upB(m3, m2, m1, p0, p1, p2, wt > 0.0, bz_buffer_face(kface, g.Nz));
     return wt * vR;
 }
@@ -152,23 +161,25 @@ __global__ __launch_bounds__(64 * TYB) void k_v_tendency(DevGrid g, double *__re
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * TYB + threadIdx.y;
     if (i >= g.Nx || j >= g.Ny) return;
+    if (g.bounded_y && j == 0) return;               // the wall face is never updated (like w at k = 0)
     const int k0 = blockIdx.z * kchunk;
     const int k1 = min(k0 + kchunk, g.Nz);
     const long long sy = g.Sx, sz = g.Sxy;
     long long n = g.idx(i, j, k0);
+    const int Bf = by_face(g, j), Bc = by_center(g, j), Bcm = by_center(g, j - 1);
 
     double zm3 = v[n - 3 * sz], zm2 = v[n - 2 * sz], zm1 = v[n - sz], z0 = v[n], zp1 = v[n + sz], zp2 = v[n + 2 * sz];
-    double Fz_lo = flux_Wv(g, rw, n, zm3, zm2, zm1, z0, zp1, zp2, k0);
+    double Fz_lo = flux_Wv(g, rw, n, zm3, zm2, zm1, z0, zp1, zp2, k0, j);
 
     for (int k = k0; k < k1; ++k, n += sz) {
         double zp3 = v[n + 3 * sz];
-        double Fz_hi = flux_Wv(g, rw, n + sz, zm2, zm1, z0, zp1, zp2, zp3, k + 1);
+        double Fz_hi = flux_Wv(g, rw, n + sz, zm2, zm1, z0, zp1, zp2, zp3, k + 1, j);
         const double Ax = g.Ax[k], Ay = g.Ay[k];
 
         // x: F_Uv at x-faces i (lo) and i+1 (hi); advecting flux = Centered4 in y of Ax*rho_u
         // (Flat y: the y face of the v cell coincides with its centre, no interpolation)
-        double ut_lo = g.flat_y ? Ax * ru[n] : bz_symm4(Ax * ru[n - 2 * sy], Ax * ru[n - sy], Ax * ru[n], Ax * ru[n + sy]);
-        double ut_hi = g.flat_y ? Ax * ru[n + 1] : bz_symm4(Ax * ru[n + 1 - 2 * sy], Ax * ru[n + 1 - sy], Ax * ru[n + 1], Ax * ru[n + 1 + sy]);
+        double ut_lo = g.flat_y ? Ax * ru[n] : symm_y(Ax * ru[n - 2 * sy], Ax * ru[n - sy], Ax * ru[n], Ax * ru[n + sy], Bf);
+        double ut_hi = g.flat_y ? Ax * ru[n + 1] : symm_y(Ax * ru[n + 1 - 2 * sy], Ax * ru[n + 1 - sy], Ax * ru[n + 1], Ax * ru[n + 1 + sy], Bf);
         double xm3 = v[n - 3], xm2 = v[n - 2], xm1 = v[n - 1], xp1 = v[n + 1], xp2 = v[n + 2], xp3 = v[n + 3];
         double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
         double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
@@ -178,10 +189,11 @@ __global__ __launch_bounds__(64 * TYB) void k_v_tendency(DevGrid g, double *__re
         if (!g.flat_y) {
             double q_m2 = Ay * rv[n - 2 * sy], q_m1 = Ay * rv[n - sy], q_0 = Ay * rv[n], q_p1 = Ay * rv[n + sy], q_p2 = Ay * rv[n + 2 * sy];
             double ym3 = v[n - 3 * sy], ym2 = v[n - 2 * sy], ym1 = v[n - sy], yp1 = v[n + sy], yp2 = v[n + 2 * sy], yp3 = v[n + 3 * sy];
-            double vt_hi = bz_symm4(q_m1, q_0, q_p1, q_p2);
-            double vt_lo = bz_symm4(q_m2, q_m1, q_0, q_p1);
-            Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
-            Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
+            // centre targets: faces j-1 .. j+2 around centre j (hi), j-2 .. j+1 around centre j-1 (lo); order 2 next to a wall
+            double vt_hi = (Bc == 3) ? bz_symm4(q_m1, q_0, q_p1, q_p2) : bz_symm2(q_0, q_p1);
+            double vt_lo = (Bcm == 3) ? bz_symm4(q_m2, q_m1, q_0, q_p1) : bz_symm2(q_m1, q_0);
+            Fy_hi = vt_hi * bz_upB(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0, Bc);
+            Fy_lo = vt_lo * bz_upB(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0, Bcm);
         }
 
         Gv[n] = bz_rk_apply(E.mode, E.dt, E.alpha, E.oma, E.u0, E.u0_out,
@@ -266,8 +278,8 @@ __global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__re
             double vt_lo = symm_z_face(g, g.Ay, rv, n, k, Bf);
             double vt_hi = symm_z_face(g, g.Ay, rv, n + sy, k, Bf);
             double ym3 = w[n - 3 * sy], ym2 = w[n - 2 * sy], ym1 = w[n - sy], yp1 = w[n + sy], yp2 = w[n + 2 * sy], yp3 = w[n + 3 * sy];
-            Fy_lo = vt_lo * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0);
-            Fy_hi = vt_hi * bz_up5(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0);
+            Fy_lo = vt_lo * bz_upB(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0, by_face(g, j));
+            Fy_hi = vt_hi * bz_upB(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0, by_face(g, j + 1));
         }
 
         const double adv = -(g.Vinv_f[k] * ((Fx_hi - Fx_lo) + (Fy_hi - Fy_lo) + (Fz_hi - Fz_lo)));

@@ -170,8 +170,10 @@ class AtmosphereModel:
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
         flat_y = grid.topology == (Periodic, Flat, Bounded)
-        if grid.topology != (Periodic, Periodic, Bounded) and not flat_y:
-            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded) and (Periodic, Flat, Bounded)")
+        bounded_y = grid.topology == (Periodic, Bounded, Bounded)      # walls in y: the reference benchmark driver's PBB option
+        if grid.topology != (Periodic, Periodic, Bounded) and not flat_y and not bounded_y:
+            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded), (Periodic, Flat, Bounded) and "
+                                      "(Periodic, Bounded, Bounded)")
         if advection is None:
             advection = Centered(order=2)          # the reference's default (resolved before the Flat guard: ADVICE r02)
         _base = advection.get("momentum") or next(iter(advection.values())) if isinstance(advection, dict) else advection
@@ -181,6 +183,12 @@ class AtmosphereModel:
             # kernels drop the y terms
             raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model without Coriolis / forcings / flux boundary conditions is implemented")
         formulation = str(formulation).lstrip(":")
+        if bounded_y and (isinstance(advection, dict) or not isinstance(_base, WENO) or _base.order != 5 or
+                          getattr(_base, "bounds", None) is not None or closure is not None or microphysics is not None or tracers or
+                          formulation != "LiquidIcePotentialTemperature"):
+            # Coriolis, forcings and bottom flux boundary conditions reach their y neighbours through the halo rows (as on y-slabs)
+            raise NotImplementedError("(Periodic, Bounded, Bounded): the dry WENO(order = 5) model without closure / microphysics / "
+                                      "tracers is implemented")
         if formulation not in ("LiquidIcePotentialTemperature", "StaticEnergy"):
             raise NotImplementedError(f"formulation {formulation!r} is not implemented")
         self.formulation = formulation
@@ -434,7 +442,7 @@ class AtmosphereModel:
 # ---------------------------------------------------------------------------
 def fill_halo_regions_(model, field, kind=None):
     if kind is None:
-        kind = 1 if field.zface else 0
+        kind = (1 if field.zface else 0) + (4 if field.loc[1] is Face else 0)      # + 4: a y-face field (wall faces on a Bounded y)
     model._check(model._lib.bz_fill_halo_regions(model._ctx, C.c_void_p(field.ptr()), kind), "bz_fill_halo_regions")
 
 

@@ -98,10 +98,40 @@ def test_bounded_y_tendencies_match_oracle(oracle, bz):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [(32, 16, 12), (64, 24, 16)])
-def test_bounded_y_steps_match_oracle(oracle, bz, size):
+@pytest.mark.parametrize("size", [(32, 16, 12), (96, 40, 10), (16, 128, 8)])
+def test_bounded_y_pressure_solve_matches_oracle(oracle, bz, size):
+    """solve_for_anelastic_pressure! with the cosine transform along y (k_dct_line around the contiguous y plan; Nx = 96 takes the
+    radix-3 x stage): phi against the oracle's scipy DCT + complex Thomas solve, then the projected momentum."""
     g, om = _oracle(oracle, size=size)
     grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Bounded, bz.Bounded), **EXT)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO(order=5))
+    rng = np.random.default_rng(7)
+    g.interior(om.ru)[...] = rng.standard_normal(g.interior(om.ru).shape)
+    g.interior(om.rv)[...] = rng.standard_normal(g.interior(om.rv).shape)
+    g.interior(om.rw, True)[1:-1] = rng.standard_normal(g.interior(om.rw, True)[1:-1].shape)
+    om.fill_momentum_halos()
+    for n, k in (("ru", "ρu"), ("rv", "ρv"), ("rw", "ρw")):
+        hm.momentum[k].parent.copy_(__import__("torch").from_numpy(getattr(om, n)))
+    om.compute_pressure_correction(0.7)
+    bz.compute_pressure_correction_(hm, 0.7)
+    hm.synchronize()
+    want = g.interior(om.phi)
+    assert relerr(hm.dynamics.pressure_anomaly.interior_cpu(), want) < 1e-11
+    om.make_pressure_correction(0.7)
+    bz.make_pressure_correction_(hm, 0.7)
+    for n, k in (("ru", "ρu"), ("rv", "ρv"), ("rw", "ρw")):
+        assert relerr(hm.momentum[k].interior_cpu(), g.interior(getattr(om, n), n == "rw")) < 1e-11, n
+    assert hm.max_abs_divergence() < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,stretched", [((32, 16, 12), False), ((64, 24, 16), True)])
+def test_bounded_y_steps_match_oracle(oracle, bz, size, stretched):
+    z = 1000.0 * np.linspace(0.0, 1.0, size[2] + 1) ** 1.3 if stretched else EXT["z"]
+    ext = dict(EXT, z=z)
+    g = oracle.Grid(size, topology=TOPO, **ext)
+    om = oracle.OracleModel(g, potential_temperature=300.0)
+    grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Bounded, bz.Bounded), **ext)
     hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO(order=5))
     om.set(theta=theta0, u=u0, v=v0)
     hm.set(θ=theta0, u=u0, v=v0)

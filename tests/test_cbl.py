@@ -9,11 +9,11 @@ import pytest
 from helpers import PROG
 
 
-def _oracle_cbl(oracle, size, order=5):
+def _oracle_cbl(oracle, size, order=5, topology=("Periodic", "Periodic", "Bounded")):
     from oracle.forcings import ColumnForcings
     from breeze_jl_amd import benchmarks as bm
     C = bm.CBL
-    og = oracle.Grid(size, x=(0.0, C["Lx"]), y=(0.0, C["Ly"]), z=(0.0, C["Lz"]), halo=(5, 5, 5))
+    og = oracle.Grid(size, x=(0.0, C["Lx"]), y=(0.0, C["Ly"]), z=(0.0, C["Lz"]), halo=(5, 5, 5), topology=topology)
     f, rho0 = bm.cbl_coriolis_parameter(), bm.cbl_surface_density()
     ones = np.ones(size[2])
     F = ColumnForcings(Fu=-f * C["Vg"] * ones, Fv=f * C["Ug"] * ones, coriolis_f=f, flux_theta=rho0 * C["heat_flux"],
@@ -60,13 +60,35 @@ def test_cbl_float64_steps_match_oracle(oracle, bz, order):
 
 
 @pytest.mark.gpu
-def test_cbl_float32_steps_match_the_float64_oracle(oracle, bz):
+def test_cbl_with_walls_in_y_matches_oracle(oracle, bz):
+    """the benchmark driver's PBB topology (benchmarking/run_benchmarks.jl:130: (Periodic, Bounded, Bounded)) with the case's full
+    physics list, three Float64 steps against the oracle; the wall faces of rho v stay closed"""
+    size = (32, 24, 16)
+    om = _oracle_cbl(oracle, size, topology=("Periodic", "Bounded", "Bounded"))
+    hm = bz.benchmarks.convective_boundary_layer(size, float_type=np.float64, topology=(bz.Periodic, bz.Bounded, bz.Bounded))
+    for _ in range(3):
+        om.time_step(0.5)
+        hm.time_step(0.5)
+    hm.synchronize()
+    g = om.grid
+    mom = max(np.abs(g.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    for n, k in PROG.items():
+        want, got = g.interior(getattr(om, n), zface=(n == "rw")), hm.prognostic_fields()[k].interior_cpu()
+        scale = mom if n in ("ru", "rv", "rw") else max(np.abs(want).max(), 1e-3)
+        assert np.abs(got - want).max() / scale < 1e-9, (n, np.abs(got - want).max() / scale)
+    assert float(hm.momentum["ρv"].interior[:, 0, :].abs().max()) == 0.0
+    assert np.abs(g.interior(om.rv)[:, 1:]).max() > 1e-4          # Coriolis turned the wind: rho v is no longer zero inside
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("walls", [False, True])
+def test_cbl_float32_steps_match_the_float64_oracle(oracle, bz, walls):
     """the case in the precision the reference benchmarks it in (Float32), three steps against the Float64 oracle: App. C tolerances
-    (1e-4 of the field scale after steps)"""
+    (1e-4 of the field scale after steps); walls: the PBB topology"""
     import torch
     size = (32, 24, 16)
-    om = _oracle_cbl(oracle, size)
-    hm = bz.benchmarks.convective_boundary_layer(size, float_type=np.float32)
+    om = _oracle_cbl(oracle, size, topology=("Periodic", "Bounded" if walls else "Periodic", "Bounded"))
+    hm = bz.benchmarks.convective_boundary_layer(size, float_type=np.float32, topology=(bz.Periodic, bz.Bounded if walls else bz.Periodic, bz.Bounded))
     assert hm.momentum["ρu"].parent.dtype == torch.float32
     for _ in range(3):
         om.time_step(0.5)

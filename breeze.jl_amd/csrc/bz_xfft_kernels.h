@@ -12,7 +12,10 @@
 //     make_pressure_correction! straight from LDS in the same kernel was built and measured at 512^3: 2.3 ms with two level buffers
 //     in LDS, 4.0-4.4 ms with the previous level in registers — 168 VGPRs, one workgroup per CU — against 0.6 + 1.5 ms for this
 //     kernel followed by k_project_lean, so it was dropped; so was requesting level k+1 into registers before transforming level k:
-//     the extra registers cost a workgroup per CU and 10-20 % of the rate.)
+//     the extra registers cost a workgroup per CU and 10-20 % of the rate.  Round 3 repeated the prefetch the way that paid in
+//     k_tridiag_coop — unconditional clamped loads into named registers, LDS-only barriers, first level peeled, the ISA waiting row by
+//     row with the stores left in flight: 0.545 -> 0.549 ms in Float64 (100 VGPRs: two workgroups per CU instead of three),
+//     0.367 -> 0.353 ms in Float32.  The loads are not what this kernel waits for; its LDS stages are.)
 // Transform: Stockham autosort, radix-4 stages plus one radix-2 stage when log2(Nx/2) is odd (and a leading radix-3 stage for rows of
 // 3 * 2^m cells), a team of Nx/8 threads per row,
 // twiddles from a table in LDS (exp(-2 pi i t / Nx), t < 3 Nx / 4, computed on the host in the working precision).

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * TYB) void k_scalar_tendency_bounded(DevGrid g,
 
 extern "C" int bz_set_bounds_preserving_advection(bz_ctx *ctx, const bz_bounds_preserving_advection *b)
 {
+    BZ_REJECT_BOUNDED_Y(ctx, b != nullptr, "bz_set_bounds_preserving_advection");
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx) return BZ_ERR_INVALID;
     if (!b) { ctx->bounded_mask = 0; return BZ_OK; }

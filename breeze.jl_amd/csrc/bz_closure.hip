@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void k_closure_scalar(DevGrid g, const double 
 
 extern "C" int bz_set_closure(bz_ctx *ctx, const bz_smagorinsky_lilly *closure, double *eddy_viscosity)
 {
+    BZ_REJECT_BOUNDED_Y(ctx, closure != nullptr, "bz_set_closure");
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx) return BZ_ERR_INVALID;
     if (!closure) { ctx->has_closure = false; ctx->closure_nu = nullptr; return BZ_OK; }

@@ -266,6 +266,14 @@ struct bz_tuning {
     bool graph_debug = false;         // BZ_GRAPH_DEBUG
 };
 void bzi_read_tuning(bz_tuning &t);
+// (Periodic, Bounded, Bounded) contexts run the dry anelastic WENO-5 model with column forcings / bottom fluxes; everything else says so
+#define BZ_REJECT_BOUNDED_Y(ctx, enabling, what)                                                                             \
+    do {                                                                                                                     \
+        if ((ctx) && (ctx)->dg.bounded_y && (enabling)) {                                                                                \
+            (ctx)->last_error = what ": not implemented on a Bounded y (topology (Periodic, Bounded, Bounded))";            \
+            return BZ_ERR_UNSUPPORTED;                                                                                       \
+        }                                                                                                                    \
+    } while (0)
 #define BZ_HALO_YFACE 4      // halo kind bit: the field sits on y faces (rho v, v): wall faces instead of a no-flux row on a Bounded y
 struct bz_ctx;
 bool bzi_lean_forcings_ok(const bz_ctx *ctx);

@@ -74,6 +74,21 @@ def test_order_drops_next_to_the_walls_as_in_z(oracle):
     assert [L.og_buffer_at(j, 12, 1, 0) for j in range(0, 12)] == [1, 2, 3, 3, 3, 3, 3, 3, 3, 3, 2, 1]
 
 
+def test_options_outside_the_walled_scope_raise(bz):
+    """closure, microphysics, tracers, other orders and formulations are not built for a Bounded y: the host says so before touching
+    the device (the library's bz_set_* entry points return BZ_ERR_UNSUPPORTED for the same list)"""
+    grid = bz.RectilinearGrid((16, 16, 8), topology=(bz.Periodic, bz.Bounded, bz.Bounded), **EXT)
+    dyn = lambda: bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0))
+    for kw in (dict(closure=bz.SmagorinskyLilly()), dict(tracers=("a",)), dict(advection=bz.WENO(order=9)),
+               dict(formulation="StaticEnergy"), dict(microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()))):
+        kw.setdefault("advection", bz.WENO(order=5))
+        with pytest.raises(NotImplementedError):
+            bz.AtmosphereModel(grid, dynamics=dyn(), **kw)
+    with pytest.raises(NotImplementedError):
+        bz.RectilinearGrid((16, 16, 8), topology=(bz.Bounded, bz.Periodic, bz.Bounded), **EXT) and \
+            bz.AtmosphereModel(bz.RectilinearGrid((16, 16, 8), topology=(bz.Bounded, bz.Periodic, bz.Bounded), **EXT), advection=bz.WENO(order=5))
+
+
 @pytest.mark.gpu
 def test_bounded_y_tendencies_match_oracle(oracle, bz):
     from helpers import PROG, push_state, randomize

@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 O=$1; shift
 mkdir -p $O
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compressible --no-float32 $*"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compressible $*"      # the Float32 leg rides along (its kernels carry _f32 names)
 run() { name=$1; shift; timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $O/$name -- $B > $O/$name.log 2>&1; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE

@@ -24,14 +24,17 @@ FFT = {"fwd": "poisson_fft_y_forward", "back": "poisson_fft_y_inverse"}      # l
 
 def main():
     d = json.load(open(sys.argv[1]))
-    out = {"note": __doc__.split("—", 1)[1].strip(), "source": sys.argv[1], "per_kernel_group": {}}
-    per = out["per_kernel_group"]
+    out = {"note": __doc__.split("—", 1)[1].strip(), "source": sys.argv[1], "per_kernel_group": {}, "per_kernel_group_float32": {}}
     for k, v in d.items():
         if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
             continue
         rd, wr = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
-        if k in GROUPS:
-            per[GROUPS[k]] = {"kernel": k, "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+        # kernels of the Float32 twin carry an _f32 suffix on their name (tools/gen_f32_sources.py); rocFFT's single-precision plans say _sp_
+        f32 = "_f32" in k.split("<")[0].split("(")[0] or (k.startswith("fft_rtc_") and "_sp_" in k)
+        per = out["per_kernel_group_float32" if f32 else "per_kernel_group"]
+        base = k.replace("_f32", "", 1) if f32 else k
+        if base in GROUPS:
+            per[GROUPS[base]] = {"kernel": k, "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
         elif k.startswith("fft_rtc_"):
             g = FFT["fwd" if "_fwd_" in k else "back"]
             e = per.setdefault(g, {"kernel": "rocFFT batched 1-D C2C plan along y", "read_bytes": 0.0, "write_bytes": 0.0, "hbm_bytes_per_launch": 0.0})

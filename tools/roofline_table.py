@@ -15,19 +15,26 @@ sys.path.insert(0, ROOT)
 
 def main():
     bench, pmc = sys.argv[1], sys.argv[2]
+    f32 = "--float32" in sys.argv[3:]          # the Float32 leg of the same bench line (b["float32"]), 4-byte words
     from bench import COMPULSORY_WORDS, WORDS_PER_CELL
     b = json.load(open(bench))
-    p = json.load(open(pmc))["per_kernel_group"]
+    p = json.load(open(pmc)).get("per_kernel_group_float32" if f32 else "per_kernel_group", {})
+    word = 4 if f32 else 8
+    if f32:
+        top = b
+        b = dict(b["float32"])
+        b["config"] = top["config"]
+        b.setdefault("kernel_launches_per_step", top.get("kernel_launches_per_step", {}))
     cells = 1
     for n in b["config"]["grid_per_gpu"] if "grid_per_gpu" in b["config"] else b["config"]["grid"]:
         cells *= n
     launches = b.get("kernel_launches_per_step", {})
-    print(f"# Per-kernel roofline, {b['config']['workload']}\n")
-    print(f"Step: {b['ms_per_step']:.2f} ms, {b['value'] / 1e9:.3f} Gcells/s, step fraction of the 8 TB/s roofline at 2000 B/cell/step: "
+    print(f"# Per-kernel roofline, {b['config']['workload']}" + (" — the Float32 leg (libbreeze_hip_f32.so)" if f32 else "") + "\n")
+    print(f"Step: {b['ms_per_step']:.2f} ms, {b['value'] / 1e9:.3f} Gcells/s, step fraction of the 8 TB/s roofline at {b['step_roofline'].get('algorithmic_bytes_per_cell_step', 2000)} B/cell/step: "
           f"{b['step_roofline']['frac']:.3f}.  Source: `{os.path.basename(bench)}` (HIP events on the launch stream), "
           f"`{os.path.basename(pmc)}` (rocprofv3 PMC, HBM-side bytes per launch).\n")
     print("Columns: `compulsory` = every distinct 3-D array the (fused) kernel must read or write, once — what `bench.py`'s `roofline.achieved` is priced in; "
-          "`contract` = SURVEY §8(d)'s words of the unfused kernel list the fused kernel replaces (the step figure of 250 words = 2000 B per cell and step); "
+          "`contract` = SURVEY §8(d)'s words of the unfused kernel list the fused kernel replaces (the step figure of 250 words per cell and step); "
           "`PMC` = bytes seen at the L2-fabric boundary (FETCH_SIZE / WRITE_SIZE passes).\n")
     print("| kernel group | launches/step | ms/step | ms/launch | compulsory GB/launch | compulsory TB/s (frac of 8) | contract GB/launch | contract frac of 8 TB/s | PMC GB/launch | PMC TB/s (frac of 8) |")
     print("|---|---|---|---|---|---|---|---|---|---|")
@@ -37,10 +44,10 @@ def main():
         n = launches.get(name, 3)
         per_launch = ms / n
         w = WORDS_PER_CELL.get(name)
-        alg = w * 8 * cells / 1e9 if w else None
+        alg = w * word * cells / 1e9 if w else None
         traffic = p.get(name, {}).get("hbm_bytes_per_launch")
         cw = COMPULSORY_WORDS.get(name)
-        comp = cw * 8 * cells / 1e9 if cw else None
+        comp = cw * word * cells / 1e9 if cw else None
         row = [name, f"{n:g}", f"{ms:.2f}", f"{per_launch:.3f}",
                f"{comp:.2f}" if comp else "—", f"{comp / per_launch:.2f} ({comp / per_launch / 8:.2f})" if comp else "—",
                f"{alg:.2f}" if alg else "—", f"{alg / per_launch / 8:.3f}" if alg else "—",

@@ -209,7 +209,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     if (grid->topo[0] != BZ_PERIODIC || (grid->topo[1] != BZ_PERIODIC && !flat_y && !bounded_y) || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
     if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode)) return BZ_ERR_UNSUPPORTED;
-    if (bounded_y && (slab_mode || compressible || weno_order != 5 || grid->Ny < 2 * grid->Hy)) return BZ_ERR_UNSUPPORTED;
+    if (bounded_y && (slab_mode || compressible || weno_order == 2 || grid->Ny < 2 * grid->Hy)) return BZ_ERR_UNSUPPORTED;
     if (grid->Hx < 3 || (!flat_y && grid->Hy < 3) || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
     // Oceananigans: N >= H in every direction (k_halo_y's wrap copy would otherwise read a halo row that is not filled yet)
     if (grid->Nx < grid->Hx || grid->Ny < grid->Hy || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;

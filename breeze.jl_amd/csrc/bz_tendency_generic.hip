@@ -68,6 +68,12 @@ __device__ __forceinline__ int buf_center(int idx, int N)
     return 1;
 }
 
+// Bounded y ((Periodic, Bounded, Bounded)): the buffer of row / y-face jj — wave-uniform, like the level's in z; R on a periodic y
+template <int R>
+__device__ __forceinline__ int by_face_g(const DevGrid &g, int jj) { return g.bounded_y ? buf_face<R>(jj, g.Ny) : R; }
+template <int R>
+__device__ __forceinline__ int by_center_g(const DevGrid &g, int jj) { return g.bounded_y ? buf_center<R>(jj, g.Ny) : R; }
+
 // upwind-biased value at FACE idx of centred data (p at cell idx) / at CENTRE idx of face data (p at face idx), stride s, buffer B.
 // The 2 B values straddling the target are loaded once; the biased stencil is q[0 .. 2B-2] or its mirror image q[2B-1 .. 1], picked with
 // lane-mask selects (bz_sel: the VOP3 select; the ternary form compiled to two loads per value and VCC selects).
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__
     const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
     auto fx = [&](long long m) { const double ut = u[m]; return g.rho[k] * ((g.Ax[k] * ut) * biased_face_g(c + m, 1, ut > 0.0, R)); };
-    auto fy = [&](long long m) { const double vt = v[m]; return g.rho[k] * ((g.Ay[k] * vt) * biased_face_g(c + m, sy, vt > 0.0, R)); };
+    auto fy = [&](long long m, int jj) { const double vt = v[m]; return g.rho[k] * ((g.Ay[k] * vt) * biased_face_g(c + m, sy, vt > 0.0, by_face_g<R>(g, jj))); };
     auto fz = [&](long long m, int kf) {
         const double wt = w[m];
         return g.rho_f[kf] * ((g.Az * wt) * biased_face_g(c + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz)));
@@ -189,13 +195,13 @@ __global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__
     if (PASS == 1) {
         const bool cj = IN(j, 0, g.Ny - 1);
         if (cj) F.x[n] = fx(n);
-        if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = fy(n);
+        if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = fy(n, j);
         if (cj) F.z[n] = fz(n, k);
         return;
     }
     double dx, dy, dz;
     if (PASS == 2) { dx = F.x[n + W.xp] - F.x[n]; dy = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; dz = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
-    else { dx = fx(n + 1) - fx(n); dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n); dz = fz(n + sz, k + 1) - fz(n, k); }      // a Flat y has no faces
+    else { dx = fx(n + 1) - fx(n); dy = g.flat_y ? 0.0 : fy(n + sy, j + 1) - fy(n, j); dz = fz(n + sz, k + 1) - fz(n, k); }      // a Flat y has no faces
     Gc[n] = rk_out(F, -(g.Vinv_c[k] * (dx + dy + dz)), n);
 }
 
@@ -215,9 +221,9 @@ __global__ __launch_bounds__(256) void k_u_tendency_g(DevGrid g, double *__restr
         const double ut = symm_g(ru, m, 1, R, -(R - 2), none, 0, g.Ax[k]);
         return ut * biased_center_g(u + m, 1, ut > 0.0, R);
     };
-    auto FVu = [&](long long m) {      // at (f, f, c): Centered in x of Ay rho_v to x-face
+    auto FVu = [&](long long m, int jj) {      // at (f, f, c): Centered in x of Ay rho_v to x-face
         const double vt = symm_g(rv, m, 1, R, -(R - 1), none, 0, g.Ay[k]);
-        return vt * biased_face_g(u + m, sy, vt > 0.0, R);
+        return vt * biased_face_g(u + m, sy, vt > 0.0, by_face_g<R>(g, jj));
     };
     auto FWu = [&](long long m, int kf) {
         const double wt = symm_g(rw, m, 1, R, -(R - 1), none, 0, g.Az);
@@ -226,13 +232,13 @@ __global__ __launch_bounds__(256) void k_u_tendency_g(DevGrid g, double *__restr
     if (PASS == 1) {
         const bool cj = IN(j, 0, g.Ny - 1);
         if (cj) F.x[n] = FUu(n);
-        if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = FVu(n);
+        if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = FVu(n, j);
         if (cj) F.z[n] = FWu(n, k);
         return;
     }
     double a, b, c;
     if (PASS == 2) { a = F.x[n] - F.x[n + W.xm]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
-    else { a = FUu(n) - FUu(n - 1); b = g.flat_y ? 0.0 : FVu(n + sy) - FVu(n); c = FWu(n + sz, k + 1) - FWu(n, k); }
+    else { a = FUu(n) - FUu(n - 1); b = g.flat_y ? 0.0 : FVu(n + sy, j + 1) - FVu(n, j); c = FWu(n + sz, k + 1) - FWu(n, k); }
     Gu[n] = rk_out(F, -(g.Vinv_c[k] * (a + b + c)), n);
 }
 
@@ -247,28 +253,32 @@ __global__ __launch_bounds__(256) void k_v_tendency_g(DevGrid g, double *__restr
     const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
     const ColPtr none(nullptr);
+    // Centered in y to the y-face of this row: order 2 (B - 1) with the buffer that fits (B = R on a periodic y), like the z interpolations of k_w_tendency_g
+    const int Bfy = by_face_g<R>(g, j), hfy = Bfy > 2 ? Bfy - 1 : 1;
     auto FUv = [&](long long m) {
-        const double ut = g.flat_y ? g.Ax[k] * ru[m] : symm_g(ru, m, sy, R, -(R - 1), none, 0, g.Ax[k]);      // Iy of a Flat direction: identity
+        const double ut = g.flat_y ? g.Ax[k] * ru[m] : symm_g(ru, m, sy, Bfy, -hfy, none, 0, g.Ax[k]);      // Iy of a Flat direction: identity
         return ut * biased_face_g(v + m, 1, ut > 0.0, R);
     };
-    auto FVv = [&](long long m) {
-        const double vt = symm_g(rv, m, sy, R, -(R - 2), none, 0, g.Ay[k]);
-        return vt * biased_center_g(v + m, sy, vt > 0.0, R);
+    auto FVv = [&](long long m, int jc) {      // at centre jc
+        const int B = by_center_g<R>(g, jc), h = B > 2 ? B - 1 : 1;
+        const double vt = symm_g(rv, m, sy, B, -(h - 1), none, 0, g.Ay[k]);
+        return vt * biased_center_g(v + m, sy, vt > 0.0, B);
     };
     auto FWv = [&](long long m, int kf) {
-        const double wt = g.flat_y ? g.Az * rw[m] : symm_g(rw, m, sy, R, -(R - 1), none, 0, g.Az);
+        const double wt = g.flat_y ? g.Az * rw[m] : symm_g(rw, m, sy, Bfy, -hfy, none, 0, g.Az);
         return wt * biased_face_g(v + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz));
     };
     if (PASS == 1) {
         const bool cj = IN(j, 0, g.Ny - 1);
         if (cj) F.x[n] = FUv(n);
-        if (!g.flat_y && IN(j, ext_y ? -1 : 0, g.Ny - 1)) F.y[n] = FVv(n);
+        if (!g.flat_y && IN(j, ext_y ? -1 : 0, g.Ny - 1)) F.y[n] = FVv(n, j);
         if (cj) F.z[n] = FWv(n, k);
         return;
     }
+    if (g.bounded_y && j == 0) return;      // the wall face is never updated
     double a, b, c;
     if (PASS == 2) { a = F.x[n + W.xp] - F.x[n]; b = g.flat_y ? 0.0 : F.y[n] - F.y[n + W.ym]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
-    else { a = FUv(n + 1) - FUv(n); b = g.flat_y ? 0.0 : FVv(n) - FVv(n - sy); c = FWv(n + sz, k + 1) - FWv(n, k); }
+    else { a = FUv(n + 1) - FUv(n); b = g.flat_y ? 0.0 : FVv(n, j) - FVv(n - sy, j - 1); c = FWv(n + sz, k + 1) - FWv(n, k); }
     Gv[n] = rk_out(F, -(g.Vinv_c[k] * (a + b + c)), n);
 }
 
@@ -291,11 +301,11 @@ __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restr
         const double ut = symm_g(ru, m, sz, Bf, -h, g.Ax, k, 0.0);
         return ut * biased_face_g(w + m, 1, ut > 0.0, R);
     };
-    auto FVw = [&](long long m) {
+    auto FVw = [&](long long m, int jj) {
         const int Bf = buf_face<R>(k, g.Nz);
         const int h = Bf > 2 ? Bf - 1 : 1;
         const double vt = symm_g(rv, m, sz, Bf, -h, g.Ay, k, 0.0);
-        return vt * biased_face_g(w + m, sy, vt > 0.0, R);
+        return vt * biased_face_g(w + m, sy, vt > 0.0, by_face_g<R>(g, jj));
     };
     auto FWw = [&](long long m, int kc) {      // at centre kc
         const int B = buf_center<R>(kc, g.Nz);
@@ -306,13 +316,13 @@ __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restr
     if (PASS == 1) {
         const bool cj = IN(j, 0, g.Ny - 1), ck = k >= 1;
         if (cj && ck) F.x[n] = FUw(n);
-        if (!g.flat_y && ck && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = FVw(n);
+        if (!g.flat_y && ck && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = FVw(n, j);
         if (cj) F.z[n] = FWw(n, k);
         return;
     }
     double a, b, c;
     if (PASS == 2) { a = F.x[n + W.xp] - F.x[n]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = F.z[n] - F.z[n - sz]; }
-    else { a = FUw(n + 1) - FUw(n); b = g.flat_y ? 0.0 : FVw(n + sy) - FVw(n); c = FWw(n, k) - FWw(n - sz, k - 1); }
+    else { a = FUw(n + 1) - FUw(n); b = g.flat_y ? 0.0 : FVw(n + sy, j + 1) - FVw(n, j); c = FWw(n, k) - FWw(n - sz, k - 1); }
     const double adv = -(g.Vinv_f[k] * (a + b + c));
     if (BUOY) Gw[n] = rk_out(F, adv + 0.5 * (bz_buoyancy(g, T, qv, n - sz, k - 1) + bz_buoyancy(g, T, qv, n, k)), n);
     else Gw[n] = adv;

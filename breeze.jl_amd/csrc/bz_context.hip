@@ -130,7 +130,6 @@ extern "C" int bz_set_formulation(bz_ctx *ctx, int formulation)
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx || formulation < 0 || formulation > 1) return BZ_ERR_INVALID;
     if (ctx->compressible && formulation != 0) return BZ_ERR_UNSUPPORTED;
-    BZ_REJECT_BOUNDED_Y(ctx, formulation != 0, "bz_set_formulation(StaticEnergy)");
     ctx->dg.formulation = formulation;
     return BZ_OK;
 }
@@ -140,7 +139,6 @@ extern "C" int bz_set_formulation(bz_ctx *ctx, int formulation)
 extern "C" int bz_set_saturation_adjustment(bz_ctx *ctx, const bz_saturation_adjustment *params, double *q_vapor,
                                             double *q_liquid)
 {
-    BZ_REJECT_BOUNDED_Y(ctx, params != nullptr, "bz_set_saturation_adjustment");
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx) return BZ_ERR_INVALID;
     DevGrid &g = ctx->dg;

@@ -196,7 +196,6 @@ extern "C" int bz_kessler_microphysics_update(bz_ctx *ctx, const bz_kessler_micr
 extern "C" int bz_set_kessler_microphysics(bz_ctx *ctx, const bz_kessler_microphysics *params, const bz_kessler_model_fields *f,
                                            double standard_pressure)
 {
-    BZ_REJECT_BOUNDED_Y(ctx, params != nullptr, "bz_set_kessler_microphysics");
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx) return BZ_ERR_INVALID;
     DevGrid &g = ctx->dg;

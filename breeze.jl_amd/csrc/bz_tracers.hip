@@ -37,7 +37,6 @@ __global__ __launch_bounds__(256) void k_rk3_one(DevGrid g, double *__restrict__
 
 extern "C" int bz_set_tracers(bz_ctx *ctx, int32_t n, const bz_tracer_fields *tracers)
 {
-    BZ_REJECT_BOUNDED_Y(ctx, n > 0, "bz_set_tracers");
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx || n < 0 || (n > 0 && !tracers)) return BZ_ERR_INVALID;
     if (n > BZ_MAX_TRACERS) { ctx->last_error = "bz_set_tracers: more than BZ_MAX_TRACERS tracers"; return BZ_ERR_UNSUPPORTED; }

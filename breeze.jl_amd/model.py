@@ -184,11 +184,11 @@ class AtmosphereModel:
             raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model without Coriolis / forcings / flux boundary conditions is implemented")
         formulation = str(formulation).lstrip(":")
         if bounded_y and (isinstance(advection, dict) or not isinstance(_base, WENO) or _base.order not in (5, 7, 9) or
-                          getattr(_base, "bounds", None) is not None or closure is not None or microphysics is not None or tracers or
-                          formulation != "LiquidIcePotentialTemperature"):
-            # Coriolis, forcings and bottom flux boundary conditions reach their y neighbours through the halo rows (as on y-slabs)
-            raise NotImplementedError("(Periodic, Bounded, Bounded): the dry WENO(order = 5 | 7 | 9) model without closure / microphysics / "
-                                      "tracers is implemented")
+                          getattr(_base, "bounds", None) is not None or closure is not None):
+            # Coriolis, forcings and bottom flux boundary conditions reach their y neighbours through the halo rows (as on y-slabs);
+            # microphysics, tracers and the StaticEnergy formulation are column- or cell-local
+            raise NotImplementedError("(Periodic, Bounded, Bounded): WENO(order = 5 | 7 | 9) models without a closure and without "
+                                      "bounds-preserving advection are implemented")
         if formulation not in ("LiquidIcePotentialTemperature", "StaticEnergy"):
             raise NotImplementedError(f"formulation {formulation!r} is not implemented")
         self.formulation = formulation

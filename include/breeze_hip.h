@@ -97,8 +97,8 @@ typedef struct bz_ctx bz_ctx;
  * (order + 1) / 2, anelastic or compressible model without bounds-preserving advection, operator-by-operator anelastic stepping; Centered(order = 2)
  * is weno_order = 2 of libbreeze_hip_centered2.so); topology (Periodic, Periodic, Bounded) or — single-GPU contexts —
  * (Periodic, Flat, Bounded) with Ny = 1, Hy = 0 (the reference's 2-D x-z cases, anelastic and compressible), or (Periodic, Bounded, Bounded) —
- * walls in y, the reference benchmark driver's PBB option (benchmarking/run_benchmarks.jl:130): anelastic WENO(order = 5 | 7 | 9) contexts stepped
- * operator by operator, rho v / v with impenetrable wall faces j = 0 and Ny (face Ny in the first upper halo row), cosine transform along
+ * walls in y, the reference benchmark driver's PBB option (benchmarking/run_benchmarks.jl:130): anelastic WENO(order = 5 | 7 | 9) contexts (no closure, no bounds-preserving
+ * advection) stepped operator by operator, rho v / v with impenetrable wall faces j = 0 and Ny (face Ny in the first upper halo row), cosine transform along
  * y in the pressure solve (Nx a power of two in [16, 1024] or 3 * 2^m, Ny a multiple of 8 up to 4096); halos >= 3, Float64; every extent at least its
  * halo (Oceananigans' own N >= H rule — the reference's 4 x 4 x 4 smoke-test boxes work, odd extents too); anything else returns
  * BZ_ERR_UNSUPPORTED.  Grids with Nx < 2 Hx or Ny < 2 Hy run the per-operator kernels instead of the fused tiers.

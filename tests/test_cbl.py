@@ -122,3 +122,35 @@ def test_cbl_lean_seam_equals_the_operator_sequence(bz):
         assert np.abs(x - y).max() / max(np.abs(y).max(), 1e-3) < 1e-12, k
     for fa, fb in ((a.temperature, b.temperature), (a.velocities["u"], b.velocities["u"]), (a.velocities["w"], b.velocities["w"])):
         assert np.abs(fa.cpu() - fb.cpu()).max() / np.abs(fb.cpu()).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("walls", [False, True])
+def test_cbl_budgets_at_ci_size(bz, walls):
+    """The case at the reference CI's smallest size (256 x 256 x 128) in Float64, ten steps on the tier the bench times (lean seam;
+    walls: the operator-by-operator tier of the PBB topology) — size-independent properties instead of an oracle comparison:
+    the only source of sum(rho theta dz) is the prescribed surface heat flux rho0 * 0.35 K m/s (advection is in flux form, the walls
+    are closed), so the column content grows by exactly flux * dt per step; the momentum stays discretely divergence-free; the drag
+    slows the lowest level."""
+    import torch
+    from breeze_jl_amd import benchmarks as bm
+    size, dt, steps = (256, 256, 128), 0.05, 10
+    m = bz.benchmarks.convective_boundary_layer(size, float_type=np.float64, topology=(bz.Periodic, bz.Bounded if walls else bz.Periodic, bz.Bounded))
+    dz = bm.CBL["Lz"] / size[2]
+
+    def content():
+        return float(m.potential_temperature_density.interior.sum(dtype=torch.float64)) * dz / (size[0] * size[1])
+
+    c0, u_low0 = content(), float(m.velocities["u"].interior[0].mean())
+    for _ in range(steps):
+        m.time_step(dt)
+    m.synchronize()
+    flux = bm.cbl_surface_density() * bm.CBL["heat_flux"]
+    gained = content() - c0
+    assert abs(gained - steps * dt * flux) < 2e-6 * steps * dt * flux, (gained, steps * dt * flux)
+    assert m.max_abs_divergence() < 1e-10
+    assert float(m.velocities["u"].interior[0].mean()) < u_low0 - 1e-4
+    for f in (m.temperature, m.velocities["w"], m.momentum["ρv"]):
+        assert bool(torch.isfinite(f.interior).all())
+    if walls:
+        assert float(m.momentum["ρv"].interior[:, 0, :].abs().max()) == 0.0

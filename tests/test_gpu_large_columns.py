@@ -21,9 +21,11 @@ def _interior(om, name):
     return om.grid.interior(getattr(om, name), zface=(name in ("rw", "w")))
 
 
-@pytest.mark.parametrize("size", [(512, 8, 128), (1024, 8, 128), (64, 64, 512), (128, 16, 256)])
+@pytest.mark.parametrize("size", [(512, 8, 128), (1024, 8, 128), (64, 64, 512), (128, 16, 256), (64, 8, 200), (32, 24, 130)])
 def test_pressure_correction_on_long_columns_matches_oracle(oracle, bz, size):
-    """per-operator Poisson solve + projection, 1e-11: cooperative tridiagonal kernel with 64 segments, full x-transform chunks"""
+    """per-operator Poisson solve + projection, 1e-11: cooperative tridiagonal kernel with 64 segments, full x-transform chunks.
+    Nz = 128 / 256 / 512 take the exact variants `k_tridiag_coop<64, 2 | 4 | 8, true>` (every segment holds Nz / 64 rows, straight-line
+    prefetching loop), Nz = 200 and 130 the general one with ragged segments; several column groups per workgroup in every case."""
     om, hm = make_pair(oracle, bz, size)
     randomize(om, seed=3)
     push_state(om, hm, names=("ru", "rv", "rw"))

@@ -204,8 +204,11 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     // (Periodic, Bounded, Bounded) — the reference benchmark driver's PBB option (benchmarking/run_benchmarks.jl:130): single-GPU
     // anelastic WENO-5 contexts, stepped operator by operator
     const bool bounded_y = grid->topo[1] == BZ_BOUNDED;
-    if (grid->topo[0] != BZ_PERIODIC || (grid->topo[1] != BZ_PERIODIC && !flat_y && !bounded_y) || grid->topo[2] != BZ_BOUNDED)
+    // (Bounded, Flat, Bounded) — walls in x of a 2-D model (examples/cloudy_thermal_bubble.jl:20-24, tropical_cyclone_with_rainband.jl:294)
+    const bool bounded_x = grid->topo[0] == BZ_BOUNDED;
+    if ((grid->topo[0] != BZ_PERIODIC && !bounded_x) || (grid->topo[1] != BZ_PERIODIC && !flat_y && !bounded_y) || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
+    if (bounded_x && (!flat_y || compressible || weno_order == 2 || (grid->Nx & 1) || grid->Nx < 2 * grid->Hx || grid->Nx > 4096)) return BZ_ERR_UNSUPPORTED;
     if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode)) return BZ_ERR_UNSUPPORTED;
     if (bounded_y && (slab_mode || compressible || weno_order == 2 || grid->Ny < 2 * grid->Hy)) return BZ_ERR_UNSUPPORTED;
     if (grid->Hx < 3 || (!flat_y && grid->Hy < 3) || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
@@ -319,6 +322,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.wrap_y = (slab_mode || bounded_y) ? 0 : 1;
     g.flat_y = flat_y ? 1 : 0;
     g.bounded_y = bounded_y ? 1 : 0;
+    g.bounded_x = bounded_x ? 1 : 0;
 
     ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !ctx->tune.no_fused;
 #ifndef BZ_CENTERED2

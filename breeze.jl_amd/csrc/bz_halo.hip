@@ -25,6 +25,11 @@ __global__ __launch_bounds__(64) void k_halo_x(DevGrid g, HaloList L)
     int j = blockIdx.x * 64 + threadIdx.x;
     if (j >= g.Ny) return;
     double *row = L.f[fi] + g.Sxy * kk + (long long)g.Sx * (j + g.Hy);
+    if (g.bounded_x) {      // walls in x: no-flux cell for a centre-in-x field, zero wall faces i = 0, Nx for an x-face field
+        if (L.kind[fi] & BZ_HALO_XFACE) { row[g.Hx] = 0.0; row[g.Hx + g.Nx] = 0.0; }
+        else { row[g.Hx - 1] = row[g.Hx]; row[g.Hx + g.Nx] = row[g.Hx + g.Nx - 1]; }
+        return;
+    }
     for (int h = 0; h < g.Hx; ++h) {
         row[h] = row[h + g.Nx];
         row[g.Hx + g.Nx + h] = row[g.Hx + h];
@@ -111,6 +116,6 @@ int bzi_fill_halo(bz_ctx *ctx, double *f, int kind) { return bzi_fill_halos_mult
 
 extern "C" int bz_fill_halo_regions(bz_ctx *ctx, double *field, int kind)
 {
-    if (!ctx || !field || kind < 0 || kind > 7) return BZ_ERR_INVALID;
+    if (!ctx || !field || kind < 0 || kind > 15) return BZ_ERR_INVALID;
     return bzi_fill_halo(ctx, field, kind);
 }

@@ -55,6 +55,8 @@ struct DevGrid {
     double *rqcl_field, *rqr_field, *qcl_field, *qr_field;
     int wrap_y;            // 1: y halos are this rank's own periodic images; 0: y-slab, halos filled by the neighbour ranks
     int flat_y;            // 1: topology (Periodic, Flat, Bounded): Ny = 1, Hy = 0, no y neighbours (per-operator kernels only)
+    int bounded_x;         // 1: topology (Bounded, Flat, Bounded): walls in x of a 2-D x-z model (the reference's cloudy_thermal_bubble.jl): per-lane
+                           // WENO / Centered buffers in the per-operator kernels, u / rho u with wall faces i = 0, Nx, cosine transform along x
     int bounded_y;         // 1: topology (Periodic, Bounded, Bounded): walls in y (wrap_y = 0: y neighbours are halo rows — a no-flux row for
                            // fields that are centres in y, impenetrable wall faces j = 0, Ny for rho v and v; WENO / Centered buffers by row;
                            // cosine transform along y in the pressure solve; per-operator kernels only)
@@ -274,6 +276,7 @@ void bzi_read_tuning(bz_tuning &t);
             return BZ_ERR_UNSUPPORTED;                                                                                       \
         }                                                                                                                    \
     } while (0)
+#define BZ_HALO_XFACE 8      // the same for x faces (rho u, u) on a Bounded x
 #define BZ_HALO_YFACE 4      // halo kind bit: the field sits on y faces (rho v, v): wall faces instead of a no-flux row on a Bounded y
 struct bz_ctx;
 bool bzi_lean_forcings_ok(const bz_ctx *ctx);
@@ -293,6 +296,7 @@ struct bz_ctx {
     // Poisson
     int NXH = 0;                      // Nx/2+1
     hipfftHandle plan_fwd = 0, plan_inv = 0;
+    hipfftDoubleComplex *d_dctx = nullptr;      // Bounded x: half spectrum of the permuted rows ((Nx/2 + 1) x Nz), between the row transform and the cosine combination
     bool plans_ok = false;
     // chunked Poisson pipeline (bz_poisson.hip): 2-D plans over `pchunk` levels, so that source term -> x transform -> y transform
     // (and y -> x -> projection on the way back) of one level range run back to back while the range sits in the 256 MiB Infinity Cache

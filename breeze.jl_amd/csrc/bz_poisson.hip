@@ -380,7 +380,7 @@ int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_
 {
     const long long plane = (long long)ctx->NXH * Ny;
     if (const int segs = tridiag_coop_segs(ctx, Ny)) {
-        const int nxh_real = ctx->dg.Nx / 2 + 1;
+        const int nxh_real = ctx->dg.bounded_x ? ctx->dg.Nx : ctx->dg.Nx / 2 + 1;      // as in bzi_poisson_setup
         double *d_cols = ctx->d_lower;
         const int Nz = ctx->dg.Nz;
         TriCols C{d_cols, d_cols + Nz, d_cols + 2 * Nz, d_cols + 3 * Nz, d_cols + 3 * Nz + nxh_real};
@@ -420,7 +420,8 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     const DevGrid &g = ctx->dg;
     const int Nx = g.Nx, Nz = g.Nz, Hz = g.Hz;
     const bool slab = ctx->slab_mode;
-    const int nxh_real = Nx / 2 + 1;
+    // Bounded x (2-D x-z models with walls): Nx cosine modes instead of the Nx / 2 + 1 wavenumbers of the half spectrum
+    const int nxh_real = g.bounded_x ? Nx : Nx / 2 + 1;
     // hand-written x transforms + transposed spectrum: Nx a power of two in [16, 1024] (one team of Nx / 8 <= 128 threads per row, 8 rows per
     // workgroup in 45 KiB of LDS)
     const bool pow2 = (Nx & (Nx - 1)) == 0, three_pow2 = Nx % 3 == 0 && ((Nx / 3) & (Nx / 3 - 1)) == 0;      // 96, 192, 384, 768: one radix-3 stage
@@ -459,7 +460,7 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
         mass[k] = rho[k] * dzc[k + Hz];
     }
     const double pi = 3.14159265358979323846;
-    for (int i = 0; i < nxh_real; ++i) { double s = 2.0 * std::sin(i * pi / Nx) / g.dx; lam_x[i] = s * s; }
+    for (int i = 0; i < nxh_real; ++i) { double s = 2.0 * std::sin(i * pi / (g.bounded_x ? 2.0 * Nx : (double)Nx)) / g.dx; lam_x[i] = s * s; }
     // Bounded y: the cosine modes of the staggered Neumann problem (Oceananigans poisson_eigenvalues(N, L, dim, ::Bounded))
     for (int j = 0; j < Ny; ++j) { double s = 2.0 * std::sin(j * pi / (g.bounded_y ? 2.0 * Ny : (double)Ny)) / g.dy; lam_y[j] = s * s; }
 
@@ -502,6 +503,8 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
     if (slab) return BZ_OK;          // horizontal transforms are the caller's (distributed) in slab mode
     // ---- rocFFT plans: 2-D (y,x) transforms batched over z ----
     int n[2] = {Ny, Nx};
+    if (g.bounded_x)       // half spectrum of the permuted rows between the real transform and the cosine combination
+        BZ_HIP(hipMalloc(&ctx->d_dctx, (size_t)(Nx / 2 + 1) * Nz * sizeof(hipfftDoubleComplex)));
     if (!ctx->xf && Ny == 1) {      // Flat y: rows only
         int n1[1] = {Nx};
         BZ_FFT(hipfftPlanMany(&ctx->plan_fwd, 1, n1, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, Nz));
@@ -561,6 +564,8 @@ void bzi_poisson_teardown(bz_ctx *ctx)
         if (ctx->pchunk) { hipfftDestroy(ctx->plan_fwd_c); hipfftDestroy(ctx->plan_inv_c); ctx->pchunk = 0; }
         ctx->plans_ok = false;
     }
+    if (ctx->d_dctx) hipFree(ctx->d_dctx);
+    ctx->d_dctx = nullptr;
     if (ctx->d_lower) hipFree(ctx->d_lower);
     if (ctx->d_rhs) hipFree(ctx->d_rhs);
     if (ctx->d_hat) hipFree(ctx->d_hat);
@@ -603,6 +608,41 @@ __global__ __launch_bounds__(256) void k_dct_line(double2 *__restrict__ hat, int
             }
         }
         line[m] = out;
+    }
+}
+
+// The same along a Bounded x of a 2-D model (Flat y: rows of Nx real cells, one row per level): the permuted row goes through the real
+// row transform the Flat-y solve already owns (half spectrum V_0 .. V_{N/2}, V_{N-k} = conj V_k), and the combination writes the N cosine
+// coefficients as complex numbers with zero imaginary part — the columns the tridiagonal kernels take.
+// MODE 0: permute a real row in place; 1: half spectrum -> N coefficients; 2: N coefficients -> half spectrum; 3: un-permute in place.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dctx_row(double *__restrict__ real, double2 *__restrict__ half, double2 *__restrict__ full, int N)
+{
+    extern __shared__ double2 dct_line[];
+    const int NH = N / 2 + 1;
+    const long long row = blockIdx.x;
+    if (MODE == 0 || MODE == 3) {
+        double *sm = (double *)dct_line, *x = real + row * N;
+        for (int m = threadIdx.x; m < N; m += 256) sm[m] = x[m];
+        __syncthreads();
+        for (int m = threadIdx.x; m < N; m += 256)
+            x[m] = (MODE == 0) ? ((m < N / 2) ? sm[2 * m] : sm[2 * (N - 1 - m) + 1]) : ((m & 1) ? sm[N - 1 - (m - 1) / 2] : sm[m / 2]);
+    } else if (MODE == 1) {
+        const double2 *V = half + row * NH;
+        for (int m = threadIdx.x; m < N; m += 256) {
+            const double ang = 3.14159265358979323846 * (double)m / (2.0 * (double)N);
+            const double sn = sin(ang), cs = cos(ang);
+            const double2 v = (m <= N / 2) ? V[m] : make_double2(V[N - m].x, -V[N - m].y);
+            full[row * N + m] = make_double2(2.0 * (cs * v.x + sn * v.y), 0.0);      // X_m = w_m V_m + conj(w_m V_m) = 2 Re(w_m V_m)
+        }
+    } else {
+        const double2 *X = full + row * N;
+        for (int m = threadIdx.x; m < NH; m += 256) {
+            const double ang = 3.14159265358979323846 * (double)m / (2.0 * (double)N);
+            const double sn = sin(ang), cs = cos(ang);
+            const double a = X[m].x, b = m ? X[N - m].x : 0.0;      // real coefficients: V_m = conj(w_m) (X_m - i X_{N-m}) / 2
+            half[row * NH + m] = make_double2(0.5 * (cs * a + sn * b), 0.5 * (sn * a - cs * b));
+        }
     }
 }
 
@@ -650,9 +690,14 @@ int bzi_poisson_spectral(bz_ctx *ctx)
         }
         return BZ_OK;
     }
+    const size_t lds_x = (size_t)g.Nx * sizeof(double);
     {
         ProfileScope ps(ctx, "poisson_fft_forward");
-        BZ_FFT(hipfftExecD2Z(ctx->plan_fwd, ctx->d_rhs, ctx->d_hat));
+        if (g.bounded_x) {      // cosine transform of every row (Flat y: one row per level)
+            hipLaunchKernelGGL(k_dctx_row<0>, dim3(g.Nz), dim3(256), lds_x, ctx->stream, ctx->d_rhs, nullptr, nullptr, g.Nx);
+            BZ_FFT(hipfftExecD2Z(ctx->plan_fwd, ctx->d_rhs, ctx->d_dctx));
+            hipLaunchKernelGGL(k_dctx_row<1>, dim3(g.Nz), dim3(256), 0, ctx->stream, nullptr, (double2 *)ctx->d_dctx, (double2 *)ctx->d_hat, g.Nx);
+        } else BZ_FFT(hipfftExecD2Z(ctx->plan_fwd, ctx->d_rhs, ctx->d_hat));
     }
     {
         ProfileScope ps(ctx, "poisson_tridiagonal");
@@ -661,8 +706,13 @@ int bzi_poisson_spectral(bz_ctx *ctx)
     }
     {
         ProfileScope ps(ctx, "poisson_fft_inverse");
-        BZ_FFT(hipfftExecZ2D(ctx->plan_inv, ctx->d_hat, ctx->d_rhs));
+        if (g.bounded_x) {
+            hipLaunchKernelGGL(k_dctx_row<2>, dim3(g.Nz), dim3(256), 0, ctx->stream, nullptr, (double2 *)ctx->d_dctx, (double2 *)ctx->d_hat, g.Nx);
+            BZ_FFT(hipfftExecZ2D(ctx->plan_inv, ctx->d_dctx, ctx->d_rhs));
+            hipLaunchKernelGGL(k_dctx_row<3>, dim3(g.Nz), dim3(256), lds_x, ctx->stream, ctx->d_rhs, nullptr, nullptr, g.Nx);
+        } else BZ_FFT(hipfftExecZ2D(ctx->plan_inv, ctx->d_hat, ctx->d_rhs));
     }
+    BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
 
@@ -727,7 +777,7 @@ extern "C" int bz_compute_pressure_correction(bz_ctx *ctx, const bz_state *s, do
         return BZ_ERR_UNSUPPORTED;
     }
     double *mf[3] = {s->rho_u, s->rho_v, s->rho_w};
-    int mk[3] = {0, BZ_HALO_YFACE, 1};
+    int mk[3] = {BZ_HALO_XFACE, BZ_HALO_YFACE, 1};
     int rc = bzi_fill_halos_multi(ctx, mf, mk, 3);   // anelastic_time_stepping.jl:29
     if (rc) return rc;
     rc = bzi_poisson_solve(ctx, s, dt);

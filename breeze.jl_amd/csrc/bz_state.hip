@@ -97,7 +97,7 @@ __global__ __launch_bounds__(TX *TY) void k_pressure_correct(DevGrid g, double *
     long long n = g.idx(i, j, k);
     double rc = g.rho[k], rf = g.rho_f[k];
     double p = phi[n];
-    ru[n] -= rc * dt * ((p - phi[n - 1]) * g.rdx);
+    if (!(g.bounded_x && i == 0)) ru[n] -= rc * dt * ((p - phi[n - 1]) * g.rdx);      // a wall face is never corrected
     if (!g.flat_y && !(g.bounded_y && j == 0)) rv[n] -= rc * dt * ((p - phi[n - g.Sx]) * g.rdy);      // a wall face is never corrected
     rw[n] -= rf * dt * ((p - phi[n - g.Sxy]) * g.rdzf[k]);
 }
@@ -142,7 +142,7 @@ extern "C" int bz_compute_velocities(bz_ctx *ctx, const bz_state *s)
     const DevGrid &g = ctx->dg;
     // halos of momentum first (update_atmosphere_model_state.jl:135-136)
     double *mf[3] = {s->rho_u, s->rho_v, s->rho_w};
-    int mk[3] = {0, BZ_HALO_YFACE, 1};
+    int mk[3] = {BZ_HALO_XFACE, BZ_HALO_YFACE, 1};
     int rc = bzi_fill_halos_multi(ctx, mf, mk, 3);
     if (rc) return rc;
     {
@@ -152,7 +152,7 @@ extern "C" int bz_compute_velocities(bz_ctx *ctx, const bz_state *s)
         BZ_LAUNCH_CHECK();
     }
     double *vf[3] = {s->u, s->v, s->w};
-    int vk[3] = {2, 2 | BZ_HALO_YFACE, 3};
+    int vk[3] = {2 | BZ_HALO_XFACE, 2 | BZ_HALO_YFACE, 3};
     return bzi_fill_halos_multi(ctx, vf, vk, 3);
 }
 
@@ -233,7 +233,7 @@ extern "C" int bz_max_abs_divergence(bz_ctx *ctx, const bz_state *s, double *out
     if (!ctx || !s || !out) return BZ_ERR_INVALID;
     const DevGrid &g = ctx->dg;
     double *mf[3] = {s->rho_u, s->rho_v, s->rho_w};
-    int mk[3] = {0, BZ_HALO_YFACE, 1};
+    int mk[3] = {BZ_HALO_XFACE, BZ_HALO_YFACE, 1};
     int rc = bzi_fill_halos_multi(ctx, mf, mk, 3);
     if (rc) return rc;
     BZ_HIP(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));

@@ -20,6 +20,10 @@
 
 // Bounded y ((Periodic, Bounded, Bounded)): the WENO buffer that fits at y-face / y-centre j — wave-uniform (a wavefront is one row) —
 // and the Centered advecting-flux interpolation of the same order, as in z (symm_z_face below); 3 everywhere on a periodic y
+// Bounded x ((Bounded, Flat, Bounded)): the same by lane — the buffer differs between the lanes next to a wall, so the reconstruction
+// branches diverge in the first and last wavefront of a row only
+__device__ __forceinline__ int bx_face(const DevGrid &g, int i) { return g.bounded_x ? bz_buffer_face(i, g.Nx) : 3; }
+__device__ __forceinline__ int bx_center(const DevGrid &g, int i) { return g.bounded_x ? bz_buffer_center(i, g.Nx) : 3; }
 __device__ __forceinline__ int by_face(const DevGrid &g, int j) { return g.bounded_y ? bz_buffer_face(j, g.Ny) : 3; }
 __device__ __forceinline__ int by_center(const DevGrid &g, int j) { return g.bounded_y ? bz_buffer_center(j, g.Ny) : 3; }
 __device__ __forceinline__ double symm_y(double qm2, double qm1, double q0, double qp1, int B)
@@ -59,8 +63,8 @@ __global__ __launch_bounds__(64 * TYB) void k_scalar_tendency(DevGrid g, double 
         const double rho = g.rho[k], Ax = g.Ax[k], Ay = g.Ay[k];
         double xm3 = c[n - 3], xm2 = c[n - 2], xm1 = c[n - 1], xp1 = c[n + 1], xp2 = c[n + 2], xp3 = c[n + 3];
         double u0 = u[n], u1 = u[n + 1];
-        double Fx_lo = rho * ((Ax * u0) * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, u0 > 0.0));
-        double Fx_hi = rho * ((Ax * u1) * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, u1 > 0.0));
+        double Fx_lo = rho * ((Ax * u0) * bz_upB(xm3, xm2, xm1, z0, xp1, xp2, u0 > 0.0, bx_face(g, i)));
+        double Fx_hi = rho * ((Ax * u1) * bz_upB(xm2, xm1, z0, xp1, xp2, xp3, u1 > 0.0, bx_face(g, i + 1)));
 
         double Fy_lo = 0.0, Fy_hi = 0.0;
         if (!g.flat_y) {      // a Flat y direction has no faces
@@ -82,10 +86,10 @@ __global__ __launch_bounds__(64 * TYB) void k_scalar_tendency(DevGrid g, double 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double flux_Wu(const DevGrid &g, const double *__restrict__ rw, long long nf,
                                           double m3, double m2, double m1, double p0, double p1, double p2,
-                                          int kface)
+                                          int kface, int i)
 {   // at (f,c,f): advecting flux = Centered4 in x of Az*rho_w to x-face i
     double Az = g.Az;
-    double wt = bz_symm4(Az * rw[nf - 2], Az * rw[nf - 1], Az * rw[nf], Az * rw[nf + 1]);
+    double wt = symm_y(Az * rw[nf - 2], Az * rw[nf - 1], Az * rw[nf], Az * rw[nf + 1], bx_face(g, i));
     double uR = bz_upB(m3, m2, m1, p0, p1, p2, wt > 0.0, bz_buffer_face(kface, g.Nz));
     return wt * uR;
 }
@@ -99,32 +103,34 @@ __global__ __launch_bounds__(64 * TYB) void k_u_tendency(DevGrid g, double *__re
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * TYB + threadIdx.y;
     if (i >= g.Nx || j >= g.Ny) return;
+    if (g.bounded_x && i == 0) return;               // the wall face is never updated
     const int k0 = blockIdx.z * kchunk;
     const int k1 = min(k0 + kchunk, g.Nz);
     const long long sy = g.Sx, sz = g.Sxy;
     long long n = g.idx(i, j, k0);
+    const int Bxc = bx_center(g, i), Bxcm = bx_center(g, i - 1), Bxf = bx_face(g, i);
 
     double zm3 = u[n - 3 * sz], zm2 = u[n - 2 * sz], zm1 = u[n - sz], z0 = u[n], zp1 = u[n + sz], zp2 = u[n + 2 * sz];
-    double Fz_lo = flux_Wu(g, rw, n, zm3, zm2, zm1, z0, zp1, zp2, k0);
+    double Fz_lo = flux_Wu(g, rw, n, zm3, zm2, zm1, z0, zp1, zp2, k0, i);
 
     for (int k = k0; k < k1; ++k, n += sz) {
         double zp3 = u[n + 3 * sz];
-        double Fz_hi = flux_Wu(g, rw, n + sz, zm2, zm1, z0, zp1, zp2, zp3, k + 1);
+        double Fz_hi = flux_Wu(g, rw, n + sz, zm2, zm1, z0, zp1, zp2, zp3, k + 1, i);
         const double Ax = g.Ax[k], Ay = g.Ay[k];
 
         // x: F_Uu at centres i (hi) and i-1 (lo)
         double q_m2 = Ax * ru[n - 2], q_m1 = Ax * ru[n - 1], q_0 = Ax * ru[n], q_p1 = Ax * ru[n + 1], q_p2 = Ax * ru[n + 2];
         double xm3 = u[n - 3], xm2 = u[n - 2], xm1 = u[n - 1], xp1 = u[n + 1], xp2 = u[n + 2], xp3 = u[n + 3];
-        double ut_hi = bz_symm4(q_m1, q_0, q_p1, q_p2);
-        double ut_lo = bz_symm4(q_m2, q_m1, q_0, q_p1);
-        double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
-        double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
+        double ut_hi = (Bxc == 3) ? bz_symm4(q_m1, q_0, q_p1, q_p2) : bz_symm2(q_0, q_p1);      // centre targets: order 2 next to an x wall
+        double ut_lo = (Bxcm == 3) ? bz_symm4(q_m2, q_m1, q_0, q_p1) : bz_symm2(q_m1, q_0);
+        double Fx_hi = ut_hi * bz_upB(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0, Bxc);
+        double Fx_lo = ut_lo * bz_upB(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0, Bxcm);
 
         // y: F_Vu at y-faces j (lo) and j+1 (hi)
         double Fy_lo = 0.0, Fy_hi = 0.0;
         if (!g.flat_y) {
-            double vt_lo = bz_symm4(Ay * rv[n - 2], Ay * rv[n - 1], Ay * rv[n], Ay * rv[n + 1]);
-            double vt_hi = bz_symm4(Ay * rv[n + sy - 2], Ay * rv[n + sy - 1], Ay * rv[n + sy], Ay * rv[n + sy + 1]);
+            double vt_lo = symm_y(Ay * rv[n - 2], Ay * rv[n - 1], Ay * rv[n], Ay * rv[n + 1], Bxf);
+            double vt_hi = symm_y(Ay * rv[n + sy - 2], Ay * rv[n + sy - 1], Ay * rv[n + sy], Ay * rv[n + sy + 1], Bxf);
             double ym3 = u[n - 3 * sy], ym2 = u[n - 2 * sy], ym1 = u[n - sy], yp1 = u[n + sy], yp2 = u[n + 2 * sy], yp3 = u[n + 3 * sy];
             Fy_lo = vt_lo * bz_upB(ym3, ym2, ym1, z0, yp1, yp2, vt_lo > 0.0, by_face(g, j));
             Fy_hi = vt_hi * bz_upB(ym2, ym1, z0, yp1, yp2, yp3, vt_hi > 0.0, by_face(g, j + 1));
@@ -181,8 +187,8 @@ __global__ __launch_bounds__(64 * TYB) void k_v_tendency(DevGrid g, double *__re
         double ut_lo = g.flat_y ? Ax * ru[n] : symm_y(Ax * ru[n - 2 * sy], Ax * ru[n - sy], Ax * ru[n], Ax * ru[n + sy], Bf);
         double ut_hi = g.flat_y ? Ax * ru[n + 1] : symm_y(Ax * ru[n + 1 - 2 * sy], Ax * ru[n + 1 - sy], Ax * ru[n + 1], Ax * ru[n + 1 + sy], Bf);
         double xm3 = v[n - 3], xm2 = v[n - 2], xm1 = v[n - 1], xp1 = v[n + 1], xp2 = v[n + 2], xp3 = v[n + 3];
-        double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
-        double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
+        double Fx_lo = ut_lo * bz_upB(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0, bx_face(g, i));
+        double Fx_hi = ut_hi * bz_upB(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0, bx_face(g, i + 1));
 
         // y: F_Vv at centres j (hi) and j-1 (lo)
         double Fy_hi = 0.0, Fy_lo = 0.0;
@@ -269,8 +275,8 @@ __global__ __launch_bounds__(64 * TYB) void k_w_tendency(DevGrid g, double *__re
         double ut_lo = symm_z_face(g, g.Ax, ru, n, k, Bf);
         double ut_hi = symm_z_face(g, g.Ax, ru, n + 1, k, Bf);
         double xm3 = w[n - 3], xm2 = w[n - 2], xm1 = w[n - 1], xp1 = w[n + 1], xp2 = w[n + 2], xp3 = w[n + 3];
-        double Fx_lo = ut_lo * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0);
-        double Fx_hi = ut_hi * bz_up5(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0);
+        double Fx_lo = ut_lo * bz_upB(xm3, xm2, xm1, z0, xp1, xp2, ut_lo > 0.0, bx_face(g, i));
+        double Fx_hi = ut_hi * bz_upB(xm2, xm1, z0, xp1, xp2, xp3, ut_hi > 0.0, bx_face(g, i + 1));
 
         // y: F_Vw at y-faces j (lo), j+1 (hi)
         double Fy_lo = 0.0, Fy_hi = 0.0;

@@ -70,6 +70,10 @@ __device__ __forceinline__ int buf_center(int idx, int N)
 
 // Bounded y ((Periodic, Bounded, Bounded)): the buffer of row / y-face jj — wave-uniform, like the level's in z; R on a periodic y
 template <int R>
+__device__ __forceinline__ int bx_face_g(const DevGrid &g, int ii) { return g.bounded_x ? buf_face<R>(ii, g.Nx) : R; }      // Bounded x: by lane
+template <int R>
+__device__ __forceinline__ int bx_center_g(const DevGrid &g, int ii) { return g.bounded_x ? buf_center<R>(ii, g.Nx) : R; }
+template <int R>
 __device__ __forceinline__ int by_face_g(const DevGrid &g, int jj) { return g.bounded_y ? buf_face<R>(jj, g.Ny) : R; }
 template <int R>
 __device__ __forceinline__ int by_center_g(const DevGrid &g, int jj) { return g.bounded_y ? buf_center<R>(jj, g.Ny) : R; }
@@ -157,7 +161,7 @@ __device__ __forceinline__ double rk_out(const FluxBuf &F, double G, long long n
 // PASS 1 covers the interior (x is Periodic and y wraps unless the context is a y-slab or Flat: the flux at face N is the flux at face 0,
 // bit for bit, because halos are exact periodic images; the Bounded z direction has zero mass flux through its wall faces) plus, on
 // y-slabs, one row either side (the fluxes at the slab edges come from exchanged halo rows)
-struct GenericWrap { long long xp, xm, yp, ym; bool top; };
+struct GenericWrap { long long xp, xm, yp, ym; bool top, xwall; };      // xwall: the x-face above this cell is a wall (Bounded x): zero flux
 template <int PASS>
 __device__ __forceinline__ bool generic_index(const DevGrid &g, int &i, int &j, int &k, int k0, GenericWrap &W)
 {
@@ -166,8 +170,9 @@ __device__ __forceinline__ bool generic_index(const DevGrid &g, int &i, int &j, 
     j = (int)blockIdx.y - ((PASS == 1 && ext_y) ? 1 : 0);
     k = (PASS == 1 ? 0 : k0) + (int)blockIdx.z;
     const long long sy = g.Sx;
-    W.xp = (i + 1 < g.Nx) ? 1 : 1 - g.Nx;
-    W.xm = (i > 0) ? -1 : g.Nx - 1;
+    W.xp = (i + 1 < g.Nx || g.bounded_x) ? 1 : 1 - g.Nx;
+    W.xm = (i > 0 || g.bounded_x) ? -1 : g.Nx - 1;
+    W.xwall = g.bounded_x && i == g.Nx - 1;
     W.yp = (j + 1 < g.Ny || ext_y) ? sy : sy * (1 - g.Ny);
     W.ym = (j > 0 || ext_y) ? -sy : sy * (g.Ny - 1);
     W.top = (k + 1 >= g.Nz);
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__
     if (!generic_index<PASS>(g, i, j, k, 0, W)) return;
     const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
-    auto fx = [&](long long m) { const double ut = u[m]; return g.rho[k] * ((g.Ax[k] * ut) * biased_face_g(c + m, 1, ut > 0.0, R)); };
+    auto fx = [&](long long m, int ii) { const double ut = u[m]; return g.rho[k] * ((g.Ax[k] * ut) * biased_face_g(c + m, 1, ut > 0.0, bx_face_g<R>(g, ii))); };
     auto fy = [&](long long m, int jj) { const double vt = v[m]; return g.rho[k] * ((g.Ay[k] * vt) * biased_face_g(c + m, sy, vt > 0.0, by_face_g<R>(g, jj))); };
     auto fz = [&](long long m, int kf) {
         const double wt = w[m];
@@ -194,14 +199,14 @@ __global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__
     };
     if (PASS == 1) {
         const bool cj = IN(j, 0, g.Ny - 1);
-        if (cj) F.x[n] = fx(n);
+        if (cj) F.x[n] = fx(n, i);
         if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = fy(n, j);
         if (cj) F.z[n] = fz(n, k);
         return;
     }
     double dx, dy, dz;
-    if (PASS == 2) { dx = F.x[n + W.xp] - F.x[n]; dy = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; dz = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
-    else { dx = fx(n + 1) - fx(n); dy = g.flat_y ? 0.0 : fy(n + sy, j + 1) - fy(n, j); dz = fz(n + sz, k + 1) - fz(n, k); }      // a Flat y has no faces
+    if (PASS == 2) { dx = (W.xwall ? 0.0 : F.x[n + W.xp]) - F.x[n]; dy = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; dz = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
+    else { dx = fx(n + 1, i + 1) - fx(n, i); dy = g.flat_y ? 0.0 : fy(n + sy, j + 1) - fy(n, j); dz = fz(n + sz, k + 1) - fz(n, k); }      // a Flat y has no faces
     Gc[n] = rk_out(F, -(g.Vinv_c[k] * (dx + dy + dz)), n);
 }
 
@@ -217,28 +222,31 @@ __global__ __launch_bounds__(256) void k_u_tendency_g(DevGrid g, double *__restr
     const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
     const ColPtr none(nullptr);
-    auto FUu = [&](long long m) {      // at centre: advecting flux from faces
-        const double ut = symm_g(ru, m, 1, R, -(R - 2), none, 0, g.Ax[k]);
-        return ut * biased_center_g(u + m, 1, ut > 0.0, R);
+    const int Bfx = bx_face_g<R>(g, i), hfx = Bfx > 2 ? Bfx - 1 : 1;      // Centered in x to the x-face of this lane
+    auto FUu = [&](long long m, int ic) {      // at centre ic: advecting flux from faces
+        const int B = bx_center_g<R>(g, ic), h = B > 2 ? B - 1 : 1;
+        const double ut = symm_g(ru, m, 1, B, -(h - 1), none, 0, g.Ax[k]);
+        return ut * biased_center_g(u + m, 1, ut > 0.0, B);
     };
     auto FVu = [&](long long m, int jj) {      // at (f, f, c): Centered in x of Ay rho_v to x-face
-        const double vt = symm_g(rv, m, 1, R, -(R - 1), none, 0, g.Ay[k]);
+        const double vt = symm_g(rv, m, 1, Bfx, -hfx, none, 0, g.Ay[k]);
         return vt * biased_face_g(u + m, sy, vt > 0.0, by_face_g<R>(g, jj));
     };
     auto FWu = [&](long long m, int kf) {
-        const double wt = symm_g(rw, m, 1, R, -(R - 1), none, 0, g.Az);
+        const double wt = symm_g(rw, m, 1, Bfx, -hfx, none, 0, g.Az);
         return wt * biased_face_g(u + m, sz, wt > 0.0, buf_face<R>(kf, g.Nz));
     };
     if (PASS == 1) {
         const bool cj = IN(j, 0, g.Ny - 1);
-        if (cj) F.x[n] = FUu(n);
+        if (cj) F.x[n] = FUu(n, i);
         if (!g.flat_y && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = FVu(n, j);
         if (cj) F.z[n] = FWu(n, k);
         return;
     }
+    if (g.bounded_x && i == 0) return;      // the wall face is never updated
     double a, b, c;
     if (PASS == 2) { a = F.x[n] - F.x[n + W.xm]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
-    else { a = FUu(n) - FUu(n - 1); b = g.flat_y ? 0.0 : FVu(n + sy, j + 1) - FVu(n, j); c = FWu(n + sz, k + 1) - FWu(n, k); }
+    else { a = FUu(n, i) - FUu(n - 1, i - 1); b = g.flat_y ? 0.0 : FVu(n + sy, j + 1) - FVu(n, j); c = FWu(n + sz, k + 1) - FWu(n, k); }
     Gu[n] = rk_out(F, -(g.Vinv_c[k] * (a + b + c)), n);
 }
 
@@ -255,9 +263,9 @@ __global__ __launch_bounds__(256) void k_v_tendency_g(DevGrid g, double *__restr
     const ColPtr none(nullptr);
     // Centered in y to the y-face of this row: order 2 (B - 1) with the buffer that fits (B = R on a periodic y), like the z interpolations of k_w_tendency_g
     const int Bfy = by_face_g<R>(g, j), hfy = Bfy > 2 ? Bfy - 1 : 1;
-    auto FUv = [&](long long m) {
+    auto FUv = [&](long long m, int ii) {
         const double ut = g.flat_y ? g.Ax[k] * ru[m] : symm_g(ru, m, sy, Bfy, -hfy, none, 0, g.Ax[k]);      // Iy of a Flat direction: identity
-        return ut * biased_face_g(v + m, 1, ut > 0.0, R);
+        return ut * biased_face_g(v + m, 1, ut > 0.0, bx_face_g<R>(g, ii));
     };
     auto FVv = [&](long long m, int jc) {      // at centre jc
         const int B = by_center_g<R>(g, jc), h = B > 2 ? B - 1 : 1;
@@ -270,15 +278,15 @@ __global__ __launch_bounds__(256) void k_v_tendency_g(DevGrid g, double *__restr
     };
     if (PASS == 1) {
         const bool cj = IN(j, 0, g.Ny - 1);
-        if (cj) F.x[n] = FUv(n);
+        if (cj) F.x[n] = FUv(n, i);
         if (!g.flat_y && IN(j, ext_y ? -1 : 0, g.Ny - 1)) F.y[n] = FVv(n, j);
         if (cj) F.z[n] = FWv(n, k);
         return;
     }
     if (g.bounded_y && j == 0) return;      // the wall face is never updated
     double a, b, c;
-    if (PASS == 2) { a = F.x[n + W.xp] - F.x[n]; b = g.flat_y ? 0.0 : F.y[n] - F.y[n + W.ym]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
-    else { a = FUv(n + 1) - FUv(n); b = g.flat_y ? 0.0 : FVv(n, j) - FVv(n - sy, j - 1); c = FWv(n + sz, k + 1) - FWv(n, k); }
+    if (PASS == 2) { a = (W.xwall ? 0.0 : F.x[n + W.xp]) - F.x[n]; b = g.flat_y ? 0.0 : F.y[n] - F.y[n + W.ym]; c = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
+    else { a = FUv(n + 1, i + 1) - FUv(n, i); b = g.flat_y ? 0.0 : FVv(n, j) - FVv(n - sy, j - 1); c = FWv(n + sz, k + 1) - FWv(n, k); }
     Gv[n] = rk_out(F, -(g.Vinv_c[k] * (a + b + c)), n);
 }
 
@@ -295,11 +303,11 @@ __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restr
     const bool ext_y = !g.wrap_y && !g.flat_y;
     const long long sy = g.Sx, sz = g.Sxy, n = g.idx(i, j, k);
     const ColPtr none(nullptr);
-    auto FUw = [&](long long m) {      // Centered in z of Ax(k) rho_u to z-face k
+    auto FUw = [&](long long m, int ii) {      // Centered in z of Ax(k) rho_u to z-face k
         const int Bf = buf_face<R>(k, g.Nz);
         const int h = Bf > 2 ? Bf - 1 : 1;
         const double ut = symm_g(ru, m, sz, Bf, -h, g.Ax, k, 0.0);
-        return ut * biased_face_g(w + m, 1, ut > 0.0, R);
+        return ut * biased_face_g(w + m, 1, ut > 0.0, bx_face_g<R>(g, ii));
     };
     auto FVw = [&](long long m, int jj) {
         const int Bf = buf_face<R>(k, g.Nz);
@@ -315,14 +323,14 @@ __global__ __launch_bounds__(256) void k_w_tendency_g(DevGrid g, double *__restr
     };
     if (PASS == 1) {
         const bool cj = IN(j, 0, g.Ny - 1), ck = k >= 1;
-        if (cj && ck) F.x[n] = FUw(n);
+        if (cj && ck) F.x[n] = FUw(n, i);
         if (!g.flat_y && ck && IN(j, 0, g.Ny - (ext_y ? 0 : 1))) F.y[n] = FVw(n, j);
         if (cj) F.z[n] = FWw(n, k);
         return;
     }
     double a, b, c;
-    if (PASS == 2) { a = F.x[n + W.xp] - F.x[n]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = F.z[n] - F.z[n - sz]; }
-    else { a = FUw(n + 1) - FUw(n); b = g.flat_y ? 0.0 : FVw(n + sy, j + 1) - FVw(n, j); c = FWw(n, k) - FWw(n - sz, k - 1); }
+    if (PASS == 2) { a = (W.xwall ? 0.0 : F.x[n + W.xp]) - F.x[n]; b = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; c = F.z[n] - F.z[n - sz]; }
+    else { a = FUw(n + 1, i + 1) - FUw(n, i); b = g.flat_y ? 0.0 : FVw(n + sy, j + 1) - FVw(n, j); c = FWw(n, k) - FWw(n - sz, k - 1); }
     const double adv = -(g.Vinv_f[k] * (a + b + c));
     if (BUOY) Gw[n] = rk_out(F, adv + 0.5 * (bz_buoyancy(g, T, qv, n - sz, k - 1) + bz_buoyancy(g, T, qv, n, k)), n);
     else Gw[n] = adv;
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256) void k_scalar_tendency_rho3d_g(DevGrid g, doub
         return;
     }
     double dx, dy, dz;
-    if (PASS == 2) { dx = F.x[n + W.xp] - F.x[n]; dy = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; dz = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
+    if (PASS == 2) { dx = (W.xwall ? 0.0 : F.x[n + W.xp]) - F.x[n]; dy = g.flat_y ? 0.0 : F.y[n + W.yp] - F.y[n]; dz = (W.top ? 0.0 : F.z[n + sz]) - F.z[n]; }
     else { dx = fx(n + 1) - fx(n); dy = g.flat_y ? 0.0 : fy(n + sy) - fy(n); dz = fz(n + sz, k + 1) - fz(n, k); }
     Gc[n] = -(g.Vinv_c[k] * (dx + dy + dz));
     if (Grho) {

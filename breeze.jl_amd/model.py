@@ -169,11 +169,12 @@ class AtmosphereModel:
         import torch
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
-        flat_y = grid.topology == (Periodic, Flat, Bounded)
+        bounded_x = grid.topology == (Bounded, Flat, Bounded)          # walls in x of a 2-D model: examples/cloudy_thermal_bubble.jl
+        flat_y = grid.topology == (Periodic, Flat, Bounded) or bounded_x
         bounded_y = grid.topology == (Periodic, Bounded, Bounded)      # walls in y: the reference benchmark driver's PBB option
         if grid.topology != (Periodic, Periodic, Bounded) and not flat_y and not bounded_y:
-            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded), (Periodic, Flat, Bounded) and "
-                                      "(Periodic, Bounded, Bounded)")
+            raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded), (Periodic, Flat, Bounded), "
+                                      "(Bounded, Flat, Bounded) and (Periodic, Bounded, Bounded)")
         if advection is None:
             advection = Centered(order=2)          # the reference's default (resolved before the Flat guard: ADVICE r02)
         _base = advection.get("momentum") or next(iter(advection.values())) if isinstance(advection, dict) else advection
@@ -183,6 +184,9 @@ class AtmosphereModel:
             # kernels drop the y terms
             raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model without Coriolis / forcings / flux boundary conditions is implemented")
         formulation = str(formulation).lstrip(":")
+        if bounded_x and (isinstance(advection, dict) or getattr(_base, "bounds", None) is not None or closure is not None or grid.Nx % 2):
+            raise NotImplementedError("(Bounded, Flat, Bounded): WENO(order = 5 | 7 | 9) models without a closure and without bounds-preserving "
+                                      "advection on an even number of columns are implemented")
         if bounded_y and (isinstance(advection, dict) or not isinstance(_base, WENO) or _base.order not in (5, 7, 9) or
                           getattr(_base, "bounds", None) is not None or closure is not None):
             # Coriolis, forcings and bottom flux boundary conditions reach their y neighbours through the halo rows (as on y-slabs);
@@ -442,7 +446,7 @@ class AtmosphereModel:
 # ---------------------------------------------------------------------------
 def fill_halo_regions_(model, field, kind=None):
     if kind is None:
-        kind = (1 if field.zface else 0) + (4 if field.loc[1] is Face else 0)      # + 4: a y-face field (wall faces on a Bounded y)
+        kind = (1 if field.zface else 0) + (4 if field.loc[1] is Face else 0) + (8 if field.loc[0] is Face else 0)      # + 4 / + 8: y- / x-face field
     model._check(model._lib.bz_fill_halo_regions(model._ctx, C.c_void_p(field.ptr()), kind), "bz_fill_halo_regions")
 
 

@@ -96,7 +96,9 @@ typedef struct bz_ctx bz_ctx;
  * column tables.  weno_order: 5 (the tuned kernels), or 7 / 9 (WENO(order = 7 | 9), the examples' scheme: generic kernels, halos >=
  * (order + 1) / 2, anelastic or compressible model without bounds-preserving advection, operator-by-operator anelastic stepping; Centered(order = 2)
  * is weno_order = 2 of libbreeze_hip_centered2.so); topology (Periodic, Periodic, Bounded) or — single-GPU contexts —
- * (Periodic, Flat, Bounded) with Ny = 1, Hy = 0 (the reference's 2-D x-z cases, anelastic and compressible), or (Periodic, Bounded, Bounded) —
+ * (Periodic, Flat, Bounded) with Ny = 1, Hy = 0 (the reference's 2-D x-z cases, anelastic and compressible), (Bounded, Flat, Bounded) — the same
+ * with walls in x (examples/cloudy_thermal_bubble.jl:20-24; anelastic, even Nx <= 4096, u / rho u with wall faces i = 0 and Nx, cosine transform
+ * along x) — or (Periodic, Bounded, Bounded) —
  * walls in y, the reference benchmark driver's PBB option (benchmarking/run_benchmarks.jl:130): anelastic WENO(order = 5 | 7 | 9) contexts (no closure, no bounds-preserving
  * advection) stepped operator by operator, rho v / v with impenetrable wall faces j = 0 and Ny (face Ny in the first upper halo row), cosine transform along
  * y in the pressure solve (Nx a power of two in [16, 1024] or 3 * 2^m, Ny a multiple of 8 up to 4096); halos >= 3, Float64; every extent at least its
@@ -138,7 +140,7 @@ const char *bz_last_error(const bz_ctx *ctx);
  * kind: 0 = centre-in-z field, default (no-flux) z BCs;  1 = z-face field, impenetrable walls;
  *       2 = `nothing` z BCs (diagnostic velocities): periodic wrap only; 3 = as 2 for a z-face field.
  *       + 4 for a field on y faces (rho v, v): on a Bounded y its wall faces j = 0, Ny are set to 0, where a centre-in-y field takes
- *       its first halo row from the adjacent interior row (ignored on a Periodic y). */
+ *       its first halo row from the adjacent interior row (ignored on a Periodic y); + 8 likewise for a field on x faces (rho u, u). */
 int bz_fill_halo_regions(bz_ctx *ctx, double *field, int kind);
 
 /* AtmosphereModels.compute_velocities! (update_atmosphere_model_state.jl:122-155, kernel :248-254). */

@@ -254,6 +254,32 @@ void og_fill_halo_periodic_xy(const og_grid *G, double *f, int nz_tot)
 /* Bounded y (round 3: (Periodic, Bounded, Bounded), the reference benchmark's PBB option, benchmarking/run_benchmarks.jl:130): the same
  * conventions as Bounded z below — a field that is a centre in y gets its first halo row from the adjacent interior row (no-flux), a
  * y-face field (rho v, v) carries zeros on its wall faces j = 0 and j = Ny (impenetrable walls; face Ny lives in the first upper halo row). */
+/* Bounded x ((Bounded, Flat, Bounded): examples/cloudy_thermal_bubble.jl, tropical_cyclone_with_rainband.jl): the same conventions along
+ * the row — first halo cell of a centre-in-x field from the adjacent interior cell, wall faces i = 0 and i = Nx of an x-face field zero. */
+void og_fill_halo_x_noflux(const og_grid *G, double *f, int nz_tot)
+{
+    size_t sx = SX(G), sy = SY(G);
+    if (G->tx != BOUNDED) return;
+#pragma omp parallel for schedule(static)
+    for (int kk = 0; kk < nz_tot; ++kk)
+        for (size_t jj = 0; jj < sy; ++jj) {
+            double *row = f + sx * sy * (size_t)kk + sx * jj;
+            row[G->Hx - 1] = row[G->Hx];
+            row[G->Hx + G->Nx] = row[G->Hx + G->Nx - 1];
+        }
+}
+void og_fill_halo_x_wall(const og_grid *G, double *u, int nz_tot)
+{
+    size_t sx = SX(G), sy = SY(G);
+    if (G->tx != BOUNDED) return;
+#pragma omp parallel for schedule(static)
+    for (int kk = 0; kk < nz_tot; ++kk)
+        for (size_t jj = 0; jj < sy; ++jj) {
+            double *row = u + sx * sy * (size_t)kk + sx * jj;
+            row[G->Hx] = 0.0;
+            row[G->Hx + G->Nx] = 0.0;
+        }
+}
 void og_fill_halo_y_noflux(const og_grid *G, double *f, int nz_tot)
 {
     size_t sx = SX(G), sy = SY(G);
@@ -473,9 +499,18 @@ static inline double dzc_at(const og_grid *G, int k) { return G->dzc[k + G->Hz];
 
 /* symmetric interpolation along x of q = A*M (A constant along x) */
 static inline double symm_x_center(const og_grid *G, const double *M, size_t n, int i, double A)
-{   /* to centre i from faces; Periodic/Flat-free x => always order 4 */
-    (void)i;
+{   /* to centre i from faces; a Bounded x drops the order next to the walls like z and y */
     if (G->tx == FLAT) return A * M[n];
+    if (G->tx == BOUNDED) {
+        int B = buffer_at(i, G->Nx, 1, 0);
+        if (B >= 4) {
+            double q[8]; const int h = B - 1;
+            for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - (h - 1))];
+            return symm_wide(q, B);
+        }
+        if (B == 3) return symm4(A * M[n - 1], A * M[n], A * M[n + 1], A * M[n + 2]);
+        return symm2(A * M[n], A * M[n + 1]);
+    }
     if (og_weno_R >= 4) {        /* Centered(order 2 (R - 1)): faces i-(R-2) .. i+R-1 */
         double q[8]; const int h = og_weno_R - 1;
         for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - (h - 1))];
@@ -485,8 +520,17 @@ static inline double symm_x_center(const og_grid *G, const double *M, size_t n, 
 }
 static inline double symm_x_face(const og_grid *G, const double *M, size_t n, int i, double A)
 {   /* to face i from centres */
-    (void)i;
     if (G->tx == FLAT) return A * M[n];
+    if (G->tx == BOUNDED) {
+        int B = buffer_at(i, G->Nx, 1, 1);
+        if (B >= 4) {
+            double q[8]; const int h = B - 1;
+            for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - h)];
+            return symm_wide(q, B);
+        }
+        if (B == 3) return symm4(A * M[n - 2], A * M[n - 1], A * M[n], A * M[n + 1]);
+        return symm2(A * M[n - 1], A * M[n]);
+    }
     if (og_weno_R >= 4) {        /* centres i-(R-1) .. i+R-2 */
         double q[8]; const int h = og_weno_R - 1;
         for (int m = 0; m < 2 * h; ++m) q[m] = A * M[n + (m - h)];
@@ -636,10 +680,11 @@ static inline double F_Ww(const og_grid *G, const double *rw, const double *w, i
 void og_u_tendency(const og_grid *G, double *Gu, const double *ru, const double *rv,
                    const double *rw, const double *u)
 {
+    const int i0 = (G->tx == BOUNDED) ? 1 : 0;      /* Bounded x: the wall face i = 0 is never updated */
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < G->Nz; ++k)
         for (int j = 0; j < G->Ny; ++j)
-            for (int i = 0; i < G->Nx; ++i) {
+            for (int i = i0; i < G->Nx; ++i) {
                 double Vinv = 1.0 / (G->dx * G->dy * dzc_at(G, k));
                 double a = 0.0, b = 0.0, c = 0.0;
                 if (G->tx != FLAT) a = F_Uu(G, ru, u, i, j, k) - F_Uu(G, ru, u, i - 1, j, k);
@@ -806,7 +851,7 @@ void og_pressure_correct(const og_grid *G, double *ru, double *rv, double *rw,
                 size_t n = IDX(G, i, j, k);
                 double rf = 0.5 * (rho[k - 1] + rho[k]);
                 double rc = rho[k];
-                if (G->tx != FLAT) ru[n] -= rc * dt * ((phi[n] - phi[n - 1]) * (1.0 / G->dx));
+                if (G->tx != FLAT && !(G->tx == BOUNDED && i == 0)) ru[n] -= rc * dt * ((phi[n] - phi[n - 1]) * (1.0 / G->dx));
                 if (G->ty != FLAT && !(G->ty == BOUNDED && j == 0)) rv[n] -= rc * dt * ((phi[n] - phi[n - STRY(G)]) * (1.0 / G->dy));
                 rw[n] -= rf * dt * ((phi[n] - phi[n - STRZ(G)]) * (1.0 / G->dzf[k + G->Hz]));
             }

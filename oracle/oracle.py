@@ -165,7 +165,7 @@ class Grid:
         self.Nx, self.Ny, self.Nz = N
         self.Hx, self.Hy, self.Hz = H
         assert topo[2] == BOUNDED, "oracle supports Bounded z only"
-        assert topo[0] in (PERIODIC, FLAT) and topo[1] in (PERIODIC, FLAT, SLAB, BOUNDED)      # Bounded y: (Periodic, Bounded, Bounded)
+        assert topo[0] in (PERIODIC, FLAT, BOUNDED) and topo[1] in (PERIODIC, FLAT, SLAB, BOUNDED)      # walls: (Periodic, Bounded, Bounded), (Bounded, Flat, Bounded)
 
         def regular(ext, n, flat):
             if flat:
@@ -360,15 +360,17 @@ class OracleModel:
                           _p(r.temperature), c.g, c.Rd, c.Rv, c.cpd, c.cpv, r.pst)
 
     # -- halo filling -------------------------------------------------------
-    def _halo_xy(self, f, yface=False):
-        # x / y of every field: periodic wrap; a Bounded y adds the no-flux row (centres in y) or the impenetrable wall faces (y-faces)
+    def _halo_xy(self, f, yface=False, xface=False):
+        # x / y of every field: periodic wrap; a Bounded direction adds the no-flux cell / row (centres) or the impenetrable wall faces
         cg = C.byref(self.cg)
         self.lib.og_fill_halo_periodic_xy(cg, _p(f), C.c_int(f.shape[0]))
+        if self.grid.topo[0] == BOUNDED:
+            (self.lib.og_fill_halo_x_wall if xface else self.lib.og_fill_halo_x_noflux)(cg, _p(f), C.c_int(f.shape[0]))
         if self.grid.topo[1] == BOUNDED:
             (self.lib.og_fill_halo_y_wall if yface else self.lib.og_fill_halo_y_noflux)(cg, _p(f), C.c_int(f.shape[0]))
 
-    def _halo_center(self, f, yface=False):
-        self._halo_xy(f, yface)
+    def _halo_center(self, f, yface=False, xface=False):
+        self._halo_xy(f, yface, xface)
         if self.grid.Hz > 0:
             self.lib.og_fill_halo_z_noflux(C.byref(self.cg), _p(f))
 
@@ -377,11 +379,11 @@ class OracleModel:
         if wall:
             self.lib.og_fill_halo_z_wall(C.byref(self.cg), _p(f))
 
-    def _halo_velocity(self, f, yface=False):   # `nothing` BC in z: periodic wrap only (anelastic_dynamics.jl:174-182)
-        self._halo_xy(f, yface)
+    def _halo_velocity(self, f, yface=False, xface=False):   # `nothing` BC in z: periodic wrap only (anelastic_dynamics.jl:174-182)
+        self._halo_xy(f, yface, xface)
 
     def fill_momentum_halos(self):
-        self._halo_center(self.ru)
+        self._halo_center(self.ru, xface=True)
         self._halo_center(self.rv, yface=True)
         self._halo_w(self.rw)
 
@@ -465,7 +467,7 @@ class OracleModel:
         self._halo_center(self.rq)
         self.lib.og_compute_velocities(cg, _p(self.u), _p(self.v), _p(self.w), _p(self.ru), _p(self.rv), _p(self.rw))
         for f in (self.u, self.v, self.w):
-            self._halo_velocity(f, yface=f is self.v)
+            self._halo_velocity(f, yface=f is self.v, xface=f is self.u)
         if self.microphysics == "Kessler":
             # microphysical_state + grid_moisture_fractions + update_microphysical_auxiliaries! (dcmip2016_kessler.jl:222-227,
             # 298-303,860-865): q = (q^v, q^cl + q^r), T = Pi(q) theta + L q^l / c_pm
@@ -576,10 +578,16 @@ class OracleModel:
         FFT x,y -> complex Thomas in z -> inverse FFT -> subtract mean -> real part."""
         g = self.grid
         workers = getattr(self, "fft_workers", 1)
-        if g.topo[1] == BOUNDED:       # cosine transform along the Bounded direction (DCT-II forward, its inverse back), FFT along x
+        if BOUNDED in (g.topo[0], g.topo[1]):       # cosine transform along a Bounded direction (DCT-II forward, its inverse back), FFT along a periodic one
             import scipy.fft as sfft
-            fft2 = lambda a: sfft.fft(sfft.dct(a.real, type=2, axis=1) + 1j * sfft.dct(a.imag, type=2, axis=1), axis=2)
-            ifft2 = lambda a: (lambda b: sfft.idct(b.real, type=2, axis=1) + 1j * sfft.idct(b.imag, type=2, axis=1))(sfft.ifft(a, axis=2))
+
+            def along(a, axis, topo, inverse):
+                if topo == BOUNDED:
+                    t = sfft.idct if inverse else sfft.dct
+                    return t(a.real, type=2, axis=axis) + 1j * t(a.imag, type=2, axis=axis)
+                return (sfft.ifft if inverse else sfft.fft)(a, axis=axis)      # Flat: a length-1 transform
+            fft2 = lambda a: along(along(a, 1, g.topo[1], False), 2, g.topo[0], False)
+            ifft2 = lambda a: along(along(a, 2, g.topo[0], True), 1, g.topo[1], True)
         elif workers > 1:       # bench.py's cpu_baseline leg: the same pocketfft transforms on several host threads
             import scipy.fft as sfft
             fft2 = lambda a: sfft.fft2(a, axes=(1, 2), workers=workers)

@@ -25,6 +25,27 @@ def test_dry_thermal_bubble_jl(bz):
     assert _finite(model) and model.velocities["w"].interior_cpu().max() > 0.5      # the bubble rises
 
 
+def test_cloudy_thermal_bubble_jl(bz):
+    """examples/cloudy_thermal_bubble.jl:20-75,96-140: (Bounded, Flat, Bounded), 128 x 128, halo (5, 5), surface_pressure 1e5, WENO(order = 9);
+    first dry, then with SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) (parity: tests/test_bounded_x.py)"""
+    grid = bz.RectilinearGrid((128, 128), halo=(5, 5), x=(-10e3, 10e3), z=(0.0, 10e3), topology=(bz.Bounded, bz.Flat, bz.Bounded))
+    tc = bz.ThermodynamicConstants()
+    for micro in (None, bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium())):
+        ref = bz.ReferenceState(grid, tc, surface_pressure=1e5, potential_temperature=300.0)
+        model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), thermodynamic_constants=tc, advection=bz.WENO(order=9), microphysics=micro)
+        θ = lambda x, z: 300.0 + 2.0 * np.cos(np.pi * np.minimum(1.0, np.sqrt((x / 2e3) ** 2 + ((z - 2e3) / 2e3) ** 2)) / 2) ** 2
+        if micro is None:
+            model.set(θ=θ)
+        else:
+            model.set(θ=θ, qᵗ=lambda x, z: 0.020 * np.exp(-z / 2000.0) + 0 * x)
+        for _ in range(20):
+            model.time_step(2.0)
+        model.synchronize()
+        assert _finite(model) and model.velocities["w"].interior_cpu().max() > 0.1      # the bubble rises
+        assert float(model.momentum["ρu"].interior[:, :, 0].abs().max()) == 0.0          # the west wall stays closed
+        assert model.max_abs_divergence() < 1e-10
+
+
 def test_bomex_jl(bz):
     """examples/bomex.jl:40-210: Float32, WENO(order = 9), SaturationAdjustment, SmagorinskyLilly, Coriolis + geostrophic + subsidence +
     drying / cooling forcings, bottom fluxes (parity: tests/test_closure.py, test_forcings.py, test_float32.py)"""

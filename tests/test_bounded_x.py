@@ -138,3 +138,46 @@ def test_cloudy_bubble_between_x_walls_matches_oracle(oracle, bz):
         want, got = g.interior(getattr(om, n), n == "rw"), f.interior_cpu()
         scale = mom if n in ("ru", "rw") else max(np.abs(want).max(), 1e-6)
         assert np.abs(got - want).max() < 2e-8 * scale, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("option", ["tracers", "StaticEnergy", "Kessler"])
+def test_cell_local_options_between_x_walls(oracle, bz, option):
+    """tracers (the scalar kernel again), the StaticEnergy formulation and the Kessler column physics in the walled 2-D box, three steps"""
+    tol = 1e-9
+    if option == "tracers":
+        g, om, hm = _pair(oracle, bz, (32, 16), 5, (3, 3), okw=dict(tracers=1), hkw=dict(tracers=("a",)))
+        a = lambda x, z: 1.0 + 0.5 * np.cos(np.pi * (x + 10e3) / 20e3) * (z / 10e3)
+        om.set(theta=lambda x, y, z: theta_bubble(x, z), rc0=lambda x, y, z: a(x, z))
+        hm.tracers["a"].set_interior(a)
+        hm.set(θ=lambda x, z: theta_bubble(x, z))
+        extra = [("rc0", hm.tracers["a"])]
+    elif option == "StaticEnergy":
+        g, om, hm = _pair(oracle, bz, (32, 16), 5, (3, 3), okw=dict(formulation="StaticEnergy"), hkw=dict(formulation="StaticEnergy"))
+        om.set(theta=lambda x, y, z: theta_bubble(x, z))
+        hm.set(θ=lambda x, z: theta_bubble(x, z))
+        extra, tol = [], 2e-8          # e ~ 3e5 J/kg: two more digits of cancellation in the smoothness indicators (tests/test_bounded_y.py)
+    else:
+        tc = bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula())
+        g = oracle.Grid((32, 20), topology=TOPO, x=(0.0, 4e3), z=(0.0, 5e3))
+        om = oracle.OracleModel(g, surface_pressure=1e5, potential_temperature=300.0, microphysics="Kessler")
+        grid = bz.RectilinearGrid((32, 20), topology=(bz.Bounded, bz.Flat, bz.Bounded), x=(0.0, 4e3), z=(0.0, 5e3))
+        hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, tc, surface_pressure=1e5, potential_temperature=300.0)),
+                                advection=bz.WENO(order=5), thermodynamic_constants=tc, microphysics=bz.DCMIP2016KesslerMicrophysics())
+        bub = lambda x, z: np.maximum(0.0, 1.0 - np.sqrt((x - 1e3) ** 2 + (z - 1500.0) ** 2) / 1200.0)
+        ic = dict(qt=lambda x, z: 0.016 * np.exp(-z / 3000.0) + 0.004 * bub(x, z), theta=lambda x, z: 300.0 + 0.004 * z + 1.0 * bub(x, z),
+                  qcl=lambda x, z: 0.003 * bub(x, z), qr=lambda x, z: 0.001 * bub(x, z))
+        om.set(**{k: (lambda f: (lambda x, y, z: f(x, z)))(f) for k, f in ic.items()}, u=2.0)
+        hm.set(qᵗ=ic["qt"], θ=ic["theta"], qcl=ic["qcl"], qr=ic["qr"], u=2.0)
+        μ = hm.microphysical_fields
+        extra, tol = [("rqcl", μ["ρqᶜˡ"]), ("rqr", μ["ρqʳ"])], 1e-8
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    mom = max(np.abs(g.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rw"))
+    for n, f in [("ru", hm.momentum["ρu"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density), ("T", hm.temperature)] + extra:
+        want, got = g.interior(getattr(om, n), n == "rw"), f.interior_cpu()
+        scale = mom if n in ("ru", "rw") else max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() < tol * scale, (n, np.abs(got - want).max() / scale)
+    assert float(hm.momentum["ρu"].interior[:, :, 0].abs().max()) == 0.0

@@ -338,7 +338,10 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     // Flat y: the anelastic model steps with one kernel per reference kernel (bz_tendency.hip); the compressible kernels reach their
     // y neighbours through wrap offsets, which are zero when Ny = 1 (bz_compressible.hip: wrap_of), and keep their fused sequence
     if (flat_y) { if (!compressible) ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }
-    if (bounded_y) { ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }      // one kernel per reference kernel, row-wise buffers (bz_tendency.hip)
+    if (bounded_y) {      // per-operator entry points: one kernel per reference kernel, row-wise buffers (bz_tendency.hip); whole steps of the dry
+        ctx->walls_lean_ok = ctx->fused_ok;      // model: the lean seam with its WY kernels (bz_step.hip)
+        ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false;
+    }
     ctx->compressible = compressible;
     ctx->dz_min = dzc[Hz];
     for (int k = 0; k < Nz; ++k) ctx->dz_min = std::fmin(ctx->dz_min, dzc[Hz + k]);

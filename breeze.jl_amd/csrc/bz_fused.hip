@@ -89,6 +89,26 @@ __device__ __forceinline__ void st_img_only(double *__restrict__ f, long long n,
     }
 }
 
+// y image of row j: the periodic image (wrap_y), or — walls in y — the first halo row next to a wall row (no-flux copy of a centre-in-y
+// field: the convention of the halo fill, bz_halo.hip); 0: none (interior rows; y-slabs, whose halos the neighbour ranks fill)
+__device__ __forceinline__ long long bz_y_image(const DevGrid &g, int j)
+{
+    if (g.bounded_y) return (j == 0) ? -(long long)g.Sx : (j == g.Ny - 1) ? (long long)g.Sx : 0;
+    if (!g.wrap_y) return 0;
+    return (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
+}
+// store of a y-face field (rho v, v): x image only; next to the north wall also the wall face j = Ny (zero) in the first halo row
+__device__ __forceinline__ void st_yface(const DevGrid &g, double *__restrict__ f, long long n, double v, long long ox, int j)
+{
+    if (!g.bounded_y) return;
+    f[n] = v;
+    if (ox) f[n + ox] = v;
+    if (j == g.Ny - 1) {
+        f[n + g.Sx] = 0.0;
+        if (ox) f[n + g.Sx + ox] = 0.0;
+    }
+}
+
 // Block order of the two projection kernels (1-D launch of gx * Ny * nk workgroups).  They read phi at (i, j, k), (i-1, j, k),
 // (i, j-1, k) and (i, j, k-1); launched as a (gx, Ny, nk) grid, the row below belonged to a workgroup on ANOTHER XCD (consecutive
 // workgroup ids go round-robin to the 8 XCDs, each with its own L2), and the level below had been read a whole plane of seven
@@ -141,7 +161,8 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const long long sz = g.Sxy;
     // periodic images of this column in the halo (requires Nx >= 2Hx, Ny >= 2Hy: at most one per direction)
     const long long ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
-    const long long oy = !g.wrap_y ? 0 : (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
+    const long long oy = bz_y_image(g, j);
+    const bool wall = g.bounded_y && j == 0;      // walls in y: the wall face of rho v / v keeps its zero
     // contiguous-buffer neighbours (periodic wrap)
     const long long cplane = (long long)g.Nx * g.Ny;
     const long long m = (long long)i + (long long)g.Nx * j + cplane * k;
@@ -152,12 +173,13 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
     const double rc = g.rho[k], rf = g.rho_f[k];
     const double p = F.phi_c[m];
     const double p_im = F.phi_c[m + c_im];
-    const double p_jm = (j == 0 && !g.wrap_y) ? F.phi_below[(long long)i + (long long)g.Nx * k] : F.phi_c[m + c_jm];
+    const double p_jm = wall ? p : (j == 0 && !g.wrap_y) ? F.phi_below[(long long)i + (long long)g.Nx * k] : F.phi_c[m + c_jm];
 
     // _pressure_correct_momentum!
     double ru = F.ru_in[n], rv = F.rv_in[n];
     ru -= rc * dt * ((p - p_im) * g.rdx);
     rv -= rc * dt * ((p - p_jm) * g.rdy);
+    if (wall) rv = 0.0;
     // _compute_velocities!
     double u = ru / rc, v = rv / rc;
     // thermodynamic diagnosis
@@ -179,9 +201,9 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
 
     if (F.store_phi) st_img(F.phi, n, p, ox, oy);
     st_img(F.ru, n, ru, ox, oy);
-    st_img(F.rv, n, rv, ox, oy);
+    if (g.bounded_y) { st_yface(g, F.rv, n, rv, ox, j); st_yface(g, F.v, n, v, ox, j); }
+    else { st_img(F.rv, n, rv, ox, oy); st_img(F.v, n, v, ox, oy); }
     st_img(F.u, n, u, ox, oy);
-    st_img(F.v, n, v, ox, oy);
     st_img(F.theta, n, th, ox, oy);
     st_img(F.q, n, q, ox, oy);
     st_img(F.T, n, T, ox, oy);
@@ -214,7 +236,8 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
         const long long h = bot ? -sz : sz;
         if (F.store_phi) st_img(F.phi, n + h, p, ox, oy);
         st_img(F.ru, n + h, ru, ox, oy);
-        st_img(F.rv, n + h, rv, ox, oy);
+        if (g.bounded_y) st_yface(g, F.rv, n + h, rv, ox, j);
+        else st_img(F.rv, n + h, rv, ox, oy);
         st_img(F.theta, n + h, th, ox, oy);
         st_img(F.q, n + h, q, ox, oy);
         st_img(F.T, n + h, T, ox, oy);
@@ -233,7 +256,8 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
         st_img(F.rq, n + h, rq, ox, oy);
         if (top) {
             st_img(F.u, n + sz, u, ox, oy);
-            st_img(F.v, n + sz, v, ox, oy);
+            if (g.bounded_y) st_yface(g, F.v, n + sz, v, ox, j);
+            else st_img(F.v, n + sz, v, ox, oy);
         }
     }
 }
@@ -258,7 +282,8 @@ __global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, dou
     if (i >= g.Nx) return;
     const long long sz = g.Sxy;
     const long long ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
-    const long long oy = !g.wrap_y ? 0 : (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
+    const long long oy = bz_y_image(g, j);
+    const bool wall = g.bounded_y && j == 0;      // walls in y: the wall face of rho v keeps its zero
     const long long cplane = (long long)g.Nx * g.Ny;
     const long long m = (long long)i + (long long)g.Nx * j + cplane * k;
     const long long c_im = (i > 0) ? -1 : g.Nx - 1;
@@ -268,12 +293,14 @@ __global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, dou
     const double rc = g.rho[k], rf = g.rho_f[k];
     const double p = F.phi_c[m];
     const double p_im = F.phi_c[m + c_im];
-    const double p_jm = (j == 0 && !g.wrap_y) ? F.phi_below[(long long)i + (long long)g.Nx * k] : F.phi_c[m + c_jm];
+    const double p_jm = wall ? p : (j == 0 && !g.wrap_y) ? F.phi_below[(long long)i + (long long)g.Nx * k] : F.phi_c[m + c_jm];
     double ru = F.ru_in[n], rv = F.rv_in[n];
     ru -= rc * dt * ((p - p_im) * g.rdx);
     rv -= rc * dt * ((p - p_jm) * g.rdy);
+    if (wall) rv = 0.0;
     st_img(F.ru, n, ru, ox, oy);
-    st_img(F.rv, n, rv, ox, oy);
+    if (g.bounded_y) st_yface(g, F.rv, n, rv, ox, j);
+    else st_img(F.rv, n, rv, ox, oy);
     if (!bot) {
         const double p_km = F.phi_c[m - cplane];
         double rw = F.rw_in[n];
@@ -283,7 +310,8 @@ __global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, dou
     if (bot || top) {
         const long long h = bot ? -sz : sz;
         st_img(F.ru, n + h, ru, ox, oy);
-        st_img(F.rv, n + h, rv, ox, oy);
+        if (g.bounded_y) st_yface(g, F.rv, n + h, rv, ox, j);
+        else st_img(F.rv, n + h, rv, ox, oy);
     }
     if (ox | oy) {          // edge cells only: the halo images of the scalars
         st_img_only(F.sa, n, F.sa[n], ox, oy);

@@ -288,6 +288,7 @@ struct bz_ctx {
     bz_constants constants;
     DevGrid dg;
     hipStream_t stream = nullptr;
+    bool walls_lean_ok = false;       // (Periodic, Bounded, Bounded): the grid is large enough for the lean seam's tiles (Nx >= 2 Hx, Ny >= 2 Hy)
     int num_cus = 256;                // compute units of the device (persistent-workgroup launches size their grids with it)
     std::string last_error;
 

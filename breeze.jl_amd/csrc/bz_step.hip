@@ -51,7 +51,10 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
 {
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
-    if (ctx->fused_ok && ctx->fuse_rk && ctx->lean && ctx->weno_R == 3 && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
+    // walls in y ((Periodic, Bounded, Bounded)) ride the lean seam too (WY kernels, wall rows in the projection kernels); every other
+    // configuration with walls steps operator by operator
+    const bool walls_lean = ctx->dg.bounded_y && ctx->walls_lean_ok;
+    if ((ctx->fused_ok || walls_lean) && ctx->fuse_rk && ctx->lean && ctx->weno_R == 3 && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
         (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask &&
         (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32)) {
         // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,

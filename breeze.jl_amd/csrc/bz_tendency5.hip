@@ -123,7 +123,10 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         E.u0 = U0->rho_u; E.u0_out = U0->rho_u;
         L.out = G->rho_u;
         const dim3 grid = shape(g.Nz, kc);
-        if (L.mforce) hipLaunchKernelGGL((k6_u<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (g.bounded_y) {      // walls in y: the WY instantiations (row-wise buffers)
+            if (L.mforce) hipLaunchKernelGGL((k6_u<TY, true, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+            else hipLaunchKernelGGL((k6_u<TY, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        } else if (L.mforce) hipLaunchKernelGGL((k6_u<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
         else hipLaunchKernelGGL((k6_u<TY, false>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 1) {
@@ -131,7 +134,10 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
         L.out = G->rho_v;
         const dim3 grid = shape(g.Nz, kc);
-        if (L.mforce) hipLaunchKernelGGL((k6_v<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (g.bounded_y) {
+            if (L.mforce) hipLaunchKernelGGL((k6_v<TY, true, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+            else hipLaunchKernelGGL((k6_v<TY, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        } else if (L.mforce) hipLaunchKernelGGL((k6_v<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
         else hipLaunchKernelGGL((k6_v<TY, false>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 1) {
@@ -139,14 +145,16 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         E.u0 = U0->rho_w; E.u0_out = U0->rho_w;
         L.out = G->rho_w;
         const dim3 grid = shape(g.Nz - 1, kc);
-        hipLaunchKernelGGL((k6_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (g.bounded_y) hipLaunchKernelGGL((k6_w<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     if (which & 2) {
         ProfileScope ps(ctx, "scalar_tendencies+rk3+thermo");
         E.u0 = U0->rho_theta; E.u0_out = U0->rho_theta; E.u0b = U0->rho_q; E.u0b_out = U0->rho_q;
         L.out = nullptr;
         const dim3 grid = shape(g.Nz, kc);
-        hipLaunchKernelGGL((k5_scalar_pair<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (g.bounded_y) hipLaunchKernelGGL((k5_scalar_pair<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k5_scalar_pair<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     BZ_LAUNCH_CHECK();
     return BZ_OK;

@@ -139,13 +139,31 @@ __device__ __forceinline__ double bz_temperature5r(const DevGrid &g, double rth,
     return bz_exner_pow5(g.p_r[k] / g.pst, Rm / cpm) * th;
 }
 
+// Walls in y (topology (Periodic, Bounded, Bounded)): WY instantiations of the four kernels reconstruct in y with the buffer that fits
+// at the row (wave-uniform: a wavefront is one row of the tile) and interpolate the advecting mass flux with the matching Centered order,
+// exactly as the per-operator kernels do (bz_tendency.hip: by_face, by_center, symm_y).  WY = false compiles to the code it replaced.
+template <bool WY> __device__ __forceinline__ int by5_face(const DevGrid &g, int j) { return WY ? bz_buffer_face(j, g.Ny) : 3; }
+template <bool WY> __device__ __forceinline__ int by5_center(const DevGrid &g, int j) { return WY ? bz_buffer_center(j, g.Ny) : 3; }
+template <bool WY>
+__device__ __forceinline__ double bz_up5y(double m3, double m2, double m1, double p0, double p1, double p2, bool left, int B)
+{
+    if constexpr (WY) return bz_upB(m3, m2, m1, p0, p1, p2, left, B);
+    else return bz_up5(m3, m2, m1, p0, p1, p2, left);
+}
+template <bool WY>
+__device__ __forceinline__ double bz_symm4y(double qm2, double qm1, double q0, double qp1, int B)
+{
+    if constexpr (WY) return (B == 3) ? bz_symm4(qm2, qm1, q0, qp1) : bz_symm2(qm1, q0);
+    else return bz_symm4(qm2, qm1, q0, qp1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // rho theta + rho q: tendencies -div_rhoUc(theta), -div_rhoUc(q) and their SSP-RK3 update, from rho u, rho v, rho w,
 // rho theta, rho q alone.  Structure of k_scalar_pair_lds: 64 x TY tile marching in z, (TY+6) x 70 frame of theta and q in LDS
 // (double-buffered, frame cells prefetched one level ahead), y-face fluxes shared through LDS, x-face fluxes through a wave
 // shuffle + the batched out-of-wave flux, z stencils in register rings.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY>
+template <int TY, bool WY = false>
 __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN_WAVES, BZ_LEAN_WAVES))) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72;                 // tile rows, padded row length (70 used)
@@ -167,6 +185,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
     const int ie = i0 + nact, le = nact - 1;
     const int kbeg = bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
     if (kbeg >= kend) return;                           // block-uniform
+    const int Byj = by5_face<WY>(g, j0 + tyu), Byt = by5_face<WY>(g, j0 + TY);      // y buffers of the own low face and of the face above the tile
     const unsigned sz = (unsigned)g.Sxy;      // 32-bit element indices: the context checks that a parent array holds < 2^32 elements
     const bool store = (i < g.Nx) && (j < g.Ny);
     const double *__restrict__ ru = F.ru, *__restrict__ rv = F.rv, *__restrict__ rw = F.rw;
@@ -295,10 +314,10 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
             const double(*Tk)[TC] = T[buf][0];
             const double *rr_ = Tk[ty + 3] + tx;
             fxa = rho * (cfx * bz_up5(rr_[0], rr_[1], rr_[2], a[3], rr_[4], rr_[5], lx));
-            fya = rho * (cfy * bz_up5(Tk[ty][c], Tk[ty + 1][c], Tk[ty + 2][c], a[3], Tk[ty + 4][c], Tk[ty + 5][c], ly));
+            fya = rho * (cfy * bz_up5y<WY>(Tk[ty][c], Tk[ty + 1][c], Tk[ty + 2][c], a[3], Tk[ty + 4][c], Tk[ty + 5][c], ly, Byj));
             FY[buf][0][ty][tx] = fya;
             if (duty_a)
-                FY[buf][0][TY][tx] = rho * (cfy2 * bz_up5(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2));
+                FY[buf][0][TY][tx] = rho * (cfy2 * bz_up5y<WY>(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2, Byt));
             fza_hi = rf * (cfz * bz_upB(a[1], a[2], a[3], a[4], a[5], ta, lz, Bz));
         }
         const double tb = bz_cdiv(tb_raw, rho3, rrho3);
@@ -306,10 +325,10 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
             const double(*Tk)[TC] = T[buf][1];
             const double *rr_ = Tk[ty + 3] + tx;
             fxb = rho * (cfx * bz_up5(rr_[0], rr_[1], rr_[2], b[3], rr_[4], rr_[5], lx));
-            fyb = rho * (cfy * bz_up5(Tk[ty][c], Tk[ty + 1][c], Tk[ty + 2][c], b[3], Tk[ty + 4][c], Tk[ty + 5][c], ly));
+            fyb = rho * (cfy * bz_up5y<WY>(Tk[ty][c], Tk[ty + 1][c], Tk[ty + 2][c], b[3], Tk[ty + 4][c], Tk[ty + 5][c], ly, Byj));
             FY[buf][1][ty][tx] = fyb;
             if (duty_b)
-                FY[buf][1][TY][tx] = rho * (cfy2 * bz_up5(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2));
+                FY[buf][1][TY][tx] = rho * (cfy2 * bz_up5y<WY>(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2, Byt));
             fzb_hi = rf * (cfz * bz_upB(b[1], b[2], b[3], b[4], b[5], tb, lz, Bz));
         }
         // the cell's own prognostic values (read three levels ago as ring tops: an L2 / Infinity-Cache hit), requested before the staging
@@ -356,11 +375,12 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
 
 // out-of-wave x fluxes of the momentum kernels with the advected velocity derived from its momentum component
 // (flux_x_at of bz_tendency3_kernels.h with c = m / rho)
+// By: walls in y — buffer of the y-face the advecting flux of the v kernel is interpolated to (3: order 4, the periodic case)
 template <int KIND>
-__device__ __forceinline__ double flux_x_lean(const DevGrid &g, const Tend3Fields &F, const double *__restrict__ m, int i, int j, int k)
+__device__ __forceinline__ double flux_x_lean(const DevGrid &g, const Tend3Fields &F, const double *__restrict__ m, int i, int j, int k, int By = 3)
 {
     const long long n = g.idx(i, j, k);
-    const double a = adv_x<KIND>(g, F, n, k);
+    const double a = (KIND == T3_V && By != 3) ? bz_symm2(g.Ax[k] * F.ru[n - g.Sx], g.Ax[k] * F.ru[n]) : adv_x<KIND>(g, F, n, k);
     const double rh = (KIND == T3_W) ? g.rho_f[k] : g.rho[k], rr = (KIND == T3_W) ? g.rrho_f[k] : g.rrho[k];
     if constexpr (KIND == T3_U)
         return a * bz_up5(bz_cdiv(m[n - 2], rh, rr), bz_cdiv(m[n - 1], rh, rr), bz_cdiv(m[n], rh, rr), bz_cdiv(m[n + 1], rh, rr),
@@ -380,7 +400,7 @@ __device__ __forceinline__ double flux_x_lean(const DevGrid &g, const Tend3Field
 // <= 2 frame cells), consumes them at its end, and reads its stencils with ds_read (tiles: u derived (TY+6) x 70; raw rho_u TY x 67;
 // raw rho_v (TY+1) x 67; raw rho_w TY x 67 at the upper face; double-buffered).  Same arithmetic, same bits as k5_u.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY, bool MF = false>      // MF: momentum terms of a forcing stack in the RK epilogue (Lean5::mforce)
+template <int TY, bool MF = false, bool WY = false>      // MF: momentum terms of a forcing stack in the RK epilogue (Lean5::mforce); WY: walls in y
 __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY;
@@ -474,12 +494,13 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
         // ---- y: flux at the own low y-face ----
         const double *rvr = RV[buf][ty] + tc;
         const double ay = bz_symm4(Ay * rvr[-2], Ay * rvr[-1], Ay * rvr[0], Ay * rvr[1]);
-        const double fy = ay * bz_up5(Uk[ty][tc], Uk[ty + 1][tc], Uk[ty + 2][tc], c0, Uk[ty + 4][tc], Uk[ty + 5][tc], ay > 0.0);
+        const double fy = ay * bz_up5y<WY>(Uk[ty][tc], Uk[ty + 1][tc], Uk[ty + 2][tc], c0, Uk[ty + 4][tc], Uk[ty + 5][tc], ay > 0.0, by5_face<WY>(g, __builtin_amdgcn_readfirstlane(j)));
         FY[buf][ty][tx] = fy;
         if (ty == 0) {
             const double *rvt = RV[buf][TY] + tc;
             const double at = bz_symm4(Ay * rvt[-2], Ay * rvt[-1], Ay * rvt[0], Ay * rvt[1]);
-            FY[buf][TY][tx] = at * bz_up5(Uk[TY][tc], Uk[TY + 1][tc], Uk[TY + 2][tc], Uk[TY + 3][tc], Uk[TY + 4][tc], Uk[TY + 5][tc], at > 0.0);
+            FY[buf][TY][tx] = at * bz_up5y<WY>(Uk[TY][tc], Uk[TY + 1][tc], Uk[TY + 2][tc], Uk[TY + 3][tc], Uk[TY + 4][tc], Uk[TY + 5][tc], at > 0.0,
+                                               by5_face<WY>(g, j0 + TY));
         }
         // ---- z: upper face k+1 ----
         const double tnew = bz_cdiv(tcur_raw, g.rho[k + 3], g.rrho[k + 3]);
@@ -529,7 +550,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
 // y-momentum, sixth generation (see k6_u): the v tile carries its x halo, so the x-stencil is five ds_reads instead of five loads +
 // five column divisions; ring top and u0 are loaded one level ahead.  Same arithmetic, same bits as k5_v.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY, bool MF = false>
+template <int TY, bool MF = false, bool WY = false>
 __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles
@@ -549,7 +570,9 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
     const int kbeg = bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
     if (kbeg >= kend) return;
     const ix_t sz = (ix_t)g.Sxy;
-    const bool store = (i < g.Nx) && (j < g.Ny);
+    const bool store = (i < g.Nx) && (j < g.Ny) && !(WY && j == 0);      // walls in y: the wall face is never updated
+    const int ju = __builtin_amdgcn_readfirstlane(j);      // one row per wavefront
+    const int Bf = by5_face<WY>(g, ju), Bc = by5_center<WY>(g, ju), Bc0 = by5_center<WY>(g, j0 - 1);
     const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
     Tend3Fields F;
     F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
@@ -591,7 +614,11 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
     double r[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) r[s] = bz_cdiv(rv[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
-    double fz_lo = vflux<T3_V>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
+    double fz_lo;
+    if (WY && Bf != 3) {      // walls in y: the advecting flux at (y-face j, z-face kbeg) from rows j-1, j only
+        const double wt0 = bz_symm2(Az * rw[n - (ix_t)g.Sx], Az * rw[n]);
+        fz_lo = wt0 * bz_upB(r[0], r[1], r[2], r[3], r[4], r[5], wt0 > 0.0, bz_buffer_face(kbeg, g.Nz));
+    } else fz_lo = vflux<T3_V>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
     // raw rho_v of the own column at levels k .. k+2 (the ring-top load of level k+3 enters at the end of each iteration)
     double q0 = rv[n], q1 = rv[n + sz], q2 = rv[n + 2 * sz];
     Tv[0][ty + 3][tc] = r[3];
@@ -624,7 +651,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         if constexpr (MF) { if (L.mforce & 1) { const ix_t sy = (ix_t)g.Sx; cu0 = ru[n - sy]; cu1 = ru[n - sy + 1]; cu2 = ru[n]; cu3 = ru[n + 1]; } }
         if (((k - kbeg) & 63) == 0) {
             const int kk = min(k + tx, kend - 1);
-            edge = flux_x_lean<T3_V>(g, F, rv, ie, jc, kk);
+            edge = flux_x_lean<T3_V>(g, F, rv, ie, jc, kk, Bf);
         }
         const int src = (k - kbeg) & 63;
         const double rho = g.rho[k], rrho = g.rrho[k];
@@ -635,19 +662,19 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         const double(*MV)[64] = Tm[buf][1];
         const double(*MW)[64] = Tm[buf][2];
         // ---- x: flux at (x-face i, y-face j): rho_u rows j-2..j+1, v x-stencil derived from the rho_v row ----
-        const double ut = bz_symm4(MU[ty][tx], MU[ty + 1][tx], MU[ty + 2][tx], MU[ty + 3][tx]);
+        const double ut = bz_symm4y<WY>(MU[ty][tx], MU[ty + 1][tx], MU[ty + 2][tx], MU[ty + 3][tx], Bf);
         const double fx = ut * bz_up5(vrow[-3], vrow[-2], vrow[-1], c0, vrow[1], vrow[2], ut > 0.0);
-        // ---- y: flux at centre j: rho_v rows j-1..j+2, v rows j-2..j+3 ----
-        const double vt = bz_symm4(MV[ty + 1][tx], MV[ty + 2][tx], MV[ty + 3][tx], MV[ty + 4][tx]);
-        const double fy = vt * bz_up5(V[ty + 1][tc], V[ty + 2][tc], c0, V[ty + 4][tc], V[ty + 5][tc], V[ty + 6][tc], vt > 0.0);
+        // ---- y: flux at centre j: rho_v rows j-1..j+2, v rows j-2..j+3 (walls: order 2 from faces j, j+1 next to a wall) ----
+        const double vt = (!WY || Bc == 3) ? bz_symm4(MV[ty + 1][tx], MV[ty + 2][tx], MV[ty + 3][tx], MV[ty + 4][tx]) : bz_symm2(MV[ty + 2][tx], MV[ty + 3][tx]);
+        const double fy = vt * bz_up5y<WY>(V[ty + 1][tc], V[ty + 2][tc], c0, V[ty + 4][tc], V[ty + 5][tc], V[ty + 6][tc], vt > 0.0, Bc);
         FY[buf][ty + 1][tx] = fy;
         if (ty == 0) {       // centre j0-1: rho_v rows j0-2..j0+1, v rows j0-3..j0+2
-            const double vb = bz_symm4(MV[0][tx], MV[1][tx], MV[2][tx], MV[3][tx]);
-            FY[buf][0][tx] = vb * bz_up5(V[0][tc], V[1][tc], V[2][tc], V[3][tc], V[4][tc], V[5][tc], vb > 0.0);
+            const double vb = (!WY || Bc0 == 3) ? bz_symm4(MV[0][tx], MV[1][tx], MV[2][tx], MV[3][tx]) : bz_symm2(MV[1][tx], MV[2][tx]);
+            FY[buf][0][tx] = vb * bz_up5y<WY>(V[0][tc], V[1][tc], V[2][tc], V[3][tc], V[4][tc], V[5][tc], vb > 0.0, Bc0);
         }
         // ---- z: advecting flux at (y-face j, z-face k+1) from the rho_w tile rows j-2..j+1 ----
         const double tnew = bz_cdiv(tnew_raw, g.rho[k + 3], g.rrho[k + 3]);
-        const double wt = bz_symm4(MW[ty][tx], MW[ty + 1][tx], MW[ty + 2][tx], MW[ty + 3][tx]);
+        const double wt = bz_symm4y<WY>(MW[ty][tx], MW[ty + 1][tx], MW[ty + 2][tx], MW[ty + 3][tx], Bf);
         const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
         // ---- stage level k+1 ----
         Tv[buf ^ 1][ty + 3][tc] = r[4];
@@ -671,6 +698,10 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
                 if (L.mforce & 4) Gv += rho * L.Fv[k];
             }
             if (store) L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out, Gv, q0, n);
+            if constexpr (WY) {      // the wall faces of the predictor: j = 0 (this row, not updated) and j = Ny (first halo row above the last row)
+                if (i < g.Nx && j == 0) L.out[n] = 0.0;
+                if (i < g.Nx && j == g.Ny - 1) L.out[n + (ix_t)g.Sx] = 0.0;
+            }
         }
         fz_lo = fz_hi;
         q0 = q1; q1 = q2; q2 = tnew_raw;
@@ -698,7 +729,7 @@ __device__ __forceinline__ double buoyancy5(const DevGrid &g, double T, double r
 // five loads + five column divisions; the ring top, the own T / rho q values and u0 are loaded one level ahead; the raw rho_w of the
 // own column rides a register delay line (advecting-flux ring and RK update).  Same arithmetic, same bits as k5_w.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY>
+template <int TY, bool WY = false>
 __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY, NH = TR * 70 - TY * 64;
@@ -790,11 +821,12 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
         const double ut = (Bf == 3) ? bz_symm4(qu[0], qu[1], qu[2], qu[3]) : bz_symm2(qu[1], qu[2]);
         const double fx = ut * bz_up5(wrow[-3], wrow[-2], wrow[-1], w0, wrow[1], wrow[2], ut > 0.0);
         const double vt = (Bf == 3) ? bz_symm4(qv[0], qv[1], qv[2], qv[3]) : bz_symm2(qv[1], qv[2]);
-        const double fy = vt * bz_up5(Tk[ty][tc], Tk[ty + 1][tc], Tk[ty + 2][tc], w0, Tk[ty + 4][tc], Tk[ty + 5][tc], vt > 0.0);
+        const double fy = vt * bz_up5y<WY>(Tk[ty][tc], Tk[ty + 1][tc], Tk[ty + 2][tc], w0, Tk[ty + 4][tc], Tk[ty + 5][tc], vt > 0.0, by5_face<WY>(g, __builtin_amdgcn_readfirstlane(j)));
         FY[buf][ty][tx] = fy;
         if (top) {
             const double v2 = (Bf == 3) ? bz_symm4(qt[0], qt[1], qt[2], qt[3]) : bz_symm2(qt[1], qt[2]);
-            FY[buf][TY][tx] = v2 * bz_up5(Tk[TY][tc], Tk[TY + 1][tc], Tk[TY + 2][tc], Tk[TY + 3][tc], Tk[TY + 4][tc], Tk[TY + 5][tc], v2 > 0.0);
+            FY[buf][TY][tx] = v2 * bz_up5y<WY>(Tk[TY][tc], Tk[TY + 1][tc], Tk[TY + 2][tc], Tk[TY + 3][tc], Tk[TY + 4][tc], Tk[TY + 5][tc], v2 > 0.0,
+                                               by5_face<WY>(g, j0 + TY));
         }
         const double wnew = bz_cdiv(tcur_raw, g.rho_f[k + 3], g.rrho_f[k + 3]);
         double fz_hi;

@@ -188,6 +188,39 @@ def test_bounded_y_steps_match_oracle(oracle, bz, size, stretched):
     assert hm.max_abs_divergence() < 1e-11
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("forcings", [False, True])
+def test_walled_lean_seam_equals_the_operator_sequence(bz, forcings):
+    """Whole steps of the dry WENO5 model inside y walls ride the lean seam (WY instantiations of k5_scalar_pair / k6_u / k6_v / k6_w, wall rows
+    and no-flux rows written by the projection kernels — csrc/bz_step.hip: walls_lean); three steps against the reference's call
+    sequence through the per-operator entry points, whole parent arrays: the first halo rows and the wall faces included."""
+    models = []
+    for whole in (True, False):
+        if forcings:
+            m = bz.benchmarks.convective_boundary_layer((64, 32, 16), float_type=np.float64, topology=(bz.Periodic, bz.Bounded, bz.Bounded), halo=(3, 3, 3))
+            dt = 0.5
+        else:
+            grid = bz.RectilinearGrid((64, 32, 16), topology=(bz.Periodic, bz.Bounded, bz.Bounded), **EXT)
+            m = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)), advection=bz.WENO(order=5))
+            m.set(θ=theta0, u=u0, v=v0)
+            dt = 2.0
+        m.profile_enable(True)
+        for _ in range(3):
+            bz.time_step_(m, dt, whole_step=whole)
+        m.synchronize()
+        names = set(m.profile())
+        assert ("scalar_tendencies+rk3+thermo" in names) == whole, names          # the lean kernels ran / did not run
+        models.append(m)
+    a, b = models
+    H = a.grid.Hy
+    rows = slice(H - 1, H + a.grid.Ny + 1)                                          # interior rows + the first halo row on each side
+    for k in a.prognostic_fields():
+        x, y = a.prognostic_fields()[k].cpu()[:, rows], b.prognostic_fields()[k].cpu()[:, rows]
+        assert np.abs(x - y).max() / max(np.abs(y).max(), 1e-3) < 1e-12, k
+    for fa, fb in ((a.temperature, b.temperature), (a.velocities["v"], b.velocities["v"]), (a.velocities["w"], b.velocities["w"])):
+        assert np.abs(fa.cpu()[:, rows] - fb.cpu()[:, rows]).max() / np.abs(fb.cpu()).max() < 1e-12
+
+
 # ---- the cell- and column-local options of the model inside y walls: StaticEnergy, saturation adjustment, Kessler, tracers ------------------
 def _walled(oracle, bz, size, ext, okw=None, hkw=None, theta_ref=300.0, surface_pressure=None, constants=None):
     g = oracle.Grid(size, topology=TOPO, **ext)

@@ -167,8 +167,9 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
         ctx->G_is_predictor = true;
         return BZ_OK;
     }
-    if (ctx->fused_ok && ctx->fuse_rk && (ctx->weno_R == 3 || ctx->n_tracers == 0) && ctx->dg.formulation == 0 && ctx->dg.microphysics != 2 && !ctx->bounded_mask &&
-        !(ctx->has_forcings && ctx->tune.no_fuse_forcing)) {
+    // (walls in y: the generic order-7 / 9 kernels are wall-aware, the LDS-tiled order-5 kernels of this tier are not)
+    if ((ctx->fused_ok || (walls_lean && ctx->weno_R != 3)) && ctx->fuse_rk && (ctx->weno_R == 3 || ctx->n_tracers == 0) && ctx->dg.formulation == 0 &&
+        ctx->dg.microphysics != 2 && !ctx->bounded_mask && !(ctx->has_forcings && ctx->tune.no_fuse_forcing)) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state
         // left by stage s-1), the predictor momentum goes to the G arrays and is projected from there into the
@@ -192,6 +193,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             }
             if ((ctx->has_forcings || ctx->has_bulk) &&
                 (rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
+            if (g.bounded_y && (rc = bzi_fill_halo(ctx, G->rho_v, BZ_HALO_YFACE))) return rc;      // wall faces j = 0, Ny of the predictor (the source term reads face Ny)
             if ((rc = bzi_poisson_from_momentum(ctx, s, alpha * dt, G))) return rc;
             // pressure_anomaly is a diagnostic nobody reads inside the step: only the last stage scatters it
             if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, stage == 2))) return rc;

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFi
     // eddy viscosity of the 3 x 3 x 3 neighbourhood that the flux locations of this cell touch
     double nun[3][3][3];      // [dk+1][dj+1][di+1]; the 8 corners are never used
     {
-        const long long oi[3] = {(i == 0) ? (long long)(g.Nx - 1) : -1, 0, (i == g.Nx - 1) ? -(long long)(g.Nx - 1) : 1};
+        // walls in x: the columns -1 and Nx hold the no-flux copy (bz_compute_closure_fields fills them)
+        const long long oi[3] = {(i == 0 && !g.bounded_x) ? (long long)(g.Nx - 1) : -1, 0, (i == g.Nx - 1 && !g.bounded_x) ? -(long long)(g.Nx - 1) : 1};
         // y-slab (wrap_y == 0): rows -1 and Ny hold the viscosity the extended launch of k_smagorinsky_viscosity computed there
         const long long oj[3] = {((j == 0 && g.wrap_y) ? (long long)(g.Ny - 1) : -1) * sy, 0,
                                  ((j == g.Ny - 1 && g.wrap_y) ? -(long long)(g.Ny - 1) : 1) * sy};
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(256) void k_closure_tendencies(DevGrid g, ClosureFi
     auto T23 = [&](int dj, int dk) { return g.rho_f[k + dk] * (-2 * nu_cff(dj, dk) * S23(g, v, w, n + dj * sy + dk * sz, k + dk)); };
 
     const double t12_00 = T12(0, 0), t13_00 = T13(0, 0), t23_00 = T23(0, 0);
-    {   // x momentum at face i
+    if (!(g.bounded_x && i == 0)) {   // x momentum at face i (walls in x: the wall face is never updated)
         const double div = (Ax * T11(0) - Ax * T11(-1)) + (g.flat_y ? 0.0 : Ay * T12(0, 1) - Ay * t12_00) + (Az * T13(0, 1) - Az * t13_00);
         Gu[n] -= scale * (div * rVc);
     }
-    {   // y momentum at face j
+    if (!(g.bounded_y && j == 0)) {   // y momentum at face j (walls in y: the wall face is never updated)
         const double div = (Ax * T12(1, 0) - Ax * t12_00) + (Ay * T22(0) - Ay * T22(-1)) + (Az * T23(0, 1) - Az * t23_00);
         Gv[n] -= scale * (div * rVc);
     }
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void k_closure_scalar(DevGrid g, const double 
     const int i = bx * 256 + threadIdx.x, j = by, k = bz;
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k), sy = g.Sx, sz = g.Sxy;
-    const long long oxm = (i == 0) ? (long long)(g.Nx - 1) : -1, oxp = (i == g.Nx - 1) ? -(long long)(g.Nx - 1) : 1;
+    const long long oxm = (i == 0 && !g.bounded_x) ? (long long)(g.Nx - 1) : -1, oxp = (i == g.Nx - 1 && !g.bounded_x) ? -(long long)(g.Nx - 1) : 1;
     const long long oym = ((j == 0 && g.wrap_y) ? (long long)(g.Ny - 1) : -1) * sy, oyp = ((j == g.Ny - 1 && g.wrap_y) ? -(long long)(g.Ny - 1) : 1) * sy;
     const long long ozm = (k == 0) ? 0 : -sz, ozp = (k == g.Nz - 1) ? 0 : sz;
     const double dx = g.dx, dy = g.dy, dz = g.dzc[k];
@@ -224,7 +225,6 @@ __global__ __launch_bounds__(256) void k_closure_scalar(DevGrid g, const double 
 
 extern "C" int bz_set_closure(bz_ctx *ctx, const bz_smagorinsky_lilly *closure, double *eddy_viscosity)
 {
-    BZ_REJECT_BOUNDED_Y(ctx, closure != nullptr, "bz_set_closure");
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
     if (!ctx) return BZ_ERR_INVALID;
     if (!closure) { ctx->has_closure = false; ctx->closure_nu = nullptr; return BZ_OK; }
@@ -269,6 +269,9 @@ extern "C" int bz_compute_closure_fields(bz_ctx *ctx, const bz_state *s)
     hipLaunchKernelGGL(k_smagorinsky_viscosity, dim3((g.Nx + 255) / 256, g.Ny + (ctx->slab_mode ? 2 : 0), (g.Nz + SMAG_KCHUNK - 1) / SMAG_KCHUNK),
                        dim3(256), 0, ctx->stream, g, F, s->T, qv, ctx->d_closure_ipi + 1, ctx->d_closure_ipi + (g.Nz + 2) + 1, ctx->closure_nu);
     BZ_LAUNCH_CHECK();
+    // walls in y (or x): nu_e is a centre field with the default no-flux condition — its first halo rows mirror the wall rows (the tendency
+    // kernels reach rows -1 and Ny through the halo, as on y-slabs, where the extended launch above computes them)
+    if (g.bounded_y || g.bounded_x) return bzi_fill_halo(ctx, ctx->closure_nu, 0);
     return BZ_OK;
 }
 

@@ -184,15 +184,15 @@ class AtmosphereModel:
             # kernels drop the y terms
             raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model without Coriolis / forcings / flux boundary conditions is implemented")
         formulation = str(formulation).lstrip(":")
-        if bounded_x and (isinstance(advection, dict) or getattr(_base, "bounds", None) is not None or closure is not None or grid.Nx % 2):
-            raise NotImplementedError("(Bounded, Flat, Bounded): WENO(order = 5 | 7 | 9) models without a closure and without bounds-preserving "
-                                      "advection on an even number of columns are implemented")
+        if bounded_x and (isinstance(advection, dict) or getattr(_base, "bounds", None) is not None or grid.Nx % 2):
+            raise NotImplementedError("(Bounded, Flat, Bounded): WENO(order = 5 | 7 | 9) models without bounds-preserving advection on an even "
+                                      "number of columns are implemented")
         if bounded_y and (isinstance(advection, dict) or not isinstance(_base, WENO) or _base.order not in (5, 7, 9) or
-                          getattr(_base, "bounds", None) is not None or closure is not None):
-            # Coriolis, forcings and bottom flux boundary conditions reach their y neighbours through the halo rows (as on y-slabs);
-            # microphysics, tracers and the StaticEnergy formulation are column- or cell-local
-            raise NotImplementedError("(Periodic, Bounded, Bounded): WENO(order = 5 | 7 | 9) models without a closure and without "
-                                      "bounds-preserving advection are implemented")
+                          getattr(_base, "bounds", None) is not None):
+            # Coriolis, forcings, bottom flux boundary conditions and the closure reach their y neighbours through the halo rows (as on
+            # y-slabs); microphysics, tracers and the StaticEnergy formulation are column- or cell-local
+            raise NotImplementedError("(Periodic, Bounded, Bounded): WENO(order = 5 | 7 | 9) models without bounds-preserving advection "
+                                      "are implemented")
         if formulation not in ("LiquidIcePotentialTemperature", "StaticEnergy"):
             raise NotImplementedError(f"formulation {formulation!r} is not implemented")
         self.formulation = formulation

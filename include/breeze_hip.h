@@ -99,7 +99,7 @@ typedef struct bz_ctx bz_ctx;
  * (Periodic, Flat, Bounded) with Ny = 1, Hy = 0 (the reference's 2-D x-z cases, anelastic and compressible), (Bounded, Flat, Bounded) — the same
  * with walls in x (examples/cloudy_thermal_bubble.jl:20-24; anelastic, even Nx <= 4096, u / rho u with wall faces i = 0 and Nx, cosine transform
  * along x) — or (Periodic, Bounded, Bounded) —
- * walls in y, the reference benchmark driver's PBB option (benchmarking/run_benchmarks.jl:130): anelastic WENO(order = 5 | 7 | 9) contexts (no closure, no bounds-preserving
+ * walls in y, the reference benchmark driver's PBB option (benchmarking/run_benchmarks.jl:130): anelastic WENO(order = 5 | 7 | 9) contexts (no bounds-preserving
  * advection) stepped operator by operator, rho v / v with impenetrable wall faces j = 0 and Ny (face Ny in the first upper halo row), cosine transform along
  * y in the pressure solve (Nx a power of two in [16, 1024] or 3 * 2^m, Ny a multiple of 8 up to 4096); halos >= 3, Float64; every extent at least its
  * halo (Oceananigans' own N >= H rule — the reference's 4 x 4 x 4 smoke-test boxes work, odd extents too); anything else returns

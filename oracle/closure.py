@@ -27,21 +27,40 @@ class SmagorinskyLilly:
         self.C, self.Cb, self.Pr = float(C), float(Cb), float(Pr)
 
 
-def _pad_center(g, f):
-    """(Nz+2, Ny+2, Nx+2): periodic in x, y; zero gradient in z."""
+def _pad_y(g, a, yface=False):
+    """one row on each side in y: the periodic images, or — walls in y (topology (Periodic, Bounded, Bounded)) — the no-flux copy of the
+    wall row for a field that is a centre in y, zeros for a y-face field (the row above is the wall face Ny; the row below is never read)"""
+    if g.topo[1] == 1:      # oracle.BOUNDED
+        if yface:
+            z = np.zeros_like(a[:, :1, :])
+            return np.concatenate([z, a, z], axis=1)
+        return np.concatenate([a[:, :1, :], a, a[:, -1:, :]], axis=1)
+    return np.concatenate([a[:, -1:, :], a, a[:, :1, :]], axis=1)
+
+
+def _pad_x(g, a, xface=False):
+    """the same in x (topology (Bounded, Flat, Bounded))"""
+    if g.topo[0] == 1:
+        if xface:
+            z = np.zeros_like(a[:, :, :1])
+            return np.concatenate([z, a, z], axis=2)
+        return np.concatenate([a[:, :, :1], a, a[:, :, -1:]], axis=2)
+    return np.concatenate([a[:, :, -1:], a, a[:, :, :1]], axis=2)
+
+
+def _pad_center(g, f, yface=False, xface=False):
+    """(Nz+2, Ny+2, Nx+2): periodic or walled in x and y; zero gradient in z."""
     a = f[g.Hz:g.Hz + g.Nz, g.Hy:g.Hy + g.Ny, g.Hx:g.Hx + g.Nx]
-    a = np.concatenate([a[:, -1:, :], a, a[:, :1, :]], axis=1)
-    a = np.concatenate([a[:, :, -1:], a, a[:, :, :1]], axis=2)
+    a = _pad_x(g, _pad_y(g, a, yface), xface)
     return np.concatenate([a[:1], a, a[-1:]], axis=0)
 
 
 def _pad_w(g, f):
-    """(Nz+1, Ny+2, Nx+2) faces 0..Nz, periodic in x, y; the wall faces hold 0."""
+    """(Nz+1, Ny+2, Nx+2) faces 0..Nz, periodic in x, periodic or walled in y; the wall faces hold 0."""
     a = f[g.Hz:g.Hz + g.Nz + 1, g.Hy:g.Hy + g.Ny, g.Hx:g.Hx + g.Nx].copy()
     a[0] = 0.0
     a[-1] = 0.0
-    a = np.concatenate([a[:, -1:, :], a, a[:, :1, :]], axis=1)
-    return np.concatenate([a[:, :, -1:], a, a[:, :, :1]], axis=2)
+    return _pad_x(g, _pad_y(g, a))
 
 
 def _columns(m):
@@ -60,7 +79,7 @@ def strain(m):
     Padded index convention: centre arrays [k+1, j+1, i+1]; x-face i and y-face j share the index of the cell to their right."""
     g = m.grid
     dzc, dzf, *_ = _columns(m)
-    u, v, w = _pad_center(g, m.u), _pad_center(g, m.v), _pad_w(g, m.w)
+    u, v, w = _pad_center(g, m.u, xface=True), _pad_center(g, m.v, yface=True), _pad_w(g, m.w)
     dx, dy = g.dx, g.dy
     Nz, Ny, Nx = g.Nz, g.Ny, g.Nx
     C = lambda a, dk=0, dj=0, di=0: a[1 + dk:1 + dk + Nz, 1 + dj:1 + dj + Ny, 1 + di:1 + di + Nx]
@@ -128,8 +147,7 @@ def add_closure_tendencies(m):
     S11, S22, S33, S12, S13, S23 = strain(m)
     nu = m.nu_e
     # nu padded periodically in x, y and by zero gradient in z: np[k+1, j+1, i+1]
-    nup = np.concatenate([nu[:, -1:, :], nu, nu[:, :1, :]], axis=1)
-    nup = np.concatenate([nup[:, :, -1:], nup, nup[:, :, :1]], axis=2)
+    nup = _pad_x(g, _pad_y(g, nu))
     nup = np.concatenate([nup[:1], nup, nup[-1:]], axis=0)
     r3 = rho[:, None, None]
     rf3 = rho_f[:, None, None]
@@ -154,10 +172,16 @@ def add_closure_tendencies(m):
     T11m = np.roll(T11, 1, axis=2)
     div_u = (Ax * T11 - Ax * T11m) + (Ay * T12[:, 1:, :-1] - Ay * T12[:, :-1, :-1]) + (Az * T13[1:, :, :-1] - Az * T13[:-1, :, :-1])
     I = g.interior
-    I(m.G["ru"])[...] -= div_u / Vc
+    if g.topo[0] == 1:      # walls in x: the wall face i = 0 is never updated
+        I(m.G["ru"])[:, :, 1:] -= (div_u / Vc)[:, :, 1:]
+    else:
+        I(m.G["ru"])[...] -= div_u / Vc
     T22m = np.roll(T22, 1, axis=1)
     div_v = (Ax * T12[:, :-1, 1:] - Ax * T12[:, :-1, :-1]) + (Ay * T22 - Ay * T22m) + (Az * T23[1:, :-1, :] - Az * T23[:-1, :-1, :])
-    I(m.G["rv"])[...] -= div_v / Vc
+    if g.topo[1] == 1:      # walls in y: the wall face j = 0 is never updated (its rolled T22 is meaningless)
+        I(m.G["rv"])[:, 1:, :] -= (div_v / Vc)[:, 1:, :]
+    else:
+        I(m.G["rv"])[...] -= div_v / Vc
     # z momentum at interior faces k = 1..Nz-1
     dzf3 = dzf[1:Nz, None, None]
     Axf, Ayf = dy * dzf3, dx * dzf3

@@ -181,3 +181,39 @@ def test_cell_local_options_between_x_walls(oracle, bz, option):
         scale = mom if n in ("ru", "rw") else max(np.abs(want).max(), 1e-6)
         assert np.abs(got - want).max() < tol * scale, (n, np.abs(got - want).max() / scale)
     assert float(hm.momentum["ρu"].interior[:, :, 0].abs().max()) == 0.0
+
+
+def test_closure_between_x_walls_keeps_them_closed(oracle):
+    from oracle.closure import SmagorinskyLilly
+    g = oracle.Grid((32, 16), topology=TOPO, halo=(3, 3), **EXT)
+    m = oracle.OracleModel(g, potential_temperature=300.0, closure=SmagorinskyLilly())
+    m.set(theta=lambda x, y, z: theta_bubble(x, z))
+    s0 = g.interior(m.rtheta).sum()
+    for _ in range(3):
+        m.time_step(2.0)
+    assert m.nu_e.max() > 0
+    assert np.all(g.interior(m.ru)[:, :, 0] == 0.0)
+    assert abs(g.interior(m.rtheta).sum() - s0) < 1e-13 * s0
+
+
+@pytest.mark.gpu
+def test_closure_between_x_walls_matches_oracle(oracle, bz):
+    """SmagorinskyLilly in the walled 2-D box: nu_e mirrors across the walls, the wall face of rho u is never updated"""
+    from oracle.closure import SmagorinskyLilly
+    g, om, hm = _pair(oracle, bz, (64, 32), 5, (3, 3), okw=dict(closure=SmagorinskyLilly()), hkw=dict(closure=bz.SmagorinskyLilly()))
+    om.set(theta=lambda x, y, z: theta_bubble(x, z), u=lambda x, y, z: 2.0 * np.sin(np.pi * (x - EXT["x"][0]) / (EXT["x"][1] - EXT["x"][0])) * z / 1e4)
+    hm.set(θ=lambda x, z: theta_bubble(x, z), u=lambda x, z: 2.0 * np.sin(np.pi * (x - EXT["x"][0]) / (EXT["x"][1] - EXT["x"][0])) * z / 1e4)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    nu = hm.closure_fields["νₑ"].interior_cpu()
+    assert om.nu_e.max() > 0.01
+    # after three steps: sqrt(1 - Cb N^2 / Sigma^2) next to its stability cutoff amplifies the 1e-12 differences of the state
+    assert np.abs(nu - om.nu_e).max() < 1e-5 * om.nu_e.max()
+    mom = max(np.abs(g.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rw"))
+    for n, f in (("ru", hm.momentum["ρu"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density), ("T", hm.temperature)):
+        want, got = g.interior(getattr(om, n), n == "rw"), f.interior_cpu()
+        scale = mom if n in ("ru", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() < 2e-9 * scale, n
+    assert float(hm.momentum["ρu"].interior[:, :, 0].abs().max()) == 0.0

@@ -75,11 +75,11 @@ def test_order_drops_next_to_the_walls_as_in_z(oracle):
 
 
 def test_options_outside_the_walled_scope_raise(bz):
-    """the closure, bounds-preserving advection and Centered(2) are not built for a Bounded y: the host says so before touching the
-    device (the library's bz_set_closure / bz_set_bounds_preserving_advection return BZ_ERR_UNSUPPORTED there)"""
+    """bounds-preserving advection and Centered(2) are not built for a Bounded y: the host says so before touching the device (the
+    library's bz_set_bounds_preserving_advection returns BZ_ERR_UNSUPPORTED there)"""
     grid = bz.RectilinearGrid((16, 16, 8), topology=(bz.Periodic, bz.Bounded, bz.Bounded), **EXT)
     dyn = lambda: bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0))
-    for kw in (dict(closure=bz.SmagorinskyLilly()), dict(advection=bz.Centered(order=2)),
+    for kw in (dict(advection=bz.Centered(order=2)),
                dict(advection={"momentum": bz.WENO(order=5), "ρqᵉ": bz.WENO(order=5, bounds=(0, 1))})):
         kw.setdefault("advection", bz.WENO(order=5))
         with pytest.raises(NotImplementedError):
@@ -301,3 +301,48 @@ def test_tracers_inside_y_walls(oracle, bz):
     s0 = g.interior(om.rc0).sum()
     _compare(g, om, hm, 3, 2.0, 1e-9, extra=[("rc0", hm.tracers["a"])])
     assert abs(g.interior(om.rc0).sum() - s0) < 1e-12 * abs(s0)          # no tracer leaves through a wall
+
+
+def test_closure_inside_y_walls_keeps_the_walls_closed_and_conserves_scalars(oracle):
+    """SmagorinskyLilly with a Bounded y: nu_e and the centre fields mirror across the walls (no diffusive flux through them), v is zero
+    on them, and the wall face of rho v is never updated"""
+    from oracle.closure import SmagorinskyLilly, add_closure_tendencies
+    g = oracle.Grid((16, 12, 10), topology=TOPO, **EXT)
+    om = oracle.OracleModel(g, potential_temperature=300.0, closure=SmagorinskyLilly())
+    om.set(theta=theta0, u=u0, v=v0)
+    om.update_state()
+    assert om.nu_e.max() > 0
+    for n in ("ru", "rv", "rw", "rtheta", "rq"):
+        om.G[n][...] = 0.0
+    add_closure_tendencies(om)
+    assert np.abs(g.interior(om.G["rv"])[:, 0, :]).max() == 0.0
+    assert np.abs(g.interior(om.G["rv"])[:, 1:, :]).max() > 0
+    tot = g.interior(om.G["rtheta"]).sum()
+    assert abs(tot) < 1e-12 * np.abs(g.interior(om.G["rtheta"])).sum()
+    s0 = g.interior(om.rtheta).sum()
+    for _ in range(3):
+        om.time_step(2.0)
+    assert np.abs(g.interior(om.rv)[:, 0, :]).max() == 0.0
+    assert abs(g.interior(om.rtheta).sum() - s0) < 1e-12 * abs(s0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("moist", [False, True])
+def test_closure_inside_y_walls(oracle, bz, moist):
+    from oracle.closure import SmagorinskyLilly
+    okw = dict(closure=SmagorinskyLilly())
+    hkw = dict(closure=bz.SmagorinskyLilly())
+    if moist:
+        okw["microphysics"] = "SaturationAdjustment"
+        hkw["microphysics"] = bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium())
+    g, om, hm = _walled(oracle, bz, (32, 16, 12), EXT, okw=okw, hkw=hkw)
+    qt = lambda x, y, z: 0.012 * np.exp(-z / 2500.0) * (1 + 0.1 * np.cos(np.pi * y / 1200.0)) + 0 * x
+    om.set(theta=theta0, u=u0, v=v0, **(dict(qt=qt) if moist else {}))
+    hm.set(θ=theta0, u=u0, v=v0, **(dict(qᵗ=qt) if moist else {}))
+    om.update_state()
+    bz.update_state_(hm, compute_tendencies=True)
+    hm.synchronize()
+    nu = hm.closure_fields["νₑ"].interior_cpu()
+    assert om.nu_e.max() > 0
+    assert np.abs(nu - om.nu_e).max() < 1e-11 * om.nu_e.max()
+    _compare(g, om, hm, 3, 2.0, 2e-9)

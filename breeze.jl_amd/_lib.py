@@ -174,6 +174,7 @@ SYMBOLS = {
     "bz_compute_auxiliary_thermodynamic_variables": (C.c_int, [_ctx, _sp]),
     "bz_compute_tendencies": (C.c_int, [_ctx, _sp, _pp]),
     "bz_compute_scalar_tendency": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bz_set_scalar_advection_order": (C.c_int, [_ctx, C.c_int]),
     "bz_update_state": (C.c_int, [_ctx, _sp, _pp, C.c_int]),
     "bz_store_initial_state": (C.c_int, [_ctx, _sp, _pp]),
     "bz_ssp_rk3_substep": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double, C.c_double]),

@@ -327,6 +327,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     ctx->fused_ok = (Nx >= 2 * grid->Hx) && (Ny >= 2 * grid->Hy || slab_mode) && !ctx->tune.no_fused;
 #ifndef BZ_CENTERED2
     ctx->weno_R = weno_R;
+    ctx->scalar_R = weno_R;
     // the lean and fused-RK tiers of the anelastic model are order-5 kernels (bz_step.hip tests weno_R); orders 7, 9 take the
     // fused-streaming tier: generic tendency kernels + RK update, projection / diagnosis / halo fills in fused passes (the compressible
     // sequence takes its slow tendencies from the generic kernels and is otherwise independent of the advection order)

@@ -341,6 +341,8 @@ struct bz_ctx {
     bool has_reference = false;       // ExnerReferenceState columns present (else p_r = rho_r = 0)
     bz_split_explicit se;
     int weno_R = 3;                   // stencil half-width of the advection scheme: WENO(order = 2 R - 1)
+    int scalar_R = 3;                 // ... of the scalars' scheme when momentum_advection and scalar_advection differ (bz_set_scalar_advection_order;
+                                      // examples/tropical_cyclone_world.jl:167-169: momentum WENO(order = 9), scalars WENO(order = 5)); else = weno_R
     double *d_gflux = nullptr;        // flux scratch of the generic (order 7 / 9) kernels' two-pass evaluation: 3 parent-shaped arrays
     double dz_min = 0.0;              // minimum_zspacing(grid)
     double *d_sponge = nullptr;       // UpperSponge rate * ramp per face (compressible contexts)
@@ -473,6 +475,7 @@ int bzi_fill_halos_multi(bz_ctx *ctx, double *const *fields, const int *kinds, i
 int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
 int bzi_bounded_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_compute_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_momentum_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_lean_setup(bz_ctx *ctx);
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt);
 int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,

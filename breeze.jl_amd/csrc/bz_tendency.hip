@@ -348,12 +348,92 @@ int bzi_momentum_advection_gen1(bz_ctx *ctx, const bz_state *s, const bz_prognos
     return BZ_OK;
 }
 
+// momentum_advection and scalar_advection of different orders (atmosphere_model.jl:80-82,148-158; examples/tropical_cyclone_world.jl:167-169,
+// examples/prescribed_sea_surface_temperature.jl:72-73: momentum WENO(order = 9), scalars WENO(order = 5)): the momentum kernels of the
+// momentum order, one scalar kernel per scalar of the scalars' order, then the order-independent terms — operator by operator, as the
+// reference launches them (update_atmosphere_model_state.jl:294-387)
+static int compute_tendencies_mixed(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    const DevGrid &g = ctx->dg;
+    int rc;
+    if (ctx->bounded_mask && ctx->scalar_R != 3) {
+        ctx->last_error = "bounds-preserving advection is a WENO(order = 5) scalar scheme";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    const dim3 block(64, TYB);
+    const int kc = pick_kchunk(g, g.Nz), kcw = pick_kchunk(g, g.Nz - 1);
+    const dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
+    if (ctx->weno_R != 3) {
+        if ((rc = bzi_momentum_tendencies_generic(ctx, s, G))) return rc;
+    } else {
+        {
+            ProfileScope ps(ctx, "x_momentum_tendency");
+            hipLaunchKernelGGL(k_u_tendency, grid, block, 0, ctx->stream, g, G->rho_u, s->rho_u, s->rho_v, s->rho_w, s->u, kc, RKEpilogue());
+        }
+        {
+            ProfileScope ps(ctx, "y_momentum_tendency");
+            hipLaunchKernelGGL(k_v_tendency, grid, block, 0, ctx->stream, g, G->rho_v, s->rho_u, s->rho_v, s->rho_w, s->v, kc, RKEpilogue());
+        }
+        if (g.Nz > 1) {
+            ProfileScope ps(ctx, "z_momentum_tendency");
+            const dim3 gridw(grid.x, grid.y, (g.Nz - 1 + kcw - 1) / kcw);
+            hipLaunchKernelGGL(k_w_tendency<true>, gridw, block, 0, ctx->stream, g, G->rho_w, s->rho_u, s->rho_v, s->rho_w, s->w, s->T, s->q, kcw);
+        }
+    }
+    auto scalar = [&](const char *name, double *Gc, const double *c) -> int {
+        ProfileScope ps(ctx, name);
+        if (ctx->scalar_R != 3) return bzi_scalar_tendency_generic(ctx, Gc, s->u, s->v, s->w, c);
+        hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, Gc, s->u, s->v, s->w, c, kc);
+        return BZ_OK;
+    };
+    if ((rc = scalar("potential_temperature_tendency", G->rho_theta, s->theta))) return rc;
+    if ((rc = scalar("moisture_tendency", G->rho_q, s->q))) return rc;
+    if (g.microphysics == 2) {
+        if ((rc = scalar("kessler_species_tendencies", ctx->kessler.G_cloud_liquid_density, ctx->kessler.cloud_liquid_mass_fraction))) return rc;
+        if ((rc = scalar("kessler_species_tendencies", ctx->kessler.G_rain_density, ctx->kessler.rain_mass_fraction))) return rc;
+    }
+    for (int t = 0; t < ctx->n_tracers; ++t)
+        if ((rc = scalar("tracer_tendencies", ctx->tracers[t].G, ctx->tracers[t].specific))) return rc;
+    if (g.formulation == 1) {
+        ProfileScope ps(ctx, "static_energy_buoyancy_flux");
+        hipLaunchKernelGGL(k_energy_buoyancy_flux, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, G->rho_theta, s->w, s->T, s->q);
+    }
+    if (ctx->bounded_mask && (rc = bzi_bounded_tendencies(ctx, s, G))) return rc;
+    if (ctx->has_closure && (rc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, 1.0))) return rc;
+    if (ctx->has_forcings && (rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0))) return rc;
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// the scalars' scheme where it differs from the momentum scheme the context was created with (include/breeze_hip.h)
+extern "C" int bz_set_scalar_advection_order(bz_ctx *ctx, int order)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    ++ctx->config_epoch;
+#ifdef BZ_CENTERED2
+    ctx->last_error = "bz_set_scalar_advection_order: this build is Centered(order = 2)";
+    return BZ_ERR_UNSUPPORTED;
+#else
+    const DevGrid &g = ctx->dg;
+    if (order != 5 && order != 7 && order != 9) { ctx->last_error = "bz_set_scalar_advection_order: WENO order 5, 7 or 9"; return BZ_ERR_UNSUPPORTED; }
+    const int R = (order + 1) / 2;
+    if (g.Hx < R || (!g.flat_y && g.Hy < R) || g.Hz < R) { ctx->last_error = "bz_set_scalar_advection_order: halos narrower than the scheme"; return BZ_ERR_UNSUPPORTED; }
+    if (R != ctx->weno_R && (ctx->compressible || ctx->slab_mode)) {
+        ctx->last_error = "bz_set_scalar_advection_order: a scalar order that differs from the momentum order is implemented for single-GPU anelastic contexts";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    ctx->scalar_R = R;
+    return BZ_OK;
+#endif
+}
+
 extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
     if (!ctx || !s || !G) return BZ_ERR_INVALID;
     ctx->G_is_predictor = false;
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
+    if (ctx->scalar_R != ctx->weno_R) return compute_tendencies_mixed(ctx, s, G);
     if (ctx->weno_R != 3) {      // WENO(order = 7 / 9): generic kernels for the five prognostic fields, then the order-independent terms
         if (ctx->bounded_mask) {
             ctx->last_error = "WENO(order = 7 / 9) does not implement bounds-preserving advection";
@@ -506,7 +586,7 @@ extern "C" int bz_compute_scalar_tendency(bz_ctx *ctx, const double *u, const do
     if (!ctx || !u || !v || !w || !c || !Gc) return BZ_ERR_INVALID;
     if (ctx->compressible) { ctx->last_error = "bz_compute_scalar_tendency: anelastic contexts (the compressible model: bz_compute_moisture_tendency)"; return BZ_ERR_UNSUPPORTED; }
     ProfileScope ps(ctx, "scalar_tendency");
-    if (ctx->weno_R != 3) return bzi_scalar_tendency_generic(ctx, Gc, u, v, w, c);
+    if (ctx->scalar_R != 3) return bzi_scalar_tendency_generic(ctx, Gc, u, v, w, c);
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);
     const int kc = pick_kchunk(g, g.Nz);

@@ -510,8 +510,16 @@ static int launch_scalar(bz_ctx *ctx, double *Gc, const double *u, const double 
 
 int bzi_scalar_tendency_generic(bz_ctx *ctx, double *Gc, const double *u, const double *v, const double *w, const double *c)
 {
-    if (ctx->weno_R == 5) return launch_scalar<5>(ctx, Gc, u, v, w, c);
-    if (ctx->weno_R == 4) return launch_scalar<4>(ctx, Gc, u, v, w, c);
+    if (ctx->scalar_R == 5) return launch_scalar<5>(ctx, Gc, u, v, w, c);
+    if (ctx->scalar_R == 4) return launch_scalar<4>(ctx, Gc, u, v, w, c);
+    return BZ_ERR_INVALID;
+}
+
+// momentum tendencies (advection + buoyancy) alone: the momentum half of a model whose scalars take another order (bz_tendency.hip)
+int bzi_momentum_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    if (ctx->weno_R == 5) return launch_generic<5>(ctx, s, G, true, false);
+    if (ctx->weno_R == 4) return launch_generic<4>(ctx, s, G, true, false);
     return BZ_ERR_INVALID;
 }
 

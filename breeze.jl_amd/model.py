@@ -55,23 +55,52 @@ _MOISTURE_KEYS = ("ρq", "ρqᵛ", "ρqᵉ", "ρqᵗ")
 _SPECIES_KEYS = ("ρqᶜˡ", "ρqʳ")
 
 
+def _merge_advection(advection, momentum_advection, scalar_advection):
+    """atmosphere_model.jl:146-152: a single `advection` serves momentum and scalars; otherwise `momentum_advection` and `scalar_advection`
+    (one scheme, or a NamedTuple keyed by scalar name) each default to Centered(order = 2).  Returns `advection` in the form
+    `_split_advection` takes: one scheme, or a dict keyed by `momentum` and the scalar names (`scalars` = every scalar not named)."""
+    if advection is not None:
+        if momentum_advection is not None or scalar_advection is not None:
+            raise ValueError("pass either `advection` or `momentum_advection` / `scalar_advection`")
+        return advection
+    if momentum_advection is None and scalar_advection is None:
+        return None
+    momentum_advection = momentum_advection or Centered(order=2)
+    scalar_advection = scalar_advection or Centered(order=2)
+    merged = {"momentum": momentum_advection}
+    if isinstance(scalar_advection, dict):
+        merged.update({str(k).lstrip(":"): v for k, v in scalar_advection.items()})
+        merged.setdefault("scalars", Centered(order=2))      # validate_tracer_advection: scalars a NamedTuple does not name take the default
+    else:
+        merged["scalars"] = scalar_advection
+    return merged
+
+
 def _split_advection(advection, tracer_names):
     """The reference accepts one scheme or a NamedTuple of schemes keyed by `momentum` and the scalar names
-    (atmosphere_model.jl advection keyword; examples/rico.jl:186-190).  Returns (base scheme, bounds-preserving request or None)."""
+    (atmosphere_model.jl advection keyword; examples/rico.jl:186-190).  Returns (momentum scheme, bounds-preserving request or None,
+    order of the scalars' schemes, whether scalars the NamedTuple does not name would take a scheme of another order)."""
     if not isinstance(advection, dict):
         if getattr(advection, "bounds", None) is not None:
             raise NotImplementedError("bounds-preserving WENO is a scalar scheme: pass advection = {'momentum': WENO(), ..., 'ρqᵉ': WENO(bounds=(0, 1))}")
-        return advection, None
+        return advection, None, advection.order, False
+    advection = {str(k).lstrip(":"): v for k, v in advection.items()}
     base = advection.get("momentum") or next(iter(advection.values()))
+    named = {k: v for k, v in advection.items() if k not in ("momentum", "scalars")}
+    rest = advection.get("scalars")          # scheme of the scalars not named (_merge_advection); absent: the momentum scheme's order
+    orders = {getattr(v, "order", None) for v in named.values()}
+    if len(orders) > 1:
+        raise NotImplementedError("every scalar must be advected with a scheme of one order")
+    scalar_order = orders.pop() if orders else (rest.order if rest is not None else base.order)
+    unnamed_differ = bool(named) and rest is not None and rest.order != scalar_order
+    if (base.order == 2) != (scalar_order == 2):
+        raise NotImplementedError("Centered(order = 2) for momentum with WENO scalars (or the reverse) is not implemented")
     bounded, lo_hi = {"moisture": 0, "microphysical_species": 0, "tracers": 0}, None
-    for key, scheme in advection.items():
-        key = str(key).lstrip(":")
-        if getattr(scheme, "order", None) != base.order:
-            raise NotImplementedError("every component of `advection` must have the order of the momentum scheme")
+    for key, scheme in named.items():
         b = getattr(scheme, "bounds", None)
         if b is None:
             continue
-        if key in ("momentum", "ρθ", "ρe"):
+        if key in ("ρθ", "ρe"):
             raise NotImplementedError(f"bounds-preserving advection of {key} is not implemented (moisture, microphysical species, tracers)")
         if lo_hi is not None and b != lo_hi:
             raise NotImplementedError("one pair of bounds for all bounds-preserving scalars")
@@ -84,9 +113,11 @@ def _split_advection(advection, tracer_names):
             bounded["tracers"] = 1
         else:
             raise ValueError(f"advection key {key!r} names no prognostic scalar of this model")
+    if getattr(base, "bounds", None) is not None or getattr(rest, "bounds", None) is not None:
+        raise NotImplementedError("bounds-preserving WENO is given per scalar: scalar_advection = {'ρθ': WENO(), 'ρqᵉ': WENO(bounds=(0, 1))}")
     if lo_hi is None:
-        return base, None
-    return base, dict(bounded, lower=lo_hi[0], upper=lo_hi[1])
+        return base, None, scalar_order, unnamed_differ
+    return base, dict(bounded, lower=lo_hi[0], upper=lo_hi[1]), scalar_order, unnamed_differ
 
 
 class AnelasticDynamics:
@@ -165,10 +196,11 @@ class AtmosphereModel:
     def __init__(self, grid, dynamics=None, advection=None, thermodynamic_constants=None,
                  formulation="LiquidIcePotentialTemperature", timestepper="SSPRungeKutta3",
                  closure=None, coriolis=None, microphysics=None, forcing=None, boundary_conditions=None,
-                 tracers=(), device="cuda:0"):
+                 tracers=(), device="cuda:0", momentum_advection=None, scalar_advection=None):
         import torch
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
+        advection = _merge_advection(advection, momentum_advection, scalar_advection)
         bounded_x = grid.topology == (Bounded, Flat, Bounded)          # walls in x of a 2-D model: examples/cloudy_thermal_bubble.jl
         flat_y = grid.topology == (Periodic, Flat, Bounded) or bounded_x
         bounded_y = grid.topology == (Periodic, Bounded, Bounded)      # walls in y: the reference benchmark driver's PBB option
@@ -217,19 +249,32 @@ class AtmosphereModel:
                 raise ValueError("DCMIP2016KesslerMicrophysics requires `thermodynamic_constants` with a `TetensFormula` "
                                  "saturation vapor pressure formulation. Construct the model with, e.g., "
                                  "`thermodynamic_constants = ThermodynamicConstants(saturation_vapor_pressure = TetensFormula())`.")
-        advection, self._bounded_advection = _split_advection(advection, tuple(str(n).lstrip(":") for n in
-                                                                                 ((tracers,) if isinstance(tracers, str) else tracers)))
+        _named = set(str(k).lstrip(":") for k in advection) if isinstance(advection, dict) else set()
+        _tracer_names = tuple(str(n).lstrip(":") for n in ((tracers,) if isinstance(tracers, str) else tracers))
+        advection, self._bounded_advection, self._scalar_order, _unnamed_differ = _split_advection(advection, _tracer_names)
+        if _unnamed_differ:
+            # scalar_advection was a NamedTuple: every scalar of the model it does not name takes Centered(order = 2) in the reference
+            missing = {"ρe" if formulation == "StaticEnergy" else "ρθ"} - _named
+            if not _named & set(_MOISTURE_KEYS):
+                missing.add("moisture")
+            if self._kessler:
+                missing |= set(_SPECIES_KEYS) - _named
+            missing |= {t for t in _tracer_names if t not in _named and "ρ" + t not in _named}
+            if missing:
+                raise NotImplementedError("scalar_advection names only some scalars: the others would take Centered(order = 2), and one order "
+                                          f"for all scalars is implemented (unnamed: {sorted(missing)})")
         if not torch.cuda.is_available():
             raise RuntimeError("AtmosphereModel needs a GPU: the HIP path has no CPU fallback")
         self.grid = grid
         self.advection = advection
-        if isinstance(advection, WENO) and advection.order != 5:
-            need = (advection.order + 1) // 2
+        if isinstance(advection, WENO) and max(advection.order, self._scalar_order) != 5:
+            order = max(advection.order, self._scalar_order)
+            need = (order + 1) // 2
             if min(h for h, t in zip((grid.Hx, grid.Hy, grid.Hz), grid.topology) if t != Flat) < need:
-                raise ValueError(f"WENO(order={advection.order}) needs halos of at least {need} cells in every direction "
+                raise ValueError(f"WENO(order={order}) needs halos of at least {need} cells in every direction "
                                  f"(got {(grid.Hx, grid.Hy, grid.Hz)}): RectilinearGrid(..., halo=({need}, {need}, {need}))")
-            if self._bounded_advection is not None:
-                raise NotImplementedError(f"WENO(order={advection.order}): bounds-preserving advection is implemented for order 5")
+        if self._bounded_advection is not None and self._scalar_order != 5:
+            raise NotImplementedError(f"WENO(order={self._scalar_order}): bounds-preserving advection is implemented for order 5")
         self.thermodynamic_constants = c = thermodynamic_constants or ThermodynamicConstants()
         if dynamics is None:
             dynamics = AnelasticDynamics(ReferenceState(grid, c))      # default_dynamics
@@ -298,6 +343,8 @@ class AtmosphereModel:
                     "bz_set_stream")
         if formulation == "StaticEnergy":
             self._check(lib.bz_set_formulation(self._ctx, 1), "bz_set_formulation")
+        if self._scalar_order != advection.order:      # momentum_advection and scalar_advection of different orders
+            self._check(lib.bz_set_scalar_advection_order(self._ctx, self._scalar_order), "bz_set_scalar_advection_order")
         # materialize_microphysical_fields(::WarmPhaseSaturationAdjustment): (q^v, q^l, q^e); q^e is the specific moisture slot
         if self._kessler:
             from .microphysics import kessler_parameter_struct

@@ -154,6 +154,13 @@ int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G
  * own micro-benchmark times (benchmarking/src/scalar_tendency.jl:16-25: Gc = -div_Uc; here with the reference density of the
  * anelastic model, rho_r = const on that benchmark's 1 m deep box).  WENO order of the context (5, 7 or 9). */
 int bz_compute_scalar_tendency(bz_ctx *ctx, const double *u, const double *v, const double *w, const double *c, double *Gc);
+/* AtmosphereModel(grid; momentum_advection, scalar_advection) with schemes of different orders (atmosphere_model.jl:80-82,126-127,148-158;
+ * examples/tropical_cyclone_world.jl:167-169 and examples/prescribed_sea_surface_temperature.jl:72-73: momentum WENO(order = 9), every
+ * scalar WENO(order = 5)): bz_create's weno_order is the momentum scheme, this sets the order (5, 7 or 9) of every scalar — rho theta /
+ * rho e, moisture, microphysical species, tracers.  Halos must cover both schemes.  Orders that differ run operator by operator (one
+ * kernel per field, the reference's own launch list) on single-GPU anelastic contexts; bounds-preserving advection stays a WENO(order = 5)
+ * scalar scheme.  Call before the first step. */
+int bz_set_scalar_advection_order(bz_ctx *ctx, int order);
 /* TimeSteppers.update_state!(model; compute_tendencies) (:41-68); G may be NULL iff compute_tendencies == 0. */
 int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, int compute_tendencies);
 

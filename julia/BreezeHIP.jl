@@ -72,6 +72,8 @@ function create_context(model::AtmosphereModel)
                    (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzReferenceState}, Cint), ctx, g, k, r, weno_order(model.advection))
         rc == 0 || error("bz_create failed with code $rc (WENO orders 5, 7, 9 with halos >= (order + 1) / 2)")
     end
+    so = scalar_weno_order(model.advection)      # model.advection = (; momentum, ρθ, ρqᵉ, ...) after the constructor merged the schemes
+    so == weno_order(model.advection) || set_scalar_advection_order!(ctx[], so)
     return ctx[]
 end
 
@@ -116,6 +118,12 @@ function AtmosphereModels.make_pressure_correction!(model::HIPModel, Δt)
     ctx = context(model)
     check(ccall((:bz_make_pressure_correction, libbreeze_hip), Cint, (Ptr{Cvoid}, Ref{BzState}, Cdouble),
                 ctx, state(model), Δt), "bz_make_pressure_correction", ctx)
+end
+
+# AtmosphereModel(grid; momentum_advection, scalar_advection) with schemes of different orders (atmosphere_model.jl:80-82,148-158):
+# the context is created with the momentum order; this hands over the scalars' order (5, 7 or 9)
+function set_scalar_advection_order!(ctx, order::Integer)
+    check(ccall((:bz_set_scalar_advection_order, libbreeze_hip), Cint, (Ptr{Cvoid}, Cint), ctx, order), "bz_set_scalar_advection_order", ctx)
 end
 
 # Gc = -div_ρUc(c) of one centre field with the model's velocities: the launch of compute_scalar_tendency!
@@ -325,6 +333,14 @@ const BZ_UNIQUE_ID_BYTES = 128
 
 "WENO(order = N) of the model's momentum scheme -> the weno_order argument of bz_create (5: tuned kernels; 7, 9: generic kernels)."
 weno_order(advection) = 2 * Oceananigans.Advection.required_halo_size_x(advection isa NamedTuple ? advection.momentum : advection) - 1
+
+"The scalars' order of a merged advection NamedTuple (atmosphere_model.jl:279-284); every scalar must share it (bz_set_scalar_advection_order)."
+function scalar_weno_order(advection)
+    advection isa NamedTuple || return weno_order(advection)
+    orders = unique(2 * Oceananigans.Advection.required_halo_size_x(s) - 1 for (k, s) in pairs(advection) if k != :momentum)
+    length(orders) <= 1 || error("BreezeHIP: one advection order for all scalars (got $orders)")
+    return isempty(orders) ? weno_order(advection) : first(orders)
+end
 
 "Create the slab context of this rank and attach the RCCL communicator to it."
 function slab_context!(model, y_nranks::Integer, y_rank::Integer, bcast_bytes!::Function)

@@ -278,7 +278,7 @@ class OracleModel:
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
                  standard_pressure=1e5, reference_density=None, initialize=True,
                  formulation="LiquidIcePotentialTemperature", microphysics=None, sa_abstol=1e-4, sa_maxiter=20,
-                 forcings=None, closure=None, tracers=0, advection="WENO5"):
+                 forcings=None, closure=None, tracers=0, advection="WENO5", scalar_advection=None):
         # formulation "StaticEnergy": self.theta holds e, self.rtheta holds rho*e
         # (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21)
         assert formulation in ("LiquidIcePotentialTemperature", "StaticEnergy")
@@ -301,9 +301,13 @@ class OracleModel:
             self.ref._fill(g)
         # advection: "WENO5" (default), "WENO7", "WENO9" (the order is a process-wide switch of the C library, set before every
         # tendency evaluation; halos must be at least (order + 1) / 2 wide) or "Centered2" (a separate build of the library)
+        # scalar_advection: the scalars' order where it differs from the momentum scheme (AtmosphereModel(grid; momentum_advection,
+        # scalar_advection), atmosphere_model.jl:80-82,148-158; examples/tropical_cyclone_world.jl:167-169)
         self.weno_order = {"WENO5": 5, "WENO7": 7, "WENO9": 9}.get(advection, 5)
+        self.scalar_order = {"WENO5": 5, "WENO7": 7, "WENO9": 9}[scalar_advection] if scalar_advection else self.weno_order
+        assert scalar_advection is None or advection.startswith("WENO")
         if advection.startswith("WENO"):
-            need = (self.weno_order + 1) // 2
+            need = (max(self.weno_order, self.scalar_order) + 1) // 2
             assert min(g.Hx if g.Nx > 1 else need, g.Hy if g.Ny > 1 else need, g.Hz) >= need, f"{advection} needs halos >= {need}"
         self.lib = lib("WENO5" if advection.startswith("WENO") else advection)
         self._mk_cgrid()
@@ -534,13 +538,16 @@ class OracleModel:
         L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
         L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
         if self.microphysics == "Kessler":
+            L.og_set_weno_order(C.c_int(self.scalar_order))
             L.og_scalar_tendency(cg, _p(G["rqcl"]), _p(self.u), _p(self.v), _p(self.w), _p(self.qcl))
             L.og_scalar_tendency(cg, _p(G["rqr"]), _p(self.u), _p(self.v), _p(self.w), _p(self.qr))
+            L.og_set_weno_order(C.c_int(self.weno_order))
         if self.microphysics in ("SaturationAdjustment", "Kessler"):
             L.og_w_tendency_moist(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w), _p(self.T),
                                   _p(self.qv), _p(self.ql))
         else:
             L.og_w_tendency(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w), _p(self.T), _p(self.q))
+        L.og_set_weno_order(C.c_int(self.scalar_order))      # every scalar below takes the scalars' scheme
         L.og_scalar_tendency(cg, _p(G["rtheta"]), _p(self.u), _p(self.v), _p(self.w), _p(self.theta))
         L.og_scalar_tendency(cg, _p(G["rq"]), _p(self.u), _p(self.v), _p(self.w), _p(self.q))
         if self.formulation == "StaticEnergy":

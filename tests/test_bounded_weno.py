@@ -182,7 +182,7 @@ def test_device_bounded_steps_match_oracle_and_suppress_overshoots(oracle, bz):
 def test_host_rejects_unsupported_bounded_requests(bz):
     import torch
     from breeze_jl_amd.model import _split_advection
-    base, req = _split_advection({"momentum": bz.WENO(), "ρqᵉ": bz.WENO(bounds=(0, 1)), "ρqʳ": bz.WENO(bounds=(0, 1))}, ())
+    base, req, *_ = _split_advection({"momentum": bz.WENO(), "ρqᵉ": bz.WENO(bounds=(0, 1)), "ρqʳ": bz.WENO(bounds=(0, 1))}, ())
     assert base.order == 5 and req == {"moisture": 1, "microphysical_species": 1, "tracers": 0, "lower": 0.0, "upper": 1.0}
     assert _split_advection(bz.WENO(), ())[1] is None
     with pytest.raises(NotImplementedError):

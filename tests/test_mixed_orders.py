@@ -1,0 +1,149 @@
+"""AtmosphereModel(grid; momentum_advection, scalar_advection) with schemes of different orders (atmosphere_model.jl:80-82,126-127,148-158):
+examples/tropical_cyclone_world.jl:167-169 (momentum WENO(order = 9); ρθ WENO(order = 5), ρqᵉ WENO(order = 5, bounds = (0, 1))),
+examples/prescribed_sea_surface_temperature.jl:72-73 (2-D, momentum WENO(order = 9), scalars WENO(order = 5)).  bz_create carries the momentum
+order, bz_set_scalar_advection_order the scalars'; such contexts step operator by operator, the reference's own launch list."""
+import numpy as np
+import pytest
+
+from helpers import PROG, push_state, randomize, relerr
+
+EXT = dict(x=(0.0, 1600.0), y=(0.0, 1200.0), z=(0.0, 1000.0))
+
+
+def theta0(x, y, z):
+    return 300.0 + 2.0 * np.exp(-((x - 800.0) ** 2 + (y - 500.0) ** 2 + (z - 400.0) ** 2) / 200.0 ** 2)
+
+
+def test_oracle_mixed_orders_take_each_half_from_its_scheme(oracle):
+    g = oracle.Grid((16, 12, 10), halo=(5, 5, 5), **EXT)
+    models = {k: oracle.OracleModel(g, potential_temperature=300.0, **kw) for k, kw in
+              dict(mixed=dict(advection="WENO9", scalar_advection="WENO5"), nine=dict(advection="WENO9"), five=dict(advection="WENO5")).items()}
+    for m in models.values():
+        randomize(m, seed=3)
+        m.update_state()
+    for n in ("ru", "rv", "rw"):
+        assert np.array_equal(models["mixed"].G[n], models["nine"].G[n]) and not np.array_equal(models["mixed"].G[n], models["five"].G[n])
+    for n in ("rtheta", "rq"):
+        assert np.array_equal(models["mixed"].G[n], models["five"].G[n]) and not np.array_equal(models["mixed"].G[n], models["nine"].G[n])
+
+
+def test_host_merges_the_two_keywords_like_the_reference(bz):
+    from breeze_jl_amd.model import _merge_advection, _split_advection
+    W = bz.WENO
+    assert _merge_advection(None, None, None) is None
+    a = W(order=9)
+    assert _merge_advection(a, None, None) is a
+    with pytest.raises(ValueError):
+        _merge_advection(a, W(), None)
+    m = _merge_advection(None, W(order=9), W(order=5))
+    base, req, so, differ = _split_advection(m, ())
+    assert (base.order, req, so, differ) == (9, None, 5, False)
+    m = _merge_advection(None, W(order=9), {"ρθ": W(order=5), "ρqᵉ": W(order=5, bounds=(0, 1))})
+    base, req, so, differ = _split_advection(m, ())
+    assert base.order == 9 and so == 5 and differ and req["moisture"] == 1 and (req["lower"], req["upper"]) == (0.0, 1.0)
+    with pytest.raises(NotImplementedError):      # two scalar orders
+        _split_advection(_merge_advection(None, W(order=9), {"ρθ": W(order=5), "ρqᵉ": W(order=7)}), ())
+    with pytest.raises(NotImplementedError):      # momentum defaults to Centered(order = 2)
+        _split_advection(_merge_advection(None, None, W(order=5)), ())
+    # one keyword for both = the old spelling
+    base, req, so, differ = _split_advection({"momentum": W(), "ρθ": W(), "ρqᵛ": W(bounds=(0, 1))}, ())
+    assert (base.order, so, differ) == (5, 5, False)
+
+
+def _pair(oracle, bz, size, morder, sorder, okw=None, hkw=None, scalar_advection=None, ext=EXT, flat=False):
+    kw = dict(topology=("Periodic", "Flat", "Bounded")) if flat else {}
+    g = oracle.Grid(size, halo=(5, 5) if flat else (5, 5, 5), **ext, **kw)
+    om = oracle.OracleModel(g, potential_temperature=300.0, advection=f"WENO{morder}", scalar_advection=f"WENO{sorder}", **(okw or {}))
+    hkw_grid = dict(topology=(bz.Periodic, bz.Flat, bz.Bounded)) if flat else {}
+    grid = bz.RectilinearGrid(size, halo=(5, 5) if flat else (5, 5, 5), **ext, **hkw_grid)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)),
+                            momentum_advection=bz.WENO(order=morder),
+                            scalar_advection=scalar_advection if scalar_advection is not None else bz.WENO(order=sorder), **(hkw or {}))
+    return g, om, hm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orders", [(9, 5), (5, 9), (7, 5), (9, 7)])
+def test_mixed_order_tendencies_match_oracle(oracle, bz, orders):
+    g, om, hm = _pair(oracle, bz, (40, 24, 16), *orders)
+    randomize(om, seed=21)
+    om.update_state()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=True)
+    hm.synchronize()
+    for n, k in PROG.items():
+        got, want = hm.G[k].interior_cpu(), g.interior(om.G[n], zface=(n == "rw"))
+        assert relerr(got, want) < 2e-11, (n, relerr(got, want))
+
+
+def _steps(g, om, hm, n, dt, tol, extra=()):
+    for _ in range(n):
+        om.time_step(dt)
+        hm.time_step(dt)
+    hm.synchronize()
+    mom = max(np.abs(g.interior(getattr(om, f), f == "rw")).max() for f in ("ru", "rv", "rw"))
+    pairs = [("ru", hm.momentum["ρu"]), ("rv", hm.momentum["ρv"]), ("rw", hm.momentum["ρw"]),
+             ("rtheta", hm.potential_temperature_density), ("rq", hm.moisture_density), ("T", hm.temperature)] + list(extra)
+    for f, fld in pairs:
+        want, got = g.interior(getattr(om, f), f == "rw"), fld.interior_cpu()
+        scale = mom if f in ("ru", "rv", "rw") else max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() < tol * scale, (f, np.abs(got - want).max() / scale)
+
+
+@pytest.mark.gpu
+def test_tropical_cyclone_world_scheme_list_steps_match_oracle(oracle, bz):
+    """momentum WENO(order = 9), rho theta WENO(order = 5), rho q^e WENO(order = 5, bounds = (0, 1)), saturation adjustment, f-plane
+    (examples/tropical_cyclone_world.jl:106,167-173) at reduced size"""
+    ext = dict(x=(-4e3, 4e3), y=(-3e3, 3e3), z=(0.0, 4e3))
+    sa = {"ρθ": bz.WENO(order=5), "ρqᵉ": bz.WENO(order=5, bounds=(0, 1))}
+    g, om, hm = _pair(oracle, bz, (32, 24, 16), 9, 5, okw=dict(microphysics="SaturationAdjustment"),
+                      hkw=dict(microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium())), scalar_advection=sa, ext=ext)
+    om.bounded = {"rq": (0.0, 1.0)}
+    qt = lambda x, y, z: 0.018 * np.exp(-z / 2500.0) * (1 + 0.1 * np.sin(2 * np.pi * x / 8e3)) + 0 * y
+    th = lambda x, y, z: 294.0 + 0.003 * z + 1.5 * np.maximum(0.0, 1.0 - np.sqrt(x ** 2 + (y + 500.0) ** 2 + (z - 1500.0) ** 2) / 1000.0)
+    om.set(qt=qt, theta=th, u=3.0, v=-1.0)
+    hm.set(qᵗ=qt, θ=th, u=3.0, v=-1.0)
+    _steps(g, om, hm, 3, 2.0, 2e-8, extra=[("ql", hm.microphysical_fields["qˡ"])])
+    assert (g.interior(om.ql) > 0).any()
+
+
+@pytest.mark.gpu
+def test_prescribed_sst_scheme_list_in_two_dimensions(oracle, bz):
+    """examples/prescribed_sea_surface_temperature.jl:39-73: (Periodic, Flat, Bounded), halo (5, 5), momentum WENO(order = 9), scalars
+    WENO(order = 5), warm-phase saturation adjustment"""
+    ext = dict(x=(-4e3, 4e3), z=(0.0, 4e3))
+    g, om, hm = _pair(oracle, bz, (64, 32), 9, 5, okw=dict(microphysics="SaturationAdjustment"),
+                      hkw=dict(microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium())), ext=ext, flat=True)
+    qt = lambda x, z: 0.018 * np.exp(-z / 2500.0) * (1 + 0.1 * np.sin(2 * np.pi * x / 8e3))
+    th = lambda x, z: 294.0 + 0.003 * z + 1.5 * np.maximum(0.0, 1.0 - np.sqrt(x ** 2 + (z - 1500.0) ** 2) / 1000.0)
+    om.set(qt=lambda x, y, z: qt(x, z), theta=lambda x, y, z: th(x, z))
+    hm.set(qᵗ=qt, θ=th)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    hm.synchronize()
+    mom = max(np.abs(g.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rw"))
+    for n, f in (("ru", hm.momentum["ρu"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density),
+                 ("rq", hm.moisture_density), ("T", hm.temperature)):
+        want, got = g.interior(getattr(om, n), n == "rw"), f.interior_cpu()
+        scale = mom if n in ("ru", "rw") else max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() < 2e-8 * scale, n
+    assert (g.interior(om.ql) > 0).any()
+
+
+@pytest.mark.gpu
+def test_mixed_orders_with_tracers_and_static_energy(oracle, bz):
+    g, om, hm = _pair(oracle, bz, (32, 16, 12), 9, 5, okw=dict(tracers=1, formulation="StaticEnergy"),
+                      hkw=dict(tracers=("a",), formulation="StaticEnergy"))
+    a = lambda x, y, z: 1.0 + 0.5 * np.cos(2 * np.pi * y / 1200.0) * np.sin(2 * np.pi * x / 1600.0) + 0 * z
+    om.set(theta=theta0, u=2.0, v=1.0, rc0=a)
+    hm.tracers["a"].set_interior(a)
+    hm.set(θ=theta0, u=2.0, v=1.0)
+    _steps(g, om, hm, 3, 2.0, 5e-8, extra=[("rc0", hm.tracers["a"])])
+
+
+@pytest.mark.gpu
+def test_scalars_left_to_the_default_scheme_are_refused(bz):
+    grid = bz.RectilinearGrid((16, 16, 8), halo=(5, 5, 5), **EXT)
+    with pytest.raises(NotImplementedError):
+        bz.AtmosphereModel(grid, momentum_advection=bz.WENO(order=9), scalar_advection={"ρθ": bz.WENO(order=5)})

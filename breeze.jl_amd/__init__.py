@@ -23,6 +23,6 @@ from .model import cell_advection_timescale, nan_checker  # noqa: F401,E402
 from .microphysics import (DCMIP2016KesslerMicrophysics, KesslerMicrophysicalFields, TetensFormula,  # noqa: F401,E402
                            microphysics_model_update_)
 from .forcings import (BulkDrag, BulkSensibleHeatFlux, BulkVaporFlux, FPlane, FieldBoundaryConditions, FluxBoundaryCondition, Forcing, FrictionVelocityDrag,  # noqa: F401,E402
-                       GeostrophicForcing, SmagorinskyLilly, SubsidenceForcing, geostrophic_forcings)
+                       GaussianMask, GeostrophicForcing, Relaxation, SmagorinskyLilly, SubsidenceForcing, geostrophic_forcings)
 from .model import compute_closure_fields_, compute_flux_bc_tendencies_  # noqa: F401,E402
 from . import benchmarks  # noqa: F401,E402

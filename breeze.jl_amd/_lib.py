@@ -90,6 +90,10 @@ class bz_column_forcings(C.Structure):
                 ("bottom_drag_rho0_ustar2", C.c_double), ("bottom_drag_epsilon", C.c_double)]
 
 
+class bz_column_relaxation(C.Structure):
+    _fields_ = [(f"{a}_{b}", _dp) for b in ("u", "v", "w", "theta", "moisture") for a in ("rate", "target")] + [("specific_mask", C.c_int32)]
+
+
 _KESSLER_PARAMS = ("dcmip_temperature_scale", "terminal_velocity_coefficient", "density_scale", "terminal_velocity_exponent",
                    "autoconversion_rate", "autoconversion_threshold", "accretion_rate", "accretion_exponent",
                    "evaporation_ventilation_coefficient_1", "evaporation_ventilation_coefficient_2",
@@ -234,6 +238,7 @@ SYMBOLS = {
     "bz_compute_closure_fields": (C.c_int, [_ctx, _sp]),
     "bz_set_bulk_surface_fluxes": (C.c_int, [_ctx, C.POINTER(bz_bulk_surface_fluxes)]),
     "bz_set_forcings": (C.c_int, [_ctx, C.POINTER(bz_column_forcings)]),
+    "bz_set_relaxation": (C.c_int, [_ctx, C.POINTER(bz_column_relaxation)]),
     "bz_compute_forcings": (C.c_int, [_ctx, _sp]),
     "bz_compute_flux_bc_tendencies": (C.c_int, [_ctx, _sp, _pp]),
     "bz_cell_advection_timescale": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),

@@ -205,7 +205,95 @@ static void free_forcings(bz_ctx *ctx)
     ctx->has_forcings = false;
 }
 
-void bzi_forcing_teardown(bz_ctx *ctx) { free_forcings(ctx); }
+// ---- Relaxation(rate, mask(z), target(z)) sponges (include/breeze_hip.h: bz_column_relaxation) ----
+struct RelaxCols {
+    const double *rate[5], *target[5];      // u v w theta q; nullptr = absent
+    int specific;
+};
+
+__global__ __launch_bounds__(256) void k_apply_relaxation(DevGrid g, RelaxCols R, const double *__restrict__ ru, const double *__restrict__ rv,
+                                                          const double *__restrict__ rw, const double *__restrict__ rth, const double *__restrict__ rq,
+                                                          const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
+                                                          double *__restrict__ Gu, double *__restrict__ Gv, double *__restrict__ Gw,
+                                                          double *__restrict__ Gth, double *__restrict__ Gq)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const long long n = g.idx(i, j, k);
+    // F = (rate mask) (target - field) (Oceananigans Relaxation); the specific-keyed form is rho_r F(specific field) (specific_forcing.jl:61-74)
+    if (R.rate[0] && !(g.bounded_x && i == 0)) {
+        const double F = R.rate[0][k] * (R.target[0][k] - ((R.specific & 1) ? u[n] : ru[n]));
+        Gu[n] += (R.specific & 1) ? g.rho[k] * F : F;
+    }
+    if (R.rate[1] && !(g.bounded_y && j == 0)) {
+        const double F = R.rate[1][k] * (R.target[1][k] - ((R.specific & 2) ? v[n] : rv[n]));
+        Gv[n] += (R.specific & 2) ? g.rho[k] * F : F;
+    }
+    if (R.rate[2] && k >= 1) {      // interior faces: the wall faces carry no tendency
+        const double F = R.rate[2][k] * (R.target[2][k] - ((R.specific & 4) ? w[n] : rw[n]));
+        Gw[n] += (R.specific & 4) ? g.rho_f[k] * F : F;
+    }
+    if (R.rate[3]) Gth[n] += R.rate[3][k] * (R.target[3][k] - rth[n]);
+    if (R.rate[4]) Gq[n] += R.rate[4][k] * (R.target[4][k] - rq[n]);
+}
+
+static void free_relaxation(bz_ctx *ctx)
+{
+    if (ctx->d_relax) hipFree(ctx->d_relax);
+    ctx->d_relax = nullptr;
+    ctx->has_relaxation = false;
+    ctx->relax_mask = ctx->relax_specific = 0;
+}
+
+extern "C" int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *r)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    ++ctx->config_epoch;
+    free_relaxation(ctx);
+    if (!r) return BZ_OK;
+    if (ctx->compressible || ctx->slab_mode) {
+        ctx->last_error = "bz_set_relaxation: single-device anelastic contexts";
+        return BZ_ERR_UNSUPPORTED;
+    }
+    if (r->specific_mask & ~7) { ctx->last_error = "bz_set_relaxation: specific_mask names u (1), v (2), w (4)"; return BZ_ERR_INVALID; }
+    const int Nz = ctx->dg.Nz, L = Nz + 1;
+    const double *rate[5] = {r->rate_u, r->rate_v, r->rate_w, r->rate_theta, r->rate_moisture};
+    const double *target[5] = {r->target_u, r->target_v, r->target_w, r->target_theta, r->target_moisture};
+    BZ_HIP(hipMalloc(&ctx->d_relax, (size_t)10 * L * sizeof(double)));
+    BZ_HIP(hipMemsetAsync(ctx->d_relax, 0, (size_t)10 * L * sizeof(double), ctx->stream));
+    for (int c = 0; c < 5; ++c) {
+        if (!rate[c]) continue;
+        const size_t len = (size_t)(c == 2 ? Nz + 1 : Nz) * sizeof(double);
+        BZ_HIP(hipMemcpyAsync(ctx->d_relax + (size_t)(2 * c) * L, rate[c], len, hipMemcpyHostToDevice, ctx->stream));
+        if (target[c]) BZ_HIP(hipMemcpyAsync(ctx->d_relax + (size_t)(2 * c + 1) * L, target[c], len, hipMemcpyHostToDevice, ctx->stream));
+        ctx->relax_mask |= 1 << c;
+    }
+    BZ_HIP(hipStreamSynchronize(ctx->stream));      // the host columns may go away after the call
+    ctx->relax_specific = r->specific_mask;
+    ctx->has_relaxation = ctx->relax_mask != 0;
+    return BZ_OK;
+}
+
+int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+{
+    if (!ctx->has_relaxation) return BZ_OK;
+    const DevGrid &g = ctx->dg;
+    ProfileScope ps(ctx, "relaxation_forcings");
+    RelaxCols R;
+    const int L = g.Nz + 1;
+    for (int c = 0; c < 5; ++c) {
+        const bool on = ctx->relax_mask & (1 << c);
+        R.rate[c] = on ? ctx->d_relax + (size_t)(2 * c) * L : nullptr;
+        R.target[c] = ctx->d_relax + (size_t)(2 * c + 1) * L;
+    }
+    R.specific = ctx->relax_specific;
+    hipLaunchKernelGGL(k_apply_relaxation, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, R, s->rho_u, s->rho_v, s->rho_w,
+                       s->rho_theta, s->rho_q, s->u, s->v, s->w, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+void bzi_forcing_teardown(bz_ctx *ctx) { free_forcings(ctx); free_relaxation(ctx); }
 
 extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
 {

@@ -55,7 +55,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
     // configuration with walls steps operator by operator
     const bool walls_lean = ctx->dg.bounded_y && ctx->walls_lean_ok;
     if ((ctx->fused_ok || walls_lean) && ctx->fuse_rk && ctx->lean && ctx->weno_R == 3 && ctx->scalar_R == 3 && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
-        (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask &&
+        (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && !ctx->has_relaxation && ctx->n_tracers == 0 && !ctx->bounded_mask &&
         (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32)) {
         // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,
         // q^v, T on the fly (bit-identical to the stored diagnostics), rho theta / rho q ping-pong between their own arrays
@@ -169,7 +169,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
     }
     // (walls in y: the generic order-7 / 9 kernels are wall-aware, the LDS-tiled order-5 kernels of this tier are not)
     if ((ctx->fused_ok || (walls_lean && ctx->weno_R != 3)) && ctx->fuse_rk && ctx->scalar_R == ctx->weno_R && (ctx->weno_R == 3 || ctx->n_tracers == 0) && ctx->dg.formulation == 0 &&
-        ctx->dg.microphysics != 2 && !ctx->bounded_mask && !(ctx->has_forcings && ctx->tune.no_fuse_forcing)) {
+        ctx->dg.microphysics != 2 && !ctx->bounded_mask && !ctx->has_relaxation && !(ctx->has_forcings && ctx->tune.no_fuse_forcing)) {
         // Tendencies and the following RK update in one pass (bz_tendency.hip: bzi_tendencies_fused_rk): the
         // tendency of stage s is evaluated where the reference applies it (at the start of stage s, from the state
         // left by stage s-1), the predictor momentum goes to the G arrays and is projected from there into the

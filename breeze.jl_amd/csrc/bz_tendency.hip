@@ -401,6 +401,7 @@ static int compute_tendencies_mixed(bz_ctx *ctx, const bz_state *s, const bz_pro
     if (ctx->bounded_mask && (rc = bzi_bounded_tendencies(ctx, s, G))) return rc;
     if (ctx->has_closure && (rc = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, 1.0))) return rc;
     if (ctx->has_forcings && (rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0))) return rc;
+    if ((rc = bzi_apply_relaxation(ctx, s, G))) return rc;
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -457,7 +458,7 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
         }
         if (ctx->has_closure && (rcg = bzi_apply_closure(ctx, s, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, 1.0))) return rcg;
         if (ctx->has_forcings && (rcg = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0))) return rcg;
-        return BZ_OK;
+        return bzi_apply_relaxation(ctx, s, G);
     }
     if (ctx->tend_gen >= 3 && g.formulation != 0) {
         ctx->last_error = "BZ_TEND_GEN >= 3 implements the potential-temperature formulation only";
@@ -539,6 +540,10 @@ extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_pr
     if (ctx->has_forcings) {
         int rcf = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0);
         if (rcf) return rcf;
+    }
+    {
+        int rcr = bzi_apply_relaxation(ctx, s, G);
+        if (rcr) return rcr;
     }
     BZ_LAUNCH_CHECK();
     return BZ_OK;

@@ -59,6 +59,29 @@ class Forcing:
         self.profile = profile
 
 
+class GaussianMask:
+    """GaussianMask{:z}(center, width): exp(-(z - center)^2 / (2 width^2)) (Oceananigans; examples/rico.jl:104,
+    examples/neutral_atmospheric_boundary_layer.jl:105)."""
+
+    def __init__(self, center, width, direction="z"):
+        if str(direction).lstrip(":") != "z":
+            raise NotImplementedError("GaussianMask{:z}: sponges vary with height only")
+        self.center, self.width = float(center), float(width)
+
+    def __call__(self, z):
+        return np.exp(-(z - self.center) ** 2 / (2 * self.width ** 2))
+
+
+class Relaxation:
+    """Relaxation(rate, mask, target): F = rate * mask(z) * (target(z) - field) (Oceananigans Relaxation; the sponge layers of
+    examples/rico.jl:103-105,164, neutral_atmospheric_boundary_layer.jl:127, tropical_cyclone_world.jl).  mask: GaussianMask or a function
+    of z (default 1); target: a number, a function of z or a column (default 0).  Keyed in `forcing` by a density name (ρu, ρv, ρw, ρθ / ρe,
+    ρqᵉ ...: the density relaxes, as the reference's examples write it) or by u, v, w (specific forcing: ρᵣ F)."""
+
+    def __init__(self, rate, mask=None, target=0.0):
+        self.rate, self.mask, self.target = float(rate), mask, target
+
+
 class FrictionVelocityDrag:
     """The example's bulk drag closure -ρ₀ u★² ρu / √(ρu² + ρv²) (examples/bomex.jl:95-99) as data."""
 
@@ -113,6 +136,53 @@ def _profile(value, z):
     if a.shape != z.shape:
         raise ValueError(f"profile has shape {a.shape}, expected {z.shape}")
     return a
+
+
+_RELAX_SLOTS = {"ρu": ("u", 0), "ρv": ("v", 0), "ρw": ("w", 0), "ρθ": ("theta", 0), "ρe": ("theta", 0), "ρqe": ("moisture", 0),
+                "ρqv": ("moisture", 0), "ρqt": ("moisture", 0), "ρq": ("moisture", 0), "u": ("u", 1), "v": ("v", 2), "w": ("w", 4)}
+
+
+def split_relaxation(forcing):
+    """-> (forcing without its Relaxation entries, {key: Relaxation}): sponges go to bz_set_relaxation, the rest to the forcing stack."""
+    rest, relax = {}, {}
+    for name, entry in (forcing or {}).items():
+        items = entry if isinstance(entry, (tuple, list)) else (entry,)
+        keep = tuple(it for it in items if not isinstance(it, Relaxation))
+        mine = [it for it in items if isinstance(it, Relaxation)]
+        if len(mine) > 1:
+            raise NotImplementedError(f"one Relaxation per field ({name!r})")
+        if mine:
+            relax[_key(name)] = mine[0]
+        if keep:
+            rest[name] = keep if len(keep) > 1 else keep[0]
+    return (rest or None), relax
+
+
+def materialize_relaxation(grid, relax, formulation, T=None):
+    """{key: Relaxation} -> (bz_column_relaxation, keepalive arrays) or (None, None)."""
+    T = T or _lib.types(8)
+    if not relax:
+        return None, None
+    zc, zf = np.asarray(grid.zᶜ, dtype=np.float64), np.asarray(grid.zᶠ, dtype=np.float64)
+    S, keep, seen = T.bz_column_relaxation(), [], set()
+    for k, r in relax.items():
+        if k not in _RELAX_SLOTS:
+            raise NotImplementedError(f"Relaxation on {k!r} is not implemented (ρu, ρv, ρw, ρθ / ρe, the moisture density; u, v, w)")
+        if (k == "ρe") != (formulation == "StaticEnergy") and k in ("ρe", "ρθ"):
+            raise ValueError(f"Relaxation on {k!r}: the thermodynamic density of this formulation is {'ρe' if formulation == 'StaticEnergy' else 'ρθ'}")
+        slot, bit = _RELAX_SLOTS[k]
+        if slot in seen:
+            raise NotImplementedError(f"one Relaxation per field ({slot})")
+        seen.add(slot)
+        z = zf if slot == "w" else zc
+        mask = np.ones_like(z) if r.mask is None else np.asarray([float(r.mask(zk)) for zk in z])
+        rate = np.ascontiguousarray(r.rate * mask, dtype=T.np_real)
+        target = np.ascontiguousarray(np.full_like(z, float(r.target)) if np.isscalar(r.target) else _profile(r.target, z), dtype=T.np_real)
+        keep += [rate, target]
+        setattr(S, "rate_" + slot, rate.ctypes.data_as(C.POINTER(T.real)))
+        setattr(S, "target_" + slot, target.ctypes.data_as(C.POINTER(T.real)))
+        S.specific_mask |= bit
+    return S, keep
 
 
 def materialize_forcings(grid, coriolis, forcing, boundary_conditions, T=None):

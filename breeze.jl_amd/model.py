@@ -388,7 +388,11 @@ class AtmosphereModel:
             cl = T.bz_smagorinsky_lilly(closure.C, closure.Cb, closure.Pr)
             self._check(lib.bz_set_closure(self._ctx, C.byref(cl), C.c_void_p(self.closure_fields["νₑ"].ptr())), "bz_set_closure")
         # coriolis / forcing / boundary_conditions of the BOMEX configuration -> one column-forcing stack (forcings.py)
-        from .forcings import materialize_forcings
+        from .forcings import materialize_forcings, materialize_relaxation, split_relaxation
+        forcing, _relax = split_relaxation(forcing)      # Relaxation sponges: their own attachment (bz_set_relaxation)
+        Rx, self._relaxation_keepalive = materialize_relaxation(grid, _relax, formulation, T)
+        if Rx is not None:
+            self._check(lib.bz_set_relaxation(self._ctx, C.byref(Rx)), "bz_set_relaxation")
         F, self._forcing_keepalive = materialize_forcings(grid, coriolis, forcing, boundary_conditions, T)
         if F is not None:
             if self._kessler or formulation != "LiquidIcePotentialTemperature":

@@ -514,6 +514,28 @@ typedef struct bz_column_forcings {
     double bottom_drag_epsilon;
 } bz_column_forcings;
 int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *forcings);       /* NULL detaches the stack */
+/* ---- sponge layers: Relaxation(rate, mask, target) forcings with a horizontally uniform mask and target ----
+ * Oceananigans' Relaxation — F = rate * mask(x, y, z) * (target(x, y, z, t) - field) — is how the reference's examples damp the top of
+ * the domain: examples/rico.jl:103-105,164 (w = Relaxation(rate, GaussianMask{:z})), examples/neutral_atmospheric_boundary_layer.jl:103-136
+ * (rho w relaxed to 0, rho theta to a reference profile), examples/tropical_cyclone_world.jl, tropical_cyclone_with_rainband.jl:434-490.
+ * With mask and target functions of z alone the forcing is two columns per field:
+ *   rate_*    rate * mask(z) at the field's vertical location (centres, length Nz; rho w: faces, length Nz + 1)
+ *   target_*  target(z) there (NULL = 0)
+ * for rho u, rho v, rho w, the thermodynamic density (rho theta or rho e) and the moisture density; NULL rate = no relaxation of that field.
+ * Keyed by the density name (rho w = ...) the forcing enters the density tendency as is, G += rate (target - rho phi); keyed by the specific
+ * name (w = ..., bit set in specific_mask: 1 u, 2 v, 4 w) it is a specific forcing (src/Forcings/specific_forcing.jl:61-74):
+ * G += rho_r rate (target - phi) with the reference density at the field's location.  HOST arrays, copied by the call.  bz_compute_tendencies adds the terms
+ * after the forcing stack; bz_time_step_anelastic then steps with the tendencies evaluated per operator (fused RK update, projection and
+ * diagnosis).  Single-device anelastic contexts. */
+typedef struct bz_column_relaxation {
+    const double *rate_u, *target_u;
+    const double *rate_v, *target_v;
+    const double *rate_w, *target_w;
+    const double *rate_theta, *target_theta;
+    const double *rate_moisture, *target_moisture;
+    int32_t specific_mask;
+} bz_column_relaxation;
+int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *relaxation);      /* NULL detaches */
 /* compute_forcings!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:81-86) */
 int bz_compute_forcings(bz_ctx *ctx, const bz_state *s);
 /* compute_flux_bc_tendencies!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:418-434) */

@@ -176,6 +176,26 @@ function attach_forcings!(ctx, profiles::NamedTuple, flags::NamedTuple, f, Jθ, 
                                 "bz_set_forcings", ctx)
 end
 
+struct BzColumnRelaxation
+    rate_u::Ptr{Cdouble}; target_u::Ptr{Cdouble}; rate_v::Ptr{Cdouble}; target_v::Ptr{Cdouble}; rate_w::Ptr{Cdouble}; target_w::Ptr{Cdouble}
+    rate_theta::Ptr{Cdouble}; target_theta::Ptr{Cdouble}; rate_moisture::Ptr{Cdouble}; target_moisture::Ptr{Cdouble}
+    specific_mask::Int32
+end
+
+"""
+Sponge layers: every `Relaxation(rate, mask::GaussianMask{:z}, target)` of `model.forcing` (examples/rico.jl:103-105,164;
+neutral_atmospheric_boundary_layer.jl:103-136) as two host columns, `rate .* mask.(z)` and `target.(z)` at the field's vertical nodes
+(ρw / w: the Nz + 1 faces).  `columns = (; u = (rate, target), w = ..., θ = ..., q = ...)`; `specific` lists the entries keyed by the
+specific names u, v, w (their forcing is ρᵣ F).
+"""
+function attach_relaxation!(ctx, columns::NamedTuple, specific = ())
+    p(name, i) = haskey(columns, name) ? pointer(columns[name][i]) : Ptr{Cdouble}(C_NULL)
+    mask = Int32((:u in specific) + 2 * (:v in specific) + 4 * (:w in specific))
+    R = BzColumnRelaxation(p(:u, 1), p(:u, 2), p(:v, 1), p(:v, 2), p(:w, 1), p(:w, 2), p(:θ, 1), p(:θ, 2), p(:q, 1), p(:q, 2), mask)
+    GC.@preserve columns check(ccall((:bz_set_relaxation, libbreeze_hip), Cint, (Ptr{Cvoid}, Ref{BzColumnRelaxation}), ctx, R),
+                               "bz_set_relaxation", ctx)
+end
+
 "tracers = (:a, :b): density = model.tracers[n]; `specific` is an extra centre field owned by the extension."
 function attach_tracers!(ctx, model, specific_fields)
     ts = model.timestepper

@@ -138,6 +138,35 @@ def add_forcing_tendencies(m):
         I(G["rtheta"])[...] += (rho * col(F.Fe) + 0.0) / (cpm * Pi)
 
 
+def add_relaxation_tendencies(m):
+    """Sponge layers: Oceananigans' Relaxation, F = (rate mask(z)) (target(z) - field), as the reference's examples attach it
+    (examples/rico.jl:103-105,164; neutral_atmospheric_boundary_layer.jl:103-136).  m.relaxation = {key: (rate_column, target_column)}:
+    density keys "ru", "rv", "rw", "rtheta", "rq" relax the prognostic density (G += F); the specific keys "u", "v", "w" are specific
+    forcings, G += rho_r F with the reference density at the field's location (src/Forcings/specific_forcing.jl:61-74).  Columns at the
+    field's vertical location (rw / w: Nz + 1 faces; the wall faces carry no tendency)."""
+    g, r = m.grid, m.ref
+    rho_c = r.density[g.Hz:g.Hz + g.Nz]
+    rho_f = 0.5 * (r.density[g.Hz - 1:g.Hz + g.Nz] + r.density[g.Hz:g.Hz + g.Nz + 1])
+    for key, (rate, target) in m.relaxation.items():
+        specific = key in ("u", "v", "w")
+        name = {"u": "ru", "v": "rv", "w": "rw"}.get(key, key)
+        zface = name == "rw"
+        field = g.interior(getattr(m, key), zface)
+        G = g.interior(m.G[name], zface)
+        rate, target = np.asarray(rate, dtype=np.float64)[:, None, None], np.asarray(target, dtype=np.float64)[:, None, None]
+        F = rate * (target - field)
+        if specific:
+            F = (rho_f if zface else rho_c)[:, None, None] * F
+        if zface:
+            G[1:g.Nz] += F[1:g.Nz]
+        elif name == "ru" and g.topo[0] == 1:
+            G[:, :, 1:] += F[:, :, 1:]
+        elif name == "rv" and g.topo[1] == 1:
+            G[:, 1:, :] += F[:, 1:, :]
+        else:
+            G[...] += F
+
+
 def add_flux_bc_tendencies(m):
     """compute_flux_bc_tendencies!: bottom FluxBoundaryConditions, G[.,.,1] += J / dz_1."""
     F, g = m.forcings, m.grid

@@ -567,6 +567,9 @@ class OracleModel:
         if self.forcings is not None:
             from .forcings import add_forcing_tendencies
             add_forcing_tendencies(self)
+        if getattr(self, "relaxation", None):
+            from .forcings import add_relaxation_tendencies
+            add_relaxation_tendencies(self)
 
     def liquid_ice_potential_temperature(self):
         """Diagnostics.LiquidIcePotentialTemperature (dry: theta = T / Pi) on the interior."""

@@ -1,0 +1,189 @@
+"""Sponge layers: Oceananigans' Relaxation(rate, mask, target) with a GaussianMask{:z}, the way the reference's examples damp the model
+top — examples/rico.jl:103-105,164 (w), examples/neutral_atmospheric_boundary_layer.jl:103-136 (rho w to zero, rho theta to a reference
+profile), tropical_cyclone_world.jl.  F = rate * mask(z) * (target(z) - field); density-keyed entries relax the prognostic density,
+u / v / w-keyed ones are specific forcings (rho_r F).  Boundary: bz_set_relaxation (two columns per field)."""
+import numpy as np
+import pytest
+
+from helpers import PROG, push_state, randomize, relerr
+
+EXT = dict(x=(0.0, 1600.0), y=(0.0, 1200.0), z=(0.0, 1000.0))
+SIZE = (32, 16, 20)
+
+
+def _mask(z, center=1000.0, width=200.0):
+    return np.exp(-(z - center) ** 2 / (2 * width ** 2))
+
+
+def theta_ref(z):
+    return 300.0 + 0.003 * z
+
+
+def _columns(g, ref, keys, rate=0.01):
+    """{key: (rate column, target column)} of the oracle for the host's Relaxation entries below"""
+    rho = ref.density[g.Hz:g.Hz + g.Nz]
+    out = {}
+    for k in keys:
+        z = g.zf if k in ("rw", "w") else g.zc
+        target = rho * theta_ref(g.zc) if k == "rtheta" else (0.012 * rho if k == "rq" else (2.0 * rho if k == "ru" else np.zeros_like(z)))
+        out[k] = (rate * _mask(z), target)
+    return out
+
+
+def test_oracle_relaxation_known_answers(oracle):
+    from oracle.forcings import add_relaxation_tendencies
+    g = oracle.Grid(SIZE, **EXT)
+    m = oracle.OracleModel(g, potential_temperature=300.0)
+    randomize(m, seed=5)
+    m.update_state()
+    base = {n: m.G[n].copy() for n in m.G}
+    m.relaxation = _columns(g, m.ref, ("rw", "rtheta"))
+    add_relaxation_tendencies(m)
+    dw = g.interior(m.G["rw"], True) - g.interior(base["rw"], True)
+    want = (0.01 * _mask(g.zf))[:, None, None] * (0.0 - g.interior(m.rw, True))
+    scale = np.abs(g.interior(base["rw"], True)).max()      # G - G_base cancels against the advective part
+    assert np.abs(dw[1:g.Nz] - want[1:g.Nz]).max() < 1e-14 * scale and np.all(dw[0] == 0) and np.all(dw[g.Nz] == 0)      # the wall faces carry no tendency
+    dth = g.interior(m.G["rtheta"]) - g.interior(base["rtheta"])
+    rho = m.ref.density[g.Hz:g.Hz + g.Nz]
+    wth = (0.01 * _mask(g.zc))[:, None, None] * ((rho * theta_ref(g.zc))[:, None, None] - g.interior(m.rtheta))
+    assert np.abs(dth - wth).max() < 1e-14 * max(np.abs(g.interior(base["rtheta"])).max(), np.abs(wth).max())
+    # specific key: rho at the faces times the relaxation of w itself
+    m.G["rw"][...] = base["rw"]
+    m.relaxation = _columns(g, m.ref, ("w",))
+    add_relaxation_tendencies(m)
+    dw = g.interior(m.G["rw"], True) - g.interior(base["rw"], True)
+    rho_f = 0.5 * (m.ref.density[g.Hz - 1:g.Hz + g.Nz] + m.ref.density[g.Hz:g.Hz + g.Nz + 1])
+    want = (rho_f * 0.01 * _mask(g.zf))[:, None, None] * (0.0 - g.interior(m.w, True))
+    assert np.abs(dw[1:g.Nz] - want[1:g.Nz]).max() < 1e-14 * scale
+    # a sponge on w damps the vertical momentum of the layer it covers
+    m2 = oracle.OracleModel(g, potential_temperature=300.0)
+    m2.set(theta=lambda x, y, z: 300.0 + 2.0 * np.exp(-((x - 800.0) ** 2 + (y - 600.0) ** 2 + (z - 700.0) ** 2) / 150.0 ** 2))
+    m3 = oracle.OracleModel(g, potential_temperature=300.0)
+    m3.set(theta=lambda x, y, z: 300.0 + 2.0 * np.exp(-((x - 800.0) ** 2 + (y - 600.0) ** 2 + (z - 700.0) ** 2) / 150.0 ** 2))
+    m3.relaxation = {"rw": (0.2 * _mask(g.zf), np.zeros(g.Nz + 1))}
+    for _ in range(5):
+        m2.time_step(2.0)
+        m3.time_step(2.0)
+    top = slice(g.Nz - 4, g.Nz)
+    assert np.abs(g.interior(m3.rw, True)[top]).max() < 0.8 * np.abs(g.interior(m2.rw, True)[top]).max()
+
+
+def test_host_builds_the_columns(bz):
+    from breeze_jl_amd.forcings import materialize_relaxation, split_relaxation
+    grid = bz.RectilinearGrid(SIZE, **EXT)
+    sponge = bz.Relaxation(rate=0.01, mask=bz.GaussianMask(center=1000.0, width=200.0))
+    rest, relax = split_relaxation({"ρw": sponge, "u": (bz.Forcing(lambda z: 1e-4), )})
+    assert list(rest) == ["u"] and list(relax) == ["ρw"]
+    S, keep = materialize_relaxation(grid, relax, "LiquidIcePotentialTemperature")
+    zf = np.asarray(grid.zᶠ)
+    assert np.allclose(keep[0], 0.01 * _mask(zf), rtol=1e-15) and np.all(keep[1] == 0) and S.specific_mask == 0 and not S.rate_u
+    S, keep = materialize_relaxation(grid, {"w": sponge}, "LiquidIcePotentialTemperature")
+    assert S.specific_mask == 4
+    with pytest.raises(ValueError):
+        materialize_relaxation(grid, {"ρe": sponge}, "LiquidIcePotentialTemperature")
+    with pytest.raises(NotImplementedError):
+        materialize_relaxation(grid, {"ρqᶜˡ": sponge}, "LiquidIcePotentialTemperature")
+    with pytest.raises(NotImplementedError):
+        bz.GaussianMask(center=0.0, width=1.0, direction="x")
+
+
+def _pair(oracle, bz, keys, okw=None, hkw=None, topo=None, size=SIZE):
+    tk = dict(topology=topo) if topo else {}
+    g = oracle.Grid(size, **EXT, **tk)
+    om = oracle.OracleModel(g, potential_temperature=300.0, **(okw or {}))
+    om.relaxation = _columns(g, om.ref, keys)
+    htopo = dict(topology=tuple(getattr(bz, t) for t in topo)) if topo else {}
+    grid = bz.RectilinearGrid(size, **EXT, **htopo)
+    ref = bz.ReferenceState(grid, potential_temperature=300.0)
+    mask = bz.GaussianMask(center=1000.0, width=200.0)
+    rho = np.asarray(ref.density_column()) if hasattr(ref, "density_column") else om.ref.density[g.Hz:g.Hz + g.Nz]
+    host = {"rw": ("ρw", 0.0), "w": ("w", 0.0), "rv": ("ρv", 0.0), "u": ("u", 0.0), "v": ("v", 0.0),
+            "ru": ("ρu", 2.0 * rho), "rtheta": ("ρθ", rho * theta_ref(g.zc)), "rq": ("ρqᵛ", 0.012 * rho)}
+    forcing = {host[k][0]: bz.Relaxation(rate=0.01, mask=mask, target=host[k][1]) for k in keys}
+    hkw = dict(hkw or {})
+    forcing.update(hkw.pop("forcing", {}))
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), forcing=forcing, **hkw)
+    return g, om, hm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keys", [("rw", "rtheta"), ("ru", "rv", "rw", "rtheta", "rq"), ("u", "v", "w")])
+def test_relaxation_tendencies_match_oracle(oracle, bz, keys):
+    g, om, hm = _pair(oracle, bz, keys)
+    randomize(om, seed=9)
+    om.update_state()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=True)
+    hm.synchronize()
+    om0 = oracle.OracleModel(g, potential_temperature=300.0)
+    for n in ("ru", "rv", "rw", "rtheta", "rq"):
+        getattr(om0, n)[...] = getattr(om, n)
+    om0.update_state()
+    for n, k in PROG.items():
+        zf = n == "rw"
+        want, base, got = g.interior(om.G[n], zf), g.interior(om0.G[n], zf), hm.G[k].interior_cpu()
+        assert relerr(got, want) < 1e-12, n
+        part = want - base
+        if np.abs(part).max() > 0:
+            assert np.abs((got - base) - part).max() < 1e-9 * np.abs(part).max(), n      # the relaxation term itself
+
+
+def _steps(g, om, hm, n, dt, tol):
+    for _ in range(n):
+        om.time_step(dt)
+        hm.time_step(dt)
+    hm.synchronize()
+    mom = max(np.abs(g.interior(getattr(om, f), f == "rw")).max() for f in ("ru", "rv", "rw"))
+    for f, fld in (("ru", hm.momentum["ρu"]), ("rv", hm.momentum["ρv"]), ("rw", hm.momentum["ρw"]),
+                   ("rtheta", hm.potential_temperature_density), ("rq", hm.moisture_density), ("T", hm.temperature)):
+        want, got = g.interior(getattr(om, f), f == "rw"), fld.interior_cpu()
+        scale = mom if f in ("ru", "rv", "rw") else max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() < tol * scale, (f, np.abs(got - want).max() / scale)
+
+
+def _bubble(x, y, z):
+    return 300.0 + 0.003 * z + 2.0 * np.exp(-((x - 800.0) ** 2 + (y - 600.0) ** 2 + (z - 600.0) ** 2) / 150.0 ** 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keys", [("w",), ("rw", "rtheta")])
+def test_sponged_steps_match_oracle(oracle, bz, keys):
+    """rico.jl's w sponge; the neutral boundary layer's pair (rho w to zero, rho theta to the reference profile)"""
+    g, om, hm = _pair(oracle, bz, keys)
+    om.set(theta=_bubble, u=3.0)
+    hm.set(θ=_bubble, u=3.0)
+    _steps(g, om, hm, 3, 2.0, 1e-9)
+
+
+@pytest.mark.gpu
+def test_neutral_boundary_layer_physics_list(oracle, bz):
+    """examples/neutral_atmospheric_boundary_layer.jl:127-146 at reduced size and order 5: f-plane + geostrophic forcing + SmagorinskyLilly +
+    friction-velocity drag + the two sponges"""
+    from oracle.closure import SmagorinskyLilly
+    from oracle.forcings import ColumnForcings
+    f, ug = 1e-4, 15.0
+    g0 = oracle.Grid(SIZE, **EXT)
+    rho0 = 1e5 / (287.0 * 300.0)
+    okw = dict(closure=SmagorinskyLilly(), forcings=ColumnForcings(Fu=-f * 0.0 * g0.zc, Fv=f * ug + 0.0 * g0.zc, coriolis_f=f,
+                                                                       drag_rho0_ustar2=rho0 * 0.25))
+    geo = bz.geostrophic_forcings(lambda z: ug, lambda z: 0.0)
+    drag = bz.FrictionVelocityDrag(rho0, 0.5)
+    hkw = dict(closure=bz.SmagorinskyLilly(), coriolis=bz.FPlane(f=f), forcing={"u": geo.u, "v": geo.v},
+               boundary_conditions={"ρu": bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(drag)),
+                                    "ρv": bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(drag))})
+    g, om, hm = _pair(oracle, bz, ("rw", "rtheta"), okw=okw, hkw=hkw)
+    om.set(theta=_bubble, u=ug)
+    hm.set(θ=_bubble, u=ug)
+    # 15 m/s across a 150 m bubble on a 50 m grid: the WENO weights amplify the FMA-contraction differences (DESIGN §6 "Strict-parity
+    # library"); the same list WITHOUT the sponges differs from the oracle by the same 7e-9 (rho w), so this is not the relaxation
+    _steps(g, om, hm, 3, 2.0, 2e-8)
+
+
+@pytest.mark.gpu
+def test_sponge_inside_y_walls(oracle, bz):
+    g, om, hm = _pair(oracle, bz, ("rv", "rw"), topo=("Periodic", "Bounded", "Bounded"))
+    v0 = lambda x, y, z: np.sin(np.pi * y / 1200.0) + 0 * x + 0 * z
+    om.set(theta=_bubble, v=v0)
+    hm.set(θ=_bubble, v=v0)
+    _steps(g, om, hm, 3, 2.0, 1e-9)
+    assert float(hm.momentum["ρv"].interior[:, 0, :].abs().max()) == 0.0

@@ -150,3 +150,35 @@ def test_cloudy_kelvin_helmholtz_jl(bz, oracle):
     for n, f in (("ru", model.momentum["ρu"]), ("rtheta", model.potential_temperature_density), ("rq", model.moisture_density), ("T", model.temperature)):
         want = og.interior(getattr(om, n))
         assert np.abs(f.interior_cpu() - want).max() < 1e-9 * np.abs(want).max(), n
+
+
+def test_neutral_atmospheric_boundary_layer_jl(bz):
+    """examples/neutral_atmospheric_boundary_layer.jl:36-146: 96^3 at halo (5, 5, 5), WENO(order = 9), SmagorinskyLilly, FPlane + geostrophic
+    forcing, friction-velocity drag on rho u / rho v, Gaussian sponges on rho w (to zero) and rho theta (to the capping-inversion profile);
+    parity of the list: tests/test_relaxation.py::test_neutral_boundary_layer_physics_list"""
+    N = 48                                     # the example's 96 halved; same extents
+    grid = bz.RectilinearGrid((N, N, N), halo=(5, 5, 5), x=(0.0, 3000.0), y=(0.0, 3000.0), z=(0.0, 1000.0))
+    p0, th0 = 1e5, 300.0
+    ref = bz.ReferenceState(grid, surface_pressure=p0, potential_temperature=th0)
+    dz = 1000.0 / N
+    zi1 = 468.0
+    zi2, Gi, Gtop = zi1 + 6 * dz, 8 / (6 * dz), 0.003
+    thr = lambda z: np.where(z < zi1, th0, np.where(z < zi2, th0 + Gi * (z - zi1), th0 + Gi * (zi2 - zi1) + Gtop * (z - zi2)))
+    rho0 = p0 / (287.0 * th0)
+    drag = bz.FluxBoundaryCondition(bz.FrictionVelocityDrag(rho0, 0.5, epsilon=1e-12))
+    mask = bz.GaussianMask(center=1000.0, width=200.0)
+    zc = np.asarray(grid.zᶜ)
+    rho = ref.density[grid.Hz:grid.Hz + N]                       # the example's ρθᵣ = reference_state.density * θᵣ(z)
+    geo = bz.geostrophic_forcings(lambda z: 15.0, lambda z: 0.0)
+    forcing = {"u": geo.u, "v": geo.v, "ρw": bz.Relaxation(rate=0.01, mask=mask), "ρθ": bz.Relaxation(rate=0.01, mask=mask, target=rho * thr(zc))}
+    model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), coriolis=bz.FPlane(f=1e-4), advection=bz.WENO(order=9), forcing=forcing,
+                               closure=bz.SmagorinskyLilly(), boundary_conditions={"ρu": bz.FieldBoundaryConditions(bottom=drag),
+                                                                                  "ρv": bz.FieldBoundaryConditions(bottom=drag)})
+    rng = np.random.default_rng(1)
+    model.set(θ=lambda x, y, z: thr(z) + 0.1 * rng.standard_normal((N, N, N)) * (z < zi1), u=15.0)
+    th_top0 = model.potential_temperature_density.interior_cpu()[-2].mean()
+    for _ in range(10):
+        model.time_step(0.5)
+    model.synchronize()
+    assert _finite(model) and model.closure_fields["νₑ"].interior_cpu().max() > 0.0
+    assert abs(model.potential_temperature_density.interior_cpu()[-2].mean() - th_top0) < 1e-3 * th_top0      # the sponge holds the inversion profile

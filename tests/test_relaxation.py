@@ -96,7 +96,7 @@ def _pair(oracle, bz, keys, okw=None, hkw=None, topo=None, size=SIZE):
     grid = bz.RectilinearGrid(size, **EXT, **htopo)
     ref = bz.ReferenceState(grid, potential_temperature=300.0)
     mask = bz.GaussianMask(center=1000.0, width=200.0)
-    rho = np.asarray(ref.density_column()) if hasattr(ref, "density_column") else om.ref.density[g.Hz:g.Hz + g.Nz]
+    rho = ref.density[grid.Hz:grid.Hz + grid.Nz]
     host = {"rw": ("ρw", 0.0), "w": ("w", 0.0), "rv": ("ρv", 0.0), "u": ("u", 0.0), "v": ("v", 0.0),
             "ru": ("ρu", 2.0 * rho), "rtheta": ("ρθ", rho * theta_ref(g.zc)), "rq": ("ρqᵛ", 0.012 * rho)}
     forcing = {host[k][0]: bz.Relaxation(rate=0.01, mask=mask, target=host[k][1]) for k in keys}

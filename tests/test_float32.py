@@ -500,3 +500,31 @@ def test_float32_two_dimensional_models_match_the_float64_oracle(oracle, bz):
         want = I(getattr(om, n))
         assert np.abs(f.interior_cpu().astype(np.float64) - want).max() / np.abs(want).max() < 1e-5, n
     assert np.abs(hm.momentum["ρv"].interior_cpu()).max() == 0.0
+
+
+@pytest.mark.gpu
+def test_float32_mixed_orders_with_a_sponge_match_the_float64_oracle(oracle, bz):
+    """Float32 twin of the round-3 options: momentum WENO(order = 9) with WENO(order = 5) scalars (bounds-preserving moisture) and rico.jl's
+    w sponge (examples/rico.jl:40,103-105,164,184-190 is a Float32 model), three steps against the Float64 oracle."""
+    size = (24, 24, 20)
+    ext = dict(x=(0.0, 2400.0), y=(0.0, 2400.0), z=(0.0, 2000.0))
+    og = oracle.Grid(size, halo=(5, 5, 5), **ext)
+    om = oracle.OracleModel(og, potential_temperature=300.0, advection="WENO9", scalar_advection="WENO5")
+    om.bounded = {"rq": (0.0, 1.0)}
+    mask = lambda z: np.exp(-(z - 2000.0) ** 2 / (2 * 400.0 ** 2))
+    om.relaxation = {"w": (0.125 * mask(og.zf), np.zeros(og.Nz + 1))}
+    grid = bz.RectilinearGrid(size, halo=(5, 5, 5), float_type=np.float32, **ext)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)),
+                            momentum_advection=bz.WENO(order=9), scalar_advection={"ρθ": bz.WENO(order=5), "ρqᵛ": bz.WENO(order=5, bounds=(0, 1))},
+                            forcing={"w": bz.Relaxation(rate=0.125, mask=bz.GaussianMask(center=2000.0, width=400.0))})
+    th = lambda x, y, z: 300.0 + 0.003 * z + 2.0 * np.exp(-((x - 1200.0) ** 2 + (y - 1200.0) ** 2 + (z - 1200.0) ** 2) / 300.0 ** 2)
+    qt = lambda x, y, z: 0.004 * np.exp(-z / 1500.0) + 0 * x + 0 * y
+    om.set(theta=th, u=4.0, v=-2.0, qt=qt)
+    hm.set(θ=th, u=4.0, v=-2.0, qᵗ=qt)
+    for _ in range(3):
+        om.time_step(3.0)
+        hm.time_step(3.0)
+    hm.synchronize()
+    e = _steps_errors(om, hm, [(n, hm.prognostic_fields()[k]) for n, k in PROG.items()])
+    print("float32 mixed orders + sponge:", {k: f"{v:.1e}" for k, v in e.items()})
+    assert max(e.values()) < 1e-4, e

@@ -272,7 +272,8 @@ _ALIASES = {"θ": "θ", "theta": "θ", "θˡⁱ": "θ", "θli": "θ", "ρ": "ρ"
 
 class CompressibleAtmosphereModel:
     """AtmosphereModel(grid; dynamics=CompressibleDynamics(SplitExplicitTimeDiscretization(...)), advection=WENO(order=5))
-    — timestepper :AcousticRungeKutta3, microphysics / closure / coriolis / forcing = nothing."""
+    — timestepper :AcousticRungeKutta3; coriolis = FPlane(f) and density-keyed Relaxation sponges on ρu, ρv, ρw, ρθ
+    (examples/tropical_cyclone_with_rainband.jl:434-514) are the forcing terms built; closure = nothing."""
 
     def __init__(self, grid, dynamics, advection=None, thermodynamic_constants=None, temperature_solver=None,
                  closure=None, coriolis=None, microphysics=None, forcing=None, device="cuda:0", substep_floattype=None):
@@ -295,9 +296,19 @@ class CompressibleAtmosphereModel:
                 raise NotImplementedError("bounds-preserving WENO is implemented for order 5")
         if not isinstance(dynamics, CompressibleDynamics):
             raise TypeError("dynamics must be CompressibleDynamics")
-        for name, val in (("closure", closure), ("coriolis", coriolis), ("forcing", forcing)):
-            if val is not None:
-                raise NotImplementedError(f"{name} is outside the hot-path scope of this build")
+        if closure is not None:
+            raise NotImplementedError("closure is outside the hot-path scope of this build")
+        from .forcings import FPlane, split_relaxation
+        if coriolis is not None and not isinstance(coriolis, FPlane):
+            raise NotImplementedError("coriolis: FPlane is implemented")
+        forcing_rest, self._relaxation = split_relaxation(forcing)
+        if forcing_rest:
+            raise NotImplementedError("CompressibleDynamics: Relaxation sponges keyed ρu, ρv, ρw, ρθ are the forcings implemented")
+        if set(self._relaxation) - {"ρu", "ρv", "ρw", "ρθ"}:
+            raise NotImplementedError("CompressibleDynamics: Relaxation sponges keyed ρu, ρv, ρw, ρθ")
+        if (coriolis is not None or self._relaxation) and type(self) is not CompressibleAtmosphereModel:
+            raise NotImplementedError("Coriolis and sponges of the compressible model: single-GPU contexts")
+        self.coriolis, self.forcing = coriolis, forcing
         from .microphysics import DCMIP2016KesslerMicrophysics, SaturationAdjustment, TetensFormula
         if microphysics is not None and not isinstance(microphysics, (DCMIP2016KesslerMicrophysics, SaturationAdjustment)):
             raise NotImplementedError("compressible microphysics: DCMIP2016KesslerMicrophysics() and "
@@ -420,6 +431,14 @@ class CompressibleAtmosphereModel:
             K.rain_terminal_velocity, K.precipitation_rate = μ["𝕎ʳ"].ptr(), μ["precipitation_rate"].data_ptr()
             self._check(lib.bz_set_kessler_microphysics(self._ctx, C.byref(P), C.byref(K), dynamics.standard_pressure),
                         "bz_set_kessler_microphysics")
+        if coriolis is not None:      # the f-plane term of the slow momentum tendencies (bz_set_forcings with coriolis_f alone)
+            Fc = T.bz_column_forcings()
+            Fc.coriolis_f = coriolis.f
+            self._check(lib.bz_set_forcings(self._ctx, C.byref(Fc)), "bz_set_forcings")
+        if self._relaxation:
+            from .forcings import materialize_relaxation
+            Rx, self._relaxation_keepalive = materialize_relaxation(grid, self._relaxation, "LiquidIcePotentialTemperature", T)
+            self._check(lib.bz_set_relaxation(self._ctx, C.byref(Rx)), "bz_set_relaxation")
         # seed_pressure! (compressible_dynamics.jl:254-258)
         if ref is not None:
             Hz, Nz = grid.Hz, grid.Nz

@@ -945,8 +945,12 @@ extern "C" int bz_compute_slow_tendencies(bz_ctx *ctx, const bz_compressible_sta
         rc = bzi_w_tendency_ring(ctx, &a, &Ga, nullptr, nullptr, 1);
         if (rc) return rc;
     }
-    return launch_scalar_rho3d(ctx, "density+potential_temperature_tendency", G->rho_theta, G->rho_d, s->rho_d, s->u, s->v,
-                               s->w, s->theta, s->rho_u, s->rho_v, s->rho_w);
+    if ((rc = launch_scalar_rho3d(ctx, "density+potential_temperature_tendency", G->rho_theta, G->rho_d, s->rho_d, s->u, s->v,
+                                  s->w, s->theta, s->rho_u, s->rho_v, s->rho_w))) return rc;
+    // - f x (rho U) of an FPlane and the density-keyed sponges are slow terms too (dynamics_kernel_functions.jl:79,99 through the same
+    // x / y_momentum_tendency; examples/tropical_cyclone_with_rainband.jl:434-514)
+    if (ctx->has_forcings && (rc = bzi_apply_forcings(ctx, &a, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0))) return rc;
+    return bzi_apply_relaxation(ctx, &a, &Ga);
 }
 
 // compute_acoustic_substeps / stage_substep_count_and_size(::ProportionalSubsteps) (acoustic_substepping.jl:451-495)

@@ -251,8 +251,8 @@ extern "C" int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *r)
     ++ctx->config_epoch;
     free_relaxation(ctx);
     if (!r) return BZ_OK;
-    if (ctx->compressible || ctx->slab_mode) {
-        ctx->last_error = "bz_set_relaxation: single-device anelastic contexts";
+    if (ctx->slab_mode || (ctx->compressible && (r->specific_mask || r->rate_moisture))) {
+        ctx->last_error = "bz_set_relaxation: single-device contexts; CompressibleDynamics: the density-keyed sponges of rho u, rho v, rho w, rho theta";
         return BZ_ERR_UNSUPPORTED;
     }
     if (r->specific_mask & ~7) { ctx->last_error = "bz_set_relaxation: specific_mask names u (1), v (2), w (4)"; return BZ_ERR_INVALID; }
@@ -301,9 +301,15 @@ extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
     if (!ctx) return BZ_ERR_INVALID;
     free_forcings(ctx);
     if (!f) return BZ_OK;
-    if (ctx->compressible || ctx->dg.formulation != 0 || ctx->dg.microphysics == 2) {      // y-slab contexts: through the library-owned distributed step (bz_comm.hip)
+    // CompressibleDynamics: the f-plane term of the slow momentum tendencies alone (examples/tropical_cyclone_with_rainband.jl:508-514);
+    // the column profiles are specific forcings of the anelastic model (times rho_r), the bottom fluxes belong to its flux-BC pass
+    const bool coriolis_only = !f->u_forcing && !f->v_forcing && !f->theta_forcing && !f->moisture_forcing && !f->energy_forcing &&
+                               !f->subsidence_vertical_velocity && f->bottom_theta_flux == 0.0 && f->bottom_moisture_flux == 0.0 &&
+                               f->bottom_drag_rho0_ustar2 == 0.0;
+    if ((ctx->compressible && (!coriolis_only || ctx->slab_mode)) || (!ctx->compressible && (ctx->dg.formulation != 0 || ctx->dg.microphysics == 2))) {      // y-slab contexts: through the library-owned distributed step (bz_comm.hip)
         ctx->last_error = "bz_set_forcings: the forcing stack is implemented for the anelastic "
-                          "potential-temperature model (microphysics nothing or SaturationAdjustment)";
+                          "potential-temperature model (microphysics nothing or SaturationAdjustment); single-device compressible contexts "
+                          "take coriolis_f alone";
         return BZ_ERR_UNSUPPORTED;
     }
     const int Nz = ctx->dg.Nz;

@@ -526,7 +526,8 @@ int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *forcings);       /* N
  * name (w = ..., bit set in specific_mask: 1 u, 2 v, 4 w) it is a specific forcing (src/Forcings/specific_forcing.jl:61-74):
  * G += rho_r rate (target - phi) with the reference density at the field's location.  HOST arrays, copied by the call.  bz_compute_tendencies adds the terms
  * after the forcing stack; bz_time_step_anelastic then steps with the tendencies evaluated per operator (fused RK update, projection and
- * diagnosis).  Single-device anelastic contexts. */
+ * diagnosis).  Single-device contexts; on a CompressibleDynamics context (examples/tropical_cyclone_with_rainband.jl:434-514) the density-keyed
+ * sponges of rho u, rho v, rho w, rho theta join the slow tendencies (bz_compute_slow_tendencies), and bz_set_forcings accepts coriolis_f alone. */
 typedef struct bz_column_relaxation {
     const double *rate_u, *target_u;
     const double *rate_v, *target_v;

@@ -144,11 +144,13 @@ def add_relaxation_tendencies(m):
     density keys "ru", "rv", "rw", "rtheta", "rq" relax the prognostic density (G += F); the specific keys "u", "v", "w" are specific
     forcings, G += rho_r F with the reference density at the field's location (src/Forcings/specific_forcing.jl:61-74).  Columns at the
     field's vertical location (rw / w: Nz + 1 faces; the wall faces carry no tendency)."""
-    g, r = m.grid, m.ref
-    rho_c = r.density[g.Hz:g.Hz + g.Nz]
-    rho_f = 0.5 * (r.density[g.Hz - 1:g.Hz + g.Nz] + r.density[g.Hz:g.Hz + g.Nz + 1])
+    g = m.grid
     for key, (rate, target) in m.relaxation.items():
         specific = key in ("u", "v", "w")
+        if specific:
+            r = m.ref
+            rho_c = r.density[g.Hz:g.Hz + g.Nz]
+            rho_f = 0.5 * (r.density[g.Hz - 1:g.Hz + g.Nz] + r.density[g.Hz:g.Hz + g.Nz + 1])
         name = {"u": "ru", "v": "rv", "w": "rw"}.get(key, key)
         zface = name == "rw"
         field = g.interior(getattr(m, key), zface)

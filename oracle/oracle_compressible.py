@@ -173,7 +173,10 @@ class CompressibleOracleModel:
     def __init__(self, grid, constants=None, time_discretization=None, surface_pressure=101325.0,
                  standard_pressure=1e5, reference_potential_temperature=288.0, reference_state=True,
                  newton_abstol=1e-4, newton_maxiter=8, microphysics=None, reference_vapor_mass_fraction=None,
-                 advection="WENO5"):
+                 advection="WENO5", coriolis_f=0.0, relaxation=None):
+        # coriolis_f: FPlane(f); relaxation: {"ru" | "rv" | "rw" | "rtheta": (rate column, target column)} — the sponge layers of
+        # examples/tropical_cyclone_with_rainband.jl:434-514 (oracle/forcings.py: add_relaxation_tendencies); both are slow terms
+        self.coriolis_f, self.relaxation = float(coriolis_f), relaxation
         # microphysics "Kessler": DCMIP2016KesslerMicrophysics — rho q^cl, rho q^r prognostic (dcmip2016_kessler.jl:216)
         # "SaturationAdjustment": SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) on the density-based state
         # (saturation_adjustment.jl:236-301); self.q / self.rq hold the total (equilibrium) moisture, self.qv / self.ql the partition
@@ -422,6 +425,14 @@ class CompressibleOracleModel:
         L.og_density_tendency(cg, _p(G["rho_d"]), _p(self.ru), _p(self.rv), _p(self.rw))
         L.og_scalar_tendency_3d(cg, _p(G["rtheta"]), _p(self.rho_d), _p(self.u), _p(self.v), _p(self.w), _p(self.theta))
         L.og_set_weno_order(C.c_int(5))
+        if self.coriolis_f != 0.0:      # - x_f_cross_U, - y_f_cross_U of an FPlane (dynamics_kernel_functions.jl:79,99)
+            from .forcings import _xy_to_cf, _xy_to_fc
+            g = self.grid
+            g.interior(G["ru"])[...] -= -self.coriolis_f * _xy_to_fc(self, self.rv)
+            g.interior(G["rv"])[...] -= self.coriolis_f * _xy_to_cf(self, self.ru)
+        if self.relaxation:
+            from .forcings import add_relaxation_tendencies
+            add_relaxation_tendencies(self)
 
     def assemble_slow_vertical_momentum(self):
         pr = _p(self.ref.pressure) if self.ref is not None else None

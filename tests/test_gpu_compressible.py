@@ -501,3 +501,80 @@ def test_float32_substep_storage_is_rejected_where_it_is_not_built(bz):
     with pytest.raises(NotImplementedError):
         bz.CompressibleAtmosphereModel(bz.RectilinearGrid((16, 16, 8), x=(0, 4e3), y=(0, 4e3), z=(0, 4e3), float_type=np.float32), dyn(),
                                        advection=bz.WENO(), substep_floattype=np.float64)
+
+
+def _sin2_mask(z, zlo=5e3, zhi=8e3):
+    """the sponge mask of examples/tropical_cyclone_with_rainband.jl:460-463: sin^2(pi xi / 2) above z-"""
+    xi = (z - zlo) / (zhi - zlo)
+    return np.sin(np.pi * xi / 2) ** 2 * (xi > 0)
+
+
+def _cyclone_pair(oracle, oc, bz, size=(24, 16, 20)):
+    """CompressibleDynamics(SplitExplicitTimeDiscretization()) + FPlane + sponges on rho u, rho v, rho w (to zero) and rho theta (to the
+    reference profile): the forcing list of examples/tropical_cyclone_with_rainband.jl:434-514 without the prescribed heating"""
+    f, rate = 5e-4, 1.0 / 333.0
+    og = oracle.Grid(size, x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"])
+    om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), reference_potential_temperature=300.0, coriolis_f=f)
+    Hz, Nz = og.Hz, og.Nz
+    rth_bg = om.ref.density[Hz:Hz + Nz] * 300.0
+    om.relaxation = {"ru": (rate * _sin2_mask(og.zc), np.zeros(Nz)), "rv": (rate * _sin2_mask(og.zc), np.zeros(Nz)),
+                     "rw": (rate * _sin2_mask(og.zf), np.zeros(Nz + 1)), "rtheta": (rate * _sin2_mask(og.zc), rth_bg)}
+    grid = bz.RectilinearGrid(size, x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"])
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), reference_potential_temperature=300.0, reference_state="auto")
+    sponge = lambda target=0.0: bz.Relaxation(rate=rate, mask=_sin2_mask, target=target)
+    hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), coriolis=bz.FPlane(f=f),
+                                        forcing={"ρu": sponge(), "ρv": sponge(), "ρw": sponge(), "ρθ": sponge(rth_bg)})
+    return om, hm
+
+
+def test_compressible_coriolis_and_sponge_slow_tendencies(oracle, oc, bz):
+    om, hm = _cyclone_pair(oracle, oc, bz)
+    seeded_state(om, 7)
+    om.compute_slow_tendencies()
+    plain = oc.CompressibleOracleModel(om.grid, time_discretization=oc.SplitExplicit(substeps=6), reference_potential_temperature=300.0)
+    seeded_state(plain, 7)
+    plain.compute_slow_tendencies()
+    push(om, hm)
+    for k in hm.G:
+        if k != "ρq":
+            hm.G[k].parent.zero_()
+    bz.compressible.compute_slow_tendencies_(hm)
+    g = om.grid
+    for n, k in PROG.items():
+        if n == "rq":
+            continue
+        a, b, c = hm.G[k].interior_cpu(), g.interior(om.G[n], n == "rw"), g.interior(plain.G[n], n == "rw")
+        if n == "rw":
+            a, b, c = a[1:-1], b[1:-1], c[1:-1]
+        assert rel(a, b) <= 1e-12, (n, rel(a, b))
+        if n != "rho_d":
+            assert np.abs(b - c).max() > 0, n                                        # the terms are there ...
+            assert np.abs((a - c) - (b - c)).max() <= 1e-9 * np.abs(b - c).max(), n      # ... and they are what the device added
+
+
+def test_compressible_cyclone_forcing_list_steps_match_oracle(oracle, oc, bz):
+    om, hm = _cyclone_pair(oracle, oc, bz, size=(24, 16, 24))
+    g = om.grid
+
+    def theta(x, y, z):
+        r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+        return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+    rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    vortex = lambda x, y, z: 5.0 * np.sin(2 * np.pi * y / 8e3) + 0 * x + 0 * z
+    om.set(rho=rho, theta=theta, u=vortex, v=lambda x, y, z: -5.0 * np.sin(2 * np.pi * x / 8e3) + 0 * y + 0 * z, w=0.0)
+    hm.set(ρ=rho, θ=theta, u=vortex, v=lambda x, y, z: -5.0 * np.sin(2 * np.pi * x / 8e3) + 0 * y + 0 * z, w=0.0)
+    for _ in range(3):
+        om.time_step(2.0)
+        hm.time_step(2.0)
+    worst = cmp_interior(om, hm, ("rho_d", "rtheta", "ru", "rv", "rw", "u", "v", "w", "theta", "T", "p"), 5e-9)
+    print("cyclone forcing list, 3 steps:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_compressible_forcings_outside_the_built_list_raise(bz):
+    grid = bz.RectilinearGrid((16, 16, 8), x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"])
+    dyn = lambda: bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), reference_potential_temperature=300.0, reference_state="auto")
+    with pytest.raises(NotImplementedError):
+        bz.CompressibleAtmosphereModel(grid, dyn(), advection=bz.WENO(order=5), forcing={"w": bz.Relaxation(rate=0.1)})
+    with pytest.raises(NotImplementedError):
+        bz.CompressibleAtmosphereModel(grid, dyn(), advection=bz.WENO(order=5), forcing={"θ": bz.Forcing(lambda z: 1e-3)})

@@ -410,3 +410,27 @@ def test_substep_distributions(oracle, oc):
             else:
                 assert dtau == dt / Nu and n == round(beta * Nu)
     assert oc.stage_substep_count_and_size(8, 1.0, dt, g, c, 0.5, "constant")[0] == 12
+
+
+def test_coriolis_and_sponges_are_slow_terms_with_closed_forms(oracle, oc):
+    """FPlane + density-keyed Relaxation sponges in the compressible slow tendencies (dynamics_kernel_functions.jl:79,99;
+    examples/tropical_cyclone_with_rainband.jl:434-514): on a horizontally uniform wind the advective parts vanish, so
+    G_rho_u = + f rho v - r(z) rho u,  G_rho_v = - f rho u - r(z) rho v,  G_rho_theta = r(z) (target - rho theta) exactly."""
+    f, rate = 5e-4, 0.01
+    m = rest_model(oracle, oc, size=(8, 8, 16))
+    set_rest(m)
+    g = m.grid
+    Hz, Nz = g.Hz, g.Nz
+    rho = m.ref.density[Hz:Hz + Nz][:, None, None]
+    m.set(rho=rho, theta=300.0, u=3.0, v=-2.0, w=0.0)
+    r = rate * np.exp(-(g.zc - g.zf[-1]) ** 2 / (2 * 2000.0 ** 2))
+    m.coriolis_f = f
+    m.relaxation = {"ru": (r, np.zeros(Nz)), "rv": (r, np.zeros(Nz)), "rtheta": (r, (rho * 301.0).ravel())}
+    m.compute_slow_tendencies()
+    ru, rv, rth = g.interior(m.ru), g.interior(m.rv), g.interior(m.rtheta)
+    rc = r[:, None, None]
+    scale = np.abs(f * rv).max()
+    assert np.abs(g.interior(m.G["ru"]) - (f * rv - rc * ru)).max() < 1e-12 * scale
+    assert np.abs(g.interior(m.G["rv"]) - (-f * ru - rc * rv)).max() < 1e-12 * scale
+    want = rc * (rho * 301.0 - rth)
+    assert np.abs(g.interior(m.G["rtheta"]) - want).max() < 1e-9 * np.abs(want).max()

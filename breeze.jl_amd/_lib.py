@@ -239,6 +239,7 @@ SYMBOLS = {
     "bz_set_bulk_surface_fluxes": (C.c_int, [_ctx, C.POINTER(bz_bulk_surface_fluxes)]),
     "bz_set_forcings": (C.c_int, [_ctx, C.POINTER(bz_column_forcings)]),
     "bz_set_relaxation": (C.c_int, [_ctx, C.POINTER(bz_column_relaxation)]),
+    "bz_set_field_forcing": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "bz_compute_forcings": (C.c_int, [_ctx, _sp]),
     "bz_compute_flux_bc_tendencies": (C.c_int, [_ctx, _sp, _pp]),
     "bz_cell_advection_timescale": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),

@@ -301,12 +301,12 @@ class CompressibleAtmosphereModel:
         from .forcings import FPlane, split_relaxation
         if coriolis is not None and not isinstance(coriolis, FPlane):
             raise NotImplementedError("coriolis: FPlane is implemented")
-        forcing_rest, self._relaxation = split_relaxation(forcing)
+        forcing_rest, self._relaxation, self._field_forcing = split_relaxation(forcing)
         if forcing_rest:
-            raise NotImplementedError("CompressibleDynamics: Relaxation sponges keyed ρu, ρv, ρw, ρθ are the forcings implemented")
+            raise NotImplementedError("CompressibleDynamics: Relaxation sponges keyed ρu, ρv, ρw, ρθ and a 3-D Forcing on θ / ρθ are the forcings implemented")
         if set(self._relaxation) - {"ρu", "ρv", "ρw", "ρθ"}:
             raise NotImplementedError("CompressibleDynamics: Relaxation sponges keyed ρu, ρv, ρw, ρθ")
-        if (coriolis is not None or self._relaxation) and type(self) is not CompressibleAtmosphereModel:
+        if (coriolis is not None or self._relaxation or self._field_forcing) and type(self) is not CompressibleAtmosphereModel:
             raise NotImplementedError("Coriolis and sponges of the compressible model: single-GPU contexts")
         self.coriolis, self.forcing = coriolis, forcing
         from .microphysics import DCMIP2016KesslerMicrophysics, SaturationAdjustment, TetensFormula
@@ -439,6 +439,10 @@ class CompressibleAtmosphereModel:
             from .forcings import materialize_relaxation
             Rx, self._relaxation_keepalive = materialize_relaxation(grid, self._relaxation, "LiquidIcePotentialTemperature", T)
             self._check(lib.bz_set_relaxation(self._ctx, C.byref(Rx)), "bz_set_relaxation")
+        from .forcings import materialize_field_forcing
+        self.thermodynamic_forcing_field, _spec = materialize_field_forcing(grid, self._field_forcing, "LiquidIcePotentialTemperature", self.device)
+        if self.thermodynamic_forcing_field is not None:
+            self._check(lib.bz_set_field_forcing(self._ctx, C.c_void_p(self.thermodynamic_forcing_field.ptr()), _spec), "bz_set_field_forcing")
         # seed_pressure! (compressible_dynamics.jl:254-258)
         if ref is not None:
             Hz, Nz = grid.Hz, grid.Nz

@@ -950,7 +950,7 @@ extern "C" int bz_compute_slow_tendencies(bz_ctx *ctx, const bz_compressible_sta
     // - f x (rho U) of an FPlane and the density-keyed sponges are slow terms too (dynamics_kernel_functions.jl:79,99 through the same
     // x / y_momentum_tendency; examples/tropical_cyclone_with_rainband.jl:434-514)
     if (ctx->has_forcings && (rc = bzi_apply_forcings(ctx, &a, G->rho_u, G->rho_v, G->rho_theta, G->rho_q, 1.0))) return rc;
-    return bzi_apply_relaxation(ctx, &a, &Ga);
+    return bzi_apply_relaxation(ctx, &a, &Ga, s->rho_d);
 }
 
 // compute_acoustic_substeps / stage_substep_count_and_size(::ProportionalSubsteps) (acoustic_substepping.jl:451-495)

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void k_apply_relaxation(DevGrid g, RelaxCols R
                                                           const double *__restrict__ rw, const double *__restrict__ rth, const double *__restrict__ rq,
                                                           const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ w,
                                                           double *__restrict__ Gu, double *__restrict__ Gv, double *__restrict__ Gw,
-                                                          double *__restrict__ Gth, double *__restrict__ Gq)
+                                                          double *__restrict__ Gth, double *__restrict__ Gq, const double *__restrict__ Fth,
+                                                          const double *__restrict__ rho3d, int fth_specific)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
     if (i >= g.Nx) return;
@@ -235,14 +236,27 @@ __global__ __launch_bounds__(256) void k_apply_relaxation(DevGrid g, RelaxCols R
     }
     if (R.rate[3]) Gth[n] += R.rate[3][k] * (R.target[3][k] - rth[n]);
     if (R.rate[4]) Gq[n] += R.rate[4][k] * (R.target[4][k] - rq[n]);
+    // Forcing(field) on the thermodynamic variable (bz_set_field_forcing): rho F for the specific key, with the coupling density
+    if (Fth) Gth[n] += fth_specific ? (rho3d ? rho3d[n] : g.rho[k]) * Fth[n] : Fth[n];
 }
 
 static void free_relaxation(bz_ctx *ctx)
 {
     if (ctx->d_relax) hipFree(ctx->d_relax);
     ctx->d_relax = nullptr;
-    ctx->has_relaxation = false;
     ctx->relax_mask = ctx->relax_specific = 0;
+    ctx->has_relaxation = ctx->field_forcing != nullptr;
+}
+
+extern "C" int bz_set_field_forcing(bz_ctx *ctx, const double *F, int specific)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    ++ctx->config_epoch;
+    if (F && ctx->slab_mode) { ctx->last_error = "bz_set_field_forcing: single-device contexts"; return BZ_ERR_UNSUPPORTED; }
+    ctx->field_forcing = F;
+    ctx->field_forcing_specific = specific ? 1 : 0;
+    ctx->has_relaxation = ctx->relax_mask != 0 || F != nullptr;      // one pass adds the sponges and this term (bzi_apply_relaxation)
+    return BZ_OK;
 }
 
 extern "C" int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *r)
@@ -270,11 +284,11 @@ extern "C" int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *r)
     }
     BZ_HIP(hipStreamSynchronize(ctx->stream));      // the host columns may go away after the call
     ctx->relax_specific = r->specific_mask;
-    ctx->has_relaxation = ctx->relax_mask != 0;
+    ctx->has_relaxation = ctx->relax_mask != 0 || ctx->field_forcing != nullptr;
     return BZ_OK;
 }
 
-int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
+int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const double *rho3d)
 {
     if (!ctx->has_relaxation) return BZ_OK;
     const DevGrid &g = ctx->dg;
@@ -284,11 +298,12 @@ int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
     for (int c = 0; c < 5; ++c) {
         const bool on = ctx->relax_mask & (1 << c);
         R.rate[c] = on ? ctx->d_relax + (size_t)(2 * c) * L : nullptr;
-        R.target[c] = ctx->d_relax + (size_t)(2 * c + 1) * L;
+        R.target[c] = on ? ctx->d_relax + (size_t)(2 * c + 1) * L : nullptr;
     }
     R.specific = ctx->relax_specific;
     hipLaunchKernelGGL(k_apply_relaxation, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, R, s->rho_u, s->rho_v, s->rho_w,
-                       s->rho_theta, s->rho_q, s->u, s->v, s->w, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q);
+                       s->rho_theta, s->rho_q, s->u, s->v, s->w, G->rho_u, G->rho_v, G->rho_w, G->rho_theta, G->rho_q, ctx->field_forcing, rho3d,
+                       ctx->field_forcing_specific);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

@@ -359,6 +359,8 @@ struct bz_ctx {
     bool has_relaxation = false;      // bz_set_relaxation: [rate target](u v w theta q), Nz + 1 entries each
     double *d_relax = nullptr;
     int relax_mask = 0, relax_specific = 0;
+    const double *field_forcing = nullptr;      // bz_set_field_forcing: 3-D forcing of the thermodynamic variable (caller-owned)
+    int field_forcing_specific = 0;
     bool has_forcings = false;
     double *d_forcing = nullptr;      // static profiles, subsidence velocity, level averages, subsidence profiles, partial sums
     int forcing_static_mask = 0, forcing_subsidence_mask = 0;
@@ -479,7 +481,7 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho_halo /* Nz+2Hz */);
 int bzi_bounded_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_compute_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_momentum_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
-int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
+int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const double *rho3d = nullptr);      // rho3d: coupling density of a compressible context
 int bzi_lean_setup(bz_ctx *ctx);
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt);
 int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,

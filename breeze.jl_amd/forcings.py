@@ -142,20 +142,55 @@ _RELAX_SLOTS = {"ρu": ("u", 0), "ρv": ("v", 0), "ρw": ("w", 0), "ρθ": ("the
                 "ρqv": ("moisture", 0), "ρqt": ("moisture", 0), "ρq": ("moisture", 0), "u": ("u", 1), "v": ("v", 2), "w": ("w", 4)}
 
 
+def _is_field_forcing(item):
+    """Forcing(f(x, y, z)) or Forcing(3-D array): a forcing that varies in the horizontal (the column stack takes functions of z)."""
+    if not isinstance(item, Forcing):
+        return False
+    f = item.profile
+    if callable(f):
+        import inspect
+        try:
+            return len(inspect.signature(f).parameters) == 3
+        except (TypeError, ValueError):
+            return False
+    return np.ndim(f) == 3
+
+
 def split_relaxation(forcing):
-    """-> (forcing without its Relaxation entries, {key: Relaxation}): sponges go to bz_set_relaxation, the rest to the forcing stack."""
-    rest, relax = {}, {}
+    """-> (forcing without the entries below, {key: Relaxation}, {key: Forcing}): sponges go to bz_set_relaxation, 3-D forcings of the
+    thermodynamic variable to bz_set_field_forcing, the rest to the column-forcing stack."""
+    rest, relax, field = {}, {}, {}
     for name, entry in (forcing or {}).items():
         items = entry if isinstance(entry, (tuple, list)) else (entry,)
-        keep = tuple(it for it in items if not isinstance(it, Relaxation))
+        keep = tuple(it for it in items if not isinstance(it, Relaxation) and not _is_field_forcing(it))
         mine = [it for it in items if isinstance(it, Relaxation)]
-        if len(mine) > 1:
-            raise NotImplementedError(f"one Relaxation per field ({name!r})")
+        fields = [it for it in items if _is_field_forcing(it)]
+        if len(mine) > 1 or len(fields) > 1:
+            raise NotImplementedError(f"one Relaxation and one 3-D Forcing per field ({name!r})")
         if mine:
             relax[_key(name)] = mine[0]
+        if fields:
+            if _key(name) not in ("θ", "ρθ", "e", "ρe"):
+                raise NotImplementedError(f"3-D Forcing on {name!r}: the thermodynamic variable (θ / e, or ρθ / ρe) is implemented")
+            if field:
+                raise NotImplementedError("one 3-D Forcing of the thermodynamic variable")
+            field[_key(name)] = fields[0]
         if keep:
             rest[name] = keep if len(keep) > 1 else keep[0]
-    return (rest or None), relax
+    return (rest or None), relax, field
+
+
+def materialize_field_forcing(grid, field, formulation, device):
+    """{key: Forcing} -> (device Field holding F at the cell centres, specific flag) or (None, 0)."""
+    if not field:
+        return None, 0
+    from .model import _LOC, Field
+    (k, item), = field.items()
+    if (k in ("e", "ρe")) != (formulation == "StaticEnergy"):
+        raise ValueError(f"3-D Forcing on {k!r}: the thermodynamic variable of this formulation is {'e' if formulation == 'StaticEnergy' else 'θ'}")
+    F = Field(grid, _LOC["ccc"], device)
+    F.set_interior(item.profile)
+    return F, 0 if k.startswith("ρ") else 1
 
 
 def materialize_relaxation(grid, relax, formulation, T=None):

@@ -389,10 +389,16 @@ class AtmosphereModel:
             self._check(lib.bz_set_closure(self._ctx, C.byref(cl), C.c_void_p(self.closure_fields["νₑ"].ptr())), "bz_set_closure")
         # coriolis / forcing / boundary_conditions of the BOMEX configuration -> one column-forcing stack (forcings.py)
         from .forcings import materialize_forcings, materialize_relaxation, split_relaxation
-        forcing, _relax = split_relaxation(forcing)      # Relaxation sponges: their own attachment (bz_set_relaxation)
+        forcing, _relax, _field = split_relaxation(forcing)      # Relaxation sponges and 3-D forcings: their own attachments
         Rx, self._relaxation_keepalive = materialize_relaxation(grid, _relax, formulation, T)
         if Rx is not None:
             self._check(lib.bz_set_relaxation(self._ctx, C.byref(Rx)), "bz_set_relaxation")
+        from .forcings import materialize_field_forcing
+        # Forcing(f(x, y, z)) on θ / e (or ρθ / ρe): a centre field the library reads at every tendency evaluation; refresh it with
+        # model.thermodynamic_forcing_field.set_interior(...) when the forcing depends on time
+        self.thermodynamic_forcing_field, _spec = materialize_field_forcing(grid, _field, formulation, self.device)
+        if self.thermodynamic_forcing_field is not None:
+            self._check(lib.bz_set_field_forcing(self._ctx, C.c_void_p(self.thermodynamic_forcing_field.ptr()), _spec), "bz_set_field_forcing")
         F, self._forcing_keepalive = materialize_forcings(grid, coriolis, forcing, boundary_conditions, T)
         if F is not None:
             if self._kessler or formulation != "LiquidIcePotentialTemperature":

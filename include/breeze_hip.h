@@ -537,6 +537,13 @@ typedef struct bz_column_relaxation {
     int32_t specific_mask;
 } bz_column_relaxation;
 int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *relaxation);      /* NULL detaches */
+/* Forcing(f(x, y, z, t)) / Forcing(field) on the thermodynamic variable (examples/tropical_cyclone_with_rainband.jl:419-432,511-514: the
+ * prescribed rainband heating keyed `theta`): a DEVICE array at cell centres in the parent layout of the fields, read at every tendency
+ * evaluation — the caller owns it and refreshes its contents when the forcing depends on time.  specific = 1 (keyed theta / e): a specific
+ * forcing, G_rho_theta += rho F with the coupling density (rho_r(z) of AnelasticDynamics, the prognostic dry density of CompressibleDynamics;
+ * src/Forcings/specific_forcing.jl:61-74, compressible_dynamics.jl:385); specific = 0 (keyed rho theta / rho e): G += F.  NULL detaches.
+ * Single-device contexts. */
+int bz_set_field_forcing(bz_ctx *ctx, const double *thermodynamic_forcing, int specific);
 /* compute_forcings!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:81-86) */
 int bz_compute_forcings(bz_ctx *ctx, const bz_state *s);
 /* compute_flux_bc_tendencies!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:418-434) */

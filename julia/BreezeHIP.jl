@@ -196,6 +196,14 @@ function attach_relaxation!(ctx, columns::NamedTuple, specific = ())
                                "bz_set_relaxation", ctx)
 end
 
+"""
+`Forcing(f(x, y, z, t))` / `Forcing(field)` on θ / e (specific = true) or ρθ / ρe: `F` is a CenterField the extension fills from the forcing
+(and refreshes from a callback when it depends on time); the library reads it at every tendency evaluation.
+"""
+attach_field_forcing!(ctx, F, specific::Bool) =
+    check(ccall((:bz_set_field_forcing, libbreeze_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), ctx, pointer(parent(F)), specific),
+          "bz_set_field_forcing", ctx)
+
 "tracers = (:a, :b): density = model.tracers[n]; `specific` is an extra centre field owned by the extension."
 function attach_tracers!(ctx, model, specific_fields)
     ts = model.timestepper

@@ -145,7 +145,7 @@ def add_relaxation_tendencies(m):
     forcings, G += rho_r F with the reference density at the field's location (src/Forcings/specific_forcing.jl:61-74).  Columns at the
     field's vertical location (rw / w: Nz + 1 faces; the wall faces carry no tendency)."""
     g = m.grid
-    for key, (rate, target) in m.relaxation.items():
+    for key, (rate, target) in (getattr(m, "relaxation", None) or {}).items():
         specific = key in ("u", "v", "w")
         if specific:
             r = m.ref
@@ -167,6 +167,18 @@ def add_relaxation_tendencies(m):
             G[:, 1:, :] += F[:, 1:, :]
         else:
             G[...] += F
+
+
+def add_field_forcing(m):
+    """Forcing(f(x, y, z)) on the thermodynamic variable (examples/tropical_cyclone_with_rainband.jl:419-432,511-514): m.field_forcing =
+    (F on the interior, specific).  Keyed theta it is a specific forcing, G_rho_theta += rho F with the coupling density — rho_r(z) of the
+    anelastic model, the dry density of the compressible one (specific_forcing.jl:61-74, compressible_dynamics.jl:385); keyed rho theta, G += F."""
+    g = m.grid
+    F, specific = m.field_forcing
+    if specific:
+        rho = g.interior(m.rho_d) if hasattr(m, "rho_d") else m.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+        F = rho * F
+    g.interior(m.G["rtheta"])[...] += F
 
 
 def add_flux_bc_tendencies(m):

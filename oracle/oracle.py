@@ -570,6 +570,9 @@ class OracleModel:
         if getattr(self, "relaxation", None):
             from .forcings import add_relaxation_tendencies
             add_relaxation_tendencies(self)
+        if getattr(self, "field_forcing", None) is not None:
+            from .forcings import add_field_forcing
+            add_field_forcing(self)
 
     def liquid_ice_potential_temperature(self):
         """Diagnostics.LiquidIcePotentialTemperature (dry: theta = T / Pi) on the interior."""

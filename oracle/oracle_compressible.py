@@ -433,6 +433,9 @@ class CompressibleOracleModel:
         if self.relaxation:
             from .forcings import add_relaxation_tendencies
             add_relaxation_tendencies(self)
+        if getattr(self, "field_forcing", None) is not None:
+            from .forcings import add_field_forcing
+            add_field_forcing(self)
 
     def assemble_slow_vertical_momentum(self):
         pr = _p(self.ref.pressure) if self.ref is not None else None

@@ -509,9 +509,13 @@ def _sin2_mask(z, zlo=5e3, zhi=8e3):
     return np.sin(np.pi * xi / 2) ** 2 * (xi > 0)
 
 
+def _rainband_heating(x, y, z):
+    return 1e-3 * np.exp(-((x - 1e3) ** 2 + (y + 500.0) ** 2) / 1500.0 ** 2) * np.sin(np.pi * np.clip((z - 1e3) / 4e3, 0.0, 1.0)) ** 2
+
+
 def _cyclone_pair(oracle, oc, bz, size=(24, 16, 20)):
     """CompressibleDynamics(SplitExplicitTimeDiscretization()) + FPlane + sponges on rho u, rho v, rho w (to zero) and rho theta (to the
-    reference profile): the forcing list of examples/tropical_cyclone_with_rainband.jl:434-514 without the prescribed heating"""
+    reference profile) + the prescribed heating keyed theta: the forcing list of examples/tropical_cyclone_with_rainband.jl:419-514"""
     f, rate = 5e-4, 1.0 / 333.0
     og = oracle.Grid(size, x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"])
     om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), reference_potential_temperature=300.0, coriolis_f=f)
@@ -519,11 +523,13 @@ def _cyclone_pair(oracle, oc, bz, size=(24, 16, 20)):
     rth_bg = om.ref.density[Hz:Hz + Nz] * 300.0
     om.relaxation = {"ru": (rate * _sin2_mask(og.zc), np.zeros(Nz)), "rv": (rate * _sin2_mask(og.zc), np.zeros(Nz)),
                      "rw": (rate * _sin2_mask(og.zf), np.zeros(Nz + 1)), "rtheta": (rate * _sin2_mask(og.zc), rth_bg)}
+    x, y, z = og.nodes("ccc")
+    om.field_forcing = (np.broadcast_to(_rainband_heating(x, y, z), (og.Nz, og.Ny, og.Nx)).copy(), True)
     grid = bz.RectilinearGrid(size, x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"])
     dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), reference_potential_temperature=300.0, reference_state="auto")
     sponge = lambda target=0.0: bz.Relaxation(rate=rate, mask=_sin2_mask, target=target)
     hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), coriolis=bz.FPlane(f=f),
-                                        forcing={"ρu": sponge(), "ρv": sponge(), "ρw": sponge(), "ρθ": sponge(rth_bg)})
+                                        forcing={"ρu": sponge(), "ρv": sponge(), "ρw": sponge(), "ρθ": sponge(rth_bg), "θ": bz.Forcing(_rainband_heating)})
     return om, hm
 
 
@@ -578,3 +584,5 @@ def test_compressible_forcings_outside_the_built_list_raise(bz):
         bz.CompressibleAtmosphereModel(grid, dyn(), advection=bz.WENO(order=5), forcing={"w": bz.Relaxation(rate=0.1)})
     with pytest.raises(NotImplementedError):
         bz.CompressibleAtmosphereModel(grid, dyn(), advection=bz.WENO(order=5), forcing={"θ": bz.Forcing(lambda z: 1e-3)})
+    with pytest.raises(NotImplementedError):
+        bz.CompressibleAtmosphereModel(grid, dyn(), advection=bz.WENO(order=5), forcing={"u": bz.Forcing(lambda x, y, z: 1e-3 + 0 * x)})

@@ -72,8 +72,8 @@ def test_host_builds_the_columns(bz):
     from breeze_jl_amd.forcings import materialize_relaxation, split_relaxation
     grid = bz.RectilinearGrid(SIZE, **EXT)
     sponge = bz.Relaxation(rate=0.01, mask=bz.GaussianMask(center=1000.0, width=200.0))
-    rest, relax = split_relaxation({"ρw": sponge, "u": (bz.Forcing(lambda z: 1e-4), )})
-    assert list(rest) == ["u"] and list(relax) == ["ρw"]
+    rest, relax, field = split_relaxation({"ρw": sponge, "u": (bz.Forcing(lambda z: 1e-4), ), "θ": bz.Forcing(lambda x, y, z: 1e-3 + 0 * x)})
+    assert list(rest) == ["u"] and list(relax) == ["ρw"] and list(field) == ["θ"]
     S, keep = materialize_relaxation(grid, relax, "LiquidIcePotentialTemperature")
     zf = np.asarray(grid.zᶠ)
     assert np.allclose(keep[0], 0.01 * _mask(zf), rtol=1e-15) and np.all(keep[1] == 0) and S.specific_mask == 0 and not S.rate_u
@@ -187,3 +187,28 @@ def test_sponge_inside_y_walls(oracle, bz):
     hm.set(θ=_bubble, v=v0)
     _steps(g, om, hm, 3, 2.0, 1e-9)
     assert float(hm.momentum["ρv"].interior[:, 0, :].abs().max()) == 0.0
+
+
+def _heating(x, y, z):
+    """a rainband-like heating patch (K/s), cf. examples/tropical_cyclone_with_rainband.jl:419-430"""
+    return 1e-3 * np.exp(-((x - 900.0) ** 2 + (y - 500.0) ** 2) / 300.0 ** 2) * np.sin(np.pi * np.clip(z / 800.0, 0.0, 1.0)) ** 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["θ", "ρθ"])
+def test_three_dimensional_forcing_of_the_thermodynamic_variable(oracle, bz, key):
+    g, om, hm = _pair(oracle, bz, ("rw",), hkw=dict(forcing={key: bz.Forcing(_heating)}))
+    x, y, z = g.nodes("ccc")
+    om.field_forcing = (np.broadcast_to(_heating(x, y, z), (g.Nz, g.Ny, g.Nx)).copy(), key == "θ")
+    randomize(om, seed=4)
+    om.update_state()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=True)
+    hm.synchronize()
+    for n, k in PROG.items():
+        assert relerr(hm.G[k].interior_cpu(), g.interior(om.G[n], n == "rw")) < 1e-12, n
+    om.set(theta=_bubble, u=3.0)
+    hm.set(θ=_bubble, u=3.0)
+    th0 = g.interior(om.rtheta).sum()
+    _steps(g, om, hm, 3, 2.0, 1e-9)
+    assert g.interior(om.rtheta).sum() > th0      # the patch heats

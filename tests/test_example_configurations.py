@@ -182,3 +182,34 @@ def test_neutral_atmospheric_boundary_layer_jl(bz):
     model.synchronize()
     assert _finite(model) and model.closure_fields["νₑ"].interior_cpu().max() > 0.0
     assert abs(model.potential_temperature_density.interior_cpu()[-2].mean() - th_top0) < 1e-3 * th_top0      # the sponge holds the inversion profile
+
+
+def test_tropical_cyclone_with_rainband_jl(bz):
+    """examples/tropical_cyclone_with_rainband.jl:153-175,419-514: (Periodic, Periodic, Bounded) at 5 km x 333 m, halo (5, 5, 5),
+    CompressibleDynamics(SplitExplicitTimeDiscretization()), FPlane, WENO(order = 5), sin^2 sponges above 20 km on rho u, rho v, rho w and
+    rho theta, the prescribed rainband heating keyed theta (parity: tests/test_gpu_compressible.py::test_compressible_cyclone_*)"""
+    N, Nz, L, Lz = 32, 25, 160e3, 25e3
+    grid = bz.RectilinearGrid((N, N, Nz), halo=(5, 5, 5), x=(-L / 2, L / 2), y=(-L / 2, L / 2), z=(0.0, Lz))
+    θb = lambda z: 300.0 + 0.004 * z
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), surface_pressure=101500.0, reference_potential_temperature=θb)
+    ref = bz.ExnerReferenceState(grid, surface_pressure=101500.0, potential_temperature=θb)      # the example's ρθᵣ comes from its reference state
+    Hz = grid.Hz
+    mask = lambda z: np.sin(np.pi * np.clip((z - 20e3) / 5e3, 0.0, None) / 2) ** 2 * (z > 20e3)
+    rate = 1.0 / 333.0
+    sponge = lambda target=0.0: bz.Relaxation(rate=rate, mask=mask, target=target)
+    heating = lambda x, y, z: (4.24 / 3600.0) * np.exp(-((np.sqrt(x ** 2 + y ** 2) - 40e3) / 10e3) ** 2) * np.sin(np.pi * np.clip((z - 4e3) / 8e3, 0.0, 1.0)) ** 2
+    model = bz.CompressibleAtmosphereModel(grid, dyn, coriolis=bz.FPlane(f=5e-5), advection=bz.WENO(order=5),
+                                           forcing={"ρu": sponge(), "ρv": sponge(), "ρw": sponge(), "θ": bz.Forcing(heating),
+                                                    "ρθ": sponge(np.asarray(ref.density)[Hz:Hz + Nz] * (300.0 + 0.004 * np.asarray(grid.zᶜ)))})
+    col = np.asarray(ref.density)[Hz:Hz + Nz][:, None, None]
+    vmax, rm = 20.0, 30e3
+    vt = lambda r: vmax * (r / rm) * np.exp(0.5 * (1 - (r / rm) ** 2))
+    r = lambda x, y: np.sqrt(x ** 2 + y ** 2) + 1e-9
+    model.set(ρ=col, θ=lambda x, y, z: 300.0 + 0.004 * z + 0 * x + 0 * y, u=lambda x, y, z: -vt(r(x, y)) * y / r(x, y) * np.exp(-z / 8e3),
+              v=lambda x, y, z: vt(r(x, y)) * x / r(x, y) * np.exp(-z / 8e3), w=0.0, qᵗ=0.0)
+    th0 = model.potential_temperature_density.interior_cpu().sum()
+    for _ in range(5):
+        model.time_step(10.0)
+    model.synchronize()
+    assert _finite(model)
+    assert model.potential_temperature_density.interior_cpu().sum() > th0      # the rainband heats

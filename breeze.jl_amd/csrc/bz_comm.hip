@@ -730,7 +730,7 @@ static int dist_time_step_operators(bz_ctx *ctx, const bz_state *s, const bz_pro
 static int dist_time_step_general(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
 {
     const DevGrid &g = ctx->dg;
-    if (!(ctx->fused_ok && ctx->fuse_rk && g.formulation == 0 && g.microphysics != 2 && !ctx->bounded_mask && ctx->weno_R == 3 && ctx->scalar_R == 3))
+    if (!(ctx->fused_ok && ctx->fuse_rk && g.formulation == 0 && g.microphysics != 2 && !ctx->bounded_mask && ctx->weno_R == 3 && ctx->scalar_R == 3 && !ctx->has_relaxation))
         return dist_time_step_operators(ctx, s, U0, G, dt);
     const int32_t nc = g.Nz + 2 * g.Hz, nf = nc + 1;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};
@@ -765,7 +765,7 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
 {
     BzComm *c = ctx->comm;
     const DevGrid &g = ctx->dg;
-    if (!(ctx->fused_ok && ctx->weno_R == 3 && ctx->scalar_R == 3 && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 && !ctx->has_forcings && !ctx->has_bulk &&
+    if (!(ctx->fused_ok && ctx->weno_R == 3 && ctx->scalar_R == 3 && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 && !ctx->has_forcings && !ctx->has_relaxation && !ctx->has_bulk &&
           !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask && (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32)))
         return dist_time_step_general(ctx, s, U0, G, dt);
     int rc;

@@ -252,7 +252,7 @@ extern "C" int bz_set_field_forcing(bz_ctx *ctx, const double *F, int specific)
 {
     if (!ctx) return BZ_ERR_INVALID;
     ++ctx->config_epoch;
-    if (F && ctx->slab_mode) { ctx->last_error = "bz_set_field_forcing: single-device contexts"; return BZ_ERR_UNSUPPORTED; }
+    if (F && ctx->slab_mode && ctx->compressible) { ctx->last_error = "bz_set_field_forcing: compressible y-slabs are not built"; return BZ_ERR_UNSUPPORTED; }
     ctx->field_forcing = F;
     ctx->field_forcing_specific = specific ? 1 : 0;
     ctx->has_relaxation = ctx->relax_mask != 0 || F != nullptr;      // one pass adds the sponges and this term (bzi_apply_relaxation)
@@ -265,8 +265,8 @@ extern "C" int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *r)
     ++ctx->config_epoch;
     free_relaxation(ctx);
     if (!r) return BZ_OK;
-    if (ctx->slab_mode || (ctx->compressible && (r->specific_mask || r->rate_moisture))) {
-        ctx->last_error = "bz_set_relaxation: single-device contexts; CompressibleDynamics: the density-keyed sponges of rho u, rho v, rho w, rho theta";
+    if (ctx->compressible && (ctx->slab_mode || r->specific_mask || r->rate_moisture)) {
+        ctx->last_error = "bz_set_relaxation: CompressibleDynamics takes the density-keyed sponges of rho u, rho v, rho w, rho theta on single-device contexts";
         return BZ_ERR_UNSUPPORTED;
     }
     if (r->specific_mask & ~7) { ctx->last_error = "bz_set_relaxation: specific_mask names u (1), v (2), w (4)"; return BZ_ERR_INVALID; }

@@ -419,8 +419,8 @@ extern "C" int bz_set_scalar_advection_order(bz_ctx *ctx, int order)
     if (order != 5 && order != 7 && order != 9) { ctx->last_error = "bz_set_scalar_advection_order: WENO order 5, 7 or 9"; return BZ_ERR_UNSUPPORTED; }
     const int R = (order + 1) / 2;
     if (g.Hx < R || (!g.flat_y && g.Hy < R) || g.Hz < R) { ctx->last_error = "bz_set_scalar_advection_order: halos narrower than the scheme"; return BZ_ERR_UNSUPPORTED; }
-    if (R != ctx->weno_R && (ctx->compressible || ctx->slab_mode)) {
-        ctx->last_error = "bz_set_scalar_advection_order: a scalar order that differs from the momentum order is implemented for single-GPU anelastic contexts";
+    if (R != ctx->weno_R && ctx->compressible) {
+        ctx->last_error = "bz_set_scalar_advection_order: a scalar order that differs from the momentum order is implemented for anelastic contexts";
         return BZ_ERR_UNSUPPORTED;
     }
     ctx->scalar_R = R;

@@ -158,7 +158,8 @@ int bz_compute_scalar_tendency(bz_ctx *ctx, const double *u, const double *v, co
  * examples/tropical_cyclone_world.jl:167-169 and examples/prescribed_sea_surface_temperature.jl:72-73: momentum WENO(order = 9), every
  * scalar WENO(order = 5)): bz_create's weno_order is the momentum scheme, this sets the order (5, 7 or 9) of every scalar — rho theta /
  * rho e, moisture, microphysical species, tracers.  Halos must cover both schemes.  Orders that differ run operator by operator (one
- * kernel per field, the reference's own launch list) on single-GPU anelastic contexts; bounds-preserving advection stays a WENO(order = 5)
+ * kernel per field, the reference's own launch list) on anelastic contexts (y-slabs: the operator-by-operator distributed step);
+ * bounds-preserving advection stays a WENO(order = 5)
  * scalar scheme.  Call before the first step. */
 int bz_set_scalar_advection_order(bz_ctx *ctx, int order);
 /* TimeSteppers.update_state!(model; compute_tendencies) (:41-68); G may be NULL iff compute_tendencies == 0. */
@@ -526,7 +527,7 @@ int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *forcings);       /* N
  * name (w = ..., bit set in specific_mask: 1 u, 2 v, 4 w) it is a specific forcing (src/Forcings/specific_forcing.jl:61-74):
  * G += rho_r rate (target - phi) with the reference density at the field's location.  HOST arrays, copied by the call.  bz_compute_tendencies adds the terms
  * after the forcing stack; bz_time_step_anelastic then steps with the tendencies evaluated per operator (fused RK update, projection and
- * diagnosis).  Single-device contexts; on a CompressibleDynamics context (examples/tropical_cyclone_with_rainband.jl:434-514) the density-keyed
+ * diagnosis; y-slab contexts: the operator-by-operator distributed step).  On a single-device CompressibleDynamics context (examples/tropical_cyclone_with_rainband.jl:434-514) the density-keyed
  * sponges of rho u, rho v, rho w, rho theta join the slow tendencies (bz_compute_slow_tendencies), and bz_set_forcings accepts coriolis_f alone. */
 typedef struct bz_column_relaxation {
     const double *rate_u, *target_u;
@@ -542,7 +543,7 @@ int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *relaxation);     
  * evaluation — the caller owns it and refreshes its contents when the forcing depends on time.  specific = 1 (keyed theta / e): a specific
  * forcing, G_rho_theta += rho F with the coupling density (rho_r(z) of AnelasticDynamics, the prognostic dry density of CompressibleDynamics;
  * src/Forcings/specific_forcing.jl:61-74, compressible_dynamics.jl:385); specific = 0 (keyed rho theta / rho e): G += F.  NULL detaches.
- * Single-device contexts. */
+ * On a y-slab the array is the slab's own parent array.  Compressible y-slabs: not built. */
 int bz_set_field_forcing(bz_ctx *ctx, const double *thermodynamic_forcing, int specific);
 /* compute_forcings!(model) (src/AtmosphereModels/update_atmosphere_model_state.jl:81-86) */
 int bz_compute_forcings(bz_ctx *ctx, const bz_state *s);

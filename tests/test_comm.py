@@ -316,7 +316,7 @@ def _library_slabs(bz, G, world, make_kwargs, setter, steps, dt):
     return models
 
 
-@pytest.mark.parametrize("case", ["weno9", "static_energy", "kessler"])
+@pytest.mark.parametrize("case", ["weno9", "static_energy", "kessler", "mixed_orders_sponge_heating"])
 def test_operator_by_operator_slab_step_matches_the_oracle(bz, oracle, case):
     """Model options outside the fused tiers take the operator-by-operator distributed step (bz_comm.hip: dist_time_step_operators — the
     reference's call order with the library's exchanges in place of the local halo fills): WENO(order = 9), formulation = :StaticEnergy
@@ -339,14 +339,27 @@ def test_operator_by_operator_slab_step_matches_the_oracle(bz, oracle, case):
         setter = lambda m, sl: m.set(qᵗ=full["qt"][:, sl, :], θ=full["theta"][:, sl, :], qcl=full["qcl"][:, sl, :], qr=full["qr"][:, sl, :], u=2.0, v=-1.0)
         names, tol = ("ru", "rv", "rw", "rtheta", "rq", "T"), 1e-8
     else:
-        order = 9 if case == "weno9" else 5
+        order = 9 if case in ("weno9", "mixed_orders_sponge_heating") else 5
         size, dt = (32, 24, 16), 2.0
         halo = (5, 5, 5) if order == 9 else (3, 3, 3)
         og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2], halo=halo)
         form = "StaticEnergy" if case == "static_energy" else "LiquidIcePotentialTemperature"
-        om = oracle.OracleModel(og, potential_temperature=300.0, advection=f"WENO{order}", formulation=form)
         G = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2], halo=halo)
-        mk = lambda: dict(potential_temperature=300.0, advection=bz.WENO(order=order), formulation=form)
+        if case == "mixed_orders_sponge_heating":
+            # round-3 options on slabs: momentum WENO9 + scalars WENO5, a Gaussian sponge on rho w, a 3-D heating keyed theta — all
+            # cell-local additions to the operator-by-operator distributed step
+            ztop = EXTENT[2][1]
+            gauss = lambda z: np.exp(-(z - ztop) ** 2 / (2 * (0.2 * ztop) ** 2))
+            heat = lambda x, y, z: 2e-3 * np.exp(-((x - 0.2 * EXTENT[0][1]) ** 2 + (y - 0.1 * EXTENT[1][1]) ** 2) / (0.3 * EXTENT[0][1]) ** 2) + 0 * z
+            om = oracle.OracleModel(og, potential_temperature=300.0, advection="WENO9", scalar_advection="WENO5")
+            om.relaxation = {"rw": (0.05 * gauss(og.zf), np.zeros(og.Nz + 1))}
+            xx, yy, zz = og.nodes("ccc")
+            om.field_forcing = (np.broadcast_to(heat(xx, yy, zz), (size[2], size[1], size[0])).copy(), True)
+            mk = lambda: dict(potential_temperature=300.0, momentum_advection=bz.WENO(order=9), scalar_advection=bz.WENO(order=5),
+                              forcing={"ρw": bz.Relaxation(rate=0.05, mask=gauss), "θ": bz.Forcing(heat)})
+        else:
+            om = oracle.OracleModel(og, potential_temperature=300.0, advection=f"WENO{order}", formulation=form)
+            mk = lambda: dict(potential_temperature=300.0, advection=bz.WENO(order=order), formulation=form)
         om.set(theta=theta_ic, u=3.0, v=-2.0)
         x, y, z = og.nodes("ccc")
         th = np.broadcast_to(theta_ic(x, y, z), (size[2], size[1], size[0])).copy()

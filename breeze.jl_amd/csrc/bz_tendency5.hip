@@ -133,12 +133,24 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         ProfileScope ps(ctx, "y_momentum_tendency+rk3+velocity");
         E.u0 = U0->rho_v; E.u0_out = U0->rho_v;
         L.out = G->rho_v;
+        // 64 x 16 tiles for the y-momentum kernel in Float64 (one 1024-thread workgroup per CU): its y reconstructions read five frame rows
+        // of v per interior row, the tallest frame of the four kernels — measured 1.77 -> 1.68 ms per launch at 512^3; the other three
+        // kernels are equal to within noise (x 1.59 -> 1.58, z 2.04 -> 2.05, scalars 3.09 -> 3.08) and stay on 64 x 8, as does Float32
+        // (1.06 -> 1.05).  Whole tile rows only (the slab driver's row split counts 8-row tiles; walls keep the WY instantiations).
+        if (sizeof(double) == 8 && TY == 8 && rows == 0 && !g.bounded_y && g.Ny % 16 == 0 && g.Ny >= 64) {
+            const int kc16 = pick_chunk5(g, g.Nz, 16);
+            const dim3 grid16(tx, g.Ny / 16, (g.Nz + kc16 - 1) / kc16), block16(64, 16);
+            L.xcd = (ctx->lean_xcd && ((long long)grid16.x * grid16.y * grid16.z) % 8 == 0) ? 1 : 0;
+            if (L.mforce) hipLaunchKernelGGL((k6_v<16, true>), grid16, block16, 0, ctx->stream, g, L, kc16, E);
+            else hipLaunchKernelGGL((k6_v<16, false>), grid16, block16, 0, ctx->stream, g, L, kc16, E);
+        } else {
         const dim3 grid = shape(g.Nz, kc);
         if (g.bounded_y) {
             if (L.mforce) hipLaunchKernelGGL((k6_v<TY, true, true>), grid, block, 0, ctx->stream, g, L, kc, E);
             else hipLaunchKernelGGL((k6_v<TY, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
         } else if (L.mforce) hipLaunchKernelGGL((k6_v<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
         else hipLaunchKernelGGL((k6_v<TY, false>), grid, block, 0, ctx->stream, g, L, kc, E);
+        }
     }
     if (which & 1) {
         ProfileScope ps(ctx, "z_momentum_tendency+rk3+velocity");
@@ -163,6 +175,6 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
 int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
                         const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows, int which)
 {
-    // 64 x 8 tiles (64 x 4 measured +8 % on the momentum kernels: more frame cells per interior cell)
+    // 64 x 8 tiles (64 x 4 measured +8 % on the momentum kernels: more frame cells per interior cell; 64 x 16 pays for k6_v alone, see there)
     return lean_launch<8>(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, first, rows, which);
 }

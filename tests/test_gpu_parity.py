@@ -673,7 +673,8 @@ def _moist_q(x, y, z):
 
 
 @pytest.mark.parametrize("strict", [True, False])
-@pytest.mark.parametrize("size,moist", [((32, 20, 16), False), ((32, 20, 16), True), ((72, 24, 40), True), ((130, 16, 12), False)])
+@pytest.mark.parametrize("size,moist", [((32, 20, 16), False), ((32, 20, 16), True), ((72, 24, 40), True), ((130, 16, 12), False),
+                                        ((64, 64, 12), True)])      # Ny >= 64: the 64 x 16 tiles of the y-momentum kernel
 def test_lean_seam_matches_the_diagnostic_seam(oracle, bz, size, moist, strict, monkeypatch):
     """The lean whole-step seam (bz_tendency5_kernels.h: tendency kernels on prognostic fields only, u, v, w, theta, q^v, T derived
     on the fly with the correctly rounded column division, momentum-only projection in stages 1-2) against the generation-4 seam

@@ -62,11 +62,16 @@ void bzi_lean_teardown(bz_ctx *ctx)
 }
 
 // z-chunking of the LDS-tiled kernels (same rule as pick_chunk_lds of bz_tendency3.hip)
-static int pick_chunk5(const DevGrid &g, int nlev, int rows_per_block)
+// fine: chunks of >= 64 levels and >= 4096 blocks instead of >= 128 levels and >= 1024 blocks.  Measured at 512^3 in Float64 (chunk length
+// 512 / 256 / 128 / 64 / 32 / 16): scalar pair 3.10 / 3.05 / 2.99 / 2.97 / 2.98 / 3.04 ms, x momentum 1.61 / 1.60 / 1.55 / 1.54 / 1.57 / 1.65,
+// z momentum 2.03 / 2.00 / 1.99 / 1.98 / 1.99 / 2.09 — eight blocks per tile column keep every XCD's resident blocks closer together in z than
+// two do; the 64 x 16 y-momentum kernel (1.69 / 1.70 / 1.70 / 1.73 / 1.76 / 1.81) and the Float32 build (equal to within noise) keep the coarse rule
+static int pick_chunk5(const DevGrid &g, int nlev, int rows_per_block, bool fine = false)
 {
     long long tiles = (long long)((g.Nx + 63) / 64) * ((g.Ny + rows_per_block - 1) / rows_per_block);
-    long long want = (1024 + tiles - 1) / tiles;
-    long long maxchunks = nlev / 128 > 0 ? nlev / 128 : 1;
+    const int floor_levels = fine ? 64 : 128;
+    long long want = ((fine ? 4096 : 1024) + tiles - 1) / tiles;
+    long long maxchunks = nlev / floor_levels > 0 ? nlev / floor_levels : 1;
     if (want > maxchunks) want = maxchunks;
     if (want < 1) want = 1;
     if (tiles * want < 512) {
@@ -112,7 +117,7 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
     L.by0 = rows == 1 ? 1 : 0;
     L.bys = rows == 2 ? nty - 1 : 1;
     auto shape = [&](int nlev, int &kc) {
-        kc = pick_chunk5(g, nlev, TY);
+        kc = pick_chunk5(g, nlev, TY, sizeof(double) == 8);
         dim3 grid(tx, ty, (nlev + kc - 1) / kc);
         L.xcd = (ctx->lean_xcd && ((long long)grid.x * grid.y * grid.z) % 8 == 0) ? 1 : 0;
         return grid;

@@ -14,6 +14,7 @@ GROUPS = {
     # round 3, after the walls-in-y instantiations: the WY template argument shows in the names
     "k5_scalar_pair<8, false>": "scalar_tendencies+rk3+thermo", "k6_u<8, false, false>": "x_momentum_tendency+rk3+velocity",
     "k6_v<8, false, false>": "y_momentum_tendency+rk3+velocity", "k6_w<8, false>": "z_momentum_tendency+rk3+velocity",
+    "k6_v<16, false, false>": "y_momentum_tendency+rk3+velocity",      # 64 x 16 tiles of the Float64 y-momentum kernel
     "k_tridiag_coop": "poisson_tridiagonal", "k_tridiag_coop<64>": "poisson_tridiagonal", "k_tridiag_coop<64, 8, true>": "poisson_tridiagonal", "k_x_forward<1>": "poisson_source_term+fft_x", "k_x_inverse": "poisson_fft_x_inverse",
     "k_x_forward<1, 1>": "poisson_source_term+fft_x", "k_x_inverse<1>": "poisson_fft_x_inverse",
     "k5_v<8>": "y_momentum_tendency+rk3+velocity", "k5_w<8>": "z_momentum_tendency+rk3+velocity",

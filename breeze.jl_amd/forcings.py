@@ -326,8 +326,13 @@ def materialize_bulk_fluxes(boundary_conditions, reference_state, constants, T=N
             B.drag_coefficient, B.drag_gustiness, B.drag_surface_temperature = new
             found = True
         elif isinstance(cond, BulkSensibleHeatFlux):
-            if k != "ρθ":
-                raise ValueError("BulkSensibleHeatFlux belongs on ρθ")
+            # keyed ρe in a potential-temperature model (examples/tropical_cyclone_world.jl:109-115) the condition is moved to ρθ with the
+            # potential-temperature difference, unchanged (BoundaryConditions.jl:218-227, thermodynamic_variable_bcs.jl:283); bulk fluxes
+            # are built for that formulation only (the model constructor says so for StaticEnergy)
+            if k not in ("ρθ", "ρe"):
+                raise ValueError("BulkSensibleHeatFlux belongs on ρθ (or ρe)")
+            if B.heat_coefficient:
+                raise ValueError("Cannot specify boundary conditions on both ρθ and ρe")
             B.heat_coefficient, B.heat_gustiness, B.heat_surface_temperature = cond.coefficient, cond.gustiness, cond.surface_temperature
             found = True
         elif isinstance(cond, BulkVaporFlux):

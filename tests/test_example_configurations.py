@@ -213,3 +213,35 @@ def test_tropical_cyclone_with_rainband_jl(bz):
     model.synchronize()
     assert _finite(model)
     assert model.potential_temperature_density.interior_cpu().sum() > th0      # the rainband heats
+
+
+def test_tropical_cyclone_world_jl(bz):
+    """examples/tropical_cyclone_world.jl:60-173: halo (5, 5, 5), FPlane, momentum WENO(order = 9) with rho theta WENO(order = 5) and rho q^e
+    WENO(order = 5, bounds = (0, 1)), warm-phase saturation adjustment, BulkDrag on rho u / rho v, BulkSensibleHeatFlux keyed rho e,
+    BulkVaporFlux on rho q^e, a Gaussian sponge on rho w (the radiative-cooling forcing of the example is a discrete-form function of T
+    and stays with the extension).  Parity of the pieces: tests/test_mixed_orders.py, test_forcings.py (bulk fluxes), test_relaxation.py"""
+    N, Nz, L, H = 32, 24, 96e3, 28e3
+    grid = bz.RectilinearGrid((N, N, Nz), halo=(5, 5, 5), x=(0.0, L), y=(0.0, L), z=(0.0, H))
+    T0 = 300.0
+    ref = bz.ReferenceState(grid, surface_pressure=101325.0, potential_temperature=T0)
+    CD = CT = 1.5e-3
+    bcs = {"ρu": bz.FieldBoundaryConditions(bottom=bz.BulkDrag(coefficient=CD, gustiness=1.0)),
+           "ρv": bz.FieldBoundaryConditions(bottom=bz.BulkDrag(coefficient=CD, gustiness=1.0)),
+           "ρe": bz.FieldBoundaryConditions(bottom=bz.BulkSensibleHeatFlux(coefficient=CT, gustiness=1.0, surface_temperature=T0)),
+           "ρqᵉ": bz.FieldBoundaryConditions(bottom=bz.BulkVaporFlux(coefficient=0.8 * CT, gustiness=1.0, surface_temperature=T0))}
+    sponge = bz.Relaxation(rate=1 / 30, mask=bz.GaussianMask(center=26e3, width=2e3))
+    model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), coriolis=bz.FPlane(f=3e-4), momentum_advection=bz.WENO(order=9),
+                               scalar_advection={"ρθ": bz.WENO(order=5), "ρqᵉ": bz.WENO(order=5, bounds=(0, 1))},
+                               microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), forcing={"ρw": sponge},
+                               boundary_conditions=bcs)
+    rng = np.random.default_rng(2)
+    model.set(θ=lambda x, y, z: T0 + 0.004 * z + 0.2 * rng.standard_normal((Nz, N, N)) * (z < 1e3),
+              qᵗ=lambda x, y, z: 0.015 * np.exp(-z / 3e3) + 0 * x + 0 * y, u=lambda x, y, z: 3.0 * np.sin(2 * np.pi * y / L) + 0 * x + 0 * z)
+    q0 = model.moisture_density.interior_cpu().sum()
+    for _ in range(8):
+        model.time_step(5.0)
+    model.synchronize()
+    assert _finite(model)
+    assert model.moisture_density.interior_cpu().sum() > q0          # the sea surface moistens the lowest level
+    q = model.specific_moisture.interior_cpu()
+    assert q.min() > -1e-6 and q.max() < 1.0

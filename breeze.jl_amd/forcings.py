@@ -306,7 +306,7 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions, T=None):
 def materialize_bulk_fluxes(boundary_conditions, reference_state, constants, T=None):
     """-> bz_bulk_surface_fluxes or None.  BulkDrag belongs on ρu / ρv (one coefficient for both), BulkSensibleHeatFlux on ρθ,
     BulkVaporFlux on the moisture density; anything else raises like the reference's regularization does."""
-    B, found = (T or _lib.types(8)).bz_bulk_surface_fluxes(), False
+    B, found, drag = (T or _lib.types(8)).bz_bulk_surface_fluxes(), False, None
     for name, bcs in (boundary_conditions or {}).items():
         k = _key(name)
         bottom = bcs.bottom if isinstance(bcs, FieldBoundaryConditions) else bcs
@@ -321,8 +321,9 @@ def materialize_bulk_fluxes(boundary_conditions, reference_state, constants, T=N
                     dry_air_gas_constant(constants) / constants.dry_air_heat_capacity)
                 T0 = Π0 * reference_state.potential_temperature
             new = (cond.coefficient, cond.gustiness, float(T0))
-            if found and B.drag_coefficient > 0 and (B.drag_coefficient, B.drag_gustiness, B.drag_surface_temperature) != new:
+            if drag is not None and drag != new:      # compared as given (the Float32 struct rounds what it stores)
                 raise NotImplementedError("ρu and ρv share one BulkDrag")
+            drag = new
             B.drag_coefficient, B.drag_gustiness, B.drag_surface_temperature = new
             found = True
         elif isinstance(cond, BulkSensibleHeatFlux):

@@ -112,13 +112,26 @@ def test_inertia_gravity_wave_jl(bz):
     assert np.abs(wa - wc).max() < 0.2 * np.abs(wa).max()
 
 
-def test_rico_jl_advection_list(bz):
-    """examples/rico.jl:40,184-190: Float32, per-field advection with bounds-preserving WENO for the moisture density
-    (parity: tests/test_bounded_weno.py, test_float32.py); the example's one-moment microphysics is outside this build."""
-    grid = bz.RectilinearGrid((32, 32, 20), x=(0.0, 12.8e3), y=(0.0, 12.8e3), z=(0.0, 4e3), float_type=np.float32)
+def test_rico_jl(bz):
+    """examples/rico.jl:40-190: Float32, per-field advection with bounds-preserving WENO for the moisture density, FPlane + geostrophic +
+    subsidence + large-scale drying / cooling profiles, the w sponge (Relaxation with a GaussianMask), bulk drag / sensible heat (keyed rho e) /
+    vapour fluxes, SmagorinskyLilly (parity: tests/test_bounded_weno.py, test_forcings.py, test_relaxation.py, test_float32.py); the example's
+    one-moment microphysics is outside this build — warm-phase saturation adjustment stands in."""
+    Lz = 4e3
+    grid = bz.RectilinearGrid((32, 32, 20), x=(0.0, 12.8e3), y=(0.0, 12.8e3), z=(0.0, Lz), float_type=np.float32)
+    T0 = 299.8
+    ws = lambda z: -0.005 * min(z, 2260.0) / 2260.0
+    geo = bz.geostrophic_forcings(lambda z: -9.9 + 2e-3 * z, lambda z: -3.8)
+    sub = bz.SubsidenceForcing(ws)
+    forcing = {"u": (sub, geo.u), "v": (sub, geo.v), "w": bz.Relaxation(rate=1 / 8, mask=bz.GaussianMask(center=3500.0, width=500.0)),
+               "qᵉ": (sub, bz.Forcing(lambda z: -1.0e-8 + (1.3456e-8) * min(z, 2980.0) / 2980.0)), "θ": (sub, bz.Forcing(lambda z: -2.5 / 86400.0))}
+    bcs = {"ρe": bz.FieldBoundaryConditions(bottom=bz.BulkSensibleHeatFlux(coefficient=1.094e-3, surface_temperature=T0)),
+           "ρqᵉ": bz.FieldBoundaryConditions(bottom=bz.BulkVaporFlux(coefficient=1.133e-3, surface_temperature=T0)),
+           "ρu": bz.FieldBoundaryConditions(bottom=bz.BulkDrag(coefficient=1.229e-3)), "ρv": bz.FieldBoundaryConditions(bottom=bz.BulkDrag(coefficient=1.229e-3))}
     model = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, surface_pressure=101540.0, potential_temperature=297.9)),
-                               advection={"momentum": bz.WENO(), "ρθ": bz.WENO(), "ρqᵉ": bz.WENO(bounds=(0, 1))},
-                               microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), closure=bz.SmagorinskyLilly())
+                               advection={"momentum": bz.WENO(), "ρθ": bz.WENO(), "ρqᵉ": bz.WENO(bounds=(0, 1))}, coriolis=bz.FPlane(f=4.5e-5),
+                               microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), closure=bz.SmagorinskyLilly(),
+                               forcing=forcing, boundary_conditions=bcs)
     rng = np.random.default_rng(1)
     model.set(θ=lambda x, y, z: 297.9 + 0.0035 * z + 0.1 * rng.standard_normal((20, 32, 32)), qᵗ=lambda x, y, z: 0.016 * np.exp(-z / 2000.0) + 0 * x + 0 * y, u=-9.0, v=-3.8)
     for _ in range(10):

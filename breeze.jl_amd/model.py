@@ -210,11 +210,10 @@ class AtmosphereModel:
         if advection is None:
             advection = Centered(order=2)          # the reference's default (resolved before the Flat guard: ADVICE r02)
         _base = advection.get("momentum") or next(iter(advection.values())) if isinstance(advection, dict) else advection
-        if flat_y and (coriolis is not None or forcing is not None or boundary_conditions is not None or
-                       not isinstance(_base, WENO) or _base.order not in (5, 7, 9)):
+        if flat_y and (not isinstance(_base, WENO) or _base.order not in (5, 7, 9)):
             # the reference's 2-D x-z cases (README.md:67-75, examples/dry_thermal_bubble.jl with WENO(order = 9)): the per-operator
             # kernels drop the y terms
-            raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model without Coriolis / forcings / flux boundary conditions is implemented")
+            raise NotImplementedError("(Periodic, Flat, Bounded): WENO(order = 5 | 7 | 9) models are implemented")
         formulation = str(formulation).lstrip(":")
         if bounded_x and (isinstance(advection, dict) or getattr(_base, "bounds", None) is not None or grid.Nx % 2):
             raise NotImplementedError("(Bounded, Flat, Bounded): WENO(order = 5 | 7 | 9) models without bounds-preserving advection on an even "

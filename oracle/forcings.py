@@ -211,7 +211,9 @@ def _add_bulk_fluxes(m, B, dz):
     z = g.Hz
     y0, y1, x0, x1 = g.Hy, g.Hy + g.Ny, g.Hx, g.Hx + g.Nx
     u, v = m.u[z], m.v[z]                       # first level with halos
-    sq = lambda a, jo, io: a[y0 + jo:y1 + jo, x0 + io:x1 + io] ** 2
+    fy = 0 if (g.Ny == 1 and g.Hy == 0) else 1      # a Flat direction has no neighbours: its averages collapse onto the cell
+    fx = 0 if (g.Nx == 1 and g.Hx == 0) else 1
+    sq = lambda a, jo, io: a[y0 + jo * fy:y1 + jo * fy, x0 + io * fx:x1 + io * fx] ** 2
     if B.drag_params is not None:
         C, gust, T0 = B.drag_params
         rho0 = B.p0 / (c.Rd * T0)

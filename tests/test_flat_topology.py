@@ -326,3 +326,74 @@ def test_two_dimensional_default_advection_is_rejected(bz):
     grid = bz.RectilinearGrid((16, 16), x=EXT["x"], z=EXT["z"], topology=(bz.Periodic, bz.Flat, bz.Bounded))
     with pytest.raises(NotImplementedError):
         bz.AtmosphereModel(grid)
+
+
+@pytest.mark.gpu
+def test_two_dimensional_forcing_stack_matches_oracle(oracle, bz):
+    """the BOMEX forcing / boundary-condition stack on a (Periodic, Flat, Bounded) grid — what the 2-D
+    examples/prescribed_sea_surface_temperature.jl:39-73 and radiative_convection.jl:57-62 attach to their x-z models: f-plane + geostrophic
+    + subsidence + drying / cooling profiles + bottom fluxes + friction-velocity drag, saturation adjustment; three steps vs the oracle"""
+    import test_forcings as tf
+    size = (64, 24)
+    ext = dict(x=tf.EXTENT[0], z=tf.EXTENT[2])
+    og = oracle.Grid(size, topology=("Periodic", "Flat", "Bounded"), **ext)
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment",
+                            forcings=tf._oracle_forcings(oracle, og, True))
+    grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Flat, bz.Bounded), **ext)
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5),
+                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), **tf._hip_forcing_kwargs(bz, True))
+    ic = tf._ic()
+    om.set(theta=ic["theta"], qt=lambda x, y, z: 0.0185 * np.exp(-z / 2200.0) + 0 * x, u=lambda x, y, z: -8.75 + 1.5e-3 * z + 0 * x, v=ic["v"])
+    hm.set(θ=lambda x, z: ic["theta"](x, 0.0, z), qᵗ=lambda x, z: 0.0185 * np.exp(-z / 2200.0) + 0 * x, u=lambda x, z: -8.75 + 1.5e-3 * z + 0 * x,
+           v=lambda x, z: ic["v"](x, 0.0, z))
+    for _ in range(3):
+        om.time_step(3.0)
+        hm.time_step(3.0)
+    hm.synchronize()
+    mom = max(np.abs(og.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rv", "rw"))
+    for n, f in (("ru", hm.momentum["ρu"]), ("rv", hm.momentum["ρv"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density),
+                 ("rq", hm.moisture_density), ("T", hm.temperature)):
+        want, got = og.interior(getattr(om, n), n == "rw"), f.interior_cpu()
+        scale = mom if n in ("ru", "rv", "rw") else max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() < 2e-9 * scale, (n, np.abs(got - want).max() / scale)
+
+
+@pytest.mark.gpu
+def test_two_dimensional_bulk_surface_fluxes_match_oracle(oracle, bz):
+    """BulkDrag / BulkSensibleHeatFlux / BulkVaporFlux (constant coefficients) on the 2-D grid of
+    examples/prescribed_sea_surface_temperature.jl:39-42 (its polynomial coefficients are outside this build), with a w sponge; three steps"""
+    import test_forcings as tf
+    from oracle.forcings import BulkFluxes, ColumnForcings
+    size = (64, 24)
+    ext = dict(x=tf.EXTENT[0], z=tf.EXTENT[2])
+    og = oracle.Grid(size, topology=("Periodic", "Flat", "Bounded"), **ext)
+    B = BulkFluxes(101500.0, 1e5, drag=(1.2e-3, 0.2, 299.8), heat=(1.1e-3, 0.2, 300.4), vapor=(1.3e-3, 0.1, 300.4))
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment",
+                            forcings=ColumnForcings(bulk=B))
+    ztop = tf.EXTENT[2][1]
+    mask = lambda z: np.exp(-(z - ztop) ** 2 / (2 * (0.15 * ztop) ** 2))
+    om.relaxation = {"rw": (0.05 * mask(og.zf), np.zeros(og.Nz + 1))}
+    grid = bz.RectilinearGrid(size, topology=(bz.Periodic, bz.Flat, bz.Bounded), **ext)
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+    bcs = {"ρu": bz.FieldBoundaryConditions(bottom=bz.BulkDrag(coefficient=1.2e-3, gustiness=0.2, surface_temperature=299.8)),
+           "ρv": bz.FieldBoundaryConditions(bottom=bz.BulkDrag(coefficient=1.2e-3, gustiness=0.2, surface_temperature=299.8)),
+           "ρe": bz.FieldBoundaryConditions(bottom=bz.BulkSensibleHeatFlux(coefficient=1.1e-3, gustiness=0.2, surface_temperature=300.4)),
+           "ρqᵉ": bz.FieldBoundaryConditions(bottom=bz.BulkVaporFlux(coefficient=1.3e-3, gustiness=0.1, surface_temperature=300.4))}
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), boundary_conditions=bcs,
+                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()),
+                            forcing={"ρw": bz.Relaxation(rate=0.05, mask=mask)})
+    ic = tf._ic(seed=13)
+    om.set(theta=ic["theta"], qt=lambda x, y, z: 0.0185 * np.exp(-z / 2200.0) + 0 * x, u=lambda x, y, z: -8.75 + 1.5e-3 * z + 0 * x, v=ic["v"])
+    hm.set(θ=lambda x, z: ic["theta"](x, 0.0, z), qᵗ=lambda x, z: 0.0185 * np.exp(-z / 2200.0) + 0 * x, u=lambda x, z: -8.75 + 1.5e-3 * z + 0 * x,
+           v=lambda x, z: ic["v"](x, 0.0, z))
+    for _ in range(3):
+        om.time_step(3.0)
+        hm.time_step(3.0)
+    hm.synchronize()
+    mom = max(np.abs(og.interior(getattr(om, n), n == "rw")).max() for n in ("ru", "rv", "rw"))
+    for n, f in (("ru", hm.momentum["ρu"]), ("rv", hm.momentum["ρv"]), ("rw", hm.momentum["ρw"]), ("rtheta", hm.potential_temperature_density),
+                 ("rq", hm.moisture_density), ("T", hm.temperature)):
+        want, got = og.interior(getattr(om, n), n == "rw"), f.interior_cpu()
+        scale = mom if n in ("ru", "rv", "rw") else max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() < 2e-9 * scale, (n, np.abs(got - want).max() / scale)

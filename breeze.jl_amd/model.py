@@ -215,11 +215,11 @@ class AtmosphereModel:
             # kernels drop the y terms
             raise NotImplementedError("(Periodic, Flat, Bounded): WENO(order = 5 | 7 | 9) models are implemented")
         formulation = str(formulation).lstrip(":")
-        if bounded_x and (isinstance(advection, dict) or getattr(_base, "bounds", None) is not None or grid.Nx % 2):
+        _any_bounds = any(getattr(s, "bounds", None) is not None for s in (advection.values() if isinstance(advection, dict) else (advection,)))
+        if bounded_x and (_any_bounds or grid.Nx % 2):
             raise NotImplementedError("(Bounded, Flat, Bounded): WENO(order = 5 | 7 | 9) models without bounds-preserving advection on an even "
                                       "number of columns are implemented")
-        if bounded_y and (isinstance(advection, dict) or not isinstance(_base, WENO) or _base.order not in (5, 7, 9) or
-                          getattr(_base, "bounds", None) is not None):
+        if bounded_y and (not isinstance(_base, WENO) or _base.order not in (5, 7, 9) or _any_bounds):
             # Coriolis, forcings, bottom flux boundary conditions and the closure reach their y neighbours through the halo rows (as on
             # y-slabs); microphysics, tracers and the StaticEnergy formulation are column- or cell-local
             raise NotImplementedError("(Periodic, Bounded, Bounded): WENO(order = 5 | 7 | 9) models without bounds-preserving advection "

@@ -147,3 +147,28 @@ def test_scalars_left_to_the_default_scheme_are_refused(bz):
     grid = bz.RectilinearGrid((16, 16, 8), halo=(5, 5, 5), **EXT)
     with pytest.raises(NotImplementedError):
         bz.AtmosphereModel(grid, momentum_advection=bz.WENO(order=9), scalar_advection={"ρθ": bz.WENO(order=5)})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("topo", [("Periodic", "Bounded", "Bounded"), ("Bounded", "Flat", "Bounded")])
+def test_mixed_orders_inside_walls(oracle, bz, topo):
+    """momentum WENO(order = 9) + scalars WENO(order = 5) between walls: both kernel families carry the wall buffers (generic kernels for the
+    momentum, per-operator order-5 kernels for the scalars)"""
+    flat = topo[1] == "Flat"
+    size = (32, 24) if flat else (32, 16, 12)
+    ext = dict(x=(0.0, 1600.0), z=(0.0, 1000.0)) if flat else EXT
+    halo = (5, 5) if flat else (5, 5, 5)
+    g = oracle.Grid(size, topology=topo, halo=halo, **ext)
+    om = oracle.OracleModel(g, potential_temperature=300.0, advection="WENO9", scalar_advection="WENO5")
+    grid = bz.RectilinearGrid(size, topology=tuple(getattr(bz, t) for t in topo), halo=halo, **ext)
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)),
+                            momentum_advection=bz.WENO(order=9), scalar_advection=bz.WENO(order=5))
+    th3 = lambda x, y, z: 300.0 + 2.0 * np.exp(-((x - 500.0) ** 2 + (z - 400.0) ** 2) / 200.0 ** 2) + 0 * y
+    if flat:
+        om.set(theta=th3)
+        hm.set(θ=lambda x, z: th3(x, 0.0, z))
+    else:
+        v0 = lambda x, y, z: np.sin(np.pi * y / 1200.0) * np.cos(2 * np.pi * x / 1600.0) + 0 * z
+        om.set(theta=th3, u=1.0, v=v0)
+        hm.set(θ=th3, u=1.0, v=v0)
+    _steps(g, om, hm, 3, 2.0, 2e-8)

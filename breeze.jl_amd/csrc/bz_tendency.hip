@@ -365,6 +365,10 @@ static int compute_tendencies_mixed(bz_ctx *ctx, const bz_state *s, const bz_pro
     const dim3 grid((g.Nx + 63) / 64, (g.Ny + TYB - 1) / TYB, (g.Nz + kc - 1) / kc);
     if (ctx->weno_R != 3) {
         if ((rc = bzi_momentum_tendencies_generic(ctx, s, G))) return rc;
+    } else if (ctx->tend_gen >= 2 && ctx->tend_lds) {      // the order-5 kernels bz_compute_tendencies itself would pick
+        if ((rc = bzi_u_tendency_lds(ctx, s, G))) return rc;
+        if ((rc = bzi_v_tendency_lds(ctx, s, G))) return rc;
+        if ((rc = bzi_w_tendency_ring(ctx, s, G))) return rc;
     } else {
         {
             ProfileScope ps(ctx, "x_momentum_tendency");
@@ -386,8 +390,12 @@ static int compute_tendencies_mixed(bz_ctx *ctx, const bz_state *s, const bz_pro
         hipLaunchKernelGGL(k_scalar_tendency, grid, block, 0, ctx->stream, g, Gc, s->u, s->v, s->w, c, kc);
         return BZ_OK;
     };
-    if ((rc = scalar("potential_temperature_tendency", G->rho_theta, s->theta))) return rc;
-    if ((rc = scalar("moisture_tendency", G->rho_q, s->q))) return rc;
+    if (ctx->scalar_R == 3 && ctx->tend_gen >= 2) {      // theta and moisture together in the LDS-tiled pair kernel, as in the single-order path
+        if ((rc = bzi_scalar_pair_tendency(ctx, s, G))) return rc;
+    } else {
+        if ((rc = scalar("potential_temperature_tendency", G->rho_theta, s->theta))) return rc;
+        if ((rc = scalar("moisture_tendency", G->rho_q, s->q))) return rc;
+    }
     if (g.microphysics == 2) {
         if ((rc = scalar("kessler_species_tendencies", ctx->kessler.G_cloud_liquid_density, ctx->kessler.cloud_liquid_mass_fraction))) return rc;
         if ((rc = scalar("kessler_species_tendencies", ctx->kessler.G_rain_density, ctx->kessler.rain_mass_fraction))) return rc;

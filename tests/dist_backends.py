@@ -134,7 +134,14 @@ class Mailbox:
 def make_threaded_decomposition(bz_dist, mailbox, *args, **kw):
     class ThreadedDecomposition(bz_dist.SlabDecomposition):
         def _p2p(self, sends, recvs):
+            # every rank is a thread with its own stream: the sender's pack kernels must have finished before another thread's stream
+            # reads the buffer, and the receiver's copies before the sender recycles it (torch.distributed orders both by itself; this
+            # stand-in has to say so — without the two synchronisations one run in four of the four-rank compressible test raced)
+            import torch
             mb = mailbox
+            cuda = any(t.is_cuda for t, _ in sends)
+            if cuda:
+                torch.cuda.current_stream().synchronize()
             with mb.lock:
                 for t, dst in sends:
                     mb.box.setdefault((self.rank, dst), []).append(t)
@@ -142,6 +149,8 @@ def make_threaded_decomposition(bz_dist, mailbox, *args, **kw):
             with mb.lock:
                 for t, src in recvs:
                     t.copy_(mb.box[(src, self.rank)].pop(0))
+            if cuda:
+                torch.cuda.current_stream().synchronize()
             mb.barrier.wait()
 
     return ThreadedDecomposition(*args, **kw)

@@ -87,7 +87,8 @@ class bz_column_forcings(C.Structure):
                 ("subsidence_u", C.c_int32), ("subsidence_v", C.c_int32), ("subsidence_theta", C.c_int32),
                 ("subsidence_moisture", C.c_int32), ("coriolis_f", C.c_double),
                 ("bottom_theta_flux", C.c_double), ("bottom_moisture_flux", C.c_double),
-                ("bottom_drag_rho0_ustar2", C.c_double), ("bottom_drag_epsilon", C.c_double)]
+                ("bottom_drag_rho0_ustar2", C.c_double), ("bottom_drag_epsilon", C.c_double),
+                ("bottom_energy_flux", C.c_double)]
 
 
 class bz_column_relaxation(C.Structure):

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F
 }
 
 // bottom FluxBoundaryConditions: G[i,j,1] += J / dz_1 (Oceananigans apply_z_bcs!); the drag flux of examples/bomex.jl:95-101
-__global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, double Jq, double drag, double drag_eps, double *__restrict__ Gu,
+__global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, double Jq, double Je, const double *__restrict__ qfield, double drag, double drag_eps, double *__restrict__ Gu,
                                                      double *__restrict__ Gv, double *__restrict__ Gth,
                                                      double *__restrict__ Gq, const double *__restrict__ ru,
                                                      const double *__restrict__ rv, double scale)
@@ -150,6 +150,14 @@ __global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, doub
     const long long sx = g.Hx ? 1 : 0, sy = g.Hy ? g.Sx : 0;
     if (Jth != 0.0) Gth[n] += scale * (Jth / dz);
     if (Jq != 0.0) Gq[n] += scale * (Jq / dz);
+    if (Je != 0.0) {      // energy flux -> theta flux: Q / c_pm of the lowest cell (moisture fractions as the microphysics holds them)
+        double qv, ql = 0.0;
+        if (g.microphysics == 1) { qv = g.qv_field[n]; ql = g.ql_field[n]; }
+        else qv = qfield[n];
+        const double qd = 1.0 - (qv + ql);
+        const double cpm = qd * g.cpd + qv * g.cpv + ql * g.sa_cl;
+        Gth[n] += scale * ((Je / cpm) / dz);
+    }
     if (drag != 0.0) {
         const double u = ru[n], v = rv[n];
         const double va = (rv[n - sx] + rv[n - sx + sy]) / 2, vb = (rv[n] + rv[n + sy]) / 2;
@@ -320,7 +328,7 @@ extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
     // the column profiles are specific forcings of the anelastic model (times rho_r), the bottom fluxes belong to its flux-BC pass
     const bool coriolis_only = !f->u_forcing && !f->v_forcing && !f->theta_forcing && !f->moisture_forcing && !f->energy_forcing &&
                                !f->subsidence_vertical_velocity && f->bottom_theta_flux == 0.0 && f->bottom_moisture_flux == 0.0 &&
-                               f->bottom_drag_rho0_ustar2 == 0.0;
+                               f->bottom_drag_rho0_ustar2 == 0.0 && f->bottom_energy_flux == 0.0;
     if ((ctx->compressible && (!coriolis_only || ctx->slab_mode)) || (!ctx->compressible && (ctx->dg.formulation != 0 || ctx->dg.microphysics == 2))) {      // y-slab contexts: through the library-owned distributed step (bz_comm.hip)
         ctx->last_error = "bz_set_forcings: the forcing stack is implemented for the anelastic "
                           "potential-temperature model (microphysics nothing or SaturationAdjustment); single-device compressible contexts "
@@ -350,6 +358,7 @@ extern "C" int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *f)
     ctx->forcing_f = f->coriolis_f;
     ctx->forcing_flux_theta = f->bottom_theta_flux;
     ctx->forcing_flux_q = f->bottom_moisture_flux;
+    ctx->forcing_flux_energy = f->bottom_energy_flux;
     ctx->forcing_drag = f->bottom_drag_rho0_ustar2;
     ctx->forcing_drag_eps = f->bottom_drag_epsilon;
     ctx->has_forcings = true;
@@ -459,7 +468,9 @@ int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, d
 // reference's own benchmark case: FPlane + geostrophic forcing + bottom fluxes (benchmarking/src/convective_boundary_layer.jl).
 bool bzi_lean_forcings_ok(const bz_ctx *ctx)
 {
-    return ctx->has_forcings && !ctx->has_bulk && ctx->forcing_subsidence_mask == 0 && (ctx->forcing_static_mask & (4 | 8 | 16)) == 0;
+    // (an energy flux divides by the mixture heat capacity of the stored q^v, which the lean seam does not keep inside a step)
+    return ctx->has_forcings && !ctx->has_bulk && ctx->forcing_subsidence_mask == 0 && (ctx->forcing_static_mask & (4 | 8 | 16)) == 0 &&
+           ctx->forcing_flux_energy == 0.0;
 }
 
 // T of the lowest level from the rho theta / rho q the bottom heat / moisture flux has just changed (the lean scalar kernel wrote T of
@@ -504,11 +515,12 @@ int bzi_flux_bc(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *
         if (rcb) return rcb;
     }
     if (!ctx->has_forcings) return BZ_OK;
-    if (ctx->forcing_flux_theta == 0.0 && ctx->forcing_flux_q == 0.0 && ctx->forcing_drag == 0.0) return BZ_OK;
+    if (ctx->forcing_flux_theta == 0.0 && ctx->forcing_flux_q == 0.0 && ctx->forcing_drag == 0.0 && ctx->forcing_flux_energy == 0.0) return BZ_OK;
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "flux_bc_tendencies");
     hipLaunchKernelGGL(k_bottom_flux, dim3((g.Nx + 255) / 256, g.Ny), dim3(256), 0, ctx->stream, g, ctx->forcing_flux_theta,
-                       ctx->forcing_flux_q, ctx->forcing_drag, ctx->forcing_drag_eps, Gu, Gv, Gth, Gq, s->rho_u, s->rho_v, scale);
+                       ctx->forcing_flux_q, ctx->forcing_flux_energy, s->q, ctx->forcing_drag, ctx->forcing_drag_eps, Gu, Gv, Gth, Gq, s->rho_u,
+                       s->rho_v, scale);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }

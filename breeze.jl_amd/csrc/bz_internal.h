@@ -364,7 +364,7 @@ struct bz_ctx {
     bool has_forcings = false;
     double *d_forcing = nullptr;      // static profiles, subsidence velocity, level averages, subsidence profiles, partial sums
     int forcing_static_mask = 0, forcing_subsidence_mask = 0;
-    double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0, forcing_drag_eps = 0.0;
+    double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0, forcing_drag_eps = 0.0, forcing_flux_energy = 0.0;
     // BulkDrag / BulkSensibleHeatFlux / BulkVaporFlux bottom conditions (bz_set_bulk_surface_fluxes, bz_forcing.hip)
     bool has_bulk = false;
     bz_bulk_surface_fluxes bulk;

@@ -284,7 +284,13 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions, T=None):
         cond = bottom.condition if isinstance(bottom, FluxBoundaryCondition) else bottom
         if isinstance(cond, (BulkDrag, BulkSensibleHeatFlux, BulkVaporFlux)):
             continue                      # collected by materialize_bulk_fluxes
-        if k == "ρθ":
+        if k == "ρe":      # an energy flux keyed ρe in a potential-temperature model: Q / cᵖᵐ enters ρθ (BoundaryConditions.jl:218-227)
+            if S.bottom_theta_flux:
+                raise ValueError("Cannot specify boundary conditions on both ρθ and ρe")
+            S.bottom_energy_flux = float(cond)
+        elif k == "ρθ":
+            if S.bottom_energy_flux:
+                raise ValueError("Cannot specify boundary conditions on both ρθ and ρe")
             S.bottom_theta_flux = float(cond)
         elif k in ("ρqe", "ρqv", "ρqt"):
             S.bottom_moisture_flux = float(cond)
@@ -298,7 +304,8 @@ def materialize_forcings(grid, coriolis, forcing, boundary_conditions, T=None):
         else:
             raise NotImplementedError(f"boundary condition on {name!r} is not implemented")
     S.bottom_drag_rho0_ustar2, S.bottom_drag_epsilon = drag or (0.0, 0.0)
-    if not static and ws is None and f == 0.0 and not (S.bottom_theta_flux or S.bottom_moisture_flux or S.bottom_drag_rho0_ustar2):
+    if not static and ws is None and f == 0.0 and not (S.bottom_theta_flux or S.bottom_moisture_flux or S.bottom_drag_rho0_ustar2 or
+                                                          S.bottom_energy_flux):
         return None, None                 # e.g. only bulk conditions were given
     return S, keep
 

@@ -497,6 +497,7 @@ int bz_compressible_kessler_update(bz_ctx *ctx, const bz_compressible_state *s, 
  *   bottom_drag_rho0_ustar2      rho0 u*^2 of the bulk drag FluxBoundaryCondition on rho u, rho v (examples/bomex.jl:95-101)
  *   bottom_drag_epsilon          the regulariser under the square root, J = -rho0 u*^2 rho_u / sqrt(rho_u^2 + rho_v^2 + eps)
  *                                (benchmarking/src/convective_boundary_layer.jl:142-146 uses 1e-10; the BOMEX example none)
+ *   bottom_energy_flux           see the member
  * All pointers are HOST arrays (cell centres, length Nz; the subsidence velocity Nz+1 faces), copied by the call; NULL = absent.
  * With a stack attached bz_compute_tendencies adds the forcing + Coriolis terms, and bz_time_step_anelastic calls
  * bz_compute_flux_bc_tendencies before every RK substep (src/TimeSteppers/ssp_runge_kutta_3.jl:229,243,257).
@@ -513,6 +514,9 @@ typedef struct bz_column_forcings {
     double bottom_theta_flux, bottom_moisture_flux;
     double bottom_drag_rho0_ustar2;
     double bottom_drag_epsilon;
+    double bottom_energy_flux;       /* a constant FluxBoundaryCondition keyed rho e in a potential-temperature model: the energy flux Q (W m^-2)
+                                        enters rho theta as Q / c_pm with the mixture heat capacity of the lowest cell
+                                        (EnergyFluxBoundaryCondition, src/BoundaryConditions/thermodynamic_variable_bcs.jl; BoundaryConditions.jl:218-227) */
 } bz_column_forcings;
 int bz_set_forcings(bz_ctx *ctx, const bz_column_forcings *forcings);       /* NULL detaches the stack */
 /* ---- sponge layers: Relaxation(rate, mask, target) forcings with a horizontally uniform mask and target ----

@@ -149,6 +149,7 @@ struct BzColumnForcings
     energy_forcing::Ptr{Cdouble}; subsidence_vertical_velocity::Ptr{Cdouble}
     subsidence_u::Int32; subsidence_v::Int32; subsidence_theta::Int32; subsidence_moisture::Int32
     coriolis_f::Cdouble; bottom_theta_flux::Cdouble; bottom_moisture_flux::Cdouble; bottom_drag_rho0_ustar2::Cdouble; bottom_drag_epsilon::Cdouble
+    bottom_energy_flux::Cdouble      # a constant flux keyed ρe in a θ model: Q / cᵖᵐ enters ρθ (EnergyFluxBoundaryCondition)
 end
 
 struct BzTracerFields
@@ -168,10 +169,10 @@ Column forcings of examples/bomex.jl:104-207.  `profiles` holds host `Vector{Flo
 materialized forcings (Array(interior(field, 1, 1, :))): geostrophic -f vᵍ / +f uᵍ, Forcing(field) profiles, the subsidence wˢ
 on faces; `flags` says which specific fields carry a SubsidenceForcing; fluxes are the bottom FluxBoundaryCondition values.
 """
-function attach_forcings!(ctx, profiles::NamedTuple, flags::NamedTuple, f, Jθ, Jq, ρ₀u★², ϵ = 0.0)
+function attach_forcings!(ctx, profiles::NamedTuple, flags::NamedTuple, f, Jθ, Jq, ρ₀u★², ϵ = 0.0, 𝒬 = 0.0)
     p(name) = haskey(profiles, name) ? pointer(profiles[name]) : Ptr{Cdouble}(C_NULL)
     F = BzColumnForcings(p(:u), p(:v), p(:θ), p(:q), p(:e), p(:wˢ),
-                         flags.u, flags.v, flags.θ, flags.q, f, Jθ, Jq, ρ₀u★², ϵ)      # ϵ: the drag's regulariser (convective_boundary_layer.jl:142-146)
+                         flags.u, flags.v, flags.θ, flags.q, f, Jθ, Jq, ρ₀u★², ϵ, 𝒬)      # ϵ: the drag's regulariser (convective_boundary_layer.jl:142-146)
     GC.@preserve profiles check(ccall((:bz_set_forcings, libbreeze_hip), Cint, (Ptr{Cvoid}, Ref{BzColumnForcings}), ctx, F),
                                 "bz_set_forcings", ctx)
 end

@@ -33,13 +33,16 @@ class ColumnForcings:
 
     def __init__(self, Fu=None, Fv=None, Ftheta=None, Fq=None, Fe=None, w_subsidence=None,
                  subsidence_on=("u", "v", "theta", "q"), coriolis_f=0.0, flux_theta=0.0, flux_q=0.0,
-                 drag_rho0_ustar2=0.0, bulk=None, drag_epsilon=0.0):
+                 drag_rho0_ustar2=0.0, bulk=None, drag_epsilon=0.0, flux_energy=0.0):
         self.Fu, self.Fv, self.Ftheta, self.Fq, self.Fe = Fu, Fv, Ftheta, Fq, Fe
         self.w_subsidence = w_subsidence              # Nz+1 faces
         self.subsidence_on = tuple(subsidence_on) if w_subsidence is not None else ()
         self.f = float(coriolis_f)
         self.flux_theta, self.flux_q, self.drag = float(flux_theta), float(flux_q), float(drag_rho0_ustar2)
         self.drag_eps = float(drag_epsilon)           # benchmarking/src/convective_boundary_layer.jl:142-146
+        # a constant energy flux keyed rho e in a potential-temperature model: J_theta = Q / c_pm of the lowest cell
+        # (EnergyFluxBoundaryCondition, src/BoundaryConditions/thermodynamic_variable_bcs.jl; BoundaryConditions.jl:218-227)
+        self.flux_energy = float(flux_energy)
         self.bulk = bulk                              # BulkFluxes or None
         self.sub = {}
 
@@ -191,6 +194,14 @@ def add_flux_bc_tendencies(m):
         I(m.G["rtheta"])[0] += F.flux_theta * 1.0 / dz
     if F.flux_q != 0.0:
         I(m.G["rq"])[0] += F.flux_q * 1.0 / dz
+    if getattr(F, "flux_energy", 0.0) != 0.0:
+        c = m.constants
+        if m.microphysics == "SaturationAdjustment":
+            qv, ql, cl = I(m.qv)[0], I(m.ql)[0], m._sa.cl
+        else:
+            qv, ql, cl = I(m.q)[0], 0.0, 0.0
+        cpm = (1.0 - (qv + ql)) * c.cpd + qv * c.cpv + ql * cl
+        I(m.G["rtheta"])[0] += (F.flux_energy / cpm) * 1.0 / dz
     if F.drag != 0.0:
         ru, rv = I(m.ru)[0], I(m.rv)[0]
         rv_fc = _xy_to_fc(m, m.rv)[0]

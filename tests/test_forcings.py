@@ -374,3 +374,51 @@ def test_bulk_surface_fluxes_match_oracle(oracle, bz):
         got = hm.prognostic_fields()[k].interior_cpu()
         scale = max(np.abs(og.interior(om.ru)).max(), 1e-3) if n in ("ru", "rv", "rw") else np.abs(want).max()
         assert np.abs(got - want).max() / scale < 1e-9, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("moist", [False, True])
+def test_energy_flux_keyed_rho_e_enters_rho_theta_divided_by_the_mixture_heat_capacity(oracle, bz, moist):
+    """boundary_conditions = (; ρe = FieldBoundaryConditions(bottom = FluxBoundaryCondition(Q))) in a potential-temperature model
+    (BoundaryConditions.jl:218-227, thermodynamic_variable_bcs.jl: J_theta = Q / c_pm): tendency of the lowest level and three steps"""
+    from oracle.forcings import ColumnForcings, add_flux_bc_tendencies
+    size, Q = (32, 20, 16), 120.0
+    og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1, microphysics="SaturationAdjustment" if moist else None,
+                            forcings=ColumnForcings(flux_energy=Q, flux_q=RHO0 * 5.2e-5))
+    grid = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+    bcs = {"ρe": bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(Q)),
+           "ρqᵉ": bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(RHO0 * 5.2e-5))}
+    hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), boundary_conditions=bcs,
+                            microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()) if moist else None)
+    ic = _ic(seed=21)
+    om.set(**ic)
+    om.update_state()
+    push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+    bz.update_state_(hm, compute_tendencies=True)
+    before = hm.G["ρθ"].interior_cpu().copy()
+    G0 = og.interior(om.G["rtheta"]).copy()
+    add_flux_bc_tendencies(om)
+    bz.compute_flux_bc_tendencies_(hm)
+    hm.synchronize()
+    want, got = og.interior(om.G["rtheta"]) - G0, hm.G["ρθ"].interior_cpu() - before
+    assert np.abs(want[0]).min() > 0 and np.all(want[1:] == 0) and np.all(got[1:] == 0)
+    assert np.abs(got - want).max() < 1e-9 * np.abs(want).max()
+    cpd = 1005.0
+    assert abs(want[0].mean() * og.dzc[og.Hz] - Q / cpd) < 0.03 * Q / cpd      # Q / c_pm, c_pm within 3 % of the dry value
+    om.set(**ic)
+    hm.set(θ=ic["theta"], qᵗ=ic["qt"], u=ic["u"], v=ic["v"])
+    for _ in range(3):
+        om.time_step(3.0)
+        hm.time_step(3.0)
+    hm.synchronize()
+    for n, k in PROG.items():
+        want = og.interior(getattr(om, n), zface=(n == "rw"))
+        got = hm.prognostic_fields()[k].interior_cpu()
+        scale = max(np.abs(og.interior(om.ru)).max(), 1e-3) if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(got - want).max() / scale < 1e-9, n
+    with pytest.raises(ValueError):
+        bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5),
+                           boundary_conditions={"ρe": bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(Q)),
+                                                "ρθ": bz.FieldBoundaryConditions(bottom=bz.FluxBoundaryCondition(0.01))})

@@ -141,8 +141,8 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         // 64 x 16 tiles for the y-momentum kernel in Float64 (one 1024-thread workgroup per CU): its y reconstructions read five frame rows
         // of v per interior row, the tallest frame of the four kernels — measured 1.77 -> 1.68 ms per launch at 512^3; the other three
         // kernels are equal to within noise (x 1.59 -> 1.58, z 2.04 -> 2.05, scalars 3.09 -> 3.08) and stay on 64 x 8, as does Float32
-        // (1.06 -> 1.05).  Whole tile rows only (the slab driver's row split counts 8-row tiles; walls keep the WY instantiations).
-        if (sizeof(double) == 8 && TY == 8 && rows == 0 && !g.bounded_y && g.Ny % 16 == 0 && g.Ny >= 64) {
+        // (1.06 -> 1.05).  Single-device contexts with whole tile rows (the slab driver's row split counts 8-row tiles; walls keep the WY instantiations).
+        if (sizeof(double) == 8 && TY == 8 && rows == 0 && !ctx->slab_mode && !g.bounded_y && g.Ny % 16 == 0 && g.Ny >= 64) {
             const int kc16 = pick_chunk5(g, g.Nz, 16);
             const dim3 grid16(tx, g.Ny / 16, (g.Nz + kc16 - 1) / kc16), block16(64, 16);
             L.xcd = (ctx->lean_xcd && ((long long)grid16.x * grid16.y * grid16.z) % 8 == 0) ? 1 : 0;

@@ -501,7 +501,9 @@ int bz_compressible_kessler_update(bz_ctx *ctx, const bz_compressible_state *s, 
  * All pointers are HOST arrays (cell centres, length Nz; the subsidence velocity Nz+1 faces), copied by the call; NULL = absent.
  * With a stack attached bz_compute_tendencies adds the forcing + Coriolis terms, and bz_time_step_anelastic calls
  * bz_compute_flux_bc_tendencies before every RK substep (src/TimeSteppers/ssp_runge_kutta_3.jl:229,243,257).
- * Single-device anelastic potential-temperature contexts only (microphysics nothing or SaturationAdjustment). */
+ * Anelastic potential-temperature contexts (microphysics nothing or SaturationAdjustment; single device, or y-slabs through the library-owned
+ * distributed step); a single-device CompressibleDynamics context accepts a stack whose only non-zero member is coriolis_f (the f-plane term
+ * of its slow momentum tendencies, examples/tropical_cyclone_with_rainband.jl:508-514). */
 typedef struct bz_column_forcings {
     const double *u_forcing;
     const double *v_forcing;

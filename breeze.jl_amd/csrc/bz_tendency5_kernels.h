@@ -645,10 +645,13 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
         const double tnew_raw = tcur_raw, u0v = u0cur;
         const double ru_n = g.Ax[k + 1] * ru[n + sz], rw_n = Az * rw[n + 2 * sz];
-        // Coriolis: rho_u at (i, j-1), (i+1, j-1), (i, j), (i+1, j) — the Ax rho_u tile has no x halo and is premultiplied, so four
-        // loads (L1 / L2 hits of rows this tile has just staged), issued here and used after the barrier
-        double cu0 = 0.0, cu1 = 0.0, cu2 = 0.0, cu3 = 0.0;
-        if constexpr (MF) { if (L.mforce & 1) { const ix_t sy = (ix_t)g.Sx; cu0 = ru[n - sy]; cu1 = ru[n - sy + 1]; cu2 = ru[n]; cu3 = ru[n + 1]; } }
+        // Coriolis: rho_u at (i, j-1), (i+1, j-1), (i, j), (i+1, j).  The Ax rho_u tile of this level holds the rows j-1 and j (premultiplied
+        // by the level's Ax, no x halo): three of the four values come from LDS for every lane, the column i+1 of the last lane from memory;
+        // one register crosses the barrier instead of four (round 3 loaded all four from memory: the forcing variant ran at 4 waves per
+        // SIMD in Float32 because of them and cost 0.70 ms per launch at 512 x 512 x 256 against 0.52 without forcing)
+        // (the last lane's two loads are requested here with the level's other loads and used after the stencil arithmetic)
+        double cor_u = 0.0, cg1 = 0.0, cg3 = 0.0;
+        if constexpr (MF) { if ((L.mforce & 1) && tx == 63) { const ix_t sy = (ix_t)g.Sx; cg1 = ru[n - sy + 1]; cg3 = ru[n + 1]; } }
         if (((k - kbeg) & 63) == 0) {
             const int kk = min(k + tx, kend - 1);
             edge = flux_x_lean<T3_V>(g, F, rv, ie, jc, kk, Bf);
@@ -676,6 +679,14 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         const double tnew = bz_cdiv(tnew_raw, g.rho[k + 3], g.rrho[k + 3]);
         const double wt = bz_symm4y<WY>(MW[ty][tx], MW[ty + 1][tx], MW[ty + 2][tx], MW[ty + 3][tx], Bf);
         const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
+        if constexpr (MF) {
+            if (L.mforce & 1) {      // column tx + 1 of the last lane reads the next row's first element (in bounds) and is replaced
+                const double Axk = g.Ax[k];
+                const double l1 = MU[ty + 1][tx + 1], l3 = MU[ty + 2][tx + 1];
+                const double c1 = (tx == 63) ? Axk * cg1 : l1, c3 = (tx == 63) ? Axk * cg3 : l3;
+                cor_u = (((MU[ty + 1][tx] + c1) / 2 + (MU[ty + 2][tx] + c3) / 2) / 2) / Axk;
+            }
+        }
         // ---- stage level k+1 ----
         Tv[buf ^ 1][ty + 3][tc] = r[4];
         if (sok) Tv[buf ^ 1][srow + 3][scol] = bz_cdiv(p_side, g.rho[k + 1], g.rrho[k + 1]);
@@ -694,7 +705,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
             const double dy = fy - FY[buf][ty][tx];
             double Gv = -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo)));
             if constexpr (MF) {      // -y_f_cross_U + rho F_v
-                if (L.mforce & 1) { const double a = (cu0 + cu1) / 2, b = (cu2 + cu3) / 2; Gv -= L.cor_f * ((a + b) / 2); }
+                if (L.mforce & 1) Gv -= L.cor_f * cor_u;
                 if (L.mforce & 4) Gv += rho * L.Fv[k];
             }
             if (store) L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out, Gv, q0, n);

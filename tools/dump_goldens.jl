@@ -8,11 +8,21 @@ using Breeze, Oceananigans, JSON
 
 const EXTENT = (x=(-10e3, 10e3), y=(-10e3, 10e3), z=(0, 10e3))
 
+# kind: "anelastic_weno5" | "anelastic_centered2" | "compressible_weno5" (round 1), and the options whose Oceananigans semantics the CPU oracle
+# restates from memory (DESIGN.md §2 "parity unpinned"): "anelastic_weno9" (buffer cascade 9 -> 1 next to the z walls),
+# "anelastic_walls_y" = (Periodic, Bounded, Bounded) and "anelastic_walls_x" = (Bounded, Flat, Bounded) (wall faces, no-flux halos, DCT
+# solve), "anelastic_smagorinsky" (SmagorinskyLilly), "anelastic_mixed_orders" (momentum WENO9 + scalars WENO5)
 function bubble_model(kind, size, halo)
-    grid = RectilinearGrid(CPU(); size, halo, EXTENT..., topology=(Periodic, Periodic, Bounded))
+    topology = kind == "anelastic_walls_y" ? (Periodic, Bounded, Bounded) : kind == "anelastic_walls_x" ? (Bounded, Flat, Bounded) :
+               (Periodic, Periodic, Bounded)
+    extent = kind == "anelastic_walls_x" ? (x=EXTENT.x, z=EXTENT.z) : EXTENT
+    grid = RectilinearGrid(CPU(); size, halo, extent..., topology)
     constants = ThermodynamicConstants()
     g = constants.gravitational_acceleration
-    θᵢ(x, y, z) = 300 * exp(1e-6 * z / g) + 10 * max(0, 1 - sqrt(x^2 + y^2 + (z - 3000)^2) / 2000)
+    # round-1 kinds: the centred bubble; the newer kinds: off-centre, next to the west / south walls of the walled cases
+    x₀, y₀ = kind in ("anelastic_weno5", "anelastic_centered2", "compressible_weno5") ? (0, 0) : (-4000, -5000)
+    θ₃(x, y, z) = 300 * exp(1e-6 * z / g) + 10 * max(0, 1 - sqrt((x - x₀)^2 + (y - y₀)^2 + (z - 3000)^2) / 2000)
+    θᵢ = kind == "anelastic_walls_x" ? ((x, z) -> θ₃(x, y₀, z)) : θ₃
     if kind == "compressible_weno5"
         dynamics = CompressibleDynamics(SplitExplicitTimeDiscretization(substeps=6); reference_potential_temperature=300)
         model = AtmosphereModel(grid; dynamics, advection=WENO(order=5))
@@ -20,9 +30,22 @@ function bubble_model(kind, size, halo)
         set!(model, ρ=ρᵣ, θ=θᵢ, u=3, v=-2)
     else
         reference_state = ReferenceState(grid, constants; surface_pressure=101325, potential_temperature=300)
-        advection = kind == "anelastic_centered2" ? Centered(order=2) : WENO(order=5)
-        model = AtmosphereModel(grid; dynamics=AnelasticDynamics(reference_state), advection)
-        set!(model, θ=θᵢ, u=3, v=-2)
+        dynamics = AnelasticDynamics(reference_state)
+        if kind == "anelastic_mixed_orders"
+            model = AtmosphereModel(grid; dynamics, momentum_advection=WENO(order=9), scalar_advection=WENO(order=5))
+        elseif kind == "anelastic_smagorinsky"
+            model = AtmosphereModel(grid; dynamics, advection=WENO(order=5), closure=SmagorinskyLilly())
+        else
+            advection = kind == "anelastic_centered2" ? Centered(order=2) : kind == "anelastic_weno9" ? WENO(order=9) : WENO(order=5)
+            model = AtmosphereModel(grid; dynamics, advection)
+        end
+        if kind == "anelastic_walls_x"
+            set!(model, θ=θᵢ)
+        elseif kind == "anelastic_walls_y"
+            set!(model, θ=θᵢ, u=3)                      # no flow through the walls
+        else
+            set!(model, θ=θᵢ, u=3, v=-2)
+        end
     end
     return model
 end
@@ -56,3 +79,9 @@ dump("bubble_32x20x16", "anelastic_weno5", (32, 20, 16), (3, 3, 3); Δt=2.0, ste
 dump("bubble_64x8x32", "anelastic_weno5", (64, 8, 32), (3, 3, 3); Δt=1.0, steps=3)
 dump("bubble_c2_32x20x16", "anelastic_centered2", (32, 20, 16), (3, 3, 3); Δt=2.0, steps=3)
 dump("bubble_cmp_24x16x20", "compressible_weno5", (24, 16, 20), (3, 3, 3); Δt=2.0, steps=2)
+
+dump("bubble_w9_32x20x16", "anelastic_weno9", (32, 20, 16), (5, 5, 5); Δt=2.0, steps=3)
+dump("bubble_mixed_32x20x16", "anelastic_mixed_orders", (32, 20, 16), (5, 5, 5); Δt=2.0, steps=3)
+dump("bubble_smag_32x20x16", "anelastic_smagorinsky", (32, 20, 16), (3, 3, 3); Δt=2.0, steps=3)
+dump("bubble_walls_y_32x16x16", "anelastic_walls_y", (32, 16, 16), (3, 3, 3); Δt=2.0, steps=3)
+dump("bubble_walls_x_64x32", "anelastic_walls_x", (64, 32), (5, 5); Δt=2.0, steps=3)

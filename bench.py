@@ -738,8 +738,14 @@ def run_rank(args):
             decomp.profile = True
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.time_step(dt)
+        # the reference's many_time_steps! (benchmarking/src/timestepping.jl:11-16): K steps with nothing reading the model in between,
+        # issued through the multi-step seam (bz_time_steps_anelastic): every step but the last skips the diagnosis pass, the last one
+        # leaves every field of the model current.  --single-steps issues K separate time_step! calls instead.
+        if hasattr(model, "time_steps") and not args.single_steps:
+            model.time_steps(dt, args.steps, diagnose_last=True)
+        else:
+            for _ in range(args.steps):
+                model.time_step(dt)
         barrier()
         elapsed = time.perf_counter() - t0
         model.profile_enable(False)
@@ -864,6 +870,7 @@ def main():
     ap.add_argument("--workload", choices=("bubble", "config3", "config4", "cbl", "scalar_tendency", "model_tendency"), default="bubble",
                     help="bubble: the headline workload (configs[1]); config3: 1024 x (128 N) x 512 slabs; config4: compressible + "
                          "Kessler 512x512x128 (second milestone, split over the ranks)")
+    ap.add_argument("--single-steps", action="store_true", help="K separate time_step! calls (full diagnosis after every step) instead of the multi-step seam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-full-size", action="store_true", help="skip the 512^3 leg of the CPU baseline (runs only when the host has >= 96 GB free)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the slab decomposition (explicit only)")

@@ -19,7 +19,7 @@ from .compressible import (AcousticRungeKutta3, AcousticSubstepper, Compressible
                            SplitExplicitTimeDiscretization, ThermalDivergenceDamping, DirectDivergenceDamping, UpperSponge,
                            LinearRamp, CubicRamp, Sin2Ramp)
 from .microphysics import SaturationAdjustment, SecantSolver, WarmPhaseEquilibrium  # noqa: F401,E402
-from .model import cell_advection_timescale, nan_checker  # noqa: F401,E402
+from .model import cell_advection_timescale, diagnostics_stale, many_time_steps_, nan_checker  # noqa: F401,E402
 from .microphysics import (DCMIP2016KesslerMicrophysics, KesslerMicrophysicalFields, TetensFormula,  # noqa: F401,E402
                            microphysics_model_update_)
 from .forcings import (BulkDrag, BulkSensibleHeatFlux, BulkVaporFlux, FPlane, FieldBoundaryConditions, FluxBoundaryCondition, Forcing, FrictionVelocityDrag,  # noqa: F401,E402

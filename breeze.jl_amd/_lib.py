@@ -186,6 +186,8 @@ SYMBOLS = {
     "bz_compute_pressure_correction": (C.c_int, [_ctx, _sp, C.c_double]),
     "bz_make_pressure_correction": (C.c_int, [_ctx, _sp, C.c_double]),
     "bz_time_step_anelastic": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double]),
+    "bz_time_steps_anelastic": (C.c_int, [_ctx, _sp, _pp, _pp, C.c_double, C.c_int, C.c_int]),
+    "bz_diagnostics_stale": (C.c_int, [_ctx]),
     "bz_create_slab": (C.c_int, [C.POINTER(_ctx), C.POINTER(bz_grid), C.POINTER(bz_constants),
                                  C.POINTER(bz_reference_state), C.c_int, C.c_int, C.c_int]),
     "bz_slab_info": (C.c_int, [_ctx] + [C.POINTER(C.c_int32)] * 5),

@@ -761,20 +761,37 @@ static int dist_time_step_general(bz_ctx *ctx, const bz_state *s, const bz_progn
     return BZ_OK;
 }
 
-int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
+// an undiagnosed last stage leaves its halo exchange on the side stream: whoever reads `s` next on the main stream joins it first
+int bzi_comm_join_pending(bz_ctx *ctx)
+{
+    BzComm *c = ctx->comm;
+    if (c && c->halo_pending) {
+        BZ_HIP(hipStreamWaitEvent(ctx->stream, c->ev_side, 0));
+        c->halo_pending = false;
+    }
+    return BZ_OK;
+}
+
+int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose)
 {
     BzComm *c = ctx->comm;
     const DevGrid &g = ctx->dg;
+    ctx->lean_step_last = false;
     if (!(ctx->fused_ok && ctx->weno_R == 3 && ctx->scalar_R == 3 && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 && !ctx->has_forcings && !ctx->has_relaxation && !ctx->has_bulk &&
-          !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask && (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32)))
-        return dist_time_step_general(ctx, s, U0, G, dt);
+          !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask && (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32))) {
+        // these tiers start from the stored diagnostics: rebuild them if undiagnosed lean steps came before
+        const int rcs = (ctx->lean_parity || ctx->diagnostics_stale) ? bz_comm_update_state_and_project(ctx, s, G, 1.0, 0) : BZ_OK;
+        return rcs ? rcs : dist_time_step_general(ctx, s, U0, G, dt);
+    }
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};
     BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));
     BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));
     for (int stage = 0; stage < 3; ++stage) {
         const double alpha = alphas[stage];
-        const bool from_state = (stage != 1);
+        // ping-pong parity and the undiagnosed last stage of bz_time_steps_anelastic: as in bz_step.hip
+        const bool from_state = ((stage + ctx->lean_parity) & 1) == 0;
+        const bool full = diagnose && stage == 2;
         const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
         double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
         // The scalar-pair kernel feeds nothing of the pressure solve: with messages in flight (W > 1) it runs on the context's second
@@ -798,11 +815,11 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
             if (rc) return rc;
             BZ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
         }
-        if ((rc = dist_projection(ctx, s, G, alpha * dt, stage < 2, oa, ob, G->rho_theta, G->rho_q, fork))) return rc;
-        // halos of the new state.  After stage 3 rho theta / rho q are back in `s` and the diagnostics are current: exchange them too,
-        // so that every field of `s` is what the per-operator sequence leaves
-        double *na = (stage < 2) ? oa : s->rho_theta, *nb = (stage < 2) ? ob : s->rho_q;
-        const bool async = c->overlap && stage < 2 && (c->W > 1 || c->self_messages);
+        if ((rc = dist_projection(ctx, s, G, alpha * dt, !full, oa, ob, oa, ob, fork))) return rc;
+        // halos of the new state.  After a diagnosed stage 3 rho theta / rho q are back in `s` and the diagnostics are current: exchange
+        // them too, so that every field of `s` is what the per-operator sequence leaves
+        double *na = !full ? oa : s->rho_theta, *nb = !full ? ob : s->rho_q;
+        const bool async = c->overlap && !full && (c->W > 1 || c->self_messages);
         hipStream_t st = async ? c->side : ctx->stream;
         if (async) {
             BZ_HIP(hipEventRecord(c->ev_main, ctx->stream));
@@ -810,14 +827,14 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         }
         {
             ProfileScope ps(ctx, "comm_halo_exchange");
-            if ((rc = state_halo_exchange(ctx, s, na, nb, stage == 2, st))) return rc;
+            if ((rc = state_halo_exchange(ctx, s, na, nb, full, st))) return rc;
         }
         if (async) {
             BZ_HIP(hipEventRecord(c->ev_side, c->side));
             c->halo_pending = true;
         }
     }
-    ctx->G_is_predictor = true;
+    bzi_lean_step_done(ctx, G, diagnose);
     return BZ_OK;
 }
 

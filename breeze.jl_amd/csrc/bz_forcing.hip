@@ -473,31 +473,6 @@ bool bzi_lean_forcings_ok(const bz_ctx *ctx)
            ctx->forcing_flux_energy == 0.0;
 }
 
-// T of the lowest level from the rho theta / rho q the bottom heat / moisture flux has just changed (the lean scalar kernel wrote T of
-// the pre-flux values; the expressions are k_project_diagnose<0>'s, so the bits are those of the full diagnosis)
-__global__ __launch_bounds__(256) void k_lean_bottom_T(DevGrid g, const double *__restrict__ rth, const double *__restrict__ rq,
-                                                       double *__restrict__ T)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
-    if (i >= g.Nx) return;
-    const long long n = g.idx(i, j, 0);
-    const double rc = g.rho[0];
-    const double th = rth[n] / rc, q = rq[n] / rc;
-    const double qd = 1.0 - q;
-    const double Rm = qd * g.Rd + q * g.Rv;
-    const double cpm = qd * g.cpd + q * g.cpv;
-    T[n] = pow(g.p_r[0] / g.pst, Rm / cpm) * th;
-}
-
-int bzi_lean_bottom_temperature(bz_ctx *ctx, const double *rth, const double *rq, double *T)
-{
-    if (ctx->forcing_flux_theta == 0.0 && ctx->forcing_flux_q == 0.0) return BZ_OK;
-    const DevGrid &g = ctx->dg;
-    hipLaunchKernelGGL(k_lean_bottom_T, dim3((g.Nx + 255) / 256, g.Ny), dim3(256), 0, ctx->stream, g, rth, rq, T);
-    BZ_LAUNCH_CHECK();
-    return BZ_OK;
-}
-
 extern "C" int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
     if (!ctx || !s || !G) return BZ_ERR_INVALID;

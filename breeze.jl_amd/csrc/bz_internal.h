@@ -280,7 +280,6 @@ void bzi_read_tuning(bz_tuning &t);
 #define BZ_HALO_YFACE 4      // halo kind bit: the field sits on y faces (rho v, v): wall faces instead of a no-flux row on a Bounded y
 struct bz_ctx;
 bool bzi_lean_forcings_ok(const bz_ctx *ctx);
-int bzi_lean_bottom_temperature(bz_ctx *ctx, const double *rth, const double *rq, double *T);
 
 struct bz_ctx {
     bz_tuning tune;
@@ -329,6 +328,10 @@ struct bz_ctx {
     bool fuse_rk = true;              // whole-step seam: RK update folded into the tendency kernels (BZ_NO_FUSE_RK=1 disables)
     bool G_is_predictor = false;      // after a fused step the G arrays hold predictor momentum, not tendencies
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
+    int lean_parity = 0;              // 1: a multi-step call left rho theta / rho q in the G slots lean_pp_a / lean_pp_b (bz_step.hip: bzi_lean_settle)
+    double *lean_pp_a = nullptr, *lean_pp_b = nullptr;
+    bool diagnostics_stale = false;   // u, v, w, theta, q, T, phi of `s` are older than the prognostic state (bz_time_steps_anelastic without the last diagnosis)
+    bool lean_step_last = false;      // the last step body took the lean tier
     bool lean = true;                 // whole-step seam on prognostic-only kernels (bz_tendency5_kernels.h; BZ_NO_LEAN=1 disables)
     bool lean_xcd = true;             // XCD-contiguous block order of the lean kernels (BZ_NO_XCD=1 disables)
     hipStream_t side_stream = nullptr;   // the scalar-pair kernel of a stage runs here, beside the pressure solve on the main stream
@@ -483,7 +486,10 @@ int bzi_compute_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prog
 int bzi_momentum_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G);
 int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const double *rho3d = nullptr);      // rho3d: coupling density of a compressible context
 int bzi_lean_setup(bz_ctx *ctx);
-int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt);
+int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose = true);
+int bzi_lean_settle(bz_ctx *ctx, const bz_state *s);
+int bzi_comm_join_pending(bz_ctx *ctx);
+void bzi_lean_step_done(bz_ctx *ctx, const bz_prognostic *G, bool diagnosed);
 int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                                     const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt);
 int bzi_compressible_store_initial_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0);

@@ -10,6 +10,8 @@ extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognost
 {
     if (!ctx || !s || (compute_tendencies && !G)) return BZ_ERR_INVALID;
     int rc;
+    if ((rc = bzi_lean_settle(ctx, s))) return rc;      // a multi-step call may have left rho theta / rho q in the G slots
+    ctx->diagnostics_stale = false;
     // fill_halo_regions!(prognostic_fields(model))  (:48) — momentum halos are filled inside
     // bz_compute_velocities (:135-136), the scalars here.
     double *sf[4] = {s->rho_theta, s->rho_q, ctx->dg.rqcl_field, ctx->dg.rqr_field};
@@ -23,40 +25,111 @@ extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognost
     return BZ_OK;
 }
 
-static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt);
+static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose);
 
-extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
-                                      const bz_prognostic *G, double dt)
+// host-side bookkeeping at the end of a lean step (single-device and slab drivers): where the ping-pong pair sits now
+void bzi_lean_step_done(bz_ctx *ctx, const bz_prognostic *G, bool diagnosed)
 {
-    if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
+    ctx->lean_step_last = true;
+    ctx->G_is_predictor = true;
+    if (diagnosed) ctx->lean_parity = 0;      // the diagnosis kernel wrote rho theta / rho q (or their halo images) into `s`
+    else {
+        ctx->lean_parity ^= 1;                // three swaps
+        ctx->lean_pp_a = G->rho_theta; ctx->lean_pp_b = G->rho_q;
+    }
+    ctx->diagnostics_stale = !diagnosed;
+}
+
+// The lean seam ping-pongs rho theta / rho q between their own arrays and the G slots, one swap per stage.  A step that ends with the
+// full diagnosis leaves them in `s`; a step of bz_time_steps_anelastic whose diagnostics nobody reads ends with the momentum-only
+// projection and leaves them where stage 3 wrote them (ctx->lean_parity = 1: in the G slots).  bzi_lean_settle moves them home: every
+// entry point that reads `s` without knowing about the ping-pong calls it first (bz_update_state, the per-operator tendencies, ...).
+int bzi_lean_settle(bz_ctx *ctx, const bz_state *s)
+{
+    if (ctx->comm) { const int rc = bzi_comm_join_pending(ctx); if (rc) return rc; }
+    if (!ctx->lean_parity) return BZ_OK;
+    const DevGrid &g = ctx->dg;
+    const size_t bytes = (size_t)g.Sxy * (g.Nz + 2 * g.Hz) * sizeof(double);
+    BZ_HIP(hipMemcpyAsync(s->rho_theta, ctx->lean_pp_a, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    BZ_HIP(hipMemcpyAsync(s->rho_q, ctx->lean_pp_b, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->lean_parity = 0;
+    return BZ_OK;
+}
+
+static int one_anelastic_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose)
+{
+    // a parked ping-pong pair belongs to the G arrays it was parked in
+    if (ctx->lean_parity && (ctx->lean_pp_a != G->rho_theta || ctx->lean_pp_b != G->rho_q)) {
+        const int rc = bzi_lean_settle(ctx, s);
+        if (rc) return rc;
+    }
     if (ctx->slab_mode) {
-        if (ctx->comm) return bzi_dist_time_step(ctx, s, U0, G, dt);      // the library owns the exchanges (bz_comm.hip)
+        if (ctx->comm) return bzi_dist_time_step(ctx, s, U0, G, dt, diagnose);      // the library owns the exchanges (bz_comm.hip)
         ctx->last_error = "bz_time_step_anelastic: a y-slab context needs a communicator (bz_comm_init_rccl / bz_comm_init_local) "
                           "or a host-side distributed driver";
         return BZ_ERR_UNSUPPORTED;
     }
     // launch-bound grids replay the recorded step (bz_graph.hip); a failed recording has executed nothing and falls through
-    const uint64_t key = bzi_graph_key(ctx, 1, dt, s, sizeof(*s), U0, sizeof(*U0), G, sizeof(*G), nullptr, 0);
+    const int kind = 1 + (diagnose ? 0 : 16) + (ctx->lean_parity ? 32 : 0);
+    const uint64_t key = bzi_graph_key(ctx, kind, dt, s, sizeof(*s), U0, sizeof(*U0), G, sizeof(*G), nullptr, 0);
     bool capture = false;
     int rc;
-    if (bzi_graph_begin(ctx, key, &capture) == 1) return BZ_OK;
-    if (capture) {
-        rc = anelastic_step_body(ctx, s, U0, G, dt);
-        if ((rc = bzi_graph_end(ctx, key, rc)) != -1) return rc;
+    const int parity_before = ctx->lean_parity;
+    if (bzi_graph_begin(ctx, key, &capture) == 1) {
+        // what the recorded body did to the host-side bookkeeping (lean tier only: other tiers never park the pair)
+        if (ctx->lean_step_last) { ctx->lean_parity = diagnose ? 0 : parity_before ^ 1; ctx->diagnostics_stale = !diagnose; }
+        return BZ_OK;
     }
-    return anelastic_step_body(ctx, s, U0, G, dt);
+    if (capture) {
+        rc = anelastic_step_body(ctx, s, U0, G, dt, diagnose);
+        if ((rc = bzi_graph_end(ctx, key, rc)) != -1) return rc;
+        ctx->lean_parity = parity_before;      // the recording executed nothing
+    }
+    return anelastic_step_body(ctx, s, U0, G, dt, diagnose);
 }
 
-static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt)
+extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
+                                      const bz_prognostic *G, double dt)
 {
+    if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
+    return one_anelastic_step(ctx, s, U0, G, dt, true);
+}
+
+// n steps of time_step!(model, dt) in one call — the loop of the reference's benchmark driver, many_time_steps!
+// (/root/reference/benchmarking/src/timestepping.jl:11-16) and of run!(simulation) between two callback / output iterations: nothing
+// reads model.velocities, theta, q^v, T or the pressure anomaly in between, and the lean tendency kernels derive what they need from the
+// prognostic fields.  So every step but (optionally) the last ends its third stage with the momentum-only projection instead of the
+// projection + diagnosis pass (13 words per cell written for host consumers only).  diagnose_last != 0: on return every field and halo
+// of `s` carries the bits n calls of bz_time_step_anelastic leave.  diagnose_last == 0: the prognostic state is current but parked
+// (rho theta / rho q possibly in the G slots) and the diagnostics are stale until bz_update_state(ctx, s, G, 0) — which
+// bz_time_step(s)_anelastic do NOT need: stepping can simply go on.  Tiers other than the lean seam diagnose every step.
+extern "C" int bz_time_steps_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, int n,
+                                       int diagnose_last)
+{
+    if (!ctx || !s || !U0 || !G || n < 0) return BZ_ERR_INVALID;
+    for (int it = 0; it < n; ++it) {
+        const int rc = one_anelastic_step(ctx, s, U0, G, dt, it == n - 1 && diagnose_last);
+        if (rc) return rc;
+    }
+    return BZ_OK;
+}
+
+extern "C" int bz_diagnostics_stale(const bz_ctx *ctx) { return ctx ? (ctx->diagnostics_stale ? 1 : 0) : BZ_ERR_INVALID; }
+
+static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose)
+{
+    ctx->lean_step_last = false;
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
     // walls in y ((Periodic, Bounded, Bounded)) ride the lean seam too (WY kernels, wall rows in the projection kernels); every other
     // configuration with walls steps operator by operator
     const bool walls_lean = ctx->dg.bounded_y && ctx->walls_lean_ok;
-    if ((ctx->fused_ok || walls_lean) && ctx->fuse_rk && ctx->lean && ctx->weno_R == 3 && ctx->scalar_R == 3 && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
+    const bool lean_tier = (ctx->fused_ok || walls_lean) && ctx->fuse_rk && ctx->lean && ctx->weno_R == 3 && ctx->scalar_R == 3 && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
         (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && !ctx->has_relaxation && ctx->n_tracers == 0 && !ctx->bounded_mask &&
-        (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32)) {
+        (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32);
+    // the other tiers start from the stored diagnostics: if undiagnosed lean steps came before (the configuration changed in between), rebuild them
+    if (!lean_tier && (ctx->lean_parity || ctx->diagnostics_stale) && (rc = bz_update_state(ctx, s, G, 0))) return rc;
+    if (lean_tier) {
         // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,
         // q^v, T on the fly (bit-identical to the stored diagnostics), rho theta / rho q ping-pong between their own arrays
         // and the G slots, the projection of stages 1-2 writes momentum only; stage 3 runs the full projection + diagnosis
@@ -66,7 +139,8 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
         BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));        // predictor stay 0
         for (int stage = 0; stage < 3; ++stage) {
             const double alpha = alphas[stage];
-            const bool from_state = (stage != 1);
+            const bool from_state = ((stage + ctx->lean_parity) & 1) == 0;
+            const bool full = diagnose && stage == 2;      // projection + diagnosis (else: momentum-only projection)
             const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
             double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
             if (ctx->side_scalar && !ctx->has_forcings) {
@@ -88,7 +162,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                 // rho q in the stage's output buffers — as the fused-RK tier below does
                 // (the Coriolis / profile terms went into the RK epilogues of the momentum kernels: Lean5::mforce, bz_tendency5.hip)
                 if ((rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, oa, ob, alpha * dt))) return rc;
-                if (stage < 2 && (rc = bzi_lean_bottom_temperature(ctx, oa, ob, s->T))) return rc;
+                // (T is no stored field inside the lean seam any more: the z-momentum kernel of the next stage derives it from oa, ob)
             }
             if (ctx->pchunk) {
                 // chunked pipeline: each level range goes source term -> x transform -> y transform (and, after the vertical solves,
@@ -113,14 +187,14 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                 }
                 if (ctx->side_scalar && !ctx->has_forcings) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 {
-                    ProfileScope ps(ctx, stage < 2 ? "poisson_fft_inverse+project_momentum" : "poisson_fft_inverse+project_and_diagnose");
+                    ProfileScope ps(ctx, !full ? "poisson_fft_inverse+project_momentum" : "poisson_fft_inverse+project_and_diagnose");
                     ctx->profile_mute++;
                     for (int k0 = 0; k0 < g.Nz && !rc; k0 += ch) {
                         rc = bzi_fft_chunk(ctx, k0, false);
                         ctx->kr0 = k0; ctx->krn = ch;
                         if (rc) break;
-                        if (stage < 2) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
-                        else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, G->rho_theta, G->rho_q);
+                        if (!full) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+                        else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, oa, ob);
                     }
                     ctx->krn = 0;
                     ctx->profile_mute--;
@@ -152,19 +226,19 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                     ProfileScope ps(ctx, "poisson_fft_x_inverse");
                     if ((rc = bzi_xf_inverse(ctx))) return rc;
                 }
-                if (stage < 2) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
-                else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, G->rho_theta, G->rho_q);
+                if (!full) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+                else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, oa, ob);
                 if (rc) return rc;
                 continue;
             }
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
             if (ctx->side_scalar && !ctx->has_forcings) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            if (stage < 2) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
-            else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, G->rho_theta, G->rho_q);
+            if (!full) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+            else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, oa, ob);
             if (rc) return rc;
         }
-        ctx->G_is_predictor = true;
+        bzi_lean_step_done(ctx, G, diagnose);
         return BZ_OK;
     }
     // (walls in y: the generic order-7 / 9 kernels are wall-aware, the LDS-tiled order-5 kernels of this tier are not)

@@ -22,6 +22,9 @@
 // element index type of the momentum kernels: 64-bit, so that the +-1, +-2, +-3 neighbours of a row fold into the immediate offset
 // of one address per array and level (with 32-bit unsigned indices every neighbour costs its own address arithmetic: measured
 // +10 % on the x-momentum kernel); the scalar-pair kernel keeps 32-bit indices, which is what lets it fit 128 VGPRs
+#ifndef BZ_KO
+#define BZ_KO 0      // timing experiments only (tools/gpu_knockout.sh): bit n removes one ingredient of k5_scalar_pair; results are then WRONG
+#endif
 typedef long long ix_t;
 typedef unsigned ix32_t;     // z-momentum kernel: 32-bit (138 -> 121 VGPRs, 3 -> 4 waves per SIMD; measured 3.61 -> 2.94 ms)
 
@@ -172,6 +175,14 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
     constexpr int HPT = (NHALO + NT - 1) / NT;          // frame cells per thread
     __shared__ double T[2][2][TR][TC];
     __shared__ double FY[2][2][TY + 1][64];
+    // Zero-field shortcut of the second scalar (rho q of a dry run is identically zero, and the reference advects it all the same:
+    // update_atmosphere_model_state.jl:333-343).  ZF[l % 3] != 0: every staged value of q at level l — the tile and its frame — is +-0.
+    // Then the x / y reconstructions of that level return exactly 0 (WENO of zeros; every variant of bz_weno5) and the fluxes are
+    // exact zeros: the kernel stores 0.0 instead of evaluating them.  The vertical flux takes the same shortcut per wavefront from a
+    // per-thread count of consecutive zero ring tops.  Identical bits either way (the sums of +-0 fluxes the RK update sees are +0 with
+    // or without the shortcut, and alpha (0 + dt * -0) = +0); costs ~8 instructions per level where q is not zero, saves three
+    // reconstructions (~150) where it is.
+    __shared__ int ZF[3];
 
     int bx, by, bz;
     bz_block5(F, bx, by, bz);
@@ -234,16 +245,26 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
         fza = rf * (cf * bz_upB(a[0], a[1], a[2], a[3], a[4], a[5], left, B));
         fzb = rf * (cf * bz_upB(b[0], b[1], b[2], b[3], b[4], b[5], left, B));
     }
+    // consecutive zero values of q at the top of the own column's ring (saturates; 6 = the whole ring)
+    int zrun = 0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) zrun = (b[s] == 0.0) ? zrun + 1 : 0;
+    if (t < 3) ZF[t] = 1;
+    __syncthreads();
     T[0][0][ty + 3][tx + 3] = a[3];
     T[0][1][ty + 3][tx + 3] = b[3];
     {
         const double rh = g.rho[kbeg], rr = g.rrho[kbeg];
+        bool z0 = (b[3] == 0.0);
 #pragma unroll
         for (int q = 0; q < HPT; ++q)
             if (hok[q]) {
+                const double hbv = bz_cdiv(pb[hn[q]], rh, rr);
                 T[0][0][hr[q]][hc[q]] = bz_cdiv(pa[hn[q]], rh, rr);
-                T[0][1][hr[q]][hc[q]] = bz_cdiv(pb[hn[q]], rh, rr);
+                T[0][1][hr[q]][hc[q]] = hbv;
+                z0 = z0 && (hbv == 0.0);
             }
+        if (!__all(z0) && tx == 0) ZF[0] = 0;
     }
     __syncthreads();
 
@@ -253,6 +274,9 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
     // computes, so loads issued at its top were waited for at once — a full memory latency per level and wave)
     double ru_n = ru[n], rv_n = rv[n], rw_n = rw[n + sz];
     double rvtop_n = (tyu == 0 || tyu == TY / 2) ? rv[ntop0] : 0.0;      // top-face duties of the first level: rows 0 and TY / 2
+    // ring tops arrive one level ahead as well: they are consumed mid-level (vertical flux), and a load issued at the top of its own
+    // level sits behind the previous level's stores in the in-order memory counter
+    double ta_nx = pa[n + 3 * sz], tb_nx = pb[n + 3 * sz];
     for (int k = kbeg; k < kend; ++k, n += sz) {
         // ---- loads, issued in the order their values are needed (s_waitcnt counts vector loads in order, so waiting for a load
         //      waits for everything issued before it): ring tops (vertical flux, mid-level), next level's frame cells (staging, end of
@@ -261,22 +285,33 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
         //      latency per level and wave, because the advecting fluxes are the first thing a level computes) ----
         double ha[HPT], hb[HPT];
         const unsigned lev = (unsigned)(k + 1 - kbeg) * sz;
-        const double ta_raw = pa[n + 3 * sz], tb_raw = pb[n + 3 * sz];
+        const double ta_raw = ta_nx, tb_raw = tb_nx;
+        {
+            const unsigned up = (k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz;      // the last level's request stays inside the parent array (unused)
+            ta_nx = pa[n + up]; tb_nx = pb[n + up];
+        }
+        const int lv3 = (k - kbeg) % 3;
+        if (t == 0) ZF[(lv3 + 2) % 3] = 1;      // reset the flag of level k + 2 (set while level k + 1 is staged, at the end of the next trip)
+        const bool zxy = __builtin_amdgcn_readfirstlane(ZF[lv3]) != 0;      // q is zero on the whole staged level k: exact zero x / y fluxes
 #pragma unroll
-        for (int q = 0; q < HPT; ++q) { ha[q] = hok[q] ? pa[hn[q] + lev] : 0.0; hb[q] = hok[q] ? pb[hn[q] + lev] : 0.0; }
-        const double u0a = (E.mode == 2) ? E.u0[n] : 0.0, u0b = (E.mode == 2) ? E.u0b[n] : 0.0;
+        for (int q = 0; q < HPT; ++q) {
+            if (BZ_KO & 2) { ha[q] = ta_raw; hb[q] = tb_raw; }
+            else { ha[q] = hok[q] ? pa[hn[q] + lev] : 0.0; hb[q] = hok[q] ? pb[hn[q] + lev] : 0.0; }
+        }
+        const double u0a = (BZ_KO & 16) ? ta_raw : (E.mode == 2) ? E.u0[n] : 0.0, u0b = (BZ_KO & 16) ? tb_raw : (E.mode == 2) ? E.u0b[n] : 0.0;
         const double ru_t = ru_n, rv_t = rv_n, rw_t = rw_n, rvtop = rvtop_n;
         // The y face above the tile belongs to no row of the tile: one wavefront per field evaluates it, and the duty rotates with the
         // level (field a: row (k - kbeg) mod TY, field b: half a turn later).
         const int turn = (k - kbeg) & (TY - 1);
         const bool duty_a = tyu == turn, duty_b = tyu == ((turn + TY / 2) & (TY - 1));
-        ru_n = ru[n + sz]; rv_n = rv[n + sz]; rw_n = rw[n + 2 * sz];      // level k + 1 (level kend of the last trip is a halo level: in bounds, unused)
+        if (BZ_KO & 32) { ru_n = ta_raw * 1e-3; rv_n = tb_raw; rw_n = ta_raw * 1e-4; } else {
+        ru_n = ru[n + sz]; rv_n = rv[n + sz]; rw_n = rw[n + 2 * sz]; }      // level k + 1 (level kend of the last trip is a halo level: in bounds, unused)
         {
             const int turn_n = (turn + 1) & (TY - 1);
             const bool duty_n = tyu == turn_n || tyu == ((turn_n + TY / 2) & (TY - 1));
             rvtop_n = duty_n ? rv[ntop0 + lev] : 0.0;
         }
-        const double rho = LV.rho(k), rrho = LV.rrho(k), Ax_k = LV.Ax(k), Ay_k = LV.Ay(k), Vi_k = LV.Vinv_c(k), pi_k = LV.pi(k);
+        const double rho = LV.rho(k), rrho = LV.rrho(k), Ax_k = LV.Ax(k), Ay_k = LV.Ay(k), Vi_k = LV.Vinv_c(k);
         const double rho1 = LV.rho(k + 1), rrho1 = LV.rrho(k + 1), rhof1 = LV.rho_f(k + 1), rrhof1 = LV.rrho_f(k + 1);
         const double rho3 = LV.rho(k + 3), rrho3 = LV.rrho(k + 3);
         if (((k - kbeg) & 63) == 0) {       // out-of-wave x flux for the next 64 levels (lane l <-> level k + l)
@@ -321,32 +356,44 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
             fza_hi = rf * (cfz * bz_upB(a[1], a[2], a[3], a[4], a[5], ta, lz, Bz));
         }
         const double tb = bz_cdiv(tb_raw, rho3, rrho3);
-        {
+        zrun = (tb == 0.0) ? min(zrun + 1, 6) : 0;
+        const bool zz = __all(zrun >= 6);      // b[1] .. b[5], tb are all zero in every column of the wavefront: exact zero vertical flux
+        if (zxy) {
+            fxb = 0.0; fyb = 0.0;
+            FY[buf][1][ty][tx] = 0.0;
+            if (duty_b) FY[buf][1][TY][tx] = 0.0;
+        } else {
             const double(*Tk)[TC] = T[buf][1];
             const double *rr_ = Tk[ty + 3] + tx;
+            if (BZ_KO & 128) { fxb = rho * (cfx * b[3]); fyb = rho * (cfy * b[3]); } else {
             fxb = rho * (cfx * bz_up5(rr_[0], rr_[1], rr_[2], b[3], rr_[4], rr_[5], lx));
-            fyb = rho * (cfy * bz_up5y<WY>(Tk[ty][c], Tk[ty + 1][c], Tk[ty + 2][c], b[3], Tk[ty + 4][c], Tk[ty + 5][c], ly, Byj));
+            fyb = rho * (cfy * bz_up5y<WY>(Tk[ty][c], Tk[ty + 1][c], Tk[ty + 2][c], b[3], Tk[ty + 4][c], Tk[ty + 5][c], ly, Byj)); }
             FY[buf][1][ty][tx] = fyb;
             if (duty_b)
                 FY[buf][1][TY][tx] = rho * (cfy2 * bz_up5y<WY>(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2, Byt));
-            fzb_hi = rf * (cfz * bz_upB(b[1], b[2], b[3], b[4], b[5], tb, lz, Bz));
         }
+        if (zz) fzb_hi = 0.0;
+        else fzb_hi = (BZ_KO & 128) ? rf * (cfz * b[3]) : rf * (cfz * bz_upB(b[1], b[2], b[3], b[4], b[5], tb, lz, Bz));
         // the cell's own prognostic values (read three levels ago as ring tops: an L2 / Infinity-Cache hit), requested before the staging
         // arithmetic so that the RK update after the barrier finds them
-        const double pa_n = pa[n], pb_n = pb[n];
+        const double pa_n = (BZ_KO & 4) ? a[3] : pa[n], pb_n = (BZ_KO & 4) ? b[3] : pb[n];
         // ---- stage level k+1 in the other buffer ----
         T[buf ^ 1][0][ty + 3][tx + 3] = a[4];
         T[buf ^ 1][1][ty + 3][tx + 3] = b[4];
         {
             const double rh = rho1, rr = rrho1;
+            bool z1 = (b[4] == 0.0);
 #pragma unroll
             for (int q = 0; q < HPT; ++q)
                 if (hok[q]) {
+                    const double hbv = bz_cdiv(hb[q], rh, rr);
                     T[buf ^ 1][0][hr[q]][hc[q]] = bz_cdiv(ha[q], rh, rr);
-                    T[buf ^ 1][1][hr[q]][hc[q]] = bz_cdiv(hb[q], rh, rr);
+                    T[buf ^ 1][1][hr[q]][hc[q]] = hbv;
+                    z1 = z1 && (hbv == 0.0);
                 }
+            if (!__all(z1) && tx == 0) ZF[(lv3 + 1) % 3] = 0;
         }
-        __syncthreads();
+        if (!(BZ_KO & 64)) __syncthreads();
         // ---- combine, SSP-RK3 update, temperature of the updated cell for the next stage's buoyancy ----
         {
             double na = __shfl_down(fxa, 1), nb = __shfl_down(fxb, 1);
@@ -361,8 +408,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
                 const double rth = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0a, E.u0_out, ga, pa_n, n);
                 const double rq = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0b, E.u0b_out, gb, pb_n, n);
                 F.oa[n] = rth;        // interior only: the projection kernel that follows stores the periodic images
-                F.ob[n] = rq;
-                F.T[n] = bz_temperature5r(g, rth, rq, k, rho, rrho, pi_k);
+                F.ob[n] = rq;         // (the temperature the buoyancy needs is derived from these two by the z-momentum kernel of the next stage)
             }
         }
         fza = fza_hi; fzb = fzb_hi;
@@ -725,13 +771,25 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// z-momentum: k_w_tend_lds<TY, 0> with w = rho_w / Iz(rho_r)(k) derived at staging time and the anelastic buoyancy from the
-// temperature the scalar kernel of the previous stage (or the full diagnosis at the end of the previous step) left for the
-// stage-start state, q = rho q / rho_r.
+// z-momentum: k_w_tend_lds<TY, 0> with w = rho_w / Iz(rho_r)(k) derived at staging time and the anelastic buoyancy from T and q
+// derived from the stage-start rho theta, rho q of the own column (round 4: the scalar kernel used to store T for this kernel —
+// one word per cell and stage written only to be read once; the derivation is a Markstein quotient and, in dry wavefronts, one
+// multiplication by the level's Exner factor).
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double buoyancy5(const DevGrid &g, double T, double rq, int k)
+// buoyancy of a cell from its prognostic densities: T = Pi^(Rm/cpm) theta as bz_temperature5r (the bits of the stored diagnostic),
+// q = rho q / rho_r, then the expression of buoyancy3
+__device__ __forceinline__ double buoyancy5(const DevGrid &g, double rth, double rq, int k, double rho, double rrho, double pi)
 {
-    return buoyancy3(g, T, bz_cdiv(rq, g.rho[k], g.rrho[k]), k);
+    const double th = bz_cdiv(rth, rho, rrho), q = bz_cdiv(rq, rho, rrho);
+    double T;
+    if (__all(q == 0.0)) T = pi * th;
+    else {
+        const double qd = 1.0 - q;
+        const double Rm = qd * g.Rd + q * g.Rv;
+        const double cpm = qd * g.cpd + q * g.cpv;
+        T = bz_exner_pow5(g.p_r[k] / g.pst, Rm / cpm) * th;
+    }
+    return buoyancy3(g, T, q, k);
 }
 
 
@@ -760,7 +818,8 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
     const ix32_t sz = (ix32_t)g.Sxy;
     const bool store = (i < g.Nx) && (j < g.Ny);
     const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
-    const double *__restrict__ pa = L.T, *__restrict__ pb = L.pb;       // temperature, rho q of the stage-start state
+    const double *__restrict__ pa = L.pa, *__restrict__ pb = L.pb;       // rho theta, rho q of the stage-start state
+    const Lev5 LV{L.lev};
     Tend3Fields F;
     F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
     const double Az = g.Az;
@@ -799,7 +858,7 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
         const int B = bz_buffer_center(kbeg - 1, g.Nz);
         const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
         fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
-        b_lo = buoyancy5(g, pa[n - sz], pb[n - sz], kbeg - 1);
+        b_lo = buoyancy5(g, pa[n - sz], pb[n - sz], kbeg - 1, LV.rho(kbeg - 1), LV.rrho(kbeg - 1), LV.pi(kbeg - 1));
     }
     T[0][ty + 3][tc] = wr[3];
     if (hok) T[0][hr][hc] = bz_cdiv(rw[hn], g.rho_f[kbeg], g.rrho_f[kbeg]);
@@ -814,7 +873,7 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
         // ---- prefetch for level k+1 ----
         const double p_h = hok ? rw[hn + lev + sz] : 0.0;
         const double p_top = rw[n + ((k + 4 <= g.Nz + g.Hz) ? 4 * sz : 3 * sz)];
-        const double Tcur = pa[n], rqcur = pb[n];          // consumed mid-level (buoyancy): not worth two more registers each
+        const double Tcur = pa[n], rqcur = pb[n];          // rho theta, rho q: consumed mid-level (buoyancy): not worth two more registers each
         const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
         const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
         const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];
@@ -846,7 +905,7 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
             const double wt = (B == 3) ? bz_symm4(qw[1], qw[2], qw[3], qwnew) : bz_symm2(qw[2], qw[3]);
             fz_hi = wt * bz_upB(wr[1], wr[2], wr[3], wr[4], wr[5], wnew, wt > 0.0, B);
         }
-        const double b_hi = buoyancy5(g, Tcur, rqcur, k);
+        const double b_hi = buoyancy5(g, Tcur, rqcur, k, LV.rho(k), LV.rrho(k), LV.pi(k));
         T[buf ^ 1][ty + 3][tc] = wr[4];
         if (hok) T[buf ^ 1][hr][hc] = bz_cdiv(p_h, g.rho_f[k + 1], g.rrho_f[k + 1]);
         __syncthreads();

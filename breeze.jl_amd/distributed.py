@@ -370,6 +370,20 @@ class LibrarySlabAtmosphereModel(AtmosphereModel):
         self.clock.last_Δt = float(Δt)
         self.clock.iteration += 1
 
+    def time_steps(self, Δt, n, diagnose_last=True):
+        """n distributed steps in one C call (bz_time_steps_anelastic on a slab context): steps whose diagnostics nobody reads end with the
+        momentum-only projection and exchange five halo fields instead of ten."""
+        if n <= 0:
+            return
+        if self.clock.iteration == 0:
+            self._check(self._lib.bz_comm_update_state_and_project(self._ctx, C.byref(self._state), C.byref(self._G), 1.0, 0),
+                        "bz_comm_update_state_and_project")
+        self._check(self._lib.bz_time_steps_anelastic(self._ctx, C.byref(self._state), C.byref(self._U0), C.byref(self._G), float(Δt), int(n),
+                                                      1 if diagnose_last else 0), "bz_time_steps_anelastic")
+        self.clock.time += n * float(Δt)
+        self.clock.last_Δt = float(Δt)
+        self.clock.iteration += int(n)
+
     def comm_info(self):
         """(transport name, bytes this rank has sent, number of exchanges) of the library-owned communicator."""
         name, nbytes, nex = C.c_char_p(), C.c_int64(), C.c_int32()
@@ -675,3 +689,18 @@ class SlabAtmosphereModel(SlabStepper):
         SlabStepper.time_step(self, Δt)
         self.clock.time += Δt
         self.clock.iteration += 1
+
+    def time_steps(self, Δt, n, diagnose_last=True):
+        """n steps in one C call through the library transport (bz_time_steps_anelastic on a slab context: steps whose diagnostics nobody
+        reads end with the momentum-only projection and exchange five halo fields instead of ten); the torch transport steps one by one."""
+        n = int(n)
+        if n <= 0:
+            return
+        if self.transport == "torch":
+            for _ in range(n):
+                self.time_step(Δt)
+            return
+        self._check(self._lib.bz_time_steps_anelastic(self._ctx, C.byref(self._state), C.byref(self._U0), C.byref(self._G), float(Δt), n,
+                                                      1 if diagnose_last else 0), "bz_time_steps_anelastic")
+        self.clock.time += n * Δt
+        self.clock.iteration += n

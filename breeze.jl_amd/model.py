@@ -460,6 +460,12 @@ class AtmosphereModel:
     def time_step(self, Δt):
         return time_step_(self, Δt)
 
+    def time_steps(self, Δt, n, diagnose_last=True):
+        """n × time_step!(model, Δt) in one C call (bz_time_steps_anelastic): the reference's many_time_steps! loop
+        (/root/reference/benchmarking/src/timestepping.jl:11-16) and run!'s stretch between two callback iterations.  With
+        diagnose_last=False the velocities / θ / qᵛ / T / pressure anomaly stay stale until update_state_(model) (stepping may go on)."""
+        return many_time_steps_(self, Δt, n, diagnose_last)
+
     def synchronize(self):
         self._check(self._lib.bz_sync(self._ctx), "bz_sync")
 
@@ -699,6 +705,24 @@ def time_step_(model, Δt, whole_step=True):
     model.clock.time += Δt
     model.clock.last_Δt = float(Δt)
     model.clock.iteration += 1
+
+
+def many_time_steps_(model, Δt, n, diagnose_last=True):
+    """many_time_steps!(model, Δt, n) of the reference's benchmark driver through the multi-step seam."""
+    n = int(n)
+    if n <= 0:
+        return
+    if model.clock.iteration == 0:       # maybe_prepare_first_time_step!
+        update_state_(model, compute_tendencies=True)
+    model._check(model._lib.bz_time_steps_anelastic(model._ctx, C.byref(model._state), C.byref(model._U0), C.byref(model._G),
+                                                    float(Δt), n, 1 if diagnose_last else 0), "bz_time_steps_anelastic")
+    model.clock.time += n * Δt
+    model.clock.last_Δt = float(Δt)
+    model.clock.iteration += n
+
+
+def diagnostics_stale(model):
+    return bool(model._lib.bz_diagnostics_stale(model._ctx))
 
 
 def cell_advection_timescale(model, formulation="ThreeDimensional"):

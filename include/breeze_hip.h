@@ -189,6 +189,20 @@ int bz_make_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt);
 int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
                            const bz_prognostic *G, double dt);
 
+/* n calls of time_step!(model, dt) with nothing reading the model in between: the loop of the reference's benchmark driver,
+ * many_time_steps! (benchmarking/src/timestepping.jl:11-16), and of run!(simulation) between two callback / output iterations
+ * (an IterationInterval- / TimeInterval-aware host calls it with n = the distance to the next actuation).
+ * On the lean whole-step tier (dry / vapour-only theta-formulation models, WENO order 5) the tendency kernels derive u, v, w, theta,
+ * q^v, T from the prognostic fields, so every step but the last ends with the momentum-only projection and skips the projection +
+ * diagnosis pass whose 13 output words per cell only host consumers read; the other tiers diagnose every step.
+ *   diagnose_last != 0: on return every field and halo of `s` holds the bits n calls of bz_time_step_anelastic leave.
+ *   diagnose_last == 0: the prognostic state is current but the diagnostics (and pressure_anomaly) are stale and rho_theta / rho_q may be
+ *     parked in G->rho_theta / G->rho_q (the kernels' ping-pong partner).  Stepping may simply continue (either entry point);
+ *     before anything else reads `s`, call bz_update_state(ctx, s, G, 0).  bz_diagnostics_stale(ctx) reports the flag. */
+int bz_time_steps_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
+                            const bz_prognostic *G, double dt, int n, int diagnose_last);
+int bz_diagnostics_stale(const bz_ctx *ctx);
+
 /* ---- y-slab decomposition: one process per GPU --------------------------------------------------
  * The reference re-exports Oceananigans' Distributed architecture (src/Breeze.jl:172,183,209) and has no
  * distributed code of its own; these entry points are the rank-local kernels of this repo's decomposition.

@@ -101,6 +101,41 @@ function OceananigansTimeSteppers.time_step!(model::HIPModel, Δt; callbacks=[])
     return nothing
 end
 
+# Multi-step seam: n steps with nothing reading the model in between — many_time_steps! of the benchmark driver
+# (benchmarking/src/timestepping.jl:11-16) and the stretch of run!(simulation) up to the next callback / output-writer actuation.
+# Every step but the last skips the projection + diagnosis pass (model.velocities, θ, qᵛ, T, pressure anomaly are host-side products);
+# diagnose_last = true leaves exactly what n calls of time_step! leave.
+function many_time_steps!(model::HIPModel, Δt, n::Integer; diagnose_last::Bool=true)
+    n <= 0 && return nothing
+    ctx = context(model)
+    model.clock.iteration == 0 && update_state!(model; compute_tendencies=true)
+    rc = ccall((:bz_time_steps_anelastic, libbreeze_hip), Cint,
+               (Ptr{Cvoid}, Ref{BzState}, Ref{BzPrognostic}, Ref{BzPrognostic}, Cdouble, Cint, Cint),
+               ctx, state(model), prognostic(model.timestepper.U⁰), prognostic(model.timestepper.Gⁿ), Δt, n, diagnose_last ? 1 : 0)
+    check(rc, "bz_time_steps_anelastic", ctx)
+    for _ in 1:n
+        tick!(model.clock, Δt)
+    end
+    return nothing
+end
+
+# iterations until something scheduled on the simulation wants to look at the model (IterationInterval schedules; any other schedule: 1)
+function iterations_to_next_actuation(sim)
+    n = sim.stop_iteration - sim.model.clock.iteration
+    for item in Iterators.flatten((values(sim.callbacks), values(sim.output_writers), values(sim.diagnostics)))
+        sched = item.schedule
+        n = sched isa IterationInterval ? min(n, sched.interval - mod(sim.model.clock.iteration - sched.offset, sched.interval)) : 1
+    end
+    return max(1, Int(min(n, typemax(Int32))))
+end
+
+# Simulation time_step! for the HIP model: fixed-Δt stretches between actuations go through the multi-step seam
+function time_steps_to_next_actuation!(sim)
+    n = iterations_to_next_actuation(sim)
+    many_time_steps!(sim.model, sim.Δt, n; diagnose_last=true)
+    return n
+end
+
 # Per-operator seams (src/AtmosphereModels/update_atmosphere_model_state.jl:41-68; src/AnelasticEquations/anelastic_time_stepping.jl:26-78)
 function OceananigansTimeSteppers.update_state!(model::HIPModel, callbacks=[]; compute_tendencies=true)
     ctx = context(model)

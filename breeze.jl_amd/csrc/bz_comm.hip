@@ -780,45 +780,50 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
     if (!(ctx->fused_ok && ctx->weno_R == 3 && ctx->scalar_R == 3 && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 && !ctx->has_forcings && !ctx->has_relaxation && !ctx->has_bulk &&
           !ctx->has_closure && ctx->n_tracers == 0 && !ctx->bounded_mask && (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32))) {
         // these tiers start from the stored diagnostics: rebuild them if undiagnosed lean steps came before
-        const int rcs = (ctx->lean_parity || ctx->diagnostics_stale) ? bz_comm_update_state_and_project(ctx, s, G, 1.0, 0) : BZ_OK;
+        const int rcs = ctx->diagnostics_stale ? bz_comm_update_state_and_project(ctx, s, G, 1.0, 0) : BZ_OK;
         return rcs ? rcs : dist_time_step_general(ctx, s, U0, G, dt);
     }
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};
     BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));
     BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));
+    BZ_HIP(hipMemsetAsync(U0->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));
+    BZ_HIP(hipMemsetAsync(U0->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));
     for (int stage = 0; stage < 3; ++stage) {
         const double alpha = alphas[stage];
-        // ping-pong parity and the undiagnosed last stage of bz_time_steps_anelastic: as in bz_step.hip
-        const bool from_state = ((stage + ctx->lean_parity) & 1) == 0;
+        // buffer rotation and the undiagnosed last stage of bz_time_steps_anelastic: as in bz_step.hip (bzi_lean_stage)
         const bool full = diagnose && stage == 2;
-        const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
-        double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
+        LeanStage LS;
+        bzi_lean_stage(s, U0, G, stage, &LS);
+        const bz_state *sin = &LS.sin, *sout = &LS.sout;
+        const bz_prognostic *u0 = &LS.u0;
+        const double *pa = LS.pa, *pb = LS.pb;
+        double *oa = LS.oa, *ob = LS.ob;
         // The scalar-pair kernel feeds nothing of the pressure solve: with messages in flight (W > 1) it runs on the context's second
         // stream beside the source term, the transforms and both all-to-alls, and is joined before the projection kernel.
         const bool fork = (c->W > 1 || c->self_messages || ctx->side_scalar) && !ctx->tune.comm_no_side_scalar;
         const int first_part = fork ? 1 : 3;
         if (c->halo_pending) {
             // the halos of the stage-start state are still travelling on the side stream: interior tile rows first
-            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 1, first_part))) return rc;
+            if ((rc = bzi_tendencies_lean(ctx, sin, u0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 1, first_part))) return rc;
             BZ_HIP(hipStreamWaitEvent(ctx->stream, c->ev_side, 0));
             c->halo_pending = false;
-            if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 2, first_part))) return rc;
-        } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, first_part))) return rc;
+            if ((rc = bzi_tendencies_lean(ctx, sin, u0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 2, first_part))) return rc;
+        } else if ((rc = bzi_tendencies_lean(ctx, sin, u0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, first_part))) return rc;
         if (fork) {
             BZ_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
             BZ_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
             hipStream_t keep = ctx->stream;
             ctx->stream = ctx->side_stream;
-            rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 2);
+            rc = bzi_tendencies_lean(ctx, sin, u0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 2);
             ctx->stream = keep;
             if (rc) return rc;
             BZ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
         }
-        if ((rc = dist_projection(ctx, s, G, alpha * dt, !full, oa, ob, oa, ob, fork))) return rc;
+        if ((rc = dist_projection(ctx, full ? s : sout, G, alpha * dt, !full, oa, ob, oa, ob, fork))) return rc;
         // halos of the new state.  After a diagnosed stage 3 rho theta / rho q are back in `s` and the diagnostics are current: exchange
         // them too, so that every field of `s` is what the per-operator sequence leaves
-        double *na = !full ? oa : s->rho_theta, *nb = !full ? ob : s->rho_q;
+        double *na = oa, *nb = ob;      // (a diagnosed stage 3 writes in place: oa, ob are the state arrays)
         const bool async = c->overlap && !full && (c->W > 1 || c->self_messages);
         hipStream_t st = async ? c->side : ctx->stream;
         if (async) {
@@ -827,14 +832,14 @@ int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         }
         {
             ProfileScope ps(ctx, "comm_halo_exchange");
-            if ((rc = state_halo_exchange(ctx, s, na, nb, full, st))) return rc;
+            if ((rc = state_halo_exchange(ctx, full ? s : sout, na, nb, full, st))) return rc;
         }
         if (async) {
             BZ_HIP(hipEventRecord(c->ev_side, c->side));
             c->halo_pending = true;
         }
     }
-    bzi_lean_step_done(ctx, G, diagnose);
+    bzi_lean_step_done(ctx, diagnose);
     return BZ_OK;
 }
 

@@ -102,6 +102,7 @@ __device__ __forceinline__ double bz_rk_apply_pre(int mode, double dt, double al
                                                   double uold, long long n)
 {
     if (mode == 1) { u0_out[n] = uold; u0v = uold; }
+    else if (mode == 3) u0v = uold;      // first stage of the lean seam: the stage-start array itself stays intact as U0 (bz_step.hip), nothing is stored
     return oma * u0v + alpha * (uold + dt * G);
 }
 #endif
@@ -328,8 +329,6 @@ struct bz_ctx {
     bool fuse_rk = true;              // whole-step seam: RK update folded into the tendency kernels (BZ_NO_FUSE_RK=1 disables)
     bool G_is_predictor = false;      // after a fused step the G arrays hold predictor momentum, not tendencies
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
-    int lean_parity = 0;              // 1: a multi-step call left rho theta / rho q in the G slots lean_pp_a / lean_pp_b (bz_step.hip: bzi_lean_settle)
-    double *lean_pp_a = nullptr, *lean_pp_b = nullptr;
     bool diagnostics_stale = false;   // u, v, w, theta, q, T, phi of `s` are older than the prognostic state (bz_time_steps_anelastic without the last diagnosis)
     bool lean_step_last = false;      // the last step body took the lean tier
     bool lean = true;                 // whole-step seam on prognostic-only kernels (bz_tendency5_kernels.h; BZ_NO_LEAN=1 disables)
@@ -487,9 +486,10 @@ int bzi_momentum_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_pro
 int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const double *rho3d = nullptr);      // rho3d: coupling density of a compressible context
 int bzi_lean_setup(bz_ctx *ctx);
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose = true);
-int bzi_lean_settle(bz_ctx *ctx, const bz_state *s);
 int bzi_comm_join_pending(bz_ctx *ctx);
-void bzi_lean_step_done(bz_ctx *ctx, const bz_prognostic *G, bool diagnosed);
+void bzi_lean_step_done(bz_ctx *ctx, bool diagnosed);
+struct LeanStage;
+void bzi_lean_stage(const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, int stage, LeanStage *L);
 int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                                     const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt);
 int bzi_compressible_store_initial_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0);
@@ -517,6 +517,14 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double
 int bzi_project_lean(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below,
                      const bz_prognostic *predictor, double *sa, double *sb);
 // lean whole-step tendencies (bz_tendency5.hip): prognostic-only inputs, rho theta / rho q advance from (pa, pb) into (oa, ob)
+// Buffer rotation of the lean seam (bz_step.hip: bzi_lean_stage): where stage `stage` reads and writes
+struct LeanStage {
+    bz_state sin;             // `s` with rho_u, rho_v, rho_w pointing at the stage-start momentum (stage 1: the state arrays, then the U0 slots)
+    bz_state sout;            // `s` with rho_u, rho_v, rho_w pointing at where the projection of the stage writes (stages 1-2: U0 slots, stage 3: state)
+    bz_prognostic u0;         // the step-start fields: the state arrays themselves, intact until the last projection / scalar update of the step
+    const double *pa, *pb;    // stage-start rho theta, rho q
+    double *oa, *ob;          // updated rho theta, rho q
+};
 int bzi_tendencies_lean(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, const double *pa,
                         const double *pb, double *oa, double *ob, double dt, double alpha, bool first, int rows = 0, int which = 3);
 int bzi_tendencies_fused_rk(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,

@@ -10,7 +10,7 @@ extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognost
 {
     if (!ctx || !s || (compute_tendencies && !G)) return BZ_ERR_INVALID;
     int rc;
-    if ((rc = bzi_lean_settle(ctx, s))) return rc;      // a multi-step call may have left rho theta / rho q in the G slots
+    if (ctx->comm && (rc = bzi_comm_join_pending(ctx))) return rc;      // an undiagnosed last stage leaves its halo exchange on the side stream
     ctx->diagnostics_stale = false;
     // fill_halo_regions!(prognostic_fields(model))  (:48) — momentum halos are filled inside
     // bz_compute_velocities (:135-136), the scalars here.
@@ -28,41 +28,36 @@ extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognost
 static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose);
 
 // host-side bookkeeping at the end of a lean step (single-device and slab drivers): where the ping-pong pair sits now
-void bzi_lean_step_done(bz_ctx *ctx, const bz_prognostic *G, bool diagnosed)
+void bzi_lean_step_done(bz_ctx *ctx, bool diagnosed)
 {
     ctx->lean_step_last = true;
     ctx->G_is_predictor = true;
-    if (diagnosed) ctx->lean_parity = 0;      // the diagnosis kernel wrote rho theta / rho q (or their halo images) into `s`
-    else {
-        ctx->lean_parity ^= 1;                // three swaps
-        ctx->lean_pp_a = G->rho_theta; ctx->lean_pp_b = G->rho_q;
-    }
     ctx->diagnostics_stale = !diagnosed;
 }
 
-// The lean seam ping-pongs rho theta / rho q between their own arrays and the G slots, one swap per stage.  A step that ends with the
-// full diagnosis leaves them in `s`; a step of bz_time_steps_anelastic whose diagnostics nobody reads ends with the momentum-only
-// projection and leaves them where stage 3 wrote them (ctx->lean_parity = 1: in the G slots).  bzi_lean_settle moves them home: every
-// entry point that reads `s` without knowing about the ping-pong calls it first (bz_update_state, the per-operator tendencies, ...).
-int bzi_lean_settle(bz_ctx *ctx, const bz_state *s)
+// Buffer rotation of the lean seam (round 4).  Three sets of prognostic arrays take part: A = the state `s`, B = the G slots,
+// C = the U0 slots.  Nothing is ever copied into U0 (store_initial_state!, ssp_runge_kutta_3.jl:180-186, has no pass and no store
+// of its own): the state arrays stay intact as "U0" until the last writer of the step.
+//   momentum   tendency + RK kernels: stencils from A (stage 1) / C (stages 2, 3), u0 from A, predictor -> B;
+//              projection: B -> C (stages 1, 2), B -> A (stage 3, when nothing reads A any more)
+//   scalars    stage 1: A -> B;  stage 2: stencils from B, u0 from A -> C;  stage 3: stencils from C, u0 from A -> A in place
+//              (a thread reads A only at its own cell, before it writes it)
+// so every step ends with the whole prognostic state in `s`, diagnosed or not.  The U0 arrays are the time stepper's scratch
+// (as in the reference, where nothing reads U0 outside time_step!).
+void bzi_lean_stage(const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, int stage, LeanStage *L)
 {
-    if (ctx->comm) { const int rc = bzi_comm_join_pending(ctx); if (rc) return rc; }
-    if (!ctx->lean_parity) return BZ_OK;
-    const DevGrid &g = ctx->dg;
-    const size_t bytes = (size_t)g.Sxy * (g.Nz + 2 * g.Hz) * sizeof(double);
-    BZ_HIP(hipMemcpyAsync(s->rho_theta, ctx->lean_pp_a, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    BZ_HIP(hipMemcpyAsync(s->rho_q, ctx->lean_pp_b, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    ctx->lean_parity = 0;
-    return BZ_OK;
+    L->sin = *s; L->sout = *s;
+    if (stage > 0) { L->sin.rho_u = U0->rho_u; L->sin.rho_v = U0->rho_v; L->sin.rho_w = U0->rho_w; }
+    if (stage < 2) { L->sout.rho_u = U0->rho_u; L->sout.rho_v = U0->rho_v; L->sout.rho_w = U0->rho_w; }
+    L->u0.rho_u = s->rho_u; L->u0.rho_v = s->rho_v; L->u0.rho_w = s->rho_w; L->u0.rho_theta = s->rho_theta; L->u0.rho_q = s->rho_q;
+    L->pa = stage == 0 ? s->rho_theta : stage == 1 ? G->rho_theta : U0->rho_theta;
+    L->pb = stage == 0 ? s->rho_q : stage == 1 ? G->rho_q : U0->rho_q;
+    L->oa = stage == 0 ? G->rho_theta : stage == 1 ? U0->rho_theta : s->rho_theta;
+    L->ob = stage == 0 ? G->rho_q : stage == 1 ? U0->rho_q : s->rho_q;
 }
 
 static int one_anelastic_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose)
 {
-    // a parked ping-pong pair belongs to the G arrays it was parked in
-    if (ctx->lean_parity && (ctx->lean_pp_a != G->rho_theta || ctx->lean_pp_b != G->rho_q)) {
-        const int rc = bzi_lean_settle(ctx, s);
-        if (rc) return rc;
-    }
     if (ctx->slab_mode) {
         if (ctx->comm) return bzi_dist_time_step(ctx, s, U0, G, dt, diagnose);      // the library owns the exchanges (bz_comm.hip)
         ctx->last_error = "bz_time_step_anelastic: a y-slab context needs a communicator (bz_comm_init_rccl / bz_comm_init_local) "
@@ -70,20 +65,17 @@ static int one_anelastic_step(bz_ctx *ctx, const bz_state *s, const bz_prognosti
         return BZ_ERR_UNSUPPORTED;
     }
     // launch-bound grids replay the recorded step (bz_graph.hip); a failed recording has executed nothing and falls through
-    const int kind = 1 + (diagnose ? 0 : 16) + (ctx->lean_parity ? 32 : 0);
+    const int kind = 1 + (diagnose ? 0 : 16);
     const uint64_t key = bzi_graph_key(ctx, kind, dt, s, sizeof(*s), U0, sizeof(*U0), G, sizeof(*G), nullptr, 0);
     bool capture = false;
     int rc;
-    const int parity_before = ctx->lean_parity;
     if (bzi_graph_begin(ctx, key, &capture) == 1) {
-        // what the recorded body did to the host-side bookkeeping (lean tier only: other tiers never park the pair)
-        if (ctx->lean_step_last) { ctx->lean_parity = diagnose ? 0 : parity_before ^ 1; ctx->diagnostics_stale = !diagnose; }
+        if (ctx->lean_step_last) ctx->diagnostics_stale = !diagnose;      // the host-side bookkeeping of the recorded body
         return BZ_OK;
     }
     if (capture) {
         rc = anelastic_step_body(ctx, s, U0, G, dt, diagnose);
         if ((rc = bzi_graph_end(ctx, key, rc)) != -1) return rc;
-        ctx->lean_parity = parity_before;      // the recording executed nothing
     }
     return anelastic_step_body(ctx, s, U0, G, dt, diagnose);
 }
@@ -100,9 +92,9 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
 // reads model.velocities, theta, q^v, T or the pressure anomaly in between, and the lean tendency kernels derive what they need from the
 // prognostic fields.  So every step but (optionally) the last ends its third stage with the momentum-only projection instead of the
 // projection + diagnosis pass (13 words per cell written for host consumers only).  diagnose_last != 0: on return every field and halo
-// of `s` carries the bits n calls of bz_time_step_anelastic leave.  diagnose_last == 0: the prognostic state is current but parked
-// (rho theta / rho q possibly in the G slots) and the diagnostics are stale until bz_update_state(ctx, s, G, 0) — which
-// bz_time_step(s)_anelastic do NOT need: stepping can simply go on.  Tiers other than the lean seam diagnose every step.
+// of `s` carries the bits n calls of bz_time_step_anelastic leave.  diagnose_last == 0: the prognostic fields of `s` are current, the
+// diagnostics are stale until bz_update_state(ctx, s, G, 0) — which bz_time_step(s)_anelastic do NOT need: stepping can simply go
+// on.  Tiers other than the lean seam diagnose every step.
 extern "C" int bz_time_steps_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, int n,
                                        int diagnose_last)
 {
@@ -128,7 +120,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
         (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && !ctx->has_relaxation && ctx->n_tracers == 0 && !ctx->bounded_mask &&
         (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32);
     // the other tiers start from the stored diagnostics: if undiagnosed lean steps came before (the configuration changed in between), rebuild them
-    if (!lean_tier && (ctx->lean_parity || ctx->diagnostics_stale) && (rc = bz_update_state(ctx, s, G, 0))) return rc;
+    if (!lean_tier && ctx->diagnostics_stale && (rc = bz_update_state(ctx, s, G, 0))) return rc;
     if (lean_tier) {
         // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,
         // q^v, T on the fly (bit-identical to the stored diagnostics), rho theta / rho q ping-pong between their own arrays
@@ -136,32 +128,37 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
         // kernel, so on return every field of `s` (halos included) is what the per-operator sequence leaves.
         const DevGrid &g = ctx->dg;
         BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));                 // wall faces of the
-        BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));        // predictor stay 0
+        BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));        // predictor stay 0,
+        BZ_HIP(hipMemsetAsync(U0->rho_w + g.Sxy * g.Hz, 0, g.Sxy * sizeof(double), ctx->stream));                // and so do those of the
+        BZ_HIP(hipMemsetAsync(U0->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));       // projected momentum of stages 1-2
         for (int stage = 0; stage < 3; ++stage) {
             const double alpha = alphas[stage];
-            const bool from_state = ((stage + ctx->lean_parity) & 1) == 0;
             const bool full = diagnose && stage == 2;      // projection + diagnosis (else: momentum-only projection)
-            const double *pa = from_state ? s->rho_theta : G->rho_theta, *pb = from_state ? s->rho_q : G->rho_q;
-            double *oa = from_state ? G->rho_theta : s->rho_theta, *ob = from_state ? G->rho_q : s->rho_q;
+            LeanStage LS;
+            bzi_lean_stage(s, U0, G, stage, &LS);
+            const bz_state *sin = &LS.sin, *sout = &LS.sout;
+            const bz_prognostic *u0 = &LS.u0;
+            const double *pa = LS.pa, *pb = LS.pb;
+            double *oa = LS.oa, *ob = LS.ob;
             if (ctx->side_scalar && !ctx->has_forcings) {
                 // the scalar-pair kernel feeds nothing of the pressure solve: it runs on the side stream beside the source term,
                 // the transforms and the Thomas solve (issue-bound stencil kernel next to bandwidth-bound streaming kernels)
-                if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 1))) return rc;
+                if ((rc = bzi_tendencies_lean(ctx, sin, u0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 1))) return rc;
                 BZ_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
                 BZ_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
                 hipStream_t keep = ctx->stream;
                 ctx->stream = ctx->side_stream;
-                rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 2);
+                rc = bzi_tendencies_lean(ctx, sin, u0, G, pa, pb, oa, ob, dt, alpha, stage == 0, 0, 2);
                 ctx->stream = keep;
                 if (rc) return rc;
                 BZ_HIP(hipEventRecord(ctx->ev_join, ctx->side_stream));
-            } else if ((rc = bzi_tendencies_lean(ctx, s, U0, G, pa, pb, oa, ob, dt, alpha, stage == 0))) return rc;
+            } else if ((rc = bzi_tendencies_lean(ctx, sin, u0, G, pa, pb, oa, ob, dt, alpha, stage == 0))) return rc;
             if (ctx->has_forcings) {
                 // the bottom fluxes of the stage (bzi_lean_forcings_ok), evaluated from the intact previous-stage momentum and added,
                 // weighted alpha dt, to what the fused RK updates just wrote: the predictor momentum in the G slots and rho theta /
                 // rho q in the stage's output buffers — as the fused-RK tier below does
                 // (the Coriolis / profile terms went into the RK epilogues of the momentum kernels: Lean5::mforce, bz_tendency5.hip)
-                if ((rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, oa, ob, alpha * dt))) return rc;
+                if ((rc = bzi_flux_bc(ctx, sin, G->rho_u, G->rho_v, oa, ob, alpha * dt))) return rc;
                 // (T is no stored field inside the lean seam any more: the z-momentum kernel of the next stage derives it from oa, ob)
             }
             if (ctx->pchunk) {
@@ -193,7 +190,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                         rc = bzi_fft_chunk(ctx, k0, false);
                         ctx->kr0 = k0; ctx->krn = ch;
                         if (rc) break;
-                        if (!full) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+                        if (!full) rc = bzi_project_lean(ctx, sout, alpha * dt, nullptr, nullptr, G, oa, ob);
                         else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, oa, ob);
                     }
                     ctx->krn = 0;
@@ -226,7 +223,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                     ProfileScope ps(ctx, "poisson_fft_x_inverse");
                     if ((rc = bzi_xf_inverse(ctx))) return rc;
                 }
-                if (!full) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+                if (!full) rc = bzi_project_lean(ctx, sout, alpha * dt, nullptr, nullptr, G, oa, ob);
                 else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, oa, ob);
                 if (rc) return rc;
                 continue;
@@ -234,11 +231,11 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             if ((rc = bzi_poisson_source_fused(ctx, s, alpha * dt, nullptr, G))) return rc;
             if ((rc = bzi_poisson_spectral(ctx))) return rc;
             if (ctx->side_scalar && !ctx->has_forcings) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            if (!full) rc = bzi_project_lean(ctx, s, alpha * dt, nullptr, nullptr, G, oa, ob);
+            if (!full) rc = bzi_project_lean(ctx, sout, alpha * dt, nullptr, nullptr, G, oa, ob);
             else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, oa, ob);
             if (rc) return rc;
         }
-        bzi_lean_step_done(ctx, G, diagnose);
+        bzi_lean_step_done(ctx, diagnose);
         return BZ_OK;
     }
     // (walls in y: the generic order-7 / 9 kernels are wall-aware, the LDS-tiled order-5 kernels of this tier are not)

@@ -96,7 +96,7 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
 {
     const DevGrid &g = ctx->dg;
     RKEpilogue E;
-    E.mode = first ? 1 : 2; E.dt = dt; E.alpha = alpha; E.oma = 1.0 - alpha;
+    E.mode = first ? 3 : 2; E.dt = dt; E.alpha = alpha; E.oma = 1.0 - alpha;      // 3: first stage, U0 is the stage-start array itself: nothing stored
     Lean5 L;
     L.ru = s->rho_u; L.rv = s->rho_v; L.rw = s->rho_w; L.pa = pa; L.pb = pb; L.oa = oa; L.ob = ob; L.out = nullptr;
     L.T = s->T;

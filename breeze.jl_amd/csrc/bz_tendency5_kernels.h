@@ -60,6 +60,15 @@ static_assert(sizeof(LevRow5) == 8 * sizeof(double), "LevRow5 is eight reals");
 // i.e. five waves per SIMD = still two workgroups).  Measured at 512^3 Float32: scalar-pair kernel 2.04 -> 1.88 ms with three spilled
 // registers; the z-momentum kernel and the forcing variant of the y-momentum kernel spill eight and lose 7-13 %, so they keep the default.
 #define BZ_LEAN_WAVES (sizeof(double) == 8 ? 4 : 6)
+// Round-4 additions to the scalar-pair kernel — the zero-field shortcut of the second scalar and ring tops requested one level ahead —
+// cost ~8 registers: in the Float32 build (80 registers at six waves per SIMD) they spilled 19 and the kernel went from 1.80 to 2.48 ms
+// per launch at 512^3, so they are Float64-only until the Float32 kernels are written for their own register budget.
+#ifndef BZ5_ZERO_SHORTCUT
+#define BZ5_ZERO_SHORTCUT (sizeof(double) == 8)
+#endif
+#ifndef BZ5_TOPS_AHEAD
+#define BZ5_TOPS_AHEAD (sizeof(double) == 8)
+#endif
 
 struct Lean5 {
     const double *ru, *rv, *rw;      // stage-start momentum (halos valid)
@@ -247,10 +256,12 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
     }
     // consecutive zero values of q at the top of the own column's ring (saturates; 6 = the whole ring)
     int zrun = 0;
+    if constexpr (BZ5_ZERO_SHORTCUT) {
 #pragma unroll
-    for (int s = 0; s < 6; ++s) zrun = (b[s] == 0.0) ? zrun + 1 : 0;
-    if (t < 3) ZF[t] = 1;
-    __syncthreads();
+        for (int s = 0; s < 6; ++s) zrun = (b[s] == 0.0) ? zrun + 1 : 0;
+        if (t < 3) ZF[t] = 1;
+        __syncthreads();
+    }
     T[0][0][ty + 3][tx + 3] = a[3];
     T[0][1][ty + 3][tx + 3] = b[3];
     {
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
                 T[0][1][hr[q]][hc[q]] = hbv;
                 z0 = z0 && (hbv == 0.0);
             }
-        if (!__all(z0) && tx == 0) ZF[0] = 0;
+        if (BZ5_ZERO_SHORTCUT && !__all(z0) && tx == 0) ZF[0] = 0;
     }
     __syncthreads();
 
@@ -276,7 +287,8 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
     double rvtop_n = (tyu == 0 || tyu == TY / 2) ? rv[ntop0] : 0.0;      // top-face duties of the first level: rows 0 and TY / 2
     // ring tops arrive one level ahead as well: they are consumed mid-level (vertical flux), and a load issued at the top of its own
     // level sits behind the previous level's stores in the in-order memory counter
-    double ta_nx = pa[n + 3 * sz], tb_nx = pb[n + 3 * sz];
+    double ta_nx = 0.0, tb_nx = 0.0;
+    if constexpr (BZ5_TOPS_AHEAD) { ta_nx = pa[n + 3 * sz]; tb_nx = pb[n + 3 * sz]; }
     for (int k = kbeg; k < kend; ++k, n += sz) {
         // ---- loads, issued in the order their values are needed (s_waitcnt counts vector loads in order, so waiting for a load
         //      waits for everything issued before it): ring tops (vertical flux, mid-level), next level's frame cells (staging, end of
@@ -285,14 +297,18 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
         //      latency per level and wave, because the advecting fluxes are the first thing a level computes) ----
         double ha[HPT], hb[HPT];
         const unsigned lev = (unsigned)(k + 1 - kbeg) * sz;
-        const double ta_raw = ta_nx, tb_raw = tb_nx;
-        {
+        double ta_raw, tb_raw;
+        if constexpr (BZ5_TOPS_AHEAD) {
+            ta_raw = ta_nx; tb_raw = tb_nx;
             const unsigned up = (k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz;      // the last level's request stays inside the parent array (unused)
             ta_nx = pa[n + up]; tb_nx = pb[n + up];
+        } else { ta_raw = pa[n + 3 * sz]; tb_raw = pb[n + 3 * sz]; }
+        const int lv3 = BZ5_ZERO_SHORTCUT ? (k - kbeg) % 3 : 0;
+        bool zxy = false;
+        if constexpr (BZ5_ZERO_SHORTCUT) {
+            if (t == 0) ZF[(lv3 + 2) % 3] = 1;      // reset the flag of level k + 2 (set while level k + 1 is staged, at the end of the next trip)
+            zxy = __builtin_amdgcn_readfirstlane(ZF[lv3]) != 0;      // q is zero on the whole staged level k: exact zero x / y fluxes
         }
-        const int lv3 = (k - kbeg) % 3;
-        if (t == 0) ZF[(lv3 + 2) % 3] = 1;      // reset the flag of level k + 2 (set while level k + 1 is staged, at the end of the next trip)
-        const bool zxy = __builtin_amdgcn_readfirstlane(ZF[lv3]) != 0;      // q is zero on the whole staged level k: exact zero x / y fluxes
 #pragma unroll
         for (int q = 0; q < HPT; ++q) {
             if (BZ_KO & 2) { ha[q] = ta_raw; hb[q] = tb_raw; }
@@ -356,8 +372,11 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
             fza_hi = rf * (cfz * bz_upB(a[1], a[2], a[3], a[4], a[5], ta, lz, Bz));
         }
         const double tb = bz_cdiv(tb_raw, rho3, rrho3);
-        zrun = (tb == 0.0) ? min(zrun + 1, 6) : 0;
-        const bool zz = __all(zrun >= 6);      // b[1] .. b[5], tb are all zero in every column of the wavefront: exact zero vertical flux
+        bool zz = false;
+        if constexpr (BZ5_ZERO_SHORTCUT) {
+            zrun = (tb == 0.0) ? min(zrun + 1, 6) : 0;
+            zz = __all(zrun >= 6);      // b[1] .. b[5], tb are all zero in every column of the wavefront: exact zero vertical flux
+        }
         if (zxy) {
             fxb = 0.0; fyb = 0.0;
             FY[buf][1][ty][tx] = 0.0;
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN
                     T[buf ^ 1][1][hr[q]][hc[q]] = hbv;
                     z1 = z1 && (hbv == 0.0);
                 }
-            if (!__all(z1) && tx == 0) ZF[(lv3 + 1) % 3] = 0;
+            if (BZ5_ZERO_SHORTCUT && !__all(z1) && tx == 0) ZF[(lv3 + 1) % 3] = 0;
         }
         if (!(BZ_KO & 64)) __syncthreads();
         // ---- combine, SSP-RK3 update, temperature of the updated cell for the next stage's buoyancy ----

@@ -392,21 +392,38 @@ static AcFieldsT<ST> ac_cast(const AcFields &F)
     } while (0)
 
 // assemble_slow_vertical_momentum_tendency! + initialize_stage_perturbations! (acoustic_substepping.jl:727-752,793-838)
-template <class ST>
+// ZERO: the three time-average accumulators are zeroed here (unfused substeps); with the fused substep kernels the first substep of a
+// stage assigns them instead (three words per cell and stage written only to be read back once).
+// STORE0: first stage of a whole step — the state IS U0, so the perturbations are exact zeros and store_initial_state! rides along
+// (the six copies of bzi_compressible_store_initial_state: 12 words per cell; here 6, and the five state reads are shared).
+template <bool ZERO, bool STORE0, class ST>
 __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> F)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
     if (i >= g.Nx) return;
     const long long sz = g.Sxy;
     const long long n = g.idx(i, j, k);
+    if (STORE0) {
+        // U0 - U with U0 := U: (+0) for every finite value, as the subtraction of the stored copy gives
+        ((double *)F.U0_rho_d)[n] = F.rho_d[n];
+        ((double *)F.U0_rth)[n] = F.rth[n];
+        ((double *)F.U0_ru)[n] = F.ru[n];
+        ((double *)F.U0_rv)[n] = F.rv[n];
+        ((double *)F.U0_rw)[n] = F.rw[n];
+        ((double *)F.U0_rq)[n] = F.rq[n];
+        F.rp[n] = 0.0; F.rthp_out[n] = 0.0; F.rup[n] = 0.0; F.rvp[n] = 0.0; F.rwp[n] = 0.0;
+    } else {
     F.rp[n] = F.U0_rho_d[n] - F.rho_d[n];
     F.rthp_out[n] = F.U0_rth[n] - F.rth[n];     // start buffers of the ping-pong fields (set by the launcher)
     F.rup[n] = F.U0_ru[n] - F.ru[n];
     F.rvp[n] = F.U0_rv[n] - F.rv[n];
     F.rwp[n] = F.U0_rw[n] - F.rw[n];
+    }
+    if (ZERO) {
     F.au[n] = 0.0;
     F.av[n] = 0.0;
     F.aw[n] = 0.0;
+    }
     if (k == 0) {
         F.Gs[n] = 0.0;
     } else {
@@ -416,7 +433,8 @@ __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> 
         F.Gs[n] = F.G_rw[n] - dp - g.g * rf;
     }
     if (k == g.Nz - 1) {
-        F.rwp[n + sz] = F.U0_rw[n + sz] - F.rw[n + sz];
+        if (STORE0) { ((double *)F.U0_rw)[n + sz] = F.rw[n + sz]; F.rwp[n + sz] = 0.0; }
+        else F.rwp[n + sz] = F.U0_rw[n + sz] - F.rw[n + sz];
         F.Gs[n + sz] = 0.0;
     }
 }
@@ -542,8 +560,8 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
             vp1 = ac_face_update<DAMP>(F.rvp_in[nyp], F.G_rv[nyp], rt_yp, rthp, o_yp, o0, thyp, th_0, c_yp, C_0, p_yp, p0, g.rdy, P);
             F.rup[n] = up0;
             F.rvp[n] = vp0;
-            F.au[n] += up0;
-            F.av[n] += vp0;
+            if (FIRST) { F.au[n] = 0.0 + up0; F.av[n] = 0.0 + vp0; }      // first substep of the stage: the accumulators start here (0 + x keeps the bits of the zeroed array)
+            else { F.au[n] += up0; F.av[n] += vp0; }
         } else {
             up0 = F.rup[n]; up1 = F.rup[n + W.ip]; vp0 = F.rvp[n]; vp1 = F.rvp[n + W.jp];
             F.rth_old[n] = rthp;
@@ -606,7 +624,7 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
 }
 
 // back substitution + _post_solve_recovery! (acoustic_substepping.jl:993-1002)
-template <class ST>
+template <bool FIRST, class ST>      // FIRST: first substep of a stage with the fused forward sweep: <rho w> starts here
 __global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
     const int i = blockIdx.x * ABX + threadIdx.x, j = blockIdx.y * ABY + threadIdx.y;
@@ -629,7 +647,8 @@ __global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcF
         F.rp[n] = F.rs[n] - P.dtn * dzW;
         F.rthp_out[n] = F.rths[n] - P.dtn * dzT;
         F.rwp[n] = w_lo;
-        F.aw[n] += w_lo;
+        if (FIRST) F.aw[n] = 0.0 + w_lo;
+        else F.aw[n] += w_lo;
         t_hi = F.tfac[n];
         w_hi = w_lo;
         thf_hi = thf_lo;
@@ -697,6 +716,202 @@ __global__ __launch_bounds__(256) void k_ac_recover(DevGrid g, AcFieldsT<ST> F, 
         F.rqcl[n] = F.U0_rqcl[n] + dt_stage * F.G_rqcl[n];
         F.rqr[n] = F.U0_rqr[n] + dt_stage * F.G_rqr[n];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stage epilogue of the whole-step seam in ONE pass (round 4): k_ac_finalize + k_ac_recover<MOIST> +
+// k_cmp_diagnose<true, LIN, MP> — three passes that re-read each other's output (17 + 18 + 18 words per cell) as one (38) plus the
+// three-word density pass below.  Same expressions in the same order as the three kernels, so the results carry their bits:
+//   * the last substep's divergence damping of (rho u)', (rho v)' (the damped values are consumed here and not stored: nothing reads
+//     the perturbation fields between the recovery and the next stage's initialisation);
+//   * time-averaged velocities from the accumulators and the STAGE-ENTRY densities, with their halo images;
+//   * recovery U = U^L + U' of rho theta, momentum (stored in place: pointwise) and of rho_d — which is NOT stored here, because the
+//     averages above and the velocities below read rho_d of the x / y / z neighbours: every thread forms the neighbours' new density
+//     from the old one and rho' itself, and k_ac_recover_density writes the field afterwards;
+//   * WS-RK3 update of the moisture density (and the Kessler species);
+//   * update_state!: total density, velocities, theta, q, Newton temperature, pressure, every halo image, and (LIN) the next
+//     stage's linearisation — theta_L goes to `thL_out`, a second buffer, because the damping of this pass reads the old theta_L
+//     of the neighbours (bz_ctx::d_thL2; the stage driver alternates the two).
+// Single-device contexts only (a y-slab has no rho' in its halo rows).
+template <bool DAMP, bool LIN, int MP, class ST>
+__global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F, DiagFields D, AcParams P, double dt_stage, ST *__restrict__ thL_out,
+                                                      double abstol, int maxiter)
+{
+    constexpr bool KES = (MP == 2), SA = (MP == 1);
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const WrapIdx W = wrap_of(g, i, j);
+    const long long ox = W.ox, oy = W.oy;
+    const long long sz = g.Sxy;
+    const long long n = g.idx(i, j, k), mx = n + W.im, my = n + W.jm, mz = n - sz;
+    const bool bot = (k == 0), top = (k == g.Nz - 1);
+
+    // ---- k_ac_finalize: damping of the last substep ----
+    ST up_s = F.rup[n], vp_s = F.rvp[n];
+    if (DAMP) {
+        const double d0 = F.rthp[n] - F.rth_old[n];
+        const double ddx = (d0 - (F.rthp[mx] - F.rth_old[mx])) * g.rdx;
+        const double ddy = (d0 - (F.rthp[my] - F.rth_old[my])) * g.rdy;
+        const double th = F.thL[n];
+        up_s -= P.kdamp * ddx / ((th + F.thL[mx]) / 2.0);
+        vp_s -= P.kdamp * ddy / ((th + F.thL[my]) / 2.0);
+    }
+    // ---- k_ac_finalize: time-averaged velocities (stage-entry densities and momentum) ----
+    const double r0 = F.rho_d[n], r_mx = F.rho_d[mx], r_my = F.rho_d[my];
+    const double ru0 = F.ru[n], rv0 = F.rv[n];
+    double r_mz = 0.0, rw0 = 0.0;
+    {
+        double rx = (r0 + r_mx) / 2.0, ry = (r0 + r_my) / 2.0;
+        rx = (rx == 0.0) ? 1.0 : rx;
+        ry = (ry == 0.0) ? 1.0 : ry;
+        const double ua = (ru0 + F.au[n] * P.inv_N) / rx;
+        const double va = (rv0 + F.av[n] * P.inv_N) / ry;
+        cst_img(F.au, n, ua, ox, oy);
+        cst_img(F.av, n, va, ox, oy);
+        double wa = 0.0;
+        if (!bot) {
+            r_mz = F.rho_d[mz];
+            rw0 = F.rw[n];
+            double rz = (r0 + r_mz) / 2.0;
+            rz = (rz == 0.0) ? 1.0 : rz;
+            wa = (rw0 + F.aw[n] * P.inv_N) / rz;
+        }
+        cst_img(F.aw, n, wa, ox, oy);
+        if (bot || top) {
+            const long long h = bot ? -sz : sz;
+            cst_img(F.au, n + h, ua, ox, oy);
+            cst_img(F.av, n + h, va, ox, oy);
+            if (top) cst_img(F.aw, n + sz, 0.0, ox, oy);
+        }
+    }
+    // ---- k_ac_recover ----
+    const double rd = r0 + F.rp[n];
+    const double rth = F.rth[n] + F.rthp[n];
+    const double ru = ru0 + up_s, rv = rv0 + vp_s;
+    const double rq = F.U0_rq[n] + dt_stage * F.G_rq[n];
+    double rqcl = 0.0, rqr = 0.0;
+    if (KES) {
+        rqcl = F.U0_rqcl[n] + dt_stage * F.G_rqcl[n];
+        rqr = F.U0_rqr[n] + dt_stage * F.G_rqr[n];
+    }
+    // ---- k_cmp_diagnose<true, LIN, MP> on the recovered state ----
+    const double rdx = (rd + (r_mx + F.rp[mx])) / 2.0;
+    const double rdy = (rd + (r_my + F.rp[my])) / 2.0;
+    const double u = ru / rdx, v = rv / rdy;
+    cst_img(D.rth, n, rth, ox, oy);
+    cst_img(D.ru, n, ru, ox, oy);
+    cst_img(D.rv, n, rv, ox, oy);
+    cst_img(D.u, n, u, ox, oy);
+    cst_img(D.v, n, v, ox, oy);
+    if (!bot) {
+        const double rw = rw0 + F.rwp[n];
+        const double rdz = (rd + (r_mz + F.rp[mz])) / 2.0;
+        cst_img(D.rw, n, rw, ox, oy);
+        cst_img(D.w, n, rw / rdz, ox, oy);
+    } else {
+        cst_img(D.rw, n, 0.0, ox, oy);      // impenetrable walls
+        cst_img(D.w, n, 0.0, ox, oy);
+    }
+    if (top) {
+        cst_img(D.rw, n + sz, 0.0, ox, oy);
+        cst_img(D.w, n + sz, 0.0, ox, oy);
+    }
+    double r, q, th, T, p, qcl_v = 0.0, qr_v = 0.0, sa_qv = 0.0, sa_ql = 0.0;
+    {
+        double ql = 0.0;
+        if (KES) r = rd + (rq + (rqcl + (rqr + 0.0)));
+        else r = rd + (rq + 0.0);
+        th = rth / rd;
+        q = rq / r;
+        if (KES) {
+            qcl_v = rqcl / r;
+            qr_v = rqr / r;
+            ql = qcl_v + qr_v;
+        }
+        double qvap = q;
+        if (SA) {
+            T = bz_ds_adjust(g, th, q, r, abstol, maxiter, qvap, ql);
+            cst_img(g.qv_field, n, qvap, ox, oy);
+            cst_img(g.ql_field, n, ql, ox, oy);
+            sa_qv = qvap; sa_ql = ql;
+        }
+        const double qd = 1.0 - (qvap + ql);
+        const double Rm = qd * g.Rd + qvap * g.Rv;
+        const double cpm = (KES || SA) ? qd * g.cpd + qvap * g.cpv + ql * g.sa_cl : qd * g.cpd + qvap * g.cpv;
+        if (!SA) {
+            const double kap = Rm / cpm;
+            const double gam = cpm / (cpm - Rm);
+            const double Lt = KES ? (g.sa_Ll * ql) / cpm : 0.0;
+            T = pow(th, gam) * pow(r * Rm / g.pst, gam - 1.0) + Lt;
+            double dT = T;
+            for (int it = 0; it < maxiter && fabs(dT) > abstol; ++it) {
+                const double Phi = pow(r * Rm * T / g.pst, kap) * th;
+                dT = -(T - Phi - Lt) / (1.0 - kap * Phi / T);
+                T += dT;
+            }
+        }
+        p = r * Rm * T;
+        if (KES) {
+            cst_img(F.rqcl, n, rqcl, ox, oy);
+            cst_img(F.rqr, n, rqr, ox, oy);
+            cst_img(g.qcl_field, n, qcl_v, ox, oy);
+            cst_img(g.qr_field, n, qr_v, ox, oy);
+            cst_img(g.qv_field, n, q, ox, oy);
+        }
+        cst_img(D.rq, n, rq, ox, oy);
+        cst_img(D.rho, n, r, ox, oy);
+        cst_img(D.theta, n, th, ox, oy);
+        cst_img(D.q, n, q, ox, oy);
+        cst_img(D.T, n, T, ox, oy);
+        cst_img(D.p, n, p, ox, oy);
+        if (LIN) {
+            const double Pi = pow(p / g.pst, g.Rd / g.cpd);
+            const double thl = rth / ((rd == 0.0) ? 1.0 : rd);
+            const double gr = cpm * Rm / (cpm - Rm);
+            st_store(D.Pi, n, Pi, D.st32);
+            thL_out[n] = (ST)thl;
+            st_store(D.gR, n, gr, D.st32);
+            st_store(D.Clin, n, gr * Pi, D.st32);
+        }
+    }
+    if (bot || top) {     // first z-halo cell of the no-flux centre fields (rho_d: k_ac_recover_density)
+        const long long h = bot ? -sz : sz;
+        cst_img(D.ru, n + h, ru, ox, oy);
+        cst_img(D.rv, n + h, rv, ox, oy);
+        cst_img(D.rth, n + h, rth, ox, oy);
+        cst_img(D.u, n + h, u, ox, oy);
+        cst_img(D.v, n + h, v, ox, oy);
+        cst_img(D.rq, n + h, rq, ox, oy);
+        cst_img(D.rho, n + h, r, ox, oy);
+        cst_img(D.theta, n + h, th, ox, oy);
+        cst_img(D.q, n + h, q, ox, oy);
+        cst_img(D.T, n + h, T, ox, oy);
+        cst_img(D.p, n + h, p, ox, oy);
+        if (SA) {
+            cst_img(g.qv_field, n + h, sa_qv, ox, oy);
+            cst_img(g.ql_field, n + h, sa_ql, ox, oy);
+        }
+        if (KES) {
+            cst_img(F.rqcl, n + h, rqcl, ox, oy);
+            cst_img(F.rqr, n + h, rqr, ox, oy);
+            cst_img(g.qcl_field, n + h, qcl_v, ox, oy);
+            cst_img(g.qr_field, n + h, qr_v, ox, oy);
+            cst_img(g.qv_field, n + h, q, ox, oy);
+        }
+    }
+}
+
+// rho_d = rho_d^L + rho' with its halo images and z-halo copies: the one field of the recovery whose neighbours k_ac_stage_end reads
+template <class ST>
+__global__ __launch_bounds__(256) void k_ac_recover_density(DevGrid g, double *__restrict__ rho_d, const ST *__restrict__ rp)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= g.Nx) return;
+    const WrapIdx W = wrap_of(g, i, j);
+    const long long n = g.idx(i, j, k);
+    const double rd = rho_d[n] + rp[n];
+    cst_img(rho_d, n, rd, W.ox, W.oy);
+    if (k == 0 || k == g.Nz - 1) cst_img(rho_d, n + ((k == 0) ? -g.Sxy : g.Sxy), rd, W.ox, W.oy);
 }
 
 __global__ __launch_bounds__(256) void k_ws_rk3_scalar(DevGrid g, double *__restrict__ u, const double *__restrict__ u0,
@@ -789,6 +1004,7 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
     if (hipMalloc(&ctx->d_Clin, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_tfac_ac, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_up2, ncell * sizeof(double)) != hipSuccess ||
+        hipMalloc(&ctx->d_thL2, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_vp2, ncell * sizeof(double)) != hipSuccess) {
         bz_destroy(ctx);
         *out = nullptr;
@@ -797,6 +1013,7 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
     (void)hipMemset(ctx->d_Clin, 0, ncell * sizeof(double));
     (void)hipMemset(ctx->d_tfac_ac, 0, ncell * sizeof(double));
     (void)hipMemset(ctx->d_up2, 0, ncell * sizeof(double));
+    (void)hipMemset(ctx->d_thL2, 0, ncell * sizeof(double));
     (void)hipMemset(ctx->d_vp2, 0, ncell * sizeof(double));
     // UpperSponge profile on the faces: rate * ramp(z, grid.Lz, depth), ramp = 0 below Lz - depth and 1 at z = Lz
     // (time_discretizations.jl:398-433; the reference passes grid.Lz as the sponge top, whatever z[0] is)
@@ -824,6 +1041,8 @@ void bzi_compressible_teardown(bz_ctx *ctx)
     if (ctx->d_Clin) (void)hipFree(ctx->d_Clin);
     if (ctx->d_tfac_ac) (void)hipFree(ctx->d_tfac_ac);
     if (ctx->d_up2) (void)hipFree(ctx->d_up2);
+    if (ctx->d_thL2) (void)hipFree(ctx->d_thL2);
+    ctx->d_thL2 = nullptr;
     if (ctx->d_vp2) (void)hipFree(ctx->d_vp2);
     if (ctx->d_sponge) (void)hipFree(ctx->d_sponge);
     ctx->d_Clin = ctx->d_tfac_ac = ctx->d_up2 = ctx->d_vp2 = ctx->d_sponge = nullptr;
@@ -864,6 +1083,7 @@ static int bzi_compressible_update_state(bz_ctx *ctx, const bz_compressible_stat
     {
         ProfileScope ps(ctx, with_linearization ? "update_state+linearization" : "update_state");
         DiagFields F = diag_fields(ctx, s, sub);
+        if (with_linearization) ctx->thL_alt = false;      // theta_L of the next stage goes to the caller's array
         dim3 grid((g.Nx + 255) / 256, g.Ny, g.Nz), block(256);
         const double na = ctx->se.newton_abstol;
         const int nm = ctx->se.newton_maxiter;
@@ -900,6 +1120,7 @@ extern "C" int bz_refresh_linearization(bz_ctx *ctx, const bz_compressible_state
     if (!valid_state(s) || !valid_sub(sub)) return BZ_ERR_INVALID;
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "refresh_linearization");
+    ctx->thL_alt = false;
     const int hrows = g.wrap_y ? 0 : ((ctx->se.direct_divergence_damping && ctx->se.damping_coefficient >= 0.0) ? 2 : 1);
     dim3 grid((g.Nx + 255) / 256, g.Ny + 2 * hrows, g.Nz), block(256);
     hipLaunchKernelGGL(k_cmp_linearization, grid, block, 0, ctx->stream, g, sub->exner, sub->potential_temperature,
@@ -997,7 +1218,7 @@ static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_
     F.rho = s->rho; F.p = s->p;
     F.U0_rho_d = U0->rho_d; F.U0_rth = U0->rho_theta; F.U0_ru = U0->rho_u; F.U0_rv = U0->rho_v; F.U0_rw = U0->rho_w; F.U0_rq = U0->rho_q;
     F.G_rho_d = G->rho_d; F.G_rth = G->rho_theta; F.G_ru = G->rho_u; F.G_rv = G->rho_v; F.G_rw = G->rho_w; F.G_rq = G->rho_q;
-    F.thL = a->potential_temperature; F.Clin = ctx->d_Clin;
+    F.thL = ctx->thL_alt ? ctx->d_thL2 : a->potential_temperature; F.Clin = ctx->d_Clin;
     F.rp = a->density_perturbation; F.rthp = a->density_potential_temperature_perturbation;
     F.rup = a->momentum_perturbation_u; F.rvp = a->momentum_perturbation_v; F.rwp = a->momentum_perturbation_w;
     F.rs = a->density_predictor; F.rths = a->density_potential_temperature_predictor;
@@ -1088,7 +1309,8 @@ static int direct_damping(bz_ctx *ctx, const AcFields &F, const bz_acoustic_subs
 
 // assemble_slow_vertical_momentum_tendency! + initialize_stage_perturbations!
 static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
-                                    const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta)
+                                    const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta,
+                                    bool store0 = false)
 {
     const DevGrid &g = ctx->dg;
     AcStage &S = stage_of(ctx);
@@ -1124,7 +1346,10 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     AcFields Fi = F;
     Fi.rthp_out = th_buf[S.cur]; Fi.rup = u_buf[S.cur]; Fi.rvp = v_buf[S.cur];
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
-    AC_LAUNCH0(k_ac_stage_init, , rows, b256, Fi);
+    // first stage of a whole step (the caller passes store0): the state is U0 — store_initial_state! rides along
+    if (S.fused && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA, rows, b256, Fi);
+    else if (S.fused) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA, rows, b256, Fi);
+    else AC_LAUNCH0(k_ac_stage_init, true COMMA false COMMA, rows, b256, Fi);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -1167,7 +1392,8 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
         }
         {
             ProfileScope ps(ctx, "acoustic_column_backward");
-            AC_LAUNCH(k_ac_column_backward, , colsb, bcolb, Fs, P);
+            if (sstep == 1) AC_LAUNCH(k_ac_column_backward, true COMMA, colsb, bcolb, Fs, P);
+            else AC_LAUNCH(k_ac_column_backward, false COMMA, colsb, bcolb, Fs, P);
         }
         S.cur ^= 1;
     } else {
@@ -1187,7 +1413,7 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
         }
         {
             ProfileScope ps(ctx, "acoustic_column_backward");
-            AC_LAUNCH(k_ac_column_backward, , colsb, bcolb, F, P);
+            AC_LAUNCH(k_ac_column_backward, false COMMA, colsb, bcolb, F, P);
         }
     }
     S.done = sstep;
@@ -1247,6 +1473,58 @@ static int bzi_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, c
         DiagFields D = diag_fields(ctx, s, sub);
         hipLaunchKernelGGL((k_cmp_diagnose<false, false>), rows, b256, 0, ctx->stream, g, D, 0.0, 0);
     }
+    S.ntau = 0;
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// The stage epilogue of the whole-step seam as k_ac_stage_end + k_ac_recover_density: finalize + recover (with the WS-RK3 moisture
+// update) + update_state! [+ the next stage's linearisation].  Single-device contexts, thermal or no divergence damping.
+static bool stage_end_fusable(const bz_ctx *ctx)
+{
+    return !ctx->slab_mode && !ctx->tune.no_ac_end_fuse && !(ctx->se.damping_coefficient >= 0.0 && ctx->se.direct_divergence_damping != 0);
+}
+static int bzi_acoustic_stage_end_fused(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
+                                        const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta,
+                                        bool with_linearization)
+{
+    const DevGrid &g = ctx->dg;
+    AcStage &S = stage_of(ctx);
+    if (S.done != S.ntau) {
+        ctx->last_error = "bz_acoustic_stage_end: the stage still has substeps to run";
+        return BZ_ERR_INVALID;
+    }
+    AcFields F = ac_fields(ctx, s, U0, G, sub);      // F.thL: the linearisation this stage ran on
+    DiagFields D = diag_fields(ctx, s, sub);
+    double *thL_out = ctx->thL_alt ? sub->potential_temperature : ctx->d_thL2;
+    dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
+    const double na = ctx->se.newton_abstol, dts = beta * dt;
+    const int nm = ctx->se.newton_maxiter;
+    {
+        ProfileScope ps(ctx, with_linearization ? "acoustic_stage_end+update_state+linearization" : "acoustic_stage_end+update_state");
+#define BZ_END(DAMP, LIN, MP)                                                                                                              \
+    do {                                                                                                                                   \
+        if (ctx->substep_f32)                                                                                                              \
+            hipLaunchKernelGGL((k_ac_stage_end<DAMP, LIN, MP, float>), rows, b256, 0, ctx->stream, g, ac_cast<float>(F), D, S.P, dts, (float *)thL_out, na, nm); \
+        else hipLaunchKernelGGL((k_ac_stage_end<DAMP, LIN, MP, double>), rows, b256, 0, ctx->stream, g, F, D, S.P, dts, thL_out, na, nm);  \
+    } while (0)
+#define BZ_END_MP(DAMP, LIN)                                \
+    do {                                                    \
+        if (g.microphysics == 2) BZ_END(DAMP, LIN, 2);      \
+        else if (g.microphysics == 1) BZ_END(DAMP, LIN, 1); \
+        else BZ_END(DAMP, LIN, 0);                          \
+    } while (0)
+        if (S.damping) { if (with_linearization) BZ_END_MP(true, true); else BZ_END_MP(true, false); }
+        else { if (with_linearization) BZ_END_MP(false, true); else BZ_END_MP(false, false); }
+#undef BZ_END_MP
+#undef BZ_END
+    }
+    {
+        ProfileScope ps(ctx, "acoustic_recover_density");
+        if (ctx->substep_f32) hipLaunchKernelGGL((k_ac_recover_density<float>), rows, b256, 0, ctx->stream, g, s->rho_d, (const float *)F.rp);
+        else hipLaunchKernelGGL((k_ac_recover_density<double>), rows, b256, 0, ctx->stream, g, s->rho_d, (const double *)F.rp);
+    }
+    if (with_linearization) ctx->thL_alt = !ctx->thL_alt;
     S.ntau = 0;
     BZ_LAUNCH_CHECK();
     return BZ_OK;
@@ -1418,12 +1696,24 @@ static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, c
 {
     int rc;
     const DevGrid &g = ctx->dg;
-    if ((rc = bzi_compressible_store_initial_state(ctx, s, U0))) return rc;
+    // round 4: on single-device contexts the stage epilogue is one pass (k_ac_stage_end) and store_initial_state! rides on the first
+    // stage's initialisation kernel (the state IS U0 there); BZ_NO_AC_END_FUSE=1 restores the separate passes
+    const bool fuse_end = stage_end_fusable(ctx);
+    const bool store0 = fuse_end && ctx->ac_fused;
+    if (store0) {
+        if (g.microphysics == 2) {      // the species' U0 copies stay copies (k_ac_stage_init does not know them)
+            const bz_kessler_model_fields &K = ctx->kessler;
+            const size_t nc = (size_t)g.Sxy * (size_t)(g.Nz + 2 * g.Hz) * sizeof(double);
+            ProfileScope ps(ctx, "store_initial_state");
+            BZ_HIP(hipMemcpyAsync(K.U0_cloud_liquid_density, K.cloud_liquid_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
+            BZ_HIP(hipMemcpyAsync(K.U0_rain_density, K.rain_density, nc, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    } else if ((rc = bzi_compressible_store_initial_state(ctx, s, U0))) return rc;
     // freeze_linearization_state! (acoustic_substepping.jl:288-292): the linearisation of stage 1 (refreshed again by
     // prepare_acoustic_cache! from the same state).  Its second half, seed_time_averaged_velocities!, is deliberately not
     // issued here: nothing between this point and stage 1's substep loop reads the time-averaged velocities (the slow
     // rho theta tendency of stage 1 uses model.velocities, the stage-1 moisture tendency was built by the previous
-    // update_state!), and k_ac_stage_init zeroes the three accumulators before the loop refills them — the seed is
+    // update_state!), and the first substep of the loop assigns the three accumulators — the seed is
     // unobservable inside a whole step (tests/test_gpu_compressible.py::test_whole_step_matches_operator_sequence runs the
     // per-operator sequence WITH the seed against this seam).  Per-operator drivers call bz_seed_time_averaged_velocities.
     rc = bz_refresh_linearization(ctx, s, sub);
@@ -1432,11 +1722,20 @@ static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, c
     for (int st = 0; st < 3; ++st) {
         rc = bz_compute_slow_tendencies(ctx, s, G);
         if (rc) return rc;
-        rc = bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, betas[st], true, false);
-        if (rc) return rc;
-        // update_state! (+ prepare_acoustic_cache! of the next stage: same inputs, folded into the diagnosis kernel)
-        rc = bzi_compressible_update_state(ctx, s, G, sub, true, st < 2);
-        if (rc) return rc;
+        if (!fuse_end) {
+            rc = bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, betas[st], true, false);
+            if (rc) return rc;
+            // update_state! (+ prepare_acoustic_cache! of the next stage: same inputs, folded into the diagnosis kernel)
+            rc = bzi_compressible_update_state(ctx, s, G, sub, true, st < 2);
+            if (rc) return rc;
+            continue;
+        }
+        if ((rc = bzi_acoustic_stage_begin(ctx, s, U0, G, sub, dt, betas[st], store0 && st == 0))) return rc;
+        const int ntau = stage_of(ctx).ntau;
+        for (int sstep = 1; sstep <= ntau; ++sstep)
+            if ((rc = bzi_acoustic_substep(ctx, s, U0, G, sub, sstep))) return rc;
+        if ((rc = bzi_acoustic_stage_end_fused(ctx, s, U0, G, sub, dt, betas[st], st < 2))) return rc;
+        if ((rc = bz_compute_moisture_tendency(ctx, s, G, sub))) return rc;
     }
     if (g.microphysics == 2) return bz_compressible_kessler_update(ctx, s, G, sub, dt);     // microphysics_model_update! (:316)
     return BZ_OK;

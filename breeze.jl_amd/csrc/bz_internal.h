@@ -262,6 +262,7 @@ struct bz_tuning {
     int xf_kchunk_f = 0, xf_kchunk_i = 0;      // BZ_XF_KCHUNK_F / _I: levels per block of the x transforms (0: automatic)
     bool generic_onepass = false;     // BZ_GENERIC_ONEPASS: WENO 7 / 9 with every flux evaluated by both of its cells
     bool no_ac_fuse = false;          // BZ_NO_AC_FUSE: three kernels per acoustic substep
+    bool no_ac_end_fuse = false;      // BZ_NO_AC_END_FUSE: stage epilogue as finalize + recover + update_state (three passes) and store_initial_state as copies
     bool comm_no_overlap = false;     // BZ_COMM_NO_OVERLAP
     bool comm_self_messages = false;  // BZ_COMM_SELF_MESSAGES: world 1 sends every message to itself
     bool comm_no_side_scalar = false; // BZ_COMM_NO_SIDE_SCALAR
@@ -351,6 +352,8 @@ struct bz_ctx {
     double *d_Clin = nullptr;         // centre array: gamma R_m * Pi of the current linearisation
     double *d_tfac_ac = nullptr;      // centre array: Thomas factors t_k of the acoustic column system (per stage)
     double *d_up2 = nullptr, *d_vp2 = nullptr;   // second buffers of the (rho u)', (rho v)' ping-pong (fused substep)
+    double *d_thL2 = nullptr;         // second buffer of theta_L: the fused stage epilogue writes the next stage's linearisation while it still reads this one's
+    bool thL_alt = false;             // the current theta_L lives in d_thL2 (whole-step seam only; every per-operator linearisation resets it)
     bool substep_f32 = false;         // substep_floattype = Float32 inside the Float64 library: the substepper's working fields are float arrays
     bool ac_fused = true;             // horizontal step folded into the forward column sweep (BZ_NO_AC_FUSE=1 disables)
     // DCMIP2016KesslerMicrophysics attached to the model (bz_set_kessler_microphysics)

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
             edge = flux_x_lean<T3_V>(g, F, rv, ie, jc, kk, Bf);
         }
         const int src = (k - kbeg) & 63;
-        const double rho = g.rho[k], rrho = g.rrho[k];
+        const double rho = g.rho[k];
         const double c0 = r[3];
         const double(*V)[TC] = Tv[buf];
         const double *vrow = V[ty + 3] + tc;

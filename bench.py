@@ -7,17 +7,21 @@ grid_points_per_second = Nx*Ny*Nz / time_per_step).  Workload: BASELINE.json con
 thermal bubble on a 512^3 RectilinearGrid (SURVEY.md §8d "C2"), Float64, fixed dt = 1 s,
 deterministic synthetic initial state resident in HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W [--size 512] [--scaling weak|strong] [--workload bubble|config3]
+    python bench.py --gpus N --steps K --warmup W [--size 512] [--scaling strong|weak] [--workload bubble|config3] [--preflight]
 
-Prints ONE JSON line (rank 0).  N > 1: one rank per GPU over RCCL, y-slab decomposition
-(breeze.jl_amd/distributed.py: y-halo exchange + FFT transposes):
-  --scaling weak    (default) every rank owns a size^3 slab of a size x (size N) x size periodic domain
-  --scaling strong  the size^3 domain of the N = 1 run is split N ways ("1/2/4/8-GPU cells/s for 512^3")
+Prints ONE JSON line (rank 0).  N > 1: one rank per GPU, y-slab decomposition with the RCCL communicator inside the C library
+(breeze.jl_amd/csrc/bz_comm.hip: y-halo exchange + FFT all-to-all):
+  --scaling strong  (default) the size^3 domain of the N = 1 run is split N ways — BASELINE.md §4: "1/2/4/8-GPU cells/s for 512^3"
+  --scaling weak    every rank owns a size^3 slab of a size x (size N) x size periodic domain (explicit only)
   --workload config3  BASELINE.json configs[3]: 1024 x 1024 x 512 split over the N ranks (8 ranks -> 1024 x 128 x 512 each)
-`value` is the aggregate over ranks; `comm_ms_per_step` / `compute_ms_per_step` split the step of the slowest rank.
+`value` is the aggregate over ranks; the line carries `scaling`, `transport`, `comm_ms_per_step`, `exposed_comm_ms_per_step`.
+Before any timed region a multi-rank run goes through the PREFLIGHT (also available alone as `--preflight`): communicator bootstrap on
+all ranks, a rank-coded halo exchange through the library, and two steps of a 64^3-per-rank bubble compared with the same domain
+stepped on one GPU (which exercises both all-to-alls of the pressure solve) — any failure ends the run with a JSON "error" line and
+a non-zero exit code.  There is no transport fallback: `--transport rccl` (default) or `--transport torch` (explicit) or an error.
 If the ranks are not there yet (WORLD_SIZE unset, as in `python bench.py --gpus 8`), the script launches itself under
-torch.distributed.run and relays the ranks' line; a failed multi-GPU run prints a JSON line with an "error" field and
-exits non-zero — it never silently measures something else.  `--replicas` (explicit only) runs N independent copies.
+torch.distributed.run and relays the ranks' line.  `--replicas` (explicit only) runs N independent copies.
+Roofline accounting: tools/accounting.py (compulsory bytes everywhere; contract words beside; PMC traffic from profiles/).
 """
 import argparse
 import json
@@ -34,51 +38,12 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from accounting import (A_STEP_CONTRACT_WORDS, ACOUSTIC_SUBSTEP_COMPULSORY_WORDS, ACOUSTIC_SUBSTEP_CONTRACT_WORDS, COMPULSORY_WORDS,      # noqa: E402
+                        CONTRACT_WORDS, HBM_PEAK_GBS, compulsory_words, load_traffic, roofline_block, step_compulsory_words)
 
-# Algorithmic words (8 B) per grid cell per launch of each kernel group — SURVEY.md §8(d) table.
-WORDS_PER_CELL = {
-    "ssp_rk3_substep": 20, "store_initial_state": 10, "poisson_source_term": 4,
-    "poisson_fft_forward": 4, "poisson_tridiagonal": 2, "poisson_fft_inverse": 4,
-    "make_pressure_correction": 7, "compute_velocities": 6,
-    "compute_auxiliary_thermodynamic_variables": 5,
-    "x_momentum_tendency": 5, "y_momentum_tendency": 5, "z_momentum_tendency": 7,
-    "potential_temperature_tendency": 6, "moisture_tendency": 5,
-    "scalar_tendencies": 11, "momentum_tendencies": 17, "tendencies": 28,
-    "ssp_rk3_substep+store_initial_state": 30, "project_and_diagnose": 18,
-    # tendency kernels with the RK update folded in: tendency words + the RK update words of their fields
-    "x_momentum_tendency+rk3": 9, "y_momentum_tendency+rk3": 9, "z_momentum_tendency+rk3": 11,
-    "scalar_tendencies+rk3": 19,
-    # lean whole-step seam (bz_tendency5_kernels.h): the diagnostics are no separate passes any more — each momentum kernel derives its
-    # velocity component (compute_velocities: 2 of its 6 words), the scalar kernel does the theta, q^v, T diagnosis (5 words), the
-    # projection of stages 1-2 is make_pressure_correction alone (7).  Per stage: 24 + 11 + 11 + 13 + 7 + Poisson 14 = 80, as before.
-    "x_momentum_tendency+rk3+velocity": 11, "y_momentum_tendency+rk3+velocity": 11, "z_momentum_tendency+rk3+velocity": 13,
-    "scalar_tendencies+rk3+thermo": 24, "project_momentum": 7,
-    # chunked Poisson pipeline (level ranges go source -> x -> y transforms, and y -> x -> projection, back to back)
-    "poisson_source_term+fft_forward": 8, "poisson_fft_inverse+project_momentum": 11,
-    "poisson_fft_inverse+project_and_diagnose": 22,
-    # hand-written x transforms (bz_xfft_kernels.h): source term inside the forward x pass (4 + 2), y passes and the vertical
-    # solves on the transposed spectrum (2 each), momentum projection inside the inverse x pass (2 + 7)
-    "poisson_source_term+fft_x": 6, "poisson_fft_y_forward": 2, "poisson_fft_y_inverse": 2,
-    "poisson_fft_x+project_momentum": 9, "poisson_fft_x_inverse": 2,
-}
-A_STEP_WORDS = 250          # 3 stages x 80 + 10
-
-# Compulsory words per cell per launch of the FUSED kernels of the lean whole-step seam: every distinct 3-D array the kernel has to
-# read or write, once.  The contract figures above were written for the reference's unfused kernel list (a fused kernel inherits the
-# sum of what it replaces: 24 words for the scalar-pair kernel), so a fused kernel that got faster can exceed the 8 TB/s roof in
-# contract bytes (round 3: 1.02) — which says nothing.  `roofline.achieved` is therefore priced in compulsory bytes; the contract
-# figure is reported beside it (`contract_frac`), and `traffic` is what the counters saw.
-COMPULSORY_WORDS = {
-    "scalar_tendencies+rk3+thermo": 10,        # R rho_u, rho_v, rho_w, rho_theta, rho_q; U0 x 2 (read, or written in stage 1); W rho_theta, rho_q, T
-    "x_momentum_tendency+rk3+velocity": 5,     # R rho_u, rho_v, rho_w; U0; W predictor
-    "y_momentum_tendency+rk3+velocity": 5,
-    "z_momentum_tendency+rk3+velocity": 7,     # + R T, rho_q (buoyancy)
-    "project_momentum": 7, "project_and_diagnose": 18,
-    "poisson_source_term+fft_x": 4,            # R predictor rho_u, rho_v, rho_w; W half spectrum
-    "poisson_fft_y_forward": 2, "poisson_tridiagonal": 2, "poisson_fft_y_inverse": 2, "poisson_fft_x_inverse": 2,
-}
-A_STEP_COMPULSORY_WORDS = 3 * (10 + 5 + 5 + 7 + 4 + 2 + 2 + 2 + 2) + 2 * 7 + 18      # = 149 words per cell and step (lean seam)
+WORDS_PER_CELL = CONTRACT_WORDS      # (older tools import the contract table under this name)
+A_STEP_WORDS = A_STEP_CONTRACT_WORDS
 METRIC = "grid-cells advanced/sec (tendency+Poisson step), 512^3 anelastic"
 
 
@@ -89,6 +54,33 @@ def bubble(x, y, z):
 
 
 EXTENT = ((-10e3, 10e3), (-10e3, 10e3), (0.0, 10e3))
+
+
+def kernel_table(profile):
+    return {name: {"avg_ms": ms / n, "launches": n, "total_ms": ms} for name, (ms, n) in profile.items() if n}
+
+
+def dominant_roofline(kernels, cells, word_bytes, f32=False, with_traffic=True, exclude=("comm_",)):
+    """`roofline` of the kernel group with the largest share of the timed region, among the groups tools/accounting.py can price."""
+    known = [k for k in kernels if compulsory_words(k) is not None and not k.startswith(exclude)]
+    if not known:
+        return None
+    dom = max(known, key=lambda k: kernels[k]["total_ms"])
+    traffic, src = load_traffic(ROOT, dom, f32) if with_traffic else (None, None)
+    return roofline_block(dom, kernels[dom]["avg_ms"], cells, word_bytes, traffic, src)
+
+
+def step_roofline(kernels, steps, cells_per_s, word_bytes):
+    """Whole-step figure: compulsory bytes of the launches that ran (bench.py's own launch counters x tools/accounting.py words) over the
+    step time; the fixed contract figure of SURVEY §8(d) (250 words per cell and step) beside it."""
+    launches = {k: v["launches"] / float(steps) for k, v in kernels.items()}
+    words = step_compulsory_words(launches)
+    achieved = cells_per_s * words * word_bytes / 1e9
+    contract = cells_per_s * A_STEP_CONTRACT_WORDS * word_bytes / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "per": "GPU",
+            "bytes": "compulsory", "compulsory_words_per_cell_step": words, "compulsory_bytes_per_cell_step": words * word_bytes,
+            "contract_words_per_cell_step": A_STEP_CONTRACT_WORDS, "contract_bytes_per_cell_step": A_STEP_CONTRACT_WORDS * word_bytes,
+            "contract_achieved": contract, "contract_frac": contract / HBM_PEAK_GBS}
 
 
 def compressible_milestone(bz, device, steps=2, substep_float32=False):
@@ -128,29 +120,44 @@ def compressible_milestone(bz, device, steps=2, substep_float32=False):
     sub_ms = sum(prof[k][0] for k in prof if k.startswith("acoustic_horizontal") or k.startswith("acoustic_column")) / steps
     per_sub = sub_ms / sum(nsub)
     cells = Nx * Ny * Nz
+    kernels = kernel_table(prof)
+    # the substep pair (forward sweep with the horizontal step + backward sweep) priced in compulsory words (33; the reference's unfused
+    # kernel list moves 58 contract words per substep); with substep_floattype = Float32 ten of its arrays are 4-byte words
+    fwd = kernels.get("acoustic_horizontal+column_forward", {}).get("avg_ms", 0.0)
+    t_f, src_f = load_traffic(ROOT, "acoustic_horizontal+column_forward")
+    t_b, _ = load_traffic(ROOT, "acoustic_column_backward")
+    pair_traffic = (t_f + t_b) if (t_f and t_b and not substep_float32) else None
+    sub_bytes = (ACOUSTIC_SUBSTEP_COMPULSORY_WORDS * 8 - (4 * 16 if substep_float32 else 0)) * cells      # f32 storage: 16 of the 33 words are working-field words
+    sub_roof = {"bound": "hbm", "kernel": "acoustic substep (column forward + backward)", "achieved": sub_bytes / (per_sub * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sub_bytes / (per_sub * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": pair_traffic, "traffic_source": src_f if pair_traffic else None,
+                "traffic_over_compulsory": pair_traffic / sub_bytes if pair_traffic else None,
+                "bytes": "compulsory", "compulsory_words_per_cell": ACOUSTIC_SUBSTEP_COMPULSORY_WORDS, "compulsory_bytes_per_substep": sub_bytes,
+                "contract_words_per_cell": ACOUSTIC_SUBSTEP_CONTRACT_WORDS, "forward_sweep_ms": fwd}
     out = {"metric": "grid-cells advanced/sec, compressible split-explicit WS-RK3 step", "value": cells / (ms * 1e-3),
            "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": 1.0, "substeps_per_stage": nsub,
-           "acoustic_substep_ms": per_sub,
-           "acoustic_substep_roofline": {"bound": "hbm", "algorithmic_bytes_per_cell_substep": 58 * 8,
-                                         "achieved": cells * 58 * 8 / (per_sub * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                         "unit": "GB/s", "frac": cells * 58 * 8 / (per_sub * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "acoustic_substep_ms": per_sub, "substep_loop_ms_per_step": sub_ms, "non_substep_ms_per_step": ms - sub_ms,
+           "acoustic_substep_roofline": sub_roof,
+           "roofline": dominant_roofline(kernels, cells, 8, with_traffic=not substep_float32) if not substep_float32 else None,
+           "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(kernels.items())},
            "finite": bool(torch.isfinite(m.velocities["w"].interior).all().item())}
     del m
     torch.cuda.empty_cache()
     if not substep_float32:
         try:
             r = compressible_milestone(bz, device, steps, substep_float32=True)
-            out["substep_floattype_float32"] = {k: r[k] for k in ("value", "ms_per_step", "acoustic_substep_ms", "finite")}
+            out["substep_floattype_float32"] = {k: r[k] for k in ("value", "ms_per_step", "acoustic_substep_ms", "substep_loop_ms_per_step",
+                                                                  "non_substep_ms_per_step", "acoustic_substep_roofline", "finite")}
             out["substep_floattype_float32"]["tolerance"] = "2e-6 of the field scale after three steps against the Float64 oracle (tests/test_gpu_compressible.py)"
         except Exception as exc:      # noqa: BLE001
             out["substep_floattype_float32"] = {"error": repr(exc)}
     return out
 
 
-def float32_run(bz, device, N, steps=10, warmup=2):
+def float32_run(bz, device, N, steps=10, warmup=2, single_steps=False):
     """The same workload with eltype(grid) = Float32 (lib/libbreeze_hip_f32.so) — what the reference's own GPU benchmarks run
     (benchmarking/src/convective_boundary_layer.jl:59,70).  Reported beside the Float64 headline, never as `value`
-    ("Float32 run reported separately"); algorithmic bytes are 250 words x 4 B = 1000 B per cell and step."""
+    ("Float32 run reported separately"); every roofline block in 4-byte words (tools/accounting.py)."""
     import torch
     grid = bz.RectilinearGrid((N, N, N), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2], float_type=np.float32)
     ref = bz.ReferenceState(grid, surface_pressure=101325, potential_temperature=300)
@@ -162,18 +169,23 @@ def float32_run(bz, device, N, steps=10, warmup=2):
     m.profile_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        m.time_step(1.0)
+    if single_steps:
+        for _ in range(steps):
+            m.time_step(1.0)
+    else:
+        m.time_steps(1.0, steps, diagnose_last=True)      # the multi-step seam, as the Float64 headline run
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     m.profile_enable(False)
-    prof = {k: ms / steps for k, (ms, n) in m.profile().items() if n}
+    kernels = kernel_table(m.profile())
     cells = N ** 3
     rate = cells * steps / el
     out = {"dtype": "f32", "value": rate, "unit": "cells/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "grid": [N, N, N],
-           "step_roofline": {"bound": "hbm", "achieved": rate * A_STEP_WORDS * 4 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": rate * A_STEP_WORDS * 4 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 4},
-           "kernels_ms_per_step": prof, "finite": bool(torch.isfinite(m.momentum["ρw"].parent).all().item()),
+           "roofline": dominant_roofline(kernels, cells, 4, f32=True),
+           "step_roofline": step_roofline(kernels, steps, rate, 4),
+           "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(kernels.items())},
+           "kernel_launches_per_step": {k: v["launches"] / steps for k, v in sorted(kernels.items())},
+           "finite": bool(torch.isfinite(m.momentum["ρw"].parent).all().item()),
            "tolerance_vs_float64_oracle": "1e-4 after three steps, 2e-5 per tendency (tests/test_float32.py)"}
     del m
     torch.cuda.empty_cache()
@@ -261,8 +273,11 @@ def cbl_run(args, bz, device):
         m.time_step(dt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        m.time_step(dt)
+    if args.single_steps:
+        for _ in range(args.steps):
+            m.time_step(dt)
+    else:
+        m.time_steps(dt, args.steps, diagnose_last=True)      # many_time_steps! (benchmarking/src/timestepping.jl:11-16)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     # per-kernel times from a second, untimed pass: the HIP events around ~40 launches per step cost ~0.2 ms per step, 11 % of the step at
@@ -270,22 +285,17 @@ def cbl_run(args, bz, device):
     psteps = min(args.steps, 20)
     m.profile_reset()
     m.profile_enable(True)
-    for _ in range(psteps):
-        m.time_step(dt)
+    if args.single_steps:
+        for _ in range(psteps):
+            m.time_step(dt)
+    else:
+        m.time_steps(dt, psteps, diagnose_last=True)
     torch.cuda.synchronize()
     m.profile_enable(False)
     cells, word = Nx * Ny * Nz, 4 if f32 else 8
-    kernels = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms} for k, (ms, n) in m.profile().items() if n}
-    known = [k for k in kernels if k in WORDS_PER_CELL]
-    roofline = None
-    if known:
-        dom = max(known, key=lambda k: kernels[k]["total_ms"])
-        dom_bytes = WORDS_PER_CELL[dom] * word * cells
-        achieved = dom_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"]}
+    kernels = kernel_table(m.profile())
+    roofline = dominant_roofline(kernels, cells, word, f32=f32, with_traffic=(Nx, Ny, Nz) == (512, 512, 512))
     rate = cells * args.steps / elapsed
-    step_achieved = rate * A_STEP_WORDS * word / 1e9
     out = {"metric": "grid points per second (time_step!), convective boundary layer benchmark case",
            "value": rate, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -294,9 +304,7 @@ def cbl_run(args, bz, device):
                                   f"AnelasticDynamics, WENO{args.cbl_order}, halo 5, topology {args.cbl_topology}, FPlane + geostrophic forcing + u* drag + surface heat flux, "
                                   f"{'Float32' if f32 else 'Float64'}, dt={dt}s", "grid": [Nx, Ny, Nz], "dt": dt, "parallelism": "single GPU"},
            "roofline": roofline,
-           "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_achieved / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_cell_step": A_STEP_WORDS * word,
-                             "note": "the dry-bubble contract figure (250 words per cell and step); the forcing and flux kernels of this case move a few words more"},
+           "step_roofline": step_roofline(kernels, psteps, rate, word),
            "kernels_ms_per_step": {k: v["total_ms"] / psteps for k, v in sorted(kernels.items())},
            "kernel_launches_per_step": {k: v["launches"] / psteps for k, v in sorted(kernels.items())},
            "kernel_times": f"HIP events of a second pass of {psteps} steps after the timed region",
@@ -359,12 +367,7 @@ def tendency_run(args, bz, device):
     m.profile_enable(False)
     cells, word = Nx * Ny * Nz, 4 if f32 else 8
     kernels = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms} for k, (ms, n) in m.profile().items() if n}
-    roofline = None
-    if words and kernel in kernels:
-        nbytes = words * word * cells
-        achieved = nbytes / (kernels[kernel]["avg_ms"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": kernels[kernel]["avg_ms"]}
+    roofline = roofline_block(kernel, kernels[kernel]["avg_ms"], cells, word, words=words) if (words and kernel in kernels) else None
     out = {"metric": f"grid points per second, one {'scalar tendency' if scalar else 'compute_tendencies!'} evaluation (BreezeBenchmarks {args.workload})",
            "value": cells * args.steps / elapsed, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -396,7 +399,7 @@ def config4_run(args, bz, rank, world, dist, device, fail):
     mkw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
                microphysics=bz.DCMIP2016KesslerMicrophysics())
     slabs = world > 1 or args.slab
-    transport = "rccl" if args.transport in ("auto", "rccl") else "torch"
+    transport = args.transport
     try:
         if slabs:
             m = bz.compressible.SlabCompressibleModel(G, rank, world, dyn, advection=bz.WENO(order=order), device=device,
@@ -438,6 +441,7 @@ def config4_run(args, bz, rank, world, dist, device, fail):
         fail(f"config4 run failed: {exc!r}")
     if rank == 0:
         prof = {k: v[0] / args.steps for k, v in sorted(m.profile().items())}
+        kernels = kernel_table(m.profile())
         nsub = [m.stage_substeps(dt, b)[0] for b in (1 / 3, 1 / 2, 1.0)]
         out = {"metric": "grid-cells advanced/sec (compressible split-explicit + Kessler step), 512x512x128",
                "value": Nx * Ny * Nz * args.steps / elapsed, "unit": "cells/s", "n_gpus": world, "steps": args.steps,
@@ -450,8 +454,10 @@ def config4_run(args, bz, rank, world, dist, device, fail):
                           "parallelism": "single GPU" if not slabs else
                           f"{world} y-slabs of {Nx}x{Ny // world}x{Nz}, halo exchanges over " +
                           ("RCCL inside the C library (bz_comm.hip)" if transport == "rccl" else "torch.distributed (RCCL backend)")},
+               "roofline": dominant_roofline(kernels, Nx * (Ny // world) * Nz, 4 if f32 else 8, f32=f32, with_traffic=False),
                "kernels_ms_per_step": prof, "finite": finite,
                "comm_ms_per_step": sum(v for k, v in prof.items() if k.startswith("comm_")),
+               "transport": transport if slabs else None,
                "note": "second milestone (SURVEY.md §8 a15-a17); the headline metric is the default workload"}
         if slabs and transport == "rccl":
             out["comm_bytes_sent_per_step_per_gpu"] = (m.comm_info()[1] - sent0) // args.steps
@@ -472,7 +478,7 @@ def _free_port():
 
 def error_line(args, message, **extra):
     out = {"metric": METRIC, "value": None, "unit": "cells/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+           "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling or ("strong" if args.gpus > 1 else "weak"), "vs_baseline": None, "dtype": "f64",
            "data": "synthetic", "config": {"workload": args.workload, "parallelism": f"{args.gpus} y-slabs"},
            "error": message}
     out.update(extra)
@@ -570,6 +576,64 @@ def library_halo_selfcheck(model):
         raise RuntimeError(f"rank {r}: the library's y-halo exchange delivered wrong rows")
 
 
+def preflight(args, bz, rank, world, dist, device, transport="rccl", per_rank=64, steps=2, tol=1e-10):
+    """Everything a multi-rank run needs, proven on a small problem BEFORE any timed region:
+      1. the slab model builds on every rank — communicator bootstrap inside the C library (ncclCommInitRank over the id broadcast
+         through torch.distributed) or the torch.distributed transport;
+      2. a rank-coded y-halo exchange through that transport delivers the ring neighbours' rows;
+      3. `steps` steps of a per_rank^3-per-rank dry bubble (the lean distributed step: halo exchanges under the interior tiles, both
+         all-to-alls of every pressure solve, the phi row) agree with the SAME global domain stepped by the single-GPU seam on this
+         rank's own GPU to `tol` of the field scale — every rank compares its own slab.
+    Returns a summary dict; raises on any failure (the caller turns that into a JSON error line and a non-zero exit code)."""
+    import torch
+    from breeze_jl_amd.distributed import SlabAtmosphereModel
+    n = per_rank
+    G = (n, n * world, n)
+    Ly = (EXTENT[1][1] - EXTENT[1][0]) * world
+    ggrid = bz.RectilinearGrid(G, x=EXTENT[0], y=(EXTENT[1][0], EXTENT[1][0] + Ly), z=EXTENT[2])
+
+    def ic(x, y, z):      # one bubble per 20 km of y, off-centre so that it straddles a slab edge for world > 1
+        yy = np.mod(y - EXTENT[1][0] + 7.5e3, EXTENT[1][1] - EXTENT[1][0]) + EXTENT[1][0]
+        return bubble(x, yy, z)
+
+    t0 = time.perf_counter()
+    m = SlabAtmosphereModel(ggrid, rank, world, advection=bz.WENO(order=5), surface_pressure=101325, potential_temperature=300,
+                            device=device, transport=transport)
+    if transport == "rccl":
+        library_halo_selfcheck(m)
+    elif world > 1:
+        comm_selfcheck(m.decomp, device)
+    m.set(θ=ic, u=3.0, v=-2.0)
+    m.time_steps(1.0, steps, diagnose_last=True)
+    m.synchronize() if hasattr(m, "synchronize") else torch.cuda.synchronize()
+    ref = bz.AtmosphereModel(ggrid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(ggrid, surface_pressure=101325, potential_temperature=300)),
+                             advection=bz.WENO(order=5), device=device)
+    ref.set(θ=ic, u=3.0, v=-2.0)
+    ref.time_steps(1.0, steps, diagnose_last=True)
+    ref.synchronize()
+    worst = 0.0
+    pairs = (("ρu", m.momentum["ρu"], ref.momentum["ρu"]), ("ρv", m.momentum["ρv"], ref.momentum["ρv"]), ("ρw", m.momentum["ρw"], ref.momentum["ρw"]),
+             ("ρθ", m.potential_temperature_density, ref.potential_temperature_density), ("T", m.temperature, ref.temperature))
+    mom = max(float(ref.momentum[k].interior.abs().max()) for k in ("ρu", "ρv", "ρw"))
+    for name, a, b in pairs:
+        mine = a.interior
+        want = b.interior[:, rank * n:(rank + 1) * n, :]
+        scale = mom if name.startswith("ρ") and name != "ρθ" else float(want.abs().max())
+        err = float((mine - want).abs().max()) / max(scale, 1e-30)
+        worst = max(worst, err)
+        if not (err <= tol):
+            raise RuntimeError(f"rank {rank}: preflight parity of {name} against the single-GPU step: {err:.3e} > {tol:g}")
+    if dist is not None:
+        t = torch.tensor([worst], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        worst = t.item()
+    out = {"status": "ok", "transport": transport, "world": world, "grid": list(G), "steps": steps, "tolerance": tol,
+           "max_relative_deviation_from_single_gpu": worst, "halo_selfcheck": "ok", "seconds": time.perf_counter() - t0}
+    del m, ref
+    torch.cuda.empty_cache()
+    return out
+
+
 def problem(args, world):
     """Global grid size, per-rank slab and the label of the workload."""
     N = args.size
@@ -578,11 +642,11 @@ def problem(args, world):
         label = ("dry thermal bubble 1024x1024x512 RectilinearGrid (Periodic,Periodic,Bounded), halo 3, AnelasticDynamics + WENO5 + "
                  "SSP-RK3, Float64, dt=1s, y-slabs (BASELINE.json configs[3])")
         scaling = "strong"
-    elif args.scaling == "strong" or world == 1:
+    elif (args.scaling or "strong") == "strong" or world == 1:
         G = (N, N, N)
         label = (f"dry thermal bubble {N}^3 RectilinearGrid (Periodic,Periodic,Bounded), halo 3, AnelasticDynamics + WENO5 + "
                  "SSP-RK3, Float64, dt=1s (BASELINE.json configs[1])")
-        scaling = "strong" if world > 1 else args.scaling
+        scaling = "strong" if world > 1 else (args.scaling or "weak")      # one GPU: the two notions coincide; the contract's default label
     else:
         G = (N, N * world, N)
         label = (f"dry thermal bubble {N}^3 per GPU: {N}x{N * world}x{N} RectilinearGrid (Periodic,Periodic,Bounded), halo 3, "
@@ -629,21 +693,40 @@ def run_rank(args):
                                                         flush=True), os._exit(1)))
 
     if cpu_selftest:
-        # launcher self-test (tests/test_bench_launcher.py): rendezvous, the slab communication pattern on CPU tensors
-        # under gloo, result line — no model, no GPU
+        # launcher self-test (tests/test_bench_launcher.py): rendezvous, the slab communication pattern on CPU tensors under gloo, the
+        # resolved defaults of a multi-rank run (scaling, grid, transport), the preflight's control flow (its communication check runs
+        # on CPU tensors; --selftest-fail injects a failure on the last rank) and the result / error line — no model, no GPU
         from breeze_jl_amd.distributed import SlabDecomposition
         d = SlabDecomposition(20, 6, 4, 3, rank, world)
         try:
             comm_selfcheck(d, "cpu")
+            if args.selftest_fail and rank == world - 1:
+                raise RuntimeError("injected preflight failure (--selftest-fail)")
         except Exception as exc:   # noqa: BLE001
-            fail(f"communication self-check failed: {exc!r}")
+            fail(f"preflight failed: {exc!r}")
         ok = torch.ones(1, dtype=torch.int32)
         if dist is not None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"launcher_selftest": "ok", "n_gpus": world, "backend": "gloo"}), flush=True)
+            G, label, scaling = problem(args, world)
+            print(json.dumps({"launcher_selftest": "ok", "n_gpus": world, "backend": "gloo", "scaling": scaling, "grid": list(G),
+                              "grid_per_gpu": [G[0], G[1] // world, G[2]], "transport": args.transport,
+                              "preflight": {"status": "ok", "mode": "cpu selftest: slab exchange + both transposes on CPU tensors"},
+                              "preflight_only": bool(args.preflight)}), flush=True)
         if dist is not None:
+            dist.destroy_process_group()
+        return 0
+
+    if args.preflight:      # stand-alone preflight: one JSON line, exit code 0 / 1
+        try:
+            summary = preflight(args, bz, rank, world, dist, device, transport=args.transport)
+        except Exception as exc:      # noqa: BLE001
+            fail(f"preflight failed: {exc!r}")
+        if rank == 0:
+            print(json.dumps({"preflight": summary, "n_gpus": world}), flush=True)
+        if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return 0
 
@@ -671,42 +754,26 @@ def run_rank(args):
             yy = np.mod(y - EXTENT[1][0], EXTENT[1][1] - EXTENT[1][0]) + EXTENT[1][0]
             return bubble(x, yy, z)
 
-        # Transport: "rccl" = the communicator inside the C library (bz_comm.hip: the whole step is one C call, halo exchange
-        # overlapped with interior tiles); "torch" = the Python orchestration over torch.distributed.  "auto" tries the library
-        # first — its first contact with more than one GPU is this very run — verifies a rank-coded halo exchange through it, and
-        # only if that raises on some rank do ALL ranks switch to the torch transport.  The line says which one carried the run.
-        def build(transport):
-            m = SlabAtmosphereModel(ggrid, rank, world, advection=bz.WENO(order=5), surface_pressure=101325,
-                                    potential_temperature=300, device=device, transport=transport)
-            if transport == "rccl":
-                library_halo_selfcheck(m)
-            elif world > 1:
-                comm_selfcheck(m.decomp, device)
-            m.set(θ=bubbles)
-            m.time_step(dt)
-            torch.cuda.synchronize()
-            return m
-
-        transport, transport_note = ("rccl" if args.transport == "auto" else args.transport), None
-        try:
-            err = None
+        # Transport: "rccl" = the communicator inside the C library (bz_comm.hip: the whole step is one C call, halo exchange overlapped
+        # with interior tiles); "torch" = the Python orchestration over torch.distributed (explicit only).  No fallback: whatever was
+        # asked for either passes the preflight and carries the run, or the run ends with an error line.
+        transport = args.transport
+        preflight_summary = None
+        if world > 1 and not args.no_preflight:
             try:
-                model = build(transport)
+                preflight_summary = preflight(args, bz, rank, world, dist, device, transport=transport)
             except Exception as exc:      # noqa: BLE001
-                err = repr(exc)
-                print(f"[bench rank {rank}] transport {transport}: {err}", file=sys.stderr, flush=True)
-            if args.transport == "auto":
-                bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
-                if dist is not None:
-                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-                if bad.item():
-                    transport_note = f"library transport failed on a rank ({err or 'another rank'}); torch.distributed carried the run"
-                    model = None
-                    torch.cuda.empty_cache()
-                    transport = "torch"
-                    model = build(transport)
-            elif err:
-                raise RuntimeError(err)
+                fail(f"preflight failed: {exc!r}")
+        try:
+            model = SlabAtmosphereModel(ggrid, rank, world, advection=bz.WENO(order=5), surface_pressure=101325,
+                                        potential_temperature=300, device=device, transport=transport)
+            if transport == "rccl":
+                library_halo_selfcheck(model)
+            elif world > 1:
+                comm_selfcheck(model.decomp, device)
+            model.set(θ=bubbles)
+            model.time_step(dt)
+            torch.cuda.synchronize()
             decomp = model.decomp if transport == "torch" else None
         except Exception as exc:      # noqa: BLE001
             fail(f"slab driver failed: {exc!r}")
@@ -776,31 +843,7 @@ def run_rank(args):
         for name, (ms, n) in prof.items():
             if n:
                 kernels[name] = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
-        dom = max((k for k in kernels if k in WORDS_PER_CELL), key=lambda k: kernels[k]["total_ms"])
-        contract_bytes = WORDS_PER_CELL[dom] * 8 * cells_rank
-        dom_bytes = COMPULSORY_WORDS.get(dom, WORDS_PER_CELL[dom]) * 8 * cells_rank
-        achieved = dom_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        contract_achieved = contract_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        # HBM-side bytes per launch of that kernel group measured by rocprofv3 PMC passes (committed under profiles/,
-        # collected at 512^3 on one GPU with the same build: a reference figure, not a measurement of this very run)
-        traffic, traffic_src = None, None
-        if cells_rank == 512 ** 3:
-            for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-                try:
-                    with open(os.path.join(ROOT, "profiles", fn)) as fh:
-                        traffic = json.load(fh)["per_kernel_group"][dom]["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/" + fn
-                    break
-                except (OSError, KeyError, ValueError):
-                    continue
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernels[dom]["avg_ms"],
-                    "algorithmic_words_per_cell": COMPULSORY_WORDS.get(dom, WORDS_PER_CELL[dom]),
-                    "contract_words_per_cell": WORDS_PER_CELL[dom], "contract_achieved": contract_achieved,
-                    "contract_frac": contract_achieved / HBM_PEAK_GBS,
-                    "traffic_frac": (traffic / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}
-        step_achieved = (cells_rank * args.steps / elapsed) * A_STEP_WORDS * 8 / 1e9
+        roofline = dominant_roofline(kernels, cells_rank, 8, with_traffic=(cells_rank == 512 ** 3))
         kernel_ms = sum(v["total_ms"] for k, v in kernels.items() if not k.startswith("comm_")) / args.steps
         out = {
             "metric": METRIC,
@@ -810,23 +853,26 @@ def run_rank(args):
             "config": {"workload": label, "grid": list(G), "grid_per_gpu": [G[0], G[1] // world, G[2]], "dt": dt,
                        "parallelism": parallelism},
             "roofline": roofline,
-            "step_roofline": {"bound": "hbm", "achieved": step_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": step_achieved / HBM_PEAK_GBS, "per": "GPU",
-                              "algorithmic_bytes_per_cell_step": A_STEP_WORDS * 8,
-                              "compulsory_bytes_per_cell_step": A_STEP_COMPULSORY_WORDS * 8,
-                              "compulsory_frac": (cells_rank * args.steps / elapsed) * A_STEP_COMPULSORY_WORDS * 8 / 1e9 / HBM_PEAK_GBS},
+            "step_roofline": step_roofline(kernels, args.steps, cells_rank * args.steps / elapsed, 8),
+            "stepping": "K separate time_step! calls" if (args.single_steps or not hasattr(model, "time_steps")) else
+                        "bz_time_steps_anelastic(n = K, diagnose_last = 1): the reference's many_time_steps! loop in one call; every step but the last skips the diagnosis pass",
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(kernels.items())},
             "kernel_launches_per_step": {k: v["launches"] / args.steps for k, v in sorted(kernels.items())},
             "finite": finite,
         }
         if use_slabs:
-            out["comm_ms_per_step"] = comm_ms                       # inside point-to-point batches (slowest rank)
-            out["compute_ms_per_step"] = kernel_ms                  # library kernels of rank 0 (HIP events)
-            out["other_ms_per_step"] = max(0.0, ms_per_step - comm_ms - kernel_ms)   # packs, transforms' glue, launch gaps, waits
+            # the scalar-pair kernel runs on the library's side stream whenever messages are in flight (bz_comm.hip: fork): the main
+            # stream's busy time excludes it, and what the main stream is not busy with is what the exchanges (and launch gaps) expose
+            forked = transport == "rccl" and (world > 1 or os.environ.get("BZ_COMM_SELF_MESSAGES") == "1") and os.environ.get("BZ_COMM_NO_SIDE_SCALAR") != "1"
+            side_ms = kernels.get("scalar_tendencies+rk3+thermo", {}).get("total_ms", 0.0) / args.steps if forked else 0.0
+            out["comm_ms_per_step"] = comm_ms                       # inside point-to-point batches (slowest rank; HIP events on the stream they run on)
+            out["compute_ms_per_step"] = kernel_ms                  # library kernels of rank 0 (HIP events), all streams
+            out["exposed_comm_ms_per_step"] = max(0.0, ms_per_step - (kernel_ms - side_ms))
+            out["exposed_comm_definition"] = "ms_per_step - kernel time of the main stream (all kernel groups but comm_*, and but the scalar-pair kernel when it runs on the side stream): exchanges, waits and launch gaps the main stream could not hide"
             out["comm_bytes_sent_per_step_per_gpu"] = comm_bytes
             out["transport"] = transport
-            if transport_note:
-                out["transport_note"] = transport_note
+            if preflight_summary:
+                out["preflight"] = preflight_summary
         if world == 1 and not args.no_compressible and not use_slabs and args.workload == "bubble":
             try:
                 del model
@@ -836,7 +882,7 @@ def run_rank(args):
                 out["second_milestone"] = {"error": repr(exc)}
         if world == 1 and not args.no_float32 and not use_slabs and args.workload == "bubble":
             try:
-                out["float32"] = float32_run(bz, device, args.size)
+                out["float32"] = float32_run(bz, device, args.size, single_steps=args.single_steps)
             except Exception as exc:
                 out["float32"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
@@ -859,7 +905,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N > 1: strong (default) = the size^3 domain split N ways (BASELINE.md §4); weak = size^3 per GPU (explicit only)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="run only the multi-rank preflight (communicator bootstrap, rank-coded halo exchange, 2-step 64^3-per-rank parity against the "
+                         "single-GPU step) and print its JSON line; exit code 1 with an \"error\" line on failure")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the preflight that precedes the timed region")
+    ap.add_argument("--selftest-fail", action="store_true", help="with --selftest-launcher: inject a preflight failure on the last rank")
     ap.add_argument("--cbl-size", default="512x512x256", help="--workload cbl: NxxNyxNz (CI sizes: 256x256x128, 512x512x256, 768x768x256)")
     ap.add_argument("--cbl-order", type=int, default=5, choices=(5, 7, 9), help="--workload cbl: WENO order (CI: 5 and 9)")
     ap.add_argument("--cbl-float64", action="store_true", help="--workload cbl in Float64 (the reference benchmarks Float32)")
@@ -875,8 +927,8 @@ def main():
     ap.add_argument("--no-cpu-full-size", action="store_true", help="skip the 512^3 leg of the CPU baseline (runs only when the host has >= 96 GB free)")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of the slab decomposition (explicit only)")
     ap.add_argument("--slab", action="store_true", help="N=1: run the slab driver (world 1) instead of the whole-step seam")
-    ap.add_argument("--transport", choices=("auto", "rccl", "torch"), default="auto",
-                    help="slab runs: the C library's RCCL communicator, torch.distributed, or try the first and fall back")
+    ap.add_argument("--transport", choices=("rccl", "torch"), default="rccl",
+                    help="slab runs: the C library's RCCL communicator (default) or the Python orchestration over torch.distributed; never switched silently")
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-float32", action="store_true", help="skip the Float32 run reported under `float32`")

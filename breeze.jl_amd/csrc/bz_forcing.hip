@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F
         return tot;
     };
     bool any;
-    {
+    // wall faces (v at j = 0 of a Bounded y, u at i = 0 of a Bounded x) carry no tendency: the wall-aware tendency kernels never write
+    // G there, so anything added here would pile up from evaluation to evaluation; as k_apply_relaxation
+    if (!(g.bounded_x && i == 0)) {
         double G = Gu[n];
         if (F.f != 0.0) {
             const double a = (rv[n - sx] + rv[n - sx + sy]) / 2, b = (rv[n] + rv[n + sy]) / 2;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F
         if (any) G += scale * t;
         Gu[n] = G;
     }
-    {
+    if (!(g.bounded_y && j == 0)) {
         double G = Gv[n];
         if (F.f != 0.0) {
             const double a = (ru[n - sy] + ru[n - sy + sx]) / 2, b = (ru[n] + ru[n + sx]) / 2;
@@ -164,8 +166,8 @@ __global__ __launch_bounds__(256) void k_bottom_flux(DevGrid g, double Jth, doub
         const double v_fc = (va + vb) / 2;
         const double ua = (ru[n - sy] + ru[n - sy + sx]) / 2, ub = (ru[n] + ru[n + sx]) / 2;
         const double u_cf = (ua + ub) / 2;
-        Gu[n] += scale * ((-drag * u / sqrt(u * u + v_fc * v_fc + drag_eps)) / dz);
-        Gv[n] += scale * ((-drag * v / sqrt(u_cf * u_cf + v * v + drag_eps)) / dz);
+        if (!(g.bounded_x && i == 0)) Gu[n] += scale * ((-drag * u / sqrt(u * u + v_fc * v_fc + drag_eps)) / dz);      // wall faces carry no tendency
+        if (!(g.bounded_y && j == 0)) Gv[n] += scale * ((-drag * v / sqrt(u_cf * u_cf + v * v + drag_eps)) / dz);
     }
 }
 
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(256) void k_bulk_bottom_flux(DevGrid g, BulkParams 
         const double u2 = ((sq(u[n - sy]) + sq(u[n - sy + sx])) / 2 + (sq(u[n]) + sq(u[n + sx])) / 2) / 2;
         const double Ju = -B.drag_rho0 * B.drag_c * sqrt(sq(u[n]) + v2 + B.drag_g2) * u[n];
         const double Jv = -B.drag_rho0 * B.drag_c * sqrt(u2 + sq(v[n]) + B.drag_g2) * v[n];
-        Gu[n] += scale * (Ju / dz);
-        Gv[n] += scale * (Jv / dz);
+        if (!(g.bounded_x && i == 0)) Gu[n] += scale * (Ju / dz);
+        if (!(g.bounded_y && j == 0)) Gv[n] += scale * (Jv / dz);
     }
     if (B.heat || B.vapor) {
         const double U2 = (sq(u[n]) + sq(u[n + sx])) / 2 + (sq(v[n]) + sq(v[n + sy])) / 2;
@@ -270,27 +272,37 @@ extern "C" int bz_set_field_forcing(bz_ctx *ctx, const double *F, int specific)
 extern "C" int bz_set_relaxation(bz_ctx *ctx, const bz_column_relaxation *r)
 {
     if (!ctx) return BZ_ERR_INVALID;
-    ++ctx->config_epoch;
-    free_relaxation(ctx);
-    if (!r) return BZ_OK;
-    if (ctx->compressible && (ctx->slab_mode || r->specific_mask || r->rate_moisture)) {
+    // validate first: a rejected request leaves the sponge that is attached untouched
+    if (r && ctx->compressible && (ctx->slab_mode || r->specific_mask || r->rate_moisture)) {
         ctx->last_error = "bz_set_relaxation: CompressibleDynamics takes the density-keyed sponges of rho u, rho v, rho w, rho theta on single-device contexts";
         return BZ_ERR_UNSUPPORTED;
     }
-    if (r->specific_mask & ~7) { ctx->last_error = "bz_set_relaxation: specific_mask names u (1), v (2), w (4)"; return BZ_ERR_INVALID; }
+    if (r && (r->specific_mask & ~7)) { ctx->last_error = "bz_set_relaxation: specific_mask names u (1), v (2), w (4)"; return BZ_ERR_INVALID; }
+    ++ctx->config_epoch;
+    free_relaxation(ctx);
+    if (!r) return BZ_OK;
     const int Nz = ctx->dg.Nz, L = Nz + 1;
     const double *rate[5] = {r->rate_u, r->rate_v, r->rate_w, r->rate_theta, r->rate_moisture};
     const double *target[5] = {r->target_u, r->target_v, r->target_w, r->target_theta, r->target_moisture};
-    BZ_HIP(hipMalloc(&ctx->d_relax, (size_t)10 * L * sizeof(double)));
-    BZ_HIP(hipMemsetAsync(ctx->d_relax, 0, (size_t)10 * L * sizeof(double), ctx->stream));
+    // a HIP failure on the way detaches cleanly: the context is either unchanged (above) or without a sponge
+    auto fail = [&](hipError_t e) {
+        ctx->last_error = std::string("bz_set_relaxation: ") + hipGetErrorString(e);
+        free_relaxation(ctx);
+        return -(int)e;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&ctx->d_relax, (size_t)10 * L * sizeof(double))) != hipSuccess) { ctx->d_relax = nullptr; return fail(e); }
+    if ((e = hipMemsetAsync(ctx->d_relax, 0, (size_t)10 * L * sizeof(double), ctx->stream)) != hipSuccess) return fail(e);
+    int mask = 0;
     for (int c = 0; c < 5; ++c) {
         if (!rate[c]) continue;
         const size_t len = (size_t)(c == 2 ? Nz + 1 : Nz) * sizeof(double);
-        BZ_HIP(hipMemcpyAsync(ctx->d_relax + (size_t)(2 * c) * L, rate[c], len, hipMemcpyHostToDevice, ctx->stream));
-        if (target[c]) BZ_HIP(hipMemcpyAsync(ctx->d_relax + (size_t)(2 * c + 1) * L, target[c], len, hipMemcpyHostToDevice, ctx->stream));
-        ctx->relax_mask |= 1 << c;
+        if ((e = hipMemcpyAsync(ctx->d_relax + (size_t)(2 * c) * L, rate[c], len, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+        if (target[c] && (e = hipMemcpyAsync(ctx->d_relax + (size_t)(2 * c + 1) * L, target[c], len, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+        mask |= 1 << c;
     }
-    BZ_HIP(hipStreamSynchronize(ctx->stream));      // the host columns may go away after the call
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e);      // the host columns may go away after the call
+    ctx->relax_mask = mask;
     ctx->relax_specific = r->specific_mask;
     ctx->has_relaxation = ctx->relax_mask != 0 || ctx->field_forcing != nullptr;
     return BZ_OK;

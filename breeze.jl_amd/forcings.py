@@ -150,9 +150,13 @@ def _is_field_forcing(item):
     if callable(f):
         import inspect
         try:
-            return len(inspect.signature(f).parameters) == 3
+            nargs = len(inspect.signature(f).parameters)
         except (TypeError, ValueError):
             return False
+        if nargs == 4:      # Forcing(f(x, y, z, t)): nothing here re-evaluates a forcing field as the clock advances
+            raise NotImplementedError("Forcing(f(x, y, z, t)): time-dependent 3-D forcings are not implemented — pass f(x, y, z) "
+                                      "(evaluated once) or a 3-D array and refresh it yourself between steps")
+        return nargs == 3
     return np.ndim(f) == 3
 
 

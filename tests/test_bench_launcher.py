@@ -27,7 +27,37 @@ def test_self_launch_runs_the_slab_exchange_under_gloo(world):
     assert p.returncode == 0, p.stderr[-2000:]
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
-    assert out == {"launcher_selftest": "ok", "n_gpus": world, "backend": "gloo"}
+    assert out["launcher_selftest"] == "ok" and out["n_gpus"] == world and out["backend"] == "gloo"
+    # the defaults of a multi-rank run: the curve BASELINE.md §4 names — 512^3 split N ways — over the library's
+    # RCCL transport; weak scaling and config3 are explicit options
+    assert out["scaling"] == "strong" and out["grid"] == [512, 512, 512] and out["grid_per_gpu"] == [512, 512 // world, 512]
+    assert out["transport"] == "rccl" and out["preflight"]["status"] == "ok"
+
+
+def test_explicit_scaling_options_and_preflight_mode():
+    p, lines = _run(["--gpus", "2", "--selftest-launcher", "--scaling", "weak"])
+    assert p.returncode == 0 and json.loads(lines[0])["scaling"] == "weak" and json.loads(lines[0])["grid"] == [512, 1024, 512]
+    p, lines = _run(["--gpus", "2", "--selftest-launcher", "--workload", "config3"])
+    assert p.returncode == 0 and json.loads(lines[0])["grid_per_gpu"] == [1024, 512, 512]
+    p, lines = _run(["--gpus", "2", "--selftest-launcher", "--preflight"])
+    assert p.returncode == 0 and json.loads(lines[0])["preflight_only"] is True
+
+
+def test_failed_preflight_ends_the_run_with_an_error_line():
+    """(5b) a preflight failure on ANY rank: one JSON line with an "error" field, non-zero exit code, no timed region"""
+    p, lines = _run(["--gpus", "2", "--selftest-launcher", "--selftest-fail"])
+    assert p.returncode != 0
+    assert lines, (p.stdout, p.stderr[-1500:])
+    out = json.loads(lines[-1])
+    assert out["value"] is None and "error" in out and "launcher_selftest" not in out
+
+
+def test_no_silent_transport_switch():
+    """(5c) `auto` is gone: the transport is what the command line says (rccl by default, torch explicitly) or the run fails"""
+    p, _ = _run(["--gpus", "2", "--selftest-launcher", "--transport", "auto"])
+    assert p.returncode == 2 and "invalid choice" in p.stderr
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "transport_note" not in src and "carried the run" not in src
 
 
 def test_failed_multi_gpu_run_prints_an_error_line_not_a_fallback():
@@ -47,7 +77,10 @@ def test_workload_shapes():
     sys.path.insert(0, ROOT)
     import argparse
     import bench
-    a = argparse.Namespace(size=512, scaling="weak", workload="bubble")
+    a = argparse.Namespace(size=512, scaling=None, workload="bubble")
+    assert bench.problem(a, 1)[0] == (512, 512, 512) and bench.problem(a, 1)[2] == "weak"      # one GPU: the contract's label
+    assert bench.problem(a, 8)[0] == (512, 512, 512) and bench.problem(a, 8)[2] == "strong"    # default for N > 1: BASELINE.md §4
+    a.scaling = "weak"
     assert bench.problem(a, 1)[0] == (512, 512, 512)
     assert bench.problem(a, 8)[0] == (512, 4096, 512) and bench.problem(a, 8)[2] == "weak"
     a.scaling = "strong"

@@ -346,3 +346,18 @@ def test_closure_inside_y_walls(oracle, bz, moist):
     assert om.nu_e.max() > 0
     assert np.abs(nu - om.nu_e).max() < 1e-11 * om.nu_e.max()
     _compare(g, om, hm, 3, 2.0, 2e-9)
+
+
+@pytest.mark.gpu
+def test_forcing_stack_leaves_the_wall_face_tendency_alone(bz):
+    """FPlane, the geostrophic profiles and the u* drag must not accumulate on G_rho_v at the wall face j = 0 — the wall-aware
+    tendency kernels never write that row, so whatever a forcing kernel added there would grow by f <rho u> with every evaluation.  The
+    CBL benchmark stack (FPlane + geostrophic forcing + drag + heat flux) inside y walls, tendencies evaluated four times."""
+    m = bz.benchmarks.convective_boundary_layer((64, 32, 16), float_type=np.float64, topology=(bz.Periodic, bz.Bounded, bz.Bounded), halo=(3, 3, 3))
+    for _ in range(4):
+        bz.update_state_(m, compute_tendencies=True)
+        bz.compute_flux_bc_tendencies_(m)
+    m.synchronize()
+    Gv = m.G["ρv"].interior_cpu()
+    assert np.abs(Gv[:, 0, :]).max() == 0.0
+    assert np.abs(Gv[:, 1, :]).max() > 0.0          # the first interior face does carry the Coriolis term

@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 def main():
     bench, pmc = sys.argv[1], sys.argv[2]
     f32 = "--float32" in sys.argv[3:]          # the Float32 leg of the same bench line (b["float32"]), 4-byte words
-    from bench import COMPULSORY_WORDS, WORDS_PER_CELL
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from accounting import CONTRACT_WORDS as WORDS_PER_CELL, compulsory_words
     b = json.load(open(bench))
     p = json.load(open(pmc)).get("per_kernel_group_float32" if f32 else "per_kernel_group", {})
     word = 4 if f32 else 8
@@ -30,8 +31,10 @@ def main():
         cells *= n
     launches = b.get("kernel_launches_per_step", {})
     print(f"# Per-kernel roofline, {b['config']['workload']}" + (" — the Float32 leg (libbreeze_hip_f32.so)" if f32 else "") + "\n")
-    print(f"Step: {b['ms_per_step']:.2f} ms, {b['value'] / 1e9:.3f} Gcells/s, step fraction of the 8 TB/s roofline at {b['step_roofline'].get('algorithmic_bytes_per_cell_step', 2000)} B/cell/step: "
-          f"{b['step_roofline']['frac']:.3f}.  Source: `{os.path.basename(bench)}` (HIP events on the launch stream), "
+    sr = b['step_roofline']
+    print(f"Step: {b['ms_per_step']:.2f} ms, {b['value'] / 1e9:.3f} Gcells/s; step fraction of the 8 TB/s roofline: {sr['frac']:.3f} in compulsory bytes "
+          f"({sr.get('compulsory_bytes_per_cell_step', 0):.0f} B per cell and step), {sr.get('contract_frac', float('nan')):.3f} in SURVEY §8(d) contract bytes "
+          f"({sr.get('contract_bytes_per_cell_step', 0):.0f} B).  Source: `{os.path.basename(bench)}` (HIP events on the launch stream), "
           f"`{os.path.basename(pmc)}` (rocprofv3 PMC, HBM-side bytes per launch).\n")
     print("Columns: `compulsory` = every distinct 3-D array the (fused) kernel must read or write, once — what `bench.py`'s `roofline.achieved` is priced in; "
           "`contract` = SURVEY §8(d)'s words of the unfused kernel list the fused kernel replaces (the step figure of 250 words per cell and step); "
@@ -46,7 +49,7 @@ def main():
         w = WORDS_PER_CELL.get(name)
         alg = w * word * cells / 1e9 if w else None
         traffic = p.get(name, {}).get("hbm_bytes_per_launch")
-        cw = COMPULSORY_WORDS.get(name)
+        cw = compulsory_words(name)
         comp = cw * word * cells / 1e9 if cw else None
         row = [name, f"{n:g}", f"{ms:.2f}", f"{per_launch:.3f}",
                f"{comp:.2f}" if comp else "—", f"{comp / per_launch:.2f} ({comp / per_launch / 8:.2f})" if comp else "—",

@@ -381,6 +381,36 @@ def tendency_run(args, bz, device):
     return 0
 
 
+def supercell_model(bz, size, device, order=5, f32=False, slab=None):
+    """BASELINE configs[4]: the splitting-supercell shape — CompressibleDynamics + SplitExplicitTimeDiscretization defaults +
+    DCMIP2016 Kessler microphysics on the example's 168 km x 168 km x 20 km box (/root/reference/examples/splitting_supercell.jl:88-96),
+    moist column + 3 K warm bubble + sheared wind, initial condition set.  slab = (rank, world, transport): this rank's y-slab."""
+    Nx, Ny, Nz = size
+    gkw = {"float_type": np.float32} if f32 else {}
+    if order != 5:
+        gkw["halo"] = (5, 5, 5)
+    G = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 168e3), y=(0.0, 168e3), z=(0.0, 20e3), **gkw)
+    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), surface_pressure=1e5, reference_potential_temperature=300.0)
+    mkw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
+               microphysics=bz.DCMIP2016KesslerMicrophysics())
+    if slab:
+        rank, world, transport = slab
+        m = bz.compressible.SlabCompressibleModel(G, rank, world, dyn, advection=bz.WENO(order=order), device=device, transport=transport, **mkw)
+    else:
+        m = bz.CompressibleAtmosphereModel(G, dyn, advection=bz.WENO(order=order), device=device, **mkw)
+    Hz = m.grid.Hz
+    col = m.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
+
+    def theta(x, y, z):      # neutral column + the example's bubble: 3 K at (84 km, 84 km, 1.5 km), radii 10 km x 1.5 km
+        r = np.sqrt(((x - 84e3) / 10e3) ** 2 + ((y - 84e3) / 10e3) ** 2 + ((z - 1500.0) / 1500.0) ** 2)
+        return 300.0 + 3.0 * np.cos(np.pi / 2 * np.minimum(r, 1.0)) ** 2
+
+    m.set(ρ=lambda x, y, z: col * 300.0 / theta(x, y, z), θ=theta, v=0.0, w=0.0,
+          u=lambda x, y, z: 0.0015 * np.minimum(z, 5e3) + 0 * x + 0 * y,
+          qᵗ=lambda x, y, z: 0.014 * np.exp(-z / 2500.0) + 0 * x + 0 * y)
+    return m
+
+
 def config4_run(args, bz, rank, world, dist, device, fail):
     """--workload config4: BASELINE configs[4], the splitting-supercell shape — CompressibleDynamics, split-explicit WS-RK3 with
     acoustic substeps, DCMIP2016 Kessler microphysics, 512 x 512 x 128 cells on the example's 168 km x 168 km x 20 km box
@@ -391,31 +421,10 @@ def config4_run(args, bz, rank, world, dist, device, fail):
     Nx, Ny, Nz, dt = 512, 512, 128, 2.0
     f32 = bool(getattr(args, "config4_float32", False))      # the example's own precision (splitting_supercell.jl:86), single GPU
     order = int(getattr(args, "config4_order", 5))           # splitting_supercell.jl:279 uses WENO(order = 9): generic kernels, 5-cell halos
-    gkw = {"float_type": np.float32} if f32 else {}
-    if order != 5:
-        gkw["halo"] = (5, 5, 5)
-    G = bz.RectilinearGrid((Nx, Ny, Nz), x=(0.0, 168e3), y=(0.0, 168e3), z=(0.0, 20e3), **gkw)
-    dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(), surface_pressure=1e5, reference_potential_temperature=300.0)
-    mkw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
-               microphysics=bz.DCMIP2016KesslerMicrophysics())
     slabs = world > 1 or args.slab
     transport = args.transport
     try:
-        if slabs:
-            m = bz.compressible.SlabCompressibleModel(G, rank, world, dyn, advection=bz.WENO(order=order), device=device,
-                                                      transport=transport, **mkw)
-        else:
-            m = bz.CompressibleAtmosphereModel(G, dyn, advection=bz.WENO(order=order), device=device, **mkw)
-        Hz = m.grid.Hz
-        col = m.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
-
-        def theta(x, y, z):      # neutral column + the example's bubble: 3 K at (84 km, 84 km, 1.5 km), radii 10 km x 1.5 km
-            r = np.sqrt(((x - 84e3) / 10e3) ** 2 + ((y - 84e3) / 10e3) ** 2 + ((z - 1500.0) / 1500.0) ** 2)
-            return 300.0 + 3.0 * np.cos(np.pi / 2 * np.minimum(r, 1.0)) ** 2
-
-        m.set(ρ=lambda x, y, z: col * 300.0 / theta(x, y, z), θ=theta, v=0.0, w=0.0,
-              u=lambda x, y, z: 0.0015 * np.minimum(z, 5e3) + 0 * x + 0 * y,
-              qᵗ=lambda x, y, z: 0.014 * np.exp(-z / 2500.0) + 0 * x + 0 * y)
+        m = supercell_model(bz, (Nx, Ny, Nz), device, order=order, f32=f32, slab=(rank, world, transport) if slabs else None)
         for _ in range(max(1, args.warmup)):
             m.time_step(dt)
         m.profile_reset()

@@ -274,12 +274,14 @@ CENTERED2_LIB_PATH = os.path.join(_HERE, "lib", "libbreeze_hip_centered2.so")
 _libs = {}
 
 
-def load(advection_order=5):
+def load(advection_order=5, ft2_hypothesis=0):
     """Load libbreeze_hip.so (advection = WENO(order = 5)) or, for advection_order = 2, libbreeze_hip_centered2.so — the same
-    sources built with the reconstructions collapsed to Centered(order = 2) — and bind every declared symbol.  Raises if the
-    library is absent."""
+    sources built with the reconstructions collapsed to Centered(order = 2) — and bind every declared symbol.  ft2_hypothesis = 1 | 2:
+    lib/libbreeze_hip_ft2_<level>.so, the WENO kernels built with BZ_WENO_FT2 (csrc/bz_weno.h).  Raises if the library is absent."""
     global _lib
     path = CENTERED2_LIB_PATH if advection_order == 2 else LIB_PATH      # WENO orders 5, 7, 9 live in the same library
+    if ft2_hypothesis and advection_order != 2:
+        path = os.path.join(_HERE, "lib", f"libbreeze_hip_ft2_{int(ft2_hypothesis)}.so")
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -295,7 +297,7 @@ def load(advection_order=5):
         fn.restype = res
         fn.argtypes = args
     _libs[path] = lib
-    if advection_order != 2:
+    if advection_order != 2 and not ft2_hypothesis:
         _lib = lib
     return lib
 

@@ -338,7 +338,7 @@ class CompressibleAtmosphereModel:
                 raise NotImplementedError("Float32 grids: WENO(order = 5 | 7 | 9) is wired up")
             self._lib = lib = _lib.load_f32()
         else:
-            self._lib = lib = _lib.load(advection.order)
+            self._lib = lib = _lib.load(advection.order, getattr(advection, "ft2_hypothesis", 0))
 
         def fld(loc):
             return Field(grid, _LOC[loc], self.device)

@@ -39,8 +39,20 @@
             tau = (s == 0) ? BZW_T##R[s] * b : tau + BZW_T##R[s] * b;                                           \
         }                                                                                                       \
         tau = fabs(tau);                                                                                        \
+        if (BZ_WENO_FT2 == 2) {      /* the FT2 hypothesis (bz_weno.h): quotients, alpha and the normalised weights in Float32 */ \
+            float af[R], sum = 0.0f;                                                                            \
+            _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                     \
+                const float rr = (float)tau / ((float)beta[s] + 1e-8f);                                         \
+                af[s] = (float)BZW_D##R[s] * (1.0f + rr * rr);                                                  \
+                sum += af[s];                                                                                   \
+            }                                                                                                   \
+            double acc = 0.0;                                                                                   \
+            /* full candidates (v + increment): Float32 weights do not sum to one exactly, and v (1 - sum w) is not small for theta ~ 300 K */ \
+            _Pragma("unroll") for (int s = 0; s < R; ++s) acc += (double)(af[s] / sum) * (v[R - 1] + p[s]);     \
+            return acc;                                                                                         \
+        }                                                                                                       \
         _Pragma("unroll") for (int s = 0; s < R; ++s) {                                                         \
-            const double rr = tau * bz_recip<1>(beta[s] + BZ_WENO_EPS);                                         \
+            const double rr = (BZ_WENO_FT2 == 1) ? bz_newton_div(tau, beta[s] + BZ_WENO_EPS) : tau * bz_recip<1>(beta[s] + BZ_WENO_EPS); \
             const double a = BZW_D##R[s] * (1.0 + rr * rr);                                                     \
             num = (s == 0) ? a * p[s] : num + a * p[s];                                                         \
             den = (s == 0) ? a : den + a;                                                                       \

@@ -103,8 +103,61 @@ __device__ __forceinline__ double bz_weno5_diff(double a, double b, double c, do
     return fma(num, __builtin_amdgcn_rcp(den), c);
 }
 
+// ---- the open parity hypothesis ------------------------------------------------------------
+// Recent Oceananigans carries a second float type in its WENO scheme, WENO{N, FT, FT2} with FT2 = Float32 by default, "for the weight
+// computation".  What exactly is evaluated in FT2 cannot be read here (Oceananigans is not vendored), so two variants exist beside the
+// default (everything in the grid's FT), selected at build time (lib/libbreeze_hip_ft2_<level>.so, make ft2) and by og_set_weno_ft2()
+// in the oracle:
+//   BZ_WENO_FT2 = 1  the quotients tau / (beta_s + eps) through newton_div(FT2, a, b): reciprocal of b in Float32, one Newton step in FT
+//                    (x = a * inv; x += (a - x * b) * inv) — beta, tau, alpha and the normalisation stay in FT.  Differs from the
+//                    default by ~1e-14 of the reconstructed value: a golden file could not tell them apart at the 1e-12 tolerance.
+//   BZ_WENO_FT2 = 2  beta, tau, alpha and the normalised weights in Float32 (inputs rounded to Float32 for the indicators), the
+//                    candidate polynomials and their weighted sum in FT.  Differs from the default by ~1e-7 of the cell-to-cell
+//                    variation: the case in which a perfect Float64 port would sit at 1e-7, not 1e-12, from CPU().
+// Reference operation order (as bz_weno5_ref) in both.  tools/dump_goldens.jl records typeof(advection) and
+// tests/test_reference_goldens.py reports which variant a golden file matches.
+#ifndef BZ_WENO_FT2
+#define BZ_WENO_FT2 0
+#endif
+__device__ __forceinline__ double bz_newton_div(double a, double b)
+{
+    const double inv = (double)(1.0f / (float)b);
+    double x = a * inv;
+    x = x + (a - x * b) * inv;
+    return x;
+}
+__device__ __forceinline__ double bz_weno5_ft2(double a, double b, double c, double d, double e)
+{
+    const double p0 = (1.0 / 3.0) * c + (5.0 / 6.0) * d - (1.0 / 6.0) * e;
+    const double p1 = -(1.0 / 6.0) * b + (5.0 / 6.0) * c + (1.0 / 3.0) * d;
+    const double p2 = (1.0 / 3.0) * a - (7.0 / 6.0) * b + (11.0 / 6.0) * c;
+#if BZ_WENO_FT2 == 2
+    const float af = (float)a, bf = (float)b, cf = (float)c, df = (float)d, ef = (float)e;
+    const float b0 = cf * (10.0f * cf - 31.0f * df + 11.0f * ef) + df * (25.0f * df - 19.0f * ef) + ef * (4.0f * ef);
+    const float b1 = bf * (4.0f * bf - 13.0f * cf + 5.0f * df) + cf * (13.0f * cf - 13.0f * df) + df * (4.0f * df);
+    const float b2 = af * (4.0f * af - 19.0f * bf + 11.0f * cf) + bf * (25.0f * bf - 31.0f * cf) + cf * (10.0f * cf);
+    const float tau = fabsf(b0 - b2);
+    const float r0 = tau / (b0 + 1e-8f), r1 = tau / (b1 + 1e-8f), r2 = tau / (b2 + 1e-8f);
+    const float a0 = (3.0f / 10.0f) * (1.0f + r0 * r0), a1 = (3.0f / 5.0f) * (1.0f + r1 * r1), a2 = (1.0f / 10.0f) * (1.0f + r2 * r2);
+    const float sum = a0 + a1 + a2;
+    const double w0 = (double)(a0 / sum), w1 = (double)(a1 / sum), w2 = (double)(a2 / sum);
+    return w0 * p0 + w1 * p1 + w2 * p2;
+#else
+    const double b0 = c * (10.0 * c - 31.0 * d + 11.0 * e) + d * (25.0 * d - 19.0 * e) + e * (4.0 * e);
+    const double b1 = b * (4.0 * b - 13.0 * c + 5.0 * d) + c * (13.0 * c - 13.0 * d) + d * (4.0 * d);
+    const double b2 = a * (4.0 * a - 19.0 * b + 11.0 * c) + b * (25.0 * b - 31.0 * c) + c * (10.0 * c);
+    const double tau = fabs(b0 - b2);
+    const double r0 = bz_newton_div(tau, b0 + BZ_WENO_EPS), r1 = bz_newton_div(tau, b1 + BZ_WENO_EPS), r2 = bz_newton_div(tau, b2 + BZ_WENO_EPS);
+    const double a0 = (3.0 / 10.0) * (1.0 + r0 * r0), a1 = (3.0 / 5.0) * (1.0 + r1 * r1), a2 = (1.0 / 10.0) * (1.0 + r2 * r2);
+    return (a0 * p0 + a1 * p1 + a2 * p2) / (a0 + a1 + a2);
+#endif
+}
+
 __device__ __forceinline__ double bz_weno5(double a, double b, double c, double d, double e)
 {
+#if BZ_WENO_FT2
+    return bz_weno5_ft2(a, b, c, d, e);
+#endif
 #ifdef BZ_WENO_STUB      // timing experiments only: keeps every input live, no WENO arithmetic
     return 0.2 * (a + b + c + d + e);
 #elif BZ_WENO_ONE_DIVISION == 2
@@ -132,15 +185,31 @@ __device__ __forceinline__ double bz_recip(double x)
 // cells (a,b,c), upwind cell b, value at the face between b and c
 __device__ __forceinline__ double bz_weno3(double a, double b, double c)
 {
+    double p0 = 0.5 * b + 0.5 * c;
+    double p1 = -0.5 * a + 1.5 * b;
+#if BZ_WENO_FT2 == 2
+    {
+        const float af = (float)a, bf = (float)b, cf = (float)c;
+        const float b0 = (cf - bf) * (cf - bf), b1 = (bf - af) * (bf - af);
+        const float tau = fabsf(b0 - b1);
+        const float r0 = tau / (b0 + 1e-8f), r1 = tau / (b1 + 1e-8f);
+        const float a0 = (2.0f / 3.0f) * (1.0f + r0 * r0), a1 = (1.0f / 3.0f) * (1.0f + r1 * r1);
+        const float sum = a0 + a1;
+        return (double)(a0 / sum) * p0 + (double)(a1 / sum) * p1;
+    }
+#endif
     double b0 = (c - b) * (c - b);
     double b1 = (b - a) * (b - a);
     double tau = fabs(b0 - b1);
+#if BZ_WENO_FT2 == 1
+    double r0 = bz_newton_div(tau, b0 + BZ_WENO_EPS);
+    double r1 = bz_newton_div(tau, b1 + BZ_WENO_EPS);
+#else
     double r0 = tau / (b0 + BZ_WENO_EPS);
     double r1 = tau / (b1 + BZ_WENO_EPS);
+#endif
     double a0 = (2.0 / 3.0) * (1.0 + r0 * r0);
     double a1 = (1.0 / 3.0) * (1.0 + r1 * r1);
-    double p0 = 0.5 * b + 0.5 * c;
-    double p1 = -0.5 * a + 1.5 * b;
     return (a0 * p0 + a1 * p1) / (a0 + a1);
 }
 

@@ -38,9 +38,15 @@ class WENO:
     densities (examples/rico.jl:184-190, examples/tropical_cyclone_world.jl:169); it is a per-scalar scheme:
     `advection = {"momentum": WENO(), "ρθ": WENO(), "ρqᵉ": WENO(bounds=(0, 1))}`."""
 
-    def __init__(self, order=5, bounds=None):
+    def __init__(self, order=5, bounds=None, ft2_hypothesis=0):
+        """ft2_hypothesis (0, 1, 2): which reading of Oceananigans' second float type FT2 = Float32 the reconstruction follows (SURVEY
+        Appendix D.1; csrc/bz_weno.h: BZ_WENO_FT2) — 0 everything in the grid's type (shipped), 1 newton_div quotients, 2 weights in Float32.
+        1 and 2 run from lib/libbreeze_hip_ft2_<level>.so (Float64 grids): parity instrumentation for the day reference goldens exist."""
         if order not in (5, 7, 9):
             raise NotImplementedError("WENO orders 5, 7 and 9 are implemented in the HIP path")
+        if ft2_hypothesis not in (0, 1, 2):
+            raise ValueError("ft2_hypothesis is 0, 1 or 2")
+        self.ft2_hypothesis = ft2_hypothesis
         if order != 5 and bounds is not None:
             raise NotImplementedError("bounds-preserving WENO is implemented for order 5")
         self.order = order
@@ -287,7 +293,7 @@ class AtmosphereModel:
                 raise NotImplementedError("Float32 grids: WENO(order = 5 | 7 | 9) is wired up on the host side")
             self._lib = lib = _lib.load_f32()
         else:
-            self._lib = lib = _lib.load(advection.order)
+            self._lib = lib = _lib.load(advection.order, getattr(advection, "ft2_hypothesis", 0))
 
         def fld(loc):
             return Field(grid, _LOC[loc], self.device)

@@ -65,6 +65,23 @@ static inline size_t SY(const og_grid *G) { return (size_t)(G->Ny + 2 * G->Hy); 
 
 static const double WENO_EPS = 1e-8;
 
+/* The open parity hypothesis (the device twin is BZ_WENO_FT2 of csrc/bz_weno.h): what recent Oceananigans
+ * evaluates in its second float type FT2 (Float32 by default) cannot be read here.  0 (default): everything in Float64;
+ * 1: the quotients tau / (beta_s + eps) through newton_div(Float32, a, b) — Float32 reciprocal + one Newton step in Float64;
+ * 2: beta, tau, alpha and the normalised weights in Float32, candidate polynomials and their weighted sum in Float64.
+ * Process-wide switch (the oracle is single-model test infrastructure). */
+static int og_weno_ft2 = 0;
+void og_set_weno_ft2(int level) { og_weno_ft2 = (level == 1 || level == 2) ? level : 0; }
+int og_get_weno_ft2(void) { return og_weno_ft2; }
+static inline double newton_div32(double a, double b)
+{
+    const double inv = (double)(1.0f / (float)b);
+    double x = a * inv;
+    x = x + (a - x * b) * inv;
+    return x;
+}
+static inline double weno_quot(double tau, double bpe) { return og_weno_ft2 == 1 ? newton_div32(tau, bpe) : tau / bpe; }
+
 /* 5th order: cells (a,b,c,d,e), upwind cell c, value at the face between c and d.
  * Stencil 0 = (c,d,e), 1 = (b,c,d), 2 = (a,b,c); optimal weights 3/10, 3/5, 1/10.
  * Smoothness indicators are 3x Jiang-Shu (Oceananigans coefficient tables). */
@@ -74,15 +91,26 @@ static inline double weno5(double a, double b, double c, double d, double e)
     double b1 = b * (4.0 * b - 13.0 * c + 5.0 * d) + c * (13.0 * c - 13.0 * d) + d * (4.0 * d);
     double b2 = a * (4.0 * a - 19.0 * b + 11.0 * c) + b * (25.0 * b - 31.0 * c) + c * (10.0 * c);
     double tau = fabs(b0 - b2);
-    double r0 = tau / (b0 + WENO_EPS);
-    double r1 = tau / (b1 + WENO_EPS);
-    double r2 = tau / (b2 + WENO_EPS);
-    double a0 = (3.0 / 10.0) * (1.0 + r0 * r0);
-    double a1 = (3.0 / 5.0) * (1.0 + r1 * r1);
-    double a2 = (1.0 / 10.0) * (1.0 + r2 * r2);
     double p0 = (1.0 / 3.0) * c + (5.0 / 6.0) * d - (1.0 / 6.0) * e;
     double p1 = -(1.0 / 6.0) * b + (5.0 / 6.0) * c + (1.0 / 3.0) * d;
     double p2 = (1.0 / 3.0) * a - (7.0 / 6.0) * b + (11.0 / 6.0) * c;
+    if (og_weno_ft2 == 2) {
+        const float af = (float)a, bf = (float)b, cf = (float)c, df = (float)d, ef = (float)e;
+        const float f0 = cf * (10.0f * cf - 31.0f * df + 11.0f * ef) + df * (25.0f * df - 19.0f * ef) + ef * (4.0f * ef);
+        const float f1 = bf * (4.0f * bf - 13.0f * cf + 5.0f * df) + cf * (13.0f * cf - 13.0f * df) + df * (4.0f * df);
+        const float f2 = af * (4.0f * af - 19.0f * bf + 11.0f * cf) + bf * (25.0f * bf - 31.0f * cf) + cf * (10.0f * cf);
+        const float tf = fabsf(f0 - f2);
+        const float q0 = tf / (f0 + 1e-8f), q1 = tf / (f1 + 1e-8f), q2 = tf / (f2 + 1e-8f);
+        const float w0 = (3.0f / 10.0f) * (1.0f + q0 * q0), w1 = (3.0f / 5.0f) * (1.0f + q1 * q1), w2 = (1.0f / 10.0f) * (1.0f + q2 * q2);
+        const float sum = w0 + w1 + w2;
+        return (double)(w0 / sum) * p0 + (double)(w1 / sum) * p1 + (double)(w2 / sum) * p2;
+    }
+    double r0 = weno_quot(tau, b0 + WENO_EPS);
+    double r1 = weno_quot(tau, b1 + WENO_EPS);
+    double r2 = weno_quot(tau, b2 + WENO_EPS);
+    double a0 = (3.0 / 10.0) * (1.0 + r0 * r0);
+    double a1 = (3.0 / 5.0) * (1.0 + r1 * r1);
+    double a2 = (1.0 / 10.0) * (1.0 + r2 * r2);
     return (a0 * p0 + a1 * p1 + a2 * p2) / (a0 + a1 + a2);
 }
 
@@ -92,12 +120,21 @@ static inline double weno3(double a, double b, double c)
     double b0 = (c - b) * (c - b);
     double b1 = (b - a) * (b - a);
     double tau = fabs(b0 - b1);
-    double r0 = tau / (b0 + WENO_EPS);
-    double r1 = tau / (b1 + WENO_EPS);
-    double a0 = (2.0 / 3.0) * (1.0 + r0 * r0);
-    double a1 = (1.0 / 3.0) * (1.0 + r1 * r1);
     double p0 = 0.5 * b + 0.5 * c;
     double p1 = -0.5 * a + 1.5 * b;
+    if (og_weno_ft2 == 2) {
+        const float af = (float)a, bf = (float)b, cf = (float)c;
+        const float f0 = (cf - bf) * (cf - bf), f1 = (bf - af) * (bf - af);
+        const float tf = fabsf(f0 - f1);
+        const float q0 = tf / (f0 + 1e-8f), q1 = tf / (f1 + 1e-8f);
+        const float w0 = (2.0f / 3.0f) * (1.0f + q0 * q0), w1 = (1.0f / 3.0f) * (1.0f + q1 * q1);
+        const float sum = w0 + w1;
+        return (double)(w0 / sum) * p0 + (double)(w1 / sum) * p1;
+    }
+    double r0 = weno_quot(tau, b0 + WENO_EPS);
+    double r1 = weno_quot(tau, b1 + WENO_EPS);
+    double a0 = (2.0 / 3.0) * (1.0 + r0 * r0);
+    double a1 = (1.0 / 3.0) * (1.0 + r1 * r1);
     return (a0 * p0 + a1 * p1) / (a0 + a1);
 }
 
@@ -124,8 +161,19 @@ static inline double weno3(double a, double b, double c)
             tau = (s == 0) ? OGW_T##R[s] * b : tau + OGW_T##R[s] * b;                                        \
         }                                                                                                    \
         tau = fabs(tau);                                                                                     \
+        if (og_weno_ft2 == 2) {                                                                              \
+            float af[R], sum = 0.0f;                                                                         \
+            double acc = 0.0;                                                                                \
+            for (int s = 0; s < R; ++s) {                                                                    \
+                const float rr = (float)tau / ((float)beta[s] + 1e-8f);                                      \
+                af[s] = (float)OGW_D##R[s] * (1.0f + rr * rr);                                               \
+                sum += af[s];                                                                                \
+            }                                                                                                \
+            for (int s = 0; s < R; ++s) acc += (double)(af[s] / sum) * p[s];                                 \
+            return acc;                                                                                      \
+        }                                                                                                    \
         for (int s = 0; s < R; ++s) {                                                                        \
-            double rr = tau / (beta[s] + WENO_EPS);                                                          \
+            double rr = weno_quot(tau, beta[s] + WENO_EPS);                                                  \
             double a = OGW_D##R[s] * (1.0 + rr * rr);                                                        \
             num = (s == 0) ? a * p[s] : num + a * p[s];                                                      \
             den = (s == 0) ? a : den + a;                                                                    \

@@ -278,7 +278,7 @@ class OracleModel:
     def __init__(self, grid, constants=None, surface_pressure=101325.0, potential_temperature=288.0,
                  standard_pressure=1e5, reference_density=None, initialize=True,
                  formulation="LiquidIcePotentialTemperature", microphysics=None, sa_abstol=1e-4, sa_maxiter=20,
-                 forcings=None, closure=None, tracers=0, advection="WENO5", scalar_advection=None):
+                 forcings=None, closure=None, tracers=0, advection="WENO5", scalar_advection=None, weno_ft2=0):
         # formulation "StaticEnergy": self.theta holds e, self.rtheta holds rho*e
         # (src/StaticEnergyFormulations/static_energy_formulation.jl:18-21)
         assert formulation in ("LiquidIcePotentialTemperature", "StaticEnergy")
@@ -303,6 +303,9 @@ class OracleModel:
         # tendency evaluation; halos must be at least (order + 1) / 2 wide) or "Centered2" (a separate build of the library)
         # scalar_advection: the scalars' order where it differs from the momentum scheme (AtmosphereModel(grid; momentum_advection,
         # scalar_advection), atmosphere_model.jl:80-82,148-158; examples/tropical_cyclone_world.jl:167-169)
+        # weno_ft2: 0 (default) | 1 | 2 — the FT2 hypothesis of SURVEY Appendix D.1 (breeze_oracle.c: og_set_weno_ft2)
+        assert weno_ft2 in (0, 1, 2)
+        self.weno_ft2 = weno_ft2
         self.weno_order = {"WENO5": 5, "WENO7": 7, "WENO9": 9}.get(advection, 5)
         self.scalar_order = {"WENO5": 5, "WENO7": 7, "WENO9": 9}[scalar_advection] if scalar_advection else self.weno_order
         assert scalar_advection is None or advection.startswith("WENO")
@@ -527,10 +530,12 @@ class OracleModel:
         # the WENO order is a process-wide switch of the C library: select this model's order for the evaluation and put the
         # default back afterwards, so that direct callers of og_*_tendency (tests) always see order 5
         self.lib.og_set_weno_order(C.c_int(self.weno_order))
+        self.lib.og_set_weno_ft2(C.c_int(self.weno_ft2))
         try:
             self._compute_tendencies()
         finally:
             self.lib.og_set_weno_order(C.c_int(5))
+            self.lib.og_set_weno_ft2(C.c_int(0))
 
     def _compute_tendencies(self):
         cg = C.byref(self.cg)

@@ -335,11 +335,13 @@ class CompressibleOracleModel:
             # the momentum / theta / rho_d tendencies computed here by the reference are overwritten
             # by compute_slow_*_tendencies! before they are used.
             L.og_set_weno_order(C.c_int(self.weno_order))
+            L.og_set_weno_ft2(C.c_int(getattr(self, "weno_ft2", 0)))      # the FT2 hypothesis (oracle.py: OracleModel.weno_ft2)
             L.og_scalar_tendency_3d(cg, _p(self.G["rq"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.q))
             if kes:
                 L.og_scalar_tendency_3d(cg, _p(self.G["rqcl"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qcl))
                 L.og_scalar_tendency_3d(cg, _p(self.G["rqr"]), _p(self.rho), _p(self.au), _p(self.av), _p(self.aw), _p(self.qr))
             L.og_set_weno_order(C.c_int(5))
+            L.og_set_weno_ft2(C.c_int(0))
 
     def _sa_thermo(self):
         """maybe_adjust_thermodynamic_state on the LiquidIceDensityState of every cell (theta = rho theta / rho_d, q^t = rho q / rho,
@@ -419,12 +421,14 @@ class CompressibleOracleModel:
     def compute_slow_tendencies(self):
         cg, L, G = C.byref(self.cg), self.lib, self.G
         L.og_set_weno_order(C.c_int(self.weno_order))           # process-wide switch of the C library (oracle.py)
+        L.og_set_weno_ft2(C.c_int(getattr(self, "weno_ft2", 0)))
         L.og_u_tendency(cg, _p(G["ru"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.u))
         L.og_v_tendency(cg, _p(G["rv"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.v))
         L.og_w_tendency_slow(cg, _p(G["rw"]), _p(self.ru), _p(self.rv), _p(self.rw), _p(self.w))
         L.og_density_tendency(cg, _p(G["rho_d"]), _p(self.ru), _p(self.rv), _p(self.rw))
         L.og_scalar_tendency_3d(cg, _p(G["rtheta"]), _p(self.rho_d), _p(self.u), _p(self.v), _p(self.w), _p(self.theta))
         L.og_set_weno_order(C.c_int(5))
+        L.og_set_weno_ft2(C.c_int(0))
         if self.coriolis_f != 0.0:      # - x_f_cross_U, - y_f_cross_U of an FPlane (dynamics_kernel_functions.jl:79,99)
             from .forcings import _xy_to_cf, _xy_to_fc
             g = self.grid

@@ -54,7 +54,11 @@ function dump(name, kind, size, halo; Δt, steps)
     model = bubble_model(kind, size, halo)
     outdir = joinpath(@__DIR__, "..", "tests", "golden", "reference", name); mkpath(outdir)
     manifest = Dict("kind" => kind, "size" => collect(size), "halo" => collect(halo), "dt" => Δt, "steps" => steps,
-                    "breeze" => string(pkgversion(Breeze)), "oceananigans" => string(pkgversion(Oceananigans)), "fields" => Dict())
+                    "breeze" => string(pkgversion(Breeze)), "oceananigans" => string(pkgversion(Oceananigans)),
+                    # the scheme's type parameters: WENO{N, FT, FT2, ...} — FT2 is the float type of the weight computation (SURVEY
+                    # App. D.1); the reader (tests/test_reference_goldens.py) starts with the matching reading of the oracle / kernels
+                    "advection_type" => string(typeof(model.advection)), "eltype" => string(eltype(model.grid)),
+                    "fields" => Dict())
     function save(tag)
         G = model.timestepper.Gⁿ
         fields = merge(Oceananigans.prognostic_fields(model), model.velocities, (; T=model.temperature),

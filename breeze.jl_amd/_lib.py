@@ -303,7 +303,7 @@ def load(advection_order=5, ft2_hypothesis=0):
 
 
 # ---- Float32 twin (lib/libbreeze_hip_f32.so, generated by tools/gen_f32_sources.py: every double of the ABI is a float) --------
-F32_LIB_PATH = os.path.join(_HERE, "lib", "libbreeze_hip_f32.so")
+F32_LIB_PATH = os.environ.get("BREEZE_HIP_F32_LIB") or os.path.join(_HERE, "lib", "libbreeze_hip_f32.so")      # (BREEZE_HIP_F32_LIB: A/B builds of the Float32 twin)
 _f32_structs = {}
 
 

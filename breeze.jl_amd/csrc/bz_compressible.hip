@@ -535,6 +535,23 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
     // rings: theta^L at k, k+1 (own column) and at faces k-1, k; C at k-1, k; old (rho w)' at faces k-1, k, k+1
     double th_0 = F.thL[n], th_p = F.thL[n + sz];
     double C_m = 0.0, C_0 = F.Clin[n];
+    // Neighbours of the two linearisation fields (round 4).  The own-column values ride rings that are loaded one (C) or two (theta_L)
+    // levels ahead; the neighbours used to be loaded at the level that needs them — the same cache lines, one or two level fronts of
+    // the whole grid later (47 KB per block and level x 1024 resident blocks: long evicted), so every line of theta_L and C crossed
+    // the fabric twice.  Now the x neighbours come from the neighbouring lanes' ring values (a row of the block is one wavefront; only
+    // its two edge lanes load), and the y neighbours are requested together with the own-column value of their level and carried.
+#ifndef AC_FX
+#define AC_FX 1
+#endif
+    const bool FX = AC_FX && FUSED && (ACX == 64) && sizeof(ST) == 8;      // (Float32 working fields: measured slower — 74 -> 101 ms per step of forward sweeps — and stay on the loads)
+    const int lane = threadIdx.x;
+    double thy_m0 = 0.0, thy_p0 = 0.0, thy_m1 = 0.0, thy_p1 = 0.0;      // theta_L of rows j-1 / j+1 at levels k and k+1
+    double cy_m0 = 0.0, cy_p0 = 0.0;                                    // C of rows j-1 / j+1 at level k
+    if (FX) {
+        thy_m0 = F.thL[n + W.jm]; thy_p0 = F.thL[n + W.jp];
+        thy_m1 = F.thL[n + sz + W.jm]; thy_p1 = F.thL[n + sz + W.jp];
+        cy_m0 = F.Clin[n + W.jm]; cy_p0 = F.Clin[n + W.jp];
+    }
     double w_m = 0.0, w_0 = F.rwp[n], w_p = F.rwp[n + sz];
     double rs_m = 0.0, rths_m = 0.0, rp_m = 0.0, rthp_m = 0.0;
     double beta = 1.0, phi_m = 0.0, c_m = 0.0;     // row 0: b = 1, c = 0, f = 0
@@ -544,7 +561,17 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
         const double rdc = g.rdzc[k];
         const double Ax = g.Ax[k], Ay = g.Ay[k], Vinv = g.Vinv_c[k];
         const double rp = F.rp[n], rthp = F.rthp[n];
-        const double thxm = F.thL[n + W.im], thxp = F.thL[n + W.ip], thym = F.thL[n + W.jm], thyp = F.thL[n + W.jp];
+        double thxm, thxp, thym, thyp;
+        if (FX) {
+            // lanes 0 and 63 of the row hold the block's edge columns: their outer neighbours belong to another block (or wrap around)
+            const double e_m = (lane == 0) ? F.thL[n + W.im] : 0.0, e_p = (lane == ACX - 1 || i == g.Nx - 1) ? F.thL[n + W.ip] : 0.0;
+            thxm = __shfl_up(th_0, 1); thxp = __shfl_down(th_0, 1);
+            if (lane == 0) thxm = e_m;
+            if (lane == ACX - 1 || i == g.Nx - 1) thxp = e_p;
+            thym = thy_m0; thyp = thy_p0;
+        } else {
+            thxm = F.thL[n + W.im]; thxp = F.thL[n + W.ip]; thym = F.thL[n + W.jm]; thyp = F.thL[n + W.jp];
+        }
         double up0, up1, vp0, vp1;
         if (FUSED) {
             const long long nxm = n + W.im, nxp = n + W.ip, nym = n + W.jm, nyp = n + W.jp;
@@ -552,7 +579,13 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
             double o0 = 0.0, o_xm = 0.0, o_xp = 0.0, o_ym = 0.0, o_yp = 0.0;
             if (DAMP) { o0 = F.rth_old[n]; o_xm = F.rth_old[nxm]; o_xp = F.rth_old[nxp]; o_ym = F.rth_old[nym]; o_yp = F.rth_old[nyp]; }
             double c_xm = 0.0, c_xp = 0.0, c_ym = 0.0, c_yp = 0.0;
-            if (P.gate != 0.0) { c_xm = F.Clin[nxm]; c_xp = F.Clin[nxp]; c_ym = F.Clin[nym]; c_yp = F.Clin[nyp]; }
+            if (FX) {
+                const double e_m = (lane == 0) ? F.Clin[nxm] : 0.0, e_p = (lane == ACX - 1 || i == g.Nx - 1) ? F.Clin[nxp] : 0.0;
+                c_xm = __shfl_up(C_0, 1); c_xp = __shfl_down(C_0, 1);
+                if (lane == 0) c_xm = e_m;
+                if (lane == ACX - 1 || i == g.Nx - 1) c_xp = e_p;
+                c_ym = cy_m0; c_yp = cy_p0;
+            } else if (P.gate != 0.0) { c_xm = F.Clin[nxm]; c_xp = F.Clin[nxp]; c_ym = F.Clin[nym]; c_yp = F.Clin[nyp]; }
             const double p0 = F.p[n], p_xm = F.p[nxm], p_xp = F.p[nxp], p_ym = F.p[nym], p_yp = F.p[nyp];
             up0 = ac_face_update<DAMP>(F.rup_in[n], F.G_ru[n], rthp, rt_xm, o0, o_xm, th_0, thxm, C_0, c_xm, p0, p_xm, g.rdx, P);
             up1 = ac_face_update<DAMP>(F.rup_in[nxp], F.G_ru[nxp], rt_xp, rthp, o_xp, o0, thxp, th_0, c_xp, C_0, p_xp, p0, g.rdx, P);
@@ -619,6 +652,11 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
             C_0 = F.Clin[n + sz];
             th_p = (k + 2 < Nz) ? F.thL[n + 2 * sz] : th_0;
             w_p = F.rwp[n + 2 * sz];
+            if (FX) {      // the y neighbours of the levels just requested, with them
+                cy_m0 = F.Clin[n + sz + W.jm]; cy_p0 = F.Clin[n + sz + W.jp];
+                thy_m0 = thy_m1; thy_p0 = thy_p1;
+                if (k + 2 < Nz) { thy_m1 = F.thL[n + 2 * sz + W.jm]; thy_p1 = F.thL[n + 2 * sz + W.jp]; }
+            }
         }
     }
 }

@@ -59,15 +59,22 @@ static_assert(sizeof(LevRow5) == 8 * sizeof(double), "LevRow5 is eight reals");
 // build (three workgroups, <= 80 VGPRs: a Float32 value is one register, and the Float32 kernels sat at 84-85 — allocated as 88,
 // i.e. five waves per SIMD = still two workgroups).  Measured at 512^3 Float32: scalar-pair kernel 2.04 -> 1.88 ms with three spilled
 // registers; the z-momentum kernel and the forcing variant of the y-momentum kernel spill eight and lose 7-13 %, so they keep the default.
+#ifndef BZ_LEAN_WAVES
 #define BZ_LEAN_WAVES (sizeof(double) == 8 ? 4 : 6)
+#endif
 // Round-4 additions to the scalar-pair kernel — the zero-field shortcut of the second scalar and ring tops requested one level ahead —
-// cost ~8 registers: in the Float32 build (80 registers at six waves per SIMD) they spilled 19 and the kernel went from 1.80 to 2.48 ms
-// per launch at 512^3, so they are Float64-only until the Float32 kernels are written for their own register budget.
+// cost ~8 registers.  The Float32 kernel sat at 80 registers for six waves per SIMD: with the additions it spilled (19 registers,
+// 1.78 -> 2.48 ms per launch at 512^3; the shortcut alone 2.25), so the Float32 scalar kernel is compiled for four waves per SIMD
+// instead (two workgroups per CU, as Float64) with both additions on: 1.47 ms (four waves without them: 1.85).  The momentum kernels
+// keep BZ_LEAN_WAVES.
 #ifndef BZ5_ZERO_SHORTCUT
-#define BZ5_ZERO_SHORTCUT (sizeof(double) == 8)
+#define BZ5_ZERO_SHORTCUT 1
 #endif
 #ifndef BZ5_TOPS_AHEAD
-#define BZ5_TOPS_AHEAD (sizeof(double) == 8)
+#define BZ5_TOPS_AHEAD 1
+#endif
+#ifndef BZ5_SCALAR_WAVES
+#define BZ5_SCALAR_WAVES 4
 #endif
 
 struct Lean5 {
@@ -176,7 +183,7 @@ __device__ __forceinline__ double bz_symm4y(double qm2, double qm1, double q0, d
 // shuffle + the batched out-of-wave flux, z stencils in register rings.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TY, bool WY = false>
-__global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ_LEAN_WAVES, BZ_LEAN_WAVES))) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
+__global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCALAR_WAVES, BZ5_SCALAR_WAVES))) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72;                 // tile rows, padded row length (70 used)
     constexpr int NHALO = TR * 70 - TY * 64;            // frame cells per field
@@ -539,11 +546,11 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
     for (int k = kbeg; k < kend; ++k, n += sz) {
         const ix_t lev1 = (ix_t)(k + 1 - kbeg) * sz;
         // ---- prefetch for level k+1 (consumed at the end of this iteration / in the next one) ----
-        const double p_h1 = h1ok ? ru[h1n + lev1] : 0.0;
-        const double p_h2 = h2ok ? h2src[h2n + lev1] : 0.0;
-        const double p_rv = rv[n + sz], p_rw = rw[n + 2 * sz];
         const double p_top = ru[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];
-        const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
+        const double p_h1 = (BZ_KO & 256) ? p_top : h1ok ? ru[h1n + lev1] : 0.0;
+        const double p_h2 = (BZ_KO & 512) ? p_top : h2ok ? h2src[h2n + lev1] : 0.0;
+        const double p_rv = (BZ_KO & 1024) ? p_top * 0.5 : rv[n + sz], p_rw = (BZ_KO & 1024) ? p_top * 0.25 : rw[n + 2 * sz];
+        const double p_u0 = (BZ_KO & 2048) ? p_top : (E.mode == 2) ? E.u0[n + sz] : 0.0;
         if (((k - kbeg) & 63) == 0) {
             const int kk = min(k + tx, kend - 1);
             edge = flux_x_lean<T3_U>(g, F, ru, ie, jc, kk);

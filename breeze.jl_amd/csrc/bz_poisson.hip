@@ -137,10 +137,14 @@ __global__ void __launch_bounds__(64) k_tridiag_solve(int NXH, int Ny, int Nz, c
 // ---------------------------------------------------------------------------------------------------------------------------------
 #define TCO_COLS 8
 #define TCO_M 8
-// minimum waves per SIMD the register allocation must leave room for: 4 = two 512-thread workgroups per CU in Float64 (116 VGPRs as
-// compiled); the Float32 build holds half the bytes per value but compiled to 133 VGPRs without a bound — one workgroup per CU, and the
-// same 0.60 ms per launch as Float64 — so it asks for 6 (three workgroups, <= 85 VGPRs)
+// minimum waves per SIMD the register allocation must leave room for (second argument of __launch_bounds__): 2 = ONE 512-thread
+// workgroup per CU.  That is what is shipped and what every quoted figure was measured with (0.46 ms per launch at 512^3 in Float64,
+// 0.28 in Float32): the persistent grid below is sized for one resident workgroup per CU (`resident`), each walking ngroups / 256
+// column groups with the next group's rows in flight.  4 (two workgroups per CU, <= 128 VGPRs) was measured again in round 4 (ADVICE
+// r03): the kernel spills and takes 0.98 ms — the rows of a group held in registers are the design, not an accident of the allocator.
+#ifndef TCO_MIN_WAVES
 #define TCO_MIN_WAVES 2
+#endif
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over every address space: hipcc then waits
 // for the global stores of the previous column group before it lets the next group's arithmetic start (s_waitcnt vmcnt(10) in the loop
 // of k_tridiag_coop), i.e. the store drain of every group is exposed.  Every barrier of that kernel protects LDS exchange buffers.
@@ -385,7 +389,7 @@ int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_
         const int Nz = ctx->dg.Nz;
         TriCols C{d_cols, d_cols + Nz, d_cols + 2 * Nz, d_cols + 3 * Nz, d_cols + 3 * Nz + nxh_real};
         const int ngroups = (int)((plane + TCO_COLS - 1) / TCO_COLS);
-        // 64 segments = 512 threads: two workgroups per CU resident, each walks ngroups / grid column groups (a multiple of the grid keeps the tail short)
+        // 64 segments = 512 threads: one workgroup per CU resident (TCO_MIN_WAVES / 2), each walks ngroups / grid column groups (a multiple of the grid keeps the tail short)
         const int resident = (TCO_MIN_WAVES / 2) * ctx->num_cus * (segs == 64 ? 1 : 64 / segs);
         const int per_block = (ngroups + resident - 1) / resident;
         dim3 grid((unsigned)((ngroups + per_block - 1) / per_block)), block(TCO_COLS * segs);

@@ -63,11 +63,18 @@ __device__ __forceinline__ double2 xf_cmul(double2 a, double2 b) { return make_d
 // In-place complex transform of length n2 (a power of two >= 8, or 3 * 2^m >= 48) of `row` by the team's T = n2 / 4 threads (tid = 0 .. T-1).
 // Wave-level ordering only (xf_wave_sync): callers put a workgroup barrier where other waves' data is involved.
 // INV: conjugated twiddles (unnormalised inverse).
+// Wst: the twiddles of the radix-4 stages STAGE-MAJOR (xf_stage_twiddles): stage Ns holds w^k, w^2k, w^3k for k < Ns as three runs of
+// Ns consecutive entries.  Round 4: the stages used to read W[k s], W[2 k s], W[3 k s] with s = n2 / (2 Ns) from the natural-order
+// table — lane-dependent strides of 512 / 128 / 32 bytes for Ns = 4 / 16 / 64, i.e. 4- to 8-way bank conflicts on 9 of the ~50 LDS
+// instructions of a row transform (PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.52 for k_x_inverse, 0.45 for k_x_forward; the
+// data accesses are conflict-free by the swizzle above).  Consecutive k in consecutive 16-byte slots is conflict-free.
 template <bool INV, int TW = 1>
-__device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, int tid, bool active, const double2 *__restrict__ W)
+__device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, int tid, bool active, const double2 *__restrict__ W,
+                                            const double2 *__restrict__ Wst)
 {
     const int T = n2 >> 2;
     int Ns = 1;
+    int woff = 0;
     const bool r3 = (n2 % 3) == 0;
     if (r3) {
         // n2 = 3 * 2^m (rows of 96, 192, 384, 768 cells — 768 x 768 x 256 is one of the reference's three CI grids): one radix-3 stage
@@ -109,8 +116,7 @@ __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, i
             const int k = r3 ? tid % Ns : tid & (Ns - 1);
             double2 v0 = row[XF_P(tid)], v1 = row[XF_P(tid + T)], v2 = row[XF_P(tid + 2 * T)], v3 = row[XF_P(tid + 3 * T)];
             if (Ns > 1) {
-                const int tw = k * (n2 / (2 * Ns));
-                double2 w1 = W[tw], w2 = W[2 * tw], w3 = W[3 * tw];
+                double2 w1 = Wst[woff + k], w2 = Wst[woff + Ns + k], w3 = Wst[woff + 2 * Ns + k];
                 if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
                 v1 = xf_cmul(v1, w1); v2 = xf_cmul(v2, w2); v3 = xf_cmul(v3, w3);
             }
@@ -126,6 +132,7 @@ __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, i
         xf_sync<TW>();
         if (active) { row[XF_P(j0)] = o0; row[XF_P(j0 + Ns)] = o1; row[XF_P(j0 + 2 * Ns)] = o2; row[XF_P(j0 + 3 * Ns)] = o3; }
         xf_sync<TW>();
+        if (Ns > 1) woff += 3 * Ns;
     }
     if (Ns < n2) {      // n2 = 2 Ns: two radix-2 butterflies per thread, outputs land on their own inputs
         if (active) {
@@ -142,6 +149,22 @@ __device__ __forceinline__ void xf_team_fft(double2 *__restrict__ row, int n2, i
         xf_sync<TW>();
     }
 }
+
+// Fill the stage-major twiddle table (n2 entries at most) from the natural-order one: called once per workgroup, by all threads.
+__device__ __forceinline__ void xf_stage_twiddles(double2 *__restrict__ Wst, const double2 *__restrict__ Wg, int n2, int t0, int nthreads)
+{
+    int woff = 0;
+    for (int Ns = ((n2 % 3) == 0) ? 3 : 1; Ns * 4 <= n2; Ns <<= 2) {
+        if (Ns == 1) continue;
+        const int s = n2 / (2 * Ns);
+        for (int t = t0; t < 3 * Ns; t += nthreads) {
+            const int m = t / Ns, k = t - m * Ns;
+            Wst[woff + t] = Wg[(m + 1) * k * s];
+        }
+        woff += 3 * Ns;
+    }
+}
+#define XF_WST_SLOTS(n2) (n2)
 
 // Z = transform of the packed row z[n] = x[2n] + i x[2n+1]  ->  X[0 .. n2] of the real row, in place (row has n2 + 1 slots).
 // Pairs (p, n2 - p) are independent: no barrier between a pair's reads and writes.
@@ -201,7 +224,7 @@ __device__ __forceinline__ long long xf_addr(const XfLayout &L, int Ny, int k, i
 }
 
 // SRC 1: source term from the predictor momentum (arithmetic of k_poisson_source_rows); SRC 0: rows of the contiguous rhs buffer.
-// grid (Ny / XF_RB, ceil(Nz / kchunk)), block XF_RB * Nx / 8, dynamic LDS (XF_RB * (n2 + 4) + 3 n2 / 2) * sizeof(double2).
+// grid (Ny / XF_RB, ceil(Nz / kchunk)), block XF_RB * Nx / 8, dynamic LDS (XF_RB * (n2 + 4) + 3 n2 / 2 + n2) * sizeof(double2).
 // Thread (row r, tid) owns the cell pairs i = 2 (tid + q Nx / 8), i + 1, q = 0 .. 3 — the four packed complex elements its first
 // butterfly reads; wlo carries rho_w of the lower faces from the previous level's upper faces (the block marches in z).
 template <int SRC, int TW = 1>
@@ -214,8 +237,10 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_forward(DevGrid g, const 
     const int nthreads = blockDim.x;
     const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
     double2 *__restrict__ W = xf_sm + XF_RB * RS;
+    double2 *__restrict__ Wst = W + 3 * n2 / 2;
     for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
-    __syncthreads();                                       // the twiddle table is loaded by all waves
+    xf_stage_twiddles(Wst, Wg, n2, threadIdx.x, nthreads);
+    __syncthreads();                                       // the twiddle tables are loaded by all waves
     const int j0 = blockIdx.x * XF_RB, j = j0 + r;
     const int kbeg = L.klo + blockIdx.y * kchunk, kend = min(kbeg + kchunk, L.khi);
     double2 *__restrict__ row = xf_sm + r * RS;
@@ -255,7 +280,7 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_forward(DevGrid g, const 
             }
         }
         xf_sync<TW>();
-        xf_team_fft<false, TW>(row, n2, tid, true, W);
+        xf_team_fft<false, TW>(row, n2, tid, true, W, Wst);
         xf_split_forward(row, n2, tid, W);
         __syncthreads();                                   // rows change hands: the transposed store reads all of them
         for (int e = threadIdx.x; e < L.nxp * XF_RB; e += nthreads) {
@@ -277,7 +302,9 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_inverse(DevGrid g, const 
     const int nthreads = blockDim.x;
     const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
     double2 *__restrict__ W = xf_sm + XF_RB * RS;
+    double2 *__restrict__ Wst = W + 3 * n2 / 2;
     for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
+    xf_stage_twiddles(Wst, Wg, n2, threadIdx.x, nthreads);
     const int j0 = blockIdx.x * XF_RB;
     const int kbeg = L.klo + blockIdx.y * kchunk, kend = min(kbeg + kchunk, L.khi);
     double2 *__restrict__ row = xf_sm + r * RS;
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_inverse(DevGrid g, const 
         __syncthreads();                                   // rows loaded by all waves
         xf_split_inverse(row, n2, tid, W);
         xf_sync<TW>();
-        xf_team_fft<true, TW>(row, n2, tid, true, W);
+        xf_team_fft<true, TW>(row, n2, tid, true, W, Wst);
         {   // every team stores its own row: 16-byte elements, consecutive lanes
             double *dst = phi_c + (long long)Nx * ((long long)(j0 + r) + (long long)g.Ny * k);
 #pragma unroll

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d(DevGrid g, d
                                                                    const double *__restrict__ v, const double *__restrict__ w,
                                                                    const double *__restrict__ c, const double *__restrict__ ru,
                                                                    const double *__restrict__ rv, const double *__restrict__ rw,
-                                                                   int kchunk)
+                                                                   int kchunk, const int *__restrict__ zero_if_dry)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * CTY + threadIdx.y;
@@ -265,6 +265,12 @@ __global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d(DevGrid g, d
     const int k1 = min(k0 + kchunk, g.Nz);
     const long long sy = g.Sx, sz = g.Sxy;
     long long n = g.idx(i, j, k0);
+    // moisture launch of a dry model (the moisture scan's word, bz_step.hip: bzi_scan_moisture): the advected field is identically zero,
+    // every flux an exact zero — the tendency is written as such without reading anything
+    if (zero_if_dry && __builtin_amdgcn_readfirstlane(*zero_if_dry) == 1) {
+        for (int k = k0; k < k1; ++k, n += sz) Gc[n] = 0.0;
+        return;
+    }
 
     double zm3 = c[n - 3 * sz], zm2 = c[n - 2 * sz], zm1 = c[n - sz], z0 = c[n], zp1 = c[n + sz], zp2 = c[n + 2 * sz];
     double r_lo = rho[n - sz], r0 = rho[n];
@@ -1101,14 +1107,14 @@ static DiagFields diag_fields(bz_ctx *ctx, const bz_compressible_state *s, const
 
 static int launch_scalar_rho3d(bz_ctx *ctx, const char *name, double *Gc, double *Grho, const double *rho, const double *u,
                                const double *v, const double *w, const double *c, const double *ru, const double *rv,
-                               const double *rw)
+                               const double *rw, const int *zero_if_dry = nullptr)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, name);
     if (ctx->weno_R != 3) return bzi_scalar_rho3d_generic(ctx, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
     const int kc = pick_kchunk_c(g, g.Nz);
     dim3 block(64, CTY), grid((g.Nx + 63) / 64, (g.Ny + CTY - 1) / CTY, (g.Nz + kc - 1) / kc);
-    hipLaunchKernelGGL(k_scalar_tendency_rho3d, grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw, kc);
+    hipLaunchKernelGGL(k_scalar_tendency_rho3d, grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw, kc, zero_if_dry);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -1149,6 +1155,7 @@ extern "C" int bz_compressible_update_state(bz_ctx *ctx, const bz_compressible_s
     if (!valid_state(s)) return BZ_ERR_INVALID;
     if (compute_tendencies && (!valid_prog(G) || !valid_sub(sub))) return BZ_ERR_INVALID;
     if (!ctx->fused_ok) { ctx->last_error = "compressible path needs Nx >= 2Hx and Ny >= 2Hy"; return BZ_ERR_UNSUPPORTED; }
+    if (ctx->d_qstate) BZ_HIP(hipMemsetAsync(ctx->d_qstate, 0, sizeof(int), ctx->stream));      // moisture scan: unknown again (set! ends here)
     return bzi_compressible_update_state(ctx, s, G, sub, compute_tendencies != 0, false);
 }
 
@@ -1649,8 +1656,9 @@ extern "C" int bz_compute_moisture_tendency(bz_ctx *ctx, const bz_compressible_s
 {
     BZ_REQUIRE_COMPRESSIBLE();
     if (!valid_state(s) || !valid_prog(G) || !valid_sub(sub)) return BZ_ERR_INVALID;
+    // (WENO order 5 kernels; the generic order 7 / 9 path evaluates the field whatever it holds)
     int rc = launch_scalar_rho3d(ctx, "moisture_tendency", G->rho_q, nullptr, s->rho, sub->time_averaged_u, sub->time_averaged_v,
-                                 sub->time_averaged_w, s->q, nullptr, nullptr, nullptr);
+                                 sub->time_averaged_w, s->q, nullptr, nullptr, nullptr, ctx->weno_R == 3 ? bzi_moisture_state(ctx) : nullptr);
     if (rc || ctx->dg.microphysics != 2) return rc;
     const bz_kessler_model_fields &K = ctx->kessler;      // the Kessler species ride the same transport velocities
     rc = launch_scalar_rho3d(ctx, "kessler_species_tendencies", K.G_cloud_liquid_density, nullptr, s->rho, sub->time_averaged_u,
@@ -1716,6 +1724,7 @@ extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_stat
     BZ_REQUIRE_COMPRESSIBLE();
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
+    if ((rc = bzi_scan_moisture_field(ctx, s->rho_q))) return rc;      // dry models: the moisture tendency kernels write exact zeros without reading
     if (ctx->slab_mode && ctx->comm) return bzi_dist_time_step_compressible(ctx, s, U0, G, sub, dt);     // bz_comm.hip owns the exchanges
     if ((rc = require_no_slab(ctx, "bz_time_step_compressible"))) return rc;
     // launch-bound grids replay the recorded step (bz_graph.hip); a failed recording has executed nothing and falls through

@@ -254,6 +254,7 @@ struct bz_tuning {
     int tend_gen = 0;                 // BZ_TEND_GEN (0: default)
     bool no_lean = false;             // BZ_NO_LEAN: fused-RK tier instead of the lean (prognostic-only) seam
     bool no_xcd = false;              // BZ_NO_XCD: hardware block order in the lean kernels
+    bool no_dry_shortcut = false;     // BZ_NO_DRY_SHORTCUT: the lean kernels always carry rho q (no moisture scan)
     bool side_scalar = false;         // BZ_SIDE_SCALAR: scalar kernel beside the pressure solve on one GPU too
     bool no_fuse_forcing = false;     // BZ_NO_FUSE_FORCING
     bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
@@ -330,6 +331,8 @@ struct bz_ctx {
     bool fuse_rk = true;              // whole-step seam: RK update folded into the tendency kernels (BZ_NO_FUSE_RK=1 disables)
     bool G_is_predictor = false;      // after a fused step the G arrays hold predictor momentum, not tendencies
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
+    int *d_qstate = nullptr;          // moisture scan of the lean seam (bz_step.hip: bzi_scan_moisture): 2 = rho q has a non-zero element (sticky until
+                                      // update_state!), anything else after a scan = identically zero; the lean kernels then skip every access to it
     bool diagnostics_stale = false;   // u, v, w, theta, q, T, phi of `s` are older than the prognostic state (bz_time_steps_anelastic without the last diagnosis)
     bool lean_step_last = false;      // the last step body took the lean tier
     bool lean = true;                 // whole-step seam on prognostic-only kernels (bz_tendency5_kernels.h; BZ_NO_LEAN=1 disables)
@@ -491,6 +494,9 @@ int bzi_lean_setup(bz_ctx *ctx);
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose = true);
 int bzi_comm_join_pending(bz_ctx *ctx);
 void bzi_lean_step_done(bz_ctx *ctx, bool diagnosed);
+int bzi_scan_moisture(bz_ctx *ctx, const bz_state *s);
+int bzi_scan_moisture_field(bz_ctx *ctx, const double *rho_q);
+const int *bzi_moisture_state(const bz_ctx *ctx);
 struct LeanStage;
 void bzi_lean_stage(const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, int stage, LeanStage *L);
 int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,

@@ -12,6 +12,7 @@ extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognost
     int rc;
     if (ctx->comm && (rc = bzi_comm_join_pending(ctx))) return rc;      // an undiagnosed last stage leaves its halo exchange on the side stream
     ctx->diagnostics_stale = false;
+    if (ctx->d_qstate) BZ_HIP(hipMemsetAsync(ctx->d_qstate, 0, sizeof(int), ctx->stream));      // the moisture may have been set!: unknown (= moist) until the next scan
     // fill_halo_regions!(prognostic_fields(model))  (:48) — momentum halos are filled inside
     // bz_compute_velocities (:135-136), the scalars here.
     double *sf[4] = {s->rho_theta, s->rho_q, ctx->dg.rqcl_field, ctx->dg.rqr_field};
@@ -56,6 +57,57 @@ void bzi_lean_stage(const bz_state *s, const bz_prognostic *U0, const bz_prognos
     L->ob = stage == 0 ? G->rho_q : stage == 1 ? U0->rho_q : s->rho_q;
 }
 
+// ---- moisture scan -------------------------------------------------------------------------------------------------------------------
+// The reference advects rho q^v in every model, dry ones included (update_atmosphere_model_state.jl:333-343).  In a dry run the field
+// is identically zero and stays so: every flux of it is an exact zero, its update is 0 -> 0.  Every step call opens with one pass over
+// rho q (1 word per cell, once per CALL — bz_time_steps_anelastic amortises it over its n steps) that leaves *d_qstate = 1 if every
+// element is zero (2 otherwise); the lean scalar-pair and z-momentum kernels read that word and, where it is 1, skip every load, store and
+// flux of rho q (4.6 of the scalar kernel's 13 words per cell, a fifth of its instructions).  The result carries the same bits either
+// way.  2 is sticky (a moist model is scanned once, later calls return at once) until bz_update_state — what set! ends with — resets it;
+// a dry model is scanned at every call, so a moisture field written behind the library's back is seen.  Contexts with a moisture
+// source (bottom moisture flux, moisture forcing, subsidence of q) or with microphysics never take the shortcut.
+// state[0]: 0 unknown (treated as moist: nothing is skipped), 1 identically zero (verified by the scan that opened this call),
+//           2 moist (sticky until bz_update_state puts 0 back);  state[1]: "some block found a non-zero element" of the scan in flight
+__global__ __launch_bounds__(256) void k_scan_moisture(const double *__restrict__ rq, long long n, int *__restrict__ state)
+{
+    if (state[0] == 2) return;
+    bool found = false;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) found = found || (rq[t] != 0.0);
+    if (__any(found) && (threadIdx.x & 63) == 0) state[1] = 1;
+}
+__global__ void k_scan_moisture_close(int *__restrict__ state)
+{
+    if (state[0] != 2) state[0] = state[1] ? 2 : 1;
+    state[1] = 0;
+}
+
+static bool moisture_sources(const bz_ctx *ctx)
+{
+    return ctx->tune.no_dry_shortcut || ctx->dg.microphysics != 0 || ctx->has_bulk || ctx->has_relaxation || ctx->field_forcing != nullptr ||
+           (ctx->has_forcings && (ctx->forcing_flux_q != 0.0 || (ctx->forcing_static_mask & 8) || (ctx->forcing_subsidence_mask & 8)));
+}
+
+// the word the lean kernels read (nullptr: no shortcut on this context)
+const int *bzi_moisture_state(const bz_ctx *ctx) { return (ctx->d_qstate && !moisture_sources(ctx)) ? ctx->d_qstate : nullptr; }
+
+int bzi_scan_moisture(bz_ctx *ctx, const bz_state *s) { return ctx->compressible ? BZ_OK : bzi_scan_moisture_field(ctx, s->rho_q); }
+
+int bzi_scan_moisture_field(bz_ctx *ctx, const double *rho_q)
+{
+    if (moisture_sources(ctx)) return BZ_OK;
+    const DevGrid &g = ctx->dg;
+    if (!ctx->d_qstate) {
+        BZ_HIP(hipMalloc(&ctx->d_qstate, 2 * sizeof(int)));
+        BZ_HIP(hipMemsetAsync(ctx->d_qstate, 0, 2 * sizeof(int), ctx->stream));
+    }
+    const long long n = (long long)g.Sxy * (g.Nz + 2 * g.Hz);
+    ProfileScope ps(ctx, "moisture_scan");
+    hipLaunchKernelGGL(k_scan_moisture, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, rho_q, n, ctx->d_qstate);
+    hipLaunchKernelGGL(k_scan_moisture_close, dim3(1), dim3(1), 0, ctx->stream, ctx->d_qstate);
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
 static int one_anelastic_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose)
 {
     if (ctx->slab_mode) {
@@ -84,7 +136,8 @@ extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_p
                                       const bz_prognostic *G, double dt)
 {
     if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
-    return one_anelastic_step(ctx, s, U0, G, dt, true);
+    const int rc = bzi_scan_moisture(ctx, s);
+    return rc ? rc : one_anelastic_step(ctx, s, U0, G, dt, true);
 }
 
 // n steps of time_step!(model, dt) in one call — the loop of the reference's benchmark driver, many_time_steps!
@@ -99,6 +152,7 @@ extern "C" int bz_time_steps_anelastic(bz_ctx *ctx, const bz_state *s, const bz_
                                        int diagnose_last)
 {
     if (!ctx || !s || !U0 || !G || n < 0) return BZ_ERR_INVALID;
+    if (n > 0) { const int rc = bzi_scan_moisture(ctx, s); if (rc) return rc; }
     for (int it = 0; it < n; ++it) {
         const int rc = one_anelastic_step(ctx, s, U0, G, dt, it == n - 1 && diagnose_last);
         if (rc) return rc;

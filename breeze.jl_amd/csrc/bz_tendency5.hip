@@ -55,6 +55,8 @@ void bzi_lean_teardown(bz_ctx *ctx)
     ctx->d_pi_dry = nullptr;
     if (ctx->d_lev_rows) hipFree(ctx->d_lev_rows);
     ctx->d_lev_rows = nullptr;
+    if (ctx->d_qstate) hipFree(ctx->d_qstate);
+    ctx->d_qstate = nullptr;
     if (ctx->side_stream) { hipStreamSynchronize(ctx->side_stream); hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
@@ -102,6 +104,7 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
     L.T = s->T;
     L.pi_dry = ColPtr(ctx->d_pi_dry + g.Hz);
     L.lev = (const LevRow5 *)ctx->d_lev_rows + g.Hz;
+    L.qstate = bzi_moisture_state(ctx);
     L.mforce = 0; L.cor_f = 0.0; L.Fu = ColPtr(nullptr); L.Fv = ColPtr(nullptr);
     if (ctx->has_forcings && bzi_lean_forcings_ok(ctx)) {      // the stack's momentum terms ride the RK epilogues of k6_u / k6_v
         const int m = ctx->forcing_static_mask;

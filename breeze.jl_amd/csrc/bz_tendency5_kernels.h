@@ -91,6 +91,7 @@ struct Lean5 {
     int mforce;
     double cor_f;
     ColPtr Fu, Fv;
+    const int *qstate;               // moisture scan (bz_step.hip: bzi_scan_moisture): *qstate == 1 <=> rho q is identically zero; nullptr: not known
     int xcd;                         // 1: XCD-contiguous block order (grid size divisible by 8)
     int by0, bys;                    // tile row of block row b is by0 + b * bys (sub-launches of the slab driver: interior rows
                                      // while the y-halo exchange is in flight, then the two edge rows)
@@ -182,23 +183,28 @@ __device__ __forceinline__ double bz_symm4y(double qm2, double qm1, double q0, d
 // (double-buffered, frame cells prefetched one level ahead), y-face fluxes shared through LDS, x-face fluxes through a wave
 // shuffle + the batched out-of-wave flux, z stencils in register rings.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY, bool WY = false>
-__global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCALAR_WAVES, BZ5_SCALAR_WAVES))) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
+// DRYQ: the second scalar is identically zero in the whole field (Lean5::qstate, set by the scan that opens every step call:
+// bz_step.hip: bzi_scan_moisture) — rho q of a dry run, which the reference advects all the same
+// (update_atmosphere_model_state.jl:333-343).  Every flux of it is an exact zero and its update is 0 -> 0, so the instantiation
+// neither loads nor stores anything of q: 4.6 of the kernel's 13 words per cell.  Identical bits: the arrays stay zero.
+template <int TY, bool WY, bool DRYQ>
+__device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean5 &F, int kchunk, const RKEpilogue &E, double *Tp, double *FYp, int *ZF)
 {
+    constexpr bool Q = !DRYQ;
     constexpr int TR = TY + 6, TC = 72;                 // tile rows, padded row length (70 used)
     constexpr int NHALO = TR * 70 - TY * 64;            // frame cells per field
     constexpr int NT = 64 * TY;
     constexpr int HPT = (NHALO + NT - 1) / NT;          // frame cells per thread
-    __shared__ double T[2][2][TR][TC];
-    __shared__ double FY[2][2][TY + 1][64];
+    double(*T)[2][TR][TC] = (double(*)[2][TR][TC])Tp;                  // T[2][2][TR][TC]
+    double(*FY)[2][TY + 1][64] = (double(*)[2][TY + 1][64])FYp;        // FY[2][2][TY + 1][64]
     // Zero-field shortcut of the second scalar (rho q of a dry run is identically zero, and the reference advects it all the same:
     // update_atmosphere_model_state.jl:333-343).  ZF[l % 3] != 0: every staged value of q at level l — the tile and its frame — is +-0.
     // Then the x / y reconstructions of that level return exactly 0 (WENO of zeros; every variant of bz_weno5) and the fluxes are
     // exact zeros: the kernel stores 0.0 instead of evaluating them.  The vertical flux takes the same shortcut per wavefront from a
     // per-thread count of consecutive zero ring tops.  Identical bits either way (the sums of +-0 fluxes the RK update sees are +0 with
     // or without the shortcut, and alpha (0 + dt * -0) = +0); costs ~8 instructions per level where q is not zero, saves three
-    // reconstructions (~150) where it is.
-    __shared__ int ZF[3];
+    // reconstructions (~150) where it is.  (ZF: three ints of the caller's LDS; this local form still serves fields that are zero only in part.)
+    constexpr bool ZS = BZ5_ZERO_SHORTCUT && Q;
 
     int bx, by, bz;
     bz_block5(F, bx, by, bz);
@@ -250,39 +256,41 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCA
     for (int s = 0; s < 6; ++s) {
         const double rh = g.rho[kbeg + s - 3], rr = g.rrho[kbeg + s - 3];
         a[s] = bz_cdiv(pa[n + s * sz - 3 * sz], rh, rr);
-        b[s] = bz_cdiv(pb[n + s * sz - 3 * sz], rh, rr);
+        b[s] = Q ? bz_cdiv(pb[n + s * sz - 3 * sz], rh, rr) : 0.0;
     }
-    double fza, fzb;
+    double fza, fzb = 0.0;
     {
         const double wt = bz_cdiv(rw[n], g.rho_f[kbeg], g.rrho_f[kbeg]);
         const bool left = wt > 0.0;
         const int B = bz_buffer_face(kbeg, g.Nz);
         const double cf = g.Az * wt, rf = g.rho_f[kbeg];
         fza = rf * (cf * bz_upB(a[0], a[1], a[2], a[3], a[4], a[5], left, B));
-        fzb = rf * (cf * bz_upB(b[0], b[1], b[2], b[3], b[4], b[5], left, B));
+        if constexpr (Q) fzb = rf * (cf * bz_upB(b[0], b[1], b[2], b[3], b[4], b[5], left, B));
     }
     // consecutive zero values of q at the top of the own column's ring (saturates; 6 = the whole ring)
     int zrun = 0;
-    if constexpr (BZ5_ZERO_SHORTCUT) {
+    if constexpr (ZS) {
 #pragma unroll
         for (int s = 0; s < 6; ++s) zrun = (b[s] == 0.0) ? zrun + 1 : 0;
         if (t < 3) ZF[t] = 1;
         __syncthreads();
     }
     T[0][0][ty + 3][tx + 3] = a[3];
-    T[0][1][ty + 3][tx + 3] = b[3];
+    if constexpr (Q) T[0][1][ty + 3][tx + 3] = b[3];
     {
         const double rh = g.rho[kbeg], rr = g.rrho[kbeg];
         bool z0 = (b[3] == 0.0);
 #pragma unroll
         for (int q = 0; q < HPT; ++q)
             if (hok[q]) {
-                const double hbv = bz_cdiv(pb[hn[q]], rh, rr);
                 T[0][0][hr[q]][hc[q]] = bz_cdiv(pa[hn[q]], rh, rr);
-                T[0][1][hr[q]][hc[q]] = hbv;
-                z0 = z0 && (hbv == 0.0);
+                if constexpr (Q) {
+                    const double hbv = bz_cdiv(pb[hn[q]], rh, rr);
+                    T[0][1][hr[q]][hc[q]] = hbv;
+                    z0 = z0 && (hbv == 0.0);
+                }
             }
-        if (BZ5_ZERO_SHORTCUT && !__all(z0) && tx == 0) ZF[0] = 0;
+        if (ZS && !__all(z0) && tx == 0) ZF[0] = 0;
     }
     __syncthreads();
 
@@ -291,11 +299,11 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCA
     // the level's own momentum elements arrive one level ahead (software pipeline: the advecting fluxes are the first thing a level
     // computes, so loads issued at its top were waited for at once — a full memory latency per level and wave)
     double ru_n = ru[n], rv_n = rv[n], rw_n = rw[n + sz];
-    double rvtop_n = (tyu == 0 || tyu == TY / 2) ? rv[ntop0] : 0.0;      // top-face duties of the first level: rows 0 and TY / 2
+    double rvtop_n = (tyu == 0 || (Q && tyu == TY / 2)) ? rv[ntop0] : 0.0;      // top-face duties of the first level: rows 0 and TY / 2
     // ring tops arrive one level ahead as well: they are consumed mid-level (vertical flux), and a load issued at the top of its own
     // level sits behind the previous level's stores in the in-order memory counter
     double ta_nx = 0.0, tb_nx = 0.0;
-    if constexpr (BZ5_TOPS_AHEAD) { ta_nx = pa[n + 3 * sz]; tb_nx = pb[n + 3 * sz]; }
+    if constexpr (BZ5_TOPS_AHEAD) { ta_nx = pa[n + 3 * sz]; if constexpr (Q) tb_nx = pb[n + 3 * sz]; }
     for (int k = kbeg; k < kend; ++k, n += sz) {
         // ---- loads, issued in the order their values are needed (s_waitcnt counts vector loads in order, so waiting for a load
         //      waits for everything issued before it): ring tops (vertical flux, mid-level), next level's frame cells (staging, end of
@@ -304,34 +312,35 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCA
         //      latency per level and wave, because the advecting fluxes are the first thing a level computes) ----
         double ha[HPT], hb[HPT];
         const unsigned lev = (unsigned)(k + 1 - kbeg) * sz;
-        double ta_raw, tb_raw;
+        double ta_raw, tb_raw = 0.0;
         if constexpr (BZ5_TOPS_AHEAD) {
             ta_raw = ta_nx; tb_raw = tb_nx;
             const unsigned up = (k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz;      // the last level's request stays inside the parent array (unused)
-            ta_nx = pa[n + up]; tb_nx = pb[n + up];
-        } else { ta_raw = pa[n + 3 * sz]; tb_raw = pb[n + 3 * sz]; }
-        const int lv3 = BZ5_ZERO_SHORTCUT ? (k - kbeg) % 3 : 0;
+            ta_nx = pa[n + up];
+            if constexpr (Q) tb_nx = pb[n + up];
+        } else { ta_raw = pa[n + 3 * sz]; if constexpr (Q) tb_raw = pb[n + 3 * sz]; }
+        const int lv3 = ZS ? (k - kbeg) % 3 : 0;
         bool zxy = false;
-        if constexpr (BZ5_ZERO_SHORTCUT) {
+        if constexpr (ZS) {
             if (t == 0) ZF[(lv3 + 2) % 3] = 1;      // reset the flag of level k + 2 (set while level k + 1 is staged, at the end of the next trip)
             zxy = __builtin_amdgcn_readfirstlane(ZF[lv3]) != 0;      // q is zero on the whole staged level k: exact zero x / y fluxes
         }
 #pragma unroll
         for (int q = 0; q < HPT; ++q) {
             if (BZ_KO & 2) { ha[q] = ta_raw; hb[q] = tb_raw; }
-            else { ha[q] = hok[q] ? pa[hn[q] + lev] : 0.0; hb[q] = hok[q] ? pb[hn[q] + lev] : 0.0; }
+            else { ha[q] = hok[q] ? pa[hn[q] + lev] : 0.0; hb[q] = (Q && hok[q]) ? pb[hn[q] + lev] : 0.0; }
         }
-        const double u0a = (BZ_KO & 16) ? ta_raw : (E.mode == 2) ? E.u0[n] : 0.0, u0b = (BZ_KO & 16) ? tb_raw : (E.mode == 2) ? E.u0b[n] : 0.0;
+        const double u0a = (BZ_KO & 16) ? ta_raw : (E.mode == 2) ? E.u0[n] : 0.0, u0b = (BZ_KO & 16) ? tb_raw : (Q && E.mode == 2) ? E.u0b[n] : 0.0;
         const double ru_t = ru_n, rv_t = rv_n, rw_t = rw_n, rvtop = rvtop_n;
         // The y face above the tile belongs to no row of the tile: one wavefront per field evaluates it, and the duty rotates with the
         // level (field a: row (k - kbeg) mod TY, field b: half a turn later).
         const int turn = (k - kbeg) & (TY - 1);
-        const bool duty_a = tyu == turn, duty_b = tyu == ((turn + TY / 2) & (TY - 1));
+        const bool duty_a = tyu == turn, duty_b = Q && tyu == ((turn + TY / 2) & (TY - 1));
         if (BZ_KO & 32) { ru_n = ta_raw * 1e-3; rv_n = tb_raw; rw_n = ta_raw * 1e-4; } else {
         ru_n = ru[n + sz]; rv_n = rv[n + sz]; rw_n = rw[n + 2 * sz]; }      // level k + 1 (level kend of the last trip is a halo level: in bounds, unused)
         {
             const int turn_n = (turn + 1) & (TY - 1);
-            const bool duty_n = tyu == turn_n || tyu == ((turn_n + TY / 2) & (TY - 1));
+            const bool duty_n = tyu == turn_n || (Q && tyu == ((turn_n + TY / 2) & (TY - 1)));
             rvtop_n = duty_n ? rv[ntop0 + lev] : 0.0;
         }
         const double rho = LV.rho(k), rrho = LV.rrho(k), Ax_k = LV.Ax(k), Ay_k = LV.Ay(k), Vi_k = LV.Vinv_c(k);
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCA
             const double cf = g.Ax[kk] * ue;
             ea = rhk * (cf * bz_up5(bz_cdiv(pa[ne - 3], rhk, rrk), bz_cdiv(pa[ne - 2], rhk, rrk), bz_cdiv(pa[ne - 1], rhk, rrk),
                                     bz_cdiv(pa[ne], rhk, rrk), bz_cdiv(pa[ne + 1], rhk, rrk), bz_cdiv(pa[ne + 2], rhk, rrk), le_));
+            if constexpr (Q)
             eb = rhk * (cf * bz_up5(bz_cdiv(pb[ne - 3], rhk, rrk), bz_cdiv(pb[ne - 2], rhk, rrk), bz_cdiv(pb[ne - 1], rhk, rrk),
                                     bz_cdiv(pb[ne], rhk, rrk), bz_cdiv(pb[ne + 1], rhk, rrk), bz_cdiv(pb[ne + 2], rhk, rrk), le_));
         }
@@ -378,9 +388,12 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCA
                 FY[buf][0][TY][tx] = rho * (cfy2 * bz_up5y<WY>(Tk[TY][c], Tk[TY + 1][c], Tk[TY + 2][c], Tk[TY + 3][c], Tk[TY + 4][c], Tk[TY + 5][c], ly2, Byt));
             fza_hi = rf * (cfz * bz_upB(a[1], a[2], a[3], a[4], a[5], ta, lz, Bz));
         }
-        const double tb = bz_cdiv(tb_raw, rho3, rrho3);
+        double tb = 0.0;
+        fxb = 0.0; fyb = 0.0; fzb_hi = 0.0;
+        if constexpr (Q) {
+        tb = bz_cdiv(tb_raw, rho3, rrho3);
         bool zz = false;
-        if constexpr (BZ5_ZERO_SHORTCUT) {
+        if constexpr (ZS) {
             zrun = (tb == 0.0) ? min(zrun + 1, 6) : 0;
             zz = __all(zrun >= 6);      // b[1] .. b[5], tb are all zero in every column of the wavefront: exact zero vertical flux
         }
@@ -400,41 +413,52 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCA
         }
         if (zz) fzb_hi = 0.0;
         else fzb_hi = (BZ_KO & 128) ? rf * (cfz * b[3]) : rf * (cfz * bz_upB(b[1], b[2], b[3], b[4], b[5], tb, lz, Bz));
+        }
         // the cell's own prognostic values (read three levels ago as ring tops: an L2 / Infinity-Cache hit), requested before the staging
         // arithmetic so that the RK update after the barrier finds them
-        const double pa_n = (BZ_KO & 4) ? a[3] : pa[n], pb_n = (BZ_KO & 4) ? b[3] : pb[n];
+        const double pa_n = (BZ_KO & 4) ? a[3] : pa[n], pb_n = (!Q || (BZ_KO & 4)) ? b[3] : pb[n];
         // ---- stage level k+1 in the other buffer ----
         T[buf ^ 1][0][ty + 3][tx + 3] = a[4];
-        T[buf ^ 1][1][ty + 3][tx + 3] = b[4];
+        if constexpr (Q) T[buf ^ 1][1][ty + 3][tx + 3] = b[4];
         {
             const double rh = rho1, rr = rrho1;
             bool z1 = (b[4] == 0.0);
 #pragma unroll
             for (int q = 0; q < HPT; ++q)
                 if (hok[q]) {
-                    const double hbv = bz_cdiv(hb[q], rh, rr);
                     T[buf ^ 1][0][hr[q]][hc[q]] = bz_cdiv(ha[q], rh, rr);
-                    T[buf ^ 1][1][hr[q]][hc[q]] = hbv;
-                    z1 = z1 && (hbv == 0.0);
+                    if constexpr (Q) {
+                        const double hbv = bz_cdiv(hb[q], rh, rr);
+                        T[buf ^ 1][1][hr[q]][hc[q]] = hbv;
+                        z1 = z1 && (hbv == 0.0);
+                    }
                 }
-            if (BZ5_ZERO_SHORTCUT && !__all(z1) && tx == 0) ZF[(lv3 + 1) % 3] = 0;
+            if (ZS && !__all(z1) && tx == 0) ZF[(lv3 + 1) % 3] = 0;
         }
         if (!(BZ_KO & 64)) __syncthreads();
         // ---- combine, SSP-RK3 update, temperature of the updated cell for the next stage's buoyancy ----
         {
-            double na = __shfl_down(fxa, 1), nb = __shfl_down(fxb, 1);
-            const double xa = __shfl(ea, src), xb = __shfl(eb, src);
-            if (tx == le) { na = xa; nb = xb; }
+            double na = __shfl_down(fxa, 1);
+            const double xa = __shfl(ea, src);
+            if (tx == le) na = xa;
             const double dya = FY[buf][0][ty + 1][tx] - fya;
-            const double dyb = FY[buf][1][ty + 1][tx] - fyb;
             const double Vi = Vi_k;
             const double ga = -(Vi * ((na - fxa) + dya + (fza_hi - fza)));
-            const double gb = -(Vi * ((nb - fxb) + dyb + (fzb_hi - fzb)));
+            double gb = 0.0;
+            if constexpr (Q) {
+                double nb = __shfl_down(fxb, 1);
+                const double xb = __shfl(eb, src);
+                if (tx == le) nb = xb;
+                const double dyb = FY[buf][1][ty + 1][tx] - fyb;
+                gb = -(Vi * ((nb - fxb) + dyb + (fzb_hi - fzb)));
+            }
             if (store) {
                 const double rth = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0a, E.u0_out, ga, pa_n, n);
-                const double rq = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0b, E.u0b_out, gb, pb_n, n);
                 F.oa[n] = rth;        // interior only: the projection kernel that follows stores the periodic images
-                F.ob[n] = rq;         // (the temperature the buoyancy needs is derived from these two by the z-momentum kernel of the next stage)
+                if constexpr (Q) {
+                    const double rq = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0b, E.u0b_out, gb, pb_n, n);
+                    F.ob[n] = rq;     // (the temperature the buoyancy needs is derived from these two by the z-momentum kernel of the next stage)
+                }
             }
         }
         fza = fza_hi; fzb = fzb_hi;
@@ -443,6 +467,20 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCA
         a[5] = ta; b[5] = tb;
         buf ^= 1;
     }
+}
+
+
+template <int TY, bool WY = false>
+__global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCALAR_WAVES, BZ5_SCALAR_WAVES))) void k5_scalar_pair(DevGrid g, Lean5 F, int kchunk, RKEpilogue E)
+{
+    constexpr int TR = TY + 6, TC = 72;
+    __shared__ double T[2 * 2 * TR * TC];
+    __shared__ double FY[2 * 2 * (TY + 1) * 64];
+    __shared__ int ZF[3];
+    // wave-uniform: one scalar load of the state the moisture scan left (1: every element of rho q is zero)
+    const bool dry = F.qstate != nullptr && __builtin_amdgcn_readfirstlane(*F.qstate) == 1;
+    if (dry) k5_scalar_pair_body<TY, WY, true>(g, F, kchunk, E, T, FY, ZF);
+    else k5_scalar_pair_body<TY, WY, false>(g, F, kchunk, E, T, FY, ZF);
 }
 
 // out-of-wave x fluxes of the momentum kernels with the advected velocity derived from its momentum component
@@ -846,6 +884,7 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
     const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
     const double *__restrict__ pa = L.pa, *__restrict__ pb = L.pb;       // rho theta, rho q of the stage-start state
     const Lev5 LV{L.lev};
+    const bool dryq = L.qstate != nullptr && __builtin_amdgcn_readfirstlane(*L.qstate) == 1;      // rho q identically zero: its loads are skipped
     Tend3Fields F;
     F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
     const double Az = g.Az;
@@ -884,7 +923,7 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
         const int B = bz_buffer_center(kbeg - 1, g.Nz);
         const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
         fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
-        b_lo = buoyancy5(g, pa[n - sz], pb[n - sz], kbeg - 1, LV.rho(kbeg - 1), LV.rrho(kbeg - 1), LV.pi(kbeg - 1));
+        b_lo = buoyancy5(g, pa[n - sz], dryq ? 0.0 : pb[n - sz], kbeg - 1, LV.rho(kbeg - 1), LV.rrho(kbeg - 1), LV.pi(kbeg - 1));
     }
     T[0][ty + 3][tc] = wr[3];
     if (hok) T[0][hr][hc] = bz_cdiv(rw[hn], g.rho_f[kbeg], g.rrho_f[kbeg]);
@@ -899,7 +938,7 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
         // ---- prefetch for level k+1 ----
         const double p_h = hok ? rw[hn + lev + sz] : 0.0;
         const double p_top = rw[n + ((k + 4 <= g.Nz + g.Hz) ? 4 * sz : 3 * sz)];
-        const double Tcur = pa[n], rqcur = pb[n];          // rho theta, rho q: consumed mid-level (buoyancy): not worth two more registers each
+        const double Tcur = pa[n], rqcur = dryq ? 0.0 : pb[n];          // rho theta, rho q (not read where the scan found it zero): consumed mid-level (buoyancy)
         const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
         const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
         const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];

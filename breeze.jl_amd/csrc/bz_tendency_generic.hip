@@ -163,6 +163,9 @@ struct FluxBuf {
     // stores (1 - alpha) u0 + alpha (uold + dt G); uold = the prognostic field the tendency belongs to (E.mode 0: store G)
     RKEpilogue E;
     const double *uold;
+    // fused-RK moisture launch only: the moisture scan's word (bz_step.hip: bzi_scan_moisture); where rho q is identically zero its
+    // update is 0 -> 0 and both passes of the launch return at once (nothing is read or written; U0 of rho q is then never read either)
+    const int *skip_if_dry;
 };
 __device__ __forceinline__ double rk_out(const FluxBuf &F, double G, long long n)
 {
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(256) void k_scalar_tendency_g(DevGrid g, double *__
                                                            const double *__restrict__ v, const double *__restrict__ w,
                                                            const double *__restrict__ c, FluxBuf F)
 {
+    if (F.skip_if_dry && __builtin_amdgcn_readfirstlane(*F.skip_if_dry) == 1) return;
     int i, j, k;
     GenericWrap W;
     if (!generic_index<PASS>(g, i, j, k, 0, W)) return;
@@ -457,7 +461,9 @@ static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G
         {
             ProfileScope ps(ctx, E ? "moisture_tendency+rk3" : "moisture_tendency");
             epi(U0 ? U0->rho_q : nullptr, s->rho_q);
+            if (E) F.skip_if_dry = bzi_moisture_state(ctx);
             GENERIC_LAUNCH(k_scalar_tendency_g, , 0, g.Nz, E ? s->rho_q : G->rho_q, s->u, s->v, s->w, s->q);
+            F.skip_if_dry = nullptr;
         }
     }
     BZ_LAUNCH_CHECK();

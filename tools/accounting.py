@@ -82,13 +82,23 @@ COMPULSORY_WORDS = {
     "kessler_species_tendencies": 6,
     "store_initial_state": 12,
 }
+# Dry runs (rho q identically zero, found by the moisture scan that opens every step call — bz_step.hip: bzi_scan_moisture): the two lean
+# kernels that would touch rho q skip it altogether, so their compulsory array lists shrink; bench.py prices a run in these when its
+# profile shows the scan and the workload set no moisture (and reports the moist variant of the same workload beside it)
+COMPULSORY_WORDS_DRY = {
+    "scalar_tendencies+rk3+thermo": (5, 6, 6),         # R rho_u, rho_v, rho_w, rho_theta [+ U0]; W rho_theta
+    "z_momentum_tendency+rk3+velocity": (5, 6, 6),     # R rho_u, rho_v, rho_w, rho_theta [+ U0]; W predictor
+    "moisture_scan": 1,                                # R rho_q (once per step CALL)
+}
 ACOUSTIC_SUBSTEP_COMPULSORY_WORDS = 33                 # forward 23 + backward 10 (fused substep, thermal divergence damping)
 
 
-def compulsory_words(group, launches_per_step=None):
+def compulsory_words(group, dry=False):
     """Mean compulsory words per cell per launch of a kernel group (None: unknown group).  Stage-dependent groups are averaged over the
-    three stages — a step launches each of them once per stage."""
-    w = COMPULSORY_WORDS.get(group)
+    three stages — a step launches each of them once per stage.  dry: the run took the zero-moisture path of the lean kernels."""
+    w = COMPULSORY_WORDS_DRY.get(group) if dry else None
+    if w is None:
+        w = COMPULSORY_WORDS.get(group)
     if w is None:
         return None
     if isinstance(w, tuple):
@@ -96,22 +106,22 @@ def compulsory_words(group, launches_per_step=None):
     return float(w)
 
 
-def step_compulsory_words(launches_per_step, groups=None):
+def step_compulsory_words(launches_per_step, groups=None, dry=False):
     """Compulsory words per cell and step of a set of kernel groups from their launches per step (bench.py's own counters)."""
     tot = 0.0
     for name, n in launches_per_step.items():
         if groups is not None and name not in groups:
             continue
-        w = compulsory_words(name)
+        w = compulsory_words(name, dry)
         if w is not None:
             tot += w * n
     return tot
 
 
-def roofline_block(group, avg_launch_ms, cells, word_bytes, traffic_bytes=None, traffic_source=None, words=None):
+def roofline_block(group, avg_launch_ms, cells, word_bytes, traffic_bytes=None, traffic_source=None, words=None, dry=False):
     """The `roofline` object of a bench line for one kernel group: priced in compulsory bytes; contract words beside it; PMC traffic
     (bytes per launch) and its ratio to the compulsory bytes when a committed PMC file has the group."""
-    w = words if words is not None else compulsory_words(group)
+    w = words if words is not None else compulsory_words(group, dry)
     if w is None or not avg_launch_ms:
         return None
     nbytes = w * word_bytes * cells
@@ -121,7 +131,7 @@ def roofline_block(group, avg_launch_ms, cells, word_bytes, traffic_bytes=None, 
            "traffic_over_compulsory": (traffic_bytes / nbytes) if traffic_bytes else None,
            "traffic_frac": (traffic_bytes / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_bytes else None,
            "avg_launch_ms": avg_launch_ms, "bytes": "compulsory: every distinct 3-D array of the fused kernel once (tools/accounting.py)",
-           "compulsory_words_per_cell": w, "compulsory_bytes_per_launch": nbytes,
+           "compulsory_words_per_cell": w, "compulsory_bytes_per_launch": nbytes, "dry_path": bool(dry and group in COMPULSORY_WORDS_DRY),
            "contract_words_per_cell": CONTRACT_WORDS.get(group),
            "contract_bytes_per_launch": CONTRACT_WORDS[group] * word_bytes * cells if group in CONTRACT_WORDS else None}
     return out

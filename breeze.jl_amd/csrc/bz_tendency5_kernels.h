@@ -252,10 +252,16 @@ __device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean
 
     // vertical rings of theta, q
     double a[6], b[6];
+    // DRYQ: the registers the second scalar would take hold the own column's RAW rho theta of levels k .. k + 2, so that the RK update
+    // finds its own cell without the re-read the general path does three levels after the value arrived as ring top (one word per cell
+    // out of the Infinity Cache)
+    double araw[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const double rh = g.rho[kbeg + s - 3], rr = g.rrho[kbeg + s - 3];
-        a[s] = bz_cdiv(pa[n + s * sz - 3 * sz], rh, rr);
+        const double raw = pa[n + s * sz - 3 * sz];
+        a[s] = bz_cdiv(raw, rh, rr);
+        if (DRYQ && s >= 3) araw[s - 3] = raw;
         b[s] = Q ? bz_cdiv(pb[n + s * sz - 3 * sz], rh, rr) : 0.0;
     }
     double fza, fzb = 0.0;
@@ -416,7 +422,8 @@ __device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean
         }
         // the cell's own prognostic values (read three levels ago as ring tops: an L2 / Infinity-Cache hit), requested before the staging
         // arithmetic so that the RK update after the barrier finds them
-        const double pa_n = (BZ_KO & 4) ? a[3] : pa[n], pb_n = (!Q || (BZ_KO & 4)) ? b[3] : pb[n];
+        const double pa_n = DRYQ ? araw[0] : (BZ_KO & 4) ? a[3] : pa[n], pb_n = (!Q || (BZ_KO & 4)) ? b[3] : pb[n];
+        if constexpr (DRYQ) { araw[0] = araw[1]; araw[1] = araw[2]; araw[2] = ta_raw; }
         // ---- stage level k+1 in the other buffer ----
         T[buf ^ 1][0][ty + 3][tx + 3] = a[4];
         if constexpr (Q) T[buf ^ 1][1][ty + 3][tx + 3] = b[4];

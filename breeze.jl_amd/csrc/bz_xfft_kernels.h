@@ -22,6 +22,7 @@
 // Included by bz_fused.hip.
 #pragma once
 
+typedef double xf_pair2 __attribute__((ext_vector_type(2), aligned(sizeof(double))));      // two consecutive reals, element-aligned
 #define XF_RB 8        // rows of y per workgroup: a transposed store / load moves XF_RB consecutive complex numbers (128 B) per kx
 
 // LDS slot of element p < n2 of a row: the low four bits (the 16-byte slot inside a 256-byte bank period) are XOR-swizzled with a
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_forward(DevGrid g, const 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long long n = g.idx(2 * (tid + T * q), j, kbeg);
-            wlo[2 * q] = rw[n]; wlo[2 * q + 1] = rw[n + 1];
+            const xf_pair2 w2 = *(const xf_pair2 *)(rw + n);
+            wlo[2 * q] = w2.x; wlo[2 * q + 1] = w2.y;
         }
     }
     for (int k = kbeg; k < kend; ++k) {
@@ -261,9 +263,12 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_forward(DevGrid g, const 
             for (int q = 0; q < 4; ++q) {
                 const int i = 2 * (tid + T * q);
                 const long long n = g.idx(i, j, k);
-                const double u0 = ru[n], u1 = ru[n + 1], u2 = ru[n + ((i + 2 < Nx) ? 2 : 2 - Nx)];
-                const double v0 = rv[n], v1 = rv[n + 1], vp0 = rv[n + jp], vp1 = rv[n + jp + 1];
-                const double wh0 = rw[n + g.Sxy], wh1 = rw[n + g.Sxy + 1];
+                // the cell pair (i, i + 1) of every array as one element-aligned two-word request (round 4: the Float32 kernel moved 4 bytes per lane)
+                const xf_pair2 up = *(const xf_pair2 *)(ru + n), vq = *(const xf_pair2 *)(rv + n), vpq = *(const xf_pair2 *)(rv + n + jp),
+                               whq = *(const xf_pair2 *)(rw + n + g.Sxy);
+                const double u0 = up.x, u1 = up.y, u2 = ru[n + ((i + 2 < Nx) ? 2 : 2 - Nx)];
+                const double v0 = vq.x, v1 = vq.y, vp0 = vpq.x, vp1 = vpq.y;
+                const double wh0 = whq.x, wh1 = whq.y;
                 double a = Ax * u1 - Ax * u0, b = Ay * vp0 - Ay * v0, c = Az * wh0 - Az * wlo[2 * q];
                 const double x0 = dz * (Vi * (a + b + c)) / dt;
                 a = Ax * u2 - Ax * u1; b = Ay * vp1 - Ay * v1; c = Az * wh1 - Az * wlo[2 * q + 1];

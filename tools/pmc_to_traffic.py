@@ -24,7 +24,10 @@ def main():
         group, f32 = kernel_group(k)
         if group is None:
             continue
-        per = out["per_kernel_group_float32" if f32 else "per_kernel_group"]
+        # the acoustic kernels instantiated for substep_floattype = Float32 inside the Float64 library (template argument `float`) move
+        # fewer bytes: kept apart so that the Float64-storage figures are not averaged with them
+        sub32 = (not f32) and k.startswith("k_ac_") and k.rstrip().endswith("float>")
+        per = out.setdefault("per_kernel_group_substep_float32", {}) if sub32 else out["per_kernel_group_float32" if f32 else "per_kernel_group"]
         e = per.setdefault(group, {"kernel": k if not k.startswith("fft_rtc_") else "rocFFT batched 1-D C2C plan along y", "read_bytes": 0.0, "write_bytes": 0.0,
                                    "hbm_bytes_per_launch": 0.0, "kernels": 0})
         # several instantiations of one group (e.g. the damped / undamped forward sweep) are averaged; rocFFT plans made of several kernels add up

@@ -73,6 +73,9 @@ static_assert(sizeof(LevRow5) == 8 * sizeof(double), "LevRow5 is eight reals");
 #ifndef BZ5_TOPS_AHEAD
 #define BZ5_TOPS_AHEAD 1
 #endif
+#ifndef BZ6_W_WAVES
+#define BZ6_W_WAVES 4
+#endif
 #ifndef BZ5_SCALAR_WAVES
 #define BZ5_SCALAR_WAVES 4
 #endif
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
         const double ay = bz_symm4(Ay * rvr[-2], Ay * rvr[-1], Ay * rvr[0], Ay * rvr[1]);
         const double fy = ay * bz_up5y<WY>(Uk[ty][tc], Uk[ty + 1][tc], Uk[ty + 2][tc], c0, Uk[ty + 4][tc], Uk[ty + 5][tc], ay > 0.0, by5_face<WY>(g, __builtin_amdgcn_readfirstlane(j)));
         FY[buf][ty][tx] = fy;
-        if (ty == 0) {
+        if (ty == 0 && !(BZ_KO & 4096)) {
             const double *rvt = RV[buf][TY] + tc;
             const double at = bz_symm4(Ay * rvt[-2], Ay * rvt[-1], Ay * rvt[0], Ay * rvt[1]);
             FY[buf][TY][tx] = at * bz_up5y<WY>(Uk[TY][tc], Uk[TY + 1][tc], Uk[TY + 2][tc], Uk[TY + 3][tc], Uk[TY + 4][tc], Uk[TY + 5][tc], at > 0.0,
@@ -788,7 +791,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         const double vt = (!WY || Bc == 3) ? bz_symm4(MV[ty + 1][tx], MV[ty + 2][tx], MV[ty + 3][tx], MV[ty + 4][tx]) : bz_symm2(MV[ty + 2][tx], MV[ty + 3][tx]);
         const double fy = vt * bz_up5y<WY>(V[ty + 1][tc], V[ty + 2][tc], c0, V[ty + 4][tc], V[ty + 5][tc], V[ty + 6][tc], vt > 0.0, Bc);
         FY[buf][ty + 1][tx] = fy;
-        if (ty == 0) {       // centre j0-1: rho_v rows j0-2..j0+1, v rows j0-3..j0+2
+        if (ty == 0 && !(BZ_KO & 4096)) {       // centre j0-1: rho_v rows j0-2..j0+1, v rows j0-3..j0+2
             const double vb = (!WY || Bc0 == 3) ? bz_symm4(MV[0][tx], MV[1][tx], MV[2][tx], MV[3][tx]) : bz_symm2(MV[1][tx], MV[2][tx]);
             FY[buf][0][tx] = vb * bz_up5y<WY>(V[0][tc], V[1][tc], V[2][tc], V[3][tc], V[4][tc], V[5][tc], vb > 0.0, Bc0);
         }
@@ -870,7 +873,7 @@ __device__ __forceinline__ double buoyancy5(const DevGrid &g, double rth, double
 // own column rides a register delay line (advecting-flux ring and RK update).  Same arithmetic, same bits as k5_w.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TY, bool WY = false>
-__global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
+__global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY, NH = TR * 70 - TY * 64;
     static_assert(NH <= NT, "one frame cell per thread");
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(64 * TY, 4) void k6_w(DevGrid g, Lean5 L, int kchun
         const double vt = (Bf == 3) ? bz_symm4(qv[0], qv[1], qv[2], qv[3]) : bz_symm2(qv[1], qv[2]);
         const double fy = vt * bz_up5y<WY>(Tk[ty][tc], Tk[ty + 1][tc], Tk[ty + 2][tc], w0, Tk[ty + 4][tc], Tk[ty + 5][tc], vt > 0.0, by5_face<WY>(g, __builtin_amdgcn_readfirstlane(j)));
         FY[buf][ty][tx] = fy;
-        if (top) {
+        if (top && !(BZ_KO & 4096)) {
             const double v2 = (Bf == 3) ? bz_symm4(qt[0], qt[1], qt[2], qt[3]) : bz_symm2(qt[1], qt[2]);
             FY[buf][TY][tx] = v2 * bz_up5y<WY>(Tk[TY][tc], Tk[TY + 1][tc], Tk[TY + 2][tc], Tk[TY + 3][tc], Tk[TY + 4][tc], Tk[TY + 5][tc], v2 > 0.0,
                                                by5_face<WY>(g, j0 + TY));

@@ -115,6 +115,72 @@ def test_tendencies_match_oracle(oracle, bz, order, stretched):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("order", [7, 9])
+@pytest.mark.parametrize("ftype", ["f64", "f32"])
+def test_single_pass_marching_kernel_equals_the_two_pass_path_bit_for_bit(oracle, bz, order, ftype, monkeypatch):
+    """csrc/bz_tendency_generic.hip: k_tendency_m (rows of a multiple of 64 cells inside periodic x / y) evaluates every flux once with
+    the expressions of the flux pass and differences them in the kernel: same bits as flux arrays + divergence pass (BZ_NO_GENERIC_MARCH=1),
+    oracle at the tolerance of test_tendencies_match_oracle.  Nz = 70: two level chunks (64 + 6; faces 64 + 5), a partial last group,
+    every buffer of the wall cascade; 128 x 8: two tiles in x, two in y — edge fluxes across tile and domain boundaries."""
+    import torch
+    size = (128, 8, 70)
+    zf = 10e3 * (np.linspace(0.0, 1.0, size[2] + 1) ** 1.3)
+    ext = ((-10e3, 10e3), (-10e3, 10e3))
+    og = oracle.Grid(size, x=ext[0], y=ext[1], z=zf, halo=(5, 5, 5))
+    om = oracle.OracleModel(og, potential_temperature=300.0, advection=f"WENO{order}")
+    randomize(om, seed=23)
+    om.compute_tendencies()
+    out = {}
+    for march in (True, False):
+        if march:
+            monkeypatch.delenv("BZ_NO_GENERIC_MARCH", raising=False)
+        else:
+            monkeypatch.setenv("BZ_NO_GENERIC_MARCH", "1")
+        kw = {"float_type": np.float32} if ftype == "f32" else {}
+        grid = bz.RectilinearGrid(size, x=ext[0], y=ext[1], z=zf, halo=(5, 5, 5), **kw)
+        hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)),
+                                advection=bz.WENO(order=order))
+        push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq", "u", "v", "w", "theta", "q", "T"))
+        for k in hm.G.values():
+            k.parent.zero_()
+        bz.compute_tendencies_(hm)
+        hm.synchronize()
+        out[march] = {k: hm.G[k].interior.clone() for k in PROG.values()}
+    differ = {n: float((out[True][k] - out[False][k]).abs().max()) for n, k in PROG.items() if not torch.equal(out[True][k], out[False][k])}
+    assert not differ, differ
+    for n, k in PROG.items():
+        zf_ = n == "rw"
+        want, got = om.grid.interior(om.G[n], zface=zf_), out[True][k].double().cpu().numpy()
+        if zf_:
+            want, got = want[1:-1], got[1:-1]
+        if ftype == "f64":      # (Float32 against the oracle: tests/test_float32.py, through the two-pass path these bits equal)
+            assert relerr(got, want) < 1e-11, (n, relerr(got, want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [7, 9])
+def test_single_pass_marching_steps_equal_two_pass_steps(bz, order, monkeypatch):
+    """three whole steps (fused-RK tier: the SSP-RK3 epilogue inside the kernel, rho theta advanced in place) on 64 x 8 x 20"""
+    import torch
+    out = {}
+    for march in (True, False):
+        if march:
+            monkeypatch.delenv("BZ_NO_GENERIC_MARCH", raising=False)
+        else:
+            monkeypatch.setenv("BZ_NO_GENERIC_MARCH", "1")
+        grid = bz.RectilinearGrid((64, 8, 20), x=(-10e3, 10e3), y=(-1250.0, 1250.0), z=(0.0, 10e3), halo=(5, 5, 5))
+        hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(bz.ReferenceState(grid, potential_temperature=300.0)),
+                                advection=bz.WENO(order=order))
+        hm.set(θ=bubble_theta(300.0, 9.81), u=3.0, v=-2.0, qᵗ=lambda x, y, z: 1e-3 * np.exp(-z / 2e3) + 0 * x)
+        for _ in range(3):
+            hm.time_step(2.0)
+        hm.synchronize()
+        out[march] = {k: f.interior.clone() for k, f in hm.prognostic_fields().items()}
+    for k in out[True]:
+        assert torch.equal(out[True][k], out[False][k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("order", [5, 7, 9])
 def test_single_scalar_tendency_entry_matches_oracle(oracle, bz, order):
     """bz_compute_scalar_tendency — the launch of compute_scalar_tendency! for one field, what the reference's scalar_tendency

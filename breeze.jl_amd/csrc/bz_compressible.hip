@@ -314,6 +314,106 @@ __global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d(DevGrid g, d
     }
 }
 
+// The same tendency with every face flux evaluated ONCE (round 4).  The kernel above evaluates both x faces, both y faces and the upper
+// z face of its cell: five order-5 reconstructions per cell where three are needed.  Here a thread evaluates the fluxes through its
+// low x face and low y face and through the upper z face; the high x-face flux comes from the next lane (the one beyond the tile edge:
+// one evaluation per lane for the 64 levels of the march, read back with a second shuffle), the high y-face flux through an LDS row
+// exchange of CTY levels at a time in which wave l evaluates the row outside the tile for level l (every wave: 3 CTY + 1 reconstructions
+// per group).  Same expressions per flux; the differences see rounded fluxes (bz_sub_rounded_c), where the kernel above lets the compiler
+// contract one of each pair into an fma — results differ from it by an ulp of a flux, both within 1e-12 of the oracle.
+// grid (Nx / 64, Ny / CTY, ceil(Nz / 64)): rows of a multiple of 64 cells, Ny a multiple of CTY, not Flat; halo rows in y are read as
+// they are (periodic images or a slab neighbour's rows).
+__device__ __forceinline__ double bz_sub_rounded_c(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+__global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d_x(DevGrid g, double *__restrict__ Gc, double *__restrict__ Grho,
+                                                                     const double *__restrict__ rho, const double *__restrict__ u,
+                                                                     const double *__restrict__ v, const double *__restrict__ w,
+                                                                     const double *__restrict__ c, const double *__restrict__ ru,
+                                                                     const double *__restrict__ rv, const double *__restrict__ rw,
+                                                                     const int *__restrict__ zero_if_dry, int kchunk)
+{
+    __shared__ double FY[2][CTY][CTY + 1][64];
+    __shared__ double AX[CTY][CTY][64], AZ[CTY][CTY][64];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * CTY, i = i0 + tx, j = j0 + ty;
+    const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk, g.Nz);      // kchunk <= 64: one edge flux per lane
+    const long long sy = g.Sx, sz = g.Sxy;
+    long long n = g.idx(i, j, k0);
+    if (zero_if_dry && __builtin_amdgcn_readfirstlane(*zero_if_dry) == 1) {
+        for (int k = k0; k < k1; ++k, n += sz) Gc[n] = 0.0;
+        return;
+    }
+    auto FX = [&](long long m, int k) {      // flux through the low x face of cell m
+        const double u0 = u[m];
+        return ((rho[m] + rho[m - 1]) / 2.0) * ((g.Ax[k] * u0) * bz_up5(c[m - 3], c[m - 2], c[m - 1], c[m], c[m + 1], c[m + 2], u0 > 0.0));
+    };
+    auto FYf = [&](long long m, int k) {     // low y face
+        const double v0 = v[m];
+        return ((rho[m] + rho[m - sy]) / 2.0) *
+               ((g.Ay[k] * v0) * bz_up5(c[m - 3 * sy], c[m - 2 * sy], c[m - sy], c[m], c[m + sy], c[m + 2 * sy], v0 > 0.0));
+    };
+    double edge;
+    {
+        const int kk = min(k0 + tx, k1 - 1);
+        edge = FX(g.idx(i0 + 64, j, kk), kk);
+    }
+    const long long nx0 = g.idx(i, j0 + CTY, k0);
+    double zm3 = c[n - 3 * sz], zm2 = c[n - 2 * sz], zm1 = c[n - sz], z0 = c[n], zp1 = c[n + sz], zp2 = c[n + 2 * sz];
+    double r_lo = rho[n - sz], r0 = rho[n];
+    double Fz_lo;
+    {
+        const double wt = w[n];
+        const double cR = bz_upB(zm3, zm2, zm1, z0, zp1, zp2, wt > 0.0, bz_buffer_face(k0, g.Nz));
+        Fz_lo = ((r0 + r_lo) / 2.0) * ((g.Az * wt) * cR);
+    }
+    int buf = 0;
+    for (int k = k0; k < k1; k += CTY, n += CTY * sz) {
+        const int nl = min(CTY, k1 - k);
+#pragma unroll 1
+        for (int l = 0; l < nl; ++l) {
+            const int kl = k + l;
+            const long long m = n + l * sz;
+            const double zp3 = c[m + 3 * sz];
+            const double r_hi = rho[m + sz];
+            const double wt = w[m + sz];
+            const double cR = bz_upB(zm2, zm1, z0, zp1, zp2, zp3, wt > 0.0, bz_buffer_face(kl + 1, g.Nz));
+            const double Fz_hi = ((r_hi + r0) / 2.0) * ((g.Az * wt) * cR);
+            AZ[l][ty][tx] = bz_sub_rounded_c(Fz_hi, Fz_lo);
+            const double fx = FX(m, kl);
+            double nb = __shfl_down(fx, 1);
+            const double e = __shfl(edge, kl - k0);
+            if (tx == 63) nb = e;
+            AX[l][ty][tx] = bz_sub_rounded_c(nb, fx);
+            const int reps = (ty == l) ? 2 : 1;
+#pragma unroll 1
+            for (int rep = 0; rep < reps; ++rep)
+                FY[buf][l][rep ? CTY : ty][tx] = FYf(rep ? nx0 + (long long)(kl - k0) * sz : m, kl);
+            zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
+            Fz_lo = Fz_hi;
+            r_lo = r0; r0 = r_hi;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 0; l < nl; ++l) {
+            const int kl = k + l;
+            const long long m = n + l * sz;
+            const double dy = bz_sub_rounded_c(FY[buf][l][ty + 1][tx], FY[buf][l][ty][tx]);
+            Gc[m] = -(g.Vinv_c[kl] * (AX[l][ty][tx] + dy + AZ[l][ty][tx]));
+            if (Grho) {
+                const double Ax = g.Ax[kl], Ay = g.Ay[kl];
+                const double a = Ax * ru[m + 1] - Ax * ru[m];
+                const double b = Ay * rv[m + sy] - Ay * rv[m];
+                const double cc = g.Az * rw[m + sz] - g.Az * rw[m];
+                Grho[m] = -(g.Vinv_c[kl] * (a + b + cc));
+            }
+        }
+        buf ^= 1;
+    }
+}
+
 static int pick_kchunk_c(const DevGrid &g, int nlev)
 {
     long long tiles = (long long)((g.Nx + 63) / 64) * ((g.Ny + CTY - 1) / CTY);
@@ -1112,6 +1212,14 @@ static int launch_scalar_rho3d(bz_ctx *ctx, const char *name, double *Gc, double
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, name);
     if (ctx->weno_R != 3) return bzi_scalar_rho3d_generic(ctx, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
+    if (!ctx->tune.no_rho3d_exchange && !g.flat_y && !g.bounded_x && !g.bounded_y && g.Nx % 64 == 0 && g.Ny % CTY == 0) {
+        int kc = 64;      // levels per workgroup: >= 8 wavefronts per SIMD (see march_chunk in bz_tendency_generic.hip)
+        while (kc > 8 && (long long)(g.Nx / 64) * g.Ny * ((g.Nz + kc - 1) / kc) < 8192) kc >>= 1;
+        dim3 block(64, CTY), grid(g.Nx / 64, g.Ny / CTY, (g.Nz + kc - 1) / kc);
+        hipLaunchKernelGGL(k_scalar_tendency_rho3d_x, grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw, zero_if_dry, kc);
+        BZ_LAUNCH_CHECK();
+        return BZ_OK;
+    }
     const int kc = pick_kchunk_c(g, g.Nz);
     dim3 block(64, CTY), grid((g.Nx + 63) / 64, (g.Ny + CTY - 1) / CTY, (g.Nz + kc - 1) / kc);
     hipLaunchKernelGGL(k_scalar_tendency_rho3d, grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw, kc, zero_if_dry);

@@ -261,6 +261,7 @@ struct bz_tuning {
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms
     int poisson_chunk = 0;            // BZ_POISSON_CHUNK: level-chunked Poisson pipeline (needs BZ_NO_XFFT)
     int xf_kchunk_f = 0, xf_kchunk_i = 0;      // BZ_XF_KCHUNK_F / _I: levels per block of the x transforms (0: automatic)
+    bool no_rho3d_exchange = false;   // BZ_NO_RHO3D_EXCHANGE: the compressible scalar tendency keeps the kernel that evaluates five fluxes per cell
     bool no_generic_march = false;    // BZ_NO_GENERIC_MARCH: WENO 7 / 9 keep the two-pass (flux arrays + divergence) kernels everywhere
     bool generic_onepass = false;     // BZ_GENERIC_ONEPASS: WENO 7 / 9 with every flux evaluated by both of its cells
     bool no_ac_fuse = false;          // BZ_NO_AC_FUSE: three kernels per acoustic substep

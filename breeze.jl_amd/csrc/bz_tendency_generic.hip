@@ -508,7 +508,7 @@ template <int R, int KIND, bool BUOY>
 __global__ __launch_bounds__(64 * MTY, MARCH_WAVES) void k_tendency_m(DevGrid g, double *__restrict__ G, const double *__restrict__ ru,
                                                          const double *__restrict__ rv, const double *__restrict__ rw,
                                                          const double *__restrict__ a, const double *__restrict__ T,
-                                                         const double *__restrict__ qv, FluxBuf F)
+                                                         const double *__restrict__ qv, FluxBuf F, int kchunk)
 {
     if (F.skip_if_dry && __builtin_amdgcn_readfirstlane(*F.skip_if_dry) == 1) return;
     constexpr bool XC = (KIND == 1), YC = (KIND == 2), ZC = (KIND == 3);
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64 * MTY, MARCH_WAVES) void k_tendency_m(DevGrid g,
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int i0 = blockIdx.x * 64, j0 = blockIdx.y * MTY, i = i0 + tx, j = j0 + ty;
     const int k0 = ZC ? 1 : 0, k1 = g.Nz;                    // levels [k0, k1)
-    const int kbeg = k0 + blockIdx.z * 64, kend = min(kbeg + 64, k1);
+    const int kbeg = k0 + blockIdx.z * kchunk, kend = min(kbeg + kchunk, k1);      // kchunk <= 64: one edge flux per lane
     if (kbeg >= kend) return;
     const long long sz = g.Sxy;
     const MarchFlux<R, KIND> Fl(g, ru, rv, rw, a);
@@ -606,9 +606,18 @@ static bool generic_march_ok(const bz_ctx *ctx)
     return !ctx->tune.generic_onepass && !ctx->tune.no_generic_march && g.wrap_y && !g.flat_y && !g.bounded_x && !g.bounded_y &&
            g.Nx % 64 == 0 && g.Ny % MTY == 0 && g.Nz > 1;
 }
+// levels per workgroup of the march: 64 where that leaves >= 8 wavefronts per SIMD, else shorter chunks (every chunk pays one edge flux
+// and one first z flux per thread: 1 / chunk extra reconstructions; BOMEX 256 x 256 x 128 at 64 levels had two wavefronts per SIMD and
+// ran 19 % slower than the two passes)
+static int march_chunk(const DevGrid &g)
+{
+    int kc = 64;
+    while (kc > 8 && (long long)(g.Nx / 64) * g.Ny * ((g.Nz + kc - 1) / kc) < 8192) kc >>= 1;
+    return kc;
+}
 #define MARCH_LAUNCH(KIND, BUOY, nlev, ...)                                                                                         \
-    hipLaunchKernelGGL((k_tendency_m<R, KIND, BUOY>), dim3(g.Nx / 64, g.Ny / MTY, ((nlev) + 63) / 64), dim3(64, MTY), 0, ctx->stream, g, \
-                       __VA_ARGS__, F)
+    hipLaunchKernelGGL((k_tendency_m<R, KIND, BUOY>), dim3(g.Nx / 64, g.Ny / MTY, ((nlev) + mkc - 1) / mkc), dim3(64, MTY), 0, ctx->stream, g, \
+                       __VA_ARGS__, F, mkc)
 
 // E != nullptr: the fused-RK tier of the whole-step seam (bz_step.hip) — the divergence pass of every field applies the SSP-RK3 update:
 // the predictor momentum goes to the G slots (the prognostic momentum keeps feeding the advecting fluxes of the kernels that follow),
@@ -619,6 +628,7 @@ static int launch_generic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G
 {
     const DevGrid &g = ctx->dg;
     const bool onepass = ctx->tune.generic_onepass, march = generic_march_ok(ctx);
+    const int mkc = march_chunk(g);
     FluxBuf F{};
     int rc;
     if (!onepass && !(march && MARCH_W) && (rc = generic_flux_buffers(ctx, F))) return rc;
@@ -718,6 +728,7 @@ static int launch_scalar(bz_ctx *ctx, double *Gc, const double *u, const double 
 {
     const DevGrid &g = ctx->dg;
     const bool onepass = ctx->tune.generic_onepass, march = generic_march_ok(ctx);
+    const int mkc = march_chunk(g);
     FluxBuf F{};
     int rc;
     const double *nul = nullptr;

@@ -76,8 +76,10 @@ static_assert(sizeof(LevRow5) == 8 * sizeof(double), "LevRow5 is eight reals");
 #ifndef BZ6_W_WAVES
 #define BZ6_W_WAVES 4
 #endif
+// (later in round 4 the Float32 objects lost the SLP vectoriser — csrc/Makefile: F32FLAGS — and with it the operand-pair moves: the Float32
+// scalar kernel needs 75 - 80 registers with both additions and runs at six waves again: 0.97 -> 0.92 ms per launch in its dry form)
 #ifndef BZ5_SCALAR_WAVES
-#define BZ5_SCALAR_WAVES 4
+#define BZ5_SCALAR_WAVES (sizeof(double) == 8 ? 4 : 6)
 #endif
 
 struct Lean5 {

@@ -26,6 +26,12 @@ for ord in 5 9; do
 done
 echo "== config4 (compressible + Kessler, 512x512x128)"
 timeout 600 python bench.py --workload config4 --steps 5 --warmup 2 > $O/config4.json 2> $O/config4.err
+echo "== BOMEX 256x256x128 (physics list of examples/bomex.jl) and the 256^3 bubble with WENO9"
+timeout 300 python tools/bench_bomex.py 2>/dev/null | tail -1 > $O/bomex_weno5_f64.json
+timeout 300 python tools/bench_bomex.py --float32 2>/dev/null | tail -1 > $O/bomex_weno5_f32.json
+timeout 300 python tools/bench_bomex.py --order 9 2>/dev/null | tail -1 > $O/bomex_weno9_f64.json
+timeout 300 python tools/bench_bomex.py --order 9 --float32 2>/dev/null | tail -1 > $O/bomex_weno9_f32.json
+timeout 300 python tools/bench_order.py --size 256 --order 9 2>/dev/null | tail -1 > $O/bubble256_weno9_f64.json
 echo "== slab driver on one GPU: world 1, and with every message sent to itself"
 timeout 600 python bench.py --slab --steps 10 --warmup 3 --no-cpu-baseline --no-compressible --no-float32 > $O/slab_world1.json 2> $O/slab_world1.err
 BZ_COMM_SELF_MESSAGES=1 timeout 600 python bench.py --slab --steps 10 --warmup 3 --no-cpu-baseline --no-compressible --no-float32 > $O/slab_world1_self_messages.json 2> $O/slab_self.err
@@ -38,7 +44,7 @@ ls -la $O | head -40
 python - $O <<'PY'
 import json, sys, os
 O = sys.argv[1]
-for f in ("bench.json", "cbl_weno5.json", "cbl_weno9.json", "config4.json", "slab_world1.json", "slab_world1_self_messages.json"):
+for f in ("bench.json", "cbl_weno5.json", "cbl_weno9.json", "config4.json", "slab_world1.json", "slab_world1_self_messages.json", "bomex_weno5_f64.json", "bomex_weno5_f32.json", "bomex_weno9_f64.json", "bomex_weno9_f32.json", "bubble256_weno9_f64.json"):
     try:
         d = json.loads([l for l in open(os.path.join(O, f)).read().splitlines() if l.startswith("{")][-1])
         print(f, d.get("ms_per_step"), d.get("value"), (d.get("roofline") or {}).get("kernel"), (d.get("roofline") or {}).get("frac"))

@@ -9,7 +9,7 @@ if [ "$mode" = build32 ]; then      # the same for the Float32 twin: FILE.hip is
   f=$1; shift; base=${f%.hip}
   while [ $# -gt 1 ]; do
     name=$1; flags=$2; shift; shift
-    ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-value -Wno-unused-result -DBZ_WENO_ONE_DIVISION=2 $flags -c $C/build/f32/$f -o $C/build/f32/var_$name.o &&
+    ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-value -Wno-unused-result -DBZ_WENO_ONE_DIVISION=2 -fno-slp-vectorize $flags -c $C/build/f32/$f -o $C/build/f32/var_$name.o &&
       objs=$(ls $C/build/f32/bz_*.o | grep -v "/$base.o") &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $objs $C/build/f32/var_$name.o -shared -L/opt/rocm/lib -lhipfft -ldl -lpthread -Wl,-rpath,/opt/rocm/lib -o breeze.jl_amd/lib/var32_$name.so ) &
   done

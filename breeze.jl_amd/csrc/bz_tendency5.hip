@@ -25,6 +25,8 @@ __global__ void k_lev_rows(DevGrid g, const double *__restrict__ pi, LevRow5 *__
     LevRow5 r;
     r.rho = g.rho[k]; r.rrho = g.rrho[k]; r.rho_f = g.rho_f[k]; r.rrho_f = g.rrho_f[k];
     r.Ax = g.Ax[k]; r.Ay = g.Ay[k]; r.Vinv_c = g.Vinv_c[k]; r.pi = pi[t];
+    r.Vinv_f = g.Vinv_f[k]; r.T_r = g.T_r[k];
+    for (int q = 0; q < 6; ++q) r.pad[q] = 0.0;
     rows[t] = r;
 }
 

@@ -37,12 +37,14 @@ struct LevRow5 {
     double rho_f, rrho_f;    // the same at the lower face of level k
     double Ax, Ay, Vinv_c;
     double pi;               // dry Exner factor (p_r[k]/p_st)^(Rd/cpd)
+    double Vinv_f, T_r;      // round 4 (z-momentum kernel): 1 / V at the lower face, reference temperature
+    double pad[6];           // rows of 128 bytes
 };
 // row access through the constant address space, field by field (adjacent fields merge into one wide s_load)
 struct Lev5 {
     const LevRow5 *p;
 #ifdef __HIPCC__
-    __device__ __forceinline__ double at(int k, int f) const { return ((ColPtr::cptr)(const double *)p)[(long long)k * 8 + f]; }
+    __device__ __forceinline__ double at(int k, int f) const { return ((ColPtr::cptr)(const double *)p)[(long long)k * 16 + f]; }
     __device__ __forceinline__ double rho(int k) const { return at(k, 0); }
     __device__ __forceinline__ double rrho(int k) const { return at(k, 1); }
     __device__ __forceinline__ double rho_f(int k) const { return at(k, 2); }
@@ -51,9 +53,11 @@ struct Lev5 {
     __device__ __forceinline__ double Ay(int k) const { return at(k, 5); }
     __device__ __forceinline__ double Vinv_c(int k) const { return at(k, 6); }
     __device__ __forceinline__ double pi(int k) const { return at(k, 7); }
+    __device__ __forceinline__ double Vinv_f(int k) const { return at(k, 8); }
+    __device__ __forceinline__ double T_r(int k) const { return at(k, 9); }
 #endif
 };
-static_assert(sizeof(LevRow5) == 8 * sizeof(double), "LevRow5 is eight reals");
+static_assert(sizeof(LevRow5) == 16 * sizeof(double), "LevRow5 is sixteen reals");
 
 // Waves per SIMD the lean kernels are compiled for: 4 in Float64 (two 512-thread workgroups per CU, <= 128 VGPRs), 6 in the Float32
 // build (three workgroups, <= 80 VGPRs: a Float32 value is one register, and the Float32 kernels sat at 84-85 — allocated as 88,
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
 // ---------------------------------------------------------------------------------------------------------------------
 // buoyancy of a cell from its prognostic densities: T = Pi^(Rm/cpm) theta as bz_temperature5r (the bits of the stored diagnostic),
 // q = rho q / rho_r, then the expression of buoyancy3
-__device__ __forceinline__ double buoyancy5(const DevGrid &g, double rth, double rq, int k, double rho, double rrho, double pi)
+__device__ __forceinline__ double buoyancy5(const DevGrid &g, double rth, double rq, int k, double rho, double rrho, double pi, double T_ref)
 {
     const double th = bz_cdiv(rth, rho, rrho), q = bz_cdiv(rq, rho, rrho);
     double T;
@@ -865,7 +869,10 @@ __device__ __forceinline__ double buoyancy5(const DevGrid &g, double rth, double
         const double cpm = qd * g.cpd + q * g.cpv;
         T = bz_exner_pow5(g.p_r[k] / g.pst, Rm / cpm) * th;
     }
-    return buoyancy3(g, T, q, k);
+    // buoyancy3 with the level's rho_r and T_r from the packed row (the same table entries)
+    const double Rm = (1.0 - q) * g.Rd + q * g.Rv;
+    const double rhop = rho * (g.Rd * T_ref / (Rm * T) - 1.0);
+    return -g.g * rhop;
 }
 
 
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const double x = rw[n + s * sz - 3 * sz];
-        wr[s] = bz_cdiv(x, g.rho_f[kbeg + s - 3], g.rrho_f[kbeg + s - 3]);
+        wr[s] = bz_cdiv(x, LV.rho_f(kbeg + s - 3), LV.rrho_f(kbeg + s - 3));
         if (s >= 1 && s <= 4) qw[s - 1] = Az * x;   // levels kbeg-2 .. kbeg+1
         if (s == 3) raw0 = x;
         if (s == 4) raw1 = x;
@@ -926,19 +933,19 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int kk = kbeg - 2 + s;
-        qu[s] = g.Ax[kk] * ru[n + s * sz - 2 * sz];
-        qv[s] = g.Ay[kk] * rv[n + s * sz - 2 * sz];
-        qt[s] = top ? g.Ay[kk] * rv[ntop0 + s * sz - 2 * sz] : 0.0;
+        qu[s] = LV.Ax(kk) * ru[n + s * sz - 2 * sz];
+        qv[s] = LV.Ay(kk) * rv[n + s * sz - 2 * sz];
+        qt[s] = top ? LV.Ay(kk) * rv[ntop0 + s * sz - 2 * sz] : 0.0;
     }
     double fz_lo, b_lo;
     {
         const int B = bz_buffer_center(kbeg - 1, g.Nz);
         const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
         fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
-        b_lo = buoyancy5(g, pa[n - sz], dryq ? 0.0 : pb[n - sz], kbeg - 1, LV.rho(kbeg - 1), LV.rrho(kbeg - 1), LV.pi(kbeg - 1));
+        b_lo = buoyancy5(g, pa[n - sz], dryq ? 0.0 : pb[n - sz], kbeg - 1, LV.rho(kbeg - 1), LV.rrho(kbeg - 1), LV.pi(kbeg - 1), LV.T_r(kbeg - 1));
     }
     T[0][ty + 3][tc] = wr[3];
-    if (hok) T[0][hr][hc] = bz_cdiv(rw[hn], g.rho_f[kbeg], g.rrho_f[kbeg]);
+    if (hok) T[0][hr][hc] = bz_cdiv(rw[hn], LV.rho_f(kbeg), LV.rrho_f(kbeg));
     double tcur_raw = rw[n + 3 * sz];
     double u0cur = (E.mode == 2) ? E.u0[n] : 0.0;
     __syncthreads();
@@ -952,7 +959,7 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
         const double p_top = rw[n + ((k + 4 <= g.Nz + g.Hz) ? 4 * sz : 3 * sz)];
         const double Tcur = pa[n], rqcur = dryq ? 0.0 : pb[n];          // rho theta, rho q (not read where the scan found it zero): consumed mid-level (buoyancy)
         const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
-        const double Axn = g.Ax[k + 2], Ayn = g.Ay[k + 2];
+        const double Axn = LV.Ax(k + 2), Ayn = LV.Ay(k + 2);
         const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];
         const double qtn = top ? Ayn * rv[ntop0 + lev + 2 * sz] : 0.0;
         if (((k - kbeg) & 63) == 0) {
@@ -975,16 +982,16 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
             FY[buf][TY][tx] = v2 * bz_up5y<WY>(Tk[TY][tc], Tk[TY + 1][tc], Tk[TY + 2][tc], Tk[TY + 3][tc], Tk[TY + 4][tc], Tk[TY + 5][tc], v2 > 0.0,
                                                by5_face<WY>(g, j0 + TY));
         }
-        const double wnew = bz_cdiv(tcur_raw, g.rho_f[k + 3], g.rrho_f[k + 3]);
+        const double wnew = bz_cdiv(tcur_raw, LV.rho_f(k + 3), LV.rrho_f(k + 3));
         double fz_hi;
         {
             const int B = bz_buffer_center(k, g.Nz);
             const double wt = (B == 3) ? bz_symm4(qw[1], qw[2], qw[3], qwnew) : bz_symm2(qw[2], qw[3]);
             fz_hi = wt * bz_upB(wr[1], wr[2], wr[3], wr[4], wr[5], wnew, wt > 0.0, B);
         }
-        const double b_hi = buoyancy5(g, Tcur, rqcur, k, LV.rho(k), LV.rrho(k), LV.pi(k));
+        const double b_hi = buoyancy5(g, Tcur, rqcur, k, LV.rho(k), LV.rrho(k), LV.pi(k), LV.T_r(k));
         T[buf ^ 1][ty + 3][tc] = wr[4];
-        if (hok) T[buf ^ 1][hr][hc] = bz_cdiv(p_h, g.rho_f[k + 1], g.rrho_f[k + 1]);
+        if (hok) T[buf ^ 1][hr][hc] = bz_cdiv(p_h, LV.rho_f(k + 1), LV.rrho_f(k + 1));
         __syncthreads();
         {
             double nb = __shfl_down(fx, 1);
@@ -992,7 +999,7 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
             if (tx == le) nb = e;
             const double dx = nb - fx;
             const double dy = FY[buf][ty + 1][tx] - fy;
-            const double adv = -(g.Vinv_f[k] * (dx + dy + (fz_hi - fz_lo)));
+            const double adv = -(LV.Vinv_f(k) * (dx + dy + (fz_hi - fz_lo)));
             if (store)
                 L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out, adv + 0.5 * (b_lo + b_hi), raw0, n);
         }

@@ -154,3 +154,33 @@ def test_cbl_budgets_at_ci_size(bz, walls):
         assert bool(torch.isfinite(f.interior).all())
     if walls:
         assert float(m.momentum["ρv"].interior[:, 0, :].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ftype", ["f64", "f32"])
+def test_cbl_weno9_budgets_at_ci_size(bz, ftype):
+    """WENO(order = 9) — the second scheme of the reference's CI matrix — at 256 x 256 x 128, ten steps through bz_time_steps_anelastic
+    (what bench.py --workload cbl --cbl-order 9 times): scalars and x / y momentum run the single marching pass of
+    csrc/bz_tendency_generic.hip (rows of a multiple of 64 cells), the z-momentum its two passes.  Same size-independent properties as
+    above; Float32 is the precision the reference benchmarks in (sums accumulate in Float64 here, the fields are Float32)."""
+    import torch
+    from breeze_jl_amd import benchmarks as bm
+    size, dt, steps = (256, 256, 128), 0.05, 10
+    f32 = ftype == "f32"
+    m = bz.benchmarks.convective_boundary_layer(size, float_type=np.float32 if f32 else np.float64, advection=bz.WENO(order=9))
+    dz = bm.CBL["Lz"] / size[2]
+
+    def content():
+        return float(m.potential_temperature_density.interior.sum(dtype=torch.float64)) * dz / (size[0] * size[1])
+
+    c0, u_low0 = content(), float(m.velocities["u"].interior[0].double().mean())
+    m.time_steps(dt, steps)
+    m.synchronize()
+    flux = bm.cbl_surface_density() * bm.CBL["heat_flux"]
+    gained = content() - c0
+    # Float32: a stored rho theta carries 6e-8 of its ~350 kg K / m^3; the column content (~3e5) is known to ~1e-2 of the 1.9e-1 gained
+    assert abs(gained - steps * dt * flux) < (5e-2 if f32 else 2e-6) * steps * dt * flux, (gained, steps * dt * flux)
+    assert m.max_abs_divergence() < (1e-3 if f32 else 1e-10)
+    assert float(m.velocities["u"].interior[0].double().mean()) < u_low0 - 1e-4
+    for f in (m.temperature, m.velocities["w"], m.momentum["ρv"]):
+        assert bool(torch.isfinite(f.interior).all())

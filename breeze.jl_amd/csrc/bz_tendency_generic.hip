@@ -481,6 +481,20 @@ struct MarchFlux {
         const double vt = symm_g(rv, m, sz, Bf, -h, g.Ay, k, 0.0);
         return vt * biased_face_g(a + m, sy, vt > 0.0, R);
     }
+    // z-face kf, in two halves (KIND 0, 1, 2): the advecting factor at the face (m = index of the cell above it) and the flux from it and
+    // the reconstructed value — Z(m, kf) == Zfin(Zmass(m), biased_face_g(a + m, sz, Zmass(m) > 0, buf_face(kf)), kf), which the marching
+    // kernel evaluates with the z stencil in a register ring
+    __device__ __forceinline__ double Zmass(long long m) const
+    {
+        if (KIND == 0) return rw[m];
+        if (KIND == 1) return symm_g(rw, m, 1, R, -(R - 1), none, 0, g.Az);
+        return symm_g(rw, m, sy, R, -(R - 1), none, 0, g.Az);
+    }
+    __device__ __forceinline__ double Zfin(double wt, double rec, int kf) const
+    {
+        if (KIND == 0) return g.rho_f[kf] * ((g.Az * wt) * rec);
+        return wt * rec;
+    }
     // z-face kf (KIND 0, 1, 2) / z-centre kf (KIND 3)
     __device__ __forceinline__ double Z(long long m, int kf) const
     {
@@ -492,6 +506,23 @@ struct MarchFlux {
         return wt * biased_center_g(a + m, sz, wt > 0.0, B);
     }
 };
+
+// upwind-biased value at a z face from the ring zr[0 .. 2R-1] = levels kf-R .. kf+R-1 around face kf (biased_face_g(p, sz, left, B) with
+// p[(j - R) sz] = zr[j]): buffer B of the wall cascade picks the central 2 B entries
+template <int R>
+__device__ __forceinline__ double ring_face_g(const double (&zr)[2 * R], bool left, int B)
+{
+    if (B == R) return weno_wide_g<R>(zr, left);
+    if (R == 5 && B == 4) {
+        double q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = zr[j + (R - 4)];
+        return weno_wide_g<4>(q, left);
+    }
+    if (B == 3) return bz_up5(zr[R - 3], zr[R - 2], zr[R - 1], zr[R], zr[R + 1], zr[R + 2], left);
+    if (B == 2) return bz_up3(zr[R - 2], zr[R - 1], zr[R], zr[R + 1], left);
+    return bz_sel(bz_lanes(left), zr[R - 1], zr[R]);
+}
 
 // a - b that is never contracted with a product feeding it: the two-pass path rounds every flux when it stores it, so the differences
 // below must see rounded products too (hipcc's default -ffp-contract=fast-honor-pragmas would turn nb - ut * r into an fma)
@@ -535,6 +566,16 @@ __global__ __launch_bounds__(64 * MTY, MARCH_WAVES) void k_tendency_m(DevGrid g,
     const int yown = ty + (YC ? 1 : 0), yext = YC ? 0 : MTY;
     // z: flux of the lower face (centre below for KIND 3) of the first level
     double zlo = ZC ? Fl.Z(n - sz, kbeg - 1) : Fl.Z(n, kbeg);
+    // z stencil of the advected field around the upper face of the current level, in registers (KIND 0, 1, 2): one load per level
+    // instead of 2 R (the stencil loads are what the L1 path of a CU spends its cycles on: 58 four-byte requests per cell and level in
+    // the x-momentum kernel, 64 bytes per clock)
+    double zr[2 * R];
+    const int ktop = g.Nz + g.Hz - 1;                         // last level a parent array holds
+    auto lev = [&](int kk) { return (long long)(max(min(kk, ktop), -g.Hz) - kbeg) * sz; };      // offset of level kk from n at chunk start, clamped to the array
+    if (!ZC) {
+#pragma unroll
+        for (int q = 0; q < 2 * R; ++q) zr[q] = a[n + lev(kbeg + 1 - R + q)];
+    }
     int buf = 0;
     for (int k = kbeg; k < kend; k += MTY, n += MTY * sz) {
         const int nl = min(MTY, kend - k);
@@ -553,7 +594,17 @@ __global__ __launch_bounds__(64 * MTY, MARCH_WAVES) void k_tendency_m(DevGrid g,
                 FY[buf][l][rep ? yext : yown][tx] = Fl.Y(rep ? nx0 + (long long)(kl - kbeg) * sz : m, kl);
             double zhi;
             if (ZC) zhi = Fl.Z(m, kl);
-            else zhi = (kl + 1 >= g.Nz) ? 0.0 : Fl.Z(m + sz, kl + 1);
+            else {
+                if (kl + 1 >= g.Nz) zhi = 0.0;
+                else {
+                    const double wt = Fl.Zmass(m + sz);
+                    zhi = Fl.Zfin(wt, ring_face_g<R>(zr, wt > 0.0, buf_face<R>(kl + 1, g.Nz)), kl + 1);
+                }
+                const double znew = a[m + (long long)(min(kl + 1 + R, ktop) - kl) * sz];      // level kl + 1 + R: top of the next face's ring
+#pragma unroll
+                for (int q = 0; q < 2 * R - 1; ++q) zr[q] = zr[q + 1];
+                zr[2 * R - 1] = znew;
+            }
             AZ[l][ty][tx] = bz_sub_rounded(zhi, zlo);
             zlo = zhi;
         }

@@ -187,6 +187,43 @@ def test_slow_tendencies_match_oracle(oracle, oc, bz, stretched):
         assert rel(a, b) <= 1e-12, (n, rel(a, b))
 
 
+@pytest.mark.parametrize("size", [(64, 8, 20), (128, 8, 70)])
+def test_slow_tendencies_on_rows_of_64_cells_take_the_exchange_kernel(oracle, oc, bz, size, monkeypatch):
+    """Rows of a multiple of 64 cells with Ny a multiple of 4: the rho theta (+ rho_d) and moisture tendencies run
+    k_scalar_tendency_rho3d_x (csrc/bz_compressible.hip: every face flux evaluated once, exchanged by lane shuffle / LDS rows in groups of
+    four levels, short level chunks on small grids) — against the oracle at the tolerance of the test above, and against the kernel it
+    replaces (BZ_NO_RHO3D_EXCHANGE=1; an ulp of a flux apart).  128 x 8 x 70: two tiles in x, two tile rows (outside rows across the
+    periodic boundary), level chunks of 8 with partial groups."""
+    zf = 8e3 * (0.6 * np.linspace(0, 1, size[2] + 1) + 0.4 * np.linspace(0, 1, size[2] + 1) ** 2)
+    got = {}
+    for exchange in (True, False):
+        if exchange:
+            monkeypatch.delenv("BZ_NO_RHO3D_EXCHANGE", raising=False)
+        else:
+            monkeypatch.setenv("BZ_NO_RHO3D_EXCHANGE", "1")
+        om, hm = make_pair(oracle, oc, bz, size=size, z_faces=zf)
+        seeded_state(om, 5)
+        om.update_state(compute_tendencies=True)          # the moisture tendency (total-density carrier, time-averaged velocities)
+        om.compute_slow_tendencies()
+        push(om, hm)
+        for k in hm.G:
+            hm.G[k].parent.zero_()
+        bz.compressible.update_state_(hm, compute_tendencies=True)          # the same kernel with the averaged velocities in the velocity slots
+        bz.compressible.compute_slow_tendencies_(hm)
+        got[exchange] = {k: hm.G[k].interior_cpu().copy() for k in hm.G}
+    g = om.grid
+    for n, k in PROG.items():
+        b = g.interior(om.G[n], n == "rw")
+        for exchange in (True, False):
+            a = got[exchange][k]
+            if n == "rw":
+                assert rel(a[1:-1], b[1:-1]) <= 1e-12, (n, exchange)
+            else:
+                assert rel(a, b) <= 1e-12, (n, exchange, rel(a, b))
+        assert rel(got[True][k], got[False][k]) <= 1e-13, n
+    assert np.abs(got[True]["ρθ"]).max() > 0 and np.abs(got[True]["ρq"]).max() > 0
+
+
 CASES = [
     dict(substeps=6),                                            # default damping, N_tau = 2, 3, 6
     dict(substeps=6, damping_coefficient=None, forward_weight=0.55),
@@ -273,6 +310,28 @@ def test_time_steps_match_oracle(oracle, oc, bz, td):
     for n, k in (("au", "time_averaged_u"), ("av", "time_averaged_v"), ("aw", "time_averaged_w")):
         err = np.abs(getattr(sub, k).interior_cpu() - g.interior(getattr(om, n), n == "aw")).max() / scale
         assert err <= 5e-9, (n, err)
+
+
+def test_time_steps_on_rows_of_64_cells_match_oracle(oracle, oc, bz):
+    """the three-step case above on 64 x 8 x 24: the scalar tendencies of every stage run the exchange kernel (k_scalar_tendency_rho3d_x);
+    dt = 0.5 s: the 64-cell rows are 125 m wide, a quarter of the cells above"""
+    om, hm = make_pair(oracle, oc, bz, size=(64, 8, 24), substeps=6)
+    g = om.grid
+
+    def theta(x, y, z):
+        r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+        return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+    def qv(x, y, z):
+        return 5e-3 * np.exp(-z / 2e3) * (1 + 0.2 * np.sin(2 * np.pi * x / 8e3)) + 0 * y
+
+    rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+    om.set(rho=rho, theta=theta, u=lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z, v=0.0, w=0.0, qv=qv)
+    hm.set(ρ=rho, θ=theta, u=lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z, v=0.0, w=0.0, qᵗ=qv)
+    for _ in range(3):
+        om.time_step(0.5)
+        hm.time_step(0.5)
+    cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rv", "rw", "u", "v", "w", "theta", "q", "T", "p"), 5e-9)
 
 
 def test_whole_step_matches_operator_sequence(oracle, oc, bz):

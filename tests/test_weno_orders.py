@@ -182,10 +182,12 @@ def test_single_pass_marching_steps_equal_two_pass_steps(bz, order, monkeypatch)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("order", [5, 7, 9])
-def test_single_scalar_tendency_entry_matches_oracle(oracle, bz, order):
+@pytest.mark.parametrize("size", [(24, 16, 14), (64, 8, 14)])
+def test_single_scalar_tendency_entry_matches_oracle(oracle, bz, order, size):
     """bz_compute_scalar_tendency — the launch of compute_scalar_tendency! for one field, what the reference's scalar_tendency
-    micro-benchmark times (benchmarking/src/scalar_tendency.jl:16-25) — against the oracle's -div_rhoUc(theta)."""
-    om, hm = _pair(oracle, bz, (24, 16, 14), order)
+    micro-benchmark times (benchmarking/src/scalar_tendency.jl:16-25) — against the oracle's -div_rhoUc(theta).  Rows of 64 cells:
+    orders 7 / 9 take the marching kernel (the micro-benchmark's 256-cell rows do)."""
+    om, hm = _pair(oracle, bz, size, order)
     randomize(om, seed=5)
     om.compute_tendencies()
     push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq", "u", "v", "w", "theta", "q", "T"))

@@ -260,6 +260,7 @@ extern "C" int bz_compute_closure_fields(bz_ctx *ctx, const bz_state *s)
 {
     if (!ctx || !s) return BZ_ERR_INVALID;
     if (!ctx->has_closure) return BZ_OK;
+    { const int rcs = bzi_refresh_diagnostics(ctx, s, "bz_compute_closure_fields"); if (rcs) return rcs; }
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "smagorinsky_viscosity");
     const double *qv = (g.microphysics == 1) ? g.qv_field : s->q;      // specific_humidity(model)

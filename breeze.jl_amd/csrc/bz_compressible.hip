@@ -1264,6 +1264,7 @@ extern "C" int bz_compressible_update_state(bz_ctx *ctx, const bz_compressible_s
     if (compute_tendencies && (!valid_prog(G) || !valid_sub(sub))) return BZ_ERR_INVALID;
     if (!ctx->fused_ok) { ctx->last_error = "compressible path needs Nx >= 2Hx and Ny >= 2Hy"; return BZ_ERR_UNSUPPORTED; }
     if (ctx->d_qstate) BZ_HIP(hipMemsetAsync(ctx->d_qstate, 0, sizeof(int), ctx->stream));      // moisture scan: unknown again (set! ends here)
+    bzi_moisture_unknown(ctx);
     return bzi_compressible_update_state(ctx, s, G, sub, compute_tendencies != 0, false);
 }
 

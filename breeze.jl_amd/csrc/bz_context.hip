@@ -169,6 +169,8 @@ extern "C" int bz_set_saturation_adjustment(bz_ctx *ctx, const bz_saturation_adj
 extern "C" int bz_sync(bz_ctx *ctx)
 {
     if (!ctx) return BZ_ERR_INVALID;
+    // an undiagnosed last stage leaves its halo exchange on the side stream: a host that reads `s` after bz_sync must see it landed
+    if (ctx->comm) { const int rc = bzi_comm_join_pending(ctx); if (rc) return rc; }
     BZ_HIP(hipStreamSynchronize(ctx->stream));
     return BZ_OK;
 }
@@ -259,7 +261,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     }
 
     // ---- column tables: 11 columns of nf entries each ----
-    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_RDZC, C_ZC, C_RRHO, C_RRHOF, C_COUNT };
+    enum { C_DZC, C_DZF, C_RDZF, C_AX, C_AY, C_VIC, C_VIF, C_RHO, C_RHOF, C_PR, C_TR, C_RDZC, C_ZC, C_RRHO, C_RRHOF, C_LNPI, C_COUNT };
     std::vector<double> cols((size_t)C_COUNT * nf, 0.0);
     auto col = [&](int c) { return cols.data() + (size_t)c * nf; };
     const double dx = grid->dx, dy = grid->dy;
@@ -274,6 +276,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
         col(C_RRHO)[k] = 1.0 / ref->density[k];
         col(C_PR)[k] = ref->pressure[k];
         col(C_TR)[k] = ref->temperature[k];
+        col(C_LNPI)[k] = std::log(ref->pressure[k] / ref->standard_pressure);
     }
     for (int k = 0; k < nf; ++k) {
         col(C_DZF)[k] = dzf[k];
@@ -317,11 +320,14 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     g.rho = dcol(C_RHO); g.rho_f = dcol(C_RHOF);
     g.rrho = dcol(C_RRHO); g.rrho_f = dcol(C_RRHOF);
     g.p_r = dcol(C_PR); g.T_r = dcol(C_TR);
+    g.lnpi = dcol(C_LNPI);
+    g.pi_dry = ColPtr(nullptr);      // set by bzi_lean_setup (anelastic contexts)
     g.g = constants->gravitational_acceleration;
     g.Rd = constants->dry_air_gas_constant;
     g.Rv = constants->vapor_gas_constant;
     g.cpd = constants->dry_air_heat_capacity;
     g.cpv = constants->vapor_heat_capacity;
+    g.kap_num = g.Rv * g.cpd - g.Rd * g.cpv;
     g.pst = ref->standard_pressure;
     g.wrap_y = (slab_mode || bounded_y) ? 0 : 1;
     g.flat_y = flat_y ? 1 : 0;

@@ -427,6 +427,7 @@ extern "C" int bz_compute_forcings(bz_ctx *ctx, const bz_state *s)
 {
     if (!ctx || !s) return BZ_ERR_INVALID;
     if (!ctx->has_forcings || !ctx->forcing_subsidence_mask) return BZ_OK;
+    { const int rcs = bzi_refresh_diagnostics(ctx, s, "bz_compute_forcings"); if (rcs) return rcs; }
     const DevGrid &g = ctx->dg;
     const int Nz = g.Nz;
     ProfileScope ps(ctx, "subsidence_averages");
@@ -488,6 +489,7 @@ bool bzi_lean_forcings_ok(const bz_ctx *ctx)
 extern "C" int bz_compute_flux_bc_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
     if (!ctx || !s || !G) return BZ_ERR_INVALID;
+    { const int rcs = bzi_refresh_diagnostics(ctx, s, "bz_compute_flux_bc_tendencies"); if (rcs) return rcs; }
     if (ctx->G_is_predictor) {      // a fused whole step left predictor momentum in G: the fluxes must land on tendencies
         int rc = bz_compute_tendencies(ctx, s, G);
         if (rc) return rc;

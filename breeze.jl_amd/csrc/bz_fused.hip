@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
         qr = g.rqr_field[n] / rc;
         qvv = q;
     } else if (SA == 1) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
-    else T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : pow(g.p_r[k] / g.pst, Rm / cpm) * th;
+    else T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : bz_exner_factor(g, k, q, cpm) * th;
 
     if (F.store_phi) st_img(F.phi, n, p, ox, oy);
     st_img(F.ru, n, ru, ox, oy);

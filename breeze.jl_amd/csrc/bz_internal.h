@@ -43,6 +43,8 @@ struct DevGrid {
     ColPtr rho, rho_f;                   // rho_r at centres;  0.5*(rho[k-1]+rho[k]) at faces
     ColPtr rrho, rrho_f;                 // their correctly rounded reciprocals (host 1.0/x), for bz_cdiv
     ColPtr p_r, T_r;
+    ColPtr pi_dry, lnpi;                 // dry Exner factor (p_r[k]/p_st)^(Rd/cpd) (device pow, bz_tendency5.hip: k_pi_dry) and ln(p_r[k]/p_st): bz_exner_factor
+    double kap_num;                      // Rv cpd - Rd cpv
     double g, Rd, Rv, cpd, cpv, pst;
     int formulation;       // 0: liquid-ice potential temperature (theta), 1: static energy (e) in the `theta` slots
     // microphysics = SaturationAdjustment(equilibrium = WarmPhaseEquilibrium()) (bz_set_saturation_adjustment)
@@ -108,6 +110,49 @@ __device__ __forceinline__ double bz_rk_apply_pre(int mode, double dt, double al
 #endif
 
 #ifdef __HIPCC__
+// Exner factor Pi^(Rm / cpm) of a moist cell in the anelastic model, Pi = p_r[k] / p_st (T = Pi^(Rm/cpm) theta,
+// /root/reference/src/Thermodynamics/dynamic_states.jl:31-58).  The base is a COLUMN constant and only the exponent varies with the
+// cell, so pow() — ~150 FP64 instructions of extended-precision log + exp, which round 4 parked behind a call in the z-momentum kernel
+// (2.0 -> 2.8 ms per launch at 512^3 as soon as a wavefront held vapour) — is one exp() of a small argument:
+//     Pi^(Rm/cpm) = Pi^kappa_d exp((Rm/cpm - kappa_d) ln Pi),   Rm/cpm - kappa_d = q (Rv cpd - Rd cpv) / (cpm cpd)   (exact algebra, no cancellation)
+// with Pi^kappa_d and ln Pi tabulated per level.  q = 0 gives exp(0) = 1: the dry table entry, bit for bit, so dry and moist cells of one
+// field are continuous and the wave-uniform dry branch of the lean kernels is an optimisation, not a different formula.  |argument| <
+// 0.07 q |ln Pi|: a few 1e-3, so the result is within ~1.5 ulp of pow() (the oracle's form) — tests/test_gpu_parity.py holds T to 1e-14.
+// Every kernel of the theta formulation that derives T without microphysics uses this one function (k_thermo, k_project_diagnose<0>,
+// the lean z-momentum kernel), so stored and derived temperatures carry the same bits.
+// exp(a) of a small argument: the degree-9 Taylor polynomial in Horner form on |a| <= 1/16 (truncation a^10 / 10! < 3e-19: nine FMAs,
+// no extra registers — inlined, the library exp() pushed the z-momentum kernel past its 128 registers, and behind a call it cost spills
+// around the call).  For atmospheric q and pressures |a| ~ 0.07 q |ln Pi| is a few 1e-3.  Larger arguments (q -> 1 at stratospheric
+// pressures: unphysical, but the function must not be wrong there) are halved wave-uniformly until they fit and the result is squared
+// back: exp(a) = exp(a / 2^s)^(2^s), each squaring doubling the relative error (s <= 5 for |a| <= 2).
+// a Float64 literal as a scalar-register pair materialised where it is used: without it the compiler hoists the nine coefficients below
+// out of the level loop of the z-momentum kernel into eighteen VGPRs, which that kernel (128 of 128) pays for with scratch spills
+__device__ __forceinline__ double bz_sconst(double c)
+{
+    asm volatile("" : "+s"(c));
+    return c;
+}
+__device__ __forceinline__ double bz_exp_small(double a)
+{
+    int s = 0;
+    while (!__all(fabs(a) <= 0.0625) && s < 40) { a *= 0.5; ++s; }
+    double p = bz_sconst(1.0 / 362880.0);
+    p = fma(p, a, bz_sconst(1.0 / 40320.0));
+    p = fma(p, a, bz_sconst(1.0 / 5040.0));
+    p = fma(p, a, bz_sconst(1.0 / 720.0));
+    p = fma(p, a, bz_sconst(1.0 / 120.0));
+    p = fma(p, a, bz_sconst(1.0 / 24.0));
+    p = fma(p, a, bz_sconst(1.0 / 6.0));
+    p = fma(p, a, 0.5);
+    p = fma(p, a, 1.0);
+    p = fma(p, a, 1.0);
+    for (; s > 0; --s) p *= p;
+    return p;
+}
+__device__ __forceinline__ double bz_exner_factor(const DevGrid &g, int k, double q, double cpm)
+{
+    return g.pi_dry[k] * bz_exp_small(((q * g.kap_num) / (cpm * g.cpd)) * g.lnpi[k]);
+}
 // ---- moist thermodynamics shared by the diagnosis and buoyancy kernels -----------------------------------------------
 // anelastic buoyancy -g rho' with rho' = rho_r (R_m,r T_r / (R_m T) - 1)  (anelastic_buoyancy.jl:36-72); the moisture
 // fractions come from grid_moisture_fractions: (q, 0) without microphysics, (q^v, q^l) fields with saturation adjustment.
@@ -333,6 +378,13 @@ struct bz_ctx {
     bool fuse_rk = true;              // whole-step seam: RK update folded into the tendency kernels (BZ_NO_FUSE_RK=1 disables)
     bool G_is_predictor = false;      // after a fused step the G arrays hold predictor momentum, not tendencies
     bool fused_ok = true;             // Nx >= 2Hx && Ny >= 2Hy: fused halo-image stores are valid
+    // host view of the scan's verdict (round 5): 0 unknown (after bz_update_state: the next scan is read back synchronously, once), 1 dry at
+    // the last scan (a dry model is scanned at every call; its verdict travels back asynchronously), 2 moist (sticky, like the device word:
+    // no more scans, and only the general kernels are launched).  Lets the dry and the general tendency bodies be separate KERNELS.
+    int q_host = 0;
+    int *h_qstate = nullptr;          // pinned
+    hipEvent_t ev_q = nullptr;
+    bool q_pending = false;
     int *d_qstate = nullptr;          // moisture scan of the lean seam (bz_step.hip: bzi_scan_moisture): 2 = rho q has a non-zero element (sticky until
                                       // update_state!), anything else after a scan = identically zero; the lean kernels then skip every access to it
     bool diagnostics_stale = false;   // u, v, w, theta, q, T, phi of `s` are older than the prognostic state (bz_time_steps_anelastic without the last diagnosis)
@@ -404,7 +456,7 @@ struct bz_ctx {
         int seen = 0;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        bool g_is_predictor = false;
+        bool g_is_predictor = false, lean_step_last = false;      // host-side bookkeeping the recorded body leaves (restored on replay)
     } graph_slots[2];
     int graph_next = 0;
     hipStream_t graph_stream = nullptr, graph_user_stream = nullptr;      // recording stream (the legacy default stream cannot be captured)
@@ -495,10 +547,15 @@ int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G,
 int bzi_lean_setup(bz_ctx *ctx);
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose = true);
 int bzi_comm_join_pending(bz_ctx *ctx);
+// entry points that read the stored diagnostics (u, v, w, theta, q, T): after bz_time_steps_anelastic(..., diagnose_last = 0) they are older
+// than the prognostic state.  With the state at hand they are rebuilt first (bz_update_state, on slab contexts with its halo exchange);
+// without it (s == nullptr) the call fails with BZ_ERR_INVALID and a message instead of answering from stale fields
+int bzi_refresh_diagnostics(bz_ctx *ctx, const bz_state *s, const char *who);
 void bzi_lean_step_done(bz_ctx *ctx, bool diagnosed);
 int bzi_scan_moisture(bz_ctx *ctx, const bz_state *s);
 int bzi_scan_moisture_field(bz_ctx *ctx, const double *rho_q);
 const int *bzi_moisture_state(const bz_ctx *ctx);
+void bzi_moisture_unknown(bz_ctx *ctx);      // bz_update_state / bz_compressible_update_state: the field may have been set!
 struct LeanStage;
 void bzi_lean_stage(const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, int stage, LeanStage *L);
 int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,

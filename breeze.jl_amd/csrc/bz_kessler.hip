@@ -285,5 +285,6 @@ extern "C" int bz_kessler_model_update(bz_ctx *ctx, const bz_state *s, const bz_
 {
     if (!ctx || !s || !G) return BZ_ERR_INVALID;
     if (ctx->dg.microphysics != 2) { ctx->last_error = "bz_kessler_model_update: no Kessler microphysics attached"; return BZ_ERR_INVALID; }
+    { const int rcs = bzi_refresh_diagnostics(ctx, s, "bz_kessler_model_update"); if (rcs) return rcs; }
     return bzi_kessler_update(ctx, s, G, dt);
 }

@@ -61,8 +61,7 @@ __global__ __launch_bounds__(TX *TY) void k_thermo(DevGrid g, double *__restrict
         g.ql_field[n] = qll;
         return;
     }
-    double Pi = pow(g.p_r[k] / g.pst, Rm / cpm);
-    T[n] = Pi * th;
+    T[n] = bz_exner_factor(g, k, q, cpm) * th;
 }
 
 struct RKFields {
@@ -271,6 +270,7 @@ __global__ __launch_bounds__(TX *TY) void k_max_inverse_advection_timescale(DevG
 extern "C" int bz_cell_advection_timescale(bz_ctx *ctx, const double *u, const double *v, const double *w, double *out)
 {
     if (!ctx || !u || !v || !out) return BZ_ERR_INVALID;
+    { const int rcs = bzi_refresh_diagnostics(ctx, nullptr, "bz_cell_advection_timescale"); if (rcs) return rcs; }      // the velocities are diagnostics
     const DevGrid &g = ctx->dg;
     BZ_HIP(hipMemsetAsync(ctx->d_scalar, 0, sizeof(double), ctx->stream));
     hipLaunchKernelGGL(k_max_inverse_advection_timescale, cell_grid(g, g.Nz), dim3(TX, TY), 0, ctx->stream, g, u, v,

@@ -13,6 +13,7 @@ extern "C" int bz_update_state(bz_ctx *ctx, const bz_state *s, const bz_prognost
     if (ctx->comm && (rc = bzi_comm_join_pending(ctx))) return rc;      // an undiagnosed last stage leaves its halo exchange on the side stream
     ctx->diagnostics_stale = false;
     if (ctx->d_qstate) BZ_HIP(hipMemsetAsync(ctx->d_qstate, 0, sizeof(int), ctx->stream));      // the moisture may have been set!: unknown (= moist) until the next scan
+    bzi_moisture_unknown(ctx);
     // fill_halo_regions!(prognostic_fields(model))  (:48) — momentum halos are filled inside
     // bz_compute_velocities (:135-136), the scalars here.
     double *sf[4] = {s->rho_theta, s->rho_q, ctx->dg.rqcl_field, ctx->dg.rqr_field};
@@ -80,11 +81,21 @@ __global__ void k_scan_moisture_close(int *__restrict__ state)
     if (state[0] != 2) state[0] = state[1] ? 2 : 1;
     state[1] = 0;
 }
+// y-slab contexts: the verdict must be the DOMAIN's, not the slab's (a rank whose slab is dry while its neighbour's is not would drop
+// the moisture that arrives through its halo rows for the rest of the call): every rank contributes "found" (0 / 1, also a
+// rank that already knows it is moist) to a sum over the communicator and closes the scan on the sum
+__global__ void k_scan_moisture_flag(const int *__restrict__ state, double *__restrict__ flag) { flag[0] = (state[0] == 2 || state[1]) ? 1.0 : 0.0; }
+__global__ void k_scan_moisture_close_global(int *__restrict__ state, const double *__restrict__ flag)
+{
+    state[0] = flag[0] != 0.0 ? 2 : 1;
+    state[1] = 0;
+}
 
 static bool moisture_sources(const bz_ctx *ctx)
 {
     return ctx->tune.no_dry_shortcut || ctx->dg.microphysics != 0 || ctx->has_bulk || ctx->has_relaxation || ctx->field_forcing != nullptr ||
-           (ctx->has_forcings && (ctx->forcing_flux_q != 0.0 || (ctx->forcing_static_mask & 8) || (ctx->forcing_subsidence_mask & 8)));
+           (ctx->has_forcings && (ctx->forcing_flux_q != 0.0 || (ctx->forcing_static_mask & 8) || (ctx->forcing_subsidence_mask & 8))) ||
+           (ctx->slab_mode && !ctx->comm);      // slabs driven from the host: the library cannot ask the other ranks, so nothing is skipped
 }
 
 // the word the lean kernels read (nullptr: no shortcut on this context)
@@ -92,20 +103,62 @@ const int *bzi_moisture_state(const bz_ctx *ctx) { return (ctx->d_qstate && !moi
 
 int bzi_scan_moisture(bz_ctx *ctx, const bz_state *s) { return ctx->compressible ? BZ_OK : bzi_scan_moisture_field(ctx, s->rho_q); }
 
+void bzi_moisture_unknown(bz_ctx *ctx) { ctx->q_host = 0; ctx->q_pending = false; }
+
 int bzi_scan_moisture_field(bz_ctx *ctx, const double *rho_q)
 {
     if (moisture_sources(ctx)) return BZ_OK;
     const DevGrid &g = ctx->dg;
+    int rc;
     if (!ctx->d_qstate) {
-        BZ_HIP(hipMalloc(&ctx->d_qstate, 2 * sizeof(int)));
-        BZ_HIP(hipMemsetAsync(ctx->d_qstate, 0, 2 * sizeof(int), ctx->stream));
+        BZ_HIP(hipMalloc(&ctx->d_qstate, 2 * sizeof(int) + 2 * sizeof(double)));      // [state, found] + the flag of the slab all-reduce
+        BZ_HIP(hipMemsetAsync(ctx->d_qstate, 0, 2 * sizeof(int) + 2 * sizeof(double), ctx->stream));
+        BZ_HIP(hipHostMalloc(&ctx->h_qstate, sizeof(int)));
+        BZ_HIP(hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming));
+        ctx->q_host = 0;
     }
+    // the verdict of the previous call's scan, if it has landed (asynchronous copy, never waited for)
+    if (ctx->q_pending && hipEventQuery(ctx->ev_q) == hipSuccess) { ctx->q_host = *ctx->h_qstate; ctx->q_pending = false; }
+    if (ctx->q_host == 2) return BZ_OK;      // moist is sticky on the device (until bz_update_state) and on every rank of a slab communicator alike: nothing to scan
+    // an undiagnosed last stage leaves the halo exchange of rho q on the side stream: the scan reads those rows
+    if (ctx->comm && (rc = bzi_comm_join_pending(ctx))) return rc;
     const long long n = (long long)g.Sxy * (g.Nz + 2 * g.Hz);
+    {
     ProfileScope ps(ctx, "moisture_scan");
     hipLaunchKernelGGL(k_scan_moisture, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, rho_q, n, ctx->d_qstate);
-    hipLaunchKernelGGL(k_scan_moisture_close, dim3(1), dim3(1), 0, ctx->stream, ctx->d_qstate);
+    if (ctx->comm) {
+        double *flag = (double *)(ctx->d_qstate + 2);
+        hipLaunchKernelGGL(k_scan_moisture_flag, dim3(1), dim3(1), 0, ctx->stream, ctx->d_qstate, flag);
+        BZ_LAUNCH_CHECK();
+        if ((rc = bzi_comm_allreduce_sum(ctx, flag, 1))) return rc;      // a collective: every rank of the communicator scans at every call
+        hipLaunchKernelGGL(k_scan_moisture_close_global, dim3(1), dim3(1), 0, ctx->stream, ctx->d_qstate, flag);
+    } else
+        hipLaunchKernelGGL(k_scan_moisture_close, dim3(1), dim3(1), 0, ctx->stream, ctx->d_qstate);
     BZ_LAUNCH_CHECK();
+    }
+    if (ctx->graph_capturing) return BZ_OK;      // (never: the scan precedes the recorded region)
+    BZ_HIP(hipMemcpyAsync(ctx->h_qstate, ctx->d_qstate, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->q_host == 0) {
+        // first scan since update_state!: read the verdict back before the first tendency launch — one host wait per set! / first step —
+        // so that from here on the host launches the body that applies (separate kernels, separate rocprofv3 rows)
+        BZ_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->q_host = *ctx->h_qstate;
+        ctx->q_pending = false;
+    } else {
+        BZ_HIP(hipEventRecord(ctx->ev_q, ctx->stream));
+        ctx->q_pending = true;
+    }
     return BZ_OK;
+}
+
+// the lean whole-step seam applies: dry / vapour WENO5 theta model without closure, bulk fluxes, relaxation, tracers, microphysics
+// (walls in y ((Periodic, Bounded, Bounded)) ride it too: WY kernels, wall rows in the projection kernels)
+static bool anelastic_lean_tier(const bz_ctx *ctx)
+{
+    const bool walls_lean = ctx->dg.bounded_y && ctx->walls_lean_ok;
+    return (ctx->fused_ok || walls_lean) && ctx->fuse_rk && ctx->lean && ctx->weno_R == 3 && ctx->scalar_R == 3 && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
+        (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && !ctx->has_relaxation && ctx->n_tracers == 0 && !ctx->bounded_mask &&
+        (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32);
 }
 
 static int one_anelastic_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose)
@@ -116,8 +169,12 @@ static int one_anelastic_step(bz_ctx *ctx, const bz_state *s, const bz_prognosti
                           "or a host-side distributed driver";
         return BZ_ERR_UNSUPPORTED;
     }
+    // the tiers other than the lean seam start from the stored diagnostics: if undiagnosed lean steps came before (the configuration
+    // changed in between), rebuild them — here, outside the region a graph records (a rebuild baked into a recorded step would run, and
+    // reset the moisture scan's word, on every replay)
+    if (ctx->diagnostics_stale && !anelastic_lean_tier(ctx)) { const int rcs = bz_update_state(ctx, s, G, 0); if (rcs) return rcs; }
     // launch-bound grids replay the recorded step (bz_graph.hip); a failed recording has executed nothing and falls through
-    const int kind = 1 + (diagnose ? 0 : 16);
+    const int kind = 1 + (diagnose ? 0 : 16) + 32 * ctx->q_host;      // (the host's view of the moisture scan selects the kernels a recording holds)
     const uint64_t key = bzi_graph_key(ctx, kind, dt, s, sizeof(*s), U0, sizeof(*U0), G, sizeof(*G), nullptr, 0);
     bool capture = false;
     int rc;
@@ -160,6 +217,17 @@ extern "C" int bz_time_steps_anelastic(bz_ctx *ctx, const bz_state *s, const bz_
     return BZ_OK;
 }
 
+int bzi_refresh_diagnostics(bz_ctx *ctx, const bz_state *s, const char *who)
+{
+    if (!ctx->diagnostics_stale) return BZ_OK;
+    if (!s) {
+        ctx->last_error = std::string(who) + ": the diagnostics are stale (bz_time_steps_anelastic ended without the last diagnosis); call bz_update_state first";
+        return BZ_ERR_INVALID;
+    }
+    if (ctx->comm) return bz_comm_update_state_and_project(ctx, s, nullptr, 1.0, 0);
+    return bz_update_state(ctx, s, nullptr, 0);
+}
+
 extern "C" int bz_diagnostics_stale(const bz_ctx *ctx) { return ctx ? (ctx->diagnostics_stale ? 1 : 0) : BZ_ERR_INVALID; }
 
 static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose)
@@ -170,11 +238,8 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
     // walls in y ((Periodic, Bounded, Bounded)) ride the lean seam too (WY kernels, wall rows in the projection kernels); every other
     // configuration with walls steps operator by operator
     const bool walls_lean = ctx->dg.bounded_y && ctx->walls_lean_ok;
-    const bool lean_tier = (ctx->fused_ok || walls_lean) && ctx->fuse_rk && ctx->lean && ctx->weno_R == 3 && ctx->scalar_R == 3 && !ctx->compressible && ctx->dg.formulation == 0 && ctx->dg.microphysics == 0 &&
-        (!ctx->has_forcings || bzi_lean_forcings_ok(ctx)) && !ctx->has_bulk && !ctx->has_closure && !ctx->has_relaxation && ctx->n_tracers == 0 && !ctx->bounded_mask &&
-        (long long)ctx->dg.Sxy * (ctx->dg.Nz + 2 * ctx->dg.Hz + 1) < (1LL << 32);
-    // the other tiers start from the stored diagnostics: if undiagnosed lean steps came before (the configuration changed in between), rebuild them
-    if (!lean_tier && ctx->diagnostics_stale && (rc = bz_update_state(ctx, s, G, 0))) return rc;
+    const bool lean_tier = anelastic_lean_tier(ctx);
+    // (the other tiers start from the stored diagnostics: one_anelastic_step rebuilt them if undiagnosed lean steps came before)
     if (lean_tier) {
         // Lean seam (bz_tendency5_kernels.h): the tendency kernels read the prognostic fields only and derive u, v, w, theta,
         // q^v, T on the fly (bit-identical to the stored diagnostics), rho theta / rho q ping-pong between their own arrays

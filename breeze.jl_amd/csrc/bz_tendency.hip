@@ -439,6 +439,7 @@ extern "C" int bz_set_scalar_advection_order(bz_ctx *ctx, int order)
 extern "C" int bz_compute_tendencies(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G)
 {
     if (!ctx || !s || !G) return BZ_ERR_INVALID;
+    { const int rcs = bzi_refresh_diagnostics(ctx, s, "bz_compute_tendencies"); if (rcs) return rcs; }
     ctx->G_is_predictor = false;
     const DevGrid &g = ctx->dg;
     dim3 block(64, TYB);

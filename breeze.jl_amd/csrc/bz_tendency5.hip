@@ -36,6 +36,7 @@ int bzi_lean_setup(bz_ctx *ctx)
     const int n = g.Nz + 2 * g.Hz;
     BZ_HIP(hipMalloc(&ctx->d_pi_dry, n * sizeof(double)));
     hipLaunchKernelGGL(k_pi_dry, dim3((n + 63) / 64), dim3(64), 0, 0, g, ctx->d_pi_dry, n);
+    ctx->dg.pi_dry = ColPtr(ctx->d_pi_dry + g.Hz);      // bz_exner_factor (bz_internal.h) of every later launch
     BZ_HIP(hipMalloc(&ctx->d_lev_rows, n * sizeof(LevRow5)));
     hipLaunchKernelGGL(k_lev_rows, dim3((n + 63) / 64), dim3(64), 0, 0, g, ctx->d_pi_dry, (LevRow5 *)ctx->d_lev_rows, n);
     BZ_HIP(hipGetLastError());
@@ -59,6 +60,10 @@ void bzi_lean_teardown(bz_ctx *ctx)
     ctx->d_lev_rows = nullptr;
     if (ctx->d_qstate) hipFree(ctx->d_qstate);
     ctx->d_qstate = nullptr;
+    if (ctx->h_qstate) hipHostFree(ctx->h_qstate);
+    ctx->h_qstate = nullptr;
+    if (ctx->ev_q) hipEventDestroy(ctx->ev_q);
+    ctx->ev_q = nullptr;
     if (ctx->side_stream) { hipStreamSynchronize(ctx->side_stream); hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
@@ -107,6 +112,7 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
     L.pi_dry = ColPtr(ctx->d_pi_dry + g.Hz);
     L.lev = (const LevRow5 *)ctx->d_lev_rows + g.Hz;
     L.qstate = bzi_moisture_state(ctx);
+    const int qh = L.qstate ? ctx->q_host : 2;      // the host's view of the scan's verdict (bz_step.hip); no word: the general bodies only
     L.mforce = 0; L.cor_f = 0.0; L.Fu = ColPtr(nullptr); L.Fv = ColPtr(nullptr);
     if (ctx->has_forcings && bzi_lean_forcings_ok(ctx)) {      // the stack's momentum terms ride the RK epilogues of k6_u / k6_v
         const int m = ctx->forcing_static_mask;
@@ -167,16 +173,24 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         E.u0 = U0->rho_w; E.u0_out = U0->rho_w;
         L.out = G->rho_w;
         const dim3 grid = shape(g.Nz - 1, kc);
-        if (g.bounded_y) hipLaunchKernelGGL((k6_w<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
-        else hipLaunchKernelGGL((k6_w<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        // dry and general body are separate kernels (see bz_lean_skip): general alone once the host knows the model is moist (or has no word)
+#define BZ_LAUNCH_DRY_GENERAL(KERNEL, WYV)                                                                                                  \
+        do {                                                                                                                                \
+            if (qh != 2) {                                                                                                                  \
+                hipLaunchKernelGGL((KERNEL<TY, WYV, true, true>), grid, block, 0, ctx->stream, g, L, kc, E);                                \
+                hipLaunchKernelGGL((KERNEL<TY, WYV, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);                               \
+            } else hipLaunchKernelGGL((KERNEL<TY, WYV, false, false>), grid, block, 0, ctx->stream, g, L, kc, E);                           \
+        } while (0)
+        if (g.bounded_y) BZ_LAUNCH_DRY_GENERAL(k6_w, true);
+        else BZ_LAUNCH_DRY_GENERAL(k6_w, false);
     }
     if (which & 2) {
         ProfileScope ps(ctx, "scalar_tendencies+rk3+thermo");
         E.u0 = U0->rho_theta; E.u0_out = U0->rho_theta; E.u0b = U0->rho_q; E.u0b_out = U0->rho_q;
         L.out = nullptr;
         const dim3 grid = shape(g.Nz, kc);
-        if (g.bounded_y) hipLaunchKernelGGL((k5_scalar_pair<TY, true>), grid, block, 0, ctx->stream, g, L, kc, E);
-        else hipLaunchKernelGGL((k5_scalar_pair<TY>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (g.bounded_y) BZ_LAUNCH_DRY_GENERAL(k5_scalar_pair, true);
+        else BZ_LAUNCH_DRY_GENERAL(k5_scalar_pair, false);
     }
     BZ_LAUNCH_CHECK();
     return BZ_OK;

@@ -384,6 +384,11 @@ class LibrarySlabAtmosphereModel(AtmosphereModel):
         self.clock.last_Δt = float(Δt)
         self.clock.iteration += int(n)
 
+    def _refresh_diagnostics(self):
+        """update_state! with the y-halo exchanges — a collective: every rank of the communicator has to get here (all ranks read, or none)."""
+        self._check(self._lib.bz_comm_update_state_and_project(self._ctx, C.byref(self._state), C.byref(self._G), 1.0, 0),
+                    "bz_comm_update_state_and_project")
+
     def comm_info(self):
         """(transport name, bytes this rank has sent, number of exchanges) of the library-owned communicator."""
         name, nbytes, nex = C.c_char_p(), C.c_int64(), C.c_int32()

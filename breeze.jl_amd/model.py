@@ -172,10 +172,21 @@ class Field:
         arr = np.broadcast_to(np.asarray(value, dtype=np.float64), shape)
         self.interior.copy_(torch.from_numpy(np.array(arr, dtype=np.float64, order="C")).to(self.dtype))
 
+    # diagnostic fields of a model (u, v, w, θ, qᵛ, T, pressure anomaly) know their owner: after time_steps(..., diagnose_last=False)
+    # they are older than the prognostic state, and a host read rebuilds them first (update_state!) instead of returning stale values
+    _owner = None
+
+    def _fresh(self):
+        m = self._owner() if self._owner is not None else None
+        if m is not None and getattr(m, "_ctx", None) and diagnostics_stale(m):
+            m._refresh_diagnostics()
+
     def cpu(self):
+        self._fresh()
         return self.parent.cpu().numpy()
 
     def interior_cpu(self):
+        self._fresh()
         return self.interior.cpu().numpy()
 
 
@@ -309,6 +320,9 @@ class AtmosphereModel:
         self.specific_moisture = fld("ccc")
         self.temperature = fld("ccc")
         dynamics.pressure_anomaly = fld("ccc")
+        import weakref
+        for _f in (*self.velocities.values(), self.potential_temperature, self.specific_moisture, self.temperature, dynamics.pressure_anomaly):
+            _f._owner = weakref.ref(self)
         self.microphysical_fields = {}
         if self._kessler:      # materialize_microphysical_fields(::DCMIP2016KM) (dcmip2016_kessler.jl:255-290)
             self.microphysical_fields = {k: fld("ccc") for k in ("ρqᶜˡ", "ρqʳ", "qᵛ", "qᶜˡ", "qʳ", "𝕎ʳ")}
@@ -474,6 +488,10 @@ class AtmosphereModel:
 
     def synchronize(self):
         self._check(self._lib.bz_sync(self._ctx), "bz_sync")
+
+    def _refresh_diagnostics(self):
+        """update_state!(model; compute_tendencies=false) after undiagnosed steps (slab models override it with the exchanging form)."""
+        update_state_(self, compute_tendencies=False)
 
     # -- profiling -----------------------------------------------------------
     def graph_enable(self, on=True):
@@ -734,6 +752,8 @@ def diagnostics_stale(model):
 def cell_advection_timescale(model, formulation="ThreeDimensional"):
     """cell_advection_timescale(model) (src/AtmosphereModels/cell_advection_timescale.jl:47-66): the TimeStepWizard's
     advective timescale min 1/(|u|/Δx + |v|/Δy + |w|/Δz); formulation "Horizontal" drops the vertical term."""
+    if diagnostics_stale(model):      # the velocities are diagnostics: rebuild them after undiagnosed steps (time_steps(..., diagnose_last=False))
+        model._refresh_diagnostics()
     out = model._T.real()
     w = None if str(formulation).startswith("Horizontal") else C.c_void_p(model.velocities["w"].ptr())
     model._check(model._lib.bz_cell_advection_timescale(model._ctx, C.c_void_p(model.velocities["u"].ptr()),

@@ -163,3 +163,44 @@ def test_slab_ranks_multi_step_is_bitwise_the_single_step_sequence(bz, world):
         for ma, mb, mc in zip(a, b, c):
             assert np.array_equal(get(ma).cpu(), get(mb).cpu()), name
             assert np.array_equal(get(ma).cpu(), get(mc).cpu()), name
+
+
+def test_consumers_of_stale_diagnostics_rebuild_or_refuse(bz):
+    """after time_steps(..., diagnose_last=False) the velocities / θ / qᵛ / T are older than the prognostic state.  The C entry
+    points that read them rebuild them when they are handed the state (bz_compute_tendencies) or refuse (bz_cell_advection_timescale takes
+    bare pointers: BZ_ERR_INVALID + message); the host wrappers (cell_advection_timescale, Field.cpu()) rebuild first."""
+    import ctypes as C
+    a, b, c = _model(bz), _model(bz), _model(bz)
+    for _ in range(2):
+        a.time_step(2.0)
+    a.synchronize()
+    want_tau = bz.cell_advection_timescale(a)
+    # (i) the C entry point refuses to answer from stale velocities
+    b.time_steps(2.0, 2, diagnose_last=False)
+    assert bz.diagnostics_stale(b)
+    out = b._T.real()
+    rc = b._lib.bz_cell_advection_timescale(b._ctx, C.c_void_p(b.velocities["u"].ptr()), C.c_void_p(b.velocities["v"].ptr()),
+                                            C.c_void_p(b.velocities["w"].ptr()), C.byref(out))
+    assert rc != 0 and b"stale" in b._lib.bz_last_error(b._ctx)
+    # (ii) the host wrapper rebuilds, then answers what the diagnosed run answers (1e-13: separate compilations of the diagnosis)
+    tau = bz.cell_advection_timescale(b)
+    assert not bz.diagnostics_stale(b)
+    assert abs(tau - want_tau) <= 1e-12 * want_tau
+    # (iii) a host read of a diagnostic field rebuilds as well
+    c.time_steps(2.0, 2, diagnose_last=False)
+    assert bz.diagnostics_stale(c)
+    w = c.velocities["w"].cpu()
+    assert not bz.diagnostics_stale(c)
+    ref = a.velocities["w"].cpu()
+    assert np.max(np.abs(w - ref)) <= 1e-13 * max(np.max(np.abs(ref)), 1e-30)
+    # (iv) bz_compute_tendencies with the state at hand rebuilds before it reads u, v, w, θ, qᵛ, T
+    d, e = _model(bz), _model(bz)
+    d.time_steps(2.0, 2, diagnose_last=True)
+    e.time_steps(2.0, 2, diagnose_last=False)
+    bz.compute_tendencies_(d)
+    bz.compute_tendencies_(e)
+    assert not bz.diagnostics_stale(e)
+    d.synchronize(); e.synchronize()
+    for k in d.G:
+        x, y = d.G[k].cpu(), e.G[k].cpu()
+        assert np.max(np.abs(x - y)) <= 1e-12 * max(np.max(np.abs(x)), 1e-30), k

@@ -170,6 +170,18 @@ KERNEL_GROUPS = [
 ]
 
 
+def kernel_variant(name):
+    """Which body a lean scalar-pair / z-momentum kernel row is (round 5: separate kernels, k5_scalar_pair<TY, WY, DRYQ, GUARD> and
+    k6_w<TY, WY, DRYQ, GUARD>): 'dry' (rho q identically zero: priced in COMPULSORY_WORDS_DRY), 'general', or None for every other kernel.
+    A guarded launch (GUARD = true) of the body that does not apply returns at once: such rows average a few microseconds."""
+    head = name.split("(")[0]
+    head = head[5:] if head.startswith("void ") else head
+    m = re.match(r"^(?:k5_scalar_pair|k6_w)(?:_f32)?<\s*\d+\s*,\s*(?:true|false)\s*,\s*(true|false)", head)
+    if not m:
+        return None
+    return "dry" if m.group(1) == "true" else "general"
+
+
 def kernel_group(name):
     """(group, is_float32) of a rocprofv3 kernel name, or (None, False)."""
     head = name.split("(")[0]

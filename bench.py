@@ -732,6 +732,11 @@ def run_rank(args):
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=timeout)
     device = "cpu" if cpu_selftest else f"cuda:{local_rank}"
+    if not cpu_selftest and os.environ.get("BZ_BENCH_OWN_STREAM") == "1":
+        # experiments: run on a non-blocking stream of our own instead of the legacy default stream (which synchronises implicitly with
+        # every blocking stream, e.g. one created with a CU mask)
+        torch.cuda.set_device(local_rank)
+        torch.cuda.set_stream(torch.cuda.Stream())
 
     def fail(message):
         """Every rank reports; rank 0 prints the JSON error line.  Never falls back to a different measurement."""

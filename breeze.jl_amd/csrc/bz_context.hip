@@ -52,8 +52,11 @@ void bzi_read_tuning(bz_tuning &t)
     t.tend_gen = num("BZ_TEND_GEN", 0);
     t.no_lean = on("BZ_NO_LEAN");
     t.no_xcd = on("BZ_NO_XCD");
+    t.no_k6_stored = on("BZ_NO_K6_STORED");
     t.no_dry_shortcut = on("BZ_NO_DRY_SHORTCUT");
     t.side_scalar = on("BZ_SIDE_SCALAR");
+    t.side_cus = num("BZ_SIDE_CUS", 0);
+    t.side_cu_layout = num("BZ_SIDE_CU_LAYOUT", 0);
     t.no_fuse_forcing = on("BZ_NO_FUSE_FORCING");
     t.no_tridiag_coop = on("BZ_NO_TRIDIAG_COOP");
     t.no_xfft = on("BZ_NO_XFFT");

@@ -299,8 +299,11 @@ struct bz_tuning {
     int tend_gen = 0;                 // BZ_TEND_GEN (0: default)
     bool no_lean = false;             // BZ_NO_LEAN: fused-RK tier instead of the lean (prognostic-only) seam
     bool no_xcd = false;              // BZ_NO_XCD: hardware block order in the lean kernels
+    bool no_k6_stored = false;        // BZ_NO_K6_STORED: the stored-velocity tiers keep the fourth-generation tile kernels (k_{u,v,w}_tend_lds)
     bool no_dry_shortcut = false;     // BZ_NO_DRY_SHORTCUT: the lean kernels always carry rho q (no moisture scan)
     bool side_scalar = false;         // BZ_SIDE_SCALAR: scalar kernel beside the pressure solve on one GPU too
+    int side_cus = 0;                 // BZ_SIDE_CUS=N: the side stream is created on N of the GPU's CUs (CU mask)
+    int side_cu_layout = 0;           // BZ_SIDE_CU_LAYOUT (experiments): 0 the first N mask bits, 1 every (total / N)-th bit
     bool no_fuse_forcing = false;     // BZ_NO_FUSE_FORCING
     bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms
@@ -601,6 +604,8 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
                int weno_order, int y_nranks, int y_rank, bool slab_mode, bool compressible = false);
 void bzi_compressible_teardown(bz_ctx *ctx);
 int bzi_compute_tendencies3(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, bool include_w);
+bool bzi_k6_stored_ok(const bz_ctx *ctx);
+int bzi_k6_stored(bz_ctx *ctx, int comp, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0, const RKEpilogue *Ein, int bm);
 int bzi_scalar_pair_tendency(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,
                              const RKEpilogue *E = nullptr);
 int bzi_u_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0 = nullptr,

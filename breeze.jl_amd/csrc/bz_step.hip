@@ -337,11 +337,12 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                     ProfileScope ps(ctx, "poisson_fft_y_inverse");
                     if ((rc = bzi_xf_y(ctx, false))) return rc;
                 }
-                if (ctx->side_scalar && !ctx->has_forcings) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 {
                     ProfileScope ps(ctx, "poisson_fft_x_inverse");
                     if ((rc = bzi_xf_inverse(ctx))) return rc;
                 }
+                // the scalar-pair kernel of the side stream joins here: the projection kernels write the z-halo images of rho theta / rho q
+                if (ctx->side_scalar && !ctx->has_forcings) BZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 if (!full) rc = bzi_project_lean(ctx, sout, alpha * dt, nullptr, nullptr, G, oa, ob);
                 else rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, true, oa, ob);
                 if (rc) return rc;

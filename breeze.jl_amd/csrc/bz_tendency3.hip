@@ -111,6 +111,7 @@ int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, 
                         const RKEpilogue *Ein, int buoyancy_mode)
 {
     const DevGrid &g = ctx->dg;
+    if (bzi_k6_stored_ok(ctx)) return bzi_k6_stored(ctx, 2, s, G, U0, Ein, (buoyancy_mode == 0 && g.microphysics) ? 3 : buoyancy_mode);
     ProfileScope ps(ctx, Ein ? "z_momentum_tendency+rk3" : "z_momentum_tendency");
     RKEpilogue E;
     if (Ein) { E = *Ein; E.u0 = U0->rho_w; E.u0_out = U0->rho_w; }
@@ -146,6 +147,7 @@ int bzi_w_tendency_ring(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, 
 int bzi_u_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0, const RKEpilogue *Ein)
 {
     const DevGrid &g = ctx->dg;
+    if (bzi_k6_stored_ok(ctx)) return bzi_k6_stored(ctx, 0, s, G, U0, Ein, 0);
     ProfileScope ps(ctx, Ein ? "x_momentum_tendency+rk3" : "x_momentum_tendency");
     RKEpilogue E;
     if (Ein) { E = *Ein; E.u0 = U0->rho_u; E.u0_out = U0->rho_u; }
@@ -164,6 +166,7 @@ int bzi_u_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, c
 int bzi_v_tendency_lds(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0, const RKEpilogue *Ein)
 {
     const DevGrid &g = ctx->dg;
+    if (bzi_k6_stored_ok(ctx)) return bzi_k6_stored(ctx, 1, s, G, U0, Ein, 0);
     ProfileScope ps(ctx, Ein ? "y_momentum_tendency+rk3" : "y_momentum_tendency");
     RKEpilogue E;
     if (Ein) { E = *Ein; E.u0 = U0->rho_v; E.u0_out = U0->rho_v; }

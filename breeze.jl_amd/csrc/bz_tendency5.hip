@@ -41,6 +41,17 @@ int bzi_lean_setup(bz_ctx *ctx)
     hipLaunchKernelGGL(k_lev_rows, dim3((n + 63) / 64), dim3(64), 0, 0, g, ctx->d_pi_dry, (LevRow5 *)ctx->d_lev_rows, n);
     BZ_HIP(hipGetLastError());
     BZ_HIP(hipDeviceSynchronize());
+    if (ctx->tune.side_cus > 0 && ctx->tune.side_cus < ctx->num_cus) {
+        // a side stream that owns a share of the CUs: the scalar-pair kernel (issue-bound) then runs BESIDE the pressure solve (bandwidth-
+        // bound) instead of in front of it — two unmasked streams simply take turns (measured: every kernel stretches by the other's time)
+        uint32_t mask[32] = {0};
+        const int total = ctx->num_cus, want = ctx->tune.side_cus;
+        for (int b = 0; b < want; ++b) {
+            const int bit = ctx->tune.side_cu_layout == 1 ? (int)((long long)b * total / want) : b;
+            mask[bit >> 5] |= 1u << (bit & 31);
+        }
+        BZ_HIP(hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)((total + 31) / 32), mask));
+    } else
     BZ_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     BZ_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     BZ_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -191,6 +202,62 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
         const dim3 grid = shape(g.Nz, kc);
         if (g.bounded_y) BZ_LAUNCH_DRY_GENERAL(k5_scalar_pair, true);
         else BZ_LAUNCH_DRY_GENERAL(k5_scalar_pair, false);
+    }
+    BZ_LAUNCH_CHECK();
+    return BZ_OK;
+}
+
+// ---- stored-velocity instantiations of the sixth-generation momentum kernels (round 5) -------------------------------------------------
+// The tiers that keep u, v, w as stored fields — the fused-RK tier (saturation adjustment, closures, tracers, forcing stacks: BASELINE
+// configs[2]), the per-operator entry points and the slow tendencies of the compressible model (configs[4]) — ran the fourth-generation
+// tiles (k_{u,v,w}_tend_lds: x stencils from global memory, loads at their point of use, hardware block order; 0.29 of the roof on the
+// compressible slow tendencies).  They now launch k6_u / k6_v / k6_w<ST>: the same kernels as the lean seam with
+// the velocity read instead of derived.  comp: 0 u, 1 v, 2 w;  bm: buoyancy mode of the z-momentum kernel (k6_w).
+bool bzi_k6_stored_ok(const bz_ctx *ctx)
+{
+    const DevGrid &g = ctx->dg;
+    return !ctx->tune.no_k6_stored && !g.flat_y && !g.bounded_x && !g.bounded_y && g.Nz > 1 &&
+           (long long)g.Sxy * (g.Nz + 2 * g.Hz + 1) < (1LL << 32);
+}
+
+int bzi_k6_stored(bz_ctx *ctx, int comp, const bz_state *s, const bz_prognostic *G, const bz_prognostic *U0, const RKEpilogue *Ein, int bm)
+{
+    constexpr int TY = 8;
+    const DevGrid &g = ctx->dg;
+    RKEpilogue E;
+    if (Ein) E = *Ein;
+    Lean5 L;
+    L.ru = s->rho_u; L.rv = s->rho_v; L.rw = s->rho_w; L.pa = L.pb = nullptr; L.oa = L.ob = nullptr; L.T = nullptr;
+    L.pi_dry = ColPtr(nullptr);
+    L.lev = nullptr;
+    L.qstate = nullptr;
+    L.mforce = 0; L.cor_f = 0.0; L.Fu = ColPtr(nullptr); L.Fv = ColPtr(nullptr);
+    L.bT = s->T; L.bq = s->q;
+    L.by0 = 0; L.bys = 1;
+    const dim3 block(64, TY);
+    const int tx = (g.Nx + 63) / 64, nty = (g.Ny + TY - 1) / TY;
+    const int nlev = comp == 2 ? g.Nz - 1 : g.Nz;
+    const int kc = pick_chunk5(g, nlev, TY, sizeof(double) == 8);
+    const dim3 grid(tx, nty, (nlev + kc - 1) / kc);
+    L.xcd = (!ctx->tune.no_xcd && ((long long)grid.x * grid.y * grid.z) % 8 == 0) ? 1 : 0;
+    if (comp == 0) {
+        ProfileScope ps(ctx, Ein ? "x_momentum_tendency+rk3" : "x_momentum_tendency");
+        if (Ein) { E.u0 = U0->rho_u; E.u0_out = U0->rho_u; }
+        L.vel = s->u; L.out = G->rho_u;
+        hipLaunchKernelGGL((k6_u<TY, false, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+    } else if (comp == 1) {
+        ProfileScope ps(ctx, Ein ? "y_momentum_tendency+rk3" : "y_momentum_tendency");
+        if (Ein) { E.u0 = U0->rho_v; E.u0_out = U0->rho_v; }
+        L.vel = s->v; L.out = G->rho_v;
+        hipLaunchKernelGGL((k6_v<TY, false, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+    } else {
+        ProfileScope ps(ctx, Ein ? "z_momentum_tendency+rk3" : "z_momentum_tendency");
+        if (Ein) { E.u0 = U0->rho_w; E.u0_out = U0->rho_w; }
+        L.vel = s->w; L.out = G->rho_w;
+        if (bm == 0) hipLaunchKernelGGL((k6_w<TY, false, false, false, 0>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else if (bm == 1) hipLaunchKernelGGL((k6_w<TY, false, false, false, 1>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else if (bm == 2) hipLaunchKernelGGL((k6_w<TY, false, false, false, 2>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_w<TY, false, false, false, 3>), grid, block, 0, ctx->stream, g, L, kc, E);
     }
     BZ_LAUNCH_CHECK();
     return BZ_OK;

@@ -106,6 +106,11 @@ struct Lean5 {
     int mforce;
     double cor_f;
     ColPtr Fu, Fv;
+    // ST instantiations of k6_u / k6_v / k6_w (round 5): the advected velocity is a STORED field (the fused-RK tier of models the lean seam does
+    // not cover — saturation adjustment, closures, tracers, forcing stacks —, the per-operator entry points, and the slow tendencies of the
+    // compressible model, where rho is a 3-D field and nothing can be derived from a column constant): vel = u | v | w of the component,
+    // bT / bq = the buoyancy inputs of the z-momentum kernel (T and q; pressure and total density in the compressible form)
+    const double *vel, *bT, *bq;
     const int *qstate;               // moisture scan (bz_step.hip: bzi_scan_moisture): *qstate == 1 <=> rho q is identically zero; nullptr: not known
     int xcd;                         // 1: XCD-contiguous block order (grid size divisible by 8)
     int by0, bys;                    // tile row of block row b is by0 + b * bys (sub-launches of the slab driver: interior rows
@@ -540,9 +545,12 @@ __device__ __forceinline__ double flux_x_lean(const DevGrid &g, const Tend3Field
 // <= 2 frame cells), consumes them at its end, and reads its stencils with ds_read (tiles: u derived (TY+6) x 70; raw rho_u TY x 67;
 // raw rho_v (TY+1) x 67; raw rho_w TY x 67 at the upper face; double-buffered).  Same arithmetic, same bits as k5_u.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY, bool MF = false, bool WY = false>      // MF: momentum terms of a forcing stack in the RK epilogue (Lean5::mforce); WY: walls in y
+// ST: the advected velocity is read from the stored field Lean5::vel instead of being derived from the momentum (see Lean5); the
+// arithmetic per flux is that of k_u_tend_lds (bz_tendency4_kernels.h), which these instantiations replace.
+template <int TY, bool MF = false, bool WY = false, bool ST = false>      // MF: momentum terms of a forcing stack in the RK epilogue (Lean5::mforce); WY: walls in y
 __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
+    static_assert(!(ST && (MF || WY)), "stored-velocity instantiations: periodic / slab rows, no folded forcing");
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY;
     constexpr int NH1 = TR * 70 - TY * 64;               // frame of the u tile (468 for TY = 8): one cell per thread
     constexpr int NH2 = 3 * (TY + 1) + 64 + 3 * TY;      // rho_v side columns + its top row + rho_w side columns (115)
@@ -564,8 +572,9 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
     const ix_t sz = (ix_t)g.Sxy;
     const bool store = (i < g.Nx) && (j < g.Ny);
     const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
+    const double *__restrict__ vel = ST ? L.vel : L.ru;      // stored u (ST) — else unused
     Tend3Fields F;
-    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
+    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.T = F.q = nullptr; F.c = ST ? L.vel : nullptr; F.G = L.out;
     ix_t n = (ix_t)g.idx(ic, jc, kbeg);
     // frame cell 1: the u tile's frame (raw rho_u; its side cells next to the interior also feed the raw rho_u tile)
     const bool h1ok = !(BZ_KO & 32768) && t < NH1;
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
 
     double r[6];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) r[s] = bz_cdiv(ru[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
+    for (int s = 0; s < 6; ++s) r[s] = ST ? vel[n + s * sz - 3 * sz] : bz_cdiv(ru[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
     double fz_lo = vflux<T3_U>(g, F, n, kbeg, r[0], r[1], r[2], r[3], r[4], r[5]);
     double q0 = ru[n], q1 = ru[n + sz], q2 = ru[n + 2 * sz];          // raw rho_u of the own column at levels k, k+1, k+2
     // tiles of level kbeg
@@ -600,12 +609,13 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
     RV[0][ty][tc] = rv[n];
     RW[0][ty][tc] = rw[n + sz];
     if (h1ok) {
-        const double raw = ru[h1n];
-        U[0][h1r][h1c] = bz_cdiv(raw, g.rho[kbeg], g.rrho[kbeg]);
+        const double raw = (ST && !h1raw) ? 0.0 : ru[h1n];
+        U[0][h1r][h1c] = ST ? vel[h1n] : bz_cdiv(raw, g.rho[kbeg], g.rrho[kbeg]);
         if (h1raw) RU[0][h1r - 3][h1c] = raw;
     }
     if (h2ok) { if (h2sel) RW[0][h2r][h2c] = h2src[h2n]; else RV[0][h2r][h2c] = h2src[h2n]; }
     double tcur_raw = ru[n + 3 * sz];
+    double tcur_v = ST ? vel[n + 3 * sz] : 0.0;      // ST: the ring top of the stored velocity travels beside the raw momentum
     double u0cur = (E.mode == 2) ? E.u0[n] : 0.0;
     __syncthreads();
 
@@ -618,13 +628,15 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
         const ix_t lev1 = (ix_t)(k + 1 - kbeg) * sz;
         // ---- prefetch for level k+1 (consumed at the end of this iteration / in the next one) ----
         const double p_top = ru[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];
-        const double p_h1 = (BZ_KO & 256) ? p_top : h1ok ? ru[h1n + lev1] : 0.0;
+        const double p_topv = ST ? vel[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)] : 0.0;
+        const double p_h1 = (BZ_KO & 256) ? p_top : h1ok ? (ST ? vel : ru)[h1n + lev1] : 0.0;
+        const double p_h1raw = (ST && h1raw) ? ru[h1n + lev1] : 0.0;
         const double p_h2 = (BZ_KO & 512) ? p_top : h2ok ? h2src[h2n + lev1] : 0.0;
         const double p_rv = (BZ_KO & 1024) ? p_top * 0.5 : rv[n + sz], p_rw = (BZ_KO & 1024) ? p_top * 0.25 : rw[n + 2 * sz];
         const double p_u0 = (BZ_KO & 2048) ? p_top : (E.mode == 2) ? E.u0[n + sz] : 0.0;
         if (((k - kbeg) & 63) == 0) {
             const int kk = min(k + tx, kend - 1);
-            edge = flux_x_lean<T3_U>(g, F, ru, ie, jc, kk);
+            edge = ST ? flux_x_at<T3_U>(g, F, ie, jc, kk) : flux_x_lean<T3_U>(g, F, ru, ie, jc, kk);
         }
         const int src = (k - kbeg) & 63;
         const double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
@@ -646,7 +658,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
                                                by5_face<WY>(g, j0 + TY));
         }
         // ---- z: upper face k+1 ----
-        const double tnew = bz_cdiv(tcur_raw, g.rho[k + 3], g.rrho[k + 3]);
+        const double tnew = ST ? tcur_v : bz_cdiv(tcur_raw, g.rho[k + 3], g.rrho[k + 3]);
         const double *rwr = RW[buf][ty] + tc;
         const double wt = bz_symm4(Az * rwr[-2], Az * rwr[-1], Az * rwr[0], Az * rwr[1]);
         const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
@@ -656,8 +668,8 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
         RV[buf ^ 1][ty][tc] = p_rv;
         RW[buf ^ 1][ty][tc] = p_rw;
         if (h1ok) {
-            U[buf ^ 1][h1r][h1c] = bz_cdiv(p_h1, g.rho[k + 1], g.rrho[k + 1]);
-            if (h1raw) RU[buf ^ 1][h1r - 3][h1c] = p_h1;
+            U[buf ^ 1][h1r][h1c] = ST ? p_h1 : bz_cdiv(p_h1, g.rho[k + 1], g.rrho[k + 1]);
+            if (h1raw) RU[buf ^ 1][h1r - 3][h1c] = ST ? p_h1raw : p_h1;
         }
         if (h2ok) { if (h2sel) RW[buf ^ 1][h2r][h2c] = p_h2; else RV[buf ^ 1][h2r][h2c] = p_h2; }
         if (!(BZ_KO & 16384) && (!(BZ_KO & 8192) || ((k - kbeg) & 1))) __syncthreads();
@@ -676,7 +688,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
                 }
                 if (L.mforce & 2) Gu += g.rho[k] * L.Fu[k];
             }
-            if (store) L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out, Gu, q0, n);
+            if (store) L.out[n] = (ST && E.mode == 0) ? Gu : bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out, Gu, q0, n);
         }
         fz_lo = fz_hi;
 #pragma unroll
@@ -684,6 +696,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
         r[5] = tnew;
         q0 = q1; q1 = q2; q2 = tcur_raw;
         tcur_raw = p_top; u0cur = p_u0;
+        if (ST) tcur_v = p_topv;
         buf ^= 1;
     }
 }
@@ -693,9 +706,10 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
 // y-momentum, sixth generation (see k6_u): the v tile carries its x halo, so the x-stencil is five ds_reads instead of five loads +
 // five column divisions; ring top and u0 are loaded one level ahead.  Same arithmetic, same bits as k5_v.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY, bool MF = false, bool WY = false>
+template <int TY, bool MF = false, bool WY = false, bool ST = false>      // ST: stored v (see k6_u)
 __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
+    static_assert(!(ST && (MF || WY)), "stored-velocity instantiations: periodic / slab rows, no folded forcing");
     constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles
     constexpr int TC = 72;                                // v tile with its x halo: columns i0-3 .. i0+65 at offset 3
     __shared__ double Tv[2][RV][TC];
@@ -717,8 +731,9 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
     const int ju = __builtin_amdgcn_readfirstlane(j);      // one row per wavefront
     const int Bf = by5_face<WY>(g, ju), Bc = by5_center<WY>(g, ju), Bc0 = by5_center<WY>(g, j0 - 1);
     const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
+    const double *__restrict__ vel = ST ? L.vel : L.rv;      // stored v (ST) — else unused
     Tend3Fields F;
-    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
+    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.T = F.q = nullptr; F.c = ST ? L.vel : nullptr; F.G = L.out;
     const double Az = g.Az;
     ix_t n = (ix_t)g.idx(ic, jc, kbeg);
 
@@ -740,12 +755,12 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         else if (id < 13) { sel = 2; const int m = id - 9; row = (m < 2) ? m : TY + m; grow = j0 - 2 + row; }
         else { sel = 3; const int m = id - 13; row = (m < 2) ? m : TY + 2; grow = j0 - 2 + row; }
         hsel[q] = sel; hrow[q] = row;
-        hsrc[q] = (sel == 1) ? ru : (sel == 3) ? rw : rv;
+        hsrc[q] = (sel == 1) ? ru : (sel == 3) ? rw : (ST && sel == 0) ? vel : rv;
         hn[q] = (ix_t)g.idx(min(i0 + tx, g.Nx + 2), min(grow, g.Ny + 2), kbeg) + (sel == 3 ? sz : (ix_t)0);
     }
     auto frame_load = [&](int q, ix_t lev) -> double { return hsrc[q][hn[q] + lev]; };   // raw value at the level offset
     auto frame_store = [&](int b, int q, double raw, int klev) {          // scale / derive and stage for level klev
-        if (hsel[q] == 0) Tv[b][hrow[q]][tc] = bz_cdiv(raw, g.rho[klev], g.rrho[klev]);
+        if (hsel[q] == 0) Tv[b][hrow[q]][tc] = ST ? raw : bz_cdiv(raw, g.rho[klev], g.rrho[klev]);
         else Tm[b][hsel[q] - 1][hrow[q]][tx] = ((hsel[q] == 1) ? g.Ax[klev] : (hsel[q] == 2) ? g.Ay[klev] : Az) * raw;
     };
 
@@ -756,7 +771,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
 
     double r[6];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) r[s] = bz_cdiv(rv[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
+    for (int s = 0; s < 6; ++s) r[s] = ST ? vel[n + s * sz - 3 * sz] : bz_cdiv(rv[n + s * sz - 3 * sz], g.rho[kbeg + s - 3], g.rrho[kbeg + s - 3]);
     double fz_lo;
     if (WY && Bf != 3) {      // walls in y: the advecting flux at (y-face j, z-face kbeg) from rows j-1, j only
         const double wt0 = bz_symm2(Az * rw[n - (ix_t)g.Sx], Az * rw[n]);
@@ -765,7 +780,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
     // raw rho_v of the own column at levels k .. k+2 (the ring-top load of level k+3 enters at the end of each iteration)
     double q0 = rv[n], q1 = rv[n + sz], q2 = rv[n + 2 * sz];
     Tv[0][ty + 3][tc] = r[3];
-    if (sok) Tv[0][srow + 3][scol] = bz_cdiv(rv[sn], g.rho[kbeg], g.rrho[kbeg]);
+    if (sok) Tv[0][srow + 3][scol] = ST ? vel[sn] : bz_cdiv(rv[sn], g.rho[kbeg], g.rrho[kbeg]);
     Tm[0][0][ty + 2][tx] = g.Ax[kbeg] * ru[n];
     Tm[0][1][ty + 2][tx] = g.Ay[kbeg] * q0;
     Tm[0][2][ty + 2][tx] = Az * rw[n + sz];
@@ -775,6 +790,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
     __syncthreads();
 
     double tcur_raw = rv[n + 3 * sz];
+    double tcur_v = ST ? vel[n + 3 * sz] : 0.0;
     double u0cur = (E.mode == 2) ? E.u0[n] : 0.0;
     double edge = 0.0;
     int buf = 0;
@@ -783,8 +799,9 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         double hnext[HPT];
 #pragma unroll
         for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? frame_load(q, lev) : 0.0;
-        const double p_side = sok ? rv[sn + lev] : 0.0;
+        const double p_side = sok ? (ST ? vel : rv)[sn + lev] : 0.0;
         const double p_top = rv[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];
+        const double p_topv = ST ? vel[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)] : 0.0;
         const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
         const double tnew_raw = tcur_raw, u0v = u0cur;
         const double ru_n = g.Ax[k + 1] * ru[n + sz], rw_n = Az * rw[n + 2 * sz];
@@ -797,7 +814,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         if constexpr (MF) { if ((L.mforce & 1) && tx == 63) { const ix_t sy = (ix_t)g.Sx; cg1 = ru[n - sy + 1]; cg3 = ru[n + 1]; } }
         if (((k - kbeg) & 63) == 0) {
             const int kk = min(k + tx, kend - 1);
-            edge = flux_x_lean<T3_V>(g, F, rv, ie, jc, kk, Bf);
+            edge = ST ? flux_x_at<T3_V>(g, F, ie, jc, kk) : flux_x_lean<T3_V>(g, F, rv, ie, jc, kk, Bf);
         }
         const int src = (k - kbeg) & 63;
         const double rho = g.rho[k];
@@ -819,7 +836,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
             FY[buf][0][tx] = vb * bz_up5y<WY>(V[0][tc], V[1][tc], V[2][tc], V[3][tc], V[4][tc], V[5][tc], vb > 0.0, Bc0);
         }
         // ---- z: advecting flux at (y-face j, z-face k+1) from the rho_w tile rows j-2..j+1 ----
-        const double tnew = bz_cdiv(tnew_raw, g.rho[k + 3], g.rrho[k + 3]);
+        const double tnew = ST ? tcur_v : bz_cdiv(tnew_raw, g.rho[k + 3], g.rrho[k + 3]);
         const double wt = bz_symm4y<WY>(MW[ty][tx], MW[ty + 1][tx], MW[ty + 2][tx], MW[ty + 3][tx], Bf);
         const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
         if constexpr (MF) {
@@ -832,7 +849,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         }
         // ---- stage level k+1 ----
         Tv[buf ^ 1][ty + 3][tc] = r[4];
-        if (sok) Tv[buf ^ 1][srow + 3][scol] = bz_cdiv(p_side, g.rho[k + 1], g.rrho[k + 1]);
+        if (sok) Tv[buf ^ 1][srow + 3][scol] = ST ? p_side : bz_cdiv(p_side, g.rho[k + 1], g.rrho[k + 1]);
         Tm[buf ^ 1][0][ty + 2][tx] = ru_n;
         Tm[buf ^ 1][1][ty + 2][tx] = g.Ay[k + 1] * q1;
         Tm[buf ^ 1][2][ty + 2][tx] = rw_n;
@@ -851,7 +868,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
                 if (L.mforce & 1) Gv -= L.cor_f * cor_u;
                 if (L.mforce & 4) Gv += rho * L.Fv[k];
             }
-            if (store) L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out, Gv, q0, n);
+            if (store) L.out[n] = (ST && E.mode == 0) ? Gv : bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out, Gv, q0, n);
             if constexpr (WY) {      // the wall faces of the predictor: j = 0 (this row, not updated) and j = Ny (first halo row above the last row)
                 if (i < g.Nx && j == 0) L.out[n] = 0.0;
                 if (i < g.Nx && j == g.Ny - 1) L.out[n + (ix_t)g.Sx] = 0.0;
@@ -860,6 +877,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         fz_lo = fz_hi;
         q0 = q1; q1 = q2; q2 = tnew_raw;
         tcur_raw = p_top; u0cur = p_u0;
+        if (ST) tcur_v = p_topv;
 #pragma unroll
         for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
         r[5] = tnew;
@@ -897,9 +915,15 @@ __device__ __forceinline__ double buoyancy5(const DevGrid &g, double rth, double
 // five loads + five column divisions; the ring top, the own T / rho q values and u0 are loaded one level ahead; the raw rho_w of the
 // own column rides a register delay line (advecting-flux ring and RK update).  Same arithmetic, same bits as k5_w.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TY, bool WY = false, bool DRYQ = false, bool GUARD = true>      // DRYQ: rho q identically zero (see k5_scalar_pair): its loads are skipped, every wavefront takes the dry Exner factor
+// BM: 4 the lean seam (w and the buoyancy inputs derived from the prognostic fields); 0 .. 3 the STORED-velocity instantiations (see Lean5 / k6_u)
+// with the buoyancy modes of k_w_tend_lds (bz_tendency4_kernels.h), which they replace: 0 anelastic buoyancy from the stored T, q;
+// 3 the same with the diagnosed q^v, q^l of saturation adjustment / the Kessler species; 1 none; 2 the compressible slow vertical
+// momentum G^s = G_adv - dz(p - p_r) - g Iz(rho - rho_r) with Lean5::bT = pressure, bq = total density (acoustic_substepping.jl:727-752)
+template <int TY, bool WY = false, bool DRYQ = false, bool GUARD = true, int BM = 4>      // DRYQ: rho q identically zero (see k5_scalar_pair): its loads are skipped, every wavefront takes the dry Exner factor
 __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
+    constexpr bool ST = BM != 4;
+    static_assert(!(ST && (WY || DRYQ || GUARD)), "stored-velocity instantiations: periodic / slab rows, no moisture-scan dispatch");
     if (bz_lean_skip<DRYQ, GUARD>(L)) return;
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY, NH = TR * 70 - TY * 64;
     static_assert(NH <= NT, "one frame cell per thread");
@@ -919,10 +943,12 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
     const bool store = (i < g.Nx) && (j < g.Ny);
     const double *__restrict__ ru = L.ru, *__restrict__ rv = L.rv, *__restrict__ rw = L.rw;
     const double *__restrict__ pa = L.pa, *__restrict__ pb = L.pb;       // rho theta, rho q of the stage-start state
+    const double *__restrict__ vel = ST ? L.vel : L.rw;                 // stored w (ST) — else unused
+    const double *__restrict__ bT = L.bT, *__restrict__ bq = L.bq;       // ST: buoyancy inputs (stored fields)
     const Lev5 LV{L.lev};
     constexpr bool dryq = DRYQ;
     Tend3Fields F;
-    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.c = F.T = F.q = nullptr; F.G = L.out;
+    F.ru = L.ru; F.rv = L.rv; F.rw = L.rw; F.u = F.v = F.w = F.T = F.q = nullptr; F.c = ST ? L.vel : nullptr; F.G = L.out;
     const double Az = g.Az;
     ix32_t n = (ix32_t)g.idx(ic, jc, kbeg);
     const bool hok = t < NH;
@@ -941,7 +967,7 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const double x = rw[n + s * sz - 3 * sz];
-        wr[s] = bz_cdiv(x, LV.rho_f(kbeg + s - 3), LV.rrho_f(kbeg + s - 3));
+        wr[s] = ST ? vel[n + s * sz - 3 * sz] : bz_cdiv(x, LV.rho_f(kbeg + s - 3), LV.rrho_f(kbeg + s - 3));
         if (s >= 1 && s <= 4) qw[s - 1] = Az * x;   // levels kbeg-2 .. kbeg+1
         if (s == 3) raw0 = x;
         if (s == 4) raw1 = x;
@@ -950,20 +976,26 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int kk = kbeg - 2 + s;
-        qu[s] = LV.Ax(kk) * ru[n + s * sz - 2 * sz];
-        qv[s] = LV.Ay(kk) * rv[n + s * sz - 2 * sz];
-        qt[s] = top ? LV.Ay(kk) * rv[ntop0 + s * sz - 2 * sz] : 0.0;
+        const double Axk = ST ? g.Ax[kk] : LV.Ax(kk), Ayk = ST ? g.Ay[kk] : LV.Ay(kk);      // (compressible contexts have no packed level rows)
+        qu[s] = Axk * ru[n + s * sz - 2 * sz];
+        qv[s] = Ayk * rv[n + s * sz - 2 * sz];
+        qt[s] = top ? Ayk * rv[ntop0 + s * sz - 2 * sz] : 0.0;
     }
-    double fz_lo, b_lo;
+    double fz_lo, b_lo, r_lo = 0.0;
     {
         const int B = bz_buffer_center(kbeg - 1, g.Nz);
         const double wt = (B == 3) ? bz_symm4(qw[0], qw[1], qw[2], qw[3]) : bz_symm2(qw[1], qw[2]);
         fz_lo = wt * bz_upB(wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wt > 0.0, B);
-        b_lo = buoyancy5(g, pa[n - sz], dryq ? 0.0 : pb[n - sz], kbeg - 1, LV.rho(kbeg - 1), LV.rrho(kbeg - 1), LV.pi(kbeg - 1), LV.T_r(kbeg - 1));
+        if constexpr (BM == 4) b_lo = buoyancy5(g, pa[n - sz], dryq ? 0.0 : pb[n - sz], kbeg - 1, LV.rho(kbeg - 1), LV.rrho(kbeg - 1), LV.pi(kbeg - 1), LV.T_r(kbeg - 1));
+        else if constexpr (BM == 0) b_lo = buoyancy3(g, bT[n - sz], bq[n - sz], kbeg - 1);
+        else if constexpr (BM == 3) b_lo = bz_buoyancy(g, bT, bq, (long long)(n - sz), kbeg - 1);
+        else if constexpr (BM == 2) { b_lo = bT[n - sz] - g.p_r[kbeg - 1]; r_lo = bq[n - sz] - g.rho[kbeg - 1]; }
+        else b_lo = 0.0;
     }
     T[0][ty + 3][tc] = wr[3];
-    if (hok) T[0][hr][hc] = bz_cdiv(rw[hn], LV.rho_f(kbeg), LV.rrho_f(kbeg));
+    if (hok) T[0][hr][hc] = ST ? vel[hn] : bz_cdiv(rw[hn], LV.rho_f(kbeg), LV.rrho_f(kbeg));
     double tcur_raw = rw[n + 3 * sz];
+    double tcur_v = ST ? vel[n + 3 * sz] : 0.0;
     double u0cur = (E.mode == 2) ? E.u0[n] : 0.0;
     __syncthreads();
 
@@ -972,21 +1004,25 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
     for (int k = kbeg; k < kend; ++k, n += sz) {
         const ix32_t lev = (ix32_t)(k - kbeg) * sz;
         // ---- prefetch for level k+1 ----
-        const double p_h = hok ? rw[hn + lev + sz] : 0.0;
+        const double p_h = hok ? (ST ? vel : rw)[hn + lev + sz] : 0.0;
         const double p_top = rw[n + ((k + 4 <= g.Nz + g.Hz) ? 4 * sz : 3 * sz)];
-        const double Tcur = pa[n], rqcur = dryq ? 0.0 : pb[n];          // rho theta, rho q (not read where the scan found it zero): consumed mid-level (buoyancy)
+        const double p_topv = ST ? vel[n + ((k + 4 <= g.Nz + g.Hz) ? 4 * sz : 3 * sz)] : 0.0;
+        const double Tcur = (BM == 1) ? 0.0 : (ST ? bT : pa)[n], rqcur = (BM == 1) ? 0.0 : ST ? bq[n] : dryq ? 0.0 : pb[n];          // rho theta, rho q (not read where the scan found it zero): consumed mid-level (buoyancy)
         const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
-        const double Axn = LV.Ax(k + 2), Ayn = LV.Ay(k + 2);
+        const double Axn = ST ? g.Ax[k + 2] : LV.Ax(k + 2), Ayn = ST ? g.Ay[k + 2] : LV.Ay(k + 2);
         const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];
         const double qtn = top ? Ayn * rv[ntop0 + lev + 2 * sz] : 0.0;
         if (((k - kbeg) & 63) == 0) {
             const int kk = min(k + tx, kend - 1);
-            edge = flux_x_lean<T3_W>(g, F, rw, ie, jc, kk);
+            edge = ST ? flux_x_at<T3_W>(g, F, ie, jc, kk) : flux_x_lean<T3_W>(g, F, rw, ie, jc, kk);
         }
         const int src = (k - kbeg) & 63;
         const int Bf = bz_buffer_face(k, g.Nz);
         const double w0 = wr[3];
-        const double qwnew = Az * raw2;
+        // ST: the raw momentum of the own column is read where it is used (level k + 2 for the advecting flux, level k for the RK update)
+        // instead of riding a three-level delay line: the stored-velocity ring top took its registers
+        const double qwnew = Az * (ST ? rw[n + 2 * sz] : raw2);
+        const double uold = ST ? rw[n] : raw0;
         const double(*Tk)[TC] = T[buf];
         const double *wrow = Tk[ty + 3] + tc;
         const double ut = (Bf == 3) ? bz_symm4(qu[0], qu[1], qu[2], qu[3]) : bz_symm2(qu[1], qu[2]);
@@ -999,16 +1035,20 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
             FY[buf][TY][tx] = v2 * bz_up5y<WY>(Tk[TY][tc], Tk[TY + 1][tc], Tk[TY + 2][tc], Tk[TY + 3][tc], Tk[TY + 4][tc], Tk[TY + 5][tc], v2 > 0.0,
                                                by5_face<WY>(g, j0 + TY));
         }
-        const double wnew = bz_cdiv(tcur_raw, LV.rho_f(k + 3), LV.rrho_f(k + 3));
+        const double wnew = ST ? tcur_v : bz_cdiv(tcur_raw, LV.rho_f(k + 3), LV.rrho_f(k + 3));
         double fz_hi;
         {
             const int B = bz_buffer_center(k, g.Nz);
             const double wt = (B == 3) ? bz_symm4(qw[1], qw[2], qw[3], qwnew) : bz_symm2(qw[2], qw[3]);
             fz_hi = wt * bz_upB(wr[1], wr[2], wr[3], wr[4], wr[5], wnew, wt > 0.0, B);
         }
-        const double b_hi = buoyancy5(g, Tcur, rqcur, k, LV.rho(k), LV.rrho(k), LV.pi(k), LV.T_r(k));
+        double b_hi = 0.0, r_hi = 0.0;
+        if constexpr (BM == 4) b_hi = buoyancy5(g, Tcur, rqcur, k, LV.rho(k), LV.rrho(k), LV.pi(k), LV.T_r(k));
+        else if constexpr (BM == 0) b_hi = buoyancy3(g, Tcur, rqcur, k);
+        else if constexpr (BM == 3) b_hi = bz_buoyancy(g, bT, bq, (long long)n, k);
+        else if constexpr (BM == 2) { b_hi = Tcur - g.p_r[k]; r_hi = rqcur - g.rho[k]; }
         T[buf ^ 1][ty + 3][tc] = wr[4];
-        if (hok) T[buf ^ 1][hr][hc] = bz_cdiv(p_h, LV.rho_f(k + 1), LV.rrho_f(k + 1));
+        if (hok) T[buf ^ 1][hr][hc] = ST ? p_h : bz_cdiv(p_h, LV.rho_f(k + 1), LV.rrho_f(k + 1));
         __syncthreads();
         {
             double nb = __shfl_down(fx, 1);
@@ -1016,17 +1056,23 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
             if (tx == le) nb = e;
             const double dx = nb - fx;
             const double dy = FY[buf][ty + 1][tx] - fy;
-            const double adv = -(LV.Vinv_f(k) * (dx + dy + (fz_hi - fz_lo)));
+            const double adv = -((ST ? g.Vinv_f[k] : LV.Vinv_f(k)) * (dx + dy + (fz_hi - fz_lo)));
+            double Gval;
+            if constexpr (BM == 2) Gval = adv - (b_hi - b_lo) * g.rdzf[k] - g.g * ((r_hi + r_lo) / 2.0);
+            else if constexpr (BM == 1) Gval = adv;
+            else Gval = adv + 0.5 * (b_lo + b_hi);
             if (store)
-                L.out[n] = bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out, adv + 0.5 * (b_lo + b_hi), raw0, n);
+                L.out[n] = (ST && E.mode == 0) ? Gval : bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out, Gval, uold, n);
         }
         fz_lo = fz_hi;
         b_lo = b_hi;
+        r_lo = r_hi;
 #pragma unroll
         for (int s = 0; s < 3; ++s) { qu[s] = qu[s + 1]; qv[s] = qv[s + 1]; qt[s] = qt[s + 1]; qw[s] = qw[s + 1]; }
         qu[3] = qun; qv[3] = qvn; qt[3] = qtn; qw[3] = qwnew;
         raw0 = raw1; raw1 = raw2; raw2 = tcur_raw;
         tcur_raw = p_top; u0cur = p_u0;
+        if (ST) tcur_v = p_topv;
 #pragma unroll
         for (int s = 0; s < 5; ++s) wr[s] = wr[s + 1];
         wr[5] = wnew;

@@ -53,6 +53,7 @@ void bzi_read_tuning(bz_tuning &t)
     t.no_lean = on("BZ_NO_LEAN");
     t.no_xcd = on("BZ_NO_XCD");
     t.no_k6_stored = on("BZ_NO_K6_STORED");
+    t.no_closure_march = on("BZ_NO_CLOSURE_MARCH");
     t.no_dry_shortcut = on("BZ_NO_DRY_SHORTCUT");
     t.side_scalar = on("BZ_SIDE_SCALAR");
     t.side_cus = num("BZ_SIDE_CUS", 0);

@@ -299,6 +299,7 @@ struct bz_tuning {
     int tend_gen = 0;                 // BZ_TEND_GEN (0: default)
     bool no_lean = false;             // BZ_NO_LEAN: fused-RK tier instead of the lean (prognostic-only) seam
     bool no_xcd = false;              // BZ_NO_XCD: hardware block order in the lean kernels
+    bool no_closure_march = false;    // BZ_NO_CLOSURE_MARCH: the cell-per-thread closure kernels everywhere
     bool no_k6_stored = false;        // BZ_NO_K6_STORED: the stored-velocity tiers keep the fourth-generation tile kernels (k_{u,v,w}_tend_lds)
     bool no_dry_shortcut = false;     // BZ_NO_DRY_SHORTCUT: the lean kernels always carry rho q (no moisture scan)
     bool side_scalar = false;         // BZ_SIDE_SCALAR: scalar kernel beside the pressure solve on one GPU too

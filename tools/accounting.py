@@ -65,6 +65,13 @@ COMPULSORY_WORDS = {
     "z_momentum_tendency+rk3": (8, 8, 8),              # + T, q
     "scalar_tendencies+rk3": (11, 11, 11),             # R u, v, w, theta, q, rho_theta, rho_q, U0 x 2 (R or W); W rho_theta, rho_q
     "potential_temperature_tendency+rk3": (7, 7, 7), "moisture_tendency+rk3": (7, 7, 7),
+    "project_and_diagnose+saturation_adjustment": 18,  # project_and_diagnose + W q^v, q^l (bz_fused.hip: k_project_diagnose<1>)
+    # closure = SmagorinskyLilly and the column-forcing stack of BASELINE configs[2] (bz_closure.hip, bz_forcing.hip)
+    "smagorinsky_viscosity": 6,                        # R u, v, w, T, q^v; W nu_e
+    "closure_tendencies": 16,                          # R u, v, w, nu_e, theta, q; R + W predictor x 3, rho_theta, rho_q
+    "forcing_tendencies": 10,                          # R u, v (Coriolis / subsidence gradients are column data); R + W predictor x 2, rho_theta, rho_q
+    "subsidence_averages": 4,                          # R u, v, theta, q (horizontal means; one word per cell each)
+    "flux_bc_tendencies": 0.0,                         # bottom plane only: no 3-D array
     # per-operator kernels (one array list per operator, as SURVEY §8d counts them)
     "x_momentum_tendency": 5, "y_momentum_tendency": 5, "z_momentum_tendency": 7, "potential_temperature_tendency": 6,
     "moisture_tendency": 6, "scalar_tendencies": 11, "scalar_tendency": 5, "ssp_rk3_substep": 20, "ssp_rk3_substep+store_initial_state": 20,

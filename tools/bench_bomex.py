@@ -78,10 +78,28 @@ def main():
     cells = Nx * Ny * Nz
     ql = m.microphysical_fields["qˡ"].interior
     w = m.velocities["w"].interior
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from accounting import HBM_PEAK_GBS, compulsory_words, roofline_block, step_compulsory_words
+    word = 4 if a.float32 else 8
+    kern = {k: {"avg_ms": v[0] / v[1], "launches": v[1], "total_ms": v[0]} for k, v in prof.items() if v[1]}
+    # project_and_diagnose of a saturation-adjustment model writes q^v, q^l as well
+    words_of = lambda k: compulsory_words("project_and_diagnose+saturation_adjustment" if k == "project_and_diagnose" else k)      # noqa: E731
+    known = [k for k in kern if words_of(k)]
+    dom = max(known, key=lambda k: kern[k]["total_ms"]) if known else None
+    roofline = roofline_block(dom, kern[dom]["avg_ms"], cells, word, words=words_of(dom)) if dom else None
+    step_words = sum(words_of(k) * v["launches"] / a.steps for k, v in kern.items() if words_of(k))
+    step_gbs = cells / (ms * 1e-3) * step_words * word / 1e9
     out = {"metric": "grid-cells advanced/sec, BOMEX-shaped anelastic SSP-RK3 step (WENO + saturation adjustment + SmagorinskyLilly + forcing stack)", "weno_order": a.order,
            "value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": a.dt,
            "forcing": not a.no_forcing, "closure": None if a.no_closure else "SmagorinskyLilly", "dtype": "f32" if a.float32 else "f64",
            "kernels_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items())},
+           "kernel_launches_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
+           # one accounting (tools/accounting.py): the dominant kernel group and the whole step in COMPULSORY bytes against 8 TB/s.  At this size
+           # (8.4 M cells: 67 MB per Float64 array) every array of a kernel fits the 256 MB Infinity Cache, so the HBM roof is not what bounds
+           # these kernels — the fractions say how far the launch / latency / issue floor of a small grid sits below it
+           "roofline": roofline,
+           "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
+                             "bytes": "compulsory", "compulsory_words_per_cell_step": step_words, "unpriced_groups": sorted(k for k in kern if not words_of(k))},
            "step_contract_frac_of_8TBs": cells * (1000 if a.float32 else 2000) / (ms * 1e-3) / 8e12,
            "finite": bool(torch.isfinite(w).all().item()), "w_max": float(w.abs().max().item()),
            "cloud_fraction": float((ql > 0).double().mean().item())}

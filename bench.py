@@ -66,13 +66,19 @@ def took_dry_path(kernels):
     return "moisture_scan" in kernels
 
 
-def dominant_roofline(kernels, cells, word_bytes, f32=False, with_traffic=True, exclude=("comm_", "moisture_scan"), dry=False):
+def dominant_roofline(kernels, cells, word_bytes, f32=False, with_traffic=True, exclude=("comm_", "moisture_scan"), dry=False, general_body=False):
     """`roofline` of the kernel group with the largest share of the timed region, among the groups tools/accounting.py can price."""
     known = [k for k in kernels if compulsory_words(k) is not None and not k.startswith(exclude)]
     if not known:
         return None
     dom = max(known, key=lambda k: kernels[k]["total_ms"])
-    traffic, src = load_traffic(ROOT, dom, f32) if with_traffic else (None, None)
+    traffic, src = (None, None)
+    if with_traffic:
+        # the general body of the lean scalar-pair / z-momentum kernels has PMC rows of its own (tools/pmc_to_traffic.py)
+        if general_body:
+            traffic, src = load_traffic(ROOT, dom + " (general body)", f32)
+        if traffic is None:
+            traffic, src = load_traffic(ROOT, dom, f32)
     return roofline_block(dom, kernels[dom]["avg_ms"], cells, word_bytes, traffic, src, dry=dry)
 
 
@@ -99,7 +105,7 @@ def moist_variant(model, dt, steps=5):
     # separate kernels (k5_scalar_pair<8, false, DRYQ, GUARD>, k6_w<...>), so the rows of a rocprofv3 run separate as well
     return {"ms_per_step": ms, "steps": steps, "moisture": "q^t = 5e-3 exp(-z / 2500 m)",
             "value": cells / (ms * 1e-3), "unit": "cells/s",
-            "roofline": dominant_roofline(k, cells, 8, with_traffic=False, dry=False),
+            "roofline": dominant_roofline(k, cells, 8, with_traffic=(cells == 512 ** 3), dry=False, general_body=True),
             "step_roofline": step_roofline(k, steps, cells / (ms * 1e-3), 8, dry=False),
             "kernels_ms_per_step": {n: v["total_ms"] / steps for n, v in sorted(k.items())},
             "kernel_launches_per_step": {n: v["launches"] / steps for n, v in sorted(k.items())},

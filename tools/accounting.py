@@ -144,7 +144,7 @@ def roofline_block(group, avg_launch_ms, cells, word_bytes, traffic_bytes=None, 
     return out
 
 
-def load_traffic(root, group, f32=False, files=("r04_pmc_traffic.json", "r03_pmc_traffic.json")):
+def load_traffic(root, group, f32=False, files=("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")):
     """HBM-side bytes per launch of a kernel group from the newest committed PMC file that has it -> (bytes, 'profiles/<file>')."""
     import json
     import os
@@ -162,7 +162,13 @@ def load_traffic(root, group, f32=False, files=("r04_pmc_traffic.json", "r03_pmc
 # regular expressions on the demangled name with the `_f32` suffix of the Float32 twin removed; first match wins
 KERNEL_GROUPS = [
     (r"^k5_scalar_pair<", "scalar_tendencies+rk3+thermo"),
+    # stored-velocity instantiations of the sixth-generation kernels (round 5: k6_u / k6_v<TY, MF, WY, ST = true>, k6_w<.., BM = 0 .. 3>): the
+    # per-operator groups (in the default bench command they are the slow tendencies of the compressible leg)
+    (r"^k6_u<\d+, \w+, \w+, true>", "x_momentum_tendency"), (r"^k6_v<\d+, \w+, \w+, true>", "y_momentum_tendency"),
+    (r"^k6_w<\d+, \w+, \w+, \w+, [0-3]>", "z_momentum_tendency"),
     (r"^k6_u<", "x_momentum_tendency+rk3+velocity"), (r"^k6_v<", "y_momentum_tendency+rk3+velocity"), (r"^k6_w<", "z_momentum_tendency+rk3+velocity"),
+    (r"^k_closure_march<", "closure_tendencies"), (r"^k_closure_tendencies", "closure_tendencies"),
+    (r"^k_smagorinsky_march<", "smagorinsky_viscosity"), (r"^k_smagorinsky_viscosity", "smagorinsky_viscosity"),
     (r"^k_project_lean", "project_momentum"), (r"^k_project_diagnose<", "project_and_diagnose"),
     (r"^k_x_forward<1", "poisson_source_term+fft_x"), (r"^k_x_inverse", "poisson_fft_x_inverse"), (r"^k_tridiag_", "poisson_tridiagonal"),
     (r"^fft_rtc_fwd_", "poisson_fft_y_forward"), (r"^fft_rtc_back_", "poisson_fft_y_inverse"),
@@ -183,6 +189,8 @@ def kernel_variant(name):
     A guarded launch (GUARD = true) of the body that does not apply returns at once: such rows average a few microseconds."""
     head = name.split("(")[0]
     head = head[5:] if head.startswith("void ") else head
+    if re.match(r"^k6_w(?:_f32)?<\s*\d+\s*,\s*\w+\s*,\s*\w+\s*,\s*\w+\s*,\s*[0-3]\s*>", head):
+        return None      # stored-velocity instantiations: no moisture-scan dispatch
     m = re.match(r"^(?:k5_scalar_pair|k6_w)(?:_f32)?<\s*\d+\s*,\s*(?:true|false)\s*,\s*(true|false)", head)
     if not m:
         return None

@@ -185,7 +185,11 @@ int bz_make_pressure_correction(bz_ctx *ctx, const bz_state *s, double dt);
  * maybe_prepare_first_time_step! does).
  * NOTE: this seam folds each ssp_rk3_substep! into the preceding tendency evaluation, so on return the G arrays hold
  * the last stage's predictor momentum instead of tendencies (they are scratch of the time stepper in the reference as
- * well); bz_compute_tendencies / bz_update_state rebuild them, and bz_ssp_rk3_substep does so automatically. */
+ * well); bz_compute_tendencies / bz_update_state rebuild them, and bz_ssp_rk3_substep does so automatically.
+ * U0 CONTRACT: the U0 arrays are the time stepper's scratch and their contents are UNDEFINED after a step.  The reference fills them
+ * with the step-start state (store_initial_state!) and nothing outside time_step! reads them; the lean tier never copies the state into
+ * them (the state arrays stay intact as U0 until the last writer of the step) and parks stage-1/2 momentum and stage-2 scalars there,
+ * the compressible step stores interior cells only.  No entry point of this library reads U0 (or its halos) across calls. */
 int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
                            const bz_prognostic *G, double dt);
 
@@ -198,7 +202,10 @@ int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *
  *   diagnose_last != 0: on return every field and halo of `s` holds the bits n calls of bz_time_step_anelastic leave.
  *   diagnose_last == 0: the prognostic state is current but the diagnostics (and pressure_anomaly) are stale and rho_theta / rho_q may be
  *     parked in G->rho_theta / G->rho_q (the kernels' ping-pong partner).  Stepping may simply continue (either entry point);
- *     before anything else reads `s`, call bz_update_state(ctx, s, G, 0).  bz_diagnostics_stale(ctx) reports the flag. */
+ *     before anything else reads `s`, call bz_update_state(ctx, s, G, 0).  bz_diagnostics_stale(ctx) reports the flag.
+ *     Entry points of this library that read the diagnostics and are handed the state rebuild them first (bz_compute_tendencies,
+ *     bz_compute_closure_fields, bz_compute_forcings, bz_compute_flux_bc_tendencies, bz_kessler_model_update); bz_cell_advection_timescale,
+ *     which takes bare velocity pointers, returns BZ_ERR_INVALID while the flag is set; bz_sync joins a pending halo exchange of a slab context. */
 int bz_time_steps_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
                             const bz_prognostic *G, double dt, int n, int diagnose_last);
 int bz_diagnostics_stale(const bz_ctx *ctx);

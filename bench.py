@@ -104,6 +104,7 @@ def moist_variant(model, dt, steps=5):
     # lists (rho q read, advected and written; tools/accounting.py COMPULSORY_WORDS).  Since round 5 the dry and the general bodies are
     # separate kernels (k5_scalar_pair<8, false, DRYQ, GUARD>, k6_w<...>), so the rows of a rocprofv3 run separate as well
     return {"ms_per_step": ms, "steps": steps, "moisture": "q^t = 5e-3 exp(-z / 2500 m)",
+            "stepping": "bz_time_steps_anelastic(n = K, diagnose_last = 1), the headline's seam and K",
             "value": cells / (ms * 1e-3), "unit": "cells/s",
             "roofline": dominant_roofline(k, cells, 8, with_traffic=(cells == 512 ** 3), dry=False, general_body=True),
             "step_roofline": step_roofline(k, steps, cells / (ms * 1e-3), 8, dry=False),
@@ -944,7 +945,7 @@ def run_rank(args):
                 out["preflight"] = preflight_summary
         if world == 1 and not use_slabs and args.workload == "bubble" and not args.no_moist_variant:
             try:
-                out["moist_variant"] = moist_variant(model, dt)
+                out["moist_variant"] = moist_variant(model, dt, steps=args.steps)      # the same K as the headline: one diagnosis pass per K steps in both legs
             except Exception as exc:       # never let the side measurement take the headline line down
                 out["moist_variant"] = {"error": repr(exc)}
         if world == 1 and not args.no_compressible and not use_slabs and args.workload == "bubble":

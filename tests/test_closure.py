@@ -261,3 +261,38 @@ def test_tracers_diffuse_with_the_closure(oracle, bz, whole_step):
     for _ in range(3):
         om2.time_step(3.0)
     assert np.abs(og.interior(om2.rc1) - og.interior(om.rc1)).max() > 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("moist", [False, True])
+def test_marching_closure_kernels_on_whole_tiles(oracle, bz, moist, monkeypatch):
+    """Round 5: on grids of whole 64 x 8 tiles the eddy viscosity and the five closure divergences run as z-marching LDS-tiled kernels
+    (csrc/bz_closure.hip: k_smagorinsky_march, k_closure_march; the grids of the tests above are narrower than a tile and keep the
+    cell-per-thread kernels).  Same expressions in the same order: nu_e and every tendency carry the BITS of the cell-per-thread kernels
+    (BZ_NO_CLOSURE_MARCH=1), and both match the oracle as above.  Three chunks of levels, so chunk seams are crossed."""
+    size = (64, 16, 48)
+
+    def run(no_march):
+        if no_march:
+            monkeypatch.setenv("BZ_NO_CLOSURE_MARCH", "1")
+        else:
+            monkeypatch.delenv("BZ_NO_CLOSURE_MARCH", raising=False)
+        om, hm = _pair(oracle, bz, size=size, moist=moist)
+        om.set(**_turbulent_ic(om, 5))
+        om.update_state()
+        push_state(om, hm, names=("ru", "rv", "rw", "rtheta", "rq"))
+        bz.update_state_(hm, compute_tendencies=True)
+        hm.synchronize()
+        return om, hm
+
+    om, a = run(False)
+    _, b = run(True)
+    nu_a, nu_b = a.closure_fields["νₑ"].interior_cpu(), b.closure_fields["νₑ"].interior_cpu()
+    assert np.array_equal(nu_a, nu_b)
+    assert np.abs(nu_a - om.nu_e).max() < 1e-11 * om.nu_e.max()
+    strict = "refdiv" in bz.LIB_PATH
+    for n, k in PROG.items():
+        ga, gb = a.G[k].interior_cpu(), b.G[k].interior_cpu()
+        assert np.array_equal(ga, gb), n
+        want = om.grid.interior(om.G[n], zface=(n == "rw"))
+        assert relerr(ga, want) < (1e-12 if strict else 5e-9), n

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_project_lean(DevGrid g, PLFields F, dou
 
 #include "bz_xfft_kernels.h"
 
-static size_t xf_lds_bytes(int n2) { return ((size_t)XF_RB * XF_ROW_STRIDE(n2) + 3 * n2 / 2 + XF_WST_SLOTS(n2)) * sizeof(double2); }
+static size_t xf_lds_bytes(int n2) { return ((size_t)XF_RB * XF_ROW_STRIDE(n2) + xf_w_entries(n2) + XF_WST_SLOTS(n2)) * sizeof(double2); }
 // levels one block of the x-transform kernels walks: 16 on large grids (the twiddle table is staged once per block), fewer when
 // that would leave less than ~1024 blocks for the 256 CUs (64^3: 32 blocks of 16 levels took 52 us, 512 blocks of one level 1/3 of that)
 static int xf_chunk(int forced, int dflt, const DevGrid &g)

@@ -118,7 +118,7 @@ int bzi_scan_moisture_field(bz_ctx *ctx, const double *rho_q)
         ctx->q_host = 0;
     }
     // the verdict of the previous call's scan, if it has landed (asynchronous copy, never waited for)
-    if (ctx->q_pending && hipEventQuery(ctx->ev_q) == hipSuccess) { ctx->q_host = *ctx->h_qstate; ctx->q_pending = false; }
+    if (ctx->q_pending && !ctx->comm && hipEventQuery(ctx->ev_q) == hipSuccess) { ctx->q_host = *ctx->h_qstate; ctx->q_pending = false; }
     if (ctx->q_host == 2) return BZ_OK;      // moist is sticky on the device (until bz_update_state) and on every rank of a slab communicator alike: nothing to scan
     // an undiagnosed last stage leaves the halo exchange of rho q on the side stream: the scan reads those rows
     if (ctx->comm && (rc = bzi_comm_join_pending(ctx))) return rc;
@@ -138,9 +138,12 @@ int bzi_scan_moisture_field(bz_ctx *ctx, const double *rho_q)
     }
     if (ctx->graph_capturing) return BZ_OK;      // (never: the scan precedes the recorded region)
     BZ_HIP(hipMemcpyAsync(ctx->h_qstate, ctx->d_qstate, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->q_host == 0) {
+    if (ctx->q_host == 0 || ctx->comm) {
         // first scan since update_state!: read the verdict back before the first tendency launch — one host wait per set! / first step —
-        // so that from here on the host launches the body that applies (separate kernels, separate rocprofv3 rows)
+        // so that from here on the host launches the body that applies (separate kernels, separate rocprofv3 rows).
+        // Slab communicators read it back at EVERY call: the asynchronous path below lands at a rank-dependent time, and a rank that has
+        // learnt "moist" stops scanning — its peers would wait for it in the scan's all-reduce.  Read synchronously, the (all-reduced)
+        // verdict is the same on every rank at the same call
         BZ_HIP(hipStreamSynchronize(ctx->stream));
         ctx->q_host = *ctx->h_qstate;
         ctx->q_pending = false;

@@ -166,6 +166,17 @@ __device__ __forceinline__ void xf_stage_twiddles(double2 *__restrict__ Wst, con
     }
 }
 #define XF_WST_SLOTS(n2) (n2)
+// entries of the natural-order table exp(-2 pi i t / Nx) a workgroup keeps in LDS: the split reads W[p], p <= n2 / 2; only the radix-2 stage of
+// transforms whose length is not 3^a 4^b reads further (W[2 b], b < n2 / 2).  Round 5: rows of 512 cells (n2 = 256 = 4^4) keep 132 entries
+// instead of 384 — 39.5 KB of LDS per workgroup instead of 43.4, i.e. FOUR workgroups per CU instead of three for kernels that spend most of
+// their wave time parked on the load -> barrier -> stages -> store chain of a level (counter table)
+__host__ __device__ inline int xf_w_entries(int n2)
+{
+    int m = n2;
+    if (m % 3 == 0) m /= 3;
+    while (m % 4 == 0) m /= 4;
+    return (m == 1) ? (n2 / 2 + 4) : (3 * n2 / 2);      // m == 2: a radix-2 stage closes the transform
+}
 
 // Z = transform of the packed row z[n] = x[2n] + i x[2n+1]  ->  X[0 .. n2] of the real row, in place (row has n2 + 1 slots).
 // Pairs (p, n2 - p) are independent: no barrier between a pair's reads and writes.
@@ -238,8 +249,9 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_forward(DevGrid g, const 
     const int nthreads = blockDim.x;
     const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
     double2 *__restrict__ W = xf_sm + XF_RB * RS;
-    double2 *__restrict__ Wst = W + 3 * n2 / 2;
-    for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
+    const int wn = xf_w_entries(n2);
+    double2 *__restrict__ Wst = W + wn;
+    for (int t = threadIdx.x; t < wn; t += nthreads) W[t] = Wg[t];
     xf_stage_twiddles(Wst, Wg, n2, threadIdx.x, nthreads);
     __syncthreads();                                       // the twiddle tables are loaded by all waves
     const int j0 = blockIdx.x * XF_RB, j = j0 + r;
@@ -307,8 +319,9 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_inverse(DevGrid g, const 
     const int nthreads = blockDim.x;
     const int r = threadIdx.x / T, tid = threadIdx.x - r * T;
     double2 *__restrict__ W = xf_sm + XF_RB * RS;
-    double2 *__restrict__ Wst = W + 3 * n2 / 2;
-    for (int t = threadIdx.x; t < 3 * n2 / 2; t += nthreads) W[t] = Wg[t];
+    const int wn = xf_w_entries(n2);
+    double2 *__restrict__ Wst = W + wn;
+    for (int t = threadIdx.x; t < wn; t += nthreads) W[t] = Wg[t];
     xf_stage_twiddles(Wst, Wg, n2, threadIdx.x, nthreads);
     const int j0 = blockIdx.x * XF_RB;
     const int kbeg = L.klo + blockIdx.y * kchunk, kend = min(kbeg + kchunk, L.khi);

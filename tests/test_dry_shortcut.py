@@ -163,3 +163,55 @@ def test_dry_slab_ranks_keep_the_shortcut_and_its_bits(bz, monkeypatch):
         for k in fa:
             assert np.array_equal(fa[k], fb[k]), k
         assert float(np.abs(ma.moisture_density.cpu()).max()) == 0.0
+
+
+def test_moisture_written_behind_a_slab_rank_between_calls(bz, monkeypatch):
+    """two ranks step a dry domain (verdict "dry" on both), then rank 0 alone gets vapour written straight into its array and both step on:
+    the next call's all-reduced scan must turn BOTH ranks moist at the same call (a rank that kept scanning while its peer had stopped
+    would hang in the all-reduce), and the result carries the bits of the run that never takes the shortcut"""
+    import threading
+    import uuid
+    import torch
+    from breeze_jl_amd import distributed as bz_dist
+    size = (32, 32, 16)
+
+    def run_all():
+        G = bz.RectilinearGrid(size, x=(-10e3, 10e3), y=(-10e3, 10e3), z=(0, 10e3))
+        group = "local:" + uuid.uuid4().hex
+        models, errors = [None, None], []
+
+        def run(rank):
+            try:
+                torch.cuda.set_device(0)
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    m = bz_dist.SlabAtmosphereModel(G, rank, 2, advection=bz.WENO(), potential_temperature=300, device="cuda:0", transport=group)
+                    m.set(θ=bubble_theta(300.0, 9.81), u=3.0, v=40.0)
+                    m.time_steps(2.0, 2)
+                    m.synchronize()
+                    if rank == 0:      # behind the library's back: interior rows 4 .. 9 of rank 0's slab
+                        m.moisture_density.interior[:, 4:10, :] = 4e-3
+                    m.time_steps(2.0, 2)
+                    m.time_steps(2.0, 1)
+                    m.synchronize()
+                models[rank] = m
+            except Exception as e:      # noqa: BLE001
+                import traceback
+                errors.append((rank, repr(e), traceback.format_exc()))
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in threads), "a rank hung"
+        assert not errors, errors
+        return models
+
+    a = run_all()
+    monkeypatch.setenv("BZ_NO_DRY_SHORTCUT", "1")
+    b = run_all()
+    for ma, mb in zip(a, b):
+        fa, fb = _fields(ma), _fields(mb)
+        for k in fa:
+            assert np.array_equal(fa[k], fb[k]), k
+    assert float(np.abs(a[0].moisture_density.interior_cpu()).max()) > 0.0

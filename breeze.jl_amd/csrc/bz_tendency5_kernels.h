@@ -31,6 +31,21 @@
 #ifndef BZ6_UNROLL2
 #define BZ6_UNROLL2 0
 #endif
+#ifndef BZ6_LDS_BARRIER
+#define BZ6_LDS_BARRIER 0
+#endif
+// per-level barrier of the sixth-generation kernels: __syncthreads(), or (experiments) the LDS-scoped release / s_barrier / acquire idiom that
+// leaves the level's global loads and stores in flight across it (bz_poisson.hip: tco_lds_barrier)
+__device__ __forceinline__ void bz6_barrier()
+{
+#if BZ6_LDS_BARRIER
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    __syncthreads();
+#endif
+}
 typedef long long ix_t;
 typedef unsigned ix32_t;     // z-momentum kernel: 32-bit (138 -> 121 VGPRs, 3 -> 4 waves per SIMD; measured 3.61 -> 2.94 ms)
 
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
             if (h1raw) RU[buf ^ 1][h1r - 3][h1c] = ST ? p_h1raw : p_h1;
         }
         if (h2ok) { if (h2sel) RW[buf ^ 1][h2r][h2c] = p_h2; else RV[buf ^ 1][h2r][h2c] = p_h2; }
-        if (!(BZ_KO & 16384) && (!(BZ_KO & 8192) || ((k - kbeg) & 1))) __syncthreads();
+        if (!(BZ_KO & 16384) && (!(BZ_KO & 8192) || ((k - kbeg) & 1))) bz6_barrier();
         {
             double nb = __shfl_up(fx, 1);
             const double e = __shfl(edge, src);
@@ -856,7 +871,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
 #pragma unroll
         for (int q = 0; q < HPT; ++q)
             if (hok[q]) frame_store(buf ^ 1, q, hnext[q], k + 1);
-        __syncthreads();
+        bz6_barrier();
         {
             double nb = __shfl_down(fx, 1);
             const double e = __shfl(edge, src);
@@ -1049,7 +1064,7 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
         else if constexpr (BM == 2) { b_hi = Tcur - g.p_r[k]; r_hi = rqcur - g.rho[k]; }
         T[buf ^ 1][ty + 3][tc] = wr[4];
         if (hok) T[buf ^ 1][hr][hc] = ST ? p_h : bz_cdiv(p_h, LV.rho_f(k + 1), LV.rrho_f(k + 1));
-        __syncthreads();
+        bz6_barrier();
         {
             double nb = __shfl_down(fx, 1);
             const double e = __shfl(edge, src);

@@ -528,3 +528,47 @@ def test_float32_mixed_orders_with_a_sponge_match_the_float64_oracle(oracle, bz)
     e = _steps_errors(om, hm, [(n, hm.prognostic_fields()[k]) for n, k in PROG.items()])
     print("float32 mixed orders + sponge:", {k: f"{v:.1e}" for k, v in e.items()})
     assert max(e.values()) < 1e-4, e
+
+
+@pytest.mark.gpu
+def test_float32_marching_closure_kernels_carry_the_bits_of_the_cell_per_thread_kernels(oracle, bz, monkeypatch):
+    """Round 5: on whole 64 x 8 tiles SmagorinskyLilly runs as z-marching LDS-tiled kernels (csrc/bz_closure.hip); the Float32 twin of
+    those kernels against the Float32 cell-per-thread kernels (BZ_NO_CLOSURE_MARCH=1): nu_e and every tendency bit for bit, three steps
+    of the BOMEX physics list bit for bit (same expressions, same order)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_closure import _turbulent_ic
+    from test_forcings import EXTENT, _hip_forcing_kwargs
+    size = (64, 16, 32)
+    og = oracle.Grid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+    om = oracle.OracleModel(og, surface_pressure=101500.0, potential_temperature=299.1)
+    ic = _turbulent_ic(om, 7)
+
+    def run(no_march):
+        if no_march:
+            monkeypatch.setenv("BZ_NO_CLOSURE_MARCH", "1")
+        else:
+            monkeypatch.delenv("BZ_NO_CLOSURE_MARCH", raising=False)
+        grid = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2], float_type=np.float32)
+        ref = bz.ReferenceState(grid, surface_pressure=101500.0, potential_temperature=299.1)
+        hm = bz.AtmosphereModel(grid, dynamics=bz.AnelasticDynamics(ref), advection=bz.WENO(order=5), closure=bz.SmagorinskyLilly(),
+                                microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()), **_hip_forcing_kwargs(bz))
+        hm.set(θ=ic["theta"], qᵗ=ic["qt"], u=ic["u"], v=ic["v"])
+        bz.update_state_(hm, compute_tendencies=True)
+        hm.synchronize()
+        first = {"nu": hm.closure_fields["νₑ"].interior_cpu().copy()}
+        first.update({k: f.interior_cpu().copy() for k, f in hm.G.items()})
+        for _ in range(3):
+            hm.time_step(3.0)
+        hm.synchronize()
+        return first, {k: f.interior_cpu() for k, f in hm.prognostic_fields().items()}
+
+    fa, sa = run(False)
+    fb, sb = run(True)
+    assert fa["nu"].max() > 0
+    for k in fa:
+        assert np.array_equal(fa[k], fb[k]), k
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+        assert np.isfinite(sa[k]).all(), k

@@ -73,7 +73,9 @@ struct ForcingCols {
 
 // SCALARS = false: the stack holds momentum terms only (Coriolis, geostrophic / u, v profiles — the CBL benchmark case): the
 // theta / moisture arrays are not touched (the general form read-modify-writes all four: 8 words per cell instead of 4 + 2)
-template <bool SCALARS>
+// MOMENTUM = false (round 5): the momentum terms went into the RK epilogues of the stored-velocity momentum kernels
+// (bz_tendency5.hip: bzi_k6_stored with bz_ctx::fold_momentum_forcing); only rho theta / rho q are read-modify-written
+template <bool SCALARS, bool MOMENTUM = true>
 __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F, double *__restrict__ Gu,
                                                         double *__restrict__ Gv, double *__restrict__ Gth,
                                                         double *__restrict__ Gq, const double *__restrict__ ru,
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F
     bool any;
     // wall faces (v at j = 0 of a Bounded y, u at i = 0 of a Bounded x) carry no tendency: the wall-aware tendency kernels never write
     // G there, so anything added here would pile up from evaluation to evaluation; as k_apply_relaxation
-    if (!(g.bounded_x && i == 0)) {
+    if (MOMENTUM && !(g.bounded_x && i == 0)) {
         double G = Gu[n];
         if (F.f != 0.0) {
             const double a = (rv[n - sx] + rv[n - sx + sy]) / 2, b = (rv[n] + rv[n + sy]) / 2;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void k_apply_forcings(DevGrid g, ForcingCols F
         if (any) G += scale * t;
         Gu[n] = G;
     }
-    if (!(g.bounded_y && j == 0)) {
+    if (MOMENTUM && !(g.bounded_y && j == 0)) {
         double G = Gv[n];
         if (F.f != 0.0) {
             const double a = (ru[n - sy] + ru[n - sy + sx]) / 2, b = (ru[n] + ru[n + sx]) / 2;
@@ -447,11 +449,13 @@ extern "C" int bz_compute_forcings(bz_ctx *ctx, const bz_state *s)
 // the forcing + Coriolis terms of compute_tendencies!, added to the advective tendencies already in G
 // scale = 1 adds to tendencies; the whole-step seam passes scale = alpha dt and the arrays the fused RK update just wrote
 // (predictor momentum in G, rho_theta / rho_q in place): u_new = (1-alpha) u0 + alpha (u + dt (G + F)) either way.
-int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale)
+int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale, bool momentum_done)
 {
     const DevGrid &g = ctx->dg;
     const int Nz = g.Nz;
-    int rc = bz_compute_forcings(ctx, s);
+    // momentum_done: the caller computed the stage's subsidence profiles (bz_compute_forcings) before its tendency launches and the
+    // momentum kernels carried Coriolis / u, v profiles / u, v subsidence in their epilogues
+    int rc = momentum_done ? BZ_OK : bz_compute_forcings(ctx, s);
     if (rc) return rc;
     ProfileScope ps(ctx, "forcing_tendencies");
     ForcingCols F;
@@ -464,7 +468,12 @@ int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, d
     F.Fe = (m & 16) ? base + (size_t)4 * Nz : nullptr;
     F.sub = ctx->forcing_subsidence_mask ? base + (size_t)5 * Nz + (Nz + 1) + (size_t)4 * Nz : nullptr;
     F.f = ctx->forcing_f;
-    if (F.Fth || F.Fq || F.Fe || (ctx->forcing_subsidence_mask & 12))
+    const bool scalars = F.Fth || F.Fq || F.Fe || (ctx->forcing_subsidence_mask & 12);
+    if (momentum_done) {
+        if (scalars)
+            hipLaunchKernelGGL((k_apply_forcings<true, false>), dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, F, Gu, Gv, Gth, Gq,
+                               s->rho_u, s->rho_v, s->q, scale);
+    } else if (scalars)
         hipLaunchKernelGGL(k_apply_forcings<true>, dim3((g.Nx + 255) / 256, g.Ny, g.Nz), dim3(256), 0, ctx->stream, g, F, Gu, Gv, Gth, Gq,
                            s->rho_u, s->rho_v, s->q, scale);
     else

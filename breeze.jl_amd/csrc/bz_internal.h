@@ -306,6 +306,7 @@ struct bz_tuning {
     int side_cus = 0;                 // BZ_SIDE_CUS=N: the side stream is created on N of the GPU's CUs (CU mask)
     int side_cu_layout = 0;           // BZ_SIDE_CU_LAYOUT (experiments): 0 the first N mask bits, 1 every (total / N)-th bit
     bool no_fuse_forcing = false;     // BZ_NO_FUSE_FORCING
+    bool no_fold_forcing = false;     // BZ_NO_FOLD_FORCING: the fused-RK tier keeps the momentum terms of the forcing stack in the forcing pass
     bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms
     int poisson_chunk = 0;            // BZ_POISSON_CHUNK: level-chunked Poisson pipeline (needs BZ_NO_XFFT)
@@ -430,6 +431,7 @@ struct bz_ctx {
     bool has_forcings = false;
     double *d_forcing = nullptr;      // static profiles, subsidence velocity, level averages, subsidence profiles, partial sums
     int forcing_static_mask = 0, forcing_subsidence_mask = 0;
+    bool fold_momentum_forcing = false;      // set by the fused-RK tier around its tendency launches: bzi_k6_stored folds the momentum terms of the stack
     double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0, forcing_drag_eps = 0.0, forcing_flux_energy = 0.0;
     // BulkDrag / BulkSensibleHeatFlux / BulkVaporFlux bottom conditions (bz_set_bulk_surface_fluxes, bz_forcing.hip)
     bool has_bulk = false;
@@ -523,7 +525,7 @@ struct ProfileScope {
 
 // internal entry points shared between translation units
 int bzi_fill_halo(bz_ctx *ctx, double *f, int kind);
-int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale);
+int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale, bool momentum_done = false);
 int bzi_flux_bc(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale);
 void bzi_forcing_teardown(bz_ctx *ctx);
 int bzi_tracer_specific(bz_ctx *ctx);

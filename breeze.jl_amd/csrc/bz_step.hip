@@ -373,7 +373,14 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
         BZ_HIP(hipMemsetAsync(G->rho_w + g.Sxy * (g.Hz + g.Nz), 0, g.Sxy * sizeof(double), ctx->stream));        // predictor stay 0
         for (int stage = 0; stage < 3; ++stage) {
             const double alpha = alphas[stage];
-            if ((rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0))) return rc;
+            // momentum terms of the forcing stack in the epilogues of the stored-velocity momentum kernels (round 5): the stage's subsidence
+            // profiles are built first (from the stored u, v, theta, q of the stage start, which the tendency kernels do not touch)
+            const bool fold = ctx->has_forcings && ctx->weno_R == 3 && bzi_k6_stored_ok(ctx) && ctx->tend_lds && !ctx->tune.no_fuse_forcing && !ctx->tune.no_fold_forcing;
+            if (fold && (rc = bz_compute_forcings(ctx, s))) return rc;
+            ctx->fold_momentum_forcing = fold;
+            rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0);
+            ctx->fold_momentum_forcing = false;
+            if (rc) return rc;
             if (ctx->n_tracers) {       // tracers ride beside the fused kernels: tendency from the previous-stage state, RK in place
                 if ((rc = bzi_tracer_tendencies(ctx, s))) return rc;
                 if ((rc = bzi_tracer_rk3(ctx, dt, alpha, stage == 0))) return rc;
@@ -383,7 +390,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             if (ctx->has_forcings) {
                 // forcing, Coriolis and bottom fluxes of the stage, evaluated from the still-intact previous-stage state and
                 // added to what the fused RK update just wrote, weighted alpha dt
-                if ((rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;
+                if ((rc = bzi_apply_forcings(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt, fold))) return rc;
             }
             if ((ctx->has_forcings || ctx->has_bulk) &&
                 (rc = bzi_flux_bc(ctx, s, G->rho_u, G->rho_v, s->rho_theta, s->rho_q, alpha * dt))) return rc;

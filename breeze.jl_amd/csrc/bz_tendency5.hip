@@ -124,7 +124,7 @@ static int lean_launch(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, 
     L.lev = (const LevRow5 *)ctx->d_lev_rows + g.Hz;
     L.qstate = bzi_moisture_state(ctx);
     const int qh = L.qstate ? ctx->q_host : 2;      // the host's view of the scan's verdict (bz_step.hip); no word: the general bodies only
-    L.mforce = 0; L.cor_f = 0.0; L.Fu = ColPtr(nullptr); L.Fv = ColPtr(nullptr);
+    L.mforce = 0; L.cor_f = 0.0; L.Fu = ColPtr(nullptr); L.Fv = ColPtr(nullptr); L.Su = ColPtr(nullptr); L.Sv = ColPtr(nullptr);
     if (ctx->has_forcings && bzi_lean_forcings_ok(ctx)) {      // the stack's momentum terms ride the RK epilogues of k6_u / k6_v
         const int m = ctx->forcing_static_mask;
         L.cor_f = ctx->forcing_f;
@@ -231,7 +231,18 @@ int bzi_k6_stored(bz_ctx *ctx, int comp, const bz_state *s, const bz_prognostic 
     L.pi_dry = ColPtr(nullptr);
     L.lev = nullptr;
     L.qstate = nullptr;
-    L.mforce = 0; L.cor_f = 0.0; L.Fu = ColPtr(nullptr); L.Fv = ColPtr(nullptr);
+    L.mforce = 0; L.cor_f = 0.0; L.Fu = ColPtr(nullptr); L.Fv = ColPtr(nullptr); L.Su = ColPtr(nullptr); L.Sv = ColPtr(nullptr);
+    if (ctx->fold_momentum_forcing && Ein && comp < 2) {
+        // fused-RK tier (bz_step.hip): Coriolis, the static u / v profiles and the subsidence profiles of the stage ride the RK epilogues
+        // of the x / y momentum kernels (terms and order of k_apply_forcings); the forcing pass that follows touches the scalars only
+        const int m = ctx->forcing_static_mask, sm = ctx->forcing_subsidence_mask;
+        const double *sub = ctx->d_forcing + (size_t)5 * g.Nz + (g.Nz + 1) + (size_t)4 * g.Nz;      // 4 x Nz subsidence profiles (bz_forcing.hip)
+        L.cor_f = ctx->forcing_f;
+        if (m & 1) L.Fu = ColPtr(ctx->d_forcing);
+        if (m & 2) L.Fv = ColPtr(ctx->d_forcing + (size_t)g.Nz);
+        if (sm) { L.Su = ColPtr(sub); L.Sv = ColPtr(sub + (size_t)g.Nz); }      // (the columns of inactive fields hold zeros; k_apply_forcings adds them too)
+        L.mforce = (ctx->forcing_f != 0.0 ? 1 : 0) | ((m & 1) ? 2 : 0) | ((m & 2) ? 4 : 0) | (sm ? 8 | 16 : 0);
+    }
     L.bT = s->T; L.bq = s->q;
     L.by0 = 0; L.bys = 1;
     const dim3 block(64, TY);
@@ -244,12 +255,14 @@ int bzi_k6_stored(bz_ctx *ctx, int comp, const bz_state *s, const bz_prognostic 
         ProfileScope ps(ctx, Ein ? "x_momentum_tendency+rk3" : "x_momentum_tendency");
         if (Ein) { E.u0 = U0->rho_u; E.u0_out = U0->rho_u; }
         L.vel = s->u; L.out = G->rho_u;
-        hipLaunchKernelGGL((k6_u<TY, false, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (L.mforce) hipLaunchKernelGGL((k6_u<TY, true, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_u<TY, false, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
     } else if (comp == 1) {
         ProfileScope ps(ctx, Ein ? "y_momentum_tendency+rk3" : "y_momentum_tendency");
         if (Ein) { E.u0 = U0->rho_v; E.u0_out = U0->rho_v; }
         L.vel = s->v; L.out = G->rho_v;
-        hipLaunchKernelGGL((k6_v<TY, false, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        if (L.mforce) hipLaunchKernelGGL((k6_v<TY, true, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
+        else hipLaunchKernelGGL((k6_v<TY, false, false, true>), grid, block, 0, ctx->stream, g, L, kc, E);
     } else {
         ProfileScope ps(ctx, Ein ? "z_momentum_tendency+rk3" : "z_momentum_tendency");
         if (Ein) { E.u0 = U0->rho_w; E.u0_out = U0->rho_w; }

@@ -121,6 +121,8 @@ struct Lean5 {
     int mforce;
     double cor_f;
     ColPtr Fu, Fv;
+    ColPtr Su, Sv;                   // mforce bits 3 / 4: subsidence profiles of u / v (per-stage column data: -<w_s dz(avg)>, bz_forcing.hip: k_subsidence_profiles),
+                                     // added before the static profile as k_apply_forcings' column() does (fused-RK tier with the stored-velocity kernels)
     // ST instantiations of k6_u / k6_v / k6_w (round 5): the advected velocity is a STORED field (the fused-RK tier of models the lean seam does
     // not cover — saturation adjustment, closures, tracers, forcing stacks —, the per-operator entry points, and the slow tendencies of the
     // compressible model, where rho is a 3-D field and nothing can be derived from a column constant): vel = u | v | w of the component,
@@ -565,7 +567,7 @@ __device__ __forceinline__ double flux_x_lean(const DevGrid &g, const Tend3Field
 template <int TY, bool MF = false, bool WY = false, bool ST = false>      // MF: momentum terms of a forcing stack in the RK epilogue (Lean5::mforce); WY: walls in y
 __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
-    static_assert(!(ST && (MF || WY)), "stored-velocity instantiations: periodic / slab rows, no folded forcing");
+    static_assert(!(ST && WY), "stored-velocity instantiations: periodic / slab rows");
     constexpr int TR = TY + 6, TC = 72, NT = 64 * TY;
     constexpr int NH1 = TR * 70 - TY * 64;               // frame of the u tile (468 for TY = 8): one cell per thread
     constexpr int NH2 = 3 * (TY + 1) + 64 + 3 * TY;      // rho_v side columns + its top row + rho_w side columns (115)
@@ -642,7 +644,9 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
     for (int k = kbeg; k < kend; ++k, n += sz) {
         const ix_t lev1 = (ix_t)(k + 1 - kbeg) * sz;
         // ---- prefetch for level k+1 (consumed at the end of this iteration / in the next one) ----
-        const double p_top = ru[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];
+        // ST: the raw momentum of the next level is read where it is staged (one register) instead of riding the three-level delay line
+        // behind the ring-top load: the stored-velocity ring top took its registers
+        const double p_top = ST ? ru[n + sz] : ru[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];
         const double p_topv = ST ? vel[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)] : 0.0;
         const double p_h1 = (BZ_KO & 256) ? p_top : h1ok ? (ST ? vel : ru)[h1n + lev1] : 0.0;
         const double p_h1raw = (ST && h1raw) ? ru[h1n + lev1] : 0.0;
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
         const double fz_hi = wt * bz_upB(r[1], r[2], r[3], r[4], r[5], tnew, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
         // ---- stage level k+1 from the prefetch registers ----
         U[buf ^ 1][ty + 3][tc] = r[4];
-        RU[buf ^ 1][ty][tc] = q1;
+        RU[buf ^ 1][ty][tc] = ST ? p_top : q1;
         RV[buf ^ 1][ty][tc] = p_rv;
         RW[buf ^ 1][ty][tc] = p_rw;
         if (h1ok) {
@@ -701,7 +705,12 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
                     const double a = (rv0[-1] + rv1[-1]) / 2, b = (rv0[0] + rv1[0]) / 2;
                     Gu -= -L.cor_f * ((a + b) / 2);
                 }
-                if (L.mforce & 2) Gu += g.rho[k] * L.Fu[k];
+                if (L.mforce & (2 | 8)) {      // rho x (subsidence profile + static profile), summed in that order
+                    const double rho = g.rho[k];
+                    double tot = (L.mforce & 8) ? rho * L.Su[k] : 0.0;
+                    if (L.mforce & 2) tot = (L.mforce & 8) ? tot + rho * L.Fu[k] : rho * L.Fu[k];
+                    Gu += tot;
+                }
             }
             if (store) L.out[n] = (ST && E.mode == 0) ? Gu : bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0cur, E.u0_out, Gu, q0, n);
         }
@@ -709,8 +718,9 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
 #pragma unroll
         for (int s = 0; s < 5; ++s) r[s] = r[s + 1];
         r[5] = tnew;
-        q0 = q1; q1 = q2; q2 = tcur_raw;
-        tcur_raw = p_top; u0cur = p_u0;
+        if (ST) q0 = p_top;
+        else { q0 = q1; q1 = q2; q2 = tcur_raw; tcur_raw = p_top; }
+        u0cur = p_u0;
         if (ST) tcur_v = p_topv;
         buf ^= 1;
     }
@@ -724,7 +734,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
 template <int TY, bool MF = false, bool WY = false, bool ST = false>      // ST: stored v (see k6_u)
 __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
-    static_assert(!(ST && (MF || WY)), "stored-velocity instantiations: periodic / slab rows, no folded forcing");
+    static_assert(!(ST && WY), "stored-velocity instantiations: periodic / slab rows");
     constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles
     constexpr int TC = 72;                                // v tile with its x halo: columns i0-3 .. i0+65 at offset 3
     __shared__ double Tv[2][RV][TC];
@@ -815,7 +825,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
 #pragma unroll
         for (int q = 0; q < HPT; ++q) hnext[q] = hok[q] ? frame_load(q, lev) : 0.0;
         const double p_side = sok ? (ST ? vel : rv)[sn + lev] : 0.0;
-        const double p_top = rv[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];
+        const double p_top = ST ? rv[n + sz] : rv[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)];      // ST: the next level's raw momentum, read where it is staged (see k6_u)
         const double p_topv = ST ? vel[n + ((k + 4 <= g.Nz + g.Hz - 1) ? 4 * sz : 3 * sz)] : 0.0;
         const double p_u0 = (E.mode == 2) ? E.u0[n + sz] : 0.0;
         const double tnew_raw = tcur_raw, u0v = u0cur;
@@ -866,7 +876,7 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
         Tv[buf ^ 1][ty + 3][tc] = r[4];
         if (sok) Tv[buf ^ 1][srow + 3][scol] = ST ? p_side : bz_cdiv(p_side, g.rho[k + 1], g.rrho[k + 1]);
         Tm[buf ^ 1][0][ty + 2][tx] = ru_n;
-        Tm[buf ^ 1][1][ty + 2][tx] = g.Ay[k + 1] * q1;
+        Tm[buf ^ 1][1][ty + 2][tx] = g.Ay[k + 1] * (ST ? p_top : q1);
         Tm[buf ^ 1][2][ty + 2][tx] = rw_n;
 #pragma unroll
         for (int q = 0; q < HPT; ++q)
@@ -881,7 +891,11 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
             double Gv = -(g.Vinv_c[k] * (dx + dy + (fz_hi - fz_lo)));
             if constexpr (MF) {      // -y_f_cross_U + rho F_v
                 if (L.mforce & 1) Gv -= L.cor_f * cor_u;
-                if (L.mforce & 4) Gv += rho * L.Fv[k];
+                if (L.mforce & (4 | 16)) {
+                    double tot = (L.mforce & 16) ? rho * L.Sv[k] : 0.0;
+                    if (L.mforce & 4) tot = (L.mforce & 16) ? tot + rho * L.Fv[k] : rho * L.Fv[k];
+                    Gv += tot;
+                }
             }
             if (store) L.out[n] = (ST && E.mode == 0) ? Gv : bz_rk_apply_pre(E.mode, E.dt, E.alpha, E.oma, u0v, E.u0_out, Gv, q0, n);
             if constexpr (WY) {      // the wall faces of the predictor: j = 0 (this row, not updated) and j = Ny (first halo row above the last row)
@@ -890,8 +904,9 @@ __global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGri
             }
         }
         fz_lo = fz_hi;
-        q0 = q1; q1 = q2; q2 = tnew_raw;
-        tcur_raw = p_top; u0cur = p_u0;
+        if (ST) q0 = p_top;
+        else { q0 = q1; q1 = q2; q2 = tnew_raw; tcur_raw = p_top; }
+        u0cur = p_u0;
         if (ST) tcur_v = p_topv;
 #pragma unroll
         for (int s = 0; s < 5; ++s) r[s] = r[s + 1];

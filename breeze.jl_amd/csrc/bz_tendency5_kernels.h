@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
 // five column divisions; ring top and u0 are loaded one level ahead.  Same arithmetic, same bits as k5_v.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TY, bool MF = false, bool WY = false, bool ST = false>      // ST: stored v (see k6_u)
-__global__ __launch_bounds__(64 * TY, (MF ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
+__global__ __launch_bounds__(64 * TY, ((MF && WY) ? 4 : BZ_LEAN_WAVES)) void k6_v(DevGrid g, Lean5 L, int kchunk, RKEpilogue E)
 {
     static_assert(!(ST && WY), "stored-velocity instantiations: periodic / slab rows");
     constexpr int RV = TY + 6, RM = TY + 4;               // rows of the v tile / of the momentum tiles

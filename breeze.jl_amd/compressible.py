@@ -672,6 +672,11 @@ class SlabCompressibleModel(CompressibleAtmosphereModel):
             raise ValueError(f"Ny={global_grid.Ny} is not divisible by {world} ranks")
         self.global_grid = G = global_grid
         self.rank, self.world = rank, world
+        sft = kw.get("substep_floattype")
+        if sft is not None and np.dtype(sft) == np.float32 and G.ftype == 8 and transport == "torch":
+            # the library-owned step moves the Float32 rows of the working fields (csrc/bz_comm.hip: halo_exchange, half); the
+            # Python-issued exchange assumes the grid's real
+            raise NotImplementedError('substep_floattype = Float32 on y-slabs: transport "rccl" or "local:<name>"')
         Ny = G.Ny // world
         y0 = G.yᶠ[0] + rank * Ny * G.Δy
         z = (G.zᶠ[0], G.zᶠ[-1]) if G.regular_z else G.zᶠ

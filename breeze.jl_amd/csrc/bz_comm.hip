@@ -362,14 +362,19 @@ extern "C" int bz_comm_info(bz_ctx *ctx, const char **transport, int64_t *bytes_
 // ---- y-halo exchange --------------------------------------------------------------------------------------------------------------
 // Fill `width` rows of the upper halo (parent rows Hy+Ny ...) and / or of the lower halo (rows Hy-width .. Hy-1) of n parent arrays
 // from the ring neighbours, on stream st.  levels[m]: z levels of array m (Nz + 2 Hz, or + 1 for z-face fields).
+// half: the fields are Float32 arrays of a Float64 model (the substepper's working fields with substep_floattype = Float32): their rows
+// travel as Sx / 2 doubles (Sx is even: Nx is even on every context that decomposes)
 static int halo_exchange(bz_ctx *ctx, double *const *fields, const int32_t *levels, int n, int width, bool upper_halo, bool lower_halo,
-                         hipStream_t st)
+                         hipStream_t st, bool half = false)
 {
     BzComm *c = ctx->comm;
     const DevGrid &g = ctx->dg;
     if (n < 1 || n > BZ_COMM_MAX_FIELDS || width < 1 || width > g.Hy) return BZ_ERR_INVALID;
+    if (half && ((g.Sx & 1) || sizeof(double) != 8)) return BZ_ERR_UNSUPPORTED;
+    const int sx = half ? g.Sx / 2 : g.Sx;
+    const long long sxy = half ? g.Sxy / 2 : g.Sxy;
     size_t total = 0;
-    for (int m = 0; m < n; ++m) total += (size_t)levels[m] * width * g.Sx;
+    for (int m = 0; m < n; ++m) total += (size_t)levels[m] * width * sx;
     if (total > c->halo_cap) {
         BZ_HIP(hipStreamSynchronize(st));
         for (int d = 0; d < 2; ++d) {
@@ -385,11 +390,11 @@ static int halo_exchange(bz_ctx *ctx, double *const *fields, const int32_t *leve
     int rc = BZ_OK;
     const size_t bytes = total * sizeof(double);
     // what the UPPER neighbour's lower halo needs: my top interior rows; what the LOWER neighbour's upper halo needs: my first rows
-    if (lower_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy + g.Ny - width, width, c->halo_send[0], 0);
-    if (!rc && upper_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy, width, c->halo_send[1], 0);
+    if (lower_halo) rc = bzi_pack_rows_geom(ctx, fields, levels, n, g.Hy + g.Ny - width, width, c->halo_send[0], 0, sx, sxy);
+    if (!rc && upper_halo) rc = bzi_pack_rows_geom(ctx, fields, levels, n, g.Hy, width, c->halo_send[1], 0, sx, sxy);
     if (!rc && c->W == 1 && !c->self_messages) {  // periodic wrap onto myself: no message
-        if (lower_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy - width, width, c->halo_send[0], 1);
-        if (!rc && upper_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy + g.Ny, width, c->halo_send[1], 1);
+        if (lower_halo) rc = bzi_pack_rows_geom(ctx, fields, levels, n, g.Hy - width, width, c->halo_send[0], 1, sx, sxy);
+        if (!rc && upper_halo) rc = bzi_pack_rows_geom(ctx, fields, levels, n, g.Hy + g.Ny, width, c->halo_send[1], 1, sx, sxy);
         ctx->stream = keep;
         return rc;
     }
@@ -404,8 +409,8 @@ static int halo_exchange(bz_ctx *ctx, double *const *fields, const int32_t *leve
         c->bytes_sent += (long long)bytes * ((lower_halo ? 1 : 0) + (upper_halo ? 1 : 0));
         c->exchanges++;
     }
-    if (!rc && lower_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy - width, width, c->halo_recv[0], 1);
-    if (!rc && upper_halo) rc = bz_pack_rows(ctx, fields, levels, n, g.Hy + g.Ny, width, c->halo_recv[1], 1);
+    if (!rc && lower_halo) rc = bzi_pack_rows_geom(ctx, fields, levels, n, g.Hy - width, width, c->halo_recv[0], 1, sx, sxy);
+    if (!rc && upper_halo) rc = bzi_pack_rows_geom(ctx, fields, levels, n, g.Hy + g.Ny, width, c->halo_recv[1], 1, sx, sxy);
     ctx->stream = keep;
     return rc;
 }
@@ -856,6 +861,7 @@ struct FieldList {
     double *f[BZ_COMM_MAX_FIELDS];
     int32_t lev[BZ_COMM_MAX_FIELDS];
     int n = 0;
+    bool half = false;          // Float32 working fields of a Float64 model (see halo_exchange)
     bool overflow = false;      // a field beyond BZ_COMM_MAX_FIELDS must fail the exchange, not silently stay unexchanged
     void add(double *p, int32_t levels)
     {
@@ -873,7 +879,7 @@ static int cmp_exchange(bz_ctx *ctx, const FieldList &L)
     }
     if (!L.n) return BZ_OK;
     ProfileScope ps(ctx, "comm_halo_exchange");
-    return halo_exchange(ctx, L.f, L.lev, L.n, ctx->dg.Hy, true, true, ctx->stream);
+    return halo_exchange(ctx, L.f, L.lev, L.n, ctx->dg.Hy, true, true, ctx->stream, L.half);
 }
 
 // update_state! with the neighbour exchanges: rho_d first (face velocities divide by the dry density of row -1), then everything the
@@ -930,17 +936,20 @@ int bzi_dist_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s,
         if ((rc = bz_acoustic_stage_begin(ctx, s, U0, G, sub, dt, betas[st], &ntau, &cur))) return rc;
         for (int32_t k = 1; k <= ntau; ++k) {
             FieldList P;
+            P.half = ctx->substep_f32;      // substep_floattype = Float32: the perturbation fields are Float32 arrays (round 5)
             P.add(th_buf[cur], nc); P.add(v_buf[cur], nc);
             if ((rc = cmp_exchange(ctx, P))) return rc;
             if ((rc = bz_acoustic_substep(ctx, s, U0, G, sub, k, &cur))) return rc;
             if (ctx->se.direct_divergence_damping && ctx->se.damping_coefficient >= 0.0) {      // apply_divergence_damping!(::DirectDivergenceDamping)
                 FieldList D;
+                D.half = ctx->substep_f32;
                 D.add(u_buf[cur], nc); D.add(v_buf[cur], nc);
                 if ((rc = cmp_exchange(ctx, D))) return rc;
                 if ((rc = bz_acoustic_direct_damping(ctx, s, U0, G, sub))) return rc;
             }
         }
         FieldList T;
+        T.half = ctx->substep_f32;
         T.add(th_buf[cur], nc);
         if ((rc = cmp_exchange(ctx, T))) return rc;
         if ((rc = bz_acoustic_stage_end(ctx, s, U0, G, sub, dt, betas[st], 1))) return rc;

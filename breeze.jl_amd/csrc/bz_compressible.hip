@@ -1111,7 +1111,9 @@ extern "C" int bz_create_compressible_slab(bz_ctx **out, const bz_grid *local_gr
                                            const bz_exner_reference_state *ref, const bz_split_explicit *td, int weno_order,
                                            int y_nranks, int y_rank)
 {
-    if (td && td->substep_float_bytes != 0 && td->substep_float_bytes != (int32_t)sizeof(double)) return BZ_ERR_UNSUPPORTED;   // the per-substep halo messages carry the grid's real
+    // substep_floattype = Float32 inside a Float64 model: the per-substep halo messages carry the Float32 rows as Sx / 2 doubles (bz_comm.hip:
+    // halo_exchange, half) — the row length must be even; library-owned communicators only (the host-driven exchange moves the grid's real)
+    if (td && td->substep_float_bytes == 4 && sizeof(double) == 8 && local_grid && ((local_grid->Nx + 2 * local_grid->Hx) & 1)) return BZ_ERR_UNSUPPORTED;
     if (y_nranks < 1 || y_rank < 0 || y_rank >= y_nranks) return BZ_ERR_INVALID;
     return bzi_create_compressible(out, local_grid, constants, ref, td, weno_order, y_nranks, y_rank, true);
 }

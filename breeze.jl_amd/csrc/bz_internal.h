@@ -552,6 +552,8 @@ int bzi_momentum_tendencies_generic(bz_ctx *ctx, const bz_state *s, const bz_pro
 int bzi_apply_relaxation(bz_ctx *ctx, const bz_state *s, const bz_prognostic *G, const double *rho3d = nullptr);      // rho3d: coupling density of a compressible context
 int bzi_lean_setup(bz_ctx *ctx);
 int bzi_dist_time_step(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose = true);
+int bzi_pack_rows_geom(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n, int32_t row0, int32_t nrows, double *buffer,
+                       int32_t unpack, int sx, long long sxy);
 int bzi_comm_join_pending(bz_ctx *ctx);
 // entry points that read the stored diagnostics (u, v, w, theta, q, T): after bz_time_steps_anelastic(..., diagnose_last = 0) they are older
 // than the prognostic state.  With the state at hand they are rebuilt first (bz_update_state, on slab contexts with its halo exchange);

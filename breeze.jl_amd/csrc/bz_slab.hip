@@ -156,11 +156,12 @@ __global__ __launch_bounds__(256) void k_row_pack(RowFields R, double *__restric
     }
 }
 
-extern "C" int bz_pack_rows(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n, int32_t row0, int32_t nrows,
-                            double *buffer, int32_t unpack)
+// sx / sxy: row length and plane stride of the fields in DOUBLES — g.Sx / g.Sxy for fields of the grid's real; half of them for the
+// Float32 working fields of a Float64 model (substep_floattype = Float32 on y-slabs: a row of Sx floats travels as Sx / 2 doubles)
+int bzi_pack_rows_geom(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n, int32_t row0, int32_t nrows, double *buffer,
+                       int32_t unpack, int sx, long long sxy)
 {
     if (!ctx || !fields || !levels || !buffer || n < 1 || n > BZ_MAX_ROW_FIELDS || nrows < 1 || row0 < 0) return BZ_ERR_INVALID;
-    const DevGrid &g = ctx->dg;
     RowFields R;
     R.n = n;
     long long off = 0, maxtot = 0;
@@ -169,15 +170,22 @@ extern "C" int bz_pack_rows(bz_ctx *ctx, double *const *fields, const int32_t *l
         R.f[m] = fields[m];
         R.levels[m] = levels[m];
         R.offset[m] = off;
-        const long long tot = (long long)levels[m] * nrows * g.Sx;
+        const long long tot = (long long)levels[m] * nrows * sx;
         off += tot;
         if (tot > maxtot) maxtot = tot;
     }
     ProfileScope ps(ctx, unpack ? "halo_rows_unpack" : "halo_rows_pack");
     const unsigned bx = (unsigned)((maxtot + 255) / 256 > 4096 ? 4096 : (maxtot + 255) / 256);
-    hipLaunchKernelGGL(k_row_pack, dim3(bx, 1, n), dim3(256), 0, ctx->stream, R, buffer, g.Sx, g.Sxy, row0, nrows, unpack);
+    hipLaunchKernelGGL(k_row_pack, dim3(bx, 1, n), dim3(256), 0, ctx->stream, R, buffer, sx, sxy, row0, nrows, unpack);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
+}
+
+extern "C" int bz_pack_rows(bz_ctx *ctx, double *const *fields, const int32_t *levels, int32_t n, int32_t row0, int32_t nrows,
+                            double *buffer, int32_t unpack)
+{
+    if (!ctx) return BZ_ERR_INVALID;
+    return bzi_pack_rows_geom(ctx, fields, levels, n, row0, nrows, buffer, unpack, ctx->dg.Sx, ctx->dg.Sxy);
 }
 
 extern "C" int bz_project_and_diagnose(bz_ctx *ctx, const bz_state *s, const double *phi_c, const double *phi_below,

@@ -568,3 +568,64 @@ def test_compressible_order_nine_on_library_slabs_matches_single_gpu_model(bz, w
     # slab ranks replay a stage through begin / substep / end, the single-GPU run through the fused loop: same arithmetic, different
     # kernels; the order-9 WENO-Z weights amplify last-digit differences as they do against the oracle (tests/test_weno_orders.py: 2e-8)
     assert max(worst.values()) < 2e-8, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_compressible_float32_substep_storage_on_library_slabs_matches_single_gpu_model(bz, world):
+    """substep_floattype = Float32 inside a Float64 model (acoustic_substepping.jl:199-235) on y-slabs (round 5): the per-substep halo
+    messages of (rho theta)' and (rho v)' carry the Float32 rows of the working fields (csrc/bz_comm.hip: halo_exchange, half).  The slab
+    ranks against the single-GPU model with the same storage type: the same arithmetic on the same Float32-rounded fields, so the
+    Float64 tolerance of the test above applies (1e-10), far below the 1e-7 a mis-exchanged Float32 row would show."""
+    import uuid
+    import torch
+    size, steps, dt = (32, 24, 16), 2, 2.0
+    G = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+
+    def dynamics():
+        return bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), reference_potential_temperature=300.0)
+
+    ref = bz.CompressibleAtmosphereModel(G, dynamics(), advection=bz.WENO(), substep_floattype=np.float32)
+    Hz, Nz = G.Hz, G.Nz
+    rho = ref.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
+    ic = dict(ρ=rho, θ=cmp_theta, u=3.0, v=-2.0, w=0.0, qᵗ=cmp_qv)
+    ref.set(**ic)
+    for _ in range(steps):
+        ref.time_step(dt)
+    ref.synchronize()
+    with pytest.raises(NotImplementedError):      # the Python-issued exchange moves the grid's real
+        bz.compressible.SlabCompressibleModel(G, 0, world, dynamics(), advection=bz.WENO(), device="cuda:0", substep_floattype=np.float32)
+    group = "local:" + uuid.uuid4().hex
+    models, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                m = bz.compressible.SlabCompressibleModel(G, rank, world, dynamics(), advection=bz.WENO(), device="cuda:0", transport=group,
+                                                          substep_floattype=np.float32)
+                m.set(**ic)
+                for _ in range(steps):
+                    m.time_step(dt)
+                m.synchronize()
+            models[rank] = m
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    getters = {"ρᵈ": lambda m: m.dynamics.dry_density, "ρu": lambda m: m.momentum["ρu"], "ρv": lambda m: m.momentum["ρv"],
+               "ρw": lambda m: m.momentum["ρw"], "ρθ": lambda m: m.potential_temperature_density, "T": lambda m: m.temperature,
+               "p": lambda m: m.dynamics.pressure}
+    mom = max(np.abs(getters[k](ref).interior_cpu()).max() for k in ("ρu", "ρv", "ρw"))
+    for name, getter in getters.items():
+        got = np.concatenate([getter(m).interior_cpu() for m in models], axis=1)
+        want = getter(ref).interior_cpu()
+        scale = mom if name in ("ρu", "ρv", "ρw") else max(np.max(np.abs(want)), 1e-3)
+        err = np.max(np.abs(got - want)) / scale
+        assert err < 1e-9, (name, err)

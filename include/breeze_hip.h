@@ -353,7 +353,8 @@ typedef struct bz_split_explicit {
                                          density_potential_temperature_predictor, previous_density_potential_temperature_perturbation —
                                          0 = eltype(grid); 4 = Float32 (those ten pointers of bz_acoustic_substepper then address float arrays;
                                          (rho w)', the solver's right-hand side and the time-averaged velocities stay eltype(grid)).
-                                         Single-device contexts, thermal or no divergence damping. */
+                                         Thermal or no divergence damping; single-device contexts and y-slab contexts with a library-owned
+                                         communicator (the per-substep halo messages then carry the Float32 rows). */
     double damping_length_scale;      /* ThermalDivergenceDamping(length_scale = l) (time_discretizations.jl:215-218,235-247): <= 0 = nothing,
                                          the local scale kappa = alpha min(dx, dy)^2 / dtau (acoustic_substepping.jl:1100-1110); > 0 the fixed
                                          diffusivity (alpha l^2) / dtau in both horizontal directions (:1085-1092).  The vertical part of

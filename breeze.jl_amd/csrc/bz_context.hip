@@ -60,6 +60,7 @@ void bzi_read_tuning(bz_tuning &t)
     t.side_cu_layout = num("BZ_SIDE_CU_LAYOUT", 0);
     t.no_fuse_forcing = on("BZ_NO_FUSE_FORCING");
     t.no_fold_forcing = on("BZ_NO_FOLD_FORCING");
+    t.no_fuse_level_sums = on("BZ_NO_FUSE_LEVEL_SUMS");
     t.no_tridiag_coop = on("BZ_NO_TRIDIAG_COOP");
     t.no_xfft = on("BZ_NO_XFFT");
     t.poisson_chunk = num("BZ_POISSON_CHUNK", 0);

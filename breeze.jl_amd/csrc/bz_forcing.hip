@@ -39,14 +39,32 @@ __global__ __launch_bounds__(256) void k_level_sums(DevGrid g, const double *__r
     if (threadIdx.x < 4) partial[((long long)threadIdx.x * g.Nz + k) * FSLICES + s] = red[threadIdx.x][0];
 }
 
+// the same sums from the per-wave values the projection + diagnosis kernel left (bz_fused.hip: PDFields::lsum): block t = f Nz + k adds its P
+// values in a fixed order (thread-strided, then an LDS tree) into partial[t]
+__global__ __launch_bounds__(256) void k_level_reduce(const double *__restrict__ rows, long long P, double *__restrict__ partial)
+{
+    const double *r = rows + (long long)blockIdx.x * P;
+    double a = 0.0;
+    for (long long c = threadIdx.x; c < P; c += 256) a += r[c];
+    __shared__ double red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // Average(specific field, dims=(1,2)) then F = -zb-average(w_s dz(avg)) (subsidence_forcing.jl:75-91); one block
+// (nsl partial sums per field and level: FSLICES of k_level_sums, 1 of k_level_reduce)
 __global__ void k_subsidence_profiles(DevGrid g, const double *__restrict__ partial, const double *__restrict__ ws,
-                                      double *__restrict__ avg, double *__restrict__ sub, int mask, double count)
+                                      double *__restrict__ avg, double *__restrict__ sub, int mask, double count, int nsl)
 {
     const int Nz = g.Nz;
     for (int t = threadIdx.x; t < 4 * Nz; t += blockDim.x) {
         double sum = 0.0;
-        for (int s = 0; s < FSLICES; ++s) sum += partial[(long long)t * FSLICES + s];
+        for (int s = 0; s < nsl; ++s) sum += partial[(long long)t * nsl + s];
         avg[t] = sum / count;
     }
     __syncthreads();
@@ -214,6 +232,10 @@ static void free_forcings(bz_ctx *ctx)
 {
     if (ctx->d_forcing) hipFree(ctx->d_forcing);
     ctx->d_forcing = nullptr;
+    if (ctx->d_lsum_rows) hipFree(ctx->d_lsum_rows);
+    ctx->d_lsum_rows = nullptr;
+    ctx->lsum_P = 0;
+    ctx->lsum_fresh = false;
     ctx->has_forcings = false;
 }
 
@@ -424,16 +446,53 @@ static int bulk_flux(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, dou
     return BZ_OK;
 }
 
+// The horizontal sums can ride on the projection + diagnosis kernel of the fused-RK tier (single device, rows of a multiple of 64 cells:
+// whole wavefronts).  Summation order differs from k_level_sums (waves of a row, then rows; there: strided threads over a slice of rows).
+bool bzi_level_sums_ride(const bz_ctx *ctx)
+{
+    return ctx->has_forcings && ctx->forcing_subsidence_mask && !ctx->slab_mode && !ctx->compressible && ctx->dg.Nx % 64 == 0 &&
+           !ctx->tune.no_fuse_level_sums;
+}
+double *bzi_level_sum_rows(bz_ctx *ctx, long long *P)
+{
+    if (!bzi_level_sums_ride(ctx)) return nullptr;
+    const DevGrid &g = ctx->dg;
+    const long long p = (long long)g.Ny * ((g.Nx + 255) / 256) * 4;
+    if (!ctx->d_lsum_rows) {
+        const size_t bytes = (size_t)4 * g.Nz * (size_t)p * sizeof(double);
+        if (hipMalloc(&ctx->d_lsum_rows, bytes) != hipSuccess) { (void)hipGetLastError(); ctx->d_lsum_rows = nullptr; return nullptr; }
+        // (the slots of wavefronts beyond the end of a row are never written: they stay zero)
+        if (hipMemsetAsync(ctx->d_lsum_rows, 0, bytes, ctx->stream) != hipSuccess) return nullptr;
+        ctx->lsum_P = p;
+    }
+    *P = ctx->lsum_P;
+    return ctx->d_lsum_rows;
+}
+
 // compute_forcings!(model) (update_atmosphere_model_state.jl:81-86): horizontal averages -> subsidence profiles
 extern "C" int bz_compute_forcings(bz_ctx *ctx, const bz_state *s)
 {
     if (!ctx || !s) return BZ_ERR_INVALID;
+    ctx->lsum_fresh = false;      // a host call: the fields may have been written since the last step
+    return bzi_compute_forcings(ctx, s);
+}
+
+int bzi_compute_forcings(bz_ctx *ctx, const bz_state *s)
+{
     if (!ctx->has_forcings || !ctx->forcing_subsidence_mask) return BZ_OK;
     { const int rcs = bzi_refresh_diagnostics(ctx, s, "bz_compute_forcings"); if (rcs) return rcs; }
     const DevGrid &g = ctx->dg;
     const int Nz = g.Nz;
-    ProfileScope ps(ctx, "subsidence_averages");
+    const bool ride = ctx->lsum_fresh && ctx->d_lsum_rows;
+    ProfileScope ps(ctx, ride ? "subsidence_averages_from_wave_sums" : "subsidence_averages");
     double *ws = ctx->d_forcing + (size_t)5 * Nz, *avg = ws + (Nz + 1), *sub = avg + (size_t)4 * Nz, *partial = sub + (size_t)4 * Nz;
+    if (ride) {
+        hipLaunchKernelGGL(k_level_reduce, dim3(4 * Nz), dim3(256), 0, ctx->stream, ctx->d_lsum_rows, ctx->lsum_P, partial);
+        hipLaunchKernelGGL(k_subsidence_profiles, dim3(1), dim3(256), 0, ctx->stream, g, partial, ws, avg, sub,
+                           ctx->forcing_subsidence_mask, (double)g.Nx * (double)ctx->Ny_global, 1);
+        BZ_LAUNCH_CHECK();
+        return BZ_OK;
+    }
     hipLaunchKernelGGL(k_level_sums, dim3(Nz, FSLICES), dim3(256), 0, ctx->stream, g, s->u, s->v, s->theta, s->q, partial);
     if (ctx->slab_mode) {      // horizontal averages run over the whole domain: add the other ranks' partial sums (rank order: same bits everywhere)
         if (!ctx->comm) { ctx->last_error = "bz_compute_forcings: a y-slab context needs a communicator for the horizontal averages"; return BZ_ERR_UNSUPPORTED; }
@@ -441,7 +500,7 @@ extern "C" int bz_compute_forcings(bz_ctx *ctx, const bz_state *s)
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_subsidence_profiles, dim3(1), dim3(256), 0, ctx->stream, g, partial, ws, avg, sub,
-                       ctx->forcing_subsidence_mask, (double)g.Nx * (double)ctx->Ny_global);
+                       ctx->forcing_subsidence_mask, (double)g.Nx * (double)ctx->Ny_global, FSLICES);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -455,7 +514,7 @@ int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, d
     const int Nz = g.Nz;
     // momentum_done: the caller computed the stage's subsidence profiles (bz_compute_forcings) before its tendency launches and the
     // momentum kernels carried Coriolis / u, v profiles / u, v subsidence in their epilogues
-    int rc = momentum_done ? BZ_OK : bz_compute_forcings(ctx, s);
+    int rc = momentum_done ? BZ_OK : bzi_compute_forcings(ctx, s);
     if (rc) return rc;
     ProfileScope ps(ctx, "forcing_tendencies");
     ForcingCols F;

@@ -148,6 +148,10 @@ struct PDFields {
     const double *phi_below;                // y-slab only: phi of row j = -1 (neighbour rank), layout [k][i]
     int store_phi;                          // 0: skip the scatter into pressure_anomaly (stages whose phi nobody reads)
     int k0;                                 // first level of this launch (the chunked Poisson pipeline launches level ranges)
+    // per-wave sums of the u, v, theta, q this launch stores, for the horizontal averages of SubsidenceForcing (bz_forcing.hip:
+    // k_level_reduce): lsum[(f Nz + k) P + (j gx + bx) 4 + wave]; nullptr: not wanted.  Rows of a multiple of 64 cells only.
+    double *lsum;
+    long long lsum_P;
 };
 
 template <int SA>       // 0: no microphysics, 1: warm-phase saturation adjustment, 2: Kessler condensate species
@@ -198,6 +202,19 @@ __global__ __launch_bounds__(256) void k_project_diagnose(DevGrid g, PDFields F,
         qvv = q;
     } else if (SA == 1) T = bz_sa_diagnose(g, th, q, g.p_r[k], qvv, qll);
     else T = (g.formulation == 1) ? (th - g.g * g.zc[k]) / cpm : bz_exner_factor(g, k, q, cpm) * th;
+
+    if (F.lsum) {      // the stage's horizontal sums ride on the values in registers (a separate pass reads the four arrays again)
+        double a0 = u, a1 = v, a2 = th, a3 = q;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); a2 += __shfl_down(a2, off); a3 += __shfl_down(a3, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const long long slot = ((long long)j * gx + bx) * 4 + (threadIdx.x >> 6), fs = (long long)g.Nz * F.lsum_P;
+            double *o = F.lsum + (long long)k * F.lsum_P + slot;
+            o[0] = a0; o[fs] = a1; o[2 * fs] = a2; o[3 * fs] = a3;
+        }
+    }
 
     if (F.store_phi) st_img(F.phi, n, p, ox, oy);
     st_img(F.ru, n, ru, ox, oy);
@@ -488,7 +505,7 @@ int bzi_project_lean(bz_ctx *ctx, const bz_state *s, double dt, const double *ph
 }
 
 int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below,
-                         const bz_prognostic *predictor, bool store_phi, const double *rtheta_in, const double *rq_in)
+                         const bz_prognostic *predictor, bool store_phi, const double *rtheta_in, const double *rq_in, bool level_sums)
 {
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "project_and_diagnose");
@@ -505,6 +522,8 @@ int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double
     F.store_phi = store_phi ? 1 : 0;
     F.k0 = ctx->krn ? ctx->kr0 : 0;
     const int gx = (g.Nx + 255) / 256, nk = ctx->krn ? ctx->krn : g.Nz;
+    F.lsum = level_sums ? bzi_level_sum_rows(ctx, &F.lsum_P) : nullptr;
+    if (!F.lsum) F.lsum_P = 0;
     dim3 grid((unsigned)((long long)gx * g.Ny * nk)), block(256);
     if (g.microphysics == 2)
         hipLaunchKernelGGL((k_project_diagnose<2>), grid, block, 0, ctx->stream, g, F, dt, gx, nk);

@@ -79,6 +79,7 @@ int bzi_graph_begin(bz_ctx *ctx, uint64_t key, bool *capture)
         }
         ctx->G_is_predictor = slot->g_is_predictor;
         ctx->lean_step_last = slot->lean_step_last;
+        ctx->lsum_step_last = slot->lsum_step_last;
         ++ctx->graph_replays;
         return 1;
     }
@@ -138,6 +139,7 @@ int bzi_graph_end(bz_ctx *ctx, uint64_t key, int body_rc)
     slot->exec = exec;
     slot->g_is_predictor = ctx->G_is_predictor;
     slot->lean_step_last = ctx->lean_step_last;
+    slot->lsum_step_last = ctx->lsum_step_last;
     ++ctx->graph_captures;
     if (const hipError_t el = hipGraphLaunch(exec, ctx->stream)) {
         give_up(ctx, "hipGraphLaunch", el, 0);

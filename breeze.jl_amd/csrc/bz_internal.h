@@ -307,6 +307,7 @@ struct bz_tuning {
     int side_cu_layout = 0;           // BZ_SIDE_CU_LAYOUT (experiments): 0 the first N mask bits, 1 every (total / N)-th bit
     bool no_fuse_forcing = false;     // BZ_NO_FUSE_FORCING
     bool no_fold_forcing = false;     // BZ_NO_FOLD_FORCING: the fused-RK tier keeps the momentum terms of the forcing stack in the forcing pass
+    bool no_fuse_level_sums = false;  // BZ_NO_FUSE_LEVEL_SUMS: the subsidence averages always come from their own pass over u, v, theta, q
     bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms
     int poisson_chunk = 0;            // BZ_POISSON_CHUNK: level-chunked Poisson pipeline (needs BZ_NO_XFFT)
@@ -431,6 +432,13 @@ struct bz_ctx {
     bool has_forcings = false;
     double *d_forcing = nullptr;      // static profiles, subsidence velocity, level averages, subsidence profiles, partial sums
     int forcing_static_mask = 0, forcing_subsidence_mask = 0;
+    // horizontal sums of u, v, theta, q emitted by the projection + diagnosis kernel of the previous stage (bz_fused.hip: PDFields::lsum):
+    // true only between that launch and the next stage's bzi_compute_forcings INSIDE one bz_time_step(s)_anelastic call (the host may
+    // write the fields between calls, so nothing is trusted across them)
+    double *d_lsum_rows = nullptr;
+    long long lsum_P = 0;
+    bool lsum_fresh = false;
+    bool lsum_step_last = false;      // what the last recorded / launched step body left in lsum_fresh (graph replays restore it)
     bool fold_momentum_forcing = false;      // set by the fused-RK tier around its tendency launches: bzi_k6_stored folds the momentum terms of the stack
     double forcing_f = 0.0, forcing_flux_theta = 0.0, forcing_flux_q = 0.0, forcing_drag = 0.0, forcing_drag_eps = 0.0, forcing_flux_energy = 0.0;
     // BulkDrag / BulkSensibleHeatFlux / BulkVaporFlux bottom conditions (bz_set_bulk_surface_fluxes, bz_forcing.hip)
@@ -462,7 +470,7 @@ struct bz_ctx {
         int seen = 0;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        bool g_is_predictor = false, lean_step_last = false;      // host-side bookkeeping the recorded body leaves (restored on replay)
+        bool g_is_predictor = false, lean_step_last = false, lsum_step_last = false;      // host-side bookkeeping the recorded body leaves (restored on replay)
     } graph_slots[2];
     int graph_next = 0;
     hipStream_t graph_stream = nullptr, graph_user_stream = nullptr;      // recording stream (the legacy default stream cannot be captured)
@@ -526,6 +534,9 @@ struct ProfileScope {
 // internal entry points shared between translation units
 int bzi_fill_halo(bz_ctx *ctx, double *f, int kind);
 int bzi_apply_forcings(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale, bool momentum_done = false);
+int bzi_compute_forcings(bz_ctx *ctx, const bz_state *s);      // bz_compute_forcings; takes the level sums of bz_ctx::d_lsum_rows while lsum_fresh
+double *bzi_level_sum_rows(bz_ctx *ctx, long long *P);          // the array the projection + diagnosis kernel emits them into (nullptr: not applicable)
+bool bzi_level_sums_ride(const bz_ctx *ctx);
 int bzi_flux_bc(bz_ctx *ctx, const bz_state *s, double *Gu, double *Gv, double *Gth, double *Gq, double scale);
 void bzi_forcing_teardown(bz_ctx *ctx);
 int bzi_tracer_specific(bz_ctx *ctx);
@@ -589,7 +600,7 @@ int bzi_poisson_source_fused(bz_ctx *ctx, const bz_state *s, double dt, double *
                              const bz_prognostic *predictor = nullptr);
 int bzi_project_diagnose(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c = nullptr,
                          const double *phi_below = nullptr, const bz_prognostic *predictor = nullptr, bool store_phi = true,
-                         const double *rtheta_in = nullptr, const double *rq_in = nullptr);
+                         const double *rtheta_in = nullptr, const double *rq_in = nullptr, bool level_sums = false);
 int bzi_project_lean(bz_ctx *ctx, const bz_state *s, double dt, const double *phi_c, const double *phi_below,
                      const bz_prognostic *predictor, double *sa, double *sb);
 // lean whole-step tendencies (bz_tendency5.hip): prognostic-only inputs, rho theta / rho q advance from (pa, pb) into (oa, ob)

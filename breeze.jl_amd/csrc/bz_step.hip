@@ -177,27 +177,43 @@ static int one_anelastic_step(bz_ctx *ctx, const bz_state *s, const bz_prognosti
     // reset the moisture scan's word, on every replay)
     if (ctx->diagnostics_stale && !anelastic_lean_tier(ctx)) { const int rcs = bz_update_state(ctx, s, G, 0); if (rcs) return rcs; }
     // launch-bound grids replay the recorded step (bz_graph.hip); a failed recording has executed nothing and falls through
-    const int kind = 1 + (diagnose ? 0 : 16) + 32 * ctx->q_host;      // (the host's view of the moisture scan selects the kernels a recording holds)
+    // (the host's view of the moisture scan selects the kernels a recording holds; so does the source of the first stage's level sums)
+    const int kind = 1 + (diagnose ? 0 : 16) + 32 * ctx->q_host + (ctx->lsum_fresh ? 128 : 0);
     const uint64_t key = bzi_graph_key(ctx, kind, dt, s, sizeof(*s), U0, sizeof(*U0), G, sizeof(*G), nullptr, 0);
     bool capture = false;
     int rc;
     if (bzi_graph_begin(ctx, key, &capture) == 1) {
         if (ctx->lean_step_last) ctx->diagnostics_stale = !diagnose;      // the host-side bookkeeping of the recorded body
+        ctx->lsum_fresh = ctx->lsum_step_last;
         return BZ_OK;
     }
+    const bool lsum_in = ctx->lsum_fresh;
     if (capture) {
         rc = anelastic_step_body(ctx, s, U0, G, dt, diagnose);
         if ((rc = bzi_graph_end(ctx, key, rc)) != -1) return rc;
+        ctx->lsum_fresh = lsum_in;      // nothing ran
     }
     return anelastic_step_body(ctx, s, U0, G, dt, diagnose);
+}
+
+// The level sums of SubsidenceForcing ride on the projection + diagnosis kernel (bz_fused.hip) from one stage to the next INSIDE a call;
+// the first stage of a call takes them from its own pass (the host may have written the fields), and nothing is trusted after it.
+static void level_sums_open(bz_ctx *ctx)
+{
+    ctx->lsum_fresh = false;
+    long long P;
+    (void)bzi_level_sum_rows(ctx, &P);      // allocated here: not inside a region a graph records
 }
 
 extern "C" int bz_time_step_anelastic(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0,
                                       const bz_prognostic *G, double dt)
 {
     if (!ctx || !s || !U0 || !G) return BZ_ERR_INVALID;
-    const int rc = bzi_scan_moisture(ctx, s);
-    return rc ? rc : one_anelastic_step(ctx, s, U0, G, dt, true);
+    level_sums_open(ctx);
+    int rc = bzi_scan_moisture(ctx, s);
+    if (!rc) rc = one_anelastic_step(ctx, s, U0, G, dt, true);
+    ctx->lsum_fresh = false;
+    return rc;
 }
 
 // n steps of time_step!(model, dt) in one call — the loop of the reference's benchmark driver, many_time_steps!
@@ -212,11 +228,13 @@ extern "C" int bz_time_steps_anelastic(bz_ctx *ctx, const bz_state *s, const bz_
                                        int diagnose_last)
 {
     if (!ctx || !s || !U0 || !G || n < 0) return BZ_ERR_INVALID;
+    level_sums_open(ctx);
     if (n > 0) { const int rc = bzi_scan_moisture(ctx, s); if (rc) return rc; }
     for (int it = 0; it < n; ++it) {
         const int rc = one_anelastic_step(ctx, s, U0, G, dt, it == n - 1 && diagnose_last);
-        if (rc) return rc;
+        if (rc) { ctx->lsum_fresh = false; return rc; }
     }
+    ctx->lsum_fresh = false;
     return BZ_OK;
 }
 
@@ -236,6 +254,9 @@ extern "C" int bz_diagnostics_stale(const bz_ctx *ctx) { return ctx ? (ctx->diag
 static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt, bool diagnose)
 {
     ctx->lean_step_last = false;
+    ctx->lsum_step_last = false;
+    const bool lsum_in = ctx->lsum_fresh;      // every other tier leaves no sums behind
+    ctx->lsum_fresh = false;
     int rc;
     const double alphas[3] = {1.0, 1.0 / 4.0, 2.0 / 3.0};                   // :99-101
     // walls in y ((Periodic, Bounded, Bounded)) ride the lean seam too (WY kernels, wall rows in the projection kernels); every other
@@ -376,7 +397,8 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             // momentum terms of the forcing stack in the epilogues of the stored-velocity momentum kernels (round 5): the stage's subsidence
             // profiles are built first (from the stored u, v, theta, q of the stage start, which the tendency kernels do not touch)
             const bool fold = ctx->has_forcings && ctx->weno_R == 3 && bzi_k6_stored_ok(ctx) && ctx->tend_lds && !ctx->tune.no_fuse_forcing && !ctx->tune.no_fold_forcing;
-            if (fold && (rc = bz_compute_forcings(ctx, s))) return rc;
+            if (stage == 0) ctx->lsum_fresh = lsum_in;
+            if (fold && (rc = bzi_compute_forcings(ctx, s))) return rc;
             ctx->fold_momentum_forcing = fold;
             rc = bzi_tendencies_fused_rk(ctx, s, U0, G, dt, alpha, stage == 0);
             ctx->fold_momentum_forcing = false;
@@ -397,9 +419,13 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
             if (g.bounded_y && (rc = bzi_fill_halo(ctx, G->rho_v, BZ_HALO_YFACE))) return rc;      // wall faces j = 0, Ny of the predictor (the source term reads face Ny)
             if ((rc = bzi_poisson_from_momentum(ctx, s, alpha * dt, G))) return rc;
             // pressure_anomaly is a diagnostic nobody reads inside the step: only the last stage scatters it
-            if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, stage == 2))) return rc;
+            // (the horizontal sums of the u, v, theta, q it stores ride along: the next stage's subsidence profiles, bz_forcing.hip)
+            const bool ride = bzi_level_sums_ride(ctx) && ctx->d_lsum_rows;
+            if ((rc = bzi_project_diagnose(ctx, s, alpha * dt, nullptr, nullptr, G, stage == 2, nullptr, nullptr, ride))) return rc;
+            ctx->lsum_fresh = ride;
             if ((rc = bzi_tracer_specific(ctx))) return rc;
         }
+        ctx->lsum_step_last = ctx->lsum_fresh;
         ctx->G_is_predictor = true;
         return BZ_OK;
     }

@@ -296,3 +296,59 @@ def test_marching_closure_kernels_on_whole_tiles(oracle, bz, moist, monkeypatch)
         assert np.array_equal(ga, gb), n
         want = om.grid.interior(om.G[n], zface=(n == "rw"))
         assert relerr(ga, want) < (1e-12 if strict else 5e-9), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,dt", [((64, 16, 24), 3.0), ((320, 8, 12), 0.5)])
+def test_level_sums_ride_on_the_projection_kernel(oracle, bz, size, dt, monkeypatch):
+    """Round 5: inside one bz_time_step(s)_anelastic call the horizontal sums of u, v, theta, q^t that SubsidenceForcing averages
+    (subsidence_forcing.jl:75-91) are emitted by the projection + diagnosis kernel of the previous stage (one value per wavefront,
+    csrc/bz_fused.hip: PDFields::lsum; reduced by csrc/bz_forcing.hip: k_level_reduce) instead of a pass of their own over the four
+    arrays; the first stage of a call keeps its own pass.  Rows of one wavefront (three of a block's four slots never written) and
+    of five (a second block with one): three steps in one call against the oracle, against the same steps with BZ_NO_FUSE_LEVEL_SUMS=1
+    (another summation order: 1e-12, not bits), and bit for bit against three single-step calls replayed from recorded graphs."""
+    def run(no_ride, single_calls=0, graph=False):
+        if no_ride:
+            monkeypatch.setenv("BZ_NO_FUSE_LEVEL_SUMS", "1")
+        else:
+            monkeypatch.delenv("BZ_NO_FUSE_LEVEL_SUMS", raising=False)
+        om, hm = _pair(oracle, bz, size=size, moist=True, forced=True)
+        ic = _turbulent_ic(om, 9)
+        hm.set(θ=ic["theta"], qᵗ=ic["qt"], u=ic["u"], v=ic["v"])
+        if graph:
+            hm.graph_enable(True)
+        if single_calls:
+            for _ in range(single_calls):
+                hm.time_step(dt)
+        else:
+            hm.time_steps(dt, 3)
+        hm.synchronize()
+        return om, ic, {k: hm.prognostic_fields()[k].interior_cpu().copy() for k in PROG.values()}, hm
+
+    om, ic, a, _ = run(False)
+    _, _, b, _ = run(True)
+    om.set(**ic)
+    for _ in range(3):
+        om.time_step(dt)
+    g = om.grid
+    mom = max(np.abs(g.interior(getattr(om, n), zface=(n == "rw"))).max() for n in ("ru", "rv", "rw"))
+    for n, k in PROG.items():
+        want = g.interior(getattr(om, n), zface=(n == "rw"))
+        scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(a[k] - want).max() / scale < 2e-9, n
+        assert np.abs(a[k] - b[k]).max() / scale < 1e-12, n
+    assert any(not np.array_equal(a[k], b[k]) for k in a)          # the riding sums were used (their order of summation differs)
+    # single-step calls: stage 1 of every call sums in its own pass, stages 2 - 3 ride; replayed graphs leave the same bits
+    _, _, c, _ = run(False, single_calls=3)
+    _, _, d, hd = run(False, single_calls=6, graph=True)
+    for _ in range(3):
+        om.time_step(dt)
+    for n, k in PROG.items():
+        want = g.interior(getattr(om, n), zface=(n == "rw"))
+        scale = mom if n in ("ru", "rv", "rw") else np.abs(want).max()
+        assert np.abs(c[k] - a[k]).max() / scale < 1e-12, n
+        assert np.abs(d[k] - want).max() / scale < 4e-9, n
+    en, cap, rep = hd.graph_info()
+    if en and rep > 0:
+        _, _, e, _ = run(False, single_calls=6)
+        assert all(np.array_equal(d[k], e[k]) for k in d)

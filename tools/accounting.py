@@ -71,6 +71,7 @@ COMPULSORY_WORDS = {
     "closure_tendencies": 16,                          # R u, v, w, nu_e, theta, q; R + W predictor x 3, rho_theta, rho_q
     "forcing_tendencies": 10,                          # R u, v (Coriolis / subsidence gradients are column data); R + W predictor x 2, rho_theta, rho_q
     "subsidence_averages": 4,                          # R u, v, theta, q (horizontal means; one word per cell each)
+    "subsidence_averages_from_wave_sums": 0.0625,      # R one sum per wavefront (64 cells) of u, v, theta, q, left by project_and_diagnose
     "flux_bc_tendencies": 0.0,                         # bottom plane only: no 3-D array
     # per-operator kernels (one array list per operator, as SURVEY §8d counts them)
     "x_momentum_tendency": 5, "y_momentum_tendency": 5, "z_momentum_tendency": 7, "potential_temperature_tendency": 6,

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--dt", type=float, default=2.0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--single-calls", action="store_true", help="one bz_time_step_anelastic call per step instead of one bz_time_steps_anelastic call")
+    ap.add_argument("--graph", action="store_true", help="replay recorded steps (hipGraph, bz_graph_enable) in the timed pass")
     ap.add_argument("--no-forcing", action="store_true")
     ap.add_argument("--no-closure", action="store_true")
     ap.add_argument("--order", type=int, default=5, choices=(5, 7, 9), help="WENO order (examples/bomex.jl:204 uses 9; generic kernels)")
@@ -64,14 +66,32 @@ def main():
     for _ in range(a.warmup):
         m.time_step(a.dt)
     m.synchronize()
-    m.profile_enable(True)
-    m.profile_reset()
+    # timed region: unprofiled (the HIP events of the kernel table below sit between the launches of a step and cost ~0.3 ms of it), the
+    # reference's benchmark loop (benchmarking/src/timestepping.jl:11-16: many_time_steps!) unless --single-calls, as bench.py's headline
+    def run(n):
+        if a.single_calls:
+            for _ in range(n):
+                m.time_step(a.dt)
+        else:
+            m.time_steps(a.dt, n)
+
+    if a.graph:
+        m.graph_enable(True)
+        for _ in range(3):
+            run(2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        m.time_step(a.dt)
+    run(a.steps)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    graph_info = m.graph_info() if a.graph else None
+    if a.graph:
+        m.graph_enable(False)
+    # kernel table: a second pass with HIP events around the kernel groups
+    m.profile_enable(True)
+    m.profile_reset()
+    run(a.steps)
+    torch.cuda.synchronize()
     m.profile_enable(False)
     prof = m.profile()
     ms = (t1 - t0) / a.steps * 1e3
@@ -91,7 +111,8 @@ def main():
     step_gbs = cells / (ms * 1e-3) * step_words * word / 1e9
     out = {"metric": "grid-cells advanced/sec, BOMEX-shaped anelastic SSP-RK3 step (WENO + saturation adjustment + SmagorinskyLilly + forcing stack)", "weno_order": a.order,
            "value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": a.dt,
-           "forcing": not a.no_forcing, "closure": None if a.no_closure else "SmagorinskyLilly", "dtype": "f32" if a.float32 else "f64",
+           "stepping": ("one call per step" if a.single_calls else "bz_time_steps_anelastic (many_time_steps!)") + (", recorded steps replayed (hipGraph)" if a.graph else ""),
+           "graph_info": graph_info, "kernel_times": "HIP events of a second pass of %d steps after the timed region" % a.steps, "forcing": not a.no_forcing, "closure": None if a.no_closure else "SmagorinskyLilly", "dtype": "f32" if a.float32 else "f64",
            "kernels_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items())},
            "kernel_launches_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items())},
            # one accounting (tools/accounting.py): the dominant kernel group and the whole step in COMPULSORY bytes against 8 TB/s.  At this size

@@ -434,6 +434,7 @@ struct AcParams {
     double gate;                  // 1: perturbation horizontal PGF applied this substep, 0: skipped (first small step)
     double kdamp;                 // alpha * min(dx,dy)^2 / dtau   (0: no damping)
     double inv_N;                 // 1 / N_tau
+    int xcd;                      // forward sweep: 1 = every XCD owns a band of tile rows (see k_ac_column_forward), 0 = launch order
 };
 
 // ST = substep_floattype (acoustic_substepping.jl:199-235): the storage type of the acoustic perturbation / predictor / linearisation
@@ -630,7 +631,17 @@ __device__ __forceinline__ double ac_face_update(double up, double G, double rt_
 template <bool FIRST, bool FUSED, bool DAMP, class ST>
 __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
-    const int i = blockIdx.x * ACX + threadIdx.x, j = blockIdx.y * ACY + threadIdx.y;
+    // Workgroups go round-robin to the 8 XCDs in launch order (x fastest), so in launch order XCD c owns the tile COLUMN bx = c (mod 8): the
+    // x neighbours of every tile live behind another XCD's L2, and the one value a row's edge lane needs of them (eight arrays) costs a
+    // 128-byte line through the fabric each.  With P.xcd XCD c owns the BAND of tile rows [c gy/8, (c+1) gy/8) instead and walks it x fastest:
+    // both x neighbours and (but at the band edges) both y neighbours are tiles of the same L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (P.xcd) {
+        const unsigned w = blockIdx.y * gridDim.x + blockIdx.x, c = w & 7u, r = w >> 3;
+        bx = (int)(r % gridDim.x);
+        by = (int)(c * (gridDim.y >> 3) + r / gridDim.x);
+    }
+    const int i = bx * ACX + threadIdx.x, j = by * ACY + threadIdx.y;
     if (i >= g.Nx || j >= g.Ny) return;
     const WrapIdx W = wrap_of(g, i, j);
     const long long sz = g.Sxy;
@@ -1491,6 +1502,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     P.kdamp = !S.damping ? 0.0 : (lfix > 0.0) ? (ctx->se.damping_coefficient * (lfix * lfix)) / dtau : ctx->se.damping_coefficient * (lmin * lmin) / dtau;
     P.inv_N = 1.0 / (double)ntau;
     P.gate = 1.0;
+    P.xcd = 0;
     S.ntau = ntau;
     S.done = 0;
     S.fused = ctx->ac_fused;
@@ -1528,6 +1540,7 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
     AcFields F = ac_fields(ctx, s, U0, G, sub);
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
     dim3 cols((g.Nx + ACX - 1) / ACX, (g.Ny + ACY - 1) / ACY), bcol(ACX, ACY);
+    P.xcd = (ctx->tune.ac_xcd && cols.y % 8 == 0) ? 1 : 0;
     dim3 colsb((g.Nx + ABX - 1) / ABX, (g.Ny + ABY - 1) / ABY), bcolb(ABX, ABY);
     if (S.fused) {
         double *th_buf[2], *u_buf[2], *v_buf[2];

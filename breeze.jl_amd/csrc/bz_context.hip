@@ -61,6 +61,7 @@ void bzi_read_tuning(bz_tuning &t)
     t.no_fuse_forcing = on("BZ_NO_FUSE_FORCING");
     t.no_fold_forcing = on("BZ_NO_FOLD_FORCING");
     t.no_fuse_level_sums = on("BZ_NO_FUSE_LEVEL_SUMS");
+    t.ac_xcd = num("BZ_AC_XCD", 1);
     t.no_tridiag_coop = on("BZ_NO_TRIDIAG_COOP");
     t.no_xfft = on("BZ_NO_XFFT");
     t.poisson_chunk = num("BZ_POISSON_CHUNK", 0);

@@ -307,6 +307,7 @@ struct bz_tuning {
     int side_cu_layout = 0;           // BZ_SIDE_CU_LAYOUT (experiments): 0 the first N mask bits, 1 every (total / N)-th bit
     bool no_fuse_forcing = false;     // BZ_NO_FUSE_FORCING
     bool no_fold_forcing = false;     // BZ_NO_FOLD_FORCING: the fused-RK tier keeps the momentum terms of the forcing stack in the forcing pass
+    int ac_xcd = 1;                   // BZ_AC_XCD=0: the forward acoustic sweep in launch order (XCD = tile column) instead of XCD = band of tile rows
     bool no_fuse_level_sums = false;  // BZ_NO_FUSE_LEVEL_SUMS: the subsidence averages always come from their own pass over u, v, theta, q
     bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms

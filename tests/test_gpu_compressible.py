@@ -334,6 +334,42 @@ def test_time_steps_on_rows_of_64_cells_match_oracle(oracle, oc, bz):
     cmp_interior(om, hm, ("rho_d", "rtheta", "rq", "ru", "rv", "rw", "u", "v", "w", "theta", "q", "T", "p"), 5e-9)
 
 
+@pytest.mark.parametrize("size", [(128, 32, 12), (64, 64, 10)])
+def test_forward_sweep_with_xcd_bands_matches_oracle(oracle, oc, bz, size, monkeypatch):
+    """Round 5: where the forward sweep's grid has a multiple of 8 tile rows (Ny a multiple of 32) every XCD owns a band of tile rows and walks
+    it x fastest (csrc/bz_compressible.hip: k_ac_column_forward, AcParams::xcd; in launch order an XCD owns a tile COLUMN and every x
+    neighbour sits behind another L2).  Two tile columns x one row per band, and one column x two rows per band: three steps against the
+    oracle and bit for bit against the launch-order run (BZ_AC_XCD=0)."""
+    def run(xcd):
+        monkeypatch.setenv("BZ_AC_XCD", "1" if xcd else "0")
+        om, hm = make_pair(oracle, oc, bz, size=size, substeps=6)
+        g = om.grid
+
+        def theta(x, y, z):
+            r = np.sqrt(x ** 2 + (y - 300.0) ** 2 + (z - 3000.0) ** 2)
+            return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+        rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+        u = lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z      # noqa: E731
+        v = lambda x, y, z: -2.0 + 0 * x + 0 * y + 0 * z     # noqa: E731
+        om.set(rho=rho, theta=theta, u=u, v=v, w=0.0)
+        hm.set(ρ=rho, θ=theta, u=u, v=v, w=0.0)
+        for _ in range(3):
+            hm.time_step(0.5)
+        hm.synchronize()
+        return om, hm
+
+    om, a = run(True)
+    for _ in range(3):
+        om.time_step(0.5)
+    cmp_interior(om, a, ("rho_d", "rtheta", "ru", "rv", "rw", "u", "v", "w", "theta", "T", "p"), 5e-9)
+    _, b = run(False)
+    fa, fb = a.prognostic_fields(), b.prognostic_fields()
+    for k in fa:
+        assert np.array_equal(fa[k].interior_cpu(), fb[k].interior_cpu()), k
+
+
+
 def test_whole_step_matches_operator_sequence(oracle, oc, bz):
     """bz_time_step_compressible (fused linearisation, no redundant velocity pass) == the reference's operator
     sequence issued call by call."""

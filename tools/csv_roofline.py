@@ -38,9 +38,19 @@ def main():
         if w is None:
             continue
         word = 4 if f32 else 8
+        # substep_floattype = Float32 inside a Float64 model (k_ac_*<..., float>): the working fields of the acoustic loop are 4-byte words,
+        # (rho w)', right-hand side, factors, averaged velocities and every model field stay 8-byte (csrc/bz_compressible.hip: AcFieldsT)
+        mixed = None
+        if (not f32) and name.startswith("k_ac_") and ", float>" in name.split("(")[0]:
+            mixed = {"acoustic_horizontal+column_forward": 10 * 4 + 13 * 8, "acoustic_column_backward": 5 * 4 + 5 * 8}.get(group.split(" | ")[0], 0)
         compressible = group.startswith(("acoustic", "update_state", "refresh_lin", "density+", "kessler", "store_initial")) or group in ("x_momentum_tendency", "y_momentum_tendency", "z_momentum_tendency")
         ncell = cells_cmp if compressible else cells
-        tbs = w * word * ncell / (avg_ms * 1e-3) / 1e12
+        if mixed == 0:
+            print(f"| `{short}` | Float32 working fields, mixed word sizes (compressible leg) | {r['Calls']} | {avg_ms:.3f} | {w:.2f} | not priced | — |")
+            continue
+        tbs = (mixed if mixed else w * word) * ncell / (avg_ms * 1e-3) / 1e12
+        if mixed:
+            var = f"Float32 working fields: {mixed} B per cell"
         print(f"| `{short}` | {var or ''}{' (compressible leg)' if compressible else ''} | {r['Calls']} | {avg_ms:.3f} | {w:.2f} | {tbs:.2f} | {tbs * 1e3 / HBM_PEAK_GBS:.3f} |")
 
 

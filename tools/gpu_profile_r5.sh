@@ -30,10 +30,10 @@ done
 echo "== config4 (compressible + Kessler, 512x512x128)"
 timeout 600 python bench.py --workload config4 --steps 5 --warmup 2 > $O/config4.json 2> $O/config4.err
 echo "== BOMEX 256x256x128 (physics list of examples/bomex.jl) and the 256^3 bubble with WENO9"
-timeout 300 python tools/bench_bomex.py 2>/dev/null | tail -1 > $O/bomex_weno5_f64.json
-timeout 300 python tools/bench_bomex.py --float32 2>/dev/null | tail -1 > $O/bomex_weno5_f32.json
-timeout 300 python tools/bench_bomex.py --order 9 2>/dev/null | tail -1 > $O/bomex_weno9_f64.json
-timeout 300 python tools/bench_bomex.py --order 9 --float32 2>/dev/null | tail -1 > $O/bomex_weno9_f32.json
+timeout 300 python tools/bench_bomex.py --steps 30 2>/dev/null | tail -1 > $O/bomex_weno5_f64.json
+timeout 300 python tools/bench_bomex.py --steps 30 --float32 2>/dev/null | tail -1 > $O/bomex_weno5_f32.json
+timeout 300 python tools/bench_bomex.py --steps 30 --order 9 2>/dev/null | tail -1 > $O/bomex_weno9_f64.json
+timeout 300 python tools/bench_bomex.py --steps 30 --order 9 --float32 2>/dev/null | tail -1 > $O/bomex_weno9_f32.json
 timeout 300 python tools/bench_order.py --size 256 --order 9 2>/dev/null | tail -1 > $O/bubble256_weno9_f64.json
 echo "== slab driver on one GPU: world 1, and with every message sent to itself"
 timeout 600 python bench.py --slab --steps 10 --warmup 3 --no-cpu-baseline --no-compressible --no-float32 > $O/slab_world1.json 2> $O/slab_world1.err

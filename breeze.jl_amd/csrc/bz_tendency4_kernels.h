@@ -16,6 +16,9 @@
 #include "bz_internal.h"
 #include "bz_weno.h"
 
+#ifndef BZ4_XCD
+#define BZ4_XCD 1
+#endif
 template <int TY>
 __global__ __launch_bounds__(64 * TY) void k_scalar_pair_lds(DevGrid g, const double *__restrict__ u,
                                                             const double *__restrict__ v,
@@ -33,13 +36,25 @@ __global__ __launch_bounds__(64 * TY) void k_scalar_pair_lds(DevGrid g, const do
     __shared__ double FY[2][2][TY + 1][64];
 
     const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * TY;
+    // XCD-contiguous block order where the grid allows it (as bz_block5 of the fifth-generation kernels): consecutive workgroup ids go
+    // round-robin to the 8 XCDs, so in launch order the x and y neighbours of a tile sit behind other L2s
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, W = gx * gy * gridDim.z;
+        if (BZ4_XCD && (W & 7u) == 0) {
+            unsigned w = bx + gx * (by + gy * bz);
+            w = (w & 7u) * (W >> 3) + (w >> 3);
+            bx = (int)(w % gx); by = (int)((w / gx) % gy); bz = (int)(w / (gx * gy));
+        }
+        bx = __builtin_amdgcn_readfirstlane(bx); by = __builtin_amdgcn_readfirstlane(by); bz = __builtin_amdgcn_readfirstlane(bz);
+    }
+    const int i0 = bx * 64, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
     // ragged tiles: out-of-range threads still stage true halo values (never clamp into the interior)
     const int ic = min(i, g.Nx + 2), jc = min(j, g.Ny + 2);
     const int nact = min(64, g.Nx - i0);
     const int ie = i0 + nact, le = nact - 1;
-    const int kbeg = blockIdx.z * kchunk, kend = min(kbeg + kchunk, g.Nz);
+    const int kbeg = bz * kchunk, kend = min(kbeg + kchunk, g.Nz);
     if (kbeg >= kend) return;                           // block-uniform
     const long long sz = g.Sxy;
     const bool store = (i < g.Nx) && (j < g.Ny);

@@ -103,6 +103,9 @@ static_assert(sizeof(LevRow5) == 16 * sizeof(double), "LevRow5 is sixteen reals"
 #endif
 // (later in round 4 the Float32 objects lost the SLP vectoriser — csrc/Makefile: F32FLAGS — and with it the operand-pair moves: the Float32
 // scalar kernel needs 75 - 80 registers with both additions and runs at six waves again: 0.97 -> 0.92 ms per launch in its dry form)
+#ifndef BZ5_RAW_LDS
+#define BZ5_RAW_LDS 1      // general scalar-pair body: the own cell's raw prognostic values ride LDS slots instead of being re-read (0: re-read)
+#endif
 #ifndef BZ5_SCALAR_WAVES
 #define BZ5_SCALAR_WAVES (sizeof(double) == 8 ? 4 : 6)
 #endif
@@ -222,7 +225,7 @@ __device__ __forceinline__ double bz_symm4y(double qm2, double qm1, double q0, d
 // (update_atmosphere_model_state.jl:333-343).  Every flux of it is an exact zero and its update is 0 -> 0, so the instantiation
 // neither loads nor stores anything of q: 4.6 of the kernel's 13 words per cell.  Identical bits: the arrays stay zero.
 template <int TY, bool WY, bool DRYQ>
-__device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean5 &F, int kchunk, const RKEpilogue &E, double *Tp, double *FYp, int *ZF)
+__device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean5 &F, int kchunk, const RKEpilogue &E, double *Tp, double *FYp, int *ZF, double *RAWp)
 {
     constexpr bool Q = !DRYQ;
     constexpr int TR = TY + 6, TC = 72;                 // tile rows, padded row length (70 used)
@@ -231,6 +234,11 @@ __device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean
     constexpr int HPT = (NHALO + NT - 1) / NT;          // frame cells per thread
     double(*T)[2][TR][TC] = (double(*)[2][TR][TC])Tp;                  // T[2][2][TR][TC]
     double(*FY)[2][TY + 1][64] = (double(*)[2][TY + 1][64])FYp;        // FY[2][2][TY + 1][64]
+    // General body: the RAW rho theta, rho q of the own column's levels k .. k + 2, each thread's own three slots per field (no barrier: a
+    // thread reads and writes only its own).  The RK update needs the cell's prognostic bits; they arrived three levels earlier as ring
+    // tops, and re-reading them from memory then (round 4) went to the fabric for two words per cell (PMC: 13.9 GB per launch for 8.9 GB
+    // of compulsory words — the dry body, which has the registers to carry them, moves 1.30x its words).  RAW[3][2][NT].
+    double *__restrict__ RAW = RAWp;
     // Zero-field shortcut of the second scalar (rho q of a dry run is identically zero, and the reference advects it all the same:
     // update_atmosphere_model_state.jl:333-343).  ZF[l % 3] != 0: every staged value of q at level l — the tile and its frame — is +-0.
     // Then the x / y reconstructions of that level return exactly 0 (WENO of zeros; every variant of bz_weno5) and the fluxes are
@@ -296,7 +304,11 @@ __device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean
         const double raw = pa[n + s * sz - 3 * sz];
         a[s] = bz_cdiv(raw, rh, rr);
         if (DRYQ && s >= 3) araw[s - 3] = raw;
-        b[s] = Q ? bz_cdiv(pb[n + s * sz - 3 * sz], rh, rr) : 0.0;
+        if constexpr (Q) {
+            const double rawb = pb[n + s * sz - 3 * sz];
+            b[s] = bz_cdiv(rawb, rh, rr);
+            if (BZ5_RAW_LDS && s >= 3) { RAW[((s - 3) * 2 + 0) * NT + t] = raw; RAW[((s - 3) * 2 + 1) * NT + t] = rawb; }
+        } else b[s] = 0.0;
     }
     double fza, fzb = 0.0;
     {
@@ -359,7 +371,7 @@ __device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean
             ta_nx = pa[n + up];
             if constexpr (Q) tb_nx = pb[n + up];
         } else { ta_raw = pa[n + 3 * sz]; if constexpr (Q) tb_raw = pb[n + 3 * sz]; }
-        const int lv3 = ZS ? (k - kbeg) % 3 : 0;
+        const int lv3 = (ZS || (Q && BZ5_RAW_LDS)) ? (k - kbeg) % 3 : 0;
         bool zxy = false;
         if constexpr (ZS) {
             if (t == 0) ZF[(lv3 + 2) % 3] = 1;      // reset the flag of level k + 2 (set while level k + 1 is staged, at the end of the next trip)
@@ -456,8 +468,14 @@ __device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean
         }
         // the cell's own prognostic values (read three levels ago as ring tops: an L2 / Infinity-Cache hit), requested before the staging
         // arithmetic so that the RK update after the barrier finds them
-        const double pa_n = DRYQ ? araw[0] : (BZ_KO & 4) ? a[3] : pa[n], pb_n = (!Q || (BZ_KO & 4)) ? b[3] : pb[n];
-        if constexpr (DRYQ) { araw[0] = araw[1]; araw[1] = araw[2]; araw[2] = ta_raw; }
+        double pa_n, pb_n;
+        if constexpr (DRYQ) { pa_n = araw[0]; pb_n = b[3]; araw[0] = araw[1]; araw[1] = araw[2]; araw[2] = ta_raw; }
+        else if (BZ_KO & 4) { pa_n = a[3]; pb_n = b[3]; }
+        else if constexpr (BZ5_RAW_LDS) {
+            double *ra = RAW + (lv3 * 2 + 0) * NT + t, *rb = ra + NT;
+            pa_n = *ra; pb_n = *rb;
+            *ra = ta_raw; *rb = tb_raw;      // level k + 3 takes the slot
+        } else { pa_n = pa[n]; pb_n = pb[n]; }
         // ---- stage level k+1 in the other buffer ----
         T[buf ^ 1][0][ty + 3][tx + 3] = a[4];
         if constexpr (Q) T[buf ^ 1][1][ty + 3][tx + 3] = b[4];
@@ -531,8 +549,9 @@ __global__ __launch_bounds__(64 * TY) __attribute__((amdgpu_waves_per_eu(BZ5_SCA
     __shared__ double T[2 * 2 * TR * TC];
     __shared__ double FY[2 * 2 * (TY + 1) * 64];
     __shared__ int ZF[3];
+    __shared__ double RAW[(!DRYQ && BZ5_RAW_LDS) ? 3 * 2 * 64 * TY : 1];
     if (bz_lean_skip<DRYQ, GUARD>(F)) return;
-    k5_scalar_pair_body<TY, WY, DRYQ>(g, F, kchunk, E, T, FY, ZF);
+    k5_scalar_pair_body<TY, WY, DRYQ>(g, F, kchunk, E, T, FY, ZF, RAW);
 }
 
 // out-of-wave x fluxes of the momentum kernels with the advected velocity derived from its momentum component

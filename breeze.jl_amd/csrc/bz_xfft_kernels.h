@@ -24,6 +24,25 @@
 
 typedef double xf_pair2 __attribute__((ext_vector_type(2), aligned(sizeof(double))));      // two consecutive reals, element-aligned
 #define XF_RB 8        // rows of y per workgroup: a transposed store / load moves XF_RB consecutive complex numbers (128 B) per kx
+#ifndef XF_XCD
+#define XF_XCD 1
+#endif
+
+// Block order of the two x transforms.  blockIdx.x counts groups of XF_RB rows, and consecutive workgroup ids go round-robin to the 8 XCDs: in
+// launch order the groups j0 and j0 + XF_RB — which in Float32 share every 128-byte line of the transposed spectrum (XF_RB complex numbers of
+// 8 bytes are half a line) — sat behind different L2s, and every line crossed the fabric twice (PMC r05: k_x_inverse_f32 1.61 GB per launch for
+// 1.07 GB of compulsory bytes; Float64, whose pieces are whole lines, 1.00x).  Here XCD c owns the band of row groups [c gx/8, (c+1) gx/8) of
+// every level chunk and walks it in order, so the second half of a line is asked for by the next workgroup of the same XCD.
+__device__ __forceinline__ void xf_block(int &bj, int &bk)
+{
+    bj = blockIdx.x; bk = blockIdx.y;
+    const unsigned gx = gridDim.x;
+    if (XF_XCD && (gx & 7u) == 0) {
+        const unsigned w = blockIdx.y * gx + blockIdx.x, c = w & 7u, r = w >> 3, band = gx >> 3;
+        bj = (int)(c * band + r % band);
+        bk = (int)(r / band);
+    }
+}
 
 // LDS slot of element p < n2 of a row: the low four bits (the 16-byte slot inside a 256-byte bank period) are XOR-swizzled with a
 // function of bits 4-7, chosen by exhaustive search over linear swizzles against the access patterns of this file on the wave64
@@ -254,8 +273,10 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_forward(DevGrid g, const 
     for (int t = threadIdx.x; t < wn; t += nthreads) W[t] = Wg[t];
     xf_stage_twiddles(Wst, Wg, n2, threadIdx.x, nthreads);
     __syncthreads();                                       // the twiddle tables are loaded by all waves
-    const int j0 = blockIdx.x * XF_RB, j = j0 + r;
-    const int kbeg = L.klo + blockIdx.y * kchunk, kend = min(kbeg + kchunk, L.khi);
+    int bj, bk;
+    xf_block(bj, bk);
+    const int j0 = bj * XF_RB, j = j0 + r;
+    const int kbeg = L.klo + bk * kchunk, kend = min(kbeg + kchunk, L.khi);
     double2 *__restrict__ row = xf_sm + r * RS;
     // y-slab: row Ny is the neighbour rank's first row, delivered into the halo by the caller's exchange
     const long long jp = (j + 1 < g.Ny || !g.wrap_y) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
@@ -323,8 +344,10 @@ __global__ __launch_bounds__(XF_RB * 64 * TW) void k_x_inverse(DevGrid g, const 
     double2 *__restrict__ Wst = W + wn;
     for (int t = threadIdx.x; t < wn; t += nthreads) W[t] = Wg[t];
     xf_stage_twiddles(Wst, Wg, n2, threadIdx.x, nthreads);
-    const int j0 = blockIdx.x * XF_RB;
-    const int kbeg = L.klo + blockIdx.y * kchunk, kend = min(kbeg + kchunk, L.khi);
+    int bj, bk;
+    xf_block(bj, bk);
+    const int j0 = bj * XF_RB;
+    const int kbeg = L.klo + bk * kchunk, kend = min(kbeg + kchunk, L.khi);
     double2 *__restrict__ row = xf_sm + r * RS;
     for (int k = kbeg; k < kend; ++k) {
         for (int e = threadIdx.x; e < NXH * XF_RB; e += nthreads) {

@@ -198,14 +198,40 @@ __device__ __forceinline__ double rk_out(const FluxBuf &F, double G, long long n
 // PASS 1 covers the interior (x is Periodic and y wraps unless the context is a y-slab or Flat: the flux at face N is the flux at face 0,
 // bit for bit, because halos are exact periodic images; the Bounded z direction has zero mass flux through its wall faces) plus, on
 // y-slabs, one row either side (the fluxes at the slab edges come from exchanged halo rows)
+// Block order (round 5).  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2: in launch order (x fastest, then y)
+// the rows j - 5 .. j + 5 an order-9 y stencil reads belonged to workgroups of OTHER XCDs, and the marching kernel's grid — 8 tiles wide at
+// 512 cells — gave every XCD a tile COLUMN, its x neighbours behind another L2.  Here XCD c owns the band [c gy/8, (c+1) gy/8) of the grid's
+// y extent and walks it x fastest, then y, then z (bz_fused.hip: bz_stream_block; bz_compressible.hip: k_ac_column_forward).  Grids whose y
+// extent is not a multiple of 8 keep launch order.  The indices are wave-uniform (column tables stay scalar loads).
+#ifndef GEN_XCD
+#define GEN_XCD 1
+#endif
+#ifndef GEN_XCD_MARCH
+#define GEN_XCD_MARCH 0      // the marching kernels measured equal (momentum) or 1 % slower (theta) in band order: they keep launch order
+#endif
+__device__ __forceinline__ void generic_block(int &bx, int &by, int &bz, bool bands = GEN_XCD != 0)
+{
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    if (bands && (gy & 7u) == 0) {
+        const unsigned w = bx + gx * (by + gy * bz), c = w & 7u, rows = gy >> 3;
+        unsigned r = w >> 3;
+        bx = (int)(r % gx); r /= gx;
+        by = (int)(c * rows + r % rows);
+        bz = (int)(r / rows);
+    }
+    bx = __builtin_amdgcn_readfirstlane(bx); by = __builtin_amdgcn_readfirstlane(by); bz = __builtin_amdgcn_readfirstlane(bz);
+}
 struct GenericWrap { long long xp, xm, yp, ym; bool top, xwall; };      // xwall: the x-face above this cell is a wall (Bounded x): zero flux
 template <int PASS>
 __device__ __forceinline__ bool generic_index(const DevGrid &g, int &i, int &j, int &k, int k0, GenericWrap &W)
 {
     const bool ext_y = !g.wrap_y && !g.flat_y;
-    i = blockIdx.x * 256 + threadIdx.x;
-    j = (int)blockIdx.y - ((PASS == 1 && ext_y) ? 1 : 0);
-    k = (PASS == 1 ? 0 : k0) + (int)blockIdx.z;
+    int bx, by, bz;
+    generic_block(bx, by, bz);
+    i = bx * 256 + threadIdx.x;
+    j = by - ((PASS == 1 && ext_y) ? 1 : 0);
+    k = (PASS == 1 ? 0 : k0) + bz;
     const long long sy = g.Sx;
     W.xp = (i + 1 < g.Nx || g.bounded_x) ? 1 : 1 - g.Nx;
     W.xm = (i > 0 || g.bounded_x) ? -1 : g.Nx - 1;
@@ -546,9 +572,11 @@ __global__ __launch_bounds__(64 * MTY, MARCH_WAVES) void k_tendency_m(DevGrid g,
     __shared__ double FY[2][MTY][MTY + 1][64];
     __shared__ double AX[MTY][MTY][64], AZ[MTY][MTY][64];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * MTY, i = i0 + tx, j = j0 + ty;
+    int bx, by, bz;
+    generic_block(bx, by, bz, GEN_XCD_MARCH != 0);
+    const int i0 = bx * 64, j0 = by * MTY, i = i0 + tx, j = j0 + ty;
     const int k0 = ZC ? 1 : 0, k1 = g.Nz;                    // levels [k0, k1)
-    const int kbeg = k0 + blockIdx.z * kchunk, kend = min(kbeg + kchunk, k1);      // kchunk <= 64: one edge flux per lane
+    const int kbeg = k0 + bz * kchunk, kend = min(kbeg + kchunk, k1);      // kchunk <= 64: one edge flux per lane
     if (kbeg >= kend) return;
     const long long sz = g.Sxy;
     const MarchFlux<R, KIND> Fl(g, ru, rv, rw, a);

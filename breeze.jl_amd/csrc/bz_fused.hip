@@ -116,12 +116,16 @@ __device__ __forceinline__ void st_yface(const DevGrid &g, double *__restrict__ 
 // traffic, r02_pmc_traffic.json).  Here XCD c owns the rows j in [c Ny/8, (c+1) Ny/8) of every level and walks them x fastest,
 // then y, then z: the row below was read by the previous workgroups of the same XCD (except at its first row), the level below one
 // eighth of a plane earlier (1.8 MB of traffic at 512^2 Float64: inside the 4 MB L2), and all XCDs stream through the same level.
+#ifndef BZ_STREAM_BANDS_F32
+#define BZ_STREAM_BANDS_F32 1
+#endif
 __device__ __forceinline__ void bz_stream_block(int gx, int Ny, int nk, int &bx, int &j, int &k)
 {
     const unsigned w = blockIdx.x;
     unsigned r;
-    // Float32 fields (half the bytes per row and plane) measured faster in plain launch order: 0.87 against 0.95 ms for k_project_lean at 512^3
-    if (sizeof(double) == 8 && (Ny & 7) == 0) {
+    // (Float32: round 3 measured plain launch order faster with one cell per thread, 0.87 against 0.95 ms for k_project_lean at 512^3; with two
+    // cells per thread — one workgroup per 512-cell row — the band order wins, 0.910 -> 0.872 ms: BZ_STREAM_BANDS_F32)
+    if ((sizeof(double) == 8 || BZ_STREAM_BANDS_F32) && (Ny & 7) == 0) {
         const unsigned c = w & 7u, rows = (unsigned)Ny >> 3;
         r = w >> 3;
         bx = (int)(r % (unsigned)gx); r /= (unsigned)gx;

@@ -103,6 +103,9 @@ static_assert(sizeof(LevRow5) == 16 * sizeof(double), "LevRow5 is sixteen reals"
 #endif
 // (later in round 4 the Float32 objects lost the SLP vectoriser — csrc/Makefile: F32FLAGS — and with it the operand-pair moves: the Float32
 // scalar kernel needs 75 - 80 registers with both additions and runs at six waves again: 0.97 -> 0.92 ms per launch in its dry form)
+#ifndef BZ5_EB
+#define BZ5_EB 64      // levels per batch of the out-of-wave x flux (lane l <-> level k + l): a power of two <= 64
+#endif
 #ifndef BZ5_RAW_LDS
 #define BZ5_RAW_LDS 1      // general scalar-pair body: the own cell's raw prognostic values ride LDS slots instead of being re-read (0: re-read)
 #endif
@@ -398,8 +401,8 @@ __device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean
         const double rho = LV.rho(k), rrho = LV.rrho(k), Ax_k = LV.Ax(k), Ay_k = LV.Ay(k), Vi_k = LV.Vinv_c(k);
         const double rho1 = LV.rho(k + 1), rrho1 = LV.rrho(k + 1), rhof1 = LV.rho_f(k + 1), rrhof1 = LV.rrho_f(k + 1);
         const double rho3 = LV.rho(k + 3), rrho3 = LV.rrho(k + 3);
-        if (((k - kbeg) & 63) == 0) {       // out-of-wave x flux for the next 64 levels (lane l <-> level k + l)
-            const int kk = min(k + tx, kend - 1);
+        if (((k - kbeg) & (BZ5_EB - 1)) == 0) {       // out-of-wave x flux for the next 64 levels (lane l <-> level k + l)
+            const int kk = min(k + (tx & (BZ5_EB - 1)), kend - 1);
             const long long ne = g.idx(ie, jc, kk);
             const double rhk = g.rho[kk], rrk = g.rrho[kk];
             const double ue = bz_cdiv(ru[ne], rhk, rrk);
@@ -411,7 +414,7 @@ __device__ __forceinline__ void k5_scalar_pair_body(const DevGrid &g, const Lean
             eb = rhk * (cf * bz_up5(bz_cdiv(pb[ne - 3], rhk, rrk), bz_cdiv(pb[ne - 2], rhk, rrk), bz_cdiv(pb[ne - 1], rhk, rrk),
                                     bz_cdiv(pb[ne], rhk, rrk), bz_cdiv(pb[ne + 1], rhk, rrk), bz_cdiv(pb[ne + 2], rhk, rrk), le_));
         }
-        const int src = (k - kbeg) & 63;
+        const int src = (k - kbeg) & (BZ5_EB - 1);
         // advecting fluxes of the three low/upper faces (shared by both fields)
         const double ut = bz_cdiv(ru_t, rho, rrho), vt = bz_cdiv(rv_t, rho, rrho);
         const double wt = bz_cdiv(rw_t, rhof1, rrhof1);
@@ -672,11 +675,11 @@ __global__ __launch_bounds__(64 * TY, BZ_LEAN_WAVES) void k6_u(DevGrid g, Lean5 
         const double p_h2 = (BZ_KO & 512) ? p_top : h2ok ? h2src[h2n + lev1] : 0.0;
         const double p_rv = (BZ_KO & 1024) ? p_top * 0.5 : rv[n + sz], p_rw = (BZ_KO & 1024) ? p_top * 0.25 : rw[n + 2 * sz];
         const double p_u0 = (BZ_KO & 2048) ? p_top : (E.mode == 2) ? E.u0[n + sz] : 0.0;
-        if (((k - kbeg) & 63) == 0) {
-            const int kk = min(k + tx, kend - 1);
+        if (((k - kbeg) & (BZ5_EB - 1)) == 0) {
+            const int kk = min(k + (tx & (BZ5_EB - 1)), kend - 1);
             edge = ST ? flux_x_at<T3_U>(g, F, ie, jc, kk) : flux_x_lean<T3_U>(g, F, ru, ie, jc, kk);
         }
-        const int src = (k - kbeg) & 63;
+        const int src = (k - kbeg) & (BZ5_EB - 1);
         const double Ax = g.Ax[k], Ay = g.Ay[k], Az = g.Az;
         const double c0 = r[3];
         const double(*Uk)[TC] = U[buf];
@@ -856,11 +859,11 @@ __global__ __launch_bounds__(64 * TY, ((MF && WY) ? 4 : BZ_LEAN_WAVES)) void k6_
         // (the last lane's two loads are requested here with the level's other loads and used after the stencil arithmetic)
         double cor_u = 0.0, cg1 = 0.0, cg3 = 0.0;
         if constexpr (MF) { if ((L.mforce & 1) && tx == 63) { const ix_t sy = (ix_t)g.Sx; cg1 = ru[n - sy + 1]; cg3 = ru[n + 1]; } }
-        if (((k - kbeg) & 63) == 0) {
-            const int kk = min(k + tx, kend - 1);
+        if (((k - kbeg) & (BZ5_EB - 1)) == 0) {
+            const int kk = min(k + (tx & (BZ5_EB - 1)), kend - 1);
             edge = ST ? flux_x_at<T3_V>(g, F, ie, jc, kk) : flux_x_lean<T3_V>(g, F, rv, ie, jc, kk, Bf);
         }
-        const int src = (k - kbeg) & 63;
+        const int src = (k - kbeg) & (BZ5_EB - 1);
         const double rho = g.rho[k];
         const double c0 = r[3];
         const double(*V)[TC] = Tv[buf];
@@ -1061,11 +1064,11 @@ __global__ __launch_bounds__(64 * TY, BZ6_W_WAVES) void k6_w(DevGrid g, Lean5 L,
         const double Axn = ST ? g.Ax[k + 2] : LV.Ax(k + 2), Ayn = ST ? g.Ay[k + 2] : LV.Ay(k + 2);
         const double qun = Axn * ru[n + 2 * sz], qvn = Ayn * rv[n + 2 * sz];
         const double qtn = top ? Ayn * rv[ntop0 + lev + 2 * sz] : 0.0;
-        if (((k - kbeg) & 63) == 0) {
-            const int kk = min(k + tx, kend - 1);
+        if (((k - kbeg) & (BZ5_EB - 1)) == 0) {
+            const int kk = min(k + (tx & (BZ5_EB - 1)), kend - 1);
             edge = ST ? flux_x_at<T3_W>(g, F, ie, jc, kk) : flux_x_lean<T3_W>(g, F, rw, ie, jc, kk);
         }
-        const int src = (k - kbeg) & 63;
+        const int src = (k - kbeg) & (BZ5_EB - 1);
         const int Bf = bz_buffer_face(k, g.Nz);
         const double w0 = wr[3];
         // ST: the raw momentum of the own column is read where it is used (level k + 2 for the advecting flux, level k for the RK update)

@@ -498,6 +498,30 @@ static AcFieldsT<ST> ac_cast(const AcFields &F)
         else hipLaunchKernelGGL((KERNEL<TA double>), GRID, BLOCK, 0, ctx->stream, g, FIELDS);                                    \
     } while (0)
 
+
+// Block order of the pointwise stage kernels (grid (Nx / 256, Ny, Nz)).  They read the row below (j - 1) and the level below (k - 1) of one to
+// three of their 19 - 41 arrays; in launch order row j - 1 belonged to another XCD and level k - 1 had been read a whole plane of all the arrays
+// earlier (PMC r05: stage-init 12.2 GB per launch for 10.2 GB of words, stage-end 23.0 / 25.1 for 19.9 / 22.0).  Here XCD c owns the groups of
+// eight rows G = c, c + 8, ... and walks a group x fastest, then its eight rows, then z: the level below is eight rows of traffic away (~0.7 MB),
+// the row below inside the group too.  Ny a multiple of 64, else launch order.
+#ifndef AC_PENCIL
+#define AC_PENCIL 1
+#endif
+__device__ __forceinline__ void ac_pencil_block(int &bx, int &j, int &k)
+{
+    bx = blockIdx.x; j = blockIdx.y; k = blockIdx.z;
+    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    if (AC_PENCIL && (gy & 63u) == 0) {
+        const unsigned w = bx + gx * (j + gy * k), c = w & 7u;
+        unsigned r = w >> 3;
+        bx = (int)(r % gx); r /= gx;
+        const unsigned jj = r & 7u; r >>= 3;
+        k = (int)(r % gz); r /= gz;
+        j = (int)(((r * 8 + c) * 8) + jj);
+    }
+    bx = __builtin_amdgcn_readfirstlane(bx); j = __builtin_amdgcn_readfirstlane(j); k = __builtin_amdgcn_readfirstlane(k);
+}
+
 // assemble_slow_vertical_momentum_tendency! + initialize_stage_perturbations! (acoustic_substepping.jl:727-752,793-838)
 // ZERO: the three time-average accumulators are zeroed here (unfused substeps); with the fused substep kernels the first substep of a
 // stage assigns them instead (three words per cell and stage written only to be read back once).
@@ -506,7 +530,9 @@ static AcFieldsT<ST> ac_cast(const AcFields &F)
 template <bool ZERO, bool STORE0, class ST>
 __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> F)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    int bx, j, k;
+    ac_pencil_block(bx, j, k);
+    const int i = bx * 256 + threadIdx.x;
     if (i >= g.Nx) return;
     const long long sz = g.Sxy;
     const long long n = g.idx(i, j, k);
@@ -893,7 +919,9 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
                                                       double abstol, int maxiter)
 {
     constexpr bool KES = (MP == 2), SA = (MP == 1);
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    int bx, j, k;
+    ac_pencil_block(bx, j, k);
+    const int i = bx * 256 + threadIdx.x;
     if (i >= g.Nx) return;
     const WrapIdx W = wrap_of(g, i, j);
     const long long ox = W.ox, oy = W.oy;

@@ -449,6 +449,7 @@ struct AcFieldsT {
     // outer-step start and slow tendencies
     const double *U0_rho_d, *U0_rth, *U0_ru, *U0_rv, *U0_rw, *U0_rq;
     const double *G_rho_d, *G_rth, *G_ru, *G_rv, *G_rw, *G_rq;
+    double *Gp_ru, *Gp_rv;        // G_ru - dx p^L, G_rv - dy p^L of the stage (k_ac_stage_init<.., PF>; read by k_ac_forward2<.., PF>)
     // substepper
     const ST *thL, *Clin;
     ST *rp, *rthp, *rup, *rvp;
@@ -476,6 +477,7 @@ static AcFieldsT<ST> ac_cast(const AcFields &F)
     R.rho_d = F.rho_d; R.rth = F.rth; R.ru = F.ru; R.rv = F.rv; R.rw = F.rw; R.rq = F.rq; R.rho = F.rho; R.p = F.p;
     R.U0_rho_d = F.U0_rho_d; R.U0_rth = F.U0_rth; R.U0_ru = F.U0_ru; R.U0_rv = F.U0_rv; R.U0_rw = F.U0_rw; R.U0_rq = F.U0_rq;
     R.G_rho_d = F.G_rho_d; R.G_rth = F.G_rth; R.G_ru = F.G_ru; R.G_rv = F.G_rv; R.G_rw = F.G_rw; R.G_rq = F.G_rq;
+    R.Gp_ru = F.Gp_ru; R.Gp_rv = F.Gp_rv;
     R.thL = (const ST *)F.thL; R.Clin = (const ST *)F.Clin;
     R.rp = (ST *)F.rp; R.rthp = (ST *)F.rthp; R.rup = (ST *)F.rup; R.rvp = (ST *)F.rvp; R.rwp = F.rwp;
     R.rs = (ST *)F.rs; R.rths = (ST *)F.rths; R.rth_old = (ST *)F.rth_old;
@@ -527,7 +529,9 @@ __device__ __forceinline__ void ac_pencil_block(int &bx, int &j, int &k)
 // stage assigns them instead (three words per cell and stage written only to be read back once).
 // STORE0: first stage of a whole step — the state IS U0, so the perturbations are exact zeros and store_initial_state! rides along
 // (the six copies of bzi_compressible_store_initial_state: 12 words per cell; here 6, and the five state reads are shared).
-template <bool ZERO, bool STORE0, class ST>
+// PF (round 6): the horizontal gradient of the stage's p^L, which the reference's explicit horizontal step re-evaluates in every substep
+// (acoustic_substepping.jl:859-876), is folded into the slow tendencies once per stage: Gp_ru = G_ru - dx p^L, Gp_rv = G_rv - dy p^L.
+template <bool ZERO, bool STORE0, bool PF, class ST>
 __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> F)
 {
     int bx, j, k;
@@ -536,6 +540,12 @@ __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> 
     if (i >= g.Nx) return;
     const long long sz = g.Sxy;
     const long long n = g.idx(i, j, k);
+    if (PF) {
+        const WrapIdx W = wrap_of(g, i, j);
+        const double p0 = F.p[n];
+        F.Gp_ru[n] = F.G_ru[n] - (p0 - F.p[n + W.im]) * g.rdx;
+        F.Gp_rv[n] = F.G_rv[n] - (p0 - F.p[n + W.jm]) * g.rdy;
+    }
     if (STORE0) {
         // U0 - U with U0 := U: (+0) for every finite value, as the subtraction of the stored copy gives
         ((double *)F.U0_rho_d)[n] = F.rho_d[n];
@@ -801,6 +811,191 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
                 if (k + 2 < Nz) { thy_m1 = F.thL[n + 2 * sz + W.jm]; thy_p1 = F.thL[n + 2 * sz + W.jp]; }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the fused forward sweep written for the memory pipe.  The kernel above spends 77 % of its wave cycles parked
+// (profiles/r05_pmc_compressible.json) for two reasons its ISA shows:
+//   * its stores (rup, rvp, au, av, rs, rths, phi) cannot be proven not to alias the loads that follow them in program order (au / av are
+//     read-modify-write, the ring loads of the next level sit below the stores), so hipcc keeps that order and — the vector-memory counter
+//     returns in order — drains everything outstanding four times per level (`s_waitcnt vmcnt(0)`; store, one load, drain, store, ...):
+//     four to five memory round trips per level instead of one;
+//   * every `F.x[n + d]` is a 64-bit per-lane address: 45 base pairs = 90 of its 214 VGPRs hold addresses (two waves per SIMD).
+// Here every load of a level — the level's own words, the neighbours' and the ring words of the levels above — is issued before the
+// first store of the level, all stores close the level, and every access is `uniform base + 32-bit per-lane byte offset` (the saddr form
+// of global_load: one offset register per neighbour displacement).  The arithmetic is the text of the kernel above, so the results carry
+// its bits; PF folds the stage-constant horizontal gradient of p^L into the slow tendencies (Gp_ru, Gp_rv written by k_ac_stage_init:
+// one array and four neighbour loads less per level and substep; the only deviation, one rounding of G - dp).
+// Neighbours in x of theta_L, C, (rho theta)' and its previous value come from the neighbouring lanes; the two edge lanes of a row fetch
+// theirs with one predicated load per array.
+// ---------------------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T ac_ld(const T *base, unsigned e)
+{
+    return *(const T *)((const char *)base + (size_t)(e * (unsigned)sizeof(T)));
+}
+template <class T, class V>
+__device__ __forceinline__ void ac_st(T *base, unsigned e, V v)
+{
+    *(T *)((char *)base + (size_t)(e * (unsigned)sizeof(T))) = (T)v;
+}
+
+template <bool DAMP, bool PF>
+__device__ __forceinline__ double ac_face_update2(double up, double G, double rt_b, double rt_a, double rto_b, double rto_a,
+                                                  double th_b, double th_a, double C_b, double C_a, double p_b, double p_a,
+                                                  double rd, const AcParams &P)
+{
+    if (DAMP) {
+        const double dd = ((rt_b - rto_b) - (rt_a - rto_a)) * rd;
+        up -= P.kdamp * dd / ((th_b + th_a) / 2.0);
+    }
+    if (PF) {      // G already carries -(p_b - p_a) rd
+        if (P.gate != 0.0) G = G - P.gate * ((C_b * rt_b - C_a * rt_a) * rd);
+        return up + P.dtau * G;
+    }
+    double dp = (p_b - p_a) * rd;
+    if (P.gate != 0.0) dp = dp + P.gate * ((C_b * rt_b - C_a * rt_a) * rd);
+    return up + P.dtau * (G - dp);
+}
+
+template <bool FIRST, bool DAMP, bool PF, int MW, class ST>
+__global__ __launch_bounds__(ACX * ACY, MW) void k_ac_forward2(DevGrid g, AcFieldsT<ST> F, AcParams P)
+{
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (P.xcd) {      // XCD c owns the band of tile rows [c gy/8, (c+1) gy/8) (see k_ac_column_forward)
+        const unsigned w = blockIdx.y * gridDim.x + blockIdx.x, c = w & 7u, r = w >> 3;
+        bx = (int)(r % gridDim.x);
+        by = (int)(c * (gridDim.y >> 3) + r / gridDim.x);
+    }
+    const int i = bx * ACX + threadIdx.x, j = by * ACY + threadIdx.y;
+    if (i >= g.Nx || j >= g.Ny) return;
+    const WrapIdx W = wrap_of(g, i, j);
+    const unsigned sz = (unsigned)g.Sxy;
+    const unsigned dxp = (unsigned)(int)W.ip, dym = (unsigned)(int)W.jm, dyp = (unsigned)(int)W.jp;
+    const int Nz = g.Nz;
+    unsigned e = (unsigned)g.idx(i, j, 0);
+    const double dtn2 = P.dtn * P.dtn;
+    const int lane = threadIdx.x;
+    const bool edge_m = (lane == 0), edge_p = (lane == ACX - 1 || i == g.Nx - 1);
+    const bool edge = edge_m || edge_p;
+    const unsigned dedge = edge_m ? (unsigned)(int)W.im : dxp;
+    const ColPtr::cptr sponge = (ColPtr::cptr)F.sponge;
+    const double *Gu = PF ? F.Gp_ru : F.G_ru, *Gv = PF ? F.Gp_rv : F.G_rv;
+
+    // rings (see k_ac_column_forward): theta_L at k, k+1 of the own column and of rows j-1 / j+1, C at k-1, k (rows j-1 / j+1: k),
+    // old (rho w)' at faces k-1, k, k+1
+    double th_0 = ac_ld(F.thL, e), th_p = ac_ld(F.thL, e + sz);
+    double C_m = 0.0, C_0 = ac_ld(F.Clin, e);
+    double thy_m0 = ac_ld(F.thL, e + dym), thy_p0 = ac_ld(F.thL, e + dyp);
+    double thy_m1 = ac_ld(F.thL, e + sz + dym), thy_p1 = ac_ld(F.thL, e + sz + dyp);
+    double cy_m0 = ac_ld(F.Clin, e + dym), cy_p0 = ac_ld(F.Clin, e + dyp);
+    double w_m = 0.0, w_0 = ac_ld(F.rwp, e), w_p = ac_ld(F.rwp, e + sz);
+    double rs_m = 0.0, rths_m = 0.0, rp_m = 0.0, rthp_m = 0.0;
+    double beta = 1.0, phi_m = 0.0, c_m = 0.0;     // row 0: b = 1, c = 0, f = 0
+    double thf_0 = th_0, thf_m = th_0;               // theta at faces k (k = 0: one-sided) and k-1
+
+    for (int k = 0; k < Nz; ++k, e += sz) {
+        const double rdc = g.rdzc[k];
+        const double Ax = g.Ax[k], Ay = g.Ay[k], Vinv = g.Vinv_c[k];
+        const unsigned exp_ = e + dxp, eym = e + dym, eyp = e + dyp;
+        // ---- every load of the level ----
+        const double rp = ac_ld(F.rp, e), rthp = ac_ld(F.rthp, e);
+        const double rt_ym = ac_ld(F.rthp, eym), rt_yp = ac_ld(F.rthp, eyp);
+        double o0 = 0.0, o_ym = 0.0, o_yp = 0.0;
+        if (DAMP) { o0 = ac_ld(F.rth_old, e); o_ym = ac_ld(F.rth_old, eym); o_yp = ac_ld(F.rth_old, eyp); }
+        const double ru0 = ac_ld(F.rup_in, e), ru1 = ac_ld(F.rup_in, exp_), rv0 = ac_ld(F.rvp_in, e), rv1 = ac_ld(F.rvp_in, eyp);
+        const double Gu0 = ac_ld(Gu, e), Gu1 = ac_ld(Gu, exp_), Gv0 = ac_ld(Gv, e), Gv1 = ac_ld(Gv, eyp);
+        double p0 = 0.0, p_xm = 0.0, p_xp = 0.0, p_ym = 0.0, p_yp = 0.0;
+        if (!PF) {
+            p0 = ac_ld(F.p, e); p_xm = ac_ld(F.p, e + (unsigned)(int)W.im); p_xp = ac_ld(F.p, exp_);
+            p_ym = ac_ld(F.p, eym); p_yp = ac_ld(F.p, eyp);
+        }
+        double au_o = 0.0, av_o = 0.0;
+        if (!FIRST) { au_o = ac_ld(F.au, e); av_o = ac_ld(F.av, e); }
+        const double Grho = ac_ld(F.G_rho_d, e), Grth = ac_ld(F.G_rth, e), Gs_k = ac_ld(F.Gs, e);
+        double e_th = 0.0, e_C = 0.0, e_rt = 0.0, e_o = 0.0;      // the row's outer neighbour: lane 0 the left one, the last lane the right one
+        if (edge) {
+            const unsigned ee = e + dedge;
+            e_th = ac_ld(F.thL, ee); e_C = ac_ld(F.Clin, ee); e_rt = ac_ld(F.rthp, ee);
+            if (DAMP) e_o = ac_ld(F.rth_old, ee);
+        }
+        // ring words of the levels above (the last levels re-read an in-range level; those values are never used)
+        const unsigned e1 = (k + 1 < Nz) ? e + sz : e, e2 = (k + 2 < Nz) ? e1 + sz : e1;
+        const double C_n = ac_ld(F.Clin, e1), cy_mn = ac_ld(F.Clin, e1 + dym), cy_pn = ac_ld(F.Clin, e1 + dyp);
+        const double th_n = ac_ld(F.thL, e2), thy_mn = ac_ld(F.thL, e2 + dym), thy_pn = ac_ld(F.thL, e2 + dyp);
+        const double w_n = ac_ld(F.rwp, e1 + sz);
+        const double sp = sponge[k];                // sponge_rhs / sponge_term_diag (acoustic_substepping.jl:591-602)
+
+        // ---- neighbours in x from the neighbouring lanes ----
+        double thxm = __shfl_up(th_0, 1), thxp = __shfl_down(th_0, 1);
+        double c_xm = __shfl_up(C_0, 1), c_xp = __shfl_down(C_0, 1);
+        double rt_xm = __shfl_up(rthp, 1), rt_xp = __shfl_down(rthp, 1);
+        double o_xm = 0.0, o_xp = 0.0;
+        if (DAMP) { o_xm = __shfl_up(o0, 1); o_xp = __shfl_down(o0, 1); }
+        if (edge_m) { thxm = e_th; c_xm = e_C; rt_xm = e_rt; o_xm = e_o; }
+        if (edge_p) { thxp = e_th; c_xp = e_C; rt_xp = e_rt; o_xp = e_o; }
+        const double thym = thy_m0, thyp = thy_p0, c_ym = cy_m0, c_yp = cy_p0;
+
+        const double up0 = ac_face_update2<DAMP, PF>(ru0, Gu0, rthp, rt_xm, o0, o_xm, th_0, thxm, C_0, c_xm, p0, p_xm, g.rdx, P);
+        const double up1 = ac_face_update2<DAMP, PF>(ru1, Gu1, rt_xp, rthp, o_xp, o0, thxp, th_0, c_xp, C_0, p_xp, p0, g.rdx, P);
+        const double vp0 = ac_face_update2<DAMP, PF>(rv0, Gv0, rthp, rt_ym, o0, o_ym, th_0, thym, C_0, c_ym, p0, p_ym, g.rdy, P);
+        const double vp1 = ac_face_update2<DAMP, PF>(rv1, Gv1, rt_yp, rthp, o_yp, o0, thyp, th_0, c_yp, C_0, p_yp, p0, g.rdy, P);
+        const double au_n = FIRST ? 0.0 + up0 : au_o + up0, av_n = FIRST ? 0.0 + vp0 : av_o + vp0;
+        // theta face k+1 (top face: one-sided)
+        const double thf_p = (k + 1 < Nz) ? (th_p + th_0) / 2.0 : th_0;
+
+        const double dxM = Ax * up1 - Ax * up0;
+        const double dxT = Ax * ((thxp + th_0) / 2.0) * up1 - Ax * ((th_0 + thxm) / 2.0) * up0;
+        const double dyM = Ay * vp1 - Ay * vp0;
+        const double dyT = Ay * ((thyp + th_0) / 2.0) * vp1 - Ay * ((th_0 + thym) / 2.0) * vp0;
+        const double divM = Vinv * (dxM + dyM);
+        const double divT = Vinv * (dxT + dyT);
+        const double dzW = (w_p - w_0) * rdc;
+        const double dzT = (thf_p * w_p - thf_0 * w_0) * rdc;
+        const double rs = rp + P.dtau * (Grho - divM) - P.dto * dzW;
+        const double rths = rthp + P.dtau * (P.f_theta * Grth - divT) - P.dto * dzT;
+
+        double phi = 0.0, t = 0.0;
+        if (k > 0) {
+            const double rdf = g.rdzf[k], rdm = g.rdzc[k - 1];
+            // right-hand side at face k
+            const double dps = (C_0 * rths - C_m * rths_m) * rdf;
+            const double dpo = (C_0 * rthp - C_m * rthp_m) * rdf;
+            const double Gp = P.dto * dpo + P.dtn * dps;
+            const double Gb = g.g * (P.dto * ((rp + rp_m) / 2.0) + P.dtn * ((rs + rs_m) / 2.0));
+            const double d2 = ((w_p - w_0) * rdc - (w_0 - w_m) * rdm) * rdf;
+            const double Gd = -P.d_old * d2;
+            const double f = w_0 + P.dtau * P.f_w * Gs_k - Gp - Gb - Gd - fabs(P.dto) * sp * w_0;
+            // coefficients of row k
+            const double a = -dtn2 * C_m * thf_m * rdm * rdf + dtn2 * g.g * rdm / 2.0 + (-P.d_new * rdm * rdf);
+            const double b = 1.0 + (dtn2 * thf_0 * (C_0 * rdc + C_m * rdm) * rdf + dtn2 * g.g * (rdc - rdm) / 2.0 +
+                                    P.d_new * (rdc + rdm) * rdf + fabs(P.dtn) * sp);
+            t = c_m / beta;
+            beta = b - a * t;
+            phi = (f - a * phi_m) / beta;
+            // upper coefficient of this row, used by the next one
+            c_m = -dtn2 * C_0 * thf_p * rdc * rdf + (-dtn2 * g.g * rdc / 2.0) + (-P.d_new * rdc * rdf);
+        }
+        // ---- every store of the level ----
+        ac_st(F.rup, e, up0);
+        ac_st(F.rvp, e, vp0);
+        ac_st(F.au, e, au_n);
+        ac_st(F.av, e, av_n);
+        ac_st(F.rs, e, rs);
+        ac_st(F.rths, e, rths);
+        if (FIRST) ac_st(F.tfac, e, t);
+        ac_st(F.phi, e, phi);
+        phi_m = phi;
+
+        // advance the rings
+        rs_m = rs; rths_m = rths; rp_m = rp; rthp_m = rthp;
+        C_m = C_0; C_0 = C_n;
+        thf_m = thf_0; thf_0 = thf_p;
+        th_0 = th_p; th_p = th_n;
+        w_m = w_0; w_0 = w_p; w_p = w_n;
+        cy_m0 = cy_mn; cy_p0 = cy_pn;
+        thy_m0 = thy_m1; thy_p0 = thy_p1; thy_m1 = thy_mn; thy_p1 = thy_pn;
     }
 }
 
@@ -1190,10 +1385,16 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
         hipMalloc(&ctx->d_tfac_ac, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_up2, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_thL2, ncell * sizeof(double)) != hipSuccess ||
-        hipMalloc(&ctx->d_vp2, ncell * sizeof(double)) != hipSuccess) {
+        hipMalloc(&ctx->d_vp2, ncell * sizeof(double)) != hipSuccess ||
+        (ctx->tune.ac_pfold && !slab && (hipMalloc(&ctx->d_Gp_ru, ncell * sizeof(double)) != hipSuccess ||
+                                         hipMalloc(&ctx->d_Gp_rv, ncell * sizeof(double)) != hipSuccess))) {
         bz_destroy(ctx);
         *out = nullptr;
         return BZ_ERR_ALLOC;
+    }
+    if (ctx->d_Gp_ru) {
+        (void)hipMemset(ctx->d_Gp_ru, 0, ncell * sizeof(double));
+        (void)hipMemset(ctx->d_Gp_rv, 0, ncell * sizeof(double));
     }
     (void)hipMemset(ctx->d_Clin, 0, ncell * sizeof(double));
     (void)hipMemset(ctx->d_tfac_ac, 0, ncell * sizeof(double));
@@ -1230,6 +1431,9 @@ void bzi_compressible_teardown(bz_ctx *ctx)
     ctx->d_thL2 = nullptr;
     if (ctx->d_vp2) (void)hipFree(ctx->d_vp2);
     if (ctx->d_sponge) (void)hipFree(ctx->d_sponge);
+    if (ctx->d_Gp_ru) (void)hipFree(ctx->d_Gp_ru);
+    if (ctx->d_Gp_rv) (void)hipFree(ctx->d_Gp_rv);
+    ctx->d_Gp_ru = ctx->d_Gp_rv = nullptr;
     ctx->d_Clin = ctx->d_tfac_ac = ctx->d_up2 = ctx->d_vp2 = ctx->d_sponge = nullptr;
 }
 
@@ -1423,6 +1627,7 @@ static AcFields ac_fields(bz_ctx *ctx, const bz_compressible_state *s, const bz_
     F.tfac = ctx->d_tfac_ac;
     F.sponge = ctx->d_sponge;
     F.rup_in = F.rup; F.rvp_in = F.rvp; F.rthp_out = F.rthp;
+    F.Gp_ru = ctx->d_Gp_ru; F.Gp_rv = ctx->d_Gp_rv;
     const bz_kessler_model_fields &K = ctx->kessler;
     F.rqcl = K.cloud_liquid_density; F.rqr = K.rain_density;
     F.U0_rqcl = K.U0_cloud_liquid_density; F.U0_rqr = K.U0_rain_density;
@@ -1466,8 +1671,17 @@ __global__ __launch_bounds__(256) void k_ac_direct_apply(DevGrid g, const double
 struct AcStage {
     int ntau = 0, cur = 0, done = 0;
     bool damping = false, fused = true, direct = false;
+    bool fwd2 = false, pfold = false;      // k_ac_forward2 runs the forward sweeps of this stage; with the p^L gradient folded into Gp_ru / Gp_rv
     AcParams P;
 };
+// k_ac_forward2 addresses every array by a 32-bit byte offset from its base and fetches the outer x neighbours of a row's two edge lanes
+// with one load: arrays below 4 GB, two z halo levels (its ring words are requested two levels ahead), no row whose first lane is its last
+static bool ac_forward2_ok(const bz_ctx *ctx)
+{
+    const DevGrid &g = ctx->dg;
+    const unsigned long long bytes = (unsigned long long)g.Sxy * (unsigned long long)(g.Nz + 2 * g.Hz + 1) * sizeof(double);
+    return ctx->tune.ac_forward2 && ACX == 64 && bytes < (1ull << 32) && g.Hz >= 1 && g.Nx >= 2 && (g.Nx % ACX) != 1;
+}
 static AcStage &stage_of(bz_ctx *ctx)
 {
     static_assert(sizeof(AcStage) <= sizeof(ctx->ac_stage_storage), "AcStage does not fit its storage in bz_ctx");
@@ -1543,11 +1757,39 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     Fi.rthp_out = th_buf[S.cur]; Fi.rup = u_buf[S.cur]; Fi.rvp = v_buf[S.cur];
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
     // first stage of a whole step (the caller passes store0): the state is U0 — store_initial_state! rides along
-    if (S.fused && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA, rows, b256, Fi);
-    else if (S.fused) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA, rows, b256, Fi);
-    else AC_LAUNCH0(k_ac_stage_init, true COMMA false COMMA, rows, b256, Fi);
+    S.fwd2 = S.fused && ac_forward2_ok(ctx);
+    S.pfold = S.fwd2 && ctx->d_Gp_ru && !ctx->slab_mode;
+    if (S.pfold && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA, rows, b256, Fi);
+    else if (S.pfold) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA true COMMA, rows, b256, Fi);
+    else if (S.fused && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA, rows, b256, Fi);
+    else if (S.fused) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA false COMMA, rows, b256, Fi);
+    else AC_LAUNCH0(k_ac_stage_init, true COMMA false COMMA false COMMA, rows, b256, Fi);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
+}
+
+// the forward sweep of a fused substep through k_ac_forward2: first substep of the stage / damping of the previous substep / folded p^L
+// gradient, at the register budget for MW waves per SIMD (BZ_AC_MW)
+template <bool PF, int MW>
+static void launch_forward2_mw(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp)
+{
+    const DevGrid &g = ctx->dg;
+    if (first) AC_LAUNCH(k_ac_forward2, true COMMA false COMMA PF COMMA MW COMMA, cols, bcol, Fs, P);
+    else if (damp) AC_LAUNCH(k_ac_forward2, false COMMA true COMMA PF COMMA MW COMMA, cols, bcol, Fs, P);
+    else AC_LAUNCH(k_ac_forward2, false COMMA false COMMA PF COMMA MW COMMA, cols, bcol, Fs, P);
+}
+static void launch_forward2(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, bool pfold)
+{
+    const int mw = ctx->tune.ac_mw;
+    if (pfold) {
+        if (mw <= 2) launch_forward2_mw<true, 2>(ctx, Fs, P, cols, bcol, first, damp);
+        else if (mw == 3) launch_forward2_mw<true, 3>(ctx, Fs, P, cols, bcol, first, damp);
+        else launch_forward2_mw<true, 4>(ctx, Fs, P, cols, bcol, first, damp);
+    } else {
+        if (mw <= 2) launch_forward2_mw<false, 2>(ctx, Fs, P, cols, bcol, first, damp);
+        else if (mw == 3) launch_forward2_mw<false, 3>(ctx, Fs, P, cols, bcol, first, damp);
+        else launch_forward2_mw<false, 4>(ctx, Fs, P, cols, bcol, first, damp);
+    }
 }
 
 // substep `sstep` (1-based) of the stage opened by bzi_acoustic_stage_begin
@@ -1580,7 +1822,9 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
         Fs.rvp_in = v_buf[cur]; Fs.rvp = v_buf[cur ^ 1];
         {
             ProfileScope ps(ctx, "acoustic_horizontal+column_forward");
-            if (sstep == 1)
+            if (S.fwd2)
+                launch_forward2(ctx, Fs, P, cols, bcol, sstep == 1, damp, S.pfold);
+            else if (sstep == 1)
                 AC_LAUNCH(k_ac_column_forward, true COMMA true COMMA false COMMA, cols, bcol, Fs, P);
             else if (damp)
                 AC_LAUNCH(k_ac_column_forward, false COMMA true COMMA true COMMA, cols, bcol, Fs, P);

@@ -62,6 +62,9 @@ void bzi_read_tuning(bz_tuning &t)
     t.no_fold_forcing = on("BZ_NO_FOLD_FORCING");
     t.no_fuse_level_sums = on("BZ_NO_FUSE_LEVEL_SUMS");
     t.ac_xcd = num("BZ_AC_XCD", 1);
+    t.ac_forward2 = num("BZ_AC_FWD2", 1);
+    t.ac_pfold = num("BZ_AC_PFOLD", 1);
+    t.ac_mw = num("BZ_AC_MW", 3);
     t.no_tridiag_coop = on("BZ_NO_TRIDIAG_COOP");
     t.no_xfft = on("BZ_NO_XFFT");
     t.poisson_chunk = num("BZ_POISSON_CHUNK", 0);

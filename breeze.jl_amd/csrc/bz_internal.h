@@ -308,6 +308,9 @@ struct bz_tuning {
     bool no_fuse_forcing = false;     // BZ_NO_FUSE_FORCING
     bool no_fold_forcing = false;     // BZ_NO_FOLD_FORCING: the fused-RK tier keeps the momentum terms of the forcing stack in the forcing pass
     int ac_xcd = 1;                   // BZ_AC_XCD=0: the forward acoustic sweep in launch order (XCD = tile column) instead of XCD = band of tile rows
+    int ac_forward2 = 1;              // BZ_AC_FWD2=0: the round-5 forward acoustic sweep (k_ac_column_forward) instead of k_ac_forward2
+    int ac_pfold = 1;                 // BZ_AC_PFOLD=0: the horizontal gradient of p^L stays in every substep instead of folded into the stage's slow tendencies
+    int ac_mw = 3;                    // BZ_AC_MW: register budget of k_ac_forward2 as waves per SIMD (2, 3, 4)
     bool no_fuse_level_sums = false;  // BZ_NO_FUSE_LEVEL_SUMS: the subsidence averages always come from their own pass over u, v, theta, q
     bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms
@@ -416,6 +419,7 @@ struct bz_ctx {
     double *d_Clin = nullptr;         // centre array: gamma R_m * Pi of the current linearisation
     double *d_tfac_ac = nullptr;      // centre array: Thomas factors t_k of the acoustic column system (per stage)
     double *d_up2 = nullptr, *d_vp2 = nullptr;   // second buffers of the (rho u)', (rho v)' ping-pong (fused substep)
+    double *d_Gp_ru = nullptr, *d_Gp_rv = nullptr;   // slow horizontal momentum tendencies minus the gradient of the stage's p^L (k_ac_stage_init<PF>, round 6)
     double *d_thL2 = nullptr;         // second buffer of theta_L: the fused stage epilogue writes the next stage's linearisation while it still reads this one's
     bool thL_alt = false;             // the current theta_L lives in d_thL2 (whole-step seam only; every per-operator linearisation resets it)
     bool substep_f32 = false;         // substep_floattype = Float32 inside the Float64 library: the substepper's working fields are float arrays

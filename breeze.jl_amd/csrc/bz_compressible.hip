@@ -840,6 +840,47 @@ __device__ __forceinline__ void ac_st(T *base, unsigned e, V v)
 {
     *(T *)((char *)base + (size_t)(e * (unsigned)sizeof(T))) = (T)v;
 }
+// the same for words no other column reads (or that are read once): non-temporal, so that they do not displace the neighbour-shared
+// lines (theta_L, C, (rho theta)', the momentum perturbations and their tendencies) from the L2 before the neighbour row asks for them
+#ifndef AC2_NT
+#define AC2_NT 0
+#endif
+#ifndef AC2_BARRIER
+#define AC2_BARRIER 0
+#endif
+template <class T>
+__device__ __forceinline__ T ac_ld_nt(const T *base, unsigned e)
+{
+    if (AC2_NT & 1) return __builtin_nontemporal_load((const T *)((const char *)base + (size_t)(e * (unsigned)sizeof(T))));
+    return ac_ld(base, e);
+}
+template <class T, class V>
+__device__ __forceinline__ void ac_st_nt(T *base, unsigned e, V v)
+{
+    if (AC2_NT & 2) __builtin_nontemporal_store((T)v, (T *)((char *)base + (size_t)(e * (unsigned)sizeof(T))));
+    else ac_st(base, e, v);
+}
+
+// a value one lane up / down the 64-lane wavefront (lane l receives lane l - 1 / l + 1) as two v_mov_b32_dpp wave_shr:1 / wave_shl:1 — 4 cycles of
+// the vector ALU each where __shfl_up / __shfl_down are ds_bpermute_b32 at 10 ns of the CU's LDS pipe (instruction costs;
+// tools/dpp_check.hip: the same values, also with the upper lanes of a ragged row gone)
+template <int CTRL, class T>
+__device__ __forceinline__ T ac_lane_shift(T v)
+{
+    if constexpr (sizeof(T) == 8) {
+        const long long b = __builtin_bit_cast(long long, v);
+        int lo = (int)b, hi = (int)(b >> 32);
+        lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | (long long)(unsigned)lo);
+    } else {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    }
+}
+template <bool DPP>
+__device__ __forceinline__ double ac_lane_up(double v) { return DPP ? ac_lane_shift<0x138>(v) : __shfl_up(v, 1); }
+template <bool DPP>
+__device__ __forceinline__ double ac_lane_down(double v) { return DPP ? ac_lane_shift<0x130>(v) : __shfl_down(v, 1); }
 
 template <bool DAMP, bool PF>
 __device__ __forceinline__ double ac_face_update2(double up, double G, double rt_b, double rt_a, double rto_b, double rto_a,
@@ -859,8 +900,11 @@ __device__ __forceinline__ double ac_face_update2(double up, double G, double rt
     return up + P.dtau * (G - dp);
 }
 
-template <bool FIRST, bool DAMP, bool PF, int MW, class ST>
-__global__ __launch_bounds__(ACX * ACY, MW) void k_ac_forward2(DevGrid g, AcFieldsT<ST> F, AcParams P)
+// CFG: bit 0: 512 threads per block instead of 256; bit 1: register budget for three waves per SIMD instead of two; bit 2: the rows of a
+// block advance level by level together (one s_barrier per level); bit 3: the loads of level k + 1 are issued before level k is worked on;
+// bit 4: x neighbours by DPP wavefront shifts instead of ds_bpermute
+template <bool FIRST, bool DAMP, bool PF, int CFG, class ST>
+__global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac_forward2(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
     int bx = blockIdx.x, by = blockIdx.y;
     if (P.xcd) {      // XCD c owns the band of tile rows [c gy/8, (c+1) gy/8) (see k_ac_column_forward)
@@ -868,7 +912,8 @@ __global__ __launch_bounds__(ACX * ACY, MW) void k_ac_forward2(DevGrid g, AcFiel
         bx = (int)(r % gridDim.x);
         by = (int)(c * (gridDim.y >> 3) + r / gridDim.x);
     }
-    const int i = bx * ACX + threadIdx.x, j = by * ACY + threadIdx.y;
+    // 256 threads as 64 x 4, 128 x 2 or 256 x 1 columns (BZ_AC_BX): a wavefront is always 64 consecutive cells of one row
+    const int i = bx * (int)blockDim.x + threadIdx.x, j = by * (int)blockDim.y + threadIdx.y;
     if (i >= g.Nx || j >= g.Ny) return;
     const WrapIdx W = wrap_of(g, i, j);
     const unsigned sz = (unsigned)g.Sxy;
@@ -876,8 +921,8 @@ __global__ __launch_bounds__(ACX * ACY, MW) void k_ac_forward2(DevGrid g, AcFiel
     const int Nz = g.Nz;
     unsigned e = (unsigned)g.idx(i, j, 0);
     const double dtn2 = P.dtn * P.dtn;
-    const int lane = threadIdx.x;
-    const bool edge_m = (lane == 0), edge_p = (lane == ACX - 1 || i == g.Nx - 1);
+    const int lane = threadIdx.x & 63;
+    const bool edge_m = (lane == 0), edge_p = (lane == 63 || i == g.Nx - 1);
     const bool edge = edge_m || edge_p;
     const unsigned dedge = edge_m ? (unsigned)(int)W.im : dxp;
     const ColPtr::cptr sponge = (ColPtr::cptr)F.sponge;
@@ -895,44 +940,63 @@ __global__ __launch_bounds__(ACX * ACY, MW) void k_ac_forward2(DevGrid g, AcFiel
     double beta = 1.0, phi_m = 0.0, c_m = 0.0;     // row 0: b = 1, c = 0, f = 0
     double thf_0 = th_0, thf_m = th_0;               // theta at faces k (k = 0: one-sided) and k-1
 
-    for (int k = 0; k < Nz; ++k, e += sz) {
-        const double rdc = g.rdzc[k];
-        const double Ax = g.Ax[k], Ay = g.Ay[k], Vinv = g.Vinv_c[k];
+    // every word a level asks the memory for, as one record: `level(e, k)` issues the loads (own level k, the neighbours', the ring words of the
+    // levels above); with CFG bit 3 the record of level k + 1 is requested before level k is worked on (its loads fly under the ~280 VALU
+    // instructions, the stores and the barrier of level k: the rows of a block that advance in lock step would otherwise leave the memory
+    // pipe idle between a level's stores and the next level's loads)
+    struct AcLevel {
+        double rp, rthp, rt_ym, rt_yp, o0, o_ym, o_yp, ru0, ru1, rv0, rv1, Gu0, Gu1, Gv0, Gv1, p0, p_xm, p_xp, p_ym, p_yp, au_o, av_o, Grho, Grth, Gs_k;
+        double e_th, e_C, e_rt, e_o;      // the row's outer neighbour: lane 0 the left one, the last lane the right one
+        double C_n, cy_mn, cy_pn, th_n, thy_mn, thy_pn, w_n;
+    };
+    auto level = [&](const unsigned e, const int k) {
+        AcLevel L;
         const unsigned exp_ = e + dxp, eym = e + dym, eyp = e + dyp;
-        // ---- every load of the level ----
-        const double rp = ac_ld(F.rp, e), rthp = ac_ld(F.rthp, e);
-        const double rt_ym = ac_ld(F.rthp, eym), rt_yp = ac_ld(F.rthp, eyp);
-        double o0 = 0.0, o_ym = 0.0, o_yp = 0.0;
-        if (DAMP) { o0 = ac_ld(F.rth_old, e); o_ym = ac_ld(F.rth_old, eym); o_yp = ac_ld(F.rth_old, eyp); }
-        const double ru0 = ac_ld(F.rup_in, e), ru1 = ac_ld(F.rup_in, exp_), rv0 = ac_ld(F.rvp_in, e), rv1 = ac_ld(F.rvp_in, eyp);
-        const double Gu0 = ac_ld(Gu, e), Gu1 = ac_ld(Gu, exp_), Gv0 = ac_ld(Gv, e), Gv1 = ac_ld(Gv, eyp);
-        double p0 = 0.0, p_xm = 0.0, p_xp = 0.0, p_ym = 0.0, p_yp = 0.0;
+        L.rp = ac_ld_nt(F.rp, e); L.rthp = ac_ld(F.rthp, e);
+        L.rt_ym = ac_ld(F.rthp, eym); L.rt_yp = ac_ld(F.rthp, eyp);
+        L.o0 = 0.0; L.o_ym = 0.0; L.o_yp = 0.0;
+        if (DAMP) { L.o0 = ac_ld(F.rth_old, e); L.o_ym = ac_ld(F.rth_old, eym); L.o_yp = ac_ld(F.rth_old, eyp); }
+        L.ru0 = ac_ld(F.rup_in, e); L.ru1 = ac_ld(F.rup_in, exp_); L.rv0 = ac_ld(F.rvp_in, e); L.rv1 = ac_ld(F.rvp_in, eyp);
+        L.Gu0 = ac_ld(Gu, e); L.Gu1 = ac_ld(Gu, exp_); L.Gv0 = ac_ld(Gv, e); L.Gv1 = ac_ld(Gv, eyp);
+        L.p0 = 0.0; L.p_xm = 0.0; L.p_xp = 0.0; L.p_ym = 0.0; L.p_yp = 0.0;
         if (!PF) {
-            p0 = ac_ld(F.p, e); p_xm = ac_ld(F.p, e + (unsigned)(int)W.im); p_xp = ac_ld(F.p, exp_);
-            p_ym = ac_ld(F.p, eym); p_yp = ac_ld(F.p, eyp);
+            L.p0 = ac_ld(F.p, e); L.p_xm = ac_ld(F.p, e + (unsigned)(int)W.im); L.p_xp = ac_ld(F.p, exp_);
+            L.p_ym = ac_ld(F.p, eym); L.p_yp = ac_ld(F.p, eyp);
         }
-        double au_o = 0.0, av_o = 0.0;
-        if (!FIRST) { au_o = ac_ld(F.au, e); av_o = ac_ld(F.av, e); }
-        const double Grho = ac_ld(F.G_rho_d, e), Grth = ac_ld(F.G_rth, e), Gs_k = ac_ld(F.Gs, e);
-        double e_th = 0.0, e_C = 0.0, e_rt = 0.0, e_o = 0.0;      // the row's outer neighbour: lane 0 the left one, the last lane the right one
+        L.au_o = 0.0; L.av_o = 0.0;
+        if (!FIRST) { L.au_o = ac_ld_nt(F.au, e); L.av_o = ac_ld_nt(F.av, e); }
+        L.Grho = ac_ld_nt(F.G_rho_d, e); L.Grth = ac_ld_nt(F.G_rth, e); L.Gs_k = ac_ld_nt(F.Gs, e);
+        L.e_th = 0.0; L.e_C = 0.0; L.e_rt = 0.0; L.e_o = 0.0;
         if (edge) {
             const unsigned ee = e + dedge;
-            e_th = ac_ld(F.thL, ee); e_C = ac_ld(F.Clin, ee); e_rt = ac_ld(F.rthp, ee);
-            if (DAMP) e_o = ac_ld(F.rth_old, ee);
+            L.e_th = ac_ld(F.thL, ee); L.e_C = ac_ld(F.Clin, ee); L.e_rt = ac_ld(F.rthp, ee);
+            if (DAMP) L.e_o = ac_ld(F.rth_old, ee);
         }
         // ring words of the levels above (the last levels re-read an in-range level; those values are never used)
         const unsigned e1 = (k + 1 < Nz) ? e + sz : e, e2 = (k + 2 < Nz) ? e1 + sz : e1;
-        const double C_n = ac_ld(F.Clin, e1), cy_mn = ac_ld(F.Clin, e1 + dym), cy_pn = ac_ld(F.Clin, e1 + dyp);
-        const double th_n = ac_ld(F.thL, e2), thy_mn = ac_ld(F.thL, e2 + dym), thy_pn = ac_ld(F.thL, e2 + dyp);
-        const double w_n = ac_ld(F.rwp, e1 + sz);
+        L.C_n = ac_ld(F.Clin, e1); L.cy_mn = ac_ld(F.Clin, e1 + dym); L.cy_pn = ac_ld(F.Clin, e1 + dyp);
+        L.th_n = ac_ld(F.thL, e2); L.thy_mn = ac_ld(F.thL, e2 + dym); L.thy_pn = ac_ld(F.thL, e2 + dyp);
+        L.w_n = ac_ld_nt(F.rwp, e1 + sz);
+        return L;
+    };
+    constexpr bool PIPE = (CFG & 8) != 0;
+    auto work = [&](const AcLevel &L, const int k, const unsigned e) {
+        const double rdc = g.rdzc[k];
+        const double Ax = g.Ax[k], Ay = g.Ay[k], Vinv = g.Vinv_c[k];
+        const double rp = L.rp, rthp = L.rthp, rt_ym = L.rt_ym, rt_yp = L.rt_yp, o0 = L.o0, o_ym = L.o_ym, o_yp = L.o_yp;
+        const double ru0 = L.ru0, ru1 = L.ru1, rv0 = L.rv0, rv1 = L.rv1, Gu0 = L.Gu0, Gu1 = L.Gu1, Gv0 = L.Gv0, Gv1 = L.Gv1;
+        const double p0 = L.p0, p_xm = L.p_xm, p_xp = L.p_xp, p_ym = L.p_ym, p_yp = L.p_yp, au_o = L.au_o, av_o = L.av_o;
+        const double Grho = L.Grho, Grth = L.Grth, Gs_k = L.Gs_k, e_th = L.e_th, e_C = L.e_C, e_rt = L.e_rt, e_o = L.e_o;
+        const double C_n = L.C_n, cy_mn = L.cy_mn, cy_pn = L.cy_pn, th_n = L.th_n, thy_mn = L.thy_mn, thy_pn = L.thy_pn, w_n = L.w_n;
         const double sp = sponge[k];                // sponge_rhs / sponge_term_diag (acoustic_substepping.jl:591-602)
 
         // ---- neighbours in x from the neighbouring lanes ----
-        double thxm = __shfl_up(th_0, 1), thxp = __shfl_down(th_0, 1);
-        double c_xm = __shfl_up(C_0, 1), c_xp = __shfl_down(C_0, 1);
-        double rt_xm = __shfl_up(rthp, 1), rt_xp = __shfl_down(rthp, 1);
+        constexpr bool DPP = (CFG & 16) != 0;
+        double thxm = ac_lane_up<DPP>(th_0), thxp = ac_lane_down<DPP>(th_0);
+        double c_xm = ac_lane_up<DPP>(C_0), c_xp = ac_lane_down<DPP>(C_0);
+        double rt_xm = ac_lane_up<DPP>(rthp), rt_xp = ac_lane_down<DPP>(rthp);
         double o_xm = 0.0, o_xp = 0.0;
-        if (DAMP) { o_xm = __shfl_up(o0, 1); o_xp = __shfl_down(o0, 1); }
+        if (DAMP) { o_xm = ac_lane_up<DPP>(o0); o_xp = ac_lane_down<DPP>(o0); }
         if (edge_m) { thxm = e_th; c_xm = e_C; rt_xm = e_rt; o_xm = e_o; }
         if (edge_p) { thxp = e_th; c_xp = e_C; rt_xp = e_rt; o_xp = e_o; }
         const double thym = thy_m0, thyp = thy_p0, c_ym = cy_m0, c_yp = cy_p0;
@@ -978,15 +1042,16 @@ __global__ __launch_bounds__(ACX * ACY, MW) void k_ac_forward2(DevGrid g, AcFiel
             c_m = -dtn2 * C_0 * thf_p * rdc * rdf + (-dtn2 * g.g * rdc / 2.0) + (-P.d_new * rdc * rdf);
         }
         // ---- every store of the level ----
-        ac_st(F.rup, e, up0);
-        ac_st(F.rvp, e, vp0);
-        ac_st(F.au, e, au_n);
-        ac_st(F.av, e, av_n);
-        ac_st(F.rs, e, rs);
-        ac_st(F.rths, e, rths);
-        if (FIRST) ac_st(F.tfac, e, t);
-        ac_st(F.phi, e, phi);
+        ac_st_nt(F.rup, e, up0);
+        ac_st_nt(F.rvp, e, vp0);
+        ac_st_nt(F.au, e, au_n);
+        ac_st_nt(F.av, e, av_n);
+        ac_st_nt(F.rs, e, rs);
+        ac_st_nt(F.rths, e, rths);
+        if (FIRST) ac_st_nt(F.tfac, e, t);
+        ac_st_nt(F.phi, e, phi);
         phi_m = phi;
+        if (AC2_BARRIER || (CFG & 4)) __builtin_amdgcn_s_barrier();      // the rows of a block advance together: a row's y neighbours are requested while their lines are near
 
         // advance the rings
         rs_m = rs; rths_m = rths; rp_m = rp; rthp_m = rthp;
@@ -996,6 +1061,24 @@ __global__ __launch_bounds__(ACX * ACY, MW) void k_ac_forward2(DevGrid g, AcFiel
         w_m = w_0; w_0 = w_p; w_p = w_n;
         cy_m0 = cy_mn; cy_p0 = cy_pn;
         thy_m0 = thy_m1; thy_p0 = thy_p1; thy_m1 = thy_mn; thy_p1 = thy_pn;
+    };
+    if (!PIPE) {
+        for (int k = 0; k < Nz; ++k, e += sz) work(level(e, k), k, e);
+    } else {
+        // two levels per trip so that the two records live in fixed registers (a rotation `current = next` would have to wait for the
+        // next level's loads before it could copy them); the last level re-reads itself
+        AcLevel LA = level(e, 0), LB;
+#pragma unroll 1
+        for (int k = 0; k < Nz; k += 2, e += 2 * sz) {
+            const int k1 = (k + 1 < Nz) ? k + 1 : k;
+            LB = level(e + (unsigned)(k1 - k) * sz, k1);
+            work(LA, k, e);
+            if (k + 1 < Nz) {
+                const int k2 = (k + 2 < Nz) ? k + 2 : k + 1;
+                LA = level(e + (unsigned)(k2 - k) * sz, k2);
+                work(LB, k + 1, e + sz);
+            }
+        }
     }
 }
 
@@ -1680,7 +1763,7 @@ static bool ac_forward2_ok(const bz_ctx *ctx)
 {
     const DevGrid &g = ctx->dg;
     const unsigned long long bytes = (unsigned long long)g.Sxy * (unsigned long long)(g.Nz + 2 * g.Hz + 1) * sizeof(double);
-    return ctx->tune.ac_forward2 && ACX == 64 && bytes < (1ull << 32) && g.Hz >= 1 && g.Nx >= 2 && (g.Nx % ACX) != 1;
+    return ctx->tune.ac_forward2 && bytes < (1ull << 32) && g.Hz >= 1 && g.Nx >= 2 && (g.Nx % 64) != 1;
 }
 static AcStage &stage_of(bz_ctx *ctx)
 {
@@ -1770,26 +1853,36 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
 
 // the forward sweep of a fused substep through k_ac_forward2: first substep of the stage / damping of the previous substep / folded p^L
 // gradient, at the register budget for MW waves per SIMD (BZ_AC_MW)
-template <bool PF, int MW>
-static void launch_forward2_mw(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp)
+template <bool PF, int CFG>
+static void launch_forward2_cfg(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp)
 {
     const DevGrid &g = ctx->dg;
-    if (first) AC_LAUNCH(k_ac_forward2, true COMMA false COMMA PF COMMA MW COMMA, cols, bcol, Fs, P);
-    else if (damp) AC_LAUNCH(k_ac_forward2, false COMMA true COMMA PF COMMA MW COMMA, cols, bcol, Fs, P);
-    else AC_LAUNCH(k_ac_forward2, false COMMA false COMMA PF COMMA MW COMMA, cols, bcol, Fs, P);
+    if (first) AC_LAUNCH(k_ac_forward2, true COMMA false COMMA PF COMMA CFG COMMA, cols, bcol, Fs, P);
+    else if (damp) AC_LAUNCH(k_ac_forward2, false COMMA true COMMA PF COMMA CFG COMMA, cols, bcol, Fs, P);
+    else AC_LAUNCH(k_ac_forward2, false COMMA false COMMA PF COMMA CFG COMMA, cols, bcol, Fs, P);
 }
-static void launch_forward2(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, bool pfold)
+template <bool PF>
+static void launch_forward2_pf(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, int cfg)
 {
-    const int mw = ctx->tune.ac_mw;
-    if (pfold) {
-        if (mw <= 2) launch_forward2_mw<true, 2>(ctx, Fs, P, cols, bcol, first, damp);
-        else if (mw == 3) launch_forward2_mw<true, 3>(ctx, Fs, P, cols, bcol, first, damp);
-        else launch_forward2_mw<true, 4>(ctx, Fs, P, cols, bcol, first, damp);
-    } else {
-        if (mw <= 2) launch_forward2_mw<false, 2>(ctx, Fs, P, cols, bcol, first, damp);
-        else if (mw == 3) launch_forward2_mw<false, 3>(ctx, Fs, P, cols, bcol, first, damp);
-        else launch_forward2_mw<false, 4>(ctx, Fs, P, cols, bcol, first, damp);
+    switch (cfg) {
+    case 0: launch_forward2_cfg<PF, 0>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 1: launch_forward2_cfg<PF, 1>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 2: launch_forward2_cfg<PF, 2>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 4: launch_forward2_cfg<PF, 4>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 5: launch_forward2_cfg<PF, 5>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 8: launch_forward2_cfg<PF, 8>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 12: launch_forward2_cfg<PF, 12>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 13: launch_forward2_cfg<PF, 13>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 22: launch_forward2_cfg<PF, 22>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 28: launch_forward2_cfg<PF, 28>(ctx, Fs, P, cols, bcol, first, damp); break;
+    case 6: launch_forward2_cfg<PF, 6>(ctx, Fs, P, cols, bcol, first, damp); break;
+    default: launch_forward2_cfg<PF, 29>(ctx, Fs, P, cols, bcol, first, damp); break;
     }
+}
+static void launch_forward2(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, bool pfold, int cfg)
+{
+    if (pfold) launch_forward2_pf<true>(ctx, Fs, P, cols, bcol, first, damp, cfg);
+    else launch_forward2_pf<false>(ctx, Fs, P, cols, bcol, first, damp, cfg);
 }
 
 // substep `sstep` (1-based) of the stage opened by bzi_acoustic_stage_begin
@@ -1822,8 +1915,15 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
         Fs.rvp_in = v_buf[cur]; Fs.rvp = v_buf[cur ^ 1];
         {
             ProfileScope ps(ctx, "acoustic_horizontal+column_forward");
-            if (S.fwd2)
-                launch_forward2(ctx, Fs, P, cols, bcol, sstep == 1, damp, S.pfold);
+            if (S.fwd2) {
+                int cfg = ctx->tune.ac_cfg;
+                if (cfg != 0 && cfg != 1 && cfg != 2 && cfg != 4 && cfg != 5 && cfg != 6 && cfg != 8 && cfg != 12 && cfg != 13 && cfg != 22 && cfg != 28) cfg = 29;
+                const int bt = (cfg & 1) ? 512 : 256;
+                const int fx = ctx->tune.ac_bx == 512 && bt == 512 ? 512 : ctx->tune.ac_bx == 256 ? 256 : ctx->tune.ac_bx == 128 ? 128 : 64, fy = bt / fx;
+                dim3 cols2((g.Nx + fx - 1) / fx, (g.Ny + fy - 1) / fy), bcol2(fx, fy);
+                P.xcd = (ctx->tune.ac_xcd && cols2.y % 8 == 0) ? 1 : 0;
+                launch_forward2(ctx, Fs, P, cols2, bcol2, sstep == 1, damp, S.pfold, cfg);
+            }
             else if (sstep == 1)
                 AC_LAUNCH(k_ac_column_forward, true COMMA true COMMA false COMMA, cols, bcol, Fs, P);
             else if (damp)

@@ -64,7 +64,8 @@ void bzi_read_tuning(bz_tuning &t)
     t.ac_xcd = num("BZ_AC_XCD", 1);
     t.ac_forward2 = num("BZ_AC_FWD2", 1);
     t.ac_pfold = num("BZ_AC_PFOLD", 1);
-    t.ac_mw = num("BZ_AC_MW", 3);
+    t.ac_cfg = num("BZ_AC_CFG", 29);
+    t.ac_bx = num("BZ_AC_BX", 128);
     t.no_tridiag_coop = on("BZ_NO_TRIDIAG_COOP");
     t.no_xfft = on("BZ_NO_XFFT");
     t.poisson_chunk = num("BZ_POISSON_CHUNK", 0);

@@ -310,7 +310,9 @@ struct bz_tuning {
     int ac_xcd = 1;                   // BZ_AC_XCD=0: the forward acoustic sweep in launch order (XCD = tile column) instead of XCD = band of tile rows
     int ac_forward2 = 1;              // BZ_AC_FWD2=0: the round-5 forward acoustic sweep (k_ac_column_forward) instead of k_ac_forward2
     int ac_pfold = 1;                 // BZ_AC_PFOLD=0: the horizontal gradient of p^L stays in every substep instead of folded into the stage's slow tendencies
-    int ac_mw = 3;                    // BZ_AC_MW: register budget of k_ac_forward2 as waves per SIMD (2, 3, 4)
+    int ac_bx = 128;                  // BZ_AC_BX: columns of a k_ac_forward2 block along x (64, 128, 256, 512; rows = threads / columns)
+    int ac_cfg = 29;                  // BZ_AC_CFG: k_ac_forward2 variant (bit 0: 512-thread blocks, bit 1: register budget of three waves per SIMD, bit 2: barrier per level,
+                                      // bit 3: next level's loads in flight, bit 4: DPP lane shifts); built: 0 1 2 4 5 6 8 12 13 22 28 29
     bool no_fuse_level_sums = false;  // BZ_NO_FUSE_LEVEL_SUMS: the subsidence averages always come from their own pass over u, v, theta, q
     bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms

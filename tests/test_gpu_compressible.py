@@ -375,12 +375,13 @@ def test_forward_sweep_with_xcd_bands_matches_oracle(oracle, oc, bz, size, monke
 def test_forward_sweep_round6_kernel(oracle, oc, bz, size, td, monkeypatch):
     """Round 6: k_ac_forward2 (every load of a level before its first store, 32-bit offsets from uniform bases, x neighbours from the
     neighbouring lanes) carries the arithmetic text of k_ac_column_forward: without the fold of the p^L gradient it reproduces the round-5
-    kernel bit for bit (BZ_AC_FWD2=0), at every register budget; with the fold (Gp_ru = G_ru - dx p^L once per stage, the shipped default)
+    kernel to 1e-13 (BZ_AC_FWD2=0) and itself bit for bit in every block shape / barrier / pipelining / lane-shift variant (BZ_AC_CFG, BZ_AC_BX); with the fold (Gp_ru = G_ru - dx p^L once per stage, the shipped default)
     three steps stay within 5e-9 of the oracle and 1e-12 of the unfolded run.  Rows of two tiles, one tile and a ragged 40-cell row."""
-    def run(fwd2, pfold, mw=3):
+    def run(fwd2, pfold, cfg=29, bx=128):
         monkeypatch.setenv("BZ_AC_FWD2", str(fwd2))
         monkeypatch.setenv("BZ_AC_PFOLD", str(pfold))
-        monkeypatch.setenv("BZ_AC_MW", str(mw))
+        monkeypatch.setenv("BZ_AC_CFG", str(cfg))
+        monkeypatch.setenv("BZ_AC_BX", str(bx))
         om, hm = make_pair(oracle, oc, bz, size=size, **td)
         g = om.grid
 
@@ -404,10 +405,19 @@ def test_forward_sweep_round6_kernel(oracle, oc, bz, size, td, monkeypatch):
     cmp_interior(om, a, ("rho_d", "rtheta", "ru", "rv", "rw", "u", "v", "w", "theta", "T", "p"), 5e-9)
     _, old = run(0, 0)
     fo = {k: f.interior_cpu() for k, f in old.prognostic_fields().items()}
-    for mw in (2, 3, 4):
-        _, b = run(1, 0, mw)
-        for k, f in b.prognostic_fields().items():
-            assert np.array_equal(f.interior_cpu(), fo[k]), (k, mw)
+    # same arithmetic text as the round-5 kernel; hipcc contracts a few products differently in the restructured loop, and again in the
+    # two-level trip of the pipelined variants: bit for bit within each group, 1e-13 between the groups and against the round-5 kernel
+    groups = (((6, 64), (0, 64), (2, 128), (4, 256), (5, 64), (5, 128), (1, 256), (22, 64)),
+              ((29, 128), (8, 64), (12, 128), (13, 64), (13, 256), (28, 128), (29, 512)))
+    for grp in groups:
+        _, ref = run(1, 0, *grp[0])
+        fr = {k: f.interior_cpu() for k, f in ref.prognostic_fields().items()}
+        for k in fr:
+            assert rel(fr[k], fo[k]) <= 1e-13, (k, grp[0])
+        for cfg, bx in grp[1:]:
+            _, b = run(1, 0, cfg, bx)
+            for k, f in b.prognostic_fields().items():
+                assert np.array_equal(f.interior_cpu(), fr[k]), (k, cfg, bx)
     for k, f in a.prognostic_fields().items():
         assert rel(f.interior_cpu(), fo[k]) <= 1e-12, k
 

@@ -39,6 +39,29 @@ __global__ __launch_bounds__(256) void k_level_sums(DevGrid g, const double *__r
     if (threadIdx.x < 4) partial[((long long)threadIdx.x * g.Nz + k) * FSLICES + s] = red[threadIdx.x][0];
 }
 
+// per-wavefront sums in the layout and ORDER of the projection + diagnosis kernel (bz_fused.hip: PDFields::lsum: 64 consecutive cells of a row
+// added by the same shuffle tree): where the sums of later stages ride on that kernel, the stage that cannot (first stage of a call, host
+// calls) sums here, so that both add in one order and n single-step calls leave the bits of one n-step call
+__global__ __launch_bounds__(256) void k_level_wave_sums(DevGrid g, const double *__restrict__ u, const double *__restrict__ v,
+                                                         const double *__restrict__ th, const double *__restrict__ q,
+                                                         double *__restrict__ lsum, long long P)
+{
+    const int bx = blockIdx.x, j = blockIdx.y, k = blockIdx.z;
+    const int i = bx * 256 + threadIdx.x;
+    if (i >= g.Nx) return;      // rows of a multiple of 64 cells: whole wavefronts leave
+    const long long n = g.idx(i, j, k);
+    double a0 = u[n], a1 = v[n], a2 = th[n], a3 = q[n];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_down(a0, off); a1 += __shfl_down(a1, off); a2 += __shfl_down(a2, off); a3 += __shfl_down(a3, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const long long slot = ((long long)j * gridDim.x + bx) * 4 + (threadIdx.x >> 6), fs = (long long)g.Nz * P;
+        double *o = lsum + (long long)k * P + slot;
+        o[0] = a0; o[fs] = a1; o[2 * fs] = a2; o[3 * fs] = a3;
+    }
+}
+
 // the same sums from the per-wave values the projection + diagnosis kernel left (bz_fused.hip: PDFields::lsum): block t = f Nz + k adds its P
 // values in a fixed order (thread-strided, then an LDS tree) into partial[t]
 __global__ __launch_bounds__(256) void k_level_reduce(const double *__restrict__ rows, long long P, double *__restrict__ partial)
@@ -484,9 +507,14 @@ int bzi_compute_forcings(bz_ctx *ctx, const bz_state *s)
     const DevGrid &g = ctx->dg;
     const int Nz = g.Nz;
     const bool ride = ctx->lsum_fresh && ctx->d_lsum_rows;
+    // a context whose later stages ride sums its other stages in the riding order too (k_level_wave_sums): one order per context
+    long long Pw = 0;
+    double *rows = ride ? ctx->d_lsum_rows : bzi_level_sum_rows(ctx, &Pw);
     ProfileScope ps(ctx, ride ? "subsidence_averages_from_wave_sums" : "subsidence_averages");
     double *ws = ctx->d_forcing + (size_t)5 * Nz, *avg = ws + (Nz + 1), *sub = avg + (size_t)4 * Nz, *partial = sub + (size_t)4 * Nz;
-    if (ride) {
+    if (!ride && rows)
+        hipLaunchKernelGGL(k_level_wave_sums, dim3((g.Nx + 255) / 256, g.Ny, Nz), dim3(256), 0, ctx->stream, g, s->u, s->v, s->theta, s->q, rows, Pw);
+    if (rows) {
         hipLaunchKernelGGL(k_level_reduce, dim3(4 * Nz), dim3(256), 0, ctx->stream, ctx->d_lsum_rows, ctx->lsum_P, partial);
         hipLaunchKernelGGL(k_subsidence_profiles, dim3(1), dim3(256), 0, ctx->stream, g, partial, ws, avg, sub,
                            ctx->forcing_subsidence_mask, (double)g.Nx * (double)ctx->Ny_global, 1);

@@ -123,7 +123,7 @@ __device__ __forceinline__ double bz_rk_apply_pre(int mode, double dt, double al
 // exp(a) of a small argument: the degree-9 Taylor polynomial in Horner form on |a| <= 1/16 (truncation a^10 / 10! < 3e-19: nine FMAs,
 // no extra registers — inlined, the library exp() pushed the z-momentum kernel past its 128 registers, and behind a call it cost spills
 // around the call).  For atmospheric q and pressures |a| ~ 0.07 q |ln Pi| is a few 1e-3.  Larger arguments (q -> 1 at stratospheric
-// pressures: unphysical, but the function must not be wrong there) are halved wave-uniformly until they fit and the result is squared
+// pressures: unphysical, but the function must not be wrong there) are halved lane by lane until they fit and the result is squared
 // back: exp(a) = exp(a / 2^s)^(2^s), each squaring doubling the relative error (s <= 5 for |a| <= 2).
 // a Float64 literal as a scalar-register pair materialised where it is used: without it the compiler hoists the nine coefficients below
 // out of the level loop of the z-momentum kernel into eighteen VGPRs, which that kernel (128 of 128) pays for with scratch spills
@@ -134,8 +134,8 @@ __device__ __forceinline__ double bz_sconst(double c)
 }
 __device__ __forceinline__ double bz_exp_small(double a)
 {
-    int s = 0;
-    while (!__all(fabs(a) <= 0.0625) && s < 40) { a *= 0.5; ++s; }
+    int s = 0;      // per lane (round 6, ADVICE r05: a wave-uniform count made a cell's result depend on the cells that share its wavefront)
+    while (fabs(a) > 0.0625 && s < 64) { a *= 0.5; ++s; }
     double p = bz_sconst(1.0 / 362880.0);
     p = fma(p, a, bz_sconst(1.0 / 40320.0));
     p = fma(p, a, bz_sconst(1.0 / 5040.0));

@@ -78,7 +78,12 @@ def test_local_transport_self_messages(bz, oracle, monkeypatch):
                                               # shapes the hand-written x transforms take on slab ranks (Nx a power of two, 8 | local Ny): messages of
                                               # the all-to-alls written / read in place, zero padding of the last wavenumber block
                                               (2, (64, 32, 16), True), (4, (32, 64, 12), False), (2, (16, 16, 8), False),
-                                              (2, (1024, 16, 6), False)])      # BASELINE configs[3] row length: teams of two wavefronts
+                                              (2, (1024, 16, 6), False),       # BASELINE configs[3] row length: teams of two wavefronts
+                                              # round 6: EIGHT ranks — the target node's world size.  33 half-spectrum planes over
+                                              # 8 ranks (5 5 5 5 5 5 3 0 after the split by whole blocks: an uneven and an empty share) with 8-row
+                                              # slabs, moist; 64-row slabs of 512-cell rows (the strong 512^3 split's slab: four 16-row tiles of the
+                                              # y-momentum kernel, the outer two waiting for halo rows); 17 planes over 8 ranks
+                                              (8, (64, 64, 16), True), (8, (512, 512, 6), False), (8, (32, 48, 10), True)])
 def test_library_owned_slab_step_matches_the_oracle(bz, oracle, world, size, moist):
     steps, dt = 2, 2.0
     models = run_slabs(bz, size, world, steps, dt, moist)

@@ -57,7 +57,7 @@ def _worker(rank, world, port, size, steps, dt, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size", [(2, (32, 16, 12)), (4, (24, 24, 10)), (2, (20, 12, 8))])
+@pytest.mark.parametrize("world,size", [(2, (32, 16, 12)), (4, (24, 24, 10)), (2, (20, 12, 8)), (8, (20, 32, 6))])
 def test_slab_steps_match_single_process_oracle(world, size, tmp_path):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 2000) + world
@@ -245,7 +245,7 @@ def test_compressible_kessler_slab_steps_match_single_process_oracle(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("library", [False, True])
-@pytest.mark.parametrize("world,kessler", [(1, False), (2, False), (4, False), (2, True), (4, True)])
+@pytest.mark.parametrize("world,kessler", [(1, False), (2, False), (4, False), (2, True), (4, True), (8, False), (8, True)])
 def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, oracle, oc, world, kessler, library):
     """SlabCompressibleModel (bz_create_compressible_slab, stage begin / substep / end with the per-substep exchange of
     (rho theta)' and (rho v)') against the single-GPU whole-step seam and, directly, against the CPU oracle on the whole
@@ -256,7 +256,9 @@ def test_compressible_slab_ranks_sharing_one_gpu_match_single_gpu_model(bz, orac
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_backends
     from breeze_jl_amd import distributed as bz_dist
-    size, steps, dt = (32, 24, 16), 2, 2.0
+    size, steps, dt = ((32, 24, 16) if world < 8 else (32, 48, 12)), 2, 2.0      # eight ranks (round 6): six-row slabs
+    if world == 8 and not library:
+        pytest.skip("eight ranks run through the library-owned communicator (the path the 8-GPU launch takes)")
     G = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
 
     def dynamics():
@@ -369,7 +371,9 @@ def test_direct_divergence_damping_on_slabs_matches_single_gpu_model(bz, world, 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_backends
     from breeze_jl_amd import distributed as bz_dist
-    size, steps, dt = (32, 24, 16), 2, 2.0
+    size, steps, dt = ((32, 24, 16) if world < 8 else (32, 48, 12)), 2, 2.0      # eight ranks (round 6): six-row slabs
+    if world == 8 and not library:
+        pytest.skip("eight ranks run through the library-owned communicator (the path the 8-GPU launch takes)")
     G = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
 
     def dynamics():
@@ -579,7 +583,9 @@ def test_compressible_float32_substep_storage_on_library_slabs_matches_single_gp
     Float64 tolerance of the test above applies (1e-10), far below the 1e-7 a mis-exchanged Float32 row would show."""
     import uuid
     import torch
-    size, steps, dt = (32, 24, 16), 2, 2.0
+    size, steps, dt = ((32, 24, 16) if world < 8 else (32, 48, 12)), 2, 2.0      # eight ranks (round 6): six-row slabs
+    if world == 8 and not library:
+        pytest.skip("eight ranks run through the library-owned communicator (the path the 8-GPU launch takes)")
     G = bz.RectilinearGrid(size, x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
 
     def dynamics():

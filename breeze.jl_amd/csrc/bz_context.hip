@@ -68,6 +68,9 @@ void bzi_read_tuning(bz_tuning &t)
     t.ac_bx = num("BZ_AC_BX", 128);
     t.no_tridiag_coop = on("BZ_NO_TRIDIAG_COOP");
     t.no_xfft = on("BZ_NO_XFFT");
+    t.poisson_kxmajor = num("BZ_POISSON_KXMAJOR", 1);
+    t.poisson_kx_chunk_mb = num("BZ_POISSON_KX_CHUNK_MB", 0);
+    t.poisson_kx_pad = num("BZ_POISSON_KX_PAD", 1);
     t.poisson_chunk = num("BZ_POISSON_CHUNK", 0);
     t.xf_kchunk_f = num("BZ_XF_KCHUNK_F", 0);
     t.xf_kchunk_i = num("BZ_XF_KCHUNK_I", 0);
@@ -119,6 +122,8 @@ int bzi_apply_stream(bz_ctx *ctx, hipStream_t stream)
         BZ_FFT(hipfftSetStream(ctx->plan_inv, ctx->stream));
     }
     if (ctx->xf && ctx->plan_y) BZ_FFT(hipfftSetStream(ctx->plan_y, ctx->stream));      // the y transforms of the LDS x-transform pipeline
+    if (ctx->plan_yc) BZ_FFT(hipfftSetStream(ctx->plan_yc, ctx->stream));
+    if (ctx->plan_yc_last) BZ_FFT(hipfftSetStream(ctx->plan_yc_last, ctx->stream));
     if (ctx->pchunk) {
         BZ_FFT(hipfftSetStream(ctx->plan_fwd_c, ctx->stream));
         BZ_FFT(hipfftSetStream(ctx->plan_inv_c, ctx->stream));

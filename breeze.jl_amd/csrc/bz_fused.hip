@@ -407,6 +407,7 @@ int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognosti
     L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;
     L.blk = (long long)g.Nz * L.nkx * g.Ny;
     L.klo = klo; L.khi = khi;
+    L.kxs = (ctx->kxmajor && blocks == 1 && !hat) ? (long long)(g.Nz + ctx->kx_pad) * g.Ny : 0;
     double2 *out = (double2 *)(hat ? hat : (double *)ctx->d_hat);
     const double *pu = predictor ? predictor->rho_u : s ? s->rho_u : nullptr, *pv = predictor ? predictor->rho_v : s ? s->rho_v : nullptr,
                  *pw = predictor ? predictor->rho_w : s ? s->rho_w : nullptr;
@@ -435,6 +436,7 @@ int bzi_xf_inverse(bz_ctx *ctx, const double *hat, double *phi, int blocks, int 
     L.nxp = blocks > 1 ? ctx->nkx * blocks : n2 + 1;
     L.blk = (long long)g.Nz * L.nkx * g.Ny;
     L.klo = klo; L.khi = khi;
+    L.kxs = (ctx->kxmajor && blocks == 1 && !hat) ? (long long)(g.Nz + ctx->kx_pad) * g.Ny : 0;
     const double2 *in = (const double2 *)(hat ? hat : (const double *)ctx->d_hat);
     double *out = phi ? phi : ctx->d_rhs;
     const dim3 grid(g.Ny / XF_RB, (khi - klo + kc - 1) / kc), block(XF_RB * (n2 / 4));

@@ -316,6 +316,9 @@ struct bz_tuning {
     bool no_fuse_level_sums = false;  // BZ_NO_FUSE_LEVEL_SUMS: the subsidence averages always come from their own pass over u, v, theta, q
     bool no_tridiag_coop = false;     // BZ_NO_TRIDIAG_COOP: sequential Thomas kernel
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms
+    int poisson_kxmajor = 1;          // BZ_POISSON_KXMAJOR=0: level-major half spectrum, three whole-spectrum passes between the x transforms
+    int poisson_kx_chunk_mb = 0;      // BZ_POISSON_KX_CHUNK_MB: spectrum bytes per chunk of the kx-major pipeline (0: 256 MB)
+    int poisson_kx_pad = 1;           // BZ_POISSON_KX_PAD: phantom lines per wavenumber of the kx-major spectrum (0 .. 4)
     int poisson_chunk = 0;            // BZ_POISSON_CHUNK: level-chunked Poisson pipeline (needs BZ_NO_XFFT)
     int xf_kchunk_f = 0, xf_kchunk_i = 0;      // BZ_XF_KCHUNK_F / _I: levels per block of the x transforms (0: automatic)
     bool no_rho3d_exchange = false;   // BZ_NO_RHO3D_EXCHANGE: the compressible scalar tendency keeps the kernel that evaluates five fluxes per cell
@@ -370,6 +373,10 @@ struct bz_ctx {
     bool xf_slab = false;            // y-slab context whose rows the same kernels transform (bz_comm.hip: dist_poisson)
     void *d_wtab = nullptr;          // exp(-2 pi i t / Nx), t < 3 Nx / 4
     hipfftHandle plan_y = 0;         // contiguous batched 1-D transform along y of the transposed spectrum
+    // round 6: kx-major half spectrum hatT[(kx Nz + k) Ny + ky] and the middle of the solve in chunks of kx_cw wavenumbers (bzi_xf_middle)
+    bool kxmajor = false;
+    int kx_cw = 0, kx_nch = 0, kx_pad = 0;      // wavenumbers per chunk, chunks, phantom lines per wavenumber
+    hipfftHandle plan_yc = 0, plan_yc_last = 0;      // y transforms of one chunk / of the (shorter) last chunk
     int profile_mute = 0;            // > 0: ProfileScope objects record nothing (an enclosing scope covers the launches)
     // y-slab mode: 1-D batched plans of the distributed transform (bz_slab_transform, created on first use)
     hipfftHandle slab_plan_x_fwd = 0, slab_plan_x_inv = 0, slab_plan_y = 0;
@@ -599,7 +606,8 @@ int bzi_xf_forward(bz_ctx *ctx, const bz_state *s, double dt, const bz_prognosti
                    double *hat = nullptr, int blocks = 1, int klo = 0, int khi = 0);      // khi = 0: all levels
 int bzi_xf_inverse(bz_ctx *ctx, const double *hat = nullptr, double *phi = nullptr, int blocks = 1, int klo = 0, int khi = 0);
 int bzi_xf_y(bz_ctx *ctx, bool forward);
-int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column);
+int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column, int kx_lo = 0, int kx_hi = 0);
+int bzi_xf_middle(bz_ctx *ctx);      // y transform, vertical solves, inverse y transform on ctx->d_hat (chunked by wavenumber where ctx->kxmajor)
 // fused streaming kernels (bz_fused.hip)
 int bzi_rk3_fused(bz_ctx *ctx, const bz_state *s, const bz_prognostic *U0, const bz_prognostic *G, double dt,
                   double alpha, bool first);

@@ -161,8 +161,12 @@ __device__ __forceinline__ void tco_lds_barrier()
 // store of a group before the next group's loads could be used)
 template <int TCO_SEGS, int M, bool EXACT>
 __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_coop(int NXH, int Ny, int Nz, int kx0, int nxh_real, int ky_fastest, TriCols C,
-                                                                      double2 *__restrict__ hat, double scale, int mean_column, int ngroups)
+                                                                      double2 *__restrict__ hat, double scale, int mean_column, int ngroups,
+                                                                      long long lstride, long long kxs, int grp0)
 {
+    // Where (column c, level k) lives: hat[col_addr(c) + lstride k].  Level-major spectrum (kxs = 0): col_addr(c) = c, lstride = the plane;
+    // kx-major spectrum of the chunked pipeline (round 6; ky fastest): wavenumber kx owns Nz Ny contiguous elements, col_addr(c) =
+    // (c / Ny) kxs + c % Ny, lstride = Ny.  The launch covers the column groups [grp0, ngroups).
     __shared__ double sR[TCO_SEGS][TCO_COLS][6];      // g_f, h_f, g_l, cp_l of a segment; then sub / diag / sup of the reduced system
     __shared__ double2 sD[TCO_SEGS][TCO_COLS][2];     // dp_f, dp_l; then [0] = X_s
     __shared__ double sSum[TCO_SEGS];
@@ -176,6 +180,11 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
     }
     tco_lds_barrier();
     const long long plane = (long long)NXH * Ny;
+    auto col_addr = [&](long long c) -> long long {
+        if (!kxs) return c;
+        const unsigned cu = (unsigned)min(c, plane - 1), quo = cu / (unsigned)Ny;
+        return (long long)quo * kxs + (long long)(cu - quo * (unsigned)Ny);
+    };
     const int q = Nz / TCO_SEGS, r = Nz % TCO_SEGS;
     const int L = EXACT ? M : q + (s < r ? 1 : 0), k0 = EXACT ? s * M : s * q + min(s, r);
     // A workgroup walks column groups grp = blockIdx.x, + gridDim.x, ... and requests the rows of its NEXT group before it starts on the
@@ -191,12 +200,13 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
         ly = C.lam_y[ky];
     };
     {
-        const long long c = (long long)blockIdx.x * TCO_COLS + cc;
+        const long long c = (long long)(grp0 + (int)blockIdx.x) * TCO_COLS + cc;
+        const long long ca = col_addr(c);
         lam_of(c, lxn, lyn);
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            if constexpr (EXACT) dpn[j] = hat[c + plane * (k0 + j)];
-            else if (j < L) dpn[j] = (c < plane) ? hat[c + plane * (k0 + j)] : make_double2(0.0, 0.0);
+            if constexpr (EXACT) dpn[j] = hat[ca + lstride * (k0 + j)];
+            else if (j < L) dpn[j] = (c < plane) ? hat[ca + lstride * (k0 + j)] : make_double2(0.0, 0.0);
         }
     }
     auto trip = [&](const int grp) {
@@ -209,20 +219,22 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
     const double lam = padding ? 0.0 : lxn + lyn;
     double2 dp[M];
     double g[M], h[M];
-    double2 *col = hat + c;
+    double2 *col = hat + col_addr(c);
 #pragma unroll
     for (int j = 0; j < M; ++j) dp[j] = dpn[j];
     if constexpr (EXACT) {                                               // the last trip re-reads its own group (in bounds, unused)
         const long long cn = (grp + (int)gridDim.x < ngroups) ? c + (long long)gridDim.x * TCO_COLS : c;
+        const long long cna = col_addr(cn);
         lam_of(cn, lxn, lyn);
 #pragma unroll
-        for (int j = 0; j < M; ++j) dpn[j] = hat[cn + plane * (k0 + j)];
+        for (int j = 0; j < M; ++j) dpn[j] = hat[cna + lstride * (k0 + j)];
     } else if (grp + (int)gridDim.x < ngroups) {                         // block-uniform
         const long long cn = c + (long long)gridDim.x * TCO_COLS;
+        const long long cna = col_addr(cn);
         lam_of(cn, lxn, lyn);
 #pragma unroll
         for (int j = 0; j < M; ++j)
-            if (j < L) dpn[j] = (cn < plane) ? hat[cn + plane * (k0 + j)] : make_double2(0.0, 0.0);
+            if (j < L) dpn[j] = (cn < plane) ? hat[cna + lstride * (k0 + j)] : make_double2(0.0, 0.0);
     }
     // ---- A: local forward elimination ----
     double cp_prev = 0.0, g_prev = 0.0;
@@ -354,14 +366,14 @@ __global__ void __launch_bounds__(TCO_COLS *TCO_SEGS, TCO_MIN_WAVES) k_tridiag_c
     }
 #pragma unroll
     for (int j = 0; j < M; ++j)
-        if (j < L && live) col[plane * (k0 + j)] = dp[j];
+        if (j < L && live) col[lstride * (k0 + j)] = dp[j];
     tco_lds_barrier();                                   // the exchange buffers are rewritten by the next group
     };
     // EXACT: the first group runs outside the loop.  The memory counter returns in order and the compiler derives its waits from what
     // may be outstanding on ANY path into a point: entered straight from the prologue the loop head would see "rows still loading,
     // no stores behind them" on one path and "rows + 8 stores" on the other, and settle for waits that drain the stores of the
     // previous group in every trip (s_waitcnt vmcnt(17..10) through phase A).  Peeled, both paths into the head look alike.
-    int grp = blockIdx.x;
+    int grp = grp0 + (int)blockIdx.x;
     if constexpr (EXACT) { trip(grp); grp += gridDim.x; }
 #pragma nounroll
     for (; grp < ngroups; grp += gridDim.x) trip(grp);
@@ -380,7 +392,8 @@ static int tridiag_coop_segs(const bz_ctx *ctx, int)
 }
 
 // Thomas solve of this context's spectral block, in place: the cooperative kernel when the shape allows it, else the sequential one
-int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column)
+// kx_lo / kx_hi (kx-major spectrum only, ctx->kxmajor): the wavenumber range of one chunk of the pipeline; default: every column
+int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_column, int kx_lo, int kx_hi)
 {
     const long long plane = (long long)ctx->NXH * Ny;
     if (const int segs = tridiag_coop_segs(ctx, Ny)) {
@@ -388,13 +401,18 @@ int bzi_tridiag_launch(bz_ctx *ctx, double *hat, double scale, int Ny, int mean_
         double *d_cols = ctx->d_lower;
         const int Nz = ctx->dg.Nz;
         TriCols C{d_cols, d_cols + Nz, d_cols + 2 * Nz, d_cols + 3 * Nz, d_cols + 3 * Nz + nxh_real};
-        const int ngroups = (int)((plane + TCO_COLS - 1) / TCO_COLS);
+        const bool chunk = ctx->kxmajor && kx_hi > kx_lo;      // Ny is a multiple of TCO_COLS there: chunks are whole column groups
+        const int grp0 = chunk ? (int)((long long)kx_lo * Ny / TCO_COLS) : 0;
+        const int ngroups = chunk ? (int)((long long)kx_hi * Ny / TCO_COLS) : (int)((plane + TCO_COLS - 1) / TCO_COLS);
+        const int nrun = ngroups - grp0;
         // 64 segments = 512 threads: one workgroup per CU resident (TCO_MIN_WAVES / 2), each walks ngroups / grid column groups (a multiple of the grid keeps the tail short)
         const int resident = (TCO_MIN_WAVES / 2) * ctx->num_cus * (segs == 64 ? 1 : 64 / segs);
-        const int per_block = (ngroups + resident - 1) / resident;
-        dim3 grid((unsigned)((ngroups + per_block - 1) / per_block)), block(TCO_COLS * segs);
+        const int per_block = (nrun + resident - 1) / resident;
+        dim3 grid((unsigned)((nrun + per_block - 1) / per_block)), block(TCO_COLS * segs);
         const int kyf = (ctx->slab_mode || ctx->xf) ? 1 : 0;
-#define TCO_GO(SEGS, M, EXACT) hipLaunchKernelGGL((k_tridiag_coop<SEGS, M, EXACT>), grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column, ngroups)
+        const long long lstride = ctx->kxmajor ? (long long)Ny : plane, kxs = ctx->kxmajor ? (long long)(Nz + ctx->kx_pad) * Ny : 0;
+        if (mean_column && grp0 != 0) mean_column = 0;
+#define TCO_GO(SEGS, M, EXACT) hipLaunchKernelGGL((k_tridiag_coop<SEGS, M, EXACT>), grid, block, 0, ctx->stream, ctx->NXH, Ny, Nz, ctx->kx0, nxh_real, kyf, C, (double2 *)hat, scale, mean_column, ngroups, lstride, kxs, grp0)
         const bool whole = plane % TCO_COLS == 0;
         if (segs == 64 && Nz == 64 * 8 && whole) TCO_GO(64, 8, true);      // (128 segments of 4 rows, 1024 threads: the same 0.48 ms)
         else if (segs == 64 && Nz == 64 * 4 && whole) TCO_GO(64, 4, true);
@@ -481,7 +499,9 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
 
     if (!slab) {
         BZ_HIP(hipMalloc(&ctx->d_rhs, nreal * sizeof(double)));
-        BZ_HIP(hipMalloc(&ctx->d_hat, nhat * sizeof(hipfftDoubleComplex)));
+        // (+ room for the phantom lines of the kx-major layout: ctx->kx_pad lines per wavenumber, below)
+        BZ_HIP(hipMalloc(&ctx->d_hat, (nhat + (size_t)ctx->NXH * 4 * Ny) * sizeof(hipfftDoubleComplex)));
+        BZ_HIP(hipMemset(ctx->d_hat, 0, (nhat + (size_t)ctx->NXH * 4 * Ny) * sizeof(hipfftDoubleComplex)));
     }
     BZ_HIP(hipMalloc(&ctx->d_ibeta, nhat * sizeof(double)));
     BZ_HIP(hipMalloc(&ctx->d_tfac, nhat * sizeof(double)));
@@ -527,6 +547,30 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
         int ny[1] = {Ny};
         BZ_FFT(hipfftPlanMany(&ctx->plan_y, 1, ny, ny, 1, Ny, ny, 1, Ny, HIPFFT_Z2Z, ctx->NXH * Nz));
         BZ_FFT(hipfftSetStream(ctx->plan_y, ctx->stream));
+        // Round 6: kx-major spectrum and the chunked middle of the solve.  The y transform, the vertical solves and the inverse y transform
+        // each read and write the whole half spectrum (1.08 GB at 512^3); a range of wavenumbers of ~220 MB that takes the three passes
+        // back to back stays in the 256 MB Infinity Cache between them (tools/mall_probe.hip: three in-place streaming passes over 1.03 GB
+        // 1.24 ms whole, 0.84 ms in 128 - 256 MB chunks).  That needs a wavenumber range to be contiguous: hatT[(kx Nz + k) Ny + ky]
+        // (xf_addr, k_tridiag_coop::col_addr).  Shapes: the cooperative tridiagonal kernel's, Ny a multiple of its column group.
+        const size_t spec = (size_t)ctx->NXH * Nz * Ny * sizeof(hipfftDoubleComplex);
+        const size_t chunk_bytes = (size_t)(ctx->tune.poisson_kx_chunk_mb > 0 ? ctx->tune.poisson_kx_chunk_mb : 256) << 20;
+        if (ctx->tune.poisson_kxmajor && !g.bounded_y && tridiag_coop_segs(ctx, Ny) && Ny % TCO_COLS == 0 && spec > chunk_bytes + chunk_bytes / 2) {
+            const int nch = (int)((spec + chunk_bytes - 1) / chunk_bytes);
+            ctx->kx_cw = (ctx->NXH + nch - 1) / nch;
+            ctx->kx_nch = (ctx->NXH + ctx->kx_cw - 1) / ctx->kx_cw;
+            const int last = ctx->NXH - (ctx->kx_nch - 1) * ctx->kx_cw;
+            // consecutive wavenumbers are Nz + kx_pad lines apart: with none, the 257 segments one block of the forward x transform writes
+            // sit a power of two apart (4 MB at 512^3); the phantom lines (zeros, transformed along with the rest) break that
+            ctx->kx_pad = std::max(0, std::min(4, ctx->tune.poisson_kx_pad));
+            const int lines = Nz + ctx->kx_pad;
+            BZ_FFT(hipfftPlanMany(&ctx->plan_yc, 1, ny, ny, 1, Ny, ny, 1, Ny, HIPFFT_Z2Z, ctx->kx_cw * lines));
+            BZ_FFT(hipfftSetStream(ctx->plan_yc, ctx->stream));
+            if (last != ctx->kx_cw) {
+                BZ_FFT(hipfftPlanMany(&ctx->plan_yc_last, 1, ny, ny, 1, Ny, ny, 1, Ny, HIPFFT_Z2Z, last * lines));
+                BZ_FFT(hipfftSetStream(ctx->plan_yc_last, ctx->stream));
+            }
+            ctx->kxmajor = true;
+        }
     }
     // chunk plans of the L3-resident pipeline
     int ch = ctx->tune.poisson_chunk;
@@ -560,6 +604,9 @@ void bzi_poisson_teardown(bz_ctx *ctx)
         ctx->slab_plans_ok = false;
     }
     if (ctx->xf && ctx->plan_y) hipfftDestroy(ctx->plan_y);
+    if (ctx->plan_yc) hipfftDestroy(ctx->plan_yc);
+    if (ctx->plan_yc_last) hipfftDestroy(ctx->plan_yc_last);
+    ctx->plan_yc = ctx->plan_yc_last = 0; ctx->kxmajor = false;
     if (ctx->d_wtab) hipFree(ctx->d_wtab);
     ctx->plan_y = 0; ctx->d_wtab = nullptr; ctx->xf = ctx->xf_slab = false;
     if (ctx->plans_ok) {
@@ -673,26 +720,50 @@ int bzi_xf_y(bz_ctx *ctx, bool forward)
     return BZ_OK;
 }
 
+// the middle of the solve on the transposed half spectrum of the hand-written x transforms: y transform, vertical solves, inverse y
+// transform — whole-spectrum passes, or (ctx->kxmajor) chunk by chunk of wavenumbers with the three passes of a chunk back to back
+int bzi_xf_middle(bz_ctx *ctx)
+{
+    const DevGrid &g = ctx->dg;
+    const double scale = 1.0 / ((double)g.Nx * (double)g.Ny);
+    int rc;
+    if (ctx->kxmajor) {
+        ProfileScope ps(ctx, "poisson_fft_y+tridiagonal");
+        hipfftDoubleComplex *hat = (hipfftDoubleComplex *)ctx->d_hat;
+        for (int c = 0; c < ctx->kx_nch; ++c) {
+            const int kx_lo = c * ctx->kx_cw, kx_hi = std::min(ctx->NXH, kx_lo + ctx->kx_cw);
+            hipfftHandle plan = (kx_hi - kx_lo == ctx->kx_cw) ? ctx->plan_yc : ctx->plan_yc_last;
+            hipfftDoubleComplex *p = hat + (size_t)kx_lo * (g.Nz + ctx->kx_pad) * g.Ny;
+            BZ_FFT(hipfftExecZ2Z(plan, p, p, HIPFFT_FORWARD));
+            if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, scale, g.Ny, 1, kx_lo, kx_hi))) return rc;
+            BZ_FFT(hipfftExecZ2Z(plan, p, p, HIPFFT_BACKWARD));
+        }
+        return BZ_OK;
+    }
+    {
+        ProfileScope ps(ctx, "poisson_fft_y_forward");
+        if ((rc = bzi_xf_y(ctx, true))) return rc;
+    }
+    {
+        ProfileScope ps(ctx, "poisson_tridiagonal");
+        if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, scale, g.Ny, 1))) return rc;
+    }
+    ProfileScope ps(ctx, "poisson_fft_y_inverse");
+    return bzi_xf_y(ctx, false);
+}
+
 int bzi_poisson_spectral(bz_ctx *ctx)
 {
     const DevGrid &g = ctx->dg;
     if (ctx->xf) {
         int rc;
         {
-            ProfileScope ps(ctx, "poisson_fft_forward");
+            ProfileScope ps(ctx, "poisson_fft_x_forward");
             if ((rc = bzi_xf_forward(ctx, nullptr, 1.0, nullptr))) return rc;
-            if ((rc = bzi_xf_y(ctx, true))) return rc;
         }
-        {
-            ProfileScope ps(ctx, "poisson_tridiagonal");
-            if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1))) return rc;
-        }
-        {
-            ProfileScope ps(ctx, "poisson_fft_inverse");
-            if ((rc = bzi_xf_y(ctx, false))) return rc;
-            if ((rc = bzi_xf_inverse(ctx))) return rc;
-        }
-        return BZ_OK;
+        if ((rc = bzi_xf_middle(ctx))) return rc;
+        ProfileScope ps(ctx, "poisson_fft_x_inverse");
+        return bzi_xf_inverse(ctx);
     }
     const size_t lds_x = (size_t)g.Nx * sizeof(double);
     {
@@ -732,18 +803,7 @@ int bzi_poisson_from_momentum(bz_ctx *ctx, const bz_state *s, double dt, const b
             ProfileScope ps(ctx, "poisson_source_term+fft_x");
             if ((rc = bzi_xf_forward(ctx, s, dt, predictor))) return rc;
         }
-        {
-            ProfileScope ps(ctx, "poisson_fft_y_forward");
-            if ((rc = bzi_xf_y(ctx, true))) return rc;
-        }
-        {
-            ProfileScope ps(ctx, "poisson_tridiagonal");
-            if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1))) return rc;
-        }
-        {
-            ProfileScope ps(ctx, "poisson_fft_y_inverse");
-            if ((rc = bzi_xf_y(ctx, false))) return rc;
-        }
+        if ((rc = bzi_xf_middle(ctx))) return rc;
         ProfileScope ps(ctx, "poisson_fft_x_inverse");
         return bzi_xf_inverse(ctx);
     }

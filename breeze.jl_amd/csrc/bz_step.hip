@@ -349,18 +349,7 @@ static int anelastic_step_body(bz_ctx *ctx, const bz_state *s, const bz_prognost
                     ProfileScope ps(ctx, "poisson_source_term+fft_x");
                     if ((rc = bzi_xf_forward(ctx, s, alpha * dt, G))) return rc;
                 }
-                {
-                    ProfileScope ps(ctx, "poisson_fft_y_forward");
-                    if ((rc = bzi_xf_y(ctx, true))) return rc;
-                }
-                {
-                    ProfileScope ps(ctx, "poisson_tridiagonal");
-                    if ((rc = bzi_tridiag_launch(ctx, (double *)ctx->d_hat, 1.0 / ((double)g.Nx * (double)g.Ny), g.Ny, 1))) return rc;
-                }
-                {
-                    ProfileScope ps(ctx, "poisson_fft_y_inverse");
-                    if ((rc = bzi_xf_y(ctx, false))) return rc;
-                }
+                if ((rc = bzi_xf_middle(ctx))) return rc;
                 {
                     ProfileScope ps(ctx, "poisson_fft_x_inverse");
                     if ((rc = bzi_xf_inverse(ctx))) return rc;

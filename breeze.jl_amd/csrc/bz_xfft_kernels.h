@@ -243,13 +243,17 @@ __device__ __forceinline__ void xf_split_inverse(double2 *__restrict__ row, int 
 // Where element (level k, wavenumber kx, row) of the transposed half spectrum lives: one array hatT[(k NXH + kx) Ny + row] on a single
 // GPU (nkx = nxp = NXH, blk = 0); on a y-slab rank W blocks of nkx wavenumbers each, block d being the message for / from rank d
 // (bz_comm.hip: all-to-all of the blocks), with the zero padding of the last block (nxp = W nkx >= NXH) written by k_x_forward.
+// Round 6, single GPU: kxs != 0 — kx-major, hatT[kx kxs + k Ny + row] with kxs = Nz Ny: a range of wavenumbers is contiguous, which is what
+// lets the y transforms and the vertical solves run chunk by chunk out of the Infinity Cache (bz_poisson.hip: bzi_xf_middle).
 struct XfLayout {
     int nkx, nxp;
     long long blk;       // elements (double2) per block
     int klo, khi;        // level range of this launch (the slab driver pipelines level chunks with the all-to-all messages)
+    long long kxs;       // 0: level-major; else elements between consecutive wavenumbers (one block only)
 };
 __device__ __forceinline__ long long xf_addr(const XfLayout &L, int Ny, int k, int kx, int row)
 {
+    if (L.kxs) return (long long)kx * L.kxs + (long long)k * Ny + row;
     const int d = kx / L.nkx, kxl = kx - d * L.nkx;
     return (long long)d * L.blk + ((long long)k * L.nkx + kxl) * Ny + row;
 }

@@ -42,6 +42,7 @@ CONTRACT_WORDS = {
     "poisson_fft_inverse+project_and_diagnose": 22,
     "poisson_source_term+fft_x": 6, "poisson_fft_y_forward": 2, "poisson_fft_y_inverse": 2,
     "poisson_fft_x+project_momentum": 9, "poisson_fft_x_inverse": 2,
+    "poisson_fft_y+tridiagonal": 6, "poisson_fft_x_forward": 2,      # round 6: the three middle passes of the solve, chunk by chunk of wavenumbers
 }
 A_STEP_CONTRACT_WORDS = 250          # 3 stages x 80 + 10
 ACOUSTIC_SUBSTEP_CONTRACT_WORDS = 58
@@ -59,6 +60,8 @@ COMPULSORY_WORDS = {
     "project_and_diagnose": 16,                        # R phi, predictor x 3, rho_theta, rho_q; W momentum x 3, u, v, w, theta, q, T, phi
     "poisson_source_term+fft_x": 4,                    # R predictor x 3; W half spectrum
     "poisson_fft_y_forward": 2, "poisson_tridiagonal": 2, "poisson_fft_y_inverse": 2, "poisson_fft_x_inverse": 2,
+    "poisson_fft_y+tridiagonal": 6,                    # round 6: R + W of the half spectrum by each of the three passes (a chunk's three passes back to back: what reaches HBM is less)
+    "poisson_fft_x_forward": 2,
     # fused-RK tier (generic WENO 7 / 9 kernels, saturation adjustment, closures): tendency + RK update in one pass, stored diagnostics
     "x_momentum_tendency+rk3": (6, 6, 6),              # R rho_u, rho_v, rho_w, u [+ U0 R / W]; W predictor
     "y_momentum_tendency+rk3": (6, 6, 6),

@@ -1841,7 +1841,9 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
     // first stage of a whole step (the caller passes store0): the state is U0 — store_initial_state! rides along
     S.fwd2 = S.fused && ac_forward2_ok(ctx);
-    S.pfold = S.fwd2 && ctx->d_Gp_ru && !ctx->slab_mode;
+    // the fold costs a stage four words per cell (R G_ru, G_rv; W Gp_ru, Gp_rv) and saves every substep one (p^L): stages of >= 5 substeps
+    // (the 512 x 512 x 256 benchmark: 6, 9, 18; the supercell shape of configs[4]: 2, 3, 5 — its first two stages keep p^L in the substep)
+    S.pfold = S.fwd2 && ctx->d_Gp_ru && !ctx->slab_mode && (ntau >= 5 || ctx->tune.ac_pfold > 1);
     if (S.pfold && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA, rows, b256, Fi);
     else if (S.pfold) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA true COMMA, rows, b256, Fi);
     else if (S.fused && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA, rows, b256, Fi);

@@ -399,7 +399,7 @@ def test_forward_sweep_round6_kernel(oracle, oc, bz, size, td, monkeypatch):
         hm.synchronize()
         return om, hm
 
-    om, a = run(1, 1)
+    om, a = run(1, 2)      # 2: the fold in every stage (the default folds stages of >= 5 substeps only)
     for _ in range(3):
         om.time_step(0.5)
     cmp_interior(om, a, ("rho_d", "rtheta", "ru", "rv", "rw", "u", "v", "w", "theta", "T", "p"), 5e-9)

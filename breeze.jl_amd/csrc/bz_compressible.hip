@@ -435,7 +435,18 @@ struct AcParams {
     double kdamp;                 // alpha * min(dx,dy)^2 / dtau   (0: no damping)
     double inv_N;                 // 1 / N_tau
     int xcd;                      // forward sweep: 1 = every XCD owns a band of tile rows (see k_ac_column_forward), 0 = launch order
+    // Round 6, dry runs inside bz_time_step_compressible: the time-averaged velocities of a stage feed one thing, the moisture (tracer)
+    // tendency the NEXT stage's update uses (acoustic_runge_kutta_3.jl:189-192) — which a model whose rho q is identically zero skips
+    // (bz_step.hip: moisture scan; exact zeros either way).  Where this points at the scan's word and the word says "identically zero,
+    // verified by the scan that opened this call", the substep kernels of stages 1 and 2 neither read nor write the three accumulators
+    // (6 of a substep's 32 words) and the stage epilogue does not form the averages; stage 3 accumulates as ever, so after the step the
+    // substepper holds the averages the reference leaves.  nullptr: always accumulate (per-operator entry points, slabs, moist models).
+    const int *skip_avg_if_dry;
 };
+__device__ __forceinline__ bool ac_accumulate(const AcParams &P)
+{
+    return !(P.skip_avg_if_dry && __builtin_amdgcn_readfirstlane(*P.skip_avg_if_dry) == 1);
+}
 
 // ST = substep_floattype (acoustic_substepping.jl:199-235): the storage type of the acoustic perturbation / predictor / linearisation
 // working fields.  Kernels read ST, promote to the grid's real, compute there and store ST; (rho w)', the tridiagonal right-hand side and
@@ -927,6 +938,7 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
     const unsigned dedge = edge_m ? (unsigned)(int)W.im : dxp;
     const ColPtr::cptr sponge = (ColPtr::cptr)F.sponge;
     const double *Gu = PF ? F.Gp_ru : F.G_ru, *Gv = PF ? F.Gp_rv : F.G_rv;
+    const bool acc = ac_accumulate(P);      // uniform: the time-average accumulators of this stage are wanted
 
     // rings (see k_ac_column_forward): theta_L at k, k+1 of the own column and of rows j-1 / j+1, C at k-1, k (rows j-1 / j+1: k),
     // old (rho w)' at faces k-1, k, k+1
@@ -964,7 +976,7 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
             L.p_ym = ac_ld(F.p, eym); L.p_yp = ac_ld(F.p, eyp);
         }
         L.au_o = 0.0; L.av_o = 0.0;
-        if (!FIRST) { L.au_o = ac_ld_nt(F.au, e); L.av_o = ac_ld_nt(F.av, e); }
+        if (!FIRST && acc) { L.au_o = ac_ld_nt(F.au, e); L.av_o = ac_ld_nt(F.av, e); }
         L.Grho = ac_ld_nt(F.G_rho_d, e); L.Grth = ac_ld_nt(F.G_rth, e); L.Gs_k = ac_ld_nt(F.Gs, e);
         L.e_th = 0.0; L.e_C = 0.0; L.e_rt = 0.0; L.e_o = 0.0;
         if (edge) {
@@ -1044,8 +1056,10 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
         // ---- every store of the level ----
         ac_st_nt(F.rup, e, up0);
         ac_st_nt(F.rvp, e, vp0);
-        ac_st_nt(F.au, e, au_n);
-        ac_st_nt(F.av, e, av_n);
+        if (acc) {
+            ac_st_nt(F.au, e, au_n);
+            ac_st_nt(F.av, e, av_n);
+        }
         ac_st_nt(F.rs, e, rs);
         ac_st_nt(F.rths, e, rths);
         if (FIRST) ac_st_nt(F.tfac, e, t);
@@ -1090,6 +1104,7 @@ __global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcF
     if (i >= g.Nx || j >= g.Ny) return;
     const long long sz = g.Sxy;
     const int Nz = g.Nz;
+    const bool acc = ac_accumulate(P);
     long long n = g.idx(i, j, Nz - 1);
     double w_hi = F.rwp[n + sz];                 // top face: held at its (zero) rewind value
     double th_0 = F.thL[n];                      // theta at cell k
@@ -1106,8 +1121,10 @@ __global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcF
         F.rp[n] = F.rs[n] - P.dtn * dzW;
         F.rthp_out[n] = F.rths[n] - P.dtn * dzT;
         F.rwp[n] = w_lo;
-        if (FIRST) F.aw[n] = 0.0 + w_lo;
-        else F.aw[n] += w_lo;
+        if (acc) {
+            if (FIRST) F.aw[n] = 0.0 + w_lo;
+            else F.aw[n] += w_lo;
+        }
         t_hi = F.tfac[n];
         w_hi = w_lo;
         thf_hi = thf_lo;
@@ -1221,7 +1238,11 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
     const double r0 = F.rho_d[n], r_mx = F.rho_d[mx], r_my = F.rho_d[my];
     const double ru0 = F.ru[n], rv0 = F.rv[n];
     double r_mz = 0.0, rw0 = 0.0;
-    {
+    if (!bot) {
+        r_mz = F.rho_d[mz];
+        rw0 = F.rw[n];
+    }
+    if (ac_accumulate(P)) {      // (a dry stage 1 / 2 of a whole step carries no accumulators: AcParams::skip_avg_if_dry)
         double rx = (r0 + r_mx) / 2.0, ry = (r0 + r_my) / 2.0;
         rx = (rx == 0.0) ? 1.0 : rx;
         ry = (ry == 0.0) ? 1.0 : ry;
@@ -1231,8 +1252,6 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
         cst_img(F.av, n, va, ox, oy);
         double wa = 0.0;
         if (!bot) {
-            r_mz = F.rho_d[mz];
-            rw0 = F.rw[n];
             double rz = (r0 + r_mz) / 2.0;
             rz = (rz == 0.0) ? 1.0 : rz;
             wa = (rw0 + F.aw[n] * P.inv_N) / rz;
@@ -1828,6 +1847,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     P.inv_N = 1.0 / (double)ntau;
     P.gate = 1.0;
     P.xcd = 0;
+    P.skip_avg_if_dry = nullptr;
     S.ntau = ntau;
     S.done = 0;
     S.fused = ctx->ac_fused;
@@ -1841,6 +1861,8 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
     // first stage of a whole step (the caller passes store0): the state is U0 — store_initial_state! rides along
     S.fwd2 = S.fused && ac_forward2_ok(ctx);
+    // stages 1 and 2 of a whole step on a single device (the caller says so through ctx->ac_skip_avg): see AcParams::skip_avg_if_dry
+    if (ctx->ac_skip_avg && S.fwd2 && !ctx->slab_mode) P.skip_avg_if_dry = bzi_moisture_state(ctx);
     // the fold costs a stage four words per cell (R G_ru, G_rv; W Gp_ru, Gp_rv) and saves every substep one (p^L): stages of >= 5 substeps
     // (the 512 x 512 x 256 benchmark: 6, 9, 18; the supercell shape of configs[4]: 2, 3, 5 — its first two stages keep p^L in the substep)
     S.pfold = S.fwd2 && ctx->d_Gp_ru && !ctx->slab_mode && (ntau >= 5 || ctx->tune.ac_pfold > 1);
@@ -2275,7 +2297,10 @@ static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, c
             if (rc) return rc;
             continue;
         }
-        if ((rc = bzi_acoustic_stage_begin(ctx, s, U0, G, sub, dt, betas[st], store0 && st == 0))) return rc;
+        ctx->ac_skip_avg = st < 2;      // the averages of stages 1 and 2 feed only the (skipped) moisture tendency of a dry model
+        rc = bzi_acoustic_stage_begin(ctx, s, U0, G, sub, dt, betas[st], store0 && st == 0);
+        ctx->ac_skip_avg = false;
+        if (rc) return rc;
         const int ntau = stage_of(ctx).ntau;
         for (int sstep = 1; sstep <= ntau; ++sstep)
             if ((rc = bzi_acoustic_substep(ctx, s, U0, G, sub, sstep))) return rc;

@@ -422,6 +422,61 @@ def test_forward_sweep_round6_kernel(oracle, oc, bz, size, td, monkeypatch):
         assert rel(f.interior_cpu(), fo[k]) <= 1e-12, k
 
 
+@pytest.mark.parametrize("size", [(64, 16, 12), (40, 12, 9)])
+def test_dry_steps_skip_the_unread_time_averages_bitwise(oracle, oc, bz, size, monkeypatch):
+    """Round 6: inside bz_time_step_compressible the time-averaged velocities of stages 1 and 2 feed only the moisture tendency of the next
+    stage; a model whose rho q the opening scan found identically zero skips that tendency (exact zeros), so its substep kernels of stages
+    1 and 2 neither read nor write the three accumulators and the stage epilogue forms no averages (AcParams::skip_avg_if_dry; device-side
+    word, no host decision).  Stage 3 accumulates as ever.  Dry: every prognostic field AND the substepper's time-averaged velocities after
+    the step carry the bits of the run that never skips (BZ_NO_DRY_SHORTCUT=1); then vapour is set and two more steps stay equal as well
+    (the scan turns the word to "moist": nothing is skipped any more); the oracle agrees at the usual 5e-9."""
+    def run(no_shortcut):
+        if no_shortcut:
+            monkeypatch.setenv("BZ_NO_DRY_SHORTCUT", "1")
+        else:
+            monkeypatch.delenv("BZ_NO_DRY_SHORTCUT", raising=False)
+        om, hm = make_pair(oracle, oc, bz, size=size, substeps=6)
+        g = om.grid
+
+        def theta(x, y, z):
+            r = np.sqrt(x ** 2 + (y - 300.0) ** 2 + (z - 3000.0) ** 2)
+            return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+        rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+        u = lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z      # noqa: E731
+        om.set(rho=rho, theta=theta, u=u, v=-2.0, w=0.0)
+        hm.set(ρ=rho, θ=theta, u=u, v=-2.0, w=0.0)
+        out = []
+        for _ in range(3):
+            hm.time_step(0.5)
+        hm.synchronize()
+        sub = hm.timestepper.substepper
+        snap = lambda: {**{k: f.interior_cpu().copy() for k, f in hm.prognostic_fields().items()},      # noqa: E731
+                        **{n: getattr(sub, n).interior_cpu().copy() for n in ("time_averaged_u", "time_averaged_v", "time_averaged_w")}}
+        out.append(snap())
+        qv = lambda x, y, z: 4e-3 * np.exp(-z / 2500.0) * (1.0 + 0.2 * np.sin(2 * np.pi * x / 20e3)) + 0 * y      # noqa: E731
+        hm.set(qᵗ=qv)
+        for _ in range(2):
+            hm.time_step(0.5)
+        hm.synchronize()
+        out.append(snap())
+        return om, hm, out
+
+    om, hm, a = run(False)
+    _, _, b = run(True)
+    for x, y in zip(a, b):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    assert np.abs(a[1]["ρq"]).max() > 0 and np.abs(a[0]["ρq"]).max() == 0
+    for _ in range(3):
+        om.time_step(0.5)
+    ref_fields = a[0]
+    g = om.grid
+    want = g.interior(om.ru, zface=False)
+    got = ref_fields["ρu"]
+    assert np.abs(got - want).max() / np.abs(want).max() < 5e-9
+
+
 def test_whole_step_matches_operator_sequence(oracle, oc, bz):
     """bz_time_step_compressible (fused linearisation, no redundant velocity pass) == the reference's operator
     sequence issued call by call."""

@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 import numpy as np
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from accounting import (A_STEP_CONTRACT_WORDS, ACOUSTIC_SUBSTEP_COMPULSORY_WORDS, ACOUSTIC_SUBSTEP_CONTRACT_WORDS, COMPULSORY_WORDS,      # noqa: E402
+from accounting import (A_STEP_CONTRACT_WORDS, ACOUSTIC_SUBSTEP_COMPULSORY_WORDS, acoustic_substep_words, ACOUSTIC_SUBSTEP_CONTRACT_WORDS, COMPULSORY_WORDS,      # noqa: E402
                         CONTRACT_WORDS, HBM_PEAK_GBS, compulsory_words, load_traffic, roofline_block, step_compulsory_words)
 
 WORDS_PER_CELL = CONTRACT_WORDS      # (older tools import the contract table under this name)
@@ -136,7 +136,9 @@ def compressible_milestone(bz, device, steps=2, substep_float32=False):
     """Second milestone, reported beside the headline metric, never as `value`: the compressible
     split-explicit WS-RK3 step (acoustic substep loop) on a 512 x 512 x 256 bubble, Float64, dt = 1 s.
     substep_float32: the same model with substep_floattype = Float32 (acoustic_substepping.jl:199-235): the substepper's ten working
-    fields stored as Float32, arithmetic and every model field Float64 — reported under `substep_floattype_float32`."""
+    fields stored as Float32, arithmetic and every model field Float64 — reported under `substep_floattype_float32`.
+    The bubble is dry (q^t = 0): the step takes the dry path (no moisture tendency; since round 6 no time-average accumulators in stages
+    1 - 2, whose only reader is that tendency) — `dry_path`; the same model with vapour set is timed beside it (`moist_variant`)."""
     import torch
     Nx, Ny, Nz = 512, 512, 256
     grid = bz.RectilinearGrid((Nx, Ny, Nz), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
@@ -154,49 +156,70 @@ def compressible_milestone(bz, device, steps=2, substep_float32=False):
         return 1e5 * ex ** (cpd / Rd) / (Rd * theta(x, y, z) * ex)
 
     m.set(ρ=rho, θ=theta, u=0.0, v=0.0, w=0.0, qᵗ=0.0)
-    m.time_step(1.0)
-    m.profile_reset()
-    m.profile_enable(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        m.time_step(1.0)
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / steps
-    m.profile_enable(False)
-    prof = m.profile()
-    nsub = [m.stage_substeps(1.0, b)[0] for b in (1 / 3, 1 / 2, 1.0)]
-    sub_ms = sum(prof[k][0] for k in prof if k.startswith("acoustic_horizontal") or k.startswith("acoustic_column")) / steps
-    per_sub = sub_ms / sum(nsub)
     cells = Nx * Ny * Nz
-    kernels = kernel_table(prof)
-    # the substep pair (forward sweep with the horizontal step + backward sweep) priced in compulsory words (33; the reference's unfused
-    # kernel list moves 58 contract words per substep); with substep_floattype = Float32 ten of its arrays are 4-byte words
-    fwd = kernels.get("acoustic_horizontal+column_forward", {}).get("avg_ms", 0.0)
-    t_f, src_f = load_traffic(ROOT, "acoustic_horizontal+column_forward")
-    t_b, _ = load_traffic(ROOT, "acoustic_column_backward")
-    pair_traffic = (t_f + t_b) if (t_f and t_b and not substep_float32) else None
-    sub_bytes = (ACOUSTIC_SUBSTEP_COMPULSORY_WORDS * 8 - (4 * 16 if substep_float32 else 0)) * cells      # f32 storage: 16 of the 33 words are working-field words
-    sub_roof = {"bound": "hbm", "kernel": "acoustic substep (column forward + backward)", "achieved": sub_bytes / (per_sub * 1e-3) / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sub_bytes / (per_sub * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": pair_traffic, "traffic_source": src_f if pair_traffic else None,
-                "traffic_over_compulsory": pair_traffic / sub_bytes if pair_traffic else None,
-                "bytes": "compulsory", "compulsory_words_per_cell": ACOUSTIC_SUBSTEP_COMPULSORY_WORDS, "compulsory_bytes_per_substep": sub_bytes,
-                "contract_words_per_cell": ACOUSTIC_SUBSTEP_CONTRACT_WORDS, "forward_sweep_ms": fwd}
-    out = {"metric": "grid-cells advanced/sec, compressible split-explicit WS-RK3 step", "value": cells / (ms * 1e-3),
-           "unit": "cells/s", "ms_per_step": ms, "grid": [Nx, Ny, Nz], "dt": 1.0, "substeps_per_stage": nsub,
-           "acoustic_substep_ms": per_sub, "substep_loop_ms_per_step": sub_ms, "non_substep_ms_per_step": ms - sub_ms,
-           "acoustic_substep_roofline": sub_roof,
-           "roofline": dominant_roofline(kernels, cells, 8, with_traffic=not substep_float32) if not substep_float32 else None,
-           "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(kernels.items())},
+    nsub = [m.stage_substeps(1.0, b)[0] for b in (1 / 3, 1 / 2, 1.0)]
+
+    def timed(dry):
+        m.time_step(1.0)
+        m.profile_reset()
+        m.profile_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.time_step(1.0)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        m.profile_enable(False)
+        prof = m.profile()
+        sub_ms = sum(prof[k][0] for k in prof if k.startswith("acoustic_horizontal") or k.startswith("acoustic_column")) / steps
+        per_sub = sub_ms / sum(nsub)
+        kernels = kernel_table(prof)
+        # the substep pair (forward sweep with the horizontal step + backward sweep) priced in compulsory words (tools/accounting.py:
+        # acoustic_substep_words — 22 + 10, less the accumulators a dry stage 1 / 2 skips; the reference's unfused kernel list moves 58
+        # contract words per substep); with substep_floattype = Float32 the working-field words are 4 bytes
+        wf, wb = acoustic_substep_words(nsub, dry)
+        fwd = kernels.get("acoustic_horizontal+column_forward", {}).get("avg_ms", 0.0)
+        t_f, src_f = load_traffic(ROOT, "acoustic_horizontal+column_forward")
+        t_b, _ = load_traffic(ROOT, "acoustic_column_backward")
+        pair_traffic = (t_f + t_b) if (t_f and t_b and not substep_float32 and not dry) else None
+        sub_bytes = ((wf + wb) * 8 - (4 * 16 if substep_float32 else 0)) * cells      # f32 storage: 16 of the words are working-field words
+        sub_roof = {"bound": "hbm", "kernel": "acoustic substep (column forward + backward)", "achieved": sub_bytes / (per_sub * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sub_bytes / (per_sub * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": pair_traffic, "traffic_source": src_f if pair_traffic else None,
+                    "traffic_over_compulsory": pair_traffic / sub_bytes if pair_traffic else None,
+                    "bytes": "compulsory", "compulsory_words_per_cell": wf + wb, "compulsory_bytes_per_substep": sub_bytes,
+                    "contract_words_per_cell": ACOUSTIC_SUBSTEP_CONTRACT_WORDS, "forward_sweep_ms": fwd,
+                    "forward_sweep_frac": (wf * 8 - (4 * 10 if substep_float32 else 0)) * cells / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd else None}
+        return {"value": cells / (ms * 1e-3), "unit": "cells/s", "ms_per_step": ms, "acoustic_substep_ms": per_sub,
+                "substep_loop_ms_per_step": sub_ms, "non_substep_ms_per_step": ms - sub_ms, "acoustic_substep_roofline": sub_roof,
+                "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(kernels.items())}, "_kernels": kernels}
+
+    dry = os.environ.get("BZ_NO_DRY_SHORTCUT") is None
+    r = timed(dry)
+    kernels = r.pop("_kernels")
+    out = {"metric": "grid-cells advanced/sec, compressible split-explicit WS-RK3 step", "grid": [Nx, Ny, Nz], "dt": 1.0, "substeps_per_stage": nsub,
+           "dry_path": dry, **r,
+           "roofline": roofline_block("acoustic_horizontal+column_forward", kernels["acoustic_horizontal+column_forward"]["avg_ms"], cells, 8,
+                                      words=acoustic_substep_words(nsub, dry)[0]) if not substep_float32 else None,
            "finite": bool(torch.isfinite(m.velocities["w"].interior).all().item())}
+    # like for like: the same model with vapour set (moisture tendency evaluated, every stage accumulates the time-averaged velocities)
+    try:
+        m.set(qᵗ=lambda x, y, z: 5e-3 * np.exp(-z / 2500.0) + 0 * x + 0 * y)
+        mv = timed(False)
+        mv.pop("_kernels")
+        mv["moisture"] = "q^t = 5e-3 exp(-z / 2500 m)"
+        mv["finite"] = bool(torch.isfinite(m.velocities["w"].interior).all().item())
+        out["moist_variant"] = mv
+    except Exception as exc:      # noqa: BLE001
+        out["moist_variant"] = {"error": repr(exc)}
     del m
     torch.cuda.empty_cache()
     if not substep_float32:
         try:
             r = compressible_milestone(bz, device, steps, substep_float32=True)
             out["substep_floattype_float32"] = {k: r[k] for k in ("value", "ms_per_step", "acoustic_substep_ms", "substep_loop_ms_per_step",
-                                                                  "non_substep_ms_per_step", "acoustic_substep_roofline", "finite")}
+                                                                  "non_substep_ms_per_step", "acoustic_substep_roofline", "finite", "dry_path")}
+            out["substep_floattype_float32"]["moist_variant_ms_per_step"] = (r.get("moist_variant") or {}).get("ms_per_step")
             out["substep_floattype_float32"]["tolerance"] = "2e-6 of the field scale after three steps against the Float64 oracle (tests/test_gpu_compressible.py)"
         except Exception as exc:      # noqa: BLE001
             out["substep_floattype_float32"] = {"error": repr(exc)}

@@ -82,9 +82,11 @@ COMPULSORY_WORDS = {
     "make_pressure_correction": 7, "compute_velocities": 6, "compute_auxiliary_thermodynamic_variables": 5, "poisson_source_term": 4,
     "poisson_fft_forward": 4, "poisson_fft_inverse": 4,
     # compressible split-explicit path (bz_compressible.hip)
-    "acoustic_horizontal+column_forward": 23,          # R rho', (rho theta)' x 2 levels, theta_L, C, p, (rho u)', (rho v)', G x 4, (rho w)', G^s, <u>, <v>; W (rho u)', (rho v)', <u>, <v>, both predictors, rhs
+    # round 6: the horizontal gradient of p^L is folded into the slow momentum tendencies once per stage (stages of >= 5 substeps), so the
+    # forward sweep reads Gp_ru, Gp_rv instead of G_ru, G_rv AND p: 22 words (23 in a stage that keeps p^L in the substep)
+    "acoustic_horizontal+column_forward": 22,          # R rho', (rho theta)' x 2 levels, theta_L, C, (rho u)', (rho v)', G x 4, (rho w)', G^s, <u>, <v>; W (rho u)', (rho v)', <u>, <v>, both predictors, rhs
     "acoustic_column_backward": 10,                    # R theta_L, rhs, predictors x 2, factors, <w>; W rho', (rho theta)', (rho w)', <w>
-    "acoustic_stage_init": 19,                         # R U0 x 5, U x 5, p, rho, G_rho_w; W perturbations x 5, G^s  (first stage: U0 written instead of read)
+    "acoustic_stage_init": 23,                         # R U0 x 5, U x 5, p, rho, G_rho_w, G_rho_u, G_rho_v; W perturbations x 5, G^s, Gp_ru, Gp_rv  (first stage: U0 written instead of read)
     "acoustic_stage_end+update_state": 37,             # R U x 5, perturbations x 5, (rho theta)'_old, theta_L, <u v w>, U0_q, G_q; W U x 5 (rho_d below), <u v w>, rho, u, v, w, theta, q, T, p
     "acoustic_stage_end+update_state+linearization": 41,
     "acoustic_recover_density": 3,
@@ -101,7 +103,18 @@ COMPULSORY_WORDS_DRY = {
     "z_momentum_tendency+rk3+velocity": (5, 6, 6),     # R rho_u, rho_v, rho_w, rho_theta [+ U0]; W predictor
     "moisture_scan": 1,                                # R rho_q (once per step CALL)
 }
-ACOUSTIC_SUBSTEP_COMPULSORY_WORDS = 33                 # forward 23 + backward 10 (fused substep, thermal divergence damping)
+ACOUSTIC_SUBSTEP_COMPULSORY_WORDS = 32                 # forward 22 + backward 10 (fused substep, thermal divergence damping, p^L gradient folded)
+
+
+def acoustic_substep_words(nsub, dry, fold_min=5):
+    """Mean compulsory words per cell of the forward and the backward sweep over the substeps of one step, from the substep counts of the
+    three stages.  A stage of fewer than fold_min substeps keeps p^L in the substep (+1 word, bz_compressible.hip: AcStage::pfold); in a
+    DRY whole step (rho q identically zero, found by the opening scan) stages 1 and 2 carry no time-average accumulators: the forward sweep
+    neither reads nor writes <u>, <v> (-4 words), the backward sweep <w> (-2) (AcParams::skip_avg_if_dry)."""
+    tot = float(sum(nsub))
+    fwd = sum(n * ((22 if n >= fold_min else 23) - (4 if (dry and s < 2) else 0)) for s, n in enumerate(nsub)) / tot
+    bwd = sum(n * (10 - (2 if (dry and s < 2) else 0)) for s, n in enumerate(nsub)) / tot
+    return fwd, bwd
 
 
 def compulsory_words(group, dry=False):
@@ -148,7 +161,7 @@ def roofline_block(group, avg_launch_ms, cells, word_bytes, traffic_bytes=None, 
     return out
 
 
-def load_traffic(root, group, f32=False, files=("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")):
+def load_traffic(root, group, f32=False, files=("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")):
     """HBM-side bytes per launch of a kernel group from the newest committed PMC file that has it -> (bytes, 'profiles/<file>')."""
     import json
     import os
@@ -176,7 +189,8 @@ KERNEL_GROUPS = [
     (r"^k_project_lean", "project_momentum"), (r"^k_project_diagnose<", "project_and_diagnose"),
     (r"^k_x_forward<1", "poisson_source_term+fft_x"), (r"^k_x_inverse", "poisson_fft_x_inverse"), (r"^k_tridiag_", "poisson_tridiagonal"),
     (r"^fft_rtc_fwd_", "poisson_fft_y_forward"), (r"^fft_rtc_back_", "poisson_fft_y_inverse"),
-    (r"^k_ac_column_forward<\w+, true", "acoustic_horizontal+column_forward"), (r"^k_ac_column_backward<", "acoustic_column_backward"),
+    (r"^k_ac_column_forward<\w+, true", "acoustic_horizontal+column_forward"), (r"^k_ac_forward2<", "acoustic_horizontal+column_forward"),
+    (r"^k_ac_column_backward<", "acoustic_column_backward"),
     (r"^k_ac_stage_init<", "acoustic_stage_init"), (r"^k_ac_stage_end<\w+, true", "acoustic_stage_end+update_state+linearization"),
     (r"^k_ac_stage_end<\w+, false", "acoustic_stage_end+update_state"), (r"^k_ac_recover_density<", "acoustic_recover_density"),
     (r"^k_ac_finalize<", "acoustic_finalize"), (r"^k_ac_recover<", "acoustic_recover"),

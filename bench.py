@@ -226,6 +226,28 @@ def compressible_milestone(bz, device, steps=2, substep_float32=False):
     return out
 
 
+def milestone_in_fresh_process(bz, device):
+    """The compressible milestone timed in a process of its own (python bench.py --milestone-only).  The same library on the same box steps
+    8 - 10 % slower when its ~45 arrays of 0.56 GB are allocated after the anelastic legs of this process have allocated and freed theirs
+    (1.1 GB arrays) than in a fresh process — round 5 saw the same as 157 - 160 ms standalone against 166 - 176 ms inside this command, with
+    the difference sitting in the plain streaming kernels: what differs is where the driver places the arrays, not the
+    code measured.  A fresh process gives the placement every stand-alone user of the library gets.  BZ_BENCH_MILESTONE_INPROCESS=1 (or a
+    child that fails) keeps the measurement in this process; the line says which it was."""
+    if os.environ.get("BZ_BENCH_MILESTONE_INPROCESS") != "1":
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--milestone-only"], capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and line:
+                out = json.loads(line[-1])
+                out["measured_in"] = "a fresh process (python bench.py --milestone-only)"
+                return out
+        except Exception:      # noqa: BLE001
+            pass
+    out = compressible_milestone(bz, device)
+    out["measured_in"] = "the process of the headline run, after its models were freed"
+    return out
+
+
 def float32_run(bz, device, N, steps=10, warmup=2, single_steps=False):
     """The same workload with eltype(grid) = Float32 (lib/libbreeze_hip_f32.so) — what the reference's own GPU benchmarks run
     (benchmarking/src/convective_boundary_layer.jl:59,70).  Reported beside the Float64 headline, never as `value`
@@ -975,7 +997,7 @@ def run_rank(args):
             try:
                 del model
                 torch.cuda.empty_cache()
-                out["second_milestone"] = compressible_milestone(bz, device)
+                out["second_milestone"] = milestone_in_fresh_process(bz, device)
             except Exception as exc:       # never let the side measurement take the headline line down
                 out["second_milestone"] = {"error": repr(exc)}
         if world == 1 and not args.no_float32 and not use_slabs and args.workload == "bubble":
@@ -1041,6 +1063,7 @@ def main():
     ap.add_argument("--no-float32", action="store_true", help="skip the Float32 run reported under `float32`")
     ap.add_argument("--config4-order", type=int, default=5, choices=(5, 7, 9), help="--workload config4: WENO order (the example uses 9)")
     ap.add_argument("--config4-float32", action="store_true", help="--workload config4 in Float32, the example's own precision (one GPU)")
+    ap.add_argument("--milestone-only", action="store_true", help="run only the compressible milestone and print its JSON object (what the default command spawns)")
     ap.add_argument("--no-compressible", action="store_true",
                     help="skip the short compressible split-explicit measurement reported under `second_milestone`")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks are killed after this many seconds")
@@ -1048,6 +1071,10 @@ def main():
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU/gloo: exercise the launcher and the slab communication pattern without a GPU")
     args = ap.parse_args()
+    if args.milestone_only:
+        import breeze_jl_amd as bz
+        print(json.dumps(compressible_milestone(bz, "cuda:0")), flush=True)
+        return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_self(args, sys.argv[1:])
     return run_rank(args)

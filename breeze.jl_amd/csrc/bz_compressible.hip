@@ -376,21 +376,27 @@ __global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d_x(DevGrid g,
         for (int l = 0; l < nl; ++l) {
             const int kl = k + l;
             const long long m = n + l * sz;
+            // Round 6: every load of the level first.  The reconstructions branch on the wave's upwind direction (bz_up5), so a load written
+            // inside a flux expression stays in that flux's basic block: the ISA of the round-4 form drained the memory counter four
+            // times per level (z, x, y, outside row).  Same expressions, same bits.
             const double zp3 = c[m + 3 * sz];
             const double r_hi = rho[m + sz];
             const double wt = w[m + sz];
+            const double u0 = u[m], rxm = rho[m - 1];
+            const double xm3 = c[m - 3], xm2 = c[m - 2], xm1 = c[m - 1], xp1 = c[m + 1], xp2 = c[m + 2];
+            const double v0 = v[m], rym = rho[m - sy];
+            const double ym3 = c[m - 3 * sy], ym2 = c[m - 2 * sy], ym1 = c[m - sy], yp1 = c[m + sy], yp2 = c[m + 2 * sy];
             const double cR = bz_upB(zm2, zm1, z0, zp1, zp2, zp3, wt > 0.0, bz_buffer_face(kl + 1, g.Nz));
             const double Fz_hi = ((r_hi + r0) / 2.0) * ((g.Az * wt) * cR);
             AZ[l][ty][tx] = bz_sub_rounded_c(Fz_hi, Fz_lo);
-            const double fx = FX(m, kl);
+            // (z0 = c[m] and r0 = rho[m]: the ring values of this level)
+            const double fx = ((r0 + rxm) / 2.0) * ((g.Ax[kl] * u0) * bz_up5(xm3, xm2, xm1, z0, xp1, xp2, u0 > 0.0));
             double nb = __shfl_down(fx, 1);
             const double e = __shfl(edge, kl - k0);
             if (tx == 63) nb = e;
             AX[l][ty][tx] = bz_sub_rounded_c(nb, fx);
-            const int reps = (ty == l) ? 2 : 1;
-#pragma unroll 1
-            for (int rep = 0; rep < reps; ++rep)
-                FY[buf][l][rep ? CTY : ty][tx] = FYf(rep ? nx0 + (long long)(kl - k0) * sz : m, kl);
+            FY[buf][l][ty][tx] = ((r0 + rym) / 2.0) * ((g.Ay[kl] * v0) * bz_up5(ym3, ym2, ym1, z0, yp1, yp2, v0 > 0.0));
+            if (ty == l) FY[buf][l][CTY][tx] = FYf(nx0 + (long long)(kl - k0) * sz, kl);      // the row outside the tile: one wave per level
             zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = zp3;
             Fz_lo = Fz_hi;
             r_lo = r0; r0 = r_hi;

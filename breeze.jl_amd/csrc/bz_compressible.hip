@@ -548,7 +548,9 @@ __device__ __forceinline__ void ac_pencil_block(int &bx, int &j, int &k)
 // (the six copies of bzi_compressible_store_initial_state: 12 words per cell; here 6, and the five state reads are shared).
 // PF (round 6): the horizontal gradient of the stage's p^L, which the reference's explicit horizontal step re-evaluates in every substep
 // (acoustic_substepping.jl:859-876), is folded into the slow tendencies once per stage: Gp_ru = G_ru - dx p^L, Gp_rv = G_rv - dy p^L.
-template <bool ZERO, bool STORE0, bool PF, class ST>
+// NOPERT (round 6): the stage's initial perturbations are not stored — the first forward / backward sweep of the stage forms them from
+// U0 - U itself (k_ac_forward2<.., INIT>: 1) or knows them to be exact zeros (first stage of a whole step: 2)
+template <bool ZERO, bool STORE0, bool PF, bool NOPERT, class ST>
 __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> F)
 {
     int bx, j, k;
@@ -571,8 +573,8 @@ __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> 
         ((double *)F.U0_rv)[n] = F.rv[n];
         ((double *)F.U0_rw)[n] = F.rw[n];
         ((double *)F.U0_rq)[n] = F.rq[n];
-        F.rp[n] = 0.0; F.rthp_out[n] = 0.0; F.rup[n] = 0.0; F.rvp[n] = 0.0; F.rwp[n] = 0.0;
-    } else {
+        if (!NOPERT) { F.rp[n] = 0.0; F.rthp_out[n] = 0.0; F.rup[n] = 0.0; F.rvp[n] = 0.0; F.rwp[n] = 0.0; }
+    } else if (!NOPERT) {
     F.rp[n] = F.U0_rho_d[n] - F.rho_d[n];
     F.rthp_out[n] = F.U0_rth[n] - F.rth[n];     // start buffers of the ping-pong fields (set by the launcher)
     F.rup[n] = F.U0_ru[n] - F.ru[n];
@@ -593,8 +595,8 @@ __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> 
         F.Gs[n] = F.G_rw[n] - dp - g.g * rf;
     }
     if (k == g.Nz - 1) {
-        if (STORE0) { ((double *)F.U0_rw)[n + sz] = F.rw[n + sz]; F.rwp[n + sz] = 0.0; }
-        else F.rwp[n + sz] = F.U0_rw[n + sz] - F.rw[n + sz];
+        if (STORE0) { ((double *)F.U0_rw)[n + sz] = F.rw[n + sz]; if (!NOPERT) F.rwp[n + sz] = 0.0; }
+        else if (!NOPERT) F.rwp[n + sz] = F.U0_rw[n + sz] - F.rw[n + sz];
         F.Gs[n + sz] = 0.0;
     }
 }
@@ -920,9 +922,14 @@ __device__ __forceinline__ double ac_face_update2(double up, double G, double rt
 // CFG: bit 0: 512 threads per block instead of 256; bit 1: register budget for three waves per SIMD instead of two; bit 2: the rows of a
 // block advance level by level together (one s_barrier per level); bit 3: the loads of level k + 1 are issued before level k is worked on;
 // bit 4: x neighbours by DPP wavefront shifts instead of ds_bpermute
-template <bool FIRST, bool DAMP, bool PF, int CFG, class ST>
+// INIT (first substep of a stage only): 0 the stage's initial perturbations are read from their arrays (k_ac_stage_init stored them);
+// 1 they are formed here from U0 - U (rounded through the storage type, as the stored ones are) — the initialisation pass neither writes
+// them (5 words per cell) nor does this sweep read them back (5): it reads U0 and U (10) and stores the initial (rho theta)' (1), which
+// the next substep's damping and the stage epilogue read; 2 first stage of a whole step: the state IS U0, the perturbations are exact zeros
+template <bool FIRST, bool DAMP, bool PF, int CFG, class ST, int INIT = 0>
 __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac_forward2(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
+    static_assert(FIRST || INIT == 0, "initial perturbations belong to the first substep of a stage");
     int bx = blockIdx.x, by = blockIdx.y;
     if (P.xcd) {      // XCD c owns the band of tile rows [c gy/8, (c+1) gy/8) (see k_ac_column_forward)
         const unsigned w = blockIdx.y * gridDim.x + blockIdx.x, c = w & 7u, r = w >> 3;
@@ -953,7 +960,13 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
     double thy_m0 = ac_ld(F.thL, e + dym), thy_p0 = ac_ld(F.thL, e + dyp);
     double thy_m1 = ac_ld(F.thL, e + sz + dym), thy_p1 = ac_ld(F.thL, e + sz + dyp);
     double cy_m0 = ac_ld(F.Clin, e + dym), cy_p0 = ac_ld(F.Clin, e + dyp);
-    double w_m = 0.0, w_0 = ac_ld(F.rwp, e), w_p = ac_ld(F.rwp, e + sz);
+    // initial perturbation of a prognostic field at element ee, as k_ac_stage_init stores it (the working fields in the storage type)
+    auto pert = [&](const double *U0, const double *U, unsigned ee) { return (double)(ST)(ac_ld(U0, ee) - ac_ld(U, ee)); };
+    auto pert_w = [&](unsigned ee) { return ac_ld(F.U0_rw, ee) - ac_ld((const double *)F.rw, ee); };      // (rho w)' stays in the grid's type
+    double w_m = 0.0, w_0, w_p;
+    if (INIT == 2) { w_0 = 0.0; w_p = 0.0; }
+    else if (INIT == 1) { w_0 = pert_w(e); w_p = pert_w(e + sz); }
+    else { w_0 = ac_ld(F.rwp, e); w_p = ac_ld(F.rwp, e + sz); }
     double rs_m = 0.0, rths_m = 0.0, rp_m = 0.0, rthp_m = 0.0;
     double beta = 1.0, phi_m = 0.0, c_m = 0.0;     // row 0: b = 1, c = 0, f = 0
     double thf_0 = th_0, thf_m = th_0;               // theta at faces k (k = 0: one-sided) and k-1
@@ -970,11 +983,22 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
     auto level = [&](const unsigned e, const int k) {
         AcLevel L;
         const unsigned exp_ = e + dxp, eym = e + dym, eyp = e + dyp;
+        if (INIT == 2) { L.rp = 0.0; L.rthp = 0.0; L.rt_ym = 0.0; L.rt_yp = 0.0; }
+        else if (INIT == 1) {
+            L.rp = pert(F.U0_rho_d, F.rho_d, e); L.rthp = pert(F.U0_rth, F.rth, e);
+            L.rt_ym = pert(F.U0_rth, F.rth, eym); L.rt_yp = pert(F.U0_rth, F.rth, eyp);
+        } else {
         L.rp = ac_ld_nt(F.rp, e); L.rthp = ac_ld(F.rthp, e);
         L.rt_ym = ac_ld(F.rthp, eym); L.rt_yp = ac_ld(F.rthp, eyp);
+        }
         L.o0 = 0.0; L.o_ym = 0.0; L.o_yp = 0.0;
         if (DAMP) { L.o0 = ac_ld(F.rth_old, e); L.o_ym = ac_ld(F.rth_old, eym); L.o_yp = ac_ld(F.rth_old, eyp); }
+        if (INIT == 2) { L.ru0 = 0.0; L.ru1 = 0.0; L.rv0 = 0.0; L.rv1 = 0.0; }
+        else if (INIT == 1) {
+            L.ru0 = pert(F.U0_ru, F.ru, e); L.ru1 = pert(F.U0_ru, F.ru, exp_); L.rv0 = pert(F.U0_rv, F.rv, e); L.rv1 = pert(F.U0_rv, F.rv, eyp);
+        } else {
         L.ru0 = ac_ld(F.rup_in, e); L.ru1 = ac_ld(F.rup_in, exp_); L.rv0 = ac_ld(F.rvp_in, e); L.rv1 = ac_ld(F.rvp_in, eyp);
+        }
         L.Gu0 = ac_ld(Gu, e); L.Gu1 = ac_ld(Gu, exp_); L.Gv0 = ac_ld(Gv, e); L.Gv1 = ac_ld(Gv, eyp);
         L.p0 = 0.0; L.p_xm = 0.0; L.p_xp = 0.0; L.p_ym = 0.0; L.p_yp = 0.0;
         if (!PF) {
@@ -987,14 +1011,15 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
         L.e_th = 0.0; L.e_C = 0.0; L.e_rt = 0.0; L.e_o = 0.0;
         if (edge) {
             const unsigned ee = e + dedge;
-            L.e_th = ac_ld(F.thL, ee); L.e_C = ac_ld(F.Clin, ee); L.e_rt = ac_ld(F.rthp, ee);
+            L.e_th = ac_ld(F.thL, ee); L.e_C = ac_ld(F.Clin, ee);
+            L.e_rt = INIT == 2 ? 0.0 : INIT == 1 ? pert(F.U0_rth, F.rth, ee) : ac_ld(F.rthp, ee);
             if (DAMP) L.e_o = ac_ld(F.rth_old, ee);
         }
         // ring words of the levels above (the last levels re-read an in-range level; those values are never used)
         const unsigned e1 = (k + 1 < Nz) ? e + sz : e, e2 = (k + 2 < Nz) ? e1 + sz : e1;
         L.C_n = ac_ld(F.Clin, e1); L.cy_mn = ac_ld(F.Clin, e1 + dym); L.cy_pn = ac_ld(F.Clin, e1 + dyp);
         L.th_n = ac_ld(F.thL, e2); L.thy_mn = ac_ld(F.thL, e2 + dym); L.thy_pn = ac_ld(F.thL, e2 + dyp);
-        L.w_n = ac_ld_nt(F.rwp, e1 + sz);
+        L.w_n = INIT == 2 ? 0.0 : INIT == 1 ? pert_w(e1 + sz) : ac_ld_nt(F.rwp, e1 + sz);
         return L;
     };
     constexpr bool PIPE = (CFG & 8) != 0;
@@ -1060,6 +1085,7 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
             c_m = -dtn2 * C_0 * thf_p * rdc * rdf + (-dtn2 * g.g * rdc / 2.0) + (-P.d_new * rdc * rdf);
         }
         // ---- every store of the level ----
+        if (INIT) ac_st(F.rthp, e, rthp);      // the initial (rho theta)': the next substep's damping and the stage epilogue read it
         ac_st_nt(F.rup, e, up0);
         ac_st_nt(F.rvp, e, vp0);
         if (acc) {
@@ -1103,7 +1129,8 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
 }
 
 // back substitution + _post_solve_recovery! (acoustic_substepping.jl:993-1002)
-template <bool FIRST, class ST>      // FIRST: first substep of a stage with the fused forward sweep: <rho w> starts here
+// INIT (FIRST only; see k_ac_forward2): 1 / 2 — the initial (rho w)' of the held top face is formed here (U0 - U / zero) and stored
+template <bool FIRST, class ST, int INIT = 0>      // FIRST: first substep of a stage with the fused forward sweep: <rho w> starts here
 __global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcFieldsT<ST> F, AcParams P)
 {
     const int i = blockIdx.x * ABX + threadIdx.x, j = blockIdx.y * ABY + threadIdx.y;
@@ -1113,6 +1140,10 @@ __global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcF
     const bool acc = ac_accumulate(P);
     long long n = g.idx(i, j, Nz - 1);
     double w_hi = F.rwp[n + sz];                 // top face: held at its (zero) rewind value
+    if (INIT) {
+        w_hi = (INIT == 2) ? 0.0 : F.U0_rw[n + sz] - F.rw[n + sz];
+        F.rwp[n + sz] = w_hi;
+    }
     double th_0 = F.thL[n];                      // theta at cell k
     double thf_hi = th_0;                        // face Nz: one-sided
     double t_hi = 0.0;                           // t_{k+1}
@@ -1780,10 +1811,16 @@ struct AcStage {
     int ntau = 0, cur = 0, done = 0;
     bool damping = false, fused = true, direct = false;
     bool fwd2 = false, pfold = false;      // k_ac_forward2 runs the forward sweeps of this stage; with the p^L gradient folded into Gp_ru / Gp_rv
+    int init_mode = 0;                     // 1 / 2: the first sweeps of the stage form the initial perturbations (U0 - U / zeros) instead of reading stored ones
     AcParams P;
 };
 // k_ac_forward2 addresses every array by a 32-bit byte offset from its base and fetches the outer x neighbours of a row's two edge lanes
 // with one load: arrays below 4 GB, two z halo levels (its ring words are requested two levels ahead), no row whose first lane is its last
+static int forward2_cfg(const bz_ctx *ctx)
+{
+    const int cfg = ctx->tune.ac_cfg;
+    return (cfg != 0 && cfg != 1 && cfg != 2 && cfg != 4 && cfg != 5 && cfg != 6 && cfg != 8 && cfg != 12 && cfg != 13 && cfg != 22 && cfg != 28) ? 29 : cfg;
+}
 static bool ac_forward2_ok(const bz_ctx *ctx)
 {
     const DevGrid &g = ctx->dg;
@@ -1872,11 +1909,19 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     // the fold costs a stage four words per cell (R G_ru, G_rv; W Gp_ru, Gp_rv) and saves every substep one (p^L): stages of >= 5 substeps
     // (the 512 x 512 x 256 benchmark: 6, 9, 18; the supercell shape of configs[4]: 2, 3, 5 — its first two stages keep p^L in the substep)
     S.pfold = S.fwd2 && ctx->d_Gp_ru && !ctx->slab_mode && (ntau >= 5 || ctx->tune.ac_pfold > 1);
-    if (S.pfold && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA, rows, b256, Fi);
-    else if (S.pfold) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA true COMMA, rows, b256, Fi);
-    else if (S.fused && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA, rows, b256, Fi);
-    else if (S.fused) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA false COMMA, rows, b256, Fi);
-    else AC_LAUNCH0(k_ac_stage_init, true COMMA false COMMA false COMMA, rows, b256, Fi);
+    // the stage's first sweeps form its initial perturbations themselves (default variant of k_ac_forward2 on a single device)
+    S.init_mode = (S.fwd2 && !ctx->slab_mode && ctx->tune.ac_init_fold && forward2_cfg(ctx) == 29) ? (store0 ? 2 : 1) : 0;
+    if (S.init_mode) {
+        if (S.pfold && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA true COMMA, rows, b256, Fi);
+        else if (S.pfold) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA true COMMA true COMMA, rows, b256, Fi);
+        else if (store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA true COMMA, rows, b256, Fi);
+        else AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA false COMMA true COMMA, rows, b256, Fi);
+    }
+    else if (S.pfold && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA false COMMA, rows, b256, Fi);
+    else if (S.pfold) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA true COMMA false COMMA, rows, b256, Fi);
+    else if (S.fused && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA false COMMA, rows, b256, Fi);
+    else if (S.fused) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA false COMMA false COMMA, rows, b256, Fi);
+    else AC_LAUNCH0(k_ac_stage_init, true COMMA false COMMA false COMMA false COMMA, rows, b256, Fi);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -1884,16 +1929,29 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
 // the forward sweep of a fused substep through k_ac_forward2: first substep of the stage / damping of the previous substep / folded p^L
 // gradient, at the register budget for MW waves per SIMD (BZ_AC_MW)
 template <bool PF, int CFG>
-static void launch_forward2_cfg(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp)
+static void launch_forward2_cfg(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, int init = 0)
 {
     const DevGrid &g = ctx->dg;
+    if constexpr (CFG == 29) {
+        if (first && init) {
+            if (ctx->substep_f32) {
+                if (init == 2) hipLaunchKernelGGL((k_ac_forward2<true, false, PF, CFG, float, 2>), cols, bcol, 0, ctx->stream, g, ac_cast<float>(Fs), P);
+                else hipLaunchKernelGGL((k_ac_forward2<true, false, PF, CFG, float, 1>), cols, bcol, 0, ctx->stream, g, ac_cast<float>(Fs), P);
+            } else {
+                if (init == 2) hipLaunchKernelGGL((k_ac_forward2<true, false, PF, CFG, double, 2>), cols, bcol, 0, ctx->stream, g, Fs, P);
+                else hipLaunchKernelGGL((k_ac_forward2<true, false, PF, CFG, double, 1>), cols, bcol, 0, ctx->stream, g, Fs, P);
+            }
+            return;
+        }
+    }
     if (first) AC_LAUNCH(k_ac_forward2, true COMMA false COMMA PF COMMA CFG COMMA, cols, bcol, Fs, P);
     else if (damp) AC_LAUNCH(k_ac_forward2, false COMMA true COMMA PF COMMA CFG COMMA, cols, bcol, Fs, P);
     else AC_LAUNCH(k_ac_forward2, false COMMA false COMMA PF COMMA CFG COMMA, cols, bcol, Fs, P);
 }
 template <bool PF>
-static void launch_forward2_pf(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, int cfg)
+static void launch_forward2_pf(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, int cfg, int init)
 {
+    if (cfg == 29) { launch_forward2_cfg<PF, 29>(ctx, Fs, P, cols, bcol, first, damp, init); return; }
     switch (cfg) {
     case 0: launch_forward2_cfg<PF, 0>(ctx, Fs, P, cols, bcol, first, damp); break;
     case 1: launch_forward2_cfg<PF, 1>(ctx, Fs, P, cols, bcol, first, damp); break;
@@ -1909,10 +1967,10 @@ static void launch_forward2_pf(bz_ctx *ctx, const AcFields &Fs, const AcParams &
     default: launch_forward2_cfg<PF, 29>(ctx, Fs, P, cols, bcol, first, damp); break;
     }
 }
-static void launch_forward2(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, bool pfold, int cfg)
+static void launch_forward2(bz_ctx *ctx, const AcFields &Fs, const AcParams &P, dim3 cols, dim3 bcol, bool first, bool damp, bool pfold, int cfg, int init)
 {
-    if (pfold) launch_forward2_pf<true>(ctx, Fs, P, cols, bcol, first, damp, cfg);
-    else launch_forward2_pf<false>(ctx, Fs, P, cols, bcol, first, damp, cfg);
+    if (pfold) launch_forward2_pf<true>(ctx, Fs, P, cols, bcol, first, damp, cfg, init);
+    else launch_forward2_pf<false>(ctx, Fs, P, cols, bcol, first, damp, cfg, init);
 }
 
 // substep `sstep` (1-based) of the stage opened by bzi_acoustic_stage_begin
@@ -1946,13 +2004,12 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
         {
             ProfileScope ps(ctx, "acoustic_horizontal+column_forward");
             if (S.fwd2) {
-                int cfg = ctx->tune.ac_cfg;
-                if (cfg != 0 && cfg != 1 && cfg != 2 && cfg != 4 && cfg != 5 && cfg != 6 && cfg != 8 && cfg != 12 && cfg != 13 && cfg != 22 && cfg != 28) cfg = 29;
+                const int cfg = forward2_cfg(ctx);
                 const int bt = (cfg & 1) ? 512 : 256;
                 const int fx = ctx->tune.ac_bx == 512 && bt == 512 ? 512 : ctx->tune.ac_bx == 256 ? 256 : ctx->tune.ac_bx == 128 ? 128 : 64, fy = bt / fx;
                 dim3 cols2((g.Nx + fx - 1) / fx, (g.Ny + fy - 1) / fy), bcol2(fx, fy);
                 P.xcd = (ctx->tune.ac_xcd && cols2.y % 8 == 0) ? 1 : 0;
-                launch_forward2(ctx, Fs, P, cols2, bcol2, sstep == 1, damp, S.pfold, cfg);
+                launch_forward2(ctx, Fs, P, cols2, bcol2, sstep == 1, damp, S.pfold, cfg, S.init_mode);
             }
             else if (sstep == 1)
                 AC_LAUNCH(k_ac_column_forward, true COMMA true COMMA false COMMA, cols, bcol, Fs, P);
@@ -1963,7 +2020,16 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
         }
         {
             ProfileScope ps(ctx, "acoustic_column_backward");
-            if (sstep == 1) AC_LAUNCH(k_ac_column_backward, true COMMA, colsb, bcolb, Fs, P);
+            if (sstep == 1 && S.init_mode) {
+                if (ctx->substep_f32) {
+                    if (S.init_mode == 2) hipLaunchKernelGGL((k_ac_column_backward<true, float, 2>), colsb, bcolb, 0, ctx->stream, g, ac_cast<float>(Fs), P);
+                    else hipLaunchKernelGGL((k_ac_column_backward<true, float, 1>), colsb, bcolb, 0, ctx->stream, g, ac_cast<float>(Fs), P);
+                } else {
+                    if (S.init_mode == 2) hipLaunchKernelGGL((k_ac_column_backward<true, double, 2>), colsb, bcolb, 0, ctx->stream, g, Fs, P);
+                    else hipLaunchKernelGGL((k_ac_column_backward<true, double, 1>), colsb, bcolb, 0, ctx->stream, g, Fs, P);
+                }
+            }
+            else if (sstep == 1) AC_LAUNCH(k_ac_column_backward, true COMMA, colsb, bcolb, Fs, P);
             else AC_LAUNCH(k_ac_column_backward, false COMMA, colsb, bcolb, Fs, P);
         }
         S.cur ^= 1;

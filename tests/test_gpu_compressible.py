@@ -477,6 +477,41 @@ def test_dry_steps_skip_the_unread_time_averages_bitwise(oracle, oc, bz, size, m
     assert np.abs(got - want).max() / np.abs(want).max() < 5e-9
 
 
+@pytest.mark.parametrize("storage", [None, "float32"])
+@pytest.mark.parametrize("size,td", [((64, 16, 12), dict(substeps=6)), ((40, 12, 9), dict(substeps=4, damping_coefficient=0.05, damp_vertical=True)),
+                                     ((128, 32, 10), dict(substeps=1))])
+def test_first_sweeps_form_the_initial_perturbations_bitwise(oracle, oc, bz, size, td, storage, monkeypatch):
+    """Round 6: k_ac_stage_init no longer stores the stage's initial perturbations U0 - U (five words per cell) for the first forward sweep
+    to read back: k_ac_forward2<.., INIT> and k_ac_column_backward<.., INIT> form them from U0 and U themselves (stage 1 of a whole step:
+    exact zeros), rounded through the storage type as the stored ones were, and store only the initial (rho theta)' the next substep's
+    damping reads.  Three moist steps (every stage accumulates, the moisture tendency is evaluated) carry the bits of the run with the
+    stored perturbations (BZ_AC_INIT_FOLD=0): Float64 and Float32 substep storage, damped and undamped, one substep per stage (the
+    first sweep is also the last)."""
+    def run(fold):
+        monkeypatch.setenv("BZ_AC_INIT_FOLD", "1" if fold else "0")
+        om, hm = make_pair(oracle, oc, bz, size=size, substep_floattype=np.float32 if storage else None, **td)
+        g = om.grid
+
+        def theta(x, y, z):
+            r = np.sqrt(x ** 2 + (y - 300.0) ** 2 + (z - 3000.0) ** 2)
+            return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+        rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+        qv = lambda x, y, z: 4e-3 * np.exp(-z / 2500.0) * (1.0 + 0.2 * np.sin(2 * np.pi * x / 20e3)) + 0 * y      # noqa: E731
+        hm.set(ρ=rho, θ=theta, u=3.0, v=-2.0, w=0.0, qᵗ=qv)
+        for _ in range(3):
+            hm.time_step(0.5)
+        hm.synchronize()
+        sub = hm.timestepper.substepper
+        return {**{k: f.interior_cpu().copy() for k, f in hm.prognostic_fields().items()},
+                **{n: getattr(sub, n).interior_cpu().copy() for n in ("time_averaged_u", "time_averaged_v", "time_averaged_w")}}
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a["ρw"]).all() and np.abs(a["ρw"]).max() > 0
+
+
 def test_whole_step_matches_operator_sequence(oracle, oc, bz):
     """bz_time_step_compressible (fused linearisation, no redundant velocity pass) == the reference's operator
     sequence issued call by call."""

@@ -448,6 +448,9 @@ struct AcParams {
     // (6 of a substep's 32 words) and the stage epilogue does not form the averages; stage 3 accumulates as ever, so after the step the
     // substepper holds the averages the reference leaves.  nullptr: always accumulate (per-operator entry points, slabs, moist models).
     const int *skip_avg_if_dry;
+    // every stage of a dry whole step (same word): rho q and q are identically zero and stay so (the skipped moisture tendency is an exact
+    // zero): the stage epilogue neither reads U0_rho_q, G_rho_q nor writes rho q, q (4 of its 41 words)
+    const int *dry_q;
 };
 __device__ __forceinline__ bool ac_accumulate(const AcParams &P)
 {
@@ -1305,7 +1308,8 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
     const double rd = r0 + F.rp[n];
     const double rth = F.rth[n] + F.rthp[n];
     const double ru = ru0 + up_s, rv = rv0 + vp_s;
-    const double rq = F.U0_rq[n] + dt_stage * F.G_rq[n];
+    const bool dryq = (MP == 0) && P.dry_q && __builtin_amdgcn_readfirstlane(*P.dry_q) == 1;
+    const double rq = dryq ? 0.0 : F.U0_rq[n] + dt_stage * F.G_rq[n];
     double rqcl = 0.0, rqr = 0.0;
     if (KES) {
         rqcl = F.U0_rqcl[n] + dt_stage * F.G_rqcl[n];
@@ -1375,10 +1379,10 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
             cst_img(g.qr_field, n, qr_v, ox, oy);
             cst_img(g.qv_field, n, q, ox, oy);
         }
-        cst_img(D.rq, n, rq, ox, oy);
+        if (!dryq) cst_img(D.rq, n, rq, ox, oy);
         cst_img(D.rho, n, r, ox, oy);
         cst_img(D.theta, n, th, ox, oy);
-        cst_img(D.q, n, q, ox, oy);
+        if (!dryq) cst_img(D.q, n, q, ox, oy);
         cst_img(D.T, n, T, ox, oy);
         cst_img(D.p, n, p, ox, oy);
         if (LIN) {
@@ -1398,10 +1402,10 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
         cst_img(D.rth, n + h, rth, ox, oy);
         cst_img(D.u, n + h, u, ox, oy);
         cst_img(D.v, n + h, v, ox, oy);
-        cst_img(D.rq, n + h, rq, ox, oy);
+        if (!dryq) cst_img(D.rq, n + h, rq, ox, oy);
         cst_img(D.rho, n + h, r, ox, oy);
         cst_img(D.theta, n + h, th, ox, oy);
-        cst_img(D.q, n + h, q, ox, oy);
+        if (!dryq) cst_img(D.q, n + h, q, ox, oy);
         cst_img(D.T, n + h, T, ox, oy);
         cst_img(D.p, n + h, p, ox, oy);
         if (SA) {
@@ -1891,6 +1895,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     P.gate = 1.0;
     P.xcd = 0;
     P.skip_avg_if_dry = nullptr;
+    P.dry_q = nullptr;
     S.ntau = ntau;
     S.done = 0;
     S.fused = ctx->ac_fused;
@@ -1906,6 +1911,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     S.fwd2 = S.fused && ac_forward2_ok(ctx);
     // stages 1 and 2 of a whole step on a single device (the caller says so through ctx->ac_skip_avg): see AcParams::skip_avg_if_dry
     if (ctx->ac_skip_avg && S.fwd2 && !ctx->slab_mode) P.skip_avg_if_dry = bzi_moisture_state(ctx);
+    if (ctx->ac_whole_step && S.fwd2 && !ctx->slab_mode) P.dry_q = bzi_moisture_state(ctx);
     // the fold costs a stage four words per cell (R G_ru, G_rv; W Gp_ru, Gp_rv) and saves every substep one (p^L): stages of >= 5 substeps
     // (the 512 x 512 x 256 benchmark: 6, 9, 18; the supercell shape of configs[4]: 2, 3, 5 — its first two stages keep p^L in the substep)
     S.pfold = S.fwd2 && ctx->d_Gp_ru && !ctx->slab_mode && (ntau >= 5 || ctx->tune.ac_pfold > 1);
@@ -2370,8 +2376,10 @@ static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, c
             continue;
         }
         ctx->ac_skip_avg = st < 2;      // the averages of stages 1 and 2 feed only the (skipped) moisture tendency of a dry model
+        ctx->ac_whole_step = true;
         rc = bzi_acoustic_stage_begin(ctx, s, U0, G, sub, dt, betas[st], store0 && st == 0);
         ctx->ac_skip_avg = false;
+        ctx->ac_whole_step = false;
         if (rc) return rc;
         const int ntau = stage_of(ctx).ntau;
         for (int sstep = 1; sstep <= ntau; ++sstep)

@@ -433,6 +433,7 @@ struct bz_ctx {
     double *d_thL2 = nullptr;         // second buffer of theta_L: the fused stage epilogue writes the next stage's linearisation while it still reads this one's
     bool thL_alt = false;             // the current theta_L lives in d_thL2 (whole-step seam only; every per-operator linearisation resets it)
     bool substep_f32 = false;         // substep_floattype = Float32 inside the Float64 library: the substepper's working fields are float arrays
+    bool ac_whole_step = false;       // set around bzi_acoustic_stage_begin by the whole-step seam (AcParams::dry_q)
     bool ac_skip_avg = false;         // set around bzi_acoustic_stage_begin by the whole-step seam for its stages 1 and 2 (AcParams::skip_avg_if_dry)
     bool ac_fused = true;             // horizontal step folded into the forward column sweep (BZ_NO_AC_FUSE=1 disables)
     // DCMIP2016KesslerMicrophysics attached to the model (bz_set_kessler_microphysics)

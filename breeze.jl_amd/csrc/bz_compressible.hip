@@ -2211,6 +2211,13 @@ extern "C" int bz_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state 
     BZ_REQUIRE_COMPRESSIBLE();
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
+    // a caller that drives the slab exchanges itself packs rows with the grid's row and plane strides (bz_pack_rows): the Float32 working
+    // fields of substep_floattype = Float32 have half-width rows, which only the library-owned communicator's packer knows
+    if (ctx->slab_mode && ctx->substep_f32 && !ctx->comm) {
+        ctx->last_error = "bz_acoustic_stage_begin: substep_float_bytes = 4 on a y-slab needs the library-owned communicator (bz_comm_init_*): the per-substep "
+                          "halo rows of the Float32 working fields are packed by it";
+        return BZ_ERR_UNSUPPORTED;
+    }
     rc = bzi_acoustic_stage_begin(ctx, s, U0, G, sub, dt, beta);
     if (n_substeps) *n_substeps = stage_of(ctx).ntau;
     if (current_buffer) *current_buffer = stage_of(ctx).cur;

@@ -384,6 +384,8 @@ class LibrarySlabAtmosphereModel(AtmosphereModel):
         self.clock.last_Δt = float(Δt)
         self.clock.iteration += int(n)
 
+    _collective_refresh = True      # Field reads of stale diagnostics raise instead of entering the collective alone (model.refresh_diagnostics())
+
     def _refresh_diagnostics(self):
         """update_state! with the y-halo exchanges — a collective: every rank of the communicator has to get here (all ranks read, or none)."""
         self._check(self._lib.bz_comm_update_state_and_project(self._ctx, C.byref(self._state), C.byref(self._G), 1.0, 0),

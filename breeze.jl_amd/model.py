@@ -179,6 +179,11 @@ class Field:
     def _fresh(self):
         m = self._owner() if self._owner is not None else None
         if m is not None and getattr(m, "_ctx", None) and diagnostics_stale(m):
+            if getattr(m, "_collective_refresh", False):
+                # slab models: rebuilding the diagnostics exchanges halos — a collective a single rank's read must not enter on its own
+                # (a rank-0-only log line would wait for ranks that never come)
+                raise RuntimeError("the diagnostic fields of this slab model are older than its prognostic state (time_steps(..., diagnose_last=False)): "
+                                   "call model.refresh_diagnostics() on EVERY rank before reading them")
             m._refresh_diagnostics()
 
     def cpu(self):
@@ -492,6 +497,11 @@ class AtmosphereModel:
     def _refresh_diagnostics(self):
         """update_state!(model; compute_tendencies=false) after undiagnosed steps (slab models override it with the exchanging form)."""
         update_state_(self, compute_tendencies=False)
+
+    def refresh_diagnostics(self):
+        """Rebuild u, v, w, θ, qᵛ, T from the prognostic state if they are stale.  On slab models a collective: call it on every rank."""
+        if diagnostics_stale(self):
+            self._refresh_diagnostics()
 
     # -- profiling -----------------------------------------------------------
     def graph_enable(self, on=True):

@@ -381,3 +381,29 @@ def test_operator_by_operator_slab_step_matches_the_oracle(bz, oracle, case):
         want = og.interior(getattr(om, name), zface=(name == "rw"))
         scale = mom if name in ("ru", "rv", "rw") else max(np.max(np.abs(want)), 1e-3)
         assert np.max(np.abs(got - want)) / scale < tol, (case, name, np.max(np.abs(got - want)) / scale)
+
+
+def test_stale_diagnostics_on_a_slab_model_need_an_explicit_collective_refresh(bz):
+    """rebuilding the diagnostics of a slab model exchanges halos — a collective.  After time_steps(..., diagnose_last=False) a
+    field read no longer enters it on its own (a rank-0-only log line would wait for ranks that never come): it raises, naming
+    model.refresh_diagnostics(), which every rank calls; afterwards the fields read what a diagnosed call leaves."""
+    import torch
+    from breeze_jl_amd import distributed as bz_dist
+    G = bz.RectilinearGrid((32, 16, 12), x=EXTENT[0], y=EXTENT[1], z=EXTENT[2])
+
+    def make():
+        m = bz_dist.LibrarySlabAtmosphereModel(G, 0, 1, transport="local:" + uuid.uuid4().hex, device="cuda:0", potential_temperature=300.0,
+                                               advection=bz.WENO())
+        m.set(θ=theta_ic, u=3.0, v=-2.0, qᵗ=q_ic)
+        return m
+
+    a, b = make(), make()
+    a.time_steps(2.0, 2, diagnose_last=True)
+    b.time_steps(2.0, 2, diagnose_last=False)
+    b.synchronize()
+    with pytest.raises(RuntimeError, match="refresh_diagnostics"):
+        b.temperature.interior_cpu()
+    assert np.array_equal(b.potential_temperature_density.interior_cpu(), a.potential_temperature_density.interior_cpu())      # prognostic reads are fine
+    b.refresh_diagnostics()
+    for get in (lambda m: m.temperature, lambda m: m.velocities["u"], lambda m: m.potential_temperature):
+        assert np.array_equal(get(b).interior_cpu(), get(a).interior_cpu())

@@ -72,6 +72,7 @@ void bzi_read_tuning(bz_tuning &t)
     t.poisson_kxmajor = num("BZ_POISSON_KXMAJOR", 1);
     t.poisson_kx_chunk_mb = num("BZ_POISSON_KX_CHUNK_MB", 0);
     t.poisson_kx_pad = num("BZ_POISSON_KX_PAD", 1);
+    t.poisson_kx_chunk_kb = num("BZ_POISSON_KX_CHUNK_KB", 0);
     t.poisson_chunk = num("BZ_POISSON_CHUNK", 0);
     t.xf_kchunk_f = num("BZ_XF_KCHUNK_F", 0);
     t.xf_kchunk_i = num("BZ_XF_KCHUNK_I", 0);

@@ -319,6 +319,7 @@ struct bz_tuning {
     bool no_xfft = false;             // BZ_NO_XFFT: library 2-D plans instead of the hand-written x transforms
     int poisson_kxmajor = 1;          // BZ_POISSON_KXMAJOR=0: level-major half spectrum, three whole-spectrum passes between the x transforms
     int poisson_kx_chunk_mb = 0;      // BZ_POISSON_KX_CHUNK_MB: spectrum bytes per chunk of the kx-major pipeline (0: 256 MB)
+    int poisson_kx_chunk_kb = 0;      // BZ_POISSON_KX_CHUNK_KB: the same in KB (tests: the chunked pipeline on small grids)
     int poisson_kx_pad = 1;           // BZ_POISSON_KX_PAD: phantom lines per wavenumber of the kx-major spectrum (0 .. 4)
     int poisson_chunk = 0;            // BZ_POISSON_CHUNK: level-chunked Poisson pipeline (needs BZ_NO_XFFT)
     int xf_kchunk_f = 0, xf_kchunk_i = 0;      // BZ_XF_KCHUNK_F / _I: levels per block of the x transforms (0: automatic)

@@ -553,7 +553,8 @@ int bzi_poisson_setup(bz_ctx *ctx, const double *h_rho /* Nz+2Hz, halo-inclusive
         // 1.24 ms whole, 0.84 ms in 128 - 256 MB chunks).  That needs a wavenumber range to be contiguous: hatT[(kx Nz + k) Ny + ky]
         // (xf_addr, k_tridiag_coop::col_addr).  Shapes: the cooperative tridiagonal kernel's, Ny a multiple of its column group.
         const size_t spec = (size_t)ctx->NXH * Nz * Ny * sizeof(hipfftDoubleComplex);
-        const size_t chunk_bytes = (size_t)(ctx->tune.poisson_kx_chunk_mb > 0 ? ctx->tune.poisson_kx_chunk_mb : 256) << 20;
+        const size_t chunk_bytes = ctx->tune.poisson_kx_chunk_kb > 0 ? (size_t)ctx->tune.poisson_kx_chunk_kb << 10      // (tests: small grids take the pipeline too)
+                                   : (size_t)(ctx->tune.poisson_kx_chunk_mb > 0 ? ctx->tune.poisson_kx_chunk_mb : 256) << 20;
         if (ctx->tune.poisson_kxmajor && !g.bounded_y && tridiag_coop_segs(ctx, Ny) && Ny % TCO_COLS == 0 && spec > chunk_bytes + chunk_bytes / 2) {
             const int nch = (int)((spec + chunk_bytes - 1) / chunk_bytes);
             ctx->kx_cw = (ctx->NXH + nch - 1) / nch;

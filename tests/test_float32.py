@@ -59,11 +59,13 @@ def test_float32_tendencies_match_the_float64_oracle(oracle, bz):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [(32, 20, 16), (64, 24, 16)])      # the second shape takes the hand-written x transforms (Ny % 8 == 0)
+@pytest.mark.parametrize("size", [(32, 20, 16), (64, 24, 16), (64, 16, 32)])      # the second shape takes the hand-written x transforms (Ny % 8 == 0)
 @pytest.mark.parametrize("lean", [True, False])
 def test_float32_time_steps_match_the_float64_oracle(oracle, bz, lean, size, monkeypatch):
     if not lean:
         monkeypatch.setenv("BZ_NO_LEAN", "1")
+    if size == (64, 16, 32):      # round 6: the kx-major spectrum and the chunked middle of the solve (five chunks of 32 KB) in Float32
+        monkeypatch.setenv("BZ_POISSON_KX_CHUNK_KB", "32")
     om, hm = _pair32(oracle, bz, size)
     th = bubble_theta(300.0, 9.81)
     om.set(theta=th, u=3.0, v=-2.0)

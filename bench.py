@@ -66,7 +66,8 @@ def took_dry_path(kernels):
     return "moisture_scan" in kernels
 
 
-def dominant_roofline(kernels, cells, word_bytes, f32=False, with_traffic=True, exclude=("comm_", "moisture_scan"), dry=False, general_body=False):
+def dominant_roofline(kernels, cells, word_bytes, f32=False, with_traffic=True, exclude=("comm_", "moisture_scan"), dry=False, general_body=False,
+                      traffic_tag=None):
     """`roofline` of the kernel group with the largest share of the timed region, among the groups tools/accounting.py can price."""
     known = [k for k in kernels if compulsory_words(k) is not None and not k.startswith(exclude)]
     if not known:
@@ -78,7 +79,7 @@ def dominant_roofline(kernels, cells, word_bytes, f32=False, with_traffic=True, 
         if general_body:
             traffic, src = load_traffic(ROOT, dom + " (general body)", f32)
         if traffic is None:
-            traffic, src = load_traffic(ROOT, dom, f32)
+            traffic, src = load_traffic(ROOT, dom, f32, tag=traffic_tag)
     return roofline_block(dom, kernels[dom]["avg_ms"], cells, word_bytes, traffic, src, dry=dry)
 
 
@@ -389,7 +390,10 @@ def cbl_run(args, bz, device):
     m.profile_enable(False)
     cells, word = Nx * Ny * Nz, 4 if f32 else 8
     kernels = kernel_table(m.profile())
-    roofline = dominant_roofline(kernels, cells, word, f32=f32, with_traffic=(Nx, Ny, Nz) == (512, 512, 512), dry=took_dry_path(kernels))
+    # PMC traffic of this workload at its own grid (profiles/r06_pmc_traffic_cbl_weno<order>.json: the 512 x 512 x 256 Float32 PPB case)
+    own = (Nx, Ny, Nz) == (512, 512, 256) and f32 and args.cbl_topology == "PPB"
+    roofline = dominant_roofline(kernels, cells, word, f32=f32, with_traffic=own or (Nx, Ny, Nz) == (512, 512, 512), dry=took_dry_path(kernels),
+                                 traffic_tag=("cbl_weno%d" % args.cbl_order) if own else None)
     rate = cells * args.steps / elapsed
     out = {"metric": "grid points per second (time_step!), convective boundary layer benchmark case",
            "value": rate, "unit": "cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -559,7 +563,8 @@ def config4_run(args, bz, rank, world, dist, device, fail):
                           "parallelism": "single GPU" if not slabs else
                           f"{world} y-slabs of {Nx}x{Ny // world}x{Nz}, halo exchanges over " +
                           ("RCCL inside the C library (bz_comm.hip)" if transport == "rccl" else "torch.distributed (RCCL backend)")},
-               "roofline": dominant_roofline(kernels, Nx * (Ny // world) * Nz, 4 if f32 else 8, f32=f32, with_traffic=False),
+               "roofline": dominant_roofline(kernels, Nx * (Ny // world) * Nz, 4 if f32 else 8, f32=f32, with_traffic=(world == 1 and not f32 and order == 5),
+                                             traffic_tag="config4"),
                "kernels_ms_per_step": prof, "finite": finite,
                "comm_ms_per_step": sum(v for k, v in prof.items() if k.startswith("comm_")),
                "transport": transport if slabs else None,

@@ -161,10 +161,14 @@ def roofline_block(group, avg_launch_ms, cells, word_bytes, traffic_bytes=None, 
     return out
 
 
-def load_traffic(root, group, f32=False, files=("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")):
-    """HBM-side bytes per launch of a kernel group from the newest committed PMC file that has it -> (bytes, 'profiles/<file>')."""
+def load_traffic(root, group, f32=False, files=("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"), tag=None):
+    """HBM-side bytes per launch of a kernel group from the newest committed PMC file that has it -> (bytes, 'profiles/<file>').
+    tag: a secondary workload's own file (profiles/r06_pmc_traffic_<tag>.json: PMC passes of that workload at its own grid) and nothing else —
+    bytes per launch scale with the grid, the headline's files do not apply."""
     import json
     import os
+    if tag is not None:
+        files = ("r06_pmc_traffic_%s.json" % tag,)
     for fn in files:
         try:
             with open(os.path.join(root, "profiles", fn)) as fh:
@@ -198,7 +202,14 @@ KERNEL_GROUPS = [
     (r"^k_cmp_linearization", "refresh_linearization"), (r"^k_scalar_tendency_rho3d", "density+potential_temperature_tendency | moisture_tendency"),
     (r"^k_u_tend_lds<", "x_momentum_tendency"), (r"^k_v_tend_lds<", "y_momentum_tendency"), (r"^k_w_tend_lds<", "z_momentum_tendency"),
     (r"^k_scalar_pair_lds<", "scalar_tendencies+rk3"),
+    # generic WENO 7 / 9 kernels of the fused-RK tier (bz_tendency_generic.hip): the one-pass marching kernel k_tendency_m<R, KIND, ..>
+    # (KIND 0 scalar, 1 / 2 x / y momentum) and the two passes of the z-momentum kernel (flux pass + divergence pass: their bytes ADD)
+    (r"^k_tendency_m<\d+, 0,", "potential_temperature_tendency+rk3"), (r"^k_tendency_m<\d+, 1,", "x_momentum_tendency+rk3"),
+    (r"^k_tendency_m<\d+, 2,", "y_momentum_tendency+rk3"), (r"^k_tendency_m<\d+, 3,", "z_momentum_tendency+rk3"),
+    (r"^k_w_tendency_g<\d+, [12],", "z_momentum_tendency+rk3"), (r"^k_apply_forcings<", "forcing_tendencies"),
 ]
+# kernel groups made of several launches whose bytes add up (tools/pmc_to_traffic.py): the passes of a two-pass generic kernel
+ADDITIVE_KERNELS = (r"^k_w_tendency_g<", r"^k_u_tendency_g<\d+, [12]", r"^k_v_tendency_g<\d+, [12]", r"^k_scalar_tendency_g<\d+, [12]")
 
 
 def kernel_variant(name):

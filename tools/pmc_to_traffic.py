@@ -10,7 +10,7 @@ import sys
 import os
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from accounting import kernel_group, kernel_variant      # noqa: E402  rocprofv3 kernel name -> kernel group of bench.py (one table for every tool)
+from accounting import ADDITIVE_KERNELS, kernel_group, kernel_variant      # noqa: E402  rocprofv3 kernel name -> kernel group of bench.py (one table for every tool)
 
 
 def main():
@@ -39,7 +39,9 @@ def main():
         e = per.setdefault(group, {"kernel": k if not k.startswith("fft_rtc_") else "rocFFT batched 1-D C2C plan along y", "read_bytes": 0.0, "write_bytes": 0.0,
                                    "hbm_bytes_per_launch": 0.0, "kernels": 0})
         # several instantiations of one group (e.g. the damped / undamped forward sweep) are averaged; rocFFT plans made of several kernels add up
-        if k.startswith("fft_rtc_"):
+        import re
+        base = k.replace("_f32", "", 1)
+        if k.startswith("fft_rtc_") or any(re.search(p, base) for p in ADDITIVE_KERNELS):
             e["read_bytes"] += rd; e["write_bytes"] += wr; e["hbm_bytes_per_launch"] += rd + wr
         else:
             n = e["kernels"]

@@ -338,7 +338,17 @@ __global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d_x(DevGrid g,
     __shared__ double FY[2][CTY][CTY + 1][64];
     __shared__ double AX[CTY][CTY][64], AZ[CTY][CTY][64];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * CTY, i = i0 + tx, j = j0 + ty;
+    // Round 6: every XCD owns a band of tile rows (gridDim.y a multiple of 8).  A 64 x 4 tile reads nine rows of c for its four (y stencil)
+    // and the row below of rho; in launch order (x fastest, round-robin over the eight XCDs) the tiles above and below sit behind other
+    // L2s and every tile fetched its frame itself: PMC 1.4 x the compulsory bytes at 5.4 TB/s of real traffic — the kernel was
+    // bandwidth-bound on re-reads.  (A pipelined form — next level's loads in flight — was measured equal and removed.)
+    int bxr = blockIdx.x, byr = blockIdx.y;
+    if ((gridDim.y & 7u) == 0) {
+        const unsigned wv = blockIdx.y * gridDim.x + blockIdx.x, cx = wv & 7u, rr = wv >> 3;
+        bxr = (int)(rr % gridDim.x);
+        byr = (int)(cx * (gridDim.y >> 3) + rr / gridDim.x);
+    }
+    const int i0 = bxr * 64, j0 = byr * CTY, i = i0 + tx, j = j0 + ty;
     const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk, g.Nz);      // kchunk <= 64: one edge flux per lane
     const long long sy = g.Sx, sz = g.Sxy;
     long long n = g.idx(i, j, k0);

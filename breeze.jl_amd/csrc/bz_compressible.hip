@@ -323,6 +323,27 @@ __global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d(DevGrid g, d
 // contract one of each pair into an fma — results differ from it by an ulp of a flux, both within 1e-12 of the oracle.
 // grid (Nx / 64, Ny / CTY, ceil(Nz / 64)): rows of a multiple of 64 cells, Ny a multiple of CTY, not Flat; halo rows in y are read as
 // they are (periodic images or a slab neighbour's rows).
+// a value one lane up / down the 64-lane wavefront (lane l receives lane l - 1 / l + 1) as two v_mov_b32_dpp wave_shr:1 / wave_shl:1 — 4 cycles of
+// the vector ALU each where __shfl_up / __shfl_down are ds_bpermute_b32 at 10 ns of the CU's LDS pipe (DESIGN section 4, instruction costs;
+// tools/dpp_check.hip: the same values, also with the upper lanes of a ragged row gone)
+template <int CTRL, class T>
+__device__ __forceinline__ T ac_lane_shift(T v)
+{
+    if constexpr (sizeof(T) == 8) {
+        const long long b = __builtin_bit_cast(long long, v);
+        int lo = (int)b, hi = (int)(b >> 32);
+        lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | (long long)(unsigned)lo);
+    } else {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    }
+}
+template <bool DPP>
+__device__ __forceinline__ double ac_lane_up(double v) { return DPP ? ac_lane_shift<0x138>(v) : __shfl_up(v, 1); }
+template <bool DPP>
+__device__ __forceinline__ double ac_lane_down(double v) { return DPP ? ac_lane_shift<0x130>(v) : __shfl_down(v, 1); }
+
 __device__ __forceinline__ double bz_sub_rounded_c(double a, double b)
 {
 #pragma clang fp contract(off)
@@ -426,6 +447,156 @@ __global__ __launch_bounds__(64 * CTY) void k_scalar_tendency_rho3d_x(DevGrid g,
                 Grho[m] = -(g.Vinv_c[kl] * (a + b + cc));
             }
         }
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the same tendency with every stencil read from LDS tiles (the structure of k6_u, bz_tendency5_kernels.h).  The kernel above
+// issues 22 vector-memory instructions per wave and level (stencils straight from the L1) and keeps a CU's address path 84 - 95 % busy
+// (tools/gpu_sq_one_kernel.sh: ~32 TA cycles per 64-lane 8-byte load) at 1.3 x its compulsory bytes; here a 64 x SLT tile stages c with
+// its three-cell frame and rho with its low-side frame once per level (double-buffered; every global load of an iteration is a prefetch
+// for the NEXT level: ring tops, the thread's frame cells, its u, v, w), the x and y stencils are ds_reads, the high x-face flux comes
+// from the next lane (beyond the tile: one evaluation per lane for 64 levels), the high y-face flux from the row above through LDS (the
+// row outside the tile: wave 0).  7 loads per thread and level (13 with G_rho).  Same expressions per flux as k_scalar_tendency_rho3d_x:
+// same bits.  grid (Nx / 64, Ny / SLT, chunks): Nx a multiple of 64, Ny of SLT; XCD bands of tile rows where gridDim.y is a multiple of 8.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef SLT
+#define SLT 8
+#endif
+template <bool GRHO>
+__global__ __launch_bounds__(64 * SLT, 2) void k_scalar_rho3d_lds(DevGrid g, double *__restrict__ Gc, double *__restrict__ Grho,
+                                                                const double *__restrict__ rho, const double *__restrict__ u,
+                                                                const double *__restrict__ v, const double *__restrict__ w,
+                                                                const double *__restrict__ c, const double *__restrict__ ru,
+                                                                const double *__restrict__ rv, const double *__restrict__ rw,
+                                                                const int *__restrict__ zero_if_dry, int kchunk)
+{
+    constexpr int TY = SLT, TR = TY + 6, TC = 72, RR = TY + 2, RC = 68, NT = 64 * TY;
+    constexpr int NHC = TR * 70 - TY * 64;      // frame cells of the c tile (468 for TY = 8)
+    constexpr int NHR = RR * 65 - TY * 64;      // frame cells of the rho tile: row -1, row TY (cols -1 .. 63), column -1 of rows 0 .. TY-1 (138)
+    static_assert(NHC <= NT && NHR <= NT, "one frame cell of each tile per thread");
+    __shared__ double C[2][TR][TC];             // c:   tile row r (-3 .. TY+2) at [r + 3], column q (-3 .. 66) at [q + 3]
+    __shared__ double R[2][RR][RC];             // rho: tile row r (-1 .. TY)   at [r + 1], column q (-1 .. 63) at [q + 1]
+    __shared__ double FY[2][TY + 1][64];
+    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx, tc = tx + 3;
+    int bxr = blockIdx.x, byr = blockIdx.y;
+    if ((gridDim.y & 7u) == 0) {
+        const unsigned wv = blockIdx.y * gridDim.x + blockIdx.x, cx = wv & 7u, rr = wv >> 3;
+        bxr = (int)(rr % gridDim.x);
+        byr = (int)(cx * (gridDim.y >> 3) + rr / gridDim.x);
+    }
+    const int i0 = bxr * 64, j0 = byr * TY, i = i0 + tx, j = j0 + ty;
+    const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk, g.Nz);      // kchunk <= 64: one edge flux per lane
+    if (k0 >= k1) return;
+    const long long sy = g.Sx, sz = g.Sxy;
+    long long n = g.idx(i, j, k0);
+    if (zero_if_dry && __builtin_amdgcn_readfirstlane(*zero_if_dry) == 1) {
+        for (int k = k0; k < k1; ++k, n += sz) Gc[n] = 0.0;
+        return;
+    }
+    // frame cell of the c tile
+    const bool hc = t < NHC;
+    int hcr = 0, hcc = 0;
+    {
+        const int h = hc ? t : 0;
+        if (h < 6 * 70) { const int rr = h / 70; hcc = h - rr * 70; hcr = (rr < 3) ? rr : TY + rr; }      // rows -3 .. -1 and TY .. TY+2, whole width
+        else { const int hh = h - 6 * 70, rr = hh / 6, cc = hh - rr * 6; hcr = 3 + rr; hcc = (cc < 3) ? cc : 64 + cc; }      // side columns of the interior rows
+    }
+    const long long hcn = g.idx(i0 - 3 + hcc, j0 - 3 + hcr, k0);
+    // frame cell of the rho tile
+    const bool hr = t < NHR;
+    int hrr = 0, hrc = 0;
+    {
+        const int h = hr ? t : 0;
+        if (h < 2 * 65) { const int rr = h / 65; hrc = h - rr * 65; hrr = rr ? TY + 1 : 0; }      // rows -1 and TY
+        else { hrr = 1 + (h - 2 * 65); hrc = 0; }                                                  // column -1 of rows 0 .. TY-1
+    }
+    const long long hrn = g.idx(i0 - 1 + hrc, j0 - 1 + hrr, k0);
+    // x flux beyond the tile (column i0 + 64), one level per lane, straight from memory
+    auto FXg = [&](long long m, int k) {
+        const double u0 = u[m];
+        return ((rho[m] + rho[m - 1]) / 2.0) * ((g.Ax[k] * u0) * bz_up5(c[m - 3], c[m - 2], c[m - 1], c[m], c[m + 1], c[m + 2], u0 > 0.0));
+    };
+    double edge;
+    {
+        const int kk = min(k0 + tx, k1 - 1);
+        edge = FXg(g.idx(i0 + 64, j, kk), kk);
+    }
+    // z ring of the own column, densities of the levels k-1, k, k+1, lower z flux
+    double zm3 = c[n - 3 * sz], zm2 = c[n - 2 * sz], zm1 = c[n - sz], z0 = c[n], zp1 = c[n + sz], zp2 = c[n + 2 * sz];
+    double r0 = rho[n], r_hi = rho[n + sz];
+    double Fz_lo;
+    {
+        const double wt = w[n], r_lo = rho[n - sz];
+        const double cR = bz_upB(zm3, zm2, zm1, z0, zp1, zp2, wt > 0.0, bz_buffer_face(k0, g.Nz));
+        Fz_lo = ((r0 + r_lo) / 2.0) * ((g.Az * wt) * cR);
+    }
+    double u0 = u[n], v0 = v[n], wt = w[n + sz];
+    double grw_lo = GRHO ? rw[n] : 0.0;
+    const long long nvt = g.idx(i, j0 + TY, k0);      // v of the row outside the tile (wave 0)
+    double vT = (ty == 0) ? v[nvt] : 0.0;
+    // tiles of level k0
+    C[0][ty + 3][tc] = z0;
+    R[0][ty + 1][tx + 1] = r0;
+    if (hc) C[0][hcr][hcc] = c[hcn];
+    if (hr) R[0][hrr][hrc] = rho[hrn];
+    __syncthreads();
+    int buf = 0;
+    for (int k = k0; k < k1; ++k, n += sz) {
+        const long long lev1 = (long long)(k + 1 - k0) * sz;
+        // ---- prefetch for level k + 1 (consumed at the end of this iteration) ----
+        const double p_zp3 = c[n + 3 * sz];
+        const double p_rn = rho[n + 2 * sz];
+        const double p_w = w[n + 2 * sz];
+        const double p_u = u[n + sz], p_v = v[n + sz];
+        const double p_hc = hc ? c[hcn + lev1] : 0.0;
+        const double p_hr = hr ? rho[hrn + lev1] : 0.0;
+        const double p_vT = (ty == 0) ? v[nvt + lev1] : 0.0;
+        const double Ax = g.Ax[k], Ay = g.Ay[k];
+        if (GRHO) {      // G_rho = -div(rho u) of the cell: the x neighbour from the next lane, the lower z face carried from the level below
+            const double gru0 = ru[n], grv0 = rv[n], grv1 = rv[n + sy], grw1 = rw[n + sz];
+            double gru1 = ac_lane_down<true>(gru0);
+            if (tx == 63) gru1 = ru[n + 1];
+            const double a = Ax * gru1 - Ax * gru0;
+            const double b = Ay * grv1 - Ay * grv0;
+            const double cc = g.Az * grw1 - g.Az * grw_lo;
+            Grho[n] = -(g.Vinv_c[k] * (a + b + cc));
+            grw_lo = grw1;
+        }
+        const double(*Ck)[TC] = C[buf];
+        const double(*Rk)[RC] = R[buf];
+        // ---- z: upper face ----
+        const double cR = bz_upB(zm2, zm1, z0, zp1, zp2, p_zp3, wt > 0.0, bz_buffer_face(k + 1, g.Nz));
+        const double Fz_hi = ((r_hi + r0) / 2.0) * ((g.Az * wt) * cR);
+        const double dz = bz_sub_rounded_c(Fz_hi, Fz_lo);
+        // ---- x: low face of the own cell ----
+        const double *cr = Ck[ty + 3] + tc;
+        const double fx = ((r0 + Rk[ty + 1][tx]) / 2.0) * ((Ax * u0) * bz_up5(cr[-3], cr[-2], cr[-1], z0, cr[1], cr[2], u0 > 0.0));
+        // ---- y: low face of the own cell; wave 0 also takes the row outside the tile ----
+        const double fy = ((r0 + Rk[ty][tx + 1]) / 2.0) * ((Ay * v0) * bz_up5(Ck[ty][tc], Ck[ty + 1][tc], Ck[ty + 2][tc], z0, Ck[ty + 4][tc], Ck[ty + 5][tc], v0 > 0.0));
+        FY[buf][ty][tx] = fy;
+        if (ty == 0)
+            FY[buf][TY][tx] = ((Rk[TY + 1][tx + 1] + Rk[TY][tx + 1]) / 2.0) *
+                              ((Ay * vT) * bz_up5(Ck[TY][tc], Ck[TY + 1][tc], Ck[TY + 2][tc], Ck[TY + 3][tc], Ck[TY + 4][tc], Ck[TY + 5][tc], vT > 0.0));
+        // ---- stage level k + 1 ----
+        C[buf ^ 1][ty + 3][tc] = zp1;
+        R[buf ^ 1][ty + 1][tx + 1] = r_hi;
+        if (hc) C[buf ^ 1][hcr][hcc] = p_hc;
+        if (hr) R[buf ^ 1][hrr][hrc] = p_hr;
+        __syncthreads();
+        {
+            double nb = __shfl_down(fx, 1);
+            const double e = __shfl(edge, k - k0);
+            if (tx == 63) nb = e;
+            const double dx = bz_sub_rounded_c(nb, fx);
+            const double dy = bz_sub_rounded_c(FY[buf][ty + 1][tx], fy);
+            Gc[n] = -(g.Vinv_c[k] * (dx + dy + dz));
+        }
+        zm3 = zm2; zm2 = zm1; zm1 = z0; z0 = zp1; zp1 = zp2; zp2 = p_zp3;
+        Fz_lo = Fz_hi;
+        r0 = r_hi; r_hi = p_rn;
+        u0 = p_u; v0 = p_v; wt = p_w; vT = p_vT;
         buf ^= 1;
     }
 }
@@ -892,27 +1063,6 @@ __device__ __forceinline__ void ac_st_nt(T *base, unsigned e, V v)
     if (AC2_NT & 2) __builtin_nontemporal_store((T)v, (T *)((char *)base + (size_t)(e * (unsigned)sizeof(T))));
     else ac_st(base, e, v);
 }
-
-// a value one lane up / down the 64-lane wavefront (lane l receives lane l - 1 / l + 1) as two v_mov_b32_dpp wave_shr:1 / wave_shl:1 — 4 cycles of
-// the vector ALU each where __shfl_up / __shfl_down are ds_bpermute_b32 at 10 ns of the CU's LDS pipe (DESIGN section 4, instruction costs;
-// tools/dpp_check.hip: the same values, also with the upper lanes of a ragged row gone)
-template <int CTRL, class T>
-__device__ __forceinline__ T ac_lane_shift(T v)
-{
-    if constexpr (sizeof(T) == 8) {
-        const long long b = __builtin_bit_cast(long long, v);
-        int lo = (int)b, hi = (int)(b >> 32);
-        lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-        hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
-        return __builtin_bit_cast(T, ((long long)hi << 32) | (long long)(unsigned)lo);
-    } else {
-        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-    }
-}
-template <bool DPP>
-__device__ __forceinline__ double ac_lane_up(double v) { return DPP ? ac_lane_shift<0x138>(v) : __shfl_up(v, 1); }
-template <bool DPP>
-__device__ __forceinline__ double ac_lane_down(double v) { return DPP ? ac_lane_shift<0x130>(v) : __shfl_down(v, 1); }
 
 template <bool DAMP, bool PF>
 __device__ __forceinline__ double ac_face_update2(double up, double G, double rt_b, double rt_a, double rto_b, double rto_a,
@@ -1610,6 +1760,16 @@ static int launch_scalar_rho3d(bz_ctx *ctx, const char *name, double *Gc, double
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, name);
     if (ctx->weno_R != 3) return bzi_scalar_rho3d_generic(ctx, Gc, Grho, rho, u, v, w, c, ru, rv, rw);
+    if (!ctx->tune.no_rho3d_exchange && ctx->tune.scalar_lds && !g.flat_y && !g.bounded_x && !g.bounded_y && g.Nx % 64 == 0 && g.Ny % SLT == 0 && g.Hx >= 3 &&
+        g.Hy >= 3 && g.Hz >= 3) {
+        int kc = 64;
+        while (kc > 8 && (long long)(g.Nx / 64) * (g.Ny / SLT) * ((g.Nz + kc - 1) / kc) < 2048) kc >>= 1;
+        dim3 block(64, SLT), grid(g.Nx / 64, g.Ny / SLT, (g.Nz + kc - 1) / kc);
+        if (Grho) hipLaunchKernelGGL(k_scalar_rho3d_lds<true>, grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw, zero_if_dry, kc);
+        else hipLaunchKernelGGL(k_scalar_rho3d_lds<false>, grid, block, 0, ctx->stream, g, Gc, Grho, rho, u, v, w, c, ru, rv, rw, zero_if_dry, kc);
+        BZ_LAUNCH_CHECK();
+        return BZ_OK;
+    }
     if (!ctx->tune.no_rho3d_exchange && !g.flat_y && !g.bounded_x && !g.bounded_y && g.Nx % 64 == 0 && g.Ny % CTY == 0) {
         int kc = 64;      // levels per workgroup: >= 8 wavefronts per SIMD (see march_chunk in bz_tendency_generic.hip)
         while (kc > 8 && (long long)(g.Nx / 64) * g.Ny * ((g.Nz + kc - 1) / kc) < 8192) kc >>= 1;

@@ -79,6 +79,7 @@ void bzi_read_tuning(bz_tuning &t)
     t.generic_onepass = on("BZ_GENERIC_ONEPASS");
     t.no_generic_march = on("BZ_NO_GENERIC_MARCH");
     t.no_rho3d_exchange = on("BZ_NO_RHO3D_EXCHANGE");
+    t.scalar_lds = num("BZ_SCALAR_LDS", 1);
     t.no_ac_fuse = on("BZ_NO_AC_FUSE");
     t.no_ac_end_fuse = on("BZ_NO_AC_END_FUSE");
     t.comm_no_overlap = on("BZ_COMM_NO_OVERLAP");

@@ -323,6 +323,7 @@ struct bz_tuning {
     int poisson_kx_pad = 1;           // BZ_POISSON_KX_PAD: phantom lines per wavenumber of the kx-major spectrum (0 .. 4)
     int poisson_chunk = 0;            // BZ_POISSON_CHUNK: level-chunked Poisson pipeline (needs BZ_NO_XFFT)
     int xf_kchunk_f = 0, xf_kchunk_i = 0;      // BZ_XF_KCHUNK_F / _I: levels per block of the x transforms (0: automatic)
+    int scalar_lds = 1;               // BZ_SCALAR_LDS=0: the 3-D-density scalar tendency keeps the kernel that reads its stencils through the L1 (k_scalar_tendency_rho3d_x)
     bool no_rho3d_exchange = false;   // BZ_NO_RHO3D_EXCHANGE: the compressible scalar tendency keeps the kernel that evaluates five fluxes per cell
     bool no_generic_march = false;    // BZ_NO_GENERIC_MARCH: WENO 7 / 9 keep the two-pass (flux arrays + divergence) kernels everywhere
     bool generic_onepass = false;     // BZ_GENERIC_ONEPASS: WENO 7 / 9 with every flux evaluated by both of its cells

@@ -512,6 +512,51 @@ def test_first_sweeps_form_the_initial_perturbations_bitwise(oracle, oc, bz, siz
     assert np.isfinite(a["ρw"]).all() and np.abs(a["ρw"]).max() > 0
 
 
+@pytest.mark.parametrize("size,kessler", [((64, 16, 12), False), ((128, 24, 70), False), ((64, 8, 9), True)])
+def test_lds_tiled_scalar_tendency_matches_the_l1_kernel_and_the_oracle(oracle, oc, bz, size, kessler, monkeypatch):
+    """Round 6: k_scalar_rho3d_lds (c and rho staged in LDS tiles with their frames, stencils by ds_read, the structure of k6_u) evaluates the
+    fluxes of k_scalar_tendency_rho3d_x with the same expressions: three moist steps (rho theta + G_rho, the moisture tendency with the
+    time-averaged velocities; with Kessler the two species as well) agree with the L1 kernel's run (BZ_SCALAR_LDS=0) to 1e-13 and with the
+    oracle at the usual tolerance; one and two tile columns, 9 to 70 levels (two 64-level chunks), one tile row of eight."""
+    def run(lds):
+        monkeypatch.setenv("BZ_SCALAR_LDS", "1" if lds else "0")
+        if kessler:
+            og = oracle.Grid(size, x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"])
+            om = oc.CompressibleOracleModel(og, time_discretization=oc.SplitExplicit(substeps=6), reference_potential_temperature=300.0, microphysics="Kessler")
+            grid = bz.RectilinearGrid(size, x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"])
+            dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), reference_potential_temperature=300.0)
+            hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5),
+                                                thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
+                                                microphysics=bz.DCMIP2016KesslerMicrophysics())
+        else:
+            om, hm = make_pair(oracle, oc, bz, size=size, substeps=6)
+        g = om.grid
+
+        def theta(x, y, z):
+            r = np.sqrt(x ** 2 + (y - 300.0) ** 2 + (z - 3000.0) ** 2)
+            return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+        rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+        qv = lambda x, y, z: 4e-3 * np.exp(-z / 2500.0) * (1.0 + 0.2 * np.sin(2 * np.pi * x / 20e3)) + 0 * y      # noqa: E731
+        kw = dict(qcl=lambda x, y, z: 2e-4 * np.exp(-((z - 2000.0) / 800.0) ** 2) + 0 * x + 0 * y,
+                  qr=lambda x, y, z: 1e-4 * np.exp(-((z - 1500.0) / 700.0) ** 2) + 0 * x + 0 * y) if kessler else {}
+        om.set(rho=rho, theta=theta, u=3.0, v=-2.0, w=0.0, qv=qv, **kw)
+        hm.set(ρ=rho, θ=theta, u=3.0, v=-2.0, w=0.0, qᵗ=qv, **kw)
+        for _ in range(3):
+            hm.time_step(0.5)
+        hm.synchronize()
+        return om, hm
+
+    om, a = run(True)
+    _, b = run(False)
+    fa, fb = a.prognostic_fields(), b.prognostic_fields()
+    for k in fa:
+        assert rel(fa[k].interior_cpu(), fb[k].interior_cpu()) <= 1e-13, k
+    for _ in range(3):
+        om.time_step(0.5)
+    cmp_interior(om, a, ("rho_d", "rtheta", "ru", "rv", "rw", "rq"), 1e-8 if kessler else 5e-9)
+
+
 def test_whole_step_matches_operator_sequence(oracle, oc, bz):
     """bz_time_step_compressible (fused linearisation, no redundant velocity pass) == the reference's operator
     sequence issued call by call."""

@@ -17,7 +17,7 @@ from . import compressible  # noqa: F401,E402
 from .compressible import (AcousticRungeKutta3, AcousticSubstepper, CompressibleAtmosphereModel, CompressibleDynamics,  # noqa: F401,E402
                            ExnerReferenceState, NewtonSolver, NoDivergenceDamping, ProportionalSubsteps, ConstantSubstepSize, MonolithicFirstStage,
                            SplitExplicitTimeDiscretization, ThermalDivergenceDamping, DirectDivergenceDamping, UpperSponge,
-                           LinearRamp, CubicRamp, Sin2Ramp)
+                           LinearRamp, CubicRamp, Sin2Ramp, NormalFlowBoundaryCondition)
 from .microphysics import SaturationAdjustment, SecantSolver, WarmPhaseEquilibrium  # noqa: F401,E402
 from .model import cell_advection_timescale, diagnostics_stale, many_time_steps_, nan_checker  # noqa: F401,E402
 from .microphysics import (DCMIP2016KesslerMicrophysics, KesslerMicrophysicalFields, TetensFormula,  # noqa: F401,E402

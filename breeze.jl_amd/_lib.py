@@ -217,6 +217,7 @@ SYMBOLS = {
     "bz_acoustic_direct_damping": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp]),
     "bz_acoustic_stage_end": (C.c_int, [_ctx, _csp, _cpp, _cpp, _asp, C.c_double, C.c_double, C.c_int]),
     "bz_set_acoustic_scratch": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
+    "bz_set_acoustic_lateral_boundaries": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "bz_compute_moisture_tendency": (C.c_int, [_ctx, _csp, _cpp, _asp]),
     "bz_kessler_microphysics_update": (C.c_int, [_ctx, C.POINTER(bz_kessler_microphysics), C.POINTER(bz_kessler_fields),
                                                  C.c_double, C.c_double]),

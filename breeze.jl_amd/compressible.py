@@ -83,7 +83,7 @@ class UpperSponge:
 class SplitExplicitTimeDiscretization:
     def __init__(self, substeps=None, acoustic_cfl=0.5, forward_weight=0.65, thermodynamic_tendency_factor=1,
                  vertical_momentum_tendency_factor=1, apply_first_substep_pressure_gradient=False, damping=None,
-                 sponge=None, substep_distribution=None):
+                 sponge=None, substep_distribution=None, open_boundary_relaxation=0.5):
         damping = ThermalDivergenceDamping(coefficient=0.1) if damping is None else damping
         if not isinstance(damping, (ThermalDivergenceDamping, DirectDivergenceDamping, NoDivergenceDamping)):
             raise ValueError("`damping` must be an `AcousticDampingStrategy`")
@@ -93,6 +93,9 @@ class SplitExplicitTimeDiscretization:
             raise ValueError("`substep_distribution` must be ProportionalSubsteps(), ConstantSubstepSize() or MonolithicFirstStage()")
         if not acoustic_cfl > 0:
             raise ValueError(f"`acoustic_cfl` must be positive (got {acoustic_cfl})")
+        if not 0 < open_boundary_relaxation <= 1:      # time_discretizations.jl:573-574
+            raise ValueError(f"`open_boundary_relaxation` must be in (0, 1] (got {open_boundary_relaxation})")
+        self.open_boundary_relaxation = float(open_boundary_relaxation)
         self.substeps = None if substeps is None else int(substeps)
         self.acoustic_cfl = float(acoustic_cfl)
         self.forward_weight = float(forward_weight)
@@ -102,6 +105,19 @@ class SplitExplicitTimeDiscretization:
         self.damping = damping
         self.sponge = sponge
         self.substep_distribution = substep_distribution or ProportionalSubsteps()
+
+
+class NormalFlowBoundaryCondition:
+    """NormalFlowBoundaryCondition(value) on the wall-normal momentum of a Bounded side (the open boundary of
+    test/acoustic_substepping_open_boundaries.jl:56-57): `condition is None` is the impenetrable default."""
+
+    def __init__(self, condition=None):
+        self.condition = condition
+
+
+def is_active_open_bc(bc):
+    """is_active_open_bc (acoustic_substepping.jl:1318)"""
+    return isinstance(bc, NormalFlowBoundaryCondition) and bc.condition is not None
 
 
 class NewtonSolver:
@@ -276,7 +292,8 @@ class CompressibleAtmosphereModel:
     (examples/tropical_cyclone_with_rainband.jl:434-514) are the forcing terms built; closure = nothing."""
 
     def __init__(self, grid, dynamics, advection=None, thermodynamic_constants=None, temperature_solver=None,
-                 closure=None, coriolis=None, microphysics=None, forcing=None, device="cuda:0", substep_floattype=None):
+                 closure=None, coriolis=None, microphysics=None, forcing=None, device="cuda:0", substep_floattype=None,
+                 boundary_conditions=None):
         """substep_floattype: storage type of the acoustic substepper's working fields (the keyword of the reference's
         AcousticSubstepper constructor, acoustic_substepping.jl:181,199-235): None = eltype(grid); numpy.float32 inside a Float64
         model halves the bytes the substep kernels stream."""
@@ -284,8 +301,16 @@ class CompressibleAtmosphereModel:
         if not isinstance(grid, RectilinearGrid):
             raise TypeError("grid must be a RectilinearGrid")
         # (Periodic, Flat, Bounded): the 2-D x-z cases of examples/acoustic_wave.jl:51 and inertia_gravity_wave.jl:70
-        if grid.topology not in ((Periodic, Periodic, Bounded), (Periodic, Flat, Bounded)):
+        # a Bounded x and / or y (3-D): the acoustic substep loop with its lateral boundaries (refresh_linearization_, acoustic_rk3_substep_loop_);
+        # set / time_step / update_state_ of such a model are not built (the library returns BZ_ERR_UNSUPPORTED)
+        self.lateral_walls = Bounded in grid.topology[:2]
+        if self.lateral_walls and (Flat in grid.topology or type(self) is not CompressibleAtmosphereModel):
+            raise NotImplementedError("Bounded x / y of the compressible model: 3-D grids on one device")
+        if not self.lateral_walls and grid.topology not in ((Periodic, Periodic, Bounded), (Periodic, Flat, Bounded)):
             raise NotImplementedError("the HIP path implements topology (Periodic, Periodic, Bounded) and (Periodic, Flat, Bounded)")
+        self.boundary_conditions = boundary_conditions or {}
+        if self.boundary_conditions and not self.lateral_walls:
+            raise NotImplementedError("boundary_conditions: the open lateral boundaries of the acoustic substep loop on a Bounded x / y")
         if grid.topology[1] == Flat and not (isinstance(advection, WENO) and advection.bounds is None):
             raise NotImplementedError("(Periodic, Flat, Bounded): the WENO(order = 5 | 7 | 9) model is implemented")
         if isinstance(advection, WENO) and advection.order != 5:      # examples/splitting_supercell.jl:279 uses WENO(order = 9)
@@ -443,6 +468,12 @@ class CompressibleAtmosphereModel:
         self.thermodynamic_forcing_field, _spec = materialize_field_forcing(grid, self._field_forcing, "LiquidIcePotentialTemperature", self.device)
         if self.thermodynamic_forcing_field is not None:
             self._check(lib.bz_set_field_forcing(self._ctx, C.c_void_p(self.thermodynamic_forcing_field.ptr()), _spec), "bz_set_field_forcing")
+        if self.lateral_walls:      # is_active_open_bc of the four sides (acoustic_substepping.jl:1339-1361)
+            bu, bv = self.boundary_conditions.get("ρu"), self.boundary_conditions.get("ρv")
+            sides = [is_active_open_bc(getattr(b, k, None)) and grid.topology[d] == Bounded
+                     for b, k, d in ((bu, "west", 0), (bu, "east", 0), (bv, "south", 1), (bv, "north", 1))]
+            self._check(lib.bz_set_acoustic_lateral_boundaries(self._ctx, *(int(x) for x in sides), td.open_boundary_relaxation),
+                        "bz_set_acoustic_lateral_boundaries")
         # seed_pressure! (compressible_dynamics.jl:254-258)
         if ref is not None:
             Hz, Nz = grid.Hz, grid.Nz
@@ -571,6 +602,8 @@ def store_initial_state_(model):
 def set_(model, **kw):
     """set!(model; ρ, θ, u, v, w, qᵗ): total density first, moisture, then establish_densities!, θ and velocities
     (set_atmosphere_model.jl:198-362; compressible_time_stepping.jl:105-150)."""
+    if getattr(model, "lateral_walls", False):
+        raise NotImplementedError("set!: a compressible model on a Bounded x / y runs the acoustic substep loop only (fill its fields directly)")
     d = model.dynamics
     g = model.grid
     keys = {}
@@ -627,6 +660,8 @@ def time_step_(model, Δt, whole_step=True):
     """time_step!(model::CompressibleAcousticModel, Δt) (acoustic_runge_kutta_3.jl:264-319) without callbacks.
     whole_step=True keeps the step behind one C call; False issues the operator sequence of the reference."""
     Δt = float(Δt)
+    if getattr(model, "lateral_walls", False):
+        raise NotImplementedError("time_step!: a compressible model on a Bounded x / y runs the acoustic substep loop only")
     if model.clock.iteration == 0:                         # maybe_prepare_first_time_step!
         seed_time_averaged_velocities_(model)
         update_state_(model, compute_tendencies=True)

@@ -56,12 +56,14 @@ struct WrapIdx {
 __device__ __forceinline__ WrapIdx wrap_of(const DevGrid &g, int i, int j)
 {
     WrapIdx w;
-    w.im = (i > 0) ? -1 : g.Nx - 1;
-    w.ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx;
-    // y-slab mode (wrap_y == 0): rows -1 and Ny are halo rows delivered by the caller's neighbour exchange
+    // Bounded x (lateral walls of the acoustic loop, round 6): columns -1 and Nx are halo columns — filled by k_ac_fill_walls for the
+    // substepper's own fields (their default zero-gradient boundary condition), by the caller for the model's
+    w.im = (i > 0 || g.bounded_x) ? -1 : g.Nx - 1;
+    w.ip = (i + 1 < g.Nx || g.bounded_x) ? 1 : 1 - g.Nx;
+    // y-slab mode (wrap_y == 0): rows -1 and Ny are halo rows delivered by the caller's neighbour exchange (Bounded y: as Bounded x above)
     w.jm = (j > 0 || !g.wrap_y) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
     w.jp = (j + 1 < g.Ny || !g.wrap_y) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
-    w.ox = (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
+    w.ox = g.bounded_x ? 0 : (i < g.Hx) ? g.Nx : (i >= g.Nx - g.Hx) ? -(long long)g.Nx : 0;
     w.oy = !g.wrap_y ? 0 : (j < g.Hy) ? (long long)g.Ny * g.Sx : (j >= g.Ny - g.Hy) ? -(long long)g.Ny * g.Sx : 0;
     return w;
 }
@@ -223,13 +225,18 @@ __global__ __launch_bounds__(256) void k_cmp_diagnose(DevGrid g, DiagFields F, d
 __global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__restrict__ Pi, double *__restrict__ thL,
                                                            double *__restrict__ gR, double *__restrict__ Clin,
                                                            const double *__restrict__ p, const double *__restrict__ rho_d,
-                                                           const double *__restrict__ rth, const double *__restrict__ qv, int st32, int hrows)
+                                                           const double *__restrict__ rth, const double *__restrict__ qv, int st32, int hrows,
+                                                           int hcols)
 {
     // y-slab mode: hrows halo rows on each side are linearised locally (their inputs arrive with the state's halo exchange): one for
     // the substep kernels, two with DirectDivergenceDamping, whose delta of row -1 averages theta_L of rows -2 and -1
-    const int i = blockIdx.x * 256 + threadIdx.x, j = (int)blockIdx.y - hrows, k = blockIdx.z;
-    if (i >= g.Nx) return;
-    const long long n = g.idx(i, j, k);
+    // Bounded x / y: one halo column / row each side holds the zero-gradient copy of the adjacent interior cell — the fill_halo_regions! of
+    // acoustic_substepping.jl:365-367 on fields with default boundary conditions: the value is formed from the state of that interior cell
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x) - hcols, j = (int)blockIdx.y - hrows, k = blockIdx.z;
+    if (i >= g.Nx + hcols) return;
+    const long long nd = g.idx(i, j, k);
+    const int is = g.bounded_x ? min(max(i, 0), g.Nx - 1) : i, js = g.bounded_y ? min(max(j, 0), g.Ny - 1) : j;
+    const long long n = g.idx(is, js, k);
     const double rd = rho_d[n];
     const double q = (g.microphysics == 1) ? g.qv_field[n] : qv[n];
     const double ql = (g.microphysics == 2) ? g.qcl_field[n] + g.qr_field[n] : ((g.microphysics == 1) ? g.ql_field[n] : 0.0);
@@ -238,10 +245,10 @@ __global__ __launch_bounds__(256) void k_cmp_linearization(DevGrid g, double *__
     const double cpm = g.microphysics ? qd * g.cpd + q * g.cpv + ql * g.sa_cl : qd * g.cpd + q * g.cpv;
     const double P = pow(p[n] / g.pst, g.Rd / g.cpd);
     const double gr = cpm * Rm / (cpm - Rm);
-    st_store(Pi, n, P, st32);
-    st_store(thL, n, rth[n] / ((rd == 0.0) ? 1.0 : rd), st32);
-    st_store(gR, n, gr, st32);
-    st_store(Clin, n, gr * P, st32);
+    st_store(Pi, nd, P, st32);
+    st_store(thL, nd, rth[n] / ((rd == 0.0) ? 1.0 : rd), st32);
+    st_store(gR, nd, gr, st32);
+    st_store(Clin, nd, gr * P, st32);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -632,7 +639,27 @@ struct AcParams {
     // every stage of a dry whole step (same word): rho q and q are identically zero and stay so (the skipped moisture tendency is an exact
     // zero): the stage epilogue neither reads U0_rho_q, G_rho_q nor writes rho q, q (4 of its 41 words)
     const int *dry_q;
+    // Bounded lateral topology (round 6): 1 = the west / south face of (rho u)' / (rho v)' is an impenetrable wall (the model's momentum boundary
+    // condition there is the default one) and is held at zero — enforce_wall_impenetrability! (acoustic_substepping.jl:1378-1395); 0 = an
+    // active open boundary, whose face the substep kernels advance like any other.  The east / north wall face (index N + 1 of the
+    // reference's face field) is written by no kernel of the reference's loop — all of them are launched over :xyz — and keeps the zero the
+    // field was built with: here it is an exact zero in every flux that reads it, whatever the boundary condition.
+    int wall_w, wall_s;
 };
+// _zero_x_wall_face! / _zero_y_wall_face! (acoustic_substepping.jl:1367-1375) as a mask on the four faces a column's predictor reads: the
+// reference zeroes the plane after the horizontal step and again after the damping; nothing reads the face between the kernel that writes it and
+// the zeroing, so forming the zero where the face value is formed gives the same fields
+__device__ __forceinline__ void ac_wall_faces(const DevGrid &g, const AcParams &P, int i, int j, double &up0, double &up1, double &vp0, double &vp1)
+{
+    if (g.bounded_x) {
+        if (i == 0 && P.wall_w) up0 = 0.0;
+        if (i == g.Nx - 1) up1 = 0.0;
+    }
+    if (g.bounded_y) {
+        if (j == 0 && P.wall_s) vp0 = 0.0;
+        if (j == g.Ny - 1) vp1 = 0.0;
+    }
+}
 __device__ __forceinline__ bool ac_accumulate(const AcParams &P)
 {
     return !(P.skip_avg_if_dry && __builtin_amdgcn_readfirstlane(*P.skip_avg_if_dry) == 1);
@@ -815,9 +842,13 @@ __global__ __launch_bounds__(256) void k_ac_horizontal(DevGrid g, AcFieldsT<ST> 
         }
         up += P.dtau * (F.G_ru[n] - dpx);
         vp += P.dtau * (F.G_rv[n] - dpy);
+        if (g.bounded_x && i == 0 && P.wall_w) up = 0.0;
+        if (g.bounded_y && j == 0 && P.wall_s) vp = 0.0;
         F.au[n] += up;
         F.av[n] += vp;
     }
+    if (g.bounded_x && i == 0 && P.wall_w) up = 0.0;
+    if (g.bounded_y && j == 0 && P.wall_s) vp = 0.0;
     F.rup[n] = up;
     F.rvp[n] = vp;
 }
@@ -947,12 +978,14 @@ __global__ __launch_bounds__(ACX * ACY, AC_MINW) void k_ac_column_forward(DevGri
             up1 = ac_face_update<DAMP>(F.rup_in[nxp], F.G_ru[nxp], rt_xp, rthp, o_xp, o0, thxp, th_0, c_xp, C_0, p_xp, p0, g.rdx, P);
             vp0 = ac_face_update<DAMP>(F.rvp_in[n], F.G_rv[n], rthp, rt_ym, o0, o_ym, th_0, thym, C_0, c_ym, p0, p_ym, g.rdy, P);
             vp1 = ac_face_update<DAMP>(F.rvp_in[nyp], F.G_rv[nyp], rt_yp, rthp, o_yp, o0, thyp, th_0, c_yp, C_0, p_yp, p0, g.rdy, P);
+            ac_wall_faces(g, P, i, j, up0, up1, vp0, vp1);
             F.rup[n] = up0;
             F.rvp[n] = vp0;
             if (FIRST) { F.au[n] = 0.0 + up0; F.av[n] = 0.0 + vp0; }      // first substep of the stage: the accumulators start here (0 + x keeps the bits of the zeroed array)
             else { F.au[n] += up0; F.av[n] += vp0; }
         } else {
             up0 = F.rup[n]; up1 = F.rup[n + W.ip]; vp0 = F.rvp[n]; vp1 = F.rvp[n + W.jp];
+            ac_wall_faces(g, P, i, j, up0, up1, vp0, vp1);
             F.rth_old[n] = rthp;
         }
         // theta face k+1 (top face: one-sided)
@@ -1347,8 +1380,12 @@ __global__ __launch_bounds__(256) void k_ac_finalize(DevGrid g, AcFieldsT<ST> F,
         const double ddx = (d0 - (F.rthp[mx] - F.rth_old[mx])) * g.rdx;
         const double ddy = (d0 - (F.rthp[my] - F.rth_old[my])) * g.rdy;
         const double th = F.thL[n];
-        F.rup[n] -= P.kdamp * ddx / ((th + F.thL[mx]) / 2.0);
-        F.rvp[n] -= P.kdamp * ddy / ((th + F.thL[my]) / 2.0);
+        double up = F.rup[n] - P.kdamp * ddx / ((th + F.thL[mx]) / 2.0);
+        double vp = F.rvp[n] - P.kdamp * ddy / ((th + F.thL[my]) / 2.0);
+        if (g.bounded_x && i == 0 && P.wall_w) up = 0.0;
+        if (g.bounded_y && j == 0 && P.wall_s) vp = 0.0;
+        F.rup[n] = up;
+        F.rvp[n] = vp;
     }
     const double r0 = F.rho_d[n];
     double rx = (r0 + F.rho_d[mx]) / 2.0, ry = (r0 + F.rho_d[my]) / 2.0;
@@ -1382,6 +1419,10 @@ __global__ __launch_bounds__(256) void k_ac_recover(DevGrid g, AcFieldsT<ST> F, 
     if (t >= (long long)g.Ny * g.Sx) return;
     const int k = blockIdx.y;
     const long long n = g.Sxy * (k + g.Hz) + (long long)g.Hy * g.Sx + t;
+    if (g.bounded_x) {      // the halo columns of a Bounded x hold the caller's boundary values of the model fields, not periodic images
+        const int c = (int)(t % g.Sx);
+        if (c < g.Hx || c >= g.Hx + g.Nx) return;
+    }
     F.rho_d[n] = F.rho_d[n] + F.rp[n];
     F.rth[n] = F.rth[n] + F.rthp[n];
     F.ru[n] = F.ru[n] + F.rup[n];
@@ -1625,6 +1666,16 @@ static bool valid_sub(const bz_acoustic_substepper *a)
            a->previous_density_potential_temperature_perturbation && a->time_averaged_u && a->time_averaged_v &&
            a->time_averaged_w && a->slow_vertical_momentum_tendency && a->vertical_solver_source_term;
 }
+// Contexts with a Bounded x or y run the acoustic loop (bz_refresh_linearization, bz_acoustic_substep_loop, bz_acoustic_stage_begin /
+// _substep / _stage_end); the rest of the compressible model on lateral walls — wall-aware slow tendencies, update_state! with the model's
+// boundary conditions — is not built
+#define BZ_REJECT_WALLS(what)                                                                                                          \
+    do {                                                                                                                               \
+        if (ctx->dg.bounded_x || ctx->dg.bounded_y) {                                                                                  \
+            ctx->last_error = what ": not implemented on a Bounded x or y (compressible contexts with lateral walls run the acoustic substep loop only)"; \
+            return BZ_ERR_UNSUPPORTED;                                                                                                 \
+        }                                                                                                                              \
+    } while (0)
 #define BZ_REQUIRE_COMPRESSIBLE()                                                      \
     do {                                                                               \
         if (!ctx) return BZ_ERR_INVALID;                                               \
@@ -1818,6 +1869,8 @@ extern "C" int bz_compressible_update_state(bz_ctx *ctx, const bz_compressible_s
                                             const bz_acoustic_substepper *sub, int compute_tendencies)
 {
     BZ_REQUIRE_COMPRESSIBLE();
+    BZ_REJECT_WALLS("bz_compressible_kessler_update");
+    BZ_REJECT_WALLS("bz_compressible_update_state");
     if (!valid_state(s)) return BZ_ERR_INVALID;
     if (compute_tendencies && (!valid_prog(G) || !valid_sub(sub))) return BZ_ERR_INVALID;
     if (!ctx->fused_ok) { ctx->last_error = "compressible path needs Nx >= 2Hx and Ny >= 2Hy"; return BZ_ERR_UNSUPPORTED; }
@@ -1833,10 +1886,11 @@ extern "C" int bz_refresh_linearization(bz_ctx *ctx, const bz_compressible_state
     const DevGrid &g = ctx->dg;
     ProfileScope ps(ctx, "refresh_linearization");
     ctx->thL_alt = false;
-    const int hrows = g.wrap_y ? 0 : ((ctx->se.direct_divergence_damping && ctx->se.damping_coefficient >= 0.0) ? 2 : 1);
-    dim3 grid((g.Nx + 255) / 256, g.Ny + 2 * hrows, g.Nz), block(256);
+    const int hrows = g.wrap_y ? 0 : g.bounded_y ? 1 : ((ctx->se.direct_divergence_damping && ctx->se.damping_coefficient >= 0.0) ? 2 : 1);
+    const int hcols = g.bounded_x ? 1 : 0;
+    dim3 grid((g.Nx + 2 * hcols + 255) / 256, g.Ny + 2 * hrows, g.Nz), block(256);
     hipLaunchKernelGGL(k_cmp_linearization, grid, block, 0, ctx->stream, g, sub->exner, sub->potential_temperature,
-                       sub->gamma_R_mixture, ctx->d_Clin, s->p, s->rho_d, s->rho_theta, s->q, ctx->substep_f32 ? 1 : 0, hrows);
+                       sub->gamma_R_mixture, ctx->d_Clin, s->p, s->rho_d, s->rho_theta, s->q, ctx->substep_f32 ? 1 : 0, hrows, hcols);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -1857,6 +1911,7 @@ extern "C" int bz_seed_time_averaged_velocities(bz_ctx *ctx, const bz_compressib
 extern "C" int bz_compute_slow_tendencies(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *G)
 {
     BZ_REQUIRE_COMPRESSIBLE();
+    BZ_REJECT_WALLS("bz_compute_slow_tendencies");
     if (!valid_state(s) || !valid_prog(G)) return BZ_ERR_INVALID;
     bz_state a;
     std::memset(&a, 0, sizeof(a));
@@ -1960,24 +2015,68 @@ __global__ __launch_bounds__(256) void k_ac_direct_delta(DevGrid g, double *__re
     const int i = blockIdx.x * 256 + threadIdx.x, j = (int)blockIdx.y + jofs, k = blockIdx.z;
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k);
-    const long long ip = (i + 1 < g.Nx) ? 1 : 1 - g.Nx, im = (i > 0) ? -1 : g.Nx - 1;
+    const long long ip = (i + 1 < g.Nx || g.bounded_x) ? 1 : 1 - g.Nx, im = (i > 0 || g.bounded_x) ? -1 : g.Nx - 1;
     const long long jp = (j + 1 < g.Ny || !g.wrap_y) ? (long long)g.Sx : (long long)g.Sx * (1 - g.Ny);
     const long long jm = (j > 0 || !g.wrap_y) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
     const double Ax = g.Ax[k], Ay = g.Ay[k];
-    const double fx = Ax * ((thL[n + ip] + thL[n]) / 2.0) * up[n + ip] - Ax * ((thL[n] + thL[n + im]) / 2.0) * up[n];
-    const double fy = Ay * ((thL[n + jp] + thL[n]) / 2.0) * vp[n + jp] - Ay * ((thL[n] + thL[n + jm]) / 2.0) * vp[n];
+    // Bounded directions: the east / north wall face is an exact zero (AcParams::wall_w); the west / south one holds the value the substep stored
+    const double up1 = (g.bounded_x && i == g.Nx - 1) ? 0.0 : up[n + ip], vp1 = (g.bounded_y && j == g.Ny - 1) ? 0.0 : vp[n + jp];
+    const double fx = Ax * ((thL[n + ip] + thL[n]) / 2.0) * up1 - Ax * ((thL[n] + thL[n + im]) / 2.0) * up[n];
+    const double fy = Ay * ((thL[n + jp] + thL[n]) / 2.0) * vp1 - Ay * ((thL[n] + thL[n + jm]) / 2.0) * vp[n];
     delta[n] = (fx + fy) * g.Vinv_c[k];
 }
 __global__ __launch_bounds__(256) void k_ac_direct_apply(DevGrid g, const double *__restrict__ delta, const double *__restrict__ thL,
-                                                         double *__restrict__ up, double *__restrict__ vp, double alpha)
+                                                         double *__restrict__ up, double *__restrict__ vp, double alpha, int wall_w, int wall_s)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
     if (i >= g.Nx) return;
     const long long n = g.idx(i, j, k);
-    const long long im = (i > 0) ? -1 : g.Nx - 1;
+    const long long im = (i > 0 || g.bounded_x) ? -1 : g.Nx - 1;
     const long long jm = (j > 0 || !g.wrap_y) ? -(long long)g.Sx : (long long)g.Sx * (g.Ny - 1);
-    up[n] += alpha * (g.dx * g.dx) * ((delta[n] - delta[n + im]) * g.rdx) / ((thL[n] + thL[n + im]) / 2.0);
-    vp[n] += alpha * (g.dy * g.dy) * ((delta[n] - delta[n + jm]) * g.rdy) / ((thL[n] + thL[n + jm]) / 2.0);
+    double u1 = up[n] + alpha * (g.dx * g.dx) * ((delta[n] - delta[n + im]) * g.rdx) / ((thL[n] + thL[n + im]) / 2.0);
+    double v1 = vp[n] + alpha * (g.dy * g.dy) * ((delta[n] - delta[n + jm]) * g.rdy) / ((thL[n] + thL[n + jm]) / 2.0);
+    if (g.bounded_x && i == 0 && wall_w) u1 = 0.0;      // enforce_wall_impenetrability! after the damping (acoustic_substepping.jl:1547-1550)
+    if (g.bounded_y && j == 0 && wall_s) v1 = 0.0;
+    up[n] = u1;
+    vp[n] = v1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lateral boundaries of the acoustic loop (round 6): topologies with a Bounded x and / or y.
+// The substepper's own fields carry the default boundary conditions of their location (acoustic_substepping.jl:207-231; the test
+// test/acoustic_substepping_open_boundaries.jl:70-73 pins that the momentum perturbations do not inherit the model's): a field that is a
+// centre along a Bounded direction gets a zero-gradient halo from fill_halo_regions!, the wall faces of a face field are not touched by it.
+// k_ac_fill_walls is that fill for the one halo row / column the substep kernels read (the kernels reach neighbours through halo cells on
+// Bounded directions: wrap_of); the model's own fields (rho_d, rho theta, p, the slow tendencies) keep the halos the caller's boundary
+// conditions gave them.
+// ---------------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_ac_fill_walls(DevGrid g, T *__restrict__ f)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const int ny_rows = g.bounded_y ? 2 * g.Nx : 0, nx_cols = g.bounded_x ? 2 * g.Ny : 0;
+    if (t < ny_rows) {
+        const int side = t / g.Nx, i = t - side * g.Nx;
+        f[g.idx(i, side ? g.Ny : -1, k)] = f[g.idx(i, side ? g.Ny - 1 : 0, k)];
+    } else if (t - ny_rows < nx_cols) {
+        const int u = t - ny_rows, side = u / g.Ny, j = u - side * g.Ny;
+        f[g.idx(side ? g.Nx : -1, j, k)] = f[g.idx(side ? g.Nx - 1 : 0, j, k)];
+    }
+}
+
+// _relax_open_boundary_x! / _relax_open_boundary_y! (acoustic_substepping.jl:1323-1337): the outermost cell of rho' and (rho theta)' is pulled
+// towards the prescribed wall value v; the model's Value boundary condition left rho^L[halo] = 2 v - rho^L[cell], so the target perturbation
+// v - rho^L[cell] is (rho^L[halo] - rho^L[cell]) / 2.  One launch per open side: dir 0 = a y-z plane (cell column cb, halo column ch), 1 = an x-z plane.
+template <class ST>
+__global__ __launch_bounds__(256) void k_ac_relax_open_boundary(DevGrid g, ST *__restrict__ rp, ST *__restrict__ rthp, const double *__restrict__ rho_d,
+                                                                const double *__restrict__ rth, int dir, int cb, int ch, double alpha)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    if (t >= (dir ? g.Nx : g.Ny)) return;
+    const long long nb = dir ? g.idx(t, cb, k) : g.idx(cb, t, k), nh = dir ? g.idx(t, ch, k) : g.idx(ch, t, k);
+    const double r = rp[nb], q = rthp[nb];
+    rp[nb] = r + alpha * ((rho_d[nh] - rho_d[nb]) / 2.0 - r);
+    rthp[nb] = q + alpha * ((rth[nh] - rth[nb]) / 2.0 - q);
 }
 
 // ---- one WS-RK3 stage of the acoustic loop in three pieces (the y-slab driver exchanges halos between them) ---------
@@ -1999,7 +2098,41 @@ static bool ac_forward2_ok(const bz_ctx *ctx)
 {
     const DevGrid &g = ctx->dg;
     const unsigned long long bytes = (unsigned long long)g.Sxy * (unsigned long long)(g.Nz + 2 * g.Hz + 1) * sizeof(double);
-    return ctx->tune.ac_forward2 && bytes < (1ull << 32) && g.Hz >= 1 && g.Nx >= 2 && (g.Nx % 64) != 1;
+    return ctx->tune.ac_forward2 && bytes < (1ull << 32) && g.Hz >= 1 && g.Nx >= 2 && (g.Nx % 64) != 1 && !g.bounded_x && !g.bounded_y;
+}
+// ---- lateral walls / open boundaries (Bounded x and / or y) ----
+static bool ac_walls(const bz_ctx *ctx) { return ctx->dg.bounded_x || ctx->dg.bounded_y; }
+// fill_halo_regions! of a substepper field that is a centre along the Bounded directions: one zero-gradient halo row / column
+template <class T>
+static void fill_walls(bz_ctx *ctx, T *f)
+{
+    const DevGrid &g = ctx->dg;
+    const int n = (g.bounded_y ? 2 * g.Nx : 0) + (g.bounded_x ? 2 * g.Ny : 0);
+    if (!n) return;
+    hipLaunchKernelGGL((k_ac_fill_walls<T>), dim3((n + 255) / 256, g.Nz), dim3(256), 0, ctx->stream, g, f);
+}
+static void fill_walls_st(bz_ctx *ctx, double *f)      // a working field in the substep storage type
+{
+    if (ctx->substep_f32) fill_walls(ctx, (float *)f);
+    else fill_walls(ctx, f);
+}
+// apply_open_boundary_relaxation! (acoustic_substepping.jl:1339-1361) on rho' and the current (rho theta)'
+static void relax_open_boundaries(bz_ctx *ctx, const AcFields &F, double *rthp_cur)
+{
+    const DevGrid &g = ctx->dg;
+    const double a = ctx->ac_open_relax;
+    auto launch = [&](int dir, int cb, int ch) {
+        const int n = dir ? g.Nx : g.Ny;
+        dim3 grid((n + 255) / 256, g.Nz), block(256);
+        if (ctx->substep_f32)
+            hipLaunchKernelGGL((k_ac_relax_open_boundary<float>), grid, block, 0, ctx->stream, g, (float *)F.rp, (float *)rthp_cur, F.rho_d, F.rth, dir, cb, ch, a);
+        else
+            hipLaunchKernelGGL((k_ac_relax_open_boundary<double>), grid, block, 0, ctx->stream, g, (double *)F.rp, rthp_cur, F.rho_d, F.rth, dir, cb, ch, a);
+    };
+    if (g.bounded_x && ctx->ac_open[0]) launch(0, 0, -1);
+    if (g.bounded_x && ctx->ac_open[1]) launch(0, g.Nx - 1, g.Nx);
+    if (g.bounded_y && ctx->ac_open[2]) launch(1, 0, -1);
+    if (g.bounded_y && ctx->ac_open[3]) launch(1, g.Ny - 1, g.Ny);
 }
 static AcStage &stage_of(bz_ctx *ctx)
 {
@@ -2029,8 +2162,9 @@ static int direct_damping(bz_ctx *ctx, const AcFields &F, const bz_acoustic_subs
     const int extra = ctx->slab_mode ? 1 : 0;      // slab: delta from row -1
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), rows_d((g.Nx + 255) / 256, g.Ny + extra, g.Nz), b256(256);
     hipLaunchKernelGGL(k_ac_direct_delta, rows_d, b256, 0, ctx->stream, g, sub->density_predictor, sub->potential_temperature, up, vp, -extra);
+    if (ac_walls(ctx)) fill_walls(ctx, sub->density_predictor);      // fill_halo_regions!(delta) (acoustic_substepping.jl:1168)
     hipLaunchKernelGGL(k_ac_direct_apply, rows, b256, 0, ctx->stream, g, sub->density_predictor, sub->potential_temperature, up, vp,
-                       ctx->se.damping_coefficient);
+                       ctx->se.damping_coefficient, S.P.wall_w, S.P.wall_s);
     BZ_LAUNCH_CHECK();
     return BZ_OK;
 }
@@ -2066,6 +2200,8 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     P.xcd = 0;
     P.skip_avg_if_dry = nullptr;
     P.dry_q = nullptr;
+    P.wall_w = ctx->ac_open[0] ? 0 : 1;
+    P.wall_s = ctx->ac_open[2] ? 0 : 1;
     S.ntau = ntau;
     S.done = 0;
     S.fused = ctx->ac_fused;
@@ -2169,10 +2305,14 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
     dim3 cols((g.Nx + ACX - 1) / ACX, (g.Ny + ACY - 1) / ACY), bcol(ACX, ACY);
     P.xcd = (ctx->tune.ac_xcd && cols.y % 8 == 0) ? 1 : 0;
     dim3 colsb((g.Nx + ABX - 1) / ABX, (g.Ny + ABY - 1) / ABY), bcolb(ABX, ABY);
+    const bool walls = ac_walls(ctx);
     if (S.fused) {
         double *th_buf[2], *u_buf[2], *v_buf[2];
         stage_buffers(ctx, F, th_buf, u_buf, v_buf);
         const int cur = S.cur;
+        // Bounded x / y: fill_halo_regions! of the current (rho theta)' (acoustic_substepping.jl:798,1538); the previous one, read by the
+        // damping, is the buffer that was current — and filled — one substep ago
+        if (walls) fill_walls_st(ctx, th_buf[cur]);
         AcFields Fs = F;
         Fs.rthp = th_buf[cur]; Fs.rth_old = th_buf[cur ^ 1]; Fs.rthp_out = th_buf[cur ^ 1];
         Fs.rup_in = u_buf[cur]; Fs.rup = u_buf[cur ^ 1];
@@ -2208,8 +2348,10 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
             else if (sstep == 1) AC_LAUNCH(k_ac_column_backward, true COMMA, colsb, bcolb, Fs, P);
             else AC_LAUNCH(k_ac_column_backward, false COMMA, colsb, bcolb, Fs, P);
         }
+        if (walls) relax_open_boundaries(ctx, F, th_buf[cur ^ 1]);
         S.cur ^= 1;
     } else {
+        if (walls) { fill_walls_st(ctx, (double *)F.rthp); fill_walls_st(ctx, (double *)F.rth_old); }
         {
             ProfileScope ps(ctx, "acoustic_horizontal");
             if (damp)
@@ -2228,6 +2370,7 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
             ProfileScope ps(ctx, "acoustic_column_backward");
             AC_LAUNCH(k_ac_column_backward, false COMMA, colsb, bcolb, F, P);
         }
+        if (walls) relax_open_boundaries(ctx, F, (double *)F.rthp);
     }
     S.done = sstep;
     // DirectDivergenceDamping closes every substep (also the last one) on the current perturbation buffers; on a y-slab the driver
@@ -2263,6 +2406,7 @@ static int bzi_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, c
     }
     AcFields F = ac_fields(ctx, s, U0, G, sub);
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
+    if (ac_walls(ctx)) { fill_walls_st(ctx, (double *)F.rthp); if (!S.fused) fill_walls_st(ctx, (double *)F.rth_old); }
     {
         ProfileScope ps(ctx, "acoustic_finalize");
         if (S.damping)
@@ -2295,7 +2439,7 @@ static int bzi_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, c
 // update) + update_state! [+ the next stage's linearisation].  Single-device contexts, thermal or no divergence damping.
 static bool stage_end_fusable(const bz_ctx *ctx)
 {
-    return !ctx->slab_mode && !ctx->tune.no_ac_end_fuse && !(ctx->se.damping_coefficient >= 0.0 && ctx->se.direct_divergence_damping != 0);
+    return !ctx->slab_mode && !ac_walls(ctx) && !ctx->tune.no_ac_end_fuse && !(ctx->se.damping_coefficient >= 0.0 && ctx->se.direct_divergence_damping != 0);
 }
 static int bzi_acoustic_stage_end_fused(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                                         const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta,
@@ -2416,6 +2560,29 @@ extern "C" int bz_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s
     return bzi_acoustic_stage_end(ctx, s, U0, G, sub, dt, beta, update_moisture != 0, false);
 }
 
+// Which lateral sides of a Bounded x / y carry an active open boundary condition on the wall-normal momentum (is_active_open_bc,
+// acoustic_substepping.jl:1318): their outermost cells of rho', (rho theta)' are relaxed every substep with factor
+// open_boundary_relaxation in (0, 1] (SplitExplicitTimeDiscretization(open_boundary_relaxation = 0.5)), and their west / south wall face
+// is not zeroed; every other side of a Bounded direction is an impenetrable wall (the default).
+extern "C" int bz_set_acoustic_lateral_boundaries(bz_ctx *ctx, int west_open, int east_open, int south_open, int north_open,
+                                                  double open_boundary_relaxation)
+{
+    if (ctx) ++ctx->config_epoch;
+    BZ_REQUIRE_COMPRESSIBLE();
+    if (!(open_boundary_relaxation > 0.0) || open_boundary_relaxation > 1.0) {
+        ctx->last_error = "bz_set_acoustic_lateral_boundaries: open_boundary_relaxation must be in (0, 1]";
+        return BZ_ERR_INVALID;
+    }
+    const DevGrid &g = ctx->dg;
+    if (((west_open || east_open) && !g.bounded_x) || ((south_open || north_open) && !g.bounded_y)) {
+        ctx->last_error = "bz_set_acoustic_lateral_boundaries: an open side needs a Bounded topology in its direction";
+        return BZ_ERR_INVALID;
+    }
+    ctx->ac_open[0] = west_open != 0; ctx->ac_open[1] = east_open != 0; ctx->ac_open[2] = south_open != 0; ctx->ac_open[3] = north_open != 0;
+    ctx->ac_open_relax = open_boundary_relaxation;
+    return BZ_OK;
+}
+
 extern "C" int bz_set_acoustic_scratch(bz_ctx *ctx, double *momentum_u_second_buffer, double *momentum_v_second_buffer)
 {
     if (ctx) ++ctx->config_epoch;      // captured steps (bz_graph.hip) belong to one configuration
@@ -2430,6 +2597,7 @@ extern "C" int bz_compute_moisture_tendency(bz_ctx *ctx, const bz_compressible_s
                                             const bz_acoustic_substepper *sub)
 {
     BZ_REQUIRE_COMPRESSIBLE();
+    BZ_REJECT_WALLS("bz_compute_moisture_tendency");
     if (!valid_state(s) || !valid_prog(G) || !valid_sub(sub)) return BZ_ERR_INVALID;
     // (WENO order 5 kernels; the generic order 7 / 9 path evaluates the field whatever it holds)
     int rc = launch_scalar_rho3d(ctx, "moisture_tendency", G->rho_q, nullptr, s->rho, sub->time_averaged_u, sub->time_averaged_v,
@@ -2451,7 +2619,9 @@ extern "C" int bz_acoustic_substep_loop(bz_ctx *ctx, const bz_compressible_state
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
     if ((rc = require_no_slab(ctx, "bz_acoustic_substep_loop"))) return rc;
-    return bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, beta, false, true);
+    // Bounded x / y: the loop ends with _recover_full_state!; the halo fills with the model's boundary conditions and compute_velocities! that
+    // close the reference's function (acoustic_substepping.jl:1584-1587) are the caller's
+    return bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, beta, false, !ac_walls(ctx));
 }
 
 extern "C" int bz_acoustic_rk3_substep(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
@@ -2459,6 +2629,7 @@ extern "C" int bz_acoustic_rk3_substep(bz_ctx *ctx, const bz_compressible_state 
                                        double beta)
 {
     BZ_REQUIRE_COMPRESSIBLE();
+    BZ_REJECT_WALLS("bz_acoustic_rk3_substep");
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
     if ((rc = require_no_slab(ctx, "bz_acoustic_rk3_substep"))) return rc;
@@ -2497,6 +2668,7 @@ extern "C" int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_stat
                                          const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt)
 {
     BZ_REQUIRE_COMPRESSIBLE();
+    BZ_REJECT_WALLS("bz_time_step_compressible");
     int rc = check_loop_args(ctx, s, U0, G, sub);
     if (rc) return rc;
     if ((rc = bzi_scan_moisture_field(ctx, s->rho_q))) return rc;      // dry models: the moisture tendency kernels write exact zeros without reading
@@ -2518,6 +2690,7 @@ static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, c
 {
     int rc;
     const DevGrid &g = ctx->dg;
+    BZ_REJECT_WALLS("bz_time_step_compressible");
     // round 4: on single-device contexts the stage epilogue is one pass (k_ac_stage_end) and store_initial_state! rides on the first
     // stage's initialisation kernel (the state IS U0 there); BZ_NO_AC_END_FUSE=1 restores the separate passes
     const bool fuse_end = stage_end_fusable(ctx);

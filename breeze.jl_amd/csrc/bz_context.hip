@@ -233,9 +233,15 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     const bool bounded_x = grid->topo[0] == BZ_BOUNDED;
     if ((grid->topo[0] != BZ_PERIODIC && !bounded_x) || (grid->topo[1] != BZ_PERIODIC && !flat_y && !bounded_y) || grid->topo[2] != BZ_BOUNDED)
         return BZ_ERR_UNSUPPORTED;
+    // compressible contexts with lateral walls ((Bounded | Periodic, Bounded | Periodic, Bounded), 3-D, single device): the acoustic substep
+    // loop with its wall / open-boundary enforcement (bz_compressible.hip: BZ_REJECT_WALLS lists what they do not run)
+    if (compressible && (bounded_x || bounded_y)) {
+        if (flat_y || slab_mode || weno_order == 2 || grid->Nx < 2 * grid->Hx || grid->Ny < 2 * grid->Hy) return BZ_ERR_UNSUPPORTED;
+    } else {
     if (bounded_x && (!flat_y || compressible || weno_order == 2 || (grid->Nx & 1) || grid->Nx < 2 * grid->Hx || grid->Nx > 4096)) return BZ_ERR_UNSUPPORTED;
-    if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode)) return BZ_ERR_UNSUPPORTED;
     if (bounded_y && (slab_mode || compressible || weno_order == 2 || grid->Ny < 2 * grid->Hy)) return BZ_ERR_UNSUPPORTED;
+    }
+    if (flat_y && (grid->Ny != 1 || grid->Hy != 0 || slab_mode)) return BZ_ERR_UNSUPPORTED;
     if (grid->Hx < 3 || (!flat_y && grid->Hy < 3) || grid->Hz < 3) return BZ_ERR_UNSUPPORTED;
     // Oceananigans: N >= H in every direction (k_halo_y's wrap copy would otherwise read a halo row that is not filled yet)
     if (grid->Nx < grid->Hx || grid->Ny < grid->Hy || grid->Nz < grid->Hz) return BZ_ERR_UNSUPPORTED;
@@ -368,7 +374,7 @@ int bzi_create(bz_ctx **out, const bz_grid *grid, const bz_constants *constants,
     // Flat y: the anelastic model steps with one kernel per reference kernel (bz_tendency.hip); the compressible kernels reach their
     // y neighbours through wrap offsets, which are zero when Ny = 1 (bz_compressible.hip: wrap_of), and keep their fused sequence
     if (flat_y) { if (!compressible) ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false; }
-    if (bounded_y) {      // per-operator entry points: one kernel per reference kernel, row-wise buffers (bz_tendency.hip); whole steps of the dry
+    if (bounded_y && !compressible) {      // per-operator entry points: one kernel per reference kernel, row-wise buffers (bz_tendency.hip); whole steps of the dry
         ctx->walls_lean_ok = ctx->fused_ok;      // model: the lean seam with its WY kernels (bz_step.hip)
         ctx->fused_ok = false; ctx->tend_gen = 1; ctx->tend_lds = false;
     }

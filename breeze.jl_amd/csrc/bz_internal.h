@@ -438,6 +438,8 @@ struct bz_ctx {
     bool ac_whole_step = false;       // set around bzi_acoustic_stage_begin by the whole-step seam (AcParams::dry_q)
     bool ac_skip_avg = false;         // set around bzi_acoustic_stage_begin by the whole-step seam for its stages 1 and 2 (AcParams::skip_avg_if_dry)
     bool ac_fused = true;             // horizontal step folded into the forward column sweep (BZ_NO_AC_FUSE=1 disables)
+    int ac_open[4] = {0, 0, 0, 0};    // west, east, south, north side of a Bounded x / y carries an active open boundary condition (bz_set_acoustic_lateral_boundaries)
+    double ac_open_relax = 0.5;       // SplitExplicitTimeDiscretization(open_boundary_relaxation)
     // DCMIP2016KesslerMicrophysics attached to the model (bz_set_kessler_microphysics)
     bz_kessler_microphysics kessler_params;
     bz_kessler_model_fields kessler;

@@ -119,10 +119,13 @@ class FluxBoundaryCondition:
 
 
 class FieldBoundaryConditions:
-    def __init__(self, bottom=None, top=None):
+    def __init__(self, bottom=None, top=None, west=None, east=None, south=None, north=None):
+        """bottom: the surface flux conditions of the anelastic model; west / east / south / north: NormalFlowBoundaryCondition on the
+        wall-normal momentum of a compressible model with a Bounded x / y (the open lateral boundaries of the acoustic substep loop)."""
         if top is not None:
             raise NotImplementedError("only bottom flux boundary conditions are implemented")
         self.bottom = bottom
+        self.west, self.east, self.south, self.north = west, east, south, north
 
 
 def _key(name):

@@ -440,6 +440,21 @@ int bz_acoustic_stage_end(bz_ctx *ctx, const bz_compressible_state *s, const bz_
  * call.  Single-GPU contexts damp inside bz_acoustic_substep; there, and without DirectDivergenceDamping, this is a no-op. */
 int bz_acoustic_direct_damping(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                                const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub);
+/* Lateral boundaries of the acoustic substep loop (acoustic_substepping.jl:1300-1395: apply_open_boundary_relaxation!,
+ * enforce_wall_impenetrability!), compressible contexts on a grid with a Bounded x and / or y — (Bounded, Periodic, Bounded),
+ * (Periodic, Bounded, Bounded), (Bounded, Bounded, Bounded); single device.  Such a context runs bz_refresh_linearization,
+ * bz_acoustic_substep_loop and the three-piece stage interface; every other compressible entry point returns BZ_ERR_UNSUPPORTED on it.
+ * The substepper's own fields take the zero-gradient halo of their default boundary conditions from the library; the model's fields
+ * (rho_d, rho_theta, p, the slow tendencies) are read with the one halo row / column the caller's boundary conditions filled.
+ * *_open != 0: that side carries an active open (normal-flow) boundary condition on the wall-normal momentum — the outermost cells of rho',
+ * (rho theta)' are relaxed every substep towards (c^L[halo] - c^L[cell]) / 2 with factor open_boundary_relaxation in (0, 1]
+ * (SplitExplicitTimeDiscretization(open_boundary_relaxation = 0.5)) and the west / south wall face of the momentum perturbation is advanced
+ * by the substep like any other face; 0 (the default of every side): an impenetrable wall, whose face is held at zero.  The east / north
+ * wall face (index N + 1 of the reference's face field) is written by no kernel of the reference's loop and is an exact zero here.
+ * bz_acoustic_substep_loop ends with _recover_full_state! on such a context: the halo fills with the model's boundary conditions and
+ * compute_velocities! (:1584-1587) are the caller's. */
+int bz_set_acoustic_lateral_boundaries(bz_ctx *ctx, int west_open, int east_open, int south_open, int north_open,
+                                       double open_boundary_relaxation);
 /* Caller-owned second buffers of the (rho u)', (rho v)' ping-pong (XFace / YFace parent arrays), so that the slab driver can
  * exchange their halos; NULL, NULL returns to the context's own scratch. */
 int bz_set_acoustic_scratch(bz_ctx *ctx, double *momentum_u_second_buffer, double *momentum_v_second_buffer);

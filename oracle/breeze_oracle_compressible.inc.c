@@ -494,6 +494,8 @@ void og_direct_divergence_damping(const og_grid *G, double *rup, double *rvp, do
                 delta[n] = (fx + fy) * Vinv;
             }
     og_fill_halo_periodic_xy(G, delta, G->Nz + 2 * G->Hz);
+    og_fill_halo_x_noflux(G, delta, G->Nz + 2 * G->Hz);      /* Bounded directions: the default (zero-gradient) condition of a centre field */
+    og_fill_halo_y_noflux(G, delta, G->Nz + 2 * G->Hz);
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < G->Nz; ++k)
         for (int j = 0; j < G->Ny; ++j)
@@ -504,6 +506,30 @@ void og_direct_divergence_damping(const og_grid *G, double *rup, double *rvp, do
                 if (G->ty != FLAT)
                     rvp[n] += alpha * (G->dy * G->dy) * ((delta[n] - delta[n - sy]) * (1.0 / G->dy)) / ((thL[n] + thL[n - sy]) / 2.0);
             }
+}
+
+/* _relax_open_boundary_x! (dir 0) / _relax_open_boundary_y! (dir 1) (acoustic_substepping.jl:1323-1337): cb = outermost interior cell
+ * (0-based: 0 or N - 1), ch = the adjacent halo cell (-1 or N) */
+void og_relax_open_boundary(const og_grid *G, double *rp, double *rthp, const double *rho_d, const double *rth,
+                            int dir, int cb, int ch, double alpha)
+{
+    int n1 = dir ? G->Nx : G->Ny;
+    for (int k = 0; k < G->Nz; ++k)
+        for (int t = 0; t < n1; ++t) {
+            size_t nb = dir ? IDX(G, t, cb, k) : IDX(G, cb, t, k);
+            size_t nh = dir ? IDX(G, t, ch, k) : IDX(G, ch, t, k);
+            rp[nb] += alpha * ((rho_d[nh] - rho_d[nb]) / 2.0 - rp[nb]);
+            rthp[nb] += alpha * ((rth[nh] - rth[nb]) / 2.0 - rthp[nb]);
+        }
+}
+
+/* _zero_x_wall_face! (dir 0) / _zero_y_wall_face! (dir 1) (acoustic_substepping.jl:1367-1375): face = 0 or N (0-based; the reference's 1, N + 1) */
+void og_zero_wall_face(const og_grid *G, double *f, int dir, int face)
+{
+    int n1 = dir ? G->Nx : G->Ny;
+    for (int k = 0; k < G->Nz; ++k)
+        for (int t = 0; t < n1; ++t)
+            f[dir ? IDX(G, t, face, k) : IDX(G, face, t, k)] = 0.0;
 }
 
 /* _finalize_time_averaged_velocity! (acoustic_substepping.jl:1225-1250) */

@@ -232,6 +232,10 @@ class CompressibleOracleModel:
         self.Gs, self.rhs = zf(), zf()
         self.iteration, self.clock_time = 0, 0.0
         self.last_substeps = []
+        # sides of a Bounded x / y with an active open (normal-flow) condition on the wall-normal momentum; SplitExplicitTimeDiscretization(
+        # open_boundary_relaxation = 0.5) (time_discretizations.jl:562)
+        self.lateral_open = dict(west=False, east=False, south=False, north=False)
+        self.open_boundary_relaxation = 0.5
         # seed_pressure! (compressible_dynamics.jl:254-258)
         if self.ref is not None:
             g.interior(self.p)[...] = self.ref.pressure[g.Hz:g.Hz + g.Nz][:, None, None]
@@ -243,6 +247,50 @@ class CompressibleOracleModel:
     def _halo_center(self, f):
         self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
         self.lib.og_fill_halo_z_noflux(C.byref(self.cg), _p(f))
+
+    # -- lateral walls / open boundaries (round 6): the substepper's own fields carry the default boundary conditions of their location
+    # (acoustic_substepping.jl:207-231; the reference's test/acoustic_substepping_open_boundaries.jl:70-73 pins `west === nothing` on the
+    # momentum perturbation): zero-gradient halo along a Bounded direction for a field that is a centre there, wall faces untouched
+    def _halo_sub(self, f, xface=False, yface=False):
+        self._halo_center(f)      # periodic directions and z (y-slab tests replace this method by their exchange)
+        n = C.c_int(f.shape[0])
+        cg = C.byref(self.cg)
+        if self.grid.topo[0] == BOUNDED and not xface:
+            self.lib.og_fill_halo_x_noflux(cg, _p(f), n)
+        if self.grid.topo[1] == BOUNDED and not yface:
+            self.lib.og_fill_halo_y_noflux(cg, _p(f), n)
+
+    def _walls(self):
+        return BOUNDED in (self.grid.topo[0], self.grid.topo[1])
+
+    def enforce_wall_impenetrability(self):
+        """enforce_wall_impenetrability! (acoustic_substepping.jl:1378-1395): the wall-normal momentum perturbation on the two wall faces of
+        a Bounded direction whose momentum boundary condition is the default (impenetrable) one; self.lateral_open names the sides that
+        carry an active open boundary condition instead"""
+        g, cg, op = self.grid, C.byref(self.cg), self.lateral_open
+        if g.topo[0] == BOUNDED:
+            if not op["west"]:
+                self.lib.og_zero_wall_face(cg, _p(self.rup), C.c_int(0), C.c_int(0))
+            if not op["east"]:
+                self.lib.og_zero_wall_face(cg, _p(self.rup), C.c_int(0), C.c_int(g.Nx))
+        if g.topo[1] == BOUNDED:
+            if not op["south"]:
+                self.lib.og_zero_wall_face(cg, _p(self.rvp), C.c_int(1), C.c_int(0))
+            if not op["north"]:
+                self.lib.og_zero_wall_face(cg, _p(self.rvp), C.c_int(1), C.c_int(g.Ny))
+
+    def apply_open_boundary_relaxation(self):
+        """apply_open_boundary_relaxation! (acoustic_substepping.jl:1339-1361)"""
+        g, cg, op, a = self.grid, C.byref(self.cg), self.lateral_open, C.c_double(self.open_boundary_relaxation)
+        args = (_p(self.rp), _p(self.rthp), _p(self.rho_d), _p(self.rtheta))
+        if g.topo[0] == BOUNDED and op["west"]:
+            self.lib.og_relax_open_boundary(cg, *args, C.c_int(0), C.c_int(0), C.c_int(-1), a)
+        if g.topo[0] == BOUNDED and op["east"]:
+            self.lib.og_relax_open_boundary(cg, *args, C.c_int(0), C.c_int(g.Nx - 1), C.c_int(g.Nx), a)
+        if g.topo[1] == BOUNDED and op["south"]:
+            self.lib.og_relax_open_boundary(cg, *args, C.c_int(1), C.c_int(0), C.c_int(-1), a)
+        if g.topo[1] == BOUNDED and op["north"]:
+            self.lib.og_relax_open_boundary(cg, *args, C.c_int(1), C.c_int(g.Ny - 1), C.c_int(g.Ny), a)
 
     def _halo_w(self, f):
         self.lib.og_fill_halo_periodic_xy(C.byref(self.cg), _p(f), C.c_int(f.shape[0]))
@@ -411,7 +459,7 @@ class CompressibleOracleModel:
             cpm = qd * c.cpd + qv * c.cpv + ql * tc.cl + 0.0 * 0.0
             I(self.gR)[...] = cpm * Rm / (cpm - Rm)
         for f in (self.Pi, self.thL, self.gR):
-            self._halo_center(f)
+            self._halo_sub(f)       # fill_halo_regions! with the default conditions (acoustic_substepping.jl:365-367): zero gradient on Bounded x / y
 
     def seed_time_averaged_velocities(self):
         self.au[...] = self.u
@@ -473,8 +521,10 @@ class CompressibleOracleModel:
         for prime, name, nk in ((self.rp, "rho_d", Nz), (self.rthp, "rtheta", Nz), (self.rup, "ru", Nz),
                                 (self.rvp, "rv", Nz), (self.rwp, "rw", Nz)):
             L.og_initialize_perturbation(cg, _p(prime), _p(self.U0[name]), _p(getattr(self, name)), C.c_int(nk))
-        for f in (self.rp, self.rthp, self.rup, self.rvp):
-            self._halo_center(f)
+        for f in (self.rp, self.rthp):
+            self._halo_sub(f)
+        self._halo_sub(self.rup, xface=True)
+        self._halo_sub(self.rvp, yface=True)
         self._halo_w(self.rwp)
         d_new, d_old = self.implicit_damping_factors()
         sponge = None
@@ -487,13 +537,14 @@ class CompressibleOracleModel:
             L.og_explicit_horizontal_step(cg, _p(self.rup), _p(self.rvp), _p(self.p), _p(self.rthp), _p(self.Pi),
                                           _p(self.gR), _p(self.G["ru"]), _p(self.G["rv"]), C.c_double(dtau),
                                           C.c_int(int(gate)))
-            self._halo_center(self.rup)
-            self._halo_center(self.rvp)
+            self._halo_sub(self.rup, xface=True)
+            self._halo_sub(self.rvp, yface=True)
+            self.enforce_wall_impenetrability()
             L.og_build_predictors(cg, _p(self.rs), _p(self.rths), _p(self.rth_old), _p(self.rp), _p(self.rthp),
                                   _p(self.rwp), _p(self.rup), _p(self.rvp), _p(self.G["rho_d"]),
                                   _p(self.G["rtheta"]), _p(self.thL), C.c_double(dtau), C.c_double(dto),
                                   C.c_double(td.f_theta))
-            self._halo_center(self.rth_old)
+            self._halo_sub(self.rth_old)
             L.og_build_vertical_rhs(cg, _p(self.rhs), _p(self.rs), _p(self.rths), _p(self.rp), _p(self.rthp),
                                     _p(self.rwp), _p(self.Pi), _p(self.gR), _p(self.Gs), C.c_double(dtau),
                                     C.c_double(dtn), C.c_double(dto), C.c_double(d_old), C.c_double(td.f_w), sponge)
@@ -502,8 +553,9 @@ class CompressibleOracleModel:
             L.og_post_solve_recovery(cg, _p(self.rp), _p(self.rthp), _p(self.rwp), _p(self.rup), _p(self.rvp),
                                      _p(self.rs), _p(self.rths), _p(self.au), _p(self.av), _p(self.aw),
                                      _p(self.thL), C.c_double(dtn))
-            self._halo_center(self.rp)
-            self._halo_center(self.rthp)
+            self.apply_open_boundary_relaxation()
+            self._halo_sub(self.rp)
+            self._halo_sub(self.rthp)
             if td.damping_coefficient is not None and getattr(td, "direct_damping", False):
                 # DirectDivergenceDamping: delta lives in the density predictor, free between recovery and the next build
                 L.og_direct_divergence_damping(cg, _p(self.rup), _p(self.rvp), _p(self.rs), _p(self.thL),
@@ -512,8 +564,9 @@ class CompressibleOracleModel:
                 L.og_thermal_divergence_damping(cg, _p(self.rup), _p(self.rvp), _p(self.rthp), _p(self.rth_old),
                                                 _p(self.thL), C.c_double(td.damping_coefficient), C.c_double(dtau),
                                                 C.c_double(getattr(td, "damping_length_scale", None) or 0.0))
-            self._halo_center(self.rup)
-            self._halo_center(self.rvp)
+            self._halo_sub(self.rup, xface=True)
+            self._halo_sub(self.rvp, yface=True)
+            self.enforce_wall_impenetrability()
         L.og_finalize_time_averaged_velocity(cg, _p(self.au), _p(self.av), _p(self.aw), _p(self.ru), _p(self.rv),
                                              _p(self.rw), _p(self.rho_d), C.c_double(1.0 / float(n_tau)))
         self._halo_center(self.au)
@@ -521,6 +574,8 @@ class CompressibleOracleModel:
         self._halo_w(self.aw)
         L.og_recover_full_state(cg, _p(self.rho_d), _p(self.rtheta), _p(self.ru), _p(self.rv), _p(self.rw),
                                 _p(self.rp), _p(self.rthp), _p(self.rup), _p(self.rvp), _p(self.rwp))
+        if self._walls():      # the fills with the model's boundary conditions and compute_velocities! are the caller's (as for the library)
+            return
         for f in (self.rho_d, self.rtheta, self.ru, self.rv):
             self._halo_center(f)
         self._halo_w(self.rw)

@@ -348,6 +348,19 @@ function create_compressible_context(model)
                    (Ref{Ptr{Cvoid}}, Ref{BzGrid}, Ref{BzConstants}, Ref{BzExnerReference}, Ref{BzSplitExplicit}, Cint), ctx, g, k, r, td, 5)
         rc == 0 || error("bz_create_compressible failed with code $rc")
     end
+    # Bounded x / y: which sides carry an active open boundary condition on the wall-normal momentum (is_active_open_bc,
+    # src/CompressibleEquations/acoustic_substepping.jl:1318) and the relaxation factor of the substepper; the loop seam below then enforces the
+    # lateral boundaries itself (_zero_{x,y}_wall_face!, _relax_open_boundary_{x,y}!, :1323-1395).  On such a grid only the loop seam is forwarded:
+    # the fills with the model's boundary conditions and compute_velocities! after _recover_full_state! (:1584-1587) stay on the Julia side.
+    TX, TY, _ = topology(grid)
+    if TX === Bounded || TY === Bounded
+        bu, bv = model.momentum.ρu.boundary_conditions, model.momentum.ρv.boundary_conditions
+        active(bc) = (bc isa BoundaryCondition{<:NormalFlow}) && !(bc.condition isa Nothing)
+        rc = ccall((:bz_set_acoustic_lateral_boundaries, libbreeze_hip), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cdouble), ctx[],
+                   TX === Bounded && active(bu.west), TX === Bounded && active(bu.east), TY === Bounded && active(bv.south),
+                   TY === Bounded && active(bv.north), a.open_boundary_relaxation)
+        check(rc, "bz_set_acoustic_lateral_boundaries", ctx[])
+    end
     return ctx[]
 end
 ccontext(model) = get!(() -> create_compressible_context(model), CONTEXTS, model)

@@ -199,7 +199,7 @@ KERNEL_GROUPS = [
     (r"^k_ac_stage_end<\w+, false", "acoustic_stage_end+update_state"), (r"^k_ac_recover_density<", "acoustic_recover_density"),
     (r"^k_ac_finalize<", "acoustic_finalize"), (r"^k_ac_recover<", "acoustic_recover"),
     (r"^k_cmp_diagnose<true, true", "update_state+linearization"), (r"^k_cmp_diagnose<true, false", "update_state"),
-    (r"^k_cmp_linearization", "refresh_linearization"), (r"^k_scalar_tendency_rho3d", "density+potential_temperature_tendency | moisture_tendency"),
+    (r"^k_cmp_linearization", "refresh_linearization"), (r"^k_scalar_(tendency_rho3d|rho3d_lds)", "density+potential_temperature_tendency | moisture_tendency"),
     (r"^k_u_tend_lds<", "x_momentum_tendency"), (r"^k_v_tend_lds<", "y_momentum_tendency"), (r"^k_w_tend_lds<", "z_momentum_tendency"),
     (r"^k_scalar_pair_lds<", "scalar_tendencies+rk3"),
     # generic WENO 7 / 9 kernels of the fused-RK tier (bz_tendency_generic.hip): the one-pass marching kernel k_tendency_m<R, KIND, ..>

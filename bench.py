@@ -176,9 +176,10 @@ def compressible_milestone(bz, device, steps=2, substep_float32=False):
         per_sub = sub_ms / sum(nsub)
         kernels = kernel_table(prof)
         # the substep pair (forward sweep with the horizontal step + backward sweep) priced in compulsory words (tools/accounting.py:
-        # acoustic_substep_words — 22 + 10, less the accumulators a dry stage 1 / 2 skips; the reference's unfused kernel list moves 58
-        # contract words per substep); with substep_floattype = Float32 the working-field words are 4 bytes
-        wf, wb = acoustic_substep_words(nsub, dry)
+        # acoustic_substep_words — 22 + 10, less the accumulators a dry stage 1 / 2 skips and the <u>, <v> words of the substeps that leave
+        # them to their pair's second substep; the reference's unfused kernel list moves 58 contract words per substep); with
+        # substep_floattype = Float32 the working-field words are 4 bytes and every substep accumulates
+        wf, wb = acoustic_substep_words(nsub, dry, pair_avg=not substep_float32)
         fwd = kernels.get("acoustic_horizontal+column_forward", {}).get("avg_ms", 0.0)
         t_f, src_f = load_traffic(ROOT, "acoustic_horizontal+column_forward")
         t_b, _ = load_traffic(ROOT, "acoustic_column_backward")
@@ -201,7 +202,7 @@ def compressible_milestone(bz, device, steps=2, substep_float32=False):
     out = {"metric": "grid-cells advanced/sec, compressible split-explicit WS-RK3 step", "grid": [Nx, Ny, Nz], "dt": 1.0, "substeps_per_stage": nsub,
            "dry_path": dry, **r,
            "roofline": roofline_block("acoustic_horizontal+column_forward", kernels["acoustic_horizontal+column_forward"]["avg_ms"], cells, 8,
-                                      words=acoustic_substep_words(nsub, dry)[0]) if not substep_float32 else None,
+                                      words=acoustic_substep_words(nsub, dry, pair_avg=not substep_float32)[0]) if not substep_float32 else None,
            "finite": bool(torch.isfinite(m.velocities["w"].interior).all().item())}
     # like for like: the same model with vapour set (moisture tendency evaluated, every stage accumulates the time-averaged velocities)
     try:

@@ -645,6 +645,14 @@ struct AcParams {
     // reference's face field) is written by no kernel of the reference's loop — all of them are launched over :xyz — and keeps the zero the
     // field was built with: here it is an exact zero in every flux that reads it, whatever the boundary condition.
     int wall_w, wall_s;
+    // Round 6: <u>, <v> accumulated two substeps at a time (k_ac_forward2).  The forward sweep of substep n reads the stored (rho u)' of
+    // substep n - 1 anyway (it advances it), so a pair (n - 1, n) is added in substep n as  a += (u'_{n-1} + u'_n)  and substep n - 1 neither
+    // reads nor writes the accumulators: 4 of a sweep's 22 words in every other substep.  0: a += u'_n (the reference's order); 1: this substep
+    // leaves the accumulators alone (the next one takes the pair); 2: this substep adds the pair.  The sum differs from the reference's
+    // ((a + u'_{n-1}) + u'_n) by one rounding of a per pair.  Thermal or no damping only (the stored u'_{n-1} is then the accumulated value:
+    // its damping is applied by the sweep that reads it; DirectDivergenceDamping changes the stored field after the accumulation), working
+    // fields in the grid's type (a Float32-stored u' is the rounded value of what was accumulated).
+    int acc_mode;
 };
 // _zero_x_wall_face! / _zero_y_wall_face! (acoustic_substepping.jl:1367-1375) as a mask on the four faces a column's predictor reads: the
 // reference zeroes the plane after the horizontal step and again after the damping; nothing reads the face between the kernel that writes it and
@@ -1202,7 +1210,7 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
             L.p_ym = ac_ld(F.p, eym); L.p_yp = ac_ld(F.p, eyp);
         }
         L.au_o = 0.0; L.av_o = 0.0;
-        if (!FIRST && acc) { L.au_o = ac_ld_nt(F.au, e); L.av_o = ac_ld_nt(F.av, e); }
+        if (!FIRST && acc && P.acc_mode != 1) { L.au_o = ac_ld_nt(F.au, e); L.av_o = ac_ld_nt(F.av, e); }
         L.Grho = ac_ld_nt(F.G_rho_d, e); L.Grth = ac_ld_nt(F.G_rth, e); L.Gs_k = ac_ld_nt(F.Gs, e);
         L.e_th = 0.0; L.e_C = 0.0; L.e_rt = 0.0; L.e_o = 0.0;
         if (edge) {
@@ -1244,7 +1252,8 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
         const double up1 = ac_face_update2<DAMP, PF>(ru1, Gu1, rt_xp, rthp, o_xp, o0, thxp, th_0, c_xp, C_0, p_xp, p0, g.rdx, P);
         const double vp0 = ac_face_update2<DAMP, PF>(rv0, Gv0, rthp, rt_ym, o0, o_ym, th_0, thym, C_0, c_ym, p0, p_ym, g.rdy, P);
         const double vp1 = ac_face_update2<DAMP, PF>(rv1, Gv1, rt_yp, rthp, o_yp, o0, thyp, th_0, c_yp, C_0, p_yp, p0, g.rdy, P);
-        const double au_n = FIRST ? 0.0 + up0 : au_o + up0, av_n = FIRST ? 0.0 + vp0 : av_o + vp0;
+        const double au_n = FIRST ? 0.0 + up0 : (P.acc_mode == 2) ? au_o + (ru0 + up0) : au_o + up0;
+        const double av_n = FIRST ? 0.0 + vp0 : (P.acc_mode == 2) ? av_o + (rv0 + vp0) : av_o + vp0;
         // theta face k+1 (top face: one-sided)
         const double thf_p = (k + 1 < Nz) ? (th_p + th_0) / 2.0 : th_0;
 
@@ -1284,7 +1293,7 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
         if (INIT) ac_st(F.rthp, e, rthp);      // the initial (rho theta)': the next substep's damping and the stage epilogue read it
         ac_st_nt(F.rup, e, up0);
         ac_st_nt(F.rvp, e, vp0);
-        if (acc) {
+        if (acc && (FIRST || P.acc_mode != 1)) {
             ac_st_nt(F.au, e, au_n);
             ac_st_nt(F.av, e, av_n);
         }
@@ -2202,6 +2211,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     P.dry_q = nullptr;
     P.wall_w = ctx->ac_open[0] ? 0 : 1;
     P.wall_s = ctx->ac_open[2] ? 0 : 1;
+    P.acc_mode = 0;
     S.ntau = ntau;
     S.done = 0;
     S.fused = ctx->ac_fused;
@@ -2325,6 +2335,10 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
                 const int fx = ctx->tune.ac_bx == 512 && bt == 512 ? 512 : ctx->tune.ac_bx == 256 ? 256 : ctx->tune.ac_bx == 128 ? 128 : 64, fy = bt / fx;
                 dim3 cols2((g.Nx + fx - 1) / fx, (g.Ny + fy - 1) / fy), bcol2(fx, fy);
                 P.xcd = (ctx->tune.ac_xcd && cols2.y % 8 == 0) ? 1 : 0;
+                // <u>, <v> in pairs counted from the stage's last substep (AcParams::acc_mode): substep 1 starts the accumulators, an odd
+                // substep out (substep 2) is added alone
+                if (ctx->tune.ac_pair_avg && !S.direct && !ctx->substep_f32 && !ctx->slab_mode && sstep >= 2)
+                    P.acc_mode = ((ntau - sstep) & 1) ? 1 : (sstep >= 3 ? 2 : 0);
                 launch_forward2(ctx, Fs, P, cols2, bcol2, sstep == 1, damp, S.pfold, cfg, S.init_mode);
             }
             else if (sstep == 1)

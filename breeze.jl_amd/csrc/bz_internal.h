@@ -309,6 +309,7 @@ struct bz_tuning {
     bool no_fold_forcing = false;     // BZ_NO_FOLD_FORCING: the fused-RK tier keeps the momentum terms of the forcing stack in the forcing pass
     int ac_xcd = 1;                   // BZ_AC_XCD=0: the forward acoustic sweep in launch order (XCD = tile column) instead of XCD = band of tile rows
     int ac_forward2 = 1;              // BZ_AC_FWD2=0: the round-5 forward acoustic sweep (k_ac_column_forward) instead of k_ac_forward2
+    int ac_pair_avg = 1;              // BZ_AC_PAIR_AVG=0: <u>, <v> accumulated in every substep instead of two substeps at a time (AcParams::acc_mode)
     int ac_init_fold = 1;             // BZ_AC_INIT_FOLD=0: k_ac_stage_init stores the stage's initial perturbations and the first sweeps read them back
     int ac_pfold = 1;                 // BZ_AC_PFOLD=0: the horizontal gradient of p^L stays in every substep instead of folded into the stage's slow tendencies
     int ac_bx = 128;                  // BZ_AC_BX: columns of a k_ac_forward2 block along x (64, 128, 256, 512; rows = threads / columns)

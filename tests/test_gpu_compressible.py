@@ -477,6 +477,42 @@ def test_dry_steps_skip_the_unread_time_averages_bitwise(oracle, oc, bz, size, m
     assert np.abs(got - want).max() / np.abs(want).max() < 5e-9
 
 
+@pytest.mark.parametrize("substeps", [6, 5, 2])
+def test_time_averages_accumulated_in_pairs_of_substeps(oracle, oc, bz, substeps, monkeypatch):
+    """Round 6 (AcParams::acc_mode): the forward sweep adds <u>, <v> two substeps at a time — a += (u'_{n-1} + u'_n) in the second substep of a
+    pair, the first one leaves the accumulators alone — with the pairs counted from the stage's last substep (N_tau = 2, 3, 6 / 2, 3, 5 / 1, 1, 2:
+    an odd substep out, stages that are one pair, one-substep stages).  Against the substep-by-substep accumulation (BZ_AC_PAIR_AVG=0): the
+    averages differ by roundings of the accumulator (1e-14 of max-abs), a moist run's state after three steps by what the moisture tendency
+    makes of that (1e-13); the oracle comparison of the default build is test_time_steps_match_oracle."""
+    out = {}
+    for pair in (1, 0):
+        monkeypatch.setenv("BZ_AC_PAIR_AVG", str(pair))
+        om, hm = make_pair(oracle, oc, bz, size=(64, 16, 24), substeps=substeps)
+        g = om.grid
+
+        def theta(x, y, z):
+            r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+            return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+        qv = lambda x, y, z: 5e-3 * np.exp(-z / 2e3) * (1 + 0.2 * np.sin(2 * np.pi * x / 8e3)) + 0 * y      # noqa: E731
+        rho = om.ref.density[g.Hz:g.Hz + g.Nz][:, None, None]
+        hm.set(ρ=rho, θ=theta, u=lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z, v=-1.0, w=0.0, qᵗ=qv)
+        for _ in range(3):
+            hm.time_step(0.5)      # 64-cell rows are 125 m wide
+        hm.synchronize()
+        sub = hm.timestepper.substepper
+        out[pair] = {**{k: f.interior_cpu().copy() for k, f in hm.prognostic_fields().items()},
+                     **{n: getattr(sub, n).interior_cpu().copy() for n in ("time_averaged_u", "time_averaged_v", "time_averaged_w")}}
+    a, b = out[1], out[0]
+    assert np.array_equal(a["time_averaged_w"], b["time_averaged_w"]) or rel(a["time_averaged_w"], b["time_averaged_w"]) <= 1e-13
+    for k in ("time_averaged_u", "time_averaged_v"):
+        assert rel(a[k], b[k]) <= 1e-14, (k, rel(a[k], b[k]))
+    for k in hm.prognostic_fields():
+        assert rel(a[k], b[k]) <= 1e-13, (k, rel(a[k], b[k]))
+    assert np.abs(a["ρq"]).max() > 0 and all(np.isfinite(v).all() for v in a.values())
+
+
+
 @pytest.mark.parametrize("storage", [None, "float32"])
 @pytest.mark.parametrize("size,td", [((64, 16, 12), dict(substeps=6)), ((40, 12, 9), dict(substeps=4, damping_coefficient=0.05, damp_vertical=True)),
                                      ((128, 32, 10), dict(substeps=1))])

@@ -106,13 +106,16 @@ COMPULSORY_WORDS_DRY = {
 ACOUSTIC_SUBSTEP_COMPULSORY_WORDS = 32                 # forward 22 + backward 10 (fused substep, thermal divergence damping, p^L gradient folded)
 
 
-def acoustic_substep_words(nsub, dry, fold_min=5):
+def acoustic_substep_words(nsub, dry, fold_min=5, pair_avg=True):
     """Mean compulsory words per cell of the forward and the backward sweep over the substeps of one step, from the substep counts of the
     three stages.  A stage of fewer than fold_min substeps keeps p^L in the substep (+1 word, bz_compressible.hip: AcStage::pfold); in a
     DRY whole step (rho q identically zero, found by the opening scan) stages 1 and 2 carry no time-average accumulators: the forward sweep
-    neither reads nor writes <u>, <v> (-4 words), the backward sweep <w> (-2) (AcParams::skip_avg_if_dry)."""
+    neither reads nor writes <u>, <v> (-4 words), the backward sweep <w> (-2) (AcParams::skip_avg_if_dry).  pair_avg: in a stage that does
+    accumulate, <u>, <v> are added two substeps at a time (AcParams::acc_mode): of the substeps 2 .. N, floor((N - 1) / 2) leave the
+    accumulators alone (-4 words each)."""
     tot = float(sum(nsub))
-    fwd = sum(n * ((22 if n >= fold_min else 23) - (4 if (dry and s < 2) else 0)) for s, n in enumerate(nsub)) / tot
+    fwd = sum(n * ((22 if n >= fold_min else 23) - (4 if (dry and s < 2) else 0)) - (0 if (dry and s < 2) or not pair_avg else 4 * ((n - 1) // 2))
+              for s, n in enumerate(nsub)) / tot
     bwd = sum(n * (10 - (2 if (dry and s < 2) else 0)) for s, n in enumerate(nsub)) / tot
     return fwd, bwd
 

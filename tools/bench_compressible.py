@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--kessler", action="store_true",
                     help="BASELINE configs[4] physics: DCMIP2016 Kessler on the 168 km x 168 km x 20 km supercell box "
                          "(examples/splitting_supercell.jl:88-96), moist sounding + warm bubble")
+    ap.add_argument("--moist", action="store_true", help="vapour set in the benchmark bubble (every stage accumulates, moisture tendency evaluated)")
     a = ap.parse_args()
     import torch
     import breeze_jl_amd as bz
@@ -76,7 +77,7 @@ def main():
         qv = lambda x, y, z: 0.014 * np.exp(-z / 2500.0) + 0 * x + 0 * y
         m.set(ρ=rho, θ=theta, u=lambda x, y, z: 0.0015 * np.minimum(z, 5e3) + 0 * x + 0 * y, v=0.0, w=0.0, qᵗ=qv)
     else:
-        m.set(ρ=rho, θ=theta, u=0.0, v=0.0, w=0.0, qᵗ=0.0)
+        m.set(ρ=rho, θ=theta, u=0.0, v=0.0, w=0.0, qᵗ=(lambda x, y, z: 4e-3 * np.exp(-z / 2500.0) + 0 * x + 0 * y) if a.moist else 0.0)
     for _ in range(a.warmup):
         m.time_step(a.dt)
     m.synchronize()

@@ -269,3 +269,20 @@ def test_wall_contexts_run_the_acoustic_loop_only(oracle, oc, bz):
     for fn in (bz.compressible.update_state_, bz.compressible.compute_slow_tendencies_):
         with pytest.raises(Exception, match="Bounded x or y"):
             fn(hm)
+
+
+@pytest.mark.gpu
+def test_lateral_boundary_setter_validates_its_arguments(oracle, oc, bz):
+    """bz_set_acoustic_lateral_boundaries: the factor must lie in (0, 1] (time_discretizations.jl:573-574) and an open side needs a Bounded
+    topology in its direction; a periodic context refuses any open side."""
+    om = oracle_model(oracle, oc, TOPOLOGIES[1])
+    hm = hip_model(bz, om, TOPOLOGIES[1])
+    f = hm._lib.bz_set_acoustic_lateral_boundaries
+    assert f(hm._ctx, 0, 0, 1, 1, 0.5) == 0
+    for alpha in (0.0, -0.1, 1.5):
+        assert f(hm._ctx, 0, 0, 1, 0, alpha) != 0
+    assert f(hm._ctx, 1, 0, 0, 0, 0.5) != 0          # west of a Periodic x
+    from tests.test_gpu_compressible import make_pair
+    _, pm = make_pair(oracle, oc, bz, size=(16, 8, 8))
+    assert pm._lib.bz_set_acoustic_lateral_boundaries(pm._ctx, 0, 0, 0, 1, 0.5) != 0
+    assert pm._lib.bz_set_acoustic_lateral_boundaries(pm._ctx, 0, 0, 0, 0, 0.5) == 0

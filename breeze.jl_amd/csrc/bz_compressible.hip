@@ -1362,10 +1362,14 @@ __global__ __launch_bounds__(ABX * ABY) void k_ac_column_backward(DevGrid g, AcF
         const double dzT = (thf_hi * w_hi - thf_lo * w_lo) * rdc;
         F.rp[n] = F.rs[n] - P.dtn * dzW;
         F.rthp_out[n] = F.rths[n] - P.dtn * dzT;
+        // <w> two substeps at a time (AcParams::acc_mode): the second substep of a pair adds (w'_{n-1} + w'_n) with w'_{n-1} read from the field
+        // it is about to overwrite (one word instead of the accumulator's two in the pair's first substep)
+        const double w_old = (!FIRST && acc && P.acc_mode == 2) ? F.rwp[n] : 0.0;
         F.rwp[n] = w_lo;
         if (acc) {
             if (FIRST) F.aw[n] = 0.0 + w_lo;
-            else F.aw[n] += w_lo;
+            else if (P.acc_mode == 2) F.aw[n] += (w_old + w_lo);
+            else if (P.acc_mode == 0) F.aw[n] += w_lo;
         }
         t_hi = F.tfac[n];
         w_hi = w_lo;

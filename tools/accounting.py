@@ -116,7 +116,8 @@ def acoustic_substep_words(nsub, dry, fold_min=5, pair_avg=True):
     tot = float(sum(nsub))
     fwd = sum(n * ((22 if n >= fold_min else 23) - (4 if (dry and s < 2) else 0)) - (0 if (dry and s < 2) or not pair_avg else 4 * ((n - 1) // 2))
               for s, n in enumerate(nsub)) / tot
-    bwd = sum(n * (10 - (2 if (dry and s < 2) else 0)) for s, n in enumerate(nsub)) / tot
+    # <w> in the backward sweep: a pair's first substep leaves the accumulator alone (-2), its second reads the (rho w)' it overwrites (+1)
+    bwd = sum(n * (10 - (2 if (dry and s < 2) else 0)) - (0 if (dry and s < 2) or not pair_avg else (n - 1) // 2) for s, n in enumerate(nsub)) / tot
     return fwd, bwd
 
 

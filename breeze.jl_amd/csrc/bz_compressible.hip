@@ -653,6 +653,10 @@ struct AcParams {
     // its damping is applied by the sweep that reads it; DirectDivergenceDamping changes the stored field after the accumulation), working
     // fields in the grid's type (a Float32-stored u' is the rounded value of what was accumulated).
     int acc_mode;
+    // Round 6: the stage epilogue writes the recovered state into ANOTHER set of arrays than it reads (compressible_step_body: buffer rotation
+    // — the state arrays stay intact as U0, nothing is copied into U0): rho_d goes out with the other fields (no thread reads the output set)
+    // and rho q is stored also on the dry path (the output set may hold anything)
+    int out_of_place;
 };
 // _zero_x_wall_face! / _zero_y_wall_face! (acoustic_substepping.jl:1367-1375) as a mask on the four faces a column's predictor reads: the
 // reference zeroes the plane after the horizontal step and again after the damping; nothing reads the face between the kernel that writes it and
@@ -1533,6 +1537,7 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
     const double rdx = (rd + (r_mx + F.rp[mx])) / 2.0;
     const double rdy = (rd + (r_my + F.rp[my])) / 2.0;
     const double u = ru / rdx, v = rv / rdy;
+    if (P.out_of_place) cst_img(D.rho_d, n, rd, ox, oy);
     cst_img(D.rth, n, rth, ox, oy);
     cst_img(D.ru, n, ru, ox, oy);
     cst_img(D.rv, n, rv, ox, oy);
@@ -1593,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
             cst_img(g.qr_field, n, qr_v, ox, oy);
             cst_img(g.qv_field, n, q, ox, oy);
         }
-        if (!dryq) cst_img(D.rq, n, rq, ox, oy);
+        if (!dryq || P.out_of_place) cst_img(D.rq, n, rq, ox, oy);
         cst_img(D.rho, n, r, ox, oy);
         cst_img(D.theta, n, th, ox, oy);
         if (!dryq) cst_img(D.q, n, q, ox, oy);
@@ -1611,12 +1616,13 @@ __global__ __launch_bounds__(256) void k_ac_stage_end(DevGrid g, AcFieldsT<ST> F
     }
     if (bot || top) {     // first z-halo cell of the no-flux centre fields (rho_d: k_ac_recover_density)
         const long long h = bot ? -sz : sz;
+        if (P.out_of_place) cst_img(D.rho_d, n + h, rd, ox, oy);
         cst_img(D.ru, n + h, ru, ox, oy);
         cst_img(D.rv, n + h, rv, ox, oy);
         cst_img(D.rth, n + h, rth, ox, oy);
         cst_img(D.u, n + h, u, ox, oy);
         cst_img(D.v, n + h, v, ox, oy);
-        if (!dryq) cst_img(D.rq, n + h, rq, ox, oy);
+        if (!dryq || P.out_of_place) cst_img(D.rq, n + h, rq, ox, oy);
         cst_img(D.rho, n + h, r, ox, oy);
         cst_img(D.theta, n + h, th, ox, oy);
         if (!dryq) cst_img(D.q, n + h, q, ox, oy);
@@ -2216,6 +2222,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     P.wall_w = ctx->ac_open[0] ? 0 : 1;
     P.wall_s = ctx->ac_open[2] ? 0 : 1;
     P.acc_mode = 0;
+    P.out_of_place = 0;
     S.ntau = ntau;
     S.done = 0;
     S.fused = ctx->ac_fused;
@@ -2237,15 +2244,18 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     S.pfold = S.fwd2 && ctx->d_Gp_ru && !ctx->slab_mode && (ntau >= 5 || ctx->tune.ac_pfold > 1);
     // the stage's first sweeps form its initial perturbations themselves (default variant of k_ac_forward2 on a single device)
     S.init_mode = (S.fwd2 && !ctx->slab_mode && ctx->tune.ac_init_fold && forward2_cfg(ctx) == 29) ? (store0 ? 2 : 1) : 0;
+    // buffer rotation (compressible_step_body): the caller passed the state arrays themselves as U0 — nothing to copy; the perturbations
+    // U0 - U are (+0) by subtraction where a kernel forms them, and known zeros to the folded first sweeps
+    const bool copy0 = store0 && !ctx->ac_rotate;
     if (S.init_mode) {
-        if (S.pfold && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA true COMMA, rows, b256, Fi);
+        if (S.pfold && copy0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA true COMMA, rows, b256, Fi);
         else if (S.pfold) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA true COMMA true COMMA, rows, b256, Fi);
-        else if (store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA true COMMA, rows, b256, Fi);
+        else if (copy0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA true COMMA, rows, b256, Fi);
         else AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA false COMMA true COMMA, rows, b256, Fi);
     }
-    else if (S.pfold && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA false COMMA, rows, b256, Fi);
+    else if (S.pfold && copy0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA false COMMA, rows, b256, Fi);
     else if (S.pfold) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA true COMMA false COMMA, rows, b256, Fi);
-    else if (S.fused && store0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA false COMMA, rows, b256, Fi);
+    else if (S.fused && copy0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA false COMMA false COMMA, rows, b256, Fi);
     else if (S.fused) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA false COMMA false COMMA, rows, b256, Fi);
     else AC_LAUNCH0(k_ac_stage_init, true COMMA false COMMA false COMMA false COMMA, rows, b256, Fi);
     BZ_LAUNCH_CHECK();
@@ -2461,8 +2471,10 @@ static bool stage_end_fusable(const bz_ctx *ctx)
 }
 static int bzi_acoustic_stage_end_fused(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0,
                                         const bz_compressible_prognostic *G, const bz_acoustic_substepper *sub, double dt, double beta,
-                                        bool with_linearization)
+                                        bool with_linearization, const bz_compressible_state *s_out = nullptr)
 {
+    // s_out: the recovered prognostic fields go to this state's arrays instead of in place (buffer rotation of compressible_step_body)
+    const bool oop = s_out && s_out->rho_d != s->rho_d;
     const DevGrid &g = ctx->dg;
     AcStage &S = stage_of(ctx);
     if (S.done != S.ntau) {
@@ -2470,7 +2482,9 @@ static int bzi_acoustic_stage_end_fused(bz_ctx *ctx, const bz_compressible_state
         return BZ_ERR_INVALID;
     }
     AcFields F = ac_fields(ctx, s, U0, G, sub);      // F.thL: the linearisation this stage ran on
-    DiagFields D = diag_fields(ctx, s, sub);
+    DiagFields D = diag_fields(ctx, oop ? s_out : s, sub);
+    AcParams Pe = S.P;
+    Pe.out_of_place = oop ? 1 : 0;
     double *thL_out = ctx->thL_alt ? sub->potential_temperature : ctx->d_thL2;
     dim3 rows((g.Nx + 255) / 256, g.Ny, g.Nz), b256(256);
     const double na = ctx->se.newton_abstol, dts = beta * dt;
@@ -2480,8 +2494,8 @@ static int bzi_acoustic_stage_end_fused(bz_ctx *ctx, const bz_compressible_state
 #define BZ_END(DAMP, LIN, MP)                                                                                                              \
     do {                                                                                                                                   \
         if (ctx->substep_f32)                                                                                                              \
-            hipLaunchKernelGGL((k_ac_stage_end<DAMP, LIN, MP, float>), rows, b256, 0, ctx->stream, g, ac_cast<float>(F), D, S.P, dts, (float *)thL_out, na, nm); \
-        else hipLaunchKernelGGL((k_ac_stage_end<DAMP, LIN, MP, double>), rows, b256, 0, ctx->stream, g, F, D, S.P, dts, thL_out, na, nm);  \
+            hipLaunchKernelGGL((k_ac_stage_end<DAMP, LIN, MP, float>), rows, b256, 0, ctx->stream, g, ac_cast<float>(F), D, Pe, dts, (float *)thL_out, na, nm); \
+        else hipLaunchKernelGGL((k_ac_stage_end<DAMP, LIN, MP, double>), rows, b256, 0, ctx->stream, g, F, D, Pe, dts, thL_out, na, nm);  \
     } while (0)
 #define BZ_END_MP(DAMP, LIN)                                \
     do {                                                    \
@@ -2494,7 +2508,7 @@ static int bzi_acoustic_stage_end_fused(bz_ctx *ctx, const bz_compressible_state
 #undef BZ_END_MP
 #undef BZ_END
     }
-    {
+    if (!oop) {      // (out of place the density went out with the other fields: nothing reads the output set)
         ProfileScope ps(ctx, "acoustic_recover_density");
         if (ctx->substep_f32) hipLaunchKernelGGL((k_ac_recover_density<float>), rows, b256, 0, ctx->stream, g, s->rho_d, (const float *)F.rp);
         else hipLaunchKernelGGL((k_ac_recover_density<double>), rows, b256, 0, ctx->stream, g, s->rho_d, (const double *)F.rp);
@@ -2658,6 +2672,20 @@ extern "C" int bz_acoustic_rk3_substep(bz_ctx *ctx, const bz_compressible_state 
     return bzi_acoustic_substep_loop(ctx, s, U0, G, sub, dt, beta, true, true);
 }
 
+// buffer rotation of the whole-step seam: the z-halo levels of the six prognostic fields (the step's kernels write the first one of the centre
+// fields and none of rho w's; the deeper ones never), state arrays -> U0 arrays; blockIdx.y: level pair (below / above), blockIdx.z: field
+// (5 = rho w, whose upper halo sits one level higher)
+struct RotPtrs { double *dst[6]; const double *src[6]; };
+__global__ __launch_bounds__(256) void k_copy_deep_zhalo(DevGrid g, RotPtrs R)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Sxy) return;
+    const int h = (int)(blockIdx.y >> 1), f = blockIdx.z;
+    const bool up = blockIdx.y & 1;
+    const long long lev = up ? (long long)(g.Hz + g.Nz + h + (f == 5 ? 1 : 0)) : (long long)(g.Hz - 1 - h);
+    R.dst[f][lev * g.Sxy + t] = R.src[f][lev * g.Sxy + t];
+}
+
 // store_initial_state! (prognostic fields incl. the Kessler species into timestepper.U0)
 int bzi_compressible_store_initial_state(bz_ctx *ctx, const bz_compressible_state *s, const bz_compressible_prognostic *U0)
 {
@@ -2713,6 +2741,27 @@ static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, c
     // stage's initialisation kernel (the state IS U0 there); BZ_NO_AC_END_FUSE=1 restores the separate passes
     const bool fuse_end = stage_end_fusable(ctx);
     const bool store0 = fuse_end && ctx->ac_fused;
+    // Round 6, buffer rotation (the anelastic lean seam's scheme, bz_step.hip: bzi_lean_stage): nothing is copied into U0.  The state arrays
+    // stay intact as "U0" until the last writer of the step: stage 1 reads them as U^L and writes its recovered state into the U0 ARRAYS
+    // (out of place: k_ac_stage_end writes rho_d with the other fields, no separate density pass), stages 2 and 3 run on those with
+    // U0 := the state arrays, and stage 3's epilogue writes the final state back into the state arrays (a thread reads U0 only at its own
+    // cell, before it writes it).  12 words of store_initial_state! and two density passes less per step; the U0 arrays are the time
+    // stepper's scratch (as in the reference, where nothing reads U0 outside time_step!).  Kessler species keep their copies.
+    const bool rotate = store0 && ctx->tune.ac_rotate;
+    bz_compressible_state sB = *s;                 // the state with its six prognostic fields living in the U0 arrays
+    bz_compressible_prognostic uS = *U0;           // "U0" = the state arrays
+    if (rotate) {
+        sB.rho_d = U0->rho_d; sB.rho_theta = U0->rho_theta; sB.rho_u = U0->rho_u; sB.rho_v = U0->rho_v; sB.rho_w = U0->rho_w; sB.rho_q = U0->rho_q;
+        uS.rho_d = s->rho_d; uS.rho_theta = s->rho_theta; uS.rho_u = s->rho_u; uS.rho_v = s->rho_v; uS.rho_w = s->rho_w; uS.rho_q = s->rho_q;
+        // z-halo levels the step's kernels do not write: the U0 arrays get the state's, once per step
+        {
+            ProfileScope ps(ctx, "store_initial_state");
+            RotPtrs R;
+            R.dst[0] = U0->rho_d; R.dst[1] = U0->rho_theta; R.dst[2] = U0->rho_u; R.dst[3] = U0->rho_v; R.dst[4] = U0->rho_q; R.dst[5] = U0->rho_w;
+            R.src[0] = s->rho_d; R.src[1] = s->rho_theta; R.src[2] = s->rho_u; R.src[3] = s->rho_v; R.src[4] = s->rho_q; R.src[5] = s->rho_w;
+            hipLaunchKernelGGL(k_copy_deep_zhalo, dim3((unsigned)((g.Sxy + 255) / 256), 2 * g.Hz, 6), dim3(256), 0, ctx->stream, g, R);
+        }
+    }
     if (store0) {
         if (g.microphysics == 2) {      // the species' U0 copies stay copies (k_ac_stage_init does not know them)
             const bz_kessler_model_fields &K = ctx->kessler;
@@ -2732,7 +2781,13 @@ static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, c
     rc = bz_refresh_linearization(ctx, s, sub);
     if (rc) return rc;
     const double betas[3] = {1.0 / 3.0, 1.0 / 2.0, 1.0};
+    const bz_compressible_state *s_step = s;
+    const bz_compressible_prognostic *U0_step = U0;
     for (int st = 0; st < 3; ++st) {
+        // rotation: stage 1 runs on the state arrays (U0 = the same arrays), stages 2 and 3 on the U0 arrays (U0 = the state arrays)
+        const bz_compressible_state *s = (rotate && st > 0) ? &sB : s_step;
+        const bz_compressible_prognostic *U0 = rotate ? &uS : U0_step;
+        const bz_compressible_state *s_next = !rotate ? s : (st == 2 ? s_step : &sB);
         rc = bz_compute_slow_tendencies(ctx, s, G);
         if (rc) return rc;
         if (!fuse_end) {
@@ -2745,16 +2800,19 @@ static int compressible_step_body(bz_ctx *ctx, const bz_compressible_state *s, c
         }
         ctx->ac_skip_avg = st < 2;      // the averages of stages 1 and 2 feed only the (skipped) moisture tendency of a dry model
         ctx->ac_whole_step = true;
+        ctx->ac_rotate = rotate;
         rc = bzi_acoustic_stage_begin(ctx, s, U0, G, sub, dt, betas[st], store0 && st == 0);
+        ctx->ac_rotate = false;
         ctx->ac_skip_avg = false;
         ctx->ac_whole_step = false;
         if (rc) return rc;
         const int ntau = stage_of(ctx).ntau;
         for (int sstep = 1; sstep <= ntau; ++sstep)
             if ((rc = bzi_acoustic_substep(ctx, s, U0, G, sub, sstep))) return rc;
-        if ((rc = bzi_acoustic_stage_end_fused(ctx, s, U0, G, sub, dt, betas[st], st < 2))) return rc;
-        if ((rc = bz_compute_moisture_tendency(ctx, s, G, sub))) return rc;
+        if ((rc = bzi_acoustic_stage_end_fused(ctx, s, U0, G, sub, dt, betas[st], st < 2, s_next))) return rc;
+        if ((rc = bz_compute_moisture_tendency(ctx, s_next, G, sub))) return rc;
     }
+    s = s_step;
     if (g.microphysics == 2) return bz_compressible_kessler_update(ctx, s, G, sub, dt);     // microphysics_model_update! (:316)
     return BZ_OK;
 }

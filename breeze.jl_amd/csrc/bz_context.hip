@@ -66,6 +66,7 @@ void bzi_read_tuning(bz_tuning &t)
     t.ac_pfold = num("BZ_AC_PFOLD", 1);
     t.ac_init_fold = num("BZ_AC_INIT_FOLD", 1);
     t.ac_pair_avg = num("BZ_AC_PAIR_AVG", 1);
+    t.ac_rotate = num("BZ_AC_ROTATE", 1);
     t.ac_cfg = num("BZ_AC_CFG", 29);
     t.ac_bx = num("BZ_AC_BX", 128);
     t.no_tridiag_coop = on("BZ_NO_TRIDIAG_COOP");

@@ -309,6 +309,7 @@ struct bz_tuning {
     bool no_fold_forcing = false;     // BZ_NO_FOLD_FORCING: the fused-RK tier keeps the momentum terms of the forcing stack in the forcing pass
     int ac_xcd = 1;                   // BZ_AC_XCD=0: the forward acoustic sweep in launch order (XCD = tile column) instead of XCD = band of tile rows
     int ac_forward2 = 1;              // BZ_AC_FWD2=0: the round-5 forward acoustic sweep (k_ac_column_forward) instead of k_ac_forward2
+    int ac_rotate = 1;                // BZ_AC_ROTATE=0: store_initial_state! copies the state into U0 instead of the buffer rotation of the whole-step seam
     int ac_pair_avg = 1;              // BZ_AC_PAIR_AVG=0: <u>, <v> accumulated in every substep instead of two substeps at a time (AcParams::acc_mode)
     int ac_init_fold = 1;             // BZ_AC_INIT_FOLD=0: k_ac_stage_init stores the stage's initial perturbations and the first sweeps read them back
     int ac_pfold = 1;                 // BZ_AC_PFOLD=0: the horizontal gradient of p^L stays in every substep instead of folded into the stage's slow tendencies
@@ -437,6 +438,7 @@ struct bz_ctx {
     bool thL_alt = false;             // the current theta_L lives in d_thL2 (whole-step seam only; every per-operator linearisation resets it)
     bool substep_f32 = false;         // substep_floattype = Float32 inside the Float64 library: the substepper's working fields are float arrays
     bool ac_whole_step = false;       // set around bzi_acoustic_stage_begin by the whole-step seam (AcParams::dry_q)
+    bool ac_rotate = false;           // set around bzi_acoustic_stage_begin by the whole-step seam while its buffer rotation is on (U0 = the state arrays in stage 1)
     bool ac_skip_avg = false;         // set around bzi_acoustic_stage_begin by the whole-step seam for its stages 1 and 2 (AcParams::skip_avg_if_dry)
     bool ac_fused = true;             // horizontal step folded into the forward column sweep (BZ_NO_AC_FUSE=1 disables)
     int ac_open[4] = {0, 0, 0, 0};    // west, east, south, north side of a Bounded x / y carries an active open boundary condition (bz_set_acoustic_lateral_boundaries)

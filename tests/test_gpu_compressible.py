@@ -477,6 +477,55 @@ def test_dry_steps_skip_the_unread_time_averages_bitwise(oracle, oc, bz, size, m
     assert np.abs(got - want).max() / np.abs(want).max() < 5e-9
 
 
+@pytest.mark.parametrize("kind", ["dry", "vapour", "kessler", "saturation_adjustment"])
+def test_whole_step_rotates_its_buffers_instead_of_storing_the_initial_state(oracle, oc, bz, kind, monkeypatch):
+    """Round 6: bz_time_step_compressible copies nothing into U0 (store_initial_state!, 12 words per cell and step).  The state arrays stay
+    intact as "U0" while stage 1 writes its recovered state into the U0 ARRAYS (out of place, rho_d with the other fields: no separate
+    density pass), stages 2 - 3 run there, and stage 3's epilogue writes the final state back (csrc/bz_compressible.hip:
+    compressible_step_body).  Same arithmetic on the same values: every prognostic field, every diagnostic, the substepper's fields and the
+    Kessler species after three steps carry the bits of the run that copies (BZ_AC_ROTATE=0) — halos included."""
+    out = {}
+    for rot in (1, 0):
+        monkeypatch.setenv("BZ_AC_ROTATE", str(rot))
+        kw = {}
+        if kind == "kessler":
+            kw = dict(thermodynamic_constants=bz.ThermodynamicConstants(saturation_vapor_pressure=bz.TetensFormula()),
+                      microphysics=bz.DCMIP2016KesslerMicrophysics())
+        if kind == "saturation_adjustment":
+            kw = dict(microphysics=bz.SaturationAdjustment(equilibrium=bz.WarmPhaseEquilibrium()))
+        grid = bz.RectilinearGrid((64, 16, 24), x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"])
+        dyn = bz.CompressibleDynamics(bz.SplitExplicitTimeDiscretization(substeps=6), reference_potential_temperature=300.0)
+        hm = bz.CompressibleAtmosphereModel(grid, dyn, advection=bz.WENO(order=5), **kw)
+
+        def theta(x, y, z):
+            r = np.sqrt(x ** 2 + y ** 2 + (z - 3000.0) ** 2)
+            return 300.0 + 2.0 * np.maximum(0.0, 1.0 - r / 2000.0)
+
+        qv = lambda x, y, z: (1.4e-2 if kind in ("kessler", "saturation_adjustment") else 5e-3) * np.exp(-z / 2e3) * (1 + 0.2 * np.sin(2 * np.pi * x / 8e3)) + 0 * y      # noqa: E731
+        Hz, Nz = grid.Hz, grid.Nz
+        rho = hm.dynamics.reference_state.density[Hz:Hz + Nz][:, None, None]
+        sets = dict(ρ=rho, θ=theta, u=lambda x, y, z: 3.0 + 0 * x + 0 * y + 0 * z, v=-1.0, w=0.0)
+        if kind != "dry":
+            sets["qᵗ"] = qv
+        hm.set(**sets)
+        for _ in range(3):
+            hm.time_step(0.5)
+        hm.synchronize()
+        sub = hm.timestepper.substepper
+        snap = {k: f.cpu().copy() for k, f in hm.prognostic_fields().items()}
+        snap.update({k: f.cpu().copy() for k, f in hm.velocities.items()})
+        snap.update(theta=hm.potential_temperature.cpu().copy(), T=hm.temperature.cpu().copy(), p=hm.dynamics.pressure.cpu().copy(),
+                    rho=hm.dynamics.total_density.cpu().copy(), q=hm.specific_moisture.cpu().copy())
+        snap.update({n: getattr(sub, n).cpu().copy() for n in ("time_averaged_u", "time_averaged_v", "time_averaged_w", "density_perturbation",
+                                                               "momentum_perturbation_w", "potential_temperature")})
+        out[rot] = snap
+    for k in out[1]:
+        assert np.array_equal(out[1][k], out[0][k]), k
+    assert all(np.isfinite(v).all() for v in out[1].values())
+    if kind != "dry":
+        assert np.abs(out[1]["ρq"]).max() > 0
+
+
 @pytest.mark.parametrize("substeps", [6, 5, 2])
 def test_time_averages_accumulated_in_pairs_of_substeps(oracle, oc, bz, substeps, monkeypatch):
     """Round 6 (AcParams::acc_mode): the forward sweep adds <u>, <v> two substeps at a time — a += (u'_{n-1} + u'_n) in the second substep of a

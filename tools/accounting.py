@@ -86,7 +86,9 @@ COMPULSORY_WORDS = {
     # forward sweep reads Gp_ru, Gp_rv instead of G_ru, G_rv AND p: 22 words (23 in a stage that keeps p^L in the substep)
     "acoustic_horizontal+column_forward": 22,          # R rho', (rho theta)' x 2 levels, theta_L, C, (rho u)', (rho v)', G x 4, (rho w)', G^s, <u>, <v>; W (rho u)', (rho v)', <u>, <v>, both predictors, rhs
     "acoustic_column_backward": 10,                    # R theta_L, rhs, predictors x 2, factors, <w>; W rho', (rho theta)', (rho w)', <w>
-    "acoustic_stage_init": 23,                         # R U0 x 5, U x 5, p, rho, G_rho_w, G_rho_u, G_rho_v; W perturbations x 5, G^s, Gp_ru, Gp_rv  (first stage: U0 written instead of read)
+    # round 6: the stage's first sweeps form the initial perturbations themselves and nothing is copied into U0 (buffer rotation): the kernel
+    # is left with R p, rho, G_rho_w, G_rho_u, G_rho_v; W G^s, Gp_ru, Gp_rv (a stage that keeps p^L in the substep: R p, rho, G_rho_w; W G^s)
+    "acoustic_stage_init": 8,
     "acoustic_stage_end+update_state": 37,             # R U x 5, perturbations x 5, (rho theta)'_old, theta_L, <u v w>, U0_q, G_q; W U x 5 (rho_d below), <u v w>, rho, u, v, w, theta, q, T, p
     "acoustic_stage_end+update_state+linearization": 41,
     "acoustic_recover_density": 3,

@@ -166,10 +166,11 @@ WALL_CASES = [
 ]
 
 
-def hip_model(bz, om, topo, open_sides=(), substep_floattype=None, alpha=0.5):
+def hip_model(bz, om, topo, open_sides=(), substep_floattype=None, alpha=0.5, float_type=None):
     otd = om.td
     g = om.grid
-    grid = bz.RectilinearGrid((g.Nx, g.Ny, g.Nz), x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"], topology=topo)
+    gkw = {} if float_type is None else dict(float_type=float_type)
+    grid = bz.RectilinearGrid((g.Nx, g.Ny, g.Nz), x=EXTENT["x"], y=EXTENT["y"], z=EXTENT["z"], topology=topo, **gkw)
     damping = (bz.NoDivergenceDamping() if otd.damping_coefficient is None
                else bz.DirectDivergenceDamping(coefficient=otd.damping_coefficient) if otd.direct_damping
                else bz.ThermalDivergenceDamping(coefficient=otd.damping_coefficient, damp_vertical=otd.damp_vertical,
@@ -286,3 +287,38 @@ def test_lateral_boundary_setter_validates_its_arguments(oracle, oc, bz):
     _, pm = make_pair(oracle, oc, bz, size=(16, 8, 8))
     assert pm._lib.bz_set_acoustic_lateral_boundaries(pm._ctx, 0, 0, 0, 1, 0.5) != 0
     assert pm._lib.bz_set_acoustic_lateral_boundaries(pm._ctx, 0, 0, 0, 0, 0.5) == 0
+
+
+@pytest.mark.gpu
+def test_wall_loop_on_a_float32_grid(oracle, oc, bz):
+    """eltype(grid) = Float32 (libbreeze_hip_f32.so, the generated twin): the loop on (Bounded, Bounded, Bounded) with two open sides against the
+    Float64 oracle — perturbation fields relative to their own scale (what Float32 resolves worst), the recovered state at Float32 round-off."""
+    import torch
+    from tests.test_gpu_compressible import O2H, PROG, SUB
+    topo, open_sides = TOPOLOGIES[2], ("west", "north")
+    om = oracle_model(oracle, oc, topo, substeps=6)
+    seeded_wall_state(om, 31, open_sides=open_sides, value_bc=1.03)
+    om.open_boundary_relaxation = 0.4
+    hm = hip_model(bz, om, topo, open_sides, alpha=0.4, float_type=np.float32)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))      # noqa: E731
+    for n, f in O2H.items():
+        f(hm).parent.copy_(f32(getattr(om, n)))
+    for n, k in PROG.items():
+        hm.G[k].parent.copy_(f32(om.G[n]))
+        hm.U0[k].parent.copy_(f32(om.U0[n]))
+    for n, k in SUB.items():
+        getattr(hm.timestepper.substepper, k).parent.copy_(f32(getattr(om, n)))
+    bz.compressible.refresh_linearization_(hm)
+    om.acoustic_substep_loop(2.0, 0.5)
+    bz.compressible.acoustic_rk3_substep_loop_(hm, 2.0, 0.5)
+    g = om.grid
+    sub = hm.timestepper.substepper
+    for n, k, tol in (("rup", "momentum_perturbation_u", 2e-3), ("rvp", "momentum_perturbation_v", 2e-3), ("rwp", "momentum_perturbation_w", 2e-3)):
+        a, b = getattr(sub, k).interior_cpu().astype(np.float64), g.interior(getattr(om, n), n == "rwp")
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (n, np.abs(a - b).max() / np.abs(b).max())
+    for n in ("rho_d", "rtheta", "ru", "rv", "rw"):
+        a, b = O2H[n](hm).interior_cpu().astype(np.float64), g.interior(getattr(om, n), n == "rw")
+        scale = max(np.abs(g.interior(getattr(om, c), c == "rw")).max() for c in ("ru", "rv", "rw")) if n in ("ru", "rv", "rw") else np.abs(b).max()
+        # (the momentum carries the Float32 rounding of six substeps of pressure-gradient increments; the densities one recovery)
+        assert np.abs(a - b).max() <= (1e-5 if n in ("ru", "rv", "rw") else 2e-6) * scale, (n, np.abs(a - b).max() / scale)
+    assert not sub.momentum_perturbation_v.interior_cpu()[:, 0, :].any()      # the impenetrable south wall

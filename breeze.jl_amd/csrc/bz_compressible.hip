@@ -2351,7 +2351,7 @@ static int bzi_acoustic_substep(bz_ctx *ctx, const bz_compressible_state *s, con
                 P.xcd = (ctx->tune.ac_xcd && cols2.y % 8 == 0) ? 1 : 0;
                 // <u>, <v> in pairs counted from the stage's last substep (AcParams::acc_mode): substep 1 starts the accumulators, an odd
                 // substep out (substep 2) is added alone
-                if (ctx->tune.ac_pair_avg && !S.direct && !ctx->substep_f32 && !ctx->slab_mode && sstep >= 2)
+                if (ctx->tune.ac_pair_avg && !S.direct && !ctx->substep_f32 && sstep >= 2)      // (y-slabs too: a row accumulates its own faces)
                     P.acc_mode = ((ntau - sstep) & 1) ? 1 : (sstep >= 3 ? 2 : 0);
                 launch_forward2(ctx, Fs, P, cols2, bcol2, sstep == 1, damp, S.pfold, cfg, S.init_mode);
             }

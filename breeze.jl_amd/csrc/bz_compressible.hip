@@ -782,6 +782,12 @@ __global__ __launch_bounds__(256) void k_ac_stage_init(DevGrid g, AcFieldsT<ST> 
     if (i >= g.Nx) return;
     const long long sz = g.Sxy;
     const long long n = g.idx(i, j, k);
+    if (j >= g.Ny) {
+        // y-slab: the row above the slab.  The north face of the slab's last row reads its folded tendency; G_rv and p of this row arrived
+        // with the halo exchanges, and the rank that owns the row forms the same value from the same numbers
+        if (PF) F.Gp_rv[n] = F.G_rv[n] - (F.p[n] - F.p[n - g.Sx]) * g.rdy;
+        return;
+    }
     if (PF) {
         const WrapIdx W = wrap_of(g, i, j);
         const double p0 = F.p[n];
@@ -1759,8 +1765,8 @@ static int bzi_create_compressible(bz_ctx **out, const bz_grid *grid, const bz_c
         hipMalloc(&ctx->d_up2, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_thL2, ncell * sizeof(double)) != hipSuccess ||
         hipMalloc(&ctx->d_vp2, ncell * sizeof(double)) != hipSuccess ||
-        (ctx->tune.ac_pfold && !slab && (hipMalloc(&ctx->d_Gp_ru, ncell * sizeof(double)) != hipSuccess ||
-                                         hipMalloc(&ctx->d_Gp_rv, ncell * sizeof(double)) != hipSuccess))) {
+        (ctx->tune.ac_pfold && (hipMalloc(&ctx->d_Gp_ru, ncell * sizeof(double)) != hipSuccess ||
+                                hipMalloc(&ctx->d_Gp_rv, ncell * sizeof(double)) != hipSuccess))) {
         bz_destroy(ctx);
         *out = nullptr;
         return BZ_ERR_ALLOC;
@@ -2241,12 +2247,13 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     if (ctx->ac_whole_step && S.fwd2 && !ctx->slab_mode) P.dry_q = bzi_moisture_state(ctx);
     // the fold costs a stage four words per cell (R G_ru, G_rv; W Gp_ru, Gp_rv) and saves every substep one (p^L): stages of >= 5 substeps
     // (the 512 x 512 x 256 benchmark: 6, 9, 18; the supercell shape of configs[4]: 2, 3, 5 — its first two stages keep p^L in the substep)
-    S.pfold = S.fwd2 && ctx->d_Gp_ru && !ctx->slab_mode && (ntau >= 5 || ctx->tune.ac_pfold > 1);
+    S.pfold = S.fwd2 && ctx->d_Gp_ru && (ntau >= 5 || ctx->tune.ac_pfold > 1);      // (y-slabs: the kernel folds the row above the slab too)
     // the stage's first sweeps form its initial perturbations themselves (default variant of k_ac_forward2 on a single device)
     S.init_mode = (S.fwd2 && !ctx->slab_mode && ctx->tune.ac_init_fold && forward2_cfg(ctx) == 29) ? (store0 ? 2 : 1) : 0;
     // buffer rotation (compressible_step_body): the caller passed the state arrays themselves as U0 — nothing to copy; the perturbations
     // U0 - U are (+0) by subtraction where a kernel forms them, and known zeros to the folded first sweeps
     const bool copy0 = store0 && !ctx->ac_rotate;
+    if (S.pfold && ctx->slab_mode) rows.y = g.Ny + 1;
     if (S.init_mode) {
         if (S.pfold && copy0) AC_LAUNCH0(k_ac_stage_init, false COMMA true COMMA true COMMA true COMMA, rows, b256, Fi);
         else if (S.pfold) AC_LAUNCH0(k_ac_stage_init, false COMMA false COMMA true COMMA true COMMA, rows, b256, Fi);

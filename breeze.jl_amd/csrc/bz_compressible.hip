@@ -1301,6 +1301,10 @@ __global__ __launch_bounds__((CFG & 1) ? 512 : 256, (CFG & 2) ? 3 : 2) void k_ac
         }
         // ---- every store of the level ----
         if (INIT) ac_st(F.rthp, e, rthp);      // the initial (rho theta)': the next substep's damping and the stage epilogue read it
+        if (INIT && !g.wrap_y) {               // y-slab: and its halo rows (the exchange before this sweep carried a buffer nobody had filled)
+            if (j == 0) ac_st(F.rthp, e + dym, rt_ym);
+            if (j == g.Ny - 1) ac_st(F.rthp, e + dyp, rt_yp);
+        }
         ac_st_nt(F.rup, e, up0);
         ac_st_nt(F.rvp, e, vp0);
         if (acc && (FIRST || P.acc_mode != 1)) {
@@ -2249,7 +2253,7 @@ static int bzi_acoustic_stage_begin(bz_ctx *ctx, const bz_compressible_state *s,
     // (the 512 x 512 x 256 benchmark: 6, 9, 18; the supercell shape of configs[4]: 2, 3, 5 — its first two stages keep p^L in the substep)
     S.pfold = S.fwd2 && ctx->d_Gp_ru && (ntau >= 5 || ctx->tune.ac_pfold > 1);      // (y-slabs: the kernel folds the row above the slab too)
     // the stage's first sweeps form its initial perturbations themselves (default variant of k_ac_forward2 on a single device)
-    S.init_mode = (S.fwd2 && !ctx->slab_mode && ctx->tune.ac_init_fold && forward2_cfg(ctx) == 29) ? (store0 ? 2 : 1) : 0;
+    S.init_mode = (S.fwd2 && ctx->tune.ac_init_fold && forward2_cfg(ctx) == 29) ? (store0 ? 2 : 1) : 0;      // (y-slabs too: U0 and U carry exchanged halo rows)
     // buffer rotation (compressible_step_body): the caller passed the state arrays themselves as U0 — nothing to copy; the perturbations
     // U0 - U are (+0) by subtraction where a kernel forms them, and known zeros to the folded first sweeps
     const bool copy0 = store0 && !ctx->ac_rotate;

@@ -409,7 +409,8 @@ int bz_time_step_compressible(bz_ctx *ctx, const bz_compressible_state *s, const
 /* ---- y-slab decomposition of the compressible path (halo exchanges only, the column solve is local) ----
  * `local_grid` is this rank's slab as in bz_create_slab.  The caller's neighbour exchange fills the y halos (Hy rows) at the
  * points listed below; x and z halos stay the library's business.  Sequence of one WS-RK3 stage:
- *   [state halos valid: rho_d, rho, momentum, rho_theta, rho_q, u, v, w, theta, q, T, p, time-averaged velocities]
+ *   [state halos valid: rho_d, rho, momentum, rho_theta, rho_q, u, v, w, theta, q, T, p, time-averaged velocities; the U0 arrays are
+ *    whole-array copies of the step-start state, halo rows included (the stage's first sweeps form U0 - U on the halo rows too)]
  *   bz_refresh_linearization            (also linearises one halo row on each side)
  *   bz_compute_slow_tendencies          -> exchange G->rho_v
  *   bz_acoustic_stage_begin             returns N_tau and which buffer pair is current (0: the substepper's own
